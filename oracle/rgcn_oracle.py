@@ -1,0 +1,295 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+A numpy/scipy restatement of the reference's full-batch R-GCN path, written from
+the reference's behaviour (file:line relative to /root/reference).  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+package; `mrgcn_amd/` never does (the product path fails loudly when the HIP
+library is missing).
+
+Parity status: PINNED.  `tests/test_oracle_golden.py` checks every function here
+against the `.npz` fixtures under `tests/golden/`, which were produced by importing
+the reference itself in the authoring container (`tests/golden/make_goldens.py`).
+
+All arithmetic is done in float64 unless `dtype=np.float32` is requested, so the
+oracle is the *more* accurate side of every comparison.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+
+# ---------------------------------------------------------------------------
+# a-1  layout contract of A          mrgcn/encodings/graph_structure.py:13-38,
+#                                    :70-108, :162-169 ; tarball.py:151-157
+# ---------------------------------------------------------------------------
+def normalize_adjacency(adj: sp.csr_matrix) -> sp.csr_matrix:
+    """Row normalisation D^-1 A (graph_structure.py:162-169)."""
+    d = np.asarray(adj.sum(1)).flatten().astype(np.float64)
+    with np.errstate(divide="ignore"):
+        d_inv = 1.0 / d
+    d_inv[np.isinf(d_inv)] = 0.0
+    return sp.diags(d_inv).dot(adj).tocsr()
+
+
+def build_stacked_adjacency(triples: np.ndarray, num_nodes: int, num_pred: int,
+                            include_inverse: bool = True) -> sp.csr_matrix:
+    """Integer triples (s, p, o) -> N x (R*N) CSR, float32 values.
+
+    Block order [p0, p0^-1, p1, p1^-1, ..., identity] (graph_structure.py:78-106,
+    :33-38); column of relation block r, source node j is r*N + j."""
+    shape = (num_nodes, num_nodes)
+    blocks = []
+    for p in range(num_pred):
+        e = triples[triples[:, 1] == p]
+        row, col = e[:, 0], e[:, 2]
+        data = np.ones(len(row), dtype=np.int8)
+        blocks.append(normalize_adjacency(
+            sp.csr_matrix((data, (row, col)), shape=shape, dtype=np.int8)))
+        if include_inverse:
+            blocks.append(normalize_adjacency(
+                sp.csr_matrix((data, (col, row)), shape=shape, dtype=np.int8)))
+    blocks.append(normalize_adjacency(sp.identity(num_nodes).tocsr()))
+    A = sp.hstack(blocks, format="csr")
+    return sp.csr_matrix((A.data.astype(np.float32), A.indices, A.indptr),
+                         shape=A.shape, dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------
+# a-2  CSR -> COO int8               mrgcn/data/utils.py:165-170,
+#                                    mrgcn/data/batch.py:144-149
+# ---------------------------------------------------------------------------
+def csr_to_coo(A: sp.csr_matrix, value_mode: str = "ref_int8"):
+    """Returns (indices int64 2 x nnz, values).  `ref_int8` reproduces the cast of
+    the row-normalised floats to int8 (truncation toward zero: only 1.0 survives)."""
+    indices = np.array(A.nonzero()).astype(np.int64)
+    if value_mode == "ref_int8":
+        values = A.data.astype(np.float32).astype(np.int8)
+    elif value_mode == "norm_f32":
+        values = A.data.astype(np.float32)
+    else:
+        raise ValueError(value_mode)
+    if indices.shape[1] != values.shape[0]:
+        raise ValueError("explicit zeros stored in A (SURVEY Appendix A-2)")
+    return indices, values
+
+
+def coo_to_csr(indices: np.ndarray, values: np.ndarray, shape, dtype=np.float64):
+    return sp.csr_matrix((values.astype(dtype), (indices[0], indices[1])), shape=shape)
+
+
+# ---------------------------------------------------------------------------
+# a-4 .. a-8  GraphConvolution.forward    mrgcn/layers/graph.py:62-102
+# ---------------------------------------------------------------------------
+class LayerCfg:
+    def __init__(self, indim, outdim, num_relations, num_nodes, num_bases=-1,
+                 bias=False, input_layer=False, featureless=False):
+        self.indim, self.outdim = indim, outdim
+        self.R, self.N, self.B = num_relations, num_nodes, num_bases
+        self.bias, self.input_layer, self.featureless = bias, input_layer, featureless
+
+
+def layer_forward(cfg: LayerCfg, p: dict, X, A: sp.csr_matrix, dtype=np.float64):
+    """Returns (Y, cache).  `p` holds weight_I / weight_F / weight_I_comp /
+    weight_F_comp / b as numpy arrays with the reference's shapes (graph.py:33-57)."""
+    R, N, B, out = cfg.R, cfg.N, cfg.B, cfg.outdim
+    cache = {}
+    Y = 0.0
+    if cfg.input_layer:
+        W_I = p["weight_I"].astype(dtype)
+        if B > 0:  # graph.py:69-72  einsum('rb,bij->rij')
+            V = W_I.reshape(B, N, out)
+            W_I = np.einsum("rb,bij->rij", p["weight_I_comp"].astype(dtype), V
+                            ).reshape(R * N, out)
+        Y = A @ W_I  # graph.py:75
+        if cfg.featureless:
+            if cfg.bias:
+                Y = Y + p["b"].astype(dtype)
+            return Y, cache
+    W_F = p["weight_F"].astype(dtype)
+    if B > 0:  # graph.py:83-85
+        W_F = np.einsum("rb,bij->rij", p["weight_F_comp"].astype(dtype), W_F)
+    Xd = X.astype(dtype)
+    FW = np.einsum("ij,bjk->bik", Xd, W_F).reshape(R * Xd.shape[0], out)  # graph.py:93-94
+    AFW = A @ FW  # graph.py:95
+    Y = Y + AFW if cfg.input_layer else AFW
+    if cfg.bias:
+        Y = Y + p["b"].astype(dtype)
+    cache["W_F"] = W_F
+    return Y, cache
+
+
+def layer_backward(cfg: LayerCfg, p: dict, X, A: sp.csr_matrix, dY, cache,
+                   dtype=np.float64):
+    """Analytic gradients of `layer_forward` (what autograd does for graph.py:62-102):
+    returns (grads dict, dX or None)."""
+    R, N, B, out = cfg.R, cfg.N, cfg.B, cfg.outdim
+    g = {}
+    dD = (A.T @ dY).reshape(R, -1, out)  # dense (R, N, out)
+    if cfg.bias:
+        g["b"] = dY.sum(0)
+    if cfg.input_layer:
+        if B > 0:
+            V = p["weight_I"].astype(dtype).reshape(B, N, out)
+            comp = p["weight_I_comp"].astype(dtype)
+            g["weight_I"] = np.einsum("rb,rij->bij", comp, dD).reshape(B * N, out)
+            g["weight_I_comp"] = np.einsum("rij,bij->rb", dD, V)
+        else:
+            g["weight_I"] = dD.reshape(R * N, out)
+        if cfg.featureless:
+            return g, None
+    W_F = cache["W_F"]
+    Xd = X.astype(dtype)
+    dX = np.einsum("rjo,rio->ji", dD, W_F)
+    dW = np.einsum("ji,rjo->rio", Xd, dD)
+    if B > 0:
+        g["weight_F"] = np.einsum("rb,rio->bio", p["weight_F_comp"].astype(dtype), dW)
+        g["weight_F_comp"] = np.einsum("rio,bio->rb", dW, p["weight_F"].astype(dtype))
+    else:
+        g["weight_F"] = dW
+    return g, dX
+
+
+# ---------------------------------------------------------------------------
+# a-10  RGCN._forward_full_batch          mrgcn/models/rgcn.py:69-89
+# ---------------------------------------------------------------------------
+def rgcn_cfgs(dims, R, N, B, bias, featureless):
+    """Layer 0 is always the input layer (rgcn.py:30-37); later layers never are
+    (rgcn.py:41-51)."""
+    cfgs = []
+    for li, (i, o) in enumerate(dims):
+        cfgs.append(LayerCfg(i, o, R, N, B, bias, input_layer=(li == 0),
+                             featureless=(featureless if li == 0 else False)))
+    return cfgs
+
+
+def split_params(state: dict, num_layers: int, prefix="layers.layer_"):
+    out = []
+    for li in range(num_layers):
+        pre = f"{prefix}{li}."
+        out.append({k[len(pre):]: v for k, v in state.items() if k.startswith(pre)})
+    return out
+
+
+def rgcn_forward(cfgs, params, X, A, relu_last=False, dtype=np.float64):
+    """p_dropout = 0 (every shipped config); ReLU on all but the last layer
+    (node_classification.py:399-419), on every layer for link prediction
+    (link_prediction.py:449-464)."""
+    H = X
+    tape = []
+    for li, (cfg, p) in enumerate(zip(cfgs, params)):
+        pre, cache = layer_forward(cfg, p, H, A, dtype)
+        act = (li < len(cfgs) - 1) or relu_last
+        post = np.maximum(pre, 0.0) if act else pre
+        tape.append((H, pre, cache, act))
+        H = post
+    return H, tape
+
+
+def cross_entropy(logits, idx, targets):
+    """nn.CrossEntropyLoss (mean) over labelled rows
+    (node_classification.py:439-444).  Returns (loss, dlogits)."""
+    Z = logits[idx]
+    Z = Z - Z.max(1, keepdims=True)
+    lse = np.log(np.exp(Z).sum(1, keepdims=True))
+    logp = Z - lse
+    n = len(idx)
+    loss = -logp[np.arange(n), targets].mean()
+    dZ = np.exp(logp)
+    dZ[np.arange(n), targets] -= 1.0
+    dZ /= n
+    dlogits = np.zeros_like(logits)
+    np.add.at(dlogits, idx, dZ)
+    return loss, dlogits
+
+
+def rgcn_backward(cfgs, params, A, tape, dOut, dtype=np.float64):
+    grads = [None] * len(cfgs)
+    dH = dOut
+    for li in reversed(range(len(cfgs))):
+        H_in, pre, cache, act = tape[li]
+        dPre = dH * (pre > 0) if act else dH
+        g, dX = layer_backward(cfgs[li], params[li], H_in, A, dPre, cache, dtype)
+        grads[li] = g
+        dH = dX
+    return grads, dH
+
+
+def accuracy(logits, idx, targets):
+    """node_classification.py:432-437"""
+    return float((logits[idx].argmax(1) == targets).mean())
+
+
+# ---------------------------------------------------------------------------
+# a-12  clip_grad_norm_(…, 1.0) + Adam      node_classification.py:190-193, :35-37
+# ---------------------------------------------------------------------------
+def clip_grad_norm(grads_flat: list, max_norm=1.0):
+    """torch.nn.utils.clip_grad_norm_: total L2 norm over all grads, scale by
+    min(1, max_norm / (norm + 1e-6)).  Returns (total_norm, coef)."""
+    total = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads_flat))
+    coef = min(1.0, max_norm / (total + 1e-6))
+    return total, coef
+
+
+class Adam:
+    """torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, amsgrad False;
+    L2 weight decay added to the gradient."""
+
+    def __init__(self, lr=0.01, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.t = 0
+        self.m, self.v = {}, {}
+
+    def step(self, params: dict, grads: dict):
+        self.t += 1
+        b1, b2 = self.betas
+        for k, g in grads.items():
+            p = params[k].astype(np.float64)
+            g = g.astype(np.float64)
+            if self.wd:
+                g = g + self.wd * p
+            m = self.m.get(k, 0.0) * b1 + (1 - b1) * g
+            v = self.v.get(k, 0.0) * b2 + (1 - b2) * g * g
+            self.m[k], self.v[k] = m, v
+            mhat = m / (1 - b1 ** self.t)
+            denom = np.sqrt(v) / np.sqrt(1 - b2 ** self.t) + self.eps
+            params[k] = p - self.lr * mhat / denom
+
+
+def train_steps(dims, R, N, B, bias, featureless, state, X, A, idx, targets,
+                n_steps, relu_last=False, lr=0.01, weight_decay=0.0):
+    """Hand-driven epoch loop of node_classification.py:166-193 (zero_grad,
+    backward, clip 1.0, Adam) over an `RGCN` state dict with keys
+    `layers.layer_<i>.<name>`.  Returns a list of per-step records."""
+    cfgs = rgcn_cfgs(dims, R, N, B, bias, featureless)
+    state = {k: v.astype(np.float64) for k, v in state.items()}
+    opt = Adam(lr=lr, weight_decay=weight_decay)
+    records = []
+    for _ in range(n_steps):
+        params = split_params(state, len(cfgs))
+        logits, tape = rgcn_forward(cfgs, params, X, A, relu_last)
+        loss, dlogits = cross_entropy(logits, idx, targets)
+        grads, dX = rgcn_backward(cfgs, params, A, tape, dlogits)
+        flat = {f"layers.layer_{li}.{k}": v for li, g in enumerate(grads) for k, v in g.items()}
+        total, coef = clip_grad_norm(list(flat.values()), 1.0)
+        clipped = {k: v * coef for k, v in flat.items()}
+        rec = dict(logits=logits, loss=loss, grads=flat, dX=dX, grad_norm=total, tape=tape)
+        opt.step(state, clipped)
+        rec["state"] = {k: v.copy() for k, v in state.items()}
+        records.append(rec)
+    return records
+
+
+# ---------------------------------------------------------------------------
+# stand-alone SpMM (K3 / K6 / K9)            graph.py:75, :95 and its autograd
+# ---------------------------------------------------------------------------
+def spmm(indptr, indices, values, D, num_rows, dtype=np.float64):
+    A = sp.csr_matrix((values.astype(dtype), indices, indptr),
+                      shape=(num_rows, D.shape[0]))
+    return A @ D.astype(dtype)
+
+
+def spmm_t(indptr, indices, values, dY, num_cols, dtype=np.float64):
+    A = sp.csr_matrix((values.astype(dtype), indices, indptr),
+                      shape=(dY.shape[0], num_cols))
+    return A.T @ dY.astype(dtype)
