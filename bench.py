@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""Headline benchmark: full-batch R-GCN epoch time (ms) + stacked-CSR SpMM HBM GB/s on the
+AM-shaped synthetic graph (BASELINE.json `metric`).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one epoch = forward (2 R-GCN layers), cross-entropy on the labelled rows,
+backward, clip_grad_norm_(1.0), Adam — mrgcn/tasks/node_classification.py:166-193 — with all
+inputs resident in HBM.  N > 1 runs N independent replicas of the same epoch (the AM graph
+and its optimizer state fit one MI355X several times over; see DESIGN.md "multi-GPU").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6.29 TB/s measured copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="am", help="am | mutag | aifb | synth10m")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
+    ap.add_argument("--value-mode", default="norm_f32", choices=["norm_f32", "ref_int8"])
+    ap.add_argument("--engine", default="fused", choices=["fused", "literal"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-scale", type=float, default=1.0 / 16, help="fraction of the workload the CPU baseline runs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-literal-spmm", action="store_true")
+    ap.add_argument("--spmm-iters", type=int, default=30)
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters, stream_ptr):
+    """Average duration of `fn` over `iters` launches, measured with HIP events recorded on
+    the stream the kernels run on (through the C ABI, not torch.cuda.Event)."""
+    import ctypes as C
+    from mrgcn_amd import _lib as L
+    lib = L.load()
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    L.check(lib.mrgcn_event_create(C.byref(e0)))
+    L.check(lib.mrgcn_event_create(C.byref(e1)))
+    for _ in range(3):
+        fn()
+    L.check(lib.mrgcn_event_record(e0, stream_ptr))
+    for _ in range(iters):
+        fn()
+    L.check(lib.mrgcn_event_record(e1, stream_ptr))
+    ms = C.c_float()
+    L.check(lib.mrgcn_event_elapsed_ms(e0, e1, C.byref(ms)))
+    lib.mrgcn_event_destroy(e0)
+    lib.mrgcn_event_destroy(e1)
+    return ms.value / iters
+
+
+def cpu_baseline(args, shape_name):
+    """The reference's ATen op sequence (oracle/aten_literal.py, pinned against the reference's
+    golden vectors) timed on this host's cores on a bounded sample of the workload."""
+    import torch
+    from mrgcn_amd import synth
+    from oracle import aten_literal as AL
+    sc = args.cpu_scale * args.scale
+    g = synth.make_graph(shape_name, seed=args.seed, scale=sc, value_mode=args.value_mode)
+    sh = synth.SHAPES[shape_name]
+    dims = synth.layer_dims(shape_name)
+    featureless = sh["x_width"] == 0
+    rng = np.random.default_rng(args.seed)
+    X = None if featureless else rng.standard_normal((g.num_nodes, sh["x_width"])).astype(np.float32)
+    idx, y = synth.make_labels(shape_name, g.num_nodes, args.seed, sc)
+    cores = os.cpu_count() or 1
+    ms, threads = AL.time_epochs(dims, g.num_relations, g.num_nodes, sh["bases"], g.rows, g.cols, g.vals,
+                                 X, idx, y, featureless, warmup=1, steps=2, threads=cores, seed=args.seed)
+    return {
+        "value": ms / sc, "unit": "ms/epoch", "cores": threads, "kind": "port",
+        "sample": (f"{shape_name} x {sc:.4g} (N={g.num_nodes}, R={g.num_relations}, nnz={g.nnz}): "
+                   f"{ms:.1f} ms/epoch measured over 2 epochs after 1 warm-up with the reference's "
+                   f"literal ATen op sequence on {threads} threads; value = measured / {sc:.4g} "
+                   "(linear extrapolation to the full graph)"),
+        "measured_ms": ms, "sample_scale": sc,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd import synth
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.plan import plan_of
+    from mrgcn_amd.train import ClipAdam, train_step
+
+    name = args.workload
+    sh = synth.SHAPES[name]
+    t0 = time.time()
+    g = synth.make_graph(name, seed=args.seed, scale=args.scale, value_mode=args.value_mode)
+    N, R, B = g.num_nodes, g.num_relations, sh["bases"]
+    dims = synth.layer_dims(name)
+    featureless = sh["x_width"] == 0
+    idx_np, y_np = synth.make_labels(name, N, args.seed, args.scale)
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                (N, R * N)).to(dev)
+    torch.manual_seed(args.seed)
+    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li < len(dims) - 1 else None)
+               for li, (i, o) in enumerate(dims)]
+    model = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
+    model.set_engine(args.engine)
+    X = None if featureless else torch.randn((N, sh["x_width"]), device=dev)
+    idx = torch.from_numpy(idx_np).to(dev)
+    tgt = torch.from_numpy(y_np).to(dev)
+    opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+    plan = plan_of(A, N, R)
+    setup_s = time.time() - t0
+
+    def step():
+        return train_step(model, lambda: model(X, A), idx, tgt, opt)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    final_loss = float(loss)
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant sparse kernel: the stacked-CSR SpMM of layer 0 ----
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        F = dims[0][1]
+        ld = (F + 3) // 4 * 4
+        M = torch.randn((plan.ncols, ld), device=dev)
+        Y = torch.empty((N, F), device=dev)
+        t_c = event_time_ms(lambda: plan.spmm(L.VIEW_COMPACT, M, F=F, out=Y), args.spmm_iters, stream)
+        bytes_alg = plan.spmm_bytes(F)
+        ach = bytes_alg / (t_c * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "k_spmm_short+k_spmm_chunks+k_spmm_finalize (compact view, F=%d, ld=%d)" % (F, ld),
+                    "algorithmic_bytes": bytes_alg, "avg_ms": t_c}
+        extra = {}
+        dY = torch.randn((N, F), device=dev)
+        dM = torch.empty((plan.ncols, ld), device=dev)
+        t_t = event_time_ms(lambda: plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM), args.spmm_iters, stream)
+        extra["spmm_transposed_ms"] = t_t
+        extra["spmm_transposed_gbps"] = bytes_alg / (t_t * 1e-3) / 1e9
+        del dY, dM
+        if not args.no_literal_spmm:
+            try:  # the reference's own operand layout: dense (R*N) x F, 17.8 GB at AM scale
+                D = torch.randn((R * N, F), device=dev)
+                t_l = event_time_ms(lambda: plan.spmm(L.VIEW_LITERAL, D, out=Y), args.spmm_iters, stream)
+                extra["spmm_literal_ms"] = t_l
+                extra["spmm_literal_gbps"] = bytes_alg / (t_l * 1e-3) / 1e9
+                del D
+            except Exception as e:  # noqa: BLE001
+                extra["spmm_literal_error"] = str(e)[:200]
+        torch.cuda.synchronize(dev)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cpu = cpu_baseline(args, name)
+            except Exception as e:  # noqa: BLE001
+                cpu = {"value": None, "unit": "ms/epoch", "cores": os.cpu_count(), "kind": "port",
+                       "sample": "failed: " + str(e)[:200]}
+        n_params = sum(p.numel() for p in model.parameters())
+        out = {
+            "metric": "full-batch R-GCN epoch time (ms), AM-shaped graph",
+            "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}-shaped synthetic KG (SURVEY §8d), scale {args.scale:g}",
+                       "N": N, "R": R, "nnz": plan.nnz, "ncols_touched": plan.ncols,
+                       "layers": dims, "num_bases": B, "value_mode": args.value_mode,
+                       "engine": args.engine, "labelled": int(idx.numel()), "params": n_params,
+                       "parallelism": "replicas x%d" % world if world > 1 else "1 GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "spmm_hbm_gbps": ach,
+            "extra": dict(extra, final_loss=final_loss, setup_s=setup_s,
+                          plan_device_mb=plan.device_bytes / 2**20, long_rows=plan.long_rows,
+                          long_cols=plan.long_cols, max_row_nnz=plan.max_row_nnz),
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+/*
+ * mrgcn_hip.h — C ABI of libmrgcn_hip.so (MI355X / gfx950).
+ *
+ * The reference (wxwilcke/mrgcn) has no FFI: its hot path leans on PyTorch ATen ops
+ * called from Python.  Every entry point below replaces one such call site
+ * (file:line relative to the reference tree) and is what a ctypes binding in the
+ * reference's `mrgcn/layers/graph.py` would bind.
+ *
+ * Conventions
+ *   - plain C, no C++ / torch types; every pointer is a DEVICE pointer unless the
+ *     parameter name starts with `h_` (host);
+ *   - every call returns MRGCN_OK (0) or an error code; the message is available
+ *     from mrgcn_last_error() (thread local);
+ *   - compute calls are asynchronous and stream ordered on `stream` (a hipStream_t,
+ *     passed as void*; NULL = the null stream); they never allocate and never
+ *     synchronise, so they may be captured into a hipGraph;
+ *   - mrgcn_plan_create / _destroy / _export / mrgcn_event_* may allocate and
+ *     synchronise;
+ *   - buffers are caller owned; a plan owns only its own index copies and is
+ *     immutable after creation (safe to share between threads / streams).
+ */
+#ifndef MRGCN_HIP_H
+#define MRGCN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRGCN_ABI_VERSION 1
+
+enum mrgcn_status {
+  MRGCN_OK = 0,
+  MRGCN_ERR_INVALID = 1,     /* bad argument (shape, alignment, NULL, enum) */
+  MRGCN_ERR_HIP = 2,         /* a HIP runtime call failed */
+  MRGCN_ERR_UNSUPPORTED = 3, /* valid request this build cannot serve */
+  MRGCN_ERR_RANGE = 4        /* an index in the input is out of range */
+};
+
+enum mrgcn_val_dtype { MRGCN_VAL_I8 = 0, MRGCN_VAL_F32 = 1 };
+
+/* plan flags */
+#define MRGCN_PLAN_PRUNE_ZEROS 1u /* drop entries whose value is exactly 0 (legal: they
+                                     contribute nothing) */
+
+/* which sparse view of the plan a product runs on */
+enum mrgcn_view {
+  MRGCN_VIEW_LITERAL = 0, /* rows = output nodes, cols = r*N + j (the reference's layout) */
+  MRGCN_VIEW_COMPACT = 1, /* rows = output nodes, cols = rank of (j, r) among touched columns */
+  MRGCN_VIEW_TRANSPOSED = 2 /* rows = touched columns in (j, r) order, cols = output nodes */
+};
+
+/* arrays retrievable with mrgcn_plan_export (all int32 unless noted) */
+enum mrgcn_plan_array {
+  MRGCN_ARR_ROWPTR = 0,   /* [num_rows+1]  CSR row pointers                           */
+  MRGCN_ARR_LCOL = 1,     /* [nnz]         literal column r*N + j, sorted within a row */
+  MRGCN_ARR_CCOL = 2,     /* [nnz]         compact column id                           */
+  MRGCN_ARR_VAL = 3,      /* [nnz] float   values (A.float())                          */
+  MRGCN_ARR_CPTR = 4,     /* [ncols+1]     CSC pointers over compact columns           */
+  MRGCN_ARR_CROW = 5,     /* [nnz]         output row of each CSC entry                */
+  MRGCN_ARR_CVAL = 6,     /* [nnz] float   value of each CSC entry                     */
+  MRGCN_ARR_UREL = 7,     /* [ncols]       relation r of each compact column           */
+  MRGCN_ARR_UNODE = 8,    /* [ncols]       source node j of each compact column        */
+  MRGCN_ARR_NPTR = 9,     /* [num_nodes+1] compact-column range of each source node    */
+  MRGCN_ARR_ROWIDX = 10,  /* [nnz]         output row of each CSR entry                */
+  MRGCN_ARR_ULCOL = 11,   /* [ncols]       literal column r*N + j of each compact column */
+  MRGCN_ARR_RPERM = 12,   /* [ncols]       compact ids sorted by (relation, node)      */
+  MRGCN_ARR_RELPTR = 13   /* [R+1]         range of each relation inside RPERM         */
+};
+
+typedef struct mrgcn_plan mrgcn_plan_t;
+
+typedef struct mrgcn_plan_info {
+  int64_t num_rows;      /* rows of A (output nodes)                     */
+  int64_t num_nodes;     /* N: source nodes per relation block           */
+  int64_t num_relations; /* R                                            */
+  int64_t nnz;           /* stored entries after optional pruning        */
+  int64_t ncols;         /* distinct non-empty columns (n_cols_touched)  */
+  int64_t max_row_nnz;
+  int64_t max_col_nnz;
+  int64_t long_rows;     /* rows handled by the split-row path           */
+  int64_t long_cols;
+  int64_t device_bytes;  /* bytes of device memory the plan owns         */
+} mrgcn_plan_info_t;
+
+/* ---- library ---------------------------------------------------------------- */
+int mrgcn_abi_version(void);
+const char *mrgcn_arch(void);       /* "gfx950" */
+const char *mrgcn_last_error(void); /* message of the last failing call on this thread */
+
+/* ---- graph plan ---------------------------------------------------------------
+ * Built once per adjacency (A is static across epochs).  Input is exactly what the
+ * reference hands to GraphConvolution.forward: the uncoalesced COO of
+ * mrgcn/data/utils.py:165-170 (int64 indices 2 x nnz, given here as two rows) with
+ * int8 values (mrgcn/data/batch.py:144-149) or float32 values.  Replaces the
+ * per-call `A.float()` of mrgcn/layers/graph.py:75,:95 (done once here).
+ * Requires num_relations*num_nodes < 2^31 and nnz < 2^31. */
+int mrgcn_plan_create(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes,
+                      int32_t num_relations, int64_t nnz, const int64_t *coo_rows,
+                      const int64_t *coo_cols, const void *coo_vals, int32_t val_dtype,
+                      uint32_t flags, void *stream);
+int mrgcn_plan_destroy(mrgcn_plan_t *plan);
+int mrgcn_plan_info(const mrgcn_plan_t *plan, mrgcn_plan_info_t *h_info);
+/* copies one plan array to HOST memory (tests: index parity is bit-exact) */
+int mrgcn_plan_export(const mrgcn_plan_t *plan, int32_t which, void *h_dst, int64_t capacity_bytes);
+/* device pointer + element count of one plan array (owned by the plan, read only) */
+int mrgcn_plan_array(const mrgcn_plan_t *plan, int32_t which, const void **d_ptr, int64_t *h_count);
+
+/* ---- sparse x dense ------------------------------------------------------------
+ * Y[i, 0:F] = sum_e val[e] * D[col[e], 0:F]  (+ bias[0:F])  (optionally ReLU'd)
+ * over the entries e of row i of the chosen view.
+ *   view LITERAL    : replaces torch.mm(A.float(), W_I / FW_F), graph.py:75,:95
+ *   view COMPACT    : same product on a dense operand that holds only touched rows
+ *   view TRANSPOSED : dM[c] = sum val * dY[row]; the autograd of the above
+ *                     (SparseAddmmBackward: dDense = A^T dY)
+ * `out_index` (nullable, int32 [rows of view]) redirects output row i to
+ * Y[out_index[i]] — used to scatter compact rows into the literal (R*N) x F gradient.
+ * D, Y row-major with leading dimensions ldD, ldY (in floats).                      */
+int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const float *D, int64_t ldD,
+                   int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu,
+                   const int32_t *out_index, void *stream);
+
+/* ---- compact dense operand: forward -----------------------------------------------
+ * M is [ncols, ldM] row-major with one row per touched column c = (node j_c, relation
+ * r_c), in the plan's (j, r) order.  `accumulate` != 0 adds into M instead of storing.
+ *
+ * basis mix — replaces einsum('rb,bij->rij', weight_I_comp, weight_I.view(B,N,out)) and the
+ * view to (R*N, out) of graph.py:69-72, restricted to the rows the product will read:
+ *     M[c, 0:F] (+)= sum_b comp[r_c, b] * V[b*N + j_c, 0:F]        V: [B*N, F], comp: [R, B] */
+int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *plan, const float *V, const float *comp, int32_t B,
+                            int32_t F, float *M, int64_t ldM, int32_t accumulate, void *stream);
+/* no-bases input term (graph.py:67-68): M[c, 0:F] (+)= W[r_c*N + j_c, 0:F]      W: [R*N, F] */
+int mrgcn_gather_rows_f32(const mrgcn_plan_t *plan, const float *W, int32_t F, float *M,
+                          int64_t ldM, int32_t accumulate, void *stream);
+/* relation transform — replaces einsum('ij,bjk->bik', X, W_F) + reshape of graph.py:93-94,
+ * restricted to touched columns:
+ *     M[c, 0:F] (+)= X[j_c, 0:K] . W[r_c, 0:K, 0:F]                 X: [N, ldX], W: [R, K, F] */
+int mrgcn_rel_transform_fwd_f32(const mrgcn_plan_t *plan, const float *X, int64_t ldX, int32_t K,
+                                const float *W, int32_t F, float *M, int64_t ldM,
+                                int32_t accumulate, void *stream);
+
+/* ---- compact dense operand: backward (autograd of graph.py:69-72, :93-94) -------------
+ *     dV[b*N + j, :] = sum_{c in node j} comp[r_c, b] * dM[c, :]       (every row written)
+ *     dcomp[r, b]    = sum_{c: r_c = r} <dM[c, :], V[b*N + j_c, :]>    (zeroed inside)   */
+int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM, const float *V,
+                            const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
+                            void *stream);
+/*     dX[j, 0:K]  = sum_{c in node j} W[r_c] . dM[c, :]     (nullable; every row written)
+ *     dW[r, :, :] = sum_{c: r_c = r} X[j_c, :]^T dM[c, :]    (nullable; zeroed inside)     */
+int mrgcn_rel_transform_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM,
+                                const float *X, int64_t ldX, int32_t K, const float *W, int32_t F,
+                                float *dX, int64_t lddX, float *dW, void *stream);
+
+/* ---- epoch kernels around the layers ----------------------------------------------
+ * out = dY * (Y > 0): backward of the nn.ReLU between layers (rgcn.py:86-87) */
+int mrgcn_relu_bwd_f32(const float *dY, const float *Y, int64_t n, float *out, void *stream);
+/* loss = mean_i CE(logits[idx[i]], target[i]); dlogits (nullable, [num_rows, ldd]) is zeroed
+ * and receives d loss / d logits.  nn.CrossEntropyLoss over Y_hat[idx]
+ * (node_classification.py:439-444) and its backward. */
+int mrgcn_softmax_xent_f32(const float *logits, int64_t ld, int32_t C, const int64_t *idx,
+                           const int64_t *target, int64_t n, float *loss, float *dlogits,
+                           int64_t ldd, int64_t num_rows, void *stream);
+/* *accum += sum(x^2)  (accum is a device double, zeroed by the caller once per step) */
+int mrgcn_sumsq_accum_f32(const float *x, int64_t n, double *accum, void *stream);
+/* clip_grad_norm_(…, max_norm) (node_classification.py:192): norm = sqrt(*sumsq),
+ * coef = min(1, max_norm / (norm + 1e-6)); both stay on the device */
+int mrgcn_clip_coef_f32(const double *sumsq, float max_norm, float *coef, float *norm, void *stream);
+/* torch.optim.Adam step (node_classification.py:35-37, :193) on one tensor; the gradient is
+ * multiplied by *grad_scale (device float, nullable) first, i.e. the clip is folded in. */
+int mrgcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                        int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int64_t step, const float *grad_scale, void *stream);
+
+/* ---- timing helpers (HIP events on the caller's stream; used by bench.py) ------ */
+int mrgcn_event_create(void **event);
+int mrgcn_event_destroy(void *event);
+int mrgcn_event_record(void *event, void *stream);
+int mrgcn_event_elapsed_ms(void *start, void *stop, float *h_ms); /* synchronises on stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRGCN_HIP_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libmrgcn_hip.so (the C ABI declared in include/mrgcn_hip.h).
+
+There is NO fallback: if the library is missing or a call fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmrgcn_hip.so")
+
+# enums of include/mrgcn_hip.h
+OK = 0
+VAL_I8, VAL_F32 = 0, 1
+PLAN_PRUNE_ZEROS = 1
+VIEW_LITERAL, VIEW_COMPACT, VIEW_TRANSPOSED = 0, 1, 2
+(ARR_ROWPTR, ARR_LCOL, ARR_CCOL, ARR_VAL, ARR_CPTR, ARR_CROW, ARR_CVAL, ARR_UREL, ARR_UNODE,
+ ARR_NPTR, ARR_ROWIDX, ARR_ULCOL, ARR_RPERM, ARR_RELPTR) = range(14)
+FLOAT_ARRAYS = (ARR_VAL, ARR_CVAL)
+
+
+class MrgcnError(RuntimeError):
+    pass
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "num_rows", "num_nodes", "num_relations", "nnz", "ncols", "max_row_nnz", "max_col_nnz",
+        "long_rows", "long_cols", "device_bytes")]
+
+
+_p = C.c_void_p
+_i32, _i64, _u32 = C.c_int32, C.c_int64, C.c_uint32
+
+# name -> (restype, argtypes); kept in one table so that tests can compare it with the header
+SIGNATURES = {
+    "mrgcn_abi_version": (C.c_int, []),
+    "mrgcn_arch": (C.c_char_p, []),
+    "mrgcn_last_error": (C.c_char_p, []),
+    "mrgcn_plan_create": (C.c_int, [C.POINTER(_p), _i64, _i64, _i32, _i64, _p, _p, _p, _i32, _u32, _p]),
+    "mrgcn_plan_destroy": (C.c_int, [_p]),
+    "mrgcn_plan_info": (C.c_int, [_p, C.POINTER(PlanInfo)]),
+    "mrgcn_plan_export": (C.c_int, [_p, _i32, _p, _i64]),
+    "mrgcn_plan_array": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_i64)]),
+    "mrgcn_spmm_f32": (C.c_int, [_p, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _p]),
+    "mrgcn_basis_mix_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _i64, _i32, _p]),
+    "mrgcn_gather_rows_f32": (C.c_int, [_p, _p, _i32, _p, _i64, _i32, _p]),
+    "mrgcn_rel_transform_fwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]),
+    "mrgcn_basis_mix_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
+    "mrgcn_rel_transform_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p]),
+    "mrgcn_relu_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "mrgcn_softmax_xent_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _i64, _i64, _p]),
+    "mrgcn_sumsq_accum_f32": (C.c_int, [_p, _i64, _p, _p]),
+    "mrgcn_clip_coef_f32": (C.c_int, [_p, C.c_float, _p, _p, _p]),
+    "mrgcn_adam_step_f32": (C.c_int, [_p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_float,
+                                      C.c_float, C.c_float, _i64, _p, _p]),
+    "mrgcn_event_create": (C.c_int, [C.POINTER(_p)]),
+    "mrgcn_event_destroy": (C.c_int, [_p]),
+    "mrgcn_event_record": (C.c_int, [_p, _p]),
+    "mrgcn_event_elapsed_ms": (C.c_int, [_p, _p, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once).  Raises MrgcnError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MrgcnError(
+            f"{LIB_PATH} is missing: build it with `python -m mrgcn_amd.build` "
+            "(mrgcn_amd has no CPU or PyTorch fallback for its HIP kernels)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mrgcn_abi_version() != 1:
+        raise MrgcnError("libmrgcn_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != OK:
+        msg = load().mrgcn_last_error().decode(errors="replace")
+        raise MrgcnError(f"{what or 'mrgcn call'} failed (code {rc}): {msg}")

@@ -1,0 +1,65 @@
+"""Builds libmrgcn_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m mrgcn_amd.build [--force]
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libmrgcn_hip.so")
+ARCH = "gfx950"
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + \
+        glob.glob(os.path.join(os.path.dirname(CSRC), "..", "include", "*.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libmrgcn_hip.so")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    for src in sources():
+        obj = os.path.join(CSRC, "build", os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and all(os.path.getmtime(obj) > os.path.getmtime(h)
+                        for h in glob.glob(os.path.join(CSRC, "*.hpp")))):
+            continue
+        cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-Wno-unused-result",
+               "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,95 @@
+// Internal definitions shared by the translation units of libmrgcn_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/mrgcn_hip.h"
+
+namespace mrgcn {
+
+void set_error(const std::string &msg);
+
+#define MRGCN_HIP_TRY(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ::mrgcn::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" +      \
+                         __FILE__ + ":" + std::to_string(__LINE__) + ")");              \
+      return MRGCN_ERR_HIP;                                                              \
+    }                                                                                    \
+  } while (0)
+
+#define MRGCN_REQUIRE(cond, msg)                                     \
+  do {                                                               \
+    if (!(cond)) {                                                   \
+      ::mrgcn::set_error(std::string("invalid argument: ") + (msg)); \
+      return MRGCN_ERR_INVALID;                                      \
+    }                                                                \
+  } while (0)
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kLongThreshold = 32; // rows with more entries go to the split-row path
+constexpr int kChunk = 512;        // entries per split-row chunk (one wave each)
+constexpr int kWsFeatures = 256;   // split-row workspace is sized for this many features
+constexpr int kRelChunk = 1024;    // compact columns of one relation per transform block
+
+// One CSR-shaped view of the adjacency: `rows` output rows, entry e of row i
+// multiplies dense row idx[e] by val[e].  Rows longer than kLongThreshold are cut into
+// chunks of <= kChunk entries that one wave each reduces into `partials`.
+struct SparseView {
+  int64_t rows = 0;
+  const int32_t *ptr = nullptr;  // [rows+1]
+  const int32_t *idx = nullptr;  // [nnz]
+  const float *val = nullptr;    // [nnz]
+  // split-row path
+  int32_t n_long = 0;                  // long rows
+  int32_t n_chunks = 0;                // chunks over all long rows
+  const int32_t *long_row = nullptr;   // [n_long]   row id
+  const int32_t *long_cptr = nullptr;  // [n_long+1] chunk range of each long row
+  const int32_t *chunk_beg = nullptr;  // [n_chunks] first entry
+  const int32_t *chunk_end = nullptr;  // [n_chunks] one past last entry
+};
+
+}  // namespace mrgcn
+
+struct mrgcn_plan {
+  int64_t num_rows = 0, num_nodes = 0, num_relations = 0, nnz = 0, ncols = 0;
+  int64_t max_row_nnz = 0, max_col_nnz = 0;
+  int64_t device_bytes = 0;
+  int device = 0;
+  // CSR over output rows
+  int32_t *rowptr = nullptr, *lcol = nullptr, *ccol = nullptr, *rowidx = nullptr;
+  float *val = nullptr;
+  // CSC over compact columns, (j, r) order
+  int32_t *cptr = nullptr, *crow = nullptr, *urel = nullptr, *unode = nullptr, *nptr = nullptr,
+          *ulcol = nullptr;
+  float *cval = nullptr;
+  // relation-major order of the compact columns (for per-relation dense transforms)
+  int32_t *rperm = nullptr;   // [ncols] compact ids sorted by (relation, node)
+  int32_t *relptr = nullptr;  // [R+1]   range of each relation in rperm
+  int32_t *relchunk_rel = nullptr, *relchunk_beg = nullptr, *relchunk_end = nullptr;  // [n_relchunks]
+  int32_t n_relchunks = 0;
+  // split-row descriptors, one set per orientation
+  int32_t *r_long_row = nullptr, *r_long_cptr = nullptr, *r_chunk_beg = nullptr, *r_chunk_end = nullptr;
+  int32_t *c_long_row = nullptr, *c_long_cptr = nullptr, *c_chunk_beg = nullptr, *c_chunk_end = nullptr;
+  int32_t r_n_long = 0, r_n_chunks = 0, c_n_long = 0, c_n_chunks = 0;
+  float *partials = nullptr;  // [max(r_n_chunks, c_n_chunks) * kWsFeatures]
+
+  mrgcn::SparseView view(int which) const {
+    mrgcn::SparseView v;
+    if (which == MRGCN_VIEW_TRANSPOSED) {
+      v.rows = ncols; v.ptr = cptr; v.idx = crow; v.val = cval;
+      v.n_long = c_n_long; v.n_chunks = c_n_chunks; v.long_row = c_long_row;
+      v.long_cptr = c_long_cptr; v.chunk_beg = c_chunk_beg; v.chunk_end = c_chunk_end;
+    } else {
+      v.rows = num_rows; v.ptr = rowptr; v.idx = (which == MRGCN_VIEW_LITERAL) ? lcol : ccol;
+      v.val = val;
+      v.n_long = r_n_long; v.n_chunks = r_n_chunks; v.long_row = r_long_row;
+      v.long_cptr = r_long_cptr; v.chunk_beg = r_chunk_beg; v.chunk_end = r_chunk_end;
+    }
+    return v;
+  }
+};

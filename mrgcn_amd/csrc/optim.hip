@@ -1,0 +1,224 @@
+// Streaming kernels of the epoch that surround the layer: masked-ReLU backward, the
+// cross-entropy over labelled rows (mrgcn/tasks/node_classification.py:439-444), the global
+// gradient norm + clip coefficient (clip_grad_norm_(…, 1.0), :192) and Adam (:35-37, :193).
+// All are HBM-bound: float4 accesses, grid-stride over <= 2048 blocks.  At AM scale the
+// Adam pass over weight_I (2.67 GB x 7 streams) dominates the epoch.
+#include "common.hpp"
+
+namespace mrgcn {
+namespace {
+
+constexpr int kTB = 256;
+
+inline int stream_grid(int64_t n_vec) {
+  int64_t b = (n_vec + kTB - 1) / kTB;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+  return x;
+}
+
+__device__ __forceinline__ float block_sum(float x) {  // result valid in thread 0
+  __shared__ float s_part[kTB / kWave];
+  x = wave_sum(x);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_part[w] = x;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kTB / kWave; ++i) t += s_part[i];
+  return t;
+}
+
+// out = dY * (Y > 0)
+__global__ void k_relu_bwd(const float *__restrict__ dY, const float *__restrict__ Y, int64_t n,
+                           float *__restrict__ out) {
+  const int64_t nv = n >> 2;
+  const float4 *d4 = reinterpret_cast<const float4 *>(dY);
+  const float4 *y4 = reinterpret_cast<const float4 *>(Y);
+  float4 *o4 = reinterpret_cast<float4 *>(out);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 d = d4[i], y = y4[i], o;
+    o.x = y.x > 0.f ? d.x : 0.f;
+    o.y = y.y > 0.f ? d.y : 0.f;
+    o.z = y.z > 0.f ? d.z : 0.f;
+    o.w = y.w > 0.f ? d.w : 0.f;
+    o4[i] = o;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += blockDim.x)
+      out[i] = Y[i] > 0.f ? dY[i] : 0.f;
+}
+
+// sum of squares -> double accumulator (one atomic per block)
+__global__ void k_sumsq(const float *__restrict__ x, int64_t n, double *__restrict__ accum) {
+  const int64_t nv = n >> 2;
+  const float4 *x4 = reinterpret_cast<const float4 *>(x);
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = x4[i];
+    s = fmaf(v.x, v.x, s);
+    s = fmaf(v.y, v.y, s);
+    s = fmaf(v.z, v.z, s);
+    s = fmaf(v.w, v.w, s);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += blockDim.x) s = fmaf(x[i], x[i], s);
+  float t = block_sum(s);
+  if (threadIdx.x == 0) atomicAdd(accum, (double)t);
+}
+
+// clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6))
+__global__ void k_clip_coef(const double *__restrict__ sumsq, float max_norm, float *__restrict__ coef,
+                            float *__restrict__ norm) {
+  float nrm = (float)sqrt(*sumsq);
+  float c = max_norm / (nrm + 1e-6f);
+  *coef = c < 1.f ? c : 1.f;
+  if (norm) *norm = nrm;
+}
+
+// torch.optim.Adam (amsgrad = False, maximize = False), gradient pre-scaled by *scale
+__global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                       float *__restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                       float wd, float bc1, float bc2_sqrt, const float *__restrict__ scale) {
+  const float sc = scale ? *scale : 1.f;
+  const float step = lr / bc1;
+  const int64_t nv = n >> 2;
+  float4 *p4 = reinterpret_cast<float4 *>(p);
+  const float4 *g4 = reinterpret_cast<const float4 *>(g);
+  float4 *m4 = reinterpret_cast<float4 *>(m);
+  float4 *v4 = reinterpret_cast<float4 *>(v);
+  auto upd = [&](float &pp, float gg, float &mm, float &vv) {
+    gg *= sc;
+    if (wd != 0.f) gg = fmaf(wd, pp, gg);
+    mm = fmaf(b1, mm, (1.f - b1) * gg);
+    vv = fmaf(b2, vv, (1.f - b2) * gg * gg);
+    float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= step * (mm / denom);
+  };
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 P = p4[i], G = g4[i], M = m4[i], V = v4[i];
+    upd(P.x, G.x, M.x, V.x);
+    upd(P.y, G.y, M.y, V.y);
+    upd(P.z, G.z, M.z, V.z);
+    upd(P.w, G.w, M.w, V.w);
+    p4[i] = P;
+    m4[i] = M;
+    v4[i] = V;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += blockDim.x) {
+      float P = p[i], M = m[i], V = v[i];
+      upd(P, g[i], M, V);
+      p[i] = P;
+      m[i] = M;
+      v[i] = V;
+    }
+}
+
+// mean cross-entropy over labelled rows + its gradient w.r.t. the logits.
+// one thread per labelled row (C is small: the number of classes)
+__global__ void k_xent(const float *__restrict__ logits, int64_t ld, int C,
+                       const int64_t *__restrict__ idx, const int64_t *__restrict__ target, int64_t n,
+                       float *__restrict__ loss, float *__restrict__ dlogits, int64_t ldd) {
+  float my = 0.f;
+  const float inv_n = 1.f / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float *z = logits + idx[i] * ld;
+    float mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+    const float lse = logf(se) + mx;
+    const int64_t t = target[i];
+    my += (lse - z[t]) * inv_n;
+    if (dlogits) {
+      float *d = dlogits + idx[i] * ldd;
+      for (int c = 0; c < C; ++c) {
+        float pr = expf(z[c] - lse);
+        atomicAdd(&d[c], (pr - (c == t ? 1.f : 0.f)) * inv_n);  // a node may be listed twice
+      }
+    }
+  }
+  float t = block_sum(my);
+  if (threadIdx.x == 0) atomicAdd(loss, t);
+}
+
+}  // namespace
+}  // namespace mrgcn
+
+using namespace mrgcn;
+
+extern "C" {
+
+int mrgcn_relu_bwd_f32(const float *dY, const float *Y, int64_t n, float *out, void *stream) {
+  MRGCN_REQUIRE(dY && Y && out, "NULL");
+  MRGCN_REQUIRE((((uintptr_t)dY | (uintptr_t)Y | (uintptr_t)out) & 15) == 0, "16-byte alignment");
+  if (n == 0) return MRGCN_OK;
+  k_relu_bwd<<<dim3(stream_grid(n >> 2)), dim3(kTB), 0, (hipStream_t)stream>>>(dY, Y, n, out);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_sumsq_accum_f32(const float *x, int64_t n, double *accum, void *stream) {
+  MRGCN_REQUIRE(x && accum, "NULL");
+  MRGCN_REQUIRE(((uintptr_t)x & 15) == 0, "16-byte alignment");
+  if (n == 0) return MRGCN_OK;
+  k_sumsq<<<dim3(stream_grid(n >> 2)), dim3(kTB), 0, (hipStream_t)stream>>>(x, n, accum);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_clip_coef_f32(const double *sumsq, float max_norm, float *coef, float *norm, void *stream) {
+  MRGCN_REQUIRE(sumsq && coef, "NULL");
+  k_clip_coef<<<dim3(1), dim3(1), 0, (hipStream_t)stream>>>(sumsq, max_norm, coef, norm);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                        float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int64_t step, const float *grad_scale, void *stream) {
+  MRGCN_REQUIRE(param && grad && exp_avg && exp_avg_sq, "NULL");
+  MRGCN_REQUIRE(step >= 1, "step counts from 1");
+  MRGCN_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                "16-byte alignment");
+  if (n == 0) return MRGCN_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  k_adam<<<dim3(stream_grid(n >> 2)), dim3(kTB), 0, (hipStream_t)stream>>>(
+      param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+      (float)sqrt(bc2), grad_scale);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_softmax_xent_f32(const float *logits, int64_t ld, int32_t C, const int64_t *idx,
+                           const int64_t *target, int64_t n, float *loss, float *dlogits,
+                           int64_t ldd, int64_t num_rows, void *stream) {
+  MRGCN_REQUIRE(logits && idx && target && loss, "NULL");
+  MRGCN_REQUIRE(C > 0 && ld >= C && n > 0, "C / ld / n");
+  hipStream_t s = (hipStream_t)stream;
+  MRGCN_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), s));
+  if (dlogits) {
+    MRGCN_REQUIRE(ldd >= C && num_rows > 0, "ldd / num_rows");
+    MRGCN_HIP_TRY(hipMemsetAsync(dlogits, 0, (size_t)num_rows * ldd * sizeof(float), s));
+  }
+  int grid = (int)((n + kTB - 1) / kTB);
+  if (grid > 1024) grid = 1024;
+  k_xent<<<dim3(grid), dim3(kTB), 0, s>>>(logits, ld, C, idx, target, n, loss, dlogits, ldd);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+}  // extern "C"

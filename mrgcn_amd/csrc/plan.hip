@@ -1,0 +1,522 @@
+// Graph plan construction: the reference's uncoalesced COO (int64 indices, int8 or f32
+// values; mrgcn/data/utils.py:165-170, mrgcn/data/batch.py:144-149) -> device-resident
+// CSR over output rows + CSC over *touched* columns in (source node, relation) order.
+// One-off work per adjacency (A is static across epochs), so device-wide hipcub
+// sort/scan primitives are used; everything else is hand-written.
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "common.hpp"
+
+namespace mrgcn {
+
+thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+namespace {
+
+constexpr int kTB = 256;
+inline int nblocks(int64_t n) { return (int)((n + kTB - 1) / kTB); }
+
+// key = row * RN + col; zero-valued entries get the sentinel when pruning so that they
+// sort past the end.  Out-of-range indices raise *err.
+__global__ void k_make_keys(const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
+                            const void *__restrict__ vals, int val_dtype, int64_t nnz,
+                            int64_t num_rows, int64_t RN, int prune, int64_t *__restrict__ keys,
+                            float *__restrict__ fvals, unsigned int *__restrict__ kept,
+                            int *__restrict__ err) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz) return;
+  int64_t r = rows[e], c = cols[e];
+  float v = (val_dtype == MRGCN_VAL_I8) ? (float)((const int8_t *)vals)[e] : ((const float *)vals)[e];
+  if (r < 0 || r >= num_rows || c < 0 || c >= RN) {
+    *err = 1;
+    keys[e] = INT64_MAX;
+    fvals[e] = 0.f;
+    return;
+  }
+  if (prune && v == 0.f) {
+    keys[e] = INT64_MAX;
+    fvals[e] = 0.f;
+    return;
+  }
+  keys[e] = r * RN + c;
+  fvals[e] = v;
+  atomicAdd(kept, 1u);  // the compiler folds this into one add per wave
+}
+
+__global__ void k_decode(const int64_t *__restrict__ keys, int64_t nnz, int64_t RN, int64_t N,
+                         int64_t R, int32_t *__restrict__ rowidx, int32_t *__restrict__ lcol,
+                         int64_t *__restrict__ key2, int32_t *__restrict__ eidx) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz) return;
+  int64_t k = keys[e];
+  int64_t r = k / RN, c = k - r * RN;
+  int64_t rel = c / N, j = c - rel * N;
+  rowidx[e] = (int32_t)r;
+  lcol[e] = (int32_t)c;
+  key2[e] = j * R + rel;  // (source node, relation) order of the compact columns
+  eidx[e] = (int32_t)e;
+}
+
+// ptr[i] = first position p in sorted `keys` with keys[p] >= i * stride, i in [0, n]
+__global__ void k_lower_bound_ptr(const int64_t *__restrict__ keys, int64_t nnz, int64_t n,
+                                  int64_t stride, int32_t *__restrict__ ptr) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  int64_t target = i * stride;
+  int64_t lo = 0, hi = nnz;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  ptr[i] = (int32_t)lo;
+}
+
+__global__ void k_heads(const int64_t *__restrict__ key2s, int64_t nnz, int32_t *__restrict__ head) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  head[k] = (k == 0 || key2s[k] != key2s[k - 1]) ? 1 : 0;
+}
+
+__global__ void k_scatter_cols(const int64_t *__restrict__ key2s, const int32_t *__restrict__ eidxs,
+                               const int32_t *__restrict__ cid1, const int32_t *__restrict__ head,
+                               const int32_t *__restrict__ rowidx, const float *__restrict__ val,
+                               int64_t nnz, int64_t R, int32_t *__restrict__ ccol,
+                               int32_t *__restrict__ crow, float *__restrict__ cval,
+                               int32_t *__restrict__ cptr, int32_t *__restrict__ urel,
+                               int32_t *__restrict__ unode, int32_t *__restrict__ ulcol, int64_t N) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  int32_t e = eidxs[k];
+  int32_t c = cid1[k] - 1;
+  ccol[e] = c;
+  crow[k] = rowidx[e];
+  cval[k] = val[e];
+  if (head[k]) {
+    int64_t k2 = key2s[k];
+    int64_t j = k2 / R;
+    cptr[c] = (int32_t)k;
+    unode[c] = (int32_t)j;
+    int64_t rel = k2 - j * R;
+    urel[c] = (int32_t)rel;
+    ulcol[c] = (int32_t)(rel * N + j);
+  }
+}
+
+// ptr[i] = first position in sorted int32 `keys` with keys[pos] >= i * stride, i in [0, n]
+// (stride 1 over unode -> node pointers; stride N over sorted literal columns -> relation pointers)
+__global__ void k_node_ptr(const int32_t *__restrict__ keys, int64_t count, int64_t n, int64_t stride,
+                           int32_t *__restrict__ ptr) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  int64_t target = i * stride;
+  int64_t lo = 0, hi = count;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  ptr[i] = (int32_t)lo;
+}
+
+__global__ void k_iota(int32_t *__restrict__ a, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = (int32_t)i;
+}
+
+// per row: is it long, and how many chunks does it need
+__global__ void k_long_count(const int32_t *__restrict__ ptr, int64_t rows, int thresh, int chunk,
+                             int32_t *__restrict__ is_long, int32_t *__restrict__ nchunk,
+                             int32_t *__restrict__ maxlen) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  int32_t len = ptr[i + 1] - ptr[i];
+  int32_t lg = len > thresh;
+  is_long[i] = lg;
+  nchunk[i] = lg ? (len + chunk - 1) / chunk : 0;
+  atomicMax(maxlen, len);
+}
+
+__global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int chunk,
+                            const int32_t *__restrict__ is_long, const int32_t *__restrict__ long_pos,
+                            const int32_t *__restrict__ chunk_pos, int32_t *__restrict__ long_row,
+                            int32_t *__restrict__ long_cptr, int32_t *__restrict__ chunk_beg,
+                            int32_t *__restrict__ chunk_end) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows || !is_long[i]) return;
+  int32_t li = long_pos[i], c0 = chunk_pos[i];
+  long_row[li] = (int32_t)i;
+  long_cptr[li] = c0;
+  int32_t b = ptr[i], e = ptr[i + 1];
+  for (int32_t s = b, c = c0; s < e; s += chunk, ++c) {
+    chunk_beg[c] = s;
+    chunk_end[c] = min(s + chunk, e);
+  }
+}
+
+struct Scratch {  // frees its allocations on scope exit
+  std::vector<void *> ptrs;
+  ~Scratch() { for (void *p : ptrs) (void)hipFree(p); }
+  template <typename T> hipError_t alloc(T **p, int64_t n) {
+    hipError_t e = hipMalloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) ptrs.push_back(*p);
+    return e;
+  }
+};
+
+template <typename T> hipError_t plan_alloc(mrgcn_plan *p, T **dst, int64_t n) {
+  size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T);
+  hipError_t e = hipMalloc((void **)dst, bytes);
+  if (e == hipSuccess) p->device_bytes += (int64_t)bytes;
+  return e;
+}
+
+int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, hipStream_t s, Scratch &sc) {
+  size_t tb = 0;
+  MRGCN_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, s));
+  char *tmp = nullptr;
+  MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
+  MRGCN_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, in, out, (int)n, s));
+  return MRGCN_OK;
+}
+
+// builds the split-row descriptors of one orientation
+int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, int32_t **long_row,
+               int32_t **long_cptr, int32_t **chunk_beg, int32_t **chunk_end, int32_t *n_long,
+               int32_t *n_chunks, int64_t *max_len) {
+  Scratch sc;
+  int32_t *is_long, *nchunk, *long_pos, *chunk_pos, *d_max;
+  MRGCN_HIP_TRY(sc.alloc(&is_long, rows + 1));
+  MRGCN_HIP_TRY(sc.alloc(&nchunk, rows + 1));
+  MRGCN_HIP_TRY(sc.alloc(&long_pos, rows + 1));
+  MRGCN_HIP_TRY(sc.alloc(&chunk_pos, rows + 1));
+  MRGCN_HIP_TRY(sc.alloc(&d_max, 1));
+  MRGCN_HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
+  MRGCN_HIP_TRY(hipMemsetAsync(is_long, 0, (rows + 1) * sizeof(int32_t), s));
+  MRGCN_HIP_TRY(hipMemsetAsync(nchunk, 0, (rows + 1) * sizeof(int32_t), s));
+  if (rows > 0)
+    k_long_count<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, kLongThreshold, kChunk, is_long, nchunk, d_max);
+  // scan over rows+1 elements so that position [rows] holds the totals
+  int rc;
+  if ((rc = exclusive_scan_i32(is_long, long_pos, rows + 1, s, sc))) return rc;
+  if ((rc = exclusive_scan_i32(nchunk, chunk_pos, rows + 1, s, sc))) return rc;
+  int32_t h[3];
+  MRGCN_HIP_TRY(hipMemcpyAsync(&h[0], long_pos + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipMemcpyAsync(&h[1], chunk_pos + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipMemcpyAsync(&h[2], d_max, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  *n_long = h[0];
+  *n_chunks = h[1];
+  *max_len = h[2];
+  MRGCN_HIP_TRY(plan_alloc(p, long_row, h[0]));
+  MRGCN_HIP_TRY(plan_alloc(p, long_cptr, h[0] + 1));
+  MRGCN_HIP_TRY(plan_alloc(p, chunk_beg, h[1]));
+  MRGCN_HIP_TRY(plan_alloc(p, chunk_end, h[1]));
+  MRGCN_HIP_TRY(hipMemcpyAsync(*long_cptr + h[0], &h[1], sizeof(int32_t), hipMemcpyHostToDevice, s));
+  if (rows > 0 && h[0] > 0)
+    k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, kChunk, is_long, long_pos, chunk_pos,
+                                              *long_row, *long_cptr, *chunk_beg, *chunk_end);
+  MRGCN_HIP_TRY(hipGetLastError());
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  return MRGCN_OK;
+}
+
+int bits_for(int64_t max_value) {
+  int b = 1;
+  while (b < 63 && (max_value >> b) != 0) ++b;
+  return b;
+}
+
+int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_t *cols,
+                const void *vals, int val_dtype, uint32_t flags, hipStream_t s) {
+  const int64_t N = p->num_nodes, R = p->num_relations, RN = R * N;
+  Scratch sc;
+  int64_t *keys, *keys_s, *key2, *key2_s;
+  float *fv;
+  int32_t *eidx, *eidx_s, *head, *cid1;
+  unsigned int *d_kept;
+  int *d_err;
+  MRGCN_HIP_TRY(sc.alloc(&keys, nnz_in));
+  MRGCN_HIP_TRY(sc.alloc(&keys_s, nnz_in));
+  MRGCN_HIP_TRY(sc.alloc(&fv, nnz_in));
+  MRGCN_HIP_TRY(sc.alloc(&d_kept, 1));
+  MRGCN_HIP_TRY(sc.alloc(&d_err, 1));
+  MRGCN_HIP_TRY(hipMemsetAsync(d_kept, 0, sizeof(unsigned int), s));
+  MRGCN_HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), s));
+
+  float *val_sorted = nullptr;  // becomes plan->val
+  MRGCN_HIP_TRY(plan_alloc(p, &val_sorted, nnz_in));
+  p->val = val_sorted;
+
+  if (nnz_in > 0) {
+    k_make_keys<<<nblocks(nnz_in), kTB, 0, s>>>(rows, cols, vals, val_dtype, nnz_in, p->num_rows, RN,
+                                                (flags & MRGCN_PLAN_PRUNE_ZEROS) ? 1 : 0, keys, fv,
+                                                d_kept, d_err);
+    MRGCN_HIP_TRY(hipGetLastError());
+    // sort by (row, col); only the bits that can be set take part (sentinel uses bit 62)
+    size_t tb = 0;
+    const int end_bit = 63;
+    MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys_s, fv, val_sorted,
+                                                     (int)nnz_in, 0, end_bit, s));
+    char *tmp;
+    MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
+    MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, keys_s, fv, val_sorted,
+                                                     (int)nnz_in, 0, end_bit, s));
+  }
+  unsigned int h_kept = 0;
+  int h_err = 0;
+  MRGCN_HIP_TRY(hipMemcpyAsync(&h_kept, d_kept, sizeof(h_kept), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  if (h_err) {
+    set_error("COO index out of range (row >= num_rows or col >= num_relations*num_nodes)");
+    return MRGCN_ERR_RANGE;
+  }
+  const int64_t nnz = (int64_t)h_kept;
+  p->nnz = nnz;
+
+  MRGCN_HIP_TRY(plan_alloc(p, &p->rowptr, p->num_rows + 1));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->lcol, nnz));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->ccol, nnz));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->rowidx, nnz));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->crow, nnz));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->cval, nnz));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->nptr, N + 1));
+
+  MRGCN_HIP_TRY(sc.alloc(&key2, nnz));
+  MRGCN_HIP_TRY(sc.alloc(&key2_s, nnz));
+  MRGCN_HIP_TRY(sc.alloc(&eidx, nnz));
+  MRGCN_HIP_TRY(sc.alloc(&eidx_s, nnz));
+  MRGCN_HIP_TRY(sc.alloc(&head, nnz));
+  MRGCN_HIP_TRY(sc.alloc(&cid1, nnz));
+
+  k_lower_bound_ptr<<<nblocks(p->num_rows + 1), kTB, 0, s>>>(keys_s, nnz, p->num_rows, RN, p->rowptr);
+  MRGCN_HIP_TRY(hipGetLastError());
+  int64_t ncols = 0;
+  if (nnz > 0) {
+    k_decode<<<nblocks(nnz), kTB, 0, s>>>(keys_s, nnz, RN, N, R, p->rowidx, p->lcol, key2, eidx);
+    MRGCN_HIP_TRY(hipGetLastError());
+    size_t tb = 0;
+    const int end_bit = bits_for(RN);
+    MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key2, key2_s, eidx, eidx_s, (int)nnz,
+                                                     0, end_bit, s));
+    char *tmp;
+    MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
+    MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key2, key2_s, eidx, eidx_s, (int)nnz, 0,
+                                                     end_bit, s));
+    k_heads<<<nblocks(nnz), kTB, 0, s>>>(key2_s, nnz, head);
+    MRGCN_HIP_TRY(hipGetLastError());
+    size_t tb2 = 0;
+    MRGCN_HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb2, head, cid1, (int)nnz, s));
+    char *tmp2;
+    MRGCN_HIP_TRY(sc.alloc(&tmp2, (int64_t)tb2));
+    MRGCN_HIP_TRY(hipcub::DeviceScan::InclusiveSum(tmp2, tb2, head, cid1, (int)nnz, s));
+    int32_t h_ncols = 0;
+    MRGCN_HIP_TRY(hipMemcpyAsync(&h_ncols, cid1 + (nnz - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MRGCN_HIP_TRY(hipStreamSynchronize(s));
+    ncols = h_ncols;
+  }
+  p->ncols = ncols;
+  MRGCN_HIP_TRY(plan_alloc(p, &p->cptr, ncols + 1));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->urel, ncols));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->unode, ncols));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->ulcol, ncols));
+  if (nnz > 0) {
+    k_scatter_cols<<<nblocks(nnz), kTB, 0, s>>>(key2_s, eidx_s, cid1, head, p->rowidx, p->val, nnz, R,
+                                                p->ccol, p->crow, p->cval, p->cptr, p->urel, p->unode,
+                                                p->ulcol, N);
+    MRGCN_HIP_TRY(hipGetLastError());
+  }
+  int32_t h_nnz32 = (int32_t)nnz;
+  MRGCN_HIP_TRY(hipMemcpyAsync(p->cptr + ncols, &h_nnz32, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  k_node_ptr<<<nblocks(N + 1), kTB, 0, s>>>(p->unode, ncols, N, 1, p->nptr);
+  MRGCN_HIP_TRY(hipGetLastError());
+
+  // relation-major order of the compact columns: rperm = compact ids sorted by literal column
+  MRGCN_HIP_TRY(plan_alloc(p, &p->rperm, ncols));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->relptr, R + 1));
+  {
+    int32_t *ids, *ulcol_s;
+    MRGCN_HIP_TRY(sc.alloc(&ids, ncols));
+    MRGCN_HIP_TRY(sc.alloc(&ulcol_s, ncols));
+    if (ncols > 0) {
+      k_iota<<<nblocks(ncols), kTB, 0, s>>>(ids, ncols);
+      MRGCN_HIP_TRY(hipGetLastError());
+      size_t tb = 0;
+      const int end_bit = bits_for(RN);
+      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, p->ulcol, ulcol_s, ids, p->rperm,
+                                                       (int)ncols, 0, end_bit, s));
+      char *tmp;
+      MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
+      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, p->ulcol, ulcol_s, ids, p->rperm,
+                                                       (int)ncols, 0, end_bit, s));
+    }
+    k_node_ptr<<<nblocks(R + 1), kTB, 0, s>>>(ulcol_s, ncols, R, N, p->relptr);
+    MRGCN_HIP_TRY(hipGetLastError());
+    // relation chunks (<= kRelChunk columns of one relation each), built on the host: R is small
+    std::vector<int32_t> h_relptr(R + 1);
+    MRGCN_HIP_TRY(hipMemcpyAsync(h_relptr.data(), p->relptr, (R + 1) * sizeof(int32_t),
+                                 hipMemcpyDeviceToHost, s));
+    MRGCN_HIP_TRY(hipStreamSynchronize(s));
+    std::vector<int32_t> rel, beg, end;
+    for (int64_t r = 0; r < R; ++r)
+      for (int32_t b = h_relptr[r]; b < h_relptr[r + 1]; b += kRelChunk) {
+        rel.push_back((int32_t)r);
+        beg.push_back(b);
+        end.push_back(std::min(b + kRelChunk, h_relptr[r + 1]));
+      }
+    p->n_relchunks = (int32_t)rel.size();
+    MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_rel, p->n_relchunks));
+    MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_beg, p->n_relchunks));
+    MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_end, p->n_relchunks));
+    if (p->n_relchunks > 0) {
+      size_t nb = rel.size() * sizeof(int32_t);
+      MRGCN_HIP_TRY(hipMemcpy(p->relchunk_rel, rel.data(), nb, hipMemcpyHostToDevice));
+      MRGCN_HIP_TRY(hipMemcpy(p->relchunk_beg, beg.data(), nb, hipMemcpyHostToDevice));
+      MRGCN_HIP_TRY(hipMemcpy(p->relchunk_end, end.data(), nb, hipMemcpyHostToDevice));
+    }
+  }
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+
+  int rc;
+  if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r_long_row, &p->r_long_cptr, &p->r_chunk_beg,
+                       &p->r_chunk_end, &p->r_n_long, &p->r_n_chunks, &p->max_row_nnz)))
+    return rc;
+  if ((rc = build_long(p, p->cptr, p->ncols, s, &p->c_long_row, &p->c_long_cptr, &p->c_chunk_beg,
+                       &p->c_chunk_end, &p->c_n_long, &p->c_n_chunks, &p->max_col_nnz)))
+    return rc;
+  int64_t ws = (int64_t)std::max(p->r_n_chunks, p->c_n_chunks) * kWsFeatures;
+  MRGCN_HIP_TRY(plan_alloc(p, &p->partials, ws));
+  return MRGCN_OK;
+}
+
+void free_plan(mrgcn_plan *p) {
+  void *ptrs[] = {p->rowptr, p->lcol, p->ccol, p->rowidx, p->val, p->cptr, p->crow, p->urel, p->unode,
+                  p->nptr, p->ulcol, p->rperm, p->relptr, p->relchunk_rel, p->relchunk_beg, p->relchunk_end,
+                  p->cval, p->r_long_row, p->r_long_cptr, p->r_chunk_beg, p->r_chunk_end,
+                  p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->partials};
+  for (void *q : ptrs)
+    if (q) (void)hipFree(q);
+  delete p;
+}
+
+}  // namespace
+}  // namespace mrgcn
+
+extern "C" {
+
+int mrgcn_abi_version(void) { return MRGCN_ABI_VERSION; }
+const char *mrgcn_arch(void) { return "gfx950"; }
+const char *mrgcn_last_error(void) { return mrgcn::g_last_error.c_str(); }
+
+int mrgcn_plan_create(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, int32_t num_relations,
+                      int64_t nnz, const int64_t *coo_rows, const int64_t *coo_cols, const void *coo_vals,
+                      int32_t val_dtype, uint32_t flags, void *stream) {
+  MRGCN_REQUIRE(plan != nullptr, "plan is NULL");
+  *plan = nullptr;
+  MRGCN_REQUIRE(num_rows >= 0 && num_nodes > 0 && num_relations > 0, "bad shape");
+  MRGCN_REQUIRE(nnz >= 0 && nnz < (int64_t)INT32_MAX, "nnz must be < 2^31");
+  MRGCN_REQUIRE((int64_t)num_relations * num_nodes < (int64_t)INT32_MAX,
+                "num_relations*num_nodes must be < 2^31");
+  MRGCN_REQUIRE(num_rows < (int64_t)INT32_MAX, "num_rows must be < 2^31");
+  MRGCN_REQUIRE(val_dtype == MRGCN_VAL_I8 || val_dtype == MRGCN_VAL_F32, "val_dtype");
+  MRGCN_REQUIRE(nnz == 0 || (coo_rows && coo_cols && coo_vals), "NULL COO array");
+  mrgcn_plan *p = new mrgcn_plan();
+  p->num_rows = num_rows;
+  p->num_nodes = num_nodes;
+  p->num_relations = num_relations;
+  (void)hipGetDevice(&p->device);
+  int rc = mrgcn::create_impl(p, nnz, coo_rows, coo_cols, coo_vals, val_dtype, flags, (hipStream_t)stream);
+  if (rc != MRGCN_OK) {
+    mrgcn::free_plan(p);
+    return rc;
+  }
+  *plan = p;
+  return MRGCN_OK;
+}
+
+int mrgcn_plan_destroy(mrgcn_plan_t *plan) {
+  if (plan) mrgcn::free_plan(plan);
+  return MRGCN_OK;
+}
+
+int mrgcn_plan_info(const mrgcn_plan_t *p, mrgcn_plan_info_t *h) {
+  MRGCN_REQUIRE(p && h, "NULL");
+  h->num_rows = p->num_rows;
+  h->num_nodes = p->num_nodes;
+  h->num_relations = p->num_relations;
+  h->nnz = p->nnz;
+  h->ncols = p->ncols;
+  h->max_row_nnz = p->max_row_nnz;
+  h->max_col_nnz = p->max_col_nnz;
+  h->long_rows = p->r_n_long;
+  h->long_cols = p->c_n_long;
+  h->device_bytes = p->device_bytes;
+  return MRGCN_OK;
+}
+
+static int plan_lookup(const mrgcn_plan_t *p, int32_t which, const void **out, int64_t *count) {
+  const void *src = nullptr;
+  int64_t n = 0;
+  switch (which) {
+    case MRGCN_ARR_ROWPTR: src = p->rowptr; n = p->num_rows + 1; break;
+    case MRGCN_ARR_LCOL: src = p->lcol; n = p->nnz; break;
+    case MRGCN_ARR_CCOL: src = p->ccol; n = p->nnz; break;
+    case MRGCN_ARR_VAL: src = p->val; n = p->nnz; break;
+    case MRGCN_ARR_CPTR: src = p->cptr; n = p->ncols + 1; break;
+    case MRGCN_ARR_CROW: src = p->crow; n = p->nnz; break;
+    case MRGCN_ARR_CVAL: src = p->cval; n = p->nnz; break;
+    case MRGCN_ARR_UREL: src = p->urel; n = p->ncols; break;
+    case MRGCN_ARR_UNODE: src = p->unode; n = p->ncols; break;
+    case MRGCN_ARR_NPTR: src = p->nptr; n = p->num_nodes + 1; break;
+    case MRGCN_ARR_ROWIDX: src = p->rowidx; n = p->nnz; break;
+    case MRGCN_ARR_ULCOL: src = p->ulcol; n = p->ncols; break;
+    case MRGCN_ARR_RPERM: src = p->rperm; n = p->ncols; break;
+    case MRGCN_ARR_RELPTR: src = p->relptr; n = p->num_relations + 1; break;
+    default: MRGCN_REQUIRE(false, "unknown plan array");
+  }
+  *out = src;
+  *count = n;
+  return MRGCN_OK;
+}
+
+int mrgcn_plan_array(const mrgcn_plan_t *p, int32_t which, const void **d_ptr, int64_t *h_count) {
+  MRGCN_REQUIRE(p && d_ptr && h_count, "NULL");
+  return plan_lookup(p, which, d_ptr, h_count);
+}
+
+int mrgcn_plan_export(const mrgcn_plan_t *p, int32_t which, void *h_dst, int64_t capacity_bytes) {
+  MRGCN_REQUIRE(p && h_dst, "NULL");
+  const void *src = nullptr;
+  int64_t n = 0;
+  int rc = plan_lookup(p, which, &src, &n);
+  if (rc != MRGCN_OK) return rc;
+  MRGCN_REQUIRE(capacity_bytes >= n * 4, "destination too small");
+  if (n > 0) MRGCN_HIP_TRY(hipMemcpy(h_dst, src, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return MRGCN_OK;
+}
+
+int mrgcn_event_create(void **event) {
+  MRGCN_REQUIRE(event, "NULL");
+  hipEvent_t e;
+  MRGCN_HIP_TRY(hipEventCreate(&e));
+  *event = (void *)e;
+  return MRGCN_OK;
+}
+int mrgcn_event_destroy(void *event) {
+  if (event) MRGCN_HIP_TRY(hipEventDestroy((hipEvent_t)event));
+  return MRGCN_OK;
+}
+int mrgcn_event_record(void *event, void *stream) {
+  MRGCN_HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return MRGCN_OK;
+}
+int mrgcn_event_elapsed_ms(void *start, void *stop, float *h_ms) {
+  MRGCN_REQUIRE(h_ms, "NULL");
+  MRGCN_HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+  MRGCN_HIP_TRY(hipEventElapsedTime(h_ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return MRGCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+"""autograd wiring of the HIP kernels.  Every op here calls the C ABI; none has a PyTorch
+or CPU fallback."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .plan import GraphPlan
+
+
+class _SpmmLiteral(torch.autograd.Function):
+    """Y = A . D with D the dense (R*N) x F operand in the reference's row order
+    (mrgcn/layers/graph.py:75, :95).  Backward = A^T dY scattered into a dense
+    (R*N) x F gradient, as SparseAddmmBackward produces for the reference."""
+
+    @staticmethod
+    def forward(ctx, plan: GraphPlan, D: torch.Tensor, bias, relu: bool):
+        D = D.contiguous()
+        Y = plan.spmm(L.VIEW_LITERAL, D, bias=bias, relu=relu)
+        ctx.plan, ctx.relu, ctx.has_bias = plan, relu, bias is not None
+        ctx.d_rows = D.shape[0]
+        ctx.save_for_backward(Y if relu else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        plan = ctx.plan
+        dY = dY.contiguous()
+        (Y,) = ctx.saved_tensors
+        if ctx.relu:
+            dY = dY * (Y > 0)
+        dbias = dY.sum(0) if ctx.has_bias else None
+        dD = None
+        if ctx.needs_input_grad[1]:
+            F = dY.shape[1]
+            dD = torch.zeros((ctx.d_rows, F), dtype=torch.float32, device=dY.device)
+            ulcol_ptr, _ = plan.array_ptr(L.ARR_ULCOL)
+            plan.spmm(L.VIEW_TRANSPOSED, dY, out=dD, out_index=ulcol_ptr)
+        return None, dD, dbias, None
+
+
+def spmm_literal(plan: GraphPlan, D: torch.Tensor, bias=None, relu: bool = False) -> torch.Tensor:
+    return _SpmmLiteral.apply(plan, D, bias, relu)
+
+
+class _SpmmCompact(torch.autograd.Function):
+    """Y = A' . M with M holding one row per *touched* column, in the plan's (source node,
+    relation) order; M may be padded (leading dimension >= F)."""
+
+    @staticmethod
+    def forward(ctx, plan: GraphPlan, M: torch.Tensor, F: int, bias, relu: bool):
+        Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu)
+        ctx.plan, ctx.relu, ctx.has_bias, ctx.F, ctx.ld = plan, relu, bias is not None, F, M.shape[1]
+        ctx.save_for_backward(Y if relu else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        plan = ctx.plan
+        dY = dY.contiguous()
+        (Y,) = ctx.saved_tensors
+        if ctx.relu:
+            dY = dY * (Y > 0)
+        dbias = dY.sum(0) if ctx.has_bias else None
+        dM = None
+        if ctx.needs_input_grad[1]:
+            if ctx.ld == ctx.F:
+                dM = torch.empty((plan.ncols, ctx.ld), dtype=torch.float32, device=dY.device)
+            else:
+                dM = torch.zeros((plan.ncols, ctx.ld), dtype=torch.float32, device=dY.device)
+            plan.spmm(L.VIEW_TRANSPOSED, dY, F=ctx.F, out=dM)
+        return None, dM, None, dbias, None
+
+
+def spmm_compact(plan: GraphPlan, M: torch.Tensor, F: int, bias=None, relu: bool = False):
+    return _SpmmCompact.apply(plan, M, F, bias, relu)
+
+
+# ======================================================================================
+# fused R-GCN layer
+# ======================================================================================
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ld_for(F: int) -> int:
+    """Leading dimension of the compact operand: rows padded to a multiple of 4 floats so
+    that every gather is 16-byte aligned float4 loads."""
+    return (F + 3) // 4 * 4
+
+
+def relu_bwd(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(dY)
+    with torch.cuda.device(dY.device):
+        L.check(L.load().mrgcn_relu_bwd_f32(dY.data_ptr(), Y.data_ptr(), dY.numel(), out.data_ptr(),
+                                            _stream(dY.device)), "mrgcn_relu_bwd_f32")
+    return out
+
+
+class _RgcnLayer(torch.autograd.Function):
+    """Y = relu?( A' . M + b ),  M[c] = comp_I[r_c] . V_I[:, j_c, :]  (or weight_I[r_c*N + j_c])
+                                       + X[j_c] . W_F[r_c]
+    i.e. graph.py:62-102 without the (R*N) x out intermediates."""
+
+    @staticmethod
+    def forward(ctx, plan: GraphPlan, F: int, weight_I, comp_I, X, W_F, bias, relu: bool):
+        lib = L.load()
+        dev = plan.device
+        ld = _ld_for(F)
+        M = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
+        s = _stream(dev)
+        acc = 0
+        Xc = Wc = None
+        with torch.cuda.device(dev):
+            if weight_I is not None:
+                wI = weight_I.contiguous()
+                if comp_I is not None:
+                    cI = comp_I.contiguous()
+                    L.check(lib.mrgcn_basis_mix_fwd_f32(plan.handle, wI.data_ptr(), cI.data_ptr(),
+                                                        cI.shape[1], F, M.data_ptr(), ld, acc, s),
+                            "mrgcn_basis_mix_fwd_f32")
+                else:
+                    L.check(lib.mrgcn_gather_rows_f32(plan.handle, wI.data_ptr(), F, M.data_ptr(), ld,
+                                                      acc, s), "mrgcn_gather_rows_f32")
+                acc = 1
+            if X is not None:
+                Xc = X.contiguous()
+                Wc = W_F.contiguous()
+                L.check(lib.mrgcn_rel_transform_fwd_f32(plan.handle, Xc.data_ptr(), Xc.stride(0),
+                                                        Xc.shape[1], Wc.data_ptr(), F, M.data_ptr(), ld,
+                                                        acc, s), "mrgcn_rel_transform_fwd_f32")
+        Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu)
+        ctx.plan, ctx.F, ctx.ld, ctx.relu = plan, F, ld, relu
+        ctx.has = (weight_I is not None, comp_I is not None, X is not None, bias is not None)
+        ctx.save_for_backward(weight_I, comp_I, Xc, Wc, Y if relu else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = L.load()
+        plan, F, ld = ctx.plan, ctx.F, ctx.ld
+        weight_I, comp_I, X, W_F, Y = ctx.saved_tensors
+        has_I, has_comp, has_X, has_bias = ctx.has
+        dev = plan.device
+        s = _stream(dev)
+        dY = dY.contiguous()
+        if ctx.relu:
+            dY = relu_bwd(dY, Y)
+        dbias = dY.sum(0) if has_bias else None
+        # dM = A'^T dY over touched columns only
+        dM = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
+        plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)
+        d_wI = d_comp = dX = dW = None
+        with torch.cuda.device(dev):
+            if has_I:
+                if has_comp:
+                    d_wI = torch.empty_like(weight_I)
+                    d_comp = torch.empty_like(comp_I)
+                    L.check(lib.mrgcn_basis_mix_bwd_f32(
+                        plan.handle, dM.data_ptr(), ld, weight_I.data_ptr(), comp_I.data_ptr(),
+                        comp_I.shape[1], F, d_wI.data_ptr(), d_comp.data_ptr(), s),
+                        "mrgcn_basis_mix_bwd_f32")
+                else:
+                    # dense (R*N) x F gradient: zero + scatter of the touched rows
+                    d_wI = torch.zeros_like(weight_I)
+                    d_wI.index_copy_(0, plan.ulcol_long(), dM[:, :F])
+            if has_X:
+                need_dX = ctx.needs_input_grad[4]
+                need_dW = ctx.needs_input_grad[5]
+                K = X.shape[1]
+                if need_dX:
+                    dX = torch.empty((X.shape[0], K), dtype=torch.float32, device=dev)
+                if need_dW:
+                    dW = torch.empty_like(W_F)
+                if need_dX or need_dW:
+                    L.check(lib.mrgcn_rel_transform_bwd_f32(
+                        plan.handle, dM.data_ptr(), ld, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
+                        dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0, s),
+                        "mrgcn_rel_transform_bwd_f32")
+        return None, None, d_wI, d_comp, dX, dW, dbias, None
+
+
+def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False) -> torch.Tensor:
+    """Fused forward of one `GraphConvolution` (graph.py:62-102)."""
+    F = layer.outdim
+    B = layer.num_bases
+    weight_I = comp_I = W_F = None
+    if layer.input_layer:
+        weight_I = layer.weight_I
+        comp_I = layer.weight_I_comp if B > 0 else None
+    Xin = None
+    if not (layer.input_layer and layer.featureless):
+        Xin = X
+        W_F = layer.weight_F
+        if B > 0:  # graph.py:83-85: tiny (R x B) . (B x in*out) contraction -> library GEMM
+            W_F = (layer.weight_F_comp @ W_F.reshape(B, -1)).view(layer.num_relations, layer.indim, F)
+    if weight_I is not None and comp_I is None and Xin is None:
+        # featureless layer without bases: weight_I already *is* the literal operand
+        return spmm_literal(plan, weight_I, bias=layer.b if layer.bias else None, relu=relu)
+    return _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, layer.b if layer.bias else None, relu)

@@ -1,0 +1,136 @@
+"""Top-level model behind the reference's `MRGCN` interface (mrgcn/models/mrgcn.py:26-305):
+same constructor, `module_dict` / `gate_weights` / `gate_map` / `devices` attributes and
+state-dict keys; full-batch forward = gated literal encoders -> concatenation with X0 ->
+R-GCN on the MI355X kernels.
+
+Scope: the R-GCN path and the MLP encoders of the numeric / boolean / temporal
+datatypes.  The pretrained-backbone encoders (strings, images: torch.hub models) and the WKT
+TCNN are not on the accelerated path and are rejected at construction."""
+from __future__ import annotations
+
+import logging
+import warnings
+
+import torch
+import torch.nn as nn
+
+from .perceptron import MLP
+from .rgcn import RGCN
+
+logger = logging.getLogger(__name__)
+
+_MLP_LAYERS = {"xsd.boolean": 1, "xsd.numeric": 1, "xsd.date": 2, "xsd.dateTime": 2, "xsd.gYear": 2}
+_COUNTER_GROUP = {"xsd.boolean": "num", "xsd.numeric": "num", "xsd.date": "temp",
+                  "xsd.dateTime": "temp", "xsd.gYear": "temp"}
+_UNSUPPORTED = ("xsd.string", "xsd.anyURI", "blob.image", "ogc.wktLiteral")
+
+
+def _pick_device(want_gpu: bool):
+    if want_gpu:
+        if torch.cuda.is_available():
+            return torch.device("cuda")
+        warnings.warn("CUDA Resource not available", ResourceWarning)
+    return torch.device("cpu")
+
+
+class MRGCN(nn.Module):
+    def __init__(self, modules, embedding_modules, num_relations, num_nodes, num_bases=-1,
+                 p_dropout=0.0, featureless=False, bias=False, link_prediction=False,
+                 gcn_gpu_acceleration=False, gated=True):
+        super().__init__()
+        assert len(modules) > 0
+
+        self.num_nodes = num_nodes
+        self.p_dropout = p_dropout
+        self.module_dict = nn.ModuleDict()
+        self.devices = dict()
+        self.gate_map = dict()
+        self.modality_modules = dict()
+        self.modality_out_dim = 0
+        self.compute_modality_embeddings = False
+        self.im_norm = None
+
+        counters = {"num": 0, "temp": 0}
+        i_gate = 0
+        for datatype, args, gpu_acceleration in embedding_modules:
+            if datatype in _UNSUPPORTED:
+                raise NotImplementedError(
+                    f"{datatype}: pretrained-backbone / TCNN encoders are outside the accelerated "
+                    "R-GCN path of mrgcn_amd (SURVEY §8 next-2)")
+            if datatype not in _MLP_LAYERS:
+                raise Exception("Datatype not supported: " + datatype)
+            ncols, dim_out, p_drop = args
+            module = MLP(input_dim=ncols, output_dim=dim_out, num_layers=_MLP_LAYERS[datatype],
+                         p_dropout=p_drop)
+            grp = _COUNTER_GROUP[datatype]  # booleans+numerics and the temporal types share counters
+            mod_name = datatype.replace(".", "_") + "_" + str(counters[grp])
+            counters[grp] += 1
+            self.module_dict[mod_name] = module
+            self.modality_modules.setdefault(datatype, []).append((module, -1, dim_out, i_gate))
+            self.modality_out_dim += dim_out
+            self.compute_modality_embeddings = True
+            self.gate_map[mod_name] = i_gate
+            i_gate += 1
+            device = _pick_device(gpu_acceleration)
+            self.devices[datatype] = device
+            module.to(device)
+
+        # gates start at 0.1 so that the encoders' signal is damped at first (mrgcn.py:148-156)
+        self.gate_weights = torch.ones(i_gate)
+        if gated and i_gate > 0:
+            self.gate_weights = nn.Parameter(self.gate_weights * 0.1)
+        else:
+            self.gate_weights.requires_grad = False
+
+        self.rgcn = RGCN(modules, num_relations, num_nodes, num_bases, p_dropout, featureless, bias,
+                         link_prediction)
+        # The R-GCN of this package only computes on the GPU.  With the flag off the module is
+        # still built (state dicts, CPU-side tooling) but moved to the GPU lazily at first use.
+        device = _pick_device(gcn_gpu_acceleration or torch.cuda.is_available())
+        self.devices["relational"] = device
+        self.rgcn.to(device)
+        self.X_device = device
+
+    # ------------------------------------------------------------------------------
+    def forward(self, batch):
+        if type(batch).__name__ == "MiniBatch":
+            raise NotImplementedError("mini-batch forward (mrgcn.py:216-248) is outside the "
+                                      "full-batch path of mrgcn_amd")
+        return self._forward_full_batch(batch)
+
+    def _forward_full_batch(self, batch):
+        X0, F = batch.X[0], batch.X[1:]
+        dev = self.devices["relational"]
+        X = None
+        if self.compute_modality_embeddings:
+            batch_idx = torch.arange(self.num_nodes)
+            XF = self._compute_modality_embeddings(F, batch_idx)
+            X = torch.cat([X0.to(dev), XF], dim=1).float()
+        return self.rgcn(X, batch.A)
+
+    def _compute_modality_embeddings(self, F, batch_idx):
+        """XF[node, off:off+dim] = gate * encoder(encodings[node]) per encoding set
+        (mrgcn.py:250-305)."""
+        dev = self.devices["relational"]
+        X = torch.zeros((len(batch_idx), self.modality_out_dim), dtype=torch.float32, device=dev)
+        offset = 0
+        for datatype, encoding_sets, _ in F:
+            if datatype not in self.modality_modules:
+                continue
+            for i, encoding_set in enumerate(encoding_sets):
+                module, _, out_dim, i_gate = self.modality_modules[datatype][i]
+                gate = self.gate_weights[i_gate]
+                if torch.isclose(gate.detach().cpu(), torch.tensor(0.0)):
+                    offset += out_dim
+                    continue
+                encodings, node_idx, _ = encoding_set
+                keep = torch.isin(node_idx.cpu(), batch_idx)
+                if not bool(keep.any()):
+                    offset += out_dim
+                    continue
+                rows = node_idx.cpu()[keep].to(dev)  # full batch: batch position == node id
+                data = encodings[keep.to(encodings.device)].float()
+                out = module(data).to(dev) * gate.to(dev)
+                X[rows, offset:offset + out_dim] = out
+                offset += out_dim
+        return X

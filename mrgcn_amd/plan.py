@@ -1,0 +1,140 @@
+"""GraphPlan — host-side handle of the device-resident graph plan (built once per
+adjacency).  Input is the reference's own boundary object: the sparse COO tensor that
+`FullBatch.as_tensors_` produces (mrgcn/data/batch.py:144-149; int8 values) or a float32
+COO (the layer is value-generic: mrgcn/layers/graph.py:75 `A.float()`)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class GraphPlan:
+    def __init__(self, A: torch.Tensor, num_nodes: int, num_relations: int,
+                 prune_zeros: bool = False):
+        if not A.is_sparse:
+            raise TypeError("A must be a torch sparse COO tensor")
+        if not A.is_cuda:
+            raise L.MrgcnError("GraphPlan needs A on the GPU (no CPU path exists in mrgcn_amd)")
+        lib = L.load()
+        self.device = A.device
+        idx = A._indices()
+        val = A._values()
+        if val.dtype == torch.int8:
+            vd = L.VAL_I8
+        elif val.dtype == torch.float32:
+            vd = L.VAL_F32
+        else:
+            raise TypeError(f"unsupported adjacency dtype {val.dtype}")
+        rows = idx[0].contiguous()
+        cols = idx[1].contiguous()
+        val = val.contiguous()
+        if rows.dtype != torch.int64:
+            rows, cols = rows.long(), cols.long()
+        self.num_rows = int(A.shape[0])
+        self.num_nodes = int(num_nodes)
+        self.num_relations = int(num_relations)
+        if int(A.shape[1]) != self.num_nodes * self.num_relations:
+            raise ValueError("A.shape[1] != num_relations * num_nodes")
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(lib.mrgcn_plan_create(
+                C.byref(handle), self.num_rows, self.num_nodes, self.num_relations,
+                int(val.numel()), rows.data_ptr(), cols.data_ptr(), val.data_ptr(), vd,
+                L.PLAN_PRUNE_ZEROS if prune_zeros else 0, _stream_ptr(self.device)),
+                "mrgcn_plan_create")
+        self._h = handle
+        info = L.PlanInfo()
+        L.check(lib.mrgcn_plan_info(self._h, C.byref(info)))
+        self.nnz, self.ncols = int(info.nnz), int(info.ncols)
+        self.max_row_nnz, self.max_col_nnz = int(info.max_row_nnz), int(info.max_col_nnz)
+        self.long_rows, self.long_cols = int(info.long_rows), int(info.long_cols)
+        self.device_bytes = int(info.device_bytes)
+        self._ptr_cache = {}
+
+    # -- lifetime -------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.load().mrgcn_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise L.MrgcnError("plan already destroyed")
+        return self._h
+
+    # -- introspection ----------------------------------------------------------------
+    def export(self, which: int) -> np.ndarray:
+        """Copies one plan array to the host (index arrays int32, value arrays float32)."""
+        ptr, n = self.array_ptr(which)
+        out = np.empty(n, dtype=np.float32 if which in L.FLOAT_ARRAYS else np.int32)
+        L.check(L.load().mrgcn_plan_export(self.handle, which, out.ctypes.data, out.nbytes))
+        return out
+
+    def array_ptr(self, which: int):
+        if which not in self._ptr_cache:
+            p, n = C.c_void_p(), C.c_int64()
+            L.check(L.load().mrgcn_plan_array(self.handle, which, C.byref(p), C.byref(n)))
+            self._ptr_cache[which] = (p.value or 0, int(n.value))
+        return self._ptr_cache[which]
+
+    # -- products ---------------------------------------------------------------------
+    def view_rows(self, view: int) -> int:
+        return self.ncols if view == L.VIEW_TRANSPOSED else self.num_rows
+
+    def spmm(self, view: int, D: torch.Tensor, F: int | None = None, out: torch.Tensor | None = None,
+             bias: torch.Tensor | None = None, relu: bool = False, out_index: int = 0,
+             out_rows: int | None = None) -> torch.Tensor:
+        """Y[i, :F] = sum_e val[e] * D[idx[e], :F] over row i of `view` (see mrgcn_spmm_f32).
+        `out_index` is a device pointer (int) to an int32 row redirection table or 0."""
+        assert D.is_cuda and D.dtype == torch.float32 and D.dim() == 2 and D.stride(1) == 1
+        F = int(D.shape[1] if F is None else F)
+        if out is None:
+            rows = self.view_rows(view) if out_rows is None else out_rows
+            out = torch.empty((rows, F), dtype=torch.float32, device=D.device)
+        assert out.dtype == torch.float32 and out.stride(1) == 1 and out.is_cuda
+        if bias is not None:
+            assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() >= F
+        with torch.cuda.device(D.device):
+            L.check(L.load().mrgcn_spmm_f32(
+                self.handle, view, D.data_ptr(), D.stride(0), F, out.data_ptr(), out.stride(0),
+                bias.data_ptr() if bias is not None else 0, 1 if relu else 0, out_index,
+                _stream_ptr(D.device)), "mrgcn_spmm_f32")
+        return out
+
+    def ulcol_long(self) -> torch.Tensor:
+        """int64 device tensor: literal column r*N + j of every compact column."""
+        t = getattr(self, "_ulcol_long", None)
+        if t is None:
+            t = torch.from_numpy(self.export(L.ARR_ULCOL).astype(np.int64)).to(self.device)
+            self._ulcol_long = t
+        return t
+
+    # -- algorithmic traffic ------------------------------------------------
+    def spmm_bytes(self, F: int, value_bytes: int = 4, elem_bytes: int = 4) -> int:
+        """nnz*(4+v) + (rows+1)*4 + ncols*F*e + rows*F*e"""
+        return (self.nnz * (4 + value_bytes) + (self.num_rows + 1) * 4
+                + self.ncols * F * elem_bytes + self.num_rows * F * elem_bytes)
+
+
+def plan_of(A: torch.Tensor, num_nodes: int, num_relations: int) -> GraphPlan:
+    """Returns the plan cached on the adjacency tensor, building it on first use."""
+    p = getattr(A, "_mrgcn_plan", None)
+    if p is None or p._h is None or p.num_nodes != num_nodes or p.num_relations != num_relations:
+        p = GraphPlan(A, num_nodes, num_relations)
+        A._mrgcn_plan = p
+    return p

@@ -1,0 +1,132 @@
+"""Full-batch epoch driver: the MI355X counterpart of the train step of
+mrgcn/tasks/node_classification.py:154-193 —
+
+    Y_hat = model(batch); loss = CE(Y_hat[idx], targets)
+    zero_grad; backward; clip_grad_norm_(params, 1.0); Adam.step
+
+with the loss, the global gradient norm, the clip and Adam running as HIP kernels
+(csrc/optim.hip).  The clip coefficient never leaves the device, so one epoch has no
+host synchronisation."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _SoftmaxXent(torch.autograd.Function):
+    """nn.CrossEntropyLoss()(Y_hat[idx], targets) (node_classification.py:439-444) with the
+    gradient produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, logits, idx, targets):
+        logits = logits.contiguous()
+        N, C = logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        with torch.cuda.device(logits.device):
+            L.check(L.load().mrgcn_softmax_xent_f32(
+                logits.data_ptr(), logits.stride(0), C, idx.data_ptr(), targets.data_ptr(),
+                idx.numel(), loss.data_ptr(), dlogits.data_ptr(), dlogits.stride(0), N,
+                _stream(logits.device)), "mrgcn_softmax_xent_f32")
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None, None
+
+
+def categorical_crossentropy(Y_hat: torch.Tensor, idx: torch.Tensor, targets: torch.Tensor):
+    """`idx`, `targets`: int64 device tensors (the `Y.nonzero()` pair of the reference)."""
+    assert idx.dtype == torch.int64 and targets.dtype == torch.int64
+    return _SoftmaxXent.apply(Y_hat, idx.contiguous(), targets.contiguous())
+
+
+def categorical_accuracy(Y_hat, idx, targets):
+    """node_classification.py:432-437"""
+    labels = Y_hat[idx].argmax(dim=1)
+    return (labels == targets).float().mean(), labels, targets
+
+
+class ClipAdam(torch.optim.Optimizer):
+    """clip_grad_norm_(all params, max_norm) followed by torch.optim.Adam, as two passes of
+    HIP kernels: (1) sum of squares of every gradient into one device double, (2) Adam with
+    the clip coefficient read from device memory.  Same hyper-parameter names / param-group
+    layout as torch.optim.Adam so that `optimizer_params` groups (tasks/utils.py:8-45) work."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 max_norm=1.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.max_norm = max_norm
+        self._scratch = {}
+
+    def _dev_scratch(self, device):
+        s = self._scratch.get(device)
+        if s is None:
+            s = dict(sumsq=torch.zeros((), dtype=torch.float64, device=device),
+                     coef=torch.ones((), dtype=torch.float32, device=device),
+                     norm=torch.zeros((), dtype=torch.float32, device=device))
+            self._scratch[device] = s
+        return s
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        lib = L.load()
+        live = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if not live:
+            return None
+        device = live[0][1].device
+        if not all(p.device == device for _, p in live):
+            raise L.MrgcnError("ClipAdam: all parameters must live on one GPU")
+        sc = self._dev_scratch(device)
+        s = _stream(device)
+        with torch.cuda.device(device):
+            sc["sumsq"].zero_()
+            grads = []
+            for _, p in live:
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                grads.append(g)
+                L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), sc["sumsq"].data_ptr(), s),
+                        "mrgcn_sumsq_accum_f32")
+            use_clip = self.max_norm is not None and self.max_norm > 0
+            if use_clip:
+                L.check(lib.mrgcn_clip_coef_f32(sc["sumsq"].data_ptr(), float(self.max_norm),
+                                                sc["coef"].data_ptr(), sc["norm"].data_ptr(), s),
+                        "mrgcn_clip_coef_f32")
+            for (group, p), g in zip(live, grads):
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                b1, b2 = group["betas"]
+                L.check(lib.mrgcn_adam_step_f32(
+                    p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                    p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                    float(group["weight_decay"]), int(st["step"]),
+                    sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_adam_step_f32")
+        return None
+
+    def last_grad_norm(self) -> float:
+        """Total gradient norm of the last step (synchronises)."""
+        dev = next(iter(self._scratch))
+        return float(self._scratch[dev]["norm"].item())
+
+
+def train_step(model, forward_fn, idx, targets, optimizer):
+    """One full-batch epoch.  `forward_fn()` returns the logits (e.g. `lambda: model(batch)`).
+    Returns the loss as a device scalar (no host sync)."""
+    logits = forward_fn()
+    loss = categorical_crossentropy(logits, idx, targets)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    optimizer.step()
+    return loss.detach()

@@ -1,0 +1,199 @@
+"""GPU parity of the fused kernels, the layer / model mirrors and the epoch step against the
+golden vectors captured from the reference (tests/golden) and against the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+# logits tolerance of BASELINE.json's north_star: 1e-4 (fp32)
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def _adjacency(c, name):
+    g, A = util.load_graph(util.graph_of_case(name))
+    return util.coo_tensor(A, str(c["value_mode"]), "cuda")
+
+
+@pytest.mark.parametrize("engine", ["fused", "literal"])
+@pytest.mark.parametrize("name", util.rgcn_cases())
+def test_rgcn_forward_backward_vs_reference_goldens(name, engine):
+    c = util.load_case(name)
+    model, dims = util.build_rgcn_from_case(c, "cuda")
+    util.load_state_from_case(model, c)
+    model = model.cuda()
+    model.set_engine(engine)
+    A = _adjacency(c, name)
+    fl = bool(c["meta.featureless"])
+    X = None if fl else torch.from_numpy(c["X"]).cuda().requires_grad_(True)
+
+    # per-layer activations
+    with torch.no_grad():
+        H = X
+        for li, (key, layer) in enumerate(model.layers.items()):
+            H = layer(H, A)
+            np.testing.assert_allclose(H.cpu().numpy(), c[f"act.pre_{li}"], err_msg=f"pre_{li}", **TOL)
+            act = model.activations[key]
+            if act is not None:
+                H = act(H)
+
+    logits = model(X, A)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), c["logits"], **TOL)
+    idx = torch.from_numpy(c["labels_idx"]).cuda()
+    tgt = torch.from_numpy(c["labels_y"]).cuda()
+    from mrgcn_amd.train import categorical_crossentropy
+    loss = categorical_crossentropy(logits, idx, tgt)
+    np.testing.assert_allclose(float(loss), float(c["loss"]), rtol=1e-5, atol=1e-5)
+    loss.backward()
+    for n, p in model.named_parameters():
+        if n == "relations":
+            assert p.grad is None
+            continue
+        np.testing.assert_allclose(p.grad.cpu().numpy(), c["grad." + n], rtol=1e-3, atol=1e-5, err_msg=n)
+    if not fl:
+        np.testing.assert_allclose(X.grad.cpu().numpy(), c["grad.X"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", util.rgcn_cases())
+def test_epoch_steps_vs_reference_goldens(name):
+    """zero_grad / backward / clip 1.0 / Adam driven for n_adam epochs
+    (node_classification.py:166-193)."""
+    from mrgcn_amd.train import ClipAdam, train_step
+    c = util.load_case(name)
+    model, dims = util.build_rgcn_from_case(c, "cuda")
+    util.load_state_from_case(model, c)
+    model = model.cuda()
+    A = _adjacency(c, name)
+    fl = bool(c["meta.featureless"])
+    X = None if fl else torch.from_numpy(c["X"]).cuda()
+    idx = torch.from_numpy(c["labels_idx"]).cuda()
+    tgt = torch.from_numpy(c["labels_y"]).cuda()
+    opt = ClipAdam([p for n, p in model.named_parameters()], lr=0.01, weight_decay=0.0, max_norm=1.0)
+    n_adam = int(c["meta.n_adam"])
+    for step in range(1, n_adam + 1):
+        loss = train_step(model, lambda: model(X, A), idx, tgt, opt)
+        np.testing.assert_allclose(float(loss), float(c[f"loss_step{step}"]), rtol=2e-4, atol=2e-5)
+        if step == 1:
+            np.testing.assert_allclose(opt.last_grad_norm(), float(c["grad_norm"]), rtol=1e-4)
+        if step in (1, n_adam):
+            sd = model.state_dict()
+            for k in c.files:
+                if k.startswith(f"adam{step}."):
+                    key = k[len(f"adam{step}."):]
+                    diff = np.abs(sd[key].cpu().numpy() - c[k])
+                    # Adam's first steps move every element by ~lr*sign(g): elements whose fp32
+                    # gradient is at rounding-noise level may differ by up to 2*lr per step
+                    assert (diff > 2e-5).mean() < 2e-3, (k, float((diff > 2e-5).mean()))
+                    assert diff.max() <= 0.021 * step, k
+
+
+@pytest.mark.parametrize("name", ["mrgcn_small_featureless_b0", "mrgcn_small_featureless_b3",
+                                  "mrgcn_small_encoders_b3"])
+def test_mrgcn_through_fullbatch_boundary(name):
+    """MRGCN(FullBatch) with the reference's int8 boundary cast: logits, loss, accuracy, grads
+    and three optimizer steps."""
+    import scipy.sparse as sp
+    from mrgcn_amd.data.batch import FullBatch
+    from mrgcn_amd.models.mrgcn import MRGCN
+    from mrgcn_amd.train import ClipAdam, categorical_accuracy, categorical_crossentropy
+    c = util.load_case(name)
+    g, A = util.load_graph("graph_small")
+    N, R = int(c["meta.num_nodes"]), int(c["meta.R"])
+    enc = bool(c["meta.with_encoders"])
+    X = [np.empty((N, 0), dtype=float)]
+    modules_config = []
+    if enc:
+        ia, ib = c["enc.numeric_idx"], c["enc.boolean_idx"]
+        X.append(["xsd.numeric", [[c["enc.numeric"], ia, np.ones(len(ia), dtype=int)]], False])
+        X.append(["xsd.boolean", [[c["enc.boolean"], ib, np.ones(len(ib), dtype=int)]], False])
+        modules_config = sorted([("xsd.numeric", (4, 4, 0.0), False), ("xsd.boolean", (1, 2, 0.0), False)],
+                                key=lambda t: t[0])
+    xw = 6 if enc else 0
+    modules = [(xw, int(c["meta.hidden"]), "mrgcn", torch.nn.ReLU()),
+               (int(c["meta.hidden"]), int(c["meta.num_classes"]), "mrgcn", None)]
+    model = MRGCN(modules, modules_config, R, N, num_bases=int(c["meta.num_bases"]), p_dropout=0.0,
+                  featureless=not enc, bias=False, gcn_gpu_acceleration=True)
+    model.load_state_dict({k[5:]: torch.from_numpy(np.array(c[k])) for k in c.files if k.startswith("init.")})
+    assert model.devices["relational"].type == "cuda"
+    batch = FullBatch(A, X, np.arange(N))
+    batch.pad_(); batch.to_dense_(); batch.as_tensors_(); batch.to(model.devices)
+    assert batch.A.is_cuda and batch.A.dtype == torch.int8
+
+    idx = torch.from_numpy(c["labels_idx"]).cuda()
+    tgt = torch.from_numpy(c["labels_y"]).cuda()
+    opt = ClipAdam(list(model.parameters()), lr=0.01, max_norm=1.0)
+    for step in (1, 2, 3):
+        Y_hat = model(batch)
+        loss = categorical_crossentropy(Y_hat, idx, tgt)
+        opt.zero_grad()
+        loss.backward()
+        if step == 1:
+            np.testing.assert_allclose(Y_hat.detach().cpu().numpy(), c["logits"], **TOL)
+            np.testing.assert_allclose(float(loss), float(c["loss"]), rtol=1e-5, atol=1e-5)
+            acc = categorical_accuracy(Y_hat.detach(), idx, tgt)[0]
+            np.testing.assert_allclose(float(acc), float(c["accuracy"]), atol=1e-6)
+            for n, p in model.named_parameters():
+                np.testing.assert_allclose(p.grad.cpu().numpy(), c["grad." + n], rtol=1e-3, atol=1e-5,
+                                           err_msg=n)
+        opt.step()
+        sd = model.state_dict()
+        for k in c.files:
+            if k.startswith(f"adam{step}."):
+                diff = np.abs(sd[k[len(f"adam{step}."):]].cpu().numpy() - c[k])
+                assert (diff > 2e-5).mean() < 5e-3 and diff.max() <= 0.021 * step, k
+
+
+def _oracle_layer_case(rng, N, R, B, K, F, nnz, hub):
+    """Random layer problem + float64 oracle results for the fused kernels."""
+    import scipy.sparse as sp
+    from oracle import rgcn_oracle as O
+    RN = R * N
+    rows = rng.integers(0, N, nnz); cols = rng.integers(0, RN, nnz)
+    if hub:
+        rows = np.concatenate([rows, np.full(hub, 3)]); cols = np.concatenate([cols, rng.choice(RN, hub, replace=False)])
+        rows = np.concatenate([rows, rng.choice(N, min(hub, N), replace=False)]); cols = np.concatenate([cols, np.full(min(hub, N), 7)])
+    ident = np.arange(N)
+    rows = np.concatenate([rows, ident]); cols = np.concatenate([cols, (R - 1) * N + ident])
+    key = np.unique(rows.astype(np.int64) * RN + cols)
+    rows, cols = key // RN, key % RN
+    vals = rng.uniform(0.1, 1.0, len(rows)).astype(np.float32)
+    A = sp.csr_matrix((vals.astype(np.float64), (rows, cols)), shape=(N, RN))
+    return rows, cols, vals, A
+
+
+@pytest.mark.parametrize("N,R,B,K,F,hub", [(300, 5, 3, 7, 6, 0), (1500, 9, 40, 155, 10, 600),
+                                           (700, 4, 2, 10, 11, 300), (500, 6, 70, 3, 16, 0),
+                                           (400, 3, 5, 200, 33, 0)])
+def test_fused_layer_vs_oracle(N, R, B, K, F, hub):
+    """Input layer with bases + features, bias and ReLU: forward, every gradient."""
+    import scipy.sparse as sp
+    from oracle import rgcn_oracle as O
+    from mrgcn_amd.layers.graph import GraphConvolution
+    from mrgcn_amd.plan import plan_of
+    rng = np.random.default_rng(N + R + B)
+    rows, cols, vals, A = _oracle_layer_case(rng, N, R, B, K, F, 6 * N, hub)
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals),
+                                 (N, R * N)).cuda()
+    torch.manual_seed(N)
+    layer = GraphConvolution(K, F, R, N, num_bases=B, bias=True, input_layer=True, featureless=False).cuda()
+    with torch.no_grad():
+        layer.b.copy_(torch.randn(F) * 0.1)
+    X = torch.randn(N, K, device="cuda", requires_grad=True)
+    plan = plan_of(At, N, R)
+    Y = layer._forward_fused(X, plan, relu=True)
+    w = torch.randn_like(Y)
+    (Y * w).sum().backward()
+
+    cfg = O.LayerCfg(K, F, R, N, B, bias=True, input_layer=True, featureless=False)
+    p = {k: v.detach().cpu().numpy() for k, v in layer.named_parameters()}
+    pre, cache = O.layer_forward(cfg, p, X.detach().cpu().numpy(), A)
+    np.testing.assert_allclose(Y.detach().cpu().numpy(), np.maximum(pre, 0), rtol=1e-4, atol=1e-4)
+    dPre = w.cpu().numpy().astype(np.float64) * (pre > 0)
+    grads, dX = O.layer_backward(cfg, p, X.detach().cpu().numpy(), A, dPre, cache)
+    scale = {k: np.abs(v).max() + 1e-12 for k, v in grads.items()}
+    for k, v in grads.items():
+        got = getattr(layer, k).grad.cpu().numpy()
+        np.testing.assert_allclose(got, v, rtol=2e-4, atol=2e-5 * scale[k] + 1e-6, err_msg=k)
+    np.testing.assert_allclose(X.grad.cpu().numpy(), dX, rtol=2e-4, atol=1e-5 * np.abs(dX).max())

@@ -1,0 +1,163 @@
+"""GPU parity of the graph plan (indices bit-exact) and of the stacked-CSR sparse x dense
+product through the C ABI, against the numpy plan reference / scipy (the oracle)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+ARRAYS = ["rowptr", "lcol", "ccol", "val", "cptr", "crow", "cval", "urel", "unode", "nptr",
+          "rowidx", "ulcol", "rperm", "relptr"]
+
+
+def _plan_from_coo(rows, cols, vals, num_rows, N, R, prune=False):
+    from mrgcn_amd.plan import GraphPlan
+    idx = torch.from_numpy(np.stack([rows, cols]).astype(np.int64))
+    v = torch.from_numpy(np.asarray(vals))
+    A = torch.sparse_coo_tensor(idx, v, (num_rows, R * N)).cuda()
+    return GraphPlan(A, N, R, prune_zeros=prune)
+
+
+def _check_plan(plan, ref):
+    from mrgcn_amd import _lib as L
+    assert plan.nnz == ref["nnz"] and plan.ncols == ref["ncols"]
+    for i, name in enumerate(ARRAYS):
+        got = plan.export(getattr(L, "ARR_" + name.upper()))
+        np.testing.assert_array_equal(got, ref[name], err_msg=name)
+
+
+def _random_graph(rng, num_rows, N, R, nnz, hub_rows=0, hub_len=0, hub_cols=0):
+    RN = R * N
+    rows = rng.integers(0, num_rows, nnz)
+    cols = rng.integers(0, RN, nnz)
+    if hub_rows:
+        hr = rng.choice(num_rows, hub_rows, replace=False)
+        rows = np.concatenate([rows] + [np.full(hub_len, h) for h in hr])
+        cols = np.concatenate([cols] + [rng.choice(RN, hub_len, replace=False) for _ in hr])
+    if hub_cols:
+        hc = rng.choice(RN, hub_cols, replace=False)
+        rows = np.concatenate([rows] + [rng.choice(num_rows, min(hub_len, num_rows), replace=False) for _ in hc])
+        cols = np.concatenate([cols] + [np.full(min(hub_len, num_rows), c) for c in hc])
+    key = np.unique(rows.astype(np.int64) * RN + cols)
+    rows, cols = key // RN, key % RN
+    perm = rng.permutation(len(key))  # uncoalesced, unordered COO as input
+    rows, cols = rows[perm], cols[perm]
+    vals = rng.standard_normal(len(rows)).astype(np.float32)
+    return rows, cols, vals
+
+
+@pytest.mark.parametrize("gname,mode", [("graph_small", "ref_int8"), ("graph_small", "norm_f32"),
+                                        ("graph_smoke", "ref_int8"), ("graph_smoke", "norm_f32")])
+def test_plan_indices_bit_exact_on_golden_graphs(gname, mode):
+    from mrgcn_amd.plan import GraphPlan
+    g, A = util.load_graph(gname)
+    N, R = int(g["num_nodes"]), 2 * int(g["num_pred"]) + 1
+    t = util.coo_tensor(A, mode, "cuda")
+    plan = GraphPlan(t, N, R)
+    idx = g["coo_indices"]
+    vals = g["coo_values_i8"] if mode == "ref_int8" else A.data
+    _check_plan(plan, util.numpy_plan(idx[0], idx[1], vals, N, N, R))
+    # pruning the zeros the int8 cast produced
+    plan2 = GraphPlan(t, N, R, prune_zeros=True)
+    _check_plan(plan2, util.numpy_plan(idx[0], idx[1], vals, N, N, R, prune=True))
+    if mode == "ref_int8":
+        assert plan2.nnz == int((g["coo_values_i8"] != 0).sum())
+
+
+def test_plan_on_skewed_random_graph_and_errors():
+    from mrgcn_amd._lib import MrgcnError
+    rng = np.random.default_rng(5)
+    N, R, num_rows = 3000, 7, 3000
+    rows, cols, vals = _random_graph(rng, num_rows, N, R, 40000, hub_rows=3, hub_len=2500, hub_cols=3)
+    plan = _plan_from_coo(rows, cols, vals, num_rows, N, R)
+    _check_plan(plan, util.numpy_plan(rows, cols, vals, num_rows, N, R))
+    assert plan.long_rows >= 3 and plan.long_cols >= 3 and plan.max_row_nnz >= 2500
+    # ragged: empty graph, rectangular slice, out-of-range index
+    empty = _plan_from_coo(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32), 10, 10, 3)
+    assert empty.nnz == 0 and empty.ncols == 0
+    rect = _plan_from_coo(rows[rows < 100], cols[rows < 100], vals[rows < 100], 100, N, R)
+    _check_plan(rect, util.numpy_plan(rows[rows < 100], cols[rows < 100], vals[rows < 100], 100, N, R))
+    with pytest.raises(MrgcnError):
+        _plan_from_coo(np.array([0, 11]), np.array([0, 1]), np.ones(2, np.float32), 10, 10, 3)
+    with pytest.raises(MrgcnError):
+        _plan_from_coo(np.array([0, 1]), np.array([0, 30]), np.ones(2, np.float32), 10, 10, 3)
+
+
+FEATS = [1, 2, 3, 4, 5, 8, 10, 11, 12, 16, 17, 31, 64, 200, 300]
+
+
+@pytest.fixture(scope="module")
+def skewed():
+    rng = np.random.default_rng(11)
+    N, R, num_rows = 2000, 5, 2000
+    rows, cols, vals = _random_graph(rng, num_rows, N, R, 30000, hub_rows=2, hub_len=1700, hub_cols=2)
+    plan = _plan_from_coo(rows, cols, vals, num_rows, N, R)
+    A = sp.csr_matrix((vals.astype(np.float64), (rows, cols)), shape=(num_rows, R * N))
+    return plan, A, util.numpy_plan(rows, cols, vals, num_rows, N, R), rng
+
+
+@pytest.mark.parametrize("F", FEATS)
+def test_spmm_literal_compact_transposed(skewed, F):
+    """Tolerance: fp32 products accumulated in a different order than scipy's float64:
+    |err| <= 1e-4 * (1 + |ref|) with rows of up to ~1700 terms."""
+    from mrgcn_amd import _lib as L
+    plan, A, ref, rng = skewed
+    RN = A.shape[1]
+    D = rng.standard_normal((RN, F)).astype(np.float32)
+    Dg = torch.from_numpy(D).cuda()
+    Y_ref = A @ D.astype(np.float64)
+    Y = plan.spmm(L.VIEW_LITERAL, Dg).cpu().numpy()
+    np.testing.assert_allclose(Y, Y_ref, rtol=1e-4, atol=1e-4)
+    # compact operand with padded leading dimension
+    for ld in sorted({F, (F + 3) // 4 * 4, F + 5}):
+        M = np.zeros((plan.ncols, ld), dtype=np.float32)
+        M[:, :F] = D[ref["ulcol"]]
+        M[:, F:] = 1e30  # padding must never leak into the result
+        Yc = plan.spmm(L.VIEW_COMPACT, torch.from_numpy(M).cuda(), F=F).cpu().numpy()
+        np.testing.assert_allclose(Yc, Y_ref, rtol=1e-4, atol=1e-4)
+    # bias + ReLU epilogue
+    b = rng.standard_normal(F).astype(np.float32)
+    Yb = plan.spmm(L.VIEW_LITERAL, Dg, bias=torch.from_numpy(b).cuda(), relu=True).cpu().numpy()
+    np.testing.assert_allclose(Yb, np.maximum(Y_ref + b, 0), rtol=1e-4, atol=1e-4)
+    # transposed product = autograd of the above
+    dY = rng.standard_normal((A.shape[0], F)).astype(np.float32)
+    dM_ref = (A.T @ dY.astype(np.float64))[ref["ulcol"]]
+    dM = plan.spmm(L.VIEW_TRANSPOSED, torch.from_numpy(dY).cuda()).cpu().numpy()
+    np.testing.assert_allclose(dM, dM_ref, rtol=1e-4, atol=1e-4)
+    # scattered into the literal (R*N) x F gradient
+    dD = torch.zeros((RN, F), device="cuda")
+    ptr, _ = plan.array_ptr(L.ARR_ULCOL)
+    plan.spmm(L.VIEW_TRANSPOSED, torch.from_numpy(dY).cuda(), out=dD, out_index=ptr)
+    np.testing.assert_allclose(dD.cpu().numpy(), A.T @ dY.astype(np.float64), rtol=1e-4, atol=1e-4)
+
+
+def test_spmm_is_deterministic_and_linear(skewed):
+    from mrgcn_amd import _lib as L
+    plan, A, ref, rng = skewed
+    D1 = torch.randn((A.shape[1], 10), device="cuda")
+    D2 = torch.randn((A.shape[1], 10), device="cuda")
+    y1 = plan.spmm(L.VIEW_LITERAL, D1)
+    assert torch.equal(y1, plan.spmm(L.VIEW_LITERAL, D1))  # bitwise reproducible (no atomics)
+    y12 = plan.spmm(L.VIEW_LITERAL, D1 + D2)
+    torch.testing.assert_close(y12, y1 + plan.spmm(L.VIEW_LITERAL, D2), rtol=1e-4, atol=1e-4)
+
+
+def test_spmm_autograd_functions(skewed):
+    from mrgcn_amd import functional as Fn
+    plan, A, ref, rng = skewed
+    D = torch.randn((A.shape[1], 6), device="cuda", requires_grad=True)
+    bias = torch.randn(6, device="cuda", requires_grad=True)
+    Y = Fn.spmm_literal(plan, D, bias=bias, relu=True)
+    w = torch.randn_like(Y)
+    (Y * w).sum().backward()
+    At = torch.from_numpy(A.toarray().astype(np.float32)).cuda()
+    D2 = D.detach().clone().requires_grad_(True)
+    b2 = bias.detach().clone().requires_grad_(True)
+    Y2 = torch.relu(At @ D2 + b2)
+    (Y2 * w).sum().backward()
+    torch.testing.assert_close(Y, Y2, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(D.grad, D2.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bias.grad, b2.grad, rtol=1e-4, atol=2e-4)

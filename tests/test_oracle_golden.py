@@ -96,3 +96,36 @@ def test_rgcn_forward_backward_adam(name):
                 assert diff.max() <= 0.021 * step, k
     for step in range(1, n_adam + 1):
         np.testing.assert_allclose(recs[step - 1]["loss"], c[f"loss_step{step}"], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", RGCN_CASES)
+def test_aten_literal_port_matches_reference(name):
+    """The timed CPU baseline (oracle/aten_literal.py) executes the reference's ATen op
+    sequence: on the reference's own inputs it must reproduce logits, loss, gradients and
+    the post-Adam parameters to float32 round-off (same ops, same order)."""
+    import torch
+    from oracle import aten_literal as AL
+    c = np.load(os.path.join(GOLDEN, name + ".npz"))
+    gname = "graph_smoke" if "_smoke_" in name else "graph_small"
+    g, A_csr = load_graph(gname)
+    idx, val = O.csr_to_coo(A_csr, str(c["value_mode"]))
+    N, R, B = int(c["meta.num_nodes"]), int(c["meta.R"]), int(c["meta.num_bases"])
+    fl, lp = bool(c["meta.featureless"]), bool(c["meta.link_prediction"])
+    dims = [tuple(d) for d in c["dims"]]
+    A = AL.coo_tensor(idx[0], idx[1], val, (N, R * N))
+    p = {k[len("init."):]: torch.from_numpy(np.array(c[k])).requires_grad_(True)
+         for k in c.files if k.startswith("init.") and k != "init.relations"}
+    X = None if fl else torch.from_numpy(c["X"])
+    ep = AL.Epoch(p, len(dims), R, N, B, fl, relu_last=lp)
+    it, tt = torch.from_numpy(c["labels_idx"]), torch.from_numpy(c["labels_y"])
+    n_adam = int(c["meta.n_adam"])
+    for step in range(1, n_adam + 1):
+        Y_hat, loss, norm = ep.step(X, A, it, tt)
+        if step == 1:
+            np.testing.assert_allclose(Y_hat.detach().numpy(), c["logits"], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(loss.item(), c["loss"], rtol=1e-6)
+            np.testing.assert_allclose(float(norm), c["grad_norm"], rtol=1e-5)
+        if step in (1, n_adam):
+            for k, v in p.items():
+                diff = np.abs(v.detach().numpy() - c[f"adam{step}.{k}"])
+                assert (diff > 1e-6).mean() < 1e-3 and diff.max() <= 0.021 * step, k

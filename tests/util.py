@@ -1,0 +1,97 @@
+"""Shared helpers for the test-suite (golden loading, numpy plan reference)."""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_graph(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    A = sp.csr_matrix((g["csr_data"], g["csr_indices"], g["csr_indptr"]), shape=tuple(g["shape"]))
+    return g, A
+
+
+def graph_of_case(case_name):
+    return "graph_smoke" if "_smoke_" in case_name else "graph_small"
+
+
+def load_case(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def rgcn_cases():
+    import glob
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "rgcn_*.npz")))
+
+
+def coo_tensor(A_csr, value_mode, device="cpu"):
+    """What FullBatch.as_tensors_ produces (int8) or its float32 sibling."""
+    idx = np.array(A_csr.nonzero())
+    dtype = torch.int8 if value_mode == "ref_int8" else torch.float32
+    t = torch.sparse_coo_tensor(torch.LongTensor(idx), torch.Tensor(A_csr.data), A_csr.shape, dtype=dtype)
+    return t.to(device)
+
+
+def build_rgcn_from_case(c, device, engine="fused"):
+    from mrgcn_amd.models.rgcn import RGCN
+    N, R, B = int(c["meta.num_nodes"]), int(c["meta.R"]), int(c["meta.num_bases"])
+    bias, fl = bool(c["meta.bias"]), bool(c["meta.featureless"])
+    lp = bool(c["meta.link_prediction"])
+    dims = [tuple(int(x) for x in d) for d in c["dims"]]
+    modules = []
+    for li, (i, o) in enumerate(dims):
+        act = torch.nn.ReLU() if (li < len(dims) - 1 or lp) else None
+        modules.append((i, o, "mrgcn", act))
+    torch.manual_seed(int(c["meta.seed"]))
+    model = RGCN(modules, R, N, B, 0.0, fl, bias, lp)
+    return model, dims
+
+
+def load_state_from_case(model, c, prefix="init."):
+    sd = {k[len(prefix):]: torch.from_numpy(np.array(c[k])) for k in c.files if k.startswith(prefix)}
+    model.load_state_dict(sd, strict=True)
+
+
+# ---------------------------------------------------------------------------------------
+# numpy reference of the graph plan (index arrays must match the device plan bit for bit)
+# ---------------------------------------------------------------------------------------
+def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False):
+    rows = np.asarray(rows, dtype=np.int64)
+    cols = np.asarray(cols, dtype=np.int64)
+    v = np.asarray(vals).astype(np.float32)
+    if prune:
+        keep = v != 0
+        rows, cols, v = rows[keep], cols[keep], v[keep]
+    RN = R * N
+    key = rows * RN + cols
+    order = np.argsort(key, kind="stable")
+    key, v = key[order], v[order]
+    rowidx = (key // RN).astype(np.int32)
+    lcol = (key % RN).astype(np.int32)
+    rowptr = np.searchsorted(key, np.arange(num_rows + 1, dtype=np.int64) * RN).astype(np.int32)
+    rel, node = lcol // N, lcol % N
+    key2 = node.astype(np.int64) * R + rel
+    order2 = np.argsort(key2, kind="stable")
+    key2s = key2[order2]
+    head = np.ones(len(key2s), dtype=bool)
+    head[1:] = key2s[1:] != key2s[:-1]
+    cid = np.cumsum(head) - 1
+    ncols = int(cid[-1] + 1) if len(cid) else 0
+    ccol = np.empty(len(key), dtype=np.int32)
+    ccol[order2] = cid
+    crow = rowidx[order2]
+    cval = v[order2]
+    cptr = np.concatenate([np.nonzero(head)[0], [len(key)]]).astype(np.int32)
+    uk = key2s[head]
+    unode = (uk // R).astype(np.int32)
+    urel = (uk % R).astype(np.int32)
+    ulcol = (urel.astype(np.int64) * N + unode).astype(np.int32)
+    nptr = np.searchsorted(unode, np.arange(N + 1)).astype(np.int32)
+    rperm = np.argsort(ulcol, kind="stable").astype(np.int32)
+    relptr = np.searchsorted(ulcol[rperm], np.arange(R + 1, dtype=np.int64) * N).astype(np.int32)
+    return dict(rowptr=rowptr, lcol=lcol, ccol=ccol, val=v, rowidx=rowidx, cptr=cptr, crow=crow,
+                cval=cval, urel=urel, unode=unode, ulcol=ulcol, nptr=nptr, rperm=rperm,
+                relptr=relptr, ncols=ncols, nnz=len(key))
