@@ -7,6 +7,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  It must be the one
+# resident in the process before libmrgcn_hip.so is loaded, so that the kernels, torch's
+# allocator and torch's streams share ONE runtime (loading ours first pulls in the system
+# runtime, which then sees no device next to torch's HSA stack).
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmrgcn_hip.so")
 

@@ -71,7 +71,9 @@ class MRGCN(nn.Module):
             self.compute_modality_embeddings = True
             self.gate_map[mod_name] = i_gate
             i_gate += 1
-            device = _pick_device(gpu_acceleration)
+            # MI355X-first: the (tiny) encoders live next to the R-GCN in HBM whenever a GPU is
+            # present; the per-datatype flag only matters on a GPU-less host
+            device = _pick_device(gpu_acceleration or torch.cuda.is_available())
             self.devices[datatype] = device
             module.to(device)
 
@@ -90,6 +92,10 @@ class MRGCN(nn.Module):
         self.devices["relational"] = device
         self.rgcn.to(device)
         self.X_device = device
+        if isinstance(self.gate_weights, nn.Parameter):
+            self.gate_weights.data = self.gate_weights.data.to(device)
+        else:
+            self.gate_weights = self.gate_weights.to(device)
 
     # ------------------------------------------------------------------------------
     def forward(self, batch):
