@@ -47,7 +47,8 @@ enum mrgcn_val_dtype { MRGCN_VAL_I8 = 0, MRGCN_VAL_F32 = 1 };
 /* which sparse view of the plan a product runs on */
 enum mrgcn_view {
   MRGCN_VIEW_LITERAL = 0, /* rows = output nodes, cols = r*N + j (the reference's layout) */
-  MRGCN_VIEW_COMPACT = 1, /* rows = output nodes, cols = rank of (j, r) among touched columns */
+  MRGCN_VIEW_COMPACT = 1, /* rows = output nodes, cols = rows of the compact operand M
+                             (compact column c is stored at row MPOS[c]) */
   MRGCN_VIEW_TRANSPOSED = 2 /* rows = touched columns in (j, r) order, cols = output nodes */
 };
 
@@ -66,7 +67,11 @@ enum mrgcn_plan_array {
   MRGCN_ARR_ROWIDX = 10,  /* [nnz]         output row of each CSR entry                */
   MRGCN_ARR_ULCOL = 11,   /* [ncols]       literal column r*N + j of each compact column */
   MRGCN_ARR_RPERM = 12,   /* [ncols]       compact ids sorted by (relation, node)      */
-  MRGCN_ARR_RELPTR = 13   /* [R+1]         range of each relation inside RPERM         */
+  MRGCN_ARR_RELPTR = 13,  /* [R+1]         range of each relation inside RPERM         */
+  MRGCN_ARR_MPOS = 14,    /* [ncols]       row of the compact operand M that holds column c */
+  MRGCN_ARR_MCOL = 15,    /* [nnz]         operand row per entry of the COMPACT view; a row's
+                                           entries are sorted by it                    */
+  MRGCN_ARR_MVAL = 16     /* [nnz] float   values in MCOL's entry order                */
 };
 
 typedef struct mrgcn_plan mrgcn_plan_t;
@@ -123,7 +128,9 @@ int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const float *D, int64
 
 /* ---- compact dense operand: forward -----------------------------------------------
  * M is [ncols, ldM] row-major with one row per touched column c = (node j_c, relation
- * r_c), in the plan's (j, r) order.  `accumulate` != 0 adds into M instead of storing.
+ * r_c); column c lives at row MPOS[c] (hot columns first, then single-use columns in the
+ * order of the output row that reads them).  `accumulate` != 0 adds into M.
+ * The backward operand dM (output of the TRANSPOSED view) is in plain compact order.
  *
  * basis mix — replaces einsum('rb,bij->rij', weight_I_comp, weight_I.view(B,N,out)) and the
  * view to (R*N, out) of graph.py:69-72, restricted to the rows the product will read:

@@ -47,10 +47,12 @@ struct SparseView {
   // split-row path
   int32_t n_long = 0;                  // long rows
   int32_t n_chunks = 0;                // chunks over all long rows
+  int32_t n_multi = 0;                 // > 0 iff some long row spans several chunks
   const int32_t *long_row = nullptr;   // [n_long]   row id
   const int32_t *long_cptr = nullptr;  // [n_long+1] chunk range of each long row
   const int32_t *chunk_beg = nullptr;  // [n_chunks] first entry
   const int32_t *chunk_end = nullptr;  // [n_chunks] one past last entry
+  const int32_t *chunk_row = nullptr;  // [n_chunks] row id when the row is this single chunk, else -1
 };
 
 }  // namespace mrgcn
@@ -67,14 +69,25 @@ struct mrgcn_plan {
   int32_t *cptr = nullptr, *crow = nullptr, *urel = nullptr, *unode = nullptr, *nptr = nullptr,
           *ulcol = nullptr;
   float *cval = nullptr;
+  // Storage order of the compact dense operand M: row mpos[c] of M holds compact column c.
+  // Hot columns (read by >= 2 output rows) come first, most referenced first, so that the
+  // randomly re-read part of M is small and dense (L2 / Infinity-Cache resident); columns
+  // read exactly once follow in the order of the output row that reads them, so that a
+  // row's private operand rows are contiguous and the forward gather streams them instead of
+  // fetching one 128-B line per 40-B row.
+  int32_t *mpos = nullptr;  // [ncols] compact id -> row of M
+  int32_t *mcol = nullptr;  // [nnz]   operand row of each entry, entries of a row sorted by it
+  float *mval = nullptr;    // [nnz]   values in the same order (the COMPACT view's arrays)
   // relation-major order of the compact columns (for per-relation dense transforms)
   int32_t *rperm = nullptr;   // [ncols] compact ids sorted by (relation, node)
   int32_t *relptr = nullptr;  // [R+1]   range of each relation in rperm
   int32_t *relchunk_rel = nullptr, *relchunk_beg = nullptr, *relchunk_end = nullptr;  // [n_relchunks]
   int32_t n_relchunks = 0;
   // split-row descriptors, one set per orientation
-  int32_t *r_long_row = nullptr, *r_long_cptr = nullptr, *r_chunk_beg = nullptr, *r_chunk_end = nullptr;
-  int32_t *c_long_row = nullptr, *c_long_cptr = nullptr, *c_chunk_beg = nullptr, *c_chunk_end = nullptr;
+  int32_t *r_long_row = nullptr, *r_long_cptr = nullptr, *r_chunk_beg = nullptr, *r_chunk_end = nullptr,
+          *r_chunk_row = nullptr;
+  int32_t *c_long_row = nullptr, *c_long_cptr = nullptr, *c_chunk_beg = nullptr, *c_chunk_end = nullptr,
+          *c_chunk_row = nullptr;
   int32_t r_n_long = 0, r_n_chunks = 0, c_n_long = 0, c_n_chunks = 0;
   float *partials = nullptr;  // [max(r_n_chunks, c_n_chunks) * kWsFeatures]
 
@@ -84,11 +97,14 @@ struct mrgcn_plan {
       v.rows = ncols; v.ptr = cptr; v.idx = crow; v.val = cval;
       v.n_long = c_n_long; v.n_chunks = c_n_chunks; v.long_row = c_long_row;
       v.long_cptr = c_long_cptr; v.chunk_beg = c_chunk_beg; v.chunk_end = c_chunk_end;
+      v.chunk_row = c_chunk_row; v.n_multi = c_n_chunks - c_n_long;
     } else {
-      v.rows = num_rows; v.ptr = rowptr; v.idx = (which == MRGCN_VIEW_LITERAL) ? lcol : ccol;
-      v.val = val;
+      v.rows = num_rows; v.ptr = rowptr;
+      v.idx = (which == MRGCN_VIEW_LITERAL) ? lcol : mcol;
+      v.val = (which == MRGCN_VIEW_LITERAL) ? val : mval;
       v.n_long = r_n_long; v.n_chunks = r_n_chunks; v.long_row = r_long_row;
       v.long_cptr = r_long_cptr; v.chunk_beg = r_chunk_beg; v.chunk_end = r_chunk_end;
+      v.chunk_row = r_chunk_row; v.n_multi = r_n_chunks - r_n_long;
     }
     return v;
   }

@@ -120,6 +120,46 @@ __global__ void k_node_ptr(const int32_t *__restrict__ keys, int64_t count, int6
   ptr[i] = (int32_t)lo;
 }
 
+// storage order of the compact operand M (see common.hpp: mpos): hot columns (>= 2 entries)
+// first, most referenced first; then the single-entry columns in the order of the one output
+// row that reads them.  key = [cold:1][hot: max_count - count | cold: row][compact id]
+__global__ void k_mpos_keys(const int32_t *__restrict__ cptr, const int32_t *__restrict__ crow,
+                            int64_t ncols, int64_t max_count, int shift, int64_t *__restrict__ keys,
+                            int32_t *__restrict__ ids) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  const int32_t b = cptr[c], e = cptr[c + 1];
+  const int64_t cnt = e - b;
+  int64_t hi;
+  if (cnt >= 2) hi = max_count - cnt;                       // in [0, max_count)
+  else hi = max_count + 1 + (int64_t)crow[b];               // after every hot column
+  keys[c] = (hi << shift) | c;
+  ids[c] = (int32_t)c;
+}
+
+__global__ void k_row_pos_keys(const int32_t *__restrict__ rowidx, const int32_t *__restrict__ pos,
+                               int64_t nnz, int64_t ncols, int64_t *__restrict__ keys) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nnz) keys[e] = (int64_t)rowidx[e] * ncols + pos[e];
+}
+
+__global__ void k_keys_to_pos(const int64_t *__restrict__ keys, int64_t nnz, int64_t ncols,
+                              int32_t *__restrict__ pos) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nnz) pos[e] = (int32_t)(keys[e] % ncols);
+}
+
+__global__ void k_invert_perm(const int32_t *__restrict__ order, int64_t n, int32_t *__restrict__ pos) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos[order[i]] = (int32_t)i;
+}
+
+__global__ void k_gather_i32(const int32_t *__restrict__ table, const int32_t *__restrict__ idx,
+                             int64_t n, int32_t *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = table[idx[i]];
+}
+
 __global__ void k_iota(int32_t *__restrict__ a, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = (int32_t)i;
@@ -142,7 +182,7 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
                             const int32_t *__restrict__ is_long, const int32_t *__restrict__ long_pos,
                             const int32_t *__restrict__ chunk_pos, int32_t *__restrict__ long_row,
                             int32_t *__restrict__ long_cptr, int32_t *__restrict__ chunk_beg,
-                            int32_t *__restrict__ chunk_end) {
+                            int32_t *__restrict__ chunk_end, int32_t *__restrict__ chunk_row) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows || !is_long[i]) return;
   int32_t li = long_pos[i], c0 = chunk_pos[i];
@@ -152,6 +192,7 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
   for (int32_t s = b, c = c0; s < e; s += chunk, ++c) {
     chunk_beg[c] = s;
     chunk_end[c] = min(s + chunk, e);
+    chunk_row[c] = (e - b <= chunk) ? (int32_t)i : -1;
   }
 }
 
@@ -183,7 +224,8 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, hipStream_t s
 
 // builds the split-row descriptors of one orientation
 int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, int32_t **long_row,
-               int32_t **long_cptr, int32_t **chunk_beg, int32_t **chunk_end, int32_t *n_long,
+               int32_t **long_cptr, int32_t **chunk_beg, int32_t **chunk_end, int32_t **chunk_row,
+               int32_t *n_long,
                int32_t *n_chunks, int64_t *max_len) {
   Scratch sc;
   int32_t *is_long, *nchunk, *long_pos, *chunk_pos, *d_max;
@@ -213,10 +255,11 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(plan_alloc(p, long_cptr, h[0] + 1));
   MRGCN_HIP_TRY(plan_alloc(p, chunk_beg, h[1]));
   MRGCN_HIP_TRY(plan_alloc(p, chunk_end, h[1]));
+  MRGCN_HIP_TRY(plan_alloc(p, chunk_row, h[1]));
   MRGCN_HIP_TRY(hipMemcpyAsync(*long_cptr + h[0], &h[1], sizeof(int32_t), hipMemcpyHostToDevice, s));
   if (rows > 0 && h[0] > 0)
     k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, kChunk, is_long, long_pos, chunk_pos,
-                                              *long_row, *long_cptr, *chunk_beg, *chunk_end);
+                                              *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row);
   MRGCN_HIP_TRY(hipGetLastError());
   MRGCN_HIP_TRY(hipStreamSynchronize(s));
   return MRGCN_OK;
@@ -380,11 +423,62 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   MRGCN_HIP_TRY(hipStreamSynchronize(s));
 
   int rc;
-  if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r_long_row, &p->r_long_cptr, &p->r_chunk_beg,
-                       &p->r_chunk_end, &p->r_n_long, &p->r_n_chunks, &p->max_row_nnz)))
-    return rc;
   if ((rc = build_long(p, p->cptr, p->ncols, s, &p->c_long_row, &p->c_long_cptr, &p->c_chunk_beg,
-                       &p->c_chunk_end, &p->c_n_long, &p->c_n_chunks, &p->max_col_nnz)))
+                       &p->c_chunk_end, &p->c_chunk_row, &p->c_n_long, &p->c_n_chunks, &p->max_col_nnz)))
+    return rc;
+  // storage order of M
+  MRGCN_HIP_TRY(plan_alloc(p, &p->mpos, ncols));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->mcol, nnz));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->mval, nnz));
+  if (ncols > 0) {
+    int64_t *mk, *mk_s;
+    int32_t *ids, *order;
+    MRGCN_HIP_TRY(sc.alloc(&mk, ncols));
+    MRGCN_HIP_TRY(sc.alloc(&mk_s, ncols));
+    MRGCN_HIP_TRY(sc.alloc(&ids, ncols));
+    MRGCN_HIP_TRY(sc.alloc(&order, ncols));
+    const int shift = bits_for(ncols);
+    const int64_t max_count = p->max_col_nnz + 1;
+    k_mpos_keys<<<nblocks(ncols), kTB, 0, s>>>(p->cptr, p->crow, ncols, max_count, shift, mk, ids);
+    MRGCN_HIP_TRY(hipGetLastError());
+    const int end_bit = shift + bits_for(max_count + 1 + p->num_rows);
+    MRGCN_REQUIRE(end_bit <= 62, "graph too large for the operand-order key");
+    size_t tb = 0;
+    MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, mk, mk_s, ids, order, (int)ncols, 0,
+                                                     end_bit, s));
+    char *tmp;
+    MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
+    MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, mk, mk_s, ids, order, (int)ncols, 0,
+                                                     end_bit, s));
+    k_invert_perm<<<nblocks(ncols), kTB, 0, s>>>(order, ncols, p->mpos);
+    MRGCN_HIP_TRY(hipGetLastError());
+    // the COMPACT view walks a row's entries in rising operand position (its private, single-use
+    // operand rows are then one sequential run): own index + value arrays in that order
+    int32_t *mcol_u;
+    int64_t *rk, *rk_s;
+    MRGCN_HIP_TRY(sc.alloc(&mcol_u, nnz));
+    MRGCN_HIP_TRY(sc.alloc(&rk, nnz));
+    MRGCN_HIP_TRY(sc.alloc(&rk_s, nnz));
+    k_gather_i32<<<nblocks(nnz), kTB, 0, s>>>(p->mpos, p->ccol, nnz, mcol_u);
+    MRGCN_HIP_TRY(hipGetLastError());
+    k_row_pos_keys<<<nblocks(nnz), kTB, 0, s>>>(p->rowidx, mcol_u, nnz, ncols, rk);
+    MRGCN_HIP_TRY(hipGetLastError());
+    {
+      const int eb = bits_for(p->num_rows * ncols + ncols);
+      size_t tb2 = 0;
+      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, rk, rk_s, p->val, p->mval, (int)nnz,
+                                                       0, eb, s));
+      char *tmp2;
+      MRGCN_HIP_TRY(sc.alloc(&tmp2, (int64_t)tb2));
+      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp2, tb2, rk, rk_s, p->val, p->mval, (int)nnz, 0,
+                                                       eb, s));
+    }
+    k_keys_to_pos<<<nblocks(nnz), kTB, 0, s>>>(rk_s, nnz, ncols, p->mcol);
+    MRGCN_HIP_TRY(hipGetLastError());
+    MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  }
+  if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r_long_row, &p->r_long_cptr, &p->r_chunk_beg,
+                       &p->r_chunk_end, &p->r_chunk_row, &p->r_n_long, &p->r_n_chunks, &p->max_row_nnz)))
     return rc;
   int64_t ws = (int64_t)std::max(p->r_n_chunks, p->c_n_chunks) * kWsFeatures;
   MRGCN_HIP_TRY(plan_alloc(p, &p->partials, ws));
@@ -393,9 +487,10 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
 
 void free_plan(mrgcn_plan *p) {
   void *ptrs[] = {p->rowptr, p->lcol, p->ccol, p->rowidx, p->val, p->cptr, p->crow, p->urel, p->unode,
-                  p->nptr, p->ulcol, p->rperm, p->relptr, p->relchunk_rel, p->relchunk_beg, p->relchunk_end,
+                  p->nptr, p->ulcol, p->mpos, p->mcol, p->mval, p->rperm, p->relptr, p->relchunk_rel, p->relchunk_beg, p->relchunk_end,
                   p->cval, p->r_long_row, p->r_long_cptr, p->r_chunk_beg, p->r_chunk_end,
-                  p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->partials};
+                  p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->r_chunk_row, p->c_chunk_row,
+                  p->partials};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
@@ -474,6 +569,9 @@ static int plan_lookup(const mrgcn_plan_t *p, int32_t which, const void **out, i
     case MRGCN_ARR_ULCOL: src = p->ulcol; n = p->ncols; break;
     case MRGCN_ARR_RPERM: src = p->rperm; n = p->ncols; break;
     case MRGCN_ARR_RELPTR: src = p->relptr; n = p->num_relations + 1; break;
+    case MRGCN_ARR_MPOS: src = p->mpos; n = p->ncols; break;
+    case MRGCN_ARR_MCOL: src = p->mcol; n = p->nnz; break;
+    case MRGCN_ARR_MVAL: src = p->mval; n = p->nnz; break;
     default: MRGCN_REQUIRE(false, "unknown plan array");
   }
   *out = src;

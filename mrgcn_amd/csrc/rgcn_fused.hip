@@ -24,6 +24,7 @@ constexpr int kTB = 256;
 template <int BT>
 __global__ __launch_bounds__(kTB) void k_mix_fwd(const int32_t *__restrict__ nptr,
                                                  const int32_t *__restrict__ urel,
+                                                 const int32_t *__restrict__ mpos,
                                                  const float *__restrict__ V,
                                                  const float *__restrict__ comp, int64_t N, int R,
                                                  int B, int b0, int F, float *__restrict__ M,
@@ -61,69 +62,102 @@ __global__ __launch_bounds__(kTB) void k_mix_fwd(const int32_t *__restrict__ npt
         for (int b = 0; b < BT; ++b)
           if (b < nb) s = fmaf(cr[b], v[b], s);
       }
-      float *m = M + (int64_t)c * ldM + o;
+      float *m = M + (int64_t)mpos[c] * ldM + o;
       *m = accumulate ? (*m + s) : s;
     }
   }
 }
 
 // =====================================================================================
-// basis mix, backward.  thread = (node j, basis b), j fastest across lanes:
-//   dV[b, j, :]  = sum_{c in node j} comp[r_c, b] * dM[c, :]        (registers, no atomics)
-//   dcomp[r, b] += sum_{c in node j, r_c = r} <dM[c, :], V[b, j, :]>  (LDS atomics per block,
-//                                                                     one global flush)
+// basis mix, backward — two passes, both free of per-node dependent load chains:
+//
+//   k_mix_bwd_dv    thread = (node j, feature o), accumulators over the bases in registers:
+//                     dV[b, j, o] = sum_{c in node j} comp[r_c, b] * dM[c, o]
+//                   (mirror of the forward: for a fixed b a wave writes 256 contiguous bytes)
+//   k_mix_bwd_dcomp thread = compact column c (lanes = consecutive columns: coalesced index
+//                   and dM reads, no divergence however skewed the node degrees are):
+//                     dcomp[r_c, b] += <dM[c, :], V[b, j_c, :]>      for every b
+//                   accumulated with LDS float atomics per block, one global flush per block.
 // =====================================================================================
+template <int BT>
+__global__ __launch_bounds__(kTB) void k_mix_bwd_dv(const int32_t *__restrict__ nptr,
+                                                    const int32_t *__restrict__ urel,
+                                                    const float *__restrict__ dM, int64_t ldM,
+                                                    const float *__restrict__ comp, int64_t N, int R,
+                                                    int B, int b0, int F, float *__restrict__ dV,
+                                                    int comp_in_lds) {
+  extern __shared__ float s_comp[];  // [R][BT]
+  const int nb = min(BT, B - b0);
+  if (comp_in_lds) {
+    for (int t = threadIdx.x; t < R * BT; t += blockDim.x) {
+      int r = t / BT, b = t - r * BT;
+      s_comp[t] = (b < nb) ? comp[(int64_t)r * B + b0 + b] : 0.f;
+    }
+    __syncthreads();
+  }
+  const int64_t total = N * F;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = t / F;
+    const int o = (int)(t - j * F);
+    const int32_t c0 = nptr[j], c1 = nptr[j + 1];
+    float acc[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) acc[b] = 0.f;
+    for (int32_t c = c0; c < c1; ++c) {
+      const int r = urel[c];
+      const float d = dM[(int64_t)c * ldM + o];
+      if (comp_in_lds) {
+        const float *cr = s_comp + r * BT;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) acc[b] = fmaf(cr[b], d, acc[b]);
+      } else {
+        const float *cr = comp + (int64_t)r * B + b0;
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+          if (b < nb) acc[b] = fmaf(cr[b], d, acc[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+      if (b < nb) dV[((int64_t)(b0 + b) * N + j) * F + o] = acc[b];
+  }
+}
+
 template <int FT>
-__global__ __launch_bounds__(kTB) void k_mix_bwd(const int32_t *__restrict__ nptr,
-                                                 const int32_t *__restrict__ urel,
-                                                 const float *__restrict__ dM, int64_t ldM,
-                                                 const float *__restrict__ V,
-                                                 const float *__restrict__ comp, int64_t N, int R,
-                                                 int B, int F, float *__restrict__ dV,
-                                                 float *__restrict__ dcomp, int dcomp_in_lds) {
+__global__ __launch_bounds__(kTB) void k_mix_bwd_dcomp(const int32_t *__restrict__ urel,
+                                                       const int32_t *__restrict__ unode,
+                                                       const float *__restrict__ dM, int64_t ldM,
+                                                       const float *__restrict__ V, int64_t N, int R,
+                                                       int B, int F, int64_t ncols,
+                                                       float *__restrict__ dcomp, int dcomp_in_lds) {
   extern __shared__ float s_dcomp[];  // [R][B]
   if (dcomp_in_lds) {
     for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_dcomp[t] = 0.f;
     __syncthreads();
   }
-  const int lane_j = threadIdx.x & 63;  // node within the tile
-  const int bgrp = threadIdx.x >> 6;    // 4 basis groups per block
-  const int64_t tiles = (N + 63) / 64;
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int64_t j = tile * 64 + lane_j;
-    const bool valid = j < N;
-    int32_t c0 = 0, c1 = 0;
-    if (valid) { c0 = nptr[j]; c1 = nptr[j + 1]; }
-    for (int b = bgrp; b < B; b += 4) {
-      if (!valid) continue;
-      float v[FT], g[FT];
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols;
+       c += (int64_t)gridDim.x * blockDim.x) {
+    const int r = urel[c];
+    const int64_t j = unode[c];
+    float dm[FT];
+    const float *dp = dM + c * ldM;
+#pragma unroll
+    for (int o = 0; o < FT; ++o) dm[o] = (o < F) ? dp[o] : 0.f;
+    for (int b = 0; b < B; ++b) {
       const float *vp = V + ((int64_t)b * N + j) * F;
-#pragma unroll
-      for (int o = 0; o < FT; ++o) { v[o] = (o < F) ? vp[o] : 0.f; g[o] = 0.f; }
-      for (int32_t c = c0; c < c1; ++c) {
-        const int r = urel[c];
-        const float w = comp[(int64_t)r * B + b];
-        const float *dm = dM + (int64_t)c * ldM;
-        float dot = 0.f;
-#pragma unroll
-        for (int o = 0; o < FT; ++o) {
-          float d = (o < F) ? dm[o] : 0.f;
-          dot = fmaf(d, v[o], dot);
-          g[o] = fmaf(w, d, g[o]);
-        }
-        if (dcomp_in_lds) atomicAdd(&s_dcomp[r * B + b], dot);
-        else atomicAdd(&dcomp[(int64_t)r * B + b], dot);
-      }
-      float *gp = dV + ((int64_t)b * N + j) * F;
+      float dot = 0.f;
 #pragma unroll
       for (int o = 0; o < FT; ++o)
-        if (o < F) gp[o] = g[o];
+        if (o < F) dot = fmaf(dm[o], vp[o], dot);
+      if (dcomp_in_lds) atomicAdd(&s_dcomp[r * B + b], dot);
+      else atomicAdd(&dcomp[(int64_t)r * B + b], dot);
     }
   }
   if (dcomp_in_lds) {
     __syncthreads();
     for (int t = threadIdx.x; t < R * B; t += blockDim.x) {
-      float x = s_dcomp[t];
+      const float x = s_dcomp[t];
       if (x != 0.f) atomicAdd(&dcomp[t], x);
     }
   }
@@ -132,7 +166,8 @@ __global__ __launch_bounds__(kTB) void k_mix_bwd(const int32_t *__restrict__ npt
 // =====================================================================================
 // no-bases input term: M[c, :] = W[ulcol[c], :]   (row gather of weight_I)
 // =====================================================================================
-__global__ void k_gather_rows(const int32_t *__restrict__ ulcol, int64_t ncols,
+__global__ void k_gather_rows(const int32_t *__restrict__ ulcol, const int32_t *__restrict__ mpos,
+                              int64_t ncols,
                               const float *__restrict__ W, int F, float *__restrict__ M, int64_t ldM,
                               int accumulate) {
   const int64_t total = ncols * F;
@@ -141,7 +176,7 @@ __global__ void k_gather_rows(const int32_t *__restrict__ ulcol, int64_t ncols,
     const int64_t c = t / F;
     const int o = (int)(t - c * F);
     float x = W[(int64_t)ulcol[c] * F + o];
-    float *m = M + c * ldM + o;
+    float *m = M + (int64_t)mpos[c] * ldM + o;
     *m = accumulate ? (*m + x) : x;
   }
 }
@@ -161,6 +196,7 @@ __global__ __launch_bounds__(kTB) void k_xform_fwd(const int32_t *__restrict__ r
                                                    const int32_t *__restrict__ relchunk_end,
                                                    const int32_t *__restrict__ rperm,
                                                    const int32_t *__restrict__ unode,
+                                                   const int32_t *__restrict__ mpos,
                                                    const float *__restrict__ X, int64_t ldX, int K,
                                                    const float *__restrict__ W, int F,
                                                    float *__restrict__ M, int64_t ldM,
@@ -180,7 +216,7 @@ __global__ __launch_bounds__(kTB) void k_xform_fwd(const int32_t *__restrict__ r
     __syncthreads();
     if (threadIdx.x < nk) {
       int32_t c = rperm[t0 + threadIdx.x];
-      s_c[threadIdx.x] = c;
+      s_c[threadIdx.x] = mpos[c];
       s_j[threadIdx.x] = unode[c];
     }
     // per-thread outputs: pairs (kk, o), strided over the block (static register indices)
@@ -351,7 +387,7 @@ int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *p, const float *V, const float *
     if (!in_lds) lds = 0;
     int grid = grid_for(N * F);
 #define MIX_GO(T)                                                                               \
-  k_mix_fwd<T><<<dim3(grid), dim3(kTB), lds, s>>>(p->nptr, p->urel, V, comp, N, R, B, b0, F, M, \
+  k_mix_fwd<T><<<dim3(grid), dim3(kTB), lds, s>>>(p->nptr, p->urel, p->mpos, V, comp, N, R, B, b0, F, M, \
                                                   ldM, acc, in_lds)
     switch (BT) {
       case 2: MIX_GO(2); break;
@@ -381,21 +417,51 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
   MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)R * B * sizeof(float), s));
   // nodes without any column never get written by the kernel: zero dV first only then
   // (full-batch graphs carry the identity block, so every node owns >= 1 column)
-  size_t lds = (size_t)R * B * sizeof(float);
-  int in_lds = lds <= kLdsBudget;
-  if (!in_lds) lds = 0;
-  int64_t tiles = (N + 63) / 64;
-  int grid = (int)(tiles < 1024 ? tiles : 1024);
-#define MIXB_GO(T)                                                                                \
-  k_mix_bwd<T><<<dim3(grid), dim3(kTB), lds, s>>>(p->nptr, p->urel, dM, ldM, V, comp, N, R, B, F, \
-                                                  dV, dcomp, in_lds)
-  if (F <= 4) MIXB_GO(4);
-  else if (F <= 8) MIXB_GO(8);
-  else if (F <= 12) MIXB_GO(12);
-  else if (F <= 16) MIXB_GO(16);
-  else if (F <= 32) MIXB_GO(32);
-  else MIXB_GO(64);
-#undef MIXB_GO
+  // pass 1: dV
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int nb = (B - b0 < 64) ? (B - b0) : 64;
+    int BT = nb <= 2 ? 2 : nb <= 4 ? 4 : nb <= 8 ? 8 : nb <= 16 ? 16 : nb <= 32 ? 32 : nb <= 40 ? 40 : 64;
+    size_t lds = (size_t)R * BT * sizeof(float);
+    int in_lds = lds <= kLdsBudget;
+    if (!in_lds) lds = 0;
+    int grid = grid_for(N * F);
+#define MIXDV_GO(T)                                                                               \
+  k_mix_bwd_dv<T><<<dim3(grid), dim3(kTB), lds, s>>>(p->nptr, p->urel, dM, ldM, comp, N, R, B, b0, \
+                                                     F, dV, in_lds)
+    switch (BT) {
+      case 2: MIXDV_GO(2); break;
+      case 4: MIXDV_GO(4); break;
+      case 8: MIXDV_GO(8); break;
+      case 16: MIXDV_GO(16); break;
+      case 32: MIXDV_GO(32); break;
+      case 40: MIXDV_GO(40); break;
+      default: MIXDV_GO(64); break;
+    }
+#undef MIXDV_GO
+    MRGCN_HIP_TRY(hipGetLastError());
+  }
+  // pass 2: dcomp
+  if (p->ncols > 0) {
+    size_t lds = (size_t)R * B * sizeof(float);
+    int in_lds = lds <= kLdsBudget;
+    if (!in_lds) lds = 0;
+    int per_cu = in_lds && lds > 0 ? (int)((160 * 1024) / (lds + 512)) : 8;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    int64_t want = (p->ncols + kTB - 1) / kTB;
+    int grid = 256 * per_cu;
+    if (grid > want) grid = (int)want;
+#define MIXDC_GO(T)                                                                                 \
+  k_mix_bwd_dcomp<T><<<dim3(grid), dim3(kTB), lds, s>>>(p->urel, p->unode, dM, ldM, V, N, R, B, F, \
+                                                        p->ncols, dcomp, in_lds)
+    if (F <= 4) MIXDC_GO(4);
+    else if (F <= 8) MIXDC_GO(8);
+    else if (F <= 12) MIXDC_GO(12);
+    else if (F <= 16) MIXDC_GO(16);
+    else if (F <= 32) MIXDC_GO(32);
+    else MIXDC_GO(64);
+#undef MIXDC_GO
+  }
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
@@ -406,7 +472,7 @@ int mrgcn_gather_rows_f32(const mrgcn_plan_t *p, const float *W, int32_t F, floa
   MRGCN_REQUIRE(F > 0 && ldM >= F, "F / ldM");
   if (p->ncols == 0) return MRGCN_OK;
   k_gather_rows<<<dim3(grid_for(p->ncols * F)), dim3(kTB), 0, (hipStream_t)stream>>>(
-      p->ulcol, p->ncols, W, F, M, ldM, accumulate);
+      p->ulcol, p->mpos, p->ncols, W, F, M, ldM, accumulate);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
@@ -420,8 +486,8 @@ int mrgcn_rel_transform_fwd_f32(const mrgcn_plan_t *p, const float *X, int64_t l
   if (p->n_relchunks == 0) return MRGCN_OK;
   size_t lds = ((size_t)kKS * F + (size_t)kTK * (kKS + 1)) * sizeof(float);
   k_xform_fwd<<<dim3(p->n_relchunks), dim3(kTB), lds, (hipStream_t)stream>>>(
-      p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, p->unode, X, ldX, K, W, F, M, ldM,
-      accumulate);
+      p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, p->unode, p->mpos, X, ldX, K, W, F, M,
+      ldM, accumulate);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

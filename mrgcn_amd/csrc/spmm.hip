@@ -7,13 +7,17 @@
 // the design goal is many independent row gathers in flight per wave, vector loads
 // (VEC floats per lane) and coalesced index streaming — not FLOPs.
 //
+// One launch covers every row class (block ranges of the same grid):
 //   short rows (<= kLongThreshold entries): a subgroup of G lanes owns one row; a 64-lane
-//       wave therefore walks 64/G adjacent rows at once and every load instruction
-//       carries 64/G independent row gathers.  Deterministic (fixed summation order).
-//   long rows: cut at plan time into chunks of <= kChunk entries; one wave per chunk
-//       strides over the entries with all 64/G slots, butterfly-reduces across slots
-//       and stores one partial row; a finalise pass adds a long row's partials in chunk
-//       order (no atomics -> bitwise reproducible; no pre-zeroing of Y needed).
+//       wave walks 64/G adjacent rows at once, so every load instruction carries 64/G
+//       independent row gathers, 4 deep per lane.
+//   long rows: cut at plan time into chunks of <= kChunk entries, one wave per chunk: all
+//       64/G slots stride over the chunk, a butterfly over the slots reduces them; a row
+//       that is one chunk stores its result directly, a row of several chunks stores
+//       partials that a second tiny launch adds in chunk order.
+// No atomics anywhere: results are bitwise reproducible and Y needs no pre-zeroing.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mrgcn {
@@ -53,138 +57,191 @@ __device__ __forceinline__ void store_row(float *y, const float (&acc)[VEC], int
   }
 }
 
-// ---- short rows ----------------------------------------------------------------------
+// One gather + multiply-add of entry (c, a); `on` masks the contribution.
+template <int VEC>
+__device__ __forceinline__ void gather_fma(const float *Dq, int64_t ldD, int32_t c, float a, bool on,
+                                           float (&acc)[VEC]) {
+  // branch-free: the load is unconditional (masked-off entries carry c = 0, a valid row) so that
+  // the compiler can issue a whole batch of gathers before the first use; the select keeps a
+  // NaN/Inf in row 0 from leaking into rows that do not reference it
+  float x[VEC];
+  load_vec<VEC>(Dq + (int64_t)c * ldD, x);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = fmaf(a, on ? x[i] : 0.f, acc[i]);
+}
+
+// Latency, not bandwidth, bounds a naive row walk (pointer -> index -> gather is three dependent
+// round trips per few entries).  Both paths therefore first pull *all* indices and values of
+// their row / chunk into registers with coalesced loads (one round trip), then hand them to the
+// gathering lanes with cross-lane reads and issue the gathers back to back.
 template <int G, int VEC>
-__global__ __launch_bounds__(256) void k_spmm_short(SparseView v, const float *__restrict__ D,
-                                                    int64_t ldD, int F, float *__restrict__ Y,
-                                                    int64_t ldY, const float *__restrict__ bias,
-                                                    int relu, const int32_t *__restrict__ out_index,
-                                                    int store_vec_ok) {
+__global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restrict__ D, int64_t ldD,
+                                              int F, float *__restrict__ Y, int64_t ldY,
+                                              const float *__restrict__ bias, int relu,
+                                              const int32_t *__restrict__ out_index,
+                                              int store_vec_ok, float *__restrict__ partials,
+                                              int ldP, int chunk_blocks, int64_t short_blocks,
+                                              int64_t xcd_per) {
   constexpr int SLOTS = kWave / G;
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const int slot = lane / G, q = lane % G;
-  const int64_t row = wave * SLOTS + slot;
-  if (row >= v.rows) return;
   const int f0 = q * VEC;
   const bool active = f0 < F;
-  int32_t b = v.ptr[row], e = v.ptr[row + 1];
-  if (e - b > kLongThreshold) return;  // split-row path owns this row
-
+  const float *Dq = D + (active ? f0 : 0);  // idle feature lanes shadow lane 0 (always in bounds)
   float acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
 
-  const float *Dq = D + f0;
-  int32_t k = b;
-  // 4 gathers in flight per lane
-  for (; k + 4 <= e; k += 4) {
-    int32_t c0 = v.idx[k], c1 = v.idx[k + 1], c2 = v.idx[k + 2], c3 = v.idx[k + 3];
-    float a0 = v.val[k], a1 = v.val[k + 1], a2 = v.val[k + 2], a3 = v.val[k + 3];
-    if (active) {
-      float x0[VEC], x1[VEC], x2[VEC], x3[VEC];
-      load_vec<VEC>(Dq + (int64_t)c0 * ldD, x0);
-      load_vec<VEC>(Dq + (int64_t)c1 * ldD, x1);
-      load_vec<VEC>(Dq + (int64_t)c2 * ldD, x2);
-      load_vec<VEC>(Dq + (int64_t)c3 * ldD, x3);
+  if ((int)blockIdx.x < chunk_blocks) {
+    // ---- long rows: one wave per chunk of <= kChunk entries ------------------------------
+    const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    if (chunk >= v.n_chunks) return;
+    const int32_t b = v.chunk_beg[chunk];
+    const int32_t n = v.chunk_end[chunk] - b;
+    constexpr int T = kChunk / kWave;  // staged registers per lane
+    int32_t ci[T];
+    float ca[T];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        acc[i] = fmaf(a0, x0[i], acc[i]);
-        acc[i] = fmaf(a1, x1[i], acc[i]);
-        acc[i] = fmaf(a2, x2[i], acc[i]);
-        acc[i] = fmaf(a3, x3[i], acc[i]);
+    for (int t = 0; t < T; ++t) {  // entry b + 64 t + lane: fully coalesced
+      const int32_t m = t * kWave + lane;
+      ci[t] = (m < n) ? v.idx[b + m] : 0;
+      ca[t] = (m < n) ? v.val[b + m] : 0.f;
+    }
+    constexpr int UPT = kWave / SLOTS;  // = G steps of SLOTS entries per staged register
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t * kWave >= n) break;  // wave uniform
+      if (UPT <= 8) {
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+          const int src = u * SLOTS + slot;
+          const int32_t c = __shfl(ci[t], src, kWave);
+          const float a = __shfl(ca[t], src, kWave);
+          gather_fma<VEC>(Dq, ldD, c, a, active && (t * kWave + src < n), acc);
+        }
+      } else {
+        for (int u = 0; u < UPT; ++u) {
+          const int src = u * SLOTS + slot;
+          const int32_t c = __shfl(ci[t], src, kWave);
+          const float a = __shfl(ca[t], src, kWave);
+          gather_fma<VEC>(Dq, ldD, c, a, active && (t * kWave + src < n), acc);
+        }
       }
     }
-  }
-  for (; k < e; ++k) {
-    int32_t c = v.idx[k];
-    float a = v.val[k];
-    if (active) {
-      float x[VEC];
-      load_vec<VEC>(Dq + (int64_t)c * ldD, x);
+    // butterfly over the slots (lanes with equal q); every lane takes part
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(a, x[i], acc[i]);
+    for (int off = G; off < kWave; off <<= 1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
     }
+    if (slot == 0 && active) {
+      const int32_t row = v.chunk_row[chunk];
+      if (row >= 0) {  // the whole row was this chunk: finished
+        const int64_t orow = out_index ? (int64_t)out_index[row] : (int64_t)row;
+        store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
+      } else {
+        float *p = partials + chunk * (int64_t)ldP + f0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+          if (f0 + i < F) p[i] = acc[i];
+      }
+    }
+    return;
   }
-  if (active) {
+
+  // ---- short rows ----------------------------------------------------------------------
+  // blocks b and b+8 share an XCD (round-robin dispatch): give every XCD one contiguous run
+  // of rows so that a row block and its successor meet in the same L2
+  int64_t sb = (int64_t)blockIdx.x - chunk_blocks;
+  if (xcd_per > 0) {
+    sb = (sb & 7) * xcd_per + (sb >> 3);
+    if (sb >= short_blocks) return;
+  }
+  const int64_t wave = (sb * blockDim.x + threadIdx.x) / kWave;
+  const int64_t row = wave * SLOTS + slot;
+  // no early return: every lane takes part in the cross-lane reads below
+  int32_t b = 0, n = 0;
+  if (row < v.rows) {
+    b = v.ptr[row];
+    n = v.ptr[row + 1] - b;
+    if (n > kLongThreshold) n = 0;  // the chunk path owns this row
+  }
+  const bool mine = row < v.rows && (v.ptr[row + 1] - v.ptr[row]) <= kLongThreshold;
+  if (G <= 8) {
+    // the G lanes of a row stage its <= 32 entries: lane q holds entries q, q+G, q+2G, ...
+    constexpr int T = (kLongThreshold + G - 1) / G;
+    int32_t ci[T];
+    float ca[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int32_t m = t * G + q;
+      ci[t] = (m < n) ? v.idx[b + m] : 0;
+      ca[t] = (m < n) ? v.val[b + m] : 0.f;
+    }
+    const int sbase = slot * G;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (!__any(t * G < n)) break;  // wave uniform: nobody has entries left
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int32_t c = __shfl(ci[t], sbase + u, kWave);
+        const float a = __shfl(ca[t], sbase + u, kWave);
+        gather_fma<VEC>(Dq, ldD, c, a, active && (t * G + u < n), acc);
+      }
+    }
+  } else {
+    // wide rows (G >= 16): a row is already several cache lines; plain walk, four deep
+    int32_t k = b;
+    const int32_t e = b + n;
+    for (; k + 4 <= e; k += 4) {
+      const int32_t c0 = v.idx[k], c1 = v.idx[k + 1], c2 = v.idx[k + 2], c3 = v.idx[k + 3];
+      const float a0 = v.val[k], a1 = v.val[k + 1], a2 = v.val[k + 2], a3 = v.val[k + 3];
+      if (active) {
+        float x0[VEC], x1[VEC], x2[VEC], x3[VEC];
+        load_vec<VEC>(Dq + (int64_t)c0 * ldD, x0);
+        load_vec<VEC>(Dq + (int64_t)c1 * ldD, x1);
+        load_vec<VEC>(Dq + (int64_t)c2 * ldD, x2);
+        load_vec<VEC>(Dq + (int64_t)c3 * ldD, x3);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          acc[i] = fmaf(a0, x0[i], acc[i]);
+          acc[i] = fmaf(a1, x1[i], acc[i]);
+          acc[i] = fmaf(a2, x2[i], acc[i]);
+          acc[i] = fmaf(a3, x3[i], acc[i]);
+        }
+      }
+    }
+    for (; k < e; ++k) gather_fma<VEC>(Dq, ldD, v.idx[k], v.val[k], active, acc);
+  }
+  if (mine && active) {
     const int64_t orow = out_index ? (int64_t)out_index[row] : row;
     store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
   }
 }
 
-// ---- long rows: one wave per chunk -----------------------------------------------------
-template <int G, int VEC>
-__global__ __launch_bounds__(256) void k_spmm_chunks(SparseView v, const float *__restrict__ D,
-                                                     int64_t ldD, int F, float *__restrict__ partials,
-                                                     int ldP) {
-  constexpr int SLOTS = kWave / G;
+// ---- rows of several chunks: one wave per long row adds its partials in a fixed order ----
+__global__ __launch_bounds__(256) void k_spmm_finalize(SparseView v, const float *__restrict__ partials,
+                                                       int ldP, int F, float *__restrict__ Y,
+                                                       int64_t ldY, const float *__restrict__ bias,
+                                                       int relu, const int32_t *__restrict__ out_index) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-  if (chunk >= v.n_chunks) return;
-  const int slot = lane / G, q = lane % G;
-  const int f0 = q * VEC;
-  const bool active = f0 < F;
-  const int32_t b = v.chunk_beg[chunk], e = v.chunk_end[chunk];
-
-  float acc[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-  const float *Dq = D + f0;
-  int32_t k = b + slot;
-  for (; k + SLOTS < e; k += 2 * SLOTS) {  // two gathers in flight per lane
-    int32_t c0 = v.idx[k], c1 = v.idx[k + SLOTS];
-    float a0 = v.val[k], a1 = v.val[k + SLOTS];
-    if (active) {
-      float x0[VEC], x1[VEC];
-      load_vec<VEC>(Dq + (int64_t)c0 * ldD, x0);
-      load_vec<VEC>(Dq + (int64_t)c1 * ldD, x1);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        acc[i] = fmaf(a0, x0[i], acc[i]);
-        acc[i] = fmaf(a1, x1[i], acc[i]);
-      }
-    }
-  }
-  if (k < e) {
-    int32_t c = v.idx[k];
-    float a = v.val[k];
-    if (active) {
-      float x[VEC];
-      load_vec<VEC>(Dq + (int64_t)c * ldD, x);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(a, x[i], acc[i]);
-    }
-  }
-  // butterfly over the slots (lanes with equal q); every lane takes part
-#pragma unroll
-  for (int off = G; off < kWave; off <<= 1) {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
-  }
-  if (slot == 0 && active) {
-    float *p = partials + chunk * (int64_t)ldP + f0;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i)
-      if (f0 + i < F) p[i] = acc[i];
-  }
-}
-
-// ---- long rows: ordered sum of partials ------------------------------------------------
-__global__ void k_spmm_finalize(SparseView v, const float *__restrict__ partials, int ldP, int F,
-                                float *__restrict__ Y, int64_t ldY, const float *__restrict__ bias,
-                                int relu, const int32_t *__restrict__ out_index) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t li = t / F;
-  int f = (int)(t - li * F);
+  const int64_t li = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   if (li >= v.n_long) return;
-  int32_t c0 = v.long_cptr[li], c1 = v.long_cptr[li + 1];
-  float s = 0.f;
-  for (int32_t c = c0; c < c1; ++c) s += partials[(int64_t)c * ldP + f];
-  if (bias) s += bias[f];
-  if (relu) s = fmaxf(s, 0.f);
+  const int32_t c0 = v.long_cptr[li], c1 = v.long_cptr[li + 1];
+  if (c1 - c0 <= 1) return;  // single-chunk rows were stored by the chunk wave
   int64_t row = v.long_row[li];
   if (out_index) row = out_index[row];
-  Y[row * ldY + f] = s;
+  for (int f = 0; f < F; ++f) {
+    float s = 0.f;
+    for (int32_t c = c0 + lane; c < c1; c += kWave) s += partials[(int64_t)c * ldP + f];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+    if (lane == 0) {
+      if (bias) s += bias[f];
+      if (relu) s = fmaxf(s, 0.f);
+      Y[row * ldY + f] = s;
+    }
+  }
 }
 
 template <int G, int VEC>
@@ -192,20 +249,22 @@ int launch(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, in
            const float *bias, int relu, const int32_t *out_index, float *partials, hipStream_t s) {
   constexpr int SLOTS = kWave / G;
   const bool store_vec_ok = (ldY % VEC == 0) && (((uintptr_t)Y) % (VEC * 4) == 0);
-  if (v.rows > 0) {
-    int64_t waves = (v.rows + SLOTS - 1) / SLOTS;
-    int64_t blocks = (waves + 3) / 4;
-    k_spmm_short<G, VEC><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, bias, relu,
-                                                                       out_index, store_vec_ok ? 1 : 0);
+  const int64_t short_waves = (v.rows + SLOTS - 1) / SLOTS;
+  const int64_t short_blocks = (short_waves + 3) / 4;
+  const int64_t chunk_blocks = ((int64_t)v.n_chunks + 3) / 4;
+  static const bool xcd_map = !(getenv("MRGCN_SPMM_XCD") && atoi(getenv("MRGCN_SPMM_XCD")) == 0);
+  const int64_t xcd_per = xcd_map ? (short_blocks + 7) / 8 : 0;
+  const int64_t launch_short = xcd_map ? xcd_per * 8 : short_blocks;
+  if (launch_short + chunk_blocks > 0) {
+    k_spmm<G, VEC><<<dim3((unsigned)(launch_short + chunk_blocks)), dim3(256), 0, s>>>(
+        v, D, ldD, F, Y, ldY, bias, relu, out_index, store_vec_ok ? 1 : 0, partials, kWsFeatures,
+        (int)chunk_blocks, short_blocks, xcd_per);
     MRGCN_HIP_TRY(hipGetLastError());
   }
-  if (v.n_chunks > 0) {
-    int64_t blocks = ((int64_t)v.n_chunks + 3) / 4;
-    k_spmm_chunks<G, VEC><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(v, D, ldD, F, partials, kWsFeatures);
-    MRGCN_HIP_TRY(hipGetLastError());
-    int64_t threads = (int64_t)v.n_long * F;
-    k_spmm_finalize<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s>>>(
-        v, partials, kWsFeatures, F, Y, ldY, bias, relu, out_index);
+  if (v.n_multi > 0) {
+    const int64_t blocks = ((int64_t)v.n_long + 3) / 4;
+    k_spmm_finalize<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(v, partials, kWsFeatures, F, Y, ldY, bias,
+                                                                 relu, out_index);
     MRGCN_HIP_TRY(hipGetLastError());
   }
   return MRGCN_OK;
@@ -222,7 +281,10 @@ int dispatch(const SparseView &v, const float *D, int64_t ldD, int64_t avail, in
     int64_t padded = ((int64_t)F + w - 1) / w * w;
     return ldD % w == 0 && ((uintptr_t)D) % (w * 4) == 0 && avail >= padded;
   };
-  if (ok(4)) vec = 4; else if (ok(2)) vec = 2;
+  // MRGCN_SPMM_UNALIGNED=1: 16-byte loads on rows that are only 4/8-byte aligned (gfx950 global
+  // loads need dword alignment only); the caller guarantees 12 readable bytes past the operand
+  static const bool unaligned = getenv("MRGCN_SPMM_UNALIGNED") && atoi(getenv("MRGCN_SPMM_UNALIGNED")) != 0;
+  if (ok(4) || unaligned) vec = 4; else if (ok(2)) vec = 2;
   const int lanes = (F + vec - 1) / vec;  // lanes needed per row
 #define MRGCN_GO(G, V) return launch<G, V>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, s)
   if (vec == 4) {

@@ -84,9 +84,13 @@ def _stream(device) -> int:
 
 
 def _ld_for(F: int) -> int:
-    """Leading dimension of the compact operand: rows padded to a multiple of 4 floats so
-    that every gather is 16-byte aligned float4 loads."""
-    return (F + 3) // 4 * 4
+    """Leading dimension of the compact operand: rows padded to a multiple of 4 floats so that
+    every gather is 16-byte float4 loads.  (Measured on the AM shape, MI355X: 12 / 16 floats
+    per 10-feature row run within 1 %: with the plan's hot/cold operand order the kernel is
+    bound by request latency, not by the operand's bytes.)  MRGCN_LDM_ALIGN overrides."""
+    import os
+    a = int(os.environ.get("MRGCN_LDM_ALIGN", "4"))
+    return (F + a - 1) // a * a
 
 
 def relu_bwd(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:

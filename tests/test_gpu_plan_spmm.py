@@ -10,7 +10,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 ARRAYS = ["rowptr", "lcol", "ccol", "val", "cptr", "crow", "cval", "urel", "unode", "nptr",
-          "rowidx", "ulcol", "rperm", "relptr"]
+          "rowidx", "ulcol", "rperm", "relptr", "mpos", "mcol", "mval"]
 
 
 def _plan_from_coo(rows, cols, vals, num_rows, N, R, prune=False):
@@ -114,7 +114,7 @@ def test_spmm_literal_compact_transposed(skewed, F):
     # compact operand with padded leading dimension
     for ld in sorted({F, (F + 3) // 4 * 4, F + 5}):
         M = np.zeros((plan.ncols, ld), dtype=np.float32)
-        M[:, :F] = D[ref["ulcol"]]
+        M[ref["mpos"], :F] = D[ref["ulcol"]]  # compact column c is stored at row mpos[c]
         M[:, F:] = 1e30  # padding must never leak into the result
         Yc = plan.spmm(L.VIEW_COMPACT, torch.from_numpy(M).cuda(), F=F).cpu().numpy()
         np.testing.assert_allclose(Yc, Y_ref, rtol=1e-4, atol=1e-4)

@@ -92,6 +92,24 @@ def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False):
     nptr = np.searchsorted(unode, np.arange(N + 1)).astype(np.int32)
     rperm = np.argsort(ulcol, kind="stable").astype(np.int32)
     relptr = np.searchsorted(ulcol[rperm], np.arange(R + 1, dtype=np.int64) * N).astype(np.int32)
+    # storage order of the compact operand: hot columns (>= 2 entries) by falling count, then
+    # single-entry columns by the row that reads them
+    cnt = np.diff(cptr).astype(np.int64)
+    if ncols:
+        firstrow = crow[cptr[:-1]].astype(np.int64)
+        max_count = int(cnt.max()) + 1
+        hi = np.where(cnt >= 2, max_count - cnt, max_count + 1 + firstrow)
+        order = np.lexsort((np.arange(ncols), hi))
+        mpos = np.empty(ncols, dtype=np.int32)
+        mpos[order] = np.arange(ncols, dtype=np.int32)
+    else:
+        mpos = np.zeros(0, dtype=np.int32)
+    if len(key):  # COMPACT view: entries of a row in rising operand position
+        mc = mpos[ccol].astype(np.int64)
+        o3 = np.argsort(rowidx.astype(np.int64) * max(ncols, 1) + mc, kind="stable")
+        mcol, mval = mc[o3].astype(np.int32), v[o3]
+    else:
+        mcol, mval = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32)
     return dict(rowptr=rowptr, lcol=lcol, ccol=ccol, val=v, rowidx=rowidx, cptr=cptr, crow=crow,
                 cval=cval, urel=urel, unode=unode, ulcol=ulcol, nptr=nptr, rperm=rperm,
-                relptr=relptr, ncols=ncols, nnz=len(key))
+                relptr=relptr, mpos=mpos, mcol=mcol, mval=mval, ncols=ncols, nnz=len(key))

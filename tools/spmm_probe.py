@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Runs only the stacked-CSR SpMM on the AM-shaped graph (for rocprofv3 --pmc passes and
+quick A/B timing of operand layouts).
+
+    python tools/spmm_probe.py [--ld 16] [--view compact|literal|transposed] [--iters 20]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import event_time_ms  # noqa: E402
+from mrgcn_amd import _lib as L  # noqa: E402
+from mrgcn_amd import synth  # noqa: E402
+from mrgcn_amd.plan import GraphPlan  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="am")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--ld", type=int, nargs="+", default=[16])
+    ap.add_argument("--F", type=int, default=10)
+    ap.add_argument("--view", default="compact")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--prune", action="store_true")
+    ap.add_argument("--value-mode", default="norm_f32")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = synth.make_graph(a.workload, seed=0, scale=a.scale, value_mode=a.value_mode)
+    N, R = g.num_nodes, g.num_relations
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                (N, R * N)).to(dev)
+    plan = GraphPlan(A, N, R, prune_zeros=a.prune)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    F = a.F
+    alg = plan.spmm_bytes(F)
+    print(f"N={N} R={R} nnz={plan.nnz} ncols={plan.ncols} long_rows={plan.long_rows} "
+          f"long_cols={plan.long_cols} alg_bytes={alg}")
+    for ld in a.ld:
+        if a.view == "compact":
+            D = torch.randn((plan.ncols * ld + 8,), device=dev)[:plan.ncols * ld].view(plan.ncols, ld)
+            Y = torch.empty((N, F), device=dev)
+            fn = lambda: plan.spmm(L.VIEW_COMPACT, D, F=F, out=Y)  # noqa: E731
+        elif a.view == "literal":
+            D = torch.randn((R * N, ld), device=dev)
+            Y = torch.empty((N, F), device=dev)
+            fn = lambda: plan.spmm(L.VIEW_LITERAL, D, F=F, out=Y)  # noqa: E731
+        else:
+            D = torch.randn((N, ld), device=dev)
+            Y = torch.empty((plan.ncols, 16), device=dev)
+            fn = lambda: plan.spmm(L.VIEW_TRANSPOSED, D, F=F, out=Y)  # noqa: E731
+        ms = event_time_ms(fn, a.iters, stream)
+        print(f"view={a.view} F={F} ld={ld}: {ms*1e3:.1f} us  {alg/ms/1e6:.1f} GB/s algorithmic "
+              f"({alg/ms/1e6/8000*100:.1f}% of 8 TB/s)")
+        del D, Y
+
+
+if __name__ == "__main__":
+    main()
