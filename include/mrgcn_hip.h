@@ -129,23 +129,29 @@ int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const float *D, int64
 /* ---- compact dense operand: forward -----------------------------------------------
  * M is [ncols, ldM] row-major with one row per touched column c = (node j_c, relation
  * r_c); column c lives at row MPOS[c] (hot columns first, then single-use columns in the
- * order of the output row that reads them).  `accumulate` != 0 adds into M.
- * The backward operand dM (output of the TRANSPOSED view) is in plain compact order.
+ * order of the output row that reads them).  Producers write the WHOLE padded row (zeros in
+ * [F, ldM)) and never read M: the one scattered pass of the forward is write-only.
+ * `addend` (nullable, [ncols, ldA] in plain compact order) is added on the fly — it carries
+ * the other term of the layer.  The backward operand dM (output of the TRANSPOSED view) is in
+ * plain compact order.
  *
  * basis mix — replaces einsum('rb,bij->rij', weight_I_comp, weight_I.view(B,N,out)) and the
  * view to (R*N, out) of graph.py:69-72, restricted to the rows the product will read:
- *     M[c, 0:F] (+)= sum_b comp[r_c, b] * V[b*N + j_c, 0:F]        V: [B*N, F], comp: [R, B] */
+ *     M[MPOS[c], 0:F] = addend[c, 0:F] + sum_b comp[r_c, b] * V[b*N + j_c, 0:F]
+ *     V: [B*N, F], comp: [R, B] */
 int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *plan, const float *V, const float *comp, int32_t B,
-                            int32_t F, float *M, int64_t ldM, int32_t accumulate, void *stream);
-/* no-bases input term (graph.py:67-68): M[c, 0:F] (+)= W[r_c*N + j_c, 0:F]      W: [R*N, F] */
-int mrgcn_gather_rows_f32(const mrgcn_plan_t *plan, const float *W, int32_t F, float *M,
-                          int64_t ldM, int32_t accumulate, void *stream);
+                            int32_t F, const float *addend, int64_t ldA, float *M, int64_t ldM,
+                            void *stream);
+/* no-bases input term (graph.py:67-68): M[MPOS[c], 0:F] = addend[c, 0:F] + W[r_c*N + j_c, 0:F] */
+int mrgcn_gather_rows_f32(const mrgcn_plan_t *plan, const float *W, int32_t F, const float *addend,
+                          int64_t ldA, float *M, int64_t ldM, void *stream);
 /* relation transform — replaces einsum('ij,bjk->bik', X, W_F) + reshape of graph.py:93-94,
- * restricted to touched columns:
- *     M[c, 0:F] (+)= X[j_c, 0:K] . W[r_c, 0:K, 0:F]                 X: [N, ldX], W: [R, K, F] */
+ * restricted to touched columns (f32 MFMA 16x16x4 when K <= 256 and F <= 64):
+ *     Out[o(c), 0:F] = X[j_c, 0:K] . W[r_c, 0:K, 0:F]          X: [N, ldX], W: [R, K, F]
+ * o(c) = c (plain compact order, e.g. to serve as `addend`) or MPOS[c] (`operand_order` != 0) */
 int mrgcn_rel_transform_fwd_f32(const mrgcn_plan_t *plan, const float *X, int64_t ldX, int32_t K,
-                                const float *W, int32_t F, float *M, int64_t ldM,
-                                int32_t accumulate, void *stream);
+                                const float *W, int32_t F, float *Out, int64_t ldOut,
+                                int32_t operand_order, void *stream);
 
 /* ---- compact dense operand: backward (autograd of graph.py:69-72, :93-94) -------------
  *     dV[b*N + j, :] = sum_{c in node j} comp[r_c, b] * dM[c, :]       (every row written)
@@ -154,10 +160,16 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64_t l
                             const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
                             void *stream);
 /*     dX[j, 0:K]  = sum_{c in node j} W[r_c] . dM[c, :]     (nullable; every row written)
- *     dW[r, :, :] = sum_{c: r_c = r} X[j_c, :]^T dM[c, :]    (nullable; zeroed inside)     */
+ *     dW[r, :, :] = sum_{c: r_c = r} X[j_c, :]^T dM[c, :]    (nullable; zeroed inside)
+ * `workspace` (nullable; size from mrgcn_rel_transform_bwd_workspace) lets dX run on the matrix
+ * cores (per-column products, then a segmented sum per node) and dW reduce per-chunk partial
+ * slabs instead of contended global atomics.                                              */
+int64_t mrgcn_rel_transform_bwd_workspace(const mrgcn_plan_t *plan, int32_t K, int32_t F,
+                                          int32_t need_dX, int32_t need_dW); /* floats */
 int mrgcn_rel_transform_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM,
                                 const float *X, int64_t ldX, int32_t K, const float *W, int32_t F,
-                                float *dX, int64_t lddX, float *dW, void *stream);
+                                float *dX, int64_t lddX, float *dW, float *workspace,
+                                int64_t workspace_floats, void *stream);
 
 /* ---- epoch kernels around the layers ----------------------------------------------
  * out = dY * (Y > 0): backward of the nn.ReLU between layers (rgcn.py:86-87) */

@@ -57,6 +57,21 @@ struct SparseView {
 
 }  // namespace mrgcn
 
+struct mrgcn_plan;
+namespace mrgcn {
+// MFMA relation transforms (xform_mfma.hip)
+bool xform_mfma_fwd_supported(int K, int F);
+bool xform_mfma_dw_supported(int K, int F);
+int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
+                   int64_t ldIn, int K, const float *W, bool trans_w, int F, float *Out, int64_t ldOut,
+                   hipStream_t s);
+int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, int64_t ldIn, int K,
+                  const float *G, int64_t ldG, int F, float *dW, float *workspace,
+                  int64_t workspace_floats, hipStream_t s);
+int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *dX, int64_t lddX,
+                hipStream_t s);
+}  // namespace mrgcn
+
 struct mrgcn_plan {
   int64_t num_rows = 0, num_nodes = 0, num_relations = 0, nnz = 0, ncols = 0;
   int64_t max_row_nnz = 0, max_col_nnz = 0;
@@ -81,8 +96,11 @@ struct mrgcn_plan {
   // relation-major order of the compact columns (for per-relation dense transforms)
   int32_t *rperm = nullptr;   // [ncols] compact ids sorted by (relation, node)
   int32_t *relptr = nullptr;  // [R+1]   range of each relation in rperm
+  int32_t *rnode = nullptr;   // [ncols] unode[rperm[k]]: source node, relation-major
+  int32_t *rmpos = nullptr;   // [ncols] mpos[rperm[k]]: operand row, relation-major
   int32_t *relchunk_rel = nullptr, *relchunk_beg = nullptr, *relchunk_end = nullptr;  // [n_relchunks]
-  int32_t n_relchunks = 0;
+  int32_t *relchunk_ptr = nullptr;  // [R+1] chunk range of each relation
+  int32_t n_relchunks = 0, max_relchunks = 0;
   // split-row descriptors, one set per orientation
   int32_t *r_long_row = nullptr, *r_long_cptr = nullptr, *r_chunk_beg = nullptr, *r_chunk_end = nullptr,
           *r_chunk_row = nullptr;

@@ -402,14 +402,20 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     MRGCN_HIP_TRY(hipMemcpyAsync(h_relptr.data(), p->relptr, (R + 1) * sizeof(int32_t),
                                  hipMemcpyDeviceToHost, s));
     MRGCN_HIP_TRY(hipStreamSynchronize(s));
-    std::vector<int32_t> rel, beg, end;
-    for (int64_t r = 0; r < R; ++r)
+    std::vector<int32_t> rel, beg, end, cptr_rel(R + 1, 0);
+    for (int64_t r = 0; r < R; ++r) {
+      cptr_rel[r] = (int32_t)rel.size();
       for (int32_t b = h_relptr[r]; b < h_relptr[r + 1]; b += kRelChunk) {
         rel.push_back((int32_t)r);
         beg.push_back(b);
         end.push_back(std::min(b + kRelChunk, h_relptr[r + 1]));
       }
+      p->max_relchunks = std::max(p->max_relchunks, (int32_t)rel.size() - cptr_rel[r]);
+    }
+    cptr_rel[R] = (int32_t)rel.size();
     p->n_relchunks = (int32_t)rel.size();
+    MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_ptr, R + 1));
+    MRGCN_HIP_TRY(hipMemcpy(p->relchunk_ptr, cptr_rel.data(), (R + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
     MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_rel, p->n_relchunks));
     MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_beg, p->n_relchunks));
     MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_end, p->n_relchunks));
@@ -477,6 +483,15 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     MRGCN_HIP_TRY(hipGetLastError());
     MRGCN_HIP_TRY(hipStreamSynchronize(s));
   }
+  // relation-major copies of the per-column indices (no dependent index chain in the transforms)
+  MRGCN_HIP_TRY(plan_alloc(p, &p->rnode, ncols));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->rmpos, ncols));
+  if (ncols > 0) {
+    k_gather_i32<<<nblocks(ncols), kTB, 0, s>>>(p->unode, p->rperm, ncols, p->rnode);
+    k_gather_i32<<<nblocks(ncols), kTB, 0, s>>>(p->mpos, p->rperm, ncols, p->rmpos);
+    MRGCN_HIP_TRY(hipGetLastError());
+    MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  }
   if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r_long_row, &p->r_long_cptr, &p->r_chunk_beg,
                        &p->r_chunk_end, &p->r_chunk_row, &p->r_n_long, &p->r_n_chunks, &p->max_row_nnz)))
     return rc;
@@ -487,7 +502,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
 
 void free_plan(mrgcn_plan *p) {
   void *ptrs[] = {p->rowptr, p->lcol, p->ccol, p->rowidx, p->val, p->cptr, p->crow, p->urel, p->unode,
-                  p->nptr, p->ulcol, p->mpos, p->mcol, p->mval, p->rperm, p->relptr, p->relchunk_rel, p->relchunk_beg, p->relchunk_end,
+                  p->nptr, p->ulcol, p->mpos, p->mcol, p->mval, p->rperm, p->relptr, p->rnode, p->rmpos, p->relchunk_ptr, p->relchunk_rel, p->relchunk_beg, p->relchunk_end,
                   p->cval, p->r_long_row, p->r_long_cptr, p->r_chunk_beg, p->r_chunk_end,
                   p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->r_chunk_row, p->c_chunk_row,
                   p->partials};

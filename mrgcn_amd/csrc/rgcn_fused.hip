@@ -3,67 +3,191 @@
 // (R*N) x out operands W_I and FW_F (mrgcn/layers/graph.py:69-72, :83-85, :93-94) and of
 // their dense gradients (autograd of the same lines).
 //
-//   M[c, :] = sum_b comp_I[r_c, b] * V_I[b, j_c, :]      basis mix   (input term)
-//           + X[j_c, :] . W_F[r_c]                        relation transform (feature term)
+//   M[mpos[c], :] = sum_b comp_I[r_c, b] * V_I[b, j_c, :]      basis mix   (input term)
+//                 + X[j_c, :] . W_F[r_c]                        relation transform (feature term)
 //
 // Compact columns are numbered in (source node j, relation r) order, so everything that
 // belongs to one node is contiguous: the basis tables V[b, j, :] are streamed exactly once
-// (HBM-bound, coalesced over j for every b) and dV needs no atomics.  The per-relation
-// dense transforms run relation-major over `rperm` with the relation's weight tile and a
-// gathered X tile staged in LDS.
+// (HBM-bound, coalesced over j for every b) and dV needs no atomics.  The per-relation dense
+// transforms run relation-major on the matrix cores (xform_mfma.hip).  When both terms are
+// present the transform writes its rows in compact order (sequential) and the mix pass adds
+// them while it emits the final rows in the operand's storage order `mpos` — the only
+// scattered traffic of the forward is that one write-only pass of whole padded rows.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mrgcn {
 namespace {
 
 constexpr int kTB = 256;
+constexpr int kMixTB = 512;  // mix kernels: 8 waves share one LDS copy of comp
+constexpr int kPre = 8;      // relation ids of a node's first columns are prefetched
 
 // =====================================================================================
-// basis mix, forward:  thread = (node j, feature o); V[., j, o] lives in registers
+// basis mix, forward.  thread = (node j, padded feature o < FW); V[., j, o] in registers.
+//   M[mpos[c], o] = (addend ? addend[c, o] : 0) (+ old value if accumulate)
+//                   + sum_b comp[r_c, b] * V[b, j, o]          for o < F;  0 for F <= o < FW
 // =====================================================================================
+// LDS row stride of the staged comp slice: multiple of 4 floats (16-byte ds_read_b128) and
+// = 12 mod 32 banks when BT = 40, so that the 4-6 relations a wave touches at once land on
+// different banks
+__host__ __device__ constexpr int comp_stride(int BT) { return BT >= 4 ? BT + 4 : BT; }
+
 template <int BT>
-__global__ __launch_bounds__(kTB) void k_mix_fwd(const int32_t *__restrict__ nptr,
-                                                 const int32_t *__restrict__ urel,
-                                                 const int32_t *__restrict__ mpos,
-                                                 const float *__restrict__ V,
-                                                 const float *__restrict__ comp, int64_t N, int R,
-                                                 int B, int b0, int F, float *__restrict__ M,
-                                                 int64_t ldM, int accumulate, int comp_in_lds) {
-  extern __shared__ float s_comp[];  // [R][BT] slice b0..b0+BT of comp when it fits
+__device__ __forceinline__ void load_comp_row(const float *row, float (&w)[BT]) {
+  if constexpr (BT % 4 == 0) {
+#pragma unroll
+    for (int b = 0; b < BT; b += 4) {
+      const float4 q = *reinterpret_cast<const float4 *>(row + b);
+      w[b] = q.x; w[b + 1] = q.y; w[b + 2] = q.z; w[b + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < BT; ++b) w[b] = row[b];
+  }
+}
+
+template <int BT>
+__global__ __launch_bounds__(kMixTB) void k_mix_fwd(const int32_t *__restrict__ nptr,
+                                                    const int32_t *__restrict__ urel,
+                                                    const int32_t *__restrict__ mpos,
+                                                    const float *__restrict__ V,
+                                                    const float *__restrict__ comp, int64_t N, int R,
+                                                    int B, int b0, int F, int FW,
+                                                    const float *__restrict__ addend, int64_t ldA,
+                                                    float *__restrict__ M, int64_t ldM, int accumulate,
+                                                    int comp_in_lds) {
+  extern __shared__ __align__(16) float s_comp[];  // [R][CS] slice b0..b0+BT of comp when it fits
+  constexpr int CS = comp_stride(BT);
   const int nb = min(BT, B - b0);
   if (comp_in_lds) {
     for (int t = threadIdx.x; t < R * BT; t += blockDim.x) {
       int r = t / BT, b = t - r * BT;
-      s_comp[t] = (b < nb) ? comp[(int64_t)r * B + b0 + b] : 0.f;
+      s_comp[r * CS + b] = (b < nb) ? comp[(int64_t)r * B + b0 + b] : 0.f;
     }
     __syncthreads();
   }
-  const int64_t total = N * F;
+  const int64_t total = N * FW;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t j = t / F;
-    const int o = (int)(t - j * F);
+    const int64_t j = t / FW;
+    const int o = (int)(t - j * FW);
+    const bool live = o < F;
     const int32_t c0 = nptr[j], c1 = nptr[j + 1];
     if (c0 == c1) continue;
+    // everything the first kPre columns need is requested up front (no dependent round trips)
+    int rr[kPre];
+    int32_t pp[kPre];
+    float aa[kPre];
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+      const bool in = c0 + i < c1;
+      const int32_t c = in ? c0 + i : c0;
+      rr[i] = urel[c];
+      pp[i] = mpos ? mpos[c] : c;
+      aa[i] = (addend && live) ? addend[(int64_t)c * ldA + o] : 0.f;
+    }
     float v[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b)
-      v[b] = (b < nb) ? V[((int64_t)(b0 + b) * N + j) * F + o] : 0.f;
-    for (int32_t c = c0; c < c1; ++c) {
-      const int r = urel[c];
-      float s = 0.f;
+      v[b] = (live && b < nb) ? V[((int64_t)(b0 + b) * N + j) * F + o] : 0.f;
+
+    auto emit = [&](int r, int64_t pos, float add) {
+      float s = add;
       if (comp_in_lds) {
-        const float *cr = s_comp + r * BT;
+        float w[BT];
+        load_comp_row<BT>(s_comp + r * CS, w);
 #pragma unroll
-        for (int b = 0; b < BT; ++b) s = fmaf(cr[b], v[b], s);
+        for (int b = 0; b < BT; ++b) s = fmaf(w[b], v[b], s);
       } else {
         const float *cr = comp + (int64_t)r * B + b0;
 #pragma unroll
         for (int b = 0; b < BT; ++b)
           if (b < nb) s = fmaf(cr[b], v[b], s);
       }
-      float *m = M + (int64_t)mpos[c] * ldM + o;
-      *m = accumulate ? (*m + s) : s;
+      float *m = M + pos * ldM + o;
+      if (accumulate) s += *m;
+      *m = live ? s : 0.f;
+    };
+#pragma unroll
+    for (int i = 0; i < kPre; ++i)
+      if (c0 + i < c1) emit(rr[i], pp[i], aa[i]);
+    for (int32_t c = c0 + kPre; c < c1; ++c)
+      emit(urel[c], mpos ? mpos[c] : c, (addend && live) ? addend[(int64_t)c * ldA + o] : 0.f);
+  }
+}
+
+// =====================================================================================
+// basis mix, forward, column-parallel form (B <= 64): thread = compact column c, lanes =
+// consecutive columns.  Index loads (urel / unode / mpos) are coalesced and independent, there
+// is no per-node loop (no divergence under degree skew, no dependent load chain); the V rows of
+// a node are re-read by its ~5 columns out of L1/L2, so HBM still streams V once.
+//   M[mpos[c], 0:FW] = [ addend[c, 0:F] + sum_b comp[r_c, b] * V[b, j_c, 0:F] | 0 ]
+// comp lives in LDS with an odd row stride (lanes hold different relations: conflict free).
+// =====================================================================================
+template <int FT, bool VEC2>
+__global__ __launch_bounds__(kMixTB) void k_mix_fwd_cols(const int32_t *__restrict__ urel,
+                                                         const int32_t *__restrict__ unode,
+                                                         const int32_t *__restrict__ mpos,
+                                                         const float *__restrict__ V,
+                                                         const float *__restrict__ comp, int64_t N, int R,
+                                                         int B, int F, int FW,
+                                                         const float *__restrict__ addend, int64_t ldA,
+                                                         float *__restrict__ M, int64_t ldM, int64_t ncols,
+                                                         int comp_in_lds) {
+  extern __shared__ float s_comp[];  // [R][BS], BS = B | 1
+  const int BS = B | 1;
+  if (comp_in_lds) {
+    for (int t = threadIdx.x; t < R * B; t += blockDim.x) {
+      const int r = t / B, b = t - r * B;
+      s_comp[r * BS + b] = comp[t];
+    }
+    __syncthreads();
+  }
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols;
+       c += (int64_t)gridDim.x * blockDim.x) {
+    const int r = urel[c];
+    const int64_t j = unode[c];
+    const int64_t pos = mpos ? mpos[c] : c;
+    float acc[FT];
+#pragma unroll
+    for (int o = 0; o < FT; ++o) acc[o] = (addend && o < F) ? addend[c * ldA + o] : 0.f;
+    const float *cr = comp_in_lds ? (s_comp + r * BS) : (comp + (int64_t)r * B);
+#pragma unroll 4
+    for (int b = 0; b < B; ++b) {
+      const float w = cr[b];
+      const float *vp = V + ((int64_t)b * N + j) * F;
+      if (VEC2) {
+#pragma unroll
+        for (int o = 0; o < FT; o += 2)
+          if (o < F) {
+            const float2 vv = *reinterpret_cast<const float2 *>(vp + o);
+            acc[o] = fmaf(w, vv.x, acc[o]);
+            acc[o + 1] = fmaf(w, vv.y, acc[o + 1]);
+          }
+      } else {
+#pragma unroll
+        for (int o = 0; o < FT; ++o)
+          if (o < F) acc[o] = fmaf(w, vp[o], acc[o]);
+      }
+    }
+    float *m = M + pos * ldM;
+    if ((ldM & 3) == 0 && (FW & 3) == 0) {
+#pragma unroll
+      for (int o = 0; o < FT; o += 4)
+        if (o < FW) {
+          float4 q;
+          q.x = (o + 0 < F) ? acc[o + 0] : 0.f;
+          q.y = (o + 1 < F) ? acc[o + 1] : 0.f;
+          q.z = (o + 2 < F) ? acc[o + 2] : 0.f;
+          q.w = (o + 3 < F) ? acc[o + 3] : 0.f;
+          *reinterpret_cast<float4 *>(m + o) = q;
+        }
+    } else {
+#pragma unroll
+      for (int o = 0; o < FT; ++o)
+        if (o < FW) m[o] = (o < F) ? acc[o] : 0.f;
     }
   }
 }
@@ -80,18 +204,19 @@ __global__ __launch_bounds__(kTB) void k_mix_fwd(const int32_t *__restrict__ npt
 //                   accumulated with LDS float atomics per block, one global flush per block.
 // =====================================================================================
 template <int BT>
-__global__ __launch_bounds__(kTB) void k_mix_bwd_dv(const int32_t *__restrict__ nptr,
-                                                    const int32_t *__restrict__ urel,
-                                                    const float *__restrict__ dM, int64_t ldM,
-                                                    const float *__restrict__ comp, int64_t N, int R,
-                                                    int B, int b0, int F, float *__restrict__ dV,
-                                                    int comp_in_lds) {
-  extern __shared__ float s_comp[];  // [R][BT]
+__global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict__ nptr,
+                                                       const int32_t *__restrict__ urel,
+                                                       const float *__restrict__ dM, int64_t ldM,
+                                                       const float *__restrict__ comp, int64_t N, int R,
+                                                       int B, int b0, int F, float *__restrict__ dV,
+                                                       int comp_in_lds) {
+  extern __shared__ __align__(16) float s_comp[];  // [R][CS]
+  constexpr int CS = comp_stride(BT);
   const int nb = min(BT, B - b0);
   if (comp_in_lds) {
     for (int t = threadIdx.x; t < R * BT; t += blockDim.x) {
       int r = t / BT, b = t - r * BT;
-      s_comp[t] = (b < nb) ? comp[(int64_t)r * B + b0 + b] : 0.f;
+      s_comp[r * CS + b] = (b < nb) ? comp[(int64_t)r * B + b0 + b] : 0.f;
     }
     __syncthreads();
   }
@@ -101,39 +226,51 @@ __global__ __launch_bounds__(kTB) void k_mix_bwd_dv(const int32_t *__restrict__ 
     const int64_t j = t / F;
     const int o = (int)(t - j * F);
     const int32_t c0 = nptr[j], c1 = nptr[j + 1];
+    int rr[kPre];
+    float dd[kPre];
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+      const bool in = c0 + i < c1;
+      rr[i] = in ? urel[c0 + i] : 0;
+      dd[i] = in ? dM[(int64_t)(c0 + i) * ldM + o] : 0.f;
+    }
     float acc[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[b] = 0.f;
-    for (int32_t c = c0; c < c1; ++c) {
-      const int r = urel[c];
-      const float d = dM[(int64_t)c * ldM + o];
+    auto take = [&](int r, float d) {
       if (comp_in_lds) {
-        const float *cr = s_comp + r * BT;
+        float w[BT];
+        load_comp_row<BT>(s_comp + r * CS, w);
 #pragma unroll
-        for (int b = 0; b < BT; ++b) acc[b] = fmaf(cr[b], d, acc[b]);
+        for (int b = 0; b < BT; ++b) acc[b] = fmaf(w[b], d, acc[b]);
       } else {
         const float *cr = comp + (int64_t)r * B + b0;
 #pragma unroll
         for (int b = 0; b < BT; ++b)
           if (b < nb) acc[b] = fmaf(cr[b], d, acc[b]);
       }
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < kPre; ++i)
+      if (c0 + i < c1) take(rr[i], dd[i]);
+    for (int32_t c = c0 + kPre; c < c1; ++c) take(urel[c], dM[(int64_t)c * ldM + o]);
 #pragma unroll
     for (int b = 0; b < BT; ++b)
       if (b < nb) dV[((int64_t)(b0 + b) * N + j) * F + o] = acc[b];
   }
 }
 
-template <int FT>
-__global__ __launch_bounds__(kTB) void k_mix_bwd_dcomp(const int32_t *__restrict__ urel,
-                                                       const int32_t *__restrict__ unode,
-                                                       const float *__restrict__ dM, int64_t ldM,
-                                                       const float *__restrict__ V, int64_t N, int R,
-                                                       int B, int F, int64_t ncols,
-                                                       float *__restrict__ dcomp, int dcomp_in_lds) {
-  extern __shared__ float s_dcomp[];  // [R][B]
+template <int FT, bool VEC2>
+__global__ __launch_bounds__(kMixTB) void k_mix_bwd_dcomp(const int32_t *__restrict__ urel,
+                                                          const int32_t *__restrict__ unode,
+                                                          const float *__restrict__ dM, int64_t ldM,
+                                                          const float *__restrict__ V, int64_t N, int R,
+                                                          int B, int F, int64_t ncols,
+                                                          float *__restrict__ dcomp, int dcomp_in_lds) {
+  extern __shared__ float s_dcomp[];  // [R][BS], BS = B | 1: lanes hold different relations
+  const int BS = B | 1;
   if (dcomp_in_lds) {
-    for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_dcomp[t] = 0.f;
+    for (int t = threadIdx.x; t < R * BS; t += blockDim.x) s_dcomp[t] = 0.f;
     __syncthreads();
   }
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols;
@@ -147,46 +284,58 @@ __global__ __launch_bounds__(kTB) void k_mix_bwd_dcomp(const int32_t *__restrict
     for (int b = 0; b < B; ++b) {
       const float *vp = V + ((int64_t)b * N + j) * F;
       float dot = 0.f;
+      if (VEC2) {  // F even: rows of V are 8-byte aligned
 #pragma unroll
-      for (int o = 0; o < FT; ++o)
-        if (o < F) dot = fmaf(dm[o], vp[o], dot);
-      if (dcomp_in_lds) atomicAdd(&s_dcomp[r * B + b], dot);
+        for (int o = 0; o < FT; o += 2)
+          if (o < F) {
+            const float2 vv = *reinterpret_cast<const float2 *>(vp + o);
+            dot = fmaf(dm[o], vv.x, dot);
+            dot = fmaf(dm[o + 1], vv.y, dot);
+          }
+      } else {
+#pragma unroll
+        for (int o = 0; o < FT; ++o)
+          if (o < F) dot = fmaf(dm[o], vp[o], dot);
+      }
+      if (dcomp_in_lds) atomicAdd(&s_dcomp[r * BS + b], dot);
       else atomicAdd(&dcomp[(int64_t)r * B + b], dot);
     }
   }
   if (dcomp_in_lds) {
     __syncthreads();
     for (int t = threadIdx.x; t < R * B; t += blockDim.x) {
-      const float x = s_dcomp[t];
+      const int r = t / B, b = t - r * B;
+      const float x = s_dcomp[r * BS + b];
       if (x != 0.f) atomicAdd(&dcomp[t], x);
     }
   }
 }
 
 // =====================================================================================
-// no-bases input term: M[c, :] = W[ulcol[c], :]   (row gather of weight_I)
+// no-bases input term: M[mpos[c], :] = W[ulcol[c], :] (+ addend[c, :])
 // =====================================================================================
 __global__ void k_gather_rows(const int32_t *__restrict__ ulcol, const int32_t *__restrict__ mpos,
-                              int64_t ncols,
-                              const float *__restrict__ W, int F, float *__restrict__ M, int64_t ldM,
-                              int accumulate) {
-  const int64_t total = ncols * F;
+                              int64_t ncols, const float *__restrict__ W, int F, int FW,
+                              const float *__restrict__ addend, int64_t ldA, float *__restrict__ M,
+                              int64_t ldM) {
+  const int64_t total = ncols * FW;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t c = t / F;
-    const int o = (int)(t - c * F);
-    float x = W[(int64_t)ulcol[c] * F + o];
-    float *m = M + (int64_t)mpos[c] * ldM + o;
-    *m = accumulate ? (*m + x) : x;
+    const int64_t c = t / FW;
+    const int o = (int)(t - c * FW);
+    float x = 0.f;
+    if (o < F) {
+      x = W[(int64_t)ulcol[c] * F + o];
+      if (addend) x += addend[c * ldA + o];
+    }
+    M[(int64_t)mpos[c] * ldM + o] = x;
   }
 }
 
 // =====================================================================================
-// relation transform, forward: one block per relation chunk (<= kRelChunk compact columns of
-// one relation r, relation-major order `rperm`).  W[r] (K x F) and a gathered X tile
-// (TK columns x K) are staged in LDS; thread = (column in tile, feature o).
-//   M[c, o] (+)= sum_i X[j_c, i] * W[r, i, o]
-// K is processed in slabs of KS so that LDS use is bounded for any K.
+// relation transform fallbacks (shapes outside the MFMA kernels' limits): LDS tiles + FMA.
+// One block per relation chunk (<= kRelChunk compact columns of one relation, relation-major
+// order `rperm`); W[r] (K x F) and a gathered X tile (TK columns x K) staged in LDS.
 // =====================================================================================
 constexpr int kTK = 32;   // columns per LDS tile
 constexpr int kKS = 160;  // K slab held in LDS at once
@@ -196,14 +345,13 @@ __global__ __launch_bounds__(kTB) void k_xform_fwd(const int32_t *__restrict__ r
                                                    const int32_t *__restrict__ relchunk_end,
                                                    const int32_t *__restrict__ rperm,
                                                    const int32_t *__restrict__ unode,
-                                                   const int32_t *__restrict__ mpos,
+                                                   const int32_t *__restrict__ out_index,
                                                    const float *__restrict__ X, int64_t ldX, int K,
-                                                   const float *__restrict__ W, int F,
-                                                   float *__restrict__ M, int64_t ldM,
-                                                   int accumulate) {
+                                                   const float *__restrict__ W, int F, int FW,
+                                                   float *__restrict__ M, int64_t ldM) {
   extern __shared__ float smem[];
-  float *Ws = smem;                 // [KS][F]
-  float *Xs = smem + kKS * F;       // [TK][KS+1]
+  float *Ws = smem;            // [KS][F]
+  float *Xs = smem + kKS * F;  // [TK][KS+1]
   __shared__ int32_t s_c[kTK], s_j[kTK];
   const int chunk = blockIdx.x;
   const int r = relchunk_rel[chunk];
@@ -216,10 +364,9 @@ __global__ __launch_bounds__(kTB) void k_xform_fwd(const int32_t *__restrict__ r
     __syncthreads();
     if (threadIdx.x < nk) {
       int32_t c = rperm[t0 + threadIdx.x];
-      s_c[threadIdx.x] = mpos[c];
+      s_c[threadIdx.x] = out_index ? out_index[c] : c;
       s_j[threadIdx.x] = unode[c];
     }
-    // per-thread outputs: pairs (kk, o), strided over the block (static register indices)
     constexpr int NQ = (kTK * 64 + kTB - 1) / kTB;  // F <= 64
     float acc[NQ];
     const int npairs = nk * F;
@@ -251,18 +398,18 @@ __global__ __launch_bounds__(kTB) void k_xform_fwd(const int32_t *__restrict__ r
       const int p = q * kTB + threadIdx.x;
       if (p < npairs) {
         const int kk = p / F, o = p - kk * F;
-        float *m = M + (int64_t)s_c[kk] * ldM + o;
-        *m = accumulate ? (*m + acc[q]) : acc[q];
+        M[(int64_t)s_c[kk] * ldM + o] = acc[q];
       }
     }
+    // zero the padding of the rows just written
+    if (FW > F)
+      for (int p = threadIdx.x; p < nk * (FW - F); p += kTB) {
+        const int kk = p / (FW - F), o = F + p - kk * (FW - F);
+        M[(int64_t)s_c[kk] * ldM + o] = 0.f;
+      }
   }
 }
 
-// =====================================================================================
-// relation transform, backward w.r.t. W:  dW[r, i, o] = sum_{c in r} X[j_c, i] * dM[c, o]
-// one block per relation chunk; X tile and dM tile in LDS; thread owns pairs (i, o);
-// one atomicAdd per (block, i, o) into the zero-initialised dW.
-// =====================================================================================
 constexpr int kPP = 8;  // (i, o) pairs per thread per pass
 
 __global__ __launch_bounds__(kTB) void k_xform_bwd_dw(const int32_t *__restrict__ relchunk_rel,
@@ -279,8 +426,8 @@ __global__ __launch_bounds__(kTB) void k_xform_bwd_dw(const int32_t *__restrict_
   const int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
   __shared__ int32_t s_c[kTK], s_j[kTK];
   const int XS = kKS + 1;
-  float *Xs = smem;               // [TK][KS+1]
-  float *Ds = smem + kTK * XS;    // [TK][F]
+  float *Xs = smem;             // [TK][KS+1]
+  float *Ds = smem + kTK * XS;  // [TK][F]
   float *dWr = dW + (int64_t)r * K * F;
 
   for (int k0 = 0; k0 < K; k0 += kKS) {
@@ -328,11 +475,7 @@ __global__ __launch_bounds__(kTB) void k_xform_bwd_dw(const int32_t *__restrict_
   }
 }
 
-// =====================================================================================
-// relation transform, backward w.r.t. X (node-major; no atomics):
-//   dX[j, i] = sum_{c in node j} sum_o dM[c, o] * W[r_c, i, o]
-// thread = (node j, input feature i)
-// =====================================================================================
+// dX[j, i] = sum_{c in node j} sum_o dM[c, o] * W[r_c, i, o]   (node-major; no atomics)
 __global__ __launch_bounds__(kTB) void k_xform_bwd_dx(const int32_t *__restrict__ nptr,
                                                       const int32_t *__restrict__ urel,
                                                       const float *__restrict__ dM, int64_t ldM,
@@ -354,14 +497,30 @@ __global__ __launch_bounds__(kTB) void k_xform_bwd_dx(const int32_t *__restrict_
   }
 }
 
-int grid_for(int64_t work_items, int max_blocks = 256 * 8) {
-  int64_t b = (work_items + kTB - 1) / kTB;
+int grid_for(int64_t work_items, int tb = kTB, int max_blocks = 256 * 8) {
+  int64_t b = (work_items + tb - 1) / tb;
   if (b < 1) b = 1;
   if (b > max_blocks) b = max_blocks;
   return (int)b;
 }
 
 constexpr size_t kLdsBudget = 64 * 1024;  // dynamic LDS these kernels may take
+
+bool use_mfma() {
+  static const bool v = !(getenv("MRGCN_XFORM_MFMA") && atoi(getenv("MRGCN_XFORM_MFMA")) == 0);
+  return v;
+}
+
+// persistent grid of 512-thread blocks for a kernel that takes `lds` bytes of LDS
+int mix_grid(size_t lds, int64_t work_items) {
+  int per_cu = lds > 0 ? (int)((160 * 1024) / (lds + 256)) : 4;
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  int64_t want = (work_items + kMixTB - 1) / kMixTB;
+  int64_t grid = 256 * per_cu * 2;  // two rounds: evens out the tail
+  if (grid > want) grid = want;
+  return (int)(grid < 1 ? 1 : grid);
+}
 
 }  // namespace
 }  // namespace mrgcn
@@ -371,24 +530,59 @@ using namespace mrgcn;
 extern "C" {
 
 int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *p, const float *V, const float *comp, int32_t B,
-                            int32_t F, float *M, int64_t ldM, int32_t accumulate, void *stream) {
+                            int32_t F, const float *addend, int64_t ldA, float *M, int64_t ldM,
+                            void *stream) {
   MRGCN_REQUIRE(p && V && comp && M, "NULL");
   MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
+  MRGCN_REQUIRE(!addend || ldA >= F, "ldA");
   if (p->ncols == 0) return MRGCN_OK;
   hipStream_t s = (hipStream_t)stream;
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
-  int acc = accumulate;
+  const int FW = (int)ldM;  // the whole padded row is written (zeros past F)
+  // node-major is the default: measured 2.7 ms vs 4.95 ms for the column-parallel form (AM shape)
+  static const bool by_cols = getenv("MRGCN_MIX_COLS") && atoi(getenv("MRGCN_MIX_COLS")) != 0;
+  // timing experiments only (wrong results): write rows in compact order instead of operand order
+  static const bool dbg_seq = getenv("MRGCN_DEBUG_MIX_SEQ") && atoi(getenv("MRGCN_DEBUG_MIX_SEQ")) != 0;
+  const int32_t *mpos_arg = dbg_seq ? nullptr : p->mpos;
+  if (by_cols && B <= 64 && F <= 64 && FW <= 64) {
+    size_t lds = (size_t)R * (B | 1) * sizeof(float);
+    int in_lds = lds <= kLdsBudget;
+    if (!in_lds) lds = 0;
+    int grid = mix_grid(lds, p->ncols);
+    const bool v2 = (F % 2 == 0) && (((uintptr_t)V) % 8 == 0);
+    const int need = FW > F ? FW : F;
+#define MIXC_GO(T)                                                                                      \
+  do {                                                                                                  \
+    if (v2)                                                                                             \
+      k_mix_fwd_cols<T, true><<<dim3(grid), dim3(kMixTB), lds, s>>>(                                    \
+          p->urel, p->unode, mpos_arg, V, comp, N, R, B, F, FW, addend, ldA, M, ldM, p->ncols, in_lds);  \
+    else                                                                                                \
+      k_mix_fwd_cols<T, false><<<dim3(grid), dim3(kMixTB), lds, s>>>(                                   \
+          p->urel, p->unode, mpos_arg, V, comp, N, R, B, F, FW, addend, ldA, M, ldM, p->ncols, in_lds);  \
+  } while (0)
+    if (need <= 4) MIXC_GO(4);
+    else if (need <= 8) MIXC_GO(8);
+    else if (need <= 12) MIXC_GO(12);
+    else if (need <= 16) MIXC_GO(16);
+    else if (need <= 32) MIXC_GO(32);
+    else MIXC_GO(64);
+#undef MIXC_GO
+    MRGCN_HIP_TRY(hipGetLastError());
+    return MRGCN_OK;
+  }
+  int acc = 0;
   for (int b0 = 0; b0 < B; b0 += 64) {
     const int nb = (B - b0 < 64) ? (B - b0) : 64;
     int BT = nb <= 2 ? 2 : nb <= 4 ? 4 : nb <= 8 ? 8 : nb <= 16 ? 16 : nb <= 32 ? 32 : nb <= 40 ? 40 : 64;
-    size_t lds = (size_t)R * BT * sizeof(float);
+    size_t lds = (size_t)R * comp_stride(BT) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
-    int grid = grid_for(N * F);
-#define MIX_GO(T)                                                                               \
-  k_mix_fwd<T><<<dim3(grid), dim3(kTB), lds, s>>>(p->nptr, p->urel, p->mpos, V, comp, N, R, B, b0, F, M, \
-                                                  ldM, acc, in_lds)
+    int grid = mix_grid(lds, N * FW);
+    const float *add = acc ? nullptr : addend;
+#define MIX_GO(T)                                                                                    \
+  k_mix_fwd<T><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->nptr, p->urel, mpos_arg, V, comp, N, R, B, b0, \
+                                                     F, FW, add, ldA, M, ldM, acc, in_lds)
     switch (BT) {
       case 2: MIX_GO(2); break;
       case 4: MIX_GO(4); break;
@@ -415,19 +609,17 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
   MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)R * B * sizeof(float), s));
-  // nodes without any column never get written by the kernel: zero dV first only then
-  // (full-batch graphs carry the identity block, so every node owns >= 1 column)
   // pass 1: dV
   for (int b0 = 0; b0 < B; b0 += 64) {
     const int nb = (B - b0 < 64) ? (B - b0) : 64;
     int BT = nb <= 2 ? 2 : nb <= 4 ? 4 : nb <= 8 ? 8 : nb <= 16 ? 16 : nb <= 32 ? 32 : nb <= 40 ? 40 : 64;
-    size_t lds = (size_t)R * BT * sizeof(float);
+    size_t lds = (size_t)R * comp_stride(BT) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
-    int grid = grid_for(N * F);
-#define MIXDV_GO(T)                                                                               \
-  k_mix_bwd_dv<T><<<dim3(grid), dim3(kTB), lds, s>>>(p->nptr, p->urel, dM, ldM, comp, N, R, B, b0, \
-                                                     F, dV, in_lds)
+    int grid = mix_grid(lds, N * F);
+#define MIXDV_GO(T)                                                                                    \
+  k_mix_bwd_dv<T><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->nptr, p->urel, dM, ldM, comp, N, R, B, b0, \
+                                                        F, dV, in_lds)
     switch (BT) {
       case 2: MIXDV_GO(2); break;
       case 4: MIXDV_GO(4); break;
@@ -442,18 +634,20 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
   }
   // pass 2: dcomp
   if (p->ncols > 0) {
-    size_t lds = (size_t)R * B * sizeof(float);
+    size_t lds = (size_t)R * (B | 1) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
-    int per_cu = in_lds && lds > 0 ? (int)((160 * 1024) / (lds + 512)) : 8;
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu < 1) per_cu = 1;
-    int64_t want = (p->ncols + kTB - 1) / kTB;
-    int grid = 256 * per_cu;
-    if (grid > want) grid = (int)want;
-#define MIXDC_GO(T)                                                                                 \
-  k_mix_bwd_dcomp<T><<<dim3(grid), dim3(kTB), lds, s>>>(p->urel, p->unode, dM, ldM, V, N, R, B, F, \
-                                                        p->ncols, dcomp, in_lds)
+    int grid = mix_grid(lds, p->ncols);
+    const bool v2 = (F % 2 == 0) && (((uintptr_t)V) % 8 == 0);
+#define MIXDC_GO(T)                                                                                     \
+  do {                                                                                                  \
+    if (v2)                                                                                             \
+      k_mix_bwd_dcomp<T, true><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->urel, p->unode, dM, ldM, V, N,  \
+                                                                     R, B, F, p->ncols, dcomp, in_lds); \
+    else                                                                                                \
+      k_mix_bwd_dcomp<T, false><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->urel, p->unode, dM, ldM, V, N, \
+                                                                      R, B, F, p->ncols, dcomp, in_lds); \
+  } while (0)
     if (F <= 4) MIXDC_GO(4);
     else if (F <= 8) MIXDC_GO(8);
     else if (F <= 12) MIXDC_GO(12);
@@ -466,49 +660,74 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
   return MRGCN_OK;
 }
 
-int mrgcn_gather_rows_f32(const mrgcn_plan_t *p, const float *W, int32_t F, float *M, int64_t ldM,
-                          int32_t accumulate, void *stream) {
+int mrgcn_gather_rows_f32(const mrgcn_plan_t *p, const float *W, int32_t F, const float *addend,
+                          int64_t ldA, float *M, int64_t ldM, void *stream) {
   MRGCN_REQUIRE(p && W && M, "NULL");
   MRGCN_REQUIRE(F > 0 && ldM >= F, "F / ldM");
+  MRGCN_REQUIRE(!addend || ldA >= F, "ldA");
   if (p->ncols == 0) return MRGCN_OK;
-  k_gather_rows<<<dim3(grid_for(p->ncols * F)), dim3(kTB), 0, (hipStream_t)stream>>>(
-      p->ulcol, p->mpos, p->ncols, W, F, M, ldM, accumulate);
+  k_gather_rows<<<dim3(grid_for(p->ncols * ldM)), dim3(kTB), 0, (hipStream_t)stream>>>(
+      p->ulcol, p->mpos, p->ncols, W, F, (int)ldM, addend, ldA, M, ldM);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
 
 int mrgcn_rel_transform_fwd_f32(const mrgcn_plan_t *p, const float *X, int64_t ldX, int32_t K,
-                                const float *W, int32_t F, float *M, int64_t ldM, int32_t accumulate,
-                                void *stream) {
-  MRGCN_REQUIRE(p && X && W && M, "NULL");
-  MRGCN_REQUIRE(K > 0 && F > 0 && ldX >= K && ldM >= F, "K / F / leading dimensions");
+                                const float *W, int32_t F, float *Out, int64_t ldOut,
+                                int32_t operand_order, void *stream) {
+  MRGCN_REQUIRE(p && X && W && Out, "NULL");
+  MRGCN_REQUIRE(K > 0 && F > 0 && ldX >= K && ldOut >= F, "K / F / leading dimensions");
   MRGCN_REQUIRE(F <= 64, "rel_transform supports F <= 64 (tile the feature dimension)");
   if (p->n_relchunks == 0) return MRGCN_OK;
+  const int32_t *oidx = operand_order ? p->mpos : nullptr;
+  if (use_mfma() && xform_mfma_fwd_supported(K, F))
+    return xform_mfma_fwd(p, p->rnode, operand_order ? p->rmpos : nullptr, X, ldX, K, W, false, F, Out,
+                          ldOut, (hipStream_t)stream);
   size_t lds = ((size_t)kKS * F + (size_t)kTK * (kKS + 1)) * sizeof(float);
   k_xform_fwd<<<dim3(p->n_relchunks), dim3(kTB), lds, (hipStream_t)stream>>>(
-      p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, p->unode, p->mpos, X, ldX, K, W, F, M,
-      ldM, accumulate);
+      p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, p->unode, oidx, X, ldX, K, W, F,
+      (int)ldOut, Out, ldOut);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
 
+int64_t mrgcn_rel_transform_bwd_workspace(const mrgcn_plan_t *p, int32_t K, int32_t F, int32_t need_dX,
+                                          int32_t need_dW) {
+  if (!p) return 0;
+  int64_t a = need_dX ? p->ncols * (((int64_t)K + 3) / 4 * 4) : 0;
+  int64_t b = need_dW ? (int64_t)p->n_relchunks * K * F : 0;
+  return a > b ? a : b;
+}
+
 int mrgcn_rel_transform_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *X,
                                 int64_t ldX, int32_t K, const float *W, int32_t F, float *dX,
-                                int64_t lddX, float *dW, void *stream) {
+                                int64_t lddX, float *dW, float *workspace, int64_t workspace_floats,
+                                void *stream) {
   MRGCN_REQUIRE(p && dM && X && W, "NULL");
   MRGCN_REQUIRE(K > 0 && F > 0 && ldX >= K && ldM >= F, "K / F / leading dimensions");
   MRGCN_REQUIRE(F <= 64, "rel_transform supports F <= 64 (tile the feature dimension)");
   hipStream_t s = (hipStream_t)stream;
   if (dW) {
     MRGCN_HIP_TRY(hipMemsetAsync(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
-    if (p->n_relchunks > 0) {
+    if (use_mfma() && xform_mfma_dw_supported(K, F)) {
+      int rc = xform_mfma_dw(p, p->rnode, X, ldX, K, dM, ldM, F, dW, workspace, workspace_floats, s);
+      if (rc != MRGCN_OK) return rc;
+    } else if (p->n_relchunks > 0) {
       size_t lds = ((size_t)kTK * (kKS + 1) + (size_t)kTK * F) * sizeof(float);
       k_xform_bwd_dw<<<dim3(p->n_relchunks), dim3(kTB), lds, s>>>(
           p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, p->unode, X, ldX, K, dM, ldM, F, dW);
       MRGCN_HIP_TRY(hipGetLastError());
     }
   }
-  if (dX) {
+  const int64_t ldZ = ((int64_t)K + 3) / 4 * 4;
+  if (dX && use_mfma() && workspace && workspace_floats >= p->ncols * ldZ && xform_mfma_fwd_supported(F, K)) {
+    // Z[c, 0:K] = dM[c, 0:F] . W[r_c]^T on the matrix cores, then dX[j] = sum of node j's Z rows
+    MRGCN_REQUIRE(lddX >= K, "lddX");
+    int rc = xform_mfma_fwd(p, nullptr, nullptr, dM, ldM, F, W, true, K, workspace, ldZ, s);
+    if (rc != MRGCN_OK) return rc;
+    rc = segment_sum(p, workspace, ldZ, K, dX, lddX, s);
+    if (rc != MRGCN_OK) return rc;
+  } else if (dX) {
     MRGCN_REQUIRE(lddX >= K, "lddX");
     k_xform_bwd_dx<<<dim3(grid_for(p->num_nodes * K)), dim3(kTB), 0, s>>>(
         p->nptr, p->urel, dM, ldM, W, p->num_nodes, K, F, dX, lddX);

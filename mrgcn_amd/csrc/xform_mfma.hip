@@ -1,0 +1,343 @@
+// Per-relation dense transforms on the matrix cores (f32-in / f32-acc MFMA 16x16x4: exact f32,
+// one rounding per product, k-ordered fmaf chain) — the one place on the R-GCN path where the
+// contraction really is dense (north_star): for every compact column c = (node j_c, relation r_c)
+//
+//   fwd   Out[o(c), n]   = sum_k In[i(c), k] * Wm[r_c][k][n]             (graph.py:93-94)
+//   dW    dW[r][i][o]    += sum_{c in r} In[i(c), i] * G[c, o]              (its autograd)
+//
+// Columns are walked relation-major (`rperm`, chunks of <= kRelChunk columns of ONE relation per
+// block), so a block stages its relation's weight tile in LDS once and every wave multiplies
+// 16 gathered rows at a time.  Replaces the LDS-FMA kernels of rgcn_fused.hip (which stay as the
+// fallback for shapes outside the limits below).
+//
+// MFMA 16x16x4 f32 lane maps (cdna_hip_programming.md §3): A[l&15][k=l>>4], B[k=l>>4][l&15],
+// D: col = l&15, row = 4*(l>>4) + reg.  The k slot <-> actual k assignment is free as long as A
+// and B agree: slot kq of the s-th MFMA of a 16-wide K step stands for k = k0 + 4*kq + s, so a
+// lane feeds four MFMAs from ONE 16-byte load of its gathered row.
+#include "common.hpp"
+
+namespace mrgcn {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kMaxKSteps = 16;  // K <= 256 for the forward
+constexpr int kMaxNT = 4;       // F <= 64
+
+__device__ __forceinline__ f32x4 load4_guarded(const float *row, int k, int K) {
+  // the last K step of a row: element-wise, zero past K (never reads past the row)
+  f32x4 v;
+  v.x = (k + 0 < K) ? row[k + 0] : 0.f;
+  v.y = (k + 1 < K) ? row[k + 1] : 0.f;
+  v.z = (k + 2 < K) ? row[k + 2] : 0.f;
+  v.w = (k + 3 < K) ? row[k + 3] : 0.f;
+  return v;
+}
+
+__device__ __forceinline__ f32x4 load4_fast(const float *p) {
+  // 16-byte load from a dword-aligned address (global loads need dword alignment only)
+  return *reinterpret_cast<const f32x4 *>(p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: Out[o(c), 0:ldOut] = [ In[i(c), 0:K] . Wm[r][0:K][0:F] | 0 ]   (write only)
+//   TRANS_W = false: Wm[r][k][n] = W[(r*K + k)*F + n]        (weights stored [R][K][F])
+//   TRANS_W = true : Wm[r][k][n] = W[(r*F + n)*K + k]        (weights stored [R][F][K])
+//   rin_idx / rout_idx: nullable int32 [ncols] in RELATION-MAJOR order (aligned with rperm):
+//   input / output row of each column; null = the compact id rperm[e] itself
+// ---------------------------------------------------------------------------------------------
+template <int NT, bool TRANS_W>
+__global__ __launch_bounds__(256) void k_xform_mfma_fwd(
+    const int32_t *__restrict__ relchunk_rel, const int32_t *__restrict__ relchunk_beg,
+    const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
+    const int32_t *__restrict__ rin_idx, const int32_t *__restrict__ rout_idx,
+    const float *__restrict__ In, int64_t ldIn, int K, const float *__restrict__ W, int F,
+    float *__restrict__ Out, int64_t ldOut) {
+  extern __shared__ float WsT[];  // [NT*16][KP]: n-major, k contiguous, zero padded
+  const int ksteps = (K + 15) >> 4;
+  const int KP = ksteps * 16 + 4;  // +4 floats: rows start on different banks
+  const int chunk = blockIdx.x;
+  const int r = relchunk_rel[chunk];
+  const int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
+  for (int t = threadIdx.x; t < NT * 16 * KP; t += blockDim.x) {
+    const int n = t / KP, k = t - n * KP;
+    float w = 0.f;
+    if (n < F && k < K)
+      w = TRANS_W ? W[((int64_t)r * F + n) * K + k] : W[((int64_t)r * K + k) * F + n];
+    WsT[t] = w;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  // relation-major position e -> input row / output row; the indices of the next tile are
+  // fetched while the current one is multiplied (no dependent index round trips in the loop)
+  auto fetch = [&](int32_t e, int32_t &valid, int32_t &rin, int32_t &rout) {
+    valid = e < end ? 1 : -1;
+    const int32_t ee = e < end ? e : beg;
+    const int32_t c = (rin_idx && rout_idx) ? 0 : rperm[ee];
+    rin = rin_idx ? rin_idx[ee] : c;
+    rout = rout_idx ? rout_idx[ee] : c;
+  };
+  int32_t n_valid, n_rin, n_rout;
+  fetch(beg + wv * 16 + m, n_valid, n_rin, n_rout);
+  for (int32_t t0 = beg + wv * 16; t0 < end; t0 += 64) {  // 4 waves x 16 columns per sweep
+    const int32_t cid = n_valid, my_rout = n_rout;
+    const int64_t rin = n_rin;
+    fetch(t0 + 64 + m, n_valid, n_rin, n_rout);
+    const float *xrow = In + rin * ldIn;
+    // all K steps of the gathered row in flight at once
+    f32x4 a[kMaxKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kMaxKSteps; ++ks) {
+      if (ks < ksteps) {
+        const int k = ks * 16 + 4 * kq;
+        a[ks] = (k + 4 <= K) ? load4_fast(xrow + k) : load4_guarded(xrow, k, K);
+      }
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < kMaxKSteps; ++ks) {
+      if (ks < ksteps) {
+        f32x4 av = a[ks];
+        if (cid < 0) av = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const f32x4 bv = *reinterpret_cast<const f32x4 *>(&WsT[(nt * 16 + m) * KP + ks * 16 + 4 * kq]);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    // D: lane (n = l&15, g = l>>4) holds rows 4g + reg of the 16-column tile, feature nt*16 + n
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int32_t ok = __shfl(cid, 4 * kq + reg, 64);
+      const int64_t orow = __shfl(my_rout, 4 * kq + reg, 64);
+      if (ok < 0) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + m;
+        if (n < ldOut) Out[orow * ldOut + n] = acc[nt][reg];  // zeros past F: whole padded row
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW[r][i][o] += sum_{c in chunk} In[i(c), i] * G[c, o]        (K = rows of dW per relation <= 256,
+// F <= 16).  M dimension = i, N = o, MFMA k = columns.  Lane m of k-group kq loads 16 bytes
+// In[i(c_kq), 64*tq + 4m .. +3]: four M tiles (s = 0..3) where tile (tq, s) row m is i = 64tq+4m+s.
+// Per block: LDS accumulation over the 4 waves, then one global atomicAdd per element.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxTQ = 4;  // K <= 256
+
+__global__ __launch_bounds__(256) void k_xform_mfma_dw(
+    const int32_t *__restrict__ relchunk_rel, const int32_t *__restrict__ relchunk_beg,
+    const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
+    const int32_t *__restrict__ rin_idx, const float *__restrict__ In, int64_t ldIn, int K,
+    const float *__restrict__ G, int64_t ldG, int F, float *__restrict__ dW,
+    float *__restrict__ slab) {
+  extern __shared__ float dWs[];  // [K*F]
+  const int chunk = blockIdx.x;
+  const int r = relchunk_rel[chunk];
+  const int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
+  for (int t = threadIdx.x; t < K * F; t += blockDim.x) dWs[t] = 0.f;
+  __syncthreads();
+  const int ntq = (K + 63) >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  f32x4 acc[kMaxTQ * 4];
+#pragma unroll
+  for (int t = 0; t < kMaxTQ * 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int U = 4;  // column groups in flight per wave
+  // indices of the next sweep are fetched while the current one is multiplied
+  int32_t n_cid[U], n_rin[U];
+  auto fetch = [&](int32_t t0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t e = t0 + 4 * u + kq;
+      const int32_t ee = e < end ? e : beg;
+      const int32_t c = rperm[ee];
+      n_cid[u] = e < end ? c : -1;
+      n_rin[u] = rin_idx ? rin_idx[ee] : c;
+    }
+  };
+  fetch(beg + wv * 4 * U);
+  for (int32_t t0 = beg + wv * 4 * U; t0 < end; t0 += 16 * U) {  // 4 waves x (U x 4) columns per sweep
+    f32x4 a[U][kMaxTQ];
+    float b[U];
+    int32_t cidv[U], rinv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { cidv[u] = n_cid[u]; rinv[u] = n_rin[u]; }
+    fetch(t0 + 16 * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t cid = cidv[u];
+      const float *xrow = In + (int64_t)rinv[u] * ldIn;
+      b[u] = (cid >= 0 && m < F) ? G[(int64_t)cid * ldG + m] : 0.f;
+#pragma unroll
+      for (int tq = 0; tq < kMaxTQ; ++tq) {
+        if (tq < ntq) {
+          const int i = 64 * tq + 4 * m;
+          a[u][tq] = (i + 4 <= K) ? load4_fast(xrow + i) : load4_guarded(xrow, i, K);
+          if (cid < 0) a[u][tq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int tq = 0; tq < kMaxTQ; ++tq) {
+        if (tq < ntq) {
+          acc[tq * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].x, b[u], acc[tq * 4 + 0], 0, 0, 0);
+          acc[tq * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].y, b[u], acc[tq * 4 + 1], 0, 0, 0);
+          acc[tq * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].z, b[u], acc[tq * 4 + 2], 0, 0, 0);
+          acc[tq * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].w, b[u], acc[tq * 4 + 3], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D of tile (tq, s): lane (o = l&15, g = l>>4), reg -> row m' = 4g + reg -> i = 64tq + 4m' + s
+#pragma unroll
+  for (int tq = 0; tq < kMaxTQ; ++tq) {
+    if (tq < ntq) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int i = 64 * tq + 4 * (4 * kq + reg) + s;
+          if (i < K && m < F) atomicAdd(&dWs[i * F + m], acc[tq * 4 + s][reg]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (slab) {  // per-chunk partial, summed per relation by k_dw_reduce (no contended atomics)
+    float *out = slab + (int64_t)chunk * K * F;
+    for (int t = threadIdx.x; t < K * F; t += blockDim.x) out[t] = dWs[t];
+  } else {
+    float *dWr = dW + (int64_t)r * K * F;
+    for (int t = threadIdx.x; t < K * F; t += blockDim.x) {
+      const float x = dWs[t];
+      if (x != 0.f) atomicAdd(&dWr[t], x);
+    }
+  }
+}
+
+// dW[r] += sum of the slab rows of a segment of <= kDwSeg chunks of relation r
+constexpr int kDwSeg = 32;
+__global__ __launch_bounds__(256) void k_dw_reduce(const int32_t *__restrict__ relchunk_rel,
+                                                   const int32_t *__restrict__ relchunk_ptr, int n_seg_max,
+                                                   const float *__restrict__ slab, int KF,
+                                                   float *__restrict__ dW, int R) {
+  // grid.x = R * n_seg_max: (relation, segment)
+  const int r = blockIdx.x / n_seg_max, seg = blockIdx.x - r * n_seg_max;
+  if (r >= R) return;
+  const int c0 = relchunk_ptr[r] + seg * kDwSeg;
+  const int c1 = min(relchunk_ptr[r + 1], c0 + kDwSeg);
+  if (c0 >= c1) return;
+  for (int t = threadIdx.x; t < KF; t += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f;
+    int c = c0;
+    for (; c + 2 <= c1; c += 2) {
+      s0 += slab[(int64_t)c * KF + t];
+      s1 += slab[(int64_t)(c + 1) * KF + t];
+    }
+    if (c < c1) s0 += slab[(int64_t)c * KF + t];
+    const float s = s0 + s1;
+    if (relchunk_ptr[r + 1] - relchunk_ptr[r] <= kDwSeg) dW[(int64_t)r * KF + t] = s;  // sole writer
+    else if (s != 0.f) atomicAdd(&dW[(int64_t)r * KF + t], s);
+  }
+}
+
+// dX[j, 0:K] = sum of the rows Z[nptr[j] .. nptr[j+1]) (Z in compact (j, r) order)
+__global__ void k_segment_sum(const int32_t *__restrict__ nptr, const float *__restrict__ Z, int64_t ldZ,
+                              int64_t N, int K, float *__restrict__ dX, int64_t lddX) {
+  const int64_t total = N * K;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = t / K;
+    const int i = (int)(t - j * K);
+    const int32_t c0 = nptr[j], c1 = nptr[j + 1];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int32_t c = c0;
+    for (; c + 4 <= c1; c += 4) {
+      s0 += Z[(int64_t)c * ldZ + i];
+      s1 += Z[(int64_t)(c + 1) * ldZ + i];
+      s2 += Z[(int64_t)(c + 2) * ldZ + i];
+      s3 += Z[(int64_t)(c + 3) * ldZ + i];
+    }
+    for (; c < c1; ++c) s0 += Z[(int64_t)c * ldZ + i];
+    dX[j * lddX + i] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+}  // namespace
+
+// ---- launchers used by the C ABI entry points in rgcn_fused.hip -------------------------------
+bool xform_mfma_fwd_supported(int K, int F) { return K <= kMaxKSteps * 16 && F <= kMaxNT * 16; }
+bool xform_mfma_dw_supported(int K, int F) { return K <= kMaxTQ * 64 && F <= 16 && (size_t)K * F * 4 <= 48 * 1024; }
+
+int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
+                   int64_t ldIn, int K, const float *W, bool trans_w, int F, float *Out, int64_t ldOut,
+                   hipStream_t s) {
+  if (p->n_relchunks == 0) return MRGCN_OK;
+  int NT = (int)((ldOut < 64 ? ldOut : 64) + 15) / 16;  // tiles that cover the padded row
+  if (NT < (F + 15) / 16) NT = (F + 15) / 16;
+  const int ksteps = (K + 15) / 16;
+  const size_t lds = (size_t)NT * 16 * (ksteps * 16 + 4) * sizeof(float);
+#define XF_GO(N_, T_)                                                                               \
+  k_xform_mfma_fwd<N_, T_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                            \
+      p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn, K,    \
+      W, F, Out, ldOut)
+  if (trans_w) {
+    switch (NT) { case 1: XF_GO(1, true); break; case 2: XF_GO(2, true); break;
+                  case 3: XF_GO(3, true); break; default: XF_GO(4, true); break; }
+  } else {
+    switch (NT) { case 1: XF_GO(1, false); break; case 2: XF_GO(2, false); break;
+                  case 3: XF_GO(3, false); break; default: XF_GO(4, false); break; }
+  }
+#undef XF_GO
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, int64_t ldIn, int K,
+                  const float *G, int64_t ldG, int F, float *dW, float *workspace,
+                  int64_t workspace_floats, hipStream_t s) {
+  if (p->n_relchunks == 0) return MRGCN_OK;
+  const size_t lds = (size_t)K * F * sizeof(float);
+  float *slab = (workspace && workspace_floats >= (int64_t)p->n_relchunks * K * F) ? workspace : nullptr;
+  k_xform_mfma_dw<<<dim3(p->n_relchunks), dim3(256), lds, s>>>(p->relchunk_rel, p->relchunk_beg,
+                                                              p->relchunk_end, p->rperm, rin_idx, In,
+                                                              ldIn, K, G, ldG, F, dW, slab);
+  MRGCN_HIP_TRY(hipGetLastError());
+  if (slab) {
+    const int n_seg_max = (p->max_relchunks + kDwSeg - 1) / kDwSeg;
+    if (n_seg_max > 0) {
+      k_dw_reduce<<<dim3((unsigned)(p->num_relations * n_seg_max)), dim3(256), 0, s>>>(
+          p->relchunk_rel, p->relchunk_ptr, n_seg_max, slab, K * F, dW, (int)p->num_relations);
+      MRGCN_HIP_TRY(hipGetLastError());
+    }
+  }
+  return MRGCN_OK;
+}
+
+int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *dX, int64_t lddX,
+                hipStream_t s) {
+  int64_t work = p->num_nodes * K;
+  int64_t blocks = (work + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  k_segment_sum<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+}  // namespace mrgcn

@@ -2,10 +2,25 @@
 or CPU fallback."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
 from .plan import GraphPlan
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ld_for(F: int) -> int:
+    """Leading dimension of the compact operand: rows padded to a multiple of 4 floats (16-byte
+    float4 gathers).  Measured on the AM shape: 12 vs 16 floats per 10-feature row gather within
+    2 % of each other, while the 12-float rows make the producers' scattered pass ~8 % cheaper.
+    MRGCN_LDM_ALIGN overrides (floats, multiple of 4)."""
+    a = int(os.environ.get("MRGCN_LDM_ALIGN", "4"))
+    return (F + a - 1) // a * a
 
 
 class _SpmmLiteral(torch.autograd.Function):
@@ -28,7 +43,7 @@ class _SpmmLiteral(torch.autograd.Function):
         dY = dY.contiguous()
         (Y,) = ctx.saved_tensors
         if ctx.relu:
-            dY = dY * (Y > 0)
+            dY = relu_bwd(dY, Y)
         dbias = dY.sum(0) if ctx.has_bias else None
         dD = None
         if ctx.needs_input_grad[1]:
@@ -41,56 +56,6 @@ class _SpmmLiteral(torch.autograd.Function):
 
 def spmm_literal(plan: GraphPlan, D: torch.Tensor, bias=None, relu: bool = False) -> torch.Tensor:
     return _SpmmLiteral.apply(plan, D, bias, relu)
-
-
-class _SpmmCompact(torch.autograd.Function):
-    """Y = A' . M with M holding one row per *touched* column, in the plan's (source node,
-    relation) order; M may be padded (leading dimension >= F)."""
-
-    @staticmethod
-    def forward(ctx, plan: GraphPlan, M: torch.Tensor, F: int, bias, relu: bool):
-        Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu)
-        ctx.plan, ctx.relu, ctx.has_bias, ctx.F, ctx.ld = plan, relu, bias is not None, F, M.shape[1]
-        ctx.save_for_backward(Y if relu else None)
-        return Y
-
-    @staticmethod
-    def backward(ctx, dY):
-        plan = ctx.plan
-        dY = dY.contiguous()
-        (Y,) = ctx.saved_tensors
-        if ctx.relu:
-            dY = dY * (Y > 0)
-        dbias = dY.sum(0) if ctx.has_bias else None
-        dM = None
-        if ctx.needs_input_grad[1]:
-            if ctx.ld == ctx.F:
-                dM = torch.empty((plan.ncols, ctx.ld), dtype=torch.float32, device=dY.device)
-            else:
-                dM = torch.zeros((plan.ncols, ctx.ld), dtype=torch.float32, device=dY.device)
-            plan.spmm(L.VIEW_TRANSPOSED, dY, F=ctx.F, out=dM)
-        return None, dM, None, dbias, None
-
-
-def spmm_compact(plan: GraphPlan, M: torch.Tensor, F: int, bias=None, relu: bool = False):
-    return _SpmmCompact.apply(plan, M, F, bias, relu)
-
-
-# ======================================================================================
-# fused R-GCN layer
-# ======================================================================================
-def _stream(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
-
-
-def _ld_for(F: int) -> int:
-    """Leading dimension of the compact operand: rows padded to a multiple of 4 floats so that
-    every gather is 16-byte float4 loads.  (Measured on the AM shape, MI355X: 12 / 16 floats
-    per 10-feature row run within 1 %: with the plan's hot/cold operand order the kernel is
-    bound by request latency, not by the operand's bytes.)  MRGCN_LDM_ALIGN overrides."""
-    import os
-    a = int(os.environ.get("MRGCN_LDM_ALIGN", "4"))
-    return (F + a - 1) // a * a
 
 
 def relu_bwd(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
@@ -113,26 +78,34 @@ class _RgcnLayer(torch.autograd.Function):
         ld = _ld_for(F)
         M = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
         s = _stream(dev)
-        acc = 0
         Xc = Wc = None
         with torch.cuda.device(dev):
+            addend, ldA = 0, 0
+            if X is not None:
+                Xc = X.contiguous()
+                Wc = W_F.contiguous()
+                if weight_I is not None:
+                    # feature term in plain compact order (sequential writes); the input-term
+                    # pass below adds it while it emits the final rows in operand order
+                    ldA = (F + 3) // 4 * 4
+                    M2 = torch.empty((plan.ncols, ldA), dtype=torch.float32, device=dev)
+                    out, ldo, order = M2, ldA, 0
+                    addend = M2.data_ptr()
+                else:
+                    out, ldo, order = M, ld, 1
+                L.check(lib.mrgcn_rel_transform_fwd_f32(plan.handle, Xc.data_ptr(), Xc.stride(0),
+                                                        Xc.shape[1], Wc.data_ptr(), F, out.data_ptr(), ldo,
+                                                        order, s), "mrgcn_rel_transform_fwd_f32")
             if weight_I is not None:
                 wI = weight_I.contiguous()
                 if comp_I is not None:
                     cI = comp_I.contiguous()
                     L.check(lib.mrgcn_basis_mix_fwd_f32(plan.handle, wI.data_ptr(), cI.data_ptr(),
-                                                        cI.shape[1], F, M.data_ptr(), ld, acc, s),
+                                                        cI.shape[1], F, addend, ldA, M.data_ptr(), ld, s),
                             "mrgcn_basis_mix_fwd_f32")
                 else:
-                    L.check(lib.mrgcn_gather_rows_f32(plan.handle, wI.data_ptr(), F, M.data_ptr(), ld,
-                                                      acc, s), "mrgcn_gather_rows_f32")
-                acc = 1
-            if X is not None:
-                Xc = X.contiguous()
-                Wc = W_F.contiguous()
-                L.check(lib.mrgcn_rel_transform_fwd_f32(plan.handle, Xc.data_ptr(), Xc.stride(0),
-                                                        Xc.shape[1], Wc.data_ptr(), F, M.data_ptr(), ld,
-                                                        acc, s), "mrgcn_rel_transform_fwd_f32")
+                    L.check(lib.mrgcn_gather_rows_f32(plan.handle, wI.data_ptr(), F, addend, ldA,
+                                                      M.data_ptr(), ld, s), "mrgcn_gather_rows_f32")
         Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu)
         ctx.plan, ctx.F, ctx.ld, ctx.relu = plan, F, ld, relu
         ctx.has = (weight_I is not None, comp_I is not None, X is not None, bias is not None)
@@ -142,7 +115,7 @@ class _RgcnLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY):
         lib = L.load()
-        plan, F, ld = ctx.plan, ctx.F, ctx.ld
+        plan, F = ctx.plan, ctx.F
         weight_I, comp_I, X, W_F, Y = ctx.saved_tensors
         has_I, has_comp, has_X, has_bias = ctx.has
         dev = plan.device
@@ -151,7 +124,8 @@ class _RgcnLayer(torch.autograd.Function):
         if ctx.relu:
             dY = relu_bwd(dY, Y)
         dbias = dY.sum(0) if has_bias else None
-        # dM = A'^T dY over touched columns only
+        # dM = A'^T dY over touched columns only, plain compact order (its consumers are node-major)
+        ld = (F + 3) // 4 * 4
         dM = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
         plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)
         d_wI = d_comp = dX = dW = None
@@ -177,9 +151,15 @@ class _RgcnLayer(torch.autograd.Function):
                 if need_dW:
                     dW = torch.empty_like(W_F)
                 if need_dX or need_dW:
+                    ws = None
+                    nws = int(lib.mrgcn_rel_transform_bwd_workspace(plan.handle, K, F, int(need_dX),
+                                                                    int(need_dW)))
+                    if nws > 0:
+                        ws = torch.empty((nws,), dtype=torch.float32, device=dev)
                     L.check(lib.mrgcn_rel_transform_bwd_f32(
                         plan.handle, dM.data_ptr(), ld, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
-                        dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0, s),
+                        dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0,
+                        ws.data_ptr() if ws is not None else 0, ws.numel() if ws is not None else 0, s),
                         "mrgcn_rel_transform_bwd_f32")
         return None, None, d_wI, d_comp, dX, dW, dbias, None
 

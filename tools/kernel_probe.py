@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Times the individual C-ABI calls of one AM-shaped layer (HIP events on the stream), for
+A/B work on single kernels.   python tools/kernel_probe.py [--which mix_fwd,mix_bwd,...]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import event_time_ms  # noqa: E402
+from mrgcn_amd import _lib as L  # noqa: E402
+from mrgcn_amd import synth  # noqa: E402
+from mrgcn_amd.plan import GraphPlan  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="am")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--which", default="mix_fwd,mix_fwd_add,mix_bwd,xf_fwd0,xf_fwd1,xf_bwd0,xf_bwd1,spmm,spmm_t10,spmm_t11,adam")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--ldm", type=int, default=16)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = L.load()
+    sh = synth.SHAPES[a.workload]
+    g = synth.make_graph(a.workload, seed=0, scale=a.scale)
+    N, R, B, F, K = g.num_nodes, g.num_relations, sh["bases"], sh["hidden"], sh["x_width"]
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                (N, R * N)).to(dev)
+    plan = GraphPlan(A, N, R)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    h = plan.handle
+    nc = plan.ncols
+    ld = a.ldm
+    V = torch.randn((B * N, F), device=dev)
+    comp = torch.randn((R, B), device=dev)
+    M = torch.empty((nc, ld), device=dev)
+    M2 = torch.randn((nc, 12), device=dev)
+    dM = torch.randn((nc, 12), device=dev)
+    dV = torch.empty_like(V)
+    dcomp = torch.empty_like(comp)
+    X = torch.randn((N, K), device=dev)
+    W0 = torch.randn((R, K, F), device=dev)
+    H = torch.randn((N, F), device=dev)
+    C = sh["classes"]
+    W1 = torch.randn((R, F, C), device=dev)
+    dW0, dW1 = torch.empty_like(W0), torch.empty_like(W1)
+    dH = torch.empty_like(H)
+    dM1 = torch.randn((nc, 12), device=dev)
+    Y = torch.empty((N, F), device=dev)
+    dY10 = torch.randn((N, 10), device=dev)
+    dY11 = torch.randn((N, 11), device=dev)
+    nws = max(int(lib.mrgcn_rel_transform_bwd_workspace(h, K, F, 0, 1)),
+              int(lib.mrgcn_rel_transform_bwd_workspace(h, F, C, 1, 1)))
+    ws = torch.empty((nws,), device=dev)
+    P, G_, M_, V_ = (torch.randn((B * N * F,), device=dev) for _ in range(4))
+    coef = torch.ones((), device=dev)
+
+    def chk(rc):
+        L.check(rc)
+
+    calls = {
+        "mix_fwd": lambda: chk(lib.mrgcn_basis_mix_fwd_f32(h, V.data_ptr(), comp.data_ptr(), B, F, 0, 0, M.data_ptr(), ld, s)),
+        "mix_fwd_add": lambda: chk(lib.mrgcn_basis_mix_fwd_f32(h, V.data_ptr(), comp.data_ptr(), B, F, M2.data_ptr(), 12, M.data_ptr(), ld, s)),
+        "mix_bwd": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), dcomp.data_ptr(), s)),
+        "xf_fwd0": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, X.data_ptr(), K, K, W0.data_ptr(), F, M2.data_ptr(), 12, 0, s)),
+        "xf_fwd1": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, H.data_ptr(), F, F, W1.data_ptr(), C, M.data_ptr(), ld, 1, s)),
+        "xf_bwd0": lambda: chk(lib.mrgcn_rel_transform_bwd_f32(h, dM.data_ptr(), 12, X.data_ptr(), K, K, W0.data_ptr(), F, 0, K, dW0.data_ptr(), ws.data_ptr(), nws, s)),
+        "xf_bwd1": lambda: chk(lib.mrgcn_rel_transform_bwd_f32(h, dM1.data_ptr(), 12, H.data_ptr(), F, F, W1.data_ptr(), C, dH.data_ptr(), F, dW1.data_ptr(), ws.data_ptr(), nws, s)),
+        "spmm": lambda: plan.spmm(L.VIEW_COMPACT, M, F=F, out=Y),
+        "spmm_t10": lambda: plan.spmm(L.VIEW_TRANSPOSED, dY10, F=10, out=dM),
+        "spmm_t11": lambda: plan.spmm(L.VIEW_TRANSPOSED, dY11, F=11, out=dM),
+        "adam": lambda: chk(lib.mrgcn_adam_step_f32(P.data_ptr(), G_.data_ptr(), M_.data_ptr(), V_.data_ptr(), P.numel(), 0.01, 0.9, 0.999, 1e-8, 0.0, 1, coef.data_ptr(), s)),
+    }
+    print(f"N={N} R={R} B={B} F={F} K={K} ncols={nc} nnz={plan.nnz} ldM={ld}")
+    for name in a.which.split(","):
+        ms = event_time_ms(calls[name], a.iters, s)
+        print(f"{name:12s} {ms*1e3:9.1f} us")
+
+
+if __name__ == "__main__":
+    main()
