@@ -34,6 +34,7 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kLongThreshold = 32; // rows with more entries go to the split-row path
 constexpr int kChunk = 512;        // entries per split-row chunk (one wave each)
 constexpr int kWsFeatures = 256;   // split-row workspace is sized for this many features
+constexpr int kHotMinRefs = 16;    // columns read by >= this many rows go to the dense hot region of M
 constexpr int kRelChunk = 1024;    // compact columns of one relation per transform block
 
 // One CSR-shaped view of the adjacency: `rows` output rows, entry e of row i
@@ -85,11 +86,11 @@ struct mrgcn_plan {
           *ulcol = nullptr;
   float *cval = nullptr;
   // Storage order of the compact dense operand M: row mpos[c] of M holds compact column c.
-  // Hot columns (read by >= 2 output rows) come first, most referenced first, so that the
-  // randomly re-read part of M is small and dense (L2 / Infinity-Cache resident); columns
-  // read exactly once follow in the order of the output row that reads them, so that a
-  // row's private operand rows are contiguous and the forward gather streams them instead of
-  // fetching one 128-B line per 40-B row.
+  // Hot columns (read by >= kHotMinRefs output rows) come first, most referenced first, so that
+  // the heavily re-read part of M is small and dense (L2 resident); every other column follows in
+  // the order of the FIRST output row that reads it, so that a row's first-touch operand rows
+  // are one contiguous run and the forward gather streams them instead of fetching one 128-B
+  // line per 40-B row (only the 2nd..kth reads of a lukewarm column stay random).
   int32_t *mpos = nullptr;  // [ncols] compact id -> row of M
   int32_t *mcol = nullptr;  // [nnz]   operand row of each entry, entries of a row sorted by it
   float *mval = nullptr;    // [nnz]   values in the same order (the COMPACT view's arrays)

@@ -5,6 +5,7 @@
 // sort/scan primitives are used; everything else is hand-written.
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -120,18 +121,18 @@ __global__ void k_node_ptr(const int32_t *__restrict__ keys, int64_t count, int6
   ptr[i] = (int32_t)lo;
 }
 
-// storage order of the compact operand M (see common.hpp: mpos): hot columns (>= 2 entries)
-// first, most referenced first; then the single-entry columns in the order of the one output
-// row that reads them.  key = [cold:1][hot: max_count - count | cold: row][compact id]
+// storage order of the compact operand M (see common.hpp: mpos): hot columns (>= hot_min
+// entries) first, most referenced first; then every other column in the order of the FIRST
+// output row that reads it.  key = [hot: max_count - count | rest: max_count + 1 + row][compact id]
 __global__ void k_mpos_keys(const int32_t *__restrict__ cptr, const int32_t *__restrict__ crow,
-                            int64_t ncols, int64_t max_count, int shift, int64_t *__restrict__ keys,
-                            int32_t *__restrict__ ids) {
+                            int64_t ncols, int64_t max_count, int shift, int hot_min,
+                            int64_t *__restrict__ keys, int32_t *__restrict__ ids) {
   int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncols) return;
   const int32_t b = cptr[c], e = cptr[c + 1];
   const int64_t cnt = e - b;
   int64_t hi;
-  if (cnt >= 2) hi = max_count - cnt;                       // in [0, max_count)
+  if (cnt >= hot_min) hi = max_count - cnt;                 // in [0, max_count)
   else hi = max_count + 1 + (int64_t)crow[b];               // after every hot column
   keys[c] = (hi << shift) | c;
   ids[c] = (int32_t)c;
@@ -445,7 +446,9 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     MRGCN_HIP_TRY(sc.alloc(&order, ncols));
     const int shift = bits_for(ncols);
     const int64_t max_count = p->max_col_nnz + 1;
-    k_mpos_keys<<<nblocks(ncols), kTB, 0, s>>>(p->cptr, p->crow, ncols, max_count, shift, mk, ids);
+    int hot_min = kHotMinRefs;
+    if (const char *e = getenv("MRGCN_HOT_MIN")) hot_min = atoi(e) > 1 ? atoi(e) : hot_min;  // experiments
+    k_mpos_keys<<<nblocks(ncols), kTB, 0, s>>>(p->cptr, p->crow, ncols, max_count, shift, hot_min, mk, ids);
     MRGCN_HIP_TRY(hipGetLastError());
     const int end_bit = shift + bits_for(max_count + 1 + p->num_rows);
     MRGCN_REQUIRE(end_bit <= 62, "graph too large for the operand-order key");

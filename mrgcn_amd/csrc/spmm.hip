@@ -58,14 +58,23 @@ __device__ __forceinline__ void store_row(float *y, const float (&acc)[VEC], int
 }
 
 // One gather + multiply-add of entry (c, a); `on` masks the contribution.
-template <int VEC>
+// TAIL: rows are only dword aligned and not padded (ld = F not a multiple of 4): 16-byte loads
+// from dword-aligned addresses (legal for global loads on gfx950), scalar loads for a last
+// partial vector so that nothing past the row is touched.
+template <int VEC, bool TAIL>
 __device__ __forceinline__ void gather_fma(const float *Dq, int64_t ldD, int32_t c, float a, bool on,
-                                           float (&acc)[VEC]) {
+                                           float (&acc)[VEC], int nvalid) {
   // branch-free: the load is unconditional (masked-off entries carry c = 0, a valid row) so that
   // the compiler can issue a whole batch of gathers before the first use; the select keeps a
   // NaN/Inf in row 0 from leaking into rows that do not reference it
   float x[VEC];
-  load_vec<VEC>(Dq + (int64_t)c * ldD, x);
+  if (TAIL && nvalid < VEC) {
+    const float *p = Dq + (int64_t)c * ldD;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) x[i] = (i < nvalid) ? p[i] : 0.f;
+  } else {
+    load_vec<VEC>(Dq + (int64_t)c * ldD, x);
+  }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = fmaf(a, on ? x[i] : 0.f, acc[i]);
 }
@@ -74,20 +83,21 @@ __device__ __forceinline__ void gather_fma(const float *Dq, int64_t ldD, int32_t
 // round trips per few entries).  Both paths therefore first pull *all* indices and values of
 // their row / chunk into registers with coalesced loads (one round trip), then hand them to the
 // gathering lanes with cross-lane reads and issue the gathers back to back.
-template <int G, int VEC>
+template <int G, int VEC, bool TAIL>
 __global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restrict__ D, int64_t ldD,
                                               int F, float *__restrict__ Y, int64_t ldY,
                                               const float *__restrict__ bias, int relu,
                                               const int32_t *__restrict__ out_index,
                                               int store_vec_ok, float *__restrict__ partials,
                                               int ldP, int chunk_blocks, int64_t short_blocks,
-                                              int64_t xcd_per) {
+                                              int64_t xcd_per, int min_len) {
   constexpr int SLOTS = kWave / G;
   const int lane = threadIdx.x & (kWave - 1);
   const int slot = lane / G, q = lane % G;
   const int f0 = q * VEC;
   const bool active = f0 < F;
   const float *Dq = D + (active ? f0 : 0);  // idle feature lanes shadow lane 0 (always in bounds)
+  const int nvalid = active ? min(VEC, F - f0) : VEC;  // floats of this lane's vector inside the row
   float acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -117,14 +127,14 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restr
           const int src = u * SLOTS + slot;
           const int32_t c = __shfl(ci[t], src, kWave);
           const float a = __shfl(ca[t], src, kWave);
-          gather_fma<VEC>(Dq, ldD, c, a, active && (t * kWave + src < n), acc);
+          gather_fma<VEC, TAIL>(Dq, ldD, c, a, active && (t * kWave + src < n), acc, nvalid);
         }
       } else {
         for (int u = 0; u < UPT; ++u) {
           const int src = u * SLOTS + slot;
           const int32_t c = __shfl(ci[t], src, kWave);
           const float a = __shfl(ca[t], src, kWave);
-          gather_fma<VEC>(Dq, ldD, c, a, active && (t * kWave + src < n), acc);
+          gather_fma<VEC, TAIL>(Dq, ldD, c, a, active && (t * kWave + src < n), acc, nvalid);
         }
       }
     }
@@ -164,9 +174,12 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restr
   if (row < v.rows) {
     b = v.ptr[row];
     n = v.ptr[row + 1] - b;
-    if (n > kLongThreshold) n = 0;  // the chunk path owns this row
   }
-  const bool mine = row < v.rows && (v.ptr[row + 1] - v.ptr[row]) <= kLongThreshold;
+  // rows longer than kLongThreshold belong to the chunk path; with the tiny-row pre-pass
+  // (min_len > 0) rows of <= min_len entries (empty rows included) were already written
+  const bool mine = row < v.rows && n <= kLongThreshold && !(min_len > 0 && n <= min_len);
+  if (!mine) n = 0;
+  if (!__any(mine)) return;  // wave uniform
   if (G <= 8) {
     // the G lanes of a row stage its <= 32 entries: lane q holds entries q, q+G, q+2G, ...
     constexpr int T = (kLongThreshold + G - 1) / G;
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restr
       for (int u = 0; u < G; ++u) {
         const int32_t c = __shfl(ci[t], sbase + u, kWave);
         const float a = __shfl(ca[t], sbase + u, kWave);
-        gather_fma<VEC>(Dq, ldD, c, a, active && (t * G + u < n), acc);
+        gather_fma<VEC, TAIL>(Dq, ldD, c, a, active && (t * G + u < n), acc, nvalid);
       }
     }
   } else {
@@ -211,11 +224,99 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restr
         }
       }
     }
-    for (; k < e; ++k) gather_fma<VEC>(Dq, ldD, v.idx[k], v.val[k], active, acc);
+    for (; k < e; ++k) gather_fma<VEC, TAIL>(Dq, ldD, v.idx[k], v.val[k], active, acc, nvalid);
   }
   if (mine && active) {
     const int64_t orow = out_index ? (int64_t)out_index[row] : row;
     store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
+  }
+}
+
+// ---- tiny rows (<= kTiny entries) ------------------------------------------------------------
+// The transposed view has millions of rows of 1-2 entries (AM: 8.2 M rows, 87 % single entry):
+// a wave that owns only 64/G such rows is pure latency (pointer -> index -> gather, three
+// dependent round trips for 16 entries).  Here every G-lane group owns kRpg rows at once and
+// walks their dependency chains side by side: 4x the rows, the same three round trips.
+// Rows are 4-byte aligned only (ld = F): 16-byte loads from dword-aligned addresses, scalar tail.
+constexpr int kTiny = 4;
+constexpr int kRpg = 4;
+
+__device__ __forceinline__ void load4_tail_safe(const float *row, int f0, int F, float (&x)[4]) {
+  if (f0 + 4 <= F) {
+    const float4 t = *reinterpret_cast<const float4 *>(row + f0);
+    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = (f0 + i < F) ? row[f0 + i] : 0.f;
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_spmm_tiny(SparseView v, const float *__restrict__ D, int64_t ldD,
+                                                   int F, float *__restrict__ Y, int64_t ldY,
+                                                   const float *__restrict__ bias, int relu,
+                                                   const int32_t *__restrict__ out_index) {
+  constexpr int SLOTS = kWave / G;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int slot = lane / G, q = lane % G;
+  const int f0 = q * 4;
+  const bool active = f0 < F;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int64_t row0 = wave * (SLOTS * kRpg) + slot;  // rows row0 + k*SLOTS, k < kRpg
+  int32_t b[kRpg], n[kRpg];
+#pragma unroll
+  for (int k = 0; k < kRpg; ++k) {
+    const int64_t row = row0 + (int64_t)k * SLOTS;
+    b[k] = 0; n[k] = -1;  // -1: not this kernel's row
+    if (row < v.rows) {
+      b[k] = v.ptr[row];
+      n[k] = v.ptr[row + 1] - b[k];
+      if (n[k] > kTiny) n[k] = -1;  // the general kernel owns this row
+    }
+  }
+  int32_t ci[kRpg][kTiny];
+  float ca[kRpg][kTiny];
+#pragma unroll
+  for (int k = 0; k < kRpg; ++k)
+#pragma unroll
+    for (int e = 0; e < kTiny; ++e) {
+      const bool on = e < n[k];
+      ci[k][e] = on ? v.idx[b[k] + e] : 0;
+      ca[k][e] = on ? v.val[b[k] + e] : 0.f;
+    }
+  float x[kRpg][kTiny][4];
+#pragma unroll
+  for (int k = 0; k < kRpg; ++k)
+#pragma unroll
+    for (int e = 0; e < kTiny; ++e) {
+      if (active && e < n[k]) load4_tail_safe(D + (int64_t)ci[k][e] * ldD, f0, F, x[k][e]);
+      else { x[k][e][0] = x[k][e][1] = x[k][e][2] = x[k][e][3] = 0.f; }
+    }
+#pragma unroll
+  for (int k = 0; k < kRpg; ++k) {
+    if (n[k] < 0 || !active) continue;  // empty rows (n = 0) are written (bias / zeros)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < kTiny; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = fmaf(ca[k][e], x[k][e][i], acc[i]);
+    const int64_t row = row0 + (int64_t)k * SLOTS;
+    const int64_t orow = out_index ? (int64_t)out_index[row] : row;
+    float *y = Y + orow * ldY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float o = acc[i];
+      if (bias && f0 + i < F) o += bias[f0 + i];
+      if (relu) o = fmaxf(o, 0.f);
+      acc[i] = o;
+    }
+    if ((ldY & 3) == 0 && f0 + 4 <= F && (((uintptr_t)Y) & 15) == 0) {
+      *reinterpret_cast<float4 *>(y + f0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (f0 + i < F) y[f0 + i] = acc[i];
+    }
   }
 }
 
@@ -244,9 +345,10 @@ __global__ __launch_bounds__(256) void k_spmm_finalize(SparseView v, const float
   }
 }
 
-template <int G, int VEC>
+template <int G, int VEC, bool TAIL = false>
 int launch(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, int64_t ldY,
-           const float *bias, int relu, const int32_t *out_index, float *partials, hipStream_t s) {
+           const float *bias, int relu, const int32_t *out_index, float *partials, bool use_tiny,
+           hipStream_t s) {
   constexpr int SLOTS = kWave / G;
   const bool store_vec_ok = (ldY % VEC == 0) && (((uintptr_t)Y) % (VEC * 4) == 0);
   const int64_t short_waves = (v.rows + SLOTS - 1) / SLOTS;
@@ -255,10 +357,20 @@ int launch(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, in
   static const bool xcd_map = !(getenv("MRGCN_SPMM_XCD") && atoi(getenv("MRGCN_SPMM_XCD")) == 0);
   const int64_t xcd_per = xcd_map ? (short_blocks + 7) / 8 : 0;
   const int64_t launch_short = xcd_map ? xcd_per * 8 : short_blocks;
+  int min_len = 0;
+  if (use_tiny && v.rows > 0) {  // G*4 >= F guaranteed by the caller
+    constexpr int TG = (G * VEC + 3) / 4 < 1 ? 1 : (G * VEC + 3) / 4;  // lanes per row at 4 floats each
+    constexpr int TSLOTS = kWave / TG;
+    const int64_t waves = (v.rows + (int64_t)TSLOTS * kRpg - 1) / ((int64_t)TSLOTS * kRpg);
+    k_spmm_tiny<TG><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, bias, relu,
+                                                                            out_index);
+    MRGCN_HIP_TRY(hipGetLastError());
+    min_len = kTiny;
+  }
   if (launch_short + chunk_blocks > 0) {
-    k_spmm<G, VEC><<<dim3((unsigned)(launch_short + chunk_blocks)), dim3(256), 0, s>>>(
+    k_spmm<G, VEC, TAIL><<<dim3((unsigned)(launch_short + chunk_blocks)), dim3(256), 0, s>>>(
         v, D, ldD, F, Y, ldY, bias, relu, out_index, store_vec_ok ? 1 : 0, partials, kWsFeatures,
-        (int)chunk_blocks, short_blocks, xcd_per);
+        (int)chunk_blocks, short_blocks, xcd_per, min_len);
     MRGCN_HIP_TRY(hipGetLastError());
   }
   if (v.n_multi > 0) {
@@ -273,7 +385,7 @@ int launch(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, in
 // picks lanes-per-row G and vector width VEC for one feature tile of width F <= 256
 int dispatch(const SparseView &v, const float *D, int64_t ldD, int64_t avail, int F, float *Y,
              int64_t ldY, const float *bias, int relu, const int32_t *out_index, float *partials,
-             hipStream_t s) {
+             bool use_tiny, bool operand_cached, hipStream_t s) {
   // widest vector the operand layout allows; loads past F must stay inside the row
   // (`avail` = floats left in a row of D from this tile's first column)
   int vec = 1;
@@ -283,10 +395,22 @@ int dispatch(const SparseView &v, const float *D, int64_t ldD, int64_t avail, in
   };
   // MRGCN_SPMM_UNALIGNED=1: 16-byte loads on rows that are only 4/8-byte aligned (gfx950 global
   // loads need dword alignment only); the caller guarantees 12 readable bytes past the operand
-  static const bool unaligned = getenv("MRGCN_SPMM_UNALIGNED") && atoi(getenv("MRGCN_SPMM_UNALIGNED")) != 0;
-  if (ok(4) || unaligned) vec = 4; else if (ok(2)) vec = 2;
+  if (ok(4)) vec = 4; else if (ok(2)) vec = 2;
+  // unpadded rows that are only 4/8-byte aligned (e.g. the dY of a 10- or 11-class layer, ld = F):
+  // 16-byte loads from dword-aligned addresses with a scalar tail instead of 4- or 8-byte lanes
+  static const bool no_tail = getenv("MRGCN_SPMM_TAIL") && atoi(getenv("MRGCN_SPMM_TAIL")) == 0;
+  // (only for operands that stay cache resident: on a table far larger than the Infinity Cache a
+  // 16-byte load that straddles two 128-B lines costs two HBM line fetches — measured 463 vs 349 us
+  // on the 17.8 GB literal operand, 453 vs 496 / 472 vs 725 us on the 67-73 MB dY)
+  if (vec < 4 && F <= 32 && !no_tail && operand_cached) {
+    const int l4 = (F + 3) / 4;
+    if (l4 <= 1) return launch<1, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s);
+    if (l4 <= 2) return launch<2, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s);
+    if (l4 <= 4) return launch<4, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s);
+    return launch<8, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s);
+  }
   const int lanes = (F + vec - 1) / vec;  // lanes needed per row
-#define MRGCN_GO(G, V) return launch<G, V>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, s)
+#define MRGCN_GO(G, V) return launch<G, V>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s)
   if (vec == 4) {
     if (lanes <= 1) MRGCN_GO(1, 4);
     if (lanes <= 2) MRGCN_GO(2, 4);
@@ -337,8 +461,15 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
   else if (ldD % 2 == 0 && ((uintptr_t)D) % 8 == 0) tile = 128;
   for (int f = 0; f < F; f += tile) {
     int w = (F - f < tile) ? (F - f) : tile;
+    // optional tiny-row pre-pass for views whose rows are mostly 1-2 entries (the transposed view);
+    // measured no faster than the general kernel on the AM shape, so opt-in (MRGCN_SPMM_TINY=1)
+    static const bool tiny_on = getenv("MRGCN_SPMM_TINY") && atoi(getenv("MRGCN_SPMM_TINY")) != 0;
+    const bool use_tiny = tiny_on && w <= 64 && v.rows > 0 && (plan->nnz < 3 * v.rows);
+    const int64_t operand_rows = view == MRGCN_VIEW_LITERAL ? plan->num_relations * plan->num_nodes
+                                 : view == MRGCN_VIEW_COMPACT ? plan->ncols : plan->num_rows;
+    const bool operand_cached = operand_rows * ldD * 4 <= (int64_t)200 << 20;
     int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu,
-                      out_index, plan->partials, s);
+                      out_index, plan->partials, use_tiny, operand_cached, s);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;

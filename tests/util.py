@@ -5,6 +5,7 @@ import numpy as np
 import scipy.sparse as sp
 import torch
 
+HOT_MIN_REFS = 16  # csrc/common.hpp: kHotMinRefs
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -92,13 +93,13 @@ def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False):
     nptr = np.searchsorted(unode, np.arange(N + 1)).astype(np.int32)
     rperm = np.argsort(ulcol, kind="stable").astype(np.int32)
     relptr = np.searchsorted(ulcol[rperm], np.arange(R + 1, dtype=np.int64) * N).astype(np.int32)
-    # storage order of the compact operand: hot columns (>= 2 entries) by falling count, then
-    # single-entry columns by the row that reads them
+    # storage order of the compact operand: hot columns (>= HOT_MIN_REFS entries) by falling count,
+    # then every other column by the first row that reads it
     cnt = np.diff(cptr).astype(np.int64)
     if ncols:
         firstrow = crow[cptr[:-1]].astype(np.int64)
         max_count = int(cnt.max()) + 1
-        hi = np.where(cnt >= 2, max_count - cnt, max_count + 1 + firstrow)
+        hi = np.where(cnt >= HOT_MIN_REFS, max_count - cnt, max_count + 1 + firstrow)
         order = np.lexsort((np.arange(ncols), hi))
         mpos = np.empty(ncols, dtype=np.int32)
         mpos[order] = np.arange(ncols, dtype=np.int32)
