@@ -110,16 +110,12 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
+    from mrgcn_amd import dist as mdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    world, rank, local_rank = mdist.env_world()
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    mdist.init("nccl", dev)  # one process per GPU over RCCL (no-op at world 1)
 
     from mrgcn_amd import _lib as L
     from mrgcn_amd import synth
@@ -153,9 +149,7 @@ def main():
         return train_step(model, lambda: model(X, A), idx, tgt, opt)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        mdist.barrier(dev)
 
     for _ in range(args.warmup):
         step()
@@ -164,11 +158,7 @@ def main():
     for _ in range(args.steps):
         loss = step()
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = mdist.max_over_ranks(time.perf_counter() - t0, dev)  # replicas: the slowest rank's time
     ms_per_step = dt / args.steps * 1e3
     final_loss = float(loss)
 

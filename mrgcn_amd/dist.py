@@ -1,0 +1,51 @@
+"""Multi-GPU glue.  This round the path runs as independent replicas: the only
+cross-rank traffic is the barrier and the max-over-ranks of the timed region, over
+torch.distributed (RCCL on GPUs, gloo in the CPU tests)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend: str | None = None, device: torch.device | None = None):
+    """Initialises the default process group from the torchrun environment (no-op at world 1)."""
+    world, rank, local_rank = env_world()
+    if world <= 1 or dist.is_initialized():
+        return world, rank, local_rank
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
+    return world, rank, local_rank
+
+
+def barrier(device: torch.device | None = None):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value: float, device: torch.device | None = None) -> float:
+    """MAX all-reduce of a host scalar (the timed region of bench.py)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def replica_value(ms_per_step_local: float, device: torch.device | None = None) -> float:
+    """Replicas: every rank runs the same epoch; the job's epoch time is the slowest rank's."""
+    return max_over_ranks(ms_per_step_local, device)
