@@ -158,6 +158,7 @@ int mrgcn_rel_transform_fwd_f32(const mrgcn_plan_t *plan, const float *X, int64_
  *     dcomp[r, b]    = sum_{c: r_c = r} <dM[c, :], V[b*N + j_c, :]>    (zeroed inside)   */
 int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM, const float *V,
                             const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
+                            double *dV_sumsq /* nullable: *dV_sumsq += ||dV||^2 (device double) */,
                             void *stream);
 /*     dX[j, 0:K]  = sum_{c in node j} W[r_c] . dM[c, :]     (nullable; every row written)
  *     dW[r, :, :] = sum_{c: r_c = r} X[j_c, :]^T dM[c, :]    (nullable; zeroed inside)

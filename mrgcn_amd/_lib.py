@@ -54,7 +54,7 @@ SIGNATURES = {
     "mrgcn_gather_rows_f32": (C.c_int, [_p, _p, _i32, _p, _i64, _p, _i64, _p]),
     "mrgcn_rel_transform_fwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]),
     "mrgcn_rel_transform_bwd_workspace": (C.c_int64, [_p, _i32, _i32, _i32, _i32]),
-    "mrgcn_basis_mix_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
+    "mrgcn_basis_mix_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p]),
     "mrgcn_rel_transform_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _i64, _p]),
     "mrgcn_relu_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "mrgcn_softmax_xent_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _i64, _i64, _p]),

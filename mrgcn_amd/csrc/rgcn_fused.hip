@@ -76,45 +76,45 @@ __global__ __launch_bounds__(kMixTB) void k_mix_fwd(const int32_t *__restrict__ 
     const bool live = o < F;
     const int32_t c0 = nptr[j], c1 = nptr[j + 1];
     if (c0 == c1) continue;
-    // everything the first kPre columns need is requested up front (no dependent round trips)
-    int rr[kPre];
-    int32_t pp[kPre];
-    float aa[kPre];
-#pragma unroll
-    for (int i = 0; i < kPre; ++i) {
-      const bool in = c0 + i < c1;
-      const int32_t c = in ? c0 + i : c0;
-      rr[i] = urel[c];
-      pp[i] = mpos ? mpos[c] : c;
-      aa[i] = (addend && live) ? addend[(int64_t)c * ldA + o] : 0.f;
-    }
     float v[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b)
       v[b] = (live && b < nb) ? V[((int64_t)(b0 + b) * N + j) * F + o] : 0.f;
 
-    auto emit = [&](int r, int64_t pos, float add) {
-      float s = add;
-      if (comp_in_lds) {
-        float w[BT];
-        load_comp_row<BT>(s_comp + r * CS, w);
+    // the node's columns in chunks of kPre: everything a chunk needs (relation id, operand row,
+    // addend) is requested up front, so a chunk costs one round trip however long the node is
+    for (int32_t cb = c0; cb < c1; cb += kPre) {
+      int rr[kPre];
+      int32_t pp[kPre];
+      float aa[kPre];
 #pragma unroll
-        for (int b = 0; b < BT; ++b) s = fmaf(w[b], v[b], s);
-      } else {
-        const float *cr = comp + (int64_t)r * B + b0;
-#pragma unroll
-        for (int b = 0; b < BT; ++b)
-          if (b < nb) s = fmaf(cr[b], v[b], s);
+      for (int i = 0; i < kPre; ++i) {
+        const int32_t c = (cb + i < c1) ? cb + i : cb;
+        rr[i] = urel[c];
+        pp[i] = mpos ? mpos[c] : c;
+        aa[i] = (addend && live) ? addend[(int64_t)c * ldA + o] : 0.f;
       }
-      float *m = M + pos * ldM + o;
-      if (accumulate) s += *m;
-      *m = live ? s : 0.f;
-    };
 #pragma unroll
-    for (int i = 0; i < kPre; ++i)
-      if (c0 + i < c1) emit(rr[i], pp[i], aa[i]);
-    for (int32_t c = c0 + kPre; c < c1; ++c)
-      emit(urel[c], mpos ? mpos[c] : c, (addend && live) ? addend[(int64_t)c * ldA + o] : 0.f);
+      for (int i = 0; i < kPre; ++i) {
+        if (cb + i < c1) {
+          float s = aa[i];
+          if (comp_in_lds) {
+            float w[BT];
+            load_comp_row<BT>(s_comp + rr[i] * CS, w);
+#pragma unroll
+            for (int b = 0; b < BT; ++b) s = fmaf(w[b], v[b], s);
+          } else {
+            const float *cr = comp + (int64_t)rr[i] * B + b0;
+#pragma unroll
+            for (int b = 0; b < BT; ++b)
+              if (b < nb) s = fmaf(cr[b], v[b], s);
+          }
+          float *m = M + (int64_t)pp[i] * ldM + o;
+          if (accumulate) s += *m;
+          *m = live ? s : 0.f;
+        }
+      }
+    }
   }
 }
 
@@ -209,8 +209,9 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
                                                        const float *__restrict__ dM, int64_t ldM,
                                                        const float *__restrict__ comp, int64_t N, int R,
                                                        int B, int b0, int F, float *__restrict__ dV,
-                                                       int comp_in_lds) {
+                                                       int comp_in_lds, double *__restrict__ sumsq) {
   extern __shared__ __align__(16) float s_comp[];  // [R][CS]
+  float sq = 0.f;
   constexpr int CS = comp_stride(BT);
   const int nb = min(BT, B - b0);
   if (comp_in_lds) {
@@ -226,37 +227,53 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
     const int64_t j = t / F;
     const int o = (int)(t - j * F);
     const int32_t c0 = nptr[j], c1 = nptr[j + 1];
-    int rr[kPre];
-    float dd[kPre];
-#pragma unroll
-    for (int i = 0; i < kPre; ++i) {
-      const bool in = c0 + i < c1;
-      rr[i] = in ? urel[c0 + i] : 0;
-      dd[i] = in ? dM[(int64_t)(c0 + i) * ldM + o] : 0.f;
-    }
     float acc[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[b] = 0.f;
-    auto take = [&](int r, float d) {
-      if (comp_in_lds) {
-        float w[BT];
-        load_comp_row<BT>(s_comp + r * CS, w);
+    for (int32_t cb = c0; cb < c1; cb += kPre) {  // one round trip per chunk of kPre columns
+      int rr[kPre];
+      float dd[kPre];
 #pragma unroll
-        for (int b = 0; b < BT; ++b) acc[b] = fmaf(w[b], d, acc[b]);
-      } else {
-        const float *cr = comp + (int64_t)r * B + b0;
-#pragma unroll
-        for (int b = 0; b < BT; ++b)
-          if (b < nb) acc[b] = fmaf(cr[b], d, acc[b]);
+      for (int i = 0; i < kPre; ++i) {
+        const bool in = cb + i < c1;
+        rr[i] = in ? urel[cb + i] : 0;
+        dd[i] = in ? dM[(int64_t)(cb + i) * ldM + o] : 0.f;
       }
-    };
 #pragma unroll
-    for (int i = 0; i < kPre; ++i)
-      if (c0 + i < c1) take(rr[i], dd[i]);
-    for (int32_t c = c0 + kPre; c < c1; ++c) take(urel[c], dM[(int64_t)c * ldM + o]);
+      for (int i = 0; i < kPre; ++i) {
+        if (cb + i < c1) {
+          if (comp_in_lds) {
+            float w[BT];
+            load_comp_row<BT>(s_comp + rr[i] * CS, w);
+#pragma unroll
+            for (int b = 0; b < BT; ++b) acc[b] = fmaf(w[b], dd[i], acc[b]);
+          } else {
+            const float *cr = comp + (int64_t)rr[i] * B + b0;
+#pragma unroll
+            for (int b = 0; b < BT; ++b)
+              if (b < nb) acc[b] = fmaf(cr[b], dd[i], acc[b]);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int b = 0; b < BT; ++b)
-      if (b < nb) dV[((int64_t)(b0 + b) * N + j) * F + o] = acc[b];
+      if (b < nb) {
+        dV[((int64_t)(b0 + b) * N + j) * F + o] = acc[b];
+        sq = fmaf(acc[b], acc[b], sq);
+      }
+  }
+  if (sumsq) {  // ||dV||^2 for clip_grad_norm_: saves a separate pass over the 2.67 GB gradient
+    __shared__ float s_sq[kMixTB / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += s_sq[i];
+      atomicAdd(sumsq, (double)t);
+    }
   }
 }
 
@@ -284,14 +301,22 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dcomp(const int32_t *__restr
     for (int b = 0; b < B; ++b) {
       const float *vp = V + ((int64_t)b * N + j) * F;
       float dot = 0.f;
-      if (VEC2) {  // F even: rows of V are 8-byte aligned
+      if (VEC2) {  // F even: rows of V are 8-byte aligned; 16-byte loads need dword alignment only
 #pragma unroll
-        for (int o = 0; o < FT; o += 2)
-          if (o < F) {
+        for (int o = 0; o < FT; o += 4) {
+          if (o + 4 <= F) {
+            const float4 vv = *reinterpret_cast<const float4 *>(vp + o);
+            dot = fmaf(dm[o], vv.x, dot);
+            dot = fmaf(dm[o + 1], vv.y, dot);
+            dot = fmaf(dm[o + 2], vv.z, dot);
+            dot = fmaf(dm[o + 3], vv.w, dot);
+          } else if (o < F) {
             const float2 vv = *reinterpret_cast<const float2 *>(vp + o);
             dot = fmaf(dm[o], vv.x, dot);
             dot = fmaf(dm[o + 1], vv.y, dot);
+            if (o + 2 < F) dot = fmaf(dm[o + 2], vp[o + 2], dot);
           }
+        }
       } else {
 #pragma unroll
         for (int o = 0; o < FT; ++o)
@@ -601,7 +626,7 @@ int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *p, const float *V, const float *
 
 int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
                             const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
-                            void *stream) {
+                            double *dV_sumsq, void *stream) {
   MRGCN_REQUIRE(p && dM && V && comp && dV && dcomp, "NULL");
   MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
   MRGCN_REQUIRE(F <= 64, "basis_mix_bwd supports F <= 64 (tile the feature dimension)");
@@ -619,7 +644,7 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
     int grid = mix_grid(lds, N * F);
 #define MIXDV_GO(T)                                                                                    \
   k_mix_bwd_dv<T><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->nptr, p->urel, dM, ldM, comp, N, R, B, b0, \
-                                                        F, dV, in_lds)
+                                                        F, dV, in_lds, dV_sumsq)
     switch (BT) {
       case 2: MIXDV_GO(2); break;
       case 4: MIXDV_GO(4); break;

@@ -3,6 +3,7 @@ or CPU fallback."""
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -12,6 +13,31 @@ from .plan import GraphPlan
 
 def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+# ||grad||^2 values a producing kernel already accumulated (device doubles), keyed by the
+# gradient's data pointer; `ClipAdam` consumes them instead of re-reading the gradient.
+_GRAD_SUMSQ: dict = {}
+
+
+def register_grad_sumsq(grad: torch.Tensor, sumsq: torch.Tensor):
+    _GRAD_SUMSQ[grad.data_ptr()] = (weakref.ref(grad), sumsq)
+
+
+def pop_grad_sumsq(grad: torch.Tensor):
+    """The precomputed sum of squares of exactly this gradient tensor, or None."""
+    ent = _GRAD_SUMSQ.pop(grad.data_ptr(), None)
+    if ent is None:
+        return None
+    ref, sq = ent
+    t = ref()
+    if t is None or t.data_ptr() != grad.data_ptr() or t.numel() != grad.numel():
+        return None
+    return sq
+
+
+def clear_grad_sumsq():
+    _GRAD_SUMSQ.clear()
 
 
 def _ld_for(F: int) -> int:
@@ -134,10 +160,12 @@ class _RgcnLayer(torch.autograd.Function):
                 if has_comp:
                     d_wI = torch.empty_like(weight_I)
                     d_comp = torch.empty_like(comp_I)
+                    sq = torch.zeros((), dtype=torch.float64, device=dev)
                     L.check(lib.mrgcn_basis_mix_bwd_f32(
                         plan.handle, dM.data_ptr(), ld, weight_I.data_ptr(), comp_I.data_ptr(),
-                        comp_I.shape[1], F, d_wI.data_ptr(), d_comp.data_ptr(), s),
+                        comp_I.shape[1], F, d_wI.data_ptr(), d_comp.data_ptr(), sq.data_ptr(), s),
                         "mrgcn_basis_mix_bwd_f32")
+                    register_grad_sumsq(d_wI, sq)  # ||dV||^2 came for free with the gradient
                 else:
                     # dense (R*N) x F gradient: zero + scatter of the touched rows
                     d_wI = torch.zeros_like(weight_I)

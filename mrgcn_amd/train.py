@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
+from .functional import clear_grad_sumsq, pop_grad_sumsq
 
 
 def _stream(device) -> int:
@@ -93,8 +94,13 @@ class ClipAdam(torch.optim.Optimizer):
             for _, p in live:
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 grads.append(g)
-                L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), sc["sumsq"].data_ptr(), s),
-                        "mrgcn_sumsq_accum_f32")
+                pre = pop_grad_sumsq(g)  # already accumulated by the kernel that produced g?
+                if pre is not None:
+                    sc["sumsq"] += pre
+                else:
+                    L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), sc["sumsq"].data_ptr(), s),
+                            "mrgcn_sumsq_accum_f32")
+            clear_grad_sumsq()
             use_clip = self.max_norm is not None and self.max_norm > 0
             if use_clip:
                 L.check(lib.mrgcn_clip_coef_f32(sc["sumsq"].data_ptr(), float(self.max_norm),

@@ -65,7 +65,7 @@ def main():
     calls = {
         "mix_fwd": lambda: chk(lib.mrgcn_basis_mix_fwd_f32(h, V.data_ptr(), comp.data_ptr(), B, F, 0, 0, M.data_ptr(), ld, s)),
         "mix_fwd_add": lambda: chk(lib.mrgcn_basis_mix_fwd_f32(h, V.data_ptr(), comp.data_ptr(), B, F, M2.data_ptr(), 12, M.data_ptr(), ld, s)),
-        "mix_bwd": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), dcomp.data_ptr(), s)),
+        "mix_bwd": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), dcomp.data_ptr(), 0, s)),
         "xf_fwd0": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, X.data_ptr(), K, K, W0.data_ptr(), F, M2.data_ptr(), 12, 0, s)),
         "xf_fwd1": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, H.data_ptr(), F, F, W1.data_ptr(), C, M.data_ptr(), ld, 1, s)),
         "xf_bwd0": lambda: chk(lib.mrgcn_rel_transform_bwd_f32(h, dM.data_ptr(), 12, X.data_ptr(), K, K, W0.data_ptr(), F, 0, K, dW0.data_ptr(), ws.data_ptr(), nws, s)),
