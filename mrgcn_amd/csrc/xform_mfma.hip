@@ -46,7 +46,7 @@ __device__ __forceinline__ f32x4 load4_fast(const float *p) {
 //   rin_idx / rout_idx: nullable int32 [ncols] in RELATION-MAJOR order (aligned with rperm):
 //   input / output row of each column; null = the compact id rperm[e] itself
 // ---------------------------------------------------------------------------------------------
-template <int NT, bool TRANS_W>
+template <int NT, bool TRANS_W, int KS>
 __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
     const int32_t *__restrict__ relchunk_rel, const int32_t *__restrict__ relchunk_beg,
     const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
     fetch(t0 + 64 + m, n_valid, n_rin, n_rout);
     const float *xrow = In + rin * ldIn;
     // all K steps of the gathered row in flight at once
-    f32x4 a[kMaxKSteps];
+    f32x4 a[KS];
 #pragma unroll
-    for (int ks = 0; ks < kMaxKSteps; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       if (ks < ksteps) {
         const int k = ks * 16 + 4 * kq;
         a[ks] = (k + 4 <= K) ? load4_fast(xrow + k) : load4_guarded(xrow, k, K);
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < kMaxKSteps; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       if (ks < ksteps) {
         f32x4 av = a[ks];
         if (cid < 0) av = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxTQ = 4;  // K <= 256
 
+template <int TQ, int U>
 __global__ __launch_bounds__(256) void k_xform_mfma_dw(
     const int32_t *__restrict__ relchunk_rel, const int32_t *__restrict__ relchunk_beg,
     const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
@@ -151,11 +152,10 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
   const int ntq = (K + 63) >> 6;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m = lane & 15, kq = lane >> 4;
-  f32x4 acc[kMaxTQ * 4];
+  f32x4 acc[TQ * 4];
 #pragma unroll
-  for (int t = 0; t < kMaxTQ * 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < TQ * 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int U = 4;  // column groups in flight per wave
   // indices of the next sweep are fetched while the current one is multiplied
   int32_t n_cid[U], n_rin[U];
   auto fetch = [&](int32_t t0) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
   };
   fetch(beg + wv * 4 * U);
   for (int32_t t0 = beg + wv * 4 * U; t0 < end; t0 += 16 * U) {  // 4 waves x (U x 4) columns per sweep
-    f32x4 a[U][kMaxTQ];
+    f32x4 a[U][TQ];
     float b[U];
     int32_t cidv[U], rinv[U];
 #pragma unroll
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
       const float *xrow = In + (int64_t)rinv[u] * ldIn;
       b[u] = (cid >= 0 && m < F) ? G[(int64_t)cid * ldG + m] : 0.f;
 #pragma unroll
-      for (int tq = 0; tq < kMaxTQ; ++tq) {
+      for (int tq = 0; tq < TQ; ++tq) {
         if (tq < ntq) {
           const int i = 64 * tq + 4 * m;
           a[u][tq] = (i + 4 <= K) ? load4_fast(xrow + i) : load4_guarded(xrow, i, K);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int tq = 0; tq < kMaxTQ; ++tq) {
+      for (int tq = 0; tq < TQ; ++tq) {
         if (tq < ntq) {
           acc[tq * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].x, b[u], acc[tq * 4 + 0], 0, 0, 0);
           acc[tq * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].y, b[u], acc[tq * 4 + 1], 0, 0, 0);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
   }
   // D of tile (tq, s): lane (o = l&15, g = l>>4), reg -> row m' = 4g + reg -> i = 64tq + 4m' + s
 #pragma unroll
-  for (int tq = 0; tq < kMaxTQ; ++tq) {
+  for (int tq = 0; tq < TQ; ++tq) {
     if (tq < ntq) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -293,9 +293,20 @@ int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *r
   const int ksteps = (K + 15) / 16;
   const size_t lds = (size_t)NT * 16 * (ksteps * 16 + 4) * sizeof(float);
 #define XF_GO(N_, T_)                                                                               \
-  k_xform_mfma_fwd<N_, T_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                            \
-      p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn, K,    \
-      W, F, Out, ldOut)
+  do {                                                                                              \
+    if (ksteps <= 1)                                                                                \
+      k_xform_mfma_fwd<N_, T_, 1><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                     \
+          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn, \
+          K, W, F, Out, ldOut);                                                                     \
+    else if (ksteps <= 4)                                                                           \
+      k_xform_mfma_fwd<N_, T_, 4><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                     \
+          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn, \
+          K, W, F, Out, ldOut);                                                                     \
+    else                                                                                            \
+      k_xform_mfma_fwd<N_, T_, kMaxKSteps><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(            \
+          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn, \
+          K, W, F, Out, ldOut);                                                                     \
+  } while (0)
   if (trans_w) {
     switch (NT) { case 1: XF_GO(1, true); break; case 2: XF_GO(2, true); break;
                   case 3: XF_GO(3, true); break; default: XF_GO(4, true); break; }
@@ -314,9 +325,12 @@ int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, 
   if (p->n_relchunks == 0) return MRGCN_OK;
   const size_t lds = (size_t)K * F * sizeof(float);
   float *slab = (workspace && workspace_floats >= (int64_t)p->n_relchunks * K * F) ? workspace : nullptr;
-  k_xform_mfma_dw<<<dim3(p->n_relchunks), dim3(256), lds, s>>>(p->relchunk_rel, p->relchunk_beg,
-                                                              p->relchunk_end, p->rperm, rin_idx, In,
-                                                              ldIn, K, G, ldG, F, dW, slab);
+  if (K <= 64)
+    k_xform_mfma_dw<1, 8><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
+        p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F, dW, slab);
+  else
+    k_xform_mfma_dw<kMaxTQ, 4><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
+        p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F, dW, slab);
   MRGCN_HIP_TRY(hipGetLastError());
   if (slab) {
     const int n_seg_max = (p->max_relchunks + kDwSeg - 1) / kDwSeg;

@@ -3,7 +3,6 @@ or CPU fallback."""
 from __future__ import annotations
 
 import os
-import weakref
 
 import torch
 
@@ -16,24 +15,24 @@ def _stream(device) -> int:
 
 
 # ||grad||^2 values a producing kernel already accumulated (device doubles), keyed by the
-# gradient's data pointer; `ClipAdam` consumes them instead of re-reading the gradient.
+# gradient's storage pointer; `ClipAdam` consumes them instead of re-reading the gradient.
+# Safe by construction: autograd either adopts the returned tensor's storage as `p.grad`
+# (pointer matches) or hands the optimizer a different tensor (sum of several contributions,
+# a clone) whose pointer does not match, in which case the norm is recomputed.  The registry is
+# emptied by every optimizer step.
 _GRAD_SUMSQ: dict = {}
 
 
 def register_grad_sumsq(grad: torch.Tensor, sumsq: torch.Tensor):
-    _GRAD_SUMSQ[grad.data_ptr()] = (weakref.ref(grad), sumsq)
+    _GRAD_SUMSQ[grad.data_ptr()] = (grad.numel(), sumsq)
 
 
 def pop_grad_sumsq(grad: torch.Tensor):
-    """The precomputed sum of squares of exactly this gradient tensor, or None."""
+    """The precomputed sum of squares of the gradient living at this storage, or None."""
     ent = _GRAD_SUMSQ.pop(grad.data_ptr(), None)
-    if ent is None:
+    if ent is None or ent[0] != grad.numel():
         return None
-    ref, sq = ent
-    t = ref()
-    if t is None or t.data_ptr() != grad.data_ptr() or t.numel() != grad.numel():
-        return None
-    return sq
+    return ent[1]
 
 
 def clear_grad_sumsq():

@@ -130,6 +130,7 @@ class ClipAdam(torch.optim.Optimizer):
 def train_step(model, forward_fn, idx, targets, optimizer):
     """One full-batch epoch.  `forward_fn()` returns the logits (e.g. `lambda: model(batch)`).
     Returns the loss as a device scalar (no host sync)."""
+    clear_grad_sumsq()
     logits = forward_fn()
     loss = categorical_crossentropy(logits, idx, targets)
     optimizer.zero_grad(set_to_none=True)
