@@ -66,8 +66,8 @@ enum mrgcn_plan_array {
   MRGCN_ARR_NPTR = 9,     /* [num_nodes+1] compact-column range of each source node    */
   MRGCN_ARR_ROWIDX = 10,  /* [nnz]         output row of each CSR entry                */
   MRGCN_ARR_ULCOL = 11,   /* [ncols]       literal column r*N + j of each compact column */
-  MRGCN_ARR_RPERM = 12,   /* [ncols]       compact ids sorted by (relation, node)      */
-  MRGCN_ARR_RELPTR = 13,  /* [R+1]         range of each relation inside RPERM         */
+  MRGCN_ARR_RPERM = 12,   /* [ncols]       compact ids sorted by (node band, relation, node) */
+  MRGCN_ARR_RELPTR = 13,  /* [bands*R+1]   range of each (band, relation) group inside RPERM */
   MRGCN_ARR_MPOS = 14,    /* [ncols]       row of the compact operand M that holds column c */
   MRGCN_ARR_MCOL = 15,    /* [nnz]         operand row per entry of the COMPACT view; a row's
                                            entries are sorted by it                    */

@@ -35,6 +35,7 @@ constexpr int kLongThreshold = 32; // rows with more entries go to the split-row
 constexpr int kChunk = 512;        // entries per split-row chunk (one wave each)
 constexpr int kWsFeatures = 256;   // split-row workspace is sized for this many features
 constexpr int kHotMinRefs = 16;    // columns read by >= this many rows go to the dense hot region of M
+constexpr int kNodeBand = 131072;  // source nodes per band of the transform order (see plan.hip)
 constexpr int kRelChunk = 1024;    // compact columns of one relation per transform block
 
 // One CSR-shaped view of the adjacency: `rows` output rows, entry e of row i
@@ -95,12 +96,14 @@ struct mrgcn_plan {
   int32_t *mcol = nullptr;  // [nnz]   operand row of each entry, entries of a row sorted by it
   float *mval = nullptr;    // [nnz]   values in the same order (the COMPACT view's arrays)
   // relation-major order of the compact columns (for per-relation dense transforms)
-  int32_t *rperm = nullptr;   // [ncols] compact ids sorted by (relation, node)
-  int32_t *relptr = nullptr;  // [R+1]   range of each relation in rperm
+  int32_t *rperm = nullptr;   // [ncols] compact ids sorted by (node band, relation, node)
+  int32_t *relptr = nullptr;  // [n_bands*R+1] range of each (band, relation) group in rperm
+  int64_t node_band = 0, n_bands = 0;
   int32_t *rnode = nullptr;   // [ncols] unode[rperm[k]]: source node, relation-major
   int32_t *rmpos = nullptr;   // [ncols] mpos[rperm[k]]: operand row, relation-major
   int32_t *relchunk_rel = nullptr, *relchunk_beg = nullptr, *relchunk_end = nullptr;  // [n_relchunks]
-  int32_t *relchunk_ptr = nullptr;  // [R+1] chunk range of each relation
+  int32_t *relchunk_ptr = nullptr;  // [R+1] range of each relation inside relchunk_ids
+  int32_t *relchunk_ids = nullptr;  // [n_relchunks] chunk ids grouped by relation
   int32_t n_relchunks = 0, max_relchunks = 0;
   // split-row descriptors, one set per orientation
   int32_t *r_long_row = nullptr, *r_long_cptr = nullptr, *r_chunk_beg = nullptr, *r_chunk_end = nullptr,

@@ -161,6 +161,18 @@ __global__ void k_gather_i32(const int32_t *__restrict__ table, const int32_t *_
   if (i < n) out[i] = table[idx[i]];
 }
 
+// key of compact column c = (node j, relation r): (band(j) * R + r) * band_size + j % band_size
+__global__ void k_band_keys(const int32_t *__restrict__ unode, const int32_t *__restrict__ urel,
+                            int64_t ncols, int64_t R, int64_t band, int64_t *__restrict__ keys,
+                            int32_t *__restrict__ ids) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  const int64_t j = unode[c], r = urel[c];
+  const int64_t b = j / band;
+  keys[c] = (b * R + r) * band + (j - b * band);
+  ids[c] = (int32_t)c;
+}
+
 __global__ void k_iota(int32_t *__restrict__ a, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = (int32_t)i;
@@ -377,51 +389,73 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   k_node_ptr<<<nblocks(N + 1), kTB, 0, s>>>(p->unode, ncols, N, 1, p->nptr);
   MRGCN_HIP_TRY(hipGetLastError());
 
-  // relation-major order of the compact columns: rperm = compact ids sorted by literal column
+  // order of the compact columns for the per-relation dense transforms: (node band, relation,
+  // node).  Within a band of kNodeBand source nodes the columns are relation-major (one weight
+  // tile per group); banding keeps the input rows a group gathers (X / H / dM) inside a window
+  // that stays cache resident while every relation of the band is processed, instead of
+  // re-streaming the whole input once per relation.
   MRGCN_HIP_TRY(plan_alloc(p, &p->rperm, ncols));
-  MRGCN_HIP_TRY(plan_alloc(p, &p->relptr, R + 1));
+  int64_t band = kNodeBand;
+  if (const char *e = getenv("MRGCN_NODE_BAND")) band = atoll(e) > 0 ? atoll(e) : band;  // experiments
+  if (band > N) band = N;
+  const int64_t nbands = (N + band - 1) / band;
+  p->node_band = band;
+  p->n_bands = nbands;
+  const int64_t ngroups = nbands * R;
+  MRGCN_HIP_TRY(plan_alloc(p, &p->relptr, ngroups + 1));
   {
-    int32_t *ids, *ulcol_s;
+    int32_t *ids;
+    int64_t *k3, *k3_s;
     MRGCN_HIP_TRY(sc.alloc(&ids, ncols));
-    MRGCN_HIP_TRY(sc.alloc(&ulcol_s, ncols));
+    MRGCN_HIP_TRY(sc.alloc(&k3, ncols));
+    MRGCN_HIP_TRY(sc.alloc(&k3_s, ncols));
     if (ncols > 0) {
-      k_iota<<<nblocks(ncols), kTB, 0, s>>>(ids, ncols);
+      k_band_keys<<<nblocks(ncols), kTB, 0, s>>>(p->unode, p->urel, ncols, R, band, k3, ids);
       MRGCN_HIP_TRY(hipGetLastError());
       size_t tb = 0;
-      const int end_bit = bits_for(RN);
-      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, p->ulcol, ulcol_s, ids, p->rperm,
-                                                       (int)ncols, 0, end_bit, s));
+      const int end_bit = bits_for(ngroups * band + band);
+      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k3, k3_s, ids, p->rperm, (int)ncols, 0,
+                                                       end_bit, s));
       char *tmp;
       MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
-      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, p->ulcol, ulcol_s, ids, p->rperm,
-                                                       (int)ncols, 0, end_bit, s));
+      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k3, k3_s, ids, p->rperm, (int)ncols, 0,
+                                                       end_bit, s));
     }
-    k_node_ptr<<<nblocks(R + 1), kTB, 0, s>>>(ulcol_s, ncols, R, N, p->relptr);
+    k_lower_bound_ptr<<<nblocks(ngroups + 1), kTB, 0, s>>>(k3_s, ncols, ngroups, band, p->relptr);
     MRGCN_HIP_TRY(hipGetLastError());
-    // relation chunks (<= kRelChunk columns of one relation each), built on the host: R is small
-    std::vector<int32_t> h_relptr(R + 1);
-    MRGCN_HIP_TRY(hipMemcpyAsync(h_relptr.data(), p->relptr, (R + 1) * sizeof(int32_t),
+    // chunks (<= kRelChunk columns of one (band, relation) group each), built on the host
+    std::vector<int32_t> h_gptr(ngroups + 1);
+    MRGCN_HIP_TRY(hipMemcpyAsync(h_gptr.data(), p->relptr, (ngroups + 1) * sizeof(int32_t),
                                  hipMemcpyDeviceToHost, s));
     MRGCN_HIP_TRY(hipStreamSynchronize(s));
-    std::vector<int32_t> rel, beg, end, cptr_rel(R + 1, 0);
-    for (int64_t r = 0; r < R; ++r) {
-      cptr_rel[r] = (int32_t)rel.size();
-      for (int32_t b = h_relptr[r]; b < h_relptr[r + 1]; b += kRelChunk) {
-        rel.push_back((int32_t)r);
-        beg.push_back(b);
-        end.push_back(std::min(b + kRelChunk, h_relptr[r + 1]));
+    std::vector<int32_t> rel, beg, end;
+    std::vector<std::vector<int32_t>> by_rel(R);
+    for (int64_t g = 0; g < ngroups; ++g) {
+      const int32_t r = (int32_t)(g % R);
+      for (int32_t b0 = h_gptr[g]; b0 < h_gptr[g + 1]; b0 += kRelChunk) {
+        by_rel[r].push_back((int32_t)rel.size());
+        rel.push_back(r);
+        beg.push_back(b0);
+        end.push_back(std::min(b0 + kRelChunk, h_gptr[g + 1]));
       }
-      p->max_relchunks = std::max(p->max_relchunks, (int32_t)rel.size() - cptr_rel[r]);
     }
-    cptr_rel[R] = (int32_t)rel.size();
+    std::vector<int32_t> cptr_rel(R + 1, 0), ids_by_rel;
+    for (int64_t r = 0; r < R; ++r) {
+      cptr_rel[r] = (int32_t)ids_by_rel.size();
+      ids_by_rel.insert(ids_by_rel.end(), by_rel[r].begin(), by_rel[r].end());
+      p->max_relchunks = std::max(p->max_relchunks, (int32_t)by_rel[r].size());
+    }
+    cptr_rel[R] = (int32_t)ids_by_rel.size();
     p->n_relchunks = (int32_t)rel.size();
     MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_ptr, R + 1));
     MRGCN_HIP_TRY(hipMemcpy(p->relchunk_ptr, cptr_rel.data(), (R + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_ids, p->n_relchunks));
     MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_rel, p->n_relchunks));
     MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_beg, p->n_relchunks));
     MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_end, p->n_relchunks));
     if (p->n_relchunks > 0) {
       size_t nb = rel.size() * sizeof(int32_t);
+      MRGCN_HIP_TRY(hipMemcpy(p->relchunk_ids, ids_by_rel.data(), nb, hipMemcpyHostToDevice));
       MRGCN_HIP_TRY(hipMemcpy(p->relchunk_rel, rel.data(), nb, hipMemcpyHostToDevice));
       MRGCN_HIP_TRY(hipMemcpy(p->relchunk_beg, beg.data(), nb, hipMemcpyHostToDevice));
       MRGCN_HIP_TRY(hipMemcpy(p->relchunk_end, end.data(), nb, hipMemcpyHostToDevice));
@@ -505,7 +539,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
 
 void free_plan(mrgcn_plan *p) {
   void *ptrs[] = {p->rowptr, p->lcol, p->ccol, p->rowidx, p->val, p->cptr, p->crow, p->urel, p->unode,
-                  p->nptr, p->ulcol, p->mpos, p->mcol, p->mval, p->rperm, p->relptr, p->rnode, p->rmpos, p->relchunk_ptr, p->relchunk_rel, p->relchunk_beg, p->relchunk_end,
+                  p->nptr, p->ulcol, p->mpos, p->mcol, p->mval, p->rperm, p->relptr, p->rnode, p->rmpos, p->relchunk_ptr, p->relchunk_ids, p->relchunk_rel, p->relchunk_beg, p->relchunk_end,
                   p->cval, p->r_long_row, p->r_long_cptr, p->r_chunk_beg, p->r_chunk_end,
                   p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->r_chunk_row, p->c_chunk_row,
                   p->partials};
@@ -586,7 +620,7 @@ static int plan_lookup(const mrgcn_plan_t *p, int32_t which, const void **out, i
     case MRGCN_ARR_ROWIDX: src = p->rowidx; n = p->nnz; break;
     case MRGCN_ARR_ULCOL: src = p->ulcol; n = p->ncols; break;
     case MRGCN_ARR_RPERM: src = p->rperm; n = p->ncols; break;
-    case MRGCN_ARR_RELPTR: src = p->relptr; n = p->num_relations + 1; break;
+    case MRGCN_ARR_RELPTR: src = p->relptr; n = p->n_bands * p->num_relations + 1; break;
     case MRGCN_ARR_MPOS: src = p->mpos; n = p->ncols; break;
     case MRGCN_ARR_MCOL: src = p->mcol; n = p->nnz; break;
     case MRGCN_ARR_MVAL: src = p->mval; n = p->nnz; break;

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
 
 // dW[r] += sum of the slab rows of a segment of <= kDwSeg chunks of relation r
 constexpr int kDwSeg = 32;
-__global__ __launch_bounds__(256) void k_dw_reduce(const int32_t *__restrict__ relchunk_rel,
+__global__ __launch_bounds__(256) void k_dw_reduce(const int32_t *__restrict__ relchunk_ids,
                                                    const int32_t *__restrict__ relchunk_ptr, int n_seg_max,
                                                    const float *__restrict__ slab, int KF,
                                                    float *__restrict__ dW, int R) {
@@ -246,10 +246,10 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const int32_t *__restrict__ r
     float s0 = 0.f, s1 = 0.f;
     int c = c0;
     for (; c + 2 <= c1; c += 2) {
-      s0 += slab[(int64_t)c * KF + t];
-      s1 += slab[(int64_t)(c + 1) * KF + t];
+      s0 += slab[(int64_t)relchunk_ids[c] * KF + t];
+      s1 += slab[(int64_t)relchunk_ids[c + 1] * KF + t];
     }
-    if (c < c1) s0 += slab[(int64_t)c * KF + t];
+    if (c < c1) s0 += slab[(int64_t)relchunk_ids[c] * KF + t];
     const float s = s0 + s1;
     if (relchunk_ptr[r + 1] - relchunk_ptr[r] <= kDwSeg) dW[(int64_t)r * KF + t] = s;  // sole writer
     else if (s != 0.f) atomicAdd(&dW[(int64_t)r * KF + t], s);
@@ -336,7 +336,7 @@ int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, 
     const int n_seg_max = (p->max_relchunks + kDwSeg - 1) / kDwSeg;
     if (n_seg_max > 0) {
       k_dw_reduce<<<dim3((unsigned)(p->num_relations * n_seg_max)), dim3(256), 0, s>>>(
-          p->relchunk_rel, p->relchunk_ptr, n_seg_max, slab, K * F, dW, (int)p->num_relations);
+          p->relchunk_ids, p->relchunk_ptr, n_seg_max, slab, K * F, dW, (int)p->num_relations);
       MRGCN_HIP_TRY(hipGetLastError());
     }
   }

@@ -86,6 +86,15 @@ def test_plan_on_skewed_random_graph_and_errors():
         _plan_from_coo(np.array([0, 1]), np.array([0, 30]), np.ones(2, np.float32), 10, 10, 3)
 
 
+def test_plan_bit_exact_on_multi_band_graph():
+    """AM/5-shaped graph: 333k nodes = 3 node bands of the transform order, 8 000 long rows."""
+    from mrgcn_amd import synth
+    g = synth.make_graph("am", seed=4, scale=0.2)
+    plan = _plan_from_coo(g.rows, g.cols, g.vals, g.num_nodes, g.num_nodes, g.num_relations)
+    assert g.num_nodes > 2 * util.NODE_BAND
+    _check_plan(plan, util.numpy_plan(g.rows, g.cols, g.vals, g.num_nodes, g.num_nodes, g.num_relations))
+
+
 FEATS = [1, 2, 3, 4, 5, 8, 10, 11, 12, 16, 17, 31, 64, 200, 300]
 
 

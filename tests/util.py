@@ -6,6 +6,7 @@ import scipy.sparse as sp
 import torch
 
 HOT_MIN_REFS = 16  # csrc/common.hpp: kHotMinRefs
+NODE_BAND = 131072  # csrc/common.hpp: kNodeBand
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -91,8 +92,11 @@ def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False):
     urel = (uk % R).astype(np.int32)
     ulcol = (urel.astype(np.int64) * N + unode).astype(np.int32)
     nptr = np.searchsorted(unode, np.arange(N + 1)).astype(np.int32)
-    rperm = np.argsort(ulcol, kind="stable").astype(np.int32)
-    relptr = np.searchsorted(ulcol[rperm], np.arange(R + 1, dtype=np.int64) * N).astype(np.int32)
+    band = min(NODE_BAND, N)
+    nbands = (N + band - 1) // band
+    k3 = ((unode.astype(np.int64) // band) * R + urel) * band + unode.astype(np.int64) % band
+    rperm = np.argsort(k3, kind="stable").astype(np.int32)
+    relptr = np.searchsorted(k3[rperm], np.arange(nbands * R + 1, dtype=np.int64) * band).astype(np.int32)
     # storage order of the compact operand: hot columns (>= HOT_MIN_REFS entries) by falling count,
     # then every other column by the first row that reads it
     cnt = np.diff(cptr).astype(np.int64)
