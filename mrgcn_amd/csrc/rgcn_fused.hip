@@ -281,8 +281,8 @@ template <int FT, bool VEC2>
 __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dcomp(const int32_t *__restrict__ urel,
                                                           const int32_t *__restrict__ unode,
                                                           const float *__restrict__ dM, int64_t ldM,
-                                                          const float *__restrict__ V, int64_t N, int R,
-                                                          int B, int F, int64_t ncols,
+                                                          const float *__restrict__ V, int64_t ldV,
+                                                          int64_t N, int R, int B, int F, int64_t ncols,
                                                           float *__restrict__ dcomp, int dcomp_in_lds) {
   extern __shared__ float s_dcomp[];  // [R][BS], BS = B | 1: lanes hold different relations
   const int BS = B | 1;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dcomp(const int32_t *__restr
 #pragma unroll
     for (int o = 0; o < FT; ++o) dm[o] = (o < F) ? dp[o] : 0.f;
     for (int b = 0; b < B; ++b) {
-      const float *vp = V + ((int64_t)b * N + j) * F;
+      const float *vp = V + ((int64_t)b * N + j) * ldV;
       float dot = 0.f;
       if (VEC2) {  // F even: rows of V are 8-byte aligned; 16-byte loads need dword alignment only
 #pragma unroll
@@ -629,7 +629,6 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
                             double *dV_sumsq, void *stream) {
   MRGCN_REQUIRE(p && dM && V && comp && dV && dcomp, "NULL");
   MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
-  MRGCN_REQUIRE(F <= 64, "basis_mix_bwd supports F <= 64 (tile the feature dimension)");
   hipStream_t s = (hipStream_t)stream;
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
@@ -657,29 +656,36 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
 #undef MIXDV_GO
     MRGCN_HIP_TRY(hipGetLastError());
   }
-  // pass 2: dcomp
+  // pass 2: dcomp, the feature dimension in tiles of <= 64 (dcomp accumulates over the tiles)
   if (p->ncols > 0) {
     size_t lds = (size_t)R * (B | 1) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
     int grid = mix_grid(lds, p->ncols);
-    const bool v2 = (F % 2 == 0) && (((uintptr_t)V) % 8 == 0);
-#define MIXDC_GO(T)                                                                                     \
-  do {                                                                                                  \
-    if (v2)                                                                                             \
-      k_mix_bwd_dcomp<T, true><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->urel, p->unode, dM, ldM, V, N,  \
-                                                                     R, B, F, p->ncols, dcomp, in_lds); \
-    else                                                                                                \
-      k_mix_bwd_dcomp<T, false><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->urel, p->unode, dM, ldM, V, N, \
-                                                                      R, B, F, p->ncols, dcomp, in_lds); \
+    for (int f0 = 0; f0 < F; f0 += 64) {
+      const int Ft = (F - f0 < 64) ? (F - f0) : 64;
+      const float *dMt = dM + f0, *Vt = V + f0;
+      const bool v2 = (Ft % 2 == 0) && (F % 2 == 0) && (((uintptr_t)Vt) % 8 == 0);
+#define MIXDC_GO(T)                                                                                    \
+  do {                                                                                                 \
+    if (v2)                                                                                            \
+      k_mix_bwd_dcomp<T, true><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->urel, p->unode, dMt, ldM, Vt,  \
+                                                                     F, N, R, B, Ft, p->ncols, dcomp,  \
+                                                                     in_lds);                          \
+    else                                                                                               \
+      k_mix_bwd_dcomp<T, false><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->urel, p->unode, dMt, ldM, Vt, \
+                                                                      F, N, R, B, Ft, p->ncols, dcomp, \
+                                                                      in_lds);                         \
   } while (0)
-    if (F <= 4) MIXDC_GO(4);
-    else if (F <= 8) MIXDC_GO(8);
-    else if (F <= 12) MIXDC_GO(12);
-    else if (F <= 16) MIXDC_GO(16);
-    else if (F <= 32) MIXDC_GO(32);
-    else MIXDC_GO(64);
+      if (Ft <= 4) MIXDC_GO(4);
+      else if (Ft <= 8) MIXDC_GO(8);
+      else if (Ft <= 12) MIXDC_GO(12);
+      else if (Ft <= 16) MIXDC_GO(16);
+      else if (Ft <= 32) MIXDC_GO(32);
+      else MIXDC_GO(64);
 #undef MIXDC_GO
+      MRGCN_HIP_TRY(hipGetLastError());
+    }
   }
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;

@@ -145,6 +145,32 @@ def test_mrgcn_through_fullbatch_boundary(name):
                 assert (diff > 2e-5).mean() < 5e-3 and diff.max() <= 0.021 * step, k
 
 
+@pytest.mark.parametrize("N,R,B,F,bias", [(400, 5, 2, 200, False), (300, 7, 3, 130, True), (200, 4, 0, 96, True)])
+def test_featureless_wide_layer_vs_oracle(N, R, B, F, bias):
+    """FB15k-237-style encoder layer: featureless input layer with a wide hidden size
+    (configs/fb15k-237.toml: 2 bases, hidden 200) — forward and every gradient."""
+    from oracle import rgcn_oracle as O
+    from mrgcn_amd.layers.graph import GraphConvolution
+    from mrgcn_amd.plan import plan_of
+    rng = np.random.default_rng(F)
+    rows, cols, vals, A = _oracle_layer_case(rng, N, R, max(B, 1), 1, F, 8 * N, 150)
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals),
+                                 (N, R * N)).cuda()
+    torch.manual_seed(F)
+    layer = GraphConvolution(0, F, R, N, num_bases=B, bias=bias, input_layer=True, featureless=True).cuda()
+    Y = layer._forward_fused(None, plan_of(At, N, R), relu=True)
+    w = torch.randn_like(Y)
+    (Y * w).sum().backward()
+    cfg = O.LayerCfg(0, F, R, N, B, bias=bias, input_layer=True, featureless=True)
+    p = {k: v.detach().cpu().numpy() for k, v in layer.named_parameters()}
+    pre, cache = O.layer_forward(cfg, p, None, A)
+    np.testing.assert_allclose(Y.detach().cpu().numpy(), np.maximum(pre, 0), rtol=1e-4, atol=1e-4)
+    grads, _ = O.layer_backward(cfg, p, None, A, w.cpu().numpy().astype(np.float64) * (pre > 0), cache)
+    for k, v in grads.items():
+        got = getattr(layer, k).grad.cpu().numpy()
+        np.testing.assert_allclose(got, v, rtol=2e-4, atol=2e-5 * (np.abs(v).max() + 1e-12) + 1e-6, err_msg=k)
+
+
 def _oracle_layer_case(rng, N, R, B, K, F, nnz, hub):
     """Random layer problem + float64 oracle results for the fused kernels."""
     import scipy.sparse as sp
