@@ -3,6 +3,8 @@
 // gradient norm + clip coefficient (clip_grad_norm_(…, 1.0), :192) and Adam (:35-37, :193).
 // All are HBM-bound: float4 accesses, grid-stride over <= 2048 blocks.  At AM scale the
 // Adam pass over weight_I (2.67 GB x 7 streams) dominates the epoch.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mrgcn {
@@ -86,6 +88,7 @@ __global__ void k_clip_coef(const double *__restrict__ sumsq, float max_norm, fl
 }
 
 // torch.optim.Adam (amsgrad = False, maximize = False), gradient pre-scaled by *scale
+template <bool NT>
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                        float *__restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                        float wd, float bc1, float bc2_sqrt, const float *__restrict__ scale) {
@@ -106,14 +109,31 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
   };
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
        i += (int64_t)gridDim.x * blockDim.x) {
-    float4 P = p4[i], G = g4[i], M = m4[i], V = v4[i];
+    float4 P, G, M, V;
+    if (NT) {  // streamed once per step: keep it out of the way of resident data
+      using v4f = __attribute__((ext_vector_type(4))) float;
+      auto ld = [](const float4 *q) {
+        v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(q));
+        return make_float4(t.x, t.y, t.z, t.w);
+      };
+      P = ld(&p4[i]); G = ld(&g4[i]); M = ld(&m4[i]); V = ld(&v4[i]);
+    } else {
+      P = p4[i]; G = g4[i]; M = m4[i]; V = v4[i];
+    }
     upd(P.x, G.x, M.x, V.x);
     upd(P.y, G.y, M.y, V.y);
     upd(P.z, G.z, M.z, V.z);
     upd(P.w, G.w, M.w, V.w);
-    p4[i] = P;
-    m4[i] = M;
-    v4[i] = V;
+    if (NT) {
+      using v4f = __attribute__((ext_vector_type(4))) float;
+      auto st = [](float4 x, float4 *q) {
+        v4f t = {x.x, x.y, x.z, x.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(q));
+      };
+      st(P, &p4[i]); st(M, &m4[i]); st(V, &v4[i]);
+    } else {
+      p4[i] = P; m4[i] = M; v4[i] = V;
+    }
   }
   if (blockIdx.x == 0)
     for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += blockDim.x) {
@@ -196,9 +216,19 @@ int mrgcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *
   if (n == 0) return MRGCN_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  k_adam<<<dim3(stream_grid(n >> 2)), dim3(kTB), 0, (hipStream_t)stream>>>(
-      param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-      (float)sqrt(bc2), grad_scale);
+  static const int nt_mode = getenv("MRGCN_ADAM_NT") ? atoi(getenv("MRGCN_ADAM_NT")) : 0;
+  static const int grid_cap = getenv("MRGCN_ADAM_GRID") ? atoi(getenv("MRGCN_ADAM_GRID")) : 8192;
+  int64_t blocks = ((n >> 2) + kTB - 1) / kTB;
+  if (blocks < 1) blocks = 1;
+  if (blocks > grid_cap) blocks = grid_cap;
+  if (nt_mode)
+    k_adam<true><<<dim3((unsigned)blocks), dim3(kTB), 0, (hipStream_t)stream>>>(
+        param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+        (float)sqrt(bc2), grad_scale);
+  else
+    k_adam<false><<<dim3((unsigned)blocks), dim3(kTB), 0, (hipStream_t)stream>>>(
+        param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+        (float)sqrt(bc2), grad_scale);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -39,6 +39,20 @@ def clear_grad_sumsq():
     _GRAD_SUMSQ.clear()
 
 
+# measured on the AM shape: 14.6 ms with the overlap vs 14.3 ms without (every one of these
+# kernels already saturates the memory system on its own), so it is opt-in
+_OVERLAP = os.environ.get("MRGCN_OVERLAP", "0") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device) -> torch.cuda.Stream:
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[device] = st
+    return st
+
+
 def _ld_for(F: int) -> int:
     """Leading dimension of the compact operand: rows padded to a multiple of 4 floats (16-byte
     float4 gathers).  Measured on the AM shape: 12 vs 16 floats per 10-feature row gather within
@@ -154,6 +168,14 @@ class _RgcnLayer(torch.autograd.Function):
         dM = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
         plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)
         d_wI = d_comp = dX = dW = None
+        # The consumers of dM are independent of each other and bound by different resources
+        # (dV: HBM writes, dcomp: vector-memory issue, dW/dX: matrix cores + gathers), so the
+        # input-term and feature-term backward run on two HIP streams and overlap.
+        overlap = has_I and has_X and _OVERLAP
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if overlap else main
+        if overlap:
+            side.wait_stream(main)  # dM is ready on `main`
         with torch.cuda.device(dev):
             if has_I:
                 if has_comp:
@@ -173,21 +195,27 @@ class _RgcnLayer(torch.autograd.Function):
                 need_dX = ctx.needs_input_grad[4]
                 need_dW = ctx.needs_input_grad[5]
                 K = X.shape[1]
-                if need_dX:
-                    dX = torch.empty((X.shape[0], K), dtype=torch.float32, device=dev)
-                if need_dW:
-                    dW = torch.empty_like(W_F)
-                if need_dX or need_dW:
-                    ws = None
-                    nws = int(lib.mrgcn_rel_transform_bwd_workspace(plan.handle, K, F, int(need_dX),
-                                                                    int(need_dW)))
-                    if nws > 0:
-                        ws = torch.empty((nws,), dtype=torch.float32, device=dev)
-                    L.check(lib.mrgcn_rel_transform_bwd_f32(
-                        plan.handle, dM.data_ptr(), ld, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
-                        dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0,
-                        ws.data_ptr() if ws is not None else 0, ws.numel() if ws is not None else 0, s),
-                        "mrgcn_rel_transform_bwd_f32")
+                with torch.cuda.stream(side):
+                    if need_dX:
+                        dX = torch.empty((X.shape[0], K), dtype=torch.float32, device=dev)
+                    if need_dW:
+                        dW = torch.empty_like(W_F)
+                    if need_dX or need_dW:
+                        ws = None
+                        nws = int(lib.mrgcn_rel_transform_bwd_workspace(plan.handle, K, F, int(need_dX),
+                                                                        int(need_dW)))
+                        if nws > 0:
+                            ws = torch.empty((nws,), dtype=torch.float32, device=dev)
+                        L.check(lib.mrgcn_rel_transform_bwd_f32(
+                            plan.handle, dM.data_ptr(), ld, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
+                            dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0,
+                            ws.data_ptr() if ws is not None else 0, ws.numel() if ws is not None else 0,
+                            side.cuda_stream), "mrgcn_rel_transform_bwd_f32")
+                if overlap:
+                    main.wait_stream(side)
+                    for t in (dX, dW, ws, dM):  # allocated / used on `side`: keep the allocator honest
+                        if t is not None:
+                            t.record_stream(main if t is not dM else side)
         return None, None, d_wI, d_comp, dX, dW, dbias, None
 
 
