@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--cpu-scale", type=float, default=1.0 / 64, help="fraction of the workload the CPU baseline runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal-spmm", action="store_true")
+    ap.add_argument("--partition", action="store_true",
+                    help="N > 1: node-partition ONE graph over the ranks (strong scaling, mrgcn_amd.partition) "
+                         "instead of running N replicas")
     ap.add_argument("--spmm-iters", type=int, default=30)
     return ap.parse_args()
 
@@ -113,9 +116,13 @@ def main():
     from mrgcn_amd import dist as mdist
 
     world, rank, local_rank = mdist.env_world()
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    ngpu = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", (local_rank % ngpu) if world > 1 else 0)
     torch.cuda.set_device(dev)
-    mdist.init("nccl", dev)  # one process per GPU over RCCL (no-op at world 1)
+    # one process per GPU over RCCL; with fewer GPUs than ranks (functional tests on a 1-GPU box)
+    # the ranks share a device and talk over gloo
+    backend = os.environ.get("MRGCN_DIST_BACKEND", "nccl" if ngpu >= world else "gloo")
+    mdist.init(backend, dev if backend == "nccl" else None)  # no-op at world 1
 
     from mrgcn_amd import _lib as L
     from mrgcn_amd import synth
@@ -148,6 +155,24 @@ def main():
     def step():
         return train_step(model, lambda: model(X, A), idx, tgt, opt)
 
+    partitioned = args.partition and world > 1
+    if partitioned:
+        # strong scaling: rank g owns node range g, its weight_I rows / Adam state and its columns of A
+        from mrgcn_amd.partition import NodePartition, PartitionedRGCN, partitioned_train_step
+        del model, opt, plan, A
+        torch.cuda.empty_cache()
+        part = NodePartition(N, world, rank)
+        pmodel = PartitionedRGCN(modules, R, N, B, featureless, False, part).to(dev)
+        pmodel.sync_replicated()
+        plan = pmodel.build_plan(g.rows, g.cols, g.vals, dev)
+        Xl = None if featureless else part.shard_rows(X)
+        popt = ClipAdam(pmodel.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+        popt.set_distributed(None, pmodel.sharded_parameters())
+        model = pmodel
+
+        def step():  # noqa: F811
+            return partitioned_train_step(pmodel, Xl, idx_np, y_np, popt)
+
     def barrier():
         mdist.barrier(dev)
 
@@ -170,7 +195,7 @@ def main():
         from mrgcn_amd.functional import _ld_for
         ld = _ld_for(F)
         M = torch.randn((plan.ncols, ld), device=dev)
-        Y = torch.empty((N, F), device=dev)
+        Y = torch.empty((plan.num_rows, F), device=dev)
         t_c = event_time_ms(lambda: plan.spmm(L.VIEW_COMPACT, M, F=F, out=Y), args.spmm_iters, stream)
         bytes_alg = plan.spmm_bytes(F)
         ach = bytes_alg / (t_c * 1e-3) / 1e9
@@ -186,7 +211,7 @@ def main():
                     "kernel": "mrgcn::k_spmm<G,VEC> (+k_spmm_finalize) on the compact view, F=%d, ld=%d" % (F, ld),
                     "algorithmic_bytes": bytes_alg, "avg_ms": t_c}
         extra = {}
-        dY = torch.randn((N, F), device=dev)
+        dY = torch.randn((plan.num_rows, F), device=dev)
         dM = torch.empty((plan.ncols, ld), device=dev)
         t_t = event_time_ms(lambda: plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM), args.spmm_iters, stream)
         extra["spmm_transposed_ms"] = t_t
@@ -194,7 +219,7 @@ def main():
         del dY, dM
         if not args.no_literal_spmm:
             try:  # the reference's own operand layout: dense (R*N) x F, 17.8 GB at AM scale
-                D = torch.randn((R * N, F), device=dev)
+                D = torch.randn((R * plan.num_nodes, F), device=dev)
                 t_l = event_time_ms(lambda: plan.spmm(L.VIEW_LITERAL, D, out=Y), args.spmm_iters, stream)
                 extra["spmm_literal_ms"] = t_l
                 extra["spmm_literal_gbps"] = bytes_alg / (t_l * 1e-3) / 1e9
@@ -214,12 +239,14 @@ def main():
             "metric": "full-batch R-GCN epoch time (ms), AM-shaped graph",
             "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if partitioned else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
             "config": {"workload": f"{name}-shaped synthetic KG (SURVEY §8d), scale {args.scale:g}",
                        "N": N, "R": R, "nnz": plan.nnz, "ncols_touched": plan.ncols,
                        "layers": dims, "num_bases": B, "value_mode": args.value_mode,
                        "engine": args.engine, "labelled": int(idx.numel()), "params": n_params,
-                       "parallelism": "replicas x%d" % world if world > 1 else "1 GPU"},
+                       "parallelism": ("node-partitioned x%d" % world if partitioned else
+                                       "replicas x%d" % world) if world > 1 else "1 GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "spmm_hbm_gbps": ach,

@@ -41,7 +41,8 @@ def max_over_ranks(value: float, device: torch.device | None = None) -> float:
     """MAX all-reduce of a host scalar (the timed region of bench.py)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    on = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=on)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

@@ -1,0 +1,237 @@
+"""Node-partitioned full-batch R-GCN over the GPUs of one node.
+
+Rank g of G owns the contiguous source-node range [g*S, (g+1)*S) (S = ceil(N/G)): the rows of
+the layer input H for those nodes, their rows of `weight_I` (the dominant parameter and its
+Adam state are therefore never replicated nor communicated) and the *columns* (r, j in range)
+of the stacked adjacency A.  Per layer
+
+    forward   Y^_g = A[:, cols_g] . M_g          local, the fused kernels on the local plan
+              Y_g  = reduce-scatter_rows(Y^_g)    one collective: every rank gets its own rows
+    backward  dY^  = all-gather_rows(dY_g)        one collective
+              dM_g = A[:, cols_g]^T dY^           local; then dV_g / dX_g local,
+              d(comp, W_F, b) all-reduced          (KBs)
+
+One process per GPU, torch.distributed (RCCL over xGMI on GPUs; gloo in the tests).  The
+maths equals `mrgcn_amd.models.rgcn.RGCN` on one GPU (tests: logits and gradients agree)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import functional as Fn
+from .layers.graph import GraphConvolution
+from .plan import GraphPlan
+
+
+class NodePartition:
+    def __init__(self, num_nodes: int, world: int, rank: int):
+        assert 0 <= rank < world
+        self.N, self.world, self.rank = int(num_nodes), int(world), int(rank)
+        self.S = (self.N + world - 1) // world      # nodes per rank (last ranks may be short)
+        self.Np = self.S * world                    # padded node count (reduce-scatter needs equal parts)
+        self.j0 = min(rank * self.S, self.N)
+        self.j1 = min(self.j0 + self.S, self.N)
+
+    @property
+    def n_local(self) -> int:
+        return self.j1 - self.j0
+
+    def owner(self, nodes: np.ndarray) -> np.ndarray:
+        return np.asarray(nodes) // self.S
+
+    def local_coo(self, rows, cols, vals, num_relations: int):
+        """Entries of A whose column's source node lies in this rank's range, re-indexed to the
+        local column space r*S + (j - j0); rows stay global (padded to Np by the plan)."""
+        rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+        r, j = cols // self.N, cols % self.N
+        keep = (j >= self.j0) & (j < self.j1)
+        return rows[keep], r[keep] * self.S + (j[keep] - self.j0), np.asarray(vals)[keep]
+
+    def shard_weight_I(self, w: torch.Tensor, S_b: int) -> torch.Tensor:
+        """(S_b*N, out) -> this rank's (S_b*S, out) rows (zero rows for padding nodes)."""
+        out = w.shape[1]
+        full = w.view(S_b, self.N, out)
+        loc = torch.zeros((S_b, self.S, out), dtype=w.dtype, device=w.device)
+        loc[:, : self.n_local] = full[:, self.j0:self.j1]
+        return loc.reshape(S_b * self.S, out)
+
+    def shard_rows(self, X: torch.Tensor) -> torch.Tensor:
+        loc = torch.zeros((self.S,) + tuple(X.shape[1:]), dtype=X.dtype, device=X.device)
+        loc[: self.n_local] = X[self.j0:self.j1]
+        return loc
+
+
+# ---- collectives (RCCL on GPUs; gloo — CPU staged — in the tests) -----------------------------
+def _staged(t: torch.Tensor, group):
+    return dist.get_backend(group) == "gloo" and t.is_cuda
+
+
+def reduce_scatter_rows(x: torch.Tensor, group=None) -> torch.Tensor:
+    """x: [world*S, F] partial sums -> this rank's [S, F] rows of the total."""
+    world = dist.get_world_size(group)
+    S = x.shape[0] // world
+    if dist.get_backend(group) == "gloo":
+        buf = x.detach().cpu() if x.is_cuda else x.detach().clone()
+        dist.all_reduce(buf, group=group)
+        r = dist.get_rank(group)
+        return buf[r * S:(r + 1) * S].to(x.device).contiguous()
+    out = torch.empty((S, x.shape[1]), dtype=x.dtype, device=x.device)
+    dist.reduce_scatter_tensor(out, x.contiguous(), group=group)
+    return out
+
+
+def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
+    world = dist.get_world_size(group)
+    if _staged(x, group):
+        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(world)]
+        dist.all_gather(parts, x.detach().cpu().contiguous(), group=group)
+        return torch.cat(parts, 0).to(x.device)
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x.contiguous(), group=group)
+        return torch.cat(parts, 0)
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    return out
+
+
+def all_reduce_sum_(x: torch.Tensor, group=None) -> torch.Tensor:
+    if _staged(x, group):
+        buf = x.detach().cpu()
+        dist.all_reduce(buf, group=group)
+        x.copy_(buf.to(x.device))
+    else:
+        dist.all_reduce(x, group=group)
+    return x
+
+
+class _ReduceScatterRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return reduce_scatter_rows(x, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return all_gather_rows(g.contiguous(), ctx.group), None
+
+
+# ---- the partitioned model ----------------------------------------------------------------------
+class PartitionedRGCN(nn.Module):
+    """`RGCN` (models/rgcn.py) with node-partitioned layers.  `modules` as for RGCN.  Every
+    rank constructs it with the same seed; `load_full_state` shards a reference-shaped state."""
+
+    def __init__(self, modules, num_relations, num_nodes, num_bases, featureless, bias, part: NodePartition,
+                 group=None):
+        super().__init__()
+        self.part, self.group = part, group
+        self.num_nodes, self.num_relations, self.num_bases = num_nodes, num_relations, num_bases
+        self.layers = nn.ModuleDict()
+        self.relu = []
+        for i, (indim, outdim, _t, act) in enumerate(modules):
+            first = i == 0
+            # local layer: S source nodes per relation block (rows of weight_I for my nodes only)
+            self.layers[f"layer_{i}"] = GraphConvolution(
+                indim, outdim, num_relations, part.S, num_bases=num_bases, bias=bias, input_layer=first,
+                featureless=featureless if first else False)
+            self.relu.append(isinstance(act, nn.ReLU))
+        self.num_layers = len(self.layers)
+        self.plan = None
+
+    def sharded_parameters(self):
+        return [l.weight_I for l in self.layers.values() if l.weight_I is not None]
+
+    def replicated_parameters(self):
+        sh = {id(p) for p in self.sharded_parameters()}
+        return [p for p in self.parameters() if id(p) not in sh]
+
+    @torch.no_grad()
+    def load_full_state(self, state: dict):
+        """`state`: an `RGCN.state_dict()` in the reference's shapes (keys layers.layer_<i>.<name>)."""
+        for i, layer in enumerate(self.layers.values()):
+            for name, p in layer.named_parameters():
+                full = state[f"layers.layer_{i}.{name}"].to(p.device)
+                if name == "weight_I":
+                    S_b = self.num_bases if self.num_bases > 0 else self.num_relations
+                    p.copy_(self.part.shard_weight_I(full, S_b))
+                else:
+                    p.copy_(full)
+
+    def build_plan(self, rows, cols, vals, device):
+        lr, lc, lv = self.part.local_coo(rows, cols, vals, self.num_relations)
+        A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([lr, lc])), torch.from_numpy(lv),
+                                    (self.part.Np, self.num_relations * self.part.S)).to(device)
+        self.plan = GraphPlan(A, self.part.S, self.num_relations)
+        return self.plan
+
+    def forward(self, X_local):
+        """X_local: this rank's [S, K] input rows (None when featureless).  Returns its [S, C]
+        rows of the logits."""
+        H = X_local
+        for i, layer in enumerate(self.layers.values()):
+            Yp = Fn.rgcn_layer(self.plan, _NoBias(layer), H, relu=False)   # [Np, out] partial sums
+            Y = _ReduceScatterRows.apply(Yp, self.group)                   # [S, out] own rows
+            if layer.bias:
+                Y = Y + layer.b
+            H = torch.relu(Y) if self.relu[i] else Y
+        return H
+
+    @torch.no_grad()
+    def sync_replicated(self, src: int = 0):
+        """Replicated parameters must start identical on every rank."""
+        for q in self.replicated_parameters():
+            if _staged(q, self.group):
+                buf = q.detach().cpu()
+                dist.broadcast(buf, src, group=self.group)
+                q.copy_(buf.to(q.device))
+            else:
+                dist.broadcast(q.data, src, group=self.group)
+
+    def allreduce_replicated_grads(self):
+        """Gradients of the small replicated parameters are sums over all columns of A."""
+        for p in self.replicated_parameters():
+            if p.grad is not None:
+                all_reduce_sum_(p.grad, self.group)
+
+
+class _NoBias:
+    """View of a layer without its bias (added after the reduction, once)."""
+
+    def __init__(self, layer):
+        self._l = layer
+
+    def __getattr__(self, k):
+        if k == "bias":
+            return False
+        return getattr(self._l, k)
+
+
+def partitioned_loss(logits_local, idx_global, targets, part: NodePartition, group=None):
+    """Mean cross-entropy over ALL labelled nodes; each rank differentiates its own rows."""
+    from .train import categorical_crossentropy
+    idx_global = np.asarray(idx_global)
+    mine = (idx_global >= part.j0) & (idx_global < part.j1)
+    n_total = len(idx_global)
+    dev = logits_local.device
+    if mine.any():
+        li = torch.from_numpy(idx_global[mine] - part.j0).to(dev)
+        lt = torch.from_numpy(np.asarray(targets)[mine]).to(dev)
+        local = categorical_crossentropy(logits_local, li, lt) * (float(mine.sum()) / n_total)
+    else:
+        local = (logits_local * 0.0).sum()
+    total = local.detach().clone()
+    all_reduce_sum_(total, group)
+    return local, total
+
+
+def partitioned_train_step(model: PartitionedRGCN, X_local, idx_global, targets, optimizer):
+    Fn.clear_grad_sumsq()
+    logits = model(X_local)
+    local, total = partitioned_loss(logits, idx_global, targets, model.part, model.group)
+    optimizer.zero_grad(set_to_none=True)
+    local.backward()
+    model.allreduce_replicated_grads()
+    optimizer.step()
+    return total

@@ -67,11 +67,19 @@ class ClipAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.max_norm = max_norm
         self._scratch = {}
+        self._dist = None  # (group, ids of parameters sharded across ranks)
+
+    def set_distributed(self, group, sharded_params):
+        """Node-partitioned training (mrgcn_amd.partition): `sharded_params` hold disjoint shards
+        per rank (their squared norms add up across ranks); every other parameter is replicated
+        and already carries the all-reduced gradient (counted once)."""
+        self._dist = (group, {id(p) for p in sharded_params})
 
     def _dev_scratch(self, device):
         s = self._scratch.get(device)
         if s is None:
             s = dict(sumsq=torch.zeros((), dtype=torch.float64, device=device),
+                     sumsq_sharded=torch.zeros((), dtype=torch.float64, device=device),
                      coef=torch.ones((), dtype=torch.float32, device=device),
                      norm=torch.zeros((), dtype=torch.float32, device=device))
             self._scratch[device] = s
@@ -90,17 +98,24 @@ class ClipAdam(torch.optim.Optimizer):
         s = _stream(device)
         with torch.cuda.device(device):
             sc["sumsq"].zero_()
+            sc["sumsq_sharded"].zero_()
+            sharded = self._dist[1] if self._dist else ()
             grads = []
             for _, p in live:
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 grads.append(g)
+                acc = sc["sumsq_sharded"] if id(p) in sharded else sc["sumsq"]
                 pre = pop_grad_sumsq(g)  # already accumulated by the kernel that produced g?
                 if pre is not None:
-                    sc["sumsq"] += pre
+                    acc += pre
                 else:
-                    L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), sc["sumsq"].data_ptr(), s),
+                    L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), acc.data_ptr(), s),
                             "mrgcn_sumsq_accum_f32")
             clear_grad_sumsq()
+            if self._dist:
+                from .partition import all_reduce_sum_
+                all_reduce_sum_(sc["sumsq_sharded"], self._dist[0])
+            sc["sumsq"] += sc["sumsq_sharded"]
             use_clip = self.max_norm is not None and self.max_norm > 0
             if use_clip:
                 L.check(lib.mrgcn_clip_coef_f32(sc["sumsq"].data_ptr(), float(self.max_norm),

@@ -44,3 +44,63 @@ def test_world1_is_a_noop():
     assert D.env_world() == (1, 0, 0)
     assert D.max_over_ranks(3.5) == 3.5
     D.barrier()
+
+
+# ---- node partition: host logic on CPU, collectives over gloo ----------------------
+def test_node_partition_arithmetic_and_local_coo():
+    import numpy as np
+    from mrgcn_amd import synth
+    from mrgcn_amd.partition import NodePartition
+    g = synth.make_graph("aifb", seed=2, scale=0.2)
+    N, R = g.num_nodes, g.num_relations
+    world = 3
+    parts = [NodePartition(N, world, r) for r in range(world)]
+    assert parts[0].Np == parts[0].S * world >= N and sum(p.n_local for p in parts) == N
+    seen = 0
+    for p in parts:
+        lr, lc, lv = p.local_coo(g.rows, g.cols, g.vals, R)
+        seen += len(lr)
+        # local column r*S + (j - j0) maps back to the global column r*N + j
+        r_, jl = lc // p.S, lc % p.S
+        assert jl.max(initial=0) < max(p.n_local, 1)
+        back = r_ * N + jl + p.j0
+        key = set(zip(lr.tolist(), back.tolist()))
+        sel = (g.cols % N >= p.j0) & (g.cols % N < p.j1)
+        assert key == set(zip(g.rows[sel].tolist(), g.cols[sel].tolist()))
+    assert seen == g.nnz  # every entry belongs to exactly one rank
+    # parameter / feature sharding round trip
+    B, out = 3, 4
+    w = torch.arange(B * N * out, dtype=torch.float32).view(B * N, out)
+    cat = torch.cat([p.shard_weight_I(w, B).view(B, p.S, out)[:, :p.n_local] for p in parts], 1)
+    assert torch.equal(cat.reshape(B * N, out), w)
+
+
+def _coll_worker(rank, world, port, out):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from mrgcn_amd import partition as P
+    dist.init_process_group("gloo")
+    S, F = 3, 2
+    x = torch.full((world * S, F), float(rank + 1), requires_grad=True)
+    y = P._ReduceScatterRows.apply(x, None)            # sum over ranks of my rows
+    (y * (rank + 1)).sum().backward()                  # grad of my rows = rank + 1 -> all-gathered
+    g = torch.arange(S * F, dtype=torch.float32).view(S, F) + 100 * rank
+    out[rank] = (y.detach().tolist(), x.grad.tolist(), P.all_gather_rows(g).tolist(),
+                 P.all_reduce_sum_(torch.tensor([float(rank + 1)])).tolist())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_partition_collectives_gloo_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_coll_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    S, F = 3, 2
+    for r in (0, 1):
+        y, gx, ag, ar = out[r]
+        assert y == [[3.0] * F] * S                     # 1 + 2 on every row
+        assert gx == [[1.0] * F] * S + [[2.0] * F] * S  # backward = all-gather of the row grads
+        assert ag == (torch.arange(S * F).view(S, F).float().tolist()
+                      + (torch.arange(S * F).view(S, F).float() + 100).tolist())
+        assert ar == [3.0]

@@ -1,0 +1,94 @@
+"""Node-partitioned engine on the GPU box: two ranks (both on cuda:0, gloo with CPU
+staged collectives — RCCL needs one GPU per rank) against the single-GPU RGCN: logits,
+loss and parameters after two epochs agree."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    from mrgcn_amd import synth
+    g = synth.make_graph("aifb", seed=9, scale=0.5)
+    rng = np.random.default_rng(9)
+    N = g.num_nodes
+    X = rng.standard_normal((N, 6)).astype(np.float32)
+    idx = np.sort(rng.choice(N, 120, replace=False)).astype(np.int64)
+    y = rng.integers(0, 4, 120).astype(np.int64)
+    mods = [(6, 8, "mrgcn", torch.nn.ReLU()), (8, 4, "mrgcn", None)]
+    return g, X, idx, y, mods
+
+
+def _single():
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, train_step
+    g, X, idx, y, mods = _problem()
+    N, R = g.num_nodes, g.num_relations
+    torch.manual_seed(3)
+    model = RGCN(mods, R, N, 5, 0.0, False, True, False)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                (N, R * N)).cuda()
+    Xg = torch.from_numpy(X).cuda()
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    logits0 = model(Xg, A).detach().cpu().numpy()
+    losses = [float(train_step(model, lambda: model(Xg, A), torch.from_numpy(idx).cuda(),
+                               torch.from_numpy(y).cuda(), opt)) for _ in range(2)]
+    return state, logits0, losses, {k: v.cpu() for k, v in model.state_dict().items()}
+
+
+def _worker(rank, world, port, state, out):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from mrgcn_amd.partition import NodePartition, PartitionedRGCN, partitioned_train_step
+    from mrgcn_amd.train import ClipAdam
+    dist.init_process_group("gloo")
+    dev = torch.device("cuda:0")
+    g, X, idx, y, mods = _problem()
+    N, R = g.num_nodes, g.num_relations
+    part = NodePartition(N, world, rank)
+    model = PartitionedRGCN(mods, R, N, 5, False, True, part).to(dev)
+    model.load_full_state(state)
+    model.build_plan(g.rows, g.cols, g.vals, dev)
+    Xl = part.shard_rows(torch.from_numpy(X)).to(dev)
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    opt.set_distributed(None, model.sharded_parameters())
+    logits0 = model(Xl).detach().cpu().numpy()[: part.n_local]
+    losses = [float(partitioned_train_step(model, Xl, idx, y, opt)) for _ in range(2)]
+    wI = model.layers["layer_0"].weight_I.detach().cpu().view(5, part.S, -1)[:, : part.n_local]
+    out[rank] = (logits0, losses, wI.numpy(), model.layers["layer_1"].weight_F.detach().cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_partition_equals_single_gpu():
+    state, logits0, losses, final = _single()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), state, out), nprocs=2, join=True)
+    got_logits = np.concatenate([out[0][0], out[1][0]], 0)
+    np.testing.assert_allclose(got_logits, logits0, rtol=1e-4, atol=1e-4)
+    for r in (0, 1):
+        np.testing.assert_allclose(out[r][1], losses, rtol=2e-4, atol=2e-5)
+    N = logits0.shape[0]
+    wI = np.concatenate([out[0][2], out[1][2]], 1).reshape(5 * N, -1)
+    d = np.abs(wI - final["layers.layer_0.weight_I"].numpy())
+    assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.045      # Adam: lr-sized moves on noise-level grads
+    for r in (0, 1):
+        d = np.abs(out[r][3] - final["layers.layer_1.weight_F"].numpy())
+        assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.045
