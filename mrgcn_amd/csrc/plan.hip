@@ -428,15 +428,17 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     MRGCN_HIP_TRY(hipMemcpyAsync(h_gptr.data(), p->relptr, (ngroups + 1) * sizeof(int32_t),
                                  hipMemcpyDeviceToHost, s));
     MRGCN_HIP_TRY(hipStreamSynchronize(s));
+    int rel_chunk = kRelChunk;
+    if (const char *e = getenv("MRGCN_REL_CHUNK")) rel_chunk = atoi(e) > 15 ? atoi(e) : rel_chunk;  // experiments
     std::vector<int32_t> rel, beg, end;
     std::vector<std::vector<int32_t>> by_rel(R);
     for (int64_t g = 0; g < ngroups; ++g) {
       const int32_t r = (int32_t)(g % R);
-      for (int32_t b0 = h_gptr[g]; b0 < h_gptr[g + 1]; b0 += kRelChunk) {
+      for (int32_t b0 = h_gptr[g]; b0 < h_gptr[g + 1]; b0 += rel_chunk) {
         by_rel[r].push_back((int32_t)rel.size());
         rel.push_back(r);
         beg.push_back(b0);
-        end.push_back(std::min(b0 + kRelChunk, h_gptr[g + 1]));
+        end.push_back(std::min(b0 + rel_chunk, h_gptr[g + 1]));
       }
     }
     std::vector<int32_t> cptr_rel(R + 1, 0), ids_by_rel;

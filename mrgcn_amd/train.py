@@ -142,12 +142,32 @@ class ClipAdam(torch.optim.Optimizer):
         return float(self._scratch[dev]["norm"].item())
 
 
-def train_step(model, forward_fn, idx, targets, optimizer):
+def weight_regularisation(model, l1_lambda: float = 0.0, l2_lambda: float = 0.0):
+    """l1 * sum|p| + l2 * sum p^2 over the parameters whose NAME contains 'weight'
+    (node_classification.py:172-188).  Zero in every shipped config; plain tensor ops."""
+    reg = None
+    for name, p in model.named_parameters():
+        if "weight" not in name:
+            continue
+        term = None
+        if l1_lambda > 0:
+            term = l1_lambda * p.abs().sum()
+        if l2_lambda > 0:
+            t2 = l2_lambda * (p * p).sum()
+            term = t2 if term is None else term + t2
+        if term is not None:
+            reg = term if reg is None else reg + term
+    return reg
+
+
+def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.0, l2_lambda: float = 0.0):
     """One full-batch epoch.  `forward_fn()` returns the logits (e.g. `lambda: model(batch)`).
     Returns the loss as a device scalar (no host sync)."""
     clear_grad_sumsq()
     logits = forward_fn()
     loss = categorical_crossentropy(logits, idx, targets)
+    if l1_lambda > 0 or l2_lambda > 0:
+        loss = loss + weight_regularisation(model, l1_lambda, l2_lambda)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     optimizer.step()

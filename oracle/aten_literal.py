@@ -96,7 +96,8 @@ class Epoch:
     """Hand-driven epoch of node_classification.py:166-193."""
 
     def __init__(self, p: dict, n_layers, R, N, B, featureless, lr=0.01, weight_decay=0.0,
-                 relu_last=False):
+                 relu_last=False, l1_lambda=0.0, l2_lambda=0.0):
+        self.l1_lambda, self.l2_lambda = l1_lambda, l2_lambda
         self.p, self.n_layers, self.R, self.N, self.B = p, n_layers, R, N, B
         self.featureless, self.relu_last = featureless, relu_last
         self.criterion = torch.nn.CrossEntropyLoss()
@@ -106,6 +107,10 @@ class Epoch:
         Y_hat = forward(self.p, self.n_layers, X, A, self.R, self.N, self.B, self.featureless,
                         self.relu_last)
         loss = self.criterion(Y_hat[idx], targets)
+        if self.l1_lambda > 0:  # node_classification.py:172-179 (names containing 'weight')
+            loss = loss + self.l1_lambda * sum(v.abs().sum() for k, v in self.p.items() if "weight" in k)
+        if self.l2_lambda > 0:  # node_classification.py:181-188
+            loss = loss + self.l2_lambda * sum((v ** 2).sum() for k, v in self.p.items() if "weight" in k)
         self.opt.zero_grad()
         loss.backward()
         norm = torch.nn.utils.clip_grad_norm_(list(self.p.values()), 1.0)

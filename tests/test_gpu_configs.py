@@ -9,7 +9,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run_pair(name, scale, dims, B, featureless, value_mode, relu_last=False, epochs=3, labelled=None):
+def _run_pair(name, scale, dims, B, featureless, value_mode, relu_last=False, epochs=3, labelled=None,
+              l1=0.0, l2=0.0):
     from mrgcn_amd import synth
     from mrgcn_amd.models.rgcn import RGCN
     from mrgcn_amd.train import ClipAdam, train_step
@@ -26,7 +27,7 @@ def _run_pair(name, scale, dims, B, featureless, value_mode, relu_last=False, ep
     p = AL.make_params(dims, R, N, B, False, featureless, seed=11)
     init = {k: v.detach().clone() for k, v in p.items()}
     A_cpu = AL.coo_tensor(g.rows, g.cols, g.vals, (N, R * N))
-    ep = AL.Epoch(p, len(dims), R, N, B, featureless, relu_last=relu_last)
+    ep = AL.Epoch(p, len(dims), R, N, B, featureless, relu_last=relu_last, l1_lambda=l1, l2_lambda=l2)
     Xc = None if X is None else torch.from_numpy(X)
     ref = [ep.step(Xc, A_cpu, torch.from_numpy(idx), torch.from_numpy(y)) for _ in range(epochs)]
 
@@ -46,7 +47,7 @@ def _run_pair(name, scale, dims, B, featureless, value_mode, relu_last=False, ep
         logits = model(Xg, A).detach().cpu().numpy()
         np.testing.assert_allclose(logits, ref[e][0].detach().numpy(), rtol=1e-4, atol=1e-4,
                                    err_msg=f"{name}: logits before epoch {e}")
-        loss = train_step(model, lambda: model(Xg, A), ig, yg, opt)
+        loss = train_step(model, lambda: model(Xg, A), ig, yg, opt, l1_lambda=l1, l2_lambda=l2)
         np.testing.assert_allclose(float(loss), float(ref[e][1]), rtol=2e-4, atol=2e-5)
 
 
@@ -67,3 +68,8 @@ def test_config2_mutag_normalised_values():
 def test_config4_fb15k_encoder_quarter_shape():
     # configs/fb15k-237.toml: single featureless layer, hidden 200, 2 bases, ReLU on it
     _run_pair("fb15k", 0.25, [(0, 200)], 2, True, "ref_int8", relu_last=True, epochs=2, labelled=300)
+
+
+def test_l1_l2_regularisation_terms():
+    # node_classification.py:172-188: penalties over parameters whose name contains 'weight'
+    _run_pair("aifb", 0.5, [(5, 8), (8, 4)], 3, False, "norm_f32", labelled=100, l1=1e-4, l2=1e-3)

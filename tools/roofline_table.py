@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Per-kernel roofline table of one AM-shaped epoch: algorithmic bytes, median
+launch duration from a rocprofv3 kernel trace, achieved GB/s and the fraction of the 8 TB/s HBM
+roofline.   python tools/roofline_table.py <trace dir> > profiles/r01_kernel_roofline.md"""
+import collections
+import csv
+import glob
+import sys
+
+sys.path.insert(0, __file__.rsplit("/", 1)[0])
+from prof_summary import short  # noqa: E402
+
+# AM-shaped graph (mrgcn_amd/synth.py, seed 0) and model
+N, R, B, NNZ, NCOLS = 1666764, 267, 40, 13643406, 8165256
+K0, F0, F1 = 155, 10, 11
+LD = 12
+GB = 1e9
+PEAK = 8000.0
+
+
+def spmm_bytes(rows, ncols, F):
+    return NNZ * 8 + (rows + 1) * 4 + ncols * F * 4 + rows * F * 4
+
+
+ALG = {  # kernel-name prefix -> [(selector on grid size or None, label, bytes)]
+    "mrgcn::k_adam": ("Adam on weight_I: 7 streams x 4 B x B*N*F0", 7 * 4 * B * N * F0),
+    "mrgcn::k_mix_fwd<40>": ("V read once + addend read + M written + 3 index arrays",
+                             4 * B * N * F0 + 2 * NCOLS * LD * 4 + NCOLS * 8 + N * 4),
+    "mrgcn::k_mix_bwd_dv<40>": ("dV written + dM read + relation ids", 4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 4),
+    "mrgcn::k_mix_bwd_dcomp<12, true>": ("V read once + dM read + 2 index arrays",
+                                         4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 8),
+    "mrgcn::k_spmm<4, 4, false>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
+    "mrgcn::k_spmm<4, 4, true>": ("transposed product (autograd), F=10/11", spmm_bytes(NCOLS, N, F0)),
+    "mrgcn::k_xform_mfma_fwd<1, false, 16>": ("layer-0 transform: X read once + W + M2 written + indices",
+                                              N * K0 * 4 + R * K0 * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
+    "mrgcn::k_xform_mfma_fwd<1, false, 1>": ("layer-1 transform: H read once + W + M written + indices",
+                                             N * F0 * 4 + R * F0 * F1 * 4 + NCOLS * LD * 4 + NCOLS * 12),
+    "mrgcn::k_xform_mfma_fwd<1, true, 1>": ("layer-1 dX products: dM read + W + Z written", 2 * NCOLS * LD * 4 + NCOLS * 4),
+    "mrgcn::k_xform_mfma_dw<4, 4>": ("layer-0 dW: X read once + dM read + indices + slabs",
+                                     N * K0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
+    "mrgcn::k_xform_mfma_dw<1, 8>": ("layer-1 dW: H read once + dM read + indices", N * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
+    "mrgcn::k_segment_sum": ("dX = segmented sum of Z", NCOLS * LD * 4 + N * F0 * 4),
+}
+
+
+def main():
+    f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k in ALG:
+            d[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print(f"source: {f}\n")
+    print("HBM roofline 8.0 TB/s (MI355X spec; about 6.3 TB/s is reachable by a copy).  `bytes` are ALGORITHMIC:")
+    print("every operand counted once, gathered rows counted once however often they are re-read.\n")
+    print("| kernel | what is counted | alg. MB | launches | median us | achieved GB/s | % of 8 TB/s |")
+    print("|---|---|---:|---:|---:|---:|---:|")
+    for k, (label, nbytes) in ALG.items():
+        v = sorted(d.get(k, []))
+        if not v:
+            continue
+        if k == "mrgcn::k_adam":
+            v = [x for x in v if x > 1000]  # the weight_I launch
+        med = v[len(v) // 2]
+        gbs = nbytes / (med * 1e-6) / GB
+        print(f"| {k} | {label} | {nbytes/1e6:.0f} | {len(v)} | {med:.0f} | {gbs:.0f} | {100*gbs/PEAK:.1f} |")
+
+
+if __name__ == "__main__":
+    main()
