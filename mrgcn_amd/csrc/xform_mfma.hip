@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
 // dW[r][i][o] += sum_{c in chunk} In[i(c), i] * G[c, o]        (K = rows of dW per relation <= 256,
 // F <= 16).  M dimension = i, N = o, MFMA k = columns.  Lane m of k-group kq loads 16 bytes
 // In[i(c_kq), 64*tq + 4m .. +3]: four M tiles (s = 0..3) where tile (tq, s) row m is i = 64tq+4m+s.
-// Per block: LDS accumulation over the 4 waves, then one global atomicAdd per element.
+// Per block: every wave stores its tiles to its own LDS region, the block sums the 4 regions and
+// writes one partial slab per chunk (k_dw_reduce adds a relation's slabs).
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxTQ = 4;  // K <= 256
 
@@ -143,12 +144,10 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
     const int32_t *__restrict__ rin_idx, const float *__restrict__ In, int64_t ldIn, int K,
     const float *__restrict__ G, int64_t ldG, int F, float *__restrict__ dW,
     float *__restrict__ slab) {
-  extern __shared__ float dWs[];  // [K*F]
+  extern __shared__ float dWs[];  // [4 waves][K*F]: every wave stores its own partial tile set
   const int chunk = blockIdx.x;
   const int r = relchunk_rel[chunk];
   const int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
-  for (int t = threadIdx.x; t < K * F; t += blockDim.x) dWs[t] = 0.f;
-  __syncthreads();
   const int ntq = (K + 63) >> 6;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m = lane & 15, kq = lane >> 4;
@@ -212,19 +211,21 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int i = 64 * tq + 4 * (4 * kq + reg) + s;
-          if (i < K && m < F) atomicAdd(&dWs[i * F + m], acc[tq * 4 + s][reg]);
+          if (i < K && m < F) dWs[wv * K * F + i * F + m] = acc[tq * 4 + s][reg];  // each (i, o) once per wave
         }
       }
     }
   }
   __syncthreads();
+  const int KF = K * F;
   if (slab) {  // per-chunk partial, summed per relation by k_dw_reduce (no contended atomics)
-    float *out = slab + (int64_t)chunk * K * F;
-    for (int t = threadIdx.x; t < K * F; t += blockDim.x) out[t] = dWs[t];
+    float *out = slab + (int64_t)chunk * KF;
+    for (int t = threadIdx.x; t < KF; t += blockDim.x)
+      out[t] = (dWs[t] + dWs[KF + t]) + (dWs[2 * KF + t] + dWs[3 * KF + t]);
   } else {
-    float *dWr = dW + (int64_t)r * K * F;
-    for (int t = threadIdx.x; t < K * F; t += blockDim.x) {
-      const float x = dWs[t];
+    float *dWr = dW + (int64_t)r * KF;
+    for (int t = threadIdx.x; t < KF; t += blockDim.x) {
+      const float x = (dWs[t] + dWs[KF + t]) + (dWs[2 * KF + t] + dWs[3 * KF + t]);
       if (x != 0.f) atomicAdd(&dWr[t], x);
     }
   }
@@ -282,7 +283,7 @@ __global__ void k_segment_sum(const int32_t *__restrict__ nptr, const float *__r
 
 // ---- launchers used by the C ABI entry points in rgcn_fused.hip -------------------------------
 bool xform_mfma_fwd_supported(int K, int F) { return K <= kMaxKSteps * 16 && F <= kMaxNT * 16; }
-bool xform_mfma_dw_supported(int K, int F) { return K <= kMaxTQ * 64 && F <= 16 && (size_t)K * F * 4 <= 48 * 1024; }
+bool xform_mfma_dw_supported(int K, int F) { return K <= kMaxTQ * 64 && F <= 16 && (size_t)4 * K * F * 4 <= 64 * 1024; }
 
 int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
                    int64_t ldIn, int K, const float *W, bool trans_w, int F, float *Out, int64_t ldOut,
@@ -323,7 +324,7 @@ int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, 
                   const float *G, int64_t ldG, int F, float *dW, float *workspace,
                   int64_t workspace_floats, hipStream_t s) {
   if (p->n_relchunks == 0) return MRGCN_OK;
-  const size_t lds = (size_t)K * F * sizeof(float);
+  const size_t lds = (size_t)4 * K * F * sizeof(float);
   float *slab = (workspace && workspace_floats >= (int64_t)p->n_relchunks * K * F) ? workspace : nullptr;
   if (K <= 64)
     k_xform_mfma_dw<1, 8><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
