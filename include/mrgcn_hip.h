@@ -192,6 +192,34 @@ int mrgcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *
                         int64_t n, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int64_t step, const float *grad_scale, void *stream);
 
+/* ---- link-prediction decoder (DistMult) ---------------------
+ * triples: device int64 [n, 3] rows (s, p, o) indexing E (node embeddings = the encoder's
+ * output) and Rel (relation embeddings, rgcn.py:40-47 `relations`). */
+/* scores[t] = sum_h E[s,h] Rel[p,h] E[o,h] — score_distmult_bc with the 1-D index tensors
+ * train_model passes (tasks/link_prediction.py:266-275, :645-665) */
+int mrgcn_distmult_score_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR, int32_t H,
+                             const int64_t *triples, int64_t n, float *scores, void *stream);
+/* its backward: dE / dRel (nullable) are ACCUMULATED into (zero them first) */
+int mrgcn_distmult_score_bwd_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR,
+                                 int32_t H, const int64_t *triples, int64_t n, const float *dscores,
+                                 float *dE, int64_t lddE, float *dRel, int64_t lddR, void *stream);
+/* nn.BCEWithLogitsLoss() (link_prediction.py:57, :550-554): *loss = mean; dx (nullable) its
+ * gradient w.r.t. x */
+int mrgcn_bce_logits_f32(const float *x, const float *y, int64_t n, float *loss, float *dx,
+                         void *stream);
+/* compute_ranks_fast (link_prediction.py:593-643): ranks[0:nf] tail-corruption, ranks[nf:2nf]
+ * head-corruption rank of every fact against all num_nodes candidates;
+ * rank = #greater + round_half_even((#ties-1)/2) + 1.  Filtered ranks: per fact a sorted list
+ * of candidate nodes to ignore (the -inf entries of filter_scores_, :667-689) in CSR form,
+ * tail_* for tail corruption and head_* for head corruption; all four NULL = raw ranks.
+ * Scores are never stored.  workspace: device, >= mrgcn_distmult_ranks_workspace() bytes. */
+int64_t mrgcn_distmult_ranks_workspace(int64_t num_nodes, int32_t H, int64_t num_facts);
+int mrgcn_distmult_ranks(const float *E, int64_t ldE, int64_t num_nodes, const float *Rel,
+                         int64_t ldR, int32_t H, const int64_t *triples, int64_t num_facts,
+                         const int64_t *tail_ptr, const int32_t *tail_idx, const int64_t *head_ptr,
+                         const int32_t *head_idx, void *workspace, int64_t workspace_bytes,
+                         int64_t *ranks, void *stream);
+
 /* ---- timing helpers (HIP events on the caller's stream; used by bench.py) ------ */
 int mrgcn_event_create(void **event);
 int mrgcn_event_destroy(void *event);

@@ -1,0 +1,317 @@
+// DistMult decoder behind the R-GCN encoder (link prediction):
+//   score  mrgcn/tasks/link_prediction.py:645-665   sum_h (E[s,h] * Rel[p,h]) * E[o,h]
+//   loss   :57, :550-554                             BCEWithLogitsLoss (mean) and its gradient
+//   ranks  :593-643                                  every fact against ALL nodes, tail then head,
+//                                                    raw or filtered, tie-aware
+// The reference materialises a [facts, nodes, 3] candidate tensor and a [facts, nodes] score
+// matrix per batch; here the scores live only in registers: a block scores 256 candidate nodes
+// against kFB facts at once from a transposed copy of E (coalesced), compares with the facts'
+// true scores and adds (greater, ties) counts with integer atomics (deterministic).
+//
+// Rank arithmetic is float32, products associated as in the reference, accumulated
+// sequentially over h with contraction off, so that ranks are bit-reproducible against
+// oracle/lp_oracle.py.
+#include "common.hpp"
+
+namespace mrgcn {
+namespace {
+
+constexpr int kTB = 256;
+constexpr int kFB = 8;     // facts per block in the rank kernel
+constexpr int kHT = 64;    // h tile of the per-fact query vectors in LDS
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+  return x;
+}
+
+// ---- training scores: one wave per triple -------------------------------------------------
+__global__ void k_distmult_fwd(const float *__restrict__ E, int64_t ldE, const float *__restrict__ Rel,
+                               int64_t ldR, int H, const int64_t *__restrict__ tr, int64_t n,
+                               float *__restrict__ scores) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (kTB / kWave) + (threadIdx.x >> 6);
+  if (t >= n) return;
+  const float *s = E + tr[3 * t] * ldE, *p = Rel + tr[3 * t + 1] * ldR, *o = E + tr[3 * t + 2] * ldE;
+  float acc = 0.f;
+  for (int h = lane; h < H; h += kWave) acc += s[h] * p[h] * o[h];
+  acc = wave_sum(acc);
+  if (lane == 0) scores[t] = acc;
+}
+
+// dE[s] += g p*o ; dRel[p] += g s*o ; dE[o] += g s*p   (scatter with float atomics)
+__global__ void k_distmult_bwd(const float *__restrict__ E, int64_t ldE, const float *__restrict__ Rel,
+                               int64_t ldR, int H, const int64_t *__restrict__ tr, int64_t n,
+                               const float *__restrict__ g, float *__restrict__ dE, int64_t lddE,
+                               float *__restrict__ dRel, int64_t lddR) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (kTB / kWave) + (threadIdx.x >> 6);
+  if (t >= n) return;
+  const int64_t si = tr[3 * t], pi = tr[3 * t + 1], oi = tr[3 * t + 2];
+  const float *s = E + si * ldE, *p = Rel + pi * ldR, *o = E + oi * ldE;
+  const float gt = g[t];
+  if (gt == 0.f) return;
+  for (int h = lane; h < H; h += kWave) {
+    const float sv = s[h], pv = p[h], ov = o[h];
+    if (dE) {
+      atomicAdd(dE + si * lddE + h, gt * pv * ov);
+      atomicAdd(dE + oi * lddE + h, gt * sv * pv);
+    }
+    if (dRel) atomicAdd(dRel + pi * lddR + h, gt * sv * ov);
+  }
+}
+
+// loss = mean(max(x,0) - x y + log1p(exp(-|x|))),  dx = (sigmoid(x) - y) / n
+__global__ void k_bce_logits(const float *__restrict__ x, const float *__restrict__ y, int64_t n,
+                             float *__restrict__ loss, float *__restrict__ dx) {
+  __shared__ float s_part[kTB / kWave];
+  float acc = 0.f;
+  const float inv = 1.f / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTB) {
+    const float xi = x[i], yi = y[i];
+    acc += fmaxf(xi, 0.f) - xi * yi + log1pf(expf(-fabsf(xi)));
+    if (dx) dx[i] = (1.f / (1.f + expf(-xi)) - yi) * inv;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < kTB / kWave; ++i) t += s_part[i];
+    atomicAdd(loss, t * inv);
+  }
+}
+
+// ---- ranks -----------------------------------------------------------------------------------
+// Et[h, c] = E[c, h]
+__global__ void k_transpose(const float *__restrict__ E, int64_t ldE, int64_t N, int H,
+                            float *__restrict__ Et) {
+  __shared__ float tile[32][33];
+  const int64_t c0 = (int64_t)blockIdx.x * 32;
+  const int h0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t c = c0 + r;
+    const int h = h0 + tx;
+    tile[r][tx] = (c < N && h < H) ? E[c * ldE + h] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int h = h0 + r;
+    const int64_t c = c0 + tx;
+    if (h < H && c < N) Et[(int64_t)h * N + c] = tile[tx][r];
+  }
+}
+
+// true[f] = sum_h (E[s,h] Rel[p,h]) E[o,h], sequential; 0 for facts the reference never scores
+__global__ void k_true_scores(const float *__restrict__ E, int64_t ldE, const float *__restrict__ Rel,
+                              int64_t ldR, int H, const int64_t *__restrict__ tr, int64_t nf,
+                              int64_t N, float *__restrict__ truth, int32_t *__restrict__ counts) {
+#pragma clang fp contract(off)
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  counts[4 * f] = counts[4 * f + 1] = counts[4 * f + 2] = counts[4 * f + 3] = 0;
+  float acc = 0.f;
+  if (f < N) {
+    const float *s = E + tr[3 * f] * ldE, *p = Rel + tr[3 * f + 1] * ldR, *o = E + tr[3 * f + 2] * ldE;
+    for (int h = 0; h < H; ++h) {
+      const float sp = s[h] * p[h];
+      const float spo = sp * o[h];
+      acc = acc + spo;
+    }
+  }
+  truth[f] = acc;
+}
+
+__device__ __forceinline__ bool in_sorted(const int32_t *__restrict__ a, int64_t lo, int64_t hi, int32_t key) {
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    const int32_t v = a[mid];
+    if (v == key) return true;
+    if (v < key) lo = mid + 1; else hi = mid;
+  }
+  return false;
+}
+
+// grid (candidate tiles, fact tiles, 2 directions).  HEAD=false: candidate replaces o,
+// score = (E[s] Rel[p]) * E[c];  HEAD=true: candidate replaces s, score = (E[c] Rel[p]) * E[o].
+__global__ __launch_bounds__(kTB) void k_rank_counts(
+    const float *__restrict__ Et, int64_t N, int H, const float *__restrict__ E, int64_t ldE,
+    const float *__restrict__ Rel, int64_t ldR, const int64_t *__restrict__ tr, int64_t nf,
+    const float *__restrict__ truth, const int64_t *__restrict__ tail_ptr,
+    const int32_t *__restrict__ tail_idx, const int64_t *__restrict__ head_ptr,
+    const int32_t *__restrict__ head_idx, int32_t *__restrict__ counts) {
+#pragma clang fp contract(off)
+  __shared__ float s_a[kFB][kHT];   // tail: E[s,h]*Rel[p,h]   head: Rel[p,h]
+  __shared__ float s_b[kFB][kHT];   // head: E[o,h]
+  __shared__ int s_cnt[kFB][2];
+  const bool head = blockIdx.z == 1;
+  const int64_t c = (int64_t)blockIdx.x * kTB + threadIdx.x;
+  const int64_t f0 = (int64_t)blockIdx.y * kFB;
+  const int nfb = (int)((nf - f0) < kFB ? (nf - f0) : kFB);
+  const bool live = c < N;
+  float acc[kFB];
+#pragma unroll
+  for (int i = 0; i < kFB; ++i) acc[i] = 0.f;
+  if (threadIdx.x < kFB * 2) s_cnt[threadIdx.x >> 1][threadIdx.x & 1] = 0;
+
+  for (int h0 = 0; h0 < H; h0 += kHT) {
+    const int hn = (H - h0) < kHT ? (H - h0) : kHT;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kFB * kHT; i += kTB) {
+      const int fi = i / kHT, h = i % kHT;
+      float a = 0.f, b = 0.f;
+      if (fi < nfb && h < hn) {
+        const int64_t f = f0 + fi;
+        const float pv = Rel[tr[3 * f + 1] * ldR + h0 + h];
+        if (head) {
+          a = pv;
+          b = E[tr[3 * f + 2] * ldE + h0 + h];
+        } else {
+          a = E[tr[3 * f] * ldE + h0 + h] * pv;
+        }
+      }
+      s_a[fi][h] = a;
+      s_b[fi][h] = b;
+    }
+    __syncthreads();
+    if (live) {
+      for (int h = 0; h < hn; ++h) {
+        const float e = Et[(int64_t)(h0 + h) * N + c];
+        if (head) {
+#pragma unroll
+          for (int i = 0; i < kFB; ++i) {
+            const float ep = e * s_a[i][h];
+            const float epo = ep * s_b[i][h];
+            acc[i] = acc[i] + epo;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < kFB; ++i) {
+            const float spe = s_a[i][h] * e;
+            acc[i] = acc[i] + spe;
+          }
+        }
+      }
+    }
+  }
+  const int64_t *fptr = head ? head_ptr : tail_ptr;
+  const int32_t *fidx = head ? head_idx : tail_idx;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < kFB; ++i) {
+    bool gt = false, eq = false;
+    if (i < nfb) {
+      const int64_t f = f0 + i;
+      const float sc = (f < N) ? acc[i] : 0.f;
+      const float t = truth[f];
+      bool masked = !live;
+      if (!masked && fptr) masked = in_sorted(fidx, fptr[f], fptr[f + 1], (int32_t)c);
+      gt = !masked && sc > t;
+      eq = !masked && sc == t;
+    }
+    const int ngt = __popcll(__ballot(gt)), neq = __popcll(__ballot(eq));
+    if (lane == 0) {
+      if (ngt) atomicAdd(&s_cnt[i][0], ngt);
+      if (neq) atomicAdd(&s_cnt[i][1], neq);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nfb * 2) {
+    const int i = threadIdx.x >> 1, w = threadIdx.x & 1;
+    const int v = s_cnt[i][w];
+    if (v) atomicAdd(&counts[4 * (f0 + i) + (head ? 2 : 0) + w], v);
+  }
+}
+
+// rank = greater + round_half_even((ties - 1) / 2) + 1
+__global__ void k_rank_final(const int32_t *__restrict__ counts, int64_t nf, int64_t *__restrict__ ranks) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * nf) return;
+  const bool head = i >= nf;
+  const int64_t f = head ? i - nf : i;
+  const int64_t gt = counts[4 * f + (head ? 2 : 0)], eq = counts[4 * f + (head ? 3 : 1)];
+  const int64_t m = eq - 1;                       // >= 0: the fact's own answer always ties
+  int64_t half = m >> 1;
+  if ((m & 1) && (half & 1)) half += 1;           // x.5 rounds to the even neighbour
+  ranks[i] = gt + half + 1;
+}
+
+}  // namespace
+}  // namespace mrgcn
+
+using namespace mrgcn;
+
+extern "C" {
+
+int mrgcn_distmult_score_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR, int32_t H,
+                             const int64_t *triples, int64_t n, float *scores, void *stream) {
+  MRGCN_REQUIRE(E && Rel && triples && scores && H > 0 && n >= 0, "distmult_score: bad argument");
+  if (n == 0) return MRGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int per = kTB / kWave;
+  k_distmult_fwd<<<(unsigned)((n + per - 1) / per), kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, n, scores);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_distmult_score_bwd_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR, int32_t H,
+                                 const int64_t *triples, int64_t n, const float *dscores, float *dE,
+                                 int64_t lddE, float *dRel, int64_t lddR, void *stream) {
+  MRGCN_REQUIRE(E && Rel && triples && dscores && H > 0 && n >= 0, "distmult_score_bwd: bad argument");
+  if (n == 0 || (!dE && !dRel)) return MRGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int per = kTB / kWave;
+  k_distmult_bwd<<<(unsigned)((n + per - 1) / per), kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, n, dscores,
+                                                                   dE, lddE, dRel, lddR);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_bce_logits_f32(const float *x, const float *y, int64_t n, float *loss, float *dx, void *stream) {
+  MRGCN_REQUIRE(x && y && loss && n > 0, "bce_logits: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  MRGCN_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
+  int64_t b = (n + kTB - 1) / kTB;
+  if (b > 1024) b = 1024;
+  k_bce_logits<<<(unsigned)b, kTB, 0, st>>>(x, y, n, loss, dx);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int64_t mrgcn_distmult_ranks_workspace(int64_t num_nodes, int32_t H, int64_t num_facts) {
+  if (num_nodes < 0 || H <= 0 || num_facts < 0) return -1;
+  // Et [H, N] floats | truth [nf] floats | counts [4 nf] int32
+  return (int64_t)sizeof(float) * ((int64_t)H * num_nodes + num_facts) + (int64_t)sizeof(int32_t) * 4 * num_facts;
+}
+
+int mrgcn_distmult_ranks(const float *E, int64_t ldE, int64_t num_nodes, const float *Rel, int64_t ldR,
+                         int32_t H, const int64_t *triples, int64_t num_facts, const int64_t *tail_ptr,
+                         const int32_t *tail_idx, const int64_t *head_ptr, const int32_t *head_idx,
+                         void *workspace, int64_t workspace_bytes, int64_t *ranks, void *stream) {
+  MRGCN_REQUIRE(E && Rel && triples && ranks && workspace && H > 0 && num_nodes > 0 && num_facts >= 0,
+                "distmult_ranks: bad argument");
+  MRGCN_REQUIRE((tail_ptr == nullptr) == (head_ptr == nullptr), "distmult_ranks: give both filter lists or none");
+  MRGCN_REQUIRE(workspace_bytes >= mrgcn_distmult_ranks_workspace(num_nodes, H, num_facts),
+                "distmult_ranks: workspace too small");
+  if (num_facts == 0) return MRGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  float *Et = (float *)workspace;
+  float *truth = Et + (int64_t)H * num_nodes;
+  int32_t *counts = (int32_t *)(truth + num_facts);
+  dim3 tg((unsigned)((num_nodes + 31) / 32), (unsigned)((H + 31) / 32));
+  k_transpose<<<tg, 256, 0, st>>>(E, ldE, num_nodes, H, Et);
+  k_true_scores<<<(unsigned)((num_facts + 127) / 128), 128, 0, st>>>(E, ldE, Rel, ldR, H, triples, num_facts,
+                                                                      num_nodes, truth, counts);
+  const int64_t ftiles = (num_facts + kFB - 1) / kFB;
+  MRGCN_REQUIRE(ftiles <= 65535, "distmult_ranks: more than 524280 facts per call");
+  dim3 rg((unsigned)((num_nodes + kTB - 1) / kTB), (unsigned)ftiles, 2);
+  k_rank_counts<<<rg, kTB, 0, st>>>(Et, num_nodes, H, E, ldE, Rel, ldR, triples, num_facts, truth, tail_ptr,
+                                    tail_idx, head_ptr, head_idx, counts);
+  k_rank_final<<<(unsigned)((2 * num_facts + 255) / 256), 256, 0, st>>>(counts, num_facts, ranks);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+"""DistMult link-prediction decoder on the R-GCN encoder's output — the numeric core of
+`mrgcn/tasks/link_prediction.py` (scores :645-665, loss :550-554, negative sampling :247-263,
+ranks :593-643, metrics :373-420), same function names and argument meaning, computed by the
+HIP kernels of `csrc/distmult.hip` through the C ABI.  The reference's run loop, logging, TSV
+writers and mini-batch machinery are out of scope."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32_rows(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.MrgcnError(f"{what} must live on the GPU (mrgcn_amd has no CPU decoder)")
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise TypeError(f"{what} must be a 2-D float32 tensor")
+    return t if t.stride(1) == 1 else t.contiguous()
+
+
+def _triples(data, device) -> torch.Tensor:
+    """(s, p, o) 1-D index tensors, or an [n, 3] array -> contiguous int64 [n, 3] on `device`."""
+    if isinstance(data, (tuple, list)):
+        si, pi, oi = (torch.as_tensor(x) for x in data)
+        if not (si.dim() == pi.dim() == oi.dim() == 1 and len(si) == len(pi) == len(oi)):
+            raise NotImplementedError("score_distmult_bc: only equally long 1-D index tensors (the "
+                                      "train_model call); ranking goes through compute_ranks_fast")
+        t = torch.stack([si.long(), pi.long(), oi.long()], 1)
+    else:
+        t = torch.as_tensor(data).long()
+        if t.dim() != 2 or t.shape[1] != 3:
+            raise ValueError("facts must be [n, 3]")
+    return t.to(device).contiguous()
+
+
+class _DistMultScore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, E, Rel, triples):
+        lib = _lib.load()
+        n, H = triples.shape[0], E.shape[1]
+        scores = torch.empty(n, dtype=torch.float32, device=E.device)
+        _lib.check(lib.mrgcn_distmult_score_f32(_ptr(E), E.stride(0), _ptr(Rel), Rel.stride(0), H,
+                                                _ptr(triples), n, _ptr(scores), _stream()), "distmult_score")
+        ctx.save_for_backward(E, Rel, triples)
+        return scores
+
+    @staticmethod
+    def backward(ctx, g):
+        E, Rel, triples = ctx.saved_tensors
+        lib = _lib.load()
+        g = g.contiguous().float()
+        dE = torch.zeros_like(E, memory_format=torch.contiguous_format) if ctx.needs_input_grad[0] else None
+        dR = torch.zeros_like(Rel, memory_format=torch.contiguous_format) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.mrgcn_distmult_score_bwd_f32(
+            _ptr(E), E.stride(0), _ptr(Rel), Rel.stride(0), E.shape[1], _ptr(triples), triples.shape[0],
+            _ptr(g), _ptr(dE), dE.stride(0) if dE is not None else 0, _ptr(dR),
+            dR.stride(0) if dR is not None else 0, _stream()), "distmult_score_bwd")
+        return dE, dR, None
+
+
+def score_distmult_bc(data, node_embeddings, edge_embeddings):
+    """link_prediction.py:645-665 for the 1-D (s, p, o) index tensors train_model passes."""
+    E = _f32_rows(node_embeddings, "node_embeddings")
+    Rel = _f32_rows(edge_embeddings, "edge_embeddings")
+    return _DistMultScore.apply(E, Rel, _triples(data, E.device))
+
+
+class _BceLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        lib = _lib.load()
+        x = x.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        _lib.check(lib.mrgcn_bce_logits_f32(_ptr(x), _ptr(y), x.numel(), _ptr(loss), _ptr(dx), _stream()),
+                   "bce_logits")
+        ctx.save_for_backward(dx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None
+
+
+def binary_crossentropy(Y_hat, Y, criterion=None):
+    """link_prediction.py:550-554 with criterion = nn.BCEWithLogitsLoss() (:57); `criterion` is
+    accepted for signature parity and must be that loss (or None)."""
+    if criterion is not None and not isinstance(criterion, torch.nn.BCEWithLogitsLoss):
+        raise NotImplementedError("only nn.BCEWithLogitsLoss is implemented on the device")
+    if not Y_hat.is_cuda:
+        raise _lib.MrgcnError("binary_crossentropy: scores must live on the GPU")
+    return _BceLogits.apply(Y_hat.float(), Y.to(Y_hat.device).float().contiguous())
+
+
+def sample_negatives(batch_data: np.ndarray, rng=np.random):
+    """train_model's within-batch corruption (link_prediction.py:239-263): 20 % of the positives
+    are copied, half get a random in-batch head, half a random in-batch tail.  Returns
+    (corrupted [ncorrupt, 3], labels float32 [n + ncorrupt]).  `rng`: np.random or a RandomState
+    (the reference uses the global np.random)."""
+    n = batch_data.shape[0]
+    batch_nodes = np.union1d(batch_data[:, 0], batch_data[:, 2])
+    ncorrupt = n // 5
+    neg_idx = rng.choice(np.arange(n), ncorrupt, replace=False)
+    nhead = ncorrupt // 2
+    ntail = ncorrupt - nhead
+    corrupted = np.empty((ncorrupt, 3), dtype=int)
+    corrupted[:] = batch_data[neg_idx]
+    corrupted[:nhead, 0] = rng.choice(batch_nodes, nhead)
+    if ntail:
+        corrupted[-ntail:, 2] = rng.choice(batch_nodes, ntail)
+    Y = np.ones(n + ncorrupt, dtype=np.float32)
+    if ncorrupt:
+        Y[-ncorrupt:] = 0
+    return corrupted, Y
+
+
+def filter_lists(data: np.ndarray):
+    """The filter of compute_ranks_fast(filtered=True) (truedicts :568-591 + filter_scores_
+    :667-689) as CSR lists: per fact, the sorted nodes that are other true objects of (s, p)
+    [tail corruption] / other true subjects of (p, o) [head corruption] among `data`."""
+    data = np.asarray(data, dtype=np.int64)
+    nf = len(data)
+
+    def build(key_a, key_b, ans):
+        # group facts by (key_a, key_b); members of a group = unique answers
+        order = np.lexsort((ans, key_b, key_a))
+        ka, kb, an = key_a[order], key_b[order], ans[order]
+        new_grp = np.ones(nf, bool)
+        new_grp[1:] = (ka[1:] != ka[:-1]) | (kb[1:] != kb[:-1])
+        uniq = new_grp.copy()
+        uniq[1:] |= an[1:] != an[:-1]
+        gid_sorted = np.cumsum(new_grp) - 1                # group id per sorted fact
+        ngrp = int(gid_sorted[-1]) + 1 if nf else 0
+        gptr = np.zeros(ngrp + 1, np.int64)
+        np.add.at(gptr, gid_sorted[uniq] + 1, 1)
+        gptr = np.cumsum(gptr)
+        members = an[uniq]                                  # sorted within each group
+        gid = np.empty(nf, np.int64)
+        gid[order] = gid_sorted
+        cnt = gptr[gid + 1] - gptr[gid] - 1                 # minus the fact's own answer
+        ptr = np.zeros(nf + 1, np.int64)
+        np.cumsum(cnt, out=ptr[1:])
+        idx = np.empty(int(ptr[-1]), np.int32)
+        # expand: for fact f, members of its group except ans[f]
+        rep = np.repeat(np.arange(nf), cnt + 1)
+        off = np.arange(len(rep)) - np.repeat(np.cumsum(cnt + 1) - (cnt + 1), cnt + 1)
+        cand = members[gptr[gid[rep]] + off]
+        keep = cand != ans[rep]
+        idx[:] = cand[keep]
+        return ptr, idx
+
+    if nf == 0:
+        z = np.zeros(1, np.int64)
+        return z, np.zeros(0, np.int32), z.copy(), np.zeros(0, np.int32)
+    tp, ti = build(data[:, 0], data[:, 1], data[:, 2])
+    hp, hi = build(data[:, 1], data[:, 2], data[:, 0])
+    return tp, ti, hp, hi
+
+
+def compute_ranks_fast(data, node_embeddings, edge_embeddings, batch_size=100, filtered=False):
+    """link_prediction.py:593-643.  Returns the int64 [2 * num_facts] ranks (tail corruption
+    then head corruption) on the embeddings' device.  `batch_size` (the reference's
+    mrr_batchsize, a memory knob for its [facts, nodes] score matrix) is accepted and unused:
+    scores are never materialised here."""
+    E = _f32_rows(node_embeddings.detach(), "node_embeddings")
+    Rel = _f32_rows(edge_embeddings.detach(), "edge_embeddings")
+    lib = _lib.load()
+    dev = E.device
+    facts_np = data.cpu().numpy() if torch.is_tensor(data) else np.asarray(data)
+    tr = _triples(facts_np, dev)
+    nf, N, H = tr.shape[0], E.shape[0], E.shape[1]
+    ranks = torch.empty(2 * nf, dtype=torch.int64, device=dev)
+    if nf == 0:
+        return ranks
+    ws_bytes = lib.mrgcn_distmult_ranks_workspace(N, H, nf)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.int32, device=dev)
+    lists = [None] * 4
+    if filtered:
+        lists = [torch.from_numpy(a).to(dev) for a in filter_lists(facts_np)]
+        lists = [a if a.numel() else torch.zeros(1, dtype=a.dtype, device=dev) for a in lists]
+    _lib.check(lib.mrgcn_distmult_ranks(_ptr(E), E.stride(0), N, _ptr(Rel), Rel.stride(0), H, _ptr(tr), nf,
+                                        _ptr(lists[0]), _ptr(lists[1]), _ptr(lists[2]), _ptr(lists[3]),
+                                        _ptr(ws), ws_bytes, _ptr(ranks), _stream()), "distmult_ranks")
+    return ranks
+
+
+def mrr_hits(ranks, K=(1, 3, 10)):
+    """One batch's metrics as test_model computes them (link_prediction.py:403-407)."""
+    r = ranks.float()
+    return torch.mean(1.0 / r).item(), [float(torch.mean((ranks <= k).float())) for k in K]

@@ -129,3 +129,42 @@ def test_aten_literal_port_matches_reference(name):
             for k, v in p.items():
                 diff = np.abs(v.detach().numpy() - c[f"adam{step}.{k}"])
                 assert (diff > 1e-6).mean() < 1e-3 and diff.max() <= 0.021 * step, k
+
+
+# ---- link-prediction decoder ------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_lp_oracle_against_reference_goldens(tag):
+    from oracle import lp_oracle as lo
+    g = np.load(os.path.join(GOLDEN, "lp_decoder.npz"))
+    E, Rel, facts = g[f"{tag}.E"], g[f"{tag}.Rel"], g[f"{tag}.facts"]
+    np.testing.assert_allclose(lo.score_distmult(facts, E, Rel), g[f"{tag}.scores"], rtol=1e-5, atol=1e-5)
+    assert abs(lo.bce_with_logits(g[f"{tag}.scores"], g[f"{tag}.y"]) - float(g[f"{tag}.loss"])) < 1e-6
+    dE, dR = lo.distmult_bce_grads(facts, E, Rel, g[f"{tag}.y"])
+    np.testing.assert_allclose(dE, g[f"{tag}.dE"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dR, g[f"{tag}.dRel"], rtol=1e-4, atol=1e-6)
+    # ranks are integers: exact
+    assert np.array_equal(lo.compute_ranks(facts, E, Rel, False), g[f"{tag}.ranks_raw"])
+    assert np.array_equal(lo.compute_ranks(facts, E, Rel, True), g[f"{tag}.ranks_flt"])
+
+
+def test_lp_filter_lists_host_matches_oracle():
+    from oracle import lp_oracle as lo
+    from mrgcn_amd.tasks.link_prediction import filter_lists
+    rng = np.random.default_rng(5)
+    for n, N, P in [(0, 5, 2), (1, 5, 2), (400, 12, 3), (1000, 200, 7)]:
+        facts = np.stack([rng.integers(0, N, n), rng.integers(0, P, n), rng.integers(0, N, n)], 1).astype(np.int64)
+        for a, b in zip(filter_lists(facts), lo.filter_lists(facts)):
+            assert np.array_equal(a, b)
+
+
+def test_lp_negative_sampling_shape_and_labels():
+    from mrgcn_amd.tasks.link_prediction import sample_negatives
+    rng = np.random.RandomState(3)
+    facts = np.stack([rng.randint(0, 50, 103), rng.randint(0, 4, 103), rng.randint(0, 50, 103)], 1)
+    neg, Y = sample_negatives(facts, np.random.RandomState(0))
+    assert neg.shape == (20, 3) and Y.shape == (123,) and Y[:103].all() and not Y[103:].any()
+    nodes = np.union1d(facts[:, 0], facts[:, 2])
+    assert np.isin(neg[:, 0], nodes).all() and np.isin(neg[:, 2], nodes).all()
+    # relation untouched, exactly one side re-drawn per corrupted triple
+    pos = {tuple(f[1:]) for f in facts.tolist()} | {tuple(f[:2]) for f in facts.tolist()}
+    assert all(tuple(t[1:]) in pos or tuple(t[:2]) in pos for t in neg.tolist())
