@@ -37,6 +37,11 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
     ap.add_argument("--value-mode", default="norm_f32", choices=["norm_f32", "ref_int8"])
     ap.add_argument("--engine", default="fused", choices=["fused", "literal"])
+    ap.add_argument("--defer", action="store_true",
+                    help="deferred weight_I update (functional.defer_input_grad): no stored gradient, Adam "
+                         "inside the kernel that recomputes it; measured no faster, off by default")
+    ap.add_argument("--operand", default="f32", choices=["f32", "bf16"],
+                    help="storage type of the fused engine's compact operand (bf16: SURVEY §8d's extra run)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-scale", type=float, default=1.0 / 64, help="fraction of the workload the CPU baseline runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -145,6 +150,9 @@ def main():
                for li, (i, o) in enumerate(dims)]
     model = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
     model.set_engine(args.engine)
+    model.set_operand_dtype(args.operand)
+    from mrgcn_amd import functional as Fn
+    Fn.defer_input_grad(args.defer)
     X = None if featureless else torch.randn((N, sh["x_width"]), device=dev)
     idx = torch.from_numpy(idx_np).to(dev)
     tgt = torch.from_numpy(y_np).to(dev)
@@ -244,7 +252,7 @@ def main():
             "config": {"workload": f"{name}-shaped synthetic KG (SURVEY §8d), scale {args.scale:g}",
                        "N": N, "R": R, "nnz": plan.nnz, "ncols_touched": plan.ncols,
                        "layers": dims, "num_bases": B, "value_mode": args.value_mode,
-                       "engine": args.engine, "labelled": int(idx.numel()), "params": n_params,
+                       "engine": args.engine, "operand": args.operand, "weight_I_update": "deferred" if args.defer else "stored-grad", "labelled": int(idx.numel()), "params": n_params,
                        "parallelism": ("node-partitioned x%d" % world if partitioned else
                                        "replicas x%d" % world) if world > 1 else "1 GPU"},
             "roofline": roofline,

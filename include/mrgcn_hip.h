@@ -125,6 +125,12 @@ int mrgcn_plan_array(const mrgcn_plan_t *plan, int32_t which, const void **d_ptr
 int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const float *D, int64_t ldD,
                    int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu,
                    const int32_t *out_index, void *stream);
+/* the same product with the dense operand D stored in bf16 (raw uint16_t, ldD in elements),
+ * fp32 values, fp32 accumulation and fp32 Y — the {bf16 dense} half of the SpMM set
+ * (the reference has no bf16, tolerance is stated where it is used) */
+int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uint16_t *D, int64_t ldD,
+                    int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu,
+                    const int32_t *out_index, void *stream);
 
 /* ---- compact dense operand: forward -----------------------------------------------
  * M is [ncols, ldM] row-major with one row per touched column c = (node j_c, relation
@@ -152,6 +158,18 @@ int mrgcn_gather_rows_f32(const mrgcn_plan_t *plan, const float *W, int32_t F, c
 int mrgcn_rel_transform_fwd_f32(const mrgcn_plan_t *plan, const float *X, int64_t ldX, int32_t K,
                                 const float *W, int32_t F, float *Out, int64_t ldOut,
                                 int32_t operand_order, void *stream);
+/* bf16-operand forms of the three forward operand builders: M / Out is bf16 (raw uint16_t,
+ * leading dimension in elements), every input stays fp32 and every sum is fp32, one rounding
+ * at the store.  basis_mix: B <= 64. */
+int mrgcn_basis_mix_fwd_bf16(const mrgcn_plan_t *plan, const float *V, const float *comp, int32_t B,
+                             int32_t F, const float *addend, int64_t ldA, uint16_t *M, int64_t ldM,
+                             void *stream);
+int mrgcn_gather_rows_bf16(const mrgcn_plan_t *plan, const float *W, int32_t F, const float *addend,
+                           int64_t ldA, uint16_t *M, int64_t ldM, void *stream);
+int mrgcn_rel_transform_fwd_bf16(const mrgcn_plan_t *plan, const float *X, int64_t ldX, int32_t K,
+                                 const float *W, int32_t F, uint16_t *Out, int64_t ldOut,
+                                 int32_t operand_order, void *stream);
+
 
 /* ---- compact dense operand: backward (autograd of graph.py:69-72, :93-94) -------------
  *     dV[b*N + j, :] = sum_{c in node j} comp[r_c, b] * dM[c, :]       (every row written)
@@ -160,6 +178,20 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64_t l
                             const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
                             double *dV_sumsq /* nullable: *dV_sumsq += ||dV||^2 (device double) */,
                             void *stream);
+/* Deferred update of the basis table V (= weight_I, the 2.67 GB parameter at AM scale):
+ * clip_grad_norm_ needs ||dV|| before any parameter may move, so
+ *   pass 1  mrgcn_basis_mix_bwd_f32 with dV = NULL: dcomp and *dV_sumsq only, dV is not stored;
+ *   pass 2  (after mrgcn_clip_coef_f32) this call recomputes dV from dM and applies
+ *           torch.optim.Adam to V in the same kernel — arithmetic identical to
+ *           mrgcn_adam_step_f32 on a stored dV (node_classification.py:190-193), but the
+ *           gradient is never written to nor re-read from HBM.  dM / comp must still hold the
+ *           values of the backward pass. */
+int mrgcn_basis_mix_bwd_adam_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM,
+                                 const float *comp, int32_t B, int32_t F, float *param,
+                                 float *exp_avg, float *exp_avg_sq, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int64_t step,
+                                 const float *grad_scale, void *stream);
+
 /*     dX[j, 0:K]  = sum_{c in node j} W[r_c] . dM[c, :]     (nullable; every row written)
  *     dW[r, :, :] = sum_{c: r_c = r} X[j_c, :]^T dM[c, :]    (nullable; zeroed inside)
  * `workspace` (nullable; size from mrgcn_rel_transform_bwd_workspace) lets dX run on the matrix

@@ -53,8 +53,14 @@ SIGNATURES = {
     "mrgcn_basis_mix_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p]),
     "mrgcn_gather_rows_f32": (C.c_int, [_p, _p, _i32, _p, _i64, _p, _i64, _p]),
     "mrgcn_rel_transform_fwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]),
+    "mrgcn_spmm_bf16": (C.c_int, [_p, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _p]),
+    "mrgcn_basis_mix_fwd_bf16": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p]),
+    "mrgcn_gather_rows_bf16": (C.c_int, [_p, _p, _i32, _p, _i64, _p, _i64, _p]),
+    "mrgcn_rel_transform_fwd_bf16": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]),
     "mrgcn_rel_transform_bwd_workspace": (C.c_int64, [_p, _i32, _i32, _i32, _i32]),
     "mrgcn_basis_mix_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p]),
+    "mrgcn_basis_mix_bwd_adam_f32": (C.c_int, [_p, _p, _i64, _p, _i32, _i32, _p, _p, _p, C.c_float, C.c_float,
+                                               C.c_float, C.c_float, C.c_float, _i64, _p, _p]),
     "mrgcn_rel_transform_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _i64, _p]),
     "mrgcn_relu_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "mrgcn_softmax_xent_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _i64, _i64, _p]),

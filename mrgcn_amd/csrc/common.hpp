@@ -61,12 +61,28 @@ struct SparseView {
 
 struct mrgcn_plan;
 namespace mrgcn {
+// bf16 <-> f32 (raw uint16_t storage; round to nearest even, NaN kept quiet)
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+// operand element store: OT = float or uint16_t (bf16)
+template <typename OT> __device__ __forceinline__ void store_operand(OT *p, float v) {
+  if constexpr (sizeof(OT) == 4) *p = v; else *p = f32_to_bf16(v);
+}
+template <typename OT> __device__ __forceinline__ float load_operand(const OT *p) {
+  if constexpr (sizeof(OT) == 4) return *p; else return bf16_to_f32(*p);
+}
+
 // MFMA relation transforms (xform_mfma.hip)
 bool xform_mfma_fwd_supported(int K, int F);
 bool xform_mfma_dw_supported(int K, int F);
 int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
-                   int64_t ldIn, int K, const float *W, bool trans_w, int F, float *Out, int64_t ldOut,
-                   hipStream_t s);
+                   int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out, int64_t ldOut,
+                   hipStream_t s, bool out_bf16 = false);
 int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, int64_t ldIn, int K,
                   const float *G, int64_t ldG, int F, float *dW, float *workspace,
                   int64_t workspace_floats, hipStream_t s);

@@ -13,6 +13,7 @@
 // present the transform writes its rows in compact order (sequential) and the mix pass adds
 // them while it emits the final rows in the operand's storage order `mpos` — the only
 // scattered traffic of the forward is that one write-only pass of whole padded rows.
+#include <cmath>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -48,7 +49,7 @@ __device__ __forceinline__ void load_comp_row(const float *row, float (&w)[BT]) 
   }
 }
 
-template <int BT>
+template <int BT, typename OT>
 __global__ __launch_bounds__(kMixTB) void k_mix_fwd(const int32_t *__restrict__ nptr,
                                                     const int32_t *__restrict__ urel,
                                                     const int32_t *__restrict__ mpos,
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kMixTB) void k_mix_fwd(const int32_t *__restrict__ 
                                                     const float *__restrict__ comp, int64_t N, int R,
                                                     int B, int b0, int F, int FW,
                                                     const float *__restrict__ addend, int64_t ldA,
-                                                    float *__restrict__ M, int64_t ldM, int accumulate,
+                                                    OT *__restrict__ M, int64_t ldM, int accumulate,
                                                     int comp_in_lds) {
   extern __shared__ __align__(16) float s_comp[];  // [R][CS] slice b0..b0+BT of comp when it fits
   constexpr int CS = comp_stride(BT);
@@ -109,9 +110,9 @@ __global__ __launch_bounds__(kMixTB) void k_mix_fwd(const int32_t *__restrict__ 
             for (int b = 0; b < BT; ++b)
               if (b < nb) s = fmaf(cr[b], v[b], s);
           }
-          float *m = M + (int64_t)pp[i] * ldM + o;
-          if (accumulate) s += *m;
-          *m = live ? s : 0.f;
+          OT *m = M + (int64_t)pp[i] * ldM + o;
+          if (accumulate) s += load_operand<OT>(m);
+          store_operand<OT>(m, live ? s : 0.f);
         }
       }
     }
@@ -203,13 +204,24 @@ __global__ __launch_bounds__(kMixTB) void k_mix_fwd_cols(const int32_t *__restri
 //                     dcomp[r_c, b] += <dM[c, :], V[b, j_c, :]>      for every b
 //                   accumulated with LDS float atomics per block, one global flush per block.
 // =====================================================================================
-template <int BT>
+// MODE 0: store dV (+ ||dV||^2)          the autograd path
+// MODE 1: ||dV||^2 only                  pass 1 of the deferred update (clip needs the norm first)
+// MODE 2: Adam on V with g = dV          pass 2: the 2.67 GB gradient is never written nor re-read
+struct AdamArgs {
+  float *p, *m, *v;
+  float step, b1, b2, eps, wd, bc2_sqrt;  // step = lr / (1 - beta1^t)
+  const float *scale;                     // clip coefficient (device, nullable)
+  int dbg_skip;                           // timing experiments only: skip the column loop
+};
+
+template <int BT, int MODE>
 __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict__ nptr,
                                                        const int32_t *__restrict__ urel,
                                                        const float *__restrict__ dM, int64_t ldM,
                                                        const float *__restrict__ comp, int64_t N, int R,
                                                        int B, int b0, int F, float *__restrict__ dV,
-                                                       int comp_in_lds, double *__restrict__ sumsq) {
+                                                       int comp_in_lds, double *__restrict__ sumsq,
+                                                       AdamArgs ad) {
   extern __shared__ __align__(16) float s_comp[];  // [R][CS]
   float sq = 0.f;
   constexpr int CS = comp_stride(BT);
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
     float acc[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[b] = 0.f;
-    for (int32_t cb = c0; cb < c1; cb += kPre) {  // one round trip per chunk of kPre columns
+    for (int32_t cb = c0; cb < (ad.dbg_skip ? c0 : c1); cb += kPre) {  // one round trip per chunk of kPre columns
       int rr[kPre];
       float dd[kPre];
 #pragma unroll
@@ -256,14 +268,48 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
         }
       }
     }
+    if constexpr (MODE != 2) {
 #pragma unroll
-    for (int b = 0; b < BT; ++b)
-      if (b < nb) {
-        dV[((int64_t)(b0 + b) * N + j) * F + o] = acc[b];
-        sq = fmaf(acc[b], acc[b], sq);
+      for (int b = 0; b < BT; ++b)
+        if (b < nb) {
+          if constexpr (MODE == 0) dV[((int64_t)(b0 + b) * N + j) * F + o] = acc[b];
+          sq = fmaf(acc[b], acc[b], sq);
+        }
+    } else {
+      // torch.optim.Adam exactly as k_adam (optim.hip) computes it, eight bases per batch of
+      // loads; for a fixed b a wave touches 256 contiguous bytes of p / m / v
+      const float sc = ad.scale ? *ad.scale : 1.f;
+      constexpr int NB = BT < 8 ? BT : 8;
+#pragma unroll
+      for (int bb = 0; bb < BT; bb += NB) {
+        float pp[NB], mm[NB], vv[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int64_t idx = ((int64_t)(b0 + bb + i) * N + j) * F + o;
+          const bool in = bb + i < nb;
+          pp[i] = in ? ad.p[idx] : 0.f;
+          mm[i] = in ? ad.m[idx] : 0.f;
+          vv[i] = in ? ad.v[idx] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          if (bb + i < nb) {
+            float gg = acc[bb + i] * sc;
+            if (ad.wd != 0.f) gg = fmaf(ad.wd, pp[i], gg);
+            mm[i] = fmaf(ad.b1, mm[i], (1.f - ad.b1) * gg);
+            vv[i] = fmaf(ad.b2, vv[i], (1.f - ad.b2) * gg * gg);
+            const float denom = sqrtf(vv[i]) / ad.bc2_sqrt + ad.eps;
+            pp[i] -= ad.step * (mm[i] / denom);
+            const int64_t idx = ((int64_t)(b0 + bb + i) * N + j) * F + o;
+            ad.p[idx] = pp[i];
+            ad.m[idx] = mm[i];
+            ad.v[idx] = vv[i];
+          }
+        }
       }
+    }
   }
-  if (sumsq) {  // ||dV||^2 for clip_grad_norm_: saves a separate pass over the 2.67 GB gradient
+  if (MODE != 2 && sumsq) {  // ||dV||^2 for clip_grad_norm_: saves a separate pass over the 2.67 GB gradient
     __shared__ float s_sq[kMixTB / 64];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
@@ -339,9 +385,10 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dcomp(const int32_t *__restr
 // =====================================================================================
 // no-bases input term: M[mpos[c], :] = W[ulcol[c], :] (+ addend[c, :])
 // =====================================================================================
+template <typename OT>
 __global__ void k_gather_rows(const int32_t *__restrict__ ulcol, const int32_t *__restrict__ mpos,
                               int64_t ncols, const float *__restrict__ W, int F, int FW,
-                              const float *__restrict__ addend, int64_t ldA, float *__restrict__ M,
+                              const float *__restrict__ addend, int64_t ldA, OT *__restrict__ M,
                               int64_t ldM) {
   const int64_t total = ncols * FW;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -353,7 +400,7 @@ __global__ void k_gather_rows(const int32_t *__restrict__ ulcol, const int32_t *
       x = W[(int64_t)ulcol[c] * F + o];
       if (addend) x += addend[c * ldA + o];
     }
-    M[(int64_t)mpos[c] * ldM + o] = x;
+    store_operand<OT>(M + (int64_t)mpos[c] * ldM + o, x);
   }
 }
 
@@ -365,6 +412,7 @@ __global__ void k_gather_rows(const int32_t *__restrict__ ulcol, const int32_t *
 constexpr int kTK = 32;   // columns per LDS tile
 constexpr int kKS = 160;  // K slab held in LDS at once
 
+template <typename OT>
 __global__ __launch_bounds__(kTB) void k_xform_fwd(const int32_t *__restrict__ relchunk_rel,
                                                    const int32_t *__restrict__ relchunk_beg,
                                                    const int32_t *__restrict__ relchunk_end,
@@ -373,7 +421,7 @@ __global__ __launch_bounds__(kTB) void k_xform_fwd(const int32_t *__restrict__ r
                                                    const int32_t *__restrict__ out_index,
                                                    const float *__restrict__ X, int64_t ldX, int K,
                                                    const float *__restrict__ W, int F, int FW,
-                                                   float *__restrict__ M, int64_t ldM) {
+                                                   OT *__restrict__ M, int64_t ldM) {
   extern __shared__ float smem[];
   float *Ws = smem;            // [KS][F]
   float *Xs = smem + kKS * F;  // [TK][KS+1]
@@ -423,14 +471,14 @@ __global__ __launch_bounds__(kTB) void k_xform_fwd(const int32_t *__restrict__ r
       const int p = q * kTB + threadIdx.x;
       if (p < npairs) {
         const int kk = p / F, o = p - kk * F;
-        M[(int64_t)s_c[kk] * ldM + o] = acc[q];
+        store_operand<OT>(M + (int64_t)s_c[kk] * ldM + o, acc[q]);
       }
     }
     // zero the padding of the rows just written
     if (FW > F)
       for (int p = threadIdx.x; p < nk * (FW - F); p += kTB) {
         const int kk = p / (FW - F), o = F + p - kk * (FW - F);
-        M[(int64_t)s_c[kk] * ldM + o] = 0.f;
+        store_operand<OT>(M + (int64_t)s_c[kk] * ldM + o, 0.f);
       }
   }
 }
@@ -552,11 +600,11 @@ int mix_grid(size_t lds, int64_t work_items) {
 
 using namespace mrgcn;
 
-extern "C" {
+namespace {
 
-int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *p, const float *V, const float *comp, int32_t B,
-                            int32_t F, const float *addend, int64_t ldA, float *M, int64_t ldM,
-                            void *stream) {
+template <typename OT>
+int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32_t B, int32_t F,
+                 const float *addend, int64_t ldA, OT *M, int64_t ldM, void *stream) {
   MRGCN_REQUIRE(p && V && comp && M, "NULL");
   MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
   MRGCN_REQUIRE(!addend || ldA >= F, "ldA");
@@ -570,7 +618,7 @@ int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *p, const float *V, const float *
   // timing experiments only (wrong results): write rows in compact order instead of operand order
   static const bool dbg_seq = getenv("MRGCN_DEBUG_MIX_SEQ") && atoi(getenv("MRGCN_DEBUG_MIX_SEQ")) != 0;
   const int32_t *mpos_arg = dbg_seq ? nullptr : p->mpos;
-  if (by_cols && B <= 64 && F <= 64 && FW <= 64) {
+  if constexpr (sizeof(OT) == 4) if (by_cols && B <= 64 && F <= 64 && FW <= 64) {
     size_t lds = (size_t)R * (B | 1) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
@@ -606,7 +654,7 @@ int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *p, const float *V, const float *
     int grid = mix_grid(lds, N * FW);
     const float *add = acc ? nullptr : addend;
 #define MIX_GO(T)                                                                                    \
-  k_mix_fwd<T><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->nptr, p->urel, mpos_arg, V, comp, N, R, B, b0, \
+  k_mix_fwd<T, OT><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->nptr, p->urel, mpos_arg, V, comp, N, R, B, b0, \
                                                      F, FW, add, ldA, M, ldM, acc, in_lds)
     switch (BT) {
       case 2: MIX_GO(2); break;
@@ -624,26 +672,91 @@ int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *p, const float *V, const float *
   return MRGCN_OK;
 }
 
-int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
-                            const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
-                            double *dV_sumsq, void *stream) {
-  MRGCN_REQUIRE(p && dM && V && comp && dV && dcomp, "NULL");
-  MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
-  hipStream_t s = (hipStream_t)stream;
+template <typename OT>
+int gather_rows_impl(const mrgcn_plan_t *p, const float *W, int32_t F, const float *addend, int64_t ldA,
+                     OT *M, int64_t ldM, void *stream) {
+  MRGCN_REQUIRE(p && W && M, "NULL");
+  MRGCN_REQUIRE(F > 0 && ldM >= F, "F / ldM");
+  MRGCN_REQUIRE(!addend || ldA >= F, "ldA");
+  if (p->ncols == 0) return MRGCN_OK;
+  k_gather_rows<OT><<<dim3(grid_for(p->ncols * ldM)), dim3(kTB), 0, (hipStream_t)stream>>>(
+      p->ulcol, p->mpos, p->ncols, W, F, (int)ldM, addend, ldA, M, ldM);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+template <typename OT>
+int rel_transform_fwd_impl(const mrgcn_plan_t *p, const float *X, int64_t ldX, int32_t K, const float *W,
+                           int32_t F, OT *Out, int64_t ldOut, int32_t operand_order, void *stream) {
+  MRGCN_REQUIRE(p && X && W && Out, "NULL");
+  MRGCN_REQUIRE(K > 0 && F > 0 && ldX >= K && ldOut >= F, "K / F / leading dimensions");
+  MRGCN_REQUIRE(F <= 64, "rel_transform supports F <= 64 (tile the feature dimension)");
+  if (p->n_relchunks == 0) return MRGCN_OK;
+  const int32_t *oidx = operand_order ? p->mpos : nullptr;
+  if (use_mfma() && xform_mfma_fwd_supported(K, F))
+    return xform_mfma_fwd(p, p->rnode, operand_order ? p->rmpos : nullptr, X, ldX, K, W, false, F, Out,
+                          ldOut, (hipStream_t)stream, sizeof(OT) == 2);
+  size_t lds = ((size_t)kKS * F + (size_t)kTK * (kKS + 1)) * sizeof(float);
+  k_xform_fwd<OT><<<dim3(p->n_relchunks), dim3(kTB), lds, (hipStream_t)stream>>>(
+      p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, p->unode, oidx, X, ldX, K, W, F,
+      (int)ldOut, Out, ldOut);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *p, const float *V, const float *comp, int32_t B,
+                            int32_t F, const float *addend, int64_t ldA, float *M, int64_t ldM,
+                            void *stream) {
+  return mix_fwd_impl<float>(p, V, comp, B, F, addend, ldA, M, ldM, stream);
+}
+
+int mrgcn_basis_mix_fwd_bf16(const mrgcn_plan_t *p, const float *V, const float *comp, int32_t B,
+                             int32_t F, const float *addend, int64_t ldA, uint16_t *M, int64_t ldM,
+                             void *stream) {
+  MRGCN_REQUIRE(B <= 64, "basis_mix_fwd_bf16: more than 64 bases would re-round the operand per pass");
+  return mix_fwd_impl<uint16_t>(p, V, comp, B, F, addend, ldA, M, ldM, stream);
+}
+
+int mrgcn_gather_rows_bf16(const mrgcn_plan_t *p, const float *W, int32_t F, const float *addend,
+                           int64_t ldA, uint16_t *M, int64_t ldM, void *stream) {
+  return gather_rows_impl<uint16_t>(p, W, F, addend, ldA, M, ldM, stream);
+}
+
+int mrgcn_rel_transform_fwd_bf16(const mrgcn_plan_t *p, const float *X, int64_t ldX, int32_t K,
+                                 const float *W, int32_t F, uint16_t *Out, int64_t ldOut,
+                                 int32_t operand_order, void *stream) {
+  return rel_transform_fwd_impl<uint16_t>(p, X, ldX, K, W, F, Out, ldOut, operand_order, stream);
+}
+
+}  // extern "C"
+
+namespace {
+// the dV pass of the basis-mix backward in one of its three modes (see k_mix_bwd_dv)
+template <int MODE>
+int mix_bwd_dv_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *comp, int32_t B,
+                      int32_t F, float *dV, double *dV_sumsq, const mrgcn::AdamArgs &ad, hipStream_t s) {
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
-  MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)R * B * sizeof(float), s));
-  // pass 1: dV
-  for (int b0 = 0; b0 < B; b0 += 64) {
-    const int nb = (B - b0 < 64) ? (B - b0) : 64;
+  // bases per launch.  MODE 2 streams p / m / v of every basis it owns (3 arrays x nb slabs of
+  // 4*N*F bytes, read and written): 16 bases per launch measured best on the AM shape (4.5 ms
+  // vs 5.4 ms with all 40 at once — fewer concurrent streams per wave — and 4.8 ms with 8, where
+  // re-walking the columns starts to cost).  Must be one of the BT instantiations.
+  static const int dv_bt = getenv("MRGCN_DV_BT") ? atoi(getenv("MRGCN_DV_BT")) : 16;
+  const int step_b = MODE == 2 ? ((dv_bt == 8 || dv_bt == 16 || dv_bt == 32) ? dv_bt : 64) : 64;
+  for (int b0 = 0; b0 < B; b0 += step_b) {
+    const int nb = (B - b0 < step_b) ? (B - b0) : step_b;
     int BT = nb <= 2 ? 2 : nb <= 4 ? 4 : nb <= 8 ? 8 : nb <= 16 ? 16 : nb <= 32 ? 32 : nb <= 40 ? 40 : 64;
     size_t lds = (size_t)R * comp_stride(BT) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
     int grid = mix_grid(lds, N * F);
-#define MIXDV_GO(T)                                                                                    \
-  k_mix_bwd_dv<T><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->nptr, p->urel, dM, ldM, comp, N, R, B, b0, \
-                                                        F, dV, in_lds, dV_sumsq)
+#define MIXDV_GO(T)                                                                                       \
+  k_mix_bwd_dv<T, MODE><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->nptr, p->urel, dM, ldM, comp, N, R, B, b0, \
+                                                              F, dV, in_lds, dV_sumsq, ad)
     switch (BT) {
       case 2: MIXDV_GO(2); break;
       case 4: MIXDV_GO(4); break;
@@ -655,6 +768,44 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
     }
 #undef MIXDV_GO
     MRGCN_HIP_TRY(hipGetLastError());
+  }
+  return MRGCN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mrgcn_basis_mix_bwd_adam_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *comp,
+                                 int32_t B, int32_t F, float *param, float *exp_avg, float *exp_avg_sq,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 int64_t step, const float *grad_scale, void *stream) {
+  MRGCN_REQUIRE(p && dM && comp && param && exp_avg && exp_avg_sq, "NULL");
+  MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
+  MRGCN_REQUIRE(step >= 1, "step counts from 1");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  static const int dbg_skip = getenv("MRGCN_DEBUG_DV_SKIP") ? atoi(getenv("MRGCN_DEBUG_DV_SKIP")) : 0;
+  mrgcn::AdamArgs ad{param, exp_avg, exp_avg_sq, lr / (float)bc1, beta1, beta2, eps, weight_decay,
+                     (float)sqrt(bc2), grad_scale, dbg_skip};
+  return mix_bwd_dv_launch<2>(p, dM, ldM, comp, B, F, nullptr, nullptr, ad, (hipStream_t)stream);
+}
+
+int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
+                            const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
+                            double *dV_sumsq, void *stream) {
+  MRGCN_REQUIRE(p && dM && V && comp && dcomp, "NULL");
+  MRGCN_REQUIRE(dV || dV_sumsq, "dV may be NULL only when dV_sumsq is wanted (deferred update)");
+  MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
+  hipStream_t s = (hipStream_t)stream;
+  const int R = (int)p->num_relations;
+  const int64_t N = p->num_nodes;
+  MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)R * B * sizeof(float), s));
+  // pass 1: dV (or only its squared norm)
+  {
+    mrgcn::AdamArgs none{};
+    int rc = dV ? mix_bwd_dv_launch<0>(p, dM, ldM, comp, B, F, dV, dV_sumsq, none, s)
+                : mix_bwd_dv_launch<1>(p, dM, ldM, comp, B, F, nullptr, dV_sumsq, none, s);
+    if (rc != MRGCN_OK) return rc;
   }
   // pass 2: dcomp, the feature dimension in tiles of <= 64 (dcomp accumulates over the tiles)
   if (p->ncols > 0) {
@@ -693,33 +844,13 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
 
 int mrgcn_gather_rows_f32(const mrgcn_plan_t *p, const float *W, int32_t F, const float *addend,
                           int64_t ldA, float *M, int64_t ldM, void *stream) {
-  MRGCN_REQUIRE(p && W && M, "NULL");
-  MRGCN_REQUIRE(F > 0 && ldM >= F, "F / ldM");
-  MRGCN_REQUIRE(!addend || ldA >= F, "ldA");
-  if (p->ncols == 0) return MRGCN_OK;
-  k_gather_rows<<<dim3(grid_for(p->ncols * ldM)), dim3(kTB), 0, (hipStream_t)stream>>>(
-      p->ulcol, p->mpos, p->ncols, W, F, (int)ldM, addend, ldA, M, ldM);
-  MRGCN_HIP_TRY(hipGetLastError());
-  return MRGCN_OK;
+  return gather_rows_impl<float>(p, W, F, addend, ldA, M, ldM, stream);
 }
 
 int mrgcn_rel_transform_fwd_f32(const mrgcn_plan_t *p, const float *X, int64_t ldX, int32_t K,
                                 const float *W, int32_t F, float *Out, int64_t ldOut,
                                 int32_t operand_order, void *stream) {
-  MRGCN_REQUIRE(p && X && W && Out, "NULL");
-  MRGCN_REQUIRE(K > 0 && F > 0 && ldX >= K && ldOut >= F, "K / F / leading dimensions");
-  MRGCN_REQUIRE(F <= 64, "rel_transform supports F <= 64 (tile the feature dimension)");
-  if (p->n_relchunks == 0) return MRGCN_OK;
-  const int32_t *oidx = operand_order ? p->mpos : nullptr;
-  if (use_mfma() && xform_mfma_fwd_supported(K, F))
-    return xform_mfma_fwd(p, p->rnode, operand_order ? p->rmpos : nullptr, X, ldX, K, W, false, F, Out,
-                          ldOut, (hipStream_t)stream);
-  size_t lds = ((size_t)kKS * F + (size_t)kTK * (kKS + 1)) * sizeof(float);
-  k_xform_fwd<<<dim3(p->n_relchunks), dim3(kTB), lds, (hipStream_t)stream>>>(
-      p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, p->unode, oidx, X, ldX, K, W, F,
-      (int)ldOut, Out, ldOut);
-  MRGCN_HIP_TRY(hipGetLastError());
-  return MRGCN_OK;
+  return rel_transform_fwd_impl<float>(p, X, ldX, K, W, F, Out, ldOut, operand_order, stream);
 }
 
 int64_t mrgcn_rel_transform_bwd_workspace(const mrgcn_plan_t *p, int32_t K, int32_t F, int32_t need_dX,

@@ -28,12 +28,28 @@ template <> struct Vec<1> { using T = float; };
 template <> struct Vec<2> { using T = float2; };
 template <> struct Vec<4> { using T = float4; };
 
-template <int VEC> __device__ __forceinline__ void load_vec(const float *p, float (&x)[VEC]) {
-  using T = typename Vec<VEC>::T;
-  T t = *reinterpret_cast<const T *>(p);
-  const float *f = reinterpret_cast<const float *>(&t);
+// VEC consecutive operand elements -> floats.  DT = float, or bf16 (raw uint16_t; the forward
+// operand may be stored in bf16, accumulation stays fp32): 2*VEC bytes per lane, VEC <= 8.
+template <int VEC, typename DT> __device__ __forceinline__ void load_vec(const DT *p, float (&x)[VEC]) {
+  if constexpr (sizeof(DT) == 4) {
+    using T = typename Vec<VEC>::T;
+    T t = *reinterpret_cast<const T *>(p);
+    const float *f = reinterpret_cast<const float *>(&t);
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) x[i] = f[i];
+    for (int i = 0; i < VEC; ++i) x[i] = f[i];
+  } else if constexpr (VEC == 1) {
+    x[0] = bf16_to_f32(p[0]);
+  } else {
+    uint32_t w[VEC / 2];
+    if constexpr (VEC == 2) w[0] = *reinterpret_cast<const uint32_t *>(p);
+    if constexpr (VEC == 4) { const uint2 t = *reinterpret_cast<const uint2 *>(p); w[0] = t.x; w[1] = t.y; }
+    if constexpr (VEC == 8) { const uint4 t = *reinterpret_cast<const uint4 *>(p); w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w; }
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i) {
+      x[2 * i] = __uint_as_float(w[i] << 16);
+      x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
 }
 
 template <int VEC>
@@ -48,8 +64,13 @@ __device__ __forceinline__ void store_row(float *y, const float (&acc)[VEC], int
     o[i] = v;
   }
   if (vec_ok && f0 + VEC <= F) {
-    using T = typename Vec<VEC>::T;
-    *reinterpret_cast<T *>(y + f0) = *reinterpret_cast<const T *>(o);
+    if constexpr (VEC == 8) {
+      *reinterpret_cast<float4 *>(y + f0) = *reinterpret_cast<const float4 *>(o);
+      *reinterpret_cast<float4 *>(y + f0 + 4) = *reinterpret_cast<const float4 *>(o + 4);
+    } else {
+      using T = typename Vec<VEC>::T;
+      *reinterpret_cast<T *>(y + f0) = *reinterpret_cast<const T *>(o);
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i)
@@ -61,19 +82,23 @@ __device__ __forceinline__ void store_row(float *y, const float (&acc)[VEC], int
 // TAIL: rows are only dword aligned and not padded (ld = F not a multiple of 4): 16-byte loads
 // from dword-aligned addresses (legal for global loads on gfx950), scalar loads for a last
 // partial vector so that nothing past the row is touched.
-template <int VEC, bool TAIL>
-__device__ __forceinline__ void gather_fma(const float *Dq, int64_t ldD, int32_t c, float a, bool on,
+template <int VEC, bool TAIL, typename DT>
+__device__ __forceinline__ void gather_fma(const DT *Dq, int64_t ldD, int32_t c, float a, bool on,
                                            float (&acc)[VEC], int nvalid) {
   // branch-free: the load is unconditional (masked-off entries carry c = 0, a valid row) so that
   // the compiler can issue a whole batch of gathers before the first use; the select keeps a
   // NaN/Inf in row 0 from leaking into rows that do not reference it
   float x[VEC];
-  if (TAIL && nvalid < VEC) {
-    const float *p = Dq + (int64_t)c * ldD;
+  if constexpr (TAIL) {
+    if (nvalid < VEC) {
+      const DT *p = Dq + (int64_t)c * ldD;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) x[i] = (i < nvalid) ? p[i] : 0.f;
+      for (int i = 0; i < VEC; ++i) x[i] = (i < nvalid) ? (float)p[i] : 0.f;
+    } else {
+      load_vec<VEC, DT>(Dq + (int64_t)c * ldD, x);
+    }
   } else {
-    load_vec<VEC>(Dq + (int64_t)c * ldD, x);
+    load_vec<VEC, DT>(Dq + (int64_t)c * ldD, x);
   }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = fmaf(a, on ? x[i] : 0.f, acc[i]);
@@ -83,8 +108,8 @@ __device__ __forceinline__ void gather_fma(const float *Dq, int64_t ldD, int32_t
 // round trips per few entries).  Both paths therefore first pull *all* indices and values of
 // their row / chunk into registers with coalesced loads (one round trip), then hand them to the
 // gathering lanes with cross-lane reads and issue the gathers back to back.
-template <int G, int VEC, bool TAIL>
-__global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restrict__ D, int64_t ldD,
+template <int G, int VEC, bool TAIL, typename DT>
+__global__ __launch_bounds__(256) void k_spmm(SparseView v, const DT *__restrict__ D, int64_t ldD,
                                               int F, float *__restrict__ Y, int64_t ldY,
                                               const float *__restrict__ bias, int relu,
                                               const int32_t *__restrict__ out_index,
@@ -96,7 +121,7 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restr
   const int slot = lane / G, q = lane % G;
   const int f0 = q * VEC;
   const bool active = f0 < F;
-  const float *Dq = D + (active ? f0 : 0);  // idle feature lanes shadow lane 0 (always in bounds)
+  const DT *Dq = D + (active ? f0 : 0);  // idle feature lanes shadow lane 0 (always in bounds)
   const int nvalid = active ? min(VEC, F - f0) : VEC;  // floats of this lane's vector inside the row
   float acc[VEC];
 #pragma unroll
@@ -127,14 +152,14 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restr
           const int src = u * SLOTS + slot;
           const int32_t c = __shfl(ci[t], src, kWave);
           const float a = __shfl(ca[t], src, kWave);
-          gather_fma<VEC, TAIL>(Dq, ldD, c, a, active && (t * kWave + src < n), acc, nvalid);
+          gather_fma<VEC, TAIL, DT>(Dq, ldD, c, a, active && (t * kWave + src < n), acc, nvalid);
         }
       } else {
         for (int u = 0; u < UPT; ++u) {
           const int src = u * SLOTS + slot;
           const int32_t c = __shfl(ci[t], src, kWave);
           const float a = __shfl(ca[t], src, kWave);
-          gather_fma<VEC, TAIL>(Dq, ldD, c, a, active && (t * kWave + src < n), acc, nvalid);
+          gather_fma<VEC, TAIL, DT>(Dq, ldD, c, a, active && (t * kWave + src < n), acc, nvalid);
         }
       }
     }
@@ -199,7 +224,7 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restr
       for (int u = 0; u < G; ++u) {
         const int32_t c = __shfl(ci[t], sbase + u, kWave);
         const float a = __shfl(ca[t], sbase + u, kWave);
-        gather_fma<VEC, TAIL>(Dq, ldD, c, a, active && (t * G + u < n), acc, nvalid);
+        gather_fma<VEC, TAIL, DT>(Dq, ldD, c, a, active && (t * G + u < n), acc, nvalid);
       }
     }
   } else {
@@ -211,10 +236,10 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restr
       const float a0 = v.val[k], a1 = v.val[k + 1], a2 = v.val[k + 2], a3 = v.val[k + 3];
       if (active) {
         float x0[VEC], x1[VEC], x2[VEC], x3[VEC];
-        load_vec<VEC>(Dq + (int64_t)c0 * ldD, x0);
-        load_vec<VEC>(Dq + (int64_t)c1 * ldD, x1);
-        load_vec<VEC>(Dq + (int64_t)c2 * ldD, x2);
-        load_vec<VEC>(Dq + (int64_t)c3 * ldD, x3);
+        load_vec<VEC, DT>(Dq + (int64_t)c0 * ldD, x0);
+        load_vec<VEC, DT>(Dq + (int64_t)c1 * ldD, x1);
+        load_vec<VEC, DT>(Dq + (int64_t)c2 * ldD, x2);
+        load_vec<VEC, DT>(Dq + (int64_t)c3 * ldD, x3);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           acc[i] = fmaf(a0, x0[i], acc[i]);
@@ -224,7 +249,7 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const float *__restr
         }
       }
     }
-    for (; k < e; ++k) gather_fma<VEC, TAIL>(Dq, ldD, v.idx[k], v.val[k], active, acc, nvalid);
+    for (; k < e; ++k) gather_fma<VEC, TAIL, DT>(Dq, ldD, v.idx[k], v.val[k], active, acc, nvalid);
   }
   if (mine && active) {
     const int64_t orow = out_index ? (int64_t)out_index[row] : row;
@@ -345,12 +370,13 @@ __global__ __launch_bounds__(256) void k_spmm_finalize(SparseView v, const float
   }
 }
 
-template <int G, int VEC, bool TAIL = false>
-int launch(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, int64_t ldY,
+template <int G, int VEC, bool TAIL = false, typename DT = float>
+int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64_t ldY,
            const float *bias, int relu, const int32_t *out_index, float *partials, bool use_tiny,
            hipStream_t s) {
   constexpr int SLOTS = kWave / G;
-  const bool store_vec_ok = (ldY % VEC == 0) && (((uintptr_t)Y) % (VEC * 4) == 0);
+  constexpr int SV = VEC > 4 ? 4 : VEC;  // widest single store
+  const bool store_vec_ok = (ldY % SV == 0) && (((uintptr_t)Y) % (SV * 4) == 0);
   const int64_t short_waves = (v.rows + SLOTS - 1) / SLOTS;
   const int64_t short_blocks = (short_waves + 3) / 4;
   const int64_t chunk_blocks = ((int64_t)v.n_chunks + 3) / 4;
@@ -358,6 +384,7 @@ int launch(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, in
   const int64_t xcd_per = xcd_map ? (short_blocks + 7) / 8 : 0;
   const int64_t launch_short = xcd_map ? xcd_per * 8 : short_blocks;
   int min_len = 0;
+  if constexpr (sizeof(DT) == 4) {
   if (use_tiny && v.rows > 0) {  // G*4 >= F guaranteed by the caller
     constexpr int TG = (G * VEC + 3) / 4 < 1 ? 1 : (G * VEC + 3) / 4;  // lanes per row at 4 floats each
     constexpr int TSLOTS = kWave / TG;
@@ -367,8 +394,9 @@ int launch(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, in
     MRGCN_HIP_TRY(hipGetLastError());
     min_len = kTiny;
   }
+  }
   if (launch_short + chunk_blocks > 0) {
-    k_spmm<G, VEC, TAIL><<<dim3((unsigned)(launch_short + chunk_blocks)), dim3(256), 0, s>>>(
+    k_spmm<G, VEC, TAIL, DT><<<dim3((unsigned)(launch_short + chunk_blocks)), dim3(256), 0, s>>>(
         v, D, ldD, F, Y, ldY, bias, relu, out_index, store_vec_ok ? 1 : 0, partials, kWsFeatures,
         (int)chunk_blocks, short_blocks, xcd_per, min_len);
     MRGCN_HIP_TRY(hipGetLastError());
@@ -441,8 +469,60 @@ int dispatch(const SparseView &v, const float *D, int64_t ldD, int64_t avail, in
   return MRGCN_ERR_UNSUPPORTED;
 }
 
+// bf16 operand: 2-byte elements, up to 8 per lane (16-byte loads)
+int dispatch_bf16(const SparseView &v, const uint16_t *D, int64_t ldD, int64_t avail, int F, float *Y,
+                  int64_t ldY, const float *bias, int relu, const int32_t *out_index, float *partials,
+                  hipStream_t s) {
+  auto ok = [&](int w) {
+    int64_t padded = ((int64_t)F + w - 1) / w * w;
+    return ldD % w == 0 && ((uintptr_t)D) % (w * 2) == 0 && avail >= padded;
+  };
+  const int vec = ok(8) ? 8 : ok(4) ? 4 : ok(2) ? 2 : 1;
+  const int lanes = (F + vec - 1) / vec;
+#define MRGCN_GO(G, V) \
+  return launch<G, V, false, uint16_t>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, false, s)
+#define MRGCN_LANES(V)            \
+  if (lanes <= 1) MRGCN_GO(1, V); \
+  if (lanes <= 2) MRGCN_GO(2, V); \
+  if (lanes <= 4) MRGCN_GO(4, V); \
+  if (lanes <= 8) MRGCN_GO(8, V); \
+  if (lanes <= 16) MRGCN_GO(16, V); \
+  if (lanes <= 32) MRGCN_GO(32, V); \
+  if (lanes <= 64) MRGCN_GO(64, V);
+  if (vec == 8) { MRGCN_LANES(8) }
+  else if (vec == 4) { MRGCN_LANES(4) }
+  else if (vec == 2) { MRGCN_LANES(2) }
+  else { MRGCN_LANES(1) }
+#undef MRGCN_LANES
+#undef MRGCN_GO
+  set_error("internal: no bf16 SpMM instantiation for this feature tile");
+  return MRGCN_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 }  // namespace mrgcn
+
+extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uint16_t *D, int64_t ldD,
+                               int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu,
+                               const int32_t *out_index, void *stream) {
+  using namespace mrgcn;
+  MRGCN_REQUIRE(plan, "plan is NULL");
+  MRGCN_REQUIRE(view >= MRGCN_VIEW_LITERAL && view <= MRGCN_VIEW_TRANSPOSED, "view");
+  MRGCN_REQUIRE(F > 0 && ldD >= F && ldY >= F, "F / leading dimensions");
+  MRGCN_REQUIRE(D && Y, "NULL operand");
+  SparseView v = plan->view(view);
+  int tile = 64;
+  if (ldD % 8 == 0 && ((uintptr_t)D) % 16 == 0) tile = 256;  // kWsFeatures floats of partials per chunk
+  else if (ldD % 4 == 0 && ((uintptr_t)D) % 8 == 0) tile = 256;
+  else if (ldD % 2 == 0 && ((uintptr_t)D) % 4 == 0) tile = 128;
+  for (int f = 0; f < F; f += tile) {
+    const int w = (F - f < tile) ? (F - f) : tile;
+    int rc = dispatch_bf16(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu, out_index,
+                           plan->partials, (hipStream_t)stream);
+    if (rc != MRGCN_OK) return rc;
+  }
+  return MRGCN_OK;
+}
 
 extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const float *D, int64_t ldD,
                               int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu,

@@ -46,13 +46,13 @@ __device__ __forceinline__ f32x4 load4_fast(const float *p) {
 //   rin_idx / rout_idx: nullable int32 [ncols] in RELATION-MAJOR order (aligned with rperm):
 //   input / output row of each column; null = the compact id rperm[e] itself
 // ---------------------------------------------------------------------------------------------
-template <int NT, bool TRANS_W, int KS>
+template <int NT, bool TRANS_W, int KS, typename OT>
 __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
     const int32_t *__restrict__ relchunk_rel, const int32_t *__restrict__ relchunk_beg,
     const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
     const int32_t *__restrict__ rin_idx, const int32_t *__restrict__ rout_idx,
     const float *__restrict__ In, int64_t ldIn, int K, const float *__restrict__ W, int F,
-    float *__restrict__ Out, int64_t ldOut) {
+    OT *__restrict__ Out, int64_t ldOut) {
   extern __shared__ float WsT[];  // [NT*16][KP]: n-major, k contiguous, zero padded
   const int ksteps = (K + 15) >> 4;
   const int KP = ksteps * 16 + 4;  // +4 floats: rows start on different banks
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int n = nt * 16 + m;
-        if (n < ldOut) Out[orow * ldOut + n] = acc[nt][reg];  // zeros past F: whole padded row
+        if (n < ldOut) store_operand<OT>(Out + orow * ldOut + n, acc[nt][reg]);  // zeros past F: whole padded row
       }
     }
   }
@@ -286,36 +286,42 @@ bool xform_mfma_fwd_supported(int K, int F) { return K <= kMaxKSteps * 16 && F <
 bool xform_mfma_dw_supported(int K, int F) { return K <= kMaxTQ * 64 && F <= 16 && (size_t)4 * K * F * 4 <= 64 * 1024; }
 
 int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
-                   int64_t ldIn, int K, const float *W, bool trans_w, int F, float *Out, int64_t ldOut,
-                   hipStream_t s) {
+                   int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out, int64_t ldOut,
+                   hipStream_t s, bool out_bf16) {
   if (p->n_relchunks == 0) return MRGCN_OK;
   int NT = (int)((ldOut < 64 ? ldOut : 64) + 15) / 16;  // tiles that cover the padded row
   if (NT < (F + 15) / 16) NT = (F + 15) / 16;
   const int ksteps = (K + 15) / 16;
   const size_t lds = (size_t)NT * 16 * (ksteps * 16 + 4) * sizeof(float);
-#define XF_GO(N_, T_)                                                                               \
-  do {                                                                                              \
-    if (ksteps <= 1)                                                                                \
-      k_xform_mfma_fwd<N_, T_, 1><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                     \
-          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn, \
-          K, W, F, Out, ldOut);                                                                     \
-    else if (ksteps <= 4)                                                                           \
-      k_xform_mfma_fwd<N_, T_, 4><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                     \
-          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn, \
-          K, W, F, Out, ldOut);                                                                     \
-    else                                                                                            \
-      k_xform_mfma_fwd<N_, T_, kMaxKSteps><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(            \
-          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn, \
-          K, W, F, Out, ldOut);                                                                     \
+#define XF_GO3(N_, T_, O_)                                                                              \
+  do {                                                                                                  \
+    if (ksteps <= 1)                                                                                    \
+      k_xform_mfma_fwd<N_, T_, 1, O_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                     \
+          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn,     \
+          K, W, F, (O_ *)Out, ldOut);                                                                   \
+    else if (ksteps <= 4)                                                                               \
+      k_xform_mfma_fwd<N_, T_, 4, O_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                     \
+          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn,     \
+          K, W, F, (O_ *)Out, ldOut);                                                                   \
+    else                                                                                                \
+      k_xform_mfma_fwd<N_, T_, kMaxKSteps, O_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(            \
+          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn,     \
+          K, W, F, (O_ *)Out, ldOut);                                                                   \
   } while (0)
+#define XF_GO(N_, T_)                                                  \
+  do {                                                                 \
+    if (out_bf16) XF_GO3(N_, T_, uint16_t); else XF_GO3(N_, T_, float); \
+  } while (0)
+  if (out_bf16 && trans_w) { set_error("xform_mfma_fwd: bf16 output only for the forward operand"); return MRGCN_ERR_UNSUPPORTED; }
   if (trans_w) {
-    switch (NT) { case 1: XF_GO(1, true); break; case 2: XF_GO(2, true); break;
-                  case 3: XF_GO(3, true); break; default: XF_GO(4, true); break; }
+    switch (NT) { case 1: XF_GO3(1, true, float); break; case 2: XF_GO3(2, true, float); break;
+                  case 3: XF_GO3(3, true, float); break; default: XF_GO3(4, true, float); break; }
   } else {
     switch (NT) { case 1: XF_GO(1, false); break; case 2: XF_GO(2, false); break;
                   case 3: XF_GO(3, false); break; default: XF_GO(4, false); break; }
   }
 #undef XF_GO
+#undef XF_GO3
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -37,6 +37,35 @@ def pop_grad_sumsq(grad: torch.Tensor):
 
 def clear_grad_sumsq():
     _GRAD_SUMSQ.clear()
+    _DEFERRED.clear()
+
+
+# Deferred update of weight_I (opt-in): with it on, the backward of a bases layer does not store
+# dV (weight_I.grad stays None); it leaves ||dV||^2 plus what is needed to recompute dV here, and
+# `ClipAdam.step` applies Adam to weight_I inside the kernel that recomputes it
+# (mrgcn_basis_mix_bwd_adam_f32).  Same arithmetic, 2 x 2.67 GB less HBM traffic per AM epoch —
+# but measured NOT faster on MI355X (AM shape: 14.96 ms vs 14.66 ms with the stored gradient):
+# the recomputing kernel streams p/m/v as 4-byte lanes over many basis slabs at ~3.8 TB/s where
+# the plain float4 Adam kernel reaches ~4.7 TB/s, which eats the saved traffic.  Kept as an
+# option (it halves the peak memory of the step: no 2.67 GB gradient tensor).
+# Only valid when nothing else contributes to weight_I's gradient (no L1/L2 term, one use of the
+# layer per step) — `train_step` switches it off when a regulariser is active.
+_DEFER = False
+_DEFERRED: dict = {}
+
+
+def defer_input_grad(on: bool) -> bool:
+    """Switches the deferred weight_I update on/off; returns the previous setting."""
+    global _DEFER
+    prev, _DEFER = _DEFER, bool(on)
+    return prev
+
+
+def pop_deferred(param: torch.Tensor):
+    ent = _DEFERRED.pop(param.data_ptr(), None)
+    if ent is None or ent["numel"] != param.numel():
+        return None
+    return ent
 
 
 # measured on the AM shape: 14.6 ms with the overlap vs 14.3 ms without (every one of these
@@ -60,6 +89,11 @@ def _ld_for(F: int) -> int:
     MRGCN_LDM_ALIGN overrides (floats, multiple of 4)."""
     a = int(os.environ.get("MRGCN_LDM_ALIGN", "4"))
     return (F + a - 1) // a * a
+
+
+def _ld_for_bf16(F: int) -> int:
+    """bf16 operand rows: multiple of 8 elements (16-byte gathers)."""
+    return (F + 7) // 8 * 8
 
 
 class _SpmmLiteral(torch.autograd.Function):
@@ -111,11 +145,17 @@ class _RgcnLayer(torch.autograd.Function):
     i.e. graph.py:62-102 without the (R*N) x out intermediates."""
 
     @staticmethod
-    def forward(ctx, plan: GraphPlan, F: int, weight_I, comp_I, X, W_F, bias, relu: bool):
+    def forward(ctx, plan: GraphPlan, F: int, weight_I, comp_I, X, W_F, bias, relu: bool, bf16: bool = False):
         lib = L.load()
         dev = plan.device
-        ld = _ld_for(F)
-        M = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
+        # bf16: only the compact operand M is stored in bf16 (one rounding at its store); inputs,
+        # every accumulation, Y and the whole backward stay fp32
+        ld = _ld_for_bf16(F) if bf16 else _ld_for(F)
+        M = torch.empty((plan.ncols, ld), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+        sfx = "bf16" if bf16 else "f32"
+        xform_fwd = getattr(lib, "mrgcn_rel_transform_fwd_" + sfx)
+        mix_fwd = getattr(lib, "mrgcn_basis_mix_fwd_" + sfx)
+        gather_rows = getattr(lib, "mrgcn_gather_rows_" + sfx)
         s = _stream(dev)
         Xc = Wc = None
         with torch.cuda.device(dev):
@@ -132,19 +172,18 @@ class _RgcnLayer(torch.autograd.Function):
                     addend = M2.data_ptr()
                 else:
                     out, ldo, order = M, ld, 1
-                L.check(lib.mrgcn_rel_transform_fwd_f32(plan.handle, Xc.data_ptr(), Xc.stride(0),
-                                                        Xc.shape[1], Wc.data_ptr(), F, out.data_ptr(), ldo,
-                                                        order, s), "mrgcn_rel_transform_fwd_f32")
+                fwd = xform_fwd if out is M else lib.mrgcn_rel_transform_fwd_f32  # M2 stays fp32
+                L.check(fwd(plan.handle, Xc.data_ptr(), Xc.stride(0), Xc.shape[1], Wc.data_ptr(), F,
+                            out.data_ptr(), ldo, order, s), "mrgcn_rel_transform_fwd_" + sfx)
             if weight_I is not None:
                 wI = weight_I.contiguous()
                 if comp_I is not None:
                     cI = comp_I.contiguous()
-                    L.check(lib.mrgcn_basis_mix_fwd_f32(plan.handle, wI.data_ptr(), cI.data_ptr(),
-                                                        cI.shape[1], F, addend, ldA, M.data_ptr(), ld, s),
-                            "mrgcn_basis_mix_fwd_f32")
+                    L.check(mix_fwd(plan.handle, wI.data_ptr(), cI.data_ptr(), cI.shape[1], F, addend, ldA,
+                                    M.data_ptr(), ld, s), "mrgcn_basis_mix_fwd_" + sfx)
                 else:
-                    L.check(lib.mrgcn_gather_rows_f32(plan.handle, wI.data_ptr(), F, addend, ldA,
-                                                      M.data_ptr(), ld, s), "mrgcn_gather_rows_f32")
+                    L.check(gather_rows(plan.handle, wI.data_ptr(), F, addend, ldA, M.data_ptr(), ld, s),
+                            "mrgcn_gather_rows_" + sfx)
         Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu)
         ctx.plan, ctx.F, ctx.ld, ctx.relu = plan, F, ld, relu
         ctx.has = (weight_I is not None, comp_I is not None, X is not None, bias is not None)
@@ -179,14 +218,23 @@ class _RgcnLayer(torch.autograd.Function):
         with torch.cuda.device(dev):
             if has_I:
                 if has_comp:
-                    d_wI = torch.empty_like(weight_I)
+                    defer = _DEFER and weight_I.is_contiguous()
+                    if defer and weight_I.data_ptr() in _DEFERRED:
+                        raise L.MrgcnError("deferred weight_I update: the layer ran twice in one step")
+                    d_wI = None if defer else torch.empty_like(weight_I)
                     d_comp = torch.empty_like(comp_I)
                     sq = torch.zeros((), dtype=torch.float64, device=dev)
                     L.check(lib.mrgcn_basis_mix_bwd_f32(
                         plan.handle, dM.data_ptr(), ld, weight_I.data_ptr(), comp_I.data_ptr(),
-                        comp_I.shape[1], F, d_wI.data_ptr(), d_comp.data_ptr(), sq.data_ptr(), s),
-                        "mrgcn_basis_mix_bwd_f32")
-                    register_grad_sumsq(d_wI, sq)  # ||dV||^2 came for free with the gradient
+                        comp_I.shape[1], F, 0 if defer else d_wI.data_ptr(), d_comp.data_ptr(),
+                        sq.data_ptr(), s), "mrgcn_basis_mix_bwd_f32")
+                    if defer:
+                        # comp_I is cloned: the optimizer may update the parameter before pass 2
+                        _DEFERRED[weight_I.data_ptr()] = dict(
+                            numel=weight_I.numel(), plan=plan, dM=dM, ld=ld, comp=comp_I.detach().clone(),
+                            B=comp_I.shape[1], F=F, sumsq=sq)
+                    else:
+                        register_grad_sumsq(d_wI, sq)  # ||dV||^2 came for free with the gradient
                 else:
                     # dense (R*N) x F gradient: zero + scatter of the touched rows
                     d_wI = torch.zeros_like(weight_I)
@@ -216,7 +264,7 @@ class _RgcnLayer(torch.autograd.Function):
                     for t in (dX, dW, ws, dM):  # allocated / used on `side`: keep the allocator honest
                         if t is not None:
                             t.record_stream(main if t is not dM else side)
-        return None, None, d_wI, d_comp, dX, dW, dbias, None
+        return None, None, d_wI, d_comp, dX, dW, dbias, None, None
 
 
 def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False) -> torch.Tensor:
@@ -233,7 +281,8 @@ def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False) -> torch.Tensor:
         W_F = layer.weight_F
         if B > 0:  # graph.py:83-85: tiny (R x B) . (B x in*out) contraction -> library GEMM
             W_F = (layer.weight_F_comp @ W_F.reshape(B, -1)).view(layer.num_relations, layer.indim, F)
-    if weight_I is not None and comp_I is None and Xin is None:
+    bf16 = getattr(layer, "operand_dtype", "f32") == "bf16"
+    if weight_I is not None and comp_I is None and Xin is None and not bf16:
         # featureless layer without bases: weight_I already *is* the literal operand
         return spmm_literal(plan, weight_I, bias=layer.b if layer.bias else None, relu=relu)
-    return _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, layer.b if layer.bias else None, relu)
+    return _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, layer.b if layer.bias else None, relu, bf16)

@@ -35,6 +35,9 @@ class GraphConvolution(nn.Module):
         self.num_bases = num_bases
         self.input_layer, self.featureless, self.bias = input_layer, featureless, bias
         self.engine = DEFAULT_ENGINE
+        # storage type of the fused engine's compact operand: "f32" (parity default) or "bf16"
+        # (SURVEY §8d's additional run: bf16 dense operand, fp32 accumulation, tolerance 2e-2)
+        self.operand_dtype = "f32"
 
         use_bases = num_bases > 0
         S = num_bases if use_bases else num_relations  # graph.py:33-36

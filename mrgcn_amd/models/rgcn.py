@@ -43,6 +43,11 @@ class RGCN(nn.Module):
         for layer in self.layers.values():
             layer.engine = engine
 
+    def set_operand_dtype(self, dtype: str):
+        assert dtype in ("f32", "bf16")
+        for layer in self.layers.values():
+            layer.operand_dtype = dtype
+
     def forward(self, X, A):
         if not isinstance(A, torch.Tensor):
             raise NotImplementedError("mini-batch A_Batch input (rgcn.py:91-128) is outside the "

@@ -101,7 +101,8 @@ class GraphPlan:
              out_rows: int | None = None) -> torch.Tensor:
         """Y[i, :F] = sum_e val[e] * D[idx[e], :F] over row i of `view` (see mrgcn_spmm_f32).
         `out_index` is a device pointer (int) to an int32 row redirection table or 0."""
-        assert D.is_cuda and D.dtype == torch.float32 and D.dim() == 2 and D.stride(1) == 1
+        assert D.is_cuda and D.dtype in (torch.float32, torch.bfloat16) and D.dim() == 2 and D.stride(1) == 1
+        bf16 = D.dtype == torch.bfloat16  # dense operand in bf16: fp32 values, accumulation and Y
         F = int(D.shape[1] if F is None else F)
         if out is None:
             rows = self.view_rows(view) if out_rows is None else out_rows
@@ -110,10 +111,10 @@ class GraphPlan:
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() >= F
         with torch.cuda.device(D.device):
-            L.check(L.load().mrgcn_spmm_f32(
-                self.handle, view, D.data_ptr(), D.stride(0), F, out.data_ptr(), out.stride(0),
-                bias.data_ptr() if bias is not None else 0, 1 if relu else 0, out_index,
-                _stream_ptr(D.device)), "mrgcn_spmm_f32")
+            fn = L.load().mrgcn_spmm_bf16 if bf16 else L.load().mrgcn_spmm_f32
+            L.check(fn(self.handle, view, D.data_ptr(), D.stride(0), F, out.data_ptr(), out.stride(0),
+                       bias.data_ptr() if bias is not None else 0, 1 if relu else 0, out_index,
+                       _stream_ptr(D.device)), "mrgcn_spmm_bf16" if bf16 else "mrgcn_spmm_f32")
         return out
 
     def ulcol_long(self) -> torch.Tensor:

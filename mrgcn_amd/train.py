@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
-from .functional import clear_grad_sumsq, pop_grad_sumsq
+from .functional import clear_grad_sumsq, defer_input_grad, pop_deferred, pop_grad_sumsq
 
 
 def _stream(device) -> int:
@@ -89,9 +89,17 @@ class ClipAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         lib = L.load()
         live = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
-        if not live:
+        # parameters whose gradient was left in recomputable form (functional.defer_input_grad)
+        deferred = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    ent = pop_deferred(p)
+                    if ent is not None:
+                        deferred.append((g, p, ent))
+        if not live and not deferred:
             return None
-        device = live[0][1].device
+        device = (live[0][1] if live else deferred[0][1]).device
         if not all(p.device == device for _, p in live):
             raise L.MrgcnError("ClipAdam: all parameters must live on one GPU")
         sc = self._dev_scratch(device)
@@ -111,6 +119,8 @@ class ClipAdam(torch.optim.Optimizer):
                 else:
                     L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), acc.data_ptr(), s),
                             "mrgcn_sumsq_accum_f32")
+            for _, p, ent in deferred:
+                (sc["sumsq_sharded"] if id(p) in sharded else sc["sumsq"]).add_(ent["sumsq"])
             clear_grad_sumsq()
             if self._dist:
                 from .partition import all_reduce_sum_
@@ -121,6 +131,21 @@ class ClipAdam(torch.optim.Optimizer):
                 L.check(lib.mrgcn_clip_coef_f32(sc["sumsq"].data_ptr(), float(self.max_norm),
                                                 sc["coef"].data_ptr(), sc["norm"].data_ptr(), s),
                         "mrgcn_clip_coef_f32")
+            # deferred parameters first: their pass 2 needs the other parameters' pre-step values
+            for group, p, ent in deferred:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                b1, b2 = group["betas"]
+                L.check(lib.mrgcn_basis_mix_bwd_adam_f32(
+                    ent["plan"].handle, ent["dM"].data_ptr(), ent["ld"], ent["comp"].data_ptr(), ent["B"],
+                    ent["F"], p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                    float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                    float(group["weight_decay"]), int(st["step"]),
+                    sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_basis_mix_bwd_adam_f32")
             for (group, p), g in zip(live, grads):
                 st = self.state[p]
                 if not st:
@@ -166,9 +191,17 @@ def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.
     clear_grad_sumsq()
     logits = forward_fn()
     loss = categorical_crossentropy(logits, idx, targets)
-    if l1_lambda > 0 or l2_lambda > 0:
+    reg = l1_lambda > 0 or l2_lambda > 0
+    if reg:
         loss = loss + weight_regularisation(model, l1_lambda, l2_lambda)
     optimizer.zero_grad(set_to_none=True)
-    loss.backward()
+    # a regulariser adds its own term to weight_I's gradient: the deferred (recomputed) form
+    # cannot represent that, so it is off for such steps
+    prev = defer_input_grad(False) if reg else None
+    try:
+        loss.backward()
+    finally:
+        if reg:
+            defer_input_grad(prev)
     optimizer.step()
     return loss.detach()

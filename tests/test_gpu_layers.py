@@ -57,10 +57,64 @@ def test_rgcn_forward_backward_vs_reference_goldens(name, engine):
 
 
 @pytest.mark.parametrize("name", util.rgcn_cases())
-def test_epoch_steps_vs_reference_goldens(name):
+def test_epoch_steps_vs_reference_goldens(name, defer=False):
     """zero_grad / backward / clip 1.0 / Adam driven for n_adam epochs
     (node_classification.py:166-193)."""
+    from mrgcn_amd import functional as Fn
     from mrgcn_amd.train import ClipAdam, train_step
+    prev = Fn.defer_input_grad(defer)
+    try:
+        _epoch_steps(name, ClipAdam, train_step, defer)
+    finally:
+        Fn.defer_input_grad(prev)
+
+
+@pytest.mark.parametrize("name", [n for n in util.rgcn_cases() if "_b0_" not in n])
+def test_epoch_steps_with_deferred_weight_I_update(name):
+    """Same goldens with weight_I's gradient never stored: ||dV||^2 in the backward, Adam applied
+    inside the kernel that recomputes dV (mrgcn_basis_mix_bwd_adam_f32)."""
+    test_epoch_steps_vs_reference_goldens(name, defer=True)
+
+
+def test_deferred_update_equals_the_stored_gradient_update():
+    """The two update paths share their arithmetic (only the double-precision atomics that sum
+    the gradient norm are unordered): parameters and Adam state after 3 steps agree to fp32
+    rounding, with and without weight decay."""
+    from mrgcn_amd import functional as Fn
+    from mrgcn_amd.train import ClipAdam, train_step
+    name = "rgcn_smoke_ft_b5_norm_f32"
+    c = util.load_case(name)
+    A = _adjacency(c, name)
+    X = torch.from_numpy(c["X"]).cuda()
+    idx = torch.from_numpy(c["labels_idx"]).cuda()
+    tgt = torch.from_numpy(c["labels_y"]).cuda()
+    for wd in (0.0, 0.05):
+        out = []
+        for defer in (False, True):
+            model, _ = util.build_rgcn_from_case(c, "cuda")
+            util.load_state_from_case(model, c)
+            model = model.cuda()
+            opt = ClipAdam(list(model.parameters()), lr=0.01, weight_decay=wd, max_norm=1.0)
+            prev = Fn.defer_input_grad(defer)
+            try:
+                for _ in range(3):
+                    train_step(model, lambda: model(X, A), idx, tgt, opt)
+                    wI = model.layers["layer_0"].weight_I
+                    assert (wI.grad is None) == defer
+            finally:
+                Fn.defer_input_grad(prev)
+            st = opt.state[model.layers["layer_0"].weight_I]
+            out.append(({k: v.clone() for k, v in model.state_dict().items()}, st["exp_avg"].clone(),
+                        st["exp_avg_sq"].clone(), opt.last_grad_norm()))
+        (sa, ma, va, na), (sb, mb, vb, nb) = out
+        assert abs(na - nb) <= 1e-6 * na
+        for k in sa:
+            torch.testing.assert_close(sa[k], sb[k], rtol=1e-6, atol=1e-7, msg=k)
+        torch.testing.assert_close(ma, mb, rtol=1e-6, atol=1e-9)
+        torch.testing.assert_close(va, vb, rtol=1e-6, atol=1e-12)
+
+
+def _epoch_steps(name, ClipAdam, train_step, defer):
     c = util.load_case(name)
     model, dims = util.build_rgcn_from_case(c, "cuda")
     util.load_state_from_case(model, c)
