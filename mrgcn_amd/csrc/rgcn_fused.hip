@@ -323,6 +323,209 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
   }
 }
 
+// =====================================================================================
+// basis mix, backward, WAVE PER NODE with LANE = BASIS (the default when F <= 16, B <= 64):
+// dV and dcomp in one pass.  PMC on the AM shape showed why the two kernels around this one are
+// slow: k_mix_bwd_dcomp keeps the LDS 88 % busy with float atomics that collide (a wave of 64
+// columns holds ~13 copies of the identity relation and of every popular predicate), and
+// k_mix_bwd_dv issues 435 M VALU instructions, most of them for lanes idled by the divergence
+// between the nodes that share a wave.  With one node per wave and one basis per lane
+//   * everything per column is wave-uniform: one load fetches relation id and dM row of four
+//     columns, v_readlane hands them to the FMAs as scalars; the column loop runs exactly the
+//     node's length, no lane diverges;
+//   * the dcomp atomics of a column go to B consecutive LDS words: conflict-free;
+//   * per column and lane: F FMAs for dcomp's dot product, F FMAs for dV.
+// Global memory is touched in runs, not per lane: a wave owns kGroup consecutive nodes; their V
+// rows ([B][kGroup*F], for dcomp) enter the wave's private LDS tile with float4 loads, the wave
+// works out of LDS and leaves dV in the same tile, which it streams out as float4 runs (MODE 0)
+// or feeds to the fused Adam (MODE 2).  (Letting lane b read / write its own slab directly was
+// measured at 10 ms — 40 partial lines per instruction — and block-wide tiles with barriers at
+// 3.6-3.9 ms: the phases of a block do not overlap.)  Waves never wait for each other.
+// Needs (N*F) % 4 == 0 and 16-byte aligned V / dV / p / m / v.
+// =====================================================================================
+constexpr int kNodeTB = 1024;  // 16 waves, one block per CU: 16 wave tiles + dcomp accumulators
+constexpr int kGroup = 4;      // consecutive nodes per wave step
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int FT, int MODE, bool DCOMP>
+__global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restrict__ nptr,
+                                                          const int32_t *__restrict__ urel,
+                                                          const float *__restrict__ dM, int64_t ldM,
+                                                          const float *__restrict__ V,
+                                                          const float *__restrict__ comp, int64_t N, int R,
+                                                          int B, int F, float *__restrict__ dV,
+                                                          float *__restrict__ dcomp,
+                                                          double *__restrict__ sumsq, AdamArgs ad) {
+  extern __shared__ __align__(16) float s_mem[];  // 16 wave tiles [B][rs] | dcomp accumulators [R*B]
+  const int row = kGroup * F;  // floats per basis in a wave tile
+  const int rs = row | 1;      // odd LDS stride: lanes (bases) fall on different banks
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = blockDim.x >> 6;
+  float *s_tile = s_mem + wv * (B * rs);
+  float *s_dc = s_mem + nw * (B * rs);
+  if (DCOMP) {
+    for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_dc[t] = 0.f;
+    __syncthreads();
+  }
+  const bool on = lane < B;
+  const int b = on ? lane : 0;
+  const int64_t ngroups = (N + kGroup - 1) / kGroup;
+  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  const int64_t slab = N * F;
+  const int row4 = row >> 2;
+  const float sc = (MODE == 2 && ad.scale) ? *ad.scale : 1.f;
+  float sq = 0.f;
+  for (int64_t g = (int64_t)blockIdx.x * nw + wv; g < ngroups; g += nwaves) {
+    const int64_t j0 = g * kGroup;
+    const int64_t base = j0 * F;
+    const int64_t left4 = (slab - base) >> 2;  // float4s left in a slab from the group's start
+    // wave-uniform values travel through SGPRs: one lane loads, v_readlane hands them out
+    int32_t cp[kGroup + 1];
+    {
+      const int32_t mine = nptr[(j0 + lane < N) ? j0 + lane : N];
+#pragma unroll
+      for (int i = 0; i <= kGroup; ++i) cp[i] = __builtin_amdgcn_readlane(mine, i);
+    }
+    // relation ids of the group's first 64 columns, requested before anything depends on them
+    const int32_t rl = (cp[0] + lane < cp[kGroup]) ? urel[cp[0] + lane] : 0;
+    if constexpr (DCOMP) {  // ---- A: V rows of the group -> the wave's tile
+      for (int q = lane; q < B * row4; q += 64) {
+        const int bb = q / row4, x = q - bb * row4;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x < left4) t = reinterpret_cast<const float4 *>(V)[((int64_t)bb * slab + base) / 4 + x];
+        float *d = s_tile + bb * rs + 4 * x;
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+      }
+      wave_lds_fence();
+    }
+    // ---- B: node by node, lane = basis
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+      float *trow = s_tile + b * rs + i * F;
+      float v[FT];
+      if constexpr (DCOMP) {
+#pragma unroll
+        for (int o = 0; o < FT; ++o) v[o] = (o < F) ? trow[o] : 0.f;
+      }
+      float acc[FT];
+#pragma unroll
+      for (int o = 0; o < FT; ++o) acc[o] = 0.f;
+      const int32_t c_hi = ad.dbg_skip ? cp[i] : cp[i + 1];
+      for (int32_t cb = cp[i]; cb < c_hi; cb += 4) {
+        // one load fetches the dM rows of four columns: the 16-lane group k reads column cb + k
+        // (lane o of the group its feature o); v_readlane turns them into scalars
+        const int kq = lane >> 4, oq = lane & 15;
+        const int32_t cc = cb + kq;
+        const bool cin = cc < c_hi;
+        const float dmine = (cin && oq < F) ? dM[(int64_t)cc * ldM + oq] : 0.f;
+        const int32_t off = cb - cp[0];  // position among the group's columns (uniform)
+        int r[4];
+        if (off + 4 <= 64) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) r[kk] = __builtin_amdgcn_readlane(rl, off + kk);
+        } else {  // a group with more than 64 columns: fetch the ids of this chunk
+          const int32_t rmine = cin ? urel[cc] : 0;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) r[kk] = __builtin_amdgcn_readlane(rmine, 16 * kk);
+        }
+        float w[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) w[kk] = comp[(int64_t)r[kk] * B + b];  // R*B floats: cache resident
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (cb + kk < c_hi) {  // wave-uniform
+            float d[FT];
+#pragma unroll
+            for (int o = 0; o < FT; ++o)
+              d[o] = __builtin_bit_cast(
+                  float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dmine), 16 * kk + o));
+            if constexpr (DCOMP) {
+              float dot = 0.f;
+#pragma unroll
+              for (int o = 0; o < FT; ++o) dot = fmaf(d[o], v[o], dot);
+              if (on) atomicAdd(&s_dc[r[kk] * B + b], dot);
+            }
+#pragma unroll
+            for (int o = 0; o < FT; ++o) acc[o] = fmaf(w[kk], d[o], acc[o]);
+          }
+        }
+      }
+      if (j0 + i < N && on) {
+#pragma unroll
+        for (int o = 0; o < FT; ++o)
+          if (o < F) sq = fmaf(acc[o], acc[o], sq);
+      }
+      if constexpr (MODE != 1) {
+        if (on) {
+#pragma unroll
+          for (int o = 0; o < FT; ++o)
+            if (o < F) trow[o] = acc[o];  // the V row has been consumed: reuse it for dV
+        }
+      }
+    }
+    if constexpr (MODE != 1) {
+      wave_lds_fence();
+      // ---- C: the dV tile leaves in float4 runs
+      for (int q = lane; q < B * row4; q += 64) {
+        const int bb = q / row4, x = q - bb * row4;
+        if (x >= left4) continue;
+        const float *t = s_tile + bb * rs + 4 * x;
+        const float4 gq = make_float4(t[0], t[1], t[2], t[3]);
+        const int64_t gi = ((int64_t)bb * slab + base) / 4 + x;
+        if constexpr (MODE == 0) {
+          reinterpret_cast<float4 *>(dV)[gi] = gq;
+        } else {
+          float4 P = reinterpret_cast<const float4 *>(ad.p)[gi];
+          float4 M = reinterpret_cast<const float4 *>(ad.m)[gi];
+          float4 Vv = reinterpret_cast<const float4 *>(ad.v)[gi];
+          auto upd = [&](float &pp, float gg, float &mm, float &vv) {  // == k_adam (optim.hip)
+            gg *= sc;
+            if (ad.wd != 0.f) gg = fmaf(ad.wd, pp, gg);
+            mm = fmaf(ad.b1, mm, (1.f - ad.b1) * gg);
+            vv = fmaf(ad.b2, vv, (1.f - ad.b2) * gg * gg);
+            const float denom = sqrtf(vv) / ad.bc2_sqrt + ad.eps;
+            pp -= ad.step * (mm / denom);
+          };
+          upd(P.x, gq.x, M.x, Vv.x);
+          upd(P.y, gq.y, M.y, Vv.y);
+          upd(P.z, gq.z, M.z, Vv.z);
+          upd(P.w, gq.w, M.w, Vv.w);
+          reinterpret_cast<float4 *>(ad.p)[gi] = P;
+          reinterpret_cast<float4 *>(ad.m)[gi] = M;
+          reinterpret_cast<float4 *>(ad.v)[gi] = Vv;
+        }
+      }
+      wave_lds_fence();  // the tile is rewritten by the next group
+    }
+  }
+  if constexpr (MODE != 2) {
+    if (sumsq) {
+      __shared__ float s_sq[kNodeTB / 64];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+      if (lane == 0) s_sq[wv] = sq;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < nw; ++i) t += s_sq[i];
+        atomicAdd(sumsq, (double)t);
+      }
+    }
+  }
+  if constexpr (DCOMP) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < R * B; t += blockDim.x) {
+      const float x = s_dc[t];
+      if (x != 0.f) atomicAdd(&dcomp[t], x);
+    }
+  }
+}
+
 template <int FT, bool VEC2>
 __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dcomp(const int32_t *__restrict__ urel,
                                                           const int32_t *__restrict__ unode,
@@ -736,6 +939,51 @@ int mrgcn_rel_transform_fwd_bf16(const mrgcn_plan_t *p, const float *X, int64_t 
 
 namespace {
 // the dV pass of the basis-mix backward in one of its three modes (see k_mix_bwd_dv)
+// wave-per-node form of the basis-mix backward (k_mix_bwd_node); returns MRGCN_OK when it ran,
+// -1 when the shape is outside its limits (the caller falls back to the two-kernel form), an
+// error code otherwise.
+template <int MODE, bool DCOMP>
+int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
+                        const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
+                        double *dV_sumsq, const mrgcn::AdamArgs &ad, hipStream_t s) {
+  static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
+  const int R = (int)p->num_relations;
+  const int64_t N = p->num_nodes;
+  const size_t lds = ((size_t)(kNodeTB / 64) * B * ((kGroup * F) | 1) + (DCOMP ? (size_t)R * B : 0)) * sizeof(float);
+  auto al16 = [](const void *q) { return (((uintptr_t)q) & 15) == 0; };
+  bool ok = node_on && F <= 16 && B <= 64 && lds <= 150 * 1024 && N > 0 && (N * F) % 4 == 0;
+  if (DCOMP) ok = ok && al16(V);
+  if (MODE == 0) ok = ok && al16(dV);
+  if (MODE == 2) ok = ok && al16(ad.p) && al16(ad.m) && al16(ad.v);
+  if (!ok) return -1;
+  const int FT = (F + 3) / 4 * 4;
+  static const int grid_mult = getenv("MRGCN_MIX_NODE_GRID") ? atoi(getenv("MRGCN_MIX_NODE_GRID")) : 1;
+  int per_cu = (int)((160 * 1024) / (lds + 1024));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 4) per_cu = 4;
+  const int64_t want = ((N + kGroup - 1) / kGroup + (kNodeTB / 64) - 1) / (kNodeTB / 64);
+  int64_t grid = (int64_t)256 * per_cu * (grid_mult < 1 ? 1 : grid_mult);
+  if (grid > want) grid = want;
+#define NODE_GO(T)                                                                                        \
+  do {                                                                                                    \
+    auto kfn = k_mix_bwd_node<T, MODE, DCOMP>;                                                            \
+    if (lds > 48 * 1024)                                                                                  \
+      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                        (int)lds));                                                       \
+    kfn<<<dim3((unsigned)grid), dim3(kNodeTB), lds, s>>>(p->nptr, p->urel, dM, ldM, V, comp, N, R, B, F, dV, \
+                                                         dcomp, dV_sumsq, ad);                            \
+  } while (0)
+  switch (FT) {
+    case 4: NODE_GO(4); break;
+    case 8: NODE_GO(8); break;
+    case 12: NODE_GO(12); break;
+    default: NODE_GO(16); break;
+  }
+#undef NODE_GO
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
 template <int MODE>
 int mix_bwd_dv_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *comp, int32_t B,
                       int32_t F, float *dV, double *dV_sumsq, const mrgcn::AdamArgs &ad, hipStream_t s) {
@@ -787,6 +1035,11 @@ int mrgcn_basis_mix_bwd_adam_f32(const mrgcn_plan_t *p, const float *dM, int64_t
   static const int dbg_skip = getenv("MRGCN_DEBUG_DV_SKIP") ? atoi(getenv("MRGCN_DEBUG_DV_SKIP")) : 0;
   mrgcn::AdamArgs ad{param, exp_avg, exp_avg_sq, lr / (float)bc1, beta1, beta2, eps, weight_decay,
                      (float)sqrt(bc2), grad_scale, dbg_skip};
+  {
+    int rc = mix_bwd_node_launch<2, false>(p, dM, ldM, nullptr, comp, B, F, nullptr, nullptr, nullptr, ad,
+                                           (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   return mix_bwd_dv_launch<2>(p, dM, ldM, comp, B, F, nullptr, nullptr, ad, (hipStream_t)stream);
 }
 
@@ -800,6 +1053,12 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
   MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)R * B * sizeof(float), s));
+  {  // one pass for dV and dcomp when the shape allows it
+    mrgcn::AdamArgs none{};
+    int rc = dV ? mix_bwd_node_launch<0, true>(p, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, none, s)
+                : mix_bwd_node_launch<1, true>(p, dM, ldM, V, comp, B, F, nullptr, dcomp, dV_sumsq, none, s);
+    if (rc >= 0) return rc;
+  }
   // pass 1: dV (or only its squared norm)
   {
     mrgcn::AdamArgs none{};
