@@ -23,19 +23,21 @@ def spmm_bytes(rows, ncols, F):
 
 
 ALG = {  # kernel-name prefix -> [(selector on grid size or None, label, bytes)]
-    "mrgcn::k_adam": ("Adam on weight_I: 7 streams x 4 B x B*N*F0", 7 * 4 * B * N * F0),
-    "mrgcn::k_mix_fwd<40>": ("V read once + addend read + M written + 3 index arrays",
+    "mrgcn::k_adam<false>": ("Adam on weight_I: 7 streams x 4 B x B*N*F0", 7 * 4 * B * N * F0),
+    "mrgcn::k_mix_fwd<40, float>": ("V read once + addend read + M written + 3 index arrays",
                              4 * B * N * F0 + 2 * NCOLS * LD * 4 + NCOLS * 8 + N * 4),
-    "mrgcn::k_mix_bwd_dv<40>": ("dV written + dM read + relation ids", 4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 4),
+    "mrgcn::k_mix_bwd_node<12, 0, true>": ("dV + dcomp in one pass: V read once + dV written + dM read + relation ids",
+                                           2 * 4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 4 + N * 4),
+    "mrgcn::k_mix_bwd_dv<40, 0>": ("dV written + dM read + relation ids", 4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 4),
     "mrgcn::k_mix_bwd_dcomp<12, true>": ("V read once + dM read + 2 index arrays",
                                          4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 8),
-    "mrgcn::k_spmm<4, 4, false>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
-    "mrgcn::k_spmm<4, 4, true>": ("transposed product (autograd), F=10/11", spmm_bytes(NCOLS, N, F0)),
-    "mrgcn::k_xform_mfma_fwd<1, false, 16>": ("layer-0 transform: X read once + W + M2 written + indices",
+    "mrgcn::k_spmm<4, 4, false, float>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
+    "mrgcn::k_spmm<4, 4, true, float>": ("transposed product (autograd), F=10/11", spmm_bytes(NCOLS, N, F0)),
+    "mrgcn::k_xform_mfma_fwd<1, false, 16, float>": ("layer-0 transform: X read once + W + M2 written + indices",
                                               N * K0 * 4 + R * K0 * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
-    "mrgcn::k_xform_mfma_fwd<1, false, 1>": ("layer-1 transform: H read once + W + M written + indices",
+    "mrgcn::k_xform_mfma_fwd<1, false, 1, float>": ("layer-1 transform: H read once + W + M written + indices",
                                              N * F0 * 4 + R * F0 * F1 * 4 + NCOLS * LD * 4 + NCOLS * 12),
-    "mrgcn::k_xform_mfma_fwd<1, true, 1>": ("layer-1 dX products: dM read + W + Z written", 2 * NCOLS * LD * 4 + NCOLS * 4),
+    "mrgcn::k_xform_mfma_fwd<1, true, 1, float>": ("layer-1 dX products: dM read + W + Z written", 2 * NCOLS * LD * 4 + NCOLS * 4),
     "mrgcn::k_xform_mfma_dw<4, 4>": ("layer-0 dW: X read once + dM read + indices + slabs",
                                      N * K0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
     "mrgcn::k_xform_mfma_dw<1, 8>": ("layer-1 dW: H read once + dM read + indices", N * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
@@ -59,7 +61,7 @@ def main():
         v = sorted(d.get(k, []))
         if not v:
             continue
-        if k == "mrgcn::k_adam":
+        if k.startswith("mrgcn::k_adam"):
             v = [x for x in v if x > 1000]  # the weight_I launch
         med = v[len(v) // 2]
         gbs = nbytes / (med * 1e-6) / GB
