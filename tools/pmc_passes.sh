@@ -7,6 +7,7 @@ mem=(
  "FETCH_SIZE"
  "WRITE_SIZE"
  "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"
+ "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
  "TCC_HIT_sum TCC_MISS_sum"
  "TCC_REQ_sum TCP_TCC_READ_REQ_sum"
  "TCP_TOTAL_CACHE_ACCESSES_sum"
