@@ -6,7 +6,11 @@ A into the sparse COO tensor the layers receive — with the reference's int8 ca
 (`value_mode="ref_int8"`: the row-normalised floats truncate to 0/1) or
 as float32 (`"norm_f32"`, the intended maths).  Unlike the reference's `Batch.to`, whose
 `self.A.to(device)` discards its result (batch.py:122-123), `to` here really moves A: the
-kernels need it in HBM."""
+kernels need it in HBM.
+
+`MiniBatch` / `A_Batch` and their helpers (batch.py:150-316) follow below: the batch structure
+(row slices, neighbour sets) is built on the host with vectorised numpy instead of the
+reference's per-entry Python loops; the layers turn every slice into a device graph plan once."""
 from __future__ import annotations
 
 import numpy as np
@@ -87,3 +91,128 @@ class FullBatch(Batch):
         super().as_tensors_()
         dtype = torch.int8 if self.value_mode == "ref_int8" else torch.float32
         self.A = scipy_sparse_to_pytorch_sparse(self.A, dtype=dtype)
+
+
+# ---- mini-batch boundary objects (reference: mrgcn/data/batch.py:150-316) ------------------------
+def getNeighboursSparse(A, idx):
+    """Sorted global node ids of every source node the rows `idx` of the scipy CSR `A` touch,
+    irrespective of relation (batch.py:233-249; vectorised, same result)."""
+    import scipy.sparse as sp
+    assert isinstance(A, sp.csr_matrix)
+    idx = np.asarray(idx, dtype=np.int64)
+    num_nodes = A.shape[0]
+    lo, hi = A.indptr[idx].astype(np.int64), A.indptr[idx + 1].astype(np.int64)
+    n = hi - lo
+    if n.sum() == 0:
+        return np.zeros(0, dtype=np.int64)
+    pos = np.repeat(lo - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum()))
+    return np.unique(A.indices[pos].astype(np.int64) % num_nodes)
+
+
+def getAdjacencyNodeColumnIdx(idx, num_nodes, num_relations):
+    """Columns r*num_nodes + i of every node i in `idx` for every relation r, relation-major
+    (batch.py:251-256)."""
+    idx = torch.as_tensor(idx, dtype=torch.long)
+    r = torch.arange(num_relations, dtype=torch.long, device=idx.device)
+    return (r[:, None] * num_nodes + idx[None, :]).reshape(-1)
+
+
+def sliceSparseCOO(t, idx):
+    """Entries of the sparse COO `t` whose column is in (the ascending) `idx`, columns renumbered
+    to their position in `idx`, values replaced by float32 ONES (batch.py:258-270: the stored
+    values — incl. entries the int8 cast truncated to 0 — are discarded)."""
+    ind = t._indices()
+    idx = idx.to(ind.device)
+    pos = torch.searchsorted(idx, ind[1])
+    pos_c = pos.clamp(max=max(idx.numel() - 1, 0))
+    keep = (idx[pos_c] == ind[1]) if idx.numel() else torch.zeros_like(ind[1], dtype=torch.bool)
+    row, col = ind[0][keep], pos[keep]
+    return torch.sparse_coo_tensor(torch.vstack([row, col]),
+                                   torch.ones(col.numel(), dtype=torch.float32, device=ind.device),
+                                   size=[t.shape[0], idx.numel()])
+
+
+def mksubset(X, sample_idx):
+    """Rows / encodings of the nodes in `sample_idx`, same list structure (batch.py:272-316);
+    fixed-width (numeric array) encodings only."""
+    X0, F = X[0], X[1:]
+    X_sample = [X0[sample_idx]]
+    for modality, F_set, gpu_acceleration in F:
+        F_set_sample = []
+        for encodings, nodes_idx, seq_lengths in F_set:
+            if getattr(encodings, "dtype", None) == np.dtype("O"):
+                raise NotImplementedError("variable-length encodings are outside mrgcn_amd's scope")
+            common = np.intersect1d(nodes_idx, sample_idx)
+            if len(common) <= 0:
+                F_set_sample.append([np.empty(0), np.empty(0), np.empty(0)])
+                continue
+            mask = np.isin(nodes_idx, common)
+            F_set_sample.append([encodings[mask], np.array(sorted(common)), seq_lengths[mask]])
+        X_sample.append([modality, F_set_sample, gpu_acceleration])
+    return X_sample
+
+
+class A_Batch:
+    """Row slices of A and neighbour sets for an L-layer mini-batch (batch.py:166-231):
+    `row[i]` = A[sample_i] (scipy CSR, later sparse COO), `neighbours[i]` = sorted source nodes
+    those rows touch; sample_0 = the batch nodes, sample_{i+1} = neighbours[i]."""
+
+    def __init__(self, A=None, batch_idx=None, num_layers=0, value_mode="ref_int8"):
+        assert value_mode in VALUE_MODES
+        self.value_mode = value_mode
+        self.neighbours, self.row = [], []
+        self.node_index = None
+        self.device = torch.device("cpu")
+        self._a_idx = {}  # layer slot -> cached A_idx tensor (keeps the layers' slice cache warm)
+        if batch_idx is not None:
+            self.node_index = np.copy(batch_idx)
+        if A is not None:
+            self._populate(A, num_layers)
+
+    def _populate(self, A, num_layers):
+        sample_idx = self.node_index
+        for _ in range(num_layers):
+            self.row.append(A[sample_idx])
+            neighbours_idx = getNeighboursSparse(A, sample_idx)
+            self.neighbours.append(neighbours_idx)
+            sample_idx = neighbours_idx
+
+    def as_tensors_(self):
+        dtype = torch.int8 if self.value_mode == "ref_int8" else torch.float32
+        self.node_index = torch.from_numpy(np.asarray(self.node_index))
+        self.row = [scipy_sparse_to_pytorch_sparse(a, dtype=dtype) for a in self.row]
+        self.neighbours = [torch.from_numpy(np.asarray(a)) for a in self.neighbours]
+
+    def to(self, device):
+        self.node_index = self.node_index.to(device)
+        self.neighbours = [t.to(device) for t in self.neighbours]
+        self.row = [t.to(device) for t in self.row]
+        self._a_idx = {}
+        self.device = device
+        return self
+
+
+class MiniBatch(Batch):
+    def __init__(self, A=None, X=None, batch_node_idx=None, num_layers=None, value_mode="ref_int8"):
+        super().__init__(batch_node_idx)
+        if A is not None:
+            self.A = A_Batch(A, self.node_index, num_layers, value_mode=value_mode)
+            if X is not None:  # not featureless: features of the outermost neighbours
+                self.X = mksubset(X, self.A.neighbours[-1])
+
+    def as_tensors_(self):
+        super().as_tensors_()
+        self.A.as_tensors_()
+
+    def to(self, devices):
+        if self.X is not None:
+            for i, (datatype, encoding_sets, _) in enumerate(self.X[1:], 1):
+                device = devices[datatype]
+                for j, (encodings, node_idx, seq_lengths) in enumerate(encoding_sets):
+                    self.X[i][1][j][0] = encodings.to(device)
+                    self.X[i][1][j][1] = node_idx.to(device)
+                    self.X[i][1][j][2] = seq_lengths.to(device)
+        self.A.to(devices["relational"])
+        kinds = {str(d) for d in devices.values()}
+        self.device = next(iter(devices.values())) if len(kinds) == 1 else "ambigious"
+        return self

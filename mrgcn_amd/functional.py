@@ -267,22 +267,25 @@ class _RgcnLayer(torch.autograd.Function):
         return None, None, d_wI, d_comp, dX, dW, dbias, None, None
 
 
-def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False) -> torch.Tensor:
-    """Fused forward of one `GraphConvolution` (graph.py:62-102)."""
+def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False, input_term: bool = True,
+               feature_term: bool = True, use_bias: bool = True) -> torch.Tensor:
+    """Fused forward of one `GraphConvolution` (graph.py:62-102).  `input_term` / `feature_term`
+    select the two summands (mini-batch mode runs them on different column spaces)."""
     F = layer.outdim
     B = layer.num_bases
     weight_I = comp_I = W_F = None
-    if layer.input_layer:
+    if layer.input_layer and input_term:
         weight_I = layer.weight_I
         comp_I = layer.weight_I_comp if B > 0 else None
     Xin = None
-    if not (layer.input_layer and layer.featureless):
+    if feature_term and not (layer.input_layer and layer.featureless):
         Xin = X
         W_F = layer.weight_F
         if B > 0:  # graph.py:83-85: tiny (R x B) . (B x in*out) contraction -> library GEMM
             W_F = (layer.weight_F_comp @ W_F.reshape(B, -1)).view(layer.num_relations, layer.indim, F)
     bf16 = getattr(layer, "operand_dtype", "f32") == "bf16"
+    bias = layer.b if (layer.bias and use_bias) else None
     if weight_I is not None and comp_I is None and Xin is None and not bf16:
         # featureless layer without bases: weight_I already *is* the literal operand
-        return spmm_literal(plan, weight_I, bias=layer.b if layer.bias else None, relu=relu)
-    return _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, layer.b if layer.bias else None, relu, bf16)
+        return spmm_literal(plan, weight_I, bias=bias, relu=relu)
+    return _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, bias, relu, bf16)

@@ -73,8 +73,7 @@ class GraphConvolution(nn.Module):
     # ------------------------------------------------------------------------------
     def forward(self, X, A, A_idx=None):
         if A_idx is not None:
-            raise NotImplementedError("mini-batch slicing (graph.py:87-91) is not on the "
-                                      "full-batch path this package accelerates")
+            return self._forward_mini_batch(X, A, A_idx)
         plan = plan_of(A, self.num_nodes, self.num_relations)
         if self.engine == "literal":
             return self._forward_literal(X, plan)
@@ -98,6 +97,41 @@ class GraphConvolution(nn.Module):
         FW = torch.matmul(X.unsqueeze(0), W_F).reshape(R * X.shape[0], out)
         AFW = Fn.spmm_literal(plan, FW, bias=self.b if self.bias else None)
         return AFW if Y is None else Y + AFW
+
+    # -- mini-batch mode (graph.py:62-102 with A_idx) --------------------------------------
+    def _forward_mini_batch(self, X, A, A_idx):
+        """`A`: the row slice of the sample nodes (|sample| x R*N, global columns), `X`: features /
+        embeddings of the n_b neighbour nodes, `A_idx`: their columns for every relation.  The
+        input term keeps the global column space and the stored values; the feature term runs on
+        `sliceSparseCOO(A, A_idx)` (|sample| x R*n_b, all-ones values) — two graph plans, both
+        cached on the slice tensor."""
+        from ..data.batch import sliceSparseCOO
+        R, B, out = self.num_relations, self.num_bases, self.outdim
+        n_b = X.shape[0]
+        cached = getattr(A, "_mrgcn_slice", None)
+        if cached is None or cached[0] is not A_idx:
+            cached = (A_idx, sliceSparseCOO(A, A_idx))
+            A._mrgcn_slice = cached
+        plan_F = plan_of(cached[1], n_b, R)
+        Y = None
+        if self.input_layer:
+            plan_I = plan_of(A, self.num_nodes, R)
+            if self.engine == "literal":
+                W_I = self.weight_I
+                if B > 0:
+                    W_I = (self.weight_I_comp @ W_I.view(B, self.num_nodes * out)).view(R * self.num_nodes, out)
+                Y = Fn.spmm_literal(plan_I, W_I)
+            else:
+                Y = Fn.rgcn_layer(plan_I, self, None, feature_term=False, use_bias=False)
+        if self.engine == "literal":
+            W_F = self.weight_F
+            if B > 0:
+                W_F = (self.weight_F_comp @ W_F.view(B, -1)).view(R, self.indim, out)
+            FW = torch.matmul(X.unsqueeze(0), W_F).reshape(R * n_b, out)
+            YF = Fn.spmm_literal(plan_F, FW, bias=self.b if self.bias else None)
+        else:
+            YF = Fn.rgcn_layer(plan_F, self, X, input_term=False)
+        return YF if Y is None else Y + YF
 
     # -- fused engine ----------------------------------------------------------------------
     def _forward_fused(self, X, plan, relu=False):

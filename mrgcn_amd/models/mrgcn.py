@@ -100,9 +100,20 @@ class MRGCN(nn.Module):
     # ------------------------------------------------------------------------------
     def forward(self, batch):
         if type(batch).__name__ == "MiniBatch":
-            raise NotImplementedError("mini-batch forward (mrgcn.py:216-248) is outside the "
-                                      "full-batch path of mrgcn_amd")
+            return self._forward_mini_batch(batch)
         return self._forward_full_batch(batch)
+
+    def _forward_mini_batch(self, batch):
+        """mrgcn.py:216-248: modality embeddings only for the outermost neighbours, then the
+        mini-batch R-GCN."""
+        dev = self.devices["relational"]
+        X = None
+        if self.compute_modality_embeddings:
+            X0, F = batch.X[0], batch.X[1:]
+            batch_idx = batch.A.neighbours[-1]
+            XF = self._compute_modality_embeddings(F, batch_idx)
+            X = torch.cat([X0.to(dev), XF], dim=1).float()
+        return self.rgcn(X, batch.A)
 
     def _forward_full_batch(self, batch):
         X0, F = batch.X[0], batch.X[1:]
@@ -130,11 +141,14 @@ class MRGCN(nn.Module):
                     offset += out_dim
                     continue
                 encodings, node_idx, _ = encoding_set
-                keep = torch.isin(node_idx.cpu(), batch_idx)
+                bidx = torch.as_tensor(batch_idx).cpu()
+                keep = torch.isin(node_idx.cpu(), bidx)
                 if not bool(keep.any()):
                     offset += out_dim
                     continue
-                rows = node_idx.cpu()[keep].to(dev)  # full batch: batch position == node id
+                # rows of the batch that carry this encoding (mrgcn.py:276-277, :303); in a full
+                # batch the position equals the node id
+                rows = torch.isin(bidx, node_idx.cpu()[keep]).nonzero().squeeze(1).to(dev)
                 data = encodings[keep.to(encodings.device)].float()
                 out = module(data).to(dev) * gate.to(dev)
                 X[rows, offset:offset + out_dim] = out

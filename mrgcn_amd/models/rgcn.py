@@ -1,7 +1,7 @@
 """Stack of R-GCN layers behind the reference's `RGCN` interface (mrgcn/models/rgcn.py:12-132):
 same constructor, `layers` / `activations` ModuleDicts keyed `layer_<i>`, `relations` table for
-link prediction, `num_layers`.  Full-batch only: the ReLU between layers is folded into the
-epilogue of the layer's sparse product instead of running as its own pass."""
+link prediction, `num_layers`.  In full-batch mode the ReLU between layers is folded into the
+epilogue of the layer's sparse product; mini-batch mode (`A_Batch` input) walks the row slices."""
 from __future__ import annotations
 
 import torch
@@ -49,10 +49,34 @@ class RGCN(nn.Module):
             layer.operand_dtype = dtype
 
     def forward(self, X, A):
-        if not isinstance(A, torch.Tensor):
-            raise NotImplementedError("mini-batch A_Batch input (rgcn.py:91-128) is outside the "
-                                      "full-batch path of mrgcn_amd")
+        if not isinstance(A, torch.Tensor):  # A_Batch (rgcn.py:63-67)
+            return self._forward_mini_batch(X, A)
         return self._forward_full_batch(X, A)
+
+    def _forward_mini_batch(self, X, A):
+        """rgcn.py:91-128: layer l computes the embeddings of the nodes (L-1-l) hops from the batch
+        nodes out of those one hop further, on the matching row slice of A."""
+        from ..data.batch import getAdjacencyNodeColumnIdx
+        for layer_idx, (key, layer) in enumerate(self.layers.items()):
+            f_activation = self.activations[key] if key in self.activations else None
+            i = self.num_layers - (layer_idx + 1)
+            A_slices = A.row[i]
+            if layer.input_layer and layer.featureless:
+                X = layer(None, A_slices)
+            else:
+                A_idx = A._a_idx.get(i) if hasattr(A, "_a_idx") else None
+                if A_idx is None:
+                    A_idx = getAdjacencyNodeColumnIdx(A.neighbours[i], layer.num_nodes,
+                                                      layer.num_relations).to(A_slices.device)
+                    if hasattr(A, "_a_idx"):
+                        A._a_idx[i] = A_idx
+                X = layer(X, A_slices, A_idx)
+            if self.p_dropout > 0.0:
+                ones = dropout(torch.ones(X.shape[0]), p=self.p_dropout).to(X.device)
+                X = X * ones.unsqueeze(1)
+            if f_activation is not None:
+                X = f_activation(X)
+        return X
 
     def _forward_full_batch(self, X, A):
         for key, layer in self.layers.items():

@@ -1,0 +1,123 @@
+"""Mini-batch path (reference mrgcn/data/batch.py:150-316, mrgcn/models/rgcn.py:
+91-128, mrgcn/layers/graph.py:62-102 with A_idx) against goldens captured from the reference
+(tests/golden/make_minibatch_goldens.py): batch structure bit-exact on the host, logits / loss /
+gradients of both engines on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "minibatch_small.npz")
+TAGS = ["ft_b3", "fl_b0", "ft_b0_l3", "fl_b2_l1"]
+
+
+def _batch(g, tag, value_mode="ref_int8"):
+    from mrgcn_amd.data import batch as mb
+    _, A = util.load_graph("graph_small")
+    meta = g[tag + ".meta"]
+    fl, nl = bool(meta[0]), int(meta[3])
+    X = None if fl else [g[tag + ".X_full"]]
+    return mb.MiniBatch(A, X, g["batch_idx"], nl, value_mode=value_mode), A
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_batch_structure_bit_exact(tag):
+    from mrgcn_amd.data import batch as mb
+    g = np.load(GOLD)
+    b, A = _batch(g, tag)
+    nl = int(g[tag + ".meta"][3])
+    for i in range(nl):
+        assert np.array_equal(b.A.neighbours[i], g[f"{tag}.neighbours_{i}"])
+        assert list(b.A.row[i].shape) == list(g[f"{tag}.row_{i}.shape"])
+    b.as_tensors_()
+    for i in range(nl):  # the int8 COO of every row slice: indices and truncated values
+        assert np.array_equal(b.A.row[i]._indices().numpy(), g[f"{tag}.row_{i}.indices"])
+        assert np.array_equal(b.A.row[i]._values().numpy(), g[f"{tag}.row_{i}.values"])
+        assert b.A.row[i].dtype == torch.int8
+    if not bool(g[tag + ".meta"][0]):
+        assert np.allclose(b.X[0].numpy(), g[tag + ".X_sub"])
+        N = A.shape[0]
+        idx = mb.getAdjacencyNodeColumnIdx(b.A.neighbours[0], N, A.shape[1] // N)
+        assert np.array_equal(idx.numpy(), g[tag + ".A_idx_0"])
+        sl = mb.sliceSparseCOO(b.A.row[0], idx)
+        assert np.array_equal(sl._indices().numpy(), g[tag + ".sliced_0.indices"])
+        assert np.array_equal(sl._values().numpy(), g[tag + ".sliced_0.values"])  # all ones (quirk A-3)
+        assert list(sl.shape) == list(g[tag + ".sliced_0.shape"])
+
+
+def test_neighbours_edge_cases():
+    import scipy.sparse as sp
+    from mrgcn_amd.data import batch as mb
+    A = sp.csr_matrix(np.array([[0, 1, 0, 0, 0, 1], [0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0]], dtype=np.float32))
+    assert mb.getNeighboursSparse(A, [1]).tolist() == []                 # isolated row
+    assert mb.getNeighboursSparse(A, [0]).tolist() == [1, 2]             # columns 1 and 5 -> nodes 1, 2
+    assert mb.getNeighboursSparse(A, [0, 2, 0]).tolist() == [0, 1, 2]    # duplicates in the sample
+    t = torch.sparse_coo_tensor(torch.tensor([[0, 0, 1], [1, 5, 3]]), torch.tensor([0, 1, 1], dtype=torch.int8), (2, 6))
+    sl = mb.sliceSparseCOO(t, torch.tensor([1, 3]))
+    assert sl._indices().tolist() == [[0, 1], [0, 1]] and sl._values().tolist() == [1.0, 1.0]
+    assert mb.sliceSparseCOO(t, torch.zeros(0, dtype=torch.long)).shape == (2, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["fused", "literal"])
+@pytest.mark.parametrize("tag", TAGS)
+def test_minibatch_model_vs_reference(tag, engine):
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import categorical_crossentropy
+    g = np.load(GOLD)
+    fl, B, bias, nl, hidden, classes, xw = [int(v) for v in g[tag + ".meta"]]
+    _, A = util.load_graph("graph_small")
+    N = A.shape[0]
+    R = A.shape[1] // N
+    dims = [(xw if li == 0 else hidden, hidden if li < nl - 1 else classes) for li in range(nl)]
+    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li < nl - 1 else None) for li, (i, o) in enumerate(dims)]
+    model = RGCN(modules, R, N, B, 0.0, bool(fl), bool(bias), False)
+    model.load_state_dict({k[len(tag) + 6:]: torch.from_numpy(np.array(g[k])) for k in g.files
+                           if k.startswith(tag + ".init.")})
+    model = model.cuda()
+    model.set_engine(engine)
+    b, _ = _batch(g, tag)
+    b.as_tensors_()
+    b.A.to(torch.device("cuda"))
+    X = None if fl else b.X[0].float().cuda().requires_grad_(True)
+    for epoch in range(2):  # the second pass reuses the cached plans / slices
+        model.zero_grad()
+        if X is not None:
+            X.grad = None
+        logits = model(X, b.A)
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), g[tag + ".logits"], rtol=1e-4, atol=1e-4)
+        idx = torch.arange(len(g["batch_idx"]), device="cuda")
+        loss = categorical_crossentropy(logits, idx, torch.from_numpy(g[tag + ".y"]).cuda())
+        assert abs(float(loss.detach()) - float(g[tag + ".loss"])) < 1e-5
+        loss.backward()
+        for n, p in model.named_parameters():
+            np.testing.assert_allclose(p.grad.cpu().numpy(), g[f"{tag}.grad.{n}"], rtol=1e-3, atol=1e-5, err_msg=n)
+        if X is not None:
+            np.testing.assert_allclose(X.grad.cpu().numpy(), g[tag + ".grad.X"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_mrgcn_minibatch_boundary():
+    """MRGCN(MiniBatch) featureless: same logits as RGCN on the A_Batch, batch object moved with
+    `to(devices)` as the reference's run loop does."""
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.models.mrgcn import MRGCN
+    g = np.load(GOLD)
+    tag = "fl_b0"
+    fl, B, bias, nl, hidden, classes, xw = [int(v) for v in g[tag + ".meta"]]
+    _, A = util.load_graph("graph_small")
+    N = A.shape[0]
+    R = A.shape[1] // N
+    modules = [(0, hidden, "mrgcn", torch.nn.ReLU()), (hidden, classes, "mrgcn", None)]
+    model = MRGCN(modules, [], R, N, num_bases=B, p_dropout=0.0, featureless=True, bias=False,
+                  gcn_gpu_acceleration=True)
+    model.load_state_dict({"rgcn." + k[len(tag) + 6:]: torch.from_numpy(np.array(g[k])) for k in g.files
+                           if k.startswith(tag + ".init.")}, strict=False)
+    batch = mb.MiniBatch(A, [np.empty((N, 0))], g["batch_idx"], nl)
+    batch.as_tensors_()
+    batch.to(model.devices)
+    logits = model(batch)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g[tag + ".logits"], rtol=1e-4, atol=1e-4)
