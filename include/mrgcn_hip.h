@@ -105,6 +105,14 @@ int mrgcn_plan_create(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes,
                       int32_t num_relations, int64_t nnz, const int64_t *coo_rows,
                       const int64_t *coo_cols, const void *coo_vals, int32_t val_dtype,
                       uint32_t flags, void *stream);
+/* The same plan straight from the CSR arrays the dataset archive holds (`A.npz`:
+ * mrgcn/data/io/tarball.py:151-157; device int32 indptr / indices, float32 data), without the
+ * host-side `.nonzero()` expansion to an int64 COO (data/utils.py:165-170).
+ * boundary_cast_i8 != 0 applies the reference's int8 truncation of the values (batch.py:144-149). */
+int mrgcn_plan_create_csr(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes,
+                          int32_t num_relations, int64_t nnz, const int32_t *indptr,
+                          const int32_t *indices, const float *data, int32_t boundary_cast_i8,
+                          uint32_t flags, void *stream);
 int mrgcn_plan_destroy(mrgcn_plan_t *plan);
 int mrgcn_plan_info(const mrgcn_plan_t *plan, mrgcn_plan_info_t *h_info);
 /* copies one plan array to HOST memory (tests: index parity is bit-exact) */

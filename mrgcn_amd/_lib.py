@@ -45,6 +45,7 @@ SIGNATURES = {
     "mrgcn_arch": (C.c_char_p, []),
     "mrgcn_last_error": (C.c_char_p, []),
     "mrgcn_plan_create": (C.c_int, [C.POINTER(_p), _i64, _i64, _i32, _i64, _p, _p, _p, _i32, _u32, _p]),
+    "mrgcn_plan_create_csr": (C.c_int, [C.POINTER(_p), _i64, _i64, _i32, _i64, _p, _p, _p, _i32, _u32, _p]),
     "mrgcn_plan_destroy": (C.c_int, [_p]),
     "mrgcn_plan_info": (C.c_int, [_p, C.POINTER(PlanInfo)]),
     "mrgcn_plan_export": (C.c_int, [_p, _i32, _p, _i64]),

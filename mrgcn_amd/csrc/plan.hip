@@ -47,6 +47,25 @@ __global__ void k_make_keys(const int64_t *__restrict__ rows, const int64_t *__r
   atomicAdd(kept, 1u);  // the compiler folds this into one add per wave
 }
 
+// CSR -> the COO the plan builder consumes; `cast_i8`: the reference's boundary cast
+// (scipy_sparse_to_pytorch_sparse(..., dtype=torch.int8), data/utils.py:165-170: C truncation)
+__global__ void k_csr_to_coo(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                             const float *__restrict__ data, int64_t num_rows, int64_t nnz, int cast_i8,
+                             int64_t *__restrict__ rows, int64_t *__restrict__ cols,
+                             float *__restrict__ vals) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz) return;
+  int64_t lo = 0, hi = num_rows;  // last row whose pointer is <= e
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if ((int64_t)indptr[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  rows[e] = lo;
+  cols[e] = indices[e];
+  const float v = data[e];
+  vals[e] = cast_i8 ? (float)(int8_t)v : v;
+}
+
 __global__ void k_decode(const int64_t *__restrict__ keys, int64_t nnz, int64_t RN, int64_t N,
                          int64_t R, int32_t *__restrict__ rowidx, int32_t *__restrict__ lcol,
                          int64_t *__restrict__ key2, int32_t *__restrict__ eidx) {
@@ -583,6 +602,39 @@ int mrgcn_plan_create(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, 
   }
   *plan = p;
   return MRGCN_OK;
+}
+
+int mrgcn_plan_create_csr(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, int32_t num_relations,
+                          int64_t nnz, const int32_t *indptr, const int32_t *indices, const float *data,
+                          int32_t boundary_cast_i8, uint32_t flags, void *stream) {
+  MRGCN_REQUIRE(plan != nullptr, "plan is NULL");
+  *plan = nullptr;
+  MRGCN_REQUIRE(nnz >= 0 && nnz < (int64_t)INT32_MAX, "nnz must be < 2^31");
+  MRGCN_REQUIRE(num_rows >= 0 && indptr, "indptr");
+  MRGCN_REQUIRE(nnz == 0 || (indices && data), "NULL CSR array");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t *rows = nullptr, *cols = nullptr;
+  float *vals = nullptr;
+  const size_t n = (size_t)(nnz > 0 ? nnz : 1);
+  hipError_t e1 = hipMalloc((void **)&rows, n * sizeof(int64_t));
+  hipError_t e2 = hipMalloc((void **)&cols, n * sizeof(int64_t));
+  hipError_t e3 = hipMalloc((void **)&vals, n * sizeof(float));
+  int rc = MRGCN_OK;
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    mrgcn::set_error("plan_create_csr: out of device memory for the COO expansion");
+    rc = MRGCN_ERR_HIP;
+  } else {
+    if (nnz > 0)
+      mrgcn::k_csr_to_coo<<<mrgcn::nblocks(nnz), mrgcn::kTB, 0, s>>>(indptr, indices, data, num_rows, nnz,
+                                                                     boundary_cast_i8 ? 1 : 0, rows, cols, vals);
+    rc = mrgcn_plan_create(plan, num_rows, num_nodes, num_relations, nnz, rows, cols, vals, MRGCN_VAL_F32,
+                           flags, stream);
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(rows);
+  (void)hipFree(cols);
+  (void)hipFree(vals);
+  return rc;
 }
 
 int mrgcn_plan_destroy(mrgcn_plan_t *plan) {

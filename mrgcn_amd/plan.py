@@ -50,6 +50,10 @@ class GraphPlan:
                 int(val.numel()), rows.data_ptr(), cols.data_ptr(), val.data_ptr(), vd,
                 L.PLAN_PRUNE_ZEROS if prune_zeros else 0, _stream_ptr(self.device)),
                 "mrgcn_plan_create")
+        self._adopt(handle)
+
+    def _adopt(self, handle):
+        lib = L.load()
         self._h = handle
         info = L.PlanInfo()
         L.check(lib.mrgcn_plan_info(self._h, C.byref(info)))
@@ -58,6 +62,43 @@ class GraphPlan:
         self.long_rows, self.long_cols = int(info.long_rows), int(info.long_cols)
         self.device_bytes = int(info.device_bytes)
         self._ptr_cache = {}
+
+    @classmethod
+    def from_csr(cls, A_csr, num_nodes: int, num_relations: int, value_mode: str = "ref_int8",
+                 device="cuda", prune_zeros: bool = False) -> "GraphPlan":
+        """Plan straight from a scipy CSR (what the dataset archive holds, tarball.py:151-157): the
+        three arrays are uploaded as they are and expanded on the device — no host `.nonzero()`, no
+        int64 COO.  `value_mode="ref_int8"` applies the reference's boundary cast (batch.py:144-149)."""
+        lib = L.load()
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise L.MrgcnError("GraphPlan needs a GPU (no CPU path exists in mrgcn_amd)")
+        if int(A_csr.shape[1]) != int(num_nodes) * int(num_relations):
+            raise ValueError("A.shape[1] != num_relations * num_nodes")
+        self = cls.__new__(cls)
+        self.device = device if device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        self.num_rows, self.num_nodes, self.num_relations = int(A_csr.shape[0]), int(num_nodes), int(num_relations)
+        indptr = torch.from_numpy(np.ascontiguousarray(A_csr.indptr, dtype=np.int32)).to(self.device)
+        indices = torch.from_numpy(np.ascontiguousarray(A_csr.indices, dtype=np.int32)).to(self.device)
+        data = torch.from_numpy(np.ascontiguousarray(A_csr.data, dtype=np.float32)).to(self.device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(lib.mrgcn_plan_create_csr(
+                C.byref(handle), self.num_rows, self.num_nodes, self.num_relations, int(data.numel()),
+                indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), 1 if value_mode == "ref_int8" else 0,
+                L.PLAN_PRUNE_ZEROS if prune_zeros else 0, _stream_ptr(self.device)), "mrgcn_plan_create_csr")
+        self._adopt(handle)
+        return self
+
+    def as_adjacency_handle(self) -> torch.Tensor:
+        """An (entry-less) sparse tensor of A's shape that carries this plan: what `model(X, A)` /
+        `FullBatch.A` take when the adjacency never existed as a COO tensor.  Full-batch only (the
+        mini-batch slicer needs the entries)."""
+        A = torch.sparse_coo_tensor(torch.zeros((2, 0), dtype=torch.long, device=self.device),
+                                    torch.zeros(0, dtype=torch.float32, device=self.device),
+                                    (self.num_rows, self.num_relations * self.num_nodes))
+        A._mrgcn_plan = self
+        return A
 
     # -- lifetime -------------------------------------------------------------------
     def close(self):
