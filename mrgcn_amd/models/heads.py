@@ -1,0 +1,94 @@
+"""Heads that sit on a pretrained backbone (reference: mrgcn/models/imagecnn.py:9-41,
+mrgcn/models/transformer.py:8-38, mrgcn/models/utils.py:10-58) and the image normaliser
+(mrgcn/encodings/blob/image.py:139-166).  The reference fetches the backbones with `torch.hub.load`;
+this package has no network path, so the backbone is an `nn.Module` the caller supplies (parity of
+pretrained weights is unpinned) — the heads, freezing rule and pooling are the reference's."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def freeze_(model, layer="", _grad=False):
+    for name, param in model.named_parameters():
+        if layer in name:
+            param.requires_grad_(_grad)
+
+
+def unfreeze_(model, layer=""):
+    freeze_(model, layer, _grad=True)
+
+
+def stripClassifier(model):
+    """The children of `model` up to (excluding) its `.classifier`, as a Sequential."""
+    kept = []
+    for module in model.children():
+        if module is model.classifier:
+            break
+        kept.append(module)
+    return nn.Sequential(*kept)
+
+
+def inferOutputDim(model):
+    """Width of the last Linear / Conv2d of the model."""
+    for module in reversed(list(model.modules())):
+        if isinstance(module, nn.Linear):
+            return module.out_features
+        if isinstance(module, nn.Conv2d):
+            return module.out_channels
+    return -1
+
+
+class _Head(nn.Module):
+    def __init__(self, base_model, inter_dim, output_dim, p_dropout, bias, finetune):
+        super().__init__()
+        self.module_dict = nn.ModuleDict()
+        self.finetune = finetune
+        self.base_model = base_model
+        if self.finetune:  # (sic) the reference freezes the backbone when `finetune` is set
+            freeze_(self.base_model)
+        self.pre_fc = nn.Linear(inter_dim, inter_dim, bias=bias)
+        self.fc = nn.Linear(inter_dim, output_dim, bias=bias)
+        self.f_activation = nn.ReLU()
+
+    def _project(self, pooled):
+        out = self.f_activation(self.pre_fc(pooled))
+        if self.dropout is not None:
+            out = self.dropout(out)
+        return self.fc(out)
+
+
+class ImageCNN(_Head):
+    def __init__(self, model, output_dim, p_dropout=0.2, bias=True, finetune=True):
+        base = stripClassifier(model)
+        super().__init__(base, inferOutputDim(base), output_dim, p_dropout, bias, finetune)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.dropout = nn.Dropout(p=p_dropout) if p_dropout > 0 else None
+
+    def forward(self, X):
+        return self._project(torch.flatten(self.avgpool(self.base_model(X)), 1))
+
+
+class Transformer(_Head):
+    def __init__(self, model, output_dim, p_dropout=0.2, bias=True, finetune=True):
+        super().__init__(model, inferOutputDim(model), output_dim, p_dropout, bias, finetune)
+        self.dropout = nn.Dropout(p=p_dropout) if p_dropout > 0 else None
+
+    def forward(self, X):
+        hidden_state = self.base_model(X)[0]      # (batch, seq_len, dim)
+        return self._project(hidden_state[:, 0])  # first token
+
+
+class Normalizer:
+    """Per-channel (x - mean) / std on pixel values; means / stds given in [0, 1] are scaled by 255."""
+
+    def __init__(self, mean_values, std_values, convert_float_to_pixel=True):
+        self.mean_values = np.array(mean_values, dtype=np.float64)
+        self.std_values = np.array(std_values, dtype=np.float64)
+        if convert_float_to_pixel:
+            self.mean_values *= 255
+            self.std_values *= 255
+
+    def normalize_(self, im):
+        mean = torch.as_tensor(self.mean_values, device=im.device)[:, None, None]
+        std = torch.as_tensor(self.std_values, device=im.device)[:, None, None]
+        return ((im - mean) / std).float()  # broadcasts over a leading batch dimension

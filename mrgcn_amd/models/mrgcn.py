@@ -3,9 +3,10 @@ same constructor, `module_dict` / `gate_weights` / `gate_map` / `devices` attrib
 state-dict keys; full-batch forward = gated literal encoders -> concatenation with X0 ->
 R-GCN on the MI355X kernels.
 
-Scope: the R-GCN path and the MLP encoders of the numeric / boolean / temporal
-datatypes.  The pretrained-backbone encoders (strings, images: torch.hub models) and the WKT
-TCNN are not on the accelerated path and are rejected at construction."""
+Encoders: MLPs for the numeric / boolean / temporal datatypes, the TCNN for
+`ogc.wktLiteral`, and the string / image heads on a caller-supplied backbone module (the reference
+loads those from torch.hub; there is no network path here, so a hub config is rejected with a
+clear error).  In a mini-batch the encoders run for the outermost neighbours only."""
 from __future__ import annotations
 
 import logging
@@ -14,15 +15,17 @@ import warnings
 import torch
 import torch.nn as nn
 
+from .heads import ImageCNN, Normalizer, Transformer
 from .perceptron import MLP
 from .rgcn import RGCN
+from .temporal_cnn import TCNN
 
 logger = logging.getLogger(__name__)
 
 _MLP_LAYERS = {"xsd.boolean": 1, "xsd.numeric": 1, "xsd.date": 2, "xsd.dateTime": 2, "xsd.gYear": 2}
 _COUNTER_GROUP = {"xsd.boolean": "num", "xsd.numeric": "num", "xsd.date": "temp",
-                  "xsd.dateTime": "temp", "xsd.gYear": "temp"}
-_UNSUPPORTED = ("xsd.string", "xsd.anyURI", "blob.image", "ogc.wktLiteral")
+                  "xsd.dateTime": "temp", "xsd.gYear": "temp", "xsd.string": "llm", "xsd.anyURI": "llm",
+                  "blob.image": "img", "ogc.wktLiteral": "geo"}
 
 
 def _pick_device(want_gpu: bool):
@@ -50,23 +53,39 @@ class MRGCN(nn.Module):
         self.compute_modality_embeddings = False
         self.im_norm = None
 
-        counters = {"num": 0, "temp": 0}
+        counters = {"num": 0, "temp": 0, "llm": 0, "img": 0, "geo": 0}
         i_gate = 0
         for datatype, args, gpu_acceleration in embedding_modules:
-            if datatype in _UNSUPPORTED:
-                raise NotImplementedError(
-                    f"{datatype}: pretrained-backbone / TCNN encoders are outside the accelerated "
-                    "R-GCN path of mrgcn_amd (SURVEY §8 next-2)")
-            if datatype not in _MLP_LAYERS:
+            seq_length = -1
+            if datatype in _MLP_LAYERS:
+                ncols, dim_out, p_drop = args
+                module = MLP(input_dim=ncols, output_dim=dim_out, num_layers=_MLP_LAYERS[datatype],
+                             p_dropout=p_drop)
+            elif datatype == "ogc.wktLiteral":  # mrgcn.py:108-118
+                nrows, dim_out, model_size, p_drop = args
+                module = TCNN(features_in=nrows, features_out=dim_out, p_dropout=p_drop, size=model_size)
+                seq_length = module.minimal_length
+            elif datatype in ("xsd.string", "xsd.anyURI", "blob.image"):  # mrgcn.py:80-107
+                backbone = args[0]
+                if not isinstance(backbone, nn.Module):
+                    raise NotImplementedError(
+                        f"{datatype}: the reference loads its backbone with torch.hub (models/utils.py:32-44); "
+                        "mrgcn_amd has no network path — pass the backbone nn.Module in place of the hub config")
+                if datatype == "blob.image":
+                    _, transform_config, dim_out, p_drop = args
+                    module = ImageCNN(backbone, output_dim=dim_out, p_dropout=p_drop)
+                    if "mean" in transform_config and "std" in transform_config:
+                        self.im_norm = Normalizer(transform_config["mean"], transform_config["std"])
+                else:
+                    _, dim_out, p_drop = args
+                    module = Transformer(backbone, output_dim=dim_out, p_dropout=p_drop)
+            else:
                 raise Exception("Datatype not supported: " + datatype)
-            ncols, dim_out, p_drop = args
-            module = MLP(input_dim=ncols, output_dim=dim_out, num_layers=_MLP_LAYERS[datatype],
-                         p_dropout=p_drop)
-            grp = _COUNTER_GROUP[datatype]  # booleans+numerics and the temporal types share counters
+            grp = _COUNTER_GROUP[datatype]  # booleans+numerics, temporal types, strings+URIs share counters
             mod_name = datatype.replace(".", "_") + "_" + str(counters[grp])
             counters[grp] += 1
             self.module_dict[mod_name] = module
-            self.modality_modules.setdefault(datatype, []).append((module, -1, dim_out, i_gate))
+            self.modality_modules.setdefault(datatype, []).append((module, seq_length, dim_out, i_gate))
             self.modality_out_dim += dim_out
             self.compute_modality_embeddings = True
             self.gate_map[mod_name] = i_gate
@@ -149,7 +168,13 @@ class MRGCN(nn.Module):
                 # rows of the batch that carry this encoding (mrgcn.py:276-277, :303); in a full
                 # batch the position equals the node id
                 rows = torch.isin(bidx, node_idx.cpu()[keep]).nonzero().squeeze(1).to(dev)
-                data = encodings[keep.to(encodings.device)].float()
+                data = encodings[keep.to(encodings.device)]
+                if datatype in ("xsd.string", "xsd.anyURI"):   # token ids (mrgcn.py:287-288)
+                    data = data.int()
+                elif datatype == "blob.image" and self.im_norm is not None:
+                    data = self.im_norm.normalize_(data)
+                else:
+                    data = data.float()
                 out = module(data).to(dev) * gate.to(dev)
                 X[rows, offset:offset + out_dim] = out
                 offset += out_dim

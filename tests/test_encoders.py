@@ -1,0 +1,126 @@
+"""Modality encoders feeding X against goldens captured from the reference
+(tests/golden/make_encoder_goldens.py).  Weights are rebuilt from the same torch seed — which pins the
+init stream and the state-dict layout — and checked against per-tensor checksums."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from tests import util
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "encoders.npz")
+
+
+def _check_state(sd, g, prefix):
+    keys = sorted(sd)
+    assert keys == list(g[prefix + "keys"])
+    np.testing.assert_array_equal([sd[k].numel() for k in keys], g[prefix + "numel"])
+    np.testing.assert_allclose([float(sd[k].double().sum()) for k in keys], g[prefix + "sum"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose([float(sd[k].double().abs().sum()) for k in keys], g[prefix + "abs"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("size", ["S", "M", "L"])
+def test_tcnn_matches_reference(size):
+    from mrgcn_amd.models.temporal_cnn import TCNN
+    g = np.load(GOLD)
+    torch.manual_seed(3)
+    m = TCNN(features_in=9, features_out=7, p_dropout=0.0, size=size)
+    _check_state(m.state_dict(), g, f"tcnn{size}.sd.")          # same keys, same init stream
+    assert m.minimal_length == int(g[f"tcnn{size}.minimal_length"])
+    x = torch.from_numpy(g[f"tcnn{size}.x"])
+    m.train()
+    y = m(x)
+    y.square().sum().backward()
+    np.testing.assert_allclose(y.detach().numpy(), g[f"tcnn{size}.y_train"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.conv[0].weight.grad.numpy(), g[f"tcnn{size}.grad_conv0"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(m.conv[1].running_mean.numpy(), g[f"tcnn{size}.sd_after.running_mean0"], rtol=1e-5, atol=1e-6)
+    m.eval()
+    np.testing.assert_allclose(m(x).detach().numpy(), g[f"tcnn{size}.y_eval"], rtol=1e-4, atol=1e-5)
+
+
+class TinyImageNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.features = nn.Sequential(nn.Conv2d(3, 6, 3, padding=1), nn.ReLU(), nn.Conv2d(6, 8, 3, padding=1))
+        self.classifier = nn.Linear(8, 5)
+
+
+class TinyLM(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.emb = nn.Embedding(50, 12)
+        self.lin = nn.Linear(12, 12)
+
+    def forward(self, ids):
+        return (self.lin(self.emb(ids)),)
+
+
+def _load(module, g, prefix):
+    module.load_state_dict({k[len(prefix):]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith(prefix)})
+
+
+def test_backbone_heads_and_normalizer_match_reference():
+    from mrgcn_amd.models.heads import ImageCNN, Normalizer, Transformer
+    g = np.load(GOLD, allow_pickle=True)
+    base = TinyImageNet()
+    _load(base, g, "img.base.")
+    head = ImageCNN(base, output_dim=6, p_dropout=0.0)
+    assert sorted(head.state_dict()) == sorted(k[len("img.sd."):] for k in g.files if k.startswith("img.sd."))
+    _load(head, g, "img.sd.")
+    np.testing.assert_allclose(head(torch.from_numpy(g["img.x"])).detach().numpy(), g["img.y"], rtol=1e-5, atol=1e-6)
+    # the backbone is frozen, the head trains (imagecnn.py:18-20)
+    assert sorted(n for n, p in head.named_parameters() if p.requires_grad) == list(g["img.trainable"])
+    lm = TinyLM()
+    _load(lm, g, "lm.base.")
+    th = Transformer(lm, output_dim=4, p_dropout=0.0)
+    _load(th, g, "lm.sd.")
+    np.testing.assert_allclose(th(torch.from_numpy(g["lm.x"])).detach().numpy(), g["lm.y"], rtol=1e-5, atol=1e-6)
+    nz = Normalizer([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    x = torch.from_numpy(g["norm.x"])
+    np.testing.assert_allclose(nz.normalize_(x).numpy(), g["norm.y"], rtol=1e-6)
+    np.testing.assert_allclose(nz.normalize_(x[0]).numpy(), g["norm.single"], rtol=1e-6)
+
+
+def test_mrgcn_rejects_hub_configs_but_builds_the_rest():
+    from mrgcn_amd.models.mrgcn import MRGCN
+    modules = [(5, 4, "mrgcn", nn.ReLU()), (4, 2, "mrgcn", None)]
+    with pytest.raises(NotImplementedError):
+        MRGCN(modules, [("xsd.string", (["huggingface/pytorch-transformers", "model", "distilbert"], 5, 0.0), False)], 3, 10)
+    with pytest.raises(Exception, match="Datatype not supported"):
+        MRGCN(modules, [("xsd.unknown", (1, 1, 0.0), False)], 3, 10)
+    m = MRGCN(modules, [("blob.image", (TinyImageNet(), {"mean": [0.5] * 3, "std": [0.2] * 3}, 3, 0.0), False),
+                        ("xsd.anyURI", (TinyLM(), 2, 0.0), False)], 3, 10)
+    assert set(m.gate_map) == {"blob_image_0", "xsd_anyURI_0"} and m.im_norm is not None and m.modality_out_dim == 5
+
+
+@pytest.mark.gpu
+def test_mrgcn_with_tcnn_and_mlp_encoders_vs_reference():
+    """MRGCN(FullBatch) with an ogc.wktLiteral (TCNN) and an xsd.numeric (MLP) encoder: state-dict
+    layout + init stream, logits, gradients of the gates and of the TCNN's first convolution."""
+    from mrgcn_amd.data.batch import FullBatch
+    from mrgcn_amd.models.mrgcn import MRGCN
+    g = np.load(GOLD, allow_pickle=True)
+    _, A = util.load_graph("graph_small")
+    N = A.shape[0]
+    R = A.shape[1] // N
+    torch.manual_seed(6)
+    emb_cfg = sorted([("ogc.wktLiteral", (9, 5, "S", 0.0), False), ("xsd.numeric", (4, 3, 0.0), False)],
+                     key=lambda t: t[0])
+    modules = [(8, 6, "mrgcn", nn.ReLU()), (6, 4, "mrgcn", None)]
+    model = MRGCN(modules, emb_cfg, R, N, num_bases=3, p_dropout=0.0, featureless=False, bias=False,
+                  gcn_gpu_acceleration=True)
+    _check_state({k: v.cpu() for k, v in model.state_dict().items()}, g, "mrgcn.sd.")
+    X = [np.empty((N, 0), dtype=np.float32),
+         ["ogc.wktLiteral", [[g["mrgcn.wkt"], g["mrgcn.wkt_idx"], np.full(14, 20)]], False],
+         ["xsd.numeric", [[g["mrgcn.num"], g["mrgcn.num_idx"], np.ones(25, dtype=int)]], False]]
+    batch = FullBatch(A, X, np.arange(N))
+    batch.as_tensors_()
+    batch.to(model.devices)
+    logits = model(batch)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["mrgcn.logits"], rtol=1e-4, atol=1e-4)
+    logits.square().mean().backward()
+    np.testing.assert_allclose(model.gate_weights.grad.cpu().numpy(), g["mrgcn.grad.gate_weights"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(model.module_dict["ogc_wktLiteral_0"].conv[0].weight.grad.cpu().numpy(),
+                               g["mrgcn.grad.tcnn_conv0"], rtol=2e-3, atol=1e-6)
