@@ -234,6 +234,15 @@ def main():
                 del D
             except Exception as e:  # noqa: BLE001
                 extra["spmm_literal_error"] = str(e)[:200]
+        # the roofline denominator next to what a plain device copy reaches on this
+        # box, and the bytes the parameter tail of an epoch has to move
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB
+        dst = torch.empty_like(src)
+        t_cp = event_time_ms(lambda: dst.copy_(src), 5, stream)
+        extra["device_copy_gbps"] = 2 * src.numel() * 4 / (t_cp * 1e-3) / 1e9  # read + write
+        del src, dst
+        n_theta = sum(p.numel() for p in model.parameters())
+        extra["param_bytes"] = 4 * n_theta * (1 + 1 + 6)  # grad write, clip read, Adam 3 reads + 3 writes
         torch.cuda.synchronize(dev)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
