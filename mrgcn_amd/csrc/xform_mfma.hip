@@ -335,6 +335,9 @@ int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, 
   if (K <= 64)
     k_xform_mfma_dw<1, 8><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
         p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F, dW, slab);
+  else if (K <= 192)  // fewer accumulator tiles = fewer registers (128 vs 160) = a fourth wave per
+    k_xform_mfma_dw<3, 4><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
+        p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F, dW, slab);
   else
     k_xform_mfma_dw<kMaxTQ, 4><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
         p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F, dW, slab);
