@@ -14,6 +14,8 @@
 // D: col = l&15, row = 4*(l>>4) + reg.  The k slot <-> actual k assignment is free as long as A
 // and B agree: slot kq of the s-th MFMA of a 16-wide K step stands for k = k0 + 4*kq + s, so a
 // lane feeds four MFMAs from ONE 16-byte load of its gathered row.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mrgcn {
@@ -332,11 +334,15 @@ int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, 
   if (p->n_relchunks == 0) return MRGCN_OK;
   const size_t lds = (size_t)4 * K * F * sizeof(float);
   float *slab = (workspace && workspace_floats >= (int64_t)p->n_relchunks * K * F) ? workspace : nullptr;
+  // Unroll U (columns in flight per wave = 4 U) and tile count are chosen for registers, i.e. for
+  // waves per SIMD — the pass waits on the gathered input rows (PMC: profiles/r01_xform_pmc.md).
+  // AM shape, same run: K = 10: U = 8 / 4 / 2 -> 1.42 / 1.20 / 1.11 ms (with the dX half);
+  // K = 155: <4,4> 1.92 ms, <3,4> 1.65 ms, <3,2> 1.62 ms.
   if (K <= 64)
-    k_xform_mfma_dw<1, 8><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
+    k_xform_mfma_dw<1, 2><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
         p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F, dW, slab);
-  else if (K <= 192)  // fewer accumulator tiles = fewer registers (128 vs 160) = a fourth wave per
-    k_xform_mfma_dw<3, 4><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
+  else if (K <= 192)
+    k_xform_mfma_dw<3, 2><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
         p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F, dW, slab);
   else
     k_xform_mfma_dw<kMaxTQ, 4><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
