@@ -38,9 +38,9 @@ ALG = {  # kernel-name prefix -> [(selector on grid size or None, label, bytes)]
     "mrgcn::k_xform_mfma_fwd<1, false, 1, float>": ("layer-1 transform: H read once + W + M written + indices",
                                              N * F0 * 4 + R * F0 * F1 * 4 + NCOLS * LD * 4 + NCOLS * 12),
     "mrgcn::k_xform_mfma_fwd<1, true, 1, float>": ("layer-1 dX products: dM read + W + Z written", 2 * NCOLS * LD * 4 + NCOLS * 4),
-    "mrgcn::k_xform_mfma_dw<4, 4>": ("layer-0 dW: X read once + dM read + indices + slabs",
+    "mrgcn::k_xform_mfma_dw<3, 2>": ("layer-0 dW: X read once + dM read + indices + slabs",
                                      N * K0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
-    "mrgcn::k_xform_mfma_dw<1, 8>": ("layer-1 dW: H read once + dM read + indices", N * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
+    "mrgcn::k_xform_mfma_dw<1, 2>": ("layer-1 dW: H read once + dM read + indices", N * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
     "mrgcn::k_segment_sum": ("dX = segmented sum of Z", NCOLS * LD * 4 + N * F0 * 4),
 }
 
