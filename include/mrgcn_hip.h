@@ -243,6 +243,16 @@ int mrgcn_distmult_score_f32(const float *E, int64_t ldE, const float *Rel, int6
 int mrgcn_distmult_score_bwd_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR,
                                  int32_t H, const int64_t *triples, int64_t n, const float *dscores,
                                  float *dE, int64_t lddE, float *dRel, int64_t lddR, void *stream);
+/* the same gradients from triples visited in sorted order: order_s / order_p / order_o are device
+ * int64 permutations of 0..n-1 that sort the triples by subject / predicate / object (any order
+ * within ties).  Runs of equal targets are summed in registers, so the float atomics of the
+ * scatter form (which collide on the few hundred relation rows) shrink by the run length.
+ * dE needs order_s and order_o, dRel needs order_p; both are ACCUMULATED into. */
+int mrgcn_distmult_score_bwd_sorted_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR,
+                                        int32_t H, const int64_t *triples, int64_t n,
+                                        const float *dscores, const int64_t *order_s,
+                                        const int64_t *order_p, const int64_t *order_o, float *dE,
+                                        int64_t lddE, float *dRel, int64_t lddR, void *stream);
 /* nn.BCEWithLogitsLoss() (link_prediction.py:57, :550-554): *loss = mean; dx (nullable) its
  * gradient w.r.t. x */
 int mrgcn_bce_logits_f32(const float *x, const float *y, int64_t n, float *loss, float *dx,

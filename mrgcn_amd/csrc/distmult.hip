@@ -62,6 +62,60 @@ __global__ void k_distmult_bwd(const float *__restrict__ E, int64_t ldE, const f
   }
 }
 
+// The same gradients with far fewer atomics: `order` lists the triples sorted by their WHICH-th
+// component (0 = s, 1 = p, 2 = o); a wave walks kRun consecutive sorted triples, keeps the running
+// sum for the current target row in registers and only touches memory when the row changes.  At
+// the FB15k-237 shape every relation row is the target of ~1 400 triples and an average node row
+// of ~40: the scatter kernel above spends its time in colliding L2 atomics (1.75 ms), these three
+// passes re-read the (L2-resident) embedding rows instead.
+constexpr int kRun = 32;   // sorted triples per wave
+constexpr int kRunF = 256;   // features per pass of a wave (4 per lane)
+
+template <int WHICH>
+__global__ void k_distmult_bwd_sorted(const float *__restrict__ E, int64_t ldE, const float *__restrict__ Rel,
+                                      int64_t ldR, int H, const int64_t *__restrict__ tr,
+                                      const int64_t *__restrict__ order, int64_t n,
+                                      const float *__restrict__ g, float *__restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * (kTB / kWave) + (threadIdx.x >> 6);
+  const int64_t t0 = w * kRun;
+  if (t0 >= n) return;
+  const int h0 = blockIdx.y * kRunF;
+  float acc[kRunF / kWave];
+#pragma unroll
+  for (int k = 0; k < kRunF / kWave; ++k) acc[k] = 0.f;
+  int64_t cur = -1;
+  auto flush = [&]() {
+    if (cur < 0) return;
+#pragma unroll
+    for (int k = 0; k < kRunF / kWave; ++k) {
+      const int h = h0 + lane + kWave * k;
+      if (h < H && acc[k] != 0.f) atomicAdd(out + cur * ldo + h, acc[k]);
+      acc[k] = 0.f;
+    }
+  };
+  const int64_t t1 = (t0 + kRun < n) ? t0 + kRun : n;
+  for (int64_t t = t0; t < t1; ++t) {
+    const int64_t i = order[t];
+    const int64_t si = tr[3 * i], pi = tr[3 * i + 1], oi = tr[3 * i + 2];
+    const int64_t key = WHICH == 0 ? si : WHICH == 1 ? pi : oi;
+    if (key != cur) {  // wave-uniform
+      flush();
+      cur = key;
+    }
+    const float gt = g[i];
+    if (gt == 0.f) continue;
+    const float *a = WHICH == 0 ? Rel + pi * ldR : E + si * ldE;            // the two rows that are multiplied
+    const float *b = WHICH == 2 ? Rel + pi * ldR : E + oi * ldE;
+#pragma unroll
+    for (int k = 0; k < kRunF / kWave; ++k) {
+      const int h = h0 + lane + kWave * k;
+      if (h < H) acc[k] = fmaf(gt * a[h], b[h], acc[k]);
+    }
+  }
+  flush();
+}
+
 // loss = mean(max(x,0) - x y + log1p(exp(-|x|))),  dx = (sigmoid(x) - y) / n
 __global__ void k_bce_logits(const float *__restrict__ x, const float *__restrict__ y, int64_t n,
                              float *__restrict__ loss, float *__restrict__ dx) {
@@ -265,6 +319,26 @@ int mrgcn_distmult_score_bwd_f32(const float *E, int64_t ldE, const float *Rel, 
   const int per = kTB / kWave;
   k_distmult_bwd<<<(unsigned)((n + per - 1) / per), kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, n, dscores,
                                                                    dE, lddE, dRel, lddR);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_distmult_score_bwd_sorted_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR, int32_t H,
+                                        const int64_t *triples, int64_t n, const float *dscores,
+                                        const int64_t *order_s, const int64_t *order_p, const int64_t *order_o,
+                                        float *dE, int64_t lddE, float *dRel, int64_t lddR, void *stream) {
+  MRGCN_REQUIRE(E && Rel && triples && dscores && H > 0 && n >= 0, "distmult_score_bwd_sorted: bad argument");
+  MRGCN_REQUIRE((!dE || (order_s && order_o)) && (!dRel || order_p), "distmult_score_bwd_sorted: missing order");
+  if (n == 0 || (!dE && !dRel)) return MRGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t waves = (n + kRun - 1) / kRun;
+  dim3 grid((unsigned)((waves + kTB / kWave - 1) / (kTB / kWave)), (unsigned)((H + kRunF - 1) / kRunF));
+  if (dE) {
+    k_distmult_bwd_sorted<0><<<grid, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_s, n, dscores, dE, lddE);
+    k_distmult_bwd_sorted<2><<<grid, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_o, n, dscores, dE, lddE);
+  }
+  if (dRel)
+    k_distmult_bwd_sorted<1><<<grid, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_p, n, dscores, dRel, lddR);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -6,11 +6,15 @@ writers and mini-batch machinery are out of scope."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
 
 from .. import _lib
+
+
+_SORTED_BWD_MIN = 4096  # below this the scatter kernel's atomics do not collide enough to matter
 
 
 def _stream():
@@ -62,10 +66,20 @@ class _DistMultScore(torch.autograd.Function):
         g = g.contiguous().float()
         dE = torch.zeros_like(E, memory_format=torch.contiguous_format) if ctx.needs_input_grad[0] else None
         dR = torch.zeros_like(Rel, memory_format=torch.contiguous_format) if ctx.needs_input_grad[1] else None
-        _lib.check(lib.mrgcn_distmult_score_bwd_f32(
-            _ptr(E), E.stride(0), _ptr(Rel), Rel.stride(0), E.shape[1], _ptr(triples), triples.shape[0],
-            _ptr(g), _ptr(dE), dE.stride(0) if dE is not None else 0, _ptr(dR),
-            dR.stride(0) if dR is not None else 0, _stream()), "distmult_score_bwd")
+        n = triples.shape[0]
+        if n >= _SORTED_BWD_MIN and os.environ.get("MRGCN_LP_SORTED_BWD", "1") != "0":
+            # runs of equal subject / predicate / object are summed in registers (three passes over
+            # sorted triples) instead of one float atomic per triple and feature
+            order = [torch.argsort(triples[:, k]) for k in range(3)]
+            _lib.check(lib.mrgcn_distmult_score_bwd_sorted_f32(
+                _ptr(E), E.stride(0), _ptr(Rel), Rel.stride(0), E.shape[1], _ptr(triples), n, _ptr(g),
+                _ptr(order[0]), _ptr(order[1]), _ptr(order[2]), _ptr(dE), dE.stride(0) if dE is not None else 0,
+                _ptr(dR), dR.stride(0) if dR is not None else 0, _stream()), "distmult_score_bwd_sorted")
+        else:
+            _lib.check(lib.mrgcn_distmult_score_bwd_f32(
+                _ptr(E), E.stride(0), _ptr(Rel), Rel.stride(0), E.shape[1], _ptr(triples), n,
+                _ptr(g), _ptr(dE), dE.stride(0) if dE is not None else 0, _ptr(dR),
+                dR.stride(0) if dR is not None else 0, _stream()), "distmult_score_bwd")
         return dE, dR, None
 
 
@@ -123,6 +137,27 @@ def sample_negatives(batch_data: np.ndarray, rng=np.random):
     Y = np.ones(n + ncorrupt, dtype=np.float32)
     if ncorrupt:
         Y[-ncorrupt:] = 0
+    return corrupted, Y
+
+
+def sample_negatives_device(batch_data: torch.Tensor, generator=None):
+    """The same corruption scheme drawn on the device (a torch generator instead of np.random, so
+    not the reference's random stream): `batch_data` int64 [n, 3] on the GPU -> (corrupted
+    [n // 5, 3], labels float32 [n + n // 5]), no host round trip."""
+    n = batch_data.shape[0]
+    dev = batch_data.device
+    nodes = torch.unique(torch.cat([batch_data[:, 0], batch_data[:, 2]]))
+    ncorrupt = n // 5
+    neg_idx = torch.randperm(n, device=dev, generator=generator)[:ncorrupt]
+    nhead = ncorrupt // 2
+    ntail = ncorrupt - nhead
+    corrupted = batch_data[neg_idx].clone()
+    pick = lambda k: nodes[torch.randint(0, nodes.numel(), (k,), device=dev, generator=generator)]  # noqa: E731
+    corrupted[:nhead, 0] = pick(nhead)
+    if ntail:
+        corrupted[ncorrupt - ntail:, 2] = pick(ntail)
+    Y = torch.ones(n + ncorrupt, dtype=torch.float32, device=dev)
+    Y[n:] = 0
     return corrupted, Y
 
 

@@ -117,3 +117,41 @@ def test_lp_epoch_on_encoder_output():
         losses.append(loss.item())
     assert losses[-1] < losses[0]
     assert model.relations.grad is not None and float(model.relations.grad.abs().sum()) > 0
+
+
+def test_sorted_backward_equals_scatter_backward():
+    """The run-accumulating backward (three passes over sorted triples) against the float64 oracle
+    and against the scatter kernel, on a size that takes the sorted path (>= 4096 triples)."""
+    import os
+    from mrgcn_amd.tasks import link_prediction as lp
+    rng = np.random.default_rng(3)
+    N, P, H, n = 400, 7, 70, 6000
+    E = rng.standard_normal((N, H)).astype(np.float32)
+    Rel = rng.standard_normal((2 * P + 1, H)).astype(np.float32)
+    facts = np.stack([rng.integers(0, N, n), rng.integers(0, P, n), rng.integers(0, N, n)], 1).astype(np.int64)
+    y = (rng.random(n) < 0.8).astype(np.float32)
+    dE_ref, dR_ref = lo.distmult_bce_grads(facts, E, Rel, y)
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["MRGCN_LP_SORTED_BWD"] = flag
+        Et, Rt = torch.from_numpy(E).cuda().requires_grad_(True), torch.from_numpy(Rel).cuda().requires_grad_(True)
+        ft = torch.from_numpy(facts).cuda()
+        loss = lp.binary_crossentropy(lp.score_distmult_bc((ft[:, 0], ft[:, 1], ft[:, 2]), Et, Rt),
+                                      torch.from_numpy(y).cuda())
+        loss.backward()
+        outs.append((Et.grad.cpu().numpy(), Rt.grad.cpu().numpy()))
+    os.environ.pop("MRGCN_LP_SORTED_BWD")
+    for dE, dR in outs:
+        np.testing.assert_allclose(dE, dE_ref, rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(dR, dR_ref, rtol=1e-3, atol=1e-6)
+
+
+def test_device_negative_sampling_shapes():
+    from mrgcn_amd.tasks import link_prediction as lp
+    rs = np.random.RandomState(1)
+    facts = torch.from_numpy(np.stack([rs.randint(0, 50, 103), rs.randint(0, 4, 103), rs.randint(0, 50, 103)], 1)).cuda()
+    neg, Y = lp.sample_negatives_device(facts, torch.Generator(device="cuda").manual_seed(0))
+    assert neg.shape == (20, 3) and Y.shape == (123,) and bool(Y[:103].all()) and not bool(Y[103:].any())
+    nodes = torch.unique(torch.cat([facts[:, 0], facts[:, 2]]))
+    assert bool(torch.isin(neg[:, 0], nodes).all()) and bool(torch.isin(neg[:, 2], nodes).all())
+    assert bool(torch.isin(neg[:, 1], facts[:, 1]).all())
