@@ -357,6 +357,22 @@ __global__ __launch_bounds__(256) void k_spmm_finalize(SparseView v, const float
   if (c1 - c0 <= 1) return;  // single-chunk rows were stored by the chunk wave
   int64_t row = v.long_row[li];
   if (out_index) row = out_index[row];
+  if (F >= 32) {  // wide rows: lanes over features (coalesced), chunks in order
+    for (int f = lane; f < F; f += kWave) {
+      float s0 = 0.f, s1 = 0.f;
+      int32_t c = c0;
+      for (; c + 2 <= c1; c += 2) {
+        s0 += partials[(int64_t)c * ldP + f];
+        s1 += partials[(int64_t)(c + 1) * ldP + f];
+      }
+      if (c < c1) s0 += partials[(int64_t)c * ldP + f];
+      float s = s0 + s1;
+      if (bias) s += bias[f];
+      if (relu) s = fmaxf(s, 0.f);
+      Y[row * ldY + f] = s;
+    }
+    return;
+  }
   for (int f = 0; f < F; ++f) {
     float s = 0.f;
     for (int32_t c = c0 + lane; c < c1; c += kWave) s += partials[(int64_t)c * ldP + f];
