@@ -253,7 +253,8 @@ def main():
                        "sample": "failed: " + str(e)[:200]}
         n_params = sum(p.numel() for p in model.parameters())
         out = {
-            "metric": "full-batch R-GCN epoch time (ms), AM-shaped graph",
+            "metric": "full-batch R-GCN epoch time (ms), AM-shaped graph" if name == "am" else
+                      "full-batch R-GCN epoch time (ms), %s-shaped graph" % name,
             "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": False,
             "scaling": "strong" if partitioned else "weak", "vs_baseline": None, "dtype": "f32",
