@@ -270,6 +270,16 @@ int mrgcn_distmult_ranks(const float *E, int64_t ldE, int64_t num_nodes, const f
                          const int32_t *head_idx, void *workspace, int64_t workspace_bytes,
                          int64_t *ranks, void *stream);
 
+/* Graph-capturable Adam (torch.optim.Adam(capturable=True) semantics): the step counter and the
+ * bias corrections live in device memory, so a captured epoch replays with the right step.
+ * mrgcn_adam_bias_f32: ++*step_dev; bc_dev[0] = 1 - beta1^step, bc_dev[1] = sqrt(1 - beta2^step).
+ * mrgcn_adam_step_dev_f32: mrgcn_adam_step_f32 reading the corrections from bc_dev. */
+int mrgcn_adam_bias_f32(int64_t *step_dev, float beta1, float beta2, float *bc_dev, void *stream);
+int mrgcn_adam_step_dev_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                            int64_t n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, const float *bc_dev, const float *grad_scale,
+                            void *stream);
+
 /* ---- timing helpers (HIP events on the caller's stream; used by bench.py) ------ */
 int mrgcn_event_create(void **event);
 int mrgcn_event_destroy(void *event);

@@ -76,6 +76,9 @@ SIGNATURES = {
     "mrgcn_bce_logits_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p]),
     "mrgcn_distmult_ranks_workspace": (C.c_int64, [_i64, _i32, _i64]),
     "mrgcn_distmult_ranks": (C.c_int, [_p, _i64, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p]),
+    "mrgcn_adam_bias_f32": (C.c_int, [_p, C.c_float, C.c_float, _p, _p]),
+    "mrgcn_adam_step_dev_f32": (C.c_int, [_p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, _p, _p, _p]),
     "mrgcn_event_create": (C.c_int, [C.POINTER(_p)]),
     "mrgcn_event_destroy": (C.c_int, [_p]),
     "mrgcn_event_record": (C.c_int, [_p, _p]),

@@ -91,7 +91,12 @@ __global__ void k_clip_coef(const double *__restrict__ sumsq, float max_norm, fl
 template <bool NT>
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                        float *__restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                       float wd, float bc1, float bc2_sqrt, const float *__restrict__ scale) {
+                       float wd, float bc1, float bc2_sqrt, const float *__restrict__ scale,
+                       const float *__restrict__ bc_dev) {
+  if (bc_dev) {  // bias corrections kept on the device (graph-capturable steps)
+    bc1 = bc_dev[0];
+    bc2_sqrt = bc_dev[1];
+  }
   const float sc = scale ? *scale : 1.f;
   const float step = lr / bc1;
   const int64_t nv = n >> 2;
@@ -206,9 +211,20 @@ int mrgcn_clip_coef_f32(const double *sumsq, float max_norm, float *coef, float 
   return MRGCN_OK;
 }
 
+static int adam_impl(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                     const float *grad_scale, const float *bc_dev, void *stream);
+
 int mrgcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                         float lr, float beta1, float beta2, float eps, float weight_decay,
                         int64_t step, const float *grad_scale, void *stream) {
+  return adam_impl(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                   nullptr, stream);
+}
+
+static int adam_impl(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                     const float *grad_scale, const float *bc_dev, void *stream) {
   MRGCN_REQUIRE(param && grad && exp_avg && exp_avg_sq, "NULL");
   MRGCN_REQUIRE(step >= 1, "step counts from 1");
   MRGCN_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
@@ -224,13 +240,44 @@ int mrgcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *
   if (nt_mode)
     k_adam<true><<<dim3((unsigned)blocks), dim3(kTB), 0, (hipStream_t)stream>>>(
         param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-        (float)sqrt(bc2), grad_scale);
+        (float)sqrt(bc2), grad_scale, bc_dev);
   else
     k_adam<false><<<dim3((unsigned)blocks), dim3(kTB), 0, (hipStream_t)stream>>>(
         param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-        (float)sqrt(bc2), grad_scale);
+        (float)sqrt(bc2), grad_scale, bc_dev);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
+}
+
+}  // extern "C"
+
+namespace mrgcn {
+namespace {
+// step counter and Adam bias corrections on the device: ++*step; bc = {1 - b1^step, sqrt(1 - b2^step)}
+__global__ void k_adam_bias(int64_t *__restrict__ step, float b1, float b2, float *__restrict__ bc) {
+  const int64_t t = *step + 1;
+  *step = t;
+  bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+  bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+}  // namespace
+}  // namespace mrgcn
+
+extern "C" {
+
+int mrgcn_adam_bias_f32(int64_t *step_dev, float beta1, float beta2, float *bc_dev, void *stream) {
+  MRGCN_REQUIRE(step_dev && bc_dev, "NULL");
+  mrgcn::k_adam_bias<<<dim3(1), dim3(1), 0, (hipStream_t)stream>>>(step_dev, beta1, beta2, bc_dev);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_adam_step_dev_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                            float lr, float beta1, float beta2, float eps, float weight_decay,
+                            const float *bc_dev, const float *grad_scale, void *stream) {
+  MRGCN_REQUIRE(bc_dev, "bc_dev is NULL");
+  return adam_impl(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, 1, grad_scale,
+                   bc_dev, stream);
 }
 
 int mrgcn_softmax_xent_f32(const float *logits, int64_t ld, int32_t C, const int64_t *idx,

@@ -62,10 +62,14 @@ class ClipAdam(torch.optim.Optimizer):
     layout as torch.optim.Adam so that `optimizer_params` groups (tasks/utils.py:8-45) work."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 max_norm=1.0):
+                 max_norm=1.0, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.max_norm = max_norm
+        # capturable: step counter and bias corrections on the device (one per distinct betas), so
+        # that a hipGraph-captured step replays correctly (see GraphedTrainStep)
+        self.capturable = capturable
+        self._dev_step = {}
         self._scratch = {}
         self._dist = None  # (group, ids of parameters sharded across ranks)
 
@@ -146,6 +150,22 @@ class ClipAdam(torch.optim.Optimizer):
                     float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                     float(group["weight_decay"]), int(st["step"]),
                     sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_basis_mix_bwd_adam_f32")
+            bias = {}
+            if self.capturable:
+                if deferred:
+                    raise L.MrgcnError("ClipAdam(capturable=True) does not take deferred gradients")
+                for group in self.param_groups:  # one device counter per distinct (beta1, beta2)
+                    key = tuple(float(b) for b in group["betas"])
+                    if key in bias:
+                        continue
+                    ent = self._dev_step.get(key)
+                    if ent is None:
+                        ent = (torch.zeros((), dtype=torch.int64, device=device),
+                               torch.ones(2, dtype=torch.float32, device=device))
+                        self._dev_step[key] = ent
+                    L.check(lib.mrgcn_adam_bias_f32(ent[0].data_ptr(), key[0], key[1], ent[1].data_ptr(), s),
+                            "mrgcn_adam_bias_f32")
+                    bias[key] = ent[1]
             for (group, p), g in zip(live, grads):
                 st = self.state[p]
                 if not st:
@@ -154,6 +174,13 @@ class ClipAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
                 b1, b2 = group["betas"]
+                if self.capturable:
+                    L.check(lib.mrgcn_adam_step_dev_f32(
+                        p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                        p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                        float(group["weight_decay"]), bias[(float(b1), float(b2))].data_ptr(),
+                        sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_adam_step_dev_f32")
+                    continue
                 L.check(lib.mrgcn_adam_step_f32(
                     p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                     p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
@@ -205,3 +232,37 @@ def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.
             defer_input_grad(prev)
     optimizer.step()
     return loss.detach()
+
+
+class GraphedTrainStep:
+    """One full-batch epoch captured into a hipGraph (torch.cuda.CUDAGraph) and replayed: the ~40
+    kernel launches of a step become one graph launch, which is what bounds the small shapes
+    (AIFB / MUTAG epochs are launch-latency territory).  Everything in the step is stream-ordered
+    and allocation-free at the C ABI, the optimizer keeps its step counter on the device
+    (`ClipAdam(capturable=True)`), so the captured sequence is exactly the eager one.
+
+        step = GraphedTrainStep(model, lambda: model(X, A), idx, targets, optimizer)
+        loss = step()          # device scalar, no host sync
+
+    The graph plans must exist before capture (the warm-up steps build them); shapes are static."""
+
+    def __init__(self, model, forward_fn, idx, targets, optimizer, warmup: int = 3,
+                 l1_lambda: float = 0.0, l2_lambda: float = 0.0):
+        if not getattr(optimizer, "capturable", False):
+            raise L.MrgcnError("GraphedTrainStep needs ClipAdam(..., capturable=True)")
+        args = (model, forward_fn, idx, targets, optimizer, l1_lambda, l2_lambda)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                train_step(*args)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = train_step(*args)
+        self.warmup_steps = max(warmup, 1) + 1  # optimizer steps already taken (capture runs one)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss

@@ -277,3 +277,36 @@ def test_fused_layer_vs_oracle(N, R, B, K, F, hub):
         got = getattr(layer, k).grad.cpu().numpy()
         np.testing.assert_allclose(got, v, rtol=2e-4, atol=2e-5 * scale[k] + 1e-6, err_msg=k)
     np.testing.assert_allclose(X.grad.cpu().numpy(), dX, rtol=2e-4, atol=1e-5 * np.abs(dX).max())
+
+
+@pytest.mark.parametrize("name", ["rgcn_smoke_ft_b5_norm_f32", "rgcn_small_fl_b0_bias_ref_int8"])
+def test_graph_captured_epoch_equals_eager(name):
+    """hipGraph-captured train step (GraphedTrainStep, ClipAdam(capturable=True)): three warm-up
+    steps + three replays give the parameters of six eager steps (Adam's step counter and bias
+    corrections live on the device, so the replayed graph advances them)."""
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
+    c = util.load_case(name)
+    A = _adjacency(c, name)
+    fl = bool(c["meta.featureless"])
+    X = None if fl else torch.from_numpy(c["X"]).cuda()
+    idx = torch.from_numpy(c["labels_idx"]).cuda()
+    tgt = torch.from_numpy(c["labels_y"]).cuda()
+    states, losses = [], []
+    for graphed in (False, True):
+        model, _ = util.build_rgcn_from_case(c, "cuda")
+        util.load_state_from_case(model, c)
+        model = model.cuda()
+        opt = ClipAdam(list(model.parameters()), lr=0.01, max_norm=1.0, capturable=graphed)
+        if graphed:
+            step = GraphedTrainStep(model, lambda: model(X, A), idx, tgt, opt, warmup=3)
+            for _ in range(3):
+                loss = step()
+        else:
+            for _ in range(6):
+                loss = train_step(model, lambda: model(X, A), idx, tgt, opt)
+        torch.cuda.synchronize()
+        states.append({k: v.clone() for k, v in model.state_dict().items()})
+        losses.append(float(loss))
+    assert abs(losses[0] - losses[1]) <= 1e-5 * max(1.0, abs(losses[0]))
+    for k in states[0]:
+        torch.testing.assert_close(states[0][k], states[1][k], rtol=1e-5, atol=1e-6, msg=k)
