@@ -216,3 +216,57 @@ class MiniBatch(Batch):
         kinds = {str(d) for d in devices.values()}
         self.device = next(iter(devices.values())) if len(kinds) == 1 else "ambigious"
         return self
+
+
+# ---- batch structure built on the device -----------------------------------------------------------
+class DeviceCSR:
+    """The stacked adjacency's CSR arrays resident in HBM (uploaded once), for building mini-batches
+    without going back to scipy on the host every time batches are re-sampled."""
+
+    def __init__(self, A, device="cuda"):
+        self.shape = tuple(A.shape)
+        self.indptr = torch.from_numpy(np.ascontiguousarray(A.indptr, dtype=np.int64)).to(device)
+        self.indices = torch.from_numpy(np.ascontiguousarray(A.indices, dtype=np.int64)).to(device)
+        self.data = torch.from_numpy(np.ascontiguousarray(A.data, dtype=np.float32)).to(device)
+
+    def rows(self, sample_idx: torch.Tensor):
+        """COO (row-in-sample, global column, value) of the rows `sample_idx`, in the order
+        `A[sample_idx].nonzero()` has on the host (row-major, stored column order)."""
+        lo, hi = self.indptr[sample_idx], self.indptr[sample_idx + 1]
+        n = hi - lo
+        total = int(n.sum())
+        row = torch.repeat_interleave(torch.arange(sample_idx.numel(), device=n.device), n)
+        start = torch.cumsum(n, 0) - n
+        pos = torch.arange(total, device=n.device) - start[row] + lo[row]
+        return row, self.indices[pos], self.data[pos]
+
+
+class A_BatchDevice(A_Batch):
+    """`A_Batch` whose row slices and neighbour sets are produced on the GPU from a `DeviceCSR`
+    (gathers, `torch.unique`): same `row` / `neighbours` / `node_index` attributes, already tensors
+    on the device (as after `as_tensors_()` + `to(device)`), same contents as the host build."""
+
+    def __init__(self, A_dev: DeviceCSR, batch_idx, num_layers, value_mode="ref_int8"):
+        assert value_mode in VALUE_MODES
+        self.value_mode = value_mode
+        self.neighbours, self.row = [], []
+        self._a_idx = {}
+        dev = A_dev.indptr.device
+        self.device = dev
+        self.node_index = torch.as_tensor(np.asarray(batch_idx), dtype=torch.long, device=dev)
+        num_nodes = A_dev.shape[0]
+        sample = self.node_index
+        for _ in range(num_layers):
+            row, col, val = A_dev.rows(sample)
+            if value_mode == "ref_int8":
+                val = val.to(torch.int8)  # the boundary cast: truncation toward zero
+            self.row.append(torch.sparse_coo_tensor(torch.stack([row, col]), val, (sample.numel(), A_dev.shape[1])))
+            nb = torch.unique(col % num_nodes)  # sorted
+            self.neighbours.append(nb)
+            sample = nb
+
+    def as_tensors_(self):
+        return
+
+    def to(self, device):
+        return self if torch.device(device) == self.device else super().to(device)

@@ -121,3 +121,31 @@ def test_mrgcn_minibatch_boundary():
     batch.to(model.devices)
     logits = model(batch)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), g[tag + ".logits"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["ft_b3", "ft_b0_l3"])
+def test_device_built_batch_equals_host_built(tag):
+    """A_BatchDevice (gathers + torch.unique on the GPU) against the reference's goldens: same
+    neighbour sets, same COO of every row slice (indices, int8 values), same model output."""
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.models.rgcn import RGCN
+    g = np.load(GOLD)
+    _, A = util.load_graph("graph_small")
+    fl, B, bias, nl, hidden, classes, xw = [int(v) for v in g[tag + ".meta"]]
+    ab = mb.A_BatchDevice(mb.DeviceCSR(A), g["batch_idx"], nl)
+    for i in range(nl):
+        assert np.array_equal(ab.neighbours[i].cpu().numpy(), g[f"{tag}.neighbours_{i}"])
+        assert np.array_equal(ab.row[i]._indices().cpu().numpy(), g[f"{tag}.row_{i}.indices"])
+        assert np.array_equal(ab.row[i]._values().cpu().numpy(), g[f"{tag}.row_{i}.values"])
+    N = A.shape[0]
+    R = A.shape[1] // N
+    dims = [(xw if li == 0 else hidden, hidden if li < nl - 1 else classes) for li in range(nl)]
+    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li < nl - 1 else None) for li, (i, o) in enumerate(dims)]
+    model = RGCN(modules, R, N, B, 0.0, bool(fl), bool(bias), False)
+    model.load_state_dict({k[len(tag) + 6:]: torch.from_numpy(np.array(g[k])) for k in g.files
+                           if k.startswith(tag + ".init.")})
+    model = model.cuda()
+    X = torch.from_numpy(g[tag + ".X_full"]).cuda()[ab.neighbours[-1]]
+    logits = model(X, ab)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g[tag + ".logits"], rtol=1e-4, atol=1e-4)
