@@ -1,26 +1,33 @@
-"""MLP literal encoder with the reference's structure and initialisation
-(mrgcn/models/perceptron.py:6-46): `num_layers` blocks of Linear -> Dropout(inplace) -> ReLU
-whose widths step linearly from input_dim down to output_dim; every weight and bias is
-drawn from U(0, 1).  Dense and tiny: runs on the library GEMM (rocBLAS via nn.Linear)."""
+"""MLP literal encoder (numeric / boolean / temporal datatypes).  Structure and initialisation
+follow mrgcn/models/perceptron.py:6-46: `num_layers` blocks of Linear -> Dropout(inplace) -> ReLU
+whose widths step linearly from `input_dim` down to `output_dim`, every weight and bias drawn
+from U(0, 1) in parameter order (so the same seed gives the reference's values; state-dict keys
+`mlp.<3k>.weight|bias`).  Dense and tiny: library GEMM (rocBLAS through nn.Linear)."""
+import torch
 import torch.nn as nn
+
+
+def layer_widths(input_dim: int, output_dim: int, num_layers: int):
+    """Output width of every block: output_dim + k * ((input_dim - output_dim) // num_layers) for
+    k = num_layers - 1 ... 0."""
+    stride = (input_dim - output_dim) // num_layers
+    return [output_dim + k * stride for k in range(num_layers - 1, -1, -1)]
 
 
 class MLP(nn.Module):
     def __init__(self, input_dim, output_dim, num_layers=3, p_dropout=0.0, bias=True):
         super().__init__()
         self.input_dim, self.output_dim, self.p_dropout = input_dim, output_dim, p_dropout
-        step = (input_dim - output_dim) // num_layers
-        widths = [output_dim + k * step for k in range(num_layers - 1, -1, -1)]
-        blocks, fan_in = [], input_dim
-        for width in widths:
-            blocks += [nn.Linear(fan_in, width, bias), nn.Dropout(p=p_dropout, inplace=True), nn.ReLU()]
-            fan_in = width
-        self.mlp = nn.Sequential(*blocks)
+        dims = [input_dim] + layer_widths(input_dim, output_dim, num_layers)
+        self.mlp = nn.Sequential(*[
+            module for fan_in, fan_out in zip(dims, dims[1:])
+            for module in (nn.Linear(fan_in, fan_out, bias), nn.Dropout(p=p_dropout, inplace=True), nn.ReLU())])
         self.init()
+
+    @torch.no_grad()
+    def init(self):
+        for tensor in self.parameters():
+            tensor.uniform_(0.0, 1.0)
 
     def forward(self, X):
         return self.mlp(X)
-
-    def init(self):
-        for param in self.parameters():
-            nn.init.uniform_(param)
