@@ -117,7 +117,20 @@ __global__ __launch_bounds__(kMixFwdTB) void k_mix_fwd(const int32_t *__restrict
           }
           OT *m = M + (int64_t)pp[i] * ldM + o;
           if (accumulate) s += load_operand<OT>(m);
-          store_operand<OT>(m, live ? s : 0.f);
+          if constexpr (sizeof(OT) == 2) {
+            // bf16 rows: two features per 4-byte store (2-byte scattered stores were measured
+            // 30 % slower than the fp32 rows they replace).  Lanes o and o + 1 belong to the same
+            // node (FW is even), so they take this branch together.
+            const float mine = live ? s : 0.f;
+            const float next = __shfl_down(mine, 1, kWave);
+            if ((o & 1) == 0 && (FW & 1) == 0) {
+              *reinterpret_cast<uint32_t *>(m) = (uint32_t)f32_to_bf16(mine) | ((uint32_t)f32_to_bf16(next) << 16);
+            } else if (FW & 1) {
+              store_operand<OT>(m, mine);
+            }
+          } else {
+            store_operand<OT>(m, live ? s : 0.f);
+          }
         }
       }
     }
