@@ -121,6 +121,7 @@ struct mrgcn_plan {
   int32_t *relchunk_ptr = nullptr;  // [R+1] range of each relation inside relchunk_ids
   int32_t *relchunk_ids = nullptr;  // [n_relchunks] chunk ids grouped by relation
   int32_t n_relchunks = 0, max_relchunks = 0;
+  int32_t top_rel = -1;  // relation with the most compact columns (the identity block in the reference's layout)
   // split-row descriptors, one set per orientation
   int32_t *r_long_row = nullptr, *r_long_cptr = nullptr, *r_chunk_beg = nullptr, *r_chunk_end = nullptr,
           *r_chunk_row = nullptr;

@@ -460,6 +460,13 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
         end.push_back(std::min(b0 + rel_chunk, h_gptr[g + 1]));
       }
     }
+    {  // the relation with the most compact columns: k_mix_bwd_node keeps its dcomp row in registers
+      std::vector<int64_t> per_rel(R, 0);
+      for (int64_t g = 0; g < ngroups; ++g) per_rel[g % R] += h_gptr[g + 1] - h_gptr[g];
+      int64_t best = 0;
+      for (int64_t r = 0; r < R; ++r)
+        if (per_rel[r] > best) { best = per_rel[r]; p->top_rel = (int32_t)r; }
+    }
     std::vector<int32_t> cptr_rel(R + 1, 0), ids_by_rel;
     for (int64_t r = 0; r < R; ++r) {
       cptr_rel[r] = (int32_t)ids_by_rel.size();
