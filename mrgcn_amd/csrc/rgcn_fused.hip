@@ -994,9 +994,12 @@ int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, con
 #define NODE_GO(T)                                                                                        \
   do {                                                                                                    \
     auto kfn = k_mix_bwd_node<T, MODE, DCOMP>;                                                            \
-    if (lds > 48 * 1024)                                                                                  \
+    static size_t lds_allowed = 48 * 1024; /* per instantiation: raise the dynamic-LDS limit once */      \
+    if (lds > lds_allowed) {                                                                              \
       MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                         (int)lds));                                                       \
+      lds_allowed = lds;                                                                                  \
+    }                                                                                                     \
     kfn<<<dim3((unsigned)grid), dim3(kNodeTB), lds, s>>>(p->nptr, p->urel, dM, ldM, V, comp, N, R, B, F, dV, \
                                                          dcomp, dV_sumsq, ad, (int)p->top_rel);           \
   } while (0)
