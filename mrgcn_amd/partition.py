@@ -118,14 +118,31 @@ class _ReduceScatterRows(torch.autograd.Function):
         return all_gather_rows(g.contiguous(), ctx.group), None
 
 
+class _AllGatherRows(torch.autograd.Function):
+    """[S, F] own rows -> [world*S, F] all rows; backward: every rank's gradient w.r.t. all rows is
+    summed and each rank keeps its own rows (reduce-scatter)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return all_gather_rows(x.contiguous(), group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return reduce_scatter_rows(g.contiguous(), ctx.group), None
+
+
 # ---- the partitioned model ----------------------------------------------------------------------
 class PartitionedRGCN(nn.Module):
     """`RGCN` (models/rgcn.py) with node-partitioned layers.  `modules` as for RGCN.  Every
     rank constructs it with the same seed; `load_full_state` shards a reference-shaped state."""
 
     def __init__(self, modules, num_relations, num_nodes, num_bases, featureless, bias, part: NodePartition,
-                 group=None):
+                 group=None, link_prediction=False):
         super().__init__()
+        if link_prediction:  # DistMult relation embeddings (rgcn.py:55-61): small, replicated
+            self.relations = nn.Parameter(torch.empty((num_relations, modules[-1][1])))
+            nn.init.xavier_uniform_(self.relations)
         self.part, self.group = part, group
         self.num_nodes, self.num_relations, self.num_bases = num_nodes, num_relations, num_bases
         self.layers = nn.ModuleDict()
@@ -150,6 +167,8 @@ class PartitionedRGCN(nn.Module):
     @torch.no_grad()
     def load_full_state(self, state: dict):
         """`state`: an `RGCN.state_dict()` in the reference's shapes (keys layers.layer_<i>.<name>)."""
+        if "relations" in state and hasattr(self, "relations"):
+            self.relations.copy_(state["relations"].to(self.relations.device))
         for i, layer in enumerate(self.layers.values()):
             for name, p in layer.named_parameters():
                 full = state[f"layers.layer_{i}.{name}"].to(p.device)
@@ -230,6 +249,31 @@ def partitioned_train_step(model: PartitionedRGCN, X_local, idx_global, targets,
     Fn.clear_grad_sumsq()
     logits = model(X_local)
     local, total = partitioned_loss(logits, idx_global, targets, model.part, model.group)
+    optimizer.zero_grad(set_to_none=True)
+    local.backward()
+    model.allreduce_replicated_grads()
+    optimizer.step()
+    return total
+
+
+def partitioned_lp_step(model: PartitionedRGCN, X_local, triples, labels, optimizer):
+    """One link-prediction step on the partitioned encoder (BASELINE config 4 over several GPUs):
+    every rank computes the embeddings of its node range, the (small) embedding table is
+    all-gathered, each rank scores triples `rank::world`, and the decoder's gradient w.r.t. the
+    table returns to the owners by reduce-scatter.  `triples` [n, 3] / `labels` [n] are the full
+    batch (positives + negatives), identical on every rank.  Returns the mean BCE over all triples."""
+    from .tasks import link_prediction as lp
+    Fn.clear_grad_sumsq()
+    part, group = model.part, model.group
+    world, rank = part.world, part.rank
+    E = _AllGatherRows.apply(model(X_local), group)[: part.N]
+    n = triples.shape[0]
+    mine = torch.arange(rank, n, world, device=triples.device)
+    t = triples[mine]
+    sc = lp.score_distmult_bc((t[:, 0], t[:, 1], t[:, 2]), E, model.relations)
+    local = lp.binary_crossentropy(sc, labels[mine]) * (float(mine.numel()) / n) if mine.numel() else (E * 0.0).sum()
+    total = local.detach().clone()
+    all_reduce_sum_(total, group)
     optimizer.zero_grad(set_to_none=True)
     local.backward()
     model.allreduce_replicated_grads()

@@ -96,3 +96,72 @@ def test_partitioned_ranks_equal_single_gpu(world):
     for r in ranks:
         d = np.abs(out[r][3] - final["layers.layer_1.weight_F"].numpy())
         assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.045
+
+
+def _lp_problem():
+    from mrgcn_amd import synth
+    g = synth.make_graph("aifb", seed=4, scale=0.25, value_mode="ref_int8")
+    rng = np.random.default_rng(4)
+    N = g.num_nodes
+    n = 900
+    tr = np.stack([rng.integers(0, N, n), rng.integers(0, (g.num_relations - 1) // 2, n), rng.integers(0, N, n)], 1)
+    y = (rng.random(n) < 0.8).astype(np.float32)
+    mods = [(0, 12, "rgcn", torch.nn.ReLU())]
+    return g, tr.astype(np.int64), y, mods
+
+
+def _lp_worker(rank, world, port, state, out):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from mrgcn_amd.partition import NodePartition, PartitionedRGCN, partitioned_lp_step
+    from mrgcn_amd.train import ClipAdam
+    dist.init_process_group("gloo")
+    dev = torch.device("cuda:0")
+    g, tr, y, mods = _lp_problem()
+    N, R = g.num_nodes, g.num_relations
+    part = NodePartition(N, world, rank)
+    model = PartitionedRGCN(mods, R, N, 2, True, False, part, link_prediction=True).to(dev)
+    with torch.no_grad():
+        model.load_full_state(state)
+    model.build_plan(g.rows, g.cols, g.vals, dev)
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    opt.set_distributed(None, model.sharded_parameters())
+    t, yy = torch.from_numpy(tr).to(dev), torch.from_numpy(y).to(dev)
+    losses = [float(partitioned_lp_step(model, None, t, yy, opt)) for _ in range(3)]
+    out[rank] = (losses, model.relations.detach().cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_partitioned_link_prediction_equals_single_gpu():
+    """BASELINE config 4's shape of computation over two ranks: partitioned featureless encoder,
+    all-gathered embeddings, triples scored rank::world, decoder gradients reduce-scattered back."""
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.tasks import link_prediction as lp
+    from mrgcn_amd.train import ClipAdam
+    g, tr, y, mods = _lp_problem()
+    N, R = g.num_nodes, g.num_relations
+    torch.manual_seed(5)
+    model = RGCN(mods, R, N, 2, 0.0, True, False, True)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                (N, R * N)).cuda()
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    t, yy = torch.from_numpy(tr).cuda(), torch.from_numpy(y).cuda()
+    losses = []
+    for _ in range(3):
+        sc = lp.score_distmult_bc((t[:, 0], t[:, 1], t[:, 2]), model(None, A), model.relations)
+        loss = lp.binary_crossentropy(sc, yy)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_lp_worker, args=(2, _free_port(), state, out), nprocs=2, join=True)
+    for r in (0, 1):
+        np.testing.assert_allclose(out[r][0], losses, rtol=2e-4, atol=2e-5)
+        d = np.abs(out[r][1] - model.relations.detach().cpu().numpy())
+        assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.07
