@@ -259,7 +259,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: calls other threads make while this one captures (e.g. the process group's
+        # watchdog in a multi-rank job) do not invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = train_step(*args)
         self.warmup_steps = max(warmup, 1) + 1  # optimizer steps already taken (capture runs one)
 
