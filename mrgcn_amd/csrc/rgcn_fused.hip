@@ -983,7 +983,9 @@ int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, con
   if (MODE == 0) ok = ok && al16(dV);
   if (MODE == 2) ok = ok && al16(ad.p) && al16(ad.m) && al16(ad.v);
   if (!ok) return -1;
-  const int FT = (F + 3) / 4 * 4;
+  // register arrays of exactly F features for the hidden sizes of the BASELINE configs (10, 11):
+  // two padding features would cost a sixth of the pass's readlanes and FMAs
+  const int FT = (F == 10 || F == 11) ? F : (F + 3) / 4 * 4;
   static const int grid_mult = getenv("MRGCN_MIX_NODE_GRID") ? atoi(getenv("MRGCN_MIX_NODE_GRID")) : 1;
   int per_cu = (int)((160 * 1024) / (lds + 1024));
   if (per_cu < 1) per_cu = 1;
@@ -1006,6 +1008,8 @@ int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, con
   switch (FT) {
     case 4: NODE_GO(4); break;
     case 8: NODE_GO(8); break;
+    case 10: NODE_GO(10); break;
+    case 11: NODE_GO(11); break;
     case 12: NODE_GO(12); break;
     default: NODE_GO(16); break;
   }
