@@ -841,7 +841,12 @@ int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32
   hipStream_t s = (hipStream_t)stream;
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
-  const int FW = (int)ldM;  // the whole padded row is written (zeros past F)
+  // Columns F..ldM of M are padding that only the SpMM's 16-byte gathers touch, and their
+  // products land in accumulator lanes that are never stored (test: padding set to 1e30 does
+  // not leak): by default only the F real features are computed and written (a sixth fewer
+  // lanes and stores at F = 10, ld = 12); MRGCN_MIX_PAD=1 writes zeros there.
+  static const bool write_pad = getenv("MRGCN_MIX_PAD") && atoi(getenv("MRGCN_MIX_PAD")) != 0;
+  const int FW = write_pad ? (int)ldM : F;
   // node-major is the default: measured 2.7 ms vs 4.95 ms for the column-parallel form (AM shape)
   static const bool by_cols = getenv("MRGCN_MIX_COLS") && atoi(getenv("MRGCN_MIX_COLS")) != 0;
   // timing experiments only (wrong results): write rows in compact order instead of operand order
