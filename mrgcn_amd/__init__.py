@@ -11,7 +11,8 @@ __version__ = "0.1.0"
 
 def install_as_mrgcn():
     """Registers this package's modules under the reference's import names
-    (`mrgcn.layers.graph`, `mrgcn.models.rgcn`, `mrgcn.models.mrgcn`, `mrgcn.data.batch`)
+    (`mrgcn.layers.graph`, `mrgcn.models.{rgcn,mrgcn,perceptron,temporal_cnn}`, `mrgcn.data.batch`,
+    `mrgcn.data.io.tarball`)
     so that scripts written against the reference (`run.py:12-19`) import the MI355X
     implementations unchanged.  See INTEGRATION.md."""
     import importlib
@@ -22,9 +23,12 @@ def install_as_mrgcn():
         "mrgcn.layers.graph": "mrgcn_amd.layers.graph",
         "mrgcn.models.rgcn": "mrgcn_amd.models.rgcn",
         "mrgcn.models.mrgcn": "mrgcn_amd.models.mrgcn",
+        "mrgcn.models.perceptron": "mrgcn_amd.models.perceptron",
+        "mrgcn.models.temporal_cnn": "mrgcn_amd.models.temporal_cnn",
         "mrgcn.data.batch": "mrgcn_amd.data.batch",
+        "mrgcn.data.io.tarball": "mrgcn_amd.data.io.tarball",
     }
-    for pkg in ("mrgcn", "mrgcn.layers", "mrgcn.models", "mrgcn.data"):
+    for pkg in ("mrgcn", "mrgcn.layers", "mrgcn.models", "mrgcn.data", "mrgcn.data.io"):
         if pkg not in sys.modules:
             m = types.ModuleType(pkg)
             m.__path__ = []
@@ -36,3 +40,4 @@ def install_as_mrgcn():
         setattr(sys.modules[parent], leaf, mod)
     for pkg in ("mrgcn.layers", "mrgcn.models", "mrgcn.data"):
         setattr(sys.modules["mrgcn"], pkg.split(".")[1], sys.modules[pkg])
+    setattr(sys.modules["mrgcn.data"], "io", sys.modules["mrgcn.data.io"])
