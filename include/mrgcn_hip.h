@@ -211,6 +211,19 @@ int mrgcn_rel_transform_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64
                                 const float *X, int64_t ldX, int32_t K, const float *W, int32_t F,
                                 float *dX, int64_t lddX, float *dW, float *workspace,
                                 int64_t workspace_floats, void *stream);
+/* Same with a liveness byte per compact column (`col_live[c]` = 0: row c of dM is all zeros;
+ * nullable = every column live).  In a semi-supervised epoch only the columns that feed a row
+ * within reach of a labelled node carry gradient (autograd of graph.py:93-95 multiplies the
+ * zeros like everything else); dead columns add exact zeros to dW and dX and are skipped.  Results
+ * equal mrgcn_rel_transform_bwd_f32's.  `col_live` comes from mrgcn_rows_nonzero_f32(dM). */
+int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM,
+                                     const uint8_t *col_live, const float *X, int64_t ldX,
+                                     int32_t K, const float *W, int32_t F, float *dX, int64_t lddX,
+                                     float *dW, float *workspace, int64_t workspace_floats,
+                                     void *stream);
+/* flags[i] = 1 when X[i, 0:F] holds anything but (+-)0 — NaN counts — else 0. */
+int mrgcn_rows_nonzero_f32(const float *X, int64_t ld, int32_t F, int64_t nrows, uint8_t *flags,
+                           void *stream);
 
 /* ---- epoch kernels around the layers ----------------------------------------------
  * out = dY * (Y > 0): backward of the nn.ReLU between layers (rgcn.py:86-87) */

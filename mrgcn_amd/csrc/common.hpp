@@ -82,12 +82,12 @@ bool xform_mfma_fwd_supported(int K, int F);
 bool xform_mfma_dw_supported(int K, int F);
 int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
                    int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out, int64_t ldOut,
-                   hipStream_t s, bool out_bf16 = false);
+                   hipStream_t s, bool out_bf16 = false, const uint8_t *col_live = nullptr);
 int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, int64_t ldIn, int K,
                   const float *G, int64_t ldG, int F, float *dW, float *workspace,
-                  int64_t workspace_floats, hipStream_t s);
+                  int64_t workspace_floats, hipStream_t s, const uint8_t *col_live = nullptr);
 int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *dX, int64_t lddX,
-                hipStream_t s);
+                hipStream_t s, const uint8_t *col_live = nullptr);
 }  // namespace mrgcn
 
 struct mrgcn_plan {

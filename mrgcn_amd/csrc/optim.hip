@@ -59,6 +59,24 @@ __global__ void k_relu_bwd(const float *__restrict__ dY, const float *__restrict
       out[i] = Y[i] > 0.f ? dY[i] : 0.f;
 }
 
+// flags[i] = 1 when row i of X holds anything but zeros (NaN counts as something)
+__global__ void k_rows_nonzero(const float *__restrict__ X, int64_t ld, int F, int64_t nrows,
+                               uint8_t *__restrict__ flags, int vec_ok) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float *row = X + i * ld;
+    bool nz = false;
+    int q = 0;
+    if (vec_ok)
+      for (; q + 4 <= F; q += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(row + q);
+        nz |= (t.x != 0.f) | (t.y != 0.f) | (t.z != 0.f) | (t.w != 0.f);
+      }
+    for (; q < F; ++q) nz |= row[q] != 0.f;
+    flags[i] = nz ? 1 : 0;
+  }
+}
+
 // sum of squares -> double accumulator (one atomic per block)
 __global__ void k_sumsq(const float *__restrict__ x, int64_t n, double *__restrict__ accum) {
   const int64_t nv = n >> 2;
@@ -191,6 +209,17 @@ int mrgcn_relu_bwd_f32(const float *dY, const float *Y, int64_t n, float *out, v
   MRGCN_REQUIRE((((uintptr_t)dY | (uintptr_t)Y | (uintptr_t)out) & 15) == 0, "16-byte alignment");
   if (n == 0) return MRGCN_OK;
   k_relu_bwd<<<dim3(stream_grid(n >> 2)), dim3(kTB), 0, (hipStream_t)stream>>>(dY, Y, n, out);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_rows_nonzero_f32(const float *X, int64_t ld, int32_t F, int64_t nrows, uint8_t *flags,
+                           void *stream) {
+  MRGCN_REQUIRE(X && flags, "NULL");
+  MRGCN_REQUIRE(F > 0 && ld >= F, "F / ld");
+  if (nrows == 0) return MRGCN_OK;
+  const int vec_ok = (ld % 4 == 0) && (((uintptr_t)X & 15) == 0);
+  k_rows_nonzero<<<dim3(stream_grid(nrows)), dim3(kTB), 0, (hipStream_t)stream>>>(X, ld, F, nrows, flags, vec_ok);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -448,7 +448,8 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
                                  hipMemcpyDeviceToHost, s));
     MRGCN_HIP_TRY(hipStreamSynchronize(s));
     int rel_chunk = kRelChunk;
-    if (const char *e = getenv("MRGCN_REL_CHUNK")) rel_chunk = atoi(e) > 15 ? atoi(e) : rel_chunk;  // experiments
+    if (const char *e = getenv("MRGCN_REL_CHUNK"))  // experiments; the live-column lists hold kRelChunk
+      rel_chunk = (atoi(e) > 15 && atoi(e) <= kRelChunk) ? atoi(e) : rel_chunk;
     std::vector<int32_t> rel, beg, end;
     std::vector<std::vector<int32_t>> by_rel(R);
     for (int64_t g = 0; g < ngroups; ++g) {

@@ -42,25 +42,75 @@ __device__ __forceinline__ f32x4 load4_fast(const float *p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Live columns of one relation chunk.  In the backward of a semi-supervised epoch most rows of
+// dM are exact zeros (only columns that feed a row within reach of a label receive gradient:
+// ~10 % in layer 0 of the AM shape, < 1 % in layer 1); `col_live` (one byte per compact column,
+// written by the transposed product that made dM) names the others.  The block keeps, in chunk
+// order, the compact id and the input row of its live columns in LDS and sweeps only those.
+// 256 threads; returns the count (block uniform).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int compact_live_columns(int32_t beg, int32_t end, const int32_t *__restrict__ rperm,
+                                                    const int32_t *__restrict__ rin_idx,
+                                                    const uint8_t *__restrict__ col_live, int32_t *s_cid,
+                                                    int32_t *s_rin, int32_t *s_cnt /* [4] */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int base = 0;
+  for (int32_t r0 = beg; r0 < end; r0 += 256) {
+    const int32_t e = r0 + (int32_t)threadIdx.x;
+    const int32_t c = e < end ? rperm[e] : -1;
+    const bool live = c >= 0 && col_live[c] != 0;
+    const uint64_t bal = __ballot(live);
+    if (lane == 0) s_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int n = s_cnt[w];
+      if (w < wv) off += n;
+      tot += n;
+    }
+    if (live) {
+      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+      s_cid[pos] = c;
+      s_rin[pos] = rin_idx ? rin_idx[e] : c;
+    }
+    base += tot;
+    __syncthreads();
+  }
+  return base;
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward: Out[o(c), 0:ldOut] = [ In[i(c), 0:K] . Wm[r][0:K][0:F] | 0 ]   (write only)
 //   TRANS_W = false: Wm[r][k][n] = W[(r*K + k)*F + n]        (weights stored [R][K][F])
 //   TRANS_W = true : Wm[r][k][n] = W[(r*F + n)*K + k]        (weights stored [R][F][K])
 //   rin_idx / rout_idx: nullable int32 [ncols] in RELATION-MAJOR order (aligned with rperm):
 //   input / output row of each column; null = the compact id rperm[e] itself
 // ---------------------------------------------------------------------------------------------
-template <int NT, bool TRANS_W, int KS, typename OT>
+//   LIVE: `col_live` names the columns whose input row is not all zeros; only those are
+//   multiplied and only their output rows are written (rin_idx / rout_idx must be null: the
+//   backward dX pass, In = dM) — the consumer (k_segment_sum) skips the same columns.
+template <int NT, bool TRANS_W, int KS, typename OT, bool LIVE = false>
 __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
     const int32_t *__restrict__ relchunk_rel, const int32_t *__restrict__ relchunk_beg,
     const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
     const int32_t *__restrict__ rin_idx, const int32_t *__restrict__ rout_idx,
     const float *__restrict__ In, int64_t ldIn, int K, const float *__restrict__ W, int F,
-    OT *__restrict__ Out, int64_t ldOut) {
+    OT *__restrict__ Out, int64_t ldOut, const uint8_t *__restrict__ col_live) {
   extern __shared__ float WsT[];  // [NT*16][KP]: n-major, k contiguous, zero padded
   const int ksteps = (K + 15) >> 4;
   const int KP = ksteps * 16 + 4;  // +4 floats: rows start on different banks
   const int chunk = blockIdx.x;
   const int r = relchunk_rel[chunk];
-  const int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
+  int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
+  int32_t *s_cid = reinterpret_cast<int32_t *>(WsT + NT * 16 * KP);  // LIVE: [kRelChunk] | [kRelChunk] | [4]
+  if constexpr (LIVE) {
+    const int n = compact_live_columns(beg, end, rperm, nullptr, col_live, s_cid, s_cid + kRelChunk,
+                                       s_cid + 2 * kRelChunk);
+    if (n == 0) return;  // block uniform
+    beg = 0;
+    end = n;
+  }
   for (int t = threadIdx.x; t < NT * 16 * KP; t += blockDim.x) {
     const int n = t / KP, k = t - n * KP;
     float w = 0.f;
@@ -77,9 +127,13 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
   auto fetch = [&](int32_t e, int32_t &valid, int32_t &rin, int32_t &rout) {
     valid = e < end ? 1 : -1;
     const int32_t ee = e < end ? e : beg;
-    const int32_t c = (rin_idx && rout_idx) ? 0 : rperm[ee];
-    rin = rin_idx ? rin_idx[ee] : c;
-    rout = rout_idx ? rout_idx[ee] : c;
+    if constexpr (LIVE) {
+      rin = rout = s_cid[ee];
+    } else {
+      const int32_t c = (rin_idx && rout_idx) ? 0 : rperm[ee];
+      rin = rin_idx ? rin_idx[ee] : c;
+      rout = rout_idx ? rout_idx[ee] : c;
+    }
   };
   int32_t n_valid, n_rin, n_rout;
   fetch(beg + wv * 16 + m, n_valid, n_rin, n_rout);
@@ -139,17 +193,23 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxTQ = 4;  // K <= 256
 
-template <int TQ, int U>
+template <int TQ, int U, bool LIVE>
 __global__ __launch_bounds__(256) void k_xform_mfma_dw(
     const int32_t *__restrict__ relchunk_rel, const int32_t *__restrict__ relchunk_beg,
     const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
     const int32_t *__restrict__ rin_idx, const float *__restrict__ In, int64_t ldIn, int K,
     const float *__restrict__ G, int64_t ldG, int F, float *__restrict__ dW,
-    float *__restrict__ slab) {
+    float *__restrict__ slab, const uint8_t *__restrict__ col_live) {
   extern __shared__ float dWs[];  // [4 waves][K*F]: every wave stores its own partial tile set
   const int chunk = blockIdx.x;
   const int r = relchunk_rel[chunk];
-  const int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
+  int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
+  int32_t *s_cid = reinterpret_cast<int32_t *>(dWs + 4 * K * F);  // LIVE: [kRelChunk] | [kRelChunk] | [4]
+  int32_t *s_rin = s_cid + kRelChunk;
+  if constexpr (LIVE) {  // columns whose dM row is all zeros add nothing: sweep the others only
+    end = compact_live_columns(beg, end, rperm, rin_idx, col_live, s_cid, s_rin, s_rin + kRelChunk);
+    beg = 0;
+  }
   const int ntq = (K + 63) >> 6;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m = lane & 15, kq = lane >> 4;
@@ -163,10 +223,15 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int32_t e = t0 + 4 * u + kq;
-      const int32_t ee = e < end ? e : beg;
-      const int32_t c = rperm[ee];
-      n_cid[u] = e < end ? c : -1;
-      n_rin[u] = rin_idx ? rin_idx[ee] : c;
+      if constexpr (LIVE) {
+        n_cid[u] = e < end ? s_cid[e] : -1;
+        n_rin[u] = e < end ? s_rin[e] : 0;
+      } else {
+        const int32_t ee = e < end ? e : beg;
+        const int32_t c = rperm[ee];
+        n_cid[u] = e < end ? c : -1;
+        n_rin[u] = rin_idx ? rin_idx[ee] : c;
+      }
     }
   };
   fetch(beg + wv * 4 * U);
@@ -260,8 +325,10 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const int32_t *__restrict__ r
 }
 
 // dX[j, 0:K] = sum of the rows Z[nptr[j] .. nptr[j+1]) (Z in compact (j, r) order)
+template <bool LIVE>
 __global__ void k_segment_sum(const int32_t *__restrict__ nptr, const float *__restrict__ Z, int64_t ldZ,
-                              int64_t N, int K, float *__restrict__ dX, int64_t lddX) {
+                              int64_t N, int K, float *__restrict__ dX, int64_t lddX,
+                              const uint8_t *__restrict__ col_live) {
   const int64_t total = N * K;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
@@ -270,6 +337,12 @@ __global__ void k_segment_sum(const int32_t *__restrict__ nptr, const float *__r
     const int32_t c0 = nptr[j], c1 = nptr[j + 1];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int32_t c = c0;
+    if constexpr (LIVE) {  // rows of dead columns were never written
+      for (; c < c1; ++c)
+        if (col_live[c]) s0 += Z[(int64_t)c * ldZ + i];
+      dX[j * lddX + i] = s0;
+      continue;
+    }
     for (; c + 4 <= c1; c += 4) {
       s0 += Z[(int64_t)c * ldZ + i];
       s1 += Z[(int64_t)(c + 1) * ldZ + i];
@@ -287,28 +360,53 @@ __global__ void k_segment_sum(const int32_t *__restrict__ nptr, const float *__r
 bool xform_mfma_fwd_supported(int K, int F) { return K <= kMaxKSteps * 16 && F <= kMaxNT * 16; }
 bool xform_mfma_dw_supported(int K, int F) { return K <= kMaxTQ * 64 && F <= 16 && (size_t)4 * K * F * 4 <= 64 * 1024; }
 
+constexpr size_t kLiveLds = (2 * (size_t)kRelChunk + 4) * sizeof(int32_t);
+
 int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
                    int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out, int64_t ldOut,
-                   hipStream_t s, bool out_bf16) {
+                   hipStream_t s, bool out_bf16, const uint8_t *col_live) {
   if (p->n_relchunks == 0) return MRGCN_OK;
   int NT = (int)((ldOut < 64 ? ldOut : 64) + 15) / 16;  // tiles that cover the padded row
   if (NT < (F + 15) / 16) NT = (F + 15) / 16;
   const int ksteps = (K + 15) / 16;
-  const size_t lds = (size_t)NT * 16 * (ksteps * 16 + 4) * sizeof(float);
+  size_t lds = (size_t)NT * 16 * (ksteps * 16 + 4) * sizeof(float);
+  if (col_live) {  // backward dX pass over the live columns only
+    if (!trans_w || rin_idx || rout_idx || out_bf16 || ksteps > 4) {
+      set_error("xform_mfma_fwd: col_live is for the dX pass (transposed weights, K <= 64)");
+      return MRGCN_ERR_UNSUPPORTED;
+    }
+    lds += kLiveLds;
+#define XF_LIVE(N_)                                                                                        \
+  do {                                                                                                     \
+    if (ksteps <= 1)                                                                                       \
+      k_xform_mfma_fwd<N_, true, 1, float, true><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(             \
+          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, nullptr, nullptr, In, ldIn, K, W,   \
+          F, (float *)Out, ldOut, col_live);                                                               \
+    else                                                                                                   \
+      k_xform_mfma_fwd<N_, true, 4, float, true><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(             \
+          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, nullptr, nullptr, In, ldIn, K, W,   \
+          F, (float *)Out, ldOut, col_live);                                                               \
+  } while (0)
+    switch (NT) { case 1: XF_LIVE(1); break; case 2: XF_LIVE(2); break;
+                  case 3: XF_LIVE(3); break; default: XF_LIVE(4); break; }
+#undef XF_LIVE
+    MRGCN_HIP_TRY(hipGetLastError());
+    return MRGCN_OK;
+  }
 #define XF_GO3(N_, T_, O_)                                                                              \
   do {                                                                                                  \
     if (ksteps <= 1)                                                                                    \
       k_xform_mfma_fwd<N_, T_, 1, O_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                     \
           p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn,     \
-          K, W, F, (O_ *)Out, ldOut);                                                                   \
+          K, W, F, (O_ *)Out, ldOut, nullptr);                                                          \
     else if (ksteps <= 4)                                                                               \
       k_xform_mfma_fwd<N_, T_, 4, O_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                     \
           p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn,     \
-          K, W, F, (O_ *)Out, ldOut);                                                                   \
+          K, W, F, (O_ *)Out, ldOut, nullptr);                                                          \
     else                                                                                                \
       k_xform_mfma_fwd<N_, T_, kMaxKSteps, O_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(            \
           p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn,     \
-          K, W, F, (O_ *)Out, ldOut);                                                                   \
+          K, W, F, (O_ *)Out, ldOut, nullptr);                                                          \
   } while (0)
 #define XF_GO(N_, T_)                                                  \
   do {                                                                 \
@@ -330,23 +428,31 @@ int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *r
 
 int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, int64_t ldIn, int K,
                   const float *G, int64_t ldG, int F, float *dW, float *workspace,
-                  int64_t workspace_floats, hipStream_t s) {
+                  int64_t workspace_floats, hipStream_t s, const uint8_t *col_live) {
   if (p->n_relchunks == 0) return MRGCN_OK;
-  const size_t lds = (size_t)4 * K * F * sizeof(float);
+  size_t lds = (size_t)4 * K * F * sizeof(float);
+  if (col_live && lds + kLiveLds <= 64 * 1024) lds += kLiveLds;
+  else col_live = nullptr;  // no room for the list: every column is swept (same result)
   float *slab = (workspace && workspace_floats >= (int64_t)p->n_relchunks * K * F) ? workspace : nullptr;
   // Unroll U (columns in flight per wave = 4 U) and tile count are chosen for registers, i.e. for
   // waves per SIMD — the pass waits on the gathered input rows (PMC: profiles/r01_xform_pmc.md).
   // AM shape, same run: K = 10: U = 8 / 4 / 2 -> 1.42 / 1.20 / 1.11 ms (with the dX half);
   // K = 155: <4,4> 1.92 ms, <3,4> 1.65 ms, <3,2> 1.62 ms.
-  if (K <= 64)
-    k_xform_mfma_dw<1, 2><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
-        p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F, dW, slab);
-  else if (K <= 192)
-    k_xform_mfma_dw<3, 2><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
-        p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F, dW, slab);
-  else
-    k_xform_mfma_dw<kMaxTQ, 4><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(
-        p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F, dW, slab);
+#define DW_GO(TQ_, U_)                                                                                   \
+  do {                                                                                                   \
+    if (col_live)                                                                                        \
+      k_xform_mfma_dw<TQ_, U_, true><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                       \
+          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F,  \
+          dW, slab, col_live);                                                                           \
+    else                                                                                                 \
+      k_xform_mfma_dw<TQ_, U_, false><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                      \
+          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F,  \
+          dW, slab, nullptr);                                                                            \
+  } while (0)
+  if (K <= 64) DW_GO(1, 2);
+  else if (K <= 192) DW_GO(3, 2);
+  else DW_GO(kMaxTQ, 4);
+#undef DW_GO
   MRGCN_HIP_TRY(hipGetLastError());
   if (slab) {
     const int n_seg_max = (p->max_relchunks + kDwSeg - 1) / kDwSeg;
@@ -360,12 +466,15 @@ int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, 
 }
 
 int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *dX, int64_t lddX,
-                hipStream_t s) {
+                hipStream_t s, const uint8_t *col_live) {
   int64_t work = p->num_nodes * K;
   int64_t blocks = (work + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  k_segment_sum<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX);
+  if (col_live)
+    k_segment_sum<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, col_live);
+  else
+    k_segment_sum<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, nullptr);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

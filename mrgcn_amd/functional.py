@@ -71,6 +71,8 @@ def pop_deferred(param: torch.Tensor):
 # measured on the AM shape: 14.6 ms with the overlap vs 14.3 ms without (every one of these
 # kernels already saturates the memory system on its own), so it is opt-in
 _OVERLAP = os.environ.get("MRGCN_OVERLAP", "0") != "0"
+# Skip the compact columns without gradient in the transform backward (exact: they add zeros).
+_LIVE_COLS = os.environ.get("MRGCN_LIVE_COLS", "1") != "0"
 _SIDE_STREAMS: dict = {}
 
 
@@ -209,6 +211,13 @@ class _RgcnLayer(torch.autograd.Function):
         ld = (F + 3) // 4 * 4
         dM = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
         plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)
+        # one byte per compact column: does it carry any gradient?  (semi-supervised training: few do)
+        live = None
+        if has_X and _LIVE_COLS:
+            live = torch.empty((plan.ncols,), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                L.check(lib.mrgcn_rows_nonzero_f32(dM.data_ptr(), ld, F, plan.ncols, live.data_ptr(), s),
+                        "mrgcn_rows_nonzero_f32")
         d_wI = d_comp = dX = dW = None
         # The consumers of dM are independent of each other and bound by different resources
         # (dV: HBM writes, dcomp: vector-memory issue, dW/dX: matrix cores + gathers), so the
@@ -257,16 +266,17 @@ class _RgcnLayer(torch.autograd.Function):
                                                                         int(need_dW)))
                         if nws > 0:
                             ws = torch.empty((nws,), dtype=torch.float32, device=dev)
-                        L.check(lib.mrgcn_rel_transform_bwd_f32(
-                            plan.handle, dM.data_ptr(), ld, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
+                        L.check(lib.mrgcn_rel_transform_bwd_live_f32(
+                            plan.handle, dM.data_ptr(), ld, live.data_ptr() if live is not None else 0,
+                            X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
                             dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0,
                             ws.data_ptr() if ws is not None else 0, ws.numel() if ws is not None else 0,
-                            side.cuda_stream), "mrgcn_rel_transform_bwd_f32")
+                            side.cuda_stream), "mrgcn_rel_transform_bwd_live_f32")
                 if overlap:
                     main.wait_stream(side)
-                    for t in (dX, dW, ws, dM):  # allocated / used on `side`: keep the allocator honest
+                    for t in (dX, dW, ws, dM, live):  # allocated / used on `side`: keep the allocator honest
                         if t is not None:
-                            t.record_stream(main if t is not dM else side)
+                            t.record_stream(side if (t is dM or t is live) else main)
         return None, None, d_wI, d_comp, dX, dW, dbias, None, None
 
 

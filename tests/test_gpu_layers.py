@@ -310,3 +310,64 @@ def test_graph_captured_epoch_equals_eager(name):
     assert abs(losses[0] - losses[1]) <= 1e-5 * max(1.0, abs(losses[0]))
     for k in states[0]:
         torch.testing.assert_close(states[0][k], states[1][k], rtol=1e-5, atol=1e-6, msg=k)
+
+
+@pytest.mark.parametrize("zero_frac", [0.0, 0.5, 0.93, 1.0])
+@pytest.mark.parametrize("N,R,B,F,hub", [(900, 7, 40, 10, 500), (333, 5, 3, 11, 0), (640, 9, 64, 16, 200)])
+def test_basis_mix_backward_with_rows_without_gradient(N, R, B, F, hub, zero_frac):
+    """dV / dcomp through the C ABI when most rows of dM are exact zeros — the state of a
+    semi-supervised epoch (only columns within two hops of a label receive gradient), which the
+    wave-per-node kernel detects and skips.  Includes a node with more than 64 columns, negative
+    zeros, and the squared norm that clip_grad_norm_ consumes."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphPlan
+    rng = np.random.default_rng(N + B + int(zero_frac * 100))
+    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, 1, F, 5 * N, hub)
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals),
+                                 (N, R * N)).cuda()
+    plan = GraphPlan(At, N, R)
+    urel, unode = plan.export(L.ARR_UREL).astype(np.int64), plan.export(L.ARR_UNODE).astype(np.int64)
+    nc, ld = plan.ncols, (F + 3) // 4 * 4
+    dM = rng.standard_normal((nc, ld)).astype(np.float32)
+    dead = rng.random(nc) < zero_frac
+    dM[dead] = 0.0
+    dM[dead & (rng.random(nc) < 0.3)] = -0.0
+    V = rng.standard_normal((B, N, F)).astype(np.float32)
+    comp = rng.standard_normal((R, B)).astype(np.float32)
+
+    d64 = dM[:, :F].astype(np.float64)
+    want_dV = np.zeros((B, N, F))
+    np.add.at(want_dV, (slice(None), unode), comp.astype(np.float64)[urel].T[:, :, None] * d64[None])
+    want_dc = np.zeros((R, B))
+    np.add.at(want_dc, urel, np.einsum("cf,bcf->cb", d64, V.astype(np.float64)[:, unode]))
+
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    dMt, Vt, ct = (torch.from_numpy(x).cuda() for x in (dM, V, comp))
+    dV = torch.full((B, N, F), 7.0, device="cuda")
+    dc = torch.full((R, B), 7.0, device="cuda")
+    sq = torch.zeros((), dtype=torch.float64, device="cuda")
+    L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dMt.data_ptr(), ld, Vt.data_ptr(), ct.data_ptr(), B, F,
+                                        dV.data_ptr(), dc.data_ptr(), sq.data_ptr(), s))
+    np.testing.assert_allclose(dV.cpu().numpy(), want_dV, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dc.cpu().numpy(), want_dc, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
+    if zero_frac == 1.0:
+        assert not dV.any() and not dc.any() and float(sq) == 0.0
+
+    # norm-only form (deferred update): same dcomp and norm, no dV
+    dc2 = torch.full((R, B), 7.0, device="cuda")
+    sq.zero_()
+    L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dMt.data_ptr(), ld, Vt.data_ptr(), ct.data_ptr(), B, F,
+                                        0, dc2.data_ptr(), sq.data_ptr(), s))
+    np.testing.assert_allclose(dc2.cpu().numpy(), want_dc, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
+
+    # a NaN anywhere in a row keeps that row alive
+    if zero_frac > 0 and dead.any():
+        c = int(np.flatnonzero(dead)[0])
+        dMt[c, F - 1] = float("nan")
+        L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dMt.data_ptr(), ld, Vt.data_ptr(), ct.data_ptr(), B, F,
+                                            dV.data_ptr(), dc.data_ptr(), 0, s))
+        assert torch.isnan(dV[:, int(unode[c]), F - 1]).all()
+        assert torch.isnan(dc[int(urel[c])]).all()
