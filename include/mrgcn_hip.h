@@ -215,12 +215,24 @@ int mrgcn_rel_transform_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64
  * nullable = every column live).  In a semi-supervised epoch only the columns that feed a row
  * within reach of a labelled node carry gradient (autograd of graph.py:93-95 multiplies the
  * zeros like everything else); dead columns add exact zeros to dW and dX and are skipped.  Results
- * equal mrgcn_rel_transform_bwd_f32's.  `col_live` comes from mrgcn_rows_nonzero_f32(dM). */
+ * equal mrgcn_rel_transform_bwd_f32's.  `col_live` comes from mrgcn_spmm_transposed_live_f32
+ * (or mrgcn_rows_nonzero_f32(dM)). */
 int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM,
                                      const uint8_t *col_live, const float *X, int64_t ldX,
                                      int32_t K, const float *W, int32_t F, float *dX, int64_t lddX,
                                      float *dW, float *workspace, int64_t workspace_floats,
                                      void *stream);
+/* Y[c, 0:F] = sum_i A'[i, c] * D[i, 0:F] — mrgcn_spmm_f32 on MRGCN_VIEW_TRANSPOSED (the autograd
+ * of torch.mm(A, .), graph.py:75,:95) for an operand whose rows are mostly zeros, as the output
+ * gradient of a layer is when few nodes are labelled: rows of D that hold only zeros are not
+ * gathered (their products are zeros; rows of up to 32 entries are bitwise those of mrgcn_spmm_f32).
+ * `scratch` (mrgcn_spmm_transposed_live_scratch(plan) bytes, 16-byte aligned) holds the liveness
+ * of the rows of D; `col_live` ([ncols] bytes) receives 0 for rows of Y that are certainly all
+ * zeros, 1 otherwise — the input of mrgcn_rel_transform_bwd_live_f32. */
+int64_t mrgcn_spmm_transposed_live_scratch(const mrgcn_plan_t *plan); /* bytes */
+int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const float *D, int64_t ldD, int32_t F,
+                                   float *Y, int64_t ldY, uint8_t *scratch, uint8_t *col_live,
+                                   void *stream);
 /* flags[i] = 1 when X[i, 0:F] holds anything but (+-)0 — NaN counts — else 0. */
 int mrgcn_rows_nonzero_f32(const float *X, int64_t ld, int32_t F, int64_t nrows, uint8_t *flags,
                            void *stream);

@@ -345,6 +345,94 @@ __global__ __launch_bounds__(256) void k_spmm_tiny(SparseView v, const float *__
   }
 }
 
+// ---- transposed product with mostly-zero operand rows ----------------------------------------
+// dM = A'^T dY in the backward of a semi-supervised epoch: dY is the gradient at a layer's output,
+// and only rows within reach of a labelled node hold anything (AM shape: 5565 of 1.67 M rows in
+// layer 0, the 1000 labelled rows in layer 1).  One thread per output row (= compact column;
+// 87 % have a single entry): it looks its entries' rows up in `row_live` (a byte per operand
+// row: 1.7 MB, cache resident) and gathers only the live ones — for nine columns in ten that is
+// no gather at all, just the zero row and the flag.  Entries are added in the order k_spmm adds
+// them, the skipped ones would have added a * 0: bitwise the same result.  Rows longer than
+// kLongThreshold stay with the split-row path of k_spmm (flagged live without looking).
+template <int FT>
+__global__ __launch_bounds__(256) void k_spmm_t_live(SparseView v, const float *__restrict__ D, int64_t ldD,
+                                                     int F, float *__restrict__ Y, int64_t ldY,
+                                                     const uint8_t *__restrict__ row_live,
+                                                     uint8_t *__restrict__ col_live, int packed_rows,
+                                                     int dbg) {
+  __shared__ __align__(16) float s_out[256 * FT];
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = row < v.rows;
+  int32_t b = 0, n = 0;
+  if (valid) {
+    b = v.ptr[row];
+    n = v.ptr[row + 1] - b;
+  }
+  const bool long_row = n > kLongThreshold;  // the split-row blocks of k_spmm write it afterwards
+  if (long_row) n = 0;
+  if (dbg & 4) n = 0;
+  float acc[FT];
+#pragma unroll
+  for (int o = 0; o < FT; ++o) acc[o] = 0.f;
+  bool any = false;
+  // a wave runs as long as its longest row: look eight entries up per round trip
+  constexpr int kLook = 8;
+  for (int32_t e0 = b; e0 < b + n; e0 += kLook) {
+    int32_t ii[kLook];
+    bool lv[kLook];
+#pragma unroll
+    for (int k = 0; k < kLook; ++k) ii[k] = (e0 + k < b + n) ? v.idx[e0 + k] : -1;
+    bool some = false;
+#pragma unroll
+    for (int k = 0; k < kLook; ++k) {
+      lv[k] = (ii[k] >= 0 && !(dbg & 1)) ? row_live[ii[k]] != 0 : false;
+      some |= lv[k];
+    }
+    if (!some) continue;
+    any = true;
+#pragma unroll
+    for (int k = 0; k < kLook; ++k) {
+      if (!lv[k]) continue;
+      const float a = v.val[e0 + k];
+      const float *d = D + (int64_t)ii[k] * ldD;
+#pragma unroll
+      for (int f0 = 0; f0 < FT; f0 += 4) {
+        if (f0 < F) {
+          float x[4];
+          load4_tail_safe(d, f0, F, x);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[f0 + q] = fmaf(a, x[q], acc[f0 + q]);
+        }
+      }
+    }
+  }
+  if (valid) col_live[row] = (long_row || any) ? 1 : 0;
+  if (dbg & 2) return;
+  if (packed_rows) {
+    // ldY == roundup(F, 4), 16-byte aligned: the 64 rows of a wave are one contiguous run of Y;
+    // through LDS so that every store instruction writes whole cache lines
+    const int F4 = (int)ldY;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *mine = s_out + (size_t)threadIdx.x * F4;
+#pragma unroll
+    for (int f0 = 0; f0 < FT; f0 += 4)
+      if (f0 < F4) *reinterpret_cast<float4 *>(mine + f0) = make_float4(acc[f0], acc[f0 + 1], acc[f0 + 2], acc[f0 + 3]);
+    __syncthreads();
+    const int64_t wrow0 = (int64_t)blockIdx.x * blockDim.x + 64 * wv;
+    const int64_t left = v.rows - wrow0;
+    const int nrows = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
+    const int total4 = nrows * F4 / 4;
+    const float4 *src = reinterpret_cast<const float4 *>(s_out + (size_t)64 * wv * F4);
+    float4 *dst = reinterpret_cast<float4 *>(Y + wrow0 * ldY);
+    for (int q = lane; q < total4; q += 64) dst[q] = src[q];
+  } else if (valid && !long_row) {
+    float *y = Y + row * ldY;
+#pragma unroll
+    for (int o = 0; o < FT; ++o)
+      if (o < F) y[o] = acc[o];
+  }
+}
+
 // ---- rows of several chunks: one wave per long row adds its partials in a fixed order ----
 __global__ __launch_bounds__(256) void k_spmm_finalize(SparseView v, const float *__restrict__ partials,
                                                        int ldP, int F, float *__restrict__ Y,
@@ -517,6 +605,65 @@ int dispatch_bf16(const SparseView &v, const uint16_t *D, int64_t ldD, int64_t a
 
 }  // namespace
 }  // namespace mrgcn
+
+// flags[i] = 1 when X[i, 0:F] holds anything but zeros (optim.hip)
+extern "C" int mrgcn_rows_nonzero_f32(const float *X, int64_t ld, int32_t F, int64_t nrows, uint8_t *flags,
+                                      void *stream);
+
+extern "C" int64_t mrgcn_spmm_transposed_live_scratch(const mrgcn_plan_t *plan) {
+  return plan ? (plan->num_rows + 15) / 16 * 16 : 0;
+}
+
+extern "C" int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const float *D, int64_t ldD,
+                                              int32_t F, float *Y, int64_t ldY, uint8_t *scratch,
+                                              uint8_t *col_live, void *stream) {
+  using namespace mrgcn;
+  MRGCN_REQUIRE(plan, "plan is NULL");
+  MRGCN_REQUIRE(F > 0 && ldD >= F && ldY >= F, "F / leading dimensions");
+  MRGCN_REQUIRE(D && Y && scratch && col_live, "NULL operand");
+  hipStream_t s = (hipStream_t)stream;
+  SparseView v = plan->view(MRGCN_VIEW_TRANSPOSED);
+  if (F > 16) {  // wide layers: the general product, then the flags from its result
+    int rc = mrgcn_spmm_f32(plan, MRGCN_VIEW_TRANSPOSED, D, ldD, F, Y, ldY, nullptr, 0, nullptr, stream);
+    if (rc != MRGCN_OK) return rc;
+    return mrgcn_rows_nonzero_f32(Y, ldY, F, v.rows, col_live, stream);
+  }
+  uint8_t *row_live = scratch;
+  int rc = mrgcn_rows_nonzero_f32(D, ldD, F, plan->num_rows, row_live, stream);
+  if (rc != MRGCN_OK) return rc;
+  if (v.rows > 0) {
+    static const int dbg = getenv("MRGCN_DEBUG_TL") ? atoi(getenv("MRGCN_DEBUG_TL")) : 0;
+    const int F4 = (F + 3) / 4 * 4;
+    const int packed = (ldY == F4) && (((uintptr_t)Y) % 16 == 0);  // rows packed: coalesced stores
+    const dim3 grid((unsigned)((v.rows + 255) / 256));
+    if (F <= 4) k_spmm_t_live<4><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed, dbg);
+    else if (F <= 8) k_spmm_t_live<8><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed, dbg);
+    else if (F <= 12) k_spmm_t_live<12><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed, dbg);
+    else k_spmm_t_live<16><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed, dbg);
+    MRGCN_HIP_TRY(hipGetLastError());
+  }
+  // long rows: the split-row blocks of the general kernel only (its short-row blocks are not launched)
+  const int64_t chunk_blocks = ((int64_t)v.n_chunks + 3) / 4;
+  if (chunk_blocks > 0) {
+    const bool store_vec_ok = (ldY % 4 == 0) && (((uintptr_t)Y) % 16 == 0);
+    // lanes per row as mrgcn_spmm_f32 picks them for 16-byte loads: the same summation order
+#define LIVE_LONG(G_)                                                                               \
+  k_spmm<G_, 4, true, float><<<dim3((unsigned)chunk_blocks), dim3(256), 0, s>>>(                    \
+      v, D, ldD, F, Y, ldY, nullptr, 0, nullptr, store_vec_ok ? 1 : 0, plan->partials, kWsFeatures, \
+      (int)chunk_blocks, 0, 0, 0)
+    if (F <= 4) LIVE_LONG(1);
+    else if (F <= 8) LIVE_LONG(2);
+    else LIVE_LONG(4);
+#undef LIVE_LONG
+    MRGCN_HIP_TRY(hipGetLastError());
+    if (v.n_multi > 0) {
+      k_spmm_finalize<<<dim3((unsigned)(((int64_t)v.n_long + 3) / 4)), dim3(256), 0, s>>>(
+          v, plan->partials, kWsFeatures, F, Y, ldY, nullptr, 0, nullptr);
+      MRGCN_HIP_TRY(hipGetLastError());
+    }
+  }
+  return MRGCN_OK;
+}
 
 extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uint16_t *D, int64_t ldD,
                                int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu,

@@ -210,14 +210,19 @@ class _RgcnLayer(torch.autograd.Function):
         # dM = A'^T dY over touched columns only, plain compact order (its consumers are node-major)
         ld = (F + 3) // 4 * 4
         dM = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
-        plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)
-        # one byte per compact column: does it carry any gradient?  (semi-supervised training: few do)
         live = None
-        if has_X and _LIVE_COLS:
+        if _LIVE_COLS:
+            # with few labelled nodes most rows of dY are zeros: gather the others only, and keep one
+            # byte per compact column: does it carry any gradient?
             live = torch.empty((plan.ncols,), dtype=torch.uint8, device=dev)
+            row_live = torch.empty((int(lib.mrgcn_spmm_transposed_live_scratch(plan.handle)),),
+                                   dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
-                L.check(lib.mrgcn_rows_nonzero_f32(dM.data_ptr(), ld, F, plan.ncols, live.data_ptr(), s),
-                        "mrgcn_rows_nonzero_f32")
+                L.check(lib.mrgcn_spmm_transposed_live_f32(
+                    plan.handle, dY.data_ptr(), dY.stride(0), F, dM.data_ptr(), ld, row_live.data_ptr(),
+                    live.data_ptr(), s), "mrgcn_spmm_transposed_live_f32")
+        else:
+            plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)
         d_wI = d_comp = dX = dW = None
         # The consumers of dM are independent of each other and bound by different resources
         # (dV: HBM writes, dcomp: vector-memory issue, dW/dX: matrix cores + gathers), so the

@@ -170,3 +170,86 @@ def test_spmm_autograd_functions(skewed):
     torch.testing.assert_close(Y, Y2, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(D.grad, D2.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(bias.grad, b2.grad, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("F", [1, 3, 10, 11, 16, 20])
+@pytest.mark.parametrize("zero_frac", [0.0, 0.9, 0.997, 1.0])
+def test_transposed_product_with_zero_operand_rows(skewed, F, zero_frac):
+    """mrgcn_spmm_transposed_live_f32 (the backward product when few rows of dY carry gradient):
+    bitwise the result of the general transposed product, and a flag per compact column that is
+    0 only where the result row is all zeros.  Hub columns (> 32 entries) take the split-row path."""
+    from mrgcn_amd import _lib as L
+    plan, A, ref, rng = skewed
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    dY = rng.standard_normal((A.shape[0], F)).astype(np.float32)
+    dead = rng.random(A.shape[0]) < zero_frac
+    dY[dead] = 0.0
+    dY[dead & (rng.random(A.shape[0]) < 0.5)] = -0.0
+    dYg = torch.from_numpy(dY).cuda()
+    want = plan.spmm(L.VIEW_TRANSPOSED, dYg)  # [ncols, F]
+    for ld in sorted({F, (F + 3) // 4 * 4}):
+        got = torch.full((plan.ncols, ld), 9.0, device="cuda")
+        row_live = torch.empty(int(lib.mrgcn_spmm_transposed_live_scratch(plan.handle)), dtype=torch.uint8,
+                               device="cuda")
+        col_live = torch.full((plan.ncols,), 7, dtype=torch.uint8, device="cuda")
+        L.check(lib.mrgcn_spmm_transposed_live_f32(plan.handle, dYg.data_ptr(), F, F, got.data_ptr(), ld,
+                                                   row_live.data_ptr(), col_live.data_ptr(), s))
+        short_t = torch.from_numpy(np.diff(ref["cptr"]) <= 32).cuda()
+        assert torch.equal(got[:, :F][short_t], want[short_t]), f"ld={ld}"
+        torch.testing.assert_close(got[:, :F], want, rtol=1e-5, atol=1e-5)  # split rows: order may differ
+        if F <= 16:  # (wider layers run the general product and never touch the scratch)
+            np.testing.assert_array_equal(row_live[:plan.num_rows].cpu().numpy(),
+                                          (~dead).astype(np.uint8) if zero_frac else 1)
+        cl = col_live.cpu().numpy()
+        assert set(np.unique(cl)) <= {0, 1}
+        nz = (want != 0).any(1).cpu().numpy()
+        assert not (nz & (cl == 0)).any()          # a column with gradient is never flagged dead
+        if F <= 16:                                # flag = "some contributing row is live"
+            csc = abs(sp.csc_matrix(A)[:, ref["ulcol"]])
+            reach = (csc.T @ (~dead).astype(np.float64)) > 0 if zero_frac else np.ones(plan.ncols, bool)
+            short = np.diff(ref["cptr"]) <= 32
+            np.testing.assert_array_equal(cl[short], reach[short].astype(np.uint8))
+            assert (cl[~short] == 1).all()
+    # NaN rows are live
+    dYg[0, F - 1] = float("nan")
+    row_live = torch.empty(plan.num_rows, dtype=torch.uint8, device="cuda")
+    L.check(lib.mrgcn_rows_nonzero_f32(dYg.data_ptr(), F, F, plan.num_rows, row_live.data_ptr(), s))
+    assert int(row_live[0]) == 1
+
+
+@pytest.mark.parametrize("K,F,need_dX", [(7, 10, True), (155, 10, False), (10, 11, True), (40, 33, True),
+                                         (200, 16, True)])
+@pytest.mark.parametrize("live_frac", [0.0, 0.08, 1.0])
+def test_transform_backward_over_live_columns(skewed, K, F, need_dX, live_frac):
+    """mrgcn_rel_transform_bwd_live_f32 == mrgcn_rel_transform_bwd_f32 when the rows of dM that
+    the flags call dead are zeros (dW: MFMA accumulation order differs -> 1e-5 relative)."""
+    from mrgcn_amd import _lib as L
+    plan, A, ref, rng = skewed
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    N, R = plan.num_nodes, plan.num_relations
+    ld = (F + 3) // 4 * 4
+    dM = rng.standard_normal((plan.ncols, ld)).astype(np.float32)
+    live = rng.random(plan.ncols) < live_frac
+    dM[~live] = 0.0
+    X = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
+    W = torch.from_numpy(rng.standard_normal((R, K, F)).astype(np.float32)).cuda()
+    dMg = torch.from_numpy(dM).cuda()
+    liveg = torch.from_numpy(live.astype(np.uint8)).cuda()
+    nws = int(lib.mrgcn_rel_transform_bwd_workspace(plan.handle, K, F, int(need_dX), 1))
+    outs = []
+    for flags in (0, liveg.data_ptr()):
+        ws = torch.full((max(nws, 1),), float("nan"), device="cuda")  # dead rows of Z must never be read
+        dX = torch.full((N, K), 5.0, device="cuda")
+        dW = torch.full((R, K, F), 5.0, device="cuda")
+        L.check(lib.mrgcn_rel_transform_bwd_live_f32(plan.handle, dMg.data_ptr(), ld, flags, X.data_ptr(), K, K,
+                                                     W.data_ptr(), F, dX.data_ptr() if need_dX else 0, K,
+                                                     dW.data_ptr(), ws.data_ptr(), nws, s))
+        outs.append((dX.cpu().numpy(), dW.cpu().numpy()))
+    (dX0, dW0), (dX1, dW1) = outs
+    np.testing.assert_allclose(dW1, dW0, rtol=1e-5, atol=1e-5 * (np.abs(dW0).max() + 1e-30))
+    if need_dX:
+        np.testing.assert_allclose(dX1, dX0, rtol=1e-5, atol=1e-5 * (np.abs(dX0).max() + 1e-30))
+    if live_frac == 0.0:
+        assert not dW1.any() and (not need_dX or not dX1.any())
