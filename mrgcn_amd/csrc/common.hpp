@@ -54,7 +54,7 @@ struct SparseView {
   const int32_t *long_cptr = nullptr;  // [n_long+1] chunk range of each long row
   const int32_t *chunk_beg = nullptr;  // [n_chunks] first entry
   const int32_t *chunk_end = nullptr;  // [n_chunks] one past last entry
-  const int32_t *chunk_row = nullptr;  // [n_chunks] row id when the row is this single chunk, else -1
+  const int32_t *chunk_row = nullptr;  // [n_chunks] row id when the row is this single chunk, else -(row + 2)
 };
 
 }  // namespace mrgcn

@@ -224,7 +224,7 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
   for (int32_t s = b, c = c0; s < e; s += chunk, ++c) {
     chunk_beg[c] = s;
     chunk_end[c] = min(s + chunk, e);
-    chunk_row[c] = (e - b <= chunk) ? (int32_t)i : -1;
+    chunk_row[c] = (e - b <= chunk) ? (int32_t)i : -((int32_t)i + 2);  // < 0: one of several chunks of row -x - 2
   }
 }
 

@@ -108,14 +108,19 @@ __device__ __forceinline__ void gather_fma(const DT *Dq, int64_t ldD, int32_t c,
 // round trips per few entries).  Both paths therefore first pull *all* indices and values of
 // their row / chunk into registers with coalesced loads (one round trip), then hand them to the
 // gathering lanes with cross-lane reads and issue the gathers back to back.
-template <int G, int VEC, bool TAIL, typename DT>
+// LIVE (split-row blocks only): `op_live` flags the operand rows that hold anything but zeros and
+// `out_live` the output rows that receive any of them; dead entries are not gathered (they
+// add a * 0), chunks of dead output rows store zeros.
+template <int G, int VEC, bool TAIL, typename DT, bool LIVE = false>
 __global__ __launch_bounds__(256) void k_spmm(SparseView v, const DT *__restrict__ D, int64_t ldD,
                                               int F, float *__restrict__ Y, int64_t ldY,
                                               const float *__restrict__ bias, int relu,
                                               const int32_t *__restrict__ out_index,
                                               int store_vec_ok, float *__restrict__ partials,
                                               int ldP, int chunk_blocks, int64_t short_blocks,
-                                              int64_t xcd_per, int min_len) {
+                                              int64_t xcd_per, int min_len,
+                                              const uint8_t *__restrict__ op_live = nullptr,
+                                              const uint8_t *__restrict__ out_live = nullptr) {
   constexpr int SLOTS = kWave / G;
   const int lane = threadIdx.x & (kWave - 1);
   const int slot = lane / G, q = lane % G;
@@ -132,7 +137,11 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const DT *__restrict
     const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     if (chunk >= v.n_chunks) return;
     const int32_t b = v.chunk_beg[chunk];
-    const int32_t n = v.chunk_end[chunk] - b;
+    int32_t n = v.chunk_end[chunk] - b;
+    if constexpr (LIVE) {
+      const int32_t cr = v.chunk_row[chunk];
+      if (!out_live[cr >= 0 ? cr : -cr - 2]) n = 0;  // wave uniform: nothing live reaches this row
+    }
     constexpr int T = kChunk / kWave;  // staged registers per lane
     int32_t ci[T];
     float ca[T];
@@ -143,6 +152,24 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const DT *__restrict
       ca[t] = (m < n) ? v.val[b + m] : 0.f;
     }
     constexpr int UPT = kWave / SLOTS;  // = G steps of SLOTS entries per staged register
+    if constexpr (LIVE) {
+      // the flags of the staged entries, one look-up per register; only live entries are gathered
+      // (same slots, same order as below: identical sums)
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        if (t * kWave >= n) break;  // wave uniform
+        const int32_t m = t * kWave + lane;
+        const int lv = (m < n) ? (int)op_live[ci[t]] : 0;
+        if (!__any(lv)) continue;
+        for (int u = 0; u < UPT; ++u) {
+          const int src = u * SLOTS + slot;
+          const int32_t c = __shfl(ci[t], src, kWave);
+          const float a = __shfl(ca[t], src, kWave);
+          const int on = __shfl(lv, src, kWave);
+          if (on) gather_fma<VEC, TAIL, DT>(Dq, ldD, c, a, active, acc, nvalid);
+        }
+      }
+    } else
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       if (t * kWave >= n) break;  // wave uniform
@@ -354,12 +381,62 @@ __global__ __launch_bounds__(256) void k_spmm_tiny(SparseView v, const float *__
 // no gather at all, just the zero row and the flag.  Entries are added in the order k_spmm adds
 // them, the skipped ones would have added a * 0: bitwise the same result.  Rows longer than
 // kLongThreshold stay with the split-row path of k_spmm (flagged live without looking).
+// Pass 1 — which operand rows are live, and which compact columns do they touch.  One thread per
+// row of D: the flag; then the wave walks the (few) live rows among its 64 and sets the byte of
+// every compact column in them (`ccol`: the compact column of each entry, row-major order).
+// Plain byte stores of the same value: no atomics.  Rows longer than kLongThreshold are left to
+// k_long_rows_mark.  `col_live` was zeroed before.
+__global__ __launch_bounds__(256) void k_rows_live_mark(const float *__restrict__ D, int64_t ldD, int F,
+                                                        int64_t nrows, const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ ccol,
+                                                        uint8_t *__restrict__ row_live,
+                                                        uint8_t *__restrict__ col_live,
+                                                        int32_t *__restrict__ n_live) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool nz = false;
+  if (i < nrows) {
+    const float *row = D + i * ldD;
+    for (int q = 0; q < F; ++q) nz |= row[q] != 0.f;
+    row_live[i] = nz ? 1 : 0;
+  }
+  if (n_live) {
+    const uint64_t m = __ballot(nz);
+    if (lane == 0 && m) atomicAdd(n_live, (int32_t)__popcll(m));
+  }
+  int32_t b = 0, n = 0;
+  if (nz) {
+    b = rowptr[i];
+    n = rowptr[i + 1] - b;
+  }
+  uint64_t todo = __ballot(nz && n <= kLongThreshold);
+  while (todo) {
+    const int L = __ffsll((unsigned long long)todo) - 1;
+    todo &= todo - 1;
+    const int32_t bb = __shfl(b, L, kWave), nn = __shfl(n, L, kWave);
+    if (lane < nn) col_live[ccol[bb + lane]] = 1;
+  }
+}
+
+// the same for the split rows: one wave per chunk (<= kChunk entries) of a live long row
+__global__ __launch_bounds__(256) void k_long_rows_mark(SparseView rv, const int32_t *__restrict__ ccol,
+                                                        const uint8_t *__restrict__ row_live,
+                                                        uint8_t *__restrict__ col_live) {
+  const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int lane = threadIdx.x & 63;
+  if (c >= rv.n_chunks) return;
+  const int32_t cr = rv.chunk_row[c];
+  if (!row_live[cr >= 0 ? cr : -cr - 2]) return;
+  for (int32_t e = rv.chunk_beg[c] + lane; e < rv.chunk_end[c]; e += kWave) col_live[ccol[e]] = 1;
+}
+
+// Pass 2 — one thread per output row (= compact column); dead columns store their zero row and
+// are done, live ones gather their live entries.
 template <int FT>
 __global__ __launch_bounds__(256) void k_spmm_t_live(SparseView v, const float *__restrict__ D, int64_t ldD,
                                                      int F, float *__restrict__ Y, int64_t ldY,
                                                      const uint8_t *__restrict__ row_live,
-                                                     uint8_t *__restrict__ col_live, int packed_rows,
-                                                     int dbg) {
+                                                     const uint8_t *__restrict__ col_live, int packed_rows) {
   __shared__ __align__(16) float s_out[256 * FT];
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = row < v.rows;
@@ -369,12 +446,10 @@ __global__ __launch_bounds__(256) void k_spmm_t_live(SparseView v, const float *
     n = v.ptr[row + 1] - b;
   }
   const bool long_row = n > kLongThreshold;  // the split-row blocks of k_spmm write it afterwards
-  if (long_row) n = 0;
-  if (dbg & 4) n = 0;
+  if (long_row || !valid || !col_live[row]) n = 0;
   float acc[FT];
 #pragma unroll
   for (int o = 0; o < FT; ++o) acc[o] = 0.f;
-  bool any = false;
   // a wave runs as long as its longest row: look eight entries up per round trip
   constexpr int kLook = 8;
   for (int32_t e0 = b; e0 < b + n; e0 += kLook) {
@@ -385,11 +460,10 @@ __global__ __launch_bounds__(256) void k_spmm_t_live(SparseView v, const float *
     bool some = false;
 #pragma unroll
     for (int k = 0; k < kLook; ++k) {
-      lv[k] = (ii[k] >= 0 && !(dbg & 1)) ? row_live[ii[k]] != 0 : false;
+      lv[k] = (ii[k] >= 0) ? row_live[ii[k]] != 0 : false;
       some |= lv[k];
     }
     if (!some) continue;
-    any = true;
 #pragma unroll
     for (int k = 0; k < kLook; ++k) {
       if (!lv[k]) continue;
@@ -406,8 +480,6 @@ __global__ __launch_bounds__(256) void k_spmm_t_live(SparseView v, const float *
       }
     }
   }
-  if (valid) col_live[row] = (long_row || any) ? 1 : 0;
-  if (dbg & 2) return;
   if (packed_rows) {
     // ldY == roundup(F, 4), 16-byte aligned: the 64 rows of a wave are one contiguous run of Y;
     // through LDS so that every store instruction writes whole cache lines
@@ -616,30 +688,41 @@ extern "C" int64_t mrgcn_spmm_transposed_live_scratch(const mrgcn_plan_t *plan) 
 
 extern "C" int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const float *D, int64_t ldD,
                                               int32_t F, float *Y, int64_t ldY, uint8_t *scratch,
-                                              uint8_t *col_live, void *stream) {
+                                              uint8_t *col_live, int32_t *live_rows, void *stream) {
   using namespace mrgcn;
   MRGCN_REQUIRE(plan, "plan is NULL");
   MRGCN_REQUIRE(F > 0 && ldD >= F && ldY >= F, "F / leading dimensions");
   MRGCN_REQUIRE(D && Y && scratch && col_live, "NULL operand");
   hipStream_t s = (hipStream_t)stream;
   SparseView v = plan->view(MRGCN_VIEW_TRANSPOSED);
+  if (live_rows) MRGCN_HIP_TRY(hipMemsetAsync(live_rows, 0, sizeof(int32_t), s));
   if (F > 16) {  // wide layers: the general product, then the flags from its result
     int rc = mrgcn_spmm_f32(plan, MRGCN_VIEW_TRANSPOSED, D, ldD, F, Y, ldY, nullptr, 0, nullptr, stream);
     if (rc != MRGCN_OK) return rc;
+    if (live_rows) MRGCN_HIP_TRY(hipMemsetAsync(live_rows, 0xff, sizeof(int32_t), s));  // -1: not counted
     return mrgcn_rows_nonzero_f32(Y, ldY, F, v.rows, col_live, stream);
   }
   uint8_t *row_live = scratch;
-  int rc = mrgcn_rows_nonzero_f32(D, ldD, F, plan->num_rows, row_live, stream);
-  if (rc != MRGCN_OK) return rc;
+  MRGCN_HIP_TRY(hipMemsetAsync(col_live, 0, (size_t)v.rows, s));
+  if (plan->num_rows > 0 && v.rows > 0) {
+    k_rows_live_mark<<<dim3((unsigned)((plan->num_rows + 255) / 256)), dim3(256), 0, s>>>(
+        D, ldD, F, plan->num_rows, plan->rowptr, plan->ccol, row_live, col_live, live_rows);
+    MRGCN_HIP_TRY(hipGetLastError());
+    SparseView rv = plan->view(MRGCN_VIEW_COMPACT);
+    if (rv.n_chunks > 0) {
+      const int64_t waves = rv.n_chunks;
+      k_long_rows_mark<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s>>>(rv, plan->ccol, row_live, col_live);
+      MRGCN_HIP_TRY(hipGetLastError());
+    }
+  }
   if (v.rows > 0) {
-    static const int dbg = getenv("MRGCN_DEBUG_TL") ? atoi(getenv("MRGCN_DEBUG_TL")) : 0;
     const int F4 = (F + 3) / 4 * 4;
     const int packed = (ldY == F4) && (((uintptr_t)Y) % 16 == 0);  // rows packed: coalesced stores
     const dim3 grid((unsigned)((v.rows + 255) / 256));
-    if (F <= 4) k_spmm_t_live<4><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed, dbg);
-    else if (F <= 8) k_spmm_t_live<8><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed, dbg);
-    else if (F <= 12) k_spmm_t_live<12><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed, dbg);
-    else k_spmm_t_live<16><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed, dbg);
+    if (F <= 4) k_spmm_t_live<4><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed);
+    else if (F <= 8) k_spmm_t_live<8><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed);
+    else if (F <= 12) k_spmm_t_live<12><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed);
+    else k_spmm_t_live<16><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed);
     MRGCN_HIP_TRY(hipGetLastError());
   }
   // long rows: the split-row blocks of the general kernel only (its short-row blocks are not launched)
@@ -648,9 +731,9 @@ extern "C" int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const fl
     const bool store_vec_ok = (ldY % 4 == 0) && (((uintptr_t)Y) % 16 == 0);
     // lanes per row as mrgcn_spmm_f32 picks them for 16-byte loads: the same summation order
 #define LIVE_LONG(G_)                                                                               \
-  k_spmm<G_, 4, true, float><<<dim3((unsigned)chunk_blocks), dim3(256), 0, s>>>(                    \
+  k_spmm<G_, 4, true, float, true><<<dim3((unsigned)chunk_blocks), dim3(256), 0, s>>>(              \
       v, D, ldD, F, Y, ldY, nullptr, 0, nullptr, store_vec_ok ? 1 : 0, plan->partials, kWsFeatures, \
-      (int)chunk_blocks, 0, 0, 0)
+      (int)chunk_blocks, 0, 0, 0, row_live, col_live)
     if (F <= 4) LIVE_LONG(1);
     else if (F <= 8) LIVE_LONG(2);
     else LIVE_LONG(4);

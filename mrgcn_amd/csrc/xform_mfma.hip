@@ -354,6 +354,33 @@ __global__ void k_segment_sum(const int32_t *__restrict__ nptr, const float *__r
   }
 }
 
+// The same with liveness flags, K <= 16: one thread per node.  Nearly every node has no live
+// column (layer 1 of a semi-supervised epoch: the 1-hop neighbourhood of the labelled nodes):
+// it reads its flag bytes and stores a zero row.
+template <int KT>
+__global__ void k_segment_sum_live(const int32_t *__restrict__ nptr, const float *__restrict__ Z, int64_t ldZ,
+                                   int64_t N, int K, float *__restrict__ dX, int64_t lddX,
+                                   const uint8_t *__restrict__ col_live) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    float acc[KT];
+#pragma unroll
+    for (int i = 0; i < KT; ++i) acc[i] = 0.f;
+    const int32_t c1 = nptr[j + 1];
+    for (int32_t c = nptr[j]; c < c1; ++c) {
+      if (!col_live[c]) continue;
+      const float *z = Z + (int64_t)c * ldZ;
+#pragma unroll
+      for (int i = 0; i < KT; ++i)
+        if (i < K) acc[i] += z[i];
+    }
+    float *o = dX + j * lddX;
+#pragma unroll
+    for (int i = 0; i < KT; ++i)
+      if (i < K) o[i] = acc[i];
+  }
+}
+
 }  // namespace
 
 // ---- launchers used by the C ABI entry points in rgcn_fused.hip -------------------------------
@@ -471,7 +498,14 @@ int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *
   int64_t blocks = (work + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  if (col_live)
+  if (col_live && K <= 16) {
+    int64_t nb = (p->num_nodes + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (K <= 8)
+      k_segment_sum_live<8><<<dim3((unsigned)nb), dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, col_live);
+    else
+      k_segment_sum_live<16><<<dim3((unsigned)nb), dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, col_live);
+  } else if (col_live)
     k_segment_sum<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, col_live);
   else
     k_segment_sum<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, nullptr);

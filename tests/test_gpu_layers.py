@@ -371,3 +371,40 @@ def test_basis_mix_backward_with_rows_without_gradient(N, R, B, F, hub, zero_fra
                                             dV.data_ptr(), dc.data_ptr(), 0, s))
         assert torch.isnan(dV[:, int(unode[c]), F - 1]).all()
         assert torch.isnan(dc[int(urel[c])]).all()
+
+
+def test_backward_is_the_same_on_the_sparse_and_the_general_transposed_product():
+    """The layer's backward picks mrgcn_spmm_transposed_live_f32 while few rows of dY are live
+    and the general product otherwise (functional._LiveGauge); both must give the same gradients.
+    Dense dY: the first call takes the sparse path (nothing known yet), the second the general one;
+    sparse dY (few 'labelled' rows): both take the sparse path."""
+    from mrgcn_amd import functional as Fn
+    from mrgcn_amd.layers.graph import GraphConvolution
+    from mrgcn_amd.plan import plan_of
+    N, R, B, K, F = 1200, 6, 5, 9, 10
+    rng = np.random.default_rng(5)
+    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, K, F, 6 * N, 400)
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    plan = plan_of(At, N, R)
+    torch.manual_seed(0)
+    layer = GraphConvolution(K, F, R, N, num_bases=B, bias=True, input_layer=True, featureless=False).cuda()
+    X = torch.randn(N, K, device="cuda", requires_grad=True)
+    for labelled in (N, 7):
+        w = torch.zeros(N, F, device="cuda")
+        w[torch.randperm(N, device="cuda")[:labelled]] = torch.randn(labelled, F, device="cuda")
+        grads, paths = [], []
+        Fn._GAUGES.clear()  # a fresh start: once on the general product the count is only refreshed every 32 calls
+        for _ in range(3):
+            layer.zero_grad(); X.grad = None
+            Y = layer._forward_fused(X, plan, relu=False)
+            gauge = Fn._live_gauge(plan, F, False, X.device)
+            before = int(gauge.host[0])
+            paths.append(before < 0 or before <= 0.25 * N)
+            (Y * w).sum().backward()
+            torch.cuda.synchronize()
+            grads.append([p.grad.clone() for p in layer.parameters() if p.grad is not None] + [X.grad.clone()])
+        # the choice lags one step behind the data
+        assert paths == ([True, False, False] if labelled == N else [True, True, True]), paths
+        for g in grads[1:]:
+            for a, b in zip(grads[0], g):
+                torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)

@@ -193,8 +193,10 @@ def test_transposed_product_with_zero_operand_rows(skewed, F, zero_frac):
         row_live = torch.empty(int(lib.mrgcn_spmm_transposed_live_scratch(plan.handle)), dtype=torch.uint8,
                                device="cuda")
         col_live = torch.full((plan.ncols,), 7, dtype=torch.uint8, device="cuda")
+        n_live = torch.full((1,), 77, dtype=torch.int32, device="cuda")
         L.check(lib.mrgcn_spmm_transposed_live_f32(plan.handle, dYg.data_ptr(), F, F, got.data_ptr(), ld,
-                                                   row_live.data_ptr(), col_live.data_ptr(), s))
+                                                   row_live.data_ptr(), col_live.data_ptr(), n_live.data_ptr(), s))
+        assert int(n_live) == (int((~dead).sum()) if F <= 16 else -1)
         short_t = torch.from_numpy(np.diff(ref["cptr"]) <= 32).cuda()
         assert torch.equal(got[:, :F][short_t], want[short_t]), f"ld={ld}"
         torch.testing.assert_close(got[:, :F], want, rtol=1e-5, atol=1e-5)  # split rows: order may differ
@@ -208,9 +210,7 @@ def test_transposed_product_with_zero_operand_rows(skewed, F, zero_frac):
         if F <= 16:                                # flag = "some contributing row is live"
             csc = abs(sp.csc_matrix(A)[:, ref["ulcol"]])
             reach = (csc.T @ (~dead).astype(np.float64)) > 0 if zero_frac else np.ones(plan.ncols, bool)
-            short = np.diff(ref["cptr"]) <= 32
-            np.testing.assert_array_equal(cl[short], reach[short].astype(np.uint8))
-            assert (cl[~short] == 1).all()
+            np.testing.assert_array_equal(cl, reach.astype(np.uint8))
     # NaN rows are live
     dYg[0, F - 1] = float("nan")
     row_live = torch.empty(plan.num_rows, dtype=torch.uint8, device="cuda")

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--which", default="mix_fwd,mix_fwd_add,mix_bwd,xf_fwd0,xf_fwd1,xf_bwd0,xf_bwd1,spmm,spmm_t10,spmm_t11,adam")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--ldm", type=int, default=16)
+    ap.add_argument("--dy-zero-frac", type=float, default=0.997,
+                    help="fraction of dY rows set to zeros for spmm_tl10 (the AM epoch: 0.997 / 0.9994)")
     ap.add_argument("--dm-zero-frac", type=float, default=0.0,
                     help="fraction of dM rows set to exact zeros (the AM epoch has ~0.9)")
     a = ap.parse_args()
@@ -62,6 +64,11 @@ def main():
     ws = torch.empty((nws,), device=dev)
     P, G_, M_, V_ = (torch.randn((B * N * F,), device=dev) for _ in range(4))
     coef = torch.ones((), device=dev)
+    dYz = dY10.clone()
+    if a.dy_zero_frac > 0:
+        dYz[torch.rand(N, device=dev) < a.dy_zero_frac] = 0
+    scratch = torch.empty(int(lib.mrgcn_spmm_transposed_live_scratch(h)), dtype=torch.uint8, device=dev)
+    clive = torch.empty(nc, dtype=torch.uint8, device=dev)
     sq = torch.zeros((), device=dev, dtype=torch.float64)
 
     def chk(rc):
@@ -73,6 +80,7 @@ def main():
         "mix_bwd": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), dcomp.data_ptr(), 0, s)),
         "mix_bwd_sq": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, V.data_ptr(), comp.data_ptr(), B, F, 0, dcomp.data_ptr(), sq.data_ptr(), s)),
         "mix_bwd_adam": lambda: chk(lib.mrgcn_basis_mix_bwd_adam_f32(h, dM.data_ptr(), 12, comp.data_ptr(), B, F, P.data_ptr(), M_.data_ptr(), V_.abs_().data_ptr(), 0.01, 0.9, 0.999, 1e-8, 0.0, 1, coef.data_ptr(), s)),
+        "spmm_tl10": lambda: chk(lib.mrgcn_spmm_transposed_live_f32(h, dYz.data_ptr(), 10, 10, dM.data_ptr(), 12, scratch.data_ptr(), clive.data_ptr(), 0, s)),
         "xf_fwd0": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, X.data_ptr(), K, K, W0.data_ptr(), F, M2.data_ptr(), 12, 0, s)),
         "xf_fwd1": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, H.data_ptr(), F, F, W1.data_ptr(), C, M.data_ptr(), ld, 1, s)),
         "xf_bwd0": lambda: chk(lib.mrgcn_rel_transform_bwd_f32(h, dM.data_ptr(), 12, X.data_ptr(), K, K, W0.data_ptr(), F, 0, K, dW0.data_ptr(), ws.data_ptr(), nws, s)),
