@@ -22,27 +22,26 @@ def spmm_bytes(rows, ncols, F):
     return NNZ * 8 + (rows + 1) * 4 + ncols * F * 4 + rows * F * 4
 
 
-ALG = {  # kernel-name prefix -> [(selector on grid size or None, label, bytes)]
+ALG = {  # kernel-name prefix -> (label, bytes)
     "mrgcn::k_adam<false>": ("Adam on weight_I: 7 streams x 4 B x B*N*F0", 7 * 4 * B * N * F0),
     "mrgcn::k_mix_fwd<40, float>": ("V read once + addend read + M written + 3 index arrays",
                              4 * B * N * F0 + 2 * NCOLS * LD * 4 + NCOLS * 8 + N * 4),
-    "mrgcn::k_mix_bwd_node<12, 0, true>": ("dV + dcomp in one pass: V read once + dV written + dM read + relation ids",
+    "mrgcn::k_mix_bwd_node<10, 0, true>": ("dV + dcomp in one pass: V read once + dV written + dM read + relation ids",
                                            2 * 4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 4 + N * 4),
-    "mrgcn::k_mix_bwd_dv<40, 0>": ("dV written + dM read + relation ids", 4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 4),
-    "mrgcn::k_mix_bwd_dcomp<12, true>": ("V read once + dM read + 2 index arrays",
-                                         4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 8),
-    "mrgcn::k_spmm<4, 4, false, float>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
-    "mrgcn::k_spmm<4, 4, true, float>": ("transposed product (autograd), F=10/11", spmm_bytes(NCOLS, N, F0)),
-    "mrgcn::k_xform_mfma_fwd<1, false, 16, float>": ("layer-0 transform: X read once + W + M2 written + indices",
+    "mrgcn::k_spmm<4, 4, false, float, false>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
+    "mrgcn::k_spmm<4, 4, true, float, false>": ("general transposed product, F=10 (probe leg only; the epoch runs k_spmm_t_live)",
+                                                spmm_bytes(NCOLS, N, F0)),
+    "mrgcn::k_spmm_t_live<12>": ("transposed product over live rows: column pointers + flags read, dM written "
+                                 "(the floor whatever is live)", (NCOLS + 1) * 4 + NCOLS + NCOLS * LD * 4),
+    "mrgcn::k_xform_mfma_fwd<1, false, 16, float, false>": ("layer-0 transform: X read once + W + M2 written + indices",
                                               N * K0 * 4 + R * K0 * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
-    "mrgcn::k_xform_mfma_fwd<1, false, 1, float>": ("layer-1 transform: H read once + W + M written + indices",
+    "mrgcn::k_xform_mfma_fwd<1, false, 1, float, false>": ("layer-1 transform: H read once + W + M written + indices",
                                              N * F0 * 4 + R * F0 * F1 * 4 + NCOLS * LD * 4 + NCOLS * 12),
-    "mrgcn::k_xform_mfma_fwd<1, true, 1, float>": ("layer-1 dX products: dM read + W + Z written", 2 * NCOLS * LD * 4 + NCOLS * 4),
-    "mrgcn::k_xform_mfma_dw<3, 2>": ("layer-0 dW: X read once + dM read + indices + slabs",
-                                     N * K0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
-    "mrgcn::k_xform_mfma_dw<1, 2>": ("layer-1 dW: H read once + dM read + indices", N * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
-    "mrgcn::k_segment_sum": ("dX = segmented sum of Z", NCOLS * LD * 4 + N * F0 * 4),
 }
+# kernels whose traffic depends on how many columns carry gradient: listed with their times only
+LIVE = ["mrgcn::k_xform_mfma_dw<3, 2, true>", "mrgcn::k_xform_mfma_dw<1, 2, true>",
+        "mrgcn::k_xform_mfma_fwd<1, true, 1, float, true>", "mrgcn::k_segment_sum_live<16>",
+        "mrgcn::k_rows_live_mark", "mrgcn::k_long_rows_mark", "mrgcn::k_spmm<4, 4, true, float, true>"]
 
 
 def main():
@@ -50,7 +49,7 @@ def main():
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
-        if k in ALG:
+        if k in ALG or k in LIVE:
             d[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print(f"source: {f}\n")
     print("HBM roofline 8.0 TB/s (MI355X spec; about 6.3 TB/s is reachable by a copy).  `bytes` are ALGORITHMIC:")
@@ -66,6 +65,13 @@ def main():
         med = v[len(v) // 2]
         gbs = nbytes / (med * 1e-6) / GB
         print(f"| {k} | {label} | {nbytes/1e6:.0f} | {len(v)} | {med:.0f} | {gbs:.0f} | {100*gbs/PEAK:.1f} |")
+    print("\nBackward kernels that sweep only the compact columns with gradient (traffic depends on the labels):\n")
+    print("| kernel | launches | median us |")
+    print("|---|---:|---:|")
+    for k in LIVE:
+        v = sorted(d.get(k, []))
+        if v:
+            print(f"| {k} | {len(v)} | {v[len(v) // 2]:.0f} |")
 
 
 if __name__ == "__main__":
