@@ -232,11 +232,14 @@ int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *plan, const float *dM, 
  * device) receives the number of rows of D that are not all zeros (-1 when F > 16, where the
  * general product runs): with more than about a quarter of the rows live the general
  * mrgcn_spmm_f32 is the faster call (AM shape: 211 us at 0.3 % live rows, 467 us general,
- * 860 us with every row live), so callers keep the last count and choose. */
+ * 860 us with every row live), so callers keep the last count and choose.
+ * `write_dead_rows` = 0 leaves the rows of Y whose flag is 0 UNWRITTEN (their zeros are 90 % of this
+ * call's stores): only for consumers that take `col_live` — mrgcn_basis_mix_bwd_live_f32 and
+ * mrgcn_rel_transform_bwd_live_f32. */
 int64_t mrgcn_spmm_transposed_live_scratch(const mrgcn_plan_t *plan); /* bytes */
 int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const float *D, int64_t ldD, int32_t F,
                                    float *Y, int64_t ldY, uint8_t *scratch, uint8_t *col_live,
-                                   int32_t *live_rows, void *stream);
+                                   int32_t *live_rows, int32_t write_dead_rows, void *stream);
 /* flags[i] = 1 when X[i, 0:F] holds anything but (+-)0 — NaN counts — else 0. */
 int mrgcn_rows_nonzero_f32(const float *X, int64_t ld, int32_t F, int64_t nrows, uint8_t *flags,
                            void *stream);

@@ -67,7 +67,7 @@ SIGNATURES = {
                                                    _i64, _p]),
     "mrgcn_rows_nonzero_f32": (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
     "mrgcn_spmm_transposed_live_scratch": (C.c_int64, [_p]),
-    "mrgcn_spmm_transposed_live_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p]),
+    "mrgcn_spmm_transposed_live_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p]),
     "mrgcn_relu_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "mrgcn_softmax_xent_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _i64, _i64, _p]),
     "mrgcn_sumsq_accum_f32": (C.c_int, [_p, _i64, _p, _p]),

@@ -430,23 +430,41 @@ __global__ __launch_bounds__(256) void k_long_rows_mark(SparseView rv, const int
   for (int32_t e = rv.chunk_beg[c] + lane; e < rv.chunk_end[c]; e += kWave) col_live[ccol[e]] = 1;
 }
 
-// Pass 2 — one thread per output row (= compact column); dead columns store their zero row and
-// are done, live ones gather their live entries.
+// Pass 2 — the live output rows (= compact columns).  A block looks at kLiveTB consecutive columns,
+// packs the ids of the live ones into LDS (ballot + popcount, order kept) and lets its first threads
+// take one each: the waves that walk the pointer -> index -> flag -> gather chain have dense lanes
+// (with one thread per column, live or not, every wave paid for the chain with ~7 of 64 lanes busy).
+// Entries are added in the order k_spmm adds them (the skipped ones would have added a * 0).  Dead
+// rows are not touched here (zeroed beforehand, or left to the consumers' flags).
+constexpr int kLiveTB = 1024;
 template <int FT>
-__global__ __launch_bounds__(256) void k_spmm_t_live(SparseView v, const float *__restrict__ D, int64_t ldD,
-                                                     int F, float *__restrict__ Y, int64_t ldY,
-                                                     const uint8_t *__restrict__ row_live,
-                                                     const uint8_t *__restrict__ col_live, int packed_rows) {
-  __shared__ __align__(16) float s_out[256 * FT];
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = row < v.rows;
-  int32_t b = 0, n = 0;
-  if (valid) {
-    b = v.ptr[row];
-    n = v.ptr[row + 1] - b;
+__global__ __launch_bounds__(kLiveTB) void k_spmm_t_live(SparseView v, const float *__restrict__ D,
+                                                         int64_t ldD, int F, float *__restrict__ Y,
+                                                         int64_t ldY, const uint8_t *__restrict__ row_live,
+                                                         const uint8_t *__restrict__ col_live,
+                                                         int store_vec_ok) {
+  __shared__ int32_t s_cid[kLiveTB];
+  __shared__ int32_t s_cnt[kLiveTB / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * kLiveTB + threadIdx.x;
+  const bool live = c < v.rows && col_live[c] != 0;
+  const uint64_t bal = __ballot(live);
+  if (lane == 0) s_cnt[wv] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kLiveTB / 64; ++w) {
+    const int n = s_cnt[w];
+    if (w < wv) off += n;
+    tot += n;
   }
-  const bool long_row = n > kLongThreshold;  // the split-row blocks of k_spmm write it afterwards
-  if (long_row || !valid || !col_live[row]) n = 0;
+  if (live) s_cid[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)c;
+  __syncthreads();
+  if ((int)threadIdx.x >= tot) return;
+  const int64_t row = s_cid[threadIdx.x];
+  const int32_t b = v.ptr[row];
+  const int32_t n = v.ptr[row + 1] - b;
+  if (n > kLongThreshold) return;  // the split-row blocks of k_spmm write it
   float acc[FT];
 #pragma unroll
   for (int o = 0; o < FT; ++o) acc[o] = 0.f;
@@ -457,13 +475,8 @@ __global__ __launch_bounds__(256) void k_spmm_t_live(SparseView v, const float *
     bool lv[kLook];
 #pragma unroll
     for (int k = 0; k < kLook; ++k) ii[k] = (e0 + k < b + n) ? v.idx[e0 + k] : -1;
-    bool some = false;
 #pragma unroll
-    for (int k = 0; k < kLook; ++k) {
-      lv[k] = (ii[k] >= 0) ? row_live[ii[k]] != 0 : false;
-      some |= lv[k];
-    }
-    if (!some) continue;
+    for (int k = 0; k < kLook; ++k) lv[k] = (ii[k] >= 0) ? row_live[ii[k]] != 0 : false;
 #pragma unroll
     for (int k = 0; k < kLook; ++k) {
       if (!lv[k]) continue;
@@ -480,25 +493,12 @@ __global__ __launch_bounds__(256) void k_spmm_t_live(SparseView v, const float *
       }
     }
   }
-  if (packed_rows) {
-    // ldY == roundup(F, 4), 16-byte aligned: the 64 rows of a wave are one contiguous run of Y;
-    // through LDS so that every store instruction writes whole cache lines
-    const int F4 = (int)ldY;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float *mine = s_out + (size_t)threadIdx.x * F4;
+  float *y = Y + row * ldY;
+  if (store_vec_ok) {  // ldY >= roundup(F, 4), rows 16-byte aligned
 #pragma unroll
     for (int f0 = 0; f0 < FT; f0 += 4)
-      if (f0 < F4) *reinterpret_cast<float4 *>(mine + f0) = make_float4(acc[f0], acc[f0 + 1], acc[f0 + 2], acc[f0 + 3]);
-    __syncthreads();
-    const int64_t wrow0 = (int64_t)blockIdx.x * blockDim.x + 64 * wv;
-    const int64_t left = v.rows - wrow0;
-    const int nrows = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
-    const int total4 = nrows * F4 / 4;
-    const float4 *src = reinterpret_cast<const float4 *>(s_out + (size_t)64 * wv * F4);
-    float4 *dst = reinterpret_cast<float4 *>(Y + wrow0 * ldY);
-    for (int q = lane; q < total4; q += 64) dst[q] = src[q];
-  } else if (valid && !long_row) {
-    float *y = Y + row * ldY;
+      if (f0 < F) *reinterpret_cast<float4 *>(y + f0) = make_float4(acc[f0], acc[f0 + 1], acc[f0 + 2], acc[f0 + 3]);
+  } else {
 #pragma unroll
     for (int o = 0; o < FT; ++o)
       if (o < F) y[o] = acc[o];
@@ -688,11 +688,13 @@ extern "C" int64_t mrgcn_spmm_transposed_live_scratch(const mrgcn_plan_t *plan) 
 
 extern "C" int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const float *D, int64_t ldD,
                                               int32_t F, float *Y, int64_t ldY, uint8_t *scratch,
-                                              uint8_t *col_live, int32_t *live_rows, void *stream) {
+                                              uint8_t *col_live, int32_t *live_rows,
+                                              int32_t write_dead_rows, void *stream) {
   using namespace mrgcn;
   MRGCN_REQUIRE(plan, "plan is NULL");
   MRGCN_REQUIRE(F > 0 && ldD >= F && ldY >= F, "F / leading dimensions");
   MRGCN_REQUIRE(D && Y && scratch && col_live, "NULL operand");
+  MRGCN_REQUIRE(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   SparseView v = plan->view(MRGCN_VIEW_TRANSPOSED);
   if (live_rows) MRGCN_HIP_TRY(hipMemsetAsync(live_rows, 0, sizeof(int32_t), s));
@@ -704,6 +706,7 @@ extern "C" int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const fl
   }
   uint8_t *row_live = scratch;
   MRGCN_HIP_TRY(hipMemsetAsync(col_live, 0, (size_t)v.rows, s));
+  if (write_dead_rows && v.rows > 0) MRGCN_HIP_TRY(hipMemsetAsync(Y, 0, (size_t)v.rows * ldY * sizeof(float), s));
   if (plan->num_rows > 0 && v.rows > 0) {
     k_rows_live_mark<<<dim3((unsigned)((plan->num_rows + 255) / 256)), dim3(256), 0, s>>>(
         D, ldD, F, plan->num_rows, plan->rowptr, plan->ccol, row_live, col_live, live_rows);
@@ -714,15 +717,12 @@ extern "C" int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const fl
       k_long_rows_mark<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s>>>(rv, plan->ccol, row_live, col_live);
       MRGCN_HIP_TRY(hipGetLastError());
     }
-  }
-  if (v.rows > 0) {
-    const int F4 = (F + 3) / 4 * 4;
-    const int packed = (ldY == F4) && (((uintptr_t)Y) % 16 == 0);  // rows packed: coalesced stores
-    const dim3 grid((unsigned)((v.rows + 255) / 256));
-    if (F <= 4) k_spmm_t_live<4><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed);
-    else if (F <= 8) k_spmm_t_live<8><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed);
-    else if (F <= 12) k_spmm_t_live<12><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed);
-    else k_spmm_t_live<16><<<grid, dim3(256), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, packed);
+    const int vec_ok = (ldY % 4 == 0) && (ldY >= (F + 3) / 4 * 4) && (((uintptr_t)Y) % 16 == 0);
+    const dim3 grid((unsigned)((v.rows + kLiveTB - 1) / kLiveTB));
+    if (F <= 4) k_spmm_t_live<4><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok);
+    else if (F <= 8) k_spmm_t_live<8><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok);
+    else if (F <= 12) k_spmm_t_live<12><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok);
+    else k_spmm_t_live<16><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok);
     MRGCN_HIP_TRY(hipGetLastError());
   }
   // long rows: the split-row blocks of the general kernel only (its short-row blocks are not launched)

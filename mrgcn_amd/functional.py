@@ -260,7 +260,7 @@ class _RgcnLayer(torch.autograd.Function):
             with torch.cuda.device(dev):
                 L.check(lib.mrgcn_spmm_transposed_live_f32(
                     plan.handle, dY.data_ptr(), dY.stride(0), F, dM.data_ptr(), ld, scratch.data_ptr(),
-                    live.data_ptr(), gauge.dev.data_ptr(), s), "mrgcn_spmm_transposed_live_f32")
+                    live.data_ptr(), gauge.dev.data_ptr(), 1, s), "mrgcn_spmm_transposed_live_f32")
             gauge.publish()
         else:
             plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)

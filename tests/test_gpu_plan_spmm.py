@@ -195,7 +195,7 @@ def test_transposed_product_with_zero_operand_rows(skewed, F, zero_frac):
         col_live = torch.full((plan.ncols,), 7, dtype=torch.uint8, device="cuda")
         n_live = torch.full((1,), 77, dtype=torch.int32, device="cuda")
         L.check(lib.mrgcn_spmm_transposed_live_f32(plan.handle, dYg.data_ptr(), F, F, got.data_ptr(), ld,
-                                                   row_live.data_ptr(), col_live.data_ptr(), n_live.data_ptr(), s))
+                                                   row_live.data_ptr(), col_live.data_ptr(), n_live.data_ptr(), 1, s))
         assert int(n_live) == (int((~dead).sum()) if F <= 16 else -1)
         short_t = torch.from_numpy(np.diff(ref["cptr"]) <= 32).cuda()
         assert torch.equal(got[:, :F][short_t], want[short_t]), f"ld={ld}"
@@ -211,6 +211,16 @@ def test_transposed_product_with_zero_operand_rows(skewed, F, zero_frac):
             csc = abs(sp.csc_matrix(A)[:, ref["ulcol"]])
             reach = (csc.T @ (~dead).astype(np.float64)) > 0 if zero_frac else np.ones(plan.ncols, bool)
             np.testing.assert_array_equal(cl, reach.astype(np.uint8))
+    if F <= 16:
+        # write_dead_rows = 0: rows flagged dead are left alone (consumers go by the flags)
+        ld = (F + 3) // 4 * 4
+        got = torch.full((plan.ncols, ld), 9.0, device="cuda")
+        L.check(lib.mrgcn_spmm_transposed_live_f32(plan.handle, dYg.data_ptr(), F, F, got.data_ptr(), ld,
+                                                   row_live.data_ptr(), col_live.data_ptr(), 0, 0, s))
+        lv = col_live.bool()
+        torch.testing.assert_close(got[:, :F][lv], want[lv], rtol=1e-5, atol=1e-5)
+        short_dead = (~lv) & torch.from_numpy(np.diff(ref["cptr"]) <= 32).cuda()
+        assert (got[short_dead] == 9.0).all()
     # NaN rows are live
     dYg[0, F - 1] = float("nan")
     row_live = torch.empty(plan.num_rows, dtype=torch.uint8, device="cuda")

@@ -80,7 +80,8 @@ def main():
         "mix_bwd": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), dcomp.data_ptr(), 0, s)),
         "mix_bwd_sq": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, V.data_ptr(), comp.data_ptr(), B, F, 0, dcomp.data_ptr(), sq.data_ptr(), s)),
         "mix_bwd_adam": lambda: chk(lib.mrgcn_basis_mix_bwd_adam_f32(h, dM.data_ptr(), 12, comp.data_ptr(), B, F, P.data_ptr(), M_.data_ptr(), V_.abs_().data_ptr(), 0.01, 0.9, 0.999, 1e-8, 0.0, 1, coef.data_ptr(), s)),
-        "spmm_tl10": lambda: chk(lib.mrgcn_spmm_transposed_live_f32(h, dYz.data_ptr(), 10, 10, dM.data_ptr(), 12, scratch.data_ptr(), clive.data_ptr(), 0, s)),
+        "spmm_tl10": lambda: chk(lib.mrgcn_spmm_transposed_live_f32(h, dYz.data_ptr(), 10, 10, dM.data_ptr(), 12, scratch.data_ptr(), clive.data_ptr(), 0, 1, s)),
+        "spmm_tl10_nd": lambda: chk(lib.mrgcn_spmm_transposed_live_f32(h, dYz.data_ptr(), 10, 10, dM.data_ptr(), 12, scratch.data_ptr(), clive.data_ptr(), 0, 0, s)),
         "xf_fwd0": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, X.data_ptr(), K, K, W0.data_ptr(), F, M2.data_ptr(), 12, 0, s)),
         "xf_fwd1": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, H.data_ptr(), F, F, W1.data_ptr(), C, M.data_ptr(), ld, 1, s)),
         "xf_bwd0": lambda: chk(lib.mrgcn_rel_transform_bwd_f32(h, dM.data_ptr(), 12, X.data_ptr(), K, K, W0.data_ptr(), F, 0, K, dW0.data_ptr(), ws.data_ptr(), nws, s)),
