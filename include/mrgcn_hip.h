@@ -186,6 +186,13 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64_t l
                             const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
                             double *dV_sumsq /* nullable: *dV_sumsq += ||dV||^2 (device double) */,
                             void *stream);
+/* The same with the liveness byte per compact column that mrgcn_spmm_transposed_live_f32 wrote
+ * (nullable = mrgcn_basis_mix_bwd_f32): rows of dM flagged 0 are never read — they may be unwritten —
+ * and where a kernel has to read every row they are overwritten with zeros first (hence the
+ * non-const dM). */
+int mrgcn_basis_mix_bwd_live_f32(const mrgcn_plan_t *plan, float *dM, int64_t ldM,
+                                 const uint8_t *col_live, const float *V, const float *comp, int32_t B,
+                                 int32_t F, float *dV, float *dcomp, double *dV_sumsq, void *stream);
 /* Deferred update of the basis table V (= weight_I, the 2.67 GB parameter at AM scale):
  * clip_grad_norm_ needs ||dV|| before any parameter may move, so
  *   pass 1  mrgcn_basis_mix_bwd_f32 with dV = NULL: dcomp and *dV_sumsq only, dV is not stored;
@@ -215,9 +222,10 @@ int mrgcn_rel_transform_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64
  * nullable = every column live).  In a semi-supervised epoch only the columns that feed a row
  * within reach of a labelled node carry gradient (autograd of graph.py:93-95 multiplies the
  * zeros like everything else); dead columns add exact zeros to dW and dX and are skipped.  Results
- * equal mrgcn_rel_transform_bwd_f32's.  `col_live` comes from mrgcn_spmm_transposed_live_f32
+ * equal mrgcn_rel_transform_bwd_f32's.  Rows of dM flagged 0 are never read (they may be unwritten);
+ * where a fallback kernel has to read every row they are overwritten with zeros first.  `col_live` comes from mrgcn_spmm_transposed_live_f32
  * (or mrgcn_rows_nonzero_f32(dM)). */
-int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM,
+int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *plan, float *dM, int64_t ldM,
                                      const uint8_t *col_live, const float *X, int64_t ldX,
                                      int32_t K, const float *W, int32_t F, float *dX, int64_t lddX,
                                      float *dW, float *workspace, int64_t workspace_floats,

@@ -80,6 +80,7 @@ template <typename OT> __device__ __forceinline__ float load_operand(const OT *p
 // MFMA relation transforms (xform_mfma.hip)
 bool xform_mfma_fwd_supported(int K, int F);
 bool xform_mfma_dw_supported(int K, int F);
+bool xform_mfma_dw_live_supported(int K, int F);
 int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
                    int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out, int64_t ldOut,
                    hipStream_t s, bool out_bf16 = false, const uint8_t *col_live = nullptr);

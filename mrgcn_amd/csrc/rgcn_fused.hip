@@ -378,7 +378,8 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
                                                           int B, int F, float *__restrict__ dV,
                                                           float *__restrict__ dcomp,
                                                           double *__restrict__ sumsq, AdamArgs ad,
-                                                          int top_rel) {
+                                                          int top_rel,
+                                                          const uint8_t *__restrict__ col_live) {
   extern __shared__ __align__(16) float s_mem[];  // 16 wave tiles [B][rs] | dcomp accumulators [R*B]
   const int row = kGroup * F;  // floats per basis in a wave tile
   const int rs = row | 1;      // odd LDS stride: lanes (bases) fall on different banks
@@ -418,8 +419,12 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
     // (on the AM shape ~90 %: only columns that feed a row within two hops of a label receive
     // gradient) and a zero row adds nothing to dV or dcomp: its loads, FMAs and atomics are
     // skipped (2.45 -> 2.2 ms; what remains is the tile traffic: 0.9 ms without any column).
+    // (`col_live`, when the producer of dM supplies it, says the same without touching dM — whose
+    // dead rows may then be unwritten)
     uint64_t amask;
-    {
+    if (col_live) {
+      amask = __builtin_amdgcn_ballot_w64(cp[0] + lane < cp[kGroup] && col_live[cp[0] + lane] != 0);
+    } else {
       bool nz = false;
       if (cp[0] + lane < cp[kGroup]) {
         const float *dr = dM + (int64_t)(cp[0] + lane) * ldM;
@@ -462,11 +467,17 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
         // one load fetches the dM rows of four columns: the 16-lane group k reads column cb + k
         // (lane o of the group its feature o); v_readlane turns them into scalars
         const int32_t off = cb - cp[0];  // position among the group's columns (uniform)
-        const uint32_t live = (off + 4 <= 64) ? (uint32_t)(amask >> off) & 0xFu : 0xFu;
-        if (live == 0) continue;  // four columns without gradient
         const int kq = lane >> 4, oq = lane & 15;
         const int32_t cc = cb + kq;
         const bool cin = cc < c_hi;
+        uint32_t live = 0xFu;
+        if (off + 4 <= 64) {
+          live = (uint32_t)(amask >> off) & 0xFu;
+        } else if (col_live) {  // beyond the 64 columns the mask covers: ask the flags
+          const uint64_t bl = __builtin_amdgcn_ballot_w64(cin && col_live[cc] != 0);
+          live = (uint32_t)((bl & 1u) | ((bl >> 15) & 2u) | ((bl >> 30) & 4u) | ((bl >> 45) & 8u));
+        }
+        if (live == 0) continue;  // four columns without gradient
         const float dmine = (cin && oq < F) ? dM[(int64_t)cc * ldM + oq] : 0.f;
         int r[4];
         if (off + 4 <= 64) {
@@ -995,13 +1006,35 @@ int mrgcn_rel_transform_fwd_bf16(const mrgcn_plan_t *p, const float *X, int64_t 
 
 namespace {
 // the dV pass of the basis-mix backward in one of its three modes (see k_mix_bwd_dv)
+// rows of dM whose liveness flag is 0 were possibly never written (mrgcn_spmm_transposed_live_f32 with
+// write_dead_rows = 0): kernels that read every row get zeros there first
+__global__ void k_zero_dead_rows(float *__restrict__ dM, int64_t ldM, int F, const uint8_t *__restrict__ col_live,
+                                 int64_t ncols) {
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols;
+       c += (int64_t)gridDim.x * blockDim.x) {
+    if (col_live[c]) continue;
+    float *row = dM + c * ldM;
+    for (int o = 0; o < F; ++o) row[o] = 0.f;
+  }
+}
+
+static int zero_dead_rows(float *dM, int64_t ldM, int F, const uint8_t *col_live, int64_t ncols, hipStream_t s) {
+  if (ncols == 0) return MRGCN_OK;
+  int64_t blocks = (ncols + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  k_zero_dead_rows<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dM, ldM, F, col_live, ncols);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
 // wave-per-node form of the basis-mix backward (k_mix_bwd_node); returns MRGCN_OK when it ran,
 // -1 when the shape is outside its limits (the caller falls back to the two-kernel form), an
 // error code otherwise.
 template <int MODE, bool DCOMP>
 int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
                         const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
-                        double *dV_sumsq, const mrgcn::AdamArgs &ad, hipStream_t s) {
+                        double *dV_sumsq, const mrgcn::AdamArgs &ad, hipStream_t s,
+                        const uint8_t *col_live = nullptr) {
   static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
@@ -1032,7 +1065,7 @@ int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, con
       lds_allowed = lds;                                                                                  \
     }                                                                                                     \
     kfn<<<dim3((unsigned)grid), dim3(kNodeTB), lds, s>>>(p->nptr, p->urel, dM, ldM, V, comp, N, R, B, F, dV, \
-                                                         dcomp, dV_sumsq, ad, (int)p->top_rel);           \
+                                                         dcomp, dV_sumsq, ad, (int)p->top_rel, col_live); \
   } while (0)
   switch (FT) {
     case 4: NODE_GO(4); break;
@@ -1109,6 +1142,13 @@ int mrgcn_basis_mix_bwd_adam_f32(const mrgcn_plan_t *p, const float *dM, int64_t
 int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
                             const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
                             double *dV_sumsq, void *stream) {
+  return mrgcn_basis_mix_bwd_live_f32(p, const_cast<float *>(dM), ldM, nullptr, V, comp, B, F, dV, dcomp,
+                                      dV_sumsq, stream);
+}
+
+int mrgcn_basis_mix_bwd_live_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const uint8_t *col_live,
+                                 const float *V, const float *comp, int32_t B, int32_t F, float *dV,
+                                 float *dcomp, double *dV_sumsq, void *stream) {
   MRGCN_REQUIRE(p && dM && V && comp && dcomp, "NULL");
   MRGCN_REQUIRE(dV || dV_sumsq, "dV may be NULL only when dV_sumsq is wanted (deferred update)");
   MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
@@ -1118,9 +1158,14 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
   MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)R * B * sizeof(float), s));
   {  // one pass for dV and dcomp when the shape allows it
     mrgcn::AdamArgs none{};
-    int rc = dV ? mix_bwd_node_launch<0, true>(p, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, none, s)
-                : mix_bwd_node_launch<1, true>(p, dM, ldM, V, comp, B, F, nullptr, dcomp, dV_sumsq, none, s);
+    int rc = dV ? mix_bwd_node_launch<0, true>(p, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, none, s, col_live)
+                : mix_bwd_node_launch<1, true>(p, dM, ldM, V, comp, B, F, nullptr, dcomp, dV_sumsq, none, s, col_live);
     if (rc >= 0) return rc;
+  }
+  // the two-kernel form reads every row of dM: rows flagged dead may be unwritten
+  if (col_live) {
+    int rc = zero_dead_rows(dM, ldM, F, col_live, p->ncols, s);
+    if (rc != MRGCN_OK) return rc;
   }
   // pass 1: dV (or only its squared norm)
   {
@@ -1187,11 +1232,11 @@ int mrgcn_rel_transform_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t 
                                 int64_t ldX, int32_t K, const float *W, int32_t F, float *dX,
                                 int64_t lddX, float *dW, float *workspace, int64_t workspace_floats,
                                 void *stream) {
-  return mrgcn_rel_transform_bwd_live_f32(p, dM, ldM, nullptr, X, ldX, K, W, F, dX, lddX, dW, workspace,
-                                          workspace_floats, stream);
+  return mrgcn_rel_transform_bwd_live_f32(p, const_cast<float *>(dM), ldM, nullptr, X, ldX, K, W, F, dX, lddX,
+                                          dW, workspace, workspace_floats, stream);
 }
 
-int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM,
+int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM,
                                      const uint8_t *col_live, const float *X, int64_t ldX, int32_t K,
                                      const float *W, int32_t F, float *dX, int64_t lddX, float *dW,
                                      float *workspace, int64_t workspace_floats, void *stream) {
@@ -1199,6 +1244,18 @@ int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *p, const float *dM, int
   MRGCN_REQUIRE(K > 0 && F > 0 && ldX >= K && ldM >= F, "K / F / leading dimensions");
   MRGCN_REQUIRE(F <= 64, "rel_transform supports F <= 64 (tile the feature dimension)");
   hipStream_t s = (hipStream_t)stream;
+  if (col_live) {
+    // every kernel below that sweeps all columns reads every row of dM: rows flagged dead may be
+    // unwritten, so unless both halves take the live-column form they are zeroed first
+    const bool dw_live = !dW || (use_mfma() && xform_mfma_dw_live_supported(K, F));
+    const int64_t ldZ_ = ((int64_t)K + 3) / 4 * 4;
+    const bool dx_live = !dX || (use_mfma() && workspace && workspace_floats >= p->ncols * ldZ_ &&
+                                 xform_mfma_fwd_supported(F, K));
+    if (!(dw_live && dx_live)) {
+      int rc = zero_dead_rows(dM, ldM, F, col_live, p->ncols, s);
+      if (rc != MRGCN_OK) return rc;
+    }
+  }
   if (dW) {
     MRGCN_HIP_TRY(hipMemsetAsync(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
     if (use_mfma() && xform_mfma_dw_supported(K, F)) {

@@ -386,6 +386,10 @@ __global__ void k_segment_sum_live(const int32_t *__restrict__ nptr, const float
 // ---- launchers used by the C ABI entry points in rgcn_fused.hip -------------------------------
 bool xform_mfma_fwd_supported(int K, int F) { return K <= kMaxKSteps * 16 && F <= kMaxNT * 16; }
 bool xform_mfma_dw_supported(int K, int F) { return K <= kMaxTQ * 64 && F <= 16 && (size_t)4 * K * F * 4 <= 64 * 1024; }
+// ... and with room in LDS for the list of live columns
+bool xform_mfma_dw_live_supported(int K, int F) {
+  return xform_mfma_dw_supported(K, F) && (size_t)4 * K * F * 4 + (2 * (size_t)kRelChunk + 4) * 4 <= 64 * 1024;
+}
 
 constexpr size_t kLiveLds = (2 * (size_t)kRelChunk + 4) * sizeof(int32_t);
 

@@ -76,6 +76,10 @@ _OVERLAP = os.environ.get("MRGCN_OVERLAP", "0") != "0"
 _LIVE_COLS = os.environ.get("MRGCN_LIVE_COLS", "1") != "0"
 
 
+# tests: start dM as NaNs, so that any read of a row the producer left unwritten shows
+_POISON_DEAD = False
+
+
 class _LiveGauge:
     """How many rows of a layer's output gradient held anything the last time it was looked at.
     The sparse transposed product (mrgcn_spmm_transposed_live_f32) wins while few rows are live
@@ -249,6 +253,8 @@ class _RgcnLayer(torch.autograd.Function):
         # dM = A'^T dY over touched columns only, plain compact order (its consumers are node-major)
         ld = (F + 3) // 4 * 4
         dM = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
+        if _POISON_DEAD:
+            dM.fill_(float("nan"))
         live = None
         gauge = _live_gauge(plan, F, ctx.relu, dev) if _LIVE_COLS else None
         if gauge is not None and gauge.sparse():
@@ -257,10 +263,13 @@ class _RgcnLayer(torch.autograd.Function):
             live = torch.empty((plan.ncols,), dtype=torch.uint8, device=dev)
             scratch = torch.empty((int(lib.mrgcn_spmm_transposed_live_scratch(plan.handle)),),
                                   dtype=torch.uint8, device=dev)
+            # rows of dM without gradient are not even written when every consumer goes by the flags
+            # (the no-bases scatter and the deferred update's second pass read dM itself)
+            write_dead = int(has_I and (not has_comp or (_DEFER and weight_I.is_contiguous())))
             with torch.cuda.device(dev):
                 L.check(lib.mrgcn_spmm_transposed_live_f32(
                     plan.handle, dY.data_ptr(), dY.stride(0), F, dM.data_ptr(), ld, scratch.data_ptr(),
-                    live.data_ptr(), gauge.dev.data_ptr(), 1, s), "mrgcn_spmm_transposed_live_f32")
+                    live.data_ptr(), gauge.dev.data_ptr(), write_dead, s), "mrgcn_spmm_transposed_live_f32")
             gauge.publish()
         else:
             plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)
@@ -282,10 +291,11 @@ class _RgcnLayer(torch.autograd.Function):
                     d_wI = None if defer else torch.empty_like(weight_I)
                     d_comp = torch.empty_like(comp_I)
                     sq = torch.zeros((), dtype=torch.float64, device=dev)
-                    L.check(lib.mrgcn_basis_mix_bwd_f32(
-                        plan.handle, dM.data_ptr(), ld, weight_I.data_ptr(), comp_I.data_ptr(),
+                    L.check(lib.mrgcn_basis_mix_bwd_live_f32(
+                        plan.handle, dM.data_ptr(), ld, live.data_ptr() if live is not None else 0,
+                        weight_I.data_ptr(), comp_I.data_ptr(),
                         comp_I.shape[1], F, 0 if defer else d_wI.data_ptr(), d_comp.data_ptr(),
-                        sq.data_ptr(), s), "mrgcn_basis_mix_bwd_f32")
+                        sq.data_ptr(), s), "mrgcn_basis_mix_bwd_live_f32")
                     if defer:
                         # comp_I is cloned: the optimizer may update the parameter before pass 2
                         _DEFERRED[weight_I.data_ptr()] = dict(

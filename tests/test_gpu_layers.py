@@ -313,7 +313,8 @@ def test_graph_captured_epoch_equals_eager(name):
 
 
 @pytest.mark.parametrize("zero_frac", [0.0, 0.5, 0.93, 1.0])
-@pytest.mark.parametrize("N,R,B,F,hub", [(900, 7, 40, 10, 500), (333, 5, 3, 11, 0), (640, 9, 64, 16, 200)])
+@pytest.mark.parametrize("N,R,B,F,hub", [(900, 7, 40, 10, 500), (333, 5, 3, 11, 0), (640, 9, 64, 16, 200),
+                                         (500, 6, 70, 12, 0)])  # the last one: B > 64, two-kernel fallback
 def test_basis_mix_backward_with_rows_without_gradient(N, R, B, F, hub, zero_frac):
     """dV / dcomp through the C ABI when most rows of dM are exact zeros — the state of a
     semi-supervised epoch (only columns within two hops of a label receive gradient), which the
@@ -363,6 +364,18 @@ def test_basis_mix_backward_with_rows_without_gradient(N, R, B, F, hub, zero_fra
     np.testing.assert_allclose(dc2.cpu().numpy(), want_dc, rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
 
+    # with the producer's flags the dead rows are never read: poison them
+    liveg = torch.from_numpy((~dead).astype(np.uint8)).cuda()
+    dMp = dMt.clone()
+    dMp[torch.from_numpy(dead).cuda()] = float("nan")
+    for dv_ptr in (dV.data_ptr(), 0):
+        sq.zero_()
+        L.check(lib.mrgcn_basis_mix_bwd_live_f32(plan.handle, dMp.data_ptr(), ld, liveg.data_ptr(), Vt.data_ptr(),
+                                                 ct.data_ptr(), B, F, dv_ptr, dc.data_ptr(), sq.data_ptr(), s))
+        np.testing.assert_allclose(dc.cpu().numpy(), want_dc, rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dV.cpu().numpy(), want_dV, rtol=1e-4, atol=1e-5)
+
     # a NaN anywhere in a row keeps that row alive
     if zero_frac > 0 and dead.any():
         c = int(np.flatnonzero(dead)[0])
@@ -408,3 +421,18 @@ def test_backward_is_the_same_on_the_sparse_and_the_general_transposed_product()
         for g in grads[1:]:
             for a, b in zip(grads[0], g):
                 torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["rgcn_smoke_ft_b5_norm_f32", "rgcn_small_fl_b0_bias_ref_int8",
+                                  "rgcn_small_ft_b3_bias_norm_f32", "rgcn_small_fl_b3_bias_norm_f32"])
+def test_epoch_steps_never_read_unwritten_gradient_rows(name):
+    """Rows of dM without gradient are left unwritten by the transposed product; with dM
+    pre-filled with NaNs the golden epochs must still come out (nothing may read those rows)."""
+    from mrgcn_amd import functional as Fn
+    if name not in util.rgcn_cases():
+        pytest.skip("case not in the golden set")
+    Fn._POISON_DEAD = True
+    try:
+        test_epoch_steps_vs_reference_goldens(name)
+    finally:
+        Fn._POISON_DEAD = False

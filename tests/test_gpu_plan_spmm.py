@@ -243,17 +243,21 @@ def test_transform_backward_over_live_columns(skewed, K, F, need_dX, live_frac):
     dM = rng.standard_normal((plan.ncols, ld)).astype(np.float32)
     live = rng.random(plan.ncols) < live_frac
     dM[~live] = 0.0
+    dM_poison = dM.copy()
+    dM_poison[~live] = np.nan  # with flags, dead rows are never read (or zeroed first by a fallback)
     X = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
     W = torch.from_numpy(rng.standard_normal((R, K, F)).astype(np.float32)).cuda()
     dMg = torch.from_numpy(dM).cuda()
     liveg = torch.from_numpy(live.astype(np.uint8)).cuda()
     nws = int(lib.mrgcn_rel_transform_bwd_workspace(plan.handle, K, F, int(need_dX), 1))
     outs = []
+    dMpg = torch.from_numpy(dM_poison).cuda()
     for flags in (0, liveg.data_ptr()):
         ws = torch.full((max(nws, 1),), float("nan"), device="cuda")  # dead rows of Z must never be read
         dX = torch.full((N, K), 5.0, device="cuda")
         dW = torch.full((R, K, F), 5.0, device="cuda")
-        L.check(lib.mrgcn_rel_transform_bwd_live_f32(plan.handle, dMg.data_ptr(), ld, flags, X.data_ptr(), K, K,
+        L.check(lib.mrgcn_rel_transform_bwd_live_f32(plan.handle, (dMpg if flags else dMg).data_ptr(), ld, flags,
+                                                     X.data_ptr(), K, K,
                                                      W.data_ptr(), F, dX.data_ptr() if need_dX else 0, K,
                                                      dW.data_ptr(), ws.data_ptr(), nws, s))
         outs.append((dX.cpu().numpy(), dW.cpu().numpy()))
