@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_long_rows_mark(SparseView rv, const int
 // (with one thread per column, live or not, every wave paid for the chain with ~7 of 64 lanes busy).
 // Entries are added in the order k_spmm adds them (the skipped ones would have added a * 0).  Dead
 // rows are not touched here (zeroed beforehand, or left to the consumers' flags).
-constexpr int kLiveTB = 1024;
+constexpr int kLiveTB = 256;  // AM epoch, layer 0 / layer 1: 1024 -> 258 / 37 us, 512 -> 229 / 31, 256 -> 206 / 27
 template <int FT>
 __global__ __launch_bounds__(kLiveTB) void k_spmm_t_live(SparseView v, const float *__restrict__ D,
                                                          int64_t ldD, int F, float *__restrict__ Y,

@@ -31,15 +31,13 @@ ALG = {  # kernel-name prefix -> (label, bytes)
     "mrgcn::k_spmm<4, 4, false, float, false>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
     "mrgcn::k_spmm<4, 4, true, float, false>": ("general transposed product, F=10 (probe leg only; the epoch runs k_spmm_t_live)",
                                                 spmm_bytes(NCOLS, N, F0)),
-    "mrgcn::k_spmm_t_live<12>": ("transposed product over live rows: column pointers + flags read, dM written "
-                                 "(the floor whatever is live)", (NCOLS + 1) * 4 + NCOLS + NCOLS * LD * 4),
     "mrgcn::k_xform_mfma_fwd<1, false, 16, float, false>": ("layer-0 transform: X read once + W + M2 written + indices",
                                               N * K0 * 4 + R * K0 * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8),
     "mrgcn::k_xform_mfma_fwd<1, false, 1, float, false>": ("layer-1 transform: H read once + W + M written + indices",
                                              N * F0 * 4 + R * F0 * F1 * 4 + NCOLS * LD * 4 + NCOLS * 12),
 }
 # kernels whose traffic depends on how many columns carry gradient: listed with their times only
-LIVE = ["mrgcn::k_xform_mfma_dw<3, 2, true>", "mrgcn::k_xform_mfma_dw<1, 2, true>",
+LIVE = ["mrgcn::k_spmm_t_live<12>", "mrgcn::k_xform_mfma_dw<3, 2, true>", "mrgcn::k_xform_mfma_dw<1, 2, true>",
         "mrgcn::k_xform_mfma_fwd<1, true, 1, float, true>", "mrgcn::k_segment_sum_live<16>",
         "mrgcn::k_rows_live_mark", "mrgcn::k_long_rows_mark", "mrgcn::k_spmm<4, 4, true, float, true>"]
 
