@@ -112,6 +112,9 @@ def _live_gauge(plan, F, relu, dev):
     key = (id(plan), F, bool(relu))
     g = _GAUGES.get(key)
     if g is None or g.plan_ref() is not plan:
+        if len(_GAUGES) >= 256:  # mini-batch training builds plans by the thousand: drop the dead ones
+            for k in [k for k, v in _GAUGES.items() if v.plan_ref() is None]:
+                del _GAUGES[k]
         g = _LiveGauge(plan.num_rows, dev)
         g.plan_ref = weakref.ref(plan)
         _GAUGES[key] = g
