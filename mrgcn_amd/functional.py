@@ -90,11 +90,28 @@ class _LiveGauge:
     _RETRY = 32
     _DENSE = 0.25
 
+    _pinned = None  # one pinned page for all gauges (pinning per gauge would cost ~100 us each)
+    _free: list = []
+
     def __init__(self, num_rows, dev):
+        cls = _LiveGauge
+        if cls._pinned is None:
+            cls._pinned = torch.full((1024,), -1, dtype=torch.int32).pin_memory()
+            cls._free = list(range(1024))
         self.num_rows = num_rows
         self.dev = torch.zeros((1,), dtype=torch.int32, device=dev)
-        self.host = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+        self.slot = cls._free.pop() if cls._free else None
+        if self.slot is not None:
+            cls._pinned[self.slot] = -1
+            self.host = cls._pinned[self.slot:self.slot + 1]
+        else:  # out of slots: a private, unpinned count that never learns anything (always sparse)
+            self.host = torch.full((1,), -1, dtype=torch.int32)
         self.calls = 0
+
+    def release(self):
+        if self.slot is not None:
+            _LiveGauge._free.append(self.slot)
+            self.slot = None
 
     def sparse(self) -> bool:
         self.calls += 1
@@ -102,7 +119,8 @@ class _LiveGauge:
         return last < 0 or last <= self._DENSE * self.num_rows or self.calls % self._RETRY == 0
 
     def publish(self):
-        self.host.copy_(self.dev, non_blocking=True)
+        if self.slot is not None:
+            self.host.copy_(self.dev, non_blocking=True)
 
 
 _GAUGES = {}
@@ -112,9 +130,11 @@ def _live_gauge(plan, F, relu, dev):
     key = (id(plan), F, bool(relu))
     g = _GAUGES.get(key)
     if g is None or g.plan_ref() is not plan:
+        if g is not None:
+            g.release()
         if len(_GAUGES) >= 256:  # mini-batch training builds plans by the thousand: drop the dead ones
             for k in [k for k, v in _GAUGES.items() if v.plan_ref() is None]:
-                del _GAUGES[k]
+                _GAUGES.pop(k).release()
         g = _LiveGauge(plan.num_rows, dev)
         g.plan_ref = weakref.ref(plan)
         _GAUGES[key] = g
