@@ -40,6 +40,11 @@ def parse():
     ap.add_argument("--defer", action="store_true",
                     help="deferred weight_I update (functional.defer_input_grad): no stored gradient, Adam "
                          "inside the kernel that recomputes it; measured no faster, off by default")
+    ap.add_argument("--reorder", action="store_true",
+                    help="relabel the nodes of the synthetic graph so that those within reach of the labels "
+                         "come first (mrgcn_amd.data.reorder): the rest of weight_I then never receives "
+                         "gradient and whole chunks of it are skipped by the backward and by Adam.  Off by "
+                         "default: the benchmark graph keeps the generator's (random) numbering")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="launch every kernel of the epoch eagerly instead of replaying the epoch captured into a "
                          "hipGraph (GraphedTrainStep: one launch per epoch instead of ~40; AIFB 0.41 -> 0.26 ms, "
@@ -147,6 +152,11 @@ def main():
     dims = synth.layer_dims(name)
     featureless = sh["x_width"] == 0
     idx_np, y_np = synth.make_labels(name, N, args.seed, args.scale)
+    if args.reorder:
+        from mrgcn_amd.data import reorder
+        order, inv = reorder.label_reach_order(g.rows, g.cols, N, R, idx_np, hops=len(dims))
+        g.rows, g.cols = reorder.relabel_coo(g.rows, g.cols, N, inv)
+        idx_np = inv[idx_np]
     A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
                                 (N, R * N)).to(dev)
     torch.manual_seed(args.seed)
@@ -279,6 +289,7 @@ def main():
                        "N": N, "R": R, "nnz": plan.nnz, "ncols_touched": plan.ncols,
                        "layers": dims, "num_bases": B, "value_mode": args.value_mode,
                        "engine": args.engine, "operand": args.operand, "weight_I_update": "deferred" if args.defer else "stored-grad",
+                       "node_order": "label reach first" if args.reorder else "generator (random)",
                        "launch": "hipGraph replay" if graph_used else "eager", "labelled": int(idx.numel()), "params": n_params,
                        "parallelism": ("node-partitioned x%d" % world if partitioned else
                                        "replicas x%d" % world) if world > 1 else "1 GPU"},

@@ -191,8 +191,24 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64_t l
  * and where a kernel has to read every row they are overwritten with zeros first (hence the
  * non-const dM). */
 int mrgcn_basis_mix_bwd_live_f32(const mrgcn_plan_t *plan, float *dM, int64_t ldM,
-                                 const uint8_t *col_live, const float *V, const float *comp, int32_t B,
-                                 int32_t F, float *dV, float *dcomp, double *dV_sumsq, void *stream);
+                                 const uint8_t *col_live, const uint8_t *chunk_live, const float *V,
+                                 const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
+                                 double *dV_sumsq, void *stream);
+/* Liveness of the basis table's gradient at the granularity Adam can skip: one byte per
+ * MRGCN_WEIGHT_CHUNK consecutive floats of a basis slab (the same pattern in every slab).  A node
+ * without a live compact column has a zero gradient row in every basis; with a fixed label set it
+ * never has any other, its Adam moments stay zero and its parameters never move — exactly.
+ *   mrgcn_weight_chunks(plan, F)      number of chunks = ceil(N*F / MRGCN_WEIGHT_CHUNK)
+ *   mrgcn_weight_chunks_live          cur[c] = 1 iff a node with a live column has elements in chunk c
+ *                                     (cur is overwritten); ever[c] |= cur[c] (caller keeps it
+ *                                     across steps, zero-initialised)
+ * `chunk_live` = cur handed to mrgcn_basis_mix_bwd_live_f32 makes it skip — neither read V nor write
+ * dV for — the node groups that lie in dead chunks: dV is then UNWRITTEN there, and only
+ * mrgcn_adam_step_chunked_f32 may consume it. */
+#define MRGCN_WEIGHT_CHUNK 1024
+int64_t mrgcn_weight_chunks(const mrgcn_plan_t *plan, int32_t F);
+int mrgcn_weight_chunks_live(const mrgcn_plan_t *plan, const uint8_t *col_live, int32_t F, uint8_t *cur,
+                             uint8_t *ever, void *stream);
 /* Deferred update of the basis table V (= weight_I, the 2.67 GB parameter at AM scale):
  * clip_grad_norm_ needs ||dV|| before any parameter may move, so
  *   pass 1  mrgcn_basis_mix_bwd_f32 with dV = NULL: dcomp and *dV_sumsq only, dV is not stored;
@@ -314,6 +330,14 @@ int mrgcn_distmult_ranks(const float *E, int64_t ldE, int64_t num_nodes, const f
  * bias corrections live in device memory, so a captured epoch replays with the right step.
  * mrgcn_adam_bias_f32: ++*step_dev; bc_dev[0] = 1 - beta1^step, bc_dev[1] = sqrt(1 - beta2^step).
  * mrgcn_adam_step_dev_f32: mrgcn_adam_step_f32 reading the corrections from bc_dev. */
+/* mrgcn_adam_step_f32 / _dev_f32 (weight_decay = 0) on a parameter of B slabs of `slab_elems` floats
+ * whose gradient is live only in the chunks flagged by mrgcn_weight_chunks_live: chunks with
+ * ever = 0 are not touched (g = m = v = 0: the update is the identity), chunks with ever = 1, cur = 0
+ * are updated with g = 0 without reading grad.  `bc_dev` nullable (then `step` >= 1 is used). */
+int mrgcn_adam_step_chunked_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                int64_t slab_elems, int32_t B, const uint8_t *cur, const uint8_t *ever,
+                                float lr, float beta1, float beta2, float eps, int64_t step,
+                                const float *bc_dev, const float *grad_scale, void *stream);
 int mrgcn_adam_bias_f32(int64_t *step_dev, float beta1, float beta2, float *bc_dev, void *stream);
 int mrgcn_adam_step_dev_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                             int64_t n, float lr, float beta1, float beta2, float eps,

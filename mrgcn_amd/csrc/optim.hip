@@ -97,6 +97,56 @@ __global__ void k_sumsq(const float *__restrict__ x, int64_t n, double *__restri
 }
 
 // clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6))
+// Adam on a [B][slab] parameter whose gradient lives only in some 1024-float chunks of each slab
+// (the same chunks in every slab: weight_I with few labelled nodes).  `ever[c]` = 0: chunk c never
+// received gradient — g = m = v = 0, the update is a no-op and nothing is touched (weight_decay must
+// be 0); `cur[c]` = 0 but ever: the gradient is zero this step (g is not read: its chunk may be unwritten).
+__global__ __launch_bounds__(256) void k_adam_chunked(float *__restrict__ p, const float *__restrict__ g,
+                                                      float *__restrict__ m, float *__restrict__ v,
+                                                      int64_t slab4, int B, int64_t nch,
+                                                      const uint8_t *__restrict__ cur,
+                                                      const uint8_t *__restrict__ ever, float lr, float b1,
+                                                      float b2, float eps, float bc1, float bc2_sqrt,
+                                                      const float *__restrict__ scale,
+                                                      const float *__restrict__ bc_dev) {
+  if (bc_dev) {
+    bc1 = bc_dev[0];
+    bc2_sqrt = bc_dev[1];
+  }
+  const float sc = scale ? *scale : 1.f;
+  const float step = lr / bc1;
+  float4 *p4 = reinterpret_cast<float4 *>(p);
+  const float4 *g4 = reinterpret_cast<const float4 *>(g);
+  float4 *m4 = reinterpret_cast<float4 *>(m);
+  float4 *v4 = reinterpret_cast<float4 *>(v);
+  auto upd = [&](float &pp, float gg, float &mm, float &vv) {  // == k_adam with wd = 0
+    gg *= sc;
+    mm = fmaf(b1, mm, (1.f - b1) * gg);
+    vv = fmaf(b2, vv, (1.f - b2) * gg * gg);
+    float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= step * (mm / denom);
+  };
+  // the loop of k_adam (one linear stream over the whole parameter) with the chunk flags looked up
+  // per float4: q = position inside its slab, chunk = q / 256
+  const int64_t nv = slab4 * B;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = i % slab4;
+    const int64_t c = q >> 8;
+    if (!ever[c]) continue;
+    float4 P = p4[i], M = m4[i], V = v4[i];
+    float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cur[c]) G = g4[i];
+    upd(P.x, G.x, M.x, V.x);
+    upd(P.y, G.y, M.y, V.y);
+    upd(P.z, G.z, M.z, V.z);
+    upd(P.w, G.w, M.w, V.w);
+    p4[i] = P;
+    m4[i] = M;
+    v4[i] = V;
+  }
+}
+
 __global__ void k_clip_coef(const double *__restrict__ sumsq, float max_norm, float *__restrict__ coef,
                             float *__restrict__ norm) {
   float nrm = (float)sqrt(*sumsq);
@@ -293,6 +343,27 @@ __global__ void k_adam_bias(int64_t *__restrict__ step, float b1, float b2, floa
 }  // namespace mrgcn
 
 extern "C" {
+
+int mrgcn_adam_step_chunked_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                int64_t slab_elems, int32_t B, const uint8_t *cur, const uint8_t *ever,
+                                float lr, float beta1, float beta2, float eps, int64_t step,
+                                const float *bc_dev, const float *grad_scale, void *stream) {
+  MRGCN_REQUIRE(param && grad && exp_avg && exp_avg_sq && cur && ever, "NULL");
+  MRGCN_REQUIRE(step >= 1 || bc_dev, "step counts from 1");
+  MRGCN_REQUIRE(slab_elems > 0 && slab_elems % 4 == 0 && B > 0, "slab_elems must be a multiple of 4");
+  MRGCN_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                "16-byte alignment");
+  const double bc1 = bc_dev ? 1.0 : 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = bc_dev ? 1.0 : 1.0 - pow((double)beta2, (double)step);
+  const int64_t nch = (slab_elems + 1023) >> 10;
+  int64_t blocks = ((slab_elems >> 2) * B + 255) / 256;
+  if (blocks > 8192) blocks = 8192;  // as mrgcn_adam_step_f32
+  mrgcn::k_adam_chunked<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
+      param, grad, exp_avg, exp_avg_sq, slab_elems >> 2, B, nch, cur, ever, lr, beta1, beta2, eps, (float)bc1,
+      (float)sqrt(bc2), grad_scale, bc_dev);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
 
 int mrgcn_adam_bias_f32(int64_t *step_dev, float beta1, float beta2, float *bc_dev, void *stream) {
   MRGCN_REQUIRE(step_dev && bc_dev, "NULL");

@@ -362,6 +362,8 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
 // Needs (N*F) % 4 == 0 and 16-byte aligned V / dV / p / m / v.
 // =====================================================================================
 constexpr int kNodeTB = 1024;  // 16 waves, one block per CU: 16 wave tiles + dcomp accumulators
+constexpr int kWChunkShift = 10;  // liveness of weight_I is kept per 1024 consecutive floats of a basis slab
+static_assert((1 << kWChunkShift) == MRGCN_WEIGHT_CHUNK, "header and kernels disagree");
 constexpr int kGroup = 4;      // consecutive nodes per wave step
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -379,7 +381,8 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
                                                           float *__restrict__ dcomp,
                                                           double *__restrict__ sumsq, AdamArgs ad,
                                                           int top_rel,
-                                                          const uint8_t *__restrict__ col_live) {
+                                                          const uint8_t *__restrict__ col_live,
+                                                          const uint8_t *__restrict__ chunk_cur) {
   extern __shared__ __align__(16) float s_mem[];  // 16 wave tiles [B][rs] | dcomp accumulators [R*B]
   const int row = kGroup * F;  // floats per basis in a wave tile
   const int rs = row | 1;      // odd LDS stride: lanes (bases) fall on different banks
@@ -405,6 +408,12 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
     const int64_t j0 = g * kGroup;
     const int64_t base = j0 * F;
     const int64_t left4 = (slab - base) >> 2;  // float4s left in a slab from the group's start
+    if (chunk_cur) {
+      // no node with gradient in the 4 KB chunks of the slab that this group's rows lie in: nothing
+      // is read, nothing is written — the masked Adam (mrgcn_adam_step_chunked_f32) never looks there
+      const int64_t last = (base + row - 1 < slab ? base + row - 1 : slab - 1);
+      if (!chunk_cur[base >> kWChunkShift] && !chunk_cur[last >> kWChunkShift]) continue;
+    }
     // wave-uniform values travel through SGPRs: one lane loads, v_readlane hands them out
     int32_t cp[kGroup + 1];
     {
@@ -1034,7 +1043,7 @@ template <int MODE, bool DCOMP>
 int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
                         const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
                         double *dV_sumsq, const mrgcn::AdamArgs &ad, hipStream_t s,
-                        const uint8_t *col_live = nullptr) {
+                        const uint8_t *col_live = nullptr, const uint8_t *chunk_cur = nullptr) {
   static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
@@ -1065,7 +1074,8 @@ int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, con
       lds_allowed = lds;                                                                                  \
     }                                                                                                     \
     kfn<<<dim3((unsigned)grid), dim3(kNodeTB), lds, s>>>(p->nptr, p->urel, dM, ldM, V, comp, N, R, B, F, dV, \
-                                                         dcomp, dV_sumsq, ad, (int)p->top_rel, col_live); \
+                                                         dcomp, dV_sumsq, ad, (int)p->top_rel, col_live,  \
+                                                         chunk_cur);                                      \
   } while (0)
   switch (FT) {
     case 4: NODE_GO(4); break;
@@ -1142,13 +1152,48 @@ int mrgcn_basis_mix_bwd_adam_f32(const mrgcn_plan_t *p, const float *dM, int64_t
 int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
                             const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
                             double *dV_sumsq, void *stream) {
-  return mrgcn_basis_mix_bwd_live_f32(p, const_cast<float *>(dM), ldM, nullptr, V, comp, B, F, dV, dcomp,
-                                      dV_sumsq, stream);
+  return mrgcn_basis_mix_bwd_live_f32(p, const_cast<float *>(dM), ldM, nullptr, nullptr, V, comp, B, F, dV,
+                                      dcomp, dV_sumsq, stream);
+}
+
+// flags per node -> flags per 1024-float chunk of a basis slab of V / dV
+__global__ void k_weight_chunks_live(const int32_t *__restrict__ nptr, const uint8_t *__restrict__ col_live,
+                                     int64_t N, int F, uint8_t *__restrict__ cur, uint8_t *__restrict__ ever) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    bool live = false;
+    for (int32_t c = nptr[j]; c < nptr[j + 1] && !live; ++c) live = col_live[c] != 0;
+    if (!live) continue;
+    const int64_t c0 = (j * F) >> mrgcn::kWChunkShift, c1 = (j * F + F - 1) >> mrgcn::kWChunkShift;
+    for (int64_t c = c0; c <= c1; ++c) {
+      cur[c] = 1;
+      ever[c] = 1;
+    }
+  }
+}
+
+int64_t mrgcn_weight_chunks(const mrgcn_plan_t *p, int32_t F) {
+  return p ? ((p->num_nodes * (int64_t)F + MRGCN_WEIGHT_CHUNK - 1) >> mrgcn::kWChunkShift) : 0;
+}
+
+int mrgcn_weight_chunks_live(const mrgcn_plan_t *p, const uint8_t *col_live, int32_t F, uint8_t *cur,
+                             uint8_t *ever, void *stream) {
+  MRGCN_REQUIRE(p && col_live && cur && ever && F > 0, "NULL");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nch = mrgcn_weight_chunks(p, F);
+  MRGCN_HIP_TRY(hipMemsetAsync(cur, 0, (size_t)nch, s));
+  if (p->num_nodes > 0) {
+    int64_t blocks = (p->num_nodes + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    k_weight_chunks_live<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p->nptr, col_live, p->num_nodes, F, cur, ever);
+    MRGCN_HIP_TRY(hipGetLastError());
+  }
+  return MRGCN_OK;
 }
 
 int mrgcn_basis_mix_bwd_live_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const uint8_t *col_live,
-                                 const float *V, const float *comp, int32_t B, int32_t F, float *dV,
-                                 float *dcomp, double *dV_sumsq, void *stream) {
+                                 const uint8_t *chunk_live, const float *V, const float *comp, int32_t B,
+                                 int32_t F, float *dV, float *dcomp, double *dV_sumsq, void *stream) {
   MRGCN_REQUIRE(p && dM && V && comp && dcomp, "NULL");
   MRGCN_REQUIRE(dV || dV_sumsq, "dV may be NULL only when dV_sumsq is wanted (deferred update)");
   MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
@@ -1158,10 +1203,14 @@ int mrgcn_basis_mix_bwd_live_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, 
   MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)R * B * sizeof(float), s));
   {  // one pass for dV and dcomp when the shape allows it
     mrgcn::AdamArgs none{};
-    int rc = dV ? mix_bwd_node_launch<0, true>(p, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, none, s, col_live)
-                : mix_bwd_node_launch<1, true>(p, dM, ldM, V, comp, B, F, nullptr, dcomp, dV_sumsq, none, s, col_live);
+    int rc = dV ? mix_bwd_node_launch<0, true>(p, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, none, s, col_live,
+                                               chunk_live)
+                : mix_bwd_node_launch<1, true>(p, dM, ldM, V, comp, B, F, nullptr, dcomp, dV_sumsq, none, s, col_live,
+                                               chunk_live);
     if (rc >= 0) return rc;
   }
+  // (`chunk_live` only lets the wave-per-node kernel leave dead chunks alone; the kernels below write
+  // every row of dV, which is just as good for the masked Adam)
   // the two-kernel form reads every row of dM: rows flagged dead may be unwritten
   if (col_live) {
     int rc = zero_dead_rows(dM, ldM, F, col_live, p->ncols, s);

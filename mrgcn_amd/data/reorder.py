@@ -1,0 +1,45 @@
+"""Node numbering for semi-supervised training.
+
+With a handful of labelled nodes only the nodes within `num_layers` in-neighbour steps of a label
+ever receive gradient in the input layer's node table (`weight_I`, graph.py:62-75): every other
+row of it has a zero gradient, zero Adam moments and never moves.  The HIP backward and `ClipAdam`
+skip such rows at the granularity of 4 KB chunks of the table (functional.sparse_weight_grad), so
+the saving depends on how the reachable nodes are numbered: scattered over the id range (any KG
+whose ids follow first appearance in the dump) nearly every chunk holds one; numbered first, the
+rest of the table is never touched.  The reference numbers nodes arbitrarily (the order of
+`mkdataset`'s entity index), so renumbering is a pure relabelling of the dataset:
+
+    order, inv = label_reach_order(rows, cols, N, R, idx, hops=num_layers)
+    rows, cols = relabel_coo(rows, cols, N, inv)         # adjacency N x (R*N)
+    X, idx     = X[order], inv[idx]                      # features, labelled nodes
+    # logits_new[inv] are the logits of the original numbering
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+def label_reach_order(rows, cols, num_nodes: int, num_relations: int, idx, hops: int = 2):
+    """`order` (new id -> old id) and `inv` (old id -> new id): first, in rising old id, the nodes
+    that rows within `hops - 1` in-neighbour steps of `idx` read from (the nodes whose `weight_I`
+    rows can receive gradient in a `hops`-layer R-GCN); then all others, in rising old id."""
+    rows = np.asarray(rows, dtype=np.int64)
+    src = np.asarray(cols, dtype=np.int64) % num_nodes
+    reads = sp.csr_matrix((np.ones(len(rows), dtype=np.int8), (rows, src)), shape=(num_nodes, num_nodes))
+    reach = np.zeros(num_nodes, dtype=bool)
+    reach[np.asarray(idx, dtype=np.int64)] = True
+    for _ in range(hops):
+        nxt = reach.copy()
+        nxt[np.unique(reads[np.flatnonzero(reach)].indices)] = True
+        reach = nxt
+    order = np.concatenate([np.flatnonzero(reach), np.flatnonzero(~reach)]).astype(np.int64)
+    inv = np.empty(num_nodes, dtype=np.int64)
+    inv[order] = np.arange(num_nodes, dtype=np.int64)
+    return order, inv
+
+
+def relabel_coo(rows, cols, num_nodes: int, inv):
+    """The stacked adjacency N x (R*N) with node ids mapped through `inv` (rows and source nodes)."""
+    rows = np.asarray(rows, dtype=np.int64)
+    cols = np.asarray(cols, dtype=np.int64)
+    rel, src = cols // num_nodes, cols % num_nodes
+    return inv[rows], rel * num_nodes + inv[src]

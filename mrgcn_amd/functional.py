@@ -79,6 +79,32 @@ _LIVE_COLS = os.environ.get("MRGCN_LIVE_COLS", "1") != "0"
 # tests: start dM as NaNs, so that any read of a row the producer left unwritten shows
 _POISON_DEAD = False
 
+# Chunk-sparse gradient of weight_I (train_step turns it on for ClipAdam without weight decay): nodes
+# without a live compact column have a zero gradient row in every basis, and with a fixed label set
+# never any other — their Adam moments stay zero and their parameters never move.  The backward then
+# leaves the 4 KB chunks of dV without any live node unwritten and ClipAdam runs
+# mrgcn_adam_step_chunked_f32, which never touches chunks that never had gradient.  How much that
+# saves depends on how the nodes are numbered: see mrgcn_amd.data.reorder.
+_SPARSE_WGRAD = False
+_WCHUNKS: dict = {}
+_WCHUNK_DENSE = 0.75  # fraction of chunks that ever had gradient above which the masks are dropped
+
+
+def sparse_weight_grad(enabled: bool) -> bool:
+    """Returns the previous setting."""
+    global _SPARSE_WGRAD
+    prev, _SPARSE_WGRAD = _SPARSE_WGRAD, bool(enabled)
+    return prev
+
+
+def pop_weight_chunks(param: torch.Tensor):
+    """(cur, ever, slab_elems, B) when this step's gradient of `param` was produced chunk-sparse."""
+    ent = _WCHUNKS.get(param.data_ptr())
+    if ent is None or not ent["fresh"] or ent["numel"] != param.numel():
+        return None
+    ent["fresh"] = False
+    return ent
+
 
 class _LiveGauge:
     """How many rows of a layer's output gradient held anything the last time it was looked at.
@@ -314,8 +340,37 @@ class _RgcnLayer(torch.autograd.Function):
                     d_wI = None if defer else torch.empty_like(weight_I)
                     d_comp = torch.empty_like(comp_I)
                     sq = torch.zeros((), dtype=torch.float64, device=dev)
+                    chunk_cur = 0
+                    stale = _WCHUNKS.get(weight_I.data_ptr())
+                    if stale is not None:
+                        stale["fresh"] = False  # a mask of an earlier step says nothing about this gradient
+                    if _SPARSE_WGRAD and not defer and live is not None and weight_I.is_contiguous():
+                        ent = _WCHUNKS.get(weight_I.data_ptr())
+                        nch = int(lib.mrgcn_weight_chunks(plan.handle, F))
+                        if ent is None or ent["numel"] != weight_I.numel() or ent["cur"].numel() != nch:
+                            ent = dict(cur=torch.zeros(nch, dtype=torch.uint8, device=dev),
+                                       ever=torch.zeros(nch, dtype=torch.uint8, device=dev),
+                                       n_ever=torch.zeros(1, dtype=torch.int32, device=dev),
+                                       n_ever_host=torch.full((1,), -1, dtype=torch.int32).pin_memory(),
+                                       numel=weight_I.numel(), slab=plan.num_nodes * F, B=comp_I.shape[1],
+                                       fresh=False, dense=False)
+                            _WCHUNKS[weight_I.data_ptr()] = ent
+                        # with most chunks live the masks only cost (AM shape, nodes numbered at random:
+                        # every chunk holds a node with gradient; + 0.16 ms): the count of the previous
+                        # step decides, and once dense the parameter stays on the plain path (`ever` is
+                        # not maintained there)
+                        if not ent["dense"] and int(ent["n_ever_host"][0]) > _WCHUNK_DENSE * nch:
+                            ent["dense"] = True
+                        if not ent["dense"]:
+                            L.check(lib.mrgcn_weight_chunks_live(plan.handle, live.data_ptr(), F,
+                                                                 ent["cur"].data_ptr(), ent["ever"].data_ptr(), s),
+                                    "mrgcn_weight_chunks_live")
+                            torch.sum(ent["ever"], dim=(0,), keepdim=True, dtype=torch.int32, out=ent["n_ever"])
+                            ent["n_ever_host"].copy_(ent["n_ever"], non_blocking=True)
+                            ent["fresh"] = True
+                            chunk_cur = ent["cur"].data_ptr()
                     L.check(lib.mrgcn_basis_mix_bwd_live_f32(
-                        plan.handle, dM.data_ptr(), ld, live.data_ptr() if live is not None else 0,
+                        plan.handle, dM.data_ptr(), ld, live.data_ptr() if live is not None else 0, chunk_cur,
                         weight_I.data_ptr(), comp_I.data_ptr(),
                         comp_I.shape[1], F, 0 if defer else d_wI.data_ptr(), d_comp.data_ptr(),
                         sq.data_ptr(), s), "mrgcn_basis_mix_bwd_live_f32")

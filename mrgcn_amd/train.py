@@ -12,7 +12,14 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
-from .functional import clear_grad_sumsq, defer_input_grad, pop_deferred, pop_grad_sumsq
+from .functional import (clear_grad_sumsq, defer_input_grad, pop_deferred, pop_grad_sumsq, pop_weight_chunks,
+                         sparse_weight_grad)
+
+
+import os
+
+# MRGCN_SPARSE_WGRAD=0 switches the chunk-sparse weight_I gradient off (A/B runs)
+_SPARSE_WGRAD_DEFAULT = os.environ.get("MRGCN_SPARSE_WGRAD", "1") != "0"
 
 
 def _stream(device) -> int:
@@ -174,6 +181,19 @@ class ClipAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
                 b1, b2 = group["betas"]
+                chunks = pop_weight_chunks(p)
+                if chunks is not None:
+                    # gradient written only where nodes with gradient live (functional.sparse_weight_grad)
+                    if float(group["weight_decay"]) != 0.0:
+                        raise L.MrgcnError("chunk-sparse gradients need weight_decay = 0 (a decayed "
+                                           "parameter moves without gradient)")
+                    bc = bias[(float(b1), float(b2))].data_ptr() if self.capturable else 0
+                    L.check(lib.mrgcn_adam_step_chunked_f32(
+                        p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                        chunks["slab"], chunks["B"], chunks["cur"].data_ptr(), chunks["ever"].data_ptr(),
+                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), bc,
+                        sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_adam_step_chunked_f32")
+                    continue
                 if self.capturable:
                     L.check(lib.mrgcn_adam_step_dev_f32(
                         p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
@@ -225,9 +245,15 @@ def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.
     # a regulariser adds its own term to weight_I's gradient: the deferred (recomputed) form
     # cannot represent that, so it is off for such steps
     prev = defer_input_grad(False) if reg else None
+    # weight_I's gradient may stay unwritten where no node has any (chunk-sparse) when the optimizer
+    # is the one that knows how to read it and nothing but the loss feeds that gradient
+    sparse_ok = (_SPARSE_WGRAD_DEFAULT and not reg and isinstance(optimizer, ClipAdam)
+                 and all(float(g["weight_decay"]) == 0.0 for g in optimizer.param_groups))
+    prev_sparse = sparse_weight_grad(sparse_ok)
     try:
         loss.backward()
     finally:
+        sparse_weight_grad(prev_sparse)
         if reg:
             defer_input_grad(prev)
     optimizer.step()

@@ -144,3 +144,23 @@ def test_numpy_plan_reference_is_consistent():
     np.testing.assert_array_equal(p["ulcol"][p["ccol"]], p["lcol"])
     np.testing.assert_array_equal(np.sort(p["rperm"]), np.arange(p["ncols"]))
     assert p["cptr"][-1] == p["nnz"] and p["nptr"][-1] == p["ncols"] and p["relptr"][-1] == p["ncols"]
+
+
+def test_label_reach_order_puts_reachable_nodes_first():
+    """data.reorder: a permutation; the nodes that rows within reach of the labels read from come
+    first (rising old id inside both groups); relabelling keeps the relation of every entry."""
+    import numpy as np
+    from mrgcn_amd.data import reorder
+    N, R = 50, 3
+    # chain 0 <- 1 <- 2 <- ... (row i reads node i+1 under relation i % 2), self loops under relation 2
+    rows = np.concatenate([np.arange(N - 1), np.arange(N)])
+    cols = np.concatenate([(np.arange(N - 1) % 2) * N + np.arange(1, N), 2 * N + np.arange(N)])
+    idx = np.array([10, 30])
+    order, inv = reorder.label_reach_order(rows, cols, N, R, idx, hops=2)
+    assert sorted(order.tolist()) == list(range(N))
+    assert (order[inv] == np.arange(N)).all()
+    assert order[:6].tolist() == [10, 11, 12, 30, 31, 32]          # 2 hops along the chain
+    assert (np.diff(order[6:]) > 0).all()
+    r2, c2 = reorder.relabel_coo(rows, cols, N, inv)
+    assert (c2 // N == cols // N).all()
+    assert (order[r2] == rows).all() and (order[c2 % N] == cols % N).all()

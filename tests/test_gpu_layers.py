@@ -370,7 +370,7 @@ def test_basis_mix_backward_with_rows_without_gradient(N, R, B, F, hub, zero_fra
     dMp[torch.from_numpy(dead).cuda()] = float("nan")
     for dv_ptr in (dV.data_ptr(), 0):
         sq.zero_()
-        L.check(lib.mrgcn_basis_mix_bwd_live_f32(plan.handle, dMp.data_ptr(), ld, liveg.data_ptr(), Vt.data_ptr(),
+        L.check(lib.mrgcn_basis_mix_bwd_live_f32(plan.handle, dMp.data_ptr(), ld, liveg.data_ptr(), 0, Vt.data_ptr(),
                                                  ct.data_ptr(), B, F, dv_ptr, dc.data_ptr(), sq.data_ptr(), s))
         np.testing.assert_allclose(dc.cpu().numpy(), want_dc, rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
@@ -436,3 +436,116 @@ def test_epoch_steps_never_read_unwritten_gradient_rows(name):
         test_epoch_steps_vs_reference_goldens(name)
     finally:
         Fn._POISON_DEAD = False
+
+
+def _sparse_label_problem(N=6000, R=3, seed=3, labelled=6):
+    """A graph with low in-degree and a handful of labels: most of the node table never gets gradient."""
+    rng = np.random.default_rng(seed)
+    nnz = N
+    rows = rng.integers(0, N, nnz); cols = rng.integers(0, (R - 1) * N, nnz)
+    ident = np.arange(N)
+    rows = np.concatenate([rows, ident]); cols = np.concatenate([cols, (R - 1) * N + ident])
+    key = np.unique(rows.astype(np.int64) * (R * N) + cols)
+    rows, cols = key // (R * N), key % (R * N)
+    vals = rng.uniform(0.2, 1.0, len(rows)).astype(np.float32)
+    idx = rng.choice(N, labelled, replace=False).astype(np.int64)
+    y = rng.integers(0, 4, labelled).astype(np.int64)
+    return rows, cols, vals, idx, y
+
+
+def _train_rgcn(rows, cols, vals, N, R, idx, y, steps, sparse, graphed=False, seed=0):
+    from mrgcn_amd import train as T
+    from mrgcn_amd.models.rgcn import RGCN
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    torch.manual_seed(seed)
+    dims = [(N, 10), (10, 4)]
+    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li == 0 else None) for li, (i, o) in enumerate(dims)]
+    model = RGCN(modules, R, N, 5, 0.0, True, False, False).cuda()
+    opt = T.ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=graphed)
+    it, tg = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
+    prev = T._SPARSE_WGRAD_DEFAULT
+    T._SPARSE_WGRAD_DEFAULT = sparse
+    try:
+        losses = []
+        if graphed:
+            step = T.GraphedTrainStep(model, lambda: model(None, A), it, tg, opt, warmup=2)
+            losses = [float(step()) for _ in range(steps - 2)]  # the two warm-up steps count
+        else:
+            losses = [float(T.train_step(model, lambda: model(None, A), it, tg, opt)) for _ in range(steps)]
+        with torch.no_grad():
+            logits = model(None, A).cpu().numpy()
+    finally:
+        T._SPARSE_WGRAD_DEFAULT = prev
+    return losses, logits, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, opt
+
+
+@pytest.mark.parametrize("reordered", [False, True])
+def test_chunk_sparse_weight_gradient_trains_exactly_like_the_dense_one(reordered):
+    """functional.sparse_weight_grad: chunks of weight_I's gradient without any live node are neither
+    written nor read, Adam never touches chunks that never had gradient — the parameters after
+    several epochs are bit for bit those of the dense path; also through a captured hipGraph, and
+    on a graph renumbered with data.reorder (logits permute with the nodes)."""
+    from mrgcn_amd import functional as Fn
+    from mrgcn_amd.data import reorder
+    N, R = 6000, 3
+    rows, cols, vals, idx, y = _sparse_label_problem(N, R)
+    if reordered:
+        order, inv = reorder.label_reach_order(rows, cols, N, R, idx, hops=2)
+        rows, cols = reorder.relabel_coo(rows, cols, N, inv)
+        idx = inv[idx]
+    dense = _train_rgcn(rows, cols, vals, N, R, idx, y, 5, sparse=False)
+    Fn._WCHUNKS.clear()
+    sparse = _train_rgcn(rows, cols, vals, N, R, idx, y, 5, sparse=True)
+    ent = next(iter(Fn._WCHUNKS.values()))
+    ever = ent["ever"].cpu().numpy()
+    assert 0 < ever.sum() < len(ever) // 2, "the test graph must leave most chunks without gradient"
+    if reordered:
+        assert ever[: ever.sum()].all(), "reachable nodes first: the live chunks are a prefix"
+    # (dcomp is summed with float atomics: the clip norm, hence every update, may differ in the last
+    # bits between any two runs — the tolerance is for that, not for the skipping)
+    tol = dict(rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(np.asarray(sparse[0]), np.asarray(dense[0]), **tol)
+    for k in dense[2]:
+        np.testing.assert_allclose(sparse[2][k], dense[2][k], err_msg=k, **tol)
+    for (pd, sd), (ps, ss) in zip(dense[3].state.items(), sparse[3].state.items()):
+        for key in ("exp_avg", "exp_avg_sq"):
+            torch.testing.assert_close(ss[key], sd[key], **tol)
+        if ps.numel() == ent["numel"]:  # weight_I: chunks that never had gradient were never touched
+            dead = torch.from_numpy(np.repeat(ever == 0, 1024)[: ent["slab"]]).cuda()
+            for key in ("exp_avg", "exp_avg_sq"):
+                assert not ss[key].view(ent["B"], -1)[:, dead].any()
+                assert not sd[key].view(ent["B"], -1)[:, dead].any()  # ... and the dense run agrees: all zeros
+    Fn._WCHUNKS.clear()
+    graphed = _train_rgcn(rows, cols, vals, N, R, idx, y, 5, sparse=True, graphed=True)
+    for k in dense[2]:
+        np.testing.assert_allclose(graphed[2][k], dense[2][k], err_msg=k, **tol)
+
+
+def test_renumbering_nodes_permutes_the_logits():
+    from mrgcn_amd.data import reorder
+    N, R = 6000, 3
+    rows, cols, vals, idx, y = _sparse_label_problem(N, R)
+    base = _train_rgcn(rows, cols, vals, N, R, idx, y, 1, sparse=False)
+    order, inv = reorder.label_reach_order(rows, cols, N, R, idx, hops=2)
+    assert sorted(order.tolist()) == list(range(N)) and (order[inv] == np.arange(N)).all()
+    r2, c2 = reorder.relabel_coo(rows, cols, N, inv)
+    # the same model on the renumbered graph: permute the node table accordingly
+    from mrgcn_amd import train as T
+    from mrgcn_amd.models.rgcn import RGCN
+    A2 = torch.sparse_coo_tensor(torch.from_numpy(np.stack([r2, c2])), torch.from_numpy(vals), (N, R * N)).cuda()
+    torch.manual_seed(0)
+    dims = [(N, 10), (10, 4)]
+    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li == 0 else None) for li, (i, o) in enumerate(dims)]
+    model = RGCN(modules, R, N, 5, 0.0, True, False, False).cuda()
+    with torch.no_grad():
+        first = next(iter(model.layers.values()))
+        w = first.weight_I.view(5, N, 10)
+        first.weight_I.copy_(w[:, torch.from_numpy(order).cuda(), :].reshape(5 * N, 10).clone())
+        logits2 = model(None, A2).cpu().numpy()
+    # `base` took one training step before its logits were read: compare the untrained forward instead
+    torch.manual_seed(0)
+    model0 = RGCN(modules, R, N, 5, 0.0, True, False, False).cuda()
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    with torch.no_grad():
+        logits0 = model0(None, A).cpu().numpy()
+    np.testing.assert_allclose(logits2[inv], logits0, rtol=1e-5, atol=1e-6)
