@@ -549,3 +549,82 @@ def test_renumbering_nodes_permutes_the_logits():
     with torch.no_grad():
         logits0 = model0(None, A).cpu().numpy()
     np.testing.assert_allclose(logits2[inv], logits0, rtol=1e-5, atol=1e-6)
+
+
+def test_chunked_adam_and_chunk_flags_through_the_c_abi():
+    """mrgcn_weight_chunks_live marks the 1024-float chunks of a basis slab that hold a node with a live
+    column; mrgcn_basis_mix_bwd_live_f32 leaves dV untouched in the other chunks;
+    mrgcn_adam_step_chunked_f32 == mrgcn_adam_step_f32 given that the gradient is zero outside the
+    `cur` chunks and the moments are zero outside the `ever` chunks — and it touches nothing there."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphPlan
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(9)
+    N, R, B, F = 3000, 4, 6, 10
+    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, 1, F, 3 * N, 0)
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    plan = GraphPlan(At, N, R)
+    unode = plan.export(L.ARR_UNODE).astype(np.int64)
+    live_nodes = np.zeros(N, bool); live_nodes[rng.choice(N, 40, replace=False)] = True
+    col_live = live_nodes[unode] & (rng.random(plan.ncols) < 0.7)
+    node_has = np.zeros(N, bool); node_has[unode[col_live]] = True
+    nch = int(lib.mrgcn_weight_chunks(plan.handle, F))
+    assert nch == (N * F + 1023) // 1024
+    want = np.zeros(nch, np.uint8)
+    for j in np.flatnonzero(node_has):
+        want[(j * F) // 1024:(j * F + F - 1) // 1024 + 1] = 1
+    cur = torch.full((nch,), 9, dtype=torch.uint8, device="cuda")
+    ever = torch.zeros(nch, dtype=torch.uint8, device="cuda"); ever[0] = 1
+    clg = torch.from_numpy(col_live.astype(np.uint8)).cuda()
+    L.check(lib.mrgcn_weight_chunks_live(plan.handle, clg.data_ptr(), F, cur.data_ptr(), ever.data_ptr(), s))
+    np.testing.assert_array_equal(cur.cpu().numpy(), want)
+    w_ever = want.copy(); w_ever[0] = 1
+    np.testing.assert_array_equal(ever.cpu().numpy(), w_ever)
+
+    # dV stays untouched (NaN here) in dead chunks, equals the dense kernel's in live ones
+    ld = 12
+    dM = rng.standard_normal((plan.ncols, ld)).astype(np.float32); dM[~col_live] = np.nan
+    V = torch.from_numpy(rng.standard_normal((B * N, F)).astype(np.float32)).cuda()
+    comp = torch.from_numpy(rng.standard_normal((R, B)).astype(np.float32)).cuda()
+    dMg = torch.from_numpy(dM).cuda()
+    outs = []
+    for chunk_ptr in (0, cur.data_ptr()):
+        dV = torch.full((B * N, F), float("nan"), device="cuda")
+        dc = torch.empty((R, B), device="cuda")
+        sq = torch.zeros((), dtype=torch.float64, device="cuda")
+        L.check(lib.mrgcn_basis_mix_bwd_live_f32(plan.handle, dMg.data_ptr(), ld, clg.data_ptr(), chunk_ptr,
+                                                 V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), dc.data_ptr(),
+                                                 sq.data_ptr(), s))
+        outs.append((dV.view(B, N * F).cpu().numpy(), dc.cpu().numpy(), float(sq)))
+    elem_live = np.repeat(want.astype(bool), 1024)[: N * F]
+    assert not np.isnan(outs[0][0]).any()
+    np.testing.assert_array_equal(outs[1][0][:, elem_live], outs[0][0][:, elem_live])
+    dead_part = outs[1][0][:, ~elem_live]  # untouched, or zeros where a 4-node group straddles a live chunk
+    assert (np.isnan(dead_part) | (dead_part == 0)).all() and np.isnan(dead_part).mean() > 0.9
+    assert not outs[0][0][:, ~elem_live].any()
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(outs[1][2], outs[0][2], rtol=1e-6)
+
+    # Adam: three steps, `cur` changing, against the plain kernel
+    n = B * N * F
+    p0 = torch.randn(n, device="cuda")
+    pa, pb = p0.clone(), p0.clone()
+    ma, va, mb, vb = (torch.zeros(n, device="cuda") for _ in range(4))
+    coef = torch.full((), 0.5, device="cuda")
+    ever_t = torch.zeros(nch, dtype=torch.uint8, device="cuda")
+    for step in (1, 2, 3):
+        cur_np = (rng.random(nch) < 0.3).astype(np.uint8)
+        cur_t = torch.from_numpy(cur_np).cuda()
+        ever_t |= cur_t
+        mask = torch.from_numpy(np.repeat(cur_np.astype(bool), 1024)[: N * F]).cuda()
+        g = torch.randn(B, N * F, device="cuda") * mask
+        g_sparse = torch.where(mask, g, torch.full_like(g, float("nan")))  # unwritten where not `cur`
+        L.check(lib.mrgcn_adam_step_f32(pa.data_ptr(), g.data_ptr(), ma.data_ptr(), va.data_ptr(), n, 0.01, 0.9, 0.999,
+                                        1e-8, 0.0, step, coef.data_ptr(), s))
+        L.check(lib.mrgcn_adam_step_chunked_f32(pb.data_ptr(), g_sparse.data_ptr(), mb.data_ptr(), vb.data_ptr(), N * F, B,
+                                                cur_t.data_ptr(), ever_t.data_ptr(), 0.01, 0.9, 0.999, 1e-8, step, 0,
+                                                coef.data_ptr(), s))
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    never = torch.from_numpy(np.repeat(ever_t.cpu().numpy() == 0, 1024)[: N * F]).cuda()
+    assert torch.equal(pb.view(B, -1)[:, never], p0.view(B, -1)[:, never])
