@@ -175,6 +175,7 @@ class ClipAdam(torch.optim.Optimizer):
                     bias[key] = ent[1]
             for (group, p), g in zip(live, grads):
                 st = self.state[p]
+                had_state = bool(st)
                 if not st:
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
@@ -187,6 +188,15 @@ class ClipAdam(torch.optim.Optimizer):
                     if float(group["weight_decay"]) != 0.0:
                         raise L.MrgcnError("chunk-sparse gradients need weight_decay = 0 (a decayed "
                                            "parameter moves without gradient)")
+                    if had_state and not chunks.get("state_synced"):
+                        # moments that were not built under these masks (a loaded checkpoint, steps taken
+                        # on the plain path): every chunk that holds a non-zero moment counts as `ever`
+                        nzm = (st["exp_avg"].view(chunks["B"], -1) != 0).any(0)
+                        nzm |= (st["exp_avg_sq"].view(chunks["B"], -1) != 0).any(0)
+                        pad = chunks["ever"].numel() * 1024 - nzm.numel()
+                        nzm = torch.nn.functional.pad(nzm, (0, pad)).view(-1, 1024).any(1)
+                        chunks["ever"] |= nzm.to(torch.uint8)
+                    chunks["state_synced"] = True
                     bc = bias[(float(b1), float(b2))].data_ptr() if self.capturable else 0
                     L.check(lib.mrgcn_adam_step_chunked_f32(
                         p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),

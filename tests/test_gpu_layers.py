@@ -628,3 +628,37 @@ def test_chunked_adam_and_chunk_flags_through_the_c_abi():
         assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
     never = torch.from_numpy(np.repeat(ever_t.cpu().numpy() == 0, 1024)[: N * F]).cuda()
     assert torch.equal(pb.view(B, -1)[:, never], p0.view(B, -1)[:, never])
+
+
+def test_chunk_sparse_adam_respects_moments_it_did_not_build():
+    """Steps on the plain path first (moments everywhere the labels of that phase reached), then the
+    chunk-sparse path with other labels: chunks that hold non-zero moments keep being updated."""
+    from mrgcn_amd import functional as Fn
+    from mrgcn_amd import train as T
+    from mrgcn_amd.models.rgcn import RGCN
+    N, R = 6000, 3
+    rows, cols, vals, idx, y = _sparse_label_problem(N, R)
+    _, _, _, idx2, y2 = _sparse_label_problem(N, R, seed=17)
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    dims = [(N, 10), (10, 4)]
+    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li == 0 else None) for li, (i, o) in enumerate(dims)]
+    results = []
+    for second_phase_sparse in (False, True):
+        Fn._WCHUNKS.clear()
+        torch.manual_seed(1)
+        model = RGCN(modules, R, N, 5, 0.0, True, False, False).cuda()
+        opt = T.ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+        prev = T._SPARSE_WGRAD_DEFAULT
+        try:
+            T._SPARSE_WGRAD_DEFAULT = False
+            for _ in range(2):
+                T.train_step(model, lambda: model(None, A), torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda(), opt)
+            T._SPARSE_WGRAD_DEFAULT = second_phase_sparse
+            for _ in range(3):
+                T.train_step(model, lambda: model(None, A), torch.from_numpy(idx2).cuda(), torch.from_numpy(y2).cuda(), opt)
+        finally:
+            T._SPARSE_WGRAD_DEFAULT = prev
+        results.append({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    assert Fn._WCHUNKS, "the second phase of the second run must have used the masks"
+    for k in results[0]:
+        np.testing.assert_allclose(results[1][k], results[0][k], rtol=1e-5, atol=1e-8, err_msg=k)
