@@ -344,6 +344,10 @@ class _RgcnLayer(torch.autograd.Function):
                     stale = _WCHUNKS.get(weight_I.data_ptr())
                     if stale is not None:
                         stale["fresh"] = False  # a mask of an earlier step says nothing about this gradient
+                        if not _SPARSE_WGRAD or stale["dense"]:
+                            # a step on the plain path may put moments where `ever` has never looked:
+                            # the next masked step rebuilds `ever` from the optimizer state
+                            stale["state_synced"] = False
                     if _SPARSE_WGRAD and not defer and live is not None and weight_I.is_contiguous():
                         ent = _WCHUNKS.get(weight_I.data_ptr())
                         nch = int(lib.mrgcn_weight_chunks(plan.handle, F))
