@@ -45,6 +45,10 @@ def parse():
                          "come first (mrgcn_amd.data.reorder): the rest of weight_I then never receives "
                          "gradient and whole chunks of it are skipped by the backward and by Adam.  Off by "
                          "default: the benchmark graph keeps the generator's (random) numbering")
+    ap.add_argument("--no-renumbered-extra", dest="renumbered_extra", action="store_false",
+                    help="skip the informational second measurement (extra.epoch_ms_nodes_renumbered: the same "
+                         "epoch on the graph renumbered by mrgcn_amd.data.reorder); N = 1, graphs up to 40 M "
+                         "non-zeros only")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="launch every kernel of the epoch eagerly instead of replaying the epoch captured into a "
                          "hipGraph (GraphedTrainStep: one launch per epoch instead of ~40; AIFB 0.41 -> 0.26 ms, "
@@ -121,6 +125,41 @@ def cpu_baseline(args, shape_name):
                    "(linear extrapolation to the full graph)"),
         "measured_ms": ms, "sample_scale": sc, "host_cores": cores,
     }
+
+
+def renumbered_epoch_ms(args, g, idx_np, y_np, dims, modules, R, N, B, featureless, x_width, dev):
+    """Informational: the same epoch after renumbering the nodes so that those within reach of the labels
+    come first (a relabelling of the dataset; logits permute with the nodes).  The half of weight_I that
+    never receives gradient is then contiguous and is skipped by the backward and by Adam."""
+    import torch
+    from mrgcn_amd.data import reorder
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
+    order, inv = reorder.label_reach_order(g.rows, g.cols, N, R, idx_np, hops=len(dims))
+    rows2, cols2 = reorder.relabel_coo(g.rows, g.cols, N, inv)
+    A2 = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows2, cols2])), torch.from_numpy(g.vals),
+                                 (N, R * N)).to(dev)
+    torch.manual_seed(args.seed)
+    model = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
+    model.set_engine(args.engine)
+    model.set_operand_dtype(args.operand)
+    X = None if featureless else torch.randn((N, x_width), device=dev)
+    idx = torch.from_numpy(inv[idx_np]).to(dev)
+    tgt = torch.from_numpy(y_np).to(dev)
+    opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=args.graph)
+    if args.graph:
+        step = GraphedTrainStep(model, lambda: model(X, A2), idx, tgt, opt, warmup=max(args.warmup, 2))
+    else:
+        def step():
+            return train_step(model, lambda: model(X, A2), idx, tgt, opt)
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / args.steps * 1e3
 
 
 def main():
@@ -251,6 +290,13 @@ def main():
         extra["spmm_transposed_ms"] = t_t
         extra["spmm_transposed_gbps"] = bytes_alg / (t_t * 1e-3) / 1e9
         del dY, dM
+        if (args.renumbered_extra and world == 1 and not args.reorder and not args.defer and not partitioned
+                and plan.nnz <= 40_000_000):
+            try:
+                extra["epoch_ms_nodes_renumbered"] = renumbered_epoch_ms(
+                    args, g, idx_np, y_np, dims, modules, R, N, B, featureless, sh["x_width"], dev)
+            except Exception as e:  # noqa: BLE001  (informational leg only)
+                extra["epoch_ms_nodes_renumbered_error"] = str(e)[:200]
         if not args.no_literal_spmm:
             try:  # the reference's own operand layout: dense (R*N) x F, 17.8 GB at AM scale
                 D = torch.randn((R * plan.num_nodes, F), device=dev)
