@@ -151,7 +151,8 @@ __global__ void k_mpos_keys(const int32_t *__restrict__ cptr, const int32_t *__r
   const int32_t b = cptr[c], e = cptr[c + 1];
   const int64_t cnt = e - b;
   int64_t hi;
-  if (cnt >= hot_min) hi = max_count - cnt;                 // in [0, max_count)
+  if (hot_min < 0) hi = 0;                                   // experiment: plain compact (node, relation) order
+  else if (cnt >= hot_min) hi = max_count - cnt;            // in [0, max_count)
   else hi = max_count + 1 + (int64_t)crow[b];               // after every hot column
   keys[c] = (hi << shift) | c;
   ids[c] = (int32_t)c;
@@ -510,7 +511,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     const int shift = bits_for(ncols);
     const int64_t max_count = p->max_col_nnz + 1;
     int hot_min = kHotMinRefs;
-    if (const char *e = getenv("MRGCN_HOT_MIN")) hot_min = atoi(e) > 1 ? atoi(e) : hot_min;  // experiments
+    if (const char *e = getenv("MRGCN_HOT_MIN")) hot_min = (atoi(e) > 1 || atoi(e) < 0) ? atoi(e) : hot_min;  // experiments
     k_mpos_keys<<<nblocks(ncols), kTB, 0, s>>>(p->cptr, p->crow, ncols, max_count, shift, hot_min, mk, ids);
     MRGCN_HIP_TRY(hipGetLastError());
     const int end_bit = shift + bits_for(max_count + 1 + p->num_rows);
