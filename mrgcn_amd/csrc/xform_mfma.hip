@@ -49,35 +49,54 @@ __device__ __forceinline__ f32x4 load4_fast(const float *p) {
 // order, the compact id and the input row of its live columns in LDS and sweeps only those.
 // 256 threads; returns the count (block uniform).
 // ---------------------------------------------------------------------------------------------
+constexpr int kLiveRounds = kRelChunk / 256;
+static_assert(kRelChunk % 256 == 0, "a chunk is compacted in rounds of 256 positions");
+constexpr size_t kLiveLds = (2 * (size_t)kRelChunk + 4 * kLiveRounds) * sizeof(int32_t);  // ids | input rows | counts
 __device__ __forceinline__ int compact_live_columns(int32_t beg, int32_t end, const int32_t *__restrict__ rperm,
                                                     const int32_t *__restrict__ rin_idx,
                                                     const uint8_t *__restrict__ col_live, int32_t *s_cid,
-                                                    int32_t *s_rin, int32_t *s_cnt /* [4] */) {
+                                                    int32_t *s_rin, int32_t *s_cnt /* [4 * kLiveRounds] */) {
+  // all (<= kRelChunk = 4 x 256) positions of the chunk in one go: the index and flag loads of the
+  // four rounds are in flight together, one pair of barriers
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int base = 0;
-  for (int32_t r0 = beg; r0 < end; r0 += 256) {
-    const int32_t e = r0 + (int32_t)threadIdx.x;
-    const int32_t c = e < end ? rperm[e] : -1;
-    const bool live = c >= 0 && col_live[c] != 0;
-    const uint64_t bal = __ballot(live);
-    if (lane == 0) s_cnt[wv] = __popcll(bal);
-    __syncthreads();
-    int off = base, tot = 0;
+  int32_t c[kLiveRounds], e[kLiveRounds];
+  bool live[kLiveRounds];
+  uint64_t bal[kLiveRounds];
+#pragma unroll
+  for (int k = 0; k < kLiveRounds; ++k) {
+    e[k] = beg + k * 256 + (int32_t)threadIdx.x;
+    c[k] = e[k] < end ? rperm[e[k]] : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < kLiveRounds; ++k) live[k] = c[k] >= 0 && col_live[c[k]] != 0;
+#pragma unroll
+  for (int k = 0; k < kLiveRounds; ++k) {
+    bal[k] = __ballot(live[k]);
+    if (lane == 0) s_cnt[k * 4 + wv] = __popcll(bal[k]);
+  }
+  __syncthreads();
+  int total = 0;
+  int off[kLiveRounds];
+#pragma unroll
+  for (int k = 0; k < kLiveRounds; ++k) {
+    off[k] = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const int n = s_cnt[w];
-      if (w < wv) off += n;
-      tot += n;
+      const int n = s_cnt[k * 4 + w];
+      if (w == wv) off[k] = total;  // chunk order: round k, then wave w, then lane
+      total += n;
     }
-    if (live) {
-      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-      s_cid[pos] = c;
-      s_rin[pos] = rin_idx ? rin_idx[e] : c;
-    }
-    base += tot;
-    __syncthreads();
   }
-  return base;
+#pragma unroll
+  for (int k = 0; k < kLiveRounds; ++k) {
+    if (live[k]) {
+      const int pos = off[k] + __popcll(bal[k] & ((1ull << lane) - 1ull));
+      s_cid[pos] = c[k];
+      s_rin[pos] = rin_idx ? rin_idx[e[k]] : c[k];
+    }
+  }
+  __syncthreads();
+  return total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -388,10 +407,9 @@ bool xform_mfma_fwd_supported(int K, int F) { return K <= kMaxKSteps * 16 && F <
 bool xform_mfma_dw_supported(int K, int F) { return K <= kMaxTQ * 64 && F <= 16 && (size_t)4 * K * F * 4 <= 64 * 1024; }
 // ... and with room in LDS for the list of live columns
 bool xform_mfma_dw_live_supported(int K, int F) {
-  return xform_mfma_dw_supported(K, F) && (size_t)4 * K * F * 4 + (2 * (size_t)kRelChunk + 4) * 4 <= 64 * 1024;
+  return xform_mfma_dw_supported(K, F) && (size_t)4 * K * F * 4 + kLiveLds <= 64 * 1024;
 }
 
-constexpr size_t kLiveLds = (2 * (size_t)kRelChunk + 4) * sizeof(int32_t);
 
 int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
                    int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out, int64_t ldOut,
