@@ -228,6 +228,13 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
   if constexpr (LIVE) {  // columns whose dM row is all zeros add nothing: sweep the others only
     end = compact_live_columns(beg, end, rperm, rin_idx, col_live, s_cid, s_rin, s_rin + kRelChunk);
     beg = 0;
+    if (end == 0) {  // block uniform: nothing live in this chunk — its partial slab is zero
+      if (slab) {
+        float *out = slab + (int64_t)chunk * K * F;
+        for (int t = threadIdx.x; t < K * F; t += blockDim.x) out[t] = 0.f;
+      }
+      return;
+    }
   }
   const int ntq = (K + 63) >> 6;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -498,6 +505,7 @@ int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, 
           p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F,  \
           dW, slab, nullptr);                                                                            \
   } while (0)
+  // (live form, K = 155, columns in flight per wave 4 / 8 / 16: 591 / 463 / 485 us)
   if (K <= 64) DW_GO(1, 2);
   else if (K <= 192) DW_GO(3, 2);
   else DW_GO(kMaxTQ, 4);
