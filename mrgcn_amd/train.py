@@ -79,6 +79,11 @@ class ClipAdam(torch.optim.Optimizer):
         self._dev_step = {}
         self._scratch = {}
         self._dist = None  # (group, ids of parameters sharded across ranks)
+        self._state_gen = 0  # bumped by load_state_dict: masks built for the old moments are re-derived
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._state_gen = getattr(self, "_state_gen", 0) + 1
 
     def set_distributed(self, group, sharded_params):
         """Node-partitioned training (mrgcn_amd.partition): `sharded_params` hold disjoint shards
@@ -188,6 +193,10 @@ class ClipAdam(torch.optim.Optimizer):
                     if float(group["weight_decay"]) != 0.0:
                         raise L.MrgcnError("chunk-sparse gradients need weight_decay = 0 (a decayed "
                                            "parameter moves without gradient)")
+                    owner = (id(self), getattr(self, "_state_gen", 0))  # this optimizer, this (possibly re-loaded) state
+                    if chunks.get("synced_for") != owner:
+                        chunks["state_synced"] = False
+                        chunks["synced_for"] = owner
                     if had_state and not chunks.get("state_synced"):
                         # moments that were not built under these masks (a loaded checkpoint, steps taken
                         # on the plain path): every chunk that holds a non-zero moment counts as `ever`
