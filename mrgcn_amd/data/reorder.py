@@ -43,3 +43,40 @@ def relabel_coo(rows, cols, num_nodes: int, inv):
     cols = np.asarray(cols, dtype=np.int64)
     rel, src = cols // num_nodes, cols % num_nodes
     return inv[rows], rel * num_nodes + inv[src]
+
+
+def relabel_csr(A, num_nodes: int, inv):
+    """The stacked CSR adjacency N x (R*N) (archive member `A`, tarball.py:151-157) renumbered."""
+    coo = sp.coo_matrix(A)
+    rows, cols = relabel_coo(coo.row, coo.col, num_nodes, inv)
+    return sp.csr_matrix((coo.data, (rows, cols)), shape=A.shape)
+
+
+def renumber_dataset(d: dict, order, inv) -> dict:
+    """A dataset archive as `mrgcn_amd.data.dataset.load_tarball` returns it (members of
+    `mkdataset.py`: A, Y, F, data, sample_map, class_map), with every node id mapped through `inv`:
+    adjacency rows / source nodes, the rows of the label matrices, the node indices of the feature
+    encodings (`[encodings, node_idx, seq_len]` per datatype) and subject / object of the link-
+    prediction triples.  Logits of a model trained on the result are those of the original numbering
+    at `logits_new[inv]`."""
+    order = np.asarray(order, dtype=np.int64)
+    inv = np.asarray(inv, dtype=np.int64)
+    N = len(order)
+    out = dict(d)
+    if d.get("A") is not None:
+        out["A"] = relabel_csr(d["A"], N, inv)
+    if d.get("Y") is not None:
+        out["Y"] = {split: (Y[order] if Y is not None else None) for split, Y in d["Y"].items()}
+    if d.get("F") is not None:
+        out["F"] = {dt: [[enc, inv[np.asarray(node_idx, dtype=np.int64)], seq_len] + list(rest)
+                         for enc, node_idx, seq_len, *rest in sets]
+                    for dt, sets in d["F"].items()}
+    if d.get("data") is not None:
+        data = {}
+        for split, triples in d["data"].items():
+            t = np.array(triples, copy=True)
+            if t.ndim == 2 and t.shape[1] >= 3 and t.size:
+                t[:, 0], t[:, 2] = inv[t[:, 0]], inv[t[:, 2]]
+            data[split] = t
+        out["data"] = data
+    return out

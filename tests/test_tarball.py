@@ -121,3 +121,35 @@ def test_adjacency_from_triples_matches_reference_builder(gname):
     assert A.shape == ref.shape and A.dtype == np.float32
     assert np.array_equal(A.indptr, ref.indptr) and np.array_equal(A.indices, ref.indices)
     assert np.array_equal(A.data, ref.data)
+
+
+def test_renumbering_a_dataset_archive_keeps_every_reference_consistent():
+    """data.reorder.renumber_dataset on the golden archive: adjacency entries, label rows, feature
+    node indices and triples all follow the permutation chosen from the training labels."""
+    import numpy as np
+    from mrgcn_amd.data import reorder
+    from mrgcn_amd.data.dataset import labels_of, load_tarball
+    d = load_tarball(TAR)
+    A = d["A"].tocsr()
+    N = A.shape[0]
+    R = A.shape[1] // N
+    idx, _ = labels_of(d["Y"]["train"])
+    coo = A.tocoo()
+    order, inv = reorder.label_reach_order(coo.row, coo.col, N, R, idx, hops=2)
+    d2 = reorder.renumber_dataset(d, order, inv)
+    A2 = d2["A"]
+    assert A2.shape == A.shape and A2.nnz == A.nnz
+    c2 = A2.tocoo()
+    back = dict(zip(zip(order[c2.row].tolist(), ((c2.col // N) * N + order[c2.col % N]).tolist()), c2.data.tolist()))
+    assert back == dict(zip(zip(coo.row.tolist(), coo.col.tolist()), coo.data.tolist()))
+    for split in d["Y"]:
+        assert (d2["Y"][split].toarray() == d["Y"][split].toarray()[order]).all()
+    i2, t2 = labels_of(d2["Y"]["train"])
+    assert sorted(order[i2].tolist()) == sorted(idx.tolist())
+    assert sorted(i2.tolist()) == sorted(inv[idx].tolist())
+    for dt in d["F"]:
+        for (e, n, s), (e2, n2, s2) in zip(d["F"][dt], d2["F"][dt]):
+            assert (e2 == e).all() and (order[n2] == n).all() and (s2 == s).all()
+    for split in d["data"]:
+        t, t2_ = np.asarray(d["data"][split]), d2["data"][split]
+        assert (order[t2_[:, 0]] == t[:, 0]).all() and (t2_[:, 1] == t[:, 1]).all() and (order[t2_[:, 2]] == t[:, 2]).all()
