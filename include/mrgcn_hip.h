@@ -206,6 +206,28 @@ int mrgcn_basis_mix_bwd_live_f32(const mrgcn_plan_t *plan, float *dM, int64_t ld
  * dV for — the node groups that lie in dead chunks: dV is then UNWRITTEN there, and only
  * mrgcn_adam_step_chunked_f32 may consume it. */
 #define MRGCN_WEIGHT_CHUNK 1024
+/* NODE-MAJOR optimizer space for the basis table (any node numbering): the gradient and the Adam
+ * moments of V are kept as [N][B][F] — the B rows of a node form one contiguous block — while V itself
+ * stays [B][N][F].
+ *   mrgcn_nodemajor_supported(plan, B, F)   1 when both calls below serve the shape
+ *   mrgcn_basis_mix_bwd_nodemajor_f32       as mrgcn_basis_mix_bwd_live_f32, but dV_nm[j] ([B][F]) is
+ *                                           written only for nodes with a live column and
+ *                                           node_cur[j] (one byte per node) says which
+ *   mrgcn_adam_step_nodemajor_f32           Adam (weight_decay = 0): nodes with node_ever = 0 are
+ *                                           skipped (g = m = v = 0: identity), nodes with
+ *                                           node_ever = 1, node_cur = 0 are updated with g = 0
+ *                                           without reading dV_nm; the caller maintains
+ *                                           node_ever |= node_cur across steps */
+int32_t mrgcn_nodemajor_supported(const mrgcn_plan_t *plan, int32_t B, int32_t F);
+int mrgcn_basis_mix_bwd_nodemajor_f32(const mrgcn_plan_t *plan, float *dM, int64_t ldM,
+                                      const uint8_t *col_live, const float *V, const float *comp,
+                                      int32_t B, int32_t F, float *dV_nm, uint8_t *node_cur, float *dcomp,
+                                      double *dV_sumsq, void *stream);
+int mrgcn_adam_step_nodemajor_f32(float *param, const float *grad_nm, float *exp_avg_nm,
+                                  float *exp_avg_sq_nm, int64_t N, int32_t B, int32_t F,
+                                  const uint8_t *node_cur, const uint8_t *node_ever, float lr, float beta1,
+                                  float beta2, float eps, int64_t step, const float *bc_dev,
+                                  const float *grad_scale, void *stream);
 int64_t mrgcn_weight_chunks(const mrgcn_plan_t *plan, int32_t F);
 int mrgcn_weight_chunks_live(const mrgcn_plan_t *plan, const uint8_t *col_live, int32_t F, uint8_t *cur,
                              uint8_t *ever, void *stream);

@@ -64,6 +64,10 @@ SIGNATURES = {
                                                C.c_float, C.c_float, C.c_float, _i64, _p, _p]),
     "mrgcn_rel_transform_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _i64, _p]),
     "mrgcn_basis_mix_bwd_live_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p]),
+    "mrgcn_nodemajor_supported": (C.c_int32, [_p, _i32, _i32]),
+    "mrgcn_basis_mix_bwd_nodemajor_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
+    "mrgcn_adam_step_nodemajor_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p, C.c_float, C.c_float,
+                                                C.c_float, C.c_float, _i64, _p, _p, _p]),
     "mrgcn_weight_chunks": (C.c_int64, [_p, _i32]),
     "mrgcn_weight_chunks_live": (C.c_int, [_p, _p, _i32, _p, _p, _p]),
     "mrgcn_adam_step_chunked_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, C.c_float, C.c_float, C.c_float,

@@ -147,6 +147,102 @@ __global__ __launch_bounds__(256) void k_adam_chunked(float *__restrict__ p, con
   }
 }
 
+// Adam on a [B][N][F] parameter whose gradient and moments are kept NODE-MAJOR ([N][B][F]: the B rows
+// of a node are one contiguous block).  Nodes that never had gradient (`ever` = 0) are skipped in any
+// node numbering — with few labelled nodes that is half of the AM node table — and nodes without
+// gradient this step (`cur` = 0) are updated with g = 0 without reading their (unwritten) block.
+// A block transposes a tile of T consecutive nodes through LDS: the parameter tile enters and leaves
+// as B runs of T*F floats (whole cache lines), gradient and moments as one contiguous run per node.
+// tools/micro/adam_nodemajor.hip: 5.1 TB/s — 2.36 ms for the AM table at 50 % live nodes, 3.25 ms with
+// every node live, against 3.36 ms for the 7-stream k_adam.
+template <int T>
+__global__ __launch_bounds__(256) void k_adam_nodemajor(float *__restrict__ p, const float *__restrict__ g,
+                                                        float *__restrict__ m, float *__restrict__ v, int64_t N,
+                                                        int B, int F, const uint8_t *__restrict__ cur,
+                                                        const uint8_t *__restrict__ ever, float lr, float b1,
+                                                        float b2, float eps, float bc1, float bc2_sqrt,
+                                                        const float *__restrict__ scale,
+                                                        const float *__restrict__ bc_dev) {
+  extern __shared__ __align__(16) float s_p[];  // [B][RS]
+  __shared__ int s_any;
+  if (bc_dev) {
+    bc1 = bc_dev[0];
+    bc2_sqrt = bc_dev[1];
+  }
+  const float sc = scale ? *scale : 1.f;
+  const float step = lr / bc1;
+  auto upd = [&](float &pp, float gg, float &mm, float &vv) {  // == k_adam with wd = 0
+    gg *= sc;
+    mm = fmaf(b1, mm, (1.f - b1) * gg);
+    vv = fmaf(b2, vv, (1.f - b2) * gg * gg);
+    float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= step * (mm / denom);
+  };
+  const int RS = T * F + 4;
+  const int nf4 = (B * F) >> 2;  // float4s of one node's block
+  const int64_t slab = N * F;
+  const int64_t ntiles = (N + T - 1) / T;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t j0 = tile * T;
+    const int nt = (int)((N - j0 < T) ? N - j0 : T);
+    __syncthreads();  // s_any / s_p of the previous tile are done with
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < nt && ever[j0 + threadIdx.x]) s_any = 1;
+    __syncthreads();
+    if (!s_any) continue;  // block uniform: nothing in this tile ever had gradient
+    const int run = nt * F;
+    if ((run & 3) == 0) {
+      const int run4 = run >> 2;
+      for (int q = threadIdx.x; q < B * run4; q += 256) {
+        const int b = q / run4, x = q - b * run4;
+        *reinterpret_cast<float4 *>(&s_p[b * RS + 4 * x]) =
+            *reinterpret_cast<const float4 *>(p + (int64_t)b * slab + j0 * F + 4 * x);
+      }
+    } else {  // the last, partial tile
+      for (int q = threadIdx.x; q < B * run; q += 256) {
+        const int b = q / run, x = q - b * run;
+        s_p[b * RS + x] = p[(int64_t)b * slab + j0 * F + x];
+      }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nt * nf4; q += 256) {
+      const int t = q / nf4, w = q - t * nf4;
+      if (!ever[j0 + t]) continue;
+      const int64_t i4 = (j0 + t) * (int64_t)nf4 + w;
+      float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cur[j0 + t]) G = reinterpret_cast<const float4 *>(g)[i4];
+      float4 M = reinterpret_cast<const float4 *>(m)[i4], V = reinterpret_cast<const float4 *>(v)[i4];
+      const int e0 = 4 * w;
+      int b = e0 / F, o = e0 - b * F;
+      float *pp = &s_p[b * RS + t * F + o];
+      upd(*pp, G.x, M.x, V.x);
+      if (++o == F) { o = 0; ++b; } pp = &s_p[b * RS + t * F + o];
+      upd(*pp, G.y, M.y, V.y);
+      if (++o == F) { o = 0; ++b; } pp = &s_p[b * RS + t * F + o];
+      upd(*pp, G.z, M.z, V.z);
+      if (++o == F) { o = 0; ++b; } pp = &s_p[b * RS + t * F + o];
+      upd(*pp, G.w, M.w, V.w);
+      reinterpret_cast<float4 *>(m)[i4] = M;
+      reinterpret_cast<float4 *>(v)[i4] = V;
+    }
+    __syncthreads();
+    if ((run & 3) == 0) {
+      const int run4 = run >> 2;
+      for (int q = threadIdx.x; q < B * run4; q += 256) {
+        const int b = q / run4, x = q - b * run4;
+        *reinterpret_cast<float4 *>(p + (int64_t)b * slab + j0 * F + 4 * x) =
+            *reinterpret_cast<const float4 *>(&s_p[b * RS + 4 * x]);
+      }
+    } else {
+      for (int q = threadIdx.x; q < B * run; q += 256) {
+        const int b = q / run, x = q - b * run;
+        p[(int64_t)b * slab + j0 * F + x] = s_p[b * RS + x];
+      }
+    }
+  }
+}
+
 __global__ void k_clip_coef(const double *__restrict__ sumsq, float max_norm, float *__restrict__ coef,
                             float *__restrict__ norm) {
   float nrm = (float)sqrt(*sumsq);
@@ -361,6 +457,35 @@ int mrgcn_adam_step_chunked_f32(float *param, const float *grad, float *exp_avg,
   mrgcn::k_adam_chunked<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
       param, grad, exp_avg, exp_avg_sq, slab_elems >> 2, B, nch, cur, ever, lr, beta1, beta2, eps, (float)bc1,
       (float)sqrt(bc2), grad_scale, bc_dev);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_adam_step_nodemajor_f32(float *param, const float *grad_nm, float *exp_avg_nm, float *exp_avg_sq_nm,
+                                  int64_t N, int32_t B, int32_t F, const uint8_t *node_cur,
+                                  const uint8_t *node_ever, float lr, float beta1, float beta2, float eps,
+                                  int64_t step, const float *bc_dev, const float *grad_scale, void *stream) {
+  MRGCN_REQUIRE(param && grad_nm && exp_avg_nm && exp_avg_sq_nm && node_cur && node_ever, "NULL");
+  MRGCN_REQUIRE(step >= 1 || bc_dev, "step counts from 1");
+  MRGCN_REQUIRE(N > 0 && B > 0 && F > 0 && (N * F) % 4 == 0 && (B * F) % 4 == 0, "N*F and B*F must be multiples of 4");
+  MRGCN_REQUIRE((((uintptr_t)param | (uintptr_t)grad_nm | (uintptr_t)exp_avg_nm | (uintptr_t)exp_avg_sq_nm) & 15) == 0,
+                "16-byte alignment");
+  const double bc1 = bc_dev ? 1.0 : 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = bc_dev ? 1.0 : 1.0 - pow((double)beta2, (double)step);
+  auto lds_for = [&](int T) { return (size_t)B * (T * F + 4) * sizeof(float); };
+  const int T = lds_for(32) <= 60 * 1024 ? 32 : lds_for(16) <= 60 * 1024 ? 16 : 8;
+  MRGCN_REQUIRE(lds_for(T) <= 60 * 1024, "B * F too large for the node-major Adam tile");
+  int64_t blocks = (N + T - 1) / T;
+  if (blocks > 3072) blocks = 3072;
+  hipStream_t s = (hipStream_t)stream;
+#define NM_GO(T_)                                                                                          \
+  mrgcn::k_adam_nodemajor<T_><<<dim3((unsigned)blocks), dim3(256), lds_for(T_), s>>>(                      \
+      param, grad_nm, exp_avg_nm, exp_avg_sq_nm, N, B, F, node_cur, node_ever, lr, beta1, beta2, eps,      \
+      (float)bc1, (float)sqrt(bc2), grad_scale, bc_dev)
+  if (T == 32) NM_GO(32);
+  else if (T == 16) NM_GO(16);
+  else NM_GO(8);
+#undef NM_GO
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -382,7 +382,8 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
                                                           double *__restrict__ sumsq, AdamArgs ad,
                                                           int top_rel,
                                                           const uint8_t *__restrict__ col_live,
-                                                          const uint8_t *__restrict__ chunk_cur) {
+                                                          const uint8_t *__restrict__ chunk_cur,
+                                                          uint8_t *__restrict__ node_out) {
   extern __shared__ __align__(16) float s_mem[];  // 16 wave tiles [B][rs] | dcomp accumulators [R*B]
   const int row = kGroup * F;  // floats per basis in a wave tile
   const int rs = row | 1;      // odd LDS stride: lanes (bases) fall on different banks
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
       wave_lds_fence();
     }
     // ---- B: node by node, lane = basis
+    bool node_any[kGroup];  // MODE 3: did the node have a live column (wave uniform)
 #pragma unroll
     for (int i = 0; i < kGroup; ++i) {
       float *trow = s_tile + b * rs + i * F;
@@ -472,6 +474,7 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
 #pragma unroll
       for (int o = 0; o < FT; ++o) acc[o] = 0.f;
       const int32_t c_hi = ad.dbg_skip ? cp[i] : cp[i + 1];
+      if constexpr (MODE == 3) node_any[i] = false;
       for (int32_t cb = cp[i]; cb < c_hi; cb += 4) {
         // one load fetches the dM rows of four columns: the 16-lane group k reads column cb + k
         // (lane o of the group its feature o); v_readlane turns them into scalars
@@ -486,7 +489,9 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
           const uint64_t bl = __builtin_amdgcn_ballot_w64(cin && col_live[cc] != 0);
           live = (uint32_t)((bl & 1u) | ((bl >> 15) & 2u) | ((bl >> 30) & 4u) | ((bl >> 45) & 8u));
         }
+        if (c_hi - cb < 4) live &= (1u << (c_hi - cb)) - 1u;  // the chunk's tail belongs to the next node
         if (live == 0) continue;  // four columns without gradient
+        if constexpr (MODE == 3) node_any[i] = true;
         const float dmine = (cin && oq < F) ? dM[(int64_t)cc * ldM + oq] : 0.f;
         int r[4];
         if (off + 4 <= 64) {
@@ -537,7 +542,30 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
         }
       }
     }
-    if constexpr (MODE != 1) {
+    if constexpr (MODE == 3) {
+      // ---- C': NODE-MAJOR gradient ([N][B][F]: the B rows of a node are one contiguous block), live
+      // nodes only — the layout the node-major Adam (mrgcn_adam_step_nodemajor_f32) streams; a dead
+      // node's block is left alone and its flag says so
+      wave_lds_fence();
+      const int nf4 = (B * F) >> 2;
+#pragma unroll
+      for (int i = 0; i < kGroup; ++i) {
+        if (j0 + i >= N) break;
+        if (lane == 0) node_out[j0 + i] = node_any[i] ? 1 : 0;
+        if (!node_any[i]) continue;  // wave uniform
+        float4 *dst = reinterpret_cast<float4 *>(dV) + (j0 + i) * (int64_t)nf4;
+        for (int q = lane; q < nf4; q += 64) {
+          float x[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int e = 4 * q + k, bb = e / F;
+            x[k] = s_tile[bb * rs + i * F + (e - bb * F)];
+          }
+          dst[q] = make_float4(x[0], x[1], x[2], x[3]);
+        }
+      }
+      wave_lds_fence();
+    } else if constexpr (MODE != 1) {
       wave_lds_fence();
       // ---- C: the dV tile leaves in float4 runs
       for (int q = lane; q < B * row4; q += 64) {
@@ -1039,11 +1067,18 @@ static int zero_dead_rows(float *dM, int64_t ldM, int F, const uint8_t *col_live
 // wave-per-node form of the basis-mix backward (k_mix_bwd_node); returns MRGCN_OK when it ran,
 // -1 when the shape is outside its limits (the caller falls back to the two-kernel form), an
 // error code otherwise.
+// can the wave-per-node kernel run this shape (DCOMP form)?
+static bool node_kernel_shape_ok(const mrgcn_plan_t *p, int B, int F) {
+  const size_t lds = ((size_t)(kNodeTB / 64) * B * ((kGroup * F) | 1) + (size_t)p->num_relations * B) * sizeof(float);
+  return F <= 16 && B <= 64 && lds <= 150 * 1024 && p->num_nodes > 0 && (p->num_nodes * (int64_t)F) % 4 == 0;
+}
+
 template <int MODE, bool DCOMP>
 int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
                         const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
                         double *dV_sumsq, const mrgcn::AdamArgs &ad, hipStream_t s,
-                        const uint8_t *col_live = nullptr, const uint8_t *chunk_cur = nullptr) {
+                        const uint8_t *col_live = nullptr, const uint8_t *chunk_cur = nullptr,
+                        uint8_t *node_out = nullptr) {
   static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
@@ -1052,6 +1087,7 @@ int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, con
   bool ok = node_on && F <= 16 && B <= 64 && lds <= 150 * 1024 && N > 0 && (N * F) % 4 == 0;
   if (DCOMP) ok = ok && al16(V);
   if (MODE == 0) ok = ok && al16(dV);
+  if (MODE == 3) ok = ok && al16(dV) && node_out && (B * F) % 4 == 0;
   if (MODE == 2) ok = ok && al16(ad.p) && al16(ad.m) && al16(ad.v);
   if (!ok) return -1;
   // register arrays of exactly F features for the hidden sizes of the BASELINE configs (10, 11):
@@ -1075,7 +1111,7 @@ int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, con
     }                                                                                                     \
     kfn<<<dim3((unsigned)grid), dim3(kNodeTB), lds, s>>>(p->nptr, p->urel, dM, ldM, V, comp, N, R, B, F, dV, \
                                                          dcomp, dV_sumsq, ad, (int)p->top_rel, col_live,  \
-                                                         chunk_cur);                                      \
+                                                         chunk_cur, node_out);                            \
   } while (0)
   switch (FT) {
     case 4: NODE_GO(4); break;
@@ -1189,6 +1225,31 @@ int mrgcn_weight_chunks_live(const mrgcn_plan_t *p, const uint8_t *col_live, int
     MRGCN_HIP_TRY(hipGetLastError());
   }
   return MRGCN_OK;
+}
+
+int32_t mrgcn_nodemajor_supported(const mrgcn_plan_t *p, int32_t B, int32_t F) {
+  static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
+  if (!p || !node_on || B <= 0 || F <= 0) return 0;
+  // the Adam side transposes tiles of >= 8 nodes through LDS: [B][T*F + 4] floats
+  return node_kernel_shape_ok(p, B, F) && (B * F) % 4 == 0 && (size_t)B * (8 * F + 4) * 4 <= 60 * 1024;
+}
+
+int mrgcn_basis_mix_bwd_nodemajor_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const uint8_t *col_live,
+                                      const float *V, const float *comp, int32_t B, int32_t F, float *dV_nm,
+                                      uint8_t *node_cur, float *dcomp, double *dV_sumsq, void *stream) {
+  MRGCN_REQUIRE(p && dM && V && comp && dcomp && dV_nm && node_cur, "NULL");
+  MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
+  MRGCN_REQUIRE(mrgcn_nodemajor_supported(p, B, F), "shape not supported (mrgcn_nodemajor_supported)");
+  hipStream_t s = (hipStream_t)stream;
+  MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)p->num_relations * B * sizeof(float), s));
+  mrgcn::AdamArgs none{};
+  int rc = mix_bwd_node_launch<3, true>(p, dM, ldM, V, comp, B, F, dV_nm, dcomp, dV_sumsq, none, s, col_live, nullptr,
+                                        node_cur);
+  if (rc < 0) {
+    set_error("mrgcn_basis_mix_bwd_nodemajor_f32: operands must be 16-byte aligned");
+    return MRGCN_ERR_UNSUPPORTED;
+  }
+  return rc;
 }
 
 int mrgcn_basis_mix_bwd_live_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const uint8_t *col_live,

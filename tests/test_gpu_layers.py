@@ -662,3 +662,72 @@ def test_chunk_sparse_adam_respects_moments_it_did_not_build():
     assert Fn._WCHUNKS, "the second phase of the second run must have used the masks"
     for k in results[0]:
         np.testing.assert_allclose(results[1][k], results[0][k], rtol=1e-5, atol=1e-8, err_msg=k)
+
+
+@pytest.mark.parametrize("N,R,B,F", [(3000, 4, 6, 10), (1037 * 4, 5, 40, 10), (2048, 3, 8, 16), (1000, 3, 3, 4)])
+def test_node_major_gradient_and_adam_through_the_c_abi(N, R, B, F):
+    """mrgcn_basis_mix_bwd_nodemajor_f32 writes dV as [N][B][F] for the nodes with a live column only
+    (flags in node_cur) — the same numbers as the dense [B][N][F] kernel; mrgcn_adam_step_nodemajor_f32
+    on node-major gradient / moments == mrgcn_adam_step_f32 on the dense ones, nodes that never had
+    gradient untouched, blocks of nodes without gradient this step never read."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphPlan
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(N + B)
+    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, 1, F, 3 * N, 0)
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    plan = GraphPlan(At, N, R)
+    assert lib.mrgcn_nodemajor_supported(plan.handle, B, F) == 1
+    unode = plan.export(L.ARR_UNODE).astype(np.int64)
+    live_nodes = rng.random(N) < 0.3
+    col_live = live_nodes[unode] & (rng.random(plan.ncols) < 0.7)
+    node_has = np.zeros(N, bool); node_has[unode[col_live]] = True
+    ld = (F + 3) // 4 * 4
+    dM = rng.standard_normal((plan.ncols, ld)).astype(np.float32); dM[~col_live] = np.nan
+    V = torch.from_numpy(rng.standard_normal((B * N, F)).astype(np.float32)).cuda()
+    comp = torch.from_numpy(rng.standard_normal((R, B)).astype(np.float32)).cuda()
+    dMg = torch.from_numpy(dM).cuda()
+    clg = torch.from_numpy(col_live.astype(np.uint8)).cuda()
+    # dense reference
+    dV = torch.empty((B * N, F), device="cuda"); dc = torch.empty((R, B), device="cuda")
+    sq = torch.zeros((), dtype=torch.float64, device="cuda")
+    L.check(lib.mrgcn_basis_mix_bwd_live_f32(plan.handle, dMg.data_ptr(), ld, clg.data_ptr(), 0, V.data_ptr(),
+                                             comp.data_ptr(), B, F, dV.data_ptr(), dc.data_ptr(), sq.data_ptr(), s))
+    # node-major
+    dVn = torch.full((N, B, F), float("nan"), device="cuda"); dc2 = torch.empty((R, B), device="cuda")
+    cur = torch.full((N,), 9, dtype=torch.uint8, device="cuda")
+    sq2 = torch.zeros((), dtype=torch.float64, device="cuda")
+    L.check(lib.mrgcn_basis_mix_bwd_nodemajor_f32(plan.handle, dMg.data_ptr(), ld, clg.data_ptr(), V.data_ptr(),
+                                                  comp.data_ptr(), B, F, dVn.data_ptr(), cur.data_ptr(),
+                                                  dc2.data_ptr(), sq2.data_ptr(), s))
+    np.testing.assert_array_equal(cur.cpu().numpy(), node_has.astype(np.uint8))
+    want = dV.view(B, N, F).permute(1, 0, 2)
+    nh = torch.from_numpy(node_has).cuda()
+    assert torch.equal(dVn[nh], want[nh])
+    assert torch.isnan(dVn[~nh]).all() and not want[~nh].any()
+    np.testing.assert_allclose(dc2.cpu().numpy(), dc.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(sq2), float(sq), rtol=1e-6)
+
+    # Adam: three steps with changing `cur`
+    n = B * N * F
+    p0 = torch.randn(n, device="cuda")
+    pa, pb = p0.clone(), p0.clone()
+    ma, va = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    mb, vb = torch.zeros((N, B, F), device="cuda"), torch.zeros((N, B, F), device="cuda")
+    coef = torch.full((), 0.5, device="cuda")
+    ever = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    for step in (1, 2, 3):
+        cur_t = (torch.rand(N, device="cuda") < 0.3).to(torch.uint8)
+        ever |= cur_t
+        g = torch.randn(B, N, F, device="cuda") * cur_t.view(1, N, 1)
+        g_nm = torch.where(cur_t.bool().view(N, 1, 1), g.permute(1, 0, 2), torch.full((N, B, F), float("nan"), device="cuda")).contiguous()
+        L.check(lib.mrgcn_adam_step_f32(pa.data_ptr(), g.data_ptr(), ma.data_ptr(), va.data_ptr(), n, 0.01, 0.9, 0.999,
+                                        1e-8, 0.0, step, coef.data_ptr(), s))
+        L.check(lib.mrgcn_adam_step_nodemajor_f32(pb.data_ptr(), g_nm.data_ptr(), mb.data_ptr(), vb.data_ptr(), N, B, F,
+                                                  cur_t.data_ptr(), ever.data_ptr(), 0.01, 0.9, 0.999, 1e-8, step, 0,
+                                                  coef.data_ptr(), s))
+        assert torch.equal(pa, pb)
+        assert torch.equal(ma.view(B, N, F).permute(1, 0, 2), mb) and torch.equal(va.view(B, N, F).permute(1, 0, 2), vb)
+    never = ever == 0
+    assert torch.equal(pb.view(B, N, F)[:, never], p0.view(B, N, F)[:, never])
