@@ -450,6 +450,13 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
       }
       amask = __builtin_amdgcn_ballot_w64(nz);
     }
+    if constexpr (MODE == 3) {
+      // no column of the group's nodes carries gradient: nothing to read, nothing to write but the flags
+      if (col_live && amask == 0 && cp[kGroup] - cp[0] <= 64) {
+        if (lane < kGroup && j0 + lane < N) node_out[j0 + lane] = 0;
+        continue;
+      }
+    }
     if constexpr (DCOMP) {  // ---- A: V rows of the group -> the wave's tile
       for (int q = lane; q < B * row4; q += 64) {
         const int bb = q / row4, x = q - bb * row4;

@@ -97,6 +97,22 @@ def sparse_weight_grad(enabled: bool) -> bool:
     return prev
 
 
+# Node-major optimizer space (preferred over the chunk masks when the shape allows): the gradient of
+# weight_I is written as [N][B][F] for the nodes with gradient only and ClipAdam keeps its moments in
+# the same layout (mrgcn_adam_step_nodemajor_f32) — nodes that never had gradient are skipped whatever
+# the node numbering.  weight_I.grad stays None; the entry below carries the gradient to the optimizer.
+_NODEMAJOR: dict = {}
+_NODE_MAJOR = os.environ.get("MRGCN_NODE_MAJOR", "1") != "0"
+
+
+def pop_nodemajor(param: torch.Tensor):
+    ent = _NODEMAJOR.get(param.data_ptr())
+    if ent is None or not ent["fresh"] or ent["numel"] != param.numel():
+        return None
+    ent["fresh"] = False
+    return ent
+
+
 def pop_weight_chunks(param: torch.Tensor):
     """(cur, ever, slab_elems, B) when this step's gradient of `param` was produced chunk-sparse."""
     ent = _WCHUNKS.get(param.data_ptr())
@@ -337,54 +353,80 @@ class _RgcnLayer(torch.autograd.Function):
                     defer = _DEFER and weight_I.is_contiguous()
                     if defer and weight_I.data_ptr() in _DEFERRED:
                         raise L.MrgcnError("deferred weight_I update: the layer ran twice in one step")
-                    d_wI = None if defer else torch.empty_like(weight_I)
-                    d_comp = torch.empty_like(comp_I)
-                    sq = torch.zeros((), dtype=torch.float64, device=dev)
                     chunk_cur = 0
-                    stale = _WCHUNKS.get(weight_I.data_ptr())
-                    if stale is not None:
-                        stale["fresh"] = False  # a mask of an earlier step says nothing about this gradient
-                        if not _SPARSE_WGRAD or stale["dense"]:
-                            # a step on the plain path may put moments where `ever` has never looked:
-                            # the next masked step rebuilds `ever` from the optimizer state
-                            stale["state_synced"] = False
-                    if _SPARSE_WGRAD and not defer and live is not None and weight_I.is_contiguous():
-                        ent = _WCHUNKS.get(weight_I.data_ptr())
-                        nch = int(lib.mrgcn_weight_chunks(plan.handle, F))
-                        if ent is None or ent["numel"] != weight_I.numel() or ent["cur"].numel() != nch:
-                            ent = dict(cur=torch.zeros(nch, dtype=torch.uint8, device=dev),
-                                       ever=torch.zeros(nch, dtype=torch.uint8, device=dev),
-                                       n_ever=torch.zeros(1, dtype=torch.int32, device=dev),
-                                       n_ever_host=torch.full((1,), -1, dtype=torch.int32).pin_memory(),
-                                       numel=weight_I.numel(), slab=plan.num_nodes * F, B=comp_I.shape[1],
-                                       fresh=False, dense=False)
-                            _WCHUNKS[weight_I.data_ptr()] = ent
-                        # with most chunks live the masks only cost (AM shape, nodes numbered at random:
-                        # every chunk holds a node with gradient; + 0.16 ms): the count of the previous
-                        # step decides, and once dense the parameter stays on the plain path (`ever` is
-                        # not maintained there)
-                        if not ent["dense"] and int(ent["n_ever_host"][0]) > _WCHUNK_DENSE * nch:
-                            ent["dense"] = True
-                        if not ent["dense"]:
-                            L.check(lib.mrgcn_weight_chunks_live(plan.handle, live.data_ptr(), F,
-                                                                 ent["cur"].data_ptr(), ent["ever"].data_ptr(), s),
-                                    "mrgcn_weight_chunks_live")
-                            torch.sum(ent["ever"], dim=(0,), keepdim=True, dtype=torch.int32, out=ent["n_ever"])
-                            ent["n_ever_host"].copy_(ent["n_ever"], non_blocking=True)
-                            ent["fresh"] = True
-                            chunk_cur = ent["cur"].data_ptr()
-                    L.check(lib.mrgcn_basis_mix_bwd_live_f32(
-                        plan.handle, dM.data_ptr(), ld, live.data_ptr() if live is not None else 0, chunk_cur,
-                        weight_I.data_ptr(), comp_I.data_ptr(),
-                        comp_I.shape[1], F, 0 if defer else d_wI.data_ptr(), d_comp.data_ptr(),
-                        sq.data_ptr(), s), "mrgcn_basis_mix_bwd_live_f32")
-                    if defer:
-                        # comp_I is cloned: the optimizer may update the parameter before pass 2
-                        _DEFERRED[weight_I.data_ptr()] = dict(
-                            numel=weight_I.numel(), plan=plan, dM=dM, ld=ld, comp=comp_I.detach().clone(),
-                            B=comp_I.shape[1], F=F, sumsq=sq)
+                    nm = _NODEMAJOR.get(weight_I.data_ptr())
+                    if nm is not None:
+                        nm["fresh"] = False
+                    Bn = comp_I.shape[1]
+                    if (_SPARSE_WGRAD and _NODE_MAJOR and not defer and live is not None and weight_I.is_contiguous()
+                            and lib.mrgcn_nodemajor_supported(plan.handle, Bn, F) == 1):
+                        N_ = plan.num_nodes
+                        if nm is None or nm["numel"] != weight_I.numel() or nm["shape"] != (N_, Bn, F):
+                            nm = dict(g=torch.empty((N_, Bn, F), dtype=torch.float32, device=dev),
+                                      cur=torch.zeros(N_, dtype=torch.uint8, device=dev),
+                                      ever=torch.zeros(N_, dtype=torch.uint8, device=dev),
+                                      numel=weight_I.numel(), shape=(N_, Bn, F), fresh=False, sumsq=None)
+                            _NODEMAJOR[weight_I.data_ptr()] = nm
+                        d_comp = torch.empty_like(comp_I)
+                        sq = torch.zeros((), dtype=torch.float64, device=dev)
+                        L.check(lib.mrgcn_basis_mix_bwd_nodemajor_f32(
+                            plan.handle, dM.data_ptr(), ld, live.data_ptr(), weight_I.data_ptr(), comp_I.data_ptr(),
+                            Bn, F, nm["g"].data_ptr(), nm["cur"].data_ptr(), d_comp.data_ptr(), sq.data_ptr(), s),
+                            "mrgcn_basis_mix_bwd_nodemajor_f32")
+                        nm["ever"] |= nm["cur"]
+                        nm["sumsq"], nm["fresh"] = sq, True
+                        d_wI = None
+                        has_comp_done = True
                     else:
-                        register_grad_sumsq(d_wI, sq)  # ||dV||^2 came for free with the gradient
+                        has_comp_done = False
+                    if not has_comp_done:
+                        d_wI = None if defer else torch.empty_like(weight_I)
+                        d_comp = torch.empty_like(comp_I)
+                        sq = torch.zeros((), dtype=torch.float64, device=dev)
+                        stale = _WCHUNKS.get(weight_I.data_ptr())
+                        if stale is not None:
+                            stale["fresh"] = False  # a mask of an earlier step says nothing about this gradient
+                            if not _SPARSE_WGRAD or stale["dense"]:
+                                # a step on the plain path may put moments where `ever` has never looked:
+                                # the next masked step rebuilds `ever` from the optimizer state
+                                stale["state_synced"] = False
+                        if _SPARSE_WGRAD and not defer and live is not None and weight_I.is_contiguous():
+                            ent = _WCHUNKS.get(weight_I.data_ptr())
+                            nch = int(lib.mrgcn_weight_chunks(plan.handle, F))
+                            if ent is None or ent["numel"] != weight_I.numel() or ent["cur"].numel() != nch:
+                                ent = dict(cur=torch.zeros(nch, dtype=torch.uint8, device=dev),
+                                           ever=torch.zeros(nch, dtype=torch.uint8, device=dev),
+                                           n_ever=torch.zeros(1, dtype=torch.int32, device=dev),
+                                           n_ever_host=torch.full((1,), -1, dtype=torch.int32).pin_memory(),
+                                           numel=weight_I.numel(), slab=plan.num_nodes * F, B=comp_I.shape[1],
+                                           fresh=False, dense=False)
+                                _WCHUNKS[weight_I.data_ptr()] = ent
+                            # with most chunks live the masks only cost (AM shape, nodes numbered at random:
+                            # every chunk holds a node with gradient; + 0.16 ms): the count of the previous
+                            # step decides, and once dense the parameter stays on the plain path (`ever` is
+                            # not maintained there)
+                            if not ent["dense"] and int(ent["n_ever_host"][0]) > _WCHUNK_DENSE * nch:
+                                ent["dense"] = True
+                            if not ent["dense"]:
+                                L.check(lib.mrgcn_weight_chunks_live(plan.handle, live.data_ptr(), F,
+                                                                     ent["cur"].data_ptr(), ent["ever"].data_ptr(), s),
+                                        "mrgcn_weight_chunks_live")
+                                torch.sum(ent["ever"], dim=(0,), keepdim=True, dtype=torch.int32, out=ent["n_ever"])
+                                ent["n_ever_host"].copy_(ent["n_ever"], non_blocking=True)
+                                ent["fresh"] = True
+                                chunk_cur = ent["cur"].data_ptr()
+                        L.check(lib.mrgcn_basis_mix_bwd_live_f32(
+                            plan.handle, dM.data_ptr(), ld, live.data_ptr() if live is not None else 0, chunk_cur,
+                            weight_I.data_ptr(), comp_I.data_ptr(),
+                            comp_I.shape[1], F, 0 if defer else d_wI.data_ptr(), d_comp.data_ptr(),
+                            sq.data_ptr(), s), "mrgcn_basis_mix_bwd_live_f32")
+                        if defer:
+                            # comp_I is cloned: the optimizer may update the parameter before pass 2
+                            _DEFERRED[weight_I.data_ptr()] = dict(
+                                numel=weight_I.numel(), plan=plan, dM=dM, ld=ld, comp=comp_I.detach().clone(),
+                                B=comp_I.shape[1], F=F, sumsq=sq)
+                        else:
+                            register_grad_sumsq(d_wI, sq)  # ||dV||^2 came for free with the gradient
                 else:
                     # dense (R*N) x F gradient: zero + scatter of the touched rows
                     d_wI = torch.zeros_like(weight_I)

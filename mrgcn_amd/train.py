@@ -12,8 +12,8 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
-from .functional import (clear_grad_sumsq, defer_input_grad, pop_deferred, pop_grad_sumsq, pop_weight_chunks,
-                         sparse_weight_grad)
+from .functional import (clear_grad_sumsq, defer_input_grad, pop_deferred, pop_grad_sumsq, pop_nodemajor,
+                         pop_weight_chunks, sparse_weight_grad)
 
 
 import os
@@ -85,6 +85,22 @@ class ClipAdam(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._state_gen = getattr(self, "_state_gen", 0) + 1
 
+    def state_dict(self):
+        """torch.optim.Adam's format: moments kept node-major internally are handed out in the
+        parameter's own layout."""
+        sd = super().state_dict()
+        params = [p for g in self.param_groups for p in g["params"]]
+        state = {}
+        for k, st in sd["state"].items():
+            if isinstance(st, dict) and st.get("node_major"):
+                p = params[k]
+                st = {kk: vv for kk, vv in st.items() if kk != "node_major"}
+                for key in ("exp_avg", "exp_avg_sq"):
+                    st[key] = st[key].permute(1, 0, 2).contiguous().view_as(p)
+            state[k] = st
+        sd["state"] = state
+        return sd
+
     def set_distributed(self, group, sharded_params):
         """Node-partitioned training (mrgcn_amd.partition): `sharded_params` hold disjoint shards
         per rank (their squared norms add up across ranks); every other parameter is replicated
@@ -107,15 +123,20 @@ class ClipAdam(torch.optim.Optimizer):
         live = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
         # parameters whose gradient was left in recomputable form (functional.defer_input_grad)
         deferred = []
+        nodemajor = []  # gradient in node-major form (functional._NODEMAJOR), moments kept the same way
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
                     ent = pop_deferred(p)
                     if ent is not None:
                         deferred.append((g, p, ent))
-        if not live and not deferred:
+                        continue
+                    ent = pop_nodemajor(p)
+                    if ent is not None:
+                        nodemajor.append((g, p, ent))
+        if not live and not deferred and not nodemajor:
             return None
-        device = (live[0][1] if live else deferred[0][1]).device
+        device = (live[0][1] if live else (deferred or nodemajor)[0][1]).device
         if not all(p.device == device for _, p in live):
             raise L.MrgcnError("ClipAdam: all parameters must live on one GPU")
         sc = self._dev_scratch(device)
@@ -135,7 +156,7 @@ class ClipAdam(torch.optim.Optimizer):
                 else:
                     L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), acc.data_ptr(), s),
                             "mrgcn_sumsq_accum_f32")
-            for _, p, ent in deferred:
+            for _, p, ent in deferred + nodemajor:
                 (sc["sumsq_sharded"] if id(p) in sharded else sc["sumsq"]).add_(ent["sumsq"])
             clear_grad_sumsq()
             if self._dist:
@@ -178,9 +199,40 @@ class ClipAdam(torch.optim.Optimizer):
                     L.check(lib.mrgcn_adam_bias_f32(ent[0].data_ptr(), key[0], key[1], ent[1].data_ptr(), s),
                             "mrgcn_adam_bias_f32")
                     bias[key] = ent[1]
+            for group, p, ent in nodemajor:
+                if float(group["weight_decay"]) != 0.0:
+                    raise L.MrgcnError("node-major gradients need weight_decay = 0 (a decayed parameter "
+                                       "moves without gradient)")
+                N_, Bn, Fn_ = ent["shape"]
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros((N_, Bn, Fn_), dtype=torch.float32, device=p.device)
+                    st["exp_avg_sq"] = torch.zeros((N_, Bn, Fn_), dtype=torch.float32, device=p.device)
+                    st["node_major"] = (N_, Bn, Fn_)
+                elif not st.get("node_major"):
+                    # moments built in the parameter's layout (plain steps, a loaded checkpoint): transpose
+                    # once, and every node that holds a non-zero moment counts as `ever`
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        st[key] = st[key].reshape(Bn, N_, Fn_).permute(1, 0, 2).contiguous()
+                    st["node_major"] = (N_, Bn, Fn_)
+                    nz = (st["exp_avg"] != 0).flatten(1).any(1) | (st["exp_avg_sq"] != 0).flatten(1).any(1)
+                    ent["ever"] |= nz.to(torch.uint8)
+                st["step"] += 1
+                b1, b2 = group["betas"]
+                bc = bias[(float(b1), float(b2))].data_ptr() if self.capturable else 0
+                L.check(lib.mrgcn_adam_step_nodemajor_f32(
+                    p.data_ptr(), ent["g"].data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                    N_, Bn, Fn_, ent["cur"].data_ptr(), ent["ever"].data_ptr(), float(group["lr"]), float(b1),
+                    float(b2), float(group["eps"]), int(st["step"]), bc,
+                    sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_adam_step_nodemajor_f32")
             for (group, p), g in zip(live, grads):
                 st = self.state[p]
                 had_state = bool(st)
+                if st.get("node_major"):  # back on the plain path: moments return to the parameter's layout
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        st[key] = st[key].permute(1, 0, 2).contiguous().view_as(p)
+                    del st["node_major"]
                 if not st:
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
