@@ -28,6 +28,12 @@ ALG = {  # kernel-name prefix -> (label, bytes)
                              4 * B * N * F0 + 2 * NCOLS * LD * 4 + NCOLS * 8 + N * 4),
     "mrgcn::k_mix_bwd_node<10, 0, true>": ("dV + dcomp in one pass: V read once + dV written + dM read + relation ids",
                                            2 * 4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 4 + N * 4),
+    "mrgcn::k_mix_bwd_node<10, 3, true>": ("dV (node-major, live nodes only: half of them on this graph) + dcomp: "
+                                           "V read once + dV of the live nodes + flags",
+                                           4 * B * N * F0 + 4 * B * N * F0 // 2 + NCOLS * 2 + N * 5),
+    "mrgcn::k_adam_nodemajor<32>": ("node-major Adam: p read + written, g / m / v of the nodes that ever had gradient "
+                                    "(half of them on this graph): 2 + 5/2 streams",
+                                    2 * 4 * B * N * F0 + 5 * 4 * B * N * F0 // 2),
     "mrgcn::k_spmm<4, 4, false, float, false>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
     "mrgcn::k_spmm<4, 4, true, float, false>": ("general transposed product, F=10 (probe leg only; the epoch runs k_spmm_t_live)",
                                                 spmm_bytes(NCOLS, N, F0)),
