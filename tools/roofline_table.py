@@ -64,8 +64,10 @@ def main():
         v = sorted(d.get(k, []))
         if not v:
             continue
-        if k.startswith("mrgcn::k_adam"):
-            v = [x for x in v if x > 1000]  # the weight_I launch
+        if k == "mrgcn::k_adam<false>":
+            v = [x for x in v if x > 1000]  # the weight_I launch (absent when the node-major Adam runs)
+            if not v:
+                continue
         med = v[len(v) // 2]
         gbs = nbytes / (med * 1e-6) / GB
         print(f"| {k} | {label} | {nbytes/1e6:.0f} | {len(v)} | {med:.0f} | {gbs:.0f} | {100*gbs/PEAK:.1f} |")
