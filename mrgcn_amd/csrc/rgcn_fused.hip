@@ -405,6 +405,20 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
   const float sc = (MODE == 2 && ad.scale) ? *ad.scale : 1.f;
   float sq = 0.f;
   float hid = 0.f;
+  // MODE 3: float4 q of a node's [B][F] block gathers four tile elements; their offsets inside the
+  // tile (basis * rs + feature) are the same for every node
+  constexpr int kNmIter = (MODE == 3) ? 4 : 1;  // B * F <= 64 * 16 floats = 4 x 64 float4s
+  const int nf4 = (B * F) >> 2;
+  int nm_off[kNmIter][4];
+  if constexpr (MODE == 3) {
+#pragma unroll
+    for (int u = 0; u < kNmIter; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = 4 * (lane + 64 * u) + k, bb = e / F;
+        nm_off[u][k] = bb * rs + (e - bb * F);
+      }
+  }
   for (int64_t g = (int64_t)blockIdx.x * nw + wv; g < ngroups; g += nwaves) {
     const int64_t j0 = g * kGroup;
     const int64_t base = j0 * F;
@@ -554,21 +568,18 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
       // nodes only — the layout the node-major Adam (mrgcn_adam_step_nodemajor_f32) streams; a dead
       // node's block is left alone and its flag says so
       wave_lds_fence();
-      const int nf4 = (B * F) >> 2;
 #pragma unroll
       for (int i = 0; i < kGroup; ++i) {
         if (j0 + i >= N) break;
         if (lane == 0) node_out[j0 + i] = node_any[i] ? 1 : 0;
         if (!node_any[i]) continue;  // wave uniform
         float4 *dst = reinterpret_cast<float4 *>(dV) + (j0 + i) * (int64_t)nf4;
-        for (int q = lane; q < nf4; q += 64) {
-          float x[4];
+        const float *src = s_tile + i * F;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int e = 4 * q + k, bb = e / F;
-            x[k] = s_tile[bb * rs + i * F + (e - bb * F)];
-          }
-          dst[q] = make_float4(x[0], x[1], x[2], x[3]);
+        for (int u = 0; u < kNmIter; ++u) {
+          const int q = lane + 64 * u;
+          if (q < nf4)
+            dst[q] = make_float4(src[nm_off[u][0]], src[nm_off[u][1]], src[nm_off[u][2]], src[nm_off[u][3]]);
         }
       }
       wave_lds_fence();
