@@ -366,6 +366,11 @@ class _RgcnLayer(torch.autograd.Function):
                                       cur=torch.zeros(N_, dtype=torch.uint8, device=dev),
                                       ever=torch.zeros(N_, dtype=torch.uint8, device=dev),
                                       numel=weight_I.numel(), shape=(N_, Bn, F), fresh=False, sumsq=None)
+                            if len(_NODEMAJOR) >= 4:  # gradient buffers of models long gone: keep the newest few
+                                for k in list(_NODEMAJOR)[:len(_NODEMAJOR) - 3]:
+                                    if not _NODEMAJOR[k]["fresh"]:
+                                        del _NODEMAJOR[k]
+                            _NODEMAJOR.pop(weight_I.data_ptr(), None)
                             _NODEMAJOR[weight_I.data_ptr()] = nm
                         d_comp = torch.empty_like(comp_I)
                         sq = torch.zeros((), dtype=torch.float64, device=dev)
