@@ -216,8 +216,15 @@ class ClipAdam(torch.optim.Optimizer):
                     for key in ("exp_avg", "exp_avg_sq"):
                         st[key] = st[key].reshape(Bn, N_, Fn_).permute(1, 0, 2).contiguous()
                     st["node_major"] = (N_, Bn, Fn_)
-                    nz = (st["exp_avg"] != 0).flatten(1).any(1) | (st["exp_avg_sq"] != 0).flatten(1).any(1)
-                    ent["ever"] |= nz.to(torch.uint8)
+                    ent["seeded_for"] = None
+                owner = (id(self), getattr(self, "_state_gen", 0))
+                if ent.get("seeded_for") != owner:
+                    # these flags have not seen this optimizer's moments yet (a converted or re-loaded
+                    # state, a rebuilt gradient entry): every node with a non-zero moment counts as `ever`
+                    if st["step"] > 0:
+                        nz = (st["exp_avg"] != 0).flatten(1).any(1) | (st["exp_avg_sq"] != 0).flatten(1).any(1)
+                        ent["ever"] |= nz.to(torch.uint8)
+                    ent["seeded_for"] = owner
                 st["step"] += 1
                 b1, b2 = group["betas"]
                 bc = bias[(float(b1), float(b2))].data_ptr() if self.capturable else 0
