@@ -11,7 +11,7 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-constexpr int B = 40, F = 10, T = 32;  // T*F = 320 floats = 80 float4 per basis run
+constexpr int B = 40, F = 10;
 
 __device__ __forceinline__ void upd(float &p, float g, float &m, float &v) {
   m = fmaf(0.9f, m, 0.1f * g);
@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void k_adam_plain(float4 *p, const float4 *g, 
 }
 
 // p: [B][N][F]; g, m, v: [N][B][F]; live: one byte per node
-__global__ __launch_bounds__(256) void k_adam_nodemajor(float *p, const float *g, float *m, float *v,
+template <int T, int TB>
+__global__ __launch_bounds__(TB) void k_adam_nodemajor(float *p, const float *g, float *m, float *v,
                                                         const unsigned char *live, int64_t N) {
   __shared__ __align__(16) float s_p[B][T * F + 4];
   __shared__ int s_any;
@@ -43,14 +44,14 @@ __global__ __launch_bounds__(256) void k_adam_nodemajor(float *p, const float *g
     __syncthreads();
     if (!s_any) continue;  // block uniform
     const int run4 = nt * F / 4;  // nt*F is a multiple of 4 for full tiles (T*F = 320)
-    for (int q = threadIdx.x; q < B * run4; q += 256) {
+    for (int q = threadIdx.x; q < B * run4; q += TB) {
       const int b = q / run4, x = q - b * run4;
       const float4 t = *reinterpret_cast<const float4 *>(p + (int64_t)b * slab + j0 * F + 4 * x);
       *reinterpret_cast<float4 *>(&s_p[b][4 * x]) = t;
     }
     __syncthreads();
     // node-major side: B*F = 400 floats = 100 float4 per node
-    for (int q = threadIdx.x; q < nt * 100; q += 256) {
+    for (int q = threadIdx.x; q < nt * 100; q += TB) {
       const int t = q / 100, w = q - t * 100;
       if (!live[j0 + t]) continue;
       const int64_t i4 = (j0 + t) * 100 + w;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void k_adam_nodemajor(float *p, const float *g
       reinterpret_cast<float4 *>(v)[i4] = V;
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < B * run4; q += 256) {
+    for (int q = threadIdx.x; q < B * run4; q += TB) {
       const int b = q / run4, x = q - b * run4;
       *reinterpret_cast<float4 *>(p + (int64_t)b * slab + j0 * F + 4 * x) = *reinterpret_cast<const float4 *>(&s_p[b][4 * x]);
     }
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void k_adam_nodemajor(float *p, const float *g
 
 int main(int argc, char **argv) {
   const double frac = argc > 1 ? atof(argv[1]) : 0.5;
-  const int64_t N = 1666764 / T * T;  // whole tiles
+  const int64_t N = 1666764 / 64 * 64;  // whole tiles
   const int64_t n = (int64_t)B * N * F;
   float *p, *g, *m, *v;
   unsigned char *live;
@@ -99,15 +100,20 @@ int main(int argc, char **argv) {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
   }
   printf("plain streaming Adam: %.3f ms  (%.0f GB/s over 7 streams)\n", ms / 5, 7.0 * n * 4 / (ms / 5 * 1e-3) / 1e9);
-  for (int grid : {768, 1536, 3072}) {
+  auto run = [&](auto kern, const char *name, int tb, int grid) {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(e0));
-      for (int i = 0; i < 5; ++i) k_adam_nodemajor<<<grid, 256>>>(p, g, m, v, live, N);
+      for (int i = 0; i < 5; ++i) kern<<<grid, tb>>>(p, g, m, v, live, N);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     }
     const double bytes = 2.0 * n * 4 + 5.0 * nl * B * F * 4;
-    printf("node-major g/m/v, %.0f %% live nodes, grid %d: %.3f ms  (%.0f GB/s over %.1f GB)\n", 100.0 * nl / N, grid, ms / 5,
-           bytes / (ms / 5 * 1e-3) / 1e9, bytes / 1e9);
-  }
+    printf("node-major g/m/v, %.0f %% live nodes, %s, grid %d: %.3f ms  (%.0f GB/s over %.1f GB)\n", 100.0 * nl / N, name, grid,
+           ms / 5, bytes / (ms / 5 * 1e-3) / 1e9, bytes / 1e9);
+  };
+  run(k_adam_nodemajor<32, 256>, "T=32 256 thr", 256, 3072);
+  run(k_adam_nodemajor<32, 512>, "T=32 512 thr", 512, 3072);
+  run(k_adam_nodemajor<16, 256>, "T=16 256 thr", 256, 6144);
+  run(k_adam_nodemajor<16, 128>, "T=16 128 thr", 128, 6144);
+  run(k_adam_nodemajor<8, 128>, "T=8  128 thr", 128, 12288);
   return 0;
 }
