@@ -606,7 +606,7 @@ def test_chunked_adam_and_chunk_flags_through_the_c_abi():
     dead_part = outs[1][0][:, ~elem_live]  # untouched, or zeros where a 4-node group straddles a live chunk
     assert (np.isnan(dead_part) | (dead_part == 0)).all() and np.isnan(dead_part).mean() > 0.9
     assert not outs[0][0][:, ~elem_live].any()
-    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-5 * np.abs(outs[0][1]).max() + 1e-6)
     np.testing.assert_allclose(outs[1][2], outs[0][2], rtol=1e-6)
 
     # Adam: three steps, `cur` changing, against the plain kernel
@@ -709,7 +709,8 @@ def test_node_major_gradient_and_adam_through_the_c_abi(N, R, B, F):
     nh = torch.from_numpy(node_has).cuda()
     assert torch.equal(dVn[nh], want[nh])
     assert torch.isnan(dVn[~nh]).all() and not want[~nh].any()
-    np.testing.assert_allclose(dc2.cpu().numpy(), dc.cpu().numpy(), rtol=1e-4, atol=1e-5)  # float atomics
+    dcn = dc.cpu().numpy()  # summed with float atomics: the order, hence the last bits, differ from run to run
+    np.testing.assert_allclose(dc2.cpu().numpy(), dcn, rtol=1e-4, atol=1e-5 * np.abs(dcn).max() + 1e-6)
     np.testing.assert_allclose(float(sq2), float(sq), rtol=1e-6)
 
     # Adam: three steps with changing `cur`
