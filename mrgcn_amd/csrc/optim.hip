@@ -155,8 +155,9 @@ __global__ __launch_bounds__(256) void k_adam_chunked(float *__restrict__ p, con
 // as B runs of T*F floats (whole cache lines), gradient and moments as one contiguous run per node.
 // tools/micro/adam_nodemajor.hip: 5.1 TB/s — 2.36 ms for the AM table at 50 % live nodes, 3.25 ms with
 // every node live, against 3.36 ms for the 7-stream k_adam.
+constexpr int kNmTB = 512;  // tools/micro/adam_nodemajor.hip: 512 threads 3 % ahead of 256 at T = 32
 template <int T>
-__global__ __launch_bounds__(256) void k_adam_nodemajor(float *__restrict__ p, const float *__restrict__ g,
+__global__ __launch_bounds__(kNmTB) void k_adam_nodemajor(float *__restrict__ p, const float *__restrict__ g,
                                                         float *__restrict__ m, float *__restrict__ v, int64_t N,
                                                         int B, int F, const uint8_t *__restrict__ cur,
                                                         const uint8_t *__restrict__ ever, float lr, float b1,
@@ -194,19 +195,19 @@ __global__ __launch_bounds__(256) void k_adam_nodemajor(float *__restrict__ p, c
     const int run = nt * F;
     if ((run & 3) == 0) {
       const int run4 = run >> 2;
-      for (int q = threadIdx.x; q < B * run4; q += 256) {
+      for (int q = threadIdx.x; q < B * run4; q += kNmTB) {
         const int b = q / run4, x = q - b * run4;
         *reinterpret_cast<float4 *>(&s_p[b * RS + 4 * x]) =
             *reinterpret_cast<const float4 *>(p + (int64_t)b * slab + j0 * F + 4 * x);
       }
     } else {  // the last, partial tile
-      for (int q = threadIdx.x; q < B * run; q += 256) {
+      for (int q = threadIdx.x; q < B * run; q += kNmTB) {
         const int b = q / run, x = q - b * run;
         s_p[b * RS + x] = p[(int64_t)b * slab + j0 * F + x];
       }
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < nt * nf4; q += 256) {
+    for (int q = threadIdx.x; q < nt * nf4; q += kNmTB) {
       const int t = q / nf4, w = q - t * nf4;
       if (!ever[j0 + t]) continue;
       const int64_t i4 = (j0 + t) * (int64_t)nf4 + w;
@@ -229,13 +230,13 @@ __global__ __launch_bounds__(256) void k_adam_nodemajor(float *__restrict__ p, c
     __syncthreads();
     if ((run & 3) == 0) {
       const int run4 = run >> 2;
-      for (int q = threadIdx.x; q < B * run4; q += 256) {
+      for (int q = threadIdx.x; q < B * run4; q += kNmTB) {
         const int b = q / run4, x = q - b * run4;
         *reinterpret_cast<float4 *>(p + (int64_t)b * slab + j0 * F + 4 * x) =
             *reinterpret_cast<const float4 *>(&s_p[b * RS + 4 * x]);
       }
     } else {
-      for (int q = threadIdx.x; q < B * run; q += 256) {
+      for (int q = threadIdx.x; q < B * run; q += kNmTB) {
         const int b = q / run, x = q - b * run;
         p[(int64_t)b * slab + j0 * F + x] = s_p[b * RS + x];
       }
@@ -479,7 +480,7 @@ int mrgcn_adam_step_nodemajor_f32(float *param, const float *grad_nm, float *exp
   if (blocks > 3072) blocks = 3072;
   hipStream_t s = (hipStream_t)stream;
 #define NM_GO(T_)                                                                                          \
-  mrgcn::k_adam_nodemajor<T_><<<dim3((unsigned)blocks), dim3(256), lds_for(T_), s>>>(                      \
+  mrgcn::k_adam_nodemajor<T_><<<dim3((unsigned)blocks), dim3(mrgcn::kNmTB), lds_for(T_), s>>>(                      \
       param, grad_nm, exp_avg_nm, exp_avg_sq_nm, N, B, F, node_cur, node_ever, lr, beta1, beta2, eps,      \
       (float)bc1, (float)sqrt(bc2), grad_scale, bc_dev)
   if (T == 32) NM_GO(32);
