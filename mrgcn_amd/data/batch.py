@@ -26,6 +26,44 @@ def scipy_sparse_to_pytorch_sparse(sp_input, dtype):
                                    sp_input.shape, dtype=dtype)
 
 
+_MAX_BATCH_LENGTH = 999  # data/utils.py:109,:135: longer members do not widen the batch further
+
+
+def pad_token_sequences(seqs, pad_symbol=0, min_width=5):
+    """`seqs`: object array of 1-D integer arrays.  One `[n, L]` int64 matrix, member i left-aligned
+    in row i, the rest = `pad_symbol` (data/utils.py:135-152).  The reference fills with -1 first and
+    replaces every -1 afterwards, so a token id of -1 turns into the pad symbol as well; a member
+    longer than L is an error there (shape mismatch) and here."""
+    n = len(seqs)
+    lens = np.fromiter((len(a) for a in seqs), dtype=np.int64, count=n)
+    L = max(int(min_width), min(int(lens.max()) if n else 0, _MAX_BATCH_LENGTH))
+    if n and int(lens.max()) > L:
+        raise ValueError(f"a sequence of {int(lens.max())} tokens does not fit the padded width {L}")
+    out = np.full((n, L), pad_symbol, dtype=np.int64)
+    if n:
+        flat = np.concatenate([np.asarray(a).reshape(-1) for a in seqs]).astype(np.int64)
+        out[np.arange(L)[None, :] < lens[:, None]] = flat
+        out[out == -1] = pad_symbol
+    return out
+
+
+def pad_sparse_members(mats, time_dim=1, min_width=5):
+    """`mats`: object array of scipy CSR matrices that differ in length along `time_dim`.  Each is
+    re-declared with that dimension = `L` (no entry moves; data/utils.py:109-133)."""
+    import scipy.sparse as sp
+    n = len(mats)
+    longest = max((m.shape[time_dim] for m in mats), default=0)
+    L = max(int(min_width), min(int(longest), _MAX_BATCH_LENGTH))
+    out = np.empty(n, dtype=object)
+    for i, m in enumerate(mats):
+        if time_dim == 1:
+            out[i] = sp.csr_matrix((m.data, m.indices, m.indptr), shape=(m.shape[0], L), dtype=m.dtype)
+        else:  # rows are the time axis: the row pointer grows by empty rows
+            indptr = np.concatenate([m.indptr, np.full(max(L - m.shape[0], 0), m.indptr[-1], m.indptr.dtype)])
+            out[i] = sp.csr_matrix((m.data, m.indices, indptr), shape=(L, m.shape[1]), dtype=m.dtype)
+    return out
+
+
 class Batch:
     A = None
     X = None
@@ -38,17 +76,36 @@ class Batch:
             self.node_index = np.copy(batch_node_idx)
 
     def pad_(self, time_dim=1, pad_symbols=dict()):
-        """Only variable-length (object-array) encodings need padding; the datatypes this
-        package encodes (numeric / boolean / temporal vectors) are fixed width."""
+        """Variable-length encodings (object arrays) are brought to one width per encoding set
+        (batch.py:25-54): token sequences become an int64 matrix `[n, L]` filled with the datatype's
+        pad symbol (0 when none is given), CSR members (WKT / image rows) are widened with empty
+        columns to `L`; `L = max(max(seq_length), min(longest member, 999))`
+        (data/utils.py:109-152).  Fixed-width (numeric) encodings are left alone."""
         if self.X is None:
             return
-        for _, encoding_sets, _ in self.X[1:]:
-            for encodings, _, _ in encoding_sets:
-                if getattr(encodings, "dtype", None) == np.dtype("O"):
-                    raise NotImplementedError("variable-length encodings are outside mrgcn_amd's scope")
+        for i, (datatype, encoding_sets, _) in enumerate(self.X[1:], 1):
+            for j, (encodings, _, seq_length) in enumerate(encoding_sets):
+                if getattr(encodings, "dtype", None) != np.dtype("O"):
+                    continue
+                width = int(max(seq_length))
+                if isinstance(encodings[0], np.ndarray):
+                    padded = pad_token_sequences(encodings, pad_symbols.get(datatype, 0), width)
+                else:
+                    padded = pad_sparse_members(encodings, time_dim, width)
+                self.X[i][1][j][0] = padded
 
     def to_dense_(self):
-        return
+        """Object arrays of CSR members become one dense `[n, rows, cols]` array (batch.py:56-68)."""
+        if self.X is None:
+            return
+        import scipy.sparse as sp
+        for i, (_, encoding_sets, _) in enumerate(self.X[1:], 1):
+            for j, (encodings, _, _) in enumerate(encoding_sets):
+                if getattr(encodings, "dtype", None) != np.dtype("O") or len(encodings) == 0:
+                    continue
+                if not isinstance(encodings[0], sp.csr_matrix):
+                    continue
+                self.X[i][1][j][0] = np.stack([np.asarray(m.toarray()) for m in encodings])
 
     def as_tensors_(self):
         self.node_index = torch.from_numpy(np.asarray(self.node_index))
