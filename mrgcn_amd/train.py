@@ -310,9 +310,12 @@ def weight_regularisation(model, l1_lambda: float = 0.0, l2_lambda: float = 0.0)
     return reg
 
 
-def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.0, l2_lambda: float = 0.0):
+def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.0, l2_lambda: float = 0.0,
+               row_sparse=None):
     """One full-batch epoch.  `forward_fn()` returns the logits (e.g. `lambda: model(batch)`).
-    Returns the loss as a device scalar (no host sync)."""
+    Returns the loss as a device scalar (no host sync).  `row_sparse`: None = skip the rows of
+    weight_I's gradient / Adam update that carry no gradient whenever that is exact (ClipAdam, no
+    weight decay, no regulariser); False = always the dense gradient and the dense Adam kernel."""
     clear_grad_sumsq()
     logits = forward_fn()
     loss = categorical_crossentropy(logits, idx, targets)
@@ -325,7 +328,7 @@ def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.
     prev = defer_input_grad(False) if reg else None
     # weight_I's gradient may stay unwritten where no node has any (chunk-sparse) when the optimizer
     # is the one that knows how to read it and nothing but the loss feeds that gradient
-    sparse_ok = (_SPARSE_WGRAD_DEFAULT and not reg and isinstance(optimizer, ClipAdam)
+    sparse_ok = (row_sparse is not False and _SPARSE_WGRAD_DEFAULT and not reg and isinstance(optimizer, ClipAdam)
                  and all(float(g["weight_decay"]) == 0.0 for g in optimizer.param_groups))
     prev_sparse = sparse_weight_grad(sparse_ok)
     try:
@@ -351,10 +354,10 @@ class GraphedTrainStep:
     The graph plans must exist before capture (the warm-up steps build them); shapes are static."""
 
     def __init__(self, model, forward_fn, idx, targets, optimizer, warmup: int = 3,
-                 l1_lambda: float = 0.0, l2_lambda: float = 0.0):
+                 l1_lambda: float = 0.0, l2_lambda: float = 0.0, row_sparse=None):
         if not getattr(optimizer, "capturable", False):
             raise L.MrgcnError("GraphedTrainStep needs ClipAdam(..., capturable=True)")
-        args = (model, forward_fn, idx, targets, optimizer, l1_lambda, l2_lambda)
+        args = (model, forward_fn, idx, targets, optimizer, l1_lambda, l2_lambda, row_sparse)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

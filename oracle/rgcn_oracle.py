@@ -293,3 +293,56 @@ def spmm_t(indptr, indices, values, dY, num_cols, dtype=np.float64):
     A = sp.csr_matrix((values.astype(dtype), indices, indptr),
                       shape=(dY.shape[0], num_cols))
     return A.T @ dY.astype(dtype)
+
+
+# ---------------------------------------------------------------------------
+# the same forward, evaluated for a handful of output rows only
+# (graph.py:62-102 + rgcn.py:69-89 restricted to the rows' receptive field)
+# ---------------------------------------------------------------------------
+def rgcn_forward_at_rows(cfgs, params, X, A: sp.csr_matrix, rows, relu_last=False,
+                         chunk=65536, dtype=np.float64):
+    """Activations of the LAST layer at `rows` (sorted unique node ids), float64, without
+    ever forming an (R*N) x out operand: layer l at a set of rows needs layer l-1 at the
+    source nodes of those rows only, so a full-size graph (AM: 1.67 M nodes) is evaluated
+    for a few hundred rows in seconds.  Pinned against `rgcn_forward` by
+    tests/test_oracle_golden.py.  `params[l]` hold the reference's shapes."""
+    rows = np.asarray(rows, dtype=np.int64)
+    A = A.tocsr()
+
+    def layer_at(li, rws):
+        cfg, p = cfgs[li], params[li]
+        R, N, B, out = cfg.R, cfg.N, cfg.B, cfg.outdim
+        sub = A[rws, :].tocoo()
+        ucol, inv = np.unique(sub.col.astype(np.int64), return_inverse=True)
+        r_u, j_u = ucol // N, ucol % N
+        D = np.zeros((len(ucol), out), dtype=dtype)
+        if cfg.input_layer:
+            W_I = p["weight_I"]
+            if B > 0:  # graph.py:69-72 for the touched columns only
+                V = W_I.reshape(B, N, out)
+                comp = p["weight_I_comp"].astype(dtype)
+                for s in range(0, len(ucol), chunk):
+                    e = slice(s, s + chunk)
+                    D[e] = np.einsum("nb,bnf->nf", comp[r_u[e]], V[:, j_u[e], :].astype(dtype))
+            else:
+                D += W_I[ucol].astype(dtype)
+        if not (cfg.input_layer and cfg.featureless):
+            W_F = p["weight_F"].astype(dtype)
+            if B > 0:  # graph.py:83-85
+                W_F = np.einsum("rb,bij->rij", p["weight_F_comp"].astype(dtype), W_F)
+            src = np.unique(j_u)
+            H_src = X[src].astype(dtype) if li == 0 else layer_at(li - 1, src)
+            pos = np.searchsorted(src, j_u)
+            order = np.argsort(r_u, kind="stable")
+            bounds = np.flatnonzero(np.diff(r_u[order])) + 1
+            for grp in np.split(order, bounds):  # graph.py:93-94, one relation at a time
+                if len(grp):
+                    D[grp] += H_src[pos[grp]] @ W_F[r_u[grp[0]]]
+        sub_c = sp.csr_matrix((sub.data.astype(dtype), (sub.row, inv)), shape=(len(rws), len(ucol)))
+        Y = sub_c @ D  # graph.py:75, :95
+        if cfg.bias:
+            Y = Y + p["b"].astype(dtype)
+        act = (li < len(cfgs) - 1) or relu_last
+        return np.maximum(Y, 0.0) if act else Y
+
+    return layer_at(len(cfgs) - 1, rows)

@@ -1,0 +1,151 @@
+"""BASELINE config 5 — synthetic stress graph, 10 M nodes / 101 relation blocks / 90 M non-zeros
+(SURVEY §8 shape table; `R*N` = 1.01 G columns, several node bands): the HIP path at
+full size against numpy float64 and through size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s10m():
+    from mrgcn_amd import synth
+    from mrgcn_amd.plan import GraphPlan
+    g = synth.make_graph("synth10m", seed=0)
+    N, R = g.num_nodes, g.num_relations
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                (N, R * N)).cuda()
+    plan = GraphPlan(A, N, R)
+    A._mrgcn_plan = plan
+    return g, A, plan
+
+
+def test_config5_plan_invariants(s10m):
+    """Index arithmetic with R*N = 1.01 G columns and 77 node bands: counts, pointers, permutations."""
+    from mrgcn_amd import _lib as L
+    g, A, plan = s10m
+    N, R = g.num_nodes, g.num_relations
+    assert 2 ** 29 < R * N < 2 ** 31 and R * N * 16 * 4 > 2 ** 35  # int32 columns, 64-bit byte offsets
+    assert plan.nnz == g.nnz == 2 * len(g.triples) + N == 90_000_000
+    ucols = np.unique(g.cols)
+    assert plan.ncols == len(ucols)
+    rowptr = plan.export(L.ARR_ROWPTR).astype(np.int64)
+    assert rowptr[0] == 0 and rowptr[-1] == plan.nnz and np.all(np.diff(rowptr) >= 0)
+    assert np.array_equal(np.diff(rowptr), np.bincount(g.rows, minlength=N))
+    ulcol = plan.export(L.ARR_ULCOL).astype(np.int64)
+    urel, unode = plan.export(L.ARR_UREL).astype(np.int64), plan.export(L.ARR_UNODE).astype(np.int64)
+    assert np.array_equal(ulcol, urel * N + unode)            # no int32 wrap
+    assert np.array_equal(np.sort(ulcol), ucols)               # exactly the touched columns
+    key = unode * R + urel
+    assert np.all(np.diff(key) > 0)                            # (node, relation) order, strictly rising
+    nptr = plan.export(L.ARR_NPTR).astype(np.int64)
+    assert np.array_equal(nptr, np.searchsorted(unode, np.arange(N + 1)))
+    for arr in (L.ARR_MPOS, L.ARR_RPERM):
+        perm = plan.export(arr)
+        seen = np.zeros(plan.ncols, dtype=bool)
+        seen[perm] = True
+        assert seen.all()
+    lcol = plan.export(L.ARR_LCOL).astype(np.int64)
+    rowidx = plan.export(L.ARR_ROWIDX).astype(np.int64)
+    assert np.array_equal(np.sort(rowidx * (R * N) + lcol), np.sort(g.rows * (R * N) + g.cols))
+
+
+def _numpy_product(g, ucols_of_entry, D64, F):
+    w = g.vals.astype(np.float64)
+    Y = np.empty((g.num_nodes, F))
+    for f in range(F):
+        Y[:, f] = np.bincount(g.rows, weights=w * D64[ucols_of_entry, f], minlength=g.num_nodes)
+    return Y
+
+
+def test_config5_compact_product_vs_numpy_full_size(s10m):
+    """Y = A.M at F = 16 on all 90 M entries against a float64 numpy evaluation."""
+    from mrgcn_amd import _lib as L
+    g, A, plan = s10m
+    F = 16
+    rng = np.random.default_rng(2)
+    ulcol = plan.export(L.ARR_ULCOL).astype(np.int64)
+    mpos = plan.export(L.ARR_MPOS).astype(np.int64)
+    Mc = rng.standard_normal((plan.ncols, F)).astype(np.float32)   # compact (node, relation) order
+    M = torch.empty((plan.ncols, F), device="cuda")
+    M[torch.from_numpy(mpos).cuda()] = torch.from_numpy(Mc).cuda()
+    Y = plan.spmm(L.VIEW_COMPACT, M, F=F).cpu().numpy()
+    order = np.argsort(ulcol)
+    centry = order[np.searchsorted(ulcol[order], g.cols)]          # compact id of every entry
+    Y_ref = _numpy_product(g, centry, Mc.astype(np.float64), F)
+    np.testing.assert_allclose(Y, Y_ref, rtol=1e-4, atol=1e-4)
+    assert np.array_equal(Y, plan.spmm(L.VIEW_COMPACT, M, F=F).cpu().numpy())  # reproducible
+
+
+def test_config5_transposed_and_live_views_are_the_adjoint(s10m):
+    """<A'M, Y> = <M, A'^T Y> for the general transposed product, and the live-row form equals it
+    when only a few rows of Y hold anything."""
+    from mrgcn_amd import _lib as L
+    g, A, plan = s10m
+    F = 11
+    lib = L.load()
+    mpos = torch.from_numpy(plan.export(L.ARR_MPOS).astype(np.int64)).cuda()
+    Mc = torch.randn((plan.ncols, F), device="cuda")
+    M = torch.zeros((plan.ncols, 12), device="cuda")
+    M[mpos, :F] = Mc
+    Yw = torch.randn((g.num_nodes, F), device="cuda")
+    AM = plan.spmm(L.VIEW_COMPACT, M, F=F)
+    ATy = plan.spmm(L.VIEW_TRANSPOSED, Yw, F=F)
+    lhs = float((AM.double() * Yw.double()).sum())
+    rhs = float((Mc.double() * ATy.double()).sum())
+    assert abs(lhs - rhs) <= 5e-4 * max(1.0, abs(lhs), abs(rhs))
+    # sparse dY: 5000 live rows, hubs among them
+    deg = np.bincount(g.rows, minlength=g.num_nodes)
+    live_rows = np.unique(np.concatenate([np.argsort(deg)[-20:], np.random.default_rng(0).choice(g.num_nodes, 5000)]))
+    Ys = torch.zeros_like(Yw)
+    Ys[torch.from_numpy(live_rows).cuda()] = Yw[torch.from_numpy(live_rows).cuda()]
+    ref = plan.spmm(L.VIEW_TRANSPOSED, Ys, F=F)
+    dM = torch.full((plan.ncols, 12), float("nan"), device="cuda")
+    live = torch.empty(plan.ncols, dtype=torch.uint8, device="cuda")
+    scratch = torch.empty(int(lib.mrgcn_spmm_transposed_live_scratch(plan.handle)), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    L.check(lib.mrgcn_spmm_transposed_live_f32(plan.handle, Ys.data_ptr(), Ys.stride(0), F, dM.data_ptr(), 12,
+                                               scratch.data_ptr(), live.data_ptr(), cnt.data_ptr(), 1,
+                                               torch.cuda.current_stream().cuda_stream))
+    assert int(cnt) == len(live_rows)
+    torch.testing.assert_close(dM[:, :F], ref, rtol=1e-5, atol=1e-6)
+    nz = (ref != 0).any(1)
+    assert bool((live.bool() | ~nz).all())  # every column that carries gradient is flagged
+
+
+def test_config5_captured_epoch_equals_eager_epoch(s10m):
+    """The config-5 model (155 -> 16 -> 11, 10 bases, 1.6 G parameters): four eager epochs, and one eager
+    epoch followed by three replayed from a hipGraph (capturing executes nothing), give the same losses
+    and logits."""
+    from mrgcn_amd import synth
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
+    g, A, plan = s10m
+    N, R = g.num_nodes, g.num_relations
+    dims = synth.layer_dims("synth10m")
+    B = synth.SHAPES["synth10m"]["bases"]
+    idx, y = synth.make_labels("synth10m", N, seed=0)
+    idx, y = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
+    X = torch.randn((N, dims[0][0]), device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    mods = [(dims[0][0], dims[0][1], "mrgcn", torch.nn.ReLU()), (dims[1][0], dims[1][1], "mrgcn", None)]
+
+    def fresh():
+        torch.manual_seed(3)
+        return RGCN(mods, R, N, B, 0.0, False, True, False).cuda()
+
+    m1 = fresh()
+    o1 = ClipAdam(m1.parameters(), lr=0.01, max_norm=1.0)
+    l1 = [float(train_step(m1, lambda: m1(X, A), idx, y, o1)) for _ in range(4)]
+    m2 = fresh()
+    o2 = ClipAdam(m2.parameters(), lr=0.01, max_norm=1.0, capturable=True)
+    step = GraphedTrainStep(m2, lambda: m2(X, A), idx, y, o2, warmup=1)
+    l2 = [float(step()) for _ in range(3)]
+    assert all(np.isfinite(l1)) and l1[-1] < l1[0]
+    np.testing.assert_allclose(l2, l1[1:], rtol=2e-4, atol=2e-5)
+    with torch.no_grad():
+        a, b = m1(X, A), m2(X, A)
+    scale = float(a.abs().max())
+    assert float((a - b).abs().max()) <= 1e-4 * max(1.0, scale)
+    del m1, m2, o1, o2, step
+    torch.cuda.empty_cache()

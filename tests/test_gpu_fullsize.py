@@ -111,3 +111,120 @@ def test_int8_boundary_cast_pruned_equals_unpruned():
     D = torch.randn((R * N, 16), device="cuda")
     torch.testing.assert_close(full.spmm(L.VIEW_LITERAL, D), pruned.spmm(L.VIEW_LITERAL, D),
                                rtol=1e-6, atol=1e-6)
+
+
+# ---- the benchmarked epoch at the benchmarked size -----------------------------------------------
+def _am_model_and_data(am, seed=0):
+    from mrgcn_amd import synth
+    from mrgcn_amd.models.rgcn import RGCN
+    g, plan, A_csr = am
+    N, R = g.num_nodes, g.num_relations
+    A = plan.as_adjacency_handle()
+    dims = synth.layer_dims("am")
+    B = synth.SHAPES["am"]["bases"]
+    torch.manual_seed(seed)
+    model = RGCN([(dims[0][0], dims[0][1], "mrgcn", torch.nn.ReLU()), (dims[1][0], dims[1][1], "mrgcn", None)],
+                 R, N, B, 0.0, False, True, False).cuda()
+    X = torch.randn((N, dims[0][0]), device="cuda", generator=torch.Generator("cuda").manual_seed(seed + 1))
+    idx, y = synth.make_labels("am", N, seed=0)
+    return model, A, X, torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda(), dims, B
+
+
+def _oracle_rows(am, model, X, rows, dims, B):
+    from oracle import rgcn_oracle as O
+    g, plan, A_csr = am
+    N, R = g.num_nodes, g.num_relations
+    state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    cfgs = O.rgcn_cfgs(dims, R, N, B, True, False)
+    return O.rgcn_forward_at_rows(cfgs, O.split_params(state, len(cfgs)), X.cpu().numpy(), A_csr, rows)
+
+
+def test_am_epoch_logits_against_the_float64_oracle_at_sampled_rows(am):
+    """The path bench.py times (fused engine, live-column backward, row-sparse weight_I gradient and
+    Adam, hipGraph replay) at N = 1.67 M: logits of 200 sampled rows — labelled nodes, the largest hubs
+    and random ones — against the float64 oracle evaluated on their 2-hop receptive field
+    (oracle.rgcn_forward_at_rows, graph.py:62-102 / rgcn.py:69-89), before training and after four
+    epochs (three of them replayed).  Tolerance 1e-4, the north_star's."""
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep
+    g, plan, A_csr = am
+    model, A, X, idx, y, dims, B = _am_model_and_data(am)
+    deg = np.bincount(g.rows, minlength=g.num_nodes)
+    rng = np.random.default_rng(4)
+    rows = np.unique(np.concatenate([idx.cpu().numpy()[:80], np.argsort(deg)[-20:], rng.choice(g.num_nodes, 100)]))
+    with torch.no_grad():
+        got = model(X, A)[torch.from_numpy(rows).cuda()].cpu().numpy()
+    ref = _oracle_rows(am, model, X, rows, dims, B)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0, capturable=True)
+    step = GraphedTrainStep(model, lambda: model(X, A), idx, y, opt, warmup=1)
+    losses = [float(step()) for _ in range(3)]
+    assert losses[-1] < losses[0]
+    with torch.no_grad():
+        got = model(X, A)[torch.from_numpy(rows).cuda()].cpu().numpy()
+    ref = _oracle_rows(am, model, X, rows, dims, B)  # the oracle on the TRAINED parameters
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_am_default_epoch_equals_literal_engine_with_dense_adam(am):
+    """Three epochs at N = 1.67 M two ways from the same start: (a) the default path — fused engine,
+    gradient-sparsity shortcuts, captured and replayed; (b) the op-for-op literal engine (materialised
+    (R*N) x out operands and dense gradients, graph.py:70-75,:93-95) with the plain dense Adam kernel,
+    launched eagerly.  Losses, logits, parameters and Adam moments agree."""
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
+    g, plan, A_csr = am
+    model, A, X, idx, y, dims, B = _am_model_and_data(am, seed=5)
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0, capturable=True)
+    step = GraphedTrainStep(model, lambda: model(X, A), idx, y, opt, warmup=1)  # one eager epoch ...
+    la = [float(step()), float(step())]                                          # ... and two replayed
+    with torch.no_grad():
+        logits_a = model(X, A).clone()
+    sd_a = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    osd = opt.state_dict()
+    names = [n for n, _ in model.named_parameters()]
+    mom_a = {names[k]: (st["exp_avg"].clone(), st["exp_avg_sq"].clone()) for k, st in osd["state"].items()}
+    del step, opt
+    model.load_state_dict(init)
+    model.set_engine("literal")
+    opt_b = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    lb = [float(train_step(model, lambda: model(X, A), idx, y, opt_b, row_sparse=False)) for _ in range(3)]
+    np.testing.assert_allclose(la, lb[1:], rtol=2e-4, atol=2e-5)
+    with torch.no_grad():
+        logits_b = model(X, A)
+    assert float((logits_a - logits_b).abs().max()) <= 1e-4 * max(1.0, float(logits_b.abs().max()))
+    osd_b = opt_b.state_dict()
+    for k, st in osd_b["state"].items():
+        n = names[k]
+        ma, va = mom_a[n]
+        assert ma.shape == st["exp_avg"].shape, n
+        ms, vs = float(st["exp_avg"].abs().max()), float(st["exp_avg_sq"].abs().max())
+        assert float((ma - st["exp_avg"]).abs().max()) <= 2e-3 * ms + 1e-9, n
+        assert float((va - st["exp_avg_sq"]).abs().max()) <= 4e-3 * vs + 1e-12, n
+    for n, p in model.state_dict().items():
+        d = (sd_a[n] - p).abs()
+        # Adam's first steps move every element by ~lr * sign(g): elements whose gradient is at fp32
+        # rounding level may differ by a step; everything else agrees tightly
+        assert float((d > 2e-5).float().mean()) < 2e-3, n
+        assert float(d.max()) <= 0.021 * 3, n
+
+
+def test_am_quarter_bf16_operand_logits_within_the_stated_tolerance():
+    """Config 3 names bf16: the compact operand stored in bf16 (fp32 accumulation) on an AM/4 graph
+    with the AM model — logits within 2e-2 of the fp32 run (relative to the largest logit)."""
+    from mrgcn_amd import synth
+    from mrgcn_amd.models.rgcn import RGCN
+    g = synth.make_graph("am", seed=2, scale=0.25)
+    N, R = g.num_nodes, g.num_relations
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                (N, R * N)).cuda()
+    torch.manual_seed(0)
+    model = RGCN([(155, 10, "mrgcn", torch.nn.ReLU()), (10, 11, "mrgcn", None)], R, N, 40, 0.0, False,
+                 True, False).cuda()
+    X = torch.randn((N, 155), device="cuda")
+    with torch.no_grad():
+        ref = model(X, A)
+        model.set_operand_dtype("bf16")
+        got = model(X, A)
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert 0 < err <= 2e-2 * scale, (err, scale)

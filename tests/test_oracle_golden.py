@@ -168,3 +168,22 @@ def test_lp_negative_sampling_shape_and_labels():
     # relation untouched, exactly one side re-drawn per corrupted triple
     pos = {tuple(f[1:]) for f in facts.tolist()} | {tuple(f[:2]) for f in facts.tolist()}
     assert all(tuple(t[1:]) in pos or tuple(t[:2]) in pos for t in neg.tolist())
+
+
+@pytest.mark.parametrize("name", RGCN_CASES)
+def test_receptive_field_forward_matches_reference_logits(name):
+    """`rgcn_forward_at_rows` (the full-size AM checker of tests/test_gpu_fullsize.py) against the
+    reference's own logits on every golden case, at a sample of rows and at all of them."""
+    c, A = _case(name)
+    N, R, B = int(c["meta.num_nodes"]), int(c["meta.R"]), int(c["meta.num_bases"])
+    bias, fl = bool(c["meta.bias"]), bool(c["meta.featureless"])
+    lp = bool(c["meta.link_prediction"])
+    dims = [tuple(d) for d in c["dims"]]
+    state = {k[len("init."):]: c[k] for k in c.files if k.startswith("init.")}
+    cfgs = O.rgcn_cfgs(dims, R, N, B, bias, fl)
+    params = O.split_params(state, len(cfgs))
+    X = None if fl else c["X"]
+    rng = np.random.default_rng(3)
+    for rows in (np.sort(rng.choice(N, min(N, 17), replace=False)), np.arange(N)):
+        got = O.rgcn_forward_at_rows(cfgs, params, X, A, rows, relu_last=lp, chunk=7)
+        np.testing.assert_allclose(got, c["logits"][rows], rtol=1e-5, atol=2e-6)
