@@ -37,9 +37,6 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
     ap.add_argument("--value-mode", default="norm_f32", choices=["norm_f32", "ref_int8"])
     ap.add_argument("--engine", default="fused", choices=["fused", "literal"])
-    ap.add_argument("--defer", action="store_true",
-                    help="deferred weight_I update (functional.defer_input_grad): no stored gradient, Adam "
-                         "inside the kernel that recomputes it; measured no faster, off by default")
     ap.add_argument("--reorder", action="store_true",
                     help="relabel the nodes of the synthetic graph so that those within reach of the labels "
                          "come first (mrgcn_amd.data.reorder): the rest of weight_I then never receives "
@@ -204,12 +201,10 @@ def main():
     model = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
     model.set_engine(args.engine)
     model.set_operand_dtype(args.operand)
-    from mrgcn_amd import functional as Fn
-    Fn.defer_input_grad(args.defer)
     X = None if featureless else torch.randn((N, sh["x_width"]), device=dev)
     idx = torch.from_numpy(idx_np).to(dev)
     tgt = torch.from_numpy(y_np).to(dev)
-    opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=args.graph and not args.defer)
+    opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=args.graph)
     plan = plan_of(A, N, R)
     setup_s = time.time() - t0
 
@@ -238,7 +233,7 @@ def main():
         mdist.barrier(dev)
 
     graph_used = False
-    if args.graph and not partitioned and not args.defer:
+    if args.graph and not partitioned:
         from mrgcn_amd.train import GraphedTrainStep
         try:
             graphed = GraphedTrainStep(model, lambda: model(X, A), idx, tgt, opt, warmup=max(args.warmup, 1))
@@ -290,7 +285,7 @@ def main():
         extra["spmm_transposed_ms"] = t_t
         extra["spmm_transposed_gbps"] = bytes_alg / (t_t * 1e-3) / 1e9
         del dY, dM
-        if (args.renumbered_extra and world == 1 and not args.reorder and not args.defer and not partitioned
+        if (args.renumbered_extra and world == 1 and not args.reorder and not partitioned
                 and plan.nnz <= 40_000_000):
             try:
                 extra["epoch_ms_nodes_renumbered"] = renumbered_epoch_ms(
@@ -334,7 +329,7 @@ def main():
             "config": {"workload": f"{name}-shaped synthetic KG (SURVEY §8d), scale {args.scale:g}",
                        "N": N, "R": R, "nnz": plan.nnz, "ncols_touched": plan.ncols,
                        "layers": dims, "num_bases": B, "value_mode": args.value_mode,
-                       "engine": args.engine, "operand": args.operand, "weight_I_update": "deferred" if args.defer else "stored-grad",
+                       "engine": args.engine, "operand": args.operand, "weight_I": "node-major (N, B, out); row-sparse gradient + Adam",
                        "node_order": "label reach first" if args.reorder else "generator (random)",
                        "launch": "hipGraph replay" if graph_used else "eager", "labelled": int(idx.numel()), "params": n_params,
                        "parallelism": ("node-partitioned x%d" % world if partitioned else

@@ -151,8 +151,11 @@ int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uint16_t *D, i
  *
  * basis mix — replaces einsum('rb,bij->rij', weight_I_comp, weight_I.view(B,N,out)) and the
  * view to (R*N, out) of graph.py:69-72, restricted to the rows the product will read:
- *     M[MPOS[c], 0:F] = addend[c, 0:F] + sum_b comp[r_c, b] * V[b*N + j_c, 0:F]
- *     V: [B*N, F], comp: [R, B] */
+ *     M[MPOS[c], 0:F] = addend[c, 0:F] + sum_b comp[r_c, b] * V[j_c, b, 0:F]
+ *     comp: [R, B];  V: NODE-MAJOR basis table [N][B][F] — the B rows of a node are one contiguous
+ *     block of B*F floats.  It is the [B][N][F] -> [N][B][F] transpose of the reference's weight_I
+ *     (graph.py:50-51: (B*N, out), row b*N + j): mrgcn_amd.layers.graph.GraphConvolution keeps its
+ *     parameter in this layout and converts in its state-dict hooks. */
 int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *plan, const float *V, const float *comp, int32_t B,
                             int32_t F, const float *addend, int64_t ldA, float *M, int64_t ldM,
                             void *stream);
@@ -180,70 +183,19 @@ int mrgcn_rel_transform_fwd_bf16(const mrgcn_plan_t *plan, const float *X, int64
 
 
 /* ---- compact dense operand: backward (autograd of graph.py:69-72, :93-94) -------------
- *     dV[b*N + j, :] = sum_{c in node j} comp[r_c, b] * dM[c, :]       (every row written)
- *     dcomp[r, b]    = sum_{c: r_c = r} <dM[c, :], V[b*N + j_c, :]>    (zeroed inside)   */
-int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM, const float *V,
-                            const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
-                            double *dV_sumsq /* nullable: *dV_sumsq += ||dV||^2 (device double) */,
-                            void *stream);
-/* The same with the liveness byte per compact column that mrgcn_spmm_transposed_live_f32 wrote
- * (nullable = mrgcn_basis_mix_bwd_f32): rows of dM flagged 0 are never read — they may be unwritten —
- * and where a kernel has to read every row they are overwritten with zeros first (hence the
- * non-const dM). */
-int mrgcn_basis_mix_bwd_live_f32(const mrgcn_plan_t *plan, float *dM, int64_t ldM,
-                                 const uint8_t *col_live, const uint8_t *chunk_live, const float *V,
-                                 const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
-                                 double *dV_sumsq, void *stream);
-/* Liveness of the basis table's gradient at the granularity Adam can skip: one byte per
- * MRGCN_WEIGHT_CHUNK consecutive floats of a basis slab (the same pattern in every slab).  A node
- * without a live compact column has a zero gradient row in every basis; with a fixed label set it
- * never has any other, its Adam moments stay zero and its parameters never move — exactly.
- *   mrgcn_weight_chunks(plan, F)      number of chunks = ceil(N*F / MRGCN_WEIGHT_CHUNK)
- *   mrgcn_weight_chunks_live          cur[c] = 1 iff a node with a live column has elements in chunk c
- *                                     (cur is overwritten); ever[c] |= cur[c] (caller keeps it
- *                                     across steps, zero-initialised)
- * `chunk_live` = cur handed to mrgcn_basis_mix_bwd_live_f32 makes it skip — neither read V nor write
- * dV for — the node groups that lie in dead chunks: dV is then UNWRITTEN there, and only
- * mrgcn_adam_step_chunked_f32 may consume it. */
-#define MRGCN_WEIGHT_CHUNK 1024
-/* NODE-MAJOR optimizer space for the basis table (any node numbering): the gradient and the Adam
- * moments of V are kept as [N][B][F] — the B rows of a node form one contiguous block — while V itself
- * stays [B][N][F].
- *   mrgcn_nodemajor_supported(plan, B, F)   1 when both calls below serve the shape
- *   mrgcn_basis_mix_bwd_nodemajor_f32       as mrgcn_basis_mix_bwd_live_f32, but dV_nm[j] ([B][F]) is
- *                                           written only for nodes with a live column and
- *                                           node_cur[j] (one byte per node) says which
- *   mrgcn_adam_step_nodemajor_f32           Adam (weight_decay = 0): nodes with node_ever = 0 are
- *                                           skipped (g = m = v = 0: identity), nodes with
- *                                           node_ever = 1, node_cur = 0 are updated with g = 0
- *                                           without reading dV_nm; the caller maintains
- *                                           node_ever |= node_cur across steps */
-int32_t mrgcn_nodemajor_supported(const mrgcn_plan_t *plan, int32_t B, int32_t F);
-int mrgcn_basis_mix_bwd_nodemajor_f32(const mrgcn_plan_t *plan, float *dM, int64_t ldM,
-                                      const uint8_t *col_live, const float *V, const float *comp,
-                                      int32_t B, int32_t F, float *dV_nm, uint8_t *node_cur, float *dcomp,
-                                      double *dV_sumsq, void *stream);
-int mrgcn_adam_step_nodemajor_f32(float *param, const float *grad_nm, float *exp_avg_nm,
-                                  float *exp_avg_sq_nm, int64_t N, int32_t B, int32_t F,
-                                  const uint8_t *node_cur, const uint8_t *node_ever, float lr, float beta1,
-                                  float beta2, float eps, int64_t step, const float *bc_dev,
-                                  const float *grad_scale, void *stream);
-int64_t mrgcn_weight_chunks(const mrgcn_plan_t *plan, int32_t F);
-int mrgcn_weight_chunks_live(const mrgcn_plan_t *plan, const uint8_t *col_live, int32_t F, uint8_t *cur,
-                             uint8_t *ever, void *stream);
-/* Deferred update of the basis table V (= weight_I, the 2.67 GB parameter at AM scale):
- * clip_grad_norm_ needs ||dV|| before any parameter may move, so
- *   pass 1  mrgcn_basis_mix_bwd_f32 with dV = NULL: dcomp and *dV_sumsq only, dV is not stored;
- *   pass 2  (after mrgcn_clip_coef_f32) this call recomputes dV from dM and applies
- *           torch.optim.Adam to V in the same kernel — arithmetic identical to
- *           mrgcn_adam_step_f32 on a stored dV (node_classification.py:190-193), but the
- *           gradient is never written to nor re-read from HBM.  dM / comp must still hold the
- *           values of the backward pass. */
-int mrgcn_basis_mix_bwd_adam_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM,
-                                 const float *comp, int32_t B, int32_t F, float *param,
-                                 float *exp_avg, float *exp_avg_sq, float lr, float beta1,
-                                 float beta2, float eps, float weight_decay, int64_t step,
-                                 const float *grad_scale, void *stream);
+ *     dV[j, b, :]  = sum_{c in node j} comp[r_c, b] * dM[c, :]          (node-major, like V)
+ *     dcomp[r, b]  = sum_{c: r_c = r} <dM[c, :], V[j_c, b, :]>           (zeroed inside)
+ * col_live (nullable): the liveness byte per compact column that mrgcn_spmm_transposed_live_f32 wrote;
+ *     rows of dM flagged 0 are never read — they may be unwritten — and where a kernel has to read every
+ *     row they are overwritten with zeros first (hence the non-const dM).  NULL: every column counts.
+ * node_cur (nullable): ROW-SPARSE gradient.  A node without a live compact column has a zero gradient
+ *     block; with node_cur given such blocks of dV are left UNWRITTEN (and their V blocks unread) and
+ *     node_cur[j] = 1 / 0 says which nodes were written — only mrgcn_adam_step_rows_f32 may consume such a
+ *     gradient.  NULL: every block of dV is written (zeros where there is no gradient).
+ * dV_sumsq (nullable): *dV_sumsq += ||dV||^2 (device double), for the global clip norm. */
+int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *plan, float *dM, int64_t ldM, const uint8_t *col_live,
+                            const float *V, const float *comp, int32_t B, int32_t F, float *dV,
+                            uint8_t *node_cur, float *dcomp, double *dV_sumsq, void *stream);
 
 /*     dX[j, 0:K]  = sum_{c in node j} W[r_c] . dM[c, :]     (nullable; every row written)
  *     dW[r, :, :] = sum_{c: r_c = r} X[j_c, :]^T dM[c, :]    (nullable; zeroed inside)
@@ -280,7 +232,7 @@ int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *plan, float *dM, int64_
  * mrgcn_spmm_f32 is the faster call (AM shape: 211 us at 0.3 % live rows, 467 us general,
  * 860 us with every row live), so callers keep the last count and choose.
  * `write_dead_rows` = 0 leaves the rows of Y whose flag is 0 UNWRITTEN (their zeros are 90 % of this
- * call's stores): only for consumers that take `col_live` — mrgcn_basis_mix_bwd_live_f32 and
+ * call's stores): only for consumers that take `col_live` — mrgcn_basis_mix_bwd_f32 and
  * mrgcn_rel_transform_bwd_live_f32. */
 int64_t mrgcn_spmm_transposed_live_scratch(const mrgcn_plan_t *plan); /* bytes */
 int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const float *D, int64_t ldD, int32_t F,
@@ -352,14 +304,16 @@ int mrgcn_distmult_ranks(const float *E, int64_t ldE, int64_t num_nodes, const f
  * bias corrections live in device memory, so a captured epoch replays with the right step.
  * mrgcn_adam_bias_f32: ++*step_dev; bc_dev[0] = 1 - beta1^step, bc_dev[1] = sqrt(1 - beta2^step).
  * mrgcn_adam_step_dev_f32: mrgcn_adam_step_f32 reading the corrections from bc_dev. */
-/* mrgcn_adam_step_f32 / _dev_f32 (weight_decay = 0) on a parameter of B slabs of `slab_elems` floats
- * whose gradient is live only in the chunks flagged by mrgcn_weight_chunks_live: chunks with
- * ever = 0 are not touched (g = m = v = 0: the update is the identity), chunks with ever = 1, cur = 0
- * are updated with g = 0 without reading grad.  `bc_dev` nullable (then `step` >= 1 is used). */
-int mrgcn_adam_step_chunked_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
-                                int64_t slab_elems, int32_t B, const uint8_t *cur, const uint8_t *ever,
-                                float lr, float beta1, float beta2, float eps, int64_t step,
-                                const float *bc_dev, const float *grad_scale, void *stream);
+/* mrgcn_adam_step_f32 / _dev_f32 (weight_decay = 0) on a parameter of `nrows` rows of `rowlen` floats
+ * (the node-major basis table: nrows = N, rowlen = B*F; float4 accesses when rowlen % 4 == 0) whose gradient was produced
+ * row-sparse (mrgcn_basis_mix_bwd_f32 with node_cur): rows with row_ever = 0 and row_cur = 0 are not
+ * touched (g = m = v = 0: Adam's update is the identity), rows with row_ever = 1, row_cur = 0 are
+ * updated with g = 0 without reading grad, rows with row_cur = 1 take grad and are marked in row_ever
+ * (caller keeps row_ever across steps, zero-initialised).  `bc_dev` nullable (then `step` >= 1 is used). */
+int mrgcn_adam_step_rows_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                             int64_t nrows, int32_t rowlen, const uint8_t *row_cur, uint8_t *row_ever,
+                             float lr, float beta1, float beta2, float eps, int64_t step,
+                             const float *bc_dev, const float *grad_scale, void *stream);
 int mrgcn_adam_bias_f32(int64_t *step_dev, float beta1, float beta2, float *bc_dev, void *stream);
 int mrgcn_adam_step_dev_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                             int64_t n, float lr, float beta1, float beta2, float eps,

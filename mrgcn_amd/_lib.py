@@ -59,19 +59,10 @@ SIGNATURES = {
     "mrgcn_gather_rows_bf16": (C.c_int, [_p, _p, _i32, _p, _i64, _p, _i64, _p]),
     "mrgcn_rel_transform_fwd_bf16": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]),
     "mrgcn_rel_transform_bwd_workspace": (C.c_int64, [_p, _i32, _i32, _i32, _i32]),
-    "mrgcn_basis_mix_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p]),
-    "mrgcn_basis_mix_bwd_adam_f32": (C.c_int, [_p, _p, _i64, _p, _i32, _i32, _p, _p, _p, C.c_float, C.c_float,
-                                               C.c_float, C.c_float, C.c_float, _i64, _p, _p]),
+    "mrgcn_basis_mix_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
+    "mrgcn_adam_step_rows_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, C.c_float, C.c_float, C.c_float,
+                                           C.c_float, _i64, _p, _p, _p]),
     "mrgcn_rel_transform_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _i64, _p]),
-    "mrgcn_basis_mix_bwd_live_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p]),
-    "mrgcn_nodemajor_supported": (C.c_int32, [_p, _i32, _i32]),
-    "mrgcn_basis_mix_bwd_nodemajor_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
-    "mrgcn_adam_step_nodemajor_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p, C.c_float, C.c_float,
-                                                C.c_float, C.c_float, _i64, _p, _p, _p]),
-    "mrgcn_weight_chunks": (C.c_int64, [_p, _i32]),
-    "mrgcn_weight_chunks_live": (C.c_int, [_p, _p, _i32, _p, _p, _p]),
-    "mrgcn_adam_step_chunked_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, C.c_float, C.c_float, C.c_float,
-                                              C.c_float, _i64, _p, _p, _p]),
     "mrgcn_rel_transform_bwd_live_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p,
                                                    _i64, _p]),
     "mrgcn_rows_nonzero_f32": (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),

@@ -34,6 +34,11 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kLongThreshold = 32; // rows with more entries go to the split-row path
 constexpr int kChunk = 512;        // entries per split-row chunk (one wave each)
 constexpr int kWsFeatures = 256;   // split-row workspace is sized for this many features
+// k_spmm3 (spmm.hip): rows of <= kShort3Rows entries share a wave 64/G at a time, rows up to kMid3Rows four at a
+// time, longer rows are cut into chunks of kChunk3Entries (one gather batch of 8 per lane at G = 4)
+constexpr int kShort3Rows = 8;
+constexpr int kMid3Rows = 32;
+constexpr int kChunk3Entries = 128;
 constexpr int kHotMinRefs = 16;    // columns read by >= this many rows go to the dense hot region of M
 constexpr int kNodeBand = 131072;  // source nodes per band of the transform order (see plan.hip)
 constexpr int kRelChunk = 1024;    // compact columns of one relation per transform block
@@ -129,6 +134,10 @@ struct mrgcn_plan {
   int32_t *c_long_row = nullptr, *c_long_cptr = nullptr, *c_chunk_beg = nullptr, *c_chunk_end = nullptr,
           *c_chunk_row = nullptr;
   int32_t r_n_long = 0, r_n_chunks = 0, c_n_long = 0, c_n_chunks = 0;
+  // row orientation in k_spmm3's classes (threshold kMid3Rows, chunks of kChunk3Entries) + the list of mid rows
+  int32_t *r3_long_row = nullptr, *r3_long_cptr = nullptr, *r3_chunk_beg = nullptr, *r3_chunk_end = nullptr,
+          *r3_chunk_row = nullptr, *r_mid_rows = nullptr;
+  int32_t r3_n_long = 0, r3_n_chunks = 0, r_n_mid = 0;
   float *partials = nullptr;  // [max(r_n_chunks, c_n_chunks) * kWsFeatures]
 
   mrgcn::SparseView view(int which) const {

@@ -97,18 +97,55 @@ __global__ void k_sumsq(const float *__restrict__ x, int64_t n, double *__restri
 }
 
 // clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6))
-// Adam on a [B][slab] parameter whose gradient lives only in some 1024-float chunks of each slab
-// (the same chunks in every slab: weight_I with few labelled nodes).  `ever[c]` = 0: chunk c never
-// received gradient — g = m = v = 0, the update is a no-op and nothing is touched (weight_decay must
-// be 0); `cur[c]` = 0 but ever: the gradient is zero this step (g is not read: its chunk may be unwritten).
-__global__ __launch_bounds__(256) void k_adam_chunked(float *__restrict__ p, const float *__restrict__ g,
-                                                      float *__restrict__ m, float *__restrict__ v,
-                                                      int64_t slab4, int B, int64_t nch,
-                                                      const uint8_t *__restrict__ cur,
-                                                      const uint8_t *__restrict__ ever, float lr, float b1,
-                                                      float b2, float eps, float bc1, float bc2_sqrt,
-                                                      const float *__restrict__ scale,
-                                                      const float *__restrict__ bc_dev) {
+// Adam on a parameter made of `nrows` rows of `rowlen` floats (weight_I in its node-major layout: one row
+// = the B*F floats of a node) whose gradient exists for some rows only — a semi-supervised epoch gives
+// gradient to the nodes within reach of a label, with few labelled nodes half of the AM node table gets
+// none, ever.  `ever[r]` = 0: row r never received gradient — g = m = v = 0, the update is the identity
+// and nothing is read or written (weight_decay must be 0); `cur[r]` = 0 but ever: the gradient is zero
+// this step (g is not read: its row may be unwritten).  Rows with cur = 1 are marked ever.
+// One thread per float4 of a row (rowlen % 4 == 0; k_adam_rows_scalar: per float), rows walked by the grid.
+__global__ __launch_bounds__(256) void k_adam_rows_scalar(float *__restrict__ p, const float *__restrict__ g,
+                                                          float *__restrict__ m, float *__restrict__ v,
+                                                          int64_t nrows, int rowlen, const uint8_t *__restrict__ cur,
+                                                          uint8_t *__restrict__ ever, float lr, float b1, float b2,
+                                                          float eps, float bc1, float bc2_sqrt,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ bc_dev) {
+  if (bc_dev) {
+    bc1 = bc_dev[0];
+    bc2_sqrt = bc_dev[1];
+  }
+  const float sc = scale ? *scale : 1.f;
+  const float step = lr / bc1;
+  const int64_t n = nrows * rowlen;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / rowlen;
+    const bool c = cur[r] != 0;
+    if (!c && !ever[r]) continue;
+    float gg = (c ? g[i] : 0.f) * sc;
+    float mm = fmaf(b1, m[i], (1.f - b1) * gg);
+    float vv = fmaf(b2, v[i], (1.f - b2) * gg * gg);
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] -= step * (mm / denom);
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+// rows that took gradient count as `ever` from now on (after the update pass: no thread may see the flag change
+// under its feet)
+__global__ void k_rows_mark_ever(const uint8_t *__restrict__ cur, uint8_t *__restrict__ ever, int64_t nrows) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nrows && cur[r]) ever[r] = 1;
+}
+
+template <int RB>  // rows per block step
+__global__ __launch_bounds__(256) void k_adam_rows(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v,
+                                                   int64_t nrows, int rowlen4, const uint8_t *__restrict__ cur,
+                                                   uint8_t *__restrict__ ever, float lr, float b1, float b2,
+                                                   float eps, float bc1, float bc2_sqrt,
+                                                   const float *__restrict__ scale,
+                                                   const float *__restrict__ bc_dev) {
   if (bc_dev) {
     bc1 = bc_dev[0];
     bc2_sqrt = bc_dev[1];
@@ -126,120 +163,27 @@ __global__ __launch_bounds__(256) void k_adam_chunked(float *__restrict__ p, con
     float denom = sqrtf(vv) / bc2_sqrt + eps;
     pp -= step * (mm / denom);
   };
-  // the loop of k_adam (one linear stream over the whole parameter) with the chunk flags looked up
-  // per float4: q = position inside its slab, chunk = q / 256
-  const int64_t nv = slab4 * B;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t q = i % slab4;
-    const int64_t c = q >> 8;
-    if (!ever[c]) continue;
-    float4 P = p4[i], M = m4[i], V = v4[i];
-    float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cur[c]) G = g4[i];
-    upd(P.x, G.x, M.x, V.x);
-    upd(P.y, G.y, M.y, V.y);
-    upd(P.z, G.z, M.z, V.z);
-    upd(P.w, G.w, M.w, V.w);
-    p4[i] = P;
-    m4[i] = M;
-    v4[i] = V;
-  }
-}
-
-// Adam on a [B][N][F] parameter whose gradient and moments are kept NODE-MAJOR ([N][B][F]: the B rows
-// of a node are one contiguous block).  Nodes that never had gradient (`ever` = 0) are skipped in any
-// node numbering — with few labelled nodes that is half of the AM node table — and nodes without
-// gradient this step (`cur` = 0) are updated with g = 0 without reading their (unwritten) block.
-// A block transposes a tile of T consecutive nodes through LDS: the parameter tile enters and leaves
-// as B runs of T*F floats (whole cache lines), gradient and moments as one contiguous run per node.
-// tools/micro/adam_nodemajor.hip: 5.1 TB/s — 2.36 ms for the AM table at 50 % live nodes, 3.25 ms with
-// every node live, against 3.36 ms for the 7-stream k_adam.
-constexpr int kNmTB = 512;  // tools/micro/adam_nodemajor.hip: 512 threads 3 % ahead of 256 at T = 32
-template <int T>
-__global__ __launch_bounds__(kNmTB) void k_adam_nodemajor(float *__restrict__ p, const float *__restrict__ g,
-                                                        float *__restrict__ m, float *__restrict__ v, int64_t N,
-                                                        int B, int F, const uint8_t *__restrict__ cur,
-                                                        const uint8_t *__restrict__ ever, float lr, float b1,
-                                                        float b2, float eps, float bc1, float bc2_sqrt,
-                                                        const float *__restrict__ scale,
-                                                        const float *__restrict__ bc_dev) {
-  extern __shared__ __align__(16) float s_p[];  // [B][RS]
-  __shared__ int s_any;
-  if (bc_dev) {
-    bc1 = bc_dev[0];
-    bc2_sqrt = bc_dev[1];
-  }
-  const float sc = scale ? *scale : 1.f;
-  const float step = lr / bc1;
-  auto upd = [&](float &pp, float gg, float &mm, float &vv) {  // == k_adam with wd = 0
-    gg *= sc;
-    mm = fmaf(b1, mm, (1.f - b1) * gg);
-    vv = fmaf(b2, vv, (1.f - b2) * gg * gg);
-    float denom = sqrtf(vv) / bc2_sqrt + eps;
-    pp -= step * (mm / denom);
-  };
-  const int RS = T * F + 4;
-  const int nf4 = (B * F) >> 2;  // float4s of one node's block
-  const int64_t slab = N * F;
-  const int64_t ntiles = (N + T - 1) / T;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t j0 = tile * T;
-    const int nt = (int)((N - j0 < T) ? N - j0 : T);
-    __syncthreads();  // s_any / s_p of the previous tile are done with
-    if (threadIdx.x == 0) s_any = 0;
-    __syncthreads();
-    if ((int)threadIdx.x < nt && ever[j0 + threadIdx.x]) s_any = 1;
-    __syncthreads();
-    if (!s_any) continue;  // block uniform: nothing in this tile ever had gradient
-    const int run = nt * F;
-    if ((run & 3) == 0) {
-      const int run4 = run >> 2;
-      for (int q = threadIdx.x; q < B * run4; q += kNmTB) {
-        const int b = q / run4, x = q - b * run4;
-        *reinterpret_cast<float4 *>(&s_p[b * RS + 4 * x]) =
-            *reinterpret_cast<const float4 *>(p + (int64_t)b * slab + j0 * F + 4 * x);
-      }
-    } else {  // the last, partial tile
-      for (int q = threadIdx.x; q < B * run; q += kNmTB) {
-        const int b = q / run, x = q - b * run;
-        s_p[b * RS + x] = p[(int64_t)b * slab + j0 * F + x];
-      }
-    }
-    __syncthreads();
-    for (int q = threadIdx.x; q < nt * nf4; q += kNmTB) {
-      const int t = q / nf4, w = q - t * nf4;
-      if (!ever[j0 + t]) continue;
-      const int64_t i4 = (j0 + t) * (int64_t)nf4 + w;
+  // a block takes RB consecutive rows per step: RB * rowlen4 float4s, thread t the t-th, t + 256-th, ...
+  const int per = RB * rowlen4;
+  for (int64_t r0 = (int64_t)blockIdx.x * RB; r0 < nrows; r0 += (int64_t)gridDim.x * RB) {
+    for (int t = threadIdx.x; t < per; t += blockDim.x) {
+      const int rr = t / rowlen4;
+      const int64_t r = r0 + rr;
+      if (r >= nrows) break;
+      const bool c = cur[r] != 0;
+      if (!c && !ever[r]) continue;
+      const int64_t i = r * rowlen4 + (t - rr * rowlen4);
+      float4 P = p4[i], M = m4[i], V = v4[i];
       float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cur[j0 + t]) G = reinterpret_cast<const float4 *>(g)[i4];
-      float4 M = reinterpret_cast<const float4 *>(m)[i4], V = reinterpret_cast<const float4 *>(v)[i4];
-      const int e0 = 4 * w;
-      int b = e0 / F, o = e0 - b * F;
-      float *pp = &s_p[b * RS + t * F + o];
-      upd(*pp, G.x, M.x, V.x);
-      if (++o == F) { o = 0; ++b; } pp = &s_p[b * RS + t * F + o];
-      upd(*pp, G.y, M.y, V.y);
-      if (++o == F) { o = 0; ++b; } pp = &s_p[b * RS + t * F + o];
-      upd(*pp, G.z, M.z, V.z);
-      if (++o == F) { o = 0; ++b; } pp = &s_p[b * RS + t * F + o];
-      upd(*pp, G.w, M.w, V.w);
-      reinterpret_cast<float4 *>(m)[i4] = M;
-      reinterpret_cast<float4 *>(v)[i4] = V;
-    }
-    __syncthreads();
-    if ((run & 3) == 0) {
-      const int run4 = run >> 2;
-      for (int q = threadIdx.x; q < B * run4; q += kNmTB) {
-        const int b = q / run4, x = q - b * run4;
-        *reinterpret_cast<float4 *>(p + (int64_t)b * slab + j0 * F + 4 * x) =
-            *reinterpret_cast<const float4 *>(&s_p[b * RS + 4 * x]);
-      }
-    } else {
-      for (int q = threadIdx.x; q < B * run; q += kNmTB) {
-        const int b = q / run, x = q - b * run;
-        p[(int64_t)b * slab + j0 * F + x] = s_p[b * RS + x];
-      }
+      if (c) G = g4[i];
+      upd(P.x, G.x, M.x, V.x);
+      upd(P.y, G.y, M.y, V.y);
+      upd(P.z, G.z, M.z, V.z);
+      upd(P.w, G.w, M.w, V.w);
+      p4[i] = P;
+      m4[i] = M;
+      v4[i] = V;
+      if (c && t == rr * rowlen4) ever[r] = 1;  // (readers of the same row see cur = 1 either way)
     }
   }
 }
@@ -441,52 +385,43 @@ __global__ void k_adam_bias(int64_t *__restrict__ step, float b1, float b2, floa
 
 extern "C" {
 
-int mrgcn_adam_step_chunked_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
-                                int64_t slab_elems, int32_t B, const uint8_t *cur, const uint8_t *ever,
-                                float lr, float beta1, float beta2, float eps, int64_t step,
-                                const float *bc_dev, const float *grad_scale, void *stream) {
-  MRGCN_REQUIRE(param && grad && exp_avg && exp_avg_sq && cur && ever, "NULL");
+int mrgcn_adam_step_rows_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t nrows,
+                             int32_t rowlen, const uint8_t *row_cur, uint8_t *row_ever, float lr, float beta1,
+                             float beta2, float eps, int64_t step, const float *bc_dev, const float *grad_scale,
+                             void *stream) {
+  MRGCN_REQUIRE(param && grad && exp_avg && exp_avg_sq && row_cur && row_ever, "NULL");
   MRGCN_REQUIRE(step >= 1 || bc_dev, "step counts from 1");
-  MRGCN_REQUIRE(slab_elems > 0 && slab_elems % 4 == 0 && B > 0, "slab_elems must be a multiple of 4");
-  MRGCN_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
-                "16-byte alignment");
+  MRGCN_REQUIRE(nrows >= 0 && rowlen > 0, "nrows / rowlen");
+  if (nrows == 0) return MRGCN_OK;
   const double bc1 = bc_dev ? 1.0 : 1.0 - pow((double)beta1, (double)step);
   const double bc2 = bc_dev ? 1.0 : 1.0 - pow((double)beta2, (double)step);
-  const int64_t nch = (slab_elems + 1023) >> 10;
-  int64_t blocks = ((slab_elems >> 2) * B + 255) / 256;
-  if (blocks > 8192) blocks = 8192;  // as mrgcn_adam_step_f32
-  mrgcn::k_adam_chunked<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
-      param, grad, exp_avg, exp_avg_sq, slab_elems >> 2, B, nch, cur, ever, lr, beta1, beta2, eps, (float)bc1,
-      (float)sqrt(bc2), grad_scale, bc_dev);
-  MRGCN_HIP_TRY(hipGetLastError());
-  return MRGCN_OK;
-}
-
-int mrgcn_adam_step_nodemajor_f32(float *param, const float *grad_nm, float *exp_avg_nm, float *exp_avg_sq_nm,
-                                  int64_t N, int32_t B, int32_t F, const uint8_t *node_cur,
-                                  const uint8_t *node_ever, float lr, float beta1, float beta2, float eps,
-                                  int64_t step, const float *bc_dev, const float *grad_scale, void *stream) {
-  MRGCN_REQUIRE(param && grad_nm && exp_avg_nm && exp_avg_sq_nm && node_cur && node_ever, "NULL");
-  MRGCN_REQUIRE(step >= 1 || bc_dev, "step counts from 1");
-  MRGCN_REQUIRE(N > 0 && B > 0 && F > 0 && (N * F) % 4 == 0 && (B * F) % 4 == 0, "N*F and B*F must be multiples of 4");
-  MRGCN_REQUIRE((((uintptr_t)param | (uintptr_t)grad_nm | (uintptr_t)exp_avg_nm | (uintptr_t)exp_avg_sq_nm) & 15) == 0,
-                "16-byte alignment");
-  const double bc1 = bc_dev ? 1.0 : 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = bc_dev ? 1.0 : 1.0 - pow((double)beta2, (double)step);
-  auto lds_for = [&](int T) { return (size_t)B * (T * F + 4) * sizeof(float); };
-  const int T = lds_for(32) <= 60 * 1024 ? 32 : lds_for(16) <= 60 * 1024 ? 16 : 8;
-  MRGCN_REQUIRE(lds_for(T) <= 60 * 1024, "B * F too large for the node-major Adam tile");
-  int64_t blocks = (N + T - 1) / T;
-  if (blocks > 3072) blocks = 3072;
+  const int rowlen4 = rowlen >> 2;
   hipStream_t s = (hipStream_t)stream;
-#define NM_GO(T_)                                                                                          \
-  mrgcn::k_adam_nodemajor<T_><<<dim3((unsigned)blocks), dim3(mrgcn::kNmTB), lds_for(T_), s>>>(                      \
-      param, grad_nm, exp_avg_nm, exp_avg_sq_nm, N, B, F, node_cur, node_ever, lr, beta1, beta2, eps,      \
-      (float)bc1, (float)sqrt(bc2), grad_scale, bc_dev)
-  if (T == 32) NM_GO(32);
-  else if (T == 16) NM_GO(16);
-  else NM_GO(8);
-#undef NM_GO
+  if (rowlen % 4 != 0 ||
+      ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0)) {
+    int64_t blocks = (nrows * rowlen + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    mrgcn::k_adam_rows_scalar<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(
+        param, grad, exp_avg, exp_avg_sq, nrows, rowlen, row_cur, row_ever, lr, beta1, beta2, eps, (float)bc1,
+        (float)sqrt(bc2), grad_scale, bc_dev);
+    mrgcn::k_rows_mark_ever<<<dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s>>>(row_cur, row_ever, nrows);
+    MRGCN_HIP_TRY(hipGetLastError());
+    return MRGCN_OK;
+  }
+  // rows per block step: about 2 float4s per thread
+#define ROWS_GO(RB_)                                                                                        \
+  do {                                                                                                      \
+    int64_t blocks = (nrows + RB_ - 1) / RB_;                                                               \
+    if (blocks > 8192) blocks = 8192;                                                                       \
+    mrgcn::k_adam_rows<RB_><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(                                   \
+        param, grad, exp_avg, exp_avg_sq, nrows, rowlen4, row_cur, row_ever, lr, beta1, beta2, eps,         \
+        (float)bc1, (float)sqrt(bc2), grad_scale, bc_dev);                                                  \
+  } while (0)
+  if (rowlen4 >= 256) ROWS_GO(1);
+  else if (rowlen4 >= 64) ROWS_GO(4);
+  else if (rowlen4 >= 16) ROWS_GO(16);
+  else ROWS_GO(64);
+#undef ROWS_GO
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -259,7 +259,7 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, hipStream_t s
 int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, int32_t **long_row,
                int32_t **long_cptr, int32_t **chunk_beg, int32_t **chunk_end, int32_t **chunk_row,
                int32_t *n_long,
-               int32_t *n_chunks, int64_t *max_len) {
+               int32_t *n_chunks, int64_t *max_len, int threshold = kLongThreshold, int chunk = kChunk) {
   Scratch sc;
   int32_t *is_long, *nchunk, *long_pos, *chunk_pos, *d_max;
   MRGCN_HIP_TRY(sc.alloc(&is_long, rows + 1));
@@ -271,7 +271,7 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(hipMemsetAsync(is_long, 0, (rows + 1) * sizeof(int32_t), s));
   MRGCN_HIP_TRY(hipMemsetAsync(nchunk, 0, (rows + 1) * sizeof(int32_t), s));
   if (rows > 0)
-    k_long_count<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, kLongThreshold, kChunk, is_long, nchunk, d_max);
+    k_long_count<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, threshold, chunk, is_long, nchunk, d_max);
   // scan over rows+1 elements so that position [rows] holds the totals
   int rc;
   if ((rc = exclusive_scan_i32(is_long, long_pos, rows + 1, s, sc))) return rc;
@@ -291,8 +291,42 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(plan_alloc(p, chunk_row, h[1]));
   MRGCN_HIP_TRY(hipMemcpyAsync(*long_cptr + h[0], &h[1], sizeof(int32_t), hipMemcpyHostToDevice, s));
   if (rows > 0 && h[0] > 0)
-    k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, kChunk, is_long, long_pos, chunk_pos,
+    k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, chunk, is_long, long_pos, chunk_pos,
                                               *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row);
+  MRGCN_HIP_TRY(hipGetLastError());
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  return MRGCN_OK;
+}
+
+// rows whose length lies in (lo, hi]: flag, scan, compact (k_spmm3's four-rows-per-wave class)
+__global__ void k_len_flag(const int32_t *__restrict__ ptr, int64_t rows, int lo, int hi, int32_t *__restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const int32_t n = ptr[i + 1] - ptr[i];
+  flag[i] = (n > lo && n <= hi) ? 1 : 0;
+}
+__global__ void k_flag_compact(const int32_t *__restrict__ flag, const int32_t *__restrict__ pos, int64_t rows,
+                               int32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows && flag[i]) out[pos[i]] = (int32_t)i;
+}
+
+int build_mid(mrgcn_plan *p, const int32_t *ptr, int64_t rows, int lo, int hi, hipStream_t s, int32_t **mid_rows,
+              int32_t *n_mid) {
+  Scratch sc;
+  int32_t *flag, *pos;
+  MRGCN_HIP_TRY(sc.alloc(&flag, rows + 1));
+  MRGCN_HIP_TRY(sc.alloc(&pos, rows + 1));
+  MRGCN_HIP_TRY(hipMemsetAsync(flag, 0, (rows + 1) * sizeof(int32_t), s));
+  if (rows > 0) k_len_flag<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, lo, hi, flag);
+  int rc;
+  if ((rc = exclusive_scan_i32(flag, pos, rows + 1, s, sc))) return rc;
+  int32_t h = 0;
+  MRGCN_HIP_TRY(hipMemcpyAsync(&h, pos + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  *n_mid = h;
+  MRGCN_HIP_TRY(plan_alloc(p, mid_rows, h));
+  if (rows > 0 && h > 0) k_flag_compact<<<nblocks(rows), kTB, 0, s>>>(flag, pos, rows, *mid_rows);
   MRGCN_HIP_TRY(hipGetLastError());
   MRGCN_HIP_TRY(hipStreamSynchronize(s));
   return MRGCN_OK;
@@ -562,7 +596,17 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r_long_row, &p->r_long_cptr, &p->r_chunk_beg,
                        &p->r_chunk_end, &p->r_chunk_row, &p->r_n_long, &p->r_n_chunks, &p->max_row_nnz)))
     return rc;
+  // the same rows once more in k_spmm3's classes: <= 8 entries implicit, 9..32 as a list, > 32 in chunks of 128
+  {
+    int64_t dummy = 0;
+    if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r3_long_row, &p->r3_long_cptr, &p->r3_chunk_beg,
+                         &p->r3_chunk_end, &p->r3_chunk_row, &p->r3_n_long, &p->r3_n_chunks, &dummy, kMid3Rows,
+                         kChunk3Entries)))
+      return rc;
+    if ((rc = build_mid(p, p->rowptr, p->num_rows, kShort3Rows, kMid3Rows, s, &p->r_mid_rows, &p->r_n_mid))) return rc;
+  }
   int64_t ws = (int64_t)std::max(p->r_n_chunks, p->c_n_chunks) * kWsFeatures;
+  ws = std::max<int64_t>(ws, (int64_t)p->r3_n_chunks * 16);
   MRGCN_HIP_TRY(plan_alloc(p, &p->partials, ws));
   return MRGCN_OK;
 }
@@ -572,6 +616,7 @@ void free_plan(mrgcn_plan *p) {
                   p->nptr, p->ulcol, p->mpos, p->mcol, p->mval, p->rperm, p->relptr, p->rnode, p->rmpos, p->relchunk_ptr, p->relchunk_ids, p->relchunk_rel, p->relchunk_beg, p->relchunk_end,
                   p->cval, p->r_long_row, p->r_long_cptr, p->r_chunk_beg, p->r_chunk_end,
                   p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->r_chunk_row, p->c_chunk_row,
+                  p->r3_long_row, p->r3_long_cptr, p->r3_chunk_beg, p->r3_chunk_end, p->r3_chunk_row, p->r_mid_rows,
                   p->partials};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);

@@ -7,8 +7,11 @@
 //                 + X[j_c, :] . W_F[r_c]                        relation transform (feature term)
 //
 // Compact columns are numbered in (source node j, relation r) order, so everything that
-// belongs to one node is contiguous: the basis tables V[b, j, :] are streamed exactly once
-// (HBM-bound, coalesced over j for every b) and dV needs no atomics.  The per-relation dense
+// belongs to one node is contiguous.  The basis table is NODE-MAJOR here, V[j, b, :] ([N][B][F]: the
+// B rows of a node are one contiguous block of B*F floats) — the internal layout of the layer's
+// weight_I parameter; the reference's (B*N, out) tensor (graph.py:50-51, :69-72) is its [B][N][F]
+// transpose, produced / consumed by the layer's state-dict hooks.  V is streamed exactly once, a node
+// without gradient is skipped as one block (backward, Adam) and dV needs no atomics.  The per-relation dense
 // transforms run relation-major on the matrix cores (xform_mfma.hip).  When both terms are
 // present the transform writes its rows in compact order (sequential) and the mix pass adds
 // them while it emits the final rows in the operand's storage order `mpos` — the only
@@ -31,9 +34,9 @@ constexpr int kMixFwdTB = 1024;
 constexpr int kPre = 8;
 
 // =====================================================================================
-// basis mix, forward.  thread = (node j, padded feature o < FW); V[., j, o] in registers.
+// basis mix, forward.  thread = (node j, padded feature o < FW); V[j, ., o] in registers.
 //   M[mpos[c], o] = (addend ? addend[c, o] : 0) (+ old value if accumulate)
-//                   + sum_b comp[r_c, b] * V[b, j, o]          for o < F;  0 for F <= o < FW
+//                   + sum_b comp[r_c, b] * V[j, b, o]          for o < F;  0 for F <= o < FW
 // =====================================================================================
 // LDS row stride of the staged comp slice: multiple of 4 floats (16-byte ds_read_b128) and
 // = 12 mod 32 banks when BT = 40, so that the 4-6 relations a wave touches at once land on
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(kMixFwdTB) void k_mix_fwd(const int32_t *__restrict
     float v[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b)
-      v[b] = (live && b < nb) ? V[((int64_t)(b0 + b) * N + j) * F + o] : 0.f;
+      v[b] = (live && b < nb) ? V[((int64_t)j * B + (b0 + b)) * F + o] : 0.f;
 
     // the node's columns in chunks of kPre: everything a chunk needs (relation id, operand row,
     // addend) is requested up front, so a chunk costs one round trip however long the node is
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(kMixTB) void k_mix_fwd_cols(const int32_t *__restri
 #pragma unroll 4
     for (int b = 0; b < B; ++b) {
       const float w = cr[b];
-      const float *vp = V + ((int64_t)b * N + j) * F;
+      const float *vp = V + ((int64_t)j * B + b) * F;
       if (VEC2) {
 #pragma unroll
         for (int o = 0; o < FT; o += 2)
@@ -212,34 +215,26 @@ __global__ __launch_bounds__(kMixTB) void k_mix_fwd_cols(const int32_t *__restri
 }
 
 // =====================================================================================
-// basis mix, backward — two passes, both free of per-node dependent load chains:
+// basis mix, backward.
 //
-//   k_mix_bwd_dv    thread = (node j, feature o), accumulators over the bases in registers:
-//                     dV[b, j, o] = sum_{c in node j} comp[r_c, b] * dM[c, o]
-//                   (mirror of the forward: for a fixed b a wave writes 256 contiguous bytes)
-//   k_mix_bwd_dcomp thread = compact column c (lanes = consecutive columns: coalesced index
-//                   and dM reads, no divergence however skewed the node degrees are):
-//                     dcomp[r_c, b] += <dM[c, :], V[b, j_c, :]>      for every b
-//                   accumulated with LDS float atomics per block, one global flush per block.
+//   k_mix_bwd_nm    (F <= 16, B <= 64) WAVE STEPS OVER NODES, LANE = BASIS: dV and dcomp in one pass.
+//                     dV[j, b, :]    = sum_{c in node j} comp[r_c, b] * dM[c, :]
+//                     dcomp[r_c, b] += <dM[c, :], V[j, b, :]>
+//                   Everything per column is wave-uniform (relation id and dM row travel through
+//                   SGPRs via v_readlane), the dcomp atomics of a column go to B consecutive LDS
+//                   words, and a node without any live column costs neither its V block nor its dV
+//                   block: in the node-major layout both are one contiguous run of B*F floats that
+//                   lane b reads / writes F floats of.
+//   k_mix_bwd_dv + k_mix_bwd_dcomp   the same as two kernels for any F, B (thread = (node, feature)
+//                   with accumulators over the bases; thread = compact column with LDS atomics).
 // =====================================================================================
-// MODE 0: store dV (+ ||dV||^2)          the autograd path
-// MODE 1: ||dV||^2 only                  pass 1 of the deferred update (clip needs the norm first)
-// MODE 2: Adam on V with g = dV          pass 2: the 2.67 GB gradient is never written nor re-read
-struct AdamArgs {
-  float *p, *m, *v;
-  float step, b1, b2, eps, wd, bc2_sqrt;  // step = lr / (1 - beta1^t)
-  const float *scale;                     // clip coefficient (device, nullable)
-  int dbg_skip;                           // timing experiments only: skip the column loop
-};
-
-template <int BT, int MODE>
+template <int BT>
 __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict__ nptr,
                                                        const int32_t *__restrict__ urel,
                                                        const float *__restrict__ dM, int64_t ldM,
                                                        const float *__restrict__ comp, int64_t N, int R,
                                                        int B, int b0, int F, float *__restrict__ dV,
-                                                       int comp_in_lds, double *__restrict__ sumsq,
-                                                       AdamArgs ad) {
+                                                       int comp_in_lds, double *__restrict__ sumsq) {
   extern __shared__ __align__(16) float s_comp[];  // [R][CS]
   float sq = 0.f;
   constexpr int CS = comp_stride(BT);
@@ -260,7 +255,7 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
     float acc[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[b] = 0.f;
-    for (int32_t cb = c0; cb < (ad.dbg_skip ? c0 : c1); cb += kPre) {  // one round trip per chunk of kPre columns
+    for (int32_t cb = c0; cb < c1; cb += kPre) {  // one round trip per chunk of kPre columns
       int rr[kPre];
       float dd[kPre];
 #pragma unroll
@@ -286,48 +281,14 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
         }
       }
     }
-    if constexpr (MODE != 2) {
 #pragma unroll
-      for (int b = 0; b < BT; ++b)
-        if (b < nb) {
-          if constexpr (MODE == 0) dV[((int64_t)(b0 + b) * N + j) * F + o] = acc[b];
-          sq = fmaf(acc[b], acc[b], sq);
-        }
-    } else {
-      // torch.optim.Adam exactly as k_adam (optim.hip) computes it, eight bases per batch of
-      // loads; for a fixed b a wave touches 256 contiguous bytes of p / m / v
-      const float sc = ad.scale ? *ad.scale : 1.f;
-      constexpr int NB = BT < 8 ? BT : 8;
-#pragma unroll
-      for (int bb = 0; bb < BT; bb += NB) {
-        float pp[NB], mm[NB], vv[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          const int64_t idx = ((int64_t)(b0 + bb + i) * N + j) * F + o;
-          const bool in = bb + i < nb;
-          pp[i] = in ? ad.p[idx] : 0.f;
-          mm[i] = in ? ad.m[idx] : 0.f;
-          vv[i] = in ? ad.v[idx] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          if (bb + i < nb) {
-            float gg = acc[bb + i] * sc;
-            if (ad.wd != 0.f) gg = fmaf(ad.wd, pp[i], gg);
-            mm[i] = fmaf(ad.b1, mm[i], (1.f - ad.b1) * gg);
-            vv[i] = fmaf(ad.b2, vv[i], (1.f - ad.b2) * gg * gg);
-            const float denom = sqrtf(vv[i]) / ad.bc2_sqrt + ad.eps;
-            pp[i] -= ad.step * (mm[i] / denom);
-            const int64_t idx = ((int64_t)(b0 + bb + i) * N + j) * F + o;
-            ad.p[idx] = pp[i];
-            ad.m[idx] = mm[i];
-            ad.v[idx] = vv[i];
-          }
-        }
+    for (int b = 0; b < BT; ++b)
+      if (b < nb) {
+        dV[((int64_t)j * B + (b0 + b)) * F + o] = acc[b];
+        sq = fmaf(acc[b], acc[b], sq);
       }
-    }
   }
-  if (MODE != 2 && sumsq) {  // ||dV||^2 for clip_grad_norm_: saves a separate pass over the 2.67 GB gradient
+  if (sumsq) {  // ||dV||^2 for clip_grad_norm_: saves a separate pass over the gradient
     __shared__ float s_sq[kMixTB / 64];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
@@ -341,94 +302,75 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
   }
 }
 
-// =====================================================================================
-// basis mix, backward, WAVE PER NODE with LANE = BASIS (the default when F <= 16, B <= 64):
-// dV and dcomp in one pass.  PMC on the AM shape showed why the two kernels around this one are
-// slow: k_mix_bwd_dcomp keeps the LDS 88 % busy with float atomics that collide (a wave of 64
-// columns holds ~13 copies of the identity relation and of every popular predicate), and
-// k_mix_bwd_dv issues 435 M VALU instructions, most of them for lanes idled by the divergence
-// between the nodes that share a wave.  With one node per wave and one basis per lane
-//   * everything per column is wave-uniform: one load fetches relation id and dM row of four
-//     columns, v_readlane hands them to the FMAs as scalars; the column loop runs exactly the
-//     node's length, no lane diverges;
-//   * the dcomp atomics of a column go to B consecutive LDS words: conflict-free;
-//   * per column and lane: F FMAs for dcomp's dot product, F FMAs for dV.
-// Global memory is touched in runs, not per lane: a wave owns kGroup consecutive nodes; their V
-// rows ([B][kGroup*F], for dcomp) enter the wave's private LDS tile with float4 loads, the wave
-// works out of LDS and leaves dV in the same tile, which it streams out as float4 runs (MODE 0)
-// or feeds to the fused Adam (MODE 2).  (Letting lane b read / write its own slab directly was
-// measured at 10 ms — 40 partial lines per instruction — and block-wide tiles with barriers at
-// 3.6-3.9 ms: the phases of a block do not overlap.)  Waves never wait for each other.
-// Needs (N*F) % 4 == 0 and 16-byte aligned V / dV / p / m / v.
-// =====================================================================================
-constexpr int kNodeTB = 1024;  // 16 waves, one block per CU: 16 wave tiles + dcomp accumulators
-constexpr int kWChunkShift = 10;  // liveness of weight_I is kept per 1024 consecutive floats of a basis slab
-static_assert((1 << kWChunkShift) == MRGCN_WEIGHT_CHUNK, "header and kernels disagree");
-constexpr int kGroup = 4;      // consecutive nodes per wave step
+// ---- wave over nodes, lane = basis ---------------------------------------------------------------
+constexpr int kNodeTB = 512;  // 8 waves share one LDS copy of the dcomp accumulators
+constexpr int kGroup = 4;     // consecutive nodes whose pointers / flags / relation ids a wave fetches at once
 
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+// F floats of one basis row, rows only 4 * F bytes apart: 8-byte accesses when F is even
+template <int FT>
+__device__ __forceinline__ void load_row(const float *__restrict__ p, int F, float (&v)[FT]) {
+  if ((F & 1) == 0) {
+#pragma unroll
+    for (int o = 0; o < FT; o += 2) {
+      if (o < F) {
+        const float2 t = *reinterpret_cast<const float2 *>(p + o);
+        v[o] = t.x;
+        if (o + 1 < FT) v[o + 1] = t.y;
+      } else {
+        v[o] = 0.f;
+        if (o + 1 < FT) v[o + 1] = 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int o = 0; o < FT; ++o) v[o] = (o < F) ? p[o] : 0.f;
+  }
+}
+template <int FT>
+__device__ __forceinline__ void store_row_f(float *__restrict__ p, int F, const float (&v)[FT]) {
+  if ((F & 1) == 0) {
+#pragma unroll
+    for (int o = 0; o < FT; o += 2)
+      if (o < F) *reinterpret_cast<float2 *>(p + o) = make_float2(v[o], (o + 1 < FT) ? v[o + 1] : 0.f);
+  } else {
+#pragma unroll
+    for (int o = 0; o < FT; ++o)
+      if (o < F) p[o] = v[o];
+  }
 }
 
-template <int FT, int MODE, bool DCOMP>
-__global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restrict__ nptr,
-                                                          const int32_t *__restrict__ urel,
-                                                          const float *__restrict__ dM, int64_t ldM,
-                                                          const float *__restrict__ V,
-                                                          const float *__restrict__ comp, int64_t N, int R,
-                                                          int B, int F, float *__restrict__ dV,
-                                                          float *__restrict__ dcomp,
-                                                          double *__restrict__ sumsq, AdamArgs ad,
-                                                          int top_rel,
-                                                          const uint8_t *__restrict__ col_live,
-                                                          const uint8_t *__restrict__ chunk_cur,
-                                                          uint8_t *__restrict__ node_out) {
-  extern __shared__ __align__(16) float s_mem[];  // 16 wave tiles [B][rs] | dcomp accumulators [R*B]
-  const int row = kGroup * F;  // floats per basis in a wave tile
-  const int rs = row | 1;      // odd LDS stride: lanes (bases) fall on different banks
+// col_live  (nullable) one byte per compact column: does its dM row carry anything (dead rows of dM may
+//           be unwritten); NULL = every column counts
+// node_cur  (nullable) ROW-SPARSE gradient: only the blocks of nodes with a live column are written and
+//           node_cur[j] says which; NULL = every block is written (zeros for nodes without gradient)
+template <int FT>
+__global__ __launch_bounds__(kNodeTB) void k_mix_bwd_nm(const int32_t *__restrict__ nptr,
+                                                        const int32_t *__restrict__ urel,
+                                                        const float *__restrict__ dM, int64_t ldM,
+                                                        const float *__restrict__ V,
+                                                        const float *__restrict__ comp, int64_t N, int R,
+                                                        int B, int F, float *__restrict__ dV,
+                                                        float *__restrict__ dcomp,
+                                                        double *__restrict__ sumsq, int top_rel,
+                                                        const uint8_t *__restrict__ col_live,
+                                                        uint8_t *__restrict__ node_cur, int dc_in_lds) {
+  extern __shared__ __align__(16) float s_dc[];  // dcomp accumulators [R*B] of the block
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = blockDim.x >> 6;
-  float *s_tile = s_mem + wv * (B * rs);
-  float *s_dc = s_mem + nw * (B * rs);
-  if (DCOMP) {
+  if (dc_in_lds) {
     for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_dc[t] = 0.f;
     __syncthreads();
   }
+  float *dc = dc_in_lds ? s_dc : dcomp;
   const bool on = lane < B;
   const int b = on ? lane : 0;
   const int64_t ngroups = (N + kGroup - 1) / kGroup;
   const int64_t nwaves = (int64_t)gridDim.x * nw;
-  const int64_t slab = N * F;
-  const int row4 = row >> 2;
-  const float sc = (MODE == 2 && ad.scale) ? *ad.scale : 1.f;
   float sq = 0.f;
-  float hid = 0.f;
-  // MODE 3: float4 q of a node's [B][F] block gathers four tile elements; their offsets inside the
-  // tile (basis * rs + feature) are the same for every node
-  constexpr int kNmIter = (MODE == 3) ? 4 : 1;  // B * F <= 64 * 16 floats = 4 x 64 float4s
-  const int nf4 = (B * F) >> 2;
-  int nm_off[kNmIter][4];
-  if constexpr (MODE == 3) {
-#pragma unroll
-    for (int u = 0; u < kNmIter; ++u)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = 4 * (lane + 64 * u) + k, bb = e / F;
-        nm_off[u][k] = bb * rs + (e - bb * F);
-      }
-  }
+  float hid = 0.f;  // dcomp row of the most frequent relation (the identity block) stays in a register
   for (int64_t g = (int64_t)blockIdx.x * nw + wv; g < ngroups; g += nwaves) {
     const int64_t j0 = g * kGroup;
-    const int64_t base = j0 * F;
-    const int64_t left4 = (slab - base) >> 2;  // float4s left in a slab from the group's start
-    if (chunk_cur) {
-      // no node with gradient in the 4 KB chunks of the slab that this group's rows lie in: nothing
-      // is read, nothing is written — the masked Adam (mrgcn_adam_step_chunked_f32) never looks there
-      const int64_t last = (base + row - 1 < slab ? base + row - 1 : slab - 1);
-      if (!chunk_cur[base >> kWChunkShift] && !chunk_cur[last >> kWChunkShift]) continue;
-    }
     // wave-uniform values travel through SGPRs: one lane loads, v_readlane hands them out
     int32_t cp[kGroup + 1];
     {
@@ -436,67 +378,49 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
 #pragma unroll
       for (int i = 0; i <= kGroup; ++i) cp[i] = __builtin_amdgcn_readlane(mine, i);
     }
-    // relation ids of the group's first 64 columns, requested before anything depends on them
-    const int32_t rl = (cp[0] + lane < cp[kGroup]) ? urel[cp[0] + lane] : 0;
-    // which of those columns carry any gradient: lane l inspects the dM row of column cp[0] + l
-    // (consecutive rows: coalesced).  With few labelled nodes most rows of dM are exact zeros
-    // (on the AM shape ~90 %: only columns that feed a row within two hops of a label receive
-    // gradient) and a zero row adds nothing to dV or dcomp: its loads, FMAs and atomics are
-    // skipped (2.45 -> 2.2 ms; what remains is the tile traffic: 0.9 ms without any column).
-    // (`col_live`, when the producer of dM supplies it, says the same without touching dM — whose
-    // dead rows may then be unwritten)
-    uint64_t amask;
-    if (col_live) {
-      amask = __builtin_amdgcn_ballot_w64(cp[0] + lane < cp[kGroup] && col_live[cp[0] + lane] != 0);
-    } else {
-      bool nz = false;
-      if (cp[0] + lane < cp[kGroup]) {
-        const float *dr = dM + (int64_t)(cp[0] + lane) * ldM;
-        if ((ldM & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0) {
-          for (int q = 0; q < F; q += 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(dr + q);
-            nz |= (t.x != 0.f) | (q + 1 < F && t.y != 0.f) | (q + 2 < F && t.z != 0.f) |
-                  (q + 3 < F && t.w != 0.f);
-          }
-        } else {
-          for (int q = 0; q < F; ++q) nz |= dr[q] != 0.f;
-        }
-      }
-      amask = __builtin_amdgcn_ballot_w64(nz);
-    }
-    if constexpr (MODE == 3) {
-      // no column of the group's nodes carries gradient: nothing to read, nothing to write but the flags
-      if (col_live && amask == 0 && cp[kGroup] - cp[0] <= 64) {
-        if (lane < kGroup && j0 + lane < N) node_out[j0 + lane] = 0;
-        continue;
-      }
-    }
-    if constexpr (DCOMP) {  // ---- A: V rows of the group -> the wave's tile
-      for (int q = lane; q < B * row4; q += 64) {
-        const int bb = q / row4, x = q - bb * row4;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (x < left4) t = reinterpret_cast<const float4 *>(V)[((int64_t)bb * slab + base) / 4 + x];
-        float *d = s_tile + bb * rs + 4 * x;
-        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
-      }
-      wave_lds_fence();
-    }
-    // ---- B: node by node, lane = basis
-    bool node_any[kGroup];  // MODE 3: did the node have a live column (wave uniform)
+    const int32_t ncg = cp[kGroup] - cp[0];  // columns of the group
+    // relation ids and liveness of the group's first 64 columns, requested before anything depends on them
+    const int32_t rl = (lane < ncg) ? urel[cp[0] + lane] : 0;
+    const uint64_t amask = col_live ? __builtin_amdgcn_ballot_w64(lane < ncg && col_live[cp[0] + lane] != 0)
+                                    : __builtin_amdgcn_ballot_w64(lane < ncg);
 #pragma unroll
     for (int i = 0; i < kGroup; ++i) {
-      float *trow = s_tile + b * rs + i * F;
-      float v[FT];
-      if constexpr (DCOMP) {
-#pragma unroll
-        for (int o = 0; o < FT; ++o) v[o] = (o < F) ? trow[o] : 0.f;
+      const int64_t j = j0 + i;
+      if (j >= N) break;
+      const int32_t c_lo = cp[i], c_hi = cp[i + 1];
+      // does the node have a live column?  (columns beyond the 64 the mask covers: look the flags up)
+      bool any;
+      {
+        const int32_t lo = c_lo - cp[0], hi = c_hi - cp[0];
+        if (hi <= 64) {
+          const uint64_t m = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((lo >= 64) ? ~0ull : ((1ull << lo) - 1ull));
+          any = (amask & m) != 0;
+        } else if (!col_live) {
+          any = c_hi > c_lo;
+        } else {
+          bool f = false;
+          for (int32_t c = c_lo + lane; c < c_hi; c += 64) f |= col_live[c] != 0;
+          any = __builtin_amdgcn_ballot_w64(f) != 0;
+        }
       }
+      float *drow = dV + ((int64_t)j * B + b) * F;
+      if (!any) {  // wave uniform
+        if (node_cur) {
+          if (lane == 0) node_cur[j] = 0;
+        } else if (on) {
+          float z[FT];
+#pragma unroll
+          for (int o = 0; o < FT; ++o) z[o] = 0.f;
+          store_row_f<FT>(drow, F, z);
+        }
+        continue;
+      }
+      float v[FT];
+      load_row<FT>(V + ((int64_t)j * B + b) * F, F, v);
       float acc[FT];
 #pragma unroll
       for (int o = 0; o < FT; ++o) acc[o] = 0.f;
-      const int32_t c_hi = ad.dbg_skip ? cp[i] : cp[i + 1];
-      if constexpr (MODE == 3) node_any[i] = false;
-      for (int32_t cb = cp[i]; cb < c_hi; cb += 4) {
+      for (int32_t cb = c_lo; cb < c_hi; cb += 4) {
         // one load fetches the dM rows of four columns: the 16-lane group k reads column cb + k
         // (lane o of the group its feature o); v_readlane turns them into scalars
         const int32_t off = cb - cp[0];  // position among the group's columns (uniform)
@@ -512,8 +436,7 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
         }
         if (c_hi - cb < 4) live &= (1u << (c_hi - cb)) - 1u;  // the chunk's tail belongs to the next node
         if (live == 0) continue;  // four columns without gradient
-        if constexpr (MODE == 3) node_any[i] = true;
-        const float dmine = (cin && oq < F) ? dM[(int64_t)cc * ldM + oq] : 0.f;
+        const float dmine = (cin && oq < F && ((live >> kq) & 1u)) ? dM[(int64_t)cc * ldM + oq] : 0.f;
         int r[4];
         if (off + 4 <= 64) {
 #pragma unroll
@@ -528,112 +451,47 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_node(const int32_t *__restr
         for (int kk = 0; kk < 4; ++kk) w[kk] = comp[(int64_t)r[kk] * B + b];  // R*B floats: cache resident
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          if (cb + kk < c_hi && ((live >> kk) & 1u)) {  // wave-uniform
+          if ((live >> kk) & 1u) {  // wave-uniform
             float d[FT];
 #pragma unroll
             for (int o = 0; o < FT; ++o)
               d[o] = __builtin_bit_cast(
                   float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dmine), 16 * kk + o));
-            if constexpr (DCOMP) {
-              float dot = 0.f;
+            float dot = 0.f;
 #pragma unroll
-              for (int o = 0; o < FT; ++o) dot = fmaf(d[o], v[o], dot);
-              // the most frequent relation (the identity block: one column in every node, a fifth of
-              // all columns on the AM shape) keeps its dcomp row in a register — one scalar compare
-              // per column, one atomic per wave at the end (2.60 -> 2.48 ms; LDS float atomics cost
-              // ~3 cycles per lane whatever the addresses)
-              if (r[kk] == top_rel) hid += dot;
-              else if (on) atomicAdd(&s_dc[r[kk] * B + b], dot);
-            }
+            for (int o = 0; o < FT; ++o) dot = fmaf(d[o], v[o], dot);
+            // LDS float atomics cost ~3 cycles per lane whatever the addresses: the most frequent
+            // relation (a fifth of all columns on the AM shape) adds up in a register instead
+            if (r[kk] == top_rel) hid += dot;
+            else if (on) atomicAdd(&dc[r[kk] * B + b], dot);
 #pragma unroll
             for (int o = 0; o < FT; ++o) acc[o] = fmaf(w[kk], d[o], acc[o]);
           }
         }
       }
-      if (j0 + i < N && on) {
+      if (on) {
 #pragma unroll
         for (int o = 0; o < FT; ++o)
           if (o < F) sq = fmaf(acc[o], acc[o], sq);
+        store_row_f<FT>(drow, F, acc);
       }
-      if constexpr (MODE != 1) {
-        if (on) {
-#pragma unroll
-          for (int o = 0; o < FT; ++o)
-            if (o < F) trow[o] = acc[o];  // the V row has been consumed: reuse it for dV
-        }
-      }
-    }
-    if constexpr (MODE == 3) {
-      // ---- C': NODE-MAJOR gradient ([N][B][F]: the B rows of a node are one contiguous block), live
-      // nodes only — the layout the node-major Adam (mrgcn_adam_step_nodemajor_f32) streams; a dead
-      // node's block is left alone and its flag says so
-      wave_lds_fence();
-#pragma unroll
-      for (int i = 0; i < kGroup; ++i) {
-        if (j0 + i >= N) break;
-        if (lane == 0) node_out[j0 + i] = node_any[i] ? 1 : 0;
-        if (!node_any[i]) continue;  // wave uniform
-        float4 *dst = reinterpret_cast<float4 *>(dV) + (j0 + i) * (int64_t)nf4;
-        const float *src = s_tile + i * F;
-#pragma unroll
-        for (int u = 0; u < kNmIter; ++u) {
-          const int q = lane + 64 * u;
-          if (q < nf4)
-            dst[q] = make_float4(src[nm_off[u][0]], src[nm_off[u][1]], src[nm_off[u][2]], src[nm_off[u][3]]);
-        }
-      }
-      wave_lds_fence();
-    } else if constexpr (MODE != 1) {
-      wave_lds_fence();
-      // ---- C: the dV tile leaves in float4 runs
-      for (int q = lane; q < B * row4; q += 64) {
-        const int bb = q / row4, x = q - bb * row4;
-        if (x >= left4) continue;
-        const float *t = s_tile + bb * rs + 4 * x;
-        const float4 gq = make_float4(t[0], t[1], t[2], t[3]);
-        const int64_t gi = ((int64_t)bb * slab + base) / 4 + x;
-        if constexpr (MODE == 0) {
-          reinterpret_cast<float4 *>(dV)[gi] = gq;
-        } else {
-          float4 P = reinterpret_cast<const float4 *>(ad.p)[gi];
-          float4 M = reinterpret_cast<const float4 *>(ad.m)[gi];
-          float4 Vv = reinterpret_cast<const float4 *>(ad.v)[gi];
-          auto upd = [&](float &pp, float gg, float &mm, float &vv) {  // == k_adam (optim.hip)
-            gg *= sc;
-            if (ad.wd != 0.f) gg = fmaf(ad.wd, pp, gg);
-            mm = fmaf(ad.b1, mm, (1.f - ad.b1) * gg);
-            vv = fmaf(ad.b2, vv, (1.f - ad.b2) * gg * gg);
-            const float denom = sqrtf(vv) / ad.bc2_sqrt + ad.eps;
-            pp -= ad.step * (mm / denom);
-          };
-          upd(P.x, gq.x, M.x, Vv.x);
-          upd(P.y, gq.y, M.y, Vv.y);
-          upd(P.z, gq.z, M.z, Vv.z);
-          upd(P.w, gq.w, M.w, Vv.w);
-          reinterpret_cast<float4 *>(ad.p)[gi] = P;
-          reinterpret_cast<float4 *>(ad.m)[gi] = M;
-          reinterpret_cast<float4 *>(ad.v)[gi] = Vv;
-        }
-      }
-      wave_lds_fence();  // the tile is rewritten by the next group
+      if (node_cur && lane == 0) node_cur[j] = 1;
     }
   }
-  if constexpr (MODE != 2) {
-    if (sumsq) {
-      __shared__ float s_sq[kNodeTB / 64];
+  if (sumsq) {
+    __shared__ float s_sq[kNodeTB / 64];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
-      if (lane == 0) s_sq[wv] = sq;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int i = 0; i < nw; ++i) t += s_sq[i];
-        atomicAdd(sumsq, (double)t);
-      }
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if (lane == 0) s_sq[wv] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < nw; ++i) t += s_sq[i];
+      atomicAdd(sumsq, (double)t);
     }
   }
-  if constexpr (DCOMP) {
-    if (top_rel >= 0 && on && hid != 0.f) atomicAdd(&s_dc[top_rel * B + b], hid);
+  if (top_rel >= 0 && on && hid != 0.f) atomicAdd(&dc[top_rel * B + b], hid);
+  if (dc_in_lds) {
     __syncthreads();
     for (int t = threadIdx.x; t < R * B; t += blockDim.x) {
       const float x = s_dc[t];
@@ -664,7 +522,7 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dcomp(const int32_t *__restr
 #pragma unroll
     for (int o = 0; o < FT; ++o) dm[o] = (o < F) ? dp[o] : 0.f;
     for (int b = 0; b < B; ++b) {
-      const float *vp = V + ((int64_t)b * N + j) * ldV;
+      const float *vp = V + ((int64_t)j * B + b) * ldV;
       float dot = 0.f;
       if (VEC2) {  // F even: rows of V are 8-byte aligned; 16-byte loads need dword alignment only
 #pragma unroll
@@ -1060,7 +918,6 @@ int mrgcn_rel_transform_fwd_bf16(const mrgcn_plan_t *p, const float *X, int64_t 
 }  // extern "C"
 
 namespace {
-// the dV pass of the basis-mix backward in one of its three modes (see k_mix_bwd_dv)
 // rows of dM whose liveness flag is 0 were possibly never written (mrgcn_spmm_transposed_live_f32 with
 // write_dead_rows = 0): kernels that read every row get zeros there first
 __global__ void k_zero_dead_rows(float *__restrict__ dM, int64_t ldM, int F, const uint8_t *__restrict__ col_live,
@@ -1082,45 +939,30 @@ static int zero_dead_rows(float *dM, int64_t ldM, int F, const uint8_t *col_live
   return MRGCN_OK;
 }
 
-// wave-per-node form of the basis-mix backward (k_mix_bwd_node); returns MRGCN_OK when it ran,
-// -1 when the shape is outside its limits (the caller falls back to the two-kernel form), an
-// error code otherwise.
-// can the wave-per-node kernel run this shape (DCOMP form)?
-static bool node_kernel_shape_ok(const mrgcn_plan_t *p, int B, int F) {
-  const size_t lds = ((size_t)(kNodeTB / 64) * B * ((kGroup * F) | 1) + (size_t)p->num_relations * B) * sizeof(float);
-  return F <= 16 && B <= 64 && lds <= 150 * 1024 && p->num_nodes > 0 && (p->num_nodes * (int64_t)F) % 4 == 0;
-}
-
-template <int MODE, bool DCOMP>
-int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
-                        const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
-                        double *dV_sumsq, const mrgcn::AdamArgs &ad, hipStream_t s,
-                        const uint8_t *col_live = nullptr, const uint8_t *chunk_cur = nullptr,
-                        uint8_t *node_out = nullptr) {
+// wave-over-nodes form (k_mix_bwd_nm); MRGCN_OK when it ran, -1 when the shape is outside its limits
+int mix_bwd_nm_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V, const float *comp,
+                      int32_t B, int32_t F, float *dV, float *dcomp, double *dV_sumsq, hipStream_t s,
+                      const uint8_t *col_live, uint8_t *node_cur) {
   static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
-  const size_t lds = ((size_t)(kNodeTB / 64) * B * ((kGroup * F) | 1) + (DCOMP ? (size_t)R * B : 0)) * sizeof(float);
-  auto al16 = [](const void *q) { return (((uintptr_t)q) & 15) == 0; };
-  bool ok = node_on && F <= 16 && B <= 64 && lds <= 150 * 1024 && N > 0 && (N * F) % 4 == 0;
-  if (DCOMP) ok = ok && al16(V);
-  if (MODE == 0) ok = ok && al16(dV);
-  if (MODE == 3) ok = ok && al16(dV) && node_out && (B * F) % 4 == 0;
-  if (MODE == 2) ok = ok && al16(ad.p) && al16(ad.m) && al16(ad.v);
+  bool ok = node_on && F <= 16 && B <= 64 && N > 0;
+  if ((F & 1) == 0) ok = ok && (((uintptr_t)V | (uintptr_t)dV) & 7) == 0;  // 8-byte row accesses
   if (!ok) return -1;
-  // register arrays of exactly F features for the hidden sizes of the BASELINE configs (10, 11):
-  // two padding features would cost a sixth of the pass's readlanes and FMAs
+  size_t lds = (size_t)R * B * sizeof(float);
+  const int dc_in_lds = lds <= 96 * 1024;
+  if (!dc_in_lds) lds = 0;
+  // register arrays of exactly F features for the hidden sizes of the BASELINE configs (10, 11)
   const int FT = (F == 10 || F == 11) ? F : (F + 3) / 4 * 4;
-  static const int grid_mult = getenv("MRGCN_MIX_NODE_GRID") ? atoi(getenv("MRGCN_MIX_NODE_GRID")) : 1;
-  int per_cu = (int)((160 * 1024) / (lds + 1024));
+  int per_cu = lds > 0 ? (int)((160 * 1024) / (lds + 1024)) : 4;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
   const int64_t want = ((N + kGroup - 1) / kGroup + (kNodeTB / 64) - 1) / (kNodeTB / 64);
-  int64_t grid = (int64_t)256 * per_cu * (grid_mult < 1 ? 1 : grid_mult);
+  int64_t grid = (int64_t)256 * per_cu;
   if (grid > want) grid = want;
 #define NODE_GO(T)                                                                                        \
   do {                                                                                                    \
-    auto kfn = k_mix_bwd_node<T, MODE, DCOMP>;                                                            \
+    auto kfn = k_mix_bwd_nm<T>;                                                                           \
     static size_t lds_allowed = 48 * 1024; /* per instantiation: raise the dynamic-LDS limit once */      \
     if (lds > lds_allowed) {                                                                              \
       MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
@@ -1128,8 +970,8 @@ int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, con
       lds_allowed = lds;                                                                                  \
     }                                                                                                     \
     kfn<<<dim3((unsigned)grid), dim3(kNodeTB), lds, s>>>(p->nptr, p->urel, dM, ldM, V, comp, N, R, B, F, dV, \
-                                                         dcomp, dV_sumsq, ad, (int)p->top_rel, col_live,  \
-                                                         chunk_cur, node_out);                            \
+                                                         dcomp, dV_sumsq, (int)p->top_rel, col_live,     \
+                                                         node_cur, dc_in_lds);                           \
   } while (0)
   switch (FT) {
     case 4: NODE_GO(4); break;
@@ -1144,27 +986,20 @@ int mix_bwd_node_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, con
   return MRGCN_OK;
 }
 
-template <int MODE>
 int mix_bwd_dv_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *comp, int32_t B,
-                      int32_t F, float *dV, double *dV_sumsq, const mrgcn::AdamArgs &ad, hipStream_t s) {
+                      int32_t F, float *dV, double *dV_sumsq, hipStream_t s) {
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
-  // bases per launch.  MODE 2 streams p / m / v of every basis it owns (3 arrays x nb slabs of
-  // 4*N*F bytes, read and written): 16 bases per launch measured best on the AM shape (4.5 ms
-  // vs 5.4 ms with all 40 at once — fewer concurrent streams per wave — and 4.8 ms with 8, where
-  // re-walking the columns starts to cost).  Must be one of the BT instantiations.
-  static const int dv_bt = getenv("MRGCN_DV_BT") ? atoi(getenv("MRGCN_DV_BT")) : 16;
-  const int step_b = MODE == 2 ? ((dv_bt == 8 || dv_bt == 16 || dv_bt == 32) ? dv_bt : 64) : 64;
-  for (int b0 = 0; b0 < B; b0 += step_b) {
-    const int nb = (B - b0 < step_b) ? (B - b0) : step_b;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int nb = (B - b0 < 64) ? (B - b0) : 64;
     int BT = nb <= 2 ? 2 : nb <= 4 ? 4 : nb <= 8 ? 8 : nb <= 16 ? 16 : nb <= 32 ? 32 : nb <= 40 ? 40 : 64;
     size_t lds = (size_t)R * comp_stride(BT) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
     int grid = mix_grid(lds, N * F);
 #define MIXDV_GO(T)                                                                                       \
-  k_mix_bwd_dv<T, MODE><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->nptr, p->urel, dM, ldM, comp, N, R, B, b0, \
-                                                              F, dV, in_lds, dV_sumsq, ad)
+  k_mix_bwd_dv<T><<<dim3(grid), dim3(kMixTB), lds, s>>>(p->nptr, p->urel, dM, ldM, comp, N, R, B, b0, F, \
+                                                        dV, in_lds, dV_sumsq)
     switch (BT) {
       case 2: MIXDV_GO(2); break;
       case 4: MIXDV_GO(4); break;
@@ -1183,126 +1018,31 @@ int mix_bwd_dv_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const
 
 extern "C" {
 
-int mrgcn_basis_mix_bwd_adam_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *comp,
-                                 int32_t B, int32_t F, float *param, float *exp_avg, float *exp_avg_sq,
-                                 float lr, float beta1, float beta2, float eps, float weight_decay,
-                                 int64_t step, const float *grad_scale, void *stream) {
-  MRGCN_REQUIRE(p && dM && comp && param && exp_avg && exp_avg_sq, "NULL");
-  MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
-  MRGCN_REQUIRE(step >= 1, "step counts from 1");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  static const int dbg_skip = getenv("MRGCN_DEBUG_DV_SKIP") ? atoi(getenv("MRGCN_DEBUG_DV_SKIP")) : 0;
-  mrgcn::AdamArgs ad{param, exp_avg, exp_avg_sq, lr / (float)bc1, beta1, beta2, eps, weight_decay,
-                     (float)sqrt(bc2), grad_scale, dbg_skip};
-  {
-    int rc = mix_bwd_node_launch<2, false>(p, dM, ldM, nullptr, comp, B, F, nullptr, nullptr, nullptr, ad,
-                                           (hipStream_t)stream);
-    if (rc >= 0) return rc;
-  }
-  return mix_bwd_dv_launch<2>(p, dM, ldM, comp, B, F, nullptr, nullptr, ad, (hipStream_t)stream);
-}
-
-int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V,
-                            const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
-                            double *dV_sumsq, void *stream) {
-  return mrgcn_basis_mix_bwd_live_f32(p, const_cast<float *>(dM), ldM, nullptr, nullptr, V, comp, B, F, dV,
-                                      dcomp, dV_sumsq, stream);
-}
-
-// flags per node -> flags per 1024-float chunk of a basis slab of V / dV
-__global__ void k_weight_chunks_live(const int32_t *__restrict__ nptr, const uint8_t *__restrict__ col_live,
-                                     int64_t N, int F, uint8_t *__restrict__ cur, uint8_t *__restrict__ ever) {
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N;
-       j += (int64_t)gridDim.x * blockDim.x) {
-    bool live = false;
-    for (int32_t c = nptr[j]; c < nptr[j + 1] && !live; ++c) live = col_live[c] != 0;
-    if (!live) continue;
-    const int64_t c0 = (j * F) >> mrgcn::kWChunkShift, c1 = (j * F + F - 1) >> mrgcn::kWChunkShift;
-    for (int64_t c = c0; c <= c1; ++c) {
-      cur[c] = 1;
-      ever[c] = 1;
-    }
-  }
-}
-
-int64_t mrgcn_weight_chunks(const mrgcn_plan_t *p, int32_t F) {
-  return p ? ((p->num_nodes * (int64_t)F + MRGCN_WEIGHT_CHUNK - 1) >> mrgcn::kWChunkShift) : 0;
-}
-
-int mrgcn_weight_chunks_live(const mrgcn_plan_t *p, const uint8_t *col_live, int32_t F, uint8_t *cur,
-                             uint8_t *ever, void *stream) {
-  MRGCN_REQUIRE(p && col_live && cur && ever && F > 0, "NULL");
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t nch = mrgcn_weight_chunks(p, F);
-  MRGCN_HIP_TRY(hipMemsetAsync(cur, 0, (size_t)nch, s));
-  if (p->num_nodes > 0) {
-    int64_t blocks = (p->num_nodes + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    k_weight_chunks_live<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p->nptr, col_live, p->num_nodes, F, cur, ever);
-    MRGCN_HIP_TRY(hipGetLastError());
-  }
-  return MRGCN_OK;
-}
-
-int32_t mrgcn_nodemajor_supported(const mrgcn_plan_t *p, int32_t B, int32_t F) {
-  static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
-  if (!p || !node_on || B <= 0 || F <= 0) return 0;
-  // the Adam side transposes tiles of >= 8 nodes through LDS: [B][T*F + 4] floats
-  return node_kernel_shape_ok(p, B, F) && (B * F) % 4 == 0 && (size_t)B * (8 * F + 4) * 4 <= 60 * 1024;
-}
-
-int mrgcn_basis_mix_bwd_nodemajor_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const uint8_t *col_live,
-                                      const float *V, const float *comp, int32_t B, int32_t F, float *dV_nm,
-                                      uint8_t *node_cur, float *dcomp, double *dV_sumsq, void *stream) {
-  MRGCN_REQUIRE(p && dM && V && comp && dcomp && dV_nm && node_cur, "NULL");
-  MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
-  MRGCN_REQUIRE(mrgcn_nodemajor_supported(p, B, F), "shape not supported (mrgcn_nodemajor_supported)");
-  hipStream_t s = (hipStream_t)stream;
-  MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)p->num_relations * B * sizeof(float), s));
-  mrgcn::AdamArgs none{};
-  int rc = mix_bwd_node_launch<3, true>(p, dM, ldM, V, comp, B, F, dV_nm, dcomp, dV_sumsq, none, s, col_live, nullptr,
-                                        node_cur);
-  if (rc < 0) {
-    set_error("mrgcn_basis_mix_bwd_nodemajor_f32: operands must be 16-byte aligned");
-    return MRGCN_ERR_UNSUPPORTED;
-  }
-  return rc;
-}
-
-int mrgcn_basis_mix_bwd_live_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const uint8_t *col_live,
-                                 const uint8_t *chunk_live, const float *V, const float *comp, int32_t B,
-                                 int32_t F, float *dV, float *dcomp, double *dV_sumsq, void *stream) {
-  MRGCN_REQUIRE(p && dM && V && comp && dcomp, "NULL");
-  MRGCN_REQUIRE(dV || dV_sumsq, "dV may be NULL only when dV_sumsq is wanted (deferred update)");
+int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const uint8_t *col_live,
+                            const float *V, const float *comp, int32_t B, int32_t F, float *dV,
+                            uint8_t *node_cur, float *dcomp, double *dV_sumsq, void *stream) {
+  MRGCN_REQUIRE(p && dM && V && comp && dcomp && dV, "NULL");
   MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
   hipStream_t s = (hipStream_t)stream;
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
   MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)R * B * sizeof(float), s));
   {  // one pass for dV and dcomp when the shape allows it
-    mrgcn::AdamArgs none{};
-    int rc = dV ? mix_bwd_node_launch<0, true>(p, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, none, s, col_live,
-                                               chunk_live)
-                : mix_bwd_node_launch<1, true>(p, dM, ldM, V, comp, B, F, nullptr, dcomp, dV_sumsq, none, s, col_live,
-                                               chunk_live);
+    int rc = mix_bwd_nm_launch(p, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, s, col_live, node_cur);
     if (rc >= 0) return rc;
   }
-  // (`chunk_live` only lets the wave-per-node kernel leave dead chunks alone; the kernels below write
-  // every row of dV, which is just as good for the masked Adam)
-  // the two-kernel form reads every row of dM: rows flagged dead may be unwritten
+  // the two-kernel form reads every row of dM (rows flagged dead may be unwritten) and writes every
+  // block of dV: every node counts as written
   if (col_live) {
     int rc = zero_dead_rows(dM, ldM, F, col_live, p->ncols, s);
     if (rc != MRGCN_OK) return rc;
   }
-  // pass 1: dV (or only its squared norm)
+  if (node_cur && N > 0) MRGCN_HIP_TRY(hipMemsetAsync(node_cur, 1, (size_t)N, s));
   {
-    mrgcn::AdamArgs none{};
-    int rc = dV ? mix_bwd_dv_launch<0>(p, dM, ldM, comp, B, F, dV, dV_sumsq, none, s)
-                : mix_bwd_dv_launch<1>(p, dM, ldM, comp, B, F, nullptr, dV_sumsq, none, s);
+    int rc = mix_bwd_dv_launch(p, dM, ldM, comp, B, F, dV, dV_sumsq, s);
     if (rc != MRGCN_OK) return rc;
   }
-  // pass 2: dcomp, the feature dimension in tiles of <= 64 (dcomp accumulates over the tiles)
+  // dcomp, the feature dimension in tiles of <= 64 (dcomp accumulates over the tiles)
   if (p->ncols > 0) {
     size_t lds = (size_t)R * (B | 1) * sizeof(float);
     int in_lds = lds <= kLdsBudget;

@@ -284,6 +284,259 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const DT *__restrict
   }
 }
 
+// =====================================================================================================
+// k_spmm3 — the forward product for narrow layers (G <= 4 lanes of float4 per row: F <= 16).
+//
+// What bounds k_spmm above at F = 10 is not bandwidth but dependent round trips: it gathers four entries
+// per row, waits, looks whether any row has entries left, gathers four more (rows of <= 32 entries: up to
+// eight rounds; chunks of 512: 32 rounds) — measured 118 us with every operand row cache resident.  Here
+// every wave issues ALL its gathers (at most eight per lane) in one basic block, after one round of staging
+// loads, whatever it works on:
+//   S  rows of <= 8 entries: 64/G consecutive rows per wave, a slot of G lanes each
+//   M  rows of 9..32 entries (plan list `mid_rows`): four rows per wave, 16 lanes = 16/G sub-slots each,
+//      sub-slot s takes entries s, s + 16/G, ...; a 16-lane butterfly joins them
+//   L  rows of > 32 entries: plan chunks of <= 128 entries, one wave each, slot s takes entries s, s + 64/G, ...;
+//      a wave butterfly joins the slots; rows of several chunks leave partials for k_spmm3_finalize
+// The number of gathers is wave uniform, so the batch is picked by a switch over straight-line code: the
+// compiler's wait-count pass serialises loads that sit behind exec-dependent branches.  No atomics: bitwise
+// reproducible.  AM shape, F = 10: S 75 us / M 36 us / L 60 us on their own, each at the HBM rate of the
+// bytes it touches.
+// =====================================================================================================
+constexpr int kShort3 = kShort3Rows;    // S: rows of at most this many entries
+constexpr int kMid3 = kMid3Rows;        // M: up to this many
+constexpr int kChunk3 = kChunk3Entries; // L: entries per chunk (8 gathers per lane at G = 4)
+
+template <int NT, int VEC, bool TAIL, typename DT, typename GetFn, typename OnFn>
+__device__ __forceinline__ void gather_batch(const DT *__restrict__ Dq, int64_t ldD, bool active, int nvalid,
+                                             float (&acc)[VEC], GetFn get, OnFn on) {
+  float x[NT][VEC];
+  float a[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    int32_t c;
+    get(t, c, a[t]);
+    const DT *p = Dq + (int64_t)c * ldD;
+    if constexpr (TAIL) {
+      if (nvalid < VEC) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) x[t][i] = (i < nvalid) ? (float)p[i] : 0.f;
+      } else {
+        load_vec<VEC, DT>(p, x[t]);
+      }
+    } else {
+      load_vec<VEC, DT>(p, x[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const bool o = active && on(t);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = fmaf(a[t], o ? x[t][i] : 0.f, acc[i]);
+  }
+}
+
+template <int VEC, bool TAIL, typename DT, typename GetFn, typename OnFn>
+__device__ __forceinline__ void gather_rounds(int nr, const DT *__restrict__ Dq, int64_t ldD, bool active,
+                                              int nvalid, float (&acc)[VEC], GetFn get, OnFn on) {
+  switch (nr) {  // wave uniform
+    case 1: gather_batch<1, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
+    case 2: gather_batch<2, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
+    case 3: gather_batch<3, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
+    case 4: gather_batch<4, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
+    case 5: gather_batch<5, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
+    case 6: gather_batch<6, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
+    case 7: gather_batch<7, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
+    case 8: gather_batch<8, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
+    default: break;
+  }
+}
+
+struct View3 {  // the descriptors of the row orientation that k_spmm3 adds to SparseView
+  int32_t n_mid = 0, n_chunks = 0, n_long = 0, n_multi = 0;
+  const int32_t *mid_rows = nullptr;                                         // [n_mid] rows of 9..32 entries
+  const int32_t *chunk_beg = nullptr, *chunk_end = nullptr, *chunk_row = nullptr;  // [n_chunks], as SparseView's
+  const int32_t *long_row = nullptr, *long_cptr = nullptr;                   // [n_long], [n_long + 1]
+};
+
+template <int G, int VEC, bool TAIL, typename DT>
+__global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *__restrict__ D, int64_t ldD,
+                                               int F, float *__restrict__ Y, int64_t ldY,
+                                               const float *__restrict__ bias, int relu,
+                                               const int32_t *__restrict__ out_index, int store_vec_ok,
+                                               float *__restrict__ partials, int ldP, int chunk_blocks,
+                                               int mid_blocks, int64_t short_blocks, int64_t xcd_per) {
+  constexpr int SLOTS = kWave / G;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int slot = lane / G, q = lane % G;
+  const int f0 = q * VEC;
+  const bool active = f0 < F;
+  const DT *Dq = D + (active ? f0 : 0);  // idle feature lanes shadow lane 0 (always in bounds)
+  const int nvalid = active ? min(VEC, F - f0) : VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+
+  if ((int)blockIdx.x < chunk_blocks) {  // ---- L: one wave per chunk of <= kChunk3 entries
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= w.n_chunks) return;
+    const int32_t b = w.chunk_beg[c], n = w.chunk_end[c] - b;
+    constexpr int T = kChunk3 / kWave;
+    int32_t ci[T];
+    float ca[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {  // entry b + 64 t + lane: fully coalesced
+      const int32_t m = t * kWave + lane;
+      ci[t] = (m < n) ? v.idx[b + m] : 0;
+      ca[t] = (m < n) ? v.val[b + m] : 0.f;
+    }
+    constexpr int PER = kWave / SLOTS;  // = G gather rounds per staged register
+    const int nr = __builtin_amdgcn_readfirstlane((n + SLOTS - 1) / SLOTS);
+    gather_rounds<VEC, TAIL, DT>(
+        nr, Dq, ldD, active, nvalid, acc,
+        [&](int t, int32_t &cc, float &aa) {
+          const int src = (t % PER) * SLOTS + slot;
+          cc = __shfl(ci[t / PER], src, kWave);
+          aa = __shfl(ca[t / PER], src, kWave);
+        },
+        [&](int t) { return t * SLOTS + slot < n; });
+#pragma unroll
+    for (int off = G; off < kWave; off <<= 1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
+    }
+    if (slot == 0 && active) {
+      const int32_t row = w.chunk_row[c];
+      if (row >= 0) {  // the whole row was this chunk: finished
+        const int64_t orow = out_index ? (int64_t)out_index[row] : (int64_t)row;
+        store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
+      } else {
+        float *p = partials + (int64_t)c * ldP + f0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+          if (f0 + i < F) p[i] = acc[i];
+      }
+    }
+    return;
+  }
+  if ((int)blockIdx.x < chunk_blocks + mid_blocks) {  // ---- M: four rows per wave, 16 lanes each
+    constexpr int SS = 16 / G;                          // sub-slots per row
+    const int wv = (blockIdx.x - chunk_blocks) * 4 + (threadIdx.x >> 6);
+    const int rsel = lane >> 4, l16 = lane & 15, ss = slot % SS;
+    const int mi = wv * 4 + rsel;
+    int32_t b = 0, n = 0, row = -1;
+    if (mi < w.n_mid) {
+      row = w.mid_rows[mi];
+      b = v.ptr[row];
+      n = v.ptr[row + 1] - b;
+    }
+    if (!__any(row >= 0)) return;
+    constexpr int T = kMid3 / 16;
+    int32_t ci[T];
+    float ca[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int32_t m = t * 16 + l16;
+      ci[t] = (m < n) ? v.idx[b + m] : 0;
+      ca[t] = (m < n) ? v.val[b + m] : 0.f;
+    }
+    int nr = 0;
+#pragma unroll
+    for (int t = 0; t < kMid3 / SS; ++t)
+      if (t < 8 && __any(t * SS < n)) nr = t + 1;
+    const int base = rsel * 16;
+    gather_rounds<VEC, TAIL, DT>(
+        nr, Dq, ldD, active, nvalid, acc,
+        [&](int t, int32_t &cc, float &aa) {  // sub-slot ss takes entry t*SS + ss of its row
+          const int e = t * SS + ss;
+          cc = __shfl(ci[e / 16 < T ? e / 16 : T - 1], base + (e & 15), kWave);
+          aa = __shfl(ca[e / 16 < T ? e / 16 : T - 1], base + (e & 15), kWave);
+        },
+        [&](int t) { return t * SS + ss < n; });
+#pragma unroll
+    for (int off = G; off < 16; off <<= 1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
+    }
+    if (ss == 0 && row >= 0 && active) {
+      const int64_t orow = out_index ? (int64_t)out_index[row] : (int64_t)row;
+      store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
+    }
+    return;
+  }
+  // ---- S: 64/G consecutive rows per wave; rows of more than kShort3 entries are someone else's
+  // blocks b and b+8 share an XCD (round-robin dispatch): every XCD gets one contiguous run of rows
+  int64_t sb = (int64_t)blockIdx.x - chunk_blocks - mid_blocks;
+  if (xcd_per > 0) {
+    sb = (sb & 7) * xcd_per + (sb >> 3);
+    if (sb >= short_blocks) return;
+  }
+  const int64_t row = (sb * 4 + (threadIdx.x >> 6)) * SLOTS + slot;
+  int32_t b = 0, n = 0;
+  if (row < v.rows) {
+    b = v.ptr[row];
+    n = v.ptr[row + 1] - b;
+  }
+  const bool mine = row < v.rows && n <= kShort3;
+  if (!mine) n = 0;
+  if (!__any(mine)) return;  // wave uniform
+  constexpr int T = (kShort3 + G - 1) / G;
+  int32_t ci[T];
+  float ca[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int32_t m = t * G + q;
+    ci[t] = (m < n) ? v.idx[b + m] : 0;
+    ca[t] = (m < n) ? v.val[b + m] : 0.f;
+  }
+  int nr = 0;
+#pragma unroll
+  for (int t = 0; t < kShort3; ++t)
+    if (__any(t < n)) nr = t + 1;
+  const int sbase = slot * G;
+  gather_rounds<VEC, TAIL, DT>(
+      nr, Dq, ldD, active, nvalid, acc,
+      [&](int t, int32_t &cc, float &aa) {
+        cc = __shfl(ci[t / G], sbase + (t % G), kWave);
+        aa = __shfl(ca[t / G], sbase + (t % G), kWave);
+      },
+      [&](int t) { return t < n; });
+  if (mine && active) {
+    const int64_t orow = out_index ? (int64_t)out_index[row] : row;
+    store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
+  }
+}
+
+// rows of several chunks: one wave per long row; lane = (chunk mod 64/FP, feature), eight partials in flight
+__global__ __launch_bounds__(256) void k_spmm3_finalize(View3 w, const float *__restrict__ partials, int ldP, int F,
+                                                        float *__restrict__ Y, int64_t ldY,
+                                                        const float *__restrict__ bias, int relu,
+                                                        const int32_t *__restrict__ out_index) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t li = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  if (li >= w.n_long) return;
+  const int32_t c0 = w.long_cptr[li], c1 = w.long_cptr[li + 1];
+  if (c1 - c0 <= 1) return;  // single-chunk rows were stored by the chunk wave
+  const int f = lane & 15, k = lane >> 4;  // F <= 16 here: four chunks per step
+  float s[2] = {0.f, 0.f};
+  int32_t c = c0 + k;
+  for (; c + 4 < c1; c += 8) {
+    s[0] += partials[(int64_t)c * ldP + f];
+    s[1] += partials[(int64_t)(c + 4) * ldP + f];
+  }
+  if (c < c1) s[0] += partials[(int64_t)c * ldP + f];
+  // fixed order: (k = 0..3) joined by the butterfly
+  float t = s[0] + s[1];
+  t += __shfl_xor(t, 16, kWave);
+  t += __shfl_xor(t, 32, kWave);
+  if (k == 0 && f < F) {
+    int64_t row = w.long_row[li];
+    if (out_index) row = out_index[row];
+    if (bias) t += bias[f];
+    if (relu) t = fmaxf(t, 0.f);
+    Y[row * ldY + f] = t;
+  }
+}
+
 // ---- tiny rows (<= kTiny entries) ------------------------------------------------------------
 // The transposed view has millions of rows of 1-2 entries (AM: 8.2 M rows, 87 % single entry):
 // a wave that owns only 64/G such rows is pure latency (pointer -> index -> gather, three
@@ -549,10 +802,30 @@ __global__ __launch_bounds__(256) void k_spmm_finalize(SparseView v, const float
 template <int G, int VEC, bool TAIL = false, typename DT = float>
 int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64_t ldY,
            const float *bias, int relu, const int32_t *out_index, float *partials, bool use_tiny,
-           hipStream_t s) {
+           hipStream_t s, const View3 *w3 = nullptr) {
   constexpr int SLOTS = kWave / G;
   constexpr int SV = VEC > 4 ? 4 : VEC;  // widest single store
   const bool store_vec_ok = (ldY % SV == 0) && (((uintptr_t)Y) % (SV * 4) == 0);
+  if constexpr (G <= 4 && VEC == 4) {
+    static const bool v3_on = !(getenv("MRGCN_SPMM_V3") && atoi(getenv("MRGCN_SPMM_V3")) == 0);
+    if (w3 && v3_on && v.rows > 0) {  // one gather batch per wave (k_spmm3)
+      const int64_t short_waves = (v.rows + SLOTS - 1) / SLOTS;
+      const int64_t short_blocks = (short_waves + 3) / 4;
+      const int chunk_blocks = (w3->n_chunks + 3) / 4;
+      const int mid_blocks = ((w3->n_mid + 3) / 4 + 3) / 4;
+      const int64_t xcd_per = (short_blocks + 7) / 8;
+      k_spmm3<G, VEC, TAIL, DT><<<dim3((unsigned)(xcd_per * 8 + chunk_blocks + mid_blocks)), dim3(256), 0, s>>>(
+          v, *w3, D, ldD, F, Y, ldY, bias, relu, out_index, store_vec_ok ? 1 : 0, partials, 16, chunk_blocks,
+          mid_blocks, short_blocks, xcd_per);
+      MRGCN_HIP_TRY(hipGetLastError());
+      if (w3->n_multi > 0) {
+        k_spmm3_finalize<<<dim3((unsigned)((w3->n_long + 3) / 4)), dim3(256), 0, s>>>(*w3, partials, 16, F, Y, ldY,
+                                                                                      bias, relu, out_index);
+        MRGCN_HIP_TRY(hipGetLastError());
+      }
+      return MRGCN_OK;
+    }
+  }
   const int64_t short_waves = (v.rows + SLOTS - 1) / SLOTS;
   const int64_t short_blocks = (short_waves + 3) / 4;
   const int64_t chunk_blocks = ((int64_t)v.n_chunks + 3) / 4;
@@ -589,7 +862,7 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
 // picks lanes-per-row G and vector width VEC for one feature tile of width F <= 256
 int dispatch(const SparseView &v, const float *D, int64_t ldD, int64_t avail, int F, float *Y,
              int64_t ldY, const float *bias, int relu, const int32_t *out_index, float *partials,
-             bool use_tiny, bool operand_cached, hipStream_t s) {
+             bool use_tiny, bool operand_cached, hipStream_t s, const View3 *w3 = nullptr) {
   // widest vector the operand layout allows; loads past F must stay inside the row
   // (`avail` = floats left in a row of D from this tile's first column)
   int vec = 1;
@@ -608,13 +881,13 @@ int dispatch(const SparseView &v, const float *D, int64_t ldD, int64_t avail, in
   // on the 17.8 GB literal operand, 453 vs 496 / 472 vs 725 us on the 67-73 MB dY)
   if (vec < 4 && F <= 32 && !no_tail && operand_cached) {
     const int l4 = (F + 3) / 4;
-    if (l4 <= 1) return launch<1, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s);
-    if (l4 <= 2) return launch<2, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s);
-    if (l4 <= 4) return launch<4, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s);
+    if (l4 <= 1) return launch<1, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s, w3);
+    if (l4 <= 2) return launch<2, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s, w3);
+    if (l4 <= 4) return launch<4, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s, w3);
     return launch<8, 4, true>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s);
   }
   const int lanes = (F + vec - 1) / vec;  // lanes needed per row
-#define MRGCN_GO(G, V) return launch<G, V>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s)
+#define MRGCN_GO(G, V) return launch<G, V>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, use_tiny, s, w3)
   if (vec == 4) {
     if (lanes <= 1) MRGCN_GO(1, 4);
     if (lanes <= 2) MRGCN_GO(2, 4);
@@ -648,7 +921,7 @@ int dispatch(const SparseView &v, const float *D, int64_t ldD, int64_t avail, in
 // bf16 operand: 2-byte elements, up to 8 per lane (16-byte loads)
 int dispatch_bf16(const SparseView &v, const uint16_t *D, int64_t ldD, int64_t avail, int F, float *Y,
                   int64_t ldY, const float *bias, int relu, const int32_t *out_index, float *partials,
-                  hipStream_t s) {
+                  hipStream_t s, const View3 *w3 = nullptr) {
   auto ok = [&](int w) {
     int64_t padded = ((int64_t)F + w - 1) / w * w;
     return ldD % w == 0 && ((uintptr_t)D) % (w * 2) == 0 && avail >= padded;
@@ -656,7 +929,7 @@ int dispatch_bf16(const SparseView &v, const uint16_t *D, int64_t ldD, int64_t a
   const int vec = ok(8) ? 8 : ok(4) ? 4 : ok(2) ? 2 : 1;
   const int lanes = (F + vec - 1) / vec;
 #define MRGCN_GO(G, V) \
-  return launch<G, V, false, uint16_t>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, false, s)
+  return launch<G, V, false, uint16_t>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, false, s, w3)
 #define MRGCN_LANES(V)            \
   if (lanes <= 1) MRGCN_GO(1, V); \
   if (lanes <= 2) MRGCN_GO(2, V); \
@@ -673,6 +946,15 @@ int dispatch_bf16(const SparseView &v, const uint16_t *D, int64_t ldD, int64_t a
 #undef MRGCN_GO
   set_error("internal: no bf16 SpMM instantiation for this feature tile");
   return MRGCN_ERR_UNSUPPORTED;
+}
+
+View3 view3_of(const mrgcn_plan *p) {
+  View3 w;
+  w.n_mid = p->r_n_mid; w.mid_rows = p->r_mid_rows;
+  w.n_chunks = p->r3_n_chunks; w.n_long = p->r3_n_long; w.n_multi = p->r3_n_chunks - p->r3_n_long;
+  w.chunk_beg = p->r3_chunk_beg; w.chunk_end = p->r3_chunk_end; w.chunk_row = p->r3_chunk_row;
+  w.long_row = p->r3_long_row; w.long_cptr = p->r3_long_cptr;
+  return w;
 }
 
 }  // namespace
@@ -763,8 +1045,10 @@ extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uin
   else if (ldD % 2 == 0 && ((uintptr_t)D) % 4 == 0) tile = 128;
   for (int f = 0; f < F; f += tile) {
     const int w = (F - f < tile) ? (F - f) : tile;
+    const View3 w3 = view3_of(plan);
     int rc = dispatch_bf16(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu, out_index,
-                           plan->partials, (hipStream_t)stream);
+                           plan->partials, (hipStream_t)stream,
+                           (view != MRGCN_VIEW_TRANSPOSED && F <= 32) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;
@@ -794,8 +1078,11 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     const int64_t operand_rows = view == MRGCN_VIEW_LITERAL ? plan->num_relations * plan->num_nodes
                                  : view == MRGCN_VIEW_COMPACT ? plan->ncols : plan->num_rows;
     const bool operand_cached = operand_rows * ldD * 4 <= (int64_t)200 << 20;
+    // the row orientation (LITERAL / COMPACT views) of a narrow layer takes k_spmm3
+    const View3 w3 = view3_of(plan);
     int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu,
-                      out_index, plan->partials, use_tiny, operand_cached, s);
+                      out_index, plan->partials, use_tiny, operand_cached, s,
+                      (view != MRGCN_VIEW_TRANSPOSED && F <= 16) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;

@@ -3,7 +3,6 @@ or CPU fallback."""
 from __future__ import annotations
 
 import os
-import weakref
 
 import torch
 
@@ -15,111 +14,48 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-# ||grad||^2 values a producing kernel already accumulated (device doubles), keyed by the
-# gradient's storage pointer; `ClipAdam` consumes them instead of re-reading the gradient.
-# Safe by construction: autograd either adopts the returned tensor's storage as `p.grad`
-# (pointer matches) or hands the optimizer a different tensor (sum of several contributions,
-# a clone) whose pointer does not match, in which case the norm is recomputed.  The registry is
-# emptied by every optimizer step.
-_GRAD_SUMSQ: dict = {}
-
-
-def register_grad_sumsq(grad: torch.Tensor, sumsq: torch.Tensor):
-    _GRAD_SUMSQ[grad.data_ptr()] = (grad.numel(), sumsq)
-
-
-def pop_grad_sumsq(grad: torch.Tensor):
-    """The precomputed sum of squares of the gradient living at this storage, or None."""
-    ent = _GRAD_SUMSQ.pop(grad.data_ptr(), None)
-    if ent is None or ent[0] != grad.numel():
-        return None
-    return ent[1]
-
-
-def clear_grad_sumsq():
-    _GRAD_SUMSQ.clear()
-    _DEFERRED.clear()
-
-
-# Deferred update of weight_I (opt-in): with it on, the backward of a bases layer does not store
-# dV (weight_I.grad stays None); it leaves ||dV||^2 plus what is needed to recompute dV here, and
-# `ClipAdam.step` applies Adam to weight_I inside the kernel that recomputes it
-# (mrgcn_basis_mix_bwd_adam_f32).  Same arithmetic, 2 x 2.67 GB less HBM traffic per AM epoch —
-# but measured NOT faster on MI355X (AM shape: 14.96 ms vs 14.66 ms with the stored gradient):
-# the recomputing kernel streams p/m/v as 4-byte lanes over many basis slabs at ~3.8 TB/s where
-# the plain float4 Adam kernel reaches ~4.7 TB/s, which eats the saved traffic.  Kept as an
-# option (it halves the peak memory of the step: no 2.67 GB gradient tensor).
-# Only valid when nothing else contributes to weight_I's gradient (no L1/L2 term, one use of the
-# layer per step) — `train_step` switches it off when a regulariser is active.
-_DEFER = False
-_DEFERRED: dict = {}
-
-
-def defer_input_grad(on: bool) -> bool:
-    """Switches the deferred weight_I update on/off; returns the previous setting."""
-    global _DEFER
-    prev, _DEFER = _DEFER, bool(on)
-    return prev
-
-
-def pop_deferred(param: torch.Tensor):
-    ent = _DEFERRED.pop(param.data_ptr(), None)
-    if ent is None or ent["numel"] != param.numel():
-        return None
-    return ent
-
-
 # measured on the AM shape: 14.6 ms with the overlap vs 14.3 ms without (every one of these
 # kernels already saturates the memory system on its own), so it is opt-in
 _OVERLAP = os.environ.get("MRGCN_OVERLAP", "0") != "0"
-# Skip the compact columns without gradient in the transform backward (exact: they add zeros).
+# Skip the compact columns without gradient in the backward (exact: they add zeros).
 _LIVE_COLS = os.environ.get("MRGCN_LIVE_COLS", "1") != "0"
-
 
 # tests: start dM as NaNs, so that any read of a row the producer left unwritten shows
 _POISON_DEAD = False
 
-# Chunk-sparse gradient of weight_I (train_step turns it on for ClipAdam without weight decay): nodes
-# without a live compact column have a zero gradient row in every basis, and with a fixed label set
-# never any other — their Adam moments stay zero and their parameters never move.  The backward then
-# leaves the 4 KB chunks of dV without any live node unwritten and ClipAdam runs
-# mrgcn_adam_step_chunked_f32, which never touches chunks that never had gradient.  How much that
-# saves depends on how the nodes are numbered: see mrgcn_amd.data.reorder.
-_SPARSE_WGRAD = False
-_WCHUNKS: dict = {}
-_WCHUNK_DENSE = 0.75  # fraction of chunks that ever had gradient above which the masks are dropped
+# Row-sparse gradient of a node-major weight_I (train_step turns it on for ClipAdam without weight decay):
+# nodes without a live compact column have a zero gradient block, and with a fixed label set never any
+# other — their Adam moments stay zero and their parameters never move.  The backward then leaves those
+# blocks unwritten (and their V blocks unread) and hands the gradient to the optimizer through
+# `weight_I._mrgcn_rows` (buffer, per-node flags, squared norm) instead of `weight_I.grad`; ClipAdam runs
+# mrgcn_adam_step_rows_f32, which never touches a node that never had gradient.  The state hangs on the
+# Parameter object itself.  Outside train_step (plain `loss.backward()`) the gradient is dense and arrives
+# in `weight_I.grad` as usual.
+_ROW_SPARSE = False
 
 
-def sparse_weight_grad(enabled: bool) -> bool:
+def row_sparse_weight_grad(enabled: bool) -> bool:
     """Returns the previous setting."""
-    global _SPARSE_WGRAD
-    prev, _SPARSE_WGRAD = _SPARSE_WGRAD, bool(enabled)
+    global _ROW_SPARSE
+    prev, _ROW_SPARSE = _ROW_SPARSE, bool(enabled)
     return prev
 
 
-# Node-major optimizer space (preferred over the chunk masks when the shape allows): the gradient of
-# weight_I is written as [N][B][F] for the nodes with gradient only and ClipAdam keeps its moments in
-# the same layout (mrgcn_adam_step_nodemajor_f32) — nodes that never had gradient are skipped whatever
-# the node numbering.  weight_I.grad stays None; the entry below carries the gradient to the optimizer.
-_NODEMAJOR: dict = {}
-_NODE_MAJOR = os.environ.get("MRGCN_NODE_MAJOR", "1") != "0"
-
-
-def pop_nodemajor(param: torch.Tensor):
-    ent = _NODEMAJOR.get(param.data_ptr())
-    if ent is None or not ent["fresh"] or ent["numel"] != param.numel():
+def pop_row_grad(param: torch.Tensor):
+    """The row-sparse gradient the last backward left on `param`, or None; consumed by the call."""
+    ent = getattr(param, "_mrgcn_rows", None)
+    if ent is None or not ent["fresh"]:
         return None
     ent["fresh"] = False
     return ent
 
 
-def pop_weight_chunks(param: torch.Tensor):
-    """(cur, ever, slab_elems, B) when this step's gradient of `param` was produced chunk-sparse."""
-    ent = _WCHUNKS.get(param.data_ptr())
-    if ent is None or not ent["fresh"] or ent["numel"] != param.numel():
-        return None
-    ent["fresh"] = False
-    return ent
+def clear_row_grads(params):
+    """Gradients left by a backward whose optimizer step never came must not survive into the next."""
+    for p in params:
+        ent = getattr(p, "_mrgcn_rows", None)
+        if ent is not None:
+            ent["fresh"] = False
 
 
 class _LiveGauge:
@@ -150,8 +86,8 @@ class _LiveGauge:
             self.host = torch.full((1,), -1, dtype=torch.int32)
         self.calls = 0
 
-    def release(self):
-        if self.slot is not None:
+    def __del__(self):
+        if getattr(self, "slot", None) is not None and _LiveGauge is not None:  # (None at interpreter exit)
             _LiveGauge._free.append(self.slot)
             self.slot = None
 
@@ -165,22 +101,15 @@ class _LiveGauge:
             self.host.copy_(self.dev, non_blocking=True)
 
 
-_GAUGES = {}
-
-
 def _live_gauge(plan, F, relu, dev):
-    key = (id(plan), F, bool(relu))
-    g = _GAUGES.get(key)
-    if g is None or g.plan_ref() is not plan:
-        if g is not None:
-            g.release()
-        if len(_GAUGES) >= 256:  # mini-batch training builds plans by the thousand: drop the dead ones
-            for k in [k for k, v in _GAUGES.items() if v.plan_ref() is None]:
-                _GAUGES.pop(k).release()
-        g = _LiveGauge(plan.num_rows, dev)
-        g.plan_ref = weakref.ref(plan)
-        _GAUGES[key] = g
+    """The gauge of (plan, layer width, activation): kept on the plan object, dies with it."""
+    gauges = plan.__dict__.setdefault("_gauges", {})
+    g = gauges.get((F, bool(relu)))
+    if g is None:
+        g = gauges[(F, bool(relu))] = _LiveGauge(plan.num_rows, dev)
     return g
+
+
 _SIDE_STREAMS: dict = {}
 
 
@@ -253,12 +182,14 @@ def relu_bwd(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
 
 
 class _RgcnLayer(torch.autograd.Function):
-    """Y = relu?( A' . M + b ),  M[c] = comp_I[r_c] . V_I[:, j_c, :]  (or weight_I[r_c*N + j_c])
+    """Y = relu?( A' . M + b ),  M[c] = comp_I[r_c] . V_I[j_c, :, :]  (or weight_I[r_c*N + j_c])
                                        + X[j_c] . W_F[r_c]
-    i.e. graph.py:62-102 without the (R*N) x out intermediates."""
+    i.e. graph.py:62-102 without the (R*N) x out intermediates.  `weight_I` with bases is the layer's
+    node-major (N, B, out) parameter; without bases the reference's (R*N, out)."""
 
     @staticmethod
-    def forward(ctx, plan: GraphPlan, F: int, weight_I, comp_I, X, W_F, bias, relu: bool, bf16: bool = False):
+    def forward(ctx, plan: GraphPlan, F: int, weight_I, comp_I, X, W_F, bias, relu: bool, bf16: bool = False,
+                owner=None):
         lib = L.load()
         dev = plan.device
         # bf16: only the compact operand M is stored in bf16 (one rounding at its store); inputs,
@@ -298,7 +229,7 @@ class _RgcnLayer(torch.autograd.Function):
                     L.check(gather_rows(plan.handle, wI.data_ptr(), F, addend, ldA, M.data_ptr(), ld, s),
                             "mrgcn_gather_rows_" + sfx)
         Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu)
-        ctx.plan, ctx.F, ctx.ld, ctx.relu = plan, F, ld, relu
+        ctx.plan, ctx.F, ctx.ld, ctx.relu, ctx.owner = plan, F, ld, relu, owner
         ctx.has = (weight_I is not None, comp_I is not None, X is not None, bias is not None)
         ctx.save_for_backward(weight_I, comp_I, Xc, Wc, Y if relu else None)
         return Y
@@ -329,8 +260,8 @@ class _RgcnLayer(torch.autograd.Function):
             scratch = torch.empty((int(lib.mrgcn_spmm_transposed_live_scratch(plan.handle)),),
                                   dtype=torch.uint8, device=dev)
             # rows of dM without gradient are not even written when every consumer goes by the flags
-            # (the no-bases scatter and the deferred update's second pass read dM itself)
-            write_dead = int(has_I and (not has_comp or (_DEFER and weight_I.is_contiguous())))
+            # (the no-bases scatter reads dM itself)
+            write_dead = int(has_I and not has_comp)
             with torch.cuda.device(dev):
                 L.check(lib.mrgcn_spmm_transposed_live_f32(
                     plan.handle, dY.data_ptr(), dY.stride(0), F, dM.data_ptr(), ld, scratch.data_ptr(),
@@ -341,101 +272,48 @@ class _RgcnLayer(torch.autograd.Function):
         d_wI = d_comp = dX = dW = None
         # The consumers of dM are independent of each other and bound by different resources
         # (dV: HBM writes, dcomp: vector-memory issue, dW/dX: matrix cores + gathers), so the
-        # input-term and feature-term backward run on two HIP streams and overlap.
+        # input-term and feature-term backward may run on two HIP streams (MRGCN_OVERLAP=1).
         overlap = has_I and has_X and _OVERLAP
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if overlap else main
         if overlap:
             side.wait_stream(main)  # dM is ready on `main`
         with torch.cuda.device(dev):
-            if has_I:
-                if has_comp:
-                    defer = _DEFER and weight_I.is_contiguous()
-                    if defer and weight_I.data_ptr() in _DEFERRED:
-                        raise L.MrgcnError("deferred weight_I update: the layer ran twice in one step")
-                    chunk_cur = 0
-                    nm = _NODEMAJOR.get(weight_I.data_ptr())
-                    if nm is not None:
-                        nm["fresh"] = False
-                    Bn = comp_I.shape[1]
-                    if (_SPARSE_WGRAD and _NODE_MAJOR and not defer and live is not None and weight_I.is_contiguous()
-                            and lib.mrgcn_nodemajor_supported(plan.handle, Bn, F) == 1):
-                        N_ = plan.num_nodes
-                        if nm is None or nm["numel"] != weight_I.numel() or nm["shape"] != (N_, Bn, F):
-                            nm = dict(g=torch.empty((N_, Bn, F), dtype=torch.float32, device=dev),
-                                      cur=torch.zeros(N_, dtype=torch.uint8, device=dev),
-                                      ever=torch.zeros(N_, dtype=torch.uint8, device=dev),
-                                      numel=weight_I.numel(), shape=(N_, Bn, F), fresh=False, sumsq=None)
-                            if len(_NODEMAJOR) >= 4:  # gradient buffers of models long gone: keep the newest few
-                                for k in list(_NODEMAJOR)[:len(_NODEMAJOR) - 3]:
-                                    if not _NODEMAJOR[k]["fresh"]:
-                                        del _NODEMAJOR[k]
-                            _NODEMAJOR.pop(weight_I.data_ptr(), None)
-                            _NODEMAJOR[weight_I.data_ptr()] = nm
-                        d_comp = torch.empty_like(comp_I)
-                        sq = torch.zeros((), dtype=torch.float64, device=dev)
-                        L.check(lib.mrgcn_basis_mix_bwd_nodemajor_f32(
-                            plan.handle, dM.data_ptr(), ld, live.data_ptr(), weight_I.data_ptr(), comp_I.data_ptr(),
-                            Bn, F, nm["g"].data_ptr(), nm["cur"].data_ptr(), d_comp.data_ptr(), sq.data_ptr(), s),
-                            "mrgcn_basis_mix_bwd_nodemajor_f32")
-                        nm["ever"] |= nm["cur"]
-                        nm["sumsq"], nm["fresh"] = sq, True
-                        d_wI = None
-                        has_comp_done = True
-                    else:
-                        has_comp_done = False
-                    if not has_comp_done:
-                        d_wI = None if defer else torch.empty_like(weight_I)
-                        d_comp = torch.empty_like(comp_I)
-                        sq = torch.zeros((), dtype=torch.float64, device=dev)
-                        stale = _WCHUNKS.get(weight_I.data_ptr())
-                        if stale is not None:
-                            stale["fresh"] = False  # a mask of an earlier step says nothing about this gradient
-                            if not _SPARSE_WGRAD or stale["dense"]:
-                                # a step on the plain path may put moments where `ever` has never looked:
-                                # the next masked step rebuilds `ever` from the optimizer state
-                                stale["state_synced"] = False
-                        if _SPARSE_WGRAD and not defer and live is not None and weight_I.is_contiguous():
-                            ent = _WCHUNKS.get(weight_I.data_ptr())
-                            nch = int(lib.mrgcn_weight_chunks(plan.handle, F))
-                            if ent is None or ent["numel"] != weight_I.numel() or ent["cur"].numel() != nch:
-                                ent = dict(cur=torch.zeros(nch, dtype=torch.uint8, device=dev),
-                                           ever=torch.zeros(nch, dtype=torch.uint8, device=dev),
-                                           n_ever=torch.zeros(1, dtype=torch.int32, device=dev),
-                                           n_ever_host=torch.full((1,), -1, dtype=torch.int32).pin_memory(),
-                                           numel=weight_I.numel(), slab=plan.num_nodes * F, B=comp_I.shape[1],
-                                           fresh=False, dense=False)
-                                _WCHUNKS[weight_I.data_ptr()] = ent
-                            # with most chunks live the masks only cost (AM shape, nodes numbered at random:
-                            # every chunk holds a node with gradient; + 0.16 ms): the count of the previous
-                            # step decides, and once dense the parameter stays on the plain path (`ever` is
-                            # not maintained there)
-                            if not ent["dense"] and int(ent["n_ever_host"][0]) > _WCHUNK_DENSE * nch:
-                                ent["dense"] = True
-                            if not ent["dense"]:
-                                L.check(lib.mrgcn_weight_chunks_live(plan.handle, live.data_ptr(), F,
-                                                                     ent["cur"].data_ptr(), ent["ever"].data_ptr(), s),
-                                        "mrgcn_weight_chunks_live")
-                                torch.sum(ent["ever"], dim=(0,), keepdim=True, dtype=torch.int32, out=ent["n_ever"])
-                                ent["n_ever_host"].copy_(ent["n_ever"], non_blocking=True)
-                                ent["fresh"] = True
-                                chunk_cur = ent["cur"].data_ptr()
-                        L.check(lib.mrgcn_basis_mix_bwd_live_f32(
-                            plan.handle, dM.data_ptr(), ld, live.data_ptr() if live is not None else 0, chunk_cur,
-                            weight_I.data_ptr(), comp_I.data_ptr(),
-                            comp_I.shape[1], F, 0 if defer else d_wI.data_ptr(), d_comp.data_ptr(),
-                            sq.data_ptr(), s), "mrgcn_basis_mix_bwd_live_f32")
-                        if defer:
-                            # comp_I is cloned: the optimizer may update the parameter before pass 2
-                            _DEFERRED[weight_I.data_ptr()] = dict(
-                                numel=weight_I.numel(), plan=plan, dM=dM, ld=ld, comp=comp_I.detach().clone(),
-                                B=comp_I.shape[1], F=F, sumsq=sq)
-                        else:
-                            register_grad_sumsq(d_wI, sq)  # ||dV||^2 came for free with the gradient
+            if has_I and has_comp:
+                N_, Bn, _ = weight_I.shape
+                wI = weight_I.contiguous()
+                d_comp = torch.empty_like(comp_I)
+                param = getattr(ctx.owner, "weight_I", None)
+                rows = None
+                if (_ROW_SPARSE and live is not None and param is not None and weight_I.is_contiguous()
+                        and param.shape == weight_I.shape):
+                    rows = getattr(param, "_mrgcn_rows", None)
+                    if rows is not None and rows["fresh"]:
+                        raise L.MrgcnError("row-sparse weight_I gradient: the layer ran twice in one train_step "
+                                           "(use train_step(..., row_sparse=False))")
+                    if rows is None or rows["g"].shape != weight_I.shape or rows["g"].device != dev:
+                        rows = dict(g=torch.empty_like(wI), cur=torch.zeros(N_, dtype=torch.uint8, device=dev),
+                                    ever=torch.zeros(N_, dtype=torch.uint8, device=dev), sumsq=None, fresh=False,
+                                    seeded_for=None)
+                        param._mrgcn_rows = rows
+                if rows is not None:
+                    sq = torch.zeros((), dtype=torch.float64, device=dev)
+                    L.check(lib.mrgcn_basis_mix_bwd_f32(
+                        plan.handle, dM.data_ptr(), ld, live.data_ptr(), wI.data_ptr(), comp_I.data_ptr(), Bn, F,
+                        rows["g"].data_ptr(), rows["cur"].data_ptr(), d_comp.data_ptr(), sq.data_ptr(), s),
+                        "mrgcn_basis_mix_bwd_f32")
+                    rows["sumsq"], rows["fresh"] = sq, True
+                    d_wI = None  # travels in param._mrgcn_rows
                 else:
-                    # dense (R*N) x F gradient: zero + scatter of the touched rows
-                    d_wI = torch.zeros_like(weight_I)
-                    d_wI.index_copy_(0, plan.ulcol_long(), dM[:, :F])
+                    d_wI = torch.empty_like(wI)
+                    L.check(lib.mrgcn_basis_mix_bwd_f32(
+                        plan.handle, dM.data_ptr(), ld, live.data_ptr() if live is not None else 0, wI.data_ptr(),
+                        comp_I.data_ptr(), Bn, F, d_wI.data_ptr(), 0, d_comp.data_ptr(), 0, s),
+                        "mrgcn_basis_mix_bwd_f32")
+            elif has_I:
+                # dense (R*N) x F gradient: zero + scatter of the touched rows
+                d_wI = torch.zeros_like(weight_I)
+                d_wI.index_copy_(0, plan.ulcol_long(), dM[:, :F])
             if has_X:
                 need_dX = ctx.needs_input_grad[4]
                 need_dW = ctx.needs_input_grad[5]
@@ -462,7 +340,7 @@ class _RgcnLayer(torch.autograd.Function):
                     for t in (dX, dW, ws, dM, live):  # allocated / used on `side`: keep the allocator honest
                         if t is not None:
                             t.record_stream(side if (t is dM or t is live) else main)
-        return None, None, d_wI, d_comp, dX, dW, dbias, None, None
+        return None, None, d_wI, d_comp, dX, dW, dbias, None, None, None
 
 
 def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False, input_term: bool = True,
@@ -477,13 +355,18 @@ def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False, input_term: bool =
         comp_I = layer.weight_I_comp if B > 0 else None
     Xin = None
     if feature_term and not (layer.input_layer and layer.featureless):
+        if X is None:
+            raise L.MrgcnError("rgcn_layer: the feature term needs X")
         Xin = X
         W_F = layer.weight_F
         if B > 0:  # graph.py:83-85: tiny (R x B) . (B x in*out) contraction -> library GEMM
             W_F = (layer.weight_F_comp @ W_F.reshape(B, -1)).view(layer.num_relations, layer.indim, F)
+    if weight_I is None and Xin is None:
+        raise L.MrgcnError("rgcn_layer: neither the input term nor the feature term is selected "
+                           "(a featureless layer only has the input term)")
     bf16 = getattr(layer, "operand_dtype", "f32") == "bf16"
     bias = layer.b if (layer.bias and use_bias) else None
     if weight_I is not None and comp_I is None and Xin is None and not bf16:
         # featureless layer without bases: weight_I already *is* the literal operand
         return spmm_literal(plan, weight_I, bias=bias, relu=relu)
-    return _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, bias, relu, bf16)
+    return _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, bias, relu, bf16, layer)

@@ -13,6 +13,15 @@ Two engines share the parameters:
   "literal" materialises W_I / FW_F exactly as the reference does and multiplies with the
             literal view; kept as the op-for-op counterpart (tests, roofline of the plain
             stacked-CSR SpMM).
+
+Internal layout of `weight_I` with bases (num_bases > 0): the parameter is kept NODE-MAJOR,
+`(N, B, out)` — the B basis rows of a node are one contiguous block — instead of the reference's
+`(B*N, out)` (graph.py:50-51, rows b*N + j).  It is the same numbers transposed: `state_dict()`
+hands out and `load_state_dict()` takes the reference's shape (checkpoints are interchangeable,
+`weight_I_reference()` gives the reference view), `reset_parameters()` draws the Glorot values in
+the reference's shape and order (same seed, same initial values).  In this layout the forward, the
+backward and Adam touch a node's weights as one 4*B*out-byte run, and a node without gradient is
+skipped as a whole.  Without bases `weight_I` is `(R*N, out)` exactly as in the reference.
 """
 from __future__ import annotations
 
@@ -24,6 +33,30 @@ from ..plan import plan_of
 
 _ENGINES = ("fused", "literal")
 DEFAULT_ENGINE = "fused"
+
+
+# Library GEMMs of the literal engine are issued in pieces whose outputs stay below this many elements: with
+# (R*N) x out results beyond 4 GiB (AM/4 and up) the ROCm BLAS path was measured to return a handful of wrong
+# rows from the second call on (the fused engine never forms these operands).
+_MAX_GEMM_OUT = 1 << 28
+
+
+def _basis_contract(comp, W2d):
+    """einsum('rb,bx->rx') (graph.py:69-72 / :83-85 after the views), output columns in pieces."""
+    R, X = comp.shape[0], W2d.shape[1]
+    step = max(_MAX_GEMM_OUT // max(R, 1), 1)
+    if X <= step:
+        return comp @ W2d
+    return torch.cat([comp @ W2d[:, x0:x0 + step] for x0 in range(0, X, step)], dim=1)
+
+
+def _relation_transform(X, W_F):
+    """einsum('ij,bjk->bik') (graph.py:93-94): [R, N, out], relations in pieces."""
+    R, n, out = W_F.shape[0], X.shape[0], W_F.shape[2]
+    step = max(_MAX_GEMM_OUT // max(n * out, 1), 1)
+    if R <= step:
+        return torch.matmul(X.unsqueeze(0), W_F)
+    return torch.cat([torch.matmul(X.unsqueeze(0), W_F[r0:r0 + step]) for r0 in range(0, R, step)], dim=0)
 
 
 class GraphConvolution(nn.Module):
@@ -52,23 +85,44 @@ class GraphConvolution(nn.Module):
             ("weight_F", (S, indim, outdim) if wants_F else None),
             ("b", (outdim,) if bias else None),
         ]
+        self.weight_I_node_major = bool(use_bases and input_layer)
         for name, shape in shapes:
             if shape is None:
                 setattr(self, name, None)
             elif name == "weight_F_comp" and shared_bases_weights:
                 # graph.py:42-44: alias of weight_I_comp (None on non-input layers)
                 self.weight_F_comp = self.weight_I_comp
+            elif name == "weight_I" and self.weight_I_node_major:
+                self.weight_I = nn.Parameter(torch.empty((num_nodes, num_bases, outdim)))
+                self.weight_I._mrgcn_node_major = True  # optimizers hand its state out in the reference's layout
             else:
                 setattr(self, name, nn.Parameter(torch.empty(shape)))
+        self._register_state_dict_hook(_weight_I_to_reference)
+        self._register_load_state_dict_pre_hook(_weight_I_from_reference, with_module=True)
         self.reset_parameters()
 
     def reset_parameters(self):
-        """Glorot-uniform on every tensor but the bias, zeros on the bias (graph.py:104-116)."""
+        """Glorot-uniform on every tensor but the bias, zeros on the bias (graph.py:104-116); the values
+        are drawn in the reference's shapes and order, so the same seed gives the same parameters."""
         for name, param in self.named_parameters():
             if name == "b":
                 nn.init.zeros_(param)
+            elif name == "weight_I" and self.weight_I_node_major:
+                N, B, out = param.shape
+                ref = torch.empty((B * N, out), dtype=param.dtype, device=param.device)
+                nn.init.xavier_uniform_(ref)
+                with torch.no_grad():
+                    param.copy_(ref.view(B, N, out).permute(1, 0, 2))
             else:
                 nn.init.xavier_uniform_(param)
+
+    def weight_I_reference(self):
+        """`weight_I` in the reference's shape `(S*N, out)` (graph.py:50-51); differentiable."""
+        W = self.weight_I
+        if W is not None and self.weight_I_node_major:
+            N, B, out = W.shape
+            W = W.permute(1, 0, 2).reshape(B * N, out)
+        return W
 
     # ------------------------------------------------------------------------------
     def forward(self, X, A, A_idx=None):
@@ -84,9 +138,9 @@ class GraphConvolution(nn.Module):
         R, N, B, out = self.num_relations, self.num_nodes, self.num_bases, self.outdim
         Y = None
         if self.input_layer:
-            W_I = self.weight_I
+            W_I = self.weight_I_reference()
             if B > 0:
-                W_I = (self.weight_I_comp @ W_I.view(B, N * out)).view(R * N, out)
+                W_I = _basis_contract(self.weight_I_comp, W_I.view(B, N * out)).view(R * N, out)
             last = self.featureless
             Y = Fn.spmm_literal(plan, W_I, bias=self.b if (last and self.bias) else None)
             if last:
@@ -94,7 +148,7 @@ class GraphConvolution(nn.Module):
         W_F = self.weight_F
         if B > 0:
             W_F = (self.weight_F_comp @ W_F.view(B, -1)).view(R, self.indim, out)
-        FW = torch.matmul(X.unsqueeze(0), W_F).reshape(R * X.shape[0], out)
+        FW = _relation_transform(X, W_F).reshape(R * X.shape[0], out)
         AFW = Fn.spmm_literal(plan, FW, bias=self.b if self.bias else None)
         return AFW if Y is None else Y + AFW
 
@@ -117,17 +171,20 @@ class GraphConvolution(nn.Module):
         if self.input_layer:
             plan_I = plan_of(A, self.num_nodes, R)
             if self.engine == "literal":
-                W_I = self.weight_I
+                W_I = self.weight_I_reference()
                 if B > 0:
-                    W_I = (self.weight_I_comp @ W_I.view(B, self.num_nodes * out)).view(R * self.num_nodes, out)
-                Y = Fn.spmm_literal(plan_I, W_I)
+                    W_I = _basis_contract(self.weight_I_comp, W_I.view(B, self.num_nodes * out)
+                                          ).view(R * self.num_nodes, out)
+                Y = Fn.spmm_literal(plan_I, W_I, bias=self.b if (self.featureless and self.bias) else None)
             else:
-                Y = Fn.rgcn_layer(plan_I, self, None, feature_term=False, use_bias=False)
+                Y = Fn.rgcn_layer(plan_I, self, None, feature_term=False, use_bias=self.featureless)
+            if self.featureless:  # graph.py:77-81: the input term (+ bias) is the whole layer
+                return Y
         if self.engine == "literal":
             W_F = self.weight_F
             if B > 0:
                 W_F = (self.weight_F_comp @ W_F.view(B, -1)).view(R, self.indim, out)
-            FW = torch.matmul(X.unsqueeze(0), W_F).reshape(R * n_b, out)
+            FW = _relation_transform(X, W_F).reshape(R * n_b, out)
             YF = Fn.spmm_literal(plan_F, FW, bias=self.b if self.bias else None)
         else:
             YF = Fn.rgcn_layer(plan_F, self, X, input_term=False)
@@ -136,3 +193,24 @@ class GraphConvolution(nn.Module):
     # -- fused engine ----------------------------------------------------------------------
     def _forward_fused(self, X, plan, relu=False):
         return Fn.rgcn_layer(plan, self, X, relu=relu)
+
+
+def _weight_I_to_reference(module, state_dict, prefix, local_metadata):
+    """state_dict hook: the node-major `(N, B, out)` parameter leaves as the reference's `(B*N, out)`."""
+    key = prefix + "weight_I"
+    if getattr(module, "weight_I_node_major", False) and key in state_dict:
+        W = state_dict[key]
+        N, B, out = W.shape
+        state_dict[key] = W.permute(1, 0, 2).reshape(B * N, out)
+    return state_dict
+
+
+def _weight_I_from_reference(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                             error_msgs):
+    """load_state_dict pre-hook: a reference-shaped `weight_I` is transposed into the node-major layout."""
+    key = prefix + "weight_I"
+    if getattr(module, "weight_I_node_major", False) and key in state_dict:
+        W = state_dict[key]
+        N, B, out = module.weight_I.shape
+        if W.dim() == 2 and tuple(W.shape) == (B * N, out):
+            state_dict[key] = W.view(B, N, out).permute(1, 0, 2).contiguous()

@@ -49,12 +49,15 @@ class NodePartition:
         keep = (j >= self.j0) & (j < self.j1)
         return rows[keep], r[keep] * self.S + (j[keep] - self.j0), np.asarray(vals)[keep]
 
-    def shard_weight_I(self, w: torch.Tensor, S_b: int) -> torch.Tensor:
-        """(S_b*N, out) -> this rank's (S_b*S, out) rows (zero rows for padding nodes)."""
+    def shard_weight_I(self, w: torch.Tensor, S_b: int, node_major: bool = False) -> torch.Tensor:
+        """The reference's (S_b*N, out) -> this rank's rows (zero rows for padding nodes): (S_b*S, out),
+        or the local layer's node-major (S, S_b, out) block — one contiguous slab of the full table."""
         out = w.shape[1]
         full = w.view(S_b, self.N, out)
         loc = torch.zeros((S_b, self.S, out), dtype=w.dtype, device=w.device)
         loc[:, : self.n_local] = full[:, self.j0:self.j1]
+        if node_major:
+            return loc.permute(1, 0, 2).contiguous()
         return loc.reshape(S_b * self.S, out)
 
     def shard_rows(self, X: torch.Tensor) -> torch.Tensor:
@@ -174,7 +177,7 @@ class PartitionedRGCN(nn.Module):
                 full = state[f"layers.layer_{i}.{name}"].to(p.device)
                 if name == "weight_I":
                     S_b = self.num_bases if self.num_bases > 0 else self.num_relations
-                    p.copy_(self.part.shard_weight_I(full, S_b))
+                    p.copy_(self.part.shard_weight_I(full, S_b, node_major=layer.weight_I_node_major))
                 else:
                     p.copy_(full)
 
@@ -245,14 +248,29 @@ def partitioned_loss(logits_local, idx_global, targets, part: NodePartition, gro
     return local, total
 
 
-def partitioned_train_step(model: PartitionedRGCN, X_local, idx_global, targets, optimizer):
-    Fn.clear_grad_sumsq()
-    logits = model(X_local)
-    local, total = partitioned_loss(logits, idx_global, targets, model.part, model.group)
+def _backward_and_step(model, local, optimizer, row_sparse):
+    """backward + all-reduce of the replicated gradients + optimizer step, with the same gradient-sparsity
+    machinery as the single-GPU `train_step` (live-column backward, row-sparse weight_I gradient and Adam on
+    this rank's shard of the node table)."""
+    from .train import ClipAdam, _ROW_SPARSE_DEFAULT
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    Fn.clear_row_grads(params)
     optimizer.zero_grad(set_to_none=True)
-    local.backward()
+    sparse_ok = (row_sparse is not False and _ROW_SPARSE_DEFAULT and isinstance(optimizer, ClipAdam)
+                 and all(float(g["weight_decay"]) == 0.0 for g in optimizer.param_groups))
+    prev = Fn.row_sparse_weight_grad(sparse_ok)
+    try:
+        local.backward()
+    finally:
+        Fn.row_sparse_weight_grad(prev)
     model.allreduce_replicated_grads()
     optimizer.step()
+
+
+def partitioned_train_step(model: PartitionedRGCN, X_local, idx_global, targets, optimizer, row_sparse=None):
+    logits = model(X_local)
+    local, total = partitioned_loss(logits, idx_global, targets, model.part, model.group)
+    _backward_and_step(model, local, optimizer, row_sparse)
     return total
 
 
@@ -263,7 +281,6 @@ def partitioned_lp_step(model: PartitionedRGCN, X_local, triples, labels, optimi
     table returns to the owners by reduce-scatter.  `triples` [n, 3] / `labels` [n] are the full
     batch (positives + negatives), identical on every rank.  Returns the mean BCE over all triples."""
     from .tasks import link_prediction as lp
-    Fn.clear_grad_sumsq()
     part, group = model.part, model.group
     world, rank = part.world, part.rank
     E = _AllGatherRows.apply(model(X_local), group)[: part.N]
@@ -274,8 +291,5 @@ def partitioned_lp_step(model: PartitionedRGCN, X_local, triples, labels, optimi
     local = lp.binary_crossentropy(sc, labels[mine]) * (float(mine.numel()) / n) if mine.numel() else (E * 0.0).sum()
     total = local.detach().clone()
     all_reduce_sum_(total, group)
-    optimizer.zero_grad(set_to_none=True)
-    local.backward()
-    model.allreduce_replicated_grads()
-    optimizer.step()
+    _backward_and_step(model, local, optimizer, None)
     return total

@@ -9,17 +9,15 @@ with the loss, the global gradient norm, the clip and Adam running as HIP kernel
 host synchronisation."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
-from .functional import (clear_grad_sumsq, defer_input_grad, pop_deferred, pop_grad_sumsq, pop_nodemajor,
-                         pop_weight_chunks, sparse_weight_grad)
+from .functional import clear_row_grads, pop_row_grad, row_sparse_weight_grad
 
-
-import os
-
-# MRGCN_SPARSE_WGRAD=0 switches the chunk-sparse weight_I gradient off (A/B runs)
-_SPARSE_WGRAD_DEFAULT = os.environ.get("MRGCN_SPARSE_WGRAD", "1") != "0"
+# MRGCN_ROW_SPARSE=0 switches the row-sparse weight_I gradient off (A/B runs)
+_ROW_SPARSE_DEFAULT = os.environ.get("MRGCN_ROW_SPARSE", "1") != "0"
 
 
 def _stream(device) -> int:
@@ -62,11 +60,23 @@ def categorical_accuracy(Y_hat, idx, targets):
     return (labels == targets).float().mean(), labels, targets
 
 
+def _to_reference_layout(t):
+    """(N, B, F) node-major -> the reference's (B*N, F)."""
+    N, B, F = t.shape
+    return t.permute(1, 0, 2).reshape(B * N, F)
+
+
 class ClipAdam(torch.optim.Optimizer):
     """clip_grad_norm_(all params, max_norm) followed by torch.optim.Adam, as two passes of
     HIP kernels: (1) sum of squares of every gradient into one device double, (2) Adam with
     the clip coefficient read from device memory.  Same hyper-parameter names / param-group
-    layout as torch.optim.Adam so that `optimizer_params` groups (tasks/utils.py:8-45) work."""
+    layout as torch.optim.Adam so that `optimizer_params` groups (tasks/utils.py:8-45) work.
+
+    `state_dict()` / `load_state_dict()` speak the reference's layout: the moments of a node-major
+    `weight_I` (mrgcn_amd.layers.graph) are handed out and accepted as `(B*N, out)` tensors, so an
+    optimizer checkpoint (run.py:230-236) is interchangeable with torch.optim.Adam over the reference
+    model.  With `capturable=True` the step counter lives on the device (hipGraph replays advance it);
+    `state_dict()` reads it back, `load_state_dict()` seeds it."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  max_norm=1.0, capturable=False):
@@ -79,27 +89,54 @@ class ClipAdam(torch.optim.Optimizer):
         self._dev_step = {}
         self._scratch = {}
         self._dist = None  # (group, ids of parameters sharded across ranks)
-        self._state_gen = 0  # bumped by load_state_dict: masks built for the old moments are re-derived
+        self._state_gen = 0  # bumped by load_state_dict: row flags built for the old moments are re-derived
 
-    def load_state_dict(self, state_dict):
-        super().load_state_dict(state_dict)
-        self._state_gen = getattr(self, "_state_gen", 0) + 1
+    # -- checkpoints --------------------------------------------------------------------------------
+    def _sync_host_steps(self):
+        """Device step counters (capturable) -> the per-parameter `step` entries.  Synchronises."""
+        if not self._dev_step:
+            return
+        for group in self.param_groups:
+            ent = self._dev_step.get(tuple(float(b) for b in group["betas"]))
+            if ent is None:
+                continue
+            t = int(ent[0].item())
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"] = t
 
     def state_dict(self):
-        """torch.optim.Adam's format: moments kept node-major internally are handed out in the
-        parameter's own layout."""
+        self._sync_host_steps()
         sd = super().state_dict()
         params = [p for g in self.param_groups for p in g["params"]]
         state = {}
         for k, st in sd["state"].items():
-            if isinstance(st, dict) and st.get("node_major"):
-                p = params[k]
-                st = {kk: vv for kk, vv in st.items() if kk != "node_major"}
+            p = params[k]
+            if getattr(p, "_mrgcn_node_major", False) and isinstance(st, dict) and "exp_avg" in st:
+                st = dict(st)
                 for key in ("exp_avg", "exp_avg_sq"):
-                    st[key] = st[key].permute(1, 0, 2).contiguous().view_as(p)
+                    if st[key].dim() == 3:
+                        st[key] = _to_reference_layout(st[key])
             state[k] = st
         sd["state"] = state
         return sd
+
+    def load_state_dict(self, state_dict):
+        params = [p for g in self.param_groups for p in g["params"]]
+        sd = dict(state_dict)
+        sd["state"] = dict(sd["state"])
+        for k, st in sd["state"].items():
+            p = params[k]
+            if getattr(p, "_mrgcn_node_major", False) and "exp_avg" in st and st["exp_avg"].dim() == 2:
+                N, B, F = p.shape
+                st = dict(st)
+                for key in ("exp_avg", "exp_avg_sq"):
+                    st[key] = st[key].view(B, N, F).permute(1, 0, 2).contiguous()
+                sd["state"][k] = st
+        super().load_state_dict(sd)
+        self._state_gen += 1
+        self._dev_step = {}  # re-seeded from the loaded `step` entries at the next step
 
     def set_distributed(self, group, sharded_params):
         """Node-partitioned training (mrgcn_amd.partition): `sharded_params` hold disjoint shards
@@ -117,26 +154,28 @@ class ClipAdam(torch.optim.Optimizer):
             self._scratch[device] = s
         return s
 
+    def _new_state(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st
+
     @torch.no_grad()
     def step(self, closure=None):
         lib = L.load()
         live = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
-        # parameters whose gradient was left in recomputable form (functional.defer_input_grad)
-        deferred = []
-        nodemajor = []  # gradient in node-major form (functional._NODEMAJOR), moments kept the same way
+        rowsparse = []  # gradient left on the parameter in row-sparse form (functional._ROW_SPARSE)
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
-                    ent = pop_deferred(p)
+                    ent = pop_row_grad(p)
                     if ent is not None:
-                        deferred.append((g, p, ent))
-                        continue
-                    ent = pop_nodemajor(p)
-                    if ent is not None:
-                        nodemajor.append((g, p, ent))
-        if not live and not deferred and not nodemajor:
+                        rowsparse.append((g, p, ent))
+        if not live and not rowsparse:
             return None
-        device = (live[0][1] if live else (deferred or nodemajor)[0][1]).device
+        device = (live[0][1] if live else rowsparse[0][1]).device
         if not all(p.device == device for _, p in live):
             raise L.MrgcnError("ClipAdam: all parameters must live on one GPU")
         sc = self._dev_scratch(device)
@@ -150,15 +189,10 @@ class ClipAdam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 grads.append(g)
                 acc = sc["sumsq_sharded"] if id(p) in sharded else sc["sumsq"]
-                pre = pop_grad_sumsq(g)  # already accumulated by the kernel that produced g?
-                if pre is not None:
-                    acc += pre
-                else:
-                    L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), acc.data_ptr(), s),
-                            "mrgcn_sumsq_accum_f32")
-            for _, p, ent in deferred + nodemajor:
+                L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), acc.data_ptr(), s),
+                        "mrgcn_sumsq_accum_f32")
+            for _, p, ent in rowsparse:  # ||g||^2 came for free with the gradient
                 (sc["sumsq_sharded"] if id(p) in sharded else sc["sumsq"]).add_(ent["sumsq"])
-            clear_grad_sumsq()
             if self._dist:
                 from .partition import all_reduce_sum_
                 all_reduce_sum_(sc["sumsq_sharded"], self._dist[0])
@@ -168,122 +202,66 @@ class ClipAdam(torch.optim.Optimizer):
                 L.check(lib.mrgcn_clip_coef_f32(sc["sumsq"].data_ptr(), float(self.max_norm),
                                                 sc["coef"].data_ptr(), sc["norm"].data_ptr(), s),
                         "mrgcn_clip_coef_f32")
-            # deferred parameters first: their pass 2 needs the other parameters' pre-step values
-            for group, p, ent in deferred:
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
-                b1, b2 = group["betas"]
-                L.check(lib.mrgcn_basis_mix_bwd_adam_f32(
-                    ent["plan"].handle, ent["dM"].data_ptr(), ent["ld"], ent["comp"].data_ptr(), ent["B"],
-                    ent["F"], p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                    float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                    float(group["weight_decay"]), int(st["step"]),
-                    sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_basis_mix_bwd_adam_f32")
+            coef_ptr = sc["coef"].data_ptr() if use_clip else 0
             bias = {}
             if self.capturable:
-                if deferred:
-                    raise L.MrgcnError("ClipAdam(capturable=True) does not take deferred gradients")
                 for group in self.param_groups:  # one device counter per distinct (beta1, beta2)
                     key = tuple(float(b) for b in group["betas"])
                     if key in bias:
                         continue
                     ent = self._dev_step.get(key)
                     if ent is None:
-                        ent = (torch.zeros((), dtype=torch.int64, device=device),
+                        # seeded with the steps already taken (a loaded checkpoint, eager steps before)
+                        t0 = max([int(self.state[p].get("step", 0)) for g2 in self.param_groups
+                                  if tuple(float(b) for b in g2["betas"]) == key for p in g2["params"]
+                                  if self.state.get(p)] or [0])
+                        ent = (torch.full((), t0, dtype=torch.int64, device=device),
                                torch.ones(2, dtype=torch.float32, device=device))
                         self._dev_step[key] = ent
                     L.check(lib.mrgcn_adam_bias_f32(ent[0].data_ptr(), key[0], key[1], ent[1].data_ptr(), s),
                             "mrgcn_adam_bias_f32")
                     bias[key] = ent[1]
-            for group, p, ent in nodemajor:
+            for group, p, ent in rowsparse:
                 if float(group["weight_decay"]) != 0.0:
-                    raise L.MrgcnError("node-major gradients need weight_decay = 0 (a decayed parameter "
+                    raise L.MrgcnError("row-sparse gradients need weight_decay = 0 (a decayed parameter "
                                        "moves without gradient)")
-                N_, Bn, Fn_ = ent["shape"]
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros((N_, Bn, Fn_), dtype=torch.float32, device=p.device)
-                    st["exp_avg_sq"] = torch.zeros((N_, Bn, Fn_), dtype=torch.float32, device=p.device)
-                    st["node_major"] = (N_, Bn, Fn_)
-                elif not st.get("node_major"):
-                    # moments built in the parameter's layout (plain steps, a loaded checkpoint): transpose
-                    # once, and every node that holds a non-zero moment counts as `ever`
-                    for key in ("exp_avg", "exp_avg_sq"):
-                        st[key] = st[key].reshape(Bn, N_, Fn_).permute(1, 0, 2).contiguous()
-                    st["node_major"] = (N_, Bn, Fn_)
-                    ent["seeded_for"] = None
-                owner = (id(self), getattr(self, "_state_gen", 0))
+                st = self._new_state(p)
+                owner = (id(self), self._state_gen)
                 if ent.get("seeded_for") != owner:
-                    # these flags have not seen this optimizer's moments yet (a converted or re-loaded
-                    # state, a rebuilt gradient entry): every node with a non-zero moment counts as `ever`
-                    if st["step"] > 0:
+                    # these flags have not seen this optimizer's moments yet (a loaded or dense-built state,
+                    # a fresh gradient entry): every node that holds a non-zero moment counts as `ever`
+                    ent["ever"].zero_()
+                    if st["step"] > 0 or self._dev_step:
                         nz = (st["exp_avg"] != 0).flatten(1).any(1) | (st["exp_avg_sq"] != 0).flatten(1).any(1)
                         ent["ever"] |= nz.to(torch.uint8)
                     ent["seeded_for"] = owner
                 st["step"] += 1
                 b1, b2 = group["betas"]
                 bc = bias[(float(b1), float(b2))].data_ptr() if self.capturable else 0
-                L.check(lib.mrgcn_adam_step_nodemajor_f32(
+                nrows = p.shape[0]
+                L.check(lib.mrgcn_adam_step_rows_f32(
                     p.data_ptr(), ent["g"].data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                    N_, Bn, Fn_, ent["cur"].data_ptr(), ent["ever"].data_ptr(), float(group["lr"]), float(b1),
-                    float(b2), float(group["eps"]), int(st["step"]), bc,
-                    sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_adam_step_nodemajor_f32")
+                    nrows, p.numel() // max(nrows, 1), ent["cur"].data_ptr(), ent["ever"].data_ptr(),
+                    float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), bc, coef_ptr, s),
+                    "mrgcn_adam_step_rows_f32")
             for (group, p), g in zip(live, grads):
-                st = self.state[p]
-                had_state = bool(st)
-                if st.get("node_major"):  # back on the plain path: moments return to the parameter's layout
-                    for key in ("exp_avg", "exp_avg_sq"):
-                        st[key] = st[key].permute(1, 0, 2).contiguous().view_as(p)
-                    del st["node_major"]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st = self._new_state(p)
                 st["step"] += 1
                 b1, b2 = group["betas"]
-                chunks = pop_weight_chunks(p)
-                if chunks is not None:
-                    # gradient written only where nodes with gradient live (functional.sparse_weight_grad)
-                    if float(group["weight_decay"]) != 0.0:
-                        raise L.MrgcnError("chunk-sparse gradients need weight_decay = 0 (a decayed "
-                                           "parameter moves without gradient)")
-                    owner = (id(self), getattr(self, "_state_gen", 0))  # this optimizer, this (possibly re-loaded) state
-                    if chunks.get("synced_for") != owner:
-                        chunks["state_synced"] = False
-                        chunks["synced_for"] = owner
-                    if had_state and not chunks.get("state_synced"):
-                        # moments that were not built under these masks (a loaded checkpoint, steps taken
-                        # on the plain path): every chunk that holds a non-zero moment counts as `ever`
-                        nzm = (st["exp_avg"].view(chunks["B"], -1) != 0).any(0)
-                        nzm |= (st["exp_avg_sq"].view(chunks["B"], -1) != 0).any(0)
-                        pad = chunks["ever"].numel() * 1024 - nzm.numel()
-                        nzm = torch.nn.functional.pad(nzm, (0, pad)).view(-1, 1024).any(1)
-                        chunks["ever"] |= nzm.to(torch.uint8)
-                    chunks["state_synced"] = True
-                    bc = bias[(float(b1), float(b2))].data_ptr() if self.capturable else 0
-                    L.check(lib.mrgcn_adam_step_chunked_f32(
-                        p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                        chunks["slab"], chunks["B"], chunks["cur"].data_ptr(), chunks["ever"].data_ptr(),
-                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), bc,
-                        sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_adam_step_chunked_f32")
-                    continue
+                rows = getattr(p, "_mrgcn_rows", None)
+                if rows is not None:
+                    rows["seeded_for"] = None  # a dense step may put moments where the row flags never looked
                 if self.capturable:
                     L.check(lib.mrgcn_adam_step_dev_f32(
                         p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                         p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                        float(group["weight_decay"]), bias[(float(b1), float(b2))].data_ptr(),
-                        sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_adam_step_dev_f32")
+                        float(group["weight_decay"]), bias[(float(b1), float(b2))].data_ptr(), coef_ptr, s),
+                        "mrgcn_adam_step_dev_f32")
                     continue
                 L.check(lib.mrgcn_adam_step_f32(
                     p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                     p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                    float(group["weight_decay"]), int(st["step"]),
-                    sc["coef"].data_ptr() if use_clip else 0, s), "mrgcn_adam_step_f32")
+                    float(group["weight_decay"]), int(st["step"]), coef_ptr, s), "mrgcn_adam_step_f32")
         return None
 
     def last_grad_norm(self) -> float:
@@ -313,30 +291,27 @@ def weight_regularisation(model, l1_lambda: float = 0.0, l2_lambda: float = 0.0)
 def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.0, l2_lambda: float = 0.0,
                row_sparse=None):
     """One full-batch epoch.  `forward_fn()` returns the logits (e.g. `lambda: model(batch)`).
-    Returns the loss as a device scalar (no host sync).  `row_sparse`: None = skip the rows of
-    weight_I's gradient / Adam update that carry no gradient whenever that is exact (ClipAdam, no
-    weight decay, no regulariser); False = always the dense gradient and the dense Adam kernel."""
-    clear_grad_sumsq()
+    Returns the loss as a device scalar (no host sync).  `row_sparse`: None = skip the rows of a node-major
+    weight_I's gradient / Adam update that carry no gradient whenever that is exact (ClipAdam, no weight
+    decay, no regulariser — `weight_I.grad` stays None for such a step, the gradient travels on the
+    parameter); False = always the dense gradient in `.grad` and the dense Adam kernel."""
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    clear_row_grads(params)
     logits = forward_fn()
     loss = categorical_crossentropy(logits, idx, targets)
     reg = l1_lambda > 0 or l2_lambda > 0
     if reg:
         loss = loss + weight_regularisation(model, l1_lambda, l2_lambda)
     optimizer.zero_grad(set_to_none=True)
-    # a regulariser adds its own term to weight_I's gradient: the deferred (recomputed) form
-    # cannot represent that, so it is off for such steps
-    prev = defer_input_grad(False) if reg else None
-    # weight_I's gradient may stay unwritten where no node has any (chunk-sparse) when the optimizer
-    # is the one that knows how to read it and nothing but the loss feeds that gradient
-    sparse_ok = (row_sparse is not False and _SPARSE_WGRAD_DEFAULT and not reg and isinstance(optimizer, ClipAdam)
+    # weight_I's gradient may stay unwritten where no node has any when the optimizer is the one that
+    # knows how to read it and nothing but the loss feeds that gradient (a regulariser adds its own term)
+    sparse_ok = (row_sparse is not False and _ROW_SPARSE_DEFAULT and not reg and isinstance(optimizer, ClipAdam)
                  and all(float(g["weight_decay"]) == 0.0 for g in optimizer.param_groups))
-    prev_sparse = sparse_weight_grad(sparse_ok)
+    prev = row_sparse_weight_grad(sparse_ok)
     try:
         loss.backward()
     finally:
-        sparse_weight_grad(prev_sparse)
-        if reg:
-            defer_input_grad(prev)
+        row_sparse_weight_grad(prev)
     optimizer.step()
     return loss.detach()
 
@@ -370,7 +345,9 @@ class GraphedTrainStep:
         # watchdog in a multi-rank job) do not invalidate the capture
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = train_step(*args)
-        self.warmup_steps = max(warmup, 1) + 1  # optimizer steps already taken (capture runs one)
+        # capturing executes nothing on the device: `warmup` optimizer steps have been taken so far (the
+        # optimizer's device counter says the same; ClipAdam.state_dict() reads it back)
+        self.warmup_steps = max(warmup, 1)
 
     def __call__(self):
         self.graph.replay()

@@ -72,6 +72,8 @@ def test_node_partition_arithmetic_and_local_coo():
     B, out = 3, 4
     w = torch.arange(B * N * out, dtype=torch.float32).view(B * N, out)
     cat = torch.cat([p.shard_weight_I(w, B).view(B, p.S, out)[:, :p.n_local] for p in parts], 1)
+    cat_nm = torch.cat([p.shard_weight_I(w, B, node_major=True)[:p.n_local] for p in parts], 0)  # (N, B, out)
+    assert torch.equal(cat_nm.permute(1, 0, 2).reshape(B * N, out), w)
     assert torch.equal(cat.reshape(B * N, out), w)
 
 

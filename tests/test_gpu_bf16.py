@@ -115,6 +115,6 @@ def test_model_with_bf16_operand_close_to_reference(name):
     for n, p in model.named_parameters():
         if n != "relations":  # same direction as the reference gradient (cosine), similar size
             gref = c["grad." + n].ravel().astype(np.float64)
-            got = p.grad.cpu().numpy().ravel().astype(np.float64)
+            got = util.ref_layout(p.grad, n).cpu().numpy().ravel().astype(np.float64)
             cos = float(got @ gref) / max(np.linalg.norm(got) * np.linalg.norm(gref), 1e-30)
             assert cos > 0.99, (n, cos)

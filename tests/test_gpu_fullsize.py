@@ -165,15 +165,24 @@ def test_am_epoch_logits_against_the_float64_oracle_at_sampled_rows(am):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
 
 
-def test_am_default_epoch_equals_literal_engine_with_dense_adam(am):
-    """Three epochs at N = 1.67 M two ways from the same start: (a) the default path — fused engine,
-    gradient-sparsity shortcuts, captured and replayed; (b) the op-for-op literal engine (materialised
-    (R*N) x out operands and dense gradients, graph.py:70-75,:93-95) with the plain dense Adam kernel,
-    launched eagerly.  Losses, logits, parameters and Adam moments agree."""
-    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
-    g, plan, A_csr = am
-    model, A, X, idx, y, dims, B = _am_model_and_data(am, seed=5)
-    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+def _compare_runs(names, sd_a, sd_b, mom_a, osd_b, steps):
+    for k, st in osd_b["state"].items():
+        n = names[k]
+        ma, va = mom_a[n]
+        assert ma.shape == st["exp_avg"].shape, n
+        ms, vs = float(st["exp_avg"].abs().max()), float(st["exp_avg_sq"].abs().max())
+        assert float((ma - st["exp_avg"]).abs().max()) <= 2e-3 * ms + 1e-9, n
+        assert float((va - st["exp_avg_sq"]).abs().max()) <= 4e-3 * vs + 1e-12, n
+    for n, p in sd_b.items():
+        d = (sd_a[n] - p).abs()
+        # Adam's first steps move every element by ~lr * sign(g): elements whose gradient is at fp32
+        # rounding level may differ by a step; everything else agrees tightly
+        assert float((d > 2e-5).float().mean()) < 2e-3, n
+        assert float(d.max()) <= 0.021 * steps, n
+
+
+def _default_run(model, A, X, idx, y):
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep
     opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0, capturable=True)
     step = GraphedTrainStep(model, lambda: model(X, A), idx, y, opt, warmup=1)  # one eager epoch ...
     la = [float(step()), float(step())]                                          # ... and two replayed
@@ -183,7 +192,46 @@ def test_am_default_epoch_equals_literal_engine_with_dense_adam(am):
     osd = opt.state_dict()
     names = [n for n, _ in model.named_parameters()]
     mom_a = {names[k]: (st["exp_avg"].clone(), st["exp_avg_sq"].clone()) for k, st in osd["state"].items()}
-    del step, opt
+    assert all(int(st["step"]) == 3 for st in osd["state"].values())
+    return la, logits_a, sd_a, mom_a, names
+
+
+def test_am_default_epoch_equals_the_epoch_without_shortcuts(am):
+    """Three epochs at N = 1.67 M two ways from the same start: (a) the default path — live-column backward,
+    row-sparse weight_I gradient and Adam, captured and replayed from a hipGraph; (b) the same kernels with every
+    gradient-sparsity shortcut off (general transposed product, dense gradient in .grad, plain dense Adam kernel),
+    launched eagerly.  Losses, logits, parameters and Adam moments agree.  (The op-for-op literal engine is
+    compared at a size its 4.45 G-element library GEMM can hold: next test.)"""
+    from mrgcn_amd import functional as Fn
+    from mrgcn_amd.train import ClipAdam, train_step
+    g, plan, A_csr = am
+    model, A, X, idx, y, dims, B = _am_model_and_data(am, seed=5)
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    la, logits_a, sd_a, mom_a, names = _default_run(model, A, X, idx, y)
+    model.load_state_dict(init)
+    opt_b = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    prev, Fn._LIVE_COLS = Fn._LIVE_COLS, False
+    try:
+        lb = [float(train_step(model, lambda: model(X, A), idx, y, opt_b, row_sparse=False)) for _ in range(3)]
+    finally:
+        Fn._LIVE_COLS = prev
+    np.testing.assert_allclose(la, lb[1:], rtol=2e-5, atol=2e-6)
+    with torch.no_grad():
+        logits_b = model(X, A)
+    assert float((logits_a - logits_b).abs().max()) <= 1e-4 * max(1.0, float(logits_b.abs().max()))
+    _compare_runs(names, sd_a, model.state_dict(), mom_a, opt_b.state_dict(), 3)
+
+
+def test_am_default_epoch_equals_literal_engine_with_dense_adam(am):
+    """The same comparison against the op-for-op literal engine at N = 1.67 M: materialised (R*N) x out
+    operands (17.8 GB each) and dense gradients (graph.py:70-75,:93-95), plain dense Adam, eager launches.
+    (The literal engine issues its library GEMMs in pieces: with results beyond 4 GiB the ROCm BLAS path
+    returned a few wrong rows — layers/graph.py::_MAX_GEMM_OUT.)"""
+    from mrgcn_amd.train import ClipAdam, train_step
+    g, plan, A_csr = am
+    model, A, X, idx, y, dims, B = _am_model_and_data(am, seed=9)
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    la, logits_a, sd_a, mom_a, names = _default_run(model, A, X, idx, y)
     model.load_state_dict(init)
     model.set_engine("literal")
     opt_b = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
@@ -192,20 +240,9 @@ def test_am_default_epoch_equals_literal_engine_with_dense_adam(am):
     with torch.no_grad():
         logits_b = model(X, A)
     assert float((logits_a - logits_b).abs().max()) <= 1e-4 * max(1.0, float(logits_b.abs().max()))
-    osd_b = opt_b.state_dict()
-    for k, st in osd_b["state"].items():
-        n = names[k]
-        ma, va = mom_a[n]
-        assert ma.shape == st["exp_avg"].shape, n
-        ms, vs = float(st["exp_avg"].abs().max()), float(st["exp_avg_sq"].abs().max())
-        assert float((ma - st["exp_avg"]).abs().max()) <= 2e-3 * ms + 1e-9, n
-        assert float((va - st["exp_avg_sq"]).abs().max()) <= 4e-3 * vs + 1e-12, n
-    for n, p in model.state_dict().items():
-        d = (sd_a[n] - p).abs()
-        # Adam's first steps move every element by ~lr * sign(g): elements whose gradient is at fp32
-        # rounding level may differ by a step; everything else agrees tightly
-        assert float((d > 2e-5).float().mean()) < 2e-3, n
-        assert float(d.max()) <= 0.021 * 3, n
+    _compare_runs(names, sd_a, model.state_dict(), mom_a, opt_b.state_dict(), 3)
+    del opt_b
+    torch.cuda.empty_cache()
 
 
 def test_am_quarter_bf16_operand_logits_within_the_stated_tolerance():

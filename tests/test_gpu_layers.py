@@ -51,72 +51,22 @@ def test_rgcn_forward_backward_vs_reference_goldens(name, engine):
         if n == "relations":
             assert p.grad is None
             continue
-        np.testing.assert_allclose(p.grad.cpu().numpy(), c["grad." + n], rtol=1e-3, atol=1e-5, err_msg=n)
+        np.testing.assert_allclose(util.ref_layout(p.grad, n).cpu().numpy(), c["grad." + n], rtol=1e-3, atol=1e-5,
+                                   err_msg=n)
     if not fl:
         np.testing.assert_allclose(X.grad.cpu().numpy(), c["grad.X"], rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("row_sparse", [None, False])
 @pytest.mark.parametrize("name", util.rgcn_cases())
-def test_epoch_steps_vs_reference_goldens(name, defer=False):
+def test_epoch_steps_vs_reference_goldens(name, row_sparse):
     """zero_grad / backward / clip 1.0 / Adam driven for n_adam epochs
-    (node_classification.py:166-193)."""
-    from mrgcn_amd import functional as Fn
+    (node_classification.py:166-193), with the row-sparse weight_I gradient (default) and the dense one."""
     from mrgcn_amd.train import ClipAdam, train_step
-    prev = Fn.defer_input_grad(defer)
-    try:
-        _epoch_steps(name, ClipAdam, train_step, defer)
-    finally:
-        Fn.defer_input_grad(prev)
+    _epoch_steps(name, ClipAdam, train_step, row_sparse)
 
 
-@pytest.mark.parametrize("name", [n for n in util.rgcn_cases() if "_b0_" not in n])
-def test_epoch_steps_with_deferred_weight_I_update(name):
-    """Same goldens with weight_I's gradient never stored: ||dV||^2 in the backward, Adam applied
-    inside the kernel that recomputes dV (mrgcn_basis_mix_bwd_adam_f32)."""
-    test_epoch_steps_vs_reference_goldens(name, defer=True)
-
-
-def test_deferred_update_equals_the_stored_gradient_update():
-    """The two update paths share their arithmetic (only the double-precision atomics that sum
-    the gradient norm are unordered): parameters and Adam state after 3 steps agree to fp32
-    rounding, with and without weight decay."""
-    from mrgcn_amd import functional as Fn
-    from mrgcn_amd.train import ClipAdam, train_step
-    name = "rgcn_smoke_ft_b5_norm_f32"
-    c = util.load_case(name)
-    A = _adjacency(c, name)
-    X = torch.from_numpy(c["X"]).cuda()
-    idx = torch.from_numpy(c["labels_idx"]).cuda()
-    tgt = torch.from_numpy(c["labels_y"]).cuda()
-    for wd in (0.0, 0.05):
-        out = []
-        for defer in (False, True):
-            model, _ = util.build_rgcn_from_case(c, "cuda")
-            util.load_state_from_case(model, c)
-            model = model.cuda()
-            opt = ClipAdam(list(model.parameters()), lr=0.01, weight_decay=wd, max_norm=1.0)
-            prev = Fn.defer_input_grad(defer)
-            prev_nm, Fn._NODE_MAJOR = Fn._NODE_MAJOR, False  # "stored" = the dense gradient tensor
-            try:
-                for _ in range(3):
-                    train_step(model, lambda: model(X, A), idx, tgt, opt)
-                    wI = model.layers["layer_0"].weight_I
-                    assert (wI.grad is None) == defer
-            finally:
-                Fn.defer_input_grad(prev)
-                Fn._NODE_MAJOR = prev_nm
-            st = opt.state[model.layers["layer_0"].weight_I]
-            out.append(({k: v.clone() for k, v in model.state_dict().items()}, st["exp_avg"].clone(),
-                        st["exp_avg_sq"].clone(), opt.last_grad_norm()))
-        (sa, ma, va, na), (sb, mb, vb, nb) = out
-        assert abs(na - nb) <= 1e-6 * na
-        for k in sa:
-            torch.testing.assert_close(sa[k], sb[k], rtol=1e-6, atol=1e-7, msg=k)
-        torch.testing.assert_close(ma, mb, rtol=1e-6, atol=1e-9)
-        torch.testing.assert_close(va, vb, rtol=1e-6, atol=1e-12)
-
-
-def _epoch_steps(name, ClipAdam, train_step, defer):
+def _epoch_steps(name, ClipAdam, train_step, row_sparse=None):
     c = util.load_case(name)
     model, dims = util.build_rgcn_from_case(c, "cuda")
     util.load_state_from_case(model, c)
@@ -129,7 +79,7 @@ def _epoch_steps(name, ClipAdam, train_step, defer):
     opt = ClipAdam([p for n, p in model.named_parameters()], lr=0.01, weight_decay=0.0, max_norm=1.0)
     n_adam = int(c["meta.n_adam"])
     for step in range(1, n_adam + 1):
-        loss = train_step(model, lambda: model(X, A), idx, tgt, opt)
+        loss = train_step(model, lambda: model(X, A), idx, tgt, opt, row_sparse=row_sparse)
         np.testing.assert_allclose(float(loss), float(c[f"loss_step{step}"]), rtol=2e-4, atol=2e-5)
         if step == 1:
             np.testing.assert_allclose(opt.last_grad_norm(), float(c["grad_norm"]), rtol=1e-4)
@@ -191,8 +141,8 @@ def test_mrgcn_through_fullbatch_boundary(name):
             acc = categorical_accuracy(Y_hat.detach(), idx, tgt)[0]
             np.testing.assert_allclose(float(acc), float(c["accuracy"]), atol=1e-6)
             for n, p in model.named_parameters():
-                np.testing.assert_allclose(p.grad.cpu().numpy(), c["grad." + n], rtol=1e-3, atol=1e-5,
-                                           err_msg=n)
+                np.testing.assert_allclose(util.ref_layout(p.grad, n).cpu().numpy(), c["grad." + n], rtol=1e-3,
+                                           atol=1e-5, err_msg=n)
         opt.step()
         sd = model.state_dict()
         for k in c.files:
@@ -218,12 +168,12 @@ def test_featureless_wide_layer_vs_oracle(N, R, B, F, bias):
     w = torch.randn_like(Y)
     (Y * w).sum().backward()
     cfg = O.LayerCfg(0, F, R, N, B, bias=bias, input_layer=True, featureless=True)
-    p = {k: v.detach().cpu().numpy() for k, v in layer.named_parameters()}
+    p = {k: v.detach().cpu().numpy() for k, v in layer.state_dict().items()}  # the reference's shapes
     pre, cache = O.layer_forward(cfg, p, None, A)
     np.testing.assert_allclose(Y.detach().cpu().numpy(), np.maximum(pre, 0), rtol=1e-4, atol=1e-4)
     grads, _ = O.layer_backward(cfg, p, None, A, w.cpu().numpy().astype(np.float64) * (pre > 0), cache)
     for k, v in grads.items():
-        got = getattr(layer, k).grad.cpu().numpy()
+        got = util.ref_layout(getattr(layer, k).grad, k).cpu().numpy()
         np.testing.assert_allclose(got, v, rtol=2e-4, atol=2e-5 * (np.abs(v).max() + 1e-12) + 1e-6, err_msg=k)
 
 
@@ -269,14 +219,14 @@ def test_fused_layer_vs_oracle(N, R, B, K, F, hub):
     (Y * w).sum().backward()
 
     cfg = O.LayerCfg(K, F, R, N, B, bias=True, input_layer=True, featureless=False)
-    p = {k: v.detach().cpu().numpy() for k, v in layer.named_parameters()}
+    p = {k: v.detach().cpu().numpy() for k, v in layer.state_dict().items()}  # the reference's shapes
     pre, cache = O.layer_forward(cfg, p, X.detach().cpu().numpy(), A)
     np.testing.assert_allclose(Y.detach().cpu().numpy(), np.maximum(pre, 0), rtol=1e-4, atol=1e-4)
     dPre = w.cpu().numpy().astype(np.float64) * (pre > 0)
     grads, dX = O.layer_backward(cfg, p, X.detach().cpu().numpy(), A, dPre, cache)
     scale = {k: np.abs(v).max() + 1e-12 for k, v in grads.items()}
     for k, v in grads.items():
-        got = getattr(layer, k).grad.cpu().numpy()
+        got = util.ref_layout(getattr(layer, k).grad, k).cpu().numpy()
         np.testing.assert_allclose(got, v, rtol=2e-4, atol=2e-5 * scale[k] + 1e-6, err_msg=k)
     np.testing.assert_allclose(X.grad.cpu().numpy(), dX, rtol=2e-4, atol=1e-5 * np.abs(dX).max())
 
@@ -318,10 +268,10 @@ def test_graph_captured_epoch_equals_eager(name):
 @pytest.mark.parametrize("N,R,B,F,hub", [(900, 7, 40, 10, 500), (333, 5, 3, 11, 0), (640, 9, 64, 16, 200),
                                          (500, 6, 70, 12, 0)])  # the last one: B > 64, two-kernel fallback
 def test_basis_mix_backward_with_rows_without_gradient(N, R, B, F, hub, zero_frac):
-    """dV / dcomp through the C ABI when most rows of dM are exact zeros — the state of a
-    semi-supervised epoch (only columns within two hops of a label receive gradient), which the
-    wave-per-node kernel detects and skips.  Includes a node with more than 64 columns, negative
-    zeros, and the squared norm that clip_grad_norm_ consumes."""
+    """dV / dcomp through the C ABI (node-major V / dV) when most rows of dM carry no gradient — the state of
+    a semi-supervised epoch (only columns within two hops of a label receive gradient).  Includes a node with
+    more than 64 columns, NaN-poisoned dead rows, the squared norm that clip_grad_norm_ consumes, and the
+    row-sparse form that leaves the blocks of nodes without gradient unwritten."""
     from mrgcn_amd import _lib as L
     from mrgcn_amd.plan import GraphPlan
     rng = np.random.default_rng(N + B + int(zero_frac * 100))
@@ -334,58 +284,57 @@ def test_basis_mix_backward_with_rows_without_gradient(N, R, B, F, hub, zero_fra
     dM = rng.standard_normal((nc, ld)).astype(np.float32)
     dead = rng.random(nc) < zero_frac
     dM[dead] = 0.0
-    dM[dead & (rng.random(nc) < 0.3)] = -0.0
-    V = rng.standard_normal((B, N, F)).astype(np.float32)
+    V = rng.standard_normal((N, B, F)).astype(np.float32)      # node-major
     comp = rng.standard_normal((R, B)).astype(np.float32)
 
     d64 = dM[:, :F].astype(np.float64)
-    want_dV = np.zeros((B, N, F))
-    np.add.at(want_dV, (slice(None), unode), comp.astype(np.float64)[urel].T[:, :, None] * d64[None])
+    want_dV = np.zeros((N, B, F))
+    np.add.at(want_dV, unode, comp.astype(np.float64)[urel][:, :, None] * d64[:, None, :])
     want_dc = np.zeros((R, B))
-    np.add.at(want_dc, urel, np.einsum("cf,bcf->cb", d64, V.astype(np.float64)[:, unode]))
+    np.add.at(want_dc, urel, np.einsum("cf,cbf->cb", d64, V.astype(np.float64)[unode]))
+    node_live = np.zeros(N, dtype=bool)
+    node_live[unode[~dead]] = True
 
     lib = L.load()
     s = torch.cuda.current_stream().cuda_stream
     dMt, Vt, ct = (torch.from_numpy(x).cuda() for x in (dM, V, comp))
-    dV = torch.full((B, N, F), 7.0, device="cuda")
+    # (a) no flags: every column counts, every block is written
+    dV = torch.full((N, B, F), 7.0, device="cuda")
     dc = torch.full((R, B), 7.0, device="cuda")
     sq = torch.zeros((), dtype=torch.float64, device="cuda")
-    L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dMt.data_ptr(), ld, Vt.data_ptr(), ct.data_ptr(), B, F,
-                                        dV.data_ptr(), dc.data_ptr(), sq.data_ptr(), s))
+    L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dMt.data_ptr(), ld, 0, Vt.data_ptr(), ct.data_ptr(), B, F,
+                                        dV.data_ptr(), 0, dc.data_ptr(), sq.data_ptr(), s))
     np.testing.assert_allclose(dV.cpu().numpy(), want_dV, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(dc.cpu().numpy(), want_dc, rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
     if zero_frac == 1.0:
         assert not dV.any() and not dc.any() and float(sq) == 0.0
-
-    # norm-only form (deferred update): same dcomp and norm, no dV
-    dc2 = torch.full((R, B), 7.0, device="cuda")
-    sq.zero_()
-    L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dMt.data_ptr(), ld, Vt.data_ptr(), ct.data_ptr(), B, F,
-                                        0, dc2.data_ptr(), sq.data_ptr(), s))
-    np.testing.assert_allclose(dc2.cpu().numpy(), want_dc, rtol=1e-4, atol=1e-3)
-    np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
-
-    # with the producer's flags the dead rows are never read: poison them
+    # (b) with the producer's flags the dead rows are never read: poison them; dense dV (zeros for dead nodes)
     liveg = torch.from_numpy((~dead).astype(np.uint8)).cuda()
     dMp = dMt.clone()
     dMp[torch.from_numpy(dead).cuda()] = float("nan")
-    for dv_ptr in (dV.data_ptr(), 0):
-        sq.zero_()
-        L.check(lib.mrgcn_basis_mix_bwd_live_f32(plan.handle, dMp.data_ptr(), ld, liveg.data_ptr(), 0, Vt.data_ptr(),
-                                                 ct.data_ptr(), B, F, dv_ptr, dc.data_ptr(), sq.data_ptr(), s))
-        np.testing.assert_allclose(dc.cpu().numpy(), want_dc, rtol=1e-4, atol=1e-3)
-        np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
+    dV.fill_(7.0); dc.fill_(7.0); sq.zero_()
+    L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dMp.clone().data_ptr(), ld, liveg.data_ptr(), Vt.data_ptr(),
+                                        ct.data_ptr(), B, F, dV.data_ptr(), 0, dc.data_ptr(), sq.data_ptr(), s))
     np.testing.assert_allclose(dV.cpu().numpy(), want_dV, rtol=1e-4, atol=1e-5)
-
-    # a NaN anywhere in a row keeps that row alive
-    if zero_frac > 0 and dead.any():
-        c = int(np.flatnonzero(dead)[0])
-        dMt[c, F - 1] = float("nan")
-        L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dMt.data_ptr(), ld, Vt.data_ptr(), ct.data_ptr(), B, F,
-                                            dV.data_ptr(), dc.data_ptr(), 0, s))
-        assert torch.isnan(dV[:, int(unode[c]), F - 1]).all()
-        assert torch.isnan(dc[int(urel[c])]).all()
+    np.testing.assert_allclose(dc.cpu().numpy(), want_dc, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
+    # (c) row-sparse: blocks of nodes without a live column stay as they were, the flags say which
+    dV.fill_(7.0); dc.fill_(7.0); sq.zero_()
+    cur = torch.full((N,), 9, dtype=torch.uint8, device="cuda")
+    L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dMp.clone().data_ptr(), ld, liveg.data_ptr(), Vt.data_ptr(),
+                                        ct.data_ptr(), B, F, dV.data_ptr(), cur.data_ptr(), dc.data_ptr(),
+                                        sq.data_ptr(), s))
+    curh = cur.cpu().numpy()
+    got = dV.cpu().numpy()
+    assert set(np.unique(curh)) <= {0, 1}
+    assert np.array_equal(curh.astype(bool) | ~node_live, np.ones(N, dtype=bool))  # every live node is written
+    np.testing.assert_allclose(got[curh == 1], want_dV[curh == 1], rtol=1e-4, atol=1e-5)
+    if B <= 64:  # the wave-per-node kernel skips exactly the nodes without a live column
+        assert np.array_equal(curh.astype(bool), node_live)
+        assert (got[curh == 0] == 7.0).all()
+    np.testing.assert_allclose(dc.cpu().numpy(), want_dc, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
 
 
 def test_backward_is_the_same_on_the_sparse_and_the_general_transposed_product():
@@ -408,7 +357,7 @@ def test_backward_is_the_same_on_the_sparse_and_the_general_transposed_product()
         w = torch.zeros(N, F, device="cuda")
         w[torch.randperm(N, device="cuda")[:labelled]] = torch.randn(labelled, F, device="cuda")
         grads, paths = [], []
-        Fn._GAUGES.clear()  # a fresh start: once on the general product the count is only refreshed every 32 calls
+        plan.__dict__.pop("_gauges", None)  # a fresh start: once on the general product the count is only refreshed every 32 calls
         for _ in range(3):
             layer.zero_grad(); X.grad = None
             Y = layer._forward_fused(X, plan, relu=False)
@@ -435,7 +384,7 @@ def test_epoch_steps_never_read_unwritten_gradient_rows(name):
         pytest.skip("case not in the golden set")
     Fn._POISON_DEAD = True
     try:
-        test_epoch_steps_vs_reference_goldens(name)
+        test_epoch_steps_vs_reference_goldens(name, None)
     finally:
         Fn._POISON_DEAD = False
 
@@ -455,342 +404,191 @@ def _sparse_label_problem(N=6000, R=3, seed=3, labelled=6):
     return rows, cols, vals, idx, y
 
 
-def _train_rgcn(rows, cols, vals, N, R, idx, y, steps, sparse, graphed=False, seed=0, node_major=False, bases=5):
-    from mrgcn_amd import functional as Fn
-    from mrgcn_amd import train as T
+def _train_rgcn(rows, cols, vals, N, R, idx, y, steps, row_sparse, graphed=False, seed=0, bases=5, opt_state=None,
+                model_state=None, return_opt=False):
     from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
     A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
     torch.manual_seed(seed)
-    dims = [(N, 10), (10, 4)]
-    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li == 0 else None) for li, (i, o) in enumerate(dims)]
-    model = RGCN(modules, R, N, bases, 0.0, True, False, False).cuda()
-    opt = T.ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=graphed)
-    it, tg = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
-    prev, prev_nm = T._SPARSE_WGRAD_DEFAULT, Fn._NODE_MAJOR
-    T._SPARSE_WGRAD_DEFAULT, Fn._NODE_MAJOR = sparse, node_major
-    try:
-        losses = []
-        if graphed:
-            step = T.GraphedTrainStep(model, lambda: model(None, A), it, tg, opt, warmup=2)
-            losses = [float(step()) for _ in range(steps - 2)]  # the two warm-up steps count
-        else:
-            losses = [float(T.train_step(model, lambda: model(None, A), it, tg, opt)) for _ in range(steps)]
-        with torch.no_grad():
-            logits = model(None, A).cpu().numpy()
-    finally:
-        T._SPARSE_WGRAD_DEFAULT, Fn._NODE_MAJOR = prev, prev_nm
-    return losses, logits, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, opt
+    model = RGCN([(6, 10, "mrgcn", torch.nn.ReLU()), (10, 4, "mrgcn", None)], R, N, bases, 0.0, False, True, False).cuda()
+    if model_state is not None:
+        model.load_state_dict(model_state)
+    X = torch.randn((N, 6), device="cuda", generator=torch.Generator("cuda").manual_seed(seed + 1))
+    ig, yg = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0, capturable=graphed)
+    if opt_state is not None:
+        opt.load_state_dict(opt_state)
+    losses = []
+    if graphed:
+        step = GraphedTrainStep(model, lambda: model(X, A), ig, yg, opt, warmup=1, row_sparse=row_sparse)
+        losses = [float(step()) for _ in range(steps - 1)]
+    else:
+        for _ in range(steps):
+            losses.append(float(train_step(model, lambda: model(X, A), ig, yg, opt, row_sparse=row_sparse)))
+            wI = model.layers["layer_0"].weight_I
+            assert (wI.grad is None) == (row_sparse is not False)
+    torch.cuda.synchronize()
+    out = ({k: v.clone() for k, v in model.state_dict().items()}, losses)
+    return out + (opt, model) if return_opt else out
 
 
-@pytest.mark.parametrize("reordered", [False, True])
-def test_chunk_sparse_weight_gradient_trains_exactly_like_the_dense_one(reordered):
-    """functional.sparse_weight_grad: chunks of weight_I's gradient without any live node are neither
-    written nor read, Adam never touches chunks that never had gradient — the parameters after
-    several epochs are bit for bit those of the dense path; also through a captured hipGraph, and
-    on a graph renumbered with data.reorder (logits permute with the nodes)."""
-    from mrgcn_amd import functional as Fn
-    from mrgcn_amd.data import reorder
+def test_row_sparse_weight_gradient_trains_exactly_like_the_dense_one():
+    """train_step's default (the blocks of weight_I's gradient without any live node are neither written nor
+    fed to Adam: mrgcn_adam_step_rows_f32) against row_sparse=False (dense gradient in .grad, plain Adam):
+    same parameters after 4 epochs — eager and replayed from a hipGraph."""
     N, R = 6000, 3
     rows, cols, vals, idx, y = _sparse_label_problem(N, R)
-    if reordered:
-        order, inv = reorder.label_reach_order(rows, cols, N, R, idx, hops=2)
-        rows, cols = reorder.relabel_coo(rows, cols, N, inv)
-        idx = inv[idx]
-    dense = _train_rgcn(rows, cols, vals, N, R, idx, y, 5, sparse=False)
-    Fn._WCHUNKS.clear()
-    sparse = _train_rgcn(rows, cols, vals, N, R, idx, y, 5, sparse=True)
-    ent = next(iter(Fn._WCHUNKS.values()))
-    ever = ent["ever"].cpu().numpy()
-    assert 0 < ever.sum() < len(ever) // 2, "the test graph must leave most chunks without gradient"
-    if reordered:
-        assert ever[: ever.sum()].all(), "reachable nodes first: the live chunks are a prefix"
-    # (dcomp is summed with float atomics: the clip norm, hence every update, may differ in the last
-    # bits between any two runs — the tolerance is for that, not for the skipping)
-    tol = dict(rtol=1e-5, atol=1e-8)
-    np.testing.assert_allclose(np.asarray(sparse[0]), np.asarray(dense[0]), **tol)
-    for k in dense[2]:
-        np.testing.assert_allclose(sparse[2][k], dense[2][k], err_msg=k, **tol)
-    for (pd, sd), (ps, ss) in zip(dense[3].state.items(), sparse[3].state.items()):
-        for key in ("exp_avg", "exp_avg_sq"):
-            torch.testing.assert_close(ss[key], sd[key], **tol)
-        if ps.numel() == ent["numel"]:  # weight_I: chunks that never had gradient were never touched
-            dead = torch.from_numpy(np.repeat(ever == 0, 1024)[: ent["slab"]]).cuda()
-            for key in ("exp_avg", "exp_avg_sq"):
-                assert not ss[key].view(ent["B"], -1)[:, dead].any()
-                assert not sd[key].view(ent["B"], -1)[:, dead].any()  # ... and the dense run agrees: all zeros
-    Fn._WCHUNKS.clear()
-    graphed = _train_rgcn(rows, cols, vals, N, R, idx, y, 5, sparse=True, graphed=True)
-    for k in dense[2]:
-        np.testing.assert_allclose(graphed[2][k], dense[2][k], err_msg=k, **tol)
+    dense, ld = _train_rgcn(rows, cols, vals, N, R, idx, y, 4, False)
+    sparse, ls, opt, model = _train_rgcn(rows, cols, vals, N, R, idx, y, 4, None, return_opt=True)
+    ent = model.layers["layer_0"].weight_I._mrgcn_rows
+    frac = float(ent["ever"].float().mean())
+    assert 0.0 < frac < 0.5, frac          # most of the node table never gets gradient
+    np.testing.assert_allclose(ls, ld, rtol=1e-6, atol=1e-7)
+    for k in dense:
+        torch.testing.assert_close(sparse[k], dense[k], rtol=1e-6, atol=1e-7, msg=k)
+    graphed, lg = _train_rgcn(rows, cols, vals, N, R, idx, y, 4, None, graphed=True)
+    np.testing.assert_allclose(lg, ld[1:], rtol=1e-5, atol=1e-6)
+    for k in dense:
+        torch.testing.assert_close(graphed[k], dense[k], rtol=1e-5, atol=1e-6, msg=k)
+
+
+def test_row_sparse_adam_respects_moments_it_did_not_build():
+    """Two dense epochs with labels L1, then the state goes — through state_dict()s in the reference's layout —
+    to a fresh model / optimizer that trains row-sparse with labels L2: the moments the first phase built at
+    nodes that L2 never reaches must keep moving those parameters (rows with non-zero moments count as `ever`)."""
+    N, R = 4000, 3
+    rows, cols, vals, idx1, y1 = _sparse_label_problem(N, R, seed=4, labelled=8)
+    _, _, _, idx2, y2 = _sparse_label_problem(N, R, seed=9, labelled=5)
+    res = []
+    for second_sparse in (False, None):
+        sd1, _, opt1, model1 = _train_rgcn(rows, cols, vals, N, R, idx1, y1, 2, False, return_opt=True)
+        osd = opt1.state_dict()
+        assert osd["state"][list(n for n, _ in model1.named_parameters()).index("layers.layer_0.weight_I")][
+            "exp_avg"].shape == sd1["layers.layer_0.weight_I"].shape  # reference layout (B*N, out)
+        sd2, l2 = _train_rgcn(rows, cols, vals, N, R, idx2, y2, 3, second_sparse, opt_state=osd, model_state=sd1)
+        res.append((sd2, l2))
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-6, atol=1e-7)
+    for k in res[0][0]:
+        torch.testing.assert_close(res[0][0][k], res[1][0][k], rtol=1e-6, atol=1e-7, msg=k)
+
+
+def test_capturable_optimizer_state_resumes_like_an_eager_run():
+    """ClipAdam(capturable=True): the step counter lives on the device.  One eager + two replayed epochs, a
+    checkpoint (model + optimizer state_dict()), and two more epochs resumed (a) captured again and (b) eagerly
+    without capturable give the parameters of five eager epochs: the saved `step` is the true one and a
+    resumed run takes its bias corrections from it."""
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
+    N, R = 3000, 3
+    rows, cols, vals, idx, y = _sparse_label_problem(N, R, seed=6)
+    want, lw = _train_rgcn(rows, cols, vals, N, R, idx, y, 5, None)
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    X = torch.randn((N, 6), device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    ig, yg = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
+    mods = [(6, 10, "mrgcn", torch.nn.ReLU()), (10, 4, "mrgcn", None)]
+    torch.manual_seed(0)
+    m1 = RGCN(mods, R, N, 5, 0.0, False, True, False).cuda()
+    o1 = ClipAdam(m1.parameters(), lr=0.01, max_norm=1.0, capturable=True)
+    g1 = GraphedTrainStep(m1, lambda: m1(X, A), ig, yg, o1, warmup=1)
+    g1(); g1()
+    import copy
+    msd, osd = {k: v.clone() for k, v in m1.state_dict().items()}, copy.deepcopy(o1.state_dict())
+    assert all(int(st["step"]) == 3 for st in osd["state"].values())
+    for capt in (True, False):
+        m2 = RGCN(mods, R, N, 5, 0.0, False, True, False).cuda()
+        m2.load_state_dict(msd)
+        o2 = ClipAdam(m2.parameters(), lr=0.01, max_norm=1.0, capturable=capt)
+        o2.load_state_dict(copy.deepcopy(osd))  # (torch keeps references to the tensors it is handed)
+        if capt:
+            g2 = GraphedTrainStep(m2, lambda: m2(X, A), ig, yg, o2, warmup=1)
+            last = float(g2())
+        else:
+            for _ in range(2):
+                last = float(train_step(m2, lambda: m2(X, A), ig, yg, o2))
+        np.testing.assert_allclose(last, lw[4], rtol=1e-5, atol=1e-6)
+        got = m2.state_dict()
+        for k in want:
+            torch.testing.assert_close(got[k], want[k], rtol=1e-5, atol=1e-6, msg=f"{k} capturable={capt}")
+        assert all(int(st["step"]) == 5 for st in o2.state_dict()["state"].values())
+
+
+def test_layer_used_twice_in_one_row_sparse_step_is_an_error():
+    """The row-sparse gradient lives on the parameter and is overwritten by every backward: a forward_fn that
+    runs the layer twice must not lose a contribution silently."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, train_step
+    N, R = 500, 3
+    rows, cols, vals, idx, y = _sparse_label_problem(N, R, seed=2)
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    model = RGCN([(6, 10, "mrgcn", torch.nn.ReLU()), (10, 4, "mrgcn", None)], R, N, 5, 0.0, False, True, False).cuda()
+    X = torch.randn((N, 6), device="cuda")
+    opt = ClipAdam(model.parameters(), lr=0.01)
+    ig, yg = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
+    with pytest.raises(L.MrgcnError):
+        train_step(model, lambda: model(X, A) + model(X, A), ig, yg, opt)
+    loss = train_step(model, lambda: model(X, A) + model(X, A), ig, yg, opt, row_sparse=False)  # dense: fine
+    assert np.isfinite(float(loss))
 
 
 def test_renumbering_nodes_permutes_the_logits():
+    """mrgcn_amd.data.reorder: renumbering the nodes (labelled neighbourhoods first) is a pure relabelling — the
+    logits of the renumbered graph are the permuted logits of the original."""
     from mrgcn_amd.data import reorder
-    N, R = 6000, 3
-    rows, cols, vals, idx, y = _sparse_label_problem(N, R)
-    base = _train_rgcn(rows, cols, vals, N, R, idx, y, 1, sparse=False)
+    from mrgcn_amd.models.rgcn import RGCN
+    N, R = 3000, 4
+    rows, cols, vals, idx, y = _sparse_label_problem(N, R, seed=8)
     order, inv = reorder.label_reach_order(rows, cols, N, R, idx, hops=2)
-    assert sorted(order.tolist()) == list(range(N)) and (order[inv] == np.arange(N)).all()
-    r2, c2 = reorder.relabel_coo(rows, cols, N, inv)
-    # the same model on the renumbered graph: permute the node table accordingly
-    from mrgcn_amd import train as T
-    from mrgcn_amd.models.rgcn import RGCN
-    A2 = torch.sparse_coo_tensor(torch.from_numpy(np.stack([r2, c2])), torch.from_numpy(vals), (N, R * N)).cuda()
+    rows2, cols2 = reorder.relabel_coo(rows, cols, N, inv)
     torch.manual_seed(0)
-    dims = [(N, 10), (10, 4)]
-    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li == 0 else None) for li, (i, o) in enumerate(dims)]
-    model = RGCN(modules, R, N, 5, 0.0, True, False, False).cuda()
+    mods = [(6, 10, "mrgcn", torch.nn.ReLU()), (10, 4, "mrgcn", None)]
+    m1 = RGCN(mods, R, N, 5, 0.0, False, True, False).cuda()
+    m2 = RGCN(mods, R, N, 5, 0.0, False, True, False).cuda()
+    sd = m1.state_dict()
+    B, F = 5, 10
+    wI = sd["layers.layer_0.weight_I"].view(B, N, F)
+    sd2 = dict(sd)
+    sd2["layers.layer_0.weight_I"] = wI[:, torch.from_numpy(order).cuda()].reshape(B * N, F)
+    m2.load_state_dict(sd2)
+    X = torch.randn((N, 6), device="cuda")
+    A1 = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    A2 = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows2, cols2])), torch.from_numpy(vals), (N, R * N)).cuda()
     with torch.no_grad():
-        first = next(iter(model.layers.values()))
-        w = first.weight_I.view(5, N, 10)
-        first.weight_I.copy_(w[:, torch.from_numpy(order).cuda(), :].reshape(5 * N, 10).clone())
-        logits2 = model(None, A2).cpu().numpy()
-    # `base` took one training step before its logits were read: compare the untrained forward instead
-    torch.manual_seed(0)
-    model0 = RGCN(modules, R, N, 5, 0.0, True, False, False).cuda()
-    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
-    with torch.no_grad():
-        logits0 = model0(None, A).cpu().numpy()
-    np.testing.assert_allclose(logits2[inv], logits0, rtol=1e-5, atol=1e-6)
+        y1 = m1(X, A1)
+        y2 = m2(X[torch.from_numpy(order).cuda()], A2)
+    torch.testing.assert_close(y2, y1[torch.from_numpy(order).cuda()], rtol=1e-5, atol=1e-5)
 
 
-def test_chunked_adam_and_chunk_flags_through_the_c_abi():
-    """mrgcn_weight_chunks_live marks the 1024-float chunks of a basis slab that hold a node with a live
-    column; mrgcn_basis_mix_bwd_live_f32 leaves dV untouched in the other chunks;
-    mrgcn_adam_step_chunked_f32 == mrgcn_adam_step_f32 given that the gradient is zero outside the
-    `cur` chunks and the moments are zero outside the `ever` chunks — and it touches nothing there."""
+def test_row_sparse_adam_through_the_c_abi():
+    """mrgcn_adam_step_rows_f32 against mrgcn_adam_step_f32 on the rows it may not skip: rows that never had
+    gradient are left alone bit for bit, rows with moments but no gradient this step take g = 0 without their
+    (NaN-poisoned) gradient being read, `ever` picks up `cur`.  Several row lengths, eager and device-side step."""
     from mrgcn_amd import _lib as L
-    from mrgcn_amd.plan import GraphPlan
     lib = L.load()
     s = torch.cuda.current_stream().cuda_stream
-    rng = np.random.default_rng(9)
-    N, R, B, F = 3000, 4, 6, 10
-    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, 1, F, 3 * N, 0)
-    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
-    plan = GraphPlan(At, N, R)
-    unode = plan.export(L.ARR_UNODE).astype(np.int64)
-    live_nodes = np.zeros(N, bool); live_nodes[rng.choice(N, 40, replace=False)] = True
-    col_live = live_nodes[unode] & (rng.random(plan.ncols) < 0.7)
-    node_has = np.zeros(N, bool); node_has[unode[col_live]] = True
-    nch = int(lib.mrgcn_weight_chunks(plan.handle, F))
-    assert nch == (N * F + 1023) // 1024
-    want = np.zeros(nch, np.uint8)
-    for j in np.flatnonzero(node_has):
-        want[(j * F) // 1024:(j * F + F - 1) // 1024 + 1] = 1
-    cur = torch.full((nch,), 9, dtype=torch.uint8, device="cuda")
-    ever = torch.zeros(nch, dtype=torch.uint8, device="cuda"); ever[0] = 1
-    clg = torch.from_numpy(col_live.astype(np.uint8)).cuda()
-    L.check(lib.mrgcn_weight_chunks_live(plan.handle, clg.data_ptr(), F, cur.data_ptr(), ever.data_ptr(), s))
-    np.testing.assert_array_equal(cur.cpu().numpy(), want)
-    w_ever = want.copy(); w_ever[0] = 1
-    np.testing.assert_array_equal(ever.cpu().numpy(), w_ever)
-
-    # dV stays untouched (NaN here) in dead chunks, equals the dense kernel's in live ones
-    ld = 12
-    dM = rng.standard_normal((plan.ncols, ld)).astype(np.float32); dM[~col_live] = np.nan
-    V = torch.from_numpy(rng.standard_normal((B * N, F)).astype(np.float32)).cuda()
-    comp = torch.from_numpy(rng.standard_normal((R, B)).astype(np.float32)).cuda()
-    dMg = torch.from_numpy(dM).cuda()
-    outs = []
-    for chunk_ptr in (0, cur.data_ptr()):
-        dV = torch.full((B * N, F), float("nan"), device="cuda")
-        dc = torch.empty((R, B), device="cuda")
-        sq = torch.zeros((), dtype=torch.float64, device="cuda")
-        L.check(lib.mrgcn_basis_mix_bwd_live_f32(plan.handle, dMg.data_ptr(), ld, clg.data_ptr(), chunk_ptr,
-                                                 V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), dc.data_ptr(),
-                                                 sq.data_ptr(), s))
-        outs.append((dV.view(B, N * F).cpu().numpy(), dc.cpu().numpy(), float(sq)))
-    elem_live = np.repeat(want.astype(bool), 1024)[: N * F]
-    assert not np.isnan(outs[0][0]).any()
-    np.testing.assert_array_equal(outs[1][0][:, elem_live], outs[0][0][:, elem_live])
-    dead_part = outs[1][0][:, ~elem_live]  # untouched, or zeros where a 4-node group straddles a live chunk
-    assert (np.isnan(dead_part) | (dead_part == 0)).all() and np.isnan(dead_part).mean() > 0.9
-    assert not outs[0][0][:, ~elem_live].any()
-    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-5 * np.abs(outs[0][1]).max() + 1e-6)
-    np.testing.assert_allclose(outs[1][2], outs[0][2], rtol=1e-6)
-
-    # Adam: three steps, `cur` changing, against the plain kernel
-    n = B * N * F
-    p0 = torch.randn(n, device="cuda")
-    pa, pb = p0.clone(), p0.clone()
-    ma, va, mb, vb = (torch.zeros(n, device="cuda") for _ in range(4))
-    coef = torch.full((), 0.5, device="cuda")
-    ever_t = torch.zeros(nch, dtype=torch.uint8, device="cuda")
-    for step in (1, 2, 3):
-        cur_np = (rng.random(nch) < 0.3).astype(np.uint8)
-        cur_t = torch.from_numpy(cur_np).cuda()
-        ever_t |= cur_t
-        mask = torch.from_numpy(np.repeat(cur_np.astype(bool), 1024)[: N * F]).cuda()
-        g = torch.randn(B, N * F, device="cuda") * mask
-        g_sparse = torch.where(mask, g, torch.full_like(g, float("nan")))  # unwritten where not `cur`
-        L.check(lib.mrgcn_adam_step_f32(pa.data_ptr(), g.data_ptr(), ma.data_ptr(), va.data_ptr(), n, 0.01, 0.9, 0.999,
-                                        1e-8, 0.0, step, coef.data_ptr(), s))
-        L.check(lib.mrgcn_adam_step_chunked_f32(pb.data_ptr(), g_sparse.data_ptr(), mb.data_ptr(), vb.data_ptr(), N * F, B,
-                                                cur_t.data_ptr(), ever_t.data_ptr(), 0.01, 0.9, 0.999, 1e-8, step, 0,
-                                                coef.data_ptr(), s))
-        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
-    never = torch.from_numpy(np.repeat(ever_t.cpu().numpy() == 0, 1024)[: N * F]).cuda()
-    assert torch.equal(pb.view(B, -1)[:, never], p0.view(B, -1)[:, never])
-
-
-def test_chunk_sparse_adam_respects_moments_it_did_not_build():
-    """Steps on the plain path first (moments everywhere the labels of that phase reached), then the
-    chunk-sparse path with other labels: chunks that hold non-zero moments keep being updated."""
-    from mrgcn_amd import functional as Fn
-    from mrgcn_amd import train as T
-    from mrgcn_amd.models.rgcn import RGCN
-    N, R = 6000, 3
-    rows, cols, vals, idx, y = _sparse_label_problem(N, R)
-    _, _, _, idx2, y2 = _sparse_label_problem(N, R, seed=17)
-    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
-    dims = [(N, 10), (10, 4)]
-    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li == 0 else None) for li, (i, o) in enumerate(dims)]
-    results = []
-    for second_phase_sparse in (False, True):
-        Fn._WCHUNKS.clear()
-        torch.manual_seed(1)
-        model = RGCN(modules, R, N, 5, 0.0, True, False, False).cuda()
-        opt = T.ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
-        prev = T._SPARSE_WGRAD_DEFAULT
-        try:
-            T._SPARSE_WGRAD_DEFAULT = False
-            for _ in range(2):
-                T.train_step(model, lambda: model(None, A), torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda(), opt)
-            T._SPARSE_WGRAD_DEFAULT = second_phase_sparse
-            for _ in range(3):
-                T.train_step(model, lambda: model(None, A), torch.from_numpy(idx2).cuda(), torch.from_numpy(y2).cuda(), opt)
-        finally:
-            T._SPARSE_WGRAD_DEFAULT = prev
-        results.append({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
-    assert Fn._WCHUNKS, "the second phase of the second run must have used the masks"
-    for k in results[0]:
-        np.testing.assert_allclose(results[1][k], results[0][k], rtol=1e-5, atol=1e-8, err_msg=k)
-
-
-@pytest.mark.parametrize("N,R,B,F", [(3000, 4, 6, 10), (1037 * 4, 5, 40, 10), (2048, 3, 8, 16), (1000, 3, 3, 4)])
-def test_node_major_gradient_and_adam_through_the_c_abi(N, R, B, F):
-    """mrgcn_basis_mix_bwd_nodemajor_f32 writes dV as [N][B][F] for the nodes with a live column only
-    (flags in node_cur) — the same numbers as the dense [B][N][F] kernel; mrgcn_adam_step_nodemajor_f32
-    on node-major gradient / moments == mrgcn_adam_step_f32 on the dense ones, nodes that never had
-    gradient untouched, blocks of nodes without gradient this step never read."""
-    from mrgcn_amd import _lib as L
-    from mrgcn_amd.plan import GraphPlan
-    lib = L.load()
-    s = torch.cuda.current_stream().cuda_stream
-    rng = np.random.default_rng(N + B)
-    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, 1, F, 3 * N, 0)
-    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
-    plan = GraphPlan(At, N, R)
-    assert lib.mrgcn_nodemajor_supported(plan.handle, B, F) == 1
-    unode = plan.export(L.ARR_UNODE).astype(np.int64)
-    live_nodes = rng.random(N) < 0.3
-    col_live = live_nodes[unode] & (rng.random(plan.ncols) < 0.7)
-    node_has = np.zeros(N, bool); node_has[unode[col_live]] = True
-    ld = (F + 3) // 4 * 4
-    dM = rng.standard_normal((plan.ncols, ld)).astype(np.float32); dM[~col_live] = np.nan
-    V = torch.from_numpy(rng.standard_normal((B * N, F)).astype(np.float32)).cuda()
-    comp = torch.from_numpy(rng.standard_normal((R, B)).astype(np.float32)).cuda()
-    dMg = torch.from_numpy(dM).cuda()
-    clg = torch.from_numpy(col_live.astype(np.uint8)).cuda()
-    # dense reference
-    dV = torch.empty((B * N, F), device="cuda"); dc = torch.empty((R, B), device="cuda")
-    sq = torch.zeros((), dtype=torch.float64, device="cuda")
-    L.check(lib.mrgcn_basis_mix_bwd_live_f32(plan.handle, dMg.data_ptr(), ld, clg.data_ptr(), 0, V.data_ptr(),
-                                             comp.data_ptr(), B, F, dV.data_ptr(), dc.data_ptr(), sq.data_ptr(), s))
-    # node-major
-    dVn = torch.full((N, B, F), float("nan"), device="cuda"); dc2 = torch.empty((R, B), device="cuda")
-    cur = torch.full((N,), 9, dtype=torch.uint8, device="cuda")
-    sq2 = torch.zeros((), dtype=torch.float64, device="cuda")
-    L.check(lib.mrgcn_basis_mix_bwd_nodemajor_f32(plan.handle, dMg.data_ptr(), ld, clg.data_ptr(), V.data_ptr(),
-                                                  comp.data_ptr(), B, F, dVn.data_ptr(), cur.data_ptr(),
-                                                  dc2.data_ptr(), sq2.data_ptr(), s))
-    np.testing.assert_array_equal(cur.cpu().numpy(), node_has.astype(np.uint8))
-    want = dV.view(B, N, F).permute(1, 0, 2)
-    nh = torch.from_numpy(node_has).cuda()
-    assert torch.equal(dVn[nh], want[nh])
-    assert torch.isnan(dVn[~nh]).all() and not want[~nh].any()
-    dcn = dc.cpu().numpy()  # summed with float atomics: the order, hence the last bits, differ from run to run
-    np.testing.assert_allclose(dc2.cpu().numpy(), dcn, rtol=1e-4, atol=1e-5 * np.abs(dcn).max() + 1e-6)
-    np.testing.assert_allclose(float(sq2), float(sq), rtol=1e-6)
-
-    # Adam: three steps with changing `cur`
-    n = B * N * F
-    p0 = torch.randn(n, device="cuda")
-    pa, pb = p0.clone(), p0.clone()
-    ma, va = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-    mb, vb = torch.zeros((N, B, F), device="cuda"), torch.zeros((N, B, F), device="cuda")
-    coef = torch.full((), 0.5, device="cuda")
-    ever = torch.zeros(N, dtype=torch.uint8, device="cuda")
-    for step in (1, 2, 3):
-        cur_t = (torch.rand(N, device="cuda") < 0.3).to(torch.uint8)
-        ever |= cur_t
-        g = torch.randn(B, N, F, device="cuda") * cur_t.view(1, N, 1)
-        g_nm = torch.where(cur_t.bool().view(N, 1, 1), g.permute(1, 0, 2), torch.full((N, B, F), float("nan"), device="cuda")).contiguous()
-        L.check(lib.mrgcn_adam_step_f32(pa.data_ptr(), g.data_ptr(), ma.data_ptr(), va.data_ptr(), n, 0.01, 0.9, 0.999,
-                                        1e-8, 0.0, step, coef.data_ptr(), s))
-        L.check(lib.mrgcn_adam_step_nodemajor_f32(pb.data_ptr(), g_nm.data_ptr(), mb.data_ptr(), vb.data_ptr(), N, B, F,
-                                                  cur_t.data_ptr(), ever.data_ptr(), 0.01, 0.9, 0.999, 1e-8, step, 0,
-                                                  coef.data_ptr(), s))
-        assert torch.equal(pa, pb)
-        assert torch.equal(ma.view(B, N, F).permute(1, 0, 2), mb) and torch.equal(va.view(B, N, F).permute(1, 0, 2), vb)
-    never = ever == 0
-    assert torch.equal(pb.view(B, N, F)[:, never], p0.view(B, N, F)[:, never])
-
-
-def test_node_major_optimizer_space_trains_exactly_like_the_dense_path():
-    """functional._NODE_MAJOR (default): weight_I's gradient goes to ClipAdam as [N][B][F] blocks of the
-    nodes with gradient, the moments live in the same layout, weight_I.grad stays None.  Parameters,
-    losses and the optimizer's state_dict() (handed out in the reference layout) after several epochs
-    equal the dense path's — eager, captured, and when the moments were first built on the plain path."""
-    from mrgcn_amd import functional as Fn
-    from mrgcn_amd import train as T
-    N, R = 6000, 3
-    rows, cols, vals, idx, y = _sparse_label_problem(N, R)
-    tol = dict(rtol=1e-5, atol=1e-8)
-    dense = _train_rgcn(rows, cols, vals, N, R, idx, y, 5, sparse=False, bases=6)  # B*F must be a multiple of 4
-    Fn._NODEMAJOR.clear()
-    nm = _train_rgcn(rows, cols, vals, N, R, idx, y, 5, sparse=True, node_major=True, bases=6)
-    ent = next(iter(Fn._NODEMAJOR.values()))
-    ever = ent["ever"].cpu().numpy()
-    assert 0 < ever.sum() < N // 2
-    np.testing.assert_allclose(np.asarray(nm[0]), np.asarray(dense[0]), **tol)
-    for k in dense[2]:
-        np.testing.assert_allclose(nm[2][k], dense[2][k], err_msg=k, **tol)
-    sd_d, sd_n = dense[3].state_dict(), nm[3].state_dict()
-    assert sd_d["state"].keys() == sd_n["state"].keys()
-    for k in sd_d["state"]:
-        assert "node_major" not in sd_n["state"][k]
-        for key in ("exp_avg", "exp_avg_sq"):
-            assert sd_n["state"][k][key].shape == sd_d["state"][k][key].shape
-            torch.testing.assert_close(sd_n["state"][k][key], sd_d["state"][k][key], **tol)
-    Fn._NODEMAJOR.clear()
-    graphed = _train_rgcn(rows, cols, vals, N, R, idx, y, 5, sparse=True, node_major=True, graphed=True, bases=6)
-    for k in dense[2]:
-        np.testing.assert_allclose(graphed[2][k], dense[2][k], err_msg=k, **tol)
-    # the optimizer state round-trips through state_dict / load_state_dict into a new optimizer,
-    # and plain steps may follow node-major ones (and the other way round)
-    from mrgcn_amd.models.rgcn import RGCN
-    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
-    dims = [(N, 10), (10, 4)]
-    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li == 0 else None) for li, (i, o) in enumerate(dims)]
-    it, tg = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
-    finals = []
-    for schedule in ([False] * 6, [True, True, False, False, True, True]):
-        Fn._NODEMAJOR.clear()
-        torch.manual_seed(2)
-        model = RGCN(modules, R, N, 6, 0.0, True, False, False).cuda()
-        opt = T.ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
-        prev, prev_nm = T._SPARSE_WGRAD_DEFAULT, Fn._NODE_MAJOR
-        try:
-            for k, sparse in enumerate(schedule):
-                T._SPARSE_WGRAD_DEFAULT, Fn._NODE_MAJOR = sparse, True
-                T.train_step(model, lambda: model(None, A), it, tg, opt)
-                if k == 3:  # hand the state over to a fresh optimizer
-                    sd = opt.state_dict()
-                    opt = T.ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
-                    opt.load_state_dict(sd)
-        finally:
-            T._SPARSE_WGRAD_DEFAULT, Fn._NODE_MAJOR = prev, prev_nm
-        finals.append({k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
-    for k in finals[0]:
-        np.testing.assert_allclose(finals[1][k], finals[0][k], err_msg=k, **tol)
+    gen = torch.Generator("cuda").manual_seed(3)
+    for nrows, rowlen in ((1000, 400), (257, 16), (64, 1600), (5, 4), (300, 50), (7, 3)):
+        p0 = torch.randn((nrows, rowlen), device="cuda", generator=gen)
+        g = torch.randn((nrows, rowlen), device="cuda", generator=gen)
+        m0 = torch.randn((nrows, rowlen), device="cuda", generator=gen) * 0.1
+        v0 = torch.rand((nrows, rowlen), device="cuda", generator=gen) * 0.01
+        cur = (torch.rand(nrows, device="cuda", generator=gen) < 0.4).to(torch.uint8)
+        ever = ((torch.rand(nrows, device="cuda", generator=gen) < 0.5).to(torch.uint8) | 0)
+        untouched = (cur == 0) & (ever == 0)
+        m0[untouched] = 0; v0[untouched] = 0
+        gz = g.clone(); gz[cur == 0] = 0
+        coef = torch.tensor(0.7, device="cuda")
+        # dense reference on copies
+        pr, mr, vr = p0.clone(), m0.clone(), v0.clone()
+        L.check(lib.mrgcn_adam_step_f32(pr.data_ptr(), gz.data_ptr(), mr.data_ptr(), vr.data_ptr(), pr.numel(), 0.01,
+                                        0.9, 0.999, 1e-8, 0.0, 3, coef.data_ptr(), s))
+        gp = g.clone(); gp[cur == 0] = float("nan")
+        p, m, v, ev = p0.clone(), m0.clone(), v0.clone(), ever.clone()
+        L.check(lib.mrgcn_adam_step_rows_f32(p.data_ptr(), gp.data_ptr(), m.data_ptr(), v.data_ptr(), nrows, rowlen,
+                                             cur.data_ptr(), ev.data_ptr(), 0.01, 0.9, 0.999, 1e-8, 3, 0,
+                                             coef.data_ptr(), s))
+        touched = ~untouched
+        assert torch.equal(p[untouched], p0[untouched]) and torch.equal(m[untouched], m0[untouched])
+        assert torch.equal(p[touched], pr[touched]) and torch.equal(m[touched], mr[touched])
+        assert torch.equal(v[touched], vr[touched])
+        assert torch.equal(ev, ever | cur)

@@ -70,7 +70,8 @@ def _worker(rank, world, port, state, out):
     opt.set_distributed(None, model.sharded_parameters())
     logits0 = model(Xl).detach().cpu().numpy()[: part.n_local]
     losses = [float(partitioned_train_step(model, Xl, idx, y, opt)) for _ in range(2)]
-    wI = model.layers["layer_0"].weight_I.detach().cpu().view(5, part.S, -1)[:, : part.n_local]
+    # the local shard is node-major (S, B, out): back to [B][own nodes][out]
+    wI = model.layers["layer_0"].weight_I.detach().cpu().permute(1, 0, 2)[:, : part.n_local]
     out[rank] = (logits0, losses, wI.numpy(), model.layers["layer_1"].weight_F.detach().cpu().numpy())
     dist.destroy_process_group()
 

@@ -94,7 +94,8 @@ def test_minibatch_model_vs_reference(tag, engine):
         assert abs(float(loss.detach()) - float(g[tag + ".loss"])) < 1e-5
         loss.backward()
         for n, p in model.named_parameters():
-            np.testing.assert_allclose(p.grad.cpu().numpy(), g[f"{tag}.grad.{n}"], rtol=1e-3, atol=1e-5, err_msg=n)
+            np.testing.assert_allclose(util.ref_layout(p.grad, n).cpu().numpy(), g[f"{tag}.grad.{n}"], rtol=1e-3, atol=1e-5,
+                                       err_msg=n)
         if X is not None:
             np.testing.assert_allclose(X.grad.cpu().numpy(), g[tag + ".grad.X"], rtol=1e-3, atol=1e-5)
 

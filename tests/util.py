@@ -37,6 +37,15 @@ def coo_tensor(A_csr, value_mode, device="cpu"):
     return t.to(device)
 
 
+def ref_layout(t, name):
+    """A tensor in the layout of the node-major `weight_I` parameter, (N, B, out), as the reference's (B*N, out);
+    anything else (by parameter name) unchanged."""
+    if t is not None and name.endswith("weight_I") and t.dim() == 3:
+        N, B, F = t.shape
+        return t.permute(1, 0, 2).reshape(B * N, F)
+    return t
+
+
 def build_rgcn_from_case(c, device, engine="fused"):
     from mrgcn_amd.models.rgcn import RGCN
     N, R, B = int(c["meta.num_nodes"]), int(c["meta.R"]), int(c["meta.num_bases"])

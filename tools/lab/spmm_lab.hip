@@ -151,17 +151,19 @@ __global__ __launch_bounds__(256) void k_sg(int64_t rows, const int32_t *__restr
   }
 }
 
-// multi-chunk rows: lr = long row id, chunks cptr[lr]..cptr[lr+1] in order
+// multi-chunk rows: one wave per long row; lane = (chunk mod 4, feature), chunks cptr[lr]..cptr[lr+1]
 __global__ void k_sg_finalize(int n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ cptr,
                               const float *__restrict__ partials, int F, float *__restrict__ Y) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lr = t / 16, f = t % 16;
-  if (lr >= n_long || f >= F) return;
+  const int lr = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
+  const int lane = threadIdx.x & 63, f = lane & 15, k = lane >> 4;
+  if (lr >= n_long) return;
   const int c0 = cptr[lr], c1 = cptr[lr + 1];
   if (c1 - c0 <= 1) return;
   float s = 0.f;
-  for (int c = c0; c < c1; ++c) s += partials[(int64_t)c * 16 + f];
-  Y[(int64_t)long_row[lr] * F + f] = s;
+  for (int c = c0 + k; c < c1; c += 4) s += partials[(int64_t)c * 16 + f];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if (k == 0 && f < F) Y[(int64_t)long_row[lr] * F + f] = s;
 }
 
 extern "C" int lab_sg(int F, int su, int64_t rows, const int32_t *gptr, const int32_t *gidx, const float *gval,
@@ -187,7 +189,7 @@ extern "C" int lab_sg(int F, int su, int64_t rows, const int32_t *gptr, const in
   else return 1;
 #undef GO
   if (n_long > 0)
-    k_sg_finalize<<<dim3((unsigned)((n_long * 16 + 255) / 256)), dim3(256), 0, s>>>(n_long, long_row, long_cptr,
+    k_sg_finalize<<<dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, s>>>(n_long, long_row, long_cptr,
                                                                                     partials, F, Y);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
@@ -659,7 +661,7 @@ extern "C" int lab_rows_p(int T, int GB, int waves_per_cu, int chunk_waves_per_c
     else k_chunks_p<G, 4><<<dim3(cblocks), dim3(256), 0, s>>>(n_chunks, c_beg, c_end, c_row, idx, val, D, ldD, F, Y, F,
                                                               partials, total);
     if (n_long > 0)
-      k_sg_finalize<<<dim3((unsigned)((n_long * 16 + 255) / 256)), dim3(256), 0, s>>>(n_long, long_row, long_cptr,
+      k_sg_finalize<<<dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, s>>>(n_long, long_row, long_cptr,
                                                                                       partials, F, Y);
   }
   return hipGetLastError() == hipSuccess ? 0 : 2;
@@ -841,7 +843,7 @@ extern "C" int lab_v3(int64_t rows, const int32_t *ptr, const int32_t *idx, cons
                                                      c_row, partials, n_mid, mid_rows, chunk_blocks, mid_blocks,
                                                      short_blocks, xcd_per);
   if (n_long > 0 && (which & 2))
-    k_sg_finalize<<<dim3((unsigned)((n_long * 16 + 255) / 256)), dim3(256), 0, s>>>(n_long, long_row, long_cptr,
+    k_sg_finalize<<<dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, s>>>(n_long, long_row, long_cptr,
                                                                                     partials, F, Y);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }

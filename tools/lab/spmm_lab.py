@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--seg", type=int, default=1)
     ap.add_argument("--pers", type=int, default=1)
     ap.add_argument("--v3", type=int, default=1)
+    ap.add_argument("--chunk", type=int, default=128)
     ap.add_argument("--sg", type=int, default=1)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -130,7 +131,7 @@ def main():
         rowptr = torch.from_numpy(plan.export(L.ARR_ROWPTR)).to(dev)
         rp64 = rowptr.long()
         lens = rp64[1:] - rp64[:-1]
-        CH = 128
+        CH = a.chunk
         long_rows = torch.nonzero(lens > 32).flatten()
         nch = (lens[long_rows] + CH - 1) // CH
         n_long, n_chunks = len(long_rows), int(nch.sum())
@@ -151,7 +152,7 @@ def main():
         idx_modes = {"real": mcol,
                      "seq": (torch.arange(plan.nnz, device=dev) % plan.ncols).to(torch.int32),
                      "cached": (torch.arange(plan.nnz, device=dev) % 1024).to(torch.int32)}
-        for ld in (12, 16):
+        for ld in (12,):
             M = torch.zeros((plan.ncols * ld + 8,), device=dev)[:plan.ncols * ld].view(plan.ncols, ld)
             M[mpos, :F] = Mc
             Y = torch.empty((N, F), device=dev)
