@@ -276,7 +276,7 @@ def main():
             pass
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "mrgcn::k_spmm<G,VEC> (+k_spmm_finalize) on the compact view, F=%d, ld=%d" % (F, ld),
+                    "kernel": "mrgcn::k_spmm3<G,VEC> (+k_spmm3_finalize) on the compact view, F=%d, ld=%d" % (F, ld),
                     "algorithmic_bytes": bytes_alg, "avg_ms": t_c}
         extra = {}
         dY = torch.randn((plan.num_rows, F), device=dev)

@@ -39,6 +39,7 @@ constexpr int kWsFeatures = 256;   // split-row workspace is sized for this many
 constexpr int kShort3Rows = 8;
 constexpr int kMid3Rows = 32;
 constexpr int kChunk3Entries = 128;
+constexpr int kChunk3Cap = 64;  // chunks per row at most: longer rows get chunks of several pieces of 128
 constexpr int kHotMinRefs = 16;    // columns read by >= this many rows go to the dense hot region of M
 constexpr int kNodeBand = 131072;  // source nodes per band of the transform order (see plan.hip)
 constexpr int kRelChunk = 1024;    // compact columns of one relation per transform block

@@ -199,7 +199,16 @@ __global__ void k_iota(int32_t *__restrict__ a, int64_t n) {
 }
 
 // per row: is it long, and how many chunks does it need
-__global__ void k_long_count(const int32_t *__restrict__ ptr, int64_t rows, int thresh, int chunk,
+// chunk size of a row of `len` entries: `chunk`, or — with a cap on the chunks per row — the multiple of
+// `chunk` that keeps the row within `cap` chunks (k_spmm3: a wave then walks several pieces of `chunk`
+// entries, and a row never leaves more than `cap` partial sums)
+__device__ __forceinline__ int32_t row_chunk(int32_t len, int chunk, int cap) {
+  if (cap <= 0) return chunk;
+  const int32_t n = (len + chunk - 1) / chunk;
+  return n <= cap ? chunk : chunk * ((n + cap - 1) / cap);
+}
+
+__global__ void k_long_count(const int32_t *__restrict__ ptr, int64_t rows, int thresh, int chunk, int cap,
                              int32_t *__restrict__ is_long, int32_t *__restrict__ nchunk,
                              int32_t *__restrict__ maxlen) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,11 +216,12 @@ __global__ void k_long_count(const int32_t *__restrict__ ptr, int64_t rows, int 
   int32_t len = ptr[i + 1] - ptr[i];
   int32_t lg = len > thresh;
   is_long[i] = lg;
-  nchunk[i] = lg ? (len + chunk - 1) / chunk : 0;
+  const int32_t rc = row_chunk(len, chunk, cap);
+  nchunk[i] = lg ? (len + rc - 1) / rc : 0;
   atomicMax(maxlen, len);
 }
 
-__global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int chunk,
+__global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int chunk0, int cap,
                             const int32_t *__restrict__ is_long, const int32_t *__restrict__ long_pos,
                             const int32_t *__restrict__ chunk_pos, int32_t *__restrict__ long_row,
                             int32_t *__restrict__ long_cptr, int32_t *__restrict__ chunk_beg,
@@ -222,6 +232,7 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
   long_row[li] = (int32_t)i;
   long_cptr[li] = c0;
   int32_t b = ptr[i], e = ptr[i + 1];
+  const int32_t chunk = row_chunk(e - b, chunk0, cap);
   for (int32_t s = b, c = c0; s < e; s += chunk, ++c) {
     chunk_beg[c] = s;
     chunk_end[c] = min(s + chunk, e);
@@ -259,7 +270,8 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, hipStream_t s
 int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, int32_t **long_row,
                int32_t **long_cptr, int32_t **chunk_beg, int32_t **chunk_end, int32_t **chunk_row,
                int32_t *n_long,
-               int32_t *n_chunks, int64_t *max_len, int threshold = kLongThreshold, int chunk = kChunk) {
+               int32_t *n_chunks, int64_t *max_len, int threshold = kLongThreshold, int chunk = kChunk,
+               int cap = 0) {
   Scratch sc;
   int32_t *is_long, *nchunk, *long_pos, *chunk_pos, *d_max;
   MRGCN_HIP_TRY(sc.alloc(&is_long, rows + 1));
@@ -271,7 +283,7 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(hipMemsetAsync(is_long, 0, (rows + 1) * sizeof(int32_t), s));
   MRGCN_HIP_TRY(hipMemsetAsync(nchunk, 0, (rows + 1) * sizeof(int32_t), s));
   if (rows > 0)
-    k_long_count<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, threshold, chunk, is_long, nchunk, d_max);
+    k_long_count<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, threshold, chunk, cap, is_long, nchunk, d_max);
   // scan over rows+1 elements so that position [rows] holds the totals
   int rc;
   if ((rc = exclusive_scan_i32(is_long, long_pos, rows + 1, s, sc))) return rc;
@@ -291,7 +303,7 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(plan_alloc(p, chunk_row, h[1]));
   MRGCN_HIP_TRY(hipMemcpyAsync(*long_cptr + h[0], &h[1], sizeof(int32_t), hipMemcpyHostToDevice, s));
   if (rows > 0 && h[0] > 0)
-    k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, chunk, is_long, long_pos, chunk_pos,
+    k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, chunk, cap, is_long, long_pos, chunk_pos,
                                               *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row);
   MRGCN_HIP_TRY(hipGetLastError());
   MRGCN_HIP_TRY(hipStreamSynchronize(s));
@@ -601,7 +613,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     int64_t dummy = 0;
     if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r3_long_row, &p->r3_long_cptr, &p->r3_chunk_beg,
                          &p->r3_chunk_end, &p->r3_chunk_row, &p->r3_n_long, &p->r3_n_chunks, &dummy, kMid3Rows,
-                         kChunk3Entries)))
+                         kChunk3Entries, kChunk3Cap)))
       return rc;
     if ((rc = build_mid(p, p->rowptr, p->num_rows, kShort3Rows, kMid3Rows, s, &p->r_mid_rows, &p->r_n_mid))) return rc;
   }

@@ -376,29 +376,32 @@ __global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
 
-  if ((int)blockIdx.x < chunk_blocks) {  // ---- L: one wave per chunk of <= kChunk3 entries
+  if ((int)blockIdx.x < chunk_blocks) {  // ---- L: one wave per chunk: pieces of <= kChunk3 entries, one batch each
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= w.n_chunks) return;
-    const int32_t b = w.chunk_beg[c], n = w.chunk_end[c] - b;
+    const int32_t cb = w.chunk_beg[c], ce = w.chunk_end[c];
     constexpr int T = kChunk3 / kWave;
-    int32_t ci[T];
-    float ca[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {  // entry b + 64 t + lane: fully coalesced
-      const int32_t m = t * kWave + lane;
-      ci[t] = (m < n) ? v.idx[b + m] : 0;
-      ca[t] = (m < n) ? v.val[b + m] : 0.f;
-    }
     constexpr int PER = kWave / SLOTS;  // = G gather rounds per staged register
-    const int nr = __builtin_amdgcn_readfirstlane((n + SLOTS - 1) / SLOTS);
-    gather_rounds<VEC, TAIL, DT>(
-        nr, Dq, ldD, active, nvalid, acc,
-        [&](int t, int32_t &cc, float &aa) {
-          const int src = (t % PER) * SLOTS + slot;
-          cc = __shfl(ci[t / PER], src, kWave);
-          aa = __shfl(ca[t / PER], src, kWave);
-        },
-        [&](int t) { return t * SLOTS + slot < n; });
+    for (int32_t b = cb; b < ce; b += kChunk3) {  // (rows of more than 64 * kChunk3 entries: several pieces)
+      const int32_t n = min(ce - b, kChunk3);
+      int32_t ci[T];
+      float ca[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {  // entry b + 64 t + lane: fully coalesced
+        const int32_t m = t * kWave + lane;
+        ci[t] = (m < n) ? v.idx[b + m] : 0;
+        ca[t] = (m < n) ? v.val[b + m] : 0.f;
+      }
+      const int nr = __builtin_amdgcn_readfirstlane((n + SLOTS - 1) / SLOTS);
+      gather_rounds<VEC, TAIL, DT>(
+          nr, Dq, ldD, active, nvalid, acc,
+          [&](int t, int32_t &cc, float &aa) {
+            const int src = (t % PER) * SLOTS + slot;
+            cc = __shfl(ci[t / PER], src, kWave);
+            aa = __shfl(ca[t / PER], src, kWave);
+          },
+          [&](int t) { return t * SLOTS + slot < n; });
+    }
 #pragma unroll
     for (int off = G; off < kWave; off <<= 1) {
 #pragma unroll
@@ -516,16 +519,19 @@ __global__ __launch_bounds__(256) void k_spmm3_finalize(View3 w, const float *__
   if (li >= w.n_long) return;
   const int32_t c0 = w.long_cptr[li], c1 = w.long_cptr[li + 1];
   if (c1 - c0 <= 1) return;  // single-chunk rows were stored by the chunk wave
-  const int f = lane & 15, k = lane >> 4;  // F <= 16 here: four chunks per step
-  float s[2] = {0.f, 0.f};
-  int32_t c = c0 + k;
-  for (; c + 4 < c1; c += 8) {
-    s[0] += partials[(int64_t)c * ldP + f];
-    s[1] += partials[(int64_t)(c + 4) * ldP + f];
+  const int f = lane & 15, k = lane >> 4;  // F <= 16 here: four chunks per step, at most kChunk3Cap = 64 per row
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {  // all loads of a lane in flight at once
+    const int32_t c = c0 + k + 16 * u;
+    float x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = (c + 4 * i < c1) ? partials[(int64_t)(c + 4 * i) * ldP + f] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[u] += x[i];
   }
-  if (c < c1) s[0] += partials[(int64_t)c * ldP + f];
   // fixed order: (k = 0..3) joined by the butterfly
-  float t = s[0] + s[1];
+  float t = (s[0] + s[1]) + (s[2] + s[3]);
   t += __shfl_xor(t, 16, kWave);
   t += __shfl_xor(t, 32, kWave);
   if (k == 0 && f < F) {
@@ -1077,7 +1083,9 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     const bool use_tiny = tiny_on && w <= 64 && v.rows > 0 && (plan->nnz < 3 * v.rows);
     const int64_t operand_rows = view == MRGCN_VIEW_LITERAL ? plan->num_relations * plan->num_nodes
                                  : view == MRGCN_VIEW_COMPACT ? plan->ncols : plan->num_rows;
-    const bool operand_cached = operand_rows * ldD * 4 <= (int64_t)200 << 20;
+    // (the compact operand is read front to back by the rows that own its single-use columns: a 16-byte load
+    // that straddles two lines there fetches lines its neighbours need anyway)
+    const bool operand_cached = operand_rows * ldD * 4 <= (int64_t)200 << 20 || view == MRGCN_VIEW_COMPACT;
     // the row orientation (LITERAL / COMPACT views) of a narrow layer takes k_spmm3
     const View3 w3 = view3_of(plan);
     int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu,
