@@ -69,9 +69,13 @@ enum mrgcn_plan_array {
   MRGCN_ARR_RPERM = 12,   /* [ncols]       compact ids sorted by (node band, relation, node) */
   MRGCN_ARR_RELPTR = 13,  /* [bands*R+1]   range of each (band, relation) group inside RPERM */
   MRGCN_ARR_MPOS = 14,    /* [ncols]       row of the compact operand M that holds column c */
-  MRGCN_ARR_MCOL = 15,    /* [nnz]         operand row per entry of the COMPACT view; a row's
-                                           entries are sorted by it                    */
-  MRGCN_ARR_MVAL = 16     /* [nnz] float   values in MCOL's entry order                */
+  MRGCN_ARR_MCOL = 15,    /* [nnz]         operand row per entry of the COMPACT view, whose rows are walked
+                                           CLASS-MAJOR (ranks, see ROWMAP / PTR3); a row's entries in
+                                           rising operand row                                      */
+  MRGCN_ARR_MVAL = 16,    /* [nnz] float   values in MCOL's entry order                */
+  MRGCN_ARR_ROWMAP = 17,  /* [num_rows]    COMPACT view: rank -> output row.  Ranks = rows sorted by class
+                                           (<= 8 entries, <= 32, more), row order inside a class      */
+  MRGCN_ARR_PTR3 = 18     /* [num_rows+1]  COMPACT view: entry range of each rank inside MCOL / MVAL  */
 };
 
 typedef struct mrgcn_plan mrgcn_plan_t;

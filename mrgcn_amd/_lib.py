@@ -22,7 +22,8 @@ VAL_I8, VAL_F32 = 0, 1
 PLAN_PRUNE_ZEROS = 1
 VIEW_LITERAL, VIEW_COMPACT, VIEW_TRANSPOSED = 0, 1, 2
 (ARR_ROWPTR, ARR_LCOL, ARR_CCOL, ARR_VAL, ARR_CPTR, ARR_CROW, ARR_CVAL, ARR_UREL, ARR_UNODE,
- ARR_NPTR, ARR_ROWIDX, ARR_ULCOL, ARR_RPERM, ARR_RELPTR, ARR_MPOS, ARR_MCOL, ARR_MVAL) = range(17)
+ ARR_NPTR, ARR_ROWIDX, ARR_ULCOL, ARR_RPERM, ARR_RELPTR, ARR_MPOS, ARR_MCOL, ARR_MVAL, ARR_ROWMAP,
+ ARR_PTR3) = range(19)
 FLOAT_ARRAYS = (ARR_VAL, ARR_CVAL, ARR_MVAL)
 
 

@@ -135,10 +135,17 @@ struct mrgcn_plan {
   int32_t *c_long_row = nullptr, *c_long_cptr = nullptr, *c_chunk_beg = nullptr, *c_chunk_end = nullptr,
           *c_chunk_row = nullptr;
   int32_t r_n_long = 0, r_n_chunks = 0, c_n_long = 0, c_n_chunks = 0;
-  // row orientation in k_spmm3's classes (threshold kMid3Rows, chunks of kChunk3Entries) + the list of mid rows
+  // COMPACT view: rows in class-major processing order (rank k = row rowmap[k]; ranks [0, n_short3) have
+  // <= kShort3Rows entries, the next n_mid3 <= kMid3Rows, the rest more), ptr3 = row pointer over ranks into
+  // mcol / mval; split-row descriptors over ranks for k_spmm (q_*) and k_spmm3 (r3_*)
+  int32_t *rowmap = nullptr, *ptr3 = nullptr;
+  int32_t n_short3 = 0, n_mid3 = 0;
+  int32_t *q_long_row = nullptr, *q_long_cptr = nullptr, *q_chunk_beg = nullptr, *q_chunk_end = nullptr,
+          *q_chunk_row = nullptr;
+  int32_t q_n_long = 0, q_n_chunks = 0;
   int32_t *r3_long_row = nullptr, *r3_long_cptr = nullptr, *r3_chunk_beg = nullptr, *r3_chunk_end = nullptr,
-          *r3_chunk_row = nullptr, *r_mid_rows = nullptr;
-  int32_t r3_n_long = 0, r3_n_chunks = 0, r_n_mid = 0;
+          *r3_chunk_row = nullptr;
+  int32_t r3_n_long = 0, r3_n_chunks = 0;
   float *partials = nullptr;  // [max(r_n_chunks, c_n_chunks) * kWsFeatures]
 
   mrgcn::SparseView view(int which) const {
@@ -148,10 +155,13 @@ struct mrgcn_plan {
       v.n_long = c_n_long; v.n_chunks = c_n_chunks; v.long_row = c_long_row;
       v.long_cptr = c_long_cptr; v.chunk_beg = c_chunk_beg; v.chunk_end = c_chunk_end;
       v.chunk_row = c_chunk_row; v.n_multi = c_n_chunks - c_n_long;
+    } else if (which == MRGCN_VIEW_COMPACT) {  // rows = ranks (class-major); results go to row rowmap[rank]
+      v.rows = num_rows; v.ptr = ptr3; v.idx = mcol; v.val = mval;
+      v.n_long = q_n_long; v.n_chunks = q_n_chunks; v.long_row = q_long_row;
+      v.long_cptr = q_long_cptr; v.chunk_beg = q_chunk_beg; v.chunk_end = q_chunk_end;
+      v.chunk_row = q_chunk_row; v.n_multi = q_n_chunks - q_n_long;
     } else {
-      v.rows = num_rows; v.ptr = rowptr;
-      v.idx = (which == MRGCN_VIEW_LITERAL) ? lcol : mcol;
-      v.val = (which == MRGCN_VIEW_LITERAL) ? val : mval;
+      v.rows = num_rows; v.ptr = rowptr; v.idx = lcol; v.val = val;
       v.n_long = r_n_long; v.n_chunks = r_n_chunks; v.long_row = r_long_row;
       v.long_cptr = r_long_cptr; v.chunk_beg = r_chunk_beg; v.chunk_end = r_chunk_end;
       v.chunk_row = r_chunk_row; v.n_multi = r_n_chunks - r_n_long;

@@ -141,11 +141,12 @@ __global__ void k_node_ptr(const int32_t *__restrict__ keys, int64_t count, int6
 }
 
 // storage order of the compact operand M (see common.hpp: mpos): hot columns (>= hot_min
-// entries) first, most referenced first; then every other column in the order of the FIRST
-// output row that reads it.  key = [hot: max_count - count | rest: max_count + 1 + row][compact id]
+// entries) first, most referenced first; then every other column in the order in which the FIRST
+// output row that reads it is processed (class-major rank, k_class_keys).
+// key = [hot: max_count - count | rest: max_count + 1 + rank(row)][compact id]
 __global__ void k_mpos_keys(const int32_t *__restrict__ cptr, const int32_t *__restrict__ crow,
-                            int64_t ncols, int64_t max_count, int shift, int hot_min,
-                            int64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+                            const int32_t *__restrict__ rank, int64_t ncols, int64_t max_count, int shift,
+                            int hot_min, int64_t *__restrict__ keys, int32_t *__restrict__ ids) {
   int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncols) return;
   const int32_t b = cptr[c], e = cptr[c + 1];
@@ -153,15 +154,36 @@ __global__ void k_mpos_keys(const int32_t *__restrict__ cptr, const int32_t *__r
   int64_t hi;
   if (hot_min < 0) hi = 0;                                   // experiment: plain compact (node, relation) order
   else if (cnt >= hot_min) hi = max_count - cnt;            // in [0, max_count)
-  else hi = max_count + 1 + (int64_t)crow[b];               // after every hot column
+  else hi = max_count + 1 + (int64_t)rank[crow[b]];         // after every hot column, in processing order
   keys[c] = (hi << shift) | c;
   ids[c] = (int32_t)c;
 }
 
-__global__ void k_row_pos_keys(const int32_t *__restrict__ rowidx, const int32_t *__restrict__ pos,
-                               int64_t nnz, int64_t ncols, int64_t *__restrict__ keys) {
+__global__ void k_row_pos_keys(const int32_t *__restrict__ rowidx, const int32_t *__restrict__ rank,
+                               const int32_t *__restrict__ pos, int64_t nnz, int64_t ncols,
+                               int64_t *__restrict__ keys) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < nnz) keys[e] = (int64_t)rowidx[e] * ncols + pos[e];
+  if (e < nnz) keys[e] = (int64_t)rank[rowidx[e]] * ncols + pos[e];
+}
+
+// The COMPACT view processes the rows CLASS-MAJOR: first every row of <= kShort3Rows entries, then those
+// of <= kMid3Rows, then the long ones, each class in row order.  Rows of different classes are served by
+// different waves (k_spmm3), so with this order no two classes share a line of the index / value arrays or
+// of the operand's first-touch region.  key = class * rows + row; sorting gives rank -> row.
+__global__ void k_class_keys(const int32_t *__restrict__ ptr, int64_t rows, int s_max, int m_max,
+                             int64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const int32_t n = ptr[i + 1] - ptr[i];
+  const int64_t cls = n <= s_max ? 0 : (n <= m_max ? 1 : 2);
+  keys[i] = cls * rows + i;
+  ids[i] = (int32_t)i;
+}
+__global__ void k_rank_len(const int32_t *__restrict__ ptr, const int32_t *__restrict__ rowmap, int64_t rows,
+                           int32_t *__restrict__ len) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < rows) len[k] = ptr[rowmap[k] + 1] - ptr[rowmap[k]];
+  if (k == rows) len[k] = 0;
 }
 
 __global__ void k_keys_to_pos(const int64_t *__restrict__ keys, int64_t nnz, int64_t ncols,
@@ -305,40 +327,6 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   if (rows > 0 && h[0] > 0)
     k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, chunk, cap, is_long, long_pos, chunk_pos,
                                               *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row);
-  MRGCN_HIP_TRY(hipGetLastError());
-  MRGCN_HIP_TRY(hipStreamSynchronize(s));
-  return MRGCN_OK;
-}
-
-// rows whose length lies in (lo, hi]: flag, scan, compact (k_spmm3's four-rows-per-wave class)
-__global__ void k_len_flag(const int32_t *__restrict__ ptr, int64_t rows, int lo, int hi, int32_t *__restrict__ flag) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
-  const int32_t n = ptr[i + 1] - ptr[i];
-  flag[i] = (n > lo && n <= hi) ? 1 : 0;
-}
-__global__ void k_flag_compact(const int32_t *__restrict__ flag, const int32_t *__restrict__ pos, int64_t rows,
-                               int32_t *__restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < rows && flag[i]) out[pos[i]] = (int32_t)i;
-}
-
-int build_mid(mrgcn_plan *p, const int32_t *ptr, int64_t rows, int lo, int hi, hipStream_t s, int32_t **mid_rows,
-              int32_t *n_mid) {
-  Scratch sc;
-  int32_t *flag, *pos;
-  MRGCN_HIP_TRY(sc.alloc(&flag, rows + 1));
-  MRGCN_HIP_TRY(sc.alloc(&pos, rows + 1));
-  MRGCN_HIP_TRY(hipMemsetAsync(flag, 0, (rows + 1) * sizeof(int32_t), s));
-  if (rows > 0) k_len_flag<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, lo, hi, flag);
-  int rc;
-  if ((rc = exclusive_scan_i32(flag, pos, rows + 1, s, sc))) return rc;
-  int32_t h = 0;
-  MRGCN_HIP_TRY(hipMemcpyAsync(&h, pos + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MRGCN_HIP_TRY(hipStreamSynchronize(s));
-  *n_mid = h;
-  MRGCN_HIP_TRY(plan_alloc(p, mid_rows, h));
-  if (rows > 0 && h > 0) k_flag_compact<<<nblocks(rows), kTB, 0, s>>>(flag, pos, rows, *mid_rows);
   MRGCN_HIP_TRY(hipGetLastError());
   MRGCN_HIP_TRY(hipStreamSynchronize(s));
   return MRGCN_OK;
@@ -543,6 +531,43 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   if ((rc = build_long(p, p->cptr, p->ncols, s, &p->c_long_row, &p->c_long_cptr, &p->c_chunk_beg,
                        &p->c_chunk_end, &p->c_chunk_row, &p->c_n_long, &p->c_n_chunks, &p->max_col_nnz)))
     return rc;
+  // class-major processing order of the rows (COMPACT view)
+  MRGCN_HIP_TRY(plan_alloc(p, &p->rowmap, p->num_rows));
+  MRGCN_HIP_TRY(plan_alloc(p, &p->ptr3, p->num_rows + 1));
+  int32_t *rank3 = nullptr;
+  MRGCN_HIP_TRY(sc.alloc(&rank3, p->num_rows));
+  {
+    const int64_t rows = p->num_rows;
+    int64_t *ck, *ck_s;
+    int32_t *ids, *len3, *cls_ptr;
+    MRGCN_HIP_TRY(sc.alloc(&ck, rows));
+    MRGCN_HIP_TRY(sc.alloc(&ck_s, rows));
+    MRGCN_HIP_TRY(sc.alloc(&ids, rows));
+    MRGCN_HIP_TRY(sc.alloc(&len3, rows + 1));
+    MRGCN_HIP_TRY(sc.alloc(&cls_ptr, 4));
+    if (rows > 0) {
+      k_class_keys<<<nblocks(rows), kTB, 0, s>>>(p->rowptr, rows, kShort3Rows, kMid3Rows, ck, ids);
+      MRGCN_HIP_TRY(hipGetLastError());
+      size_t tb = 0;
+      const int eb = bits_for(3 * rows + rows);
+      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ck, ck_s, ids, p->rowmap, (int)rows, 0, eb, s));
+      char *tmp;
+      MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
+      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, ck, ck_s, ids, p->rowmap, (int)rows, 0, eb, s));
+      k_invert_perm<<<nblocks(rows), kTB, 0, s>>>(p->rowmap, rows, rank3);
+      MRGCN_HIP_TRY(hipGetLastError());
+    }
+    k_lower_bound_ptr<<<1, kTB, 0, s>>>(ck_s, rows, 3, rows, cls_ptr);  // first rank of each class
+    k_rank_len<<<nblocks(rows + 1), kTB, 0, s>>>(p->rowptr, p->rowmap, rows, len3);
+    MRGCN_HIP_TRY(hipGetLastError());
+    int rc2;
+    if ((rc2 = exclusive_scan_i32(len3, p->ptr3, rows + 1, s, sc))) return rc2;
+    int32_t h[4] = {0, 0, 0, 0};
+    MRGCN_HIP_TRY(hipMemcpyAsync(h, cls_ptr, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MRGCN_HIP_TRY(hipStreamSynchronize(s));
+    p->n_short3 = h[1];
+    p->n_mid3 = h[2] - h[1];
+  }
   // storage order of M
   MRGCN_HIP_TRY(plan_alloc(p, &p->mpos, ncols));
   MRGCN_HIP_TRY(plan_alloc(p, &p->mcol, nnz));
@@ -558,7 +583,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     const int64_t max_count = p->max_col_nnz + 1;
     int hot_min = kHotMinRefs;
     if (const char *e = getenv("MRGCN_HOT_MIN")) hot_min = (atoi(e) > 1 || atoi(e) < 0) ? atoi(e) : hot_min;  // experiments
-    k_mpos_keys<<<nblocks(ncols), kTB, 0, s>>>(p->cptr, p->crow, ncols, max_count, shift, hot_min, mk, ids);
+    k_mpos_keys<<<nblocks(ncols), kTB, 0, s>>>(p->cptr, p->crow, rank3, ncols, max_count, shift, hot_min, mk, ids);
     MRGCN_HIP_TRY(hipGetLastError());
     const int end_bit = shift + bits_for(max_count + 1 + p->num_rows);
     MRGCN_REQUIRE(end_bit <= 62, "graph too large for the operand-order key");
@@ -571,8 +596,9 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
                                                      end_bit, s));
     k_invert_perm<<<nblocks(ncols), kTB, 0, s>>>(order, ncols, p->mpos);
     MRGCN_HIP_TRY(hipGetLastError());
-    // the COMPACT view walks a row's entries in rising operand position (its private, single-use
-    // operand rows are then one sequential run): own index + value arrays in that order
+    // the COMPACT view walks the rows in class-major order (ptr3 / rowmap) and a row's entries in rising
+    // operand position (its private, single-use operand rows are then one sequential run): own index +
+    // value arrays in that order
     int32_t *mcol_u;
     int64_t *rk, *rk_s;
     MRGCN_HIP_TRY(sc.alloc(&mcol_u, nnz));
@@ -580,7 +606,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     MRGCN_HIP_TRY(sc.alloc(&rk_s, nnz));
     k_gather_i32<<<nblocks(nnz), kTB, 0, s>>>(p->mpos, p->ccol, nnz, mcol_u);
     MRGCN_HIP_TRY(hipGetLastError());
-    k_row_pos_keys<<<nblocks(nnz), kTB, 0, s>>>(p->rowidx, mcol_u, nnz, ncols, rk);
+    k_row_pos_keys<<<nblocks(nnz), kTB, 0, s>>>(p->rowidx, rank3, mcol_u, nnz, ncols, rk);
     MRGCN_HIP_TRY(hipGetLastError());
     {
       const int eb = bits_for(p->num_rows * ncols + ncols);
@@ -608,16 +634,19 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r_long_row, &p->r_long_cptr, &p->r_chunk_beg,
                        &p->r_chunk_end, &p->r_chunk_row, &p->r_n_long, &p->r_n_chunks, &p->max_row_nnz)))
     return rc;
-  // the same rows once more in k_spmm3's classes: <= 8 entries implicit, 9..32 as a list, > 32 in chunks of 128
+  // the COMPACT view's own split-row descriptors, over ranks: for k_spmm (chunks of kChunk) and for k_spmm3
+  // (rows beyond kMid3Rows in chunks of kChunk3Entries, at most kChunk3Cap per row).  Descriptor "rows" are ranks.
   {
     int64_t dummy = 0;
-    if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r3_long_row, &p->r3_long_cptr, &p->r3_chunk_beg,
+    if ((rc = build_long(p, p->ptr3, p->num_rows, s, &p->q_long_row, &p->q_long_cptr, &p->q_chunk_beg,
+                         &p->q_chunk_end, &p->q_chunk_row, &p->q_n_long, &p->q_n_chunks, &dummy)))
+      return rc;
+    if ((rc = build_long(p, p->ptr3, p->num_rows, s, &p->r3_long_row, &p->r3_long_cptr, &p->r3_chunk_beg,
                          &p->r3_chunk_end, &p->r3_chunk_row, &p->r3_n_long, &p->r3_n_chunks, &dummy, kMid3Rows,
                          kChunk3Entries, kChunk3Cap)))
       return rc;
-    if ((rc = build_mid(p, p->rowptr, p->num_rows, kShort3Rows, kMid3Rows, s, &p->r_mid_rows, &p->r_n_mid))) return rc;
   }
-  int64_t ws = (int64_t)std::max(p->r_n_chunks, p->c_n_chunks) * kWsFeatures;
+  int64_t ws = (int64_t)std::max(std::max(p->r_n_chunks, p->q_n_chunks), p->c_n_chunks) * kWsFeatures;
   ws = std::max<int64_t>(ws, (int64_t)p->r3_n_chunks * 16);
   MRGCN_HIP_TRY(plan_alloc(p, &p->partials, ws));
   return MRGCN_OK;
@@ -628,7 +657,8 @@ void free_plan(mrgcn_plan *p) {
                   p->nptr, p->ulcol, p->mpos, p->mcol, p->mval, p->rperm, p->relptr, p->rnode, p->rmpos, p->relchunk_ptr, p->relchunk_ids, p->relchunk_rel, p->relchunk_beg, p->relchunk_end,
                   p->cval, p->r_long_row, p->r_long_cptr, p->r_chunk_beg, p->r_chunk_end,
                   p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->r_chunk_row, p->c_chunk_row,
-                  p->r3_long_row, p->r3_long_cptr, p->r3_chunk_beg, p->r3_chunk_end, p->r3_chunk_row, p->r_mid_rows,
+                  p->r3_long_row, p->r3_long_cptr, p->r3_chunk_beg, p->r3_chunk_end, p->r3_chunk_row,
+                  p->q_long_row, p->q_long_cptr, p->q_chunk_beg, p->q_chunk_end, p->q_chunk_row, p->rowmap, p->ptr3,
                   p->partials};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
@@ -744,6 +774,8 @@ static int plan_lookup(const mrgcn_plan_t *p, int32_t which, const void **out, i
     case MRGCN_ARR_MPOS: src = p->mpos; n = p->ncols; break;
     case MRGCN_ARR_MCOL: src = p->mcol; n = p->nnz; break;
     case MRGCN_ARR_MVAL: src = p->mval; n = p->nnz; break;
+    case MRGCN_ARR_ROWMAP: src = p->rowmap; n = p->num_rows; break;
+    case MRGCN_ARR_PTR3: src = p->ptr3; n = p->num_rows + 1; break;
     default: MRGCN_REQUIRE(false, "unknown plan array");
   }
   *out = src;

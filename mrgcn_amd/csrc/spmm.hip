@@ -351,18 +351,18 @@ __device__ __forceinline__ void gather_rounds(int nr, const DT *__restrict__ Dq,
   }
 }
 
-struct View3 {  // the descriptors of the row orientation that k_spmm3 adds to SparseView
-  int32_t n_mid = 0, n_chunks = 0, n_long = 0, n_multi = 0;
-  const int32_t *mid_rows = nullptr;                                         // [n_mid] rows of 9..32 entries
-  const int32_t *chunk_beg = nullptr, *chunk_end = nullptr, *chunk_row = nullptr;  // [n_chunks], as SparseView's
-  const int32_t *long_row = nullptr, *long_cptr = nullptr;                   // [n_long], [n_long + 1]
+struct View3 {  // what k_spmm3 needs beyond the COMPACT SparseView (whose rows are class-major ranks)
+  int32_t n_short = 0, n_mid = 0;      // ranks [0, n_short): S rows, the next n_mid: M rows, the rest: L rows
+  int32_t n_chunks = 0, n_long = 0, n_multi = 0;
+  const int32_t *rowmap = nullptr;     // [rows] rank -> output row
+  const int32_t *chunk_beg = nullptr, *chunk_end = nullptr, *chunk_row = nullptr;  // [n_chunks], rows = ranks
+  const int32_t *long_row = nullptr, *long_cptr = nullptr;                   // [n_long] ranks, [n_long + 1]
 };
 
 template <int G, int VEC, bool TAIL, typename DT>
 __global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *__restrict__ D, int64_t ldD,
                                                int F, float *__restrict__ Y, int64_t ldY,
-                                               const float *__restrict__ bias, int relu,
-                                               const int32_t *__restrict__ out_index, int store_vec_ok,
+                                               const float *__restrict__ bias, int relu, int store_vec_ok,
                                                float *__restrict__ partials, int ldP, int chunk_blocks,
                                                int mid_blocks, int64_t short_blocks, int64_t xcd_per) {
   constexpr int SLOTS = kWave / G;
@@ -408,9 +408,9 @@ __global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *
       for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
     }
     if (slot == 0 && active) {
-      const int32_t row = w.chunk_row[c];
-      if (row >= 0) {  // the whole row was this chunk: finished
-        const int64_t orow = out_index ? (int64_t)out_index[row] : (int64_t)row;
+      const int32_t rk = w.chunk_row[c];
+      if (rk >= 0) {  // the whole row was this chunk: finished
+        const int64_t orow = w.rowmap[rk];
         store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
       } else {
         float *p = partials + (int64_t)c * ldP + f0;
@@ -428,9 +428,10 @@ __global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *
     const int mi = wv * 4 + rsel;
     int32_t b = 0, n = 0, row = -1;
     if (mi < w.n_mid) {
-      row = w.mid_rows[mi];
-      b = v.ptr[row];
-      n = v.ptr[row + 1] - b;
+      const int32_t rk = w.n_short + mi;
+      row = w.rowmap[rk];
+      b = v.ptr[rk];
+      n = v.ptr[rk + 1] - b;
     }
     if (!__any(row >= 0)) return;
     constexpr int T = kMid3 / 16;
@@ -460,27 +461,25 @@ __global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
     }
-    if (ss == 0 && row >= 0 && active) {
-      const int64_t orow = out_index ? (int64_t)out_index[row] : (int64_t)row;
-      store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
-    }
+    if (ss == 0 && row >= 0 && active) store_row<VEC>(Y + (int64_t)row * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
     return;
   }
-  // ---- S: 64/G consecutive rows per wave; rows of more than kShort3 entries are someone else's
-  // blocks b and b+8 share an XCD (round-robin dispatch): every XCD gets one contiguous run of rows
+  // ---- S: 64/G consecutive ranks per wave, all of them rows of <= kShort3 entries
+  // blocks b and b+8 share an XCD (round-robin dispatch): every XCD gets one contiguous run of ranks
   int64_t sb = (int64_t)blockIdx.x - chunk_blocks - mid_blocks;
   if (xcd_per > 0) {
     sb = (sb & 7) * xcd_per + (sb >> 3);
     if (sb >= short_blocks) return;
   }
-  const int64_t row = (sb * 4 + (threadIdx.x >> 6)) * SLOTS + slot;
+  const int64_t rk = (sb * 4 + (threadIdx.x >> 6)) * SLOTS + slot;
   int32_t b = 0, n = 0;
-  if (row < v.rows) {
-    b = v.ptr[row];
-    n = v.ptr[row + 1] - b;
+  int64_t row = 0;
+  const bool mine = rk < w.n_short;
+  if (mine) {
+    b = v.ptr[rk];
+    n = v.ptr[rk + 1] - b;
+    row = w.rowmap[rk];
   }
-  const bool mine = row < v.rows && n <= kShort3;
-  if (!mine) n = 0;
   if (!__any(mine)) return;  // wave uniform
   constexpr int T = (kShort3 + G - 1) / G;
   int32_t ci[T];
@@ -503,17 +502,13 @@ __global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *
         aa = __shfl(ca[t / G], sbase + (t % G), kWave);
       },
       [&](int t) { return t < n; });
-  if (mine && active) {
-    const int64_t orow = out_index ? (int64_t)out_index[row] : row;
-    store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
-  }
+  if (mine && active) store_row<VEC>(Y + row * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
 }
 
 // rows of several chunks: one wave per long row; lane = (chunk mod 64/FP, feature), eight partials in flight
 __global__ __launch_bounds__(256) void k_spmm3_finalize(View3 w, const float *__restrict__ partials, int ldP, int F,
                                                         float *__restrict__ Y, int64_t ldY,
-                                                        const float *__restrict__ bias, int relu,
-                                                        const int32_t *__restrict__ out_index) {
+                                                        const float *__restrict__ bias, int relu) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t li = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   if (li >= w.n_long) return;
@@ -535,8 +530,7 @@ __global__ __launch_bounds__(256) void k_spmm3_finalize(View3 w, const float *__
   t += __shfl_xor(t, 16, kWave);
   t += __shfl_xor(t, 32, kWave);
   if (k == 0 && f < F) {
-    int64_t row = w.long_row[li];
-    if (out_index) row = out_index[row];
+    const int64_t row = w.rowmap[w.long_row[li]];
     if (bias) t += bias[f];
     if (relu) t = fmaxf(t, 0.f);
     Y[row * ldY + f] = t;
@@ -814,19 +808,21 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
   const bool store_vec_ok = (ldY % SV == 0) && (((uintptr_t)Y) % (SV * 4) == 0);
   if constexpr (G <= 4 && VEC == 4) {
     static const bool v3_on = !(getenv("MRGCN_SPMM_V3") && atoi(getenv("MRGCN_SPMM_V3")) == 0);
-    if (w3 && v3_on && v.rows > 0) {  // one gather batch per wave (k_spmm3)
-      const int64_t short_waves = (v.rows + SLOTS - 1) / SLOTS;
+    if (w3 && v3_on && v.rows > 0) {  // one gather batch per wave (k_spmm3); rows = class-major ranks
+      const int64_t short_waves = ((int64_t)w3->n_short + SLOTS - 1) / SLOTS;
       const int64_t short_blocks = (short_waves + 3) / 4;
       const int chunk_blocks = (w3->n_chunks + 3) / 4;
       const int mid_blocks = ((w3->n_mid + 3) / 4 + 3) / 4;
       const int64_t xcd_per = (short_blocks + 7) / 8;
-      k_spmm3<G, VEC, TAIL, DT><<<dim3((unsigned)(xcd_per * 8 + chunk_blocks + mid_blocks)), dim3(256), 0, s>>>(
-          v, *w3, D, ldD, F, Y, ldY, bias, relu, out_index, store_vec_ok ? 1 : 0, partials, 16, chunk_blocks,
-          mid_blocks, short_blocks, xcd_per);
-      MRGCN_HIP_TRY(hipGetLastError());
+      if (xcd_per * 8 + chunk_blocks + mid_blocks > 0) {
+        k_spmm3<G, VEC, TAIL, DT><<<dim3((unsigned)(xcd_per * 8 + chunk_blocks + mid_blocks)), dim3(256), 0, s>>>(
+            v, *w3, D, ldD, F, Y, ldY, bias, relu, store_vec_ok ? 1 : 0, partials, 16, chunk_blocks, mid_blocks,
+            short_blocks, xcd_per);
+        MRGCN_HIP_TRY(hipGetLastError());
+      }
       if (w3->n_multi > 0) {
         k_spmm3_finalize<<<dim3((unsigned)((w3->n_long + 3) / 4)), dim3(256), 0, s>>>(*w3, partials, 16, F, Y, ldY,
-                                                                                      bias, relu, out_index);
+                                                                                      bias, relu);
         MRGCN_HIP_TRY(hipGetLastError());
       }
       return MRGCN_OK;
@@ -956,7 +952,7 @@ int dispatch_bf16(const SparseView &v, const uint16_t *D, int64_t ldD, int64_t a
 
 View3 view3_of(const mrgcn_plan *p) {
   View3 w;
-  w.n_mid = p->r_n_mid; w.mid_rows = p->r_mid_rows;
+  w.n_short = p->n_short3; w.n_mid = p->n_mid3; w.rowmap = p->rowmap;
   w.n_chunks = p->r3_n_chunks; w.n_long = p->r3_n_long; w.n_multi = p->r3_n_chunks - p->r3_n_long;
   w.chunk_beg = p->r3_chunk_beg; w.chunk_end = p->r3_chunk_end; w.chunk_row = p->r3_chunk_row;
   w.long_row = p->r3_long_row; w.long_cptr = p->r3_long_cptr;
@@ -999,7 +995,7 @@ extern "C" int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const fl
     k_rows_live_mark<<<dim3((unsigned)((plan->num_rows + 255) / 256)), dim3(256), 0, s>>>(
         D, ldD, F, plan->num_rows, plan->rowptr, plan->ccol, row_live, col_live, live_rows);
     MRGCN_HIP_TRY(hipGetLastError());
-    SparseView rv = plan->view(MRGCN_VIEW_COMPACT);
+    SparseView rv = plan->view(MRGCN_VIEW_LITERAL);  // row-major entry coordinates, as `ccol`
     if (rv.n_chunks > 0) {
       const int64_t waves = rv.n_chunks;
       k_long_rows_mark<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s>>>(rv, plan->ccol, row_live, col_live);
@@ -1045,6 +1041,10 @@ extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uin
   MRGCN_REQUIRE(F > 0 && ldD >= F && ldY >= F, "F / leading dimensions");
   MRGCN_REQUIRE(D && Y, "NULL operand");
   SparseView v = plan->view(view);
+  if (view == MRGCN_VIEW_COMPACT) {  // its rows are class-major ranks: results go to row rowmap[rank]
+    MRGCN_REQUIRE(out_index == nullptr, "out_index is not available on the COMPACT view");
+    out_index = plan->rowmap;
+  }
   int tile = 64;
   if (ldD % 8 == 0 && ((uintptr_t)D) % 16 == 0) tile = 256;  // kWsFeatures floats of partials per chunk
   else if (ldD % 4 == 0 && ((uintptr_t)D) % 8 == 0) tile = 256;
@@ -1053,8 +1053,7 @@ extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uin
     const int w = (F - f < tile) ? (F - f) : tile;
     const View3 w3 = view3_of(plan);
     int rc = dispatch_bf16(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu, out_index,
-                           plan->partials, (hipStream_t)stream,
-                           (view != MRGCN_VIEW_TRANSPOSED && F <= 32) ? &w3 : nullptr);
+                           plan->partials, (hipStream_t)stream, (view == MRGCN_VIEW_COMPACT && F <= 16) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;
@@ -1069,6 +1068,10 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
   MRGCN_REQUIRE(F > 0 && ldD >= F && ldY >= F, "F / leading dimensions");
   MRGCN_REQUIRE(D && Y, "NULL operand");
   SparseView v = plan->view(view);
+  if (view == MRGCN_VIEW_COMPACT) {  // its rows are class-major ranks: results go to row rowmap[rank]
+    MRGCN_REQUIRE(out_index == nullptr, "out_index is not available on the COMPACT view");
+    out_index = plan->rowmap;
+  }
   hipStream_t s = (hipStream_t)stream;
   // feature tiles: one pass covers up to 64 lanes x VEC floats; the split-row workspace
   // holds kWsFeatures floats per chunk
@@ -1086,11 +1089,11 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     // (the compact operand is read front to back by the rows that own its single-use columns: a 16-byte load
     // that straddles two lines there fetches lines its neighbours need anyway)
     const bool operand_cached = operand_rows * ldD * 4 <= (int64_t)200 << 20 || view == MRGCN_VIEW_COMPACT;
-    // the row orientation (LITERAL / COMPACT views) of a narrow layer takes k_spmm3
+    // the COMPACT view of a narrow layer takes k_spmm3
     const View3 w3 = view3_of(plan);
     int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu,
                       out_index, plan->partials, use_tiny, operand_cached, s,
-                      (view != MRGCN_VIEW_TRANSPOSED && F <= 16) ? &w3 : nullptr);
+                      (view == MRGCN_VIEW_COMPACT && F <= 16) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;

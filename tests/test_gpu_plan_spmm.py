@@ -10,7 +10,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 ARRAYS = ["rowptr", "lcol", "ccol", "val", "cptr", "crow", "cval", "urel", "unode", "nptr",
-          "rowidx", "ulcol", "rperm", "relptr", "mpos", "mcol", "mval"]
+          "rowidx", "ulcol", "rperm", "relptr", "mpos", "mcol", "mval", "rowmap", "ptr3"]
 
 
 def _plan_from_coo(rows, cols, vals, num_rows, N, R, prune=False):

@@ -106,11 +106,18 @@ def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False):
     k3 = ((unode.astype(np.int64) // band) * R + urel) * band + unode.astype(np.int64) % band
     rperm = np.argsort(k3, kind="stable").astype(np.int32)
     relptr = np.searchsorted(k3[rperm], np.arange(nbands * R + 1, dtype=np.int64) * band).astype(np.int32)
+    # COMPACT view: rows in class-major order (<= 8 entries, <= 32, more; row order inside a class)
+    lens = np.diff(rowptr.astype(np.int64))
+    cls = np.where(lens <= 8, 0, np.where(lens <= 32, 1, 2))
+    rowmap = np.lexsort((np.arange(num_rows), cls)).astype(np.int32)
+    rank = np.empty(num_rows, dtype=np.int64)
+    rank[rowmap] = np.arange(num_rows)
+    ptr3 = np.concatenate([[0], np.cumsum(lens[rowmap])]).astype(np.int32)
     # storage order of the compact operand: hot columns (>= HOT_MIN_REFS entries) by falling count,
-    # then every other column by the first row that reads it
+    # then every other column by the rank of the first row that reads it
     cnt = np.diff(cptr).astype(np.int64)
     if ncols:
-        firstrow = crow[cptr[:-1]].astype(np.int64)
+        firstrow = rank[crow[cptr[:-1]].astype(np.int64)]
         max_count = int(cnt.max()) + 1
         hi = np.where(cnt >= HOT_MIN_REFS, max_count - cnt, max_count + 1 + firstrow)
         order = np.lexsort((np.arange(ncols), hi))
@@ -118,12 +125,12 @@ def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False):
         mpos[order] = np.arange(ncols, dtype=np.int32)
     else:
         mpos = np.zeros(0, dtype=np.int32)
-    if len(key):  # COMPACT view: entries of a row in rising operand position
+    if len(key):  # COMPACT view: ranks in order, entries of a row in rising operand position
         mc = mpos[ccol].astype(np.int64)
-        o3 = np.argsort(rowidx.astype(np.int64) * max(ncols, 1) + mc, kind="stable")
+        o3 = np.argsort(rank[rowidx.astype(np.int64)] * max(ncols, 1) + mc, kind="stable")
         mcol, mval = mc[o3].astype(np.int32), v[o3]
     else:
         mcol, mval = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32)
     return dict(rowptr=rowptr, lcol=lcol, ccol=ccol, val=v, rowidx=rowidx, cptr=cptr, crow=crow,
                 cval=cval, urel=urel, unode=unode, ulcol=ulcol, nptr=nptr, rperm=rperm,
-                relptr=relptr, mpos=mpos, mcol=mcol, mval=mval, ncols=ncols, nnz=len(key))
+                relptr=relptr, mpos=mpos, mcol=mcol, mval=mval, rowmap=rowmap, ptr3=ptr3, ncols=ncols, nnz=len(key))
