@@ -43,6 +43,10 @@ enum mrgcn_val_dtype { MRGCN_VAL_I8 = 0, MRGCN_VAL_F32 = 1 };
 /* plan flags */
 #define MRGCN_PLAN_PRUNE_ZEROS 1u /* drop entries whose value is exactly 0 (legal: they
                                      contribute nothing) */
+#define MRGCN_PLAN_REPLICATE 2u   /* compact operand with REPLICAS: every entry of a column read by fewer than
+                                     16 rows gets an operand row of its own, placed where its reader streams
+                                     (see mrgcn_operand_replicate); hot columns keep one shared row */
+#define MRGCN_PLAN_NO_REPLICATE 4u /* never replicate, whatever the default (env MRGCN_REPLICATE) says */
 
 /* which sparse view of the plan a product runs on */
 enum mrgcn_view {
@@ -91,6 +95,8 @@ typedef struct mrgcn_plan_info {
   int64_t long_rows;     /* rows handled by the split-row path           */
   int64_t long_cols;
   int64_t device_bytes;  /* bytes of device memory the plan owns         */
+  int64_t operand_rows;  /* rows of the compact operand M: ncols, or more with MRGCN_PLAN_REPLICATE */
+  int64_t replicas;      /* operand rows that are copies (mrgcn_operand_replicate fills them)       */
 } mrgcn_plan_info_t;
 
 /* ---- library ---------------------------------------------------------------- */

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmrgcn_hip.so")
 # enums of include/mrgcn_hip.h
 OK = 0
 VAL_I8, VAL_F32 = 0, 1
-PLAN_PRUNE_ZEROS = 1
+PLAN_PRUNE_ZEROS, PLAN_REPLICATE, PLAN_NO_REPLICATE = 1, 2, 4
 VIEW_LITERAL, VIEW_COMPACT, VIEW_TRANSPOSED = 0, 1, 2
 (ARR_ROWPTR, ARR_LCOL, ARR_CCOL, ARR_VAL, ARR_CPTR, ARR_CROW, ARR_CVAL, ARR_UREL, ARR_UNODE,
  ARR_NPTR, ARR_ROWIDX, ARR_ULCOL, ARR_RPERM, ARR_RELPTR, ARR_MPOS, ARR_MCOL, ARR_MVAL, ARR_ROWMAP,
@@ -34,7 +34,7 @@ class MrgcnError(RuntimeError):
 class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "num_rows", "num_nodes", "num_relations", "nnz", "ncols", "max_row_nnz", "max_col_nnz",
-        "long_rows", "long_cols", "device_bytes")]
+        "long_rows", "long_cols", "device_bytes", "operand_rows", "replicas")]
 
 
 _p = C.c_void_p
@@ -52,6 +52,7 @@ SIGNATURES = {
     "mrgcn_plan_export": (C.c_int, [_p, _i32, _p, _i64]),
     "mrgcn_plan_array": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_i64)]),
     "mrgcn_spmm_f32": (C.c_int, [_p, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _p, _p]),
+    "mrgcn_operand_replicate": (C.c_int, [_p, _p, _i64, _p]),
     "mrgcn_basis_mix_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p]),
     "mrgcn_gather_rows_f32": (C.c_int, [_p, _p, _i32, _p, _i64, _p, _i64, _p]),
     "mrgcn_rel_transform_fwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]),

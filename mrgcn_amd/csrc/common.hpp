@@ -115,6 +115,10 @@ struct mrgcn_plan {
   // the order of the FIRST output row that reads it, so that a row's first-touch operand rows
   // are one contiguous run and the forward gather streams them instead of fetching one 128-B
   // line per 40-B row (only the 2nd..kth reads of a lukewarm column stay random).
+  // With replicas (MRGCN_PLAN_REPLICATE): M has n_op = n_hot + (entries of non-hot columns) rows; a non-hot
+  // column's primary row mpos[c] is the row of its first reader, rep_src / rep_dst list the copies.
+  int64_t n_op = 0, n_rep = 0;
+  int32_t *rep_src = nullptr, *rep_dst = nullptr;  // [n_rep] operand rows
   int32_t *mpos = nullptr;  // [ncols] compact id -> row of M
   int32_t *mcol = nullptr;  // [nnz]   operand row of each entry, entries of a row sorted by it
   float *mval = nullptr;    // [nnz]   values in the same order (the COMPACT view's arrays)

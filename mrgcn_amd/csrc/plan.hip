@@ -166,6 +166,52 @@ __global__ void k_row_pos_keys(const int32_t *__restrict__ rowidx, const int32_t
   if (e < nnz) keys[e] = (int64_t)rank[rowidx[e]] * ncols + pos[e];
 }
 
+// ---- operand replicas ------------------------------------------------------------------------------------
+// entries in class-major order carry the operand row of their column (`m`); with replicas every entry of a
+// non-hot column (m >= n_hot) gets the next row of the stream instead
+__global__ void k_is_stream(const int32_t *__restrict__ m, int64_t nnz, int32_t n_hot, int32_t *__restrict__ flag) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nnz) flag[e] = m[e] >= n_hot ? 1 : 0;
+  if (e == nnz) flag[e] = 0;
+}
+__global__ void k_rep_assign(int32_t *__restrict__ m, const int32_t *__restrict__ spos, int64_t nnz, int32_t n_hot,
+                             const int32_t *__restrict__ col_of_mpos, int32_t *__restrict__ ecol,
+                             int32_t *__restrict__ mpos_new) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz) return;
+  const int32_t old = m[e];
+  const int32_t c = col_of_mpos[old];
+  ecol[e] = c;
+  if (old >= n_hot) {
+    const int32_t row = n_hot + spos[e];
+    m[e] = row;
+    atomicMin(&mpos_new[c], row);  // primary = the reader that is processed first
+  } else {
+    mpos_new[c] = old;  // hot: one shared row (every entry writes the same value)
+  }
+}
+__global__ void k_rep_flag(const int32_t *__restrict__ m, const int32_t *__restrict__ ecol,
+                           const int32_t *__restrict__ mpos_new, int64_t nnz, int32_t n_hot,
+                           int32_t *__restrict__ flag) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nnz) flag[e] = (m[e] >= n_hot && m[e] != mpos_new[ecol[e]]) ? 1 : 0;
+  if (e == nnz) flag[e] = 0;
+}
+__global__ void k_rep_fill(const int32_t *__restrict__ m, const int32_t *__restrict__ ecol,
+                           const int32_t *__restrict__ mpos_new, const int32_t *__restrict__ flag,
+                           const int32_t *__restrict__ pos, int64_t nnz, int32_t *__restrict__ src,
+                           int32_t *__restrict__ dst) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nnz && flag[e]) {
+    src[pos[e]] = mpos_new[ecol[e]];
+    dst[pos[e]] = m[e];
+  }
+}
+__global__ void k_fill_i32(int32_t *__restrict__ a, int64_t n, int32_t v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
 // The COMPACT view processes the rows CLASS-MAJOR: first every row of <= kShort3Rows entries, then those
 // of <= kMid3Rows, then the long ones, each class in row order.  Rows of different classes are served by
 // different waves (k_spmm3), so with this order no two classes share a line of the index / value arrays or
@@ -341,6 +387,8 @@ int bits_for(int64_t max_value) {
 int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_t *cols,
                 const void *vals, int val_dtype, uint32_t flags, hipStream_t s) {
   const int64_t N = p->num_nodes, R = p->num_relations, RN = R * N;
+  static const bool rep_default = getenv("MRGCN_REPLICATE") && atoi(getenv("MRGCN_REPLICATE")) != 0;
+  const bool replicate = !(flags & MRGCN_PLAN_NO_REPLICATE) && ((flags & MRGCN_PLAN_REPLICATE) || rep_default);
   Scratch sc;
   int64_t *keys, *keys_s, *key2, *key2_s;
   float *fv;
@@ -621,6 +669,44 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     k_keys_to_pos<<<nblocks(nnz), kTB, 0, s>>>(rk_s, nnz, ncols, p->mcol);
     MRGCN_HIP_TRY(hipGetLastError());
     MRGCN_HIP_TRY(hipStreamSynchronize(s));
+    p->n_op = ncols;
+    if (replicate && hot_min > 1) {
+      // every entry of a non-hot column gets its own operand row, in processing order
+      int32_t *n_hot_d, *flag, *spos, *ecol, *mpos_new, *rflag, *rpos;
+      MRGCN_HIP_TRY(sc.alloc(&n_hot_d, 2));
+      MRGCN_HIP_TRY(sc.alloc(&flag, nnz + 1));
+      MRGCN_HIP_TRY(sc.alloc(&spos, nnz + 1));
+      MRGCN_HIP_TRY(sc.alloc(&ecol, nnz));
+      MRGCN_HIP_TRY(sc.alloc(&mpos_new, ncols));
+      MRGCN_HIP_TRY(sc.alloc(&rflag, nnz + 1));
+      MRGCN_HIP_TRY(sc.alloc(&rpos, nnz + 1));
+      // hot columns are the sorted keys below max_count << shift
+      k_lower_bound_ptr<<<1, kTB, 0, s>>>(mk_s, ncols, 1, max_count << shift, n_hot_d);
+      int32_t h2[2] = {0, 0};
+      MRGCN_HIP_TRY(hipMemcpyAsync(h2, n_hot_d, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      MRGCN_HIP_TRY(hipStreamSynchronize(s));
+      const int32_t n_hot = h2[1];
+      k_is_stream<<<nblocks(nnz + 1), kTB, 0, s>>>(p->mcol, nnz, n_hot, flag);
+      int rc2;
+      if ((rc2 = exclusive_scan_i32(flag, spos, nnz + 1, s, sc))) return rc2;
+      k_fill_i32<<<nblocks(ncols), kTB, 0, s>>>(mpos_new, ncols, INT32_MAX);
+      k_rep_assign<<<nblocks(nnz), kTB, 0, s>>>(p->mcol, spos, nnz, n_hot, order, ecol, mpos_new);
+      k_rep_flag<<<nblocks(nnz + 1), kTB, 0, s>>>(p->mcol, ecol, mpos_new, nnz, n_hot, rflag);
+      MRGCN_HIP_TRY(hipGetLastError());
+      if ((rc2 = exclusive_scan_i32(rflag, rpos, nnz + 1, s, sc))) return rc2;
+      int32_t h3[2] = {0, 0};
+      MRGCN_HIP_TRY(hipMemcpyAsync(&h3[0], spos + nnz, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      MRGCN_HIP_TRY(hipMemcpyAsync(&h3[1], rpos + nnz, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      MRGCN_HIP_TRY(hipStreamSynchronize(s));
+      p->n_op = (int64_t)n_hot + h3[0];
+      p->n_rep = h3[1];
+      MRGCN_HIP_TRY(plan_alloc(p, &p->rep_src, p->n_rep));
+      MRGCN_HIP_TRY(plan_alloc(p, &p->rep_dst, p->n_rep));
+      k_rep_fill<<<nblocks(nnz), kTB, 0, s>>>(p->mcol, ecol, mpos_new, rflag, rpos, nnz, p->rep_src, p->rep_dst);
+      MRGCN_HIP_TRY(hipMemcpyAsync(p->mpos, mpos_new, ncols * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+      MRGCN_HIP_TRY(hipGetLastError());
+      MRGCN_HIP_TRY(hipStreamSynchronize(s));
+    }
   }
   // relation-major copies of the per-column indices (no dependent index chain in the transforms)
   MRGCN_HIP_TRY(plan_alloc(p, &p->rnode, ncols));
@@ -659,7 +745,7 @@ void free_plan(mrgcn_plan *p) {
                   p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->r_chunk_row, p->c_chunk_row,
                   p->r3_long_row, p->r3_long_cptr, p->r3_chunk_beg, p->r3_chunk_end, p->r3_chunk_row,
                   p->q_long_row, p->q_long_cptr, p->q_chunk_beg, p->q_chunk_end, p->q_chunk_row, p->rowmap, p->ptr3,
-                  p->partials};
+                  p->rep_src, p->rep_dst, p->partials};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
@@ -750,6 +836,8 @@ int mrgcn_plan_info(const mrgcn_plan_t *p, mrgcn_plan_info_t *h) {
   h->long_rows = p->r_n_long;
   h->long_cols = p->c_n_long;
   h->device_bytes = p->device_bytes;
+  h->operand_rows = p->n_op;
+  h->replicas = p->n_rep;
   return MRGCN_OK;
 }
 

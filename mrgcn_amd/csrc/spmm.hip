@@ -962,6 +962,44 @@ View3 view3_of(const mrgcn_plan *p) {
 }  // namespace
 }  // namespace mrgcn
 
+namespace mrgcn {
+namespace {
+// replicas of the compact operand: row rep_dst[k] = row rep_src[k], rows of `w4` 4-byte words; a group of
+// lanes per replica so that a row moves with one load and one store instruction
+__global__ void k_replicate(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, int64_t n_rep,
+                            uint32_t *__restrict__ M, int w4, int lanes) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t k = t / lanes;
+  const int q = (int)(t - k * lanes);
+  if (k >= n_rep) return;
+  const uint32_t *a = M + (int64_t)src[k] * w4;
+  uint32_t *b = M + (int64_t)dst[k] * w4;
+  if ((w4 & 3) == 0 && (((uintptr_t)M) & 15) == 0) {
+    for (int i = q; i * 4 < w4; i += lanes)
+      reinterpret_cast<uint4 *>(b)[i] = reinterpret_cast<const uint4 *>(a)[i];
+  } else {
+    for (int i = q; i < w4; i += lanes) b[i] = a[i];
+  }
+}
+}  // namespace
+}  // namespace mrgcn
+
+extern "C" int mrgcn_operand_replicate(const mrgcn_plan_t *plan, void *M, int64_t row_bytes, void *stream) {
+  using namespace mrgcn;
+  MRGCN_REQUIRE(plan && M, "NULL");
+  MRGCN_REQUIRE(row_bytes > 0 && row_bytes % 4 == 0, "row_bytes must be a multiple of 4");
+  if (plan->n_rep == 0) return MRGCN_OK;
+  const int w4 = (int)(row_bytes / 4);
+  int lanes = ((w4 & 3) == 0) ? w4 / 4 : w4;  // one 16-byte (or 4-byte) piece per lane
+  int lp = 1;
+  while (lp < lanes && lp < 16) lp <<= 1;
+  const int64_t threads = plan->n_rep * lp;
+  k_replicate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      plan->rep_src, plan->rep_dst, plan->n_rep, (uint32_t *)M, w4, lp);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
 // flags[i] = 1 when X[i, 0:F] holds anything but zeros (optim.hip)
 extern "C" int mrgcn_rows_nonzero_f32(const float *X, int64_t ld, int32_t F, int64_t nrows, uint8_t *flags,
                                       void *stream);
@@ -1085,7 +1123,7 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     static const bool tiny_on = getenv("MRGCN_SPMM_TINY") && atoi(getenv("MRGCN_SPMM_TINY")) != 0;
     const bool use_tiny = tiny_on && w <= 64 && v.rows > 0 && (plan->nnz < 3 * v.rows);
     const int64_t operand_rows = view == MRGCN_VIEW_LITERAL ? plan->num_relations * plan->num_nodes
-                                 : view == MRGCN_VIEW_COMPACT ? plan->ncols : plan->num_rows;
+                                 : view == MRGCN_VIEW_COMPACT ? plan->n_op : plan->num_rows;
     // (the compact operand is read front to back by the rows that own its single-use columns: a 16-byte load
     // that straddles two lines there fetches lines its neighbours need anyway)
     const bool operand_cached = operand_rows * ldD * 4 <= (int64_t)200 << 20 || view == MRGCN_VIEW_COMPACT;

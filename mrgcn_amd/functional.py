@@ -195,7 +195,7 @@ class _RgcnLayer(torch.autograd.Function):
         # bf16: only the compact operand M is stored in bf16 (one rounding at its store); inputs,
         # every accumulation, Y and the whole backward stay fp32
         ld = _ld_for_bf16(F) if bf16 else _ld_for(F)
-        M = torch.empty((plan.ncols, ld), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+        M = torch.empty((plan.nop, ld), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
         sfx = "bf16" if bf16 else "f32"
         xform_fwd = getattr(lib, "mrgcn_rel_transform_fwd_" + sfx)
         mix_fwd = getattr(lib, "mrgcn_basis_mix_fwd_" + sfx)
@@ -228,6 +228,7 @@ class _RgcnLayer(torch.autograd.Function):
                 else:
                     L.check(gather_rows(plan.handle, wI.data_ptr(), F, addend, ldA, M.data_ptr(), ld, s),
                             "mrgcn_gather_rows_" + sfx)
+        plan.replicate(M)  # (plans with operand replicas only)
         Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu)
         ctx.plan, ctx.F, ctx.ld, ctx.relu, ctx.owner = plan, F, ld, relu, owner
         ctx.has = (weight_I is not None, comp_I is not None, X is not None, bias is not None)

@@ -16,9 +16,19 @@ def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def _flags(prune_zeros, replicate) -> int:
+    """replicate: None = the library's default (env MRGCN_REPLICATE), True / False = force."""
+    f = L.PLAN_PRUNE_ZEROS if prune_zeros else 0
+    if replicate is True:
+        f |= L.PLAN_REPLICATE
+    elif replicate is False:
+        f |= L.PLAN_NO_REPLICATE
+    return f
+
+
 class GraphPlan:
     def __init__(self, A: torch.Tensor, num_nodes: int, num_relations: int,
-                 prune_zeros: bool = False):
+                 prune_zeros: bool = False, replicate=None):
         if not A.is_sparse:
             raise TypeError("A must be a torch sparse COO tensor")
         if not A.is_cuda:
@@ -48,7 +58,7 @@ class GraphPlan:
             L.check(lib.mrgcn_plan_create(
                 C.byref(handle), self.num_rows, self.num_nodes, self.num_relations,
                 int(val.numel()), rows.data_ptr(), cols.data_ptr(), val.data_ptr(), vd,
-                L.PLAN_PRUNE_ZEROS if prune_zeros else 0, _stream_ptr(self.device)),
+                _flags(prune_zeros, replicate), _stream_ptr(self.device)),
                 "mrgcn_plan_create")
         self._adopt(handle)
 
@@ -61,11 +71,13 @@ class GraphPlan:
         self.max_row_nnz, self.max_col_nnz = int(info.max_row_nnz), int(info.max_col_nnz)
         self.long_rows, self.long_cols = int(info.long_rows), int(info.long_cols)
         self.device_bytes = int(info.device_bytes)
+        # rows of the compact operand M (= ncols unless the plan keeps replicas) and how many are copies
+        self.nop, self.n_rep = int(info.operand_rows), int(info.replicas)
         self._ptr_cache = {}
 
     @classmethod
     def from_csr(cls, A_csr, num_nodes: int, num_relations: int, value_mode: str = "ref_int8",
-                 device="cuda", prune_zeros: bool = False) -> "GraphPlan":
+                 device="cuda", prune_zeros: bool = False, replicate=None) -> "GraphPlan":
         """Plan straight from a scipy CSR (what the dataset archive holds, tarball.py:151-157): the
         three arrays are uploaded as they are and expanded on the device — no host `.nonzero()`, no
         int64 COO.  `value_mode="ref_int8"` applies the reference's boundary cast (batch.py:144-149)."""
@@ -86,7 +98,7 @@ class GraphPlan:
             L.check(lib.mrgcn_plan_create_csr(
                 C.byref(handle), self.num_rows, self.num_nodes, self.num_relations, int(data.numel()),
                 indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), 1 if value_mode == "ref_int8" else 0,
-                L.PLAN_PRUNE_ZEROS if prune_zeros else 0, _stream_ptr(self.device)), "mrgcn_plan_create_csr")
+                _flags(prune_zeros, replicate), _stream_ptr(self.device)), "mrgcn_plan_create_csr")
         self._adopt(handle)
         return self
 
@@ -157,6 +169,16 @@ class GraphPlan:
                        bias.data_ptr() if bias is not None else 0, 1 if relu else 0, out_index,
                        _stream_ptr(D.device)), "mrgcn_spmm_bf16" if bf16 else "mrgcn_spmm_f32")
         return out
+
+    def replicate(self, M: torch.Tensor) -> torch.Tensor:
+        """Fills the replica rows of a compact operand whose primary rows (MPOS) are written
+        (mrgcn_operand_replicate); a no-op on a plan without replicas."""
+        if self.n_rep:
+            assert M.is_cuda and M.is_contiguous() and M.shape[0] == self.nop
+            with torch.cuda.device(M.device):
+                L.check(L.load().mrgcn_operand_replicate(self.handle, M.data_ptr(), M.stride(0) * M.element_size(),
+                                                         _stream_ptr(M.device)), "mrgcn_operand_replicate")
+        return M
 
     def ulcol_long(self) -> torch.Tensor:
         """int64 device tensor: literal column r*N + j of every compact column."""

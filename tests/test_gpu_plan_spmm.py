@@ -267,3 +267,62 @@ def test_transform_backward_over_live_columns(skewed, K, F, need_dX, live_frac):
         np.testing.assert_allclose(dX1, dX0, rtol=1e-5, atol=1e-5 * (np.abs(dX0).max() + 1e-30))
     if live_frac == 0.0:
         assert not dW1.any() and (not need_dX or not dX1.any())
+
+
+@pytest.mark.parametrize("F,ld", [(10, 12), (11, 12), (16, 16), (3, 4)])
+def test_compact_product_on_an_operand_with_replicas(F, ld):
+    """MRGCN_PLAN_REPLICATE: every entry of a column read by fewer than 16 rows owns an operand row in its reader's
+    stream; the producers write a column once (MPOS), mrgcn_operand_replicate fills the copies, and the product
+    equals the plain one.  Entries of non-hot columns reference consecutive operand rows in processing order."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphPlan
+    rng = np.random.default_rng(F)
+    N, R = 3000, 5
+    rows, cols, vals = _random_graph(rng, N, N, R, 12 * N, hub_rows=3, hub_len=2500, hub_cols=4)
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    base, plan = GraphPlan(A, N, R, replicate=False), GraphPlan(A, N, R, replicate=True)
+    assert base.n_rep == 0 and base.nop == base.ncols
+    cnt = np.diff(plan.export(L.ARR_CPTR))
+    n_hot = int((cnt >= util.HOT_MIN_REFS).sum())
+    assert plan.nop == n_hot + int(cnt[cnt < util.HOT_MIN_REFS].sum())
+    assert plan.n_rep == int((cnt[cnt < util.HOT_MIN_REFS] - 1).sum())
+    mcol, mpos = plan.export(L.ARR_MCOL), plan.export(L.ARR_MPOS)
+    stream = mcol[mcol >= n_hot]
+    assert np.array_equal(stream, n_hot + np.arange(len(stream)))          # read front to back
+    assert np.array_equal(np.sort(mpos[cnt >= util.HOT_MIN_REFS]), np.arange(n_hot))
+    Mc = rng.standard_normal((plan.ncols, F)).astype(np.float32)
+    M = torch.full((plan.nop, ld), float("nan"), device="cuda")
+    M[torch.from_numpy(mpos.astype(np.int64)).cuda(), :F] = torch.from_numpy(Mc).cuda()
+    plan.replicate(M)
+    assert not torch.isnan(M[:, :F]).any()                                # every operand row was produced
+    Y = plan.spmm(L.VIEW_COMPACT, M, F=F).cpu().numpy()
+    Mb = torch.zeros((base.ncols, ld), device="cuda")
+    Mb[torch.from_numpy(base.export(L.ARR_MPOS).astype(np.int64)).cuda(), :F] = torch.from_numpy(Mc).cuda()
+    Yb = base.spmm(L.VIEW_COMPACT, Mb, F=F).cpu().numpy()
+    A_csr = sp.csr_matrix((vals.astype(np.float64), (rows, cols)), shape=(N, R * N))
+    ref = A_csr[:, plan.export(L.ARR_ULCOL).astype(np.int64)] @ Mc.astype(np.float64)
+    np.testing.assert_allclose(Y, ref, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(Y, Yb, rtol=1e-5, atol=1e-5)
+
+
+def test_model_on_a_plan_with_replicas_matches_the_golden():
+    """A whole golden epoch on a plan built with operand replicas (layers pick the plan up from the adjacency)."""
+    from mrgcn_amd.plan import GraphPlan
+    from mrgcn_amd.train import ClipAdam, train_step
+    name = "rgcn_smoke_ft_b5_norm_f32"
+    c = util.load_case(name)
+    model, dims = util.build_rgcn_from_case(c, "cuda")
+    util.load_state_from_case(model, c)
+    model = model.cuda()
+    g, A_csr = util.load_graph(util.graph_of_case(name))
+    A = util.coo_tensor(A_csr, str(c["value_mode"]), "cuda")
+    A._mrgcn_plan = GraphPlan(A, int(c["meta.num_nodes"]), int(c["meta.R"]), replicate=True)
+    assert A._mrgcn_plan.n_rep > 0
+    X = torch.from_numpy(c["X"]).cuda()
+    with torch.no_grad():
+        np.testing.assert_allclose(model(X, A).cpu().numpy(), c["logits"], rtol=1e-4, atol=1e-4)
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    idx, tgt = torch.from_numpy(c["labels_idx"]).cuda(), torch.from_numpy(c["labels_y"]).cuda()
+    for step in range(1, int(c["meta.n_adam"]) + 1):
+        loss = train_step(model, lambda: model(X, A), idx, tgt, opt)
+        np.testing.assert_allclose(float(loss), float(c[f"loss_step{step}"]), rtol=2e-4, atol=2e-5)

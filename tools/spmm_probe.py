@@ -28,23 +28,27 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--prune", action="store_true")
     ap.add_argument("--value-mode", default="norm_f32")
+    ap.add_argument("--replicate", type=int, default=-1, help="1 / 0: operand replicas on / off (default: library)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     g = synth.make_graph(a.workload, seed=0, scale=a.scale, value_mode=a.value_mode)
     N, R = g.num_nodes, g.num_relations
     A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
                                 (N, R * N)).to(dev)
-    plan = GraphPlan(A, N, R, prune_zeros=a.prune)
+    plan = GraphPlan(A, N, R, prune_zeros=a.prune, replicate=None if a.replicate < 0 else bool(a.replicate))
     stream = torch.cuda.current_stream(dev).cuda_stream
     F = a.F
     alg = plan.spmm_bytes(F)
-    print(f"N={N} R={R} nnz={plan.nnz} ncols={plan.ncols} long_rows={plan.long_rows} "
+    print(f"N={N} R={R} nnz={plan.nnz} ncols={plan.ncols} operand_rows={plan.nop} replicas={plan.n_rep} long_rows={plan.long_rows} "
           f"long_cols={plan.long_cols} alg_bytes={alg}")
     for ld in a.ld:
         if a.view == "compact":
-            D = torch.randn((plan.ncols * ld + 8,), device=dev)[:plan.ncols * ld].view(plan.ncols, ld)
+            D = torch.randn((plan.nop * ld + 8,), device=dev)[:plan.nop * ld].view(plan.nop, ld)
             Y = torch.empty((N, F), device=dev)
             fn = lambda: plan.spmm(L.VIEW_COMPACT, D, F=F, out=Y)  # noqa: E731
+            if plan.n_rep:
+                ms_r = event_time_ms(lambda: plan.replicate(D), a.iters, stream)
+                print(f"replicate ld={ld}: {ms_r*1e3:.1f} us for {plan.n_rep} rows")
         elif a.view == "literal":
             D = torch.randn((R * N, ld), device=dev)
             Y = torch.empty((N, F), device=dev)
