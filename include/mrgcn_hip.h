@@ -150,6 +150,14 @@ int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uint16_t *D, i
                     int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu,
                     const int32_t *out_index, void *stream);
 
+/* Fills the replicas of a compact operand built on a plan with MRGCN_PLAN_REPLICATE: the producers below
+ * write each compact column once (row MPOS[c]); this call copies the row of every column read by 2..15
+ * output rows to the operand rows of its other readers, so that the forward product reads M front to back
+ * instead of fetching one 128-byte line per re-read 40-byte row.  `row_bytes` = leading dimension in bytes
+ * (multiple of 4).  A no-op on a plan without replicas.  (AM shape: product 202 -> 189 us, the copies 79 us:
+ * not the default.) */
+int mrgcn_operand_replicate(const mrgcn_plan_t *plan, void *M, int64_t row_bytes, void *stream);
+
 /* ---- compact dense operand: forward -----------------------------------------------
  * M is [ncols, ldM] row-major with one row per touched column c = (node j_c, relation
  * r_c); column c lives at row MPOS[c] (hot columns first, then single-use columns in the
@@ -329,6 +337,35 @@ int mrgcn_adam_step_dev_f32(float *param, const float *grad, float *exp_avg, flo
                             int64_t n, float lr, float beta1, float beta2, float eps,
                             float weight_decay, const float *bc_dev, const float *grad_scale,
                             void *stream);
+
+/* ---- modality encoders: the dense step in front of the graph path ----------------------
+ * Fused literal MLP + gate + masked scatter (mrgcn/models/perceptron.py:6-46 with p_dropout = 0 or in eval
+ * mode; mrgcn/models/mrgcn.py:285-303):
+ *     XF[rows[i], offset : offset + dims[L]] = gate[0] * MLP(X[i, 0:dims[0]]),   MLP = L x (Linear -> ReLU)
+ * dims: HOST array of L + 1 widths (1..16); W / b: HOST arrays of L DEVICE pointers, W[l] is
+ * [dims[l+1]][dims[l]] (nn.Linear layout), b[l] nullable; rows: nullable int64 [n] (NULL = row i).
+ * The backward ACCUMULATES into dW[l] / db[l] / dgate (caller zeroes them). */
+int32_t mrgcn_mlp_fused_supported(int32_t L, const int32_t *dims);
+int mrgcn_mlp_gate_scatter_fwd_f32(int32_t L, const int32_t *dims, const float *const *W, const float *const *b,
+                                   const float *X, int64_t ldx, int64_t n, const float *gate,
+                                   const int64_t *rows, float *XF, int64_t ldxf, int32_t offset, void *stream);
+int mrgcn_mlp_gate_scatter_bwd_f32(int32_t L, const int32_t *dims, const float *const *W, const float *const *b,
+                                   const float *X, int64_t ldx, int64_t n, const float *gate,
+                                   const int64_t *rows, const float *dXF, int64_t ldxf, int32_t offset,
+                                   float *const *dW, float *const *db, float *dgate, void *stream);
+/* Dense product on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32), the building block of the
+ * `pre_fc -> ReLU -> fc` heads (mrgcn/models/imagecnn.py:31-41, transformer.py:29-38) and of the TCNN
+ * (temporal_cnn.py:6-156):   C = epilogue(alpha * op(A) . op(B)),  epilogue: + bias[N], ReLU, * (mask > 0).
+ *   amode 0: A[m*lda + k]   1: A[k*lda + m]   2: Conv1d im2col of x[b][ci][t] (m = b*Tout + t, k = ci*KW + kw)
+ *         3: the transpose of mode 2 (m = ci*KW + kw, k = b*Tout + t)
+ *   bmode 0: B[k*ldb + n]   1: B[n*ldb + k]   2: y[b][n][t] read as [k = b*Tout + t][n]
+ *   cmode 0: C[m*ldc + n]   2: y[b][n][t], m = b*Tout + t
+ *   conv_geom (HOST, modes 2 / 3): {Cin, Tin, KW, pad, Tout, Cout}.  mask: nullable, addressed like C. */
+int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32_t N, int32_t K, const float *A,
+                   int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias,
+                   int32_t relu, const float *mask, float alpha, const int32_t *conv_geom, void *stream);
+/* out[n] = sum_m X[m*ld + n]  (bias gradients) */
+int mrgcn_colsum_f32(const float *X, int64_t ld, int32_t M, int32_t N, float *out, void *stream);
 
 /* ---- timing helpers (HIP events on the caller's stream; used by bench.py) ------ */
 int mrgcn_event_create(void **event);

@@ -86,6 +86,13 @@ SIGNATURES = {
     "mrgcn_adam_bias_f32": (C.c_int, [_p, C.c_float, C.c_float, _p, _p]),
     "mrgcn_adam_step_dev_f32": (C.c_int, [_p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_float, C.c_float,
                                           C.c_float, _p, _p, _p]),
+    "mrgcn_mlp_fused_supported": (C.c_int32, [_i32, _p]),
+    "mrgcn_mlp_gate_scatter_fwd_f32": (C.c_int, [_i32, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i32, _p]),
+    "mrgcn_mlp_gate_scatter_bwd_f32": (C.c_int, [_i32, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i32, _p, _p, _p,
+                                                 _p]),
+    "mrgcn_gemm_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i32, _p,
+                                 C.c_float, _p, _p]),
+    "mrgcn_colsum_f32": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "mrgcn_event_create": (C.c_int, [C.POINTER(_p)]),
     "mrgcn_event_destroy": (C.c_int, [_p]),
     "mrgcn_event_record": (C.c_int, [_p, _p]),

@@ -1,0 +1,432 @@
+// Modality encoders that feed X — the dense work in front of the graph path.
+//
+//   k_mlp_gate_scatter_fwd / _bwd   the literal MLPs (mrgcn/models/perceptron.py:6-46: Linear -> ReLU blocks,
+//       1 layer for numeric / boolean, 2 for the temporal datatypes, widths <= 16) FUSED with the gate multiply
+//       and the masked scatter into the feature matrix (mrgcn/models/mrgcn.py:285-303):
+//           XF[rows[i], off : off + d_out] = gate * MLP(enc[i, :])
+//       one thread per literal, all weights in LDS; the backward recomputes the activations and reduces
+//       dW = G^T A per block as a 16 x 16 product out of LDS (no per-lane atomics).
+//   k_gemm_f32   C = act(alpha * op(A) . op(B) + bias) on the matrix cores (v_mfma_f32_16x16x4_f32: exact
+//       fp32 products and sums, so the 1e-4 parity bar holds) with the epilogues the heads need: bias, ReLU,
+//       ReLU mask of a saved activation.  The `pre_fc -> ReLU -> fc` heads of the string / image encoders
+//       (mrgcn/models/imagecnn.py:31-41, transformer.py:29-38) and the TCNN's fully connected tail
+//       (temporal_cnn.py:147-153) run forward and backward on it, and so does the TCNN's Conv1d in implicit
+//       im2col form (A-loader modes below).
+//   k_colsum_f32 bias gradients (column sums).
+#include <cstdlib>
+
+#include "common.hpp"
+
+namespace mrgcn {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ---------------------------------------------------------------------------------------------------
+// fused MLP + gate + scatter
+// ---------------------------------------------------------------------------------------------------
+constexpr int kMlpW = 16;  // widest layer the fused kernels take
+constexpr int kMlpL = 4;   // deepest
+
+struct MlpGrad {
+  float *dW[4];               // [dims[l + 1]][dims[l]], accumulated into
+  float *db[4];               // nullable
+};
+
+struct MlpDesc {
+  int L;
+  int dims[kMlpL + 1];        // dims[0] = input width, dims[l + 1] = output width of layer l
+  const float *W[kMlpL];      // [dims[l + 1]][dims[l]] (nn.Linear layout)
+  const float *b[kMlpL];      // nullable
+};
+
+__device__ __forceinline__ int mlp_w_off(const MlpDesc &d, int l) {  // offset of layer l inside the LDS copy
+  int o = 0;
+  for (int i = 0; i < l; ++i) o += d.dims[i + 1] * (d.dims[i] + 1);
+  return o;
+}
+
+__device__ void mlp_stage_weights(const MlpDesc &d, float *s_w) {
+  for (int l = 0; l < d.L; ++l) {
+    const int din = d.dims[l], dout = d.dims[l + 1], base = mlp_w_off(d, l);
+    for (int t = threadIdx.x; t < dout * (din + 1); t += blockDim.x) {
+      const int j = t / (din + 1), k = t - j * (din + 1);
+      s_w[base + t] = k < din ? d.W[l][j * din + k] : (d.b[l] ? d.b[l][j] : 0.f);  // bias rides as column din
+    }
+  }
+}
+
+// activations of every layer for one input row (registers); a[0] = input, a[l + 1] = relu(W_l a[l] + b_l)
+__device__ __forceinline__ void mlp_forward_row(const MlpDesc &d, const float *s_w, float (&a)[kMlpL + 1][kMlpW]) {
+#pragma unroll
+  for (int l = 0; l < kMlpL; ++l) {
+    if (l < d.L) {
+      const int din = d.dims[l], dout = d.dims[l + 1];
+      const float *w = s_w + mlp_w_off(d, l);
+#pragma unroll
+      for (int j = 0; j < kMlpW; ++j) {
+        float y = 0.f;
+        if (j < dout) {
+          const float *wj = w + j * (din + 1);
+          y = wj[din];
+#pragma unroll
+          for (int k = 0; k < kMlpW; ++k)
+            if (k < din) y = fmaf(wj[k], a[l][k], y);
+          y = fmaxf(y, 0.f);
+        }
+        a[l + 1][j] = y;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mlp_gate_scatter_fwd(MlpDesc d, const float *__restrict__ X, int64_t ldx,
+                                                              int64_t n, const float *__restrict__ gate,
+                                                              const int64_t *__restrict__ rows,
+                                                              float *__restrict__ XF, int64_t ldxf, int off) {
+  extern __shared__ float s_w[];
+  mlp_stage_weights(d, s_w);
+  __syncthreads();
+  const float g = *gate;
+  const int dout = d.dims[d.L];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[kMlpL + 1][kMlpW];
+#pragma unroll
+    for (int k = 0; k < kMlpW; ++k) a[0][k] = k < d.dims[0] ? X[i * ldx + k] : 0.f;
+    mlp_forward_row(d, s_w, a);
+    float *o = XF + (rows ? rows[i] : i) * ldxf + off;
+#pragma unroll
+    for (int l = 1; l <= kMlpL; ++l)
+      if (l == d.L) {
+#pragma unroll
+        for (int j = 0; j < kMlpW; ++j)
+          if (j < dout) o[j] = a[l][j] * g;
+      }
+  }
+}
+
+// backward: dW_l, db_l, dgate (+=; zeroed by the caller).  Per layer the block's 256 rows leave their masked
+// output gradient G[r][j] and input activation A[r][k] in LDS, thread (j, k) sums the 256 products.
+__global__ __launch_bounds__(256) void k_mlp_gate_scatter_bwd(MlpDesc d, const float *__restrict__ X, int64_t ldx,
+                                                              int64_t n, const float *__restrict__ gate,
+                                                              const int64_t *__restrict__ rows,
+                                                              const float *__restrict__ dXF, int64_t ldxf, int off,
+                                                              MlpGrad gr, float *__restrict__ dgate) {
+  extern __shared__ float s_mem[];
+  int wtot = 0;
+  for (int l = 0; l < d.L; ++l) wtot += d.dims[l + 1] * (d.dims[l] + 1);
+  float *s_w = s_mem;
+  float *s_g = s_mem + wtot;                 // [256][kMlpW + 1]
+  float *s_a = s_g + 256 * (kMlpW + 1);      // [256][kMlpW + 1]
+  mlp_stage_weights(d, s_w);
+  __syncthreads();
+  const float gt = *gate;
+  const int tj = threadIdx.x >> 4, tk = threadIdx.x & 15;  // this thread's (j, k) of the 16 x 16 reduction
+  float dg_local = 0.f;
+  float accw[kMlpL], accb[kMlpL];
+#pragma unroll
+  for (int l = 0; l < kMlpL; ++l) accw[l] = accb[l] = 0.f;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i0 + threadIdx.x;
+    const bool on = i < n;
+    float a[kMlpL + 1][kMlpW];
+#pragma unroll
+    for (int k = 0; k < kMlpW; ++k) a[0][k] = (on && k < d.dims[0]) ? X[i * ldx + k] : 0.f;
+    mlp_forward_row(d, s_w, a);
+    float g[kMlpW];
+    const float *go = dXF + (on ? (rows ? rows[i] : i) : 0) * ldxf + off;
+#pragma unroll
+    for (int l = 1; l <= kMlpL; ++l)
+      if (l == d.L) {
+#pragma unroll
+        for (int j = 0; j < kMlpW; ++j) {
+          const float gj = (on && j < d.dims[l]) ? go[j] : 0.f;
+          dg_local = fmaf(a[l][j], gj, dg_local);   // d gate = <MLP(x), dXF>
+          g[j] = gj * gt;
+        }
+      }
+#pragma unroll
+    for (int l = kMlpL - 1; l >= 0; --l) {
+      if (l < d.L) {
+        const int din = d.dims[l], dout = d.dims[l + 1];
+#pragma unroll
+        for (int j = 0; j < kMlpW; ++j) {
+          if (!(j < dout && a[l + 1][j] > 0.f)) g[j] = 0.f;   // ReLU
+          s_g[threadIdx.x * (kMlpW + 1) + j] = g[j];
+        }
+#pragma unroll
+        for (int k = 0; k < kMlpW; ++k) s_a[threadIdx.x * (kMlpW + 1) + k] = a[l][k];
+        __syncthreads();
+        if (tj < dout && tk < din) {
+          float sw = 0.f;
+          for (int r = 0; r < 256; ++r) sw = fmaf(s_g[r * (kMlpW + 1) + tj], s_a[r * (kMlpW + 1) + tk], sw);
+          accw[l] += sw;
+        }
+        if (tk == 0 && tj < dout) {
+          float sb = 0.f;
+          for (int r = 0; r < 256; ++r) sb += s_g[r * (kMlpW + 1) + tj];
+          accb[l] += sb;
+        }
+        __syncthreads();
+        // gradient w.r.t. this layer's input
+        const float *w = s_w + mlp_w_off(d, l);
+        float gp[kMlpW];
+#pragma unroll
+        for (int k = 0; k < kMlpW; ++k) {
+          float s = 0.f;
+          if (k < din) {
+#pragma unroll
+            for (int j = 0; j < kMlpW; ++j)
+              if (j < dout) s = fmaf(w[j * (din + 1) + k], g[j], s);
+          }
+          gp[k] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < kMlpW; ++k) g[k] = gp[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < kMlpL; ++l) {
+    if (l < d.L) {
+      const int din = d.dims[l], dout = d.dims[l + 1];
+      if (tj < dout && tk < din && accw[l] != 0.f) atomicAdd(&gr.dW[l][tj * din + tk], accw[l]);
+      if (tk == 0 && tj < dout && gr.db[l] && accb[l] != 0.f) atomicAdd(&gr.db[l][tj], accb[l]);
+    }
+  }
+  // gate: block reduction
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dg_local += __shfl_xor(dg_local, o, kWave);
+  __shared__ float s_dg[4];
+  if ((threadIdx.x & 63) == 0) s_dg[threadIdx.x >> 6] = dg_local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = s_dg[0] + s_dg[1] + s_dg[2] + s_dg[3];
+    if (t != 0.f) atomicAdd(dgate, t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C[M][N] = epilogue( alpha * sum_k Aop(m, k) * Bop(k, n) )     f32 MFMA 16x16x4, block tile 64 x 64, K step 16
+//   A-loader modes: 0  A[m*lda + k]            (row major)
+//                   1  A[k*lda + m]            (transposed storage)
+//                   2  conv1d im2col of x[b][ci][t]:  m = b*Tout + t,  k = ci*KW + kw  ->
+//                      x[(b*Cin + ci)*Tin + t + kw - pad]  (0 outside)                      (forward, dW)
+//                   3  the same with m and k swapped (A^T of mode 2: dW = im2col(x)^T . dY)
+//   B-loader modes: 0  B[k*ldb + n]   1  B[n*ldb + k]
+//                   2  conv output gradient as [m = b*Tout + t][n = co]: dY[(b*Cout + co)*Tout + t]
+//   C-store modes:  0  C[m*ldc + n]   2  conv layout out[(b*Cout + n)*Tout + t],  m = b*Tout + t
+// ---------------------------------------------------------------------------------------------------
+struct ConvGeom {
+  int Cin = 0, Tin = 0, KW = 0, pad = 0, Tout = 0, Cout = 0;
+};
+
+struct GemmArgs {
+  const float *A, *B;
+  float *C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  int amode, bmode, cmode;
+  const float *bias;        // [N] nullable
+  int relu;
+  const float *mask;        // nullable: C *= (mask > 0), same addressing as C
+  float alpha;
+  ConvGeom cg;
+};
+
+__device__ __forceinline__ float gemm_a(const GemmArgs &g, int m, int k) {
+  if (m >= g.M || k >= g.K) return 0.f;
+  if (g.amode == 0) return g.A[(int64_t)m * g.lda + k];
+  if (g.amode == 1) return g.A[(int64_t)k * g.lda + m];
+  int mm = m, kk = k;
+  if (g.amode == 3) { mm = k; kk = m; }   // A^T of the im2col matrix
+  const int b = mm / g.cg.Tout, t = mm - b * g.cg.Tout;
+  const int ci = kk / g.cg.KW, kw = kk - ci * g.cg.KW;
+  const int ti = t + kw - g.cg.pad;
+  if (ti < 0 || ti >= g.cg.Tin) return 0.f;
+  return g.A[((int64_t)b * g.cg.Cin + ci) * g.cg.Tin + ti];
+}
+__device__ __forceinline__ float gemm_b(const GemmArgs &g, int k, int n) {
+  if (k >= g.K || n >= g.N) return 0.f;
+  if (g.bmode == 0) return g.B[(int64_t)k * g.ldb + n];
+  if (g.bmode == 1) return g.B[(int64_t)n * g.ldb + k];
+  const int b = k / g.cg.Tout, t = k - b * g.cg.Tout;   // bmode 2: k runs over (b, t), n over channels
+  return g.B[((int64_t)b * g.cg.Cout + n) * g.cg.Tout + t];
+}
+__device__ __forceinline__ int64_t gemm_c_index(const GemmArgs &g, int m, int n) {
+  if (g.cmode == 0) return (int64_t)m * g.ldc + n;
+  const int b = m / g.cg.Tout, t = m - b * g.cg.Tout;
+  return ((int64_t)b * g.cg.Cout + n) * g.cg.Tout + t;
+}
+
+constexpr int kGT = 64, kGK = 16, kGP = kGK + 4;  // tile, K step, padded LDS row (rows on different banks)
+
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+  __shared__ __align__(16) float As[kGT][kGP];   // [m][k]
+  __shared__ __align__(16) float Bs[kGT][kGP];   // [n][k]
+  const int m0 = blockIdx.y * kGT, n0 = blockIdx.x * kGT;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32;   // this wave's 32 x 32 quarter
+  const int lm = lane & 15, kq = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // loader mapping: thread t fills As[t / 4][4 * (t % 4) + 0..3] and the same of Bs
+  const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;
+  for (int k0 = 0; k0 < g.K; k0 += kGK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      As[lr][lk + i] = gemm_a(g, m0 + lr, k0 + lk + i);
+      Bs[lr][lk + i] = gemm_b(g, k0 + lk + i, n0 + lr);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < kGK; ks += 16) {
+      f32x4 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[i] = *reinterpret_cast<const f32x4 *>(&As[wm + i * 16 + lm][ks + 4 * kq]);
+        bv[i] = *reinterpret_cast<const f32x4 *>(&Bs[wn + i * 16 + lm][ks + 4 * kq]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // k slot kq of the s-th MFMA stands for k = k0 + 4 kq + s: any bijection of the K step works
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  // D: lane (n = lane & 15, q = lane >> 4) holds rows 4q + reg of its 16 x 16 tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = m0 + wm + i * 16 + 4 * kq + reg, n = n0 + wn + j * 16 + lm;
+        if (m >= g.M || n >= g.N) continue;
+        float v = acc[i][j][reg] * g.alpha;
+        if (g.bias) v += g.bias[n];
+        if (g.relu) v = fmaxf(v, 0.f);
+        const int64_t ci = gemm_c_index(g, m, n);
+        if (g.mask && !(g.mask[ci] > 0.f)) v = 0.f;
+        g.C[ci] = v;
+      }
+}
+
+// out[n] = sum_m X[m][n] (row major, ld) — bias gradients; one block per 64 columns
+__global__ __launch_bounds__(256) void k_colsum_f32(const float *__restrict__ X, int64_t ld, int M, int N,
+                                                    float *__restrict__ out) {
+  __shared__ float s[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float t = 0.f;
+  if (n < N)
+    for (int m = part; m < M; m += 4) t += X[(int64_t)m * ld + n];
+  s[part][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (part == 0 && n < N) out[n] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+
+}  // namespace
+}  // namespace mrgcn
+
+using namespace mrgcn;
+
+extern "C" {
+
+static int mlp_desc(MlpDesc &d, int32_t L, const int32_t *dims, const float *const *W, const float *const *b) {
+  MRGCN_REQUIRE(L >= 1 && L <= kMlpL && dims && W && b, "1 <= layers <= 4");
+  d.L = L;
+  for (int l = 0; l <= L; ++l) {
+    MRGCN_REQUIRE(dims[l] >= 1 && dims[l] <= kMlpW, "layer widths must be 1..16");
+    d.dims[l] = dims[l];
+  }
+  for (int l = 0; l < kMlpL; ++l) {
+    d.W[l] = l < L ? W[l] : nullptr;
+    d.b[l] = l < L ? b[l] : nullptr;
+    MRGCN_REQUIRE(l >= L || d.W[l], "NULL weight");
+  }
+  return MRGCN_OK;
+}
+
+int32_t mrgcn_mlp_fused_supported(int32_t L, const int32_t *dims) {
+  if (L < 1 || L > kMlpL || !dims) return 0;
+  for (int l = 0; l <= L; ++l)
+    if (dims[l] < 1 || dims[l] > kMlpW) return 0;
+  return 1;
+}
+
+int mrgcn_mlp_gate_scatter_fwd_f32(int32_t L, const int32_t *dims, const float *const *W, const float *const *b,
+                                   const float *X, int64_t ldx, int64_t n, const float *gate, const int64_t *rows,
+                                   float *XF, int64_t ldxf, int32_t offset, void *stream) {
+  MlpDesc d;
+  int rc = mlp_desc(d, L, dims, W, b);
+  if (rc != MRGCN_OK) return rc;
+  MRGCN_REQUIRE(X && gate && XF && ldx >= dims[0] && ldxf >= offset + dims[L] && offset >= 0, "operands");
+  if (n == 0) return MRGCN_OK;
+  size_t lds = 0;
+  for (int l = 0; l < L; ++l) lds += (size_t)dims[l + 1] * (dims[l] + 1) * sizeof(float);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  k_mlp_gate_scatter_fwd<<<dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream>>>(d, X, ldx, n, gate, rows, XF,
+                                                                                          ldxf, offset);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_mlp_gate_scatter_bwd_f32(int32_t L, const int32_t *dims, const float *const *W, const float *const *b,
+                                   const float *X, int64_t ldx, int64_t n, const float *gate, const int64_t *rows,
+                                   const float *dXF, int64_t ldxf, int32_t offset, float *const *dW,
+                                   float *const *db, float *dgate, void *stream) {
+  MlpDesc d;
+  int rc = mlp_desc(d, L, dims, W, b);
+  if (rc != MRGCN_OK) return rc;
+  MRGCN_REQUIRE(X && gate && dXF && dW && db && dgate, "NULL");
+  if (n == 0) return MRGCN_OK;
+  MlpGrad gr{};
+  for (int l = 0; l < L; ++l) {
+    MRGCN_REQUIRE(dW[l], "NULL weight gradient");
+    gr.dW[l] = dW[l];
+    gr.db[l] = db[l];
+  }
+  size_t lds = 2 * 256 * (kMlpW + 1) * sizeof(float);
+  for (int l = 0; l < L; ++l) lds += (size_t)dims[l + 1] * (dims[l] + 1) * sizeof(float);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  k_mlp_gate_scatter_bwd<<<dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream>>>(
+      d, X, ldx, n, gate, rows, dXF, ldxf, offset, gr, dgate);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32_t N, int32_t K, const float *A,
+                   int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias,
+                   int32_t relu, const float *mask, float alpha, const int32_t *conv_geom, void *stream) {
+  MRGCN_REQUIRE(A && B && C && M >= 0 && N >= 0 && K >= 0, "operands");
+  MRGCN_REQUIRE(amode >= 0 && amode <= 3 && bmode >= 0 && bmode <= 2 && (cmode == 0 || cmode == 2), "modes");
+  MRGCN_REQUIRE((amode < 2 && bmode < 2 && cmode == 0) || conv_geom, "conv modes need the geometry");
+  if (M == 0 || N == 0) return MRGCN_OK;
+  GemmArgs g{A, B, C, lda, ldb, ldc, M, N, K, amode, bmode, cmode, bias, relu, mask, alpha, ConvGeom{}};
+  if (conv_geom) g.cg = ConvGeom{conv_geom[0], conv_geom[1], conv_geom[2], conv_geom[3], conv_geom[4], conv_geom[5]};
+  dim3 grid((unsigned)((N + kGT - 1) / kGT), (unsigned)((M + kGT - 1) / kGT));
+  k_gemm_f32<<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_colsum_f32(const float *X, int64_t ld, int32_t M, int32_t N, float *out, void *stream) {
+  MRGCN_REQUIRE(X && out && ld >= N, "operands");
+  if (N == 0) return MRGCN_OK;
+  k_colsum_f32<<<dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream>>>(X, ld, M, N, out);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+}  // extern "C"

@@ -8,7 +8,28 @@ from __future__ import annotations
 import numpy as np
 import scipy.sparse as sp
 
-from ..synth import stacked_coo
+
+def stacked_coo(triples, N, P, value_mode="norm_f32"):
+    """COO of the N x (R*N) stacked adjacency, R = 2P + 1 (inverses + identity)."""
+    s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
+    R = 2 * P + 1
+    # forward block r = 2p: row s, col o, value 1 / #{o' : (s, p, o')}
+    kf = p * N + s
+    _, inv_f, cnt_f = np.unique(kf, return_inverse=True, return_counts=True)
+    vf = 1.0 / cnt_f[inv_f]
+    # inverse block r = 2p + 1: row o, col s, value 1 / #{s' : (s', p, o)}
+    ki = p * N + o
+    _, inv_i, cnt_i = np.unique(ki, return_inverse=True, return_counts=True)
+    vi = 1.0 / cnt_i[inv_i]
+    ident = np.arange(N, dtype=np.int64)
+    rows = np.concatenate([s, o, ident])
+    cols = np.concatenate([(2 * p) * N + o, (2 * p + 1) * N + s, (R - 1) * N + ident])
+    vals = np.concatenate([vf, vi, np.ones(N)]).astype(np.float32)
+    if value_mode == "ref_int8":
+        vals = vals.astype(np.int8)  # truncation toward zero: only exact ones survive
+    elif value_mode != "norm_f32":
+        raise ValueError(value_mode)
+    return rows, cols, vals, R
 
 
 def adjacency_from_triples(triples: np.ndarray, num_nodes: int, num_pred: int) -> sp.csr_matrix:

@@ -1,0 +1,199 @@
+"""autograd wiring of the encoder kernels (csrc/encoders.hip): the dense step in front of the graph path
+(SURVEY §8f next-2).  Like the graph ops these call the C ABI only — no PyTorch or CPU fallback inside;
+the modules in `models/` decide per call whether their input qualifies (GPU tensors, supported widths)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _gemm(amode, bmode, cmode, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, relu=False, mask=None, alpha=1.0,
+          geom=None):
+    g = (C.c_int32 * 6)(*geom) if geom is not None else None
+    with torch.cuda.device(Cout.device):
+        L.check(L.load().mrgcn_gemm_f32(
+            amode, bmode, cmode, M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, Cout.data_ptr(), ldc,
+            bias.data_ptr() if bias is not None else 0, 1 if relu else 0, mask.data_ptr() if mask is not None else 0,
+            float(alpha), g, _stream(Cout.device)), "mrgcn_gemm_f32")
+    return Cout
+
+
+def _colsum(X2d):
+    M, N = X2d.shape
+    out = torch.empty(N, dtype=torch.float32, device=X2d.device)
+    with torch.cuda.device(X2d.device):
+        L.check(L.load().mrgcn_colsum_f32(X2d.data_ptr(), X2d.stride(0), M, N, out.data_ptr(), _stream(X2d.device)),
+                "mrgcn_colsum_f32")
+    return out
+
+
+def usable(*tensors) -> bool:
+    """The HIP encoder path takes float32 GPU tensors."""
+    return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = relu?(x W^T + b) on the matrix cores (nn.Linear semantics: W is [out, in])."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu: bool):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        Wc = W.contiguous()
+        n, K = x2.shape
+        N = Wc.shape[0]
+        y = torch.empty((n, N), dtype=torch.float32, device=x.device)
+        _gemm(0, 1, 0, n, N, K, x2, K, Wc, K, y, N, bias=b.contiguous() if b is not None else None, relu=relu)
+        ctx.relu, ctx.shape, ctx.has_b = relu, x.shape, b is not None
+        ctx.save_for_backward(x2, Wc, y if relu else None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        n, K = x2.shape
+        N = W.shape[0]
+        dy2 = dy.reshape(n, N).contiguous()
+        if ctx.relu:  # gradient at the pre-activation: dy * (y > 0)
+            from .functional import relu_bwd
+            dy2 = relu_bwd(dy2, y)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((n, K), dtype=torch.float32, device=dy.device)
+            _gemm(0, 0, 0, n, K, N, dy2, N, W, K, dx, K)                      # dx = dy . W
+            dx = dx.view(ctx.shape)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            _gemm(1, 0, 0, N, K, n, dy2, N, x2, K, dW, K)                     # dW = dy^T . x
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = _colsum(dy2)
+        return dx, dW, db, None
+
+
+def linear(x, W, b=None, relu: bool = False):
+    return _Linear.apply(x, W, b, relu)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _Conv1d(torch.autograd.Function):
+    """nn.Conv1d (stride 1, dilation 1, zero padding) as an implicit-im2col product on the matrix cores:
+    y[b, co, t] = bias[co] + sum_{ci, kw} W[co, ci, kw] x[b, ci, t + kw - pad]."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, pad: int):
+        x = x.contiguous()
+        Wc = W.contiguous()
+        Bn, Cin, Tin = x.shape
+        Cout, _, KW = Wc.shape
+        Tout = Tin + 2 * pad - KW + 1
+        y = torch.empty((Bn, Cout, Tout), dtype=torch.float32, device=x.device)
+        geom = (Cin, Tin, KW, pad, Tout, Cout)
+        _gemm(2, 1, 2, Bn * Tout, Cout, Cin * KW, x, 0, Wc.view(Cout, Cin * KW), Cin * KW, y, 0,
+              bias=b.contiguous() if b is not None else None, geom=geom)
+        ctx.geom, ctx.has_b = geom, b is not None
+        ctx.save_for_backward(x, Wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        Cin, Tin, KW, pad, Tout, Cout = ctx.geom
+        Bn = x.shape[0]
+        dy = dy.contiguous()
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            # dx[b, ci, t] = sum_{co, kw'} dy[b, co, t + kw' - (KW-1-pad)] W[co, ci, KW-1-kw']: a convolution of dy
+            Wf = W.flip(2).permute(0, 2, 1).reshape(Cout * KW, Cin).contiguous()   # [(co, kw')][ci]
+            dx = torch.empty_like(x)
+            _gemm(2, 0, 2, Bn * Tin, Cin, Cout * KW, dy, 0, Wf, Cin, dx, 0,
+                  geom=(Cout, Tout, KW, KW - 1 - pad, Tin, Cin))
+        if ctx.needs_input_grad[1]:
+            # dW^T[(ci, kw)][co] = sum_{b, t} x[b, ci, t + kw - pad] dy[b, co, t]
+            dWt = torch.empty((Cin * KW, Cout), dtype=torch.float32, device=dy.device)
+            _gemm(3, 2, 0, Cin * KW, Cout, Bn * Tout, x, 0, dy, 0, dWt, Cout, geom=ctx.geom)
+            dW = dWt.t().reshape(Cout, Cin, KW).contiguous()
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 2))
+        return dx, dW, db, None
+
+
+def conv1d(x, W, b=None, padding: int = 0):
+    return _Conv1d.apply(x, W, b, int(padding))
+
+
+# ---------------------------------------------------------------------------------------------------------
+def mlp_dims(weights):
+    return [int(weights[0].shape[1])] + [int(w.shape[0]) for w in weights]
+
+
+def mlp_fused_supported(weights) -> bool:
+    dims = mlp_dims(weights)
+    arr = (C.c_int32 * len(dims))(*dims)
+    return bool(L.load().mrgcn_mlp_fused_supported(len(weights), arr))
+
+
+def _ptr_array(tensors, n):
+    return (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in tensors])
+
+
+class _MlpGateScatter(torch.autograd.Function):
+    """XF[rows, off : off + d_out] = gate_weights[i_gate] * MLP(enc) in one kernel (mrgcn.py:285-303 with
+    perceptron.py:6-46 inside).  XF is written in place and handed on."""
+
+    @staticmethod
+    def forward(ctx, XF, enc, rows, gate_weights, i_gate: int, offset: int, n_layers: int, *params):
+        weights = [p.contiguous() for p in params[:n_layers]]
+        biases = [(p.contiguous() if p is not None else None) for p in params[n_layers:]]
+        dims = mlp_dims(weights)
+        enc = enc.contiguous()
+        lib = L.load()
+        dims_arr = (C.c_int32 * len(dims))(*dims)
+        gate = gate_weights[i_gate:i_gate + 1].contiguous()
+        with torch.cuda.device(XF.device):
+            L.check(lib.mrgcn_mlp_gate_scatter_fwd_f32(
+                n_layers, dims_arr, _ptr_array(weights, n_layers), _ptr_array(biases, n_layers), enc.data_ptr(),
+                enc.stride(0), enc.shape[0], gate.data_ptr(), rows.data_ptr() if rows is not None else 0,
+                XF.data_ptr(), XF.stride(0), offset, _stream(XF.device)), "mrgcn_mlp_gate_scatter_fwd_f32")
+        ctx.meta = (i_gate, offset, n_layers, dims, [b is not None for b in biases])
+        ctx.save_for_backward(enc, rows, gate_weights, *weights, *[b for b in biases if b is not None])
+        ctx.mark_dirty(XF)
+        return XF
+
+    @staticmethod
+    def backward(ctx, dXF):
+        i_gate, offset, n_layers, dims, has_b = ctx.meta
+        enc, rows, gate_weights = ctx.saved_tensors[:3]
+        weights = list(ctx.saved_tensors[3:3 + n_layers])
+        bs = list(ctx.saved_tensors[3 + n_layers:])
+        biases = [bs.pop(0) if h else None for h in has_b]
+        dXF = dXF.contiguous()
+        dW = [torch.zeros_like(w) for w in weights]
+        db = [torch.zeros_like(b) if b is not None else None for b in biases]
+        dgate = torch.zeros_like(gate_weights)
+        gate = gate_weights[i_gate:i_gate + 1].contiguous()
+        dims_arr = (C.c_int32 * len(dims))(*dims)
+        dg_view = dgate[i_gate:i_gate + 1]
+        with torch.cuda.device(dXF.device):
+            L.check(L.load().mrgcn_mlp_gate_scatter_bwd_f32(
+                n_layers, dims_arr, _ptr_array(weights, n_layers), _ptr_array(biases, n_layers), enc.data_ptr(),
+                enc.stride(0), enc.shape[0], gate.data_ptr(), rows.data_ptr() if rows is not None else 0,
+                dXF.data_ptr(), dXF.stride(0), offset, _ptr_array(dW, n_layers), _ptr_array(db, n_layers),
+                dg_view.data_ptr(), _stream(dXF.device)), "mrgcn_mlp_gate_scatter_bwd_f32")
+        # the block this op wrote does not depend on what XF held before
+        dXF_in = dXF.clone()
+        if rows is not None:
+            dXF_in[rows, offset:offset + dims[-1]] = 0
+        else:
+            dXF_in[:, offset:offset + dims[-1]] = 0
+        return (dXF_in, None, None, dgate, None, None, None, *dW, *db)
+
+
+def mlp_gate_scatter(XF, enc, rows, gate_weights, i_gate, offset, weights, biases):
+    return _MlpGateScatter.apply(XF, enc, rows, gate_weights, int(i_gate), int(offset), len(weights), *weights, *biases)

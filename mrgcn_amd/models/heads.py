@@ -51,6 +51,14 @@ class _Head(nn.Module):
         self.f_activation = nn.ReLU()
 
     def _project(self, pooled):
+        """pre_fc -> ReLU -> dropout -> fc (imagecnn.py:31-41, transformer.py:29-38); on the GPU the two products
+        run on the matrix cores with bias / ReLU in their epilogues (dense.linear, csrc/encoders.hip)."""
+        from .. import dense
+        if dense.usable(pooled, self.pre_fc.weight):
+            out = dense.linear(pooled, self.pre_fc.weight, self.pre_fc.bias, relu=True)
+            if self.dropout is not None:
+                out = self.dropout(out)
+            return dense.linear(out, self.fc.weight, self.fc.bias)
         out = self.f_activation(self.pre_fc(pooled))
         if self.dropout is not None:
             out = self.dropout(out)

@@ -175,7 +175,14 @@ class MRGCN(nn.Module):
                     data = self.im_norm.normalize_(data)
                 else:
                     data = data.float()
-                out = module(data).to(dev) * gate.to(dev)
-                X[rows, offset:offset + out_dim] = out
+                if isinstance(module, MLP) and X.is_cuda and data.device == X.device and module.fused_ok(data):
+                    # every Linear + ReLU, the gate and the scatter in one kernel (csrc/encoders.hip)
+                    from .. import dense
+                    lin = module.linears()
+                    X = dense.mlp_gate_scatter(X, data, rows, self.gate_weights, i_gate, offset,
+                                               [l.weight for l in lin], [l.bias for l in lin])
+                else:
+                    out = module(data).to(dev) * gate.to(dev)
+                    X[rows, offset:offset + out_dim] = out
                 offset += out_dim
         return X

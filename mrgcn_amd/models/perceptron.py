@@ -2,7 +2,10 @@
 follow mrgcn/models/perceptron.py:6-46: `num_layers` blocks of Linear -> Dropout(inplace) -> ReLU
 whose widths step linearly from `input_dim` down to `output_dim`, every weight and bias drawn
 from U(0, 1) in parameter order (so the same seed gives the reference's values; state-dict keys
-`mlp.<3k>.weight|bias`).  Dense and tiny: library GEMM (rocBLAS through nn.Linear)."""
+`mlp.<3k>.weight|bias`).  Inside `MRGCN` the whole encoder — every Linear + ReLU, the gate multiply and
+the scatter into the feature matrix — is ONE HIP kernel (`dense.mlp_gate_scatter`, csrc/encoders.hip) when
+the literals live on the GPU, the widths are <= 16 and dropout is inactive; `forward` below (nn.Linear) is
+what runs otherwise (CPU-side tooling, wider layers, p_dropout > 0 in training)."""
 import torch
 import torch.nn as nn
 
@@ -31,3 +34,13 @@ class MLP(nn.Module):
 
     def forward(self, X):
         return self.mlp(X)
+
+    def linears(self):
+        return [m for m in self.mlp if isinstance(m, nn.Linear)]
+
+    def fused_ok(self, X) -> bool:
+        """Can `dense.mlp_gate_scatter` take this call?"""
+        from .. import dense
+        lin = self.linears()
+        return (dense.usable(X) and all(l.weight.is_cuda for l in lin) and not (self.training and self.p_dropout > 0)
+                and dense.mlp_fused_supported([l.weight for l in lin]))

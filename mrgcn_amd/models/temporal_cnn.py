@@ -50,8 +50,16 @@ class TCNN(nn.Module):
         self.module_dict["fc"] = self.fc
 
     def forward(self, X):
-        X = self.conv(X)
-        return self.fc(X.view(X.size(0), -1))
+        from .. import dense
+        if not dense.usable(X, self.fc[0].weight):
+            X = self.conv(X)
+            return self.fc(X.view(X.size(0), -1))
+        # GPU: every Conv1d is an implicit-im2col product on the matrix cores, the fully connected tail two more
+        # (dense.conv1d / dense.linear, csrc/encoders.hip); BatchNorm / ReLU / pooling stay elementwise passes
+        for m in self.conv:
+            X = dense.conv1d(X, m.weight, m.bias, m.padding[0]) if isinstance(m, nn.Conv1d) else m(X)
+        X = dense.linear(X.view(X.size(0), -1), self.fc[0].weight, self.fc[0].bias, relu=True)
+        return dense.linear(self.fc[2](X), self.fc[3].weight, self.fc[3].bias)
 
 
 def out_dim(seq_length, kernel_size, padding=0, stride=1, dilation=1):

@@ -124,3 +124,127 @@ def test_mrgcn_with_tcnn_and_mlp_encoders_vs_reference():
     np.testing.assert_allclose(model.gate_weights.grad.cpu().numpy(), g["mrgcn.grad.gate_weights"], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(model.module_dict["ogc_wktLiteral_0"].conv[0].weight.grad.cpu().numpy(),
                                g["mrgcn.grad.tcnn_conv0"], rtol=2e-3, atol=1e-6)
+
+
+# ---- the same encoders on the HIP kernels (csrc/encoders.hip through mrgcn_amd.dense) ---------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", ["S", "M", "L"])
+def test_tcnn_on_the_matrix_cores_matches_reference(size):
+    """Every Conv1d as an implicit-im2col f32-MFMA product, the fully connected tail likewise: forward in train
+    and eval mode, the gradient of the first convolution and BatchNorm's running mean vs the reference's values."""
+    from mrgcn_amd.models.temporal_cnn import TCNN
+    g = np.load(GOLD)
+    torch.manual_seed(3)
+    m = TCNN(features_in=9, features_out=7, p_dropout=0.0, size=size).cuda()
+    x = torch.from_numpy(g[f"tcnn{size}.x"]).cuda()
+    m.train()
+    y = m(x)
+    assert type(y.grad_fn).__name__ == "_LinearBackward"       # the HIP path ran
+    y.square().sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"tcnn{size}.y_train"], rtol=1e-4, atol=1e-5)
+    gref = g[f"tcnn{size}.grad_conv0"]  # through up to 15 convolutions and batch-statistics BatchNorms: fp32 sums in
+    np.testing.assert_allclose(m.conv[0].weight.grad.cpu().numpy(), gref, rtol=2e-3,  # another order than the CPU's
+                               atol=2e-4 * float(np.abs(gref).max()))
+    np.testing.assert_allclose(m.conv[1].running_mean.cpu().numpy(), g[f"tcnn{size}.sd_after.running_mean0"],
+                               rtol=1e-5, atol=1e-6)
+    m.eval()
+    np.testing.assert_allclose(m(x).detach().cpu().numpy(), g[f"tcnn{size}.y_eval"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_backbone_heads_on_the_matrix_cores_match_reference():
+    from mrgcn_amd.models.heads import ImageCNN, Transformer
+    g = np.load(GOLD, allow_pickle=True)
+    base = TinyImageNet()
+    _load(base, g, "img.base.")
+    head = ImageCNN(base, output_dim=6, p_dropout=0.0)
+    _load(head, g, "img.sd.")
+    head = head.cuda()
+    y = head(torch.from_numpy(g["img.x"]).cuda())
+    assert type(y.grad_fn).__name__ == "_LinearBackward"
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["img.y"], rtol=1e-5, atol=1e-6)
+    lm = TinyLM()
+    _load(lm, g, "lm.base.")
+    th = Transformer(lm, output_dim=4, p_dropout=0.0)
+    _load(th, g, "lm.sd.")
+    th = th.cuda()
+    np.testing.assert_allclose(th(torch.from_numpy(g["lm.x"]).cuda()).detach().cpu().numpy(), g["lm.y"], rtol=1e-5,
+                               atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 1, 1), (5, 3, 2), (70, 130, 65), (257, 64, 7), (33, 768, 16)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear_on_the_matrix_cores_vs_float64(shape, relu):
+    """dense.linear (f32 MFMA 16x16x4: exact fp32 arithmetic) forward and all three gradients, edge tiles included."""
+    from mrgcn_amd import dense
+    n, K, N = shape
+    gen = torch.Generator("cuda").manual_seed(n + K)
+    x = torch.randn((n, K), device="cuda", generator=gen, requires_grad=True)
+    W = torch.randn((N, K), device="cuda", generator=gen, requires_grad=True)
+    b = torch.randn((N,), device="cuda", generator=gen, requires_grad=True)
+    w = torch.randn((n, N), device="cuda", generator=gen)
+    y = dense.linear(x, W, b, relu=relu)
+    (y * w).sum().backward()
+    x64, W64, b64 = (t.detach().double().requires_grad_(True) for t in (x, W, b))
+    r = x64 @ W64.t() + b64
+    r = torch.relu(r) if relu else r
+    (r * w.double()).sum().backward()
+    tol = dict(rtol=1e-5, atol=1e-5 * max(1.0, K ** 0.5))
+    torch.testing.assert_close(y.double(), r, **tol)
+    for a, c in ((x, x64), (W, W64), (b, b64)):
+        torch.testing.assert_close(a.grad.double(), c.grad, rtol=1e-5, atol=1e-5 * max(1.0, (n * K) ** 0.5))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,T,Cout,KW,pad", [(2, 3, 20, 5, 3, 1), (7, 9, 33, 64, 7, 3), (3, 64, 10, 128, 3, 0),
+                                                 (1, 1, 2, 1, 2, 0), (5, 16, 3, 32, 3, 1)])
+def test_conv1d_on_the_matrix_cores_vs_torch(B, Cin, T, Cout, KW, pad):
+    from mrgcn_amd import dense
+    gen = torch.Generator("cuda").manual_seed(B + T)
+    x = torch.randn((B, Cin, T), device="cuda", generator=gen, requires_grad=True)
+    W = torch.randn((Cout, Cin, KW), device="cuda", generator=gen, requires_grad=True)
+    b = torch.randn((Cout,), device="cuda", generator=gen, requires_grad=True)
+    y = dense.conv1d(x, W, b, padding=pad)
+    w = torch.randn(y.shape, device="cuda", generator=gen)
+    (y * w).sum().backward()
+    x64, W64, b64 = (t.detach().double().cpu().requires_grad_(True) for t in (x, W, b))
+    r = torch.nn.functional.conv1d(x64, W64, b64, padding=pad)
+    (r * w.double().cpu()).sum().backward()
+    torch.testing.assert_close(y.double().cpu(), r, rtol=1e-5, atol=1e-4)
+    for a, c in ((x, x64), (W, W64), (b, b64)):
+        torch.testing.assert_close(a.grad.double().cpu(), c.grad, rtol=1e-5, atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,with_rows", [([1, 4], True), ([6, 4, 3], True), ([16, 16, 16, 16, 16], False),
+                                            ([3, 1], False)])
+def test_fused_mlp_gate_scatter_vs_torch(dims, with_rows):
+    """The literal encoder as ONE kernel (every Linear + ReLU, the gate, the scatter into XF) against the nn.Linear
+    path: output block, untouched remainder of XF, and the gradients of weights, biases and the gate."""
+    from mrgcn_amd import dense
+    gen = torch.Generator("cuda").manual_seed(sum(dims))
+    n, NX, off = 1000, 1500, 3
+    enc = torch.rand((n, dims[0]), device="cuda", generator=gen) * 2 - 1
+    rows = torch.randperm(NX, device="cuda", generator=gen)[:n] if with_rows else None
+    Ws = [torch.rand((o, i), device="cuda", generator=gen, requires_grad=True) for i, o in zip(dims, dims[1:])]
+    bs = [torch.rand((o,), device="cuda", generator=gen, requires_grad=True) for o in dims[1:]]
+    gates = torch.tensor([0.3, 0.1, 0.7], device="cuda", requires_grad=True)
+    width = off + dims[-1] + 2
+    XF = torch.full((NX if with_rows else n, width), 5.0, device="cuda")
+    out = dense.mlp_gate_scatter(XF, enc, rows, gates, 1, off, Ws, bs)
+    w = torch.randn(out.shape, device="cuda", generator=gen)
+    (out * w).sum().backward()
+    got = [t.grad.clone() for t in Ws + bs + [gates]]
+    for t in Ws + bs + [gates]:
+        t.grad = None
+    h = enc
+    for W, b in zip(Ws, bs):
+        h = torch.relu(h @ W.t() + b)
+    ref = torch.full_like(XF, 5.0)
+    idx = rows if rows is not None else torch.arange(n, device="cuda")
+    ref[idx, off:off + dims[-1]] = h * gates[1]
+    (ref * w).sum().backward()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    for a, t in zip(got, Ws + bs + [gates]):
+        torch.testing.assert_close(a, t.grad, rtol=2e-4, atol=2e-4 * float(t.grad.abs().max()) + 1e-6)
