@@ -141,6 +141,190 @@ __global__ __launch_bounds__(kMixFwdTB) void k_mix_fwd(const int32_t *__restrict
 }
 
 // =====================================================================================
+// basis mix, forward, ON THE MATRIX CORES (B <= 64, F <= 16, B*F % 4 == 0): per source node j the rows of
+// its columns are a small dense product
+//     M_j [ncols_j x F] = C_j [ncols_j x B] . V_j [B x F],      C_j[m, :] = comp[r of the node's m-th column, :]
+// PMC of the scalar form above (thread = (node, feature), 40 strided loads + 40 FMAs per column) showed the
+// texture addresser 67 % and the VALU 52 % busy for 3.5 GB of traffic at 3.0 TB/s.  Here a wave takes kFwdTN
+// nodes per step: their V blocks enter a per-wave LDS tile as 16-byte pieces in lane order, the comp table
+// lives transposed-free in LDS ([R][K padded to 16s], k contiguous), and v_mfma_f32_16x16x4_f32 (exact fp32)
+// multiplies up to 16 columns of a node at a time: lane (m, kq) feeds A = comp[r_m][16 ks + 4 kq ..] (one
+// 16-byte LDS read per K step) and B = V_j[16 ks + 4 kq + s][n] (the same for every column tile of the node).
+// The result lane (n, q) holds columns 4 q + reg: addend added, row stored at its operand position.
+// =====================================================================================
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+using f32x4m = __attribute__((ext_vector_type(4))) float;
+constexpr int kFwdTB = 1024;  // 16 waves share one LDS copy of comp (R x 52 floats is most of a CU's LDS at R ~ 270)
+
+// the tiles of one node: columns [c0, c1), 16 per MFMA tile.  NEAR: the relation / position words of the
+// step's columns sit in the lanes of `ur` / `mp` (column `base` + lane) and are fetched with lane permutes,
+// and the addend words of the node's (single) tile sit in `pa`; the products then hold no global load at all,
+// so the waits the compiler places never drain the loads of the NEXT step (a load merged into the same
+// registers would: the wait sits at the use, after the merge).
+template <int KS, bool NEAR, bool ADD, typename OT>
+__device__ __forceinline__ void mix_node_tiles(int32_t c0, int32_t c1, int32_t base, int32_t ur, int32_t mp,
+                                               const float (&pa)[4], const int32_t *__restrict__ urel,
+                                               const int32_t *__restrict__ mpos, const float *s_comp,
+                                               const float *s_v, int B, int F, const float *__restrict__ addend,
+                                               int64_t ldA, OT *__restrict__ M, int64_t ldM, int m, int kq) {
+  constexpr int KP = KS * 16 + 4;
+  // B operand of this node: V_j[16 ks + 4 kq + s][m]
+  f32x4m bv[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k0 = ks * 16 + 4 * kq;
+    const float *t = s_v + k0 * F + m;
+    bv[ks].x = (m < F && k0 + 0 < B) ? t[0] : 0.f;
+    bv[ks].y = (m < F && k0 + 1 < B) ? t[F] : 0.f;
+    bv[ks].z = (m < F && k0 + 2 < B) ? t[2 * F] : 0.f;
+    bv[ks].w = (m < F && k0 + 3 < B) ? t[3 * F] : 0.f;
+  }
+  for (int32_t cb = c0; cb < c1; cb += 16) {
+    const int32_t cm = cb + m;  // A side: this lane's column
+    int32_t r;
+    int32_t pos[4];  // D side: this lane's four columns 4 kq + reg
+    f32x4m acc = f32x4m{0.f, 0.f, 0.f, 0.f};
+    if (NEAR) {
+      r = __shfl(ur, (cm - base) & 63);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        pos[reg] = __shfl(mp, (cb - base + 4 * kq + reg) & 63);
+        if (ADD) acc[reg] = pa[reg];
+      }
+    } else {
+      r = urel[min(cm, c1 - 1)];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int32_t c = min(cb + 4 * kq + reg, c1 - 1);
+        pos[reg] = mpos ? mpos[c] : c;
+        if (ADD) acc[reg] = addend[(int64_t)c * ldA + min(m, F - 1)];
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f32x4m av = *reinterpret_cast<const f32x4m *>(s_comp + r * KP + ks * 16 + 4 * kq);
+      if (cm >= c1) av = f32x4m{0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[ks].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[ks].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[ks].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[ks].w, acc, 0, 0, 0);
+    }
+    if (m < F) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        if (cb + 4 * kq + reg < c1) store_operand<OT>(M + (int64_t)pos[reg] * ldM + m, acc[reg]);
+    }
+    if (NEAR && ADD) break;  // (such a node has one tile)
+  }
+}
+
+template <int KS, int NQ, int TN, bool ADD, typename OT>
+__global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
+    const int32_t *__restrict__ nptr, const int32_t *__restrict__ urel, const int32_t *__restrict__ mpos,
+    const float *__restrict__ V, const float *__restrict__ comp, int64_t N, int R, int B, int F,
+    const float *__restrict__ addend, int64_t ldA, OT *__restrict__ M, int64_t ldM) {
+  extern __shared__ __align__(16) float s_mem[];
+  constexpr int KP = KS * 16 + 4;  // padded comp row: rows start on different banks
+  float *s_comp = s_mem;           // [R][KP], zero beyond B
+  const int BF = B * F, nf4 = BF >> 2;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = blockDim.x >> 6;
+  float *s_tile = s_mem + ((R * KP + 3) & ~3) + wv * (TN * BF);
+  for (int t = threadIdx.x; t < R * KP; t += blockDim.x) {
+    const int r = t / KP, k = t - r * KP;
+    s_comp[t] = k < B ? comp[(int64_t)r * B + k] : 0.f;
+  }
+  __syncthreads();
+  const int m = lane & 15, kq = lane >> 4;  // A: column m of the tile, k quarter kq;  D: feature m, column quarter kq
+  const int64_t ngroups = (N + TN - 1) / TN;
+  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  int64_t g = (int64_t)blockIdx.x * nw + wv;
+  if (g >= ngroups) return;
+  // software pipeline over the wave's steps (TN nodes each): the node pointers run two steps ahead; the V
+  // blocks (registers: NQ = ceil(B F / 256) 16-byte pieces per lane and node), the relation / position words
+  // of the step's columns (one contiguous range: lane l holds column cp[0] + l) and the addend words of every
+  // node's first tile run one step ahead, so the loads of step s+1 fly under the products of step s.  All of
+  // them are unconditional at clamped addresses: predicated pieces would send the registers to scratch.
+#define MIX_LOAD_NP(gg) nptr[min(min((gg), ngroups - 1) * TN + min(lane, TN), N)]
+#define MIX_LOAD_V(gg)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                          \
+    const f32x4m *src = reinterpret_cast<const f32x4m *>(V) + min((gg) * TN + i, N - 1) * (int64_t)nf4;     \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) pv[i][q] = src[min(lane + 64 * q, nf4 - 1)];            \
+  }
+#define MIX_LOAD_IDX(np, ur, mp)                                                                            \
+  {                                                                                                         \
+    const int32_t a0 = __builtin_amdgcn_readlane(np, 0), a1 = __builtin_amdgcn_readlane(np, TN);            \
+    const int32_t ci = max(min(a0 + lane, a1 - 1), 0);                                                      \
+    ur = urel[ci];                                                                                          \
+    mp = mpos ? mpos[ci] : ci;                                                                              \
+    if (ADD) {                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                      \
+        const int32_t b0 = __builtin_amdgcn_readlane(np, i), b1 = __builtin_amdgcn_readlane(np, i + 1);     \
+        _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) pa_n1[i][reg] =                                 \
+            addend[(int64_t)max(min(b0 + 4 * kq + reg, b1 - 1), 0) * ldA + min(m, F - 1)];                  \
+      }                                                                                                     \
+    }                                                                                                       \
+  }
+  f32x4m pv[TN][NQ];
+  float pa_n1[TN][4], pa_cur[TN][4];
+  int32_t np_cur = MIX_LOAD_NP(g), np_n1 = MIX_LOAD_NP(g + nwaves);
+  int32_t ur_cur, mp_cur, ur_n1, mp_n1;
+  MIX_LOAD_IDX(np_cur, ur_n1, mp_n1)
+  MIX_LOAD_V(g)
+  for (; g < ngroups; g += nwaves) {
+    const int32_t np_now = np_cur;
+    const int32_t cbase = __builtin_amdgcn_readlane(np_now, 0), cend = __builtin_amdgcn_readlane(np_now, TN);
+    const int32_t np_n2 = MIX_LOAD_NP(g + 2 * nwaves);
+    ur_cur = ur_n1;
+    mp_cur = mp_n1;
+    bool near = cend - cbase <= 64;  // wave uniform
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      if (ADD) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) pa_cur[i][reg] = pa_n1[i][reg];
+        near = near && __builtin_amdgcn_readlane(np_now, i + 1) - __builtin_amdgcn_readlane(np_now, i) <= 16;
+      }
+      // this step's V blocks: registers -> the wave's tile
+      f32x4m *dst = reinterpret_cast<f32x4m *>(s_tile + i * BF);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (lane + 64 * q < nf4) dst[lane + 64 * q] = pv[i][q];
+    }
+    wave_lds_fence();
+    MIX_LOAD_V(g + nwaves)  // next step's blocks (the last step re-reads its own)
+    MIX_LOAD_IDX(np_n1, ur_n1, mp_n1)
+    np_cur = np_n1;
+    np_n1 = np_n2;
+    if (near) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int32_t c0 = __builtin_amdgcn_readlane(np_now, i), c1 = __builtin_amdgcn_readlane(np_now, i + 1);
+        if (c1 > c0)
+          mix_node_tiles<KS, true, ADD, OT>(c0, c1, cbase, ur_cur, mp_cur, pa_cur[i], urel, mpos, s_comp,
+                                            s_tile + i * BF, B, F, addend, ldA, M, ldM, m, kq);
+      }
+    } else {
+#pragma unroll 1
+      for (int i = 0; i < TN; ++i)
+        mix_node_tiles<KS, false, ADD, OT>(__builtin_amdgcn_readlane(np_now, i),
+                                           __builtin_amdgcn_readlane(np_now, i + 1), cbase, ur_cur, mp_cur,
+                                           pa_cur[0], urel, mpos, s_comp, s_tile + i * BF, B, F, addend, ldA, M,
+                                           ldM, m, kq);
+    }
+    wave_lds_fence();  // the tile is rewritten by the next step
+  }
+#undef MIX_LOAD_NP
+#undef MIX_LOAD_V
+#undef MIX_LOAD_IDX
+}
+
+// =====================================================================================
 // basis mix, forward, column-parallel form (B <= 64): thread = compact column c, lanes =
 // consecutive columns.  Index loads (urel / unode / mpos) are coalesced and independent, there
 // is no per-node loop (no divergence under degree skew, no dependent load chain); the V rows of
@@ -825,6 +1009,49 @@ int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32
 #undef MIXC_GO
     MRGCN_HIP_TRY(hipGetLastError());
     return MRGCN_OK;
+  }
+  {
+    static const bool mfma_on = !(getenv("MRGCN_MIX_MFMA") && atoi(getenv("MRGCN_MIX_MFMA")) == 0);
+    constexpr int tn = 2;  // nodes per wave step
+    const int KS = (B + 15) / 16;
+    const int NQ = (B * F + 255) / 256;  // 16-byte pieces of a V block per lane (<= KS)
+    const size_t lds =
+        ((size_t)((R * (KS * 16 + 4) + 3) & ~3) + (size_t)(kFwdTB / 64) * tn * B * F) * sizeof(float);
+    if (mfma_on && B <= 64 && F <= 16 && (B * F) % 4 == 0 && (((uintptr_t)V) & 15) == 0 &&
+        lds <= 150 * 1024) {
+      const int64_t want = ((N + tn - 1) / tn + (kFwdTB / 64) - 1) / (kFwdTB / 64);
+      int64_t grid = 256;  // one block of 16 waves per CU (LDS and the 128-register budget allow no second)
+      if (grid > want) grid = want;
+#define MIXM_GO(KS_, NQ_, TN_)                                                                              \
+  do {                                                                                                      \
+    auto kfn = addend ? k_mix_fwd_mfma<KS_, NQ_, TN_, true, OT> : k_mix_fwd_mfma<KS_, NQ_, TN_, false, OT>; \
+    static size_t lds_allowed = 48 * 1024;                                                                  \
+    if (lds > lds_allowed) {                                                                                \
+      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                        (int)lds));                                                         \
+      lds_allowed = lds;                                                                                    \
+    }                                                                                                       \
+    kfn<<<dim3((unsigned)grid), dim3(kFwdTB), lds, s>>>(p->nptr, p->urel, mpos_arg, V, comp, N, R, B, F,     \
+                                                        addend, ldA, M, ldM);                               \
+  } while (0)
+#define MIXM_TN(KS_, NQ_) MIXM_GO(KS_, NQ_, tn)
+      switch (KS * 8 + NQ) {
+        case 1 * 8 + 1: MIXM_TN(1, 1); break;
+        case 2 * 8 + 1: MIXM_TN(2, 1); break;
+        case 2 * 8 + 2: MIXM_TN(2, 2); break;
+        case 3 * 8 + 1: MIXM_TN(3, 1); break;
+        case 3 * 8 + 2: MIXM_TN(3, 2); break;
+        case 3 * 8 + 3: MIXM_TN(3, 3); break;
+        case 4 * 8 + 1: MIXM_TN(4, 1); break;
+        case 4 * 8 + 2: MIXM_TN(4, 2); break;
+        case 4 * 8 + 3: MIXM_TN(4, 3); break;
+        default: MIXM_TN(4, 4); break;
+      }
+#undef MIXM_TN
+#undef MIXM_GO
+      MRGCN_HIP_TRY(hipGetLastError());
+      return MRGCN_OK;
+    }
   }
   int acc = 0;
   for (int b0 = 0; b0 < B; b0 += 64) {

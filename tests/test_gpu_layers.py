@@ -264,6 +264,61 @@ def test_graph_captured_epoch_equals_eager(name):
         torch.testing.assert_close(states[0][k], states[1][k], rtol=1e-5, atol=1e-6, msg=k)
 
 
+@pytest.mark.parametrize("with_addend", [False, True])
+@pytest.mark.parametrize("B,F", [(4, 4), (16, 16), (20, 8), (32, 16), (40, 10), (48, 4), (48, 16), (33, 12),
+                                 (64, 4), (64, 8), (64, 12), (64, 16), (7, 6), (70, 8)])
+def test_basis_mix_forward_shapes_through_the_c_abi(B, F, with_addend):
+    """M[MPOS[c]] = addend[c] + comp[r_c] . V[j_c] for every instantiation of the matrix-core kernel (K steps
+    ceil(B / 16) x 16-byte pieces ceil(B F / 256)), the scalar kernels beyond its limits ((7, 6): B F not a
+    multiple of 4; (70, 8): B > 64), fp32 and bf16 operand rows, with a node of more than 64 columns (its step
+    leaves the prefetched range), nodes of 17..64 columns (more than one tile) and nodes without any column."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphPlan
+    N, R = 700, 90
+    rng = np.random.default_rng(B * 100 + F)
+    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, 1, F, 6 * N, 400)
+    # node 2 gets 85 columns, nodes 3..10 get 20..55 each; nodes 11..40 none at all
+    sizes = {2: 85, **{j: 20 + 5 * (j - 3) for j in range(3, 11)}}
+    extra_r = np.concatenate([rng.choice(R, size=n, replace=False) for n in sizes.values()])
+    extra_j = np.concatenate([np.full(n, j) for j, n in sizes.items()])
+    keep = ~np.isin(cols % N, np.arange(11, 41))
+    rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    rows = np.concatenate([rows, rng.integers(0, N, size=extra_r.size)])
+    cols = np.concatenate([cols, extra_r * N + extra_j])
+    vals = np.concatenate([vals, np.ones(extra_r.size, dtype=vals.dtype)])
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals),
+                                 (N, R * N)).coalesce().cuda()
+    plan = GraphPlan(At, N, R)
+    urel, unode = plan.export(L.ARR_UREL).astype(np.int64), plan.export(L.ARR_UNODE).astype(np.int64)
+    mpos = plan.export(L.ARR_MPOS).astype(np.int64)
+    per_node = np.bincount(unode, minlength=N)
+    assert per_node.max() > 64 and ((per_node > 16) & (per_node <= 64)).sum() >= 8 and (per_node == 0).sum() >= 30
+    nc = plan.ncols
+    V = rng.standard_normal((N, B, F)).astype(np.float32)
+    comp = rng.standard_normal((R, B)).astype(np.float32)
+    ldA = (F + 3) // 4 * 4
+    add = rng.standard_normal((nc, ldA)).astype(np.float32)
+    want = np.einsum("cb,cbf->cf", comp.astype(np.float64)[urel], V.astype(np.float64)[unode])
+    if with_addend:
+        want = want + add[:, :F]
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    Vt, ct, at = (torch.from_numpy(x).cuda() for x in (V, comp, add))
+    for sfx, dt, ld, tol in (("f32", torch.float32, ldA, 2e-5), ("bf16", torch.bfloat16, (F + 3) // 4 * 4, 1e-2)):
+        M = torch.full((plan.nop, ld), 7.0, dtype=dt, device="cuda")
+        rc = getattr(lib, "mrgcn_basis_mix_fwd_" + sfx)(
+            plan.handle, Vt.data_ptr(), ct.data_ptr(), B, F, at.data_ptr() if with_addend else 0, ldA, M.data_ptr(),
+            ld, s)
+        if sfx == "bf16" and B > 64:   # (a second pass over the bases would round the operand twice)
+            assert rc != 0
+            continue
+        L.check(rc)
+        got = M.float().cpu().numpy()
+        scale = np.abs(want).max()
+        np.testing.assert_allclose(got[mpos][:, :F], want, rtol=tol, atol=tol * scale, err_msg=sfx)
+        assert (got[:, F:] == 7.0).all() or (got[:, F:] == 0.0).all()   # padding: untouched (or zeroed)
+
+
 @pytest.mark.parametrize("zero_frac", [0.0, 0.5, 0.93, 1.0])
 @pytest.mark.parametrize("N,R,B,F,hub", [(900, 7, 40, 10, 500), (333, 5, 3, 11, 0), (640, 9, 64, 16, 200),
                                          (500, 6, 70, 12, 0)])  # the last one: B > 64, two-kernel fallback

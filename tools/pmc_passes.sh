@@ -11,6 +11,7 @@ mem=(
  "TCC_HIT_sum TCC_MISS_sum"
  "TCC_REQ_sum TCP_TCC_READ_REQ_sum"
  "TCP_TOTAL_CACHE_ACCESSES_sum"
+ "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
 )
 sq=(
  "SQ_WAVES SQ_BUSY_CYCLES"
