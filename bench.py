@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6.29 TB/s measured copy
+PARTITIONED_WORKLOADS = ("synth10m",)  # BASELINE.json configs[4]: one graph over the GPUs of the node
 
 
 def parse():
@@ -53,12 +54,15 @@ def parse():
     ap.add_argument("--operand", default="f32", choices=["f32", "bf16"],
                     help="storage type of the fused engine's compact operand (bf16: SURVEY §8d's extra run)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-scale", type=float, default=1.0 / 64, help="fraction of the workload the CPU baseline runs")
+    ap.add_argument("--cpu-scale", type=float, default=1.0 / 8,
+                    help="fraction of the workload the CPU baseline runs (a second run takes a quarter of it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal-spmm", action="store_true")
-    ap.add_argument("--partition", action="store_true",
+    ap.add_argument("--partition", dest="partition", action="store_true", default=None,
                     help="N > 1: node-partition ONE graph over the ranks (strong scaling, mrgcn_amd.partition) "
-                         "instead of running N replicas")
+                         "instead of running N replicas.  Default: on for the workloads BASELINE.json names as "
+                         "partitioned (synth10m = config 5), off (replicas, weak scaling) for the others")
+    ap.add_argument("--no-partition", dest="partition", action="store_false")
     ap.add_argument("--spmm-iters", type=int, default=30)
     return ap.parse_args()
 
@@ -86,41 +90,59 @@ def event_time_ms(fn, iters, stream_ptr):
 
 
 def cpu_baseline(args, shape_name):
-    """The reference's ATen op sequence (oracle/aten_literal.py, pinned against the reference's
-    golden vectors) timed on this host's cores on a bounded sample of the workload.  The thread
-    count is the best of a short sweep (the reference leaves torch's default = all cores, which
-    on a many-core host is far slower for these small sparse ops)."""
-    import torch
+    """The reference's ATen op sequence (oracle/aten_literal.py, pinned against the reference's golden vectors)
+    timed on this host's cores on bounded samples of the workload: the thread count is the best of a short sweep
+    on a 1/64 sample (the reference leaves torch's default = all cores, which on a many-core host is far slower
+    for these small sparse ops); the epoch is then timed at TWO scales (--cpu-scale, default 1/8, and a quarter
+    of it) so that the linear extrapolation to the full graph is shown by the pair instead of assumed."""
+    import torch  # noqa: F401
     from mrgcn_amd import synth
     from oracle import aten_literal as AL
-    sc = args.cpu_scale * args.scale
-    g = synth.make_graph(shape_name, seed=args.seed, scale=sc, value_mode=args.value_mode)
     sh = synth.SHAPES[shape_name]
     dims = synth.layer_dims(shape_name)
     featureless = sh["x_width"] == 0
-    rng = np.random.default_rng(args.seed)
-    X = None if featureless else rng.standard_normal((g.num_nodes, sh["x_width"])).astype(np.float32)
-    idx, y = synth.make_labels(shape_name, g.num_nodes, args.seed, sc)
     cores = os.cpu_count() or 1
+
+    def sample(sc):
+        g = synth.make_graph(shape_name, seed=args.seed, scale=sc, value_mode=args.value_mode)
+        rng = np.random.default_rng(args.seed)
+        X = None if featureless else rng.standard_normal((g.num_nodes, sh["x_width"])).astype(np.float32)
+        idx, y = synth.make_labels(shape_name, g.num_nodes, args.seed, sc)
+        return g, X, idx, y
+
+    def timed(smp, steps, threads):
+        g, X, idx, y = smp
+        return AL.time_epochs(dims, g.num_relations, g.num_nodes, sh["bases"], g.rows, g.cols, g.vals, X, idx, y,
+                              featureless, warmup=1, steps=steps, threads=threads, seed=args.seed)
+
+    big = args.cpu_scale * args.scale
+    small = big / 4
+    probe = sample(min(big, args.scale / 64))
     t_start = time.time()
     sweep = {}
     for th in sorted({min(c, cores) for c in (8, 16, 32, 64)}):
-        ms, _ = AL.time_epochs(dims, g.num_relations, g.num_nodes, sh["bases"], g.rows, g.cols, g.vals,
-                               X, idx, y, featureless, warmup=1, steps=1, threads=th, seed=args.seed)
-        sweep[th] = ms
-        if time.time() - t_start > 40:
+        sweep[th], _ = timed(probe, 1, th)
+        if time.time() - t_start > 30:
             break
     best = min(sweep, key=sweep.get)
-    ms, threads = AL.time_epochs(dims, g.num_relations, g.num_nodes, sh["bases"], g.rows, g.cols, g.vals,
-                                 X, idx, y, featureless, warmup=1, steps=3, threads=best, seed=args.seed)
+    del probe
+    s_small = sample(small)
+    ms_small, _ = timed(s_small, 3, best)
+    n_small = s_small[0].num_nodes
+    del s_small
+    s_big = sample(big)
+    g = s_big[0]
+    ms, threads = timed(s_big, 2, best)
     return {
-        "value": ms / sc, "unit": "ms/epoch", "cores": threads, "kind": "port",
-        "sample": (f"{shape_name} x {sc:.4g} (N={g.num_nodes}, R={g.num_relations}, nnz={g.nnz}): "
-                   f"{ms:.1f} ms/epoch over 3 epochs after 1 warm-up with the reference's literal "
-                   f"ATen op sequence on {threads} of {cores} host threads (best of sweep "
-                   f"{ {k: round(v, 1) for k, v in sweep.items()} }); value = measured / {sc:.4g} "
-                   "(linear extrapolation to the full graph)"),
-        "measured_ms": ms, "sample_scale": sc, "host_cores": cores,
+        "value": ms / big, "unit": "ms/epoch", "cores": threads, "kind": "port",
+        "sample": (f"{shape_name} x {big:.4g} (N={g.num_nodes}, R={g.num_relations}, nnz={g.nnz}): {ms:.1f} ms/epoch "
+                   f"over 2 epochs after 1 warm-up with the reference's literal ATen op sequence on {threads} of "
+                   f"{cores} host threads (best of a sweep on a 1/64 sample: "
+                   f"{ {k: round(v, 1) for k, v in sweep.items()} }); value = measured / {big:.4g}.  Second scale "
+                   f"{shape_name} x {small:.4g} (N={n_small}): {ms_small:.1f} ms/epoch over 3 epochs, i.e. "
+                   f"{ms_small / small:.0f} ms/epoch extrapolated — the pair shows how linear the extrapolation is"),
+        "measured_ms": ms, "sample_scale": big, "host_cores": cores,
+        "second_scale": {"sample_scale": small, "measured_ms": ms_small, "extrapolated_ms": ms_small / small},
     }
 
 
@@ -193,41 +215,43 @@ def main():
         order, inv = reorder.label_reach_order(g.rows, g.cols, N, R, idx_np, hops=len(dims))
         g.rows, g.cols = reorder.relabel_coo(g.rows, g.cols, N, inv)
         idx_np = inv[idx_np]
-    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
-                                (N, R * N)).to(dev)
+    if args.partition is None:
+        args.partition = name in PARTITIONED_WORKLOADS
+    partitioned = args.partition and world > 1
     torch.manual_seed(args.seed)
     modules = [(i, o, "mrgcn", torch.nn.ReLU() if li < len(dims) - 1 else None)
                for li, (i, o) in enumerate(dims)]
-    model = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
-    model.set_engine(args.engine)
-    model.set_operand_dtype(args.operand)
-    X = None if featureless else torch.randn((N, sh["x_width"]), device=dev)
-    idx = torch.from_numpy(idx_np).to(dev)
-    tgt = torch.from_numpy(y_np).to(dev)
-    opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=args.graph)
-    plan = plan_of(A, N, R)
-    setup_s = time.time() - t0
+    if not partitioned:
+        A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                    (N, R * N)).to(dev)
+        model = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
+        model.set_engine(args.engine)
+        model.set_operand_dtype(args.operand)
+        X = None if featureless else torch.randn((N, sh["x_width"]), device=dev)
+        idx = torch.from_numpy(idx_np).to(dev)
+        tgt = torch.from_numpy(y_np).to(dev)
+        opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=args.graph)
+        plan = plan_of(A, N, R)
 
-    def step():
-        return train_step(model, lambda: model(X, A), idx, tgt, opt)
-
-    partitioned = args.partition and world > 1
-    if partitioned:
-        # strong scaling: rank g owns node range g, its weight_I rows / Adam state and its columns of A
+        def step():
+            return train_step(model, lambda: model(X, A), idx, tgt, opt)
+    else:
+        # strong scaling: rank g owns node range g, its weight_I rows / Adam state and its columns of A; only
+        # the rank's shard of the model and of the plan is ever built
         from mrgcn_amd.partition import NodePartition, PartitionedRGCN, partitioned_train_step
-        del model, opt, plan, A
-        torch.cuda.empty_cache()
         part = NodePartition(N, world, rank)
         pmodel = PartitionedRGCN(modules, R, N, B, featureless, False, part).to(dev)
         pmodel.sync_replicated()
         plan = pmodel.build_plan(g.rows, g.cols, g.vals, dev)
-        Xl = None if featureless else part.shard_rows(X)
+        Xl = None if featureless else part.shard_rows(torch.randn((N, sh["x_width"]), device=dev))
         popt = ClipAdam(pmodel.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
         popt.set_distributed(None, pmodel.sharded_parameters())
         model = pmodel
+        idx = torch.from_numpy(idx_np)
 
-        def step():  # noqa: F811
+        def step():
             return partitioned_train_step(pmodel, Xl, idx_np, y_np, popt)
+    setup_s = time.time() - t0
 
     def barrier():
         mdist.barrier(dev)
@@ -267,15 +291,22 @@ def main():
         t_c = event_time_ms(lambda: plan.spmm(L.VIEW_COMPACT, M, F=F, out=Y), args.spmm_iters, stream)
         bytes_alg = plan.spmm_bytes(F)
         ach = bytes_alg / (t_c * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/pmc_passes.sh ->
+        # tools/make_spmm_pmc_json.py); the file records the digest of the kernel's sources and is only quoted
+        # when that equals this tree's — otherwise traffic is null
+        traffic, traffic_note = None, "no counter file for this workload"
         try:
+            from mrgcn_amd.build import source_digest
             pm = json.load(open(os.path.join(ROOT, "profiles", "spmm_pmc_latest.json")))
             if pm.get("workload") == name and pm.get("F") == F and args.scale == 1.0:
-                traffic = pm["hbm_bytes_per_launch"]
-        except Exception:  # noqa: BLE001
-            pass
+                if pm.get("source_digest") == source_digest():
+                    traffic, traffic_note = pm["hbm_bytes_per_launch"], "profiles/spmm_pmc_latest.json (PMC pass of this tree)"
+                else:
+                    traffic_note = "profiles/spmm_pmc_latest.json predates the current spmm.hip / plan.hip: not quoted"
+        except Exception as e:  # noqa: BLE001
+            traffic_note = "counter file unreadable: " + str(e)[:80]
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                     "kernel": "mrgcn::k_spmm3<G,VEC> (+k_spmm3_finalize) on the compact view, F=%d, ld=%d" % (F, ld),
                     "algorithmic_bytes": bytes_alg, "avg_ms": t_c}
         extra = {}

@@ -367,6 +367,27 @@ int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32
 /* out[n] = sum_m X[m*ld + n]  (bias gradients) */
 int mrgcn_colsum_f32(const float *X, int64_t ld, int32_t M, int32_t N, float *out, void *stream);
 
+/* ---- mini-batch frontier on the resident CSR of the stacked adjacency ---------------------
+ * Replaces, per layer of a batch, the host loops of mrgcn/data/batch.py:185-263 (`A[sample_idx]`,
+ * getNeighboursSparse :233-249, getAdjacencyNodeColumnIdx :251-256 + sliceSparseCOO :258-270).  indptr / indices:
+ * int64 CSR of A (N x R*N) in HBM; sample: int64 [n_sample] row ids.  No allocation inside: the caller provides the
+ * workspace and — after reading the two sizes row_off[n_sample] (entries) and node_pos[num_nodes] (neighbours) —
+ * the outputs.
+ *   count: row_off [n_sample+1] exclusive scan of the rows' lengths; node_pos [num_nodes+1] exclusive scan of
+ *          "node j is the source node of some entry of these rows".
+ *   emit : COO of the slice in the order A[sample].nonzero() has (row-major, stored column order): out_row = position
+ *          in `sample`, out_col = global column, out_val (nullable) = the stored value as float32 or truncated to
+ *          int8 (the reference's boundary cast); out_col_sliced (nullable) = r * n_neighbours + node_pos[j]: the
+ *          column sliceSparseCOO gives the entry; neighbours (nullable) [n_neighbours] ascending node ids. */
+size_t mrgcn_frontier_workspace_bytes(int64_t num_nodes, int64_t n_sample);
+int mrgcn_frontier_count(const int64_t *indptr, const int64_t *indices, int64_t num_nodes, const int64_t *sample,
+                         int64_t n_sample, int64_t *row_off, int32_t *node_pos, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int mrgcn_frontier_emit(const int64_t *indptr, const int64_t *indices, const float *data, int64_t num_nodes,
+                        const int64_t *sample, int64_t n_sample, const int64_t *row_off, const int32_t *node_pos,
+                        int64_t n_neighbours, int32_t value_dtype, int64_t *out_row, int64_t *out_col,
+                        void *out_val, int64_t *out_col_sliced, int64_t *neighbours, void *stream);
+
 /* ---- timing helpers (HIP events on the caller's stream; used by bench.py) ------ */
 int mrgcn_event_create(void **event);
 int mrgcn_event_destroy(void *event);

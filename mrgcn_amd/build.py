@@ -19,6 +19,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_digest(names=("spmm.hip", "plan.hip", "common.hpp")) -> str:
+    """sha256 over the named csrc files: counter files under profiles/ record it, bench.py only quotes a
+    counter-derived figure whose digest equals the tree's."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

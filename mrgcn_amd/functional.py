@@ -205,7 +205,7 @@ class _RgcnLayer(torch.autograd.Function):
         with torch.cuda.device(dev):
             addend, ldA = 0, 0
             if X is not None:
-                Xc = X.contiguous()
+                Xc = X if (X.dim() == 2 and X.stride(1) == 1) else X.contiguous()  # row-strided X is taken as it is
                 Wc = W_F.contiguous()
                 if weight_I is not None:
                     # feature term in plain compact order (sequential writes); the input-term

@@ -217,6 +217,36 @@ class PartitionedRGCN(nn.Module):
             if p.grad is not None:
                 all_reduce_sum_(p.grad, self.group)
 
+    # -- overlapped form: every replicated gradient is reduced as soon as autograd has accumulated it, on the
+    #    communication stream, while the backward of the layers below it still computes (the dominant local work
+    #    of a step — dM = A^T dY, the node table's dV, the transforms' dX / dW — needs none of these sums)
+    def begin_overlapped_grad_reduce(self):
+        """Arms post-accumulate hooks on the replicated parameters; returns a `finish()` that waits for the
+        reductions (call it before the optimizer reads the gradients).  RCCL: asynchronous all-reduce per
+        parameter on the process group's own stream; gloo (tests): the staged blocking form inside the hook —
+        same arithmetic, no overlap."""
+        pending, hooks = [], []
+        nccl = dist.get_backend(self.group) == "nccl"
+
+        def hook(p):
+            if p.grad is None:
+                return
+            if nccl:
+                pending.append(dist.all_reduce(p.grad, group=self.group, async_op=True))
+            else:
+                all_reduce_sum_(p.grad, self.group)
+
+        for q in self.replicated_parameters():
+            hooks.append(q.register_post_accumulate_grad_hook(hook))
+
+        def finish():
+            for h in hooks:
+                h.remove()
+            for w in pending:
+                w.wait()   # orders the current stream after the reduction (no host block with RCCL)
+
+        return finish
+
 
 class _NoBias:
     """View of a layer without its bias (added after the reduction, once)."""
@@ -259,11 +289,12 @@ def _backward_and_step(model, local, optimizer, row_sparse):
     sparse_ok = (row_sparse is not False and _ROW_SPARSE_DEFAULT and isinstance(optimizer, ClipAdam)
                  and all(float(g["weight_decay"]) == 0.0 for g in optimizer.param_groups))
     prev = Fn.row_sparse_weight_grad(sparse_ok)
+    finish = model.begin_overlapped_grad_reduce()
     try:
         local.backward()
     finally:
         Fn.row_sparse_weight_grad(prev)
-    model.allreduce_replicated_grads()
+        finish()
     optimizer.step()
 
 

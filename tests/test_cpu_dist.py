@@ -106,3 +106,44 @@ def test_partition_collectives_gloo_world2():
         assert ag == (torch.arange(S * F).view(S, F).float().tolist()
                       + (torch.arange(S * F).view(S, F).float() + 100).tolist())
         assert ar == [3.0]
+
+
+def _hook_worker(rank, world, port, out):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from mrgcn_amd.partition import NodePartition, PartitionedRGCN
+    dist.init_process_group("gloo")
+    torch.manual_seed(0)
+    mods = [(0, 6, "mrgcn", torch.nn.ReLU()), (6, 3, "mrgcn", None)]
+    model = PartitionedRGCN(mods, 4, 10, 2, True, True, NodePartition(10, world, rank))
+    finish = model.begin_overlapped_grad_reduce()
+    # rank r contributes (r + 1) to every replicated gradient and (r + 1) * 10 to its own shard
+    loss = sum((p * float(rank + 1)).sum() for p in model.replicated_parameters()) \
+        + sum((p * float(10 * (rank + 1))).sum() for p in model.sharded_parameters())
+    loss.backward()
+    finish()
+    rep = sorted({float(v) for p in model.replicated_parameters() for v in p.grad.flatten().tolist()})
+    sh = sorted({float(v) for p in model.sharded_parameters() for v in p.grad.flatten().tolist()})
+    # a second backward after finish() must not reduce again (hooks removed)
+    for p in model.parameters():
+        p.grad = None
+    sum((p * 1.0).sum() for p in model.replicated_parameters()).backward()
+    again = sorted({float(v) for p in model.replicated_parameters() for v in p.grad.flatten().tolist()})
+    out[rank] = (rep, sh, again)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_overlapped_reduction_of_replicated_gradients_gloo_world2():
+    """partition.py's backward: replicated gradients are summed over the ranks from post-accumulate hooks (on
+    RCCL: asynchronously, under the rest of the backward), sharded ones stay local, and the hooks are gone after
+    finish()."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_hook_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in (0, 1):
+        rep, sh, again = out[r]
+        assert rep == [3.0]                    # 1 + 2 on both ranks
+        assert sh == [10.0 * (r + 1)]          # never communicated
+        assert again == [1.0]

@@ -166,3 +166,44 @@ def test_partitioned_link_prediction_equals_single_gpu():
         np.testing.assert_allclose(out[r][0], losses, rtol=2e-4, atol=2e-5)
         d = np.abs(out[r][1] - model.relations.detach().cpu().numpy())
         assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.07
+
+
+@pytest.mark.timeout(900)
+def test_bench_runs_the_partitioned_engine_for_the_partitioned_workload():
+    """`bench.py --gpus 2` on the workload BASELINE names as partitioned (config 5, here shrunk): launched exactly
+    as the driver does (torch.distributed.run, one process per rank; two ranks on the one GPU of this box, so
+    the collectives go over gloo), it must take the node-partitioned engine without being told to, say so in
+    the line, and reach the loss of the single-process run of the same workload."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "synth10m", "--scale", "0.002", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+              "--no-literal-spmm", "--no-renumbered-extra", "--spmm-iters", "3"]
+    env = dict(os.environ, MRGCN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    multi = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                            os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                           capture_output=True, text=True, cwd=root, env=env, timeout=800)
+    assert multi.returncode == 0, multi.stderr[-2000:]
+    lines = [ln for ln in multi.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, multi.stdout[-2000:]          # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    assert j["config"]["parallelism"] == "node-partitioned x2"
+    assert j["roofline"]["frac"] > 0 and j["value"] > 0
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--no-graph"] + common,
+                            capture_output=True, text=True, cwd=root, timeout=800)
+    assert single.returncode == 0, single.stderr[-2000:]
+    j1 = json.loads([ln for ln in single.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j1["config"]["parallelism"] == "1 GPU" and j1["scaling"] == "weak"
+    # different initial values (every rank draws its own shard), same problem: both sit at the untrained loss
+    assert abs(j["extra"]["final_loss"] - j1["extra"]["final_loss"]) < 0.05 * abs(j1["extra"]["final_loss"])
+    # an explicit --no-partition runs replicas
+    rep = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--no-partition"] + common,
+                         capture_output=True, text=True, cwd=root, env=env, timeout=800)
+    assert rep.returncode == 0, rep.stderr[-2000:]
+    jr = json.loads([ln for ln in rep.stdout.splitlines() if ln.startswith("{")][-1])
+    assert jr["config"]["parallelism"] == "replicas x2" and jr["scaling"] == "weak"

@@ -6,8 +6,12 @@ HBM bytes per launch follow MI355X_MICROARCH.md §HBM: reads = TCC_EA0_RDREQ req
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mrgcn_amd.build import source_digest  # noqa: E402
 
 
 def avg(dirpat, kernel_sub):
@@ -29,7 +33,7 @@ def main():
     rd = c.get("TCC_EA0_RDREQ_32B_sum", 0) * 32 + c.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 \
         + c.get("TCC_EA0_RDREQ_128B_sum", 0) * 128
     wr = c.get("WRITE_SIZE", 0) * 1024
-    out = {"workload": "am", "F": 10, "kernel": kernel, "counters": c,
+    out = {"workload": "am", "F": 10, "kernel": kernel, "source_digest": source_digest(), "counters": c,
            "read_bytes_from_rdreq_sizes": rd, "read_bytes_fetch_size_x2": c.get("FETCH_SIZE", 0) * 1024 * 2,
            "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
     json.dump(out, sys.stdout, indent=1)
