@@ -378,7 +378,8 @@ int mrgcn_colsum_f32(const float *X, int64_t ld, int32_t M, int32_t N, float *ou
  *   emit : COO of the slice in the order A[sample].nonzero() has (row-major, stored column order): out_row = position
  *          in `sample`, out_col = global column, out_val (nullable) = the stored value as float32 or truncated to
  *          int8 (the reference's boundary cast); out_col_sliced (nullable) = r * n_neighbours + node_pos[j]: the
- *          column sliceSparseCOO gives the entry; neighbours (nullable) [n_neighbours] ascending node ids. */
+ *          column sliceSparseCOO gives the entry; neighbours (nullable) [n_neighbours] ascending node ids.
+ *          (A slice without entries writes nothing: its output pointers are not looked at.) */
 size_t mrgcn_frontier_workspace_bytes(int64_t num_nodes, int64_t n_sample);
 int mrgcn_frontier_count(const int64_t *indptr, const int64_t *indices, int64_t num_nodes, const int64_t *sample,
                          int64_t n_sample, int64_t *row_off, int32_t *node_pos, void *workspace,

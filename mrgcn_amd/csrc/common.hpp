@@ -101,6 +101,7 @@ struct mrgcn_plan {
   int64_t num_rows = 0, num_nodes = 0, num_relations = 0, nnz = 0, ncols = 0;
   int64_t max_row_nnz = 0, max_col_nnz = 0;
   int64_t device_bytes = 0;
+  hipStream_t build_stream = nullptr;  // the plan's arrays are pool allocations ordered on this stream
   int device = 0;
   // CSR over output rows
   int32_t *rowptr = nullptr, *lcol = nullptr, *ccol = nullptr, *rowidx = nullptr;

@@ -153,7 +153,7 @@ int mrgcn_frontier_emit(const int64_t *indptr, const int64_t *indices, const flo
                         const int64_t *sample, int64_t n_sample, const int64_t *row_off, const int32_t *node_pos,
                         int64_t n_neighbours, int32_t value_dtype, int64_t *out_row, int64_t *out_col,
                         void *out_val, int64_t *out_col_sliced, int64_t *neighbours, void *stream) {
-  MRGCN_REQUIRE(indptr && indices && row_off && node_pos && out_row && out_col, "NULL");
+  MRGCN_REQUIRE(indptr && indices && row_off && node_pos, "NULL");  // (outputs of an entry-less slice may be NULL)
   MRGCN_REQUIRE(!out_val || data, "values requested without data");
   MRGCN_REQUIRE(value_dtype == MRGCN_VAL_F32 || value_dtype == MRGCN_VAL_I8, "value_dtype");
   MRGCN_REQUIRE(num_nodes > 0 && n_sample >= 0 && n_neighbours >= 0, "sizes");

@@ -308,11 +308,31 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
   }
 }
 
-struct Scratch {  // frees its allocations on scope exit
+// Device memory of a plan build comes from the device's stream-ordered pool (hipMallocAsync): building the plans of
+// re-sampled mini-batch slices over and over then reuses the same blocks instead of paying a driver allocation and
+// an implicit device synchronisation (hipFree) per array.  The pool keeps up to kPoolKeep bytes between builds.
+constexpr uint64_t kPoolKeep = 4ull << 30;
+
+hipError_t pool_alloc(void **p, size_t bytes, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    int dev = 0;
+    hipMemPool_t pool;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+      uint64_t keep = kPoolKeep;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    configured = true;
+  }
+  return hipMallocAsync(p, bytes, s);
+}
+
+struct Scratch {  // returns its allocations to the pool on scope exit, ordered after the build's work on `s`
+  hipStream_t s = nullptr;
   std::vector<void *> ptrs;
-  ~Scratch() { for (void *p : ptrs) (void)hipFree(p); }
+  ~Scratch() { for (void *p : ptrs) (void)hipFreeAsync(p, s); }
   template <typename T> hipError_t alloc(T **p, int64_t n) {
-    hipError_t e = hipMalloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(T));
+    hipError_t e = pool_alloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(T), s);
     if (e == hipSuccess) ptrs.push_back(*p);
     return e;
   }
@@ -320,7 +340,7 @@ struct Scratch {  // frees its allocations on scope exit
 
 template <typename T> hipError_t plan_alloc(mrgcn_plan *p, T **dst, int64_t n) {
   size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T);
-  hipError_t e = hipMalloc((void **)dst, bytes);
+  hipError_t e = pool_alloc((void **)dst, bytes, p->build_stream);
   if (e == hipSuccess) p->device_bytes += (int64_t)bytes;
   return e;
 }
@@ -341,6 +361,7 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
                int32_t *n_chunks, int64_t *max_len, int threshold = kLongThreshold, int chunk = kChunk,
                int cap = 0) {
   Scratch sc;
+  sc.s = s;
   int32_t *is_long, *nchunk, *long_pos, *chunk_pos, *d_max;
   MRGCN_HIP_TRY(sc.alloc(&is_long, rows + 1));
   MRGCN_HIP_TRY(sc.alloc(&nchunk, rows + 1));
@@ -390,6 +411,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   static const bool rep_default = getenv("MRGCN_REPLICATE") && atoi(getenv("MRGCN_REPLICATE")) != 0;
   const bool replicate = !(flags & MRGCN_PLAN_NO_REPLICATE) && ((flags & MRGCN_PLAN_REPLICATE) || rep_default);
   Scratch sc;
+  sc.s = s;
   int64_t *keys, *keys_s, *key2, *key2_s;
   float *fv;
   int32_t *eidx, *eidx_s, *head, *cid1;
@@ -746,8 +768,11 @@ void free_plan(mrgcn_plan *p) {
                   p->r3_long_row, p->r3_long_cptr, p->r3_chunk_beg, p->r3_chunk_end, p->r3_chunk_row,
                   p->q_long_row, p->q_long_cptr, p->q_chunk_beg, p->q_chunk_end, p->q_chunk_row, p->rowmap, p->ptr3,
                   p->rep_src, p->rep_dst, p->partials};
+  // the caller guarantees nothing that uses the plan is still to be SUBMITTED; work already in flight on any
+  // stream is waited for (what hipFree did implicitly), then the blocks go back to the pool
+  (void)hipDeviceSynchronize();
   for (void *q : ptrs)
-    if (q) (void)hipFree(q);
+    if (q) (void)hipFreeAsync(q, nullptr);
   delete p;
 }
 
@@ -777,6 +802,7 @@ int mrgcn_plan_create(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, 
   p->num_nodes = num_nodes;
   p->num_relations = num_relations;
   (void)hipGetDevice(&p->device);
+  p->build_stream = (hipStream_t)stream;
   int rc = mrgcn::create_impl(p, nnz, coo_rows, coo_cols, coo_vals, val_dtype, flags, (hipStream_t)stream);
   if (rc != MRGCN_OK) {
     mrgcn::free_plan(p);
@@ -798,9 +824,9 @@ int mrgcn_plan_create_csr(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nod
   int64_t *rows = nullptr, *cols = nullptr;
   float *vals = nullptr;
   const size_t n = (size_t)(nnz > 0 ? nnz : 1);
-  hipError_t e1 = hipMalloc((void **)&rows, n * sizeof(int64_t));
-  hipError_t e2 = hipMalloc((void **)&cols, n * sizeof(int64_t));
-  hipError_t e3 = hipMalloc((void **)&vals, n * sizeof(float));
+  hipError_t e1 = mrgcn::pool_alloc((void **)&rows, n * sizeof(int64_t), s);
+  hipError_t e2 = mrgcn::pool_alloc((void **)&cols, n * sizeof(int64_t), s);
+  hipError_t e3 = mrgcn::pool_alloc((void **)&vals, n * sizeof(float), s);
   int rc = MRGCN_OK;
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
     mrgcn::set_error("plan_create_csr: out of device memory for the COO expansion");
@@ -812,10 +838,9 @@ int mrgcn_plan_create_csr(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nod
     rc = mrgcn_plan_create(plan, num_rows, num_nodes, num_relations, nnz, rows, cols, vals, MRGCN_VAL_F32,
                            flags, stream);
   }
-  (void)hipStreamSynchronize(s);
-  (void)hipFree(rows);
-  (void)hipFree(cols);
-  (void)hipFree(vals);
+  if (rows) (void)hipFreeAsync(rows, s);  // stream ordered: after the build's last read
+  if (cols) (void)hipFreeAsync(cols, s);
+  if (vals) (void)hipFreeAsync(vals, s);
   return rc;
 }
 

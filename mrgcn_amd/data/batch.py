@@ -285,23 +285,55 @@ class DeviceCSR:
         self.indptr = torch.from_numpy(np.ascontiguousarray(A.indptr, dtype=np.int64)).to(device)
         self.indices = torch.from_numpy(np.ascontiguousarray(A.indices, dtype=np.int64)).to(device)
         self.data = torch.from_numpy(np.ascontiguousarray(A.data, dtype=np.float32)).to(device)
+        self._ws = None  # workspace of the frontier kernels, grown on demand and reused by every batch
 
-    def rows(self, sample_idx: torch.Tensor):
-        """COO (row-in-sample, global column, value) of the rows `sample_idx`, in the order
-        `A[sample_idx].nonzero()` has on the host (row-major, stored column order)."""
-        lo, hi = self.indptr[sample_idx], self.indptr[sample_idx + 1]
-        n = hi - lo
-        total = int(n.sum())
-        row = torch.repeat_interleave(torch.arange(sample_idx.numel(), device=n.device), n)
-        start = torch.cumsum(n, 0) - n
-        pos = torch.arange(total, device=n.device) - start[row] + lo[row]
-        return row, self.indices[pos], self.data[pos]
+    def workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.indptr.device)
+        return self._ws
+
+    def frontier(self, sample: torch.Tensor, value_mode: str = "ref_int8"):
+        """One layer of a batch through the frontier kernels (csrc/minibatch.hip; C ABI mrgcn_frontier_count /
+        _emit): the rows `sample` of A as COO (row in sample, global column, value), the same entries' columns
+        in the sliced numbering r * n_b + position(node), and the ascending neighbour list.  One two-word
+        readback (the output sizes) is the only host synchronisation."""
+        from .. import _lib as L
+        lib = L.load()
+        dev = self.indptr.device
+        N = self.shape[0]
+        sample = sample.to(dev, torch.long).contiguous()
+        n_s = int(sample.numel())
+        ws = self.workspace(lib.mrgcn_frontier_workspace_bytes(N, n_s))
+        row_off = torch.empty(n_s + 1, dtype=torch.long, device=dev)
+        node_pos = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            L.check(lib.mrgcn_frontier_count(self.indptr.data_ptr(), self.indices.data_ptr(), N, sample.data_ptr(),
+                                             n_s, row_off.data_ptr(), node_pos.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), s), "mrgcn_frontier_count")
+            sizes = torch.stack([row_off[-1], node_pos[-1].long()]).cpu()   # the one readback
+            nnz, n_b = int(sizes[0]), int(sizes[1])
+            row = torch.empty(nnz, dtype=torch.long, device=dev)
+            col = torch.empty(nnz, dtype=torch.long, device=dev)
+            col_sl = torch.empty(nnz, dtype=torch.long, device=dev)
+            i8 = value_mode == "ref_int8"
+            val = torch.empty(nnz, dtype=torch.int8 if i8 else torch.float32, device=dev)
+            nb = torch.empty(n_b, dtype=torch.long, device=dev)
+            L.check(lib.mrgcn_frontier_emit(self.indptr.data_ptr(), self.indices.data_ptr(), self.data.data_ptr(), N,
+                                            sample.data_ptr(), n_s, row_off.data_ptr(), node_pos.data_ptr(), n_b,
+                                            L.VAL_I8 if i8 else L.VAL_F32, row.data_ptr(), col.data_ptr(),
+                                            val.data_ptr(), col_sl.data_ptr(), nb.data_ptr(), s),
+                    "mrgcn_frontier_emit")
+        return row, col, val, col_sl, nb
 
 
 class A_BatchDevice(A_Batch):
-    """`A_Batch` whose row slices and neighbour sets are produced on the GPU from a `DeviceCSR`
-    (gathers, `torch.unique`): same `row` / `neighbours` / `node_index` attributes, already tensors
-    on the device (as after `as_tensors_()` + `to(device)`), same contents as the host build."""
+    """`A_Batch` whose row slices and neighbour sets are produced on the GPU from a `DeviceCSR` by the frontier
+    kernels: same `row` / `neighbours` / `node_index` attributes, already tensors on the device (as after
+    `as_tensors_()` + `to(device)`), same contents as the host build (bit-exact against the reference's goldens).
+    The column-compacted slice of every layer (what `sliceSparseCOO(row[i], A_idx_i)` returns, batch.py:258-270)
+    comes out of the same kernel pass and is attached to `row[i]`, so the layers never run the searchsorted
+    slicer."""
 
     def __init__(self, A_dev: DeviceCSR, batch_idx, num_layers, value_mode="ref_int8"):
         assert value_mode in VALUE_MODES
@@ -312,13 +344,18 @@ class A_BatchDevice(A_Batch):
         self.device = dev
         self.node_index = torch.as_tensor(np.asarray(batch_idx), dtype=torch.long, device=dev)
         num_nodes = A_dev.shape[0]
+        R = A_dev.shape[1] // num_nodes
         sample = self.node_index
-        for _ in range(num_layers):
-            row, col, val = A_dev.rows(sample)
-            if value_mode == "ref_int8":
-                val = val.to(torch.int8)  # the boundary cast: truncation toward zero
-            self.row.append(torch.sparse_coo_tensor(torch.stack([row, col]), val, (sample.numel(), A_dev.shape[1])))
-            nb = torch.unique(col % num_nodes)  # sorted
+        for i in range(num_layers):
+            row, col, val, col_sl, nb = A_dev.frontier(sample, value_mode)
+            a = torch.sparse_coo_tensor(torch.stack([row, col]), val, (sample.numel(), A_dev.shape[1]))
+            a_idx = getAdjacencyNodeColumnIdx(nb, num_nodes, R)
+            sliced = torch.sparse_coo_tensor(torch.stack([row, col_sl]),
+                                             torch.ones(col_sl.numel(), dtype=torch.float32, device=dev),
+                                             (sample.numel(), R * nb.numel()))
+            self._a_idx[i] = a_idx
+            a._mrgcn_slice = (a_idx, sliced)   # what GraphConvolution._forward_mini_batch looks up
+            self.row.append(a)
             self.neighbours.append(nb)
             sample = nb
 

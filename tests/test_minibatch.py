@@ -139,6 +139,14 @@ def test_device_built_batch_equals_host_built(tag):
         assert np.array_equal(ab.neighbours[i].cpu().numpy(), g[f"{tag}.neighbours_{i}"])
         assert np.array_equal(ab.row[i]._indices().cpu().numpy(), g[f"{tag}.row_{i}.indices"])
         assert np.array_equal(ab.row[i]._values().cpu().numpy(), g[f"{tag}.row_{i}.values"])
+        assert ab.row[i].dtype == torch.int8
+    # the column-compacted slice the frontier kernel emits next to the row slice = the reference's
+    # sliceSparseCOO(row_0, A_idx_0)
+    a_idx, sl = ab.row[0]._mrgcn_slice
+    assert a_idx is ab._a_idx[0] and np.array_equal(a_idx.cpu().numpy(), g[tag + ".A_idx_0"])
+    assert np.array_equal(sl._indices().cpu().numpy(), g[tag + ".sliced_0.indices"])
+    assert np.array_equal(sl._values().cpu().numpy(), g[tag + ".sliced_0.values"])
+    assert list(sl.shape) == list(g[tag + ".sliced_0.shape"])
     N = A.shape[0]
     R = A.shape[1] // N
     dims = [(xw if li == 0 else hidden, hidden if li < nl - 1 else classes) for li in range(nl)]
@@ -150,3 +158,44 @@ def test_device_built_batch_equals_host_built(tag):
     X = torch.from_numpy(g[tag + ".X_full"]).cuda()[ab.neighbours[-1]]
     logits = model(X, ab)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), g[tag + ".logits"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_frontier_kernels_edge_cases_through_the_c_abi():
+    """mrgcn_frontier_count / _emit against the host functions on a graph with isolated rows, a hub row longer
+    than several waves, duplicated sample rows and an empty sample; float32 and int8 (truncating) values."""
+    import scipy.sparse as sp
+    from mrgcn_amd.data import batch as mb
+    rng = np.random.default_rng(5)
+    N, R = 300, 7
+    rows = rng.integers(0, N, 2500)
+    cols = rng.integers(0, R * N, 2500)
+    rows = np.concatenate([rows, np.full(700, 17)])                      # hub row
+    cols = np.concatenate([cols, rng.choice(R * N, 700, replace=False)])
+    keep = ~np.isin(rows, [3, 4, 250])                                    # isolated rows
+    rows, cols = rows[keep], cols[keep]
+    vals = rng.uniform(-1.9, 1.9, rows.size).astype(np.float32)           # int8 cast truncates toward zero
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(N, R * N))
+    A.sum_duplicates()
+    dcsr = mb.DeviceCSR(A)
+    for sample in ([17], [3, 4, 250], [5, 17, 5, 3, 299, 0], list(range(N)), []):
+        smp = np.asarray(sample, dtype=np.int64)
+        for mode, dt in (("ref_int8", np.int8), ("norm_f32", np.float32)):
+            row, col, val, col_sl, nb = dcsr.frontier(torch.from_numpy(smp), mode)
+            sub = A[smp] if smp.size else A[:0]
+            r_h, c_h = sub.nonzero()
+            # scipy's nonzero() drops explicit zeros; the kernels keep every stored entry (as the reference's
+            # A[sample] COO does): compare on the stored structure
+            sub = sub.tocsr()
+            r_h = np.repeat(np.arange(sub.shape[0]), np.diff(sub.indptr))
+            c_h = sub.indices
+            assert np.array_equal(row.cpu().numpy(), r_h) and np.array_equal(col.cpu().numpy(), c_h)
+            want_v = sub.data.astype(np.int32).astype(np.int8) if dt is np.int8 else sub.data
+            assert np.array_equal(val.cpu().numpy(), want_v)
+            nb_h = mb.getNeighboursSparse(A, smp) if smp.size else np.zeros(0, dtype=np.int64)
+            assert np.array_equal(nb.cpu().numpy(), nb_h)
+            if nb_h.size:
+                pos = np.searchsorted(nb_h, c_h % N)
+                assert np.array_equal(col_sl.cpu().numpy(), (c_h // N) * nb_h.size + pos)
+            else:
+                assert col_sl.numel() == 0
