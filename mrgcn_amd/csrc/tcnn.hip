@@ -1,0 +1,200 @@
+// The elementwise half of a TCNN block (reference mrgcn/models/temporal_cnn.py:6-156: Conv1d -> BatchNorm1d -> ReLU
+// [-> MaxPool1d(k, stride k) | AdaptiveMaxPool1d(n)]): batch statistics, normalisation, ReLU and the pooling
+// window in ONE pass over the convolution's output, and the matching backward (pool scatter + ReLU mask + batch-norm
+// backward).  The convolutions themselves are implicit-im2col products on the matrix cores (encoders.hip).
+// x / dx: [B][C][T] float32; y / dy / argmax: [B][C][Tout].  All of it is HBM-bound elementwise / reduction work.
+#include "common.hpp"
+
+namespace mrgcn {
+namespace {
+
+enum { POOL_NONE = 0, POOL_MAX = 1, POOL_ADAPTIVE = 2 };
+
+__host__ __device__ inline int pool_out_len(int kind, int arg, int T) {
+  if (kind == POOL_NONE) return T;
+  if (kind == POOL_MAX) return T >= arg ? (T - arg) / arg + 1 : 0;  // MaxPool1d(k, stride k), ceil_mode off
+  return arg;                                                       // AdaptiveMaxPool1d(n)
+}
+__device__ inline void pool_window(int kind, int arg, int T, int to, int &t0, int &t1) {
+  if (kind == POOL_NONE) {
+    t0 = to;
+    t1 = to + 1;
+  } else if (kind == POOL_MAX) {
+    t0 = to * arg;
+    t1 = t0 + arg;
+  } else {  // ATen's adaptive windows: [floor(to T / n), ceil((to + 1) T / n))
+    t0 = (int)(((int64_t)to * T) / arg);
+    t1 = (int)((((int64_t)to + 1) * T + arg - 1) / arg);
+  }
+}
+
+__device__ inline double block_sum(double v, double *s) {  // 256 threads
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s[wv] = v;
+  __syncthreads();
+  return s[0] + s[1] + s[2] + s[3];
+}
+
+// block per channel: mean and biased variance over (B, T)
+__global__ __launch_bounds__(256) void k_bn_stats(const float *__restrict__ x, int B, int C, int T,
+                                                  float *__restrict__ mean, float *__restrict__ var) {
+  __shared__ double s[4];
+  const int c = blockIdx.x;
+  double a = 0.0, q = 0.0;
+  const int64_t n = (int64_t)B * T;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const int64_t b = i / T, t = i - b * T;
+    const double v = x[(b * C + c) * T + t];
+    a += v;
+    q += v * v;
+  }
+  a = block_sum(a, s);
+  q = block_sum(q, s);
+  if (threadIdx.x == 0) {
+    const double m = a / (double)n;
+    mean[c] = (float)m;
+    const double vv = q / (double)n - m * m;
+    var[c] = (float)(vv > 0.0 ? vv : 0.0);
+  }
+}
+
+// thread per output element
+__global__ void k_bn_relu_pool_fwd(const float *__restrict__ x, int B, int C, int T, int Tout,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   const float *__restrict__ mean, const float *__restrict__ var, float eps,
+                                   int kind, int arg, float *__restrict__ y, int32_t *__restrict__ argmax) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= (int64_t)B * C * Tout) return;
+  const int to = (int)(o % Tout);
+  const int64_t bc = o / Tout;
+  const int c = (int)(bc % C);
+  // (x - mean) first: folding the mean into a bias (x * sc + sh) cancels badly when |mean| >> std
+  const float mu = mean[c], sc = (gamma ? gamma[c] : 1.f) / sqrtf(var[c] + eps), sh = beta ? beta[c] : 0.f;
+  int t0, t1;
+  pool_window(kind, arg, T, to, t0, t1);
+  const float *row = x + bc * T;
+  float best = -1.f;
+  int bi = t0;
+  for (int t = t0; t < t1; ++t) {
+    const float z = fmaxf((row[t] - mu) * sc + sh, 0.f);
+    if (z > best) {  // first maximum wins (ATen's order)
+      best = z;
+      bi = t;
+    }
+  }
+  y[o] = best;
+  if (argmax) argmax[o] = bi;
+}
+
+// dz[b][c][argmax] += dy where y > 0 (dz zeroed by the caller); windows of an adaptive pool may overlap
+__global__ void k_pool_relu_bwd(const float *__restrict__ y, const float *__restrict__ dy,
+                                const int32_t *__restrict__ argmax, int64_t n_out, int T, int Tout, int kind,
+                                float *__restrict__ dz) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  if (!(y[o] > 0.f)) return;
+  const int64_t bc = o / Tout;
+  const int t = argmax ? argmax[o] : (int)(o - bc * Tout);
+  if (kind == POOL_ADAPTIVE) atomicAdd(dz + bc * T + t, dy[o]);
+  else dz[bc * T + t] = dy[o];
+}
+
+// block per channel: dbeta = sum dz, dgamma = sum dz * xhat
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float *__restrict__ x, const float *__restrict__ dz,
+                                                       int B, int C, int T, const float *__restrict__ mean,
+                                                       const float *__restrict__ var, float eps,
+                                                       float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  __shared__ double s[4];
+  const int c = blockIdx.x;
+  const double m = mean[c], istd = 1.0 / sqrt((double)var[c] + (double)eps);
+  double a = 0.0, q = 0.0;
+  const int64_t n = (int64_t)B * T;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const int64_t b = i / T, t = i - b * T;
+    const int64_t e = (b * C + c) * T + t;
+    const double g = dz[e];
+    a += g;
+    q += g * ((double)x[e] - m) * istd;
+  }
+  a = block_sum(a, s);
+  q = block_sum(q, s);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)q;
+  }
+}
+
+// training: dx = gamma istd (dz - mean(dz) - xhat mean(dz xhat));  eval: dx = gamma istd dz
+__global__ void k_bn_bwd_dx(const float *__restrict__ x, const float *__restrict__ dz, int B, int C, int T,
+                            const float *__restrict__ gamma, const float *__restrict__ mean,
+                            const float *__restrict__ var, float eps, const float *__restrict__ dgamma,
+                            const float *__restrict__ dbeta, int training, float *__restrict__ dx) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)B * C * T) return;
+  const int c = (int)((e / T) % C);
+  const float istd = 1.f / sqrtf(var[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f;
+  float v = dz[e];
+  if (training) {
+    const float inv_n = 1.f / (float)((int64_t)B * T);
+    const float xhat = (x[e] - mean[c]) * istd;
+    v = v - dbeta[c] * inv_n - xhat * dgamma[c] * inv_n;
+  }
+  dx[e] = g * istd * v;
+}
+
+inline unsigned nb(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
+
+}  // namespace
+}  // namespace mrgcn
+
+using namespace mrgcn;
+
+extern "C" {
+
+int32_t mrgcn_pool_out_len(int32_t pool_kind, int32_t pool_arg, int32_t T) {
+  if (pool_kind < 0 || pool_kind > 2 || (pool_kind != POOL_NONE && pool_arg <= 0) || T < 0) return -1;
+  return pool_out_len(pool_kind, pool_arg, T);
+}
+
+int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, const float *gamma,
+                               const float *beta, float eps, int32_t training, float *mean, float *var,
+                               int32_t pool_kind, int32_t pool_arg, float *y, int32_t *argmax, void *stream) {
+  MRGCN_REQUIRE(x && y && mean && var, "NULL");
+  MRGCN_REQUIRE(B > 0 && C > 0 && T > 0, "B / C / T");
+  MRGCN_REQUIRE(pool_kind >= 0 && pool_kind <= 2 && (pool_kind == POOL_NONE || pool_arg > 0), "pool");
+  MRGCN_REQUIRE(pool_kind == POOL_NONE || argmax, "a pooled block needs the argmax buffer");
+  const int Tout = pool_out_len(pool_kind, pool_arg, T);
+  MRGCN_REQUIRE(Tout > 0, "the pooling window is longer than the sequence");
+  hipStream_t s = (hipStream_t)stream;
+  if (training) k_bn_stats<<<dim3(C), dim3(256), 0, s>>>(x, B, C, T, mean, var);
+  const int64_t n_out = (int64_t)B * C * Tout;
+  k_bn_relu_pool_fwd<<<dim3(nb(n_out)), dim3(256), 0, s>>>(x, B, C, T, Tout, gamma, beta, mean, var, eps,
+                                                         pool_kind, pool_arg, y, argmax);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_bn_relu_pool_bwd_f32(const float *x, const float *y, const float *dy, const int32_t *argmax, int32_t B,
+                               int32_t C, int32_t T, const float *gamma, const float *mean, const float *var,
+                               float eps, int32_t training, int32_t pool_kind, int32_t pool_arg, float *dz,
+                               float *dx, float *dgamma, float *dbeta, void *stream) {
+  MRGCN_REQUIRE(x && y && dy && mean && var && dz && dx && dgamma && dbeta, "NULL");
+  MRGCN_REQUIRE(B > 0 && C > 0 && T > 0, "B / C / T");
+  MRGCN_REQUIRE(pool_kind >= 0 && pool_kind <= 2 && (pool_kind == POOL_NONE || (pool_arg > 0 && argmax)), "pool");
+  const int Tout = pool_out_len(pool_kind, pool_arg, T);
+  MRGCN_REQUIRE(Tout > 0, "the pooling window is longer than the sequence");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_in = (int64_t)B * C * T, n_out = (int64_t)B * C * Tout;
+  MRGCN_HIP_TRY(hipMemsetAsync(dz, 0, (size_t)n_in * sizeof(float), s));
+  k_pool_relu_bwd<<<dim3(nb(n_out)), dim3(256), 0, s>>>(y, dy, argmax, n_out, T, Tout, pool_kind, dz);
+  k_bn_bwd_reduce<<<dim3(C), dim3(256), 0, s>>>(x, dz, B, C, T, mean, var, eps, dgamma, dbeta);
+  k_bn_bwd_dx<<<dim3(nb(n_in)), dim3(256), 0, s>>>(x, dz, B, C, T, gamma, mean, var, eps, dgamma, dbeta, training,
+                                                  dx);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+}  // extern "C"

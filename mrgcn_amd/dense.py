@@ -129,6 +129,76 @@ def conv1d(x, W, b=None, padding: int = 0):
 
 
 # ---------------------------------------------------------------------------------------------------------
+POOL_NONE, POOL_MAX, POOL_ADAPTIVE = 0, 1, 2
+
+
+class _BnReluPool(torch.autograd.Function):
+    """BatchNorm1d -> ReLU [-> MaxPool1d(k, k) | AdaptiveMaxPool1d(n)] of a [B, C, T] tensor in one pass
+    (csrc/tcnn.hip).  `mean` / `var` are written by the forward in training mode (batch statistics, biased
+    variance) and read in eval mode (running statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps: float, training: bool, kind: int, arg: int):
+        x = x.contiguous()
+        Bn, Cn, T = x.shape
+        lib = L.load()
+        Tout = int(lib.mrgcn_pool_out_len(kind, arg, T))
+        if Tout <= 0:
+            raise L.MrgcnError("bn_relu_pool: the pooling window is longer than the sequence")
+        y = torch.empty((Bn, Cn, Tout), dtype=torch.float32, device=x.device)
+        am = torch.empty((Bn, Cn, Tout), dtype=torch.int32, device=x.device) if kind != POOL_NONE else None
+        with torch.cuda.device(x.device):
+            L.check(lib.mrgcn_bn_relu_pool_fwd_f32(
+                x.data_ptr(), Bn, Cn, T, gamma.data_ptr() if gamma is not None else 0,
+                beta.data_ptr() if beta is not None else 0, float(eps), int(training), mean.data_ptr(),
+                var.data_ptr(), kind, arg, y.data_ptr(), am.data_ptr() if am is not None else 0,
+                _stream(x.device)), "mrgcn_bn_relu_pool_fwd_f32")
+        ctx.meta = (float(eps), bool(training), kind, arg)
+        ctx.save_for_backward(x, y, am, gamma, mean, var)
+        ctx.mark_non_differentiable(mean, var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, am, gamma, mean, var = ctx.saved_tensors
+        eps, training, kind, arg = ctx.meta
+        Bn, Cn, T = x.shape
+        dy = dy.contiguous()
+        dz = torch.empty_like(x)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(Cn, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(Cn, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.load().mrgcn_bn_relu_pool_bwd_f32(
+                x.data_ptr(), y.data_ptr(), dy.data_ptr(), am.data_ptr() if am is not None else 0, Bn, Cn, T,
+                gamma.data_ptr() if gamma is not None else 0, mean.data_ptr(), var.data_ptr(), eps, int(training),
+                kind, arg, dz.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _stream(x.device)),
+                "mrgcn_bn_relu_pool_bwd_f32")
+        return dx, (dgamma if gamma is not None else None), (dbeta if gamma is not None else None), None, None, \
+            None, None, None, None
+
+
+def bn_relu_pool(x, bn, pool_kind: int = POOL_NONE, pool_arg: int = 0):
+    """`bn`: an nn.BatchNorm1d; its running statistics are updated as nn.BatchNorm1d.forward does
+    (momentum, unbiased variance, num_batches_tracked) when it is in training mode."""
+    training = bn.training or bn.running_mean is None
+    if training:
+        mean = torch.empty(bn.num_features, dtype=torch.float32, device=x.device)
+        var = torch.empty_like(mean)
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    y = _BnReluPool.apply(x, bn.weight, bn.bias, mean, var, bn.eps, training, int(pool_kind), int(pool_arg))
+    if bn.training and bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            n = x.shape[0] * x.shape[2]
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------
 def mlp_dims(weights):
     return [int(weights[0].shape[1])] + [int(w.shape[0]) for w in weights]
 

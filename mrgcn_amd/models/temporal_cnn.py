@@ -3,8 +3,10 @@ mrgcn/models/temporal_cnn.py:6-160): Conv1d -> BatchNorm1d -> ReLU blocks with m
 between, an adaptive max-pool, a closing valid convolution that leaves one position, then
 Linear -> ReLU -> Dropout -> Linear.  Built from a per-size table so that the layer order — hence
 the state-dict keys (`conv.<i>.*`, `fc.<i>.*`, both also under `module_dict.`) and the order in
-which the default initialisers consume the RNG — equals the reference's.  Dense conv / GEMM work:
-runs on the ROCm libraries (MIOpen / rocBLAS) through torch.nn."""
+which the default initialisers consume the RNG — equals the reference's.  On the GPU every block runs on the
+HIP kernels: the Conv1d as an implicit-im2col product on the matrix cores, BatchNorm1d + ReLU (+ the pooling layer
+that follows) as one pass (dense.conv1d / dense.bn_relu_pool / dense.linear; csrc/encoders.hip, csrc/tcnn.hip);
+the torch.nn modules below hold the parameters / buffers and serve CPU-side tooling."""
 import torch.nn as nn
 
 # (kind, *args): "c" = Conv1d(out_channels, kernel, padding) + BatchNorm1d + ReLU, "p" = MaxPool1d(k, stride k),
@@ -54,10 +56,28 @@ class TCNN(nn.Module):
         if not dense.usable(X, self.fc[0].weight):
             X = self.conv(X)
             return self.fc(X.view(X.size(0), -1))
-        # GPU: every Conv1d is an implicit-im2col product on the matrix cores, the fully connected tail two more
-        # (dense.conv1d / dense.linear, csrc/encoders.hip); BatchNorm / ReLU / pooling stay elementwise passes
-        for m in self.conv:
-            X = dense.conv1d(X, m.weight, m.bias, m.padding[0]) if isinstance(m, nn.Conv1d) else m(X)
+        # GPU: Conv1d = implicit-im2col product on the matrix cores; BatchNorm1d + ReLU + the pooling layer behind
+        # them (if any) = one elementwise pass
+        mods = list(self.conv)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Conv1d):
+                X = dense.conv1d(X, m.weight, m.bias, m.padding[0])
+                i += 1
+            elif isinstance(m, nn.BatchNorm1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                kind, arg, used = dense.POOL_NONE, 0, 2
+                nxt = mods[i + 2] if i + 2 < len(mods) else None
+                if isinstance(nxt, nn.MaxPool1d) and nxt.stride == nxt.kernel_size and nxt.padding == 0 \
+                        and nxt.dilation == 1 and not nxt.ceil_mode:
+                    kind, arg, used = dense.POOL_MAX, int(nxt.kernel_size), 3
+                elif isinstance(nxt, nn.AdaptiveMaxPool1d):
+                    kind, arg, used = dense.POOL_ADAPTIVE, int(nxt.output_size), 3
+                X = dense.bn_relu_pool(X, m, kind, arg)
+                i += used
+            else:
+                X = m(X)
+                i += 1
         X = dense.linear(X.view(X.size(0), -1), self.fc[0].weight, self.fc[0].bias, relu=True)
         return dense.linear(self.fc[2](X), self.fc[3].weight, self.fc[3].bias)
 

@@ -248,3 +248,51 @@ def test_fused_mlp_gate_scatter_vs_torch(dims, with_rows):
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
     for a, t in zip(got, Ws + bs + [gates]):
         torch.testing.assert_close(a, t.grad, rtol=2e-4, atol=2e-4 * float(t.grad.abs().max()) + 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,T,kind,arg", [(5, 7, 20, 0, 0), (4, 64, 300, 1, 3), (3, 33, 21, 1, 2), (6, 16, 11, 2, 3),
+                                            (2, 5, 9, 2, 2), (1, 3, 4, 2, 4)])
+def test_batchnorm_relu_pool_block_vs_torch(B, C, T, kind, arg):
+    """csrc/tcnn.hip through the C ABI against nn.BatchNorm1d -> ReLU -> MaxPool1d / AdaptiveMaxPool1d (float64 on
+    the CPU): output, d x / d gamma / d beta, the running statistics after the step, and the eval-mode pass.
+    (6, 16, 11, adaptive 3): overlapping adaptive windows; (3, 33, 21, max 2): a tail position no window covers."""
+    from mrgcn_amd import dense
+    torch.manual_seed(B * 100 + T)
+    x = torch.randn(B, C, T) * 1.5 + 0.3
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C))          # negative scales too: ReLU and max do not commute with them
+        bn.bias.copy_(torch.randn(C) * 0.5)
+    ref_bn = torch.nn.BatchNorm1d(C).double()
+    ref_bn.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    pool = {0: torch.nn.Identity(), 1: torch.nn.MaxPool1d(arg, arg) if kind == 1 else None,
+            2: torch.nn.AdaptiveMaxPool1d(arg) if kind == 2 else None}[kind]
+    xr = x.double().requires_grad_(True)
+    yr = pool(torch.relu(ref_bn(xr)))
+    w = torch.randn_like(yr)
+    (yr * w).sum().backward()
+
+    bn = bn.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = dense.bn_relu_pool(xg, bn, kind, arg)
+    assert type(y.grad_fn).__name__ == "_BnReluPoolBackward"
+    (y * w.float().cuda()).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for got, want, name in ((xg.grad, xr.grad, "dx"), (bn.weight.grad, ref_bn.weight.grad, "dgamma"),
+                            (bn.bias.grad, ref_bn.bias.grad, "dbeta")):
+        want = want.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(want).max()),
+                                   err_msg=name)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref_bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref_bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    bn.eval(); ref_bn.eval()
+    xe = x.cuda().requires_grad_(True)
+    ye = dense.bn_relu_pool(xe, bn, kind, arg)
+    xre = x.double().requires_grad_(True)
+    yre = pool(torch.relu(ref_bn(xre)))
+    np.testing.assert_allclose(ye.detach().cpu().numpy(), yre.detach().numpy(), rtol=1e-4, atol=1e-5)
+    (ye * w.float().cuda()).sum().backward()
+    (yre * w).sum().backward()
+    np.testing.assert_allclose(xe.grad.cpu().numpy(), xre.grad.numpy(), rtol=2e-4, atol=2e-5)
