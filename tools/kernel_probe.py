@@ -39,7 +39,7 @@ def main():
     h = plan.handle
     nc = plan.ncols
     ld = a.ldm
-    V = torch.randn((B * N, F), device=dev)
+    V = torch.randn((N, B, F), device=dev)   # node-major basis table
     comp = torch.randn((R, B), device=dev)
     M = torch.empty((nc, ld), device=dev)
     M2 = torch.randn((nc, 12), device=dev)
@@ -68,7 +68,11 @@ def main():
     if a.dy_zero_frac > 0:
         dYz[torch.rand(N, device=dev) < a.dy_zero_frac] = 0
     scratch = torch.empty(int(lib.mrgcn_spmm_transposed_live_scratch(h)), dtype=torch.uint8, device=dev)
-    clive = torch.empty(nc, dtype=torch.uint8, device=dev)
+    clive = torch.ones(nc, dtype=torch.uint8, device=dev)
+    if a.dm_zero_frac > 0:
+        clive = (dM.abs().sum(1) > 0).to(torch.uint8)
+    ncur = torch.zeros(N, dtype=torch.uint8, device=dev)    # row-sparse gradient: which node blocks were written
+    never = torch.zeros(N, dtype=torch.uint8, device=dev)
     sq = torch.zeros((), device=dev, dtype=torch.float64)
 
     def chk(rc):
@@ -77,9 +81,9 @@ def main():
     calls = {
         "mix_fwd": lambda: chk(lib.mrgcn_basis_mix_fwd_f32(h, V.data_ptr(), comp.data_ptr(), B, F, 0, 0, M.data_ptr(), ld, s)),
         "mix_fwd_add": lambda: chk(lib.mrgcn_basis_mix_fwd_f32(h, V.data_ptr(), comp.data_ptr(), B, F, M2.data_ptr(), 12, M.data_ptr(), ld, s)),
-        "mix_bwd": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), dcomp.data_ptr(), 0, s)),
-        "mix_bwd_sq": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, V.data_ptr(), comp.data_ptr(), B, F, 0, dcomp.data_ptr(), sq.data_ptr(), s)),
-        "mix_bwd_adam": lambda: chk(lib.mrgcn_basis_mix_bwd_adam_f32(h, dM.data_ptr(), 12, comp.data_ptr(), B, F, P.data_ptr(), M_.data_ptr(), V_.abs_().data_ptr(), 0.01, 0.9, 0.999, 1e-8, 0.0, 1, coef.data_ptr(), s)),
+        "mix_bwd": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, 0, V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), 0, dcomp.data_ptr(), 0, s)),
+        "mix_bwd_rows": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, clive.data_ptr(), V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), ncur.data_ptr(), dcomp.data_ptr(), sq.data_ptr(), s)),
+        "adam_rows": lambda: chk(lib.mrgcn_adam_step_rows_f32(P.data_ptr(), dV.data_ptr(), M_.data_ptr(), V_.abs_().data_ptr(), N, B * F, ncur.data_ptr(), never.data_ptr(), 0.01, 0.9, 0.999, 1e-8, 1, 0, coef.data_ptr(), s)),
         "spmm_tl10": lambda: chk(lib.mrgcn_spmm_transposed_live_f32(h, dYz.data_ptr(), 10, 10, dM.data_ptr(), 12, scratch.data_ptr(), clive.data_ptr(), 0, 1, s)),
         "spmm_tl10_nd": lambda: chk(lib.mrgcn_spmm_transposed_live_f32(h, dYz.data_ptr(), 10, 10, dM.data_ptr(), 12, scratch.data_ptr(), clive.data_ptr(), 0, 0, s)),
         "xf_fwd0": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, X.data_ptr(), K, K, W0.data_ptr(), F, M2.data_ptr(), 12, 0, s)),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel roofline table of one AM-shaped epoch: algorithmic bytes, median
 launch duration from a rocprofv3 kernel trace, achieved GB/s and the fraction of the 8 TB/s HBM
-roofline.   python tools/roofline_table.py <trace dir> > profiles/r01_kernel_roofline.md"""
+roofline.   python tools/roofline_table.py <trace dir> > profiles/rNN_kernel_roofline.md"""
 import collections
 import csv
 import glob
@@ -22,19 +22,20 @@ def spmm_bytes(rows, ncols, F):
     return NNZ * 8 + (rows + 1) * 4 + ncols * F * 4 + rows * F * 4
 
 
+LIVE_NODES = 0.52  # share of the nodes with a live column on this graph (1 000 labels, two hops)
+
 ALG = {  # kernel-name prefix -> (label, bytes)
     "mrgcn::k_adam<false>": ("Adam on weight_I: 7 streams x 4 B x B*N*F0", 7 * 4 * B * N * F0),
+    "mrgcn::k_mix_fwd_mfma<3, 2, 2, true, float>": ("V read once + addend read + M written + 3 index arrays",
+                                                    4 * B * N * F0 + 2 * NCOLS * LD * 4 + NCOLS * 8 + N * 4),
     "mrgcn::k_mix_fwd<40, float>": ("V read once + addend read + M written + 3 index arrays",
-                             4 * B * N * F0 + 2 * NCOLS * LD * 4 + NCOLS * 8 + N * 4),
-    "mrgcn::k_mix_bwd_node<10, 0, true>": ("dV + dcomp in one pass: V read once + dV written + dM read + relation ids",
-                                           2 * 4 * B * N * F0 + NCOLS * LD * 4 + NCOLS * 4 + N * 4),
-    "mrgcn::k_mix_bwd_node<10, 3, true>": ("dV (node-major, live nodes only: half of them on this graph) + dcomp: "
-                                           "V read once + dV of the live nodes + flags",
-                                           4 * B * N * F0 + 4 * B * N * F0 // 2 + NCOLS * 2 + N * 5),
-    "mrgcn::k_adam_nodemajor<32>": ("node-major Adam: p read + written, g / m / v of the nodes that ever had gradient "
-                                    "(half of them on this graph): 2 + 5/2 streams",
-                                    2 * 4 * B * N * F0 + 5 * 4 * B * N * F0 // 2),
-    "mrgcn::k_spmm<4, 4, false, float, false>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
+                                    4 * B * N * F0 + 2 * NCOLS * LD * 4 + NCOLS * 8 + N * 4),
+    "mrgcn::k_mix_bwd_nm<10>": ("dV (node blocks of the live nodes only) + dcomp: V read for the live nodes + dV "
+                                "written + live dM rows + flags",
+                                int(2 * 4 * B * N * F0 * LIVE_NODES) + NCOLS * 2 + N * 5),
+    "mrgcn::k_adam_rows<4>": ("row-sparse Adam: p, g, m, v read and p, m, v written for the node blocks that ever "
+                              "had gradient", int(7 * 4 * B * N * F0 * LIVE_NODES)),
+    "mrgcn::k_spmm3<4, 4, false, float>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
     "mrgcn::k_spmm<4, 4, true, float, false>": ("general transposed product, F=10 (probe leg only; the epoch runs k_spmm_t_live)",
                                                 spmm_bytes(NCOLS, N, F0)),
     "mrgcn::k_xform_mfma_fwd<1, false, 16, float, false>": ("layer-0 transform: X read once + W + M2 written + indices",
