@@ -210,7 +210,8 @@ int mrgcn_rel_transform_fwd_bf16(const mrgcn_plan_t *plan, const float *X, int64
  *     block; with node_cur given such blocks of dV are left UNWRITTEN (and their V blocks unread) and
  *     node_cur[j] = 1 / 0 says which nodes were written — only mrgcn_adam_step_rows_f32 may consume such a
  *     gradient.  NULL: every block of dV is written (zeros where there is no gradient).
- * dV_sumsq (nullable): *dV_sumsq += ||dV||^2 (device double), for the global clip norm. */
+ * dV_sumsq (nullable): *dV_sumsq += ||dV||^2 (device double), for the global clip norm.
+ * dV may be NULL when node_cur and dV_sumsq are given (norm-only pass in front of mrgcn_adam_step_rows_fused_f32). */
 int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *plan, float *dM, int64_t ldM, const uint8_t *col_live,
                             const float *V, const float *comp, int32_t B, int32_t F, float *dV,
                             uint8_t *node_cur, float *dcomp, double *dV_sumsq, void *stream);
@@ -332,6 +333,18 @@ int mrgcn_adam_step_rows_f32(float *param, const float *grad, float *exp_avg, fl
                              int64_t nrows, int32_t rowlen, const uint8_t *row_cur, uint8_t *row_ever,
                              float lr, float beta1, float beta2, float eps, int64_t step,
                              const float *bc_dev, const float *grad_scale, void *stream);
+/* The same update with the gradient formed on the fly: the backward called mrgcn_basis_mix_bwd_f32 with dV = NULL
+ * (flags, dcomp and ||dV||^2 only) and this call rebuilds every live node's block from its dM rows,
+ *     dV[j][b][f] = sum_{live c of j} comp[r_c][b] * dM[c][f]        (the sums mrgcn_basis_mix_bwd_f32 forms, bit for bit),
+ * inside the Adam pass: the gradient tensor of the node table is never written nor read.  `comp` must hold the
+ * coefficients the backward saw (a snapshot when the optimizer updates them first).  Shapes:
+ * mrgcn_adam_rows_fused_supported (B <= 64, F <= 16, B*F % 4 == 0, R*B*4 <= 64 KB). */
+int32_t mrgcn_adam_rows_fused_supported(const mrgcn_plan_t *plan, int32_t B, int32_t F);
+int mrgcn_adam_step_rows_fused_f32(const mrgcn_plan_t *plan, const float *dM, int64_t ldM, const uint8_t *col_live,
+                                   const float *comp, int32_t B, int32_t F, float *param, float *exp_avg,
+                                   float *exp_avg_sq, const uint8_t *row_cur, uint8_t *row_ever, float lr,
+                                   float beta1, float beta2, float eps, int64_t step, const float *bc_dev,
+                                   const float *grad_scale, void *stream);
 int mrgcn_adam_bias_f32(int64_t *step_dev, float beta1, float beta2, float *bc_dev, void *stream);
 int mrgcn_adam_step_dev_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                             int64_t n, float lr, float beta1, float beta2, float eps,

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_nm(const int32_t *__restric
           any = __builtin_amdgcn_ballot_w64(f) != 0;
         }
       }
-      float *drow = dV + ((int64_t)j * B + b) * F;
+      float *drow = dV ? dV + ((int64_t)j * B + b) * F : nullptr;  // NULL: norm-only pass (node_cur given)
       if (!any) {  // wave uniform
         if (node_cur) {
           if (lane == 0) node_cur[j] = 0;
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_nm(const int32_t *__restric
 #pragma unroll
         for (int o = 0; o < FT; ++o)
           if (o < F) sq = fmaf(acc[o], acc[o], sq);
-        store_row_f<FT>(drow, F, acc);
+        if (drow) store_row_f<FT>(drow, F, acc);
       }
       if (node_cur && lane == 0) node_cur[j] = 1;
     }
@@ -680,6 +680,127 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_nm(const int32_t *__restric
     for (int t = threadIdx.x; t < R * B; t += blockDim.x) {
       const float x = s_dc[t];
       if (x != 0.f) atomicAdd(&dcomp[t], x);
+    }
+  }
+}
+
+// =====================================================================================
+// Adam on the node-major basis table with the gradient FORMED ON THE FLY (row-sparse steps): the backward ran
+// k_mix_bwd_nm without a dV buffer (dcomp, ||dV||^2 and the per-node flags only), and once the clip coefficient
+// is known this kernel rebuilds every live node's block from its few dM rows,
+//     dV[j][b][f] = sum_{live c of j} comp[r_c][b] * dM[c][f]        (same order, same fmaf chain: same bits),
+// and applies torch.optim.Adam to it in the same pass.  The 2.67 GB gradient tensor (AM) is never written nor
+// read back: traffic is p / m / v of the touched blocks only.  Wave per node, lane = 16-byte pieces of the block
+// (P = ceil(B F / 256) per lane); comp (a snapshot taken before the optimizer moves it) lives in LDS.
+// =====================================================================================
+constexpr int kFusedTB = 1024;  // 16 waves share one LDS copy of comp; two blocks per CU at <= 64 VGPRs
+
+// A wave takes a node's block 64 16-byte pieces at a time (AM: 100 pieces = two rounds); each lane forms the
+// gradient of its own four elements.  Few registers (one p / m / v piece per lane) -> 8 waves per SIMD.
+__global__ __launch_bounds__(kFusedTB, 8) void k_adam_rows_fused(
+    const int32_t *__restrict__ nptr, const int32_t *__restrict__ urel, const uint8_t *__restrict__ col_live,
+    const float *__restrict__ dM, int64_t ldM, const float *__restrict__ comp, int64_t N, int R, int B, int F,
+    float *__restrict__ p, float *__restrict__ m, float *__restrict__ v, const uint8_t *__restrict__ cur,
+    uint8_t *__restrict__ ever, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+    const float *__restrict__ scale, const float *__restrict__ bc_dev) {
+  extern __shared__ __align__(16) float s_comp[];  // [R][B]
+  for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_comp[t] = comp[t];
+  __syncthreads();
+  if (bc_dev) {
+    bc1 = bc_dev[0];
+    bc2_sqrt = bc_dev[1];
+  }
+  const float sc = scale ? *scale : 1.f;
+  const float step = lr / bc1;
+  auto upd = [&](float &pp, float gg, float &mm, float &vv) {  // == k_adam with wd = 0
+    gg *= sc;
+    mm = fmaf(b1, mm, (1.f - b1) * gg);
+    vv = fmaf(b2, vv, (1.f - b2) * gg * gg);
+    float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= step * (mm / denom);
+  };
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = blockDim.x >> 6;
+  const int nv = (B * F) >> 2;       // 16-byte pieces of a block
+  const int nh = (nv + 63) >> 6;     // 64-piece tasks per node
+  const unsigned magicF = 65536u / (unsigned)F + 1u;  // e / F == (e * magicF) >> 16 for e * F < 2^16 (B F <= 1024)
+  using f4 = __attribute__((ext_vector_type(4))) float;
+  const int kq = lane >> 4, oq = lane & 15;
+  const int64_t stride = (int64_t)gridDim.x * nw;  // the waves of the grid walk the nodes side by side
+  // 64 of the wave's nodes at a time: lane l fetches flags and column range of node jb + l * stride with one
+  // load each, the loop below visits only the nodes that have (or ever had) gradient — a node that never had any
+  // costs nothing, not even a dependent flag load
+  for (int64_t jb = (int64_t)blockIdx.x * nw + wv; jb < N; jb += 64 * stride) {
+    const int64_t jl = jb + lane * stride;
+    const int64_t jc = min(jl, N - 1);
+    const int32_t flv = jl < N ? ((int32_t)cur[jc] | ((int32_t)ever[jc] << 1)) : 0;
+    const int32_t n0v = nptr[jc], n1v = nptr[jc + 1];
+    uint64_t act = __builtin_amdgcn_ballot_w64(flv != 0);
+    while (act) {
+      const int l = __builtin_ctzll(act);
+      act &= act - 1;
+      const int64_t j = jb + l * stride;
+      const bool c = (__builtin_amdgcn_readlane(flv, l) & 1) != 0;
+      const int32_t n0 = __builtin_amdgcn_readlane(n0v, l), n1 = __builtin_amdgcn_readlane(n1v, l);
+      f4 *p4 = reinterpret_cast<f4 *>(p) + j * (int64_t)nv;
+      f4 *m4 = reinterpret_cast<f4 *>(m) + j * (int64_t)nv;
+      f4 *v4 = reinterpret_cast<f4 *>(v) + j * (int64_t)nv;
+      // the node's first four columns: the 16-lane group kq reads column n0 + kq (clamped: also issued for a node
+      // without gradient this step, whose columns all count as dead)
+      const int32_t cc0 = max(min(n0 + kq, n1 - 1), 0);
+      const bool lv0 = c && n0 + kq < n1 && (!col_live || col_live[cc0] != 0);
+      const int32_t r0 = urel[cc0];
+      const float d0 = dM[(int64_t)cc0 * ldM + min(oq, F - 1)];
+      for (int half = 0; half < nh; ++half) {
+        const int q = lane + 64 * half;  // this lane's piece
+        const int qc = min(q, nv - 1);
+        // unconditional at clamped addresses (see the note on straight-line loads)
+        f4 Pr = p4[qc], Mr = m4[qc], Vr = v4[qc];
+        int bf[4];  // (basis, feature) of the piece's four elements
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned e = 4u * (unsigned)qc + (unsigned)k;
+          const unsigned bb = (e * magicF) >> 16;
+          bf[k] = (int)((bb << 8) | (e - bb * (unsigned)F));
+        }
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        int32_t rmine = r0;
+        float dmine = d0;
+        bool lv = lv0;
+        for (int32_t cb = n0;;) {
+          const uint64_t bl = __builtin_amdgcn_ballot_w64(lv && oq == 0);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            if (!((bl >> (16 * kk)) & 1ull)) continue;  // wave uniform: a column without gradient (or past the node)
+            const int r = __builtin_amdgcn_readlane(rmine, 16 * kk);
+            const float *crow = s_comp + r * B;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              g[k] = fmaf(crow[bf[k] >> 8], __shfl(dmine, 16 * kk + (bf[k] & 255)), g[k]);
+          }
+          cb += 4;
+          if (!c || cb >= n1) break;  // (few nodes have more than four columns)
+          const int32_t cc = min(cb + kq, n1 - 1);
+          lv = cb + kq < n1 && (!col_live || col_live[cc] != 0);
+          rmine = urel[cc];
+          dmine = dM[(int64_t)cc * ldM + min(oq, F - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float pp = Pr[k], mm = Mr[k], vv = Vr[k];
+          upd(pp, g[k], mm, vv);
+          Pr[k] = pp;
+          Mr[k] = mm;
+          Vr[k] = vv;
+        }
+        if (q < nv) {
+          p4[q] = Pr;
+          m4[q] = Mr;
+          v4[q] = Vr;
+        }
+      }
+      if (c && lane == 0) ever[j] = 1;
     }
   }
 }
@@ -1245,11 +1366,68 @@ int mix_bwd_dv_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const
 
 extern "C" {
 
+int32_t mrgcn_adam_rows_fused_supported(const mrgcn_plan_t *p, int32_t B, int32_t F) {
+  static const bool on = !(getenv("MRGCN_FUSED_ADAM") && atoi(getenv("MRGCN_FUSED_ADAM")) == 0);
+  static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
+  if (!p || !on || !node_on) return 0;
+  const int64_t R = p->num_relations;
+  return (B > 0 && B <= 64 && F > 0 && F <= 16 && (B * F) % 4 == 0 && p->num_nodes > 0 &&
+          (size_t)R * B * sizeof(float) <= 64 * 1024) ? 1 : 0;
+}
+
+int mrgcn_adam_step_rows_fused_f32(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const uint8_t *col_live,
+                                   const float *comp, int32_t B, int32_t F, float *param, float *exp_avg,
+                                   float *exp_avg_sq, const uint8_t *row_cur, uint8_t *row_ever, float lr,
+                                   float beta1, float beta2, float eps, int64_t step, const float *bc_dev,
+                                   const float *grad_scale, void *stream) {
+  MRGCN_REQUIRE(p && dM && comp && param && exp_avg && exp_avg_sq && row_cur && row_ever, "NULL");
+  MRGCN_REQUIRE(mrgcn_adam_rows_fused_supported(p, B, F), "shape outside mrgcn_adam_rows_fused_supported");
+  MRGCN_REQUIRE(ldM >= F, "ldM");
+  MRGCN_REQUIRE(((((uintptr_t)param) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15) == 0,
+                "param / moments must be 16-byte aligned");
+  MRGCN_REQUIRE(bc_dev || step >= 1, "step");
+  hipStream_t s = (hipStream_t)stream;
+  const int R = (int)p->num_relations;
+  const int64_t N = p->num_nodes;
+  if (p->ncols == 0)  // no column, no gradient: moments of `ever` nodes decay (the gradient pointer is never read)
+    return mrgcn_adam_step_rows_f32(param, param, exp_avg, exp_avg_sq, N, B * F, row_cur, row_ever, lr, beta1,
+                                    beta2, eps, step, bc_dev, grad_scale, stream);
+  float bc1 = 1.f, bc2s = 1.f;
+  if (!bc_dev) {
+    bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  }
+  const size_t lds = (size_t)R * B * sizeof(float);
+  const int nv = (B * F) / 4;
+  int per_cu = (int)((150 * 1024) / (lds + 512));
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  int64_t grid = (int64_t)256 * per_cu;
+  const int64_t want = (N + kFusedTB / 64 - 1) / (kFusedTB / 64);
+  if (grid > want) grid = want;
+  {
+    auto kfn = k_adam_rows_fused;
+    static size_t lds_allowed = 48 * 1024;
+    if (lds > lds_allowed) {
+      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lds_allowed = lds;
+    }
+    kfn<<<dim3((unsigned)grid), dim3(kFusedTB), lds, s>>>(p->nptr, p->urel, col_live, dM, ldM, comp, N, R, B, F,
+                                                          param, exp_avg, exp_avg_sq, row_cur, row_ever, lr, beta1,
+                                                          beta2, eps, bc1, bc2s, grad_scale, bc_dev);
+  }
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
 int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const uint8_t *col_live,
                             const float *V, const float *comp, int32_t B, int32_t F, float *dV,
                             uint8_t *node_cur, float *dcomp, double *dV_sumsq, void *stream) {
-  MRGCN_REQUIRE(p && dM && V && comp && dcomp && dV, "NULL");
+  MRGCN_REQUIRE(p && dM && V && comp && dcomp, "NULL");
   MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
+  // dV == NULL: the norm-only pass in front of mrgcn_adam_step_rows_fused_f32 (flags, dcomp and ||dV||^2 only)
+  MRGCN_REQUIRE(dV || (node_cur && dV_sumsq && mrgcn_adam_rows_fused_supported(p, B, F)),
+                "dV may only be NULL with node_cur and dV_sumsq, on shapes mrgcn_adam_rows_fused_supported accepts");
   hipStream_t s = (hipStream_t)stream;
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
@@ -1258,6 +1436,7 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const
     int rc = mix_bwd_nm_launch(p, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, s, col_live, node_cur);
     if (rc >= 0) return rc;
   }
+  MRGCN_REQUIRE(dV, "the norm-only pass needs the wave-over-nodes kernel");
   // the two-kernel form reads every row of dM (rows flagged dead may be unwritten) and writes every
   // block of dV: every node counts as written
   if (col_live) {

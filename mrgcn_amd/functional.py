@@ -292,18 +292,29 @@ class _RgcnLayer(torch.autograd.Function):
                     if rows is not None and rows["fresh"]:
                         raise L.MrgcnError("row-sparse weight_I gradient: the layer ran twice in one train_step "
                                            "(use train_step(..., row_sparse=False))")
-                    if rows is None or rows["g"].shape != weight_I.shape or rows["g"].device != dev:
-                        rows = dict(g=torch.empty_like(wI), cur=torch.zeros(N_, dtype=torch.uint8, device=dev),
+                    # when the shape allows it no gradient tensor exists at all: the backward keeps flags, dcomp
+                    # and ||dV||^2, and ClipAdam rebuilds each live block from dM inside the Adam pass
+                    # (mrgcn_adam_step_rows_fused_f32); otherwise the blocks of the live nodes go to rows["g"]
+                    fused = bool(lib.mrgcn_adam_rows_fused_supported(plan.handle, Bn, F))
+                    if rows is None or rows["shape"] != tuple(weight_I.shape) or rows["cur"].device != dev:
+                        rows = dict(g=None, shape=tuple(weight_I.shape),
+                                    cur=torch.zeros(N_, dtype=torch.uint8, device=dev),
                                     ever=torch.zeros(N_, dtype=torch.uint8, device=dev), sumsq=None, fresh=False,
-                                    seeded_for=None)
+                                    seeded_for=None, fused=None)
                         param._mrgcn_rows = rows
+                    if not fused and rows["g"] is None:
+                        rows["g"] = torch.empty_like(wI)
                 if rows is not None:
                     sq = torch.zeros((), dtype=torch.float64, device=dev)
                     L.check(lib.mrgcn_basis_mix_bwd_f32(
                         plan.handle, dM.data_ptr(), ld, live.data_ptr(), wI.data_ptr(), comp_I.data_ptr(), Bn, F,
-                        rows["g"].data_ptr(), rows["cur"].data_ptr(), d_comp.data_ptr(), sq.data_ptr(), s),
-                        "mrgcn_basis_mix_bwd_f32")
+                        0 if fused else rows["g"].data_ptr(), rows["cur"].data_ptr(), d_comp.data_ptr(),
+                        sq.data_ptr(), s), "mrgcn_basis_mix_bwd_f32")
                     rows["sumsq"], rows["fresh"] = sq, True
+                    # what the fused update reads: dM and the column flags of this backward, and the coefficients
+                    # as they were (the optimizer may update weight_I_comp before weight_I)
+                    rows["fused"] = dict(plan=plan, dM=dM, ld=ld, live=live, comp=comp_I.detach().clone(), B=Bn,
+                                         F=F) if fused else None
                     d_wI = None  # travels in param._mrgcn_rows
                 else:
                     d_wI = torch.empty_like(wI)

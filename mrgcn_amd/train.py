@@ -239,6 +239,14 @@ class ClipAdam(torch.optim.Optimizer):
                 b1, b2 = group["betas"]
                 bc = bias[(float(b1), float(b2))].data_ptr() if self.capturable else 0
                 nrows = p.shape[0]
+                fz = ent.get("fused")
+                if fz is not None:  # no gradient tensor: the blocks are rebuilt from dM inside the Adam pass
+                    L.check(lib.mrgcn_adam_step_rows_fused_f32(
+                        fz["plan"].handle, fz["dM"].data_ptr(), fz["ld"], fz["live"].data_ptr(), fz["comp"].data_ptr(),
+                        fz["B"], fz["F"], p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                        ent["cur"].data_ptr(), ent["ever"].data_ptr(), float(group["lr"]), float(b1), float(b2),
+                        float(group["eps"]), int(st["step"]), bc, coef_ptr, s), "mrgcn_adam_step_rows_fused_f32")
+                    continue
                 L.check(lib.mrgcn_adam_step_rows_f32(
                     p.data_ptr(), ent["g"].data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                     nrows, p.numel() // max(nrows, 1), ent["cur"].data_ptr(), ent["ever"].data_ptr(),

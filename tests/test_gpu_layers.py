@@ -647,3 +647,66 @@ def test_row_sparse_adam_through_the_c_abi():
         assert torch.equal(p[touched], pr[touched]) and torch.equal(m[touched], mr[touched])
         assert torch.equal(v[touched], vr[touched])
         assert torch.equal(ev, ever | cur)
+
+
+@pytest.mark.parametrize("N,R,B,F,hub,zero_frac", [(900, 7, 40, 10, 500, 0.6), (640, 9, 64, 16, 200, 0.9),
+                                                   (500, 5, 16, 4, 0, 0.0), (333, 6, 48, 12, 100, 0.97)])
+def test_adam_with_the_gradient_formed_on_the_fly_through_the_c_abi(N, R, B, F, hub, zero_frac):
+    """mrgcn_basis_mix_bwd_f32(dV = NULL) + mrgcn_adam_step_rows_fused_f32 against the stored-gradient pair
+    (mrgcn_basis_mix_bwd_f32 with dV + mrgcn_adam_step_rows_f32): the same flags, dcomp and squared norm, and
+    bit-identical parameters / moments / `ever` — untouched nodes stay bit for bit, nodes with moments but no
+    gradient this step decay.  NaN-poisoned dead rows of dM are never read; the coefficients are the snapshot."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphPlan
+    rng = np.random.default_rng(N + B)
+    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, 1, F, 5 * N, hub)
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    plan = GraphPlan(At, N, R)
+    lib = L.load()
+    assert lib.mrgcn_adam_rows_fused_supported(plan.handle, B, F) == 1
+    assert lib.mrgcn_adam_rows_fused_supported(plan.handle, 7, 3) == 0      # B F not a multiple of 4
+    nc, ld = plan.ncols, (F + 3) // 4 * 4
+    s = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator("cuda").manual_seed(N)
+    dM = torch.randn((nc, ld), device="cuda", generator=gen)
+    dead = torch.rand(nc, device="cuda", generator=gen) < zero_frac
+    live = (~dead).to(torch.uint8)
+    dM[dead] = float("nan")
+    V = torch.randn((N, B, F), device="cuda", generator=gen)
+    comp = torch.randn((R, B), device="cuda", generator=gen)
+    m0 = torch.randn((N, B, F), device="cuda", generator=gen) * 0.1
+    v0 = torch.rand((N, B, F), device="cuda", generator=gen) * 0.01
+    ever0 = (torch.rand(N, device="cuda", generator=gen) < 0.3).to(torch.uint8)
+    coef = torch.tensor(0.83, device="cuda")
+    # stored-gradient reference
+    g = torch.full((N, B, F), float("nan"), device="cuda")
+    cur_r = torch.full((N,), 9, dtype=torch.uint8, device="cuda")
+    dc_r = torch.empty((R, B), device="cuda")
+    sq_r = torch.zeros((), dtype=torch.float64, device="cuda")
+    L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dM.clone().data_ptr(), ld, live.data_ptr(), V.data_ptr(),
+                                        comp.data_ptr(), B, F, g.data_ptr(), cur_r.data_ptr(), dc_r.data_ptr(),
+                                        sq_r.data_ptr(), s))
+    untouched = (cur_r == 0) & (ever0 == 0)
+    m0[untouched] = 0; v0[untouched] = 0
+    pr, mr, vr, er = V.clone(), m0.clone(), v0.clone(), ever0.clone()
+    L.check(lib.mrgcn_adam_step_rows_f32(pr.data_ptr(), g.data_ptr(), mr.data_ptr(), vr.data_ptr(), N, B * F,
+                                         cur_r.data_ptr(), er.data_ptr(), 0.01, 0.9, 0.999, 1e-8, 5, 0,
+                                         coef.data_ptr(), s))
+    # on the fly
+    cur = torch.full((N,), 9, dtype=torch.uint8, device="cuda")
+    dc = torch.empty((R, B), device="cuda")
+    sq = torch.zeros((), dtype=torch.float64, device="cuda")
+    L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dM.data_ptr(), ld, live.data_ptr(), V.data_ptr(), comp.data_ptr(),
+                                        B, F, 0, cur.data_ptr(), dc.data_ptr(), sq.data_ptr(), s))
+    assert torch.equal(cur, cur_r)
+    np.testing.assert_allclose(dc.cpu().numpy(), dc_r.cpu().numpy(), rtol=1e-5, atol=1e-4)   # (LDS atomics: order)
+    np.testing.assert_allclose(float(sq), float(sq_r), rtol=1e-6)
+    p, m, v, ev = V.clone(), m0.clone(), v0.clone(), ever0.clone()
+    L.check(lib.mrgcn_adam_step_rows_fused_f32(plan.handle, dM.data_ptr(), ld, live.data_ptr(), comp.data_ptr(), B, F,
+                                               p.data_ptr(), m.data_ptr(), v.data_ptr(), cur.data_ptr(), ev.data_ptr(),
+                                               0.01, 0.9, 0.999, 1e-8, 5, 0, coef.data_ptr(), s))
+    assert torch.equal(ev, er)
+    assert torch.equal(p, pr) and torch.equal(m, mr) and torch.equal(v, vr)
+    assert torch.equal(p[untouched], V[untouched])
+    if zero_frac > 0:
+        assert int(untouched.sum()) > 0 and int(((cur == 0) & (ever0 == 1)).sum()) > 0
