@@ -490,19 +490,34 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
 constexpr int kNodeTB = 512;  // 8 waves share one LDS copy of the dcomp accumulators
 constexpr int kGroup = 4;     // consecutive nodes whose pointers / flags / relation ids a wave fetches at once
 
-// F floats of one basis row, rows only 4 * F bytes apart: 8-byte accesses when F is even
+// F floats of one basis row, rows only 4 * F bytes apart: 8-byte aligned when F is even.  The vector memory
+// path only needs dword alignment, so such a row goes as 16-byte pieces plus an 8-byte tail (F = 10: three
+// instructions instead of five — the kernel is bound by the texture addresser, which walks the same 13 lines of
+// a node's block for every one of them)
+typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 template <int FT>
 __device__ __forceinline__ void load_row(const float *__restrict__ p, int F, float (&v)[FT]) {
   if ((F & 1) == 0) {
 #pragma unroll
-    for (int o = 0; o < FT; o += 2) {
-      if (o < F) {
-        const float2 t = *reinterpret_cast<const float2 *>(p + o);
+    for (int o = 0; o < FT; o += 4) {
+      if (o + 4 <= F && o + 4 <= FT) {
+        const f32x4_a8 t = *reinterpret_cast<const f32x4_a8 *>(p + o);
         v[o] = t.x;
-        if (o + 1 < FT) v[o + 1] = t.y;
+        v[o + 1] = t.y;
+        v[o + 2] = t.z;
+        v[o + 3] = t.w;
       } else {
-        v[o] = 0.f;
-        if (o + 1 < FT) v[o + 1] = 0.f;
+#pragma unroll
+        for (int u = o; u < o + 4 && u < FT; u += 2) {
+          if (u < F) {
+            const float2 t = *reinterpret_cast<const float2 *>(p + u);
+            v[u] = t.x;
+            if (u + 1 < FT) v[u + 1] = t.y;
+          } else {
+            v[u] = 0.f;
+            if (u + 1 < FT) v[u + 1] = 0.f;
+          }
+        }
       }
     }
   } else {
