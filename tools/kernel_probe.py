@@ -26,6 +26,7 @@ def main():
                     help="fraction of dY rows set to zeros for spmm_tl10 (the AM epoch: 0.997 / 0.9994)")
     ap.add_argument("--dm-zero-frac", type=float, default=0.0,
                     help="fraction of dM rows set to exact zeros (the AM epoch has ~0.9)")
+    ap.add_argument("--x-ld", type=int, default=0, help="row stride of X in floats (default: its width)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = L.load()
@@ -48,7 +49,8 @@ def main():
         dM[torch.rand(nc, device=dev) < a.dm_zero_frac] = 0
     dV = torch.empty_like(V)
     dcomp = torch.empty_like(comp)
-    X = torch.randn((N, K), device=dev)
+    ldx = a.x_ld if a.x_ld >= K else K
+    X = torch.randn((N, ldx), device=dev)[:, :K]     # row stride ldx (e.g. 160: whole 128-byte lines at K = 155)
     W0 = torch.randn((R, K, F), device=dev)
     H = torch.randn((N, F), device=dev)
     C = sh["classes"]
@@ -86,9 +88,9 @@ def main():
         "adam_rows": lambda: chk(lib.mrgcn_adam_step_rows_f32(P.data_ptr(), dV.data_ptr(), M_.data_ptr(), V_.abs_().data_ptr(), N, B * F, ncur.data_ptr(), never.data_ptr(), 0.01, 0.9, 0.999, 1e-8, 1, 0, coef.data_ptr(), s)),
         "spmm_tl10": lambda: chk(lib.mrgcn_spmm_transposed_live_f32(h, dYz.data_ptr(), 10, 10, dM.data_ptr(), 12, scratch.data_ptr(), clive.data_ptr(), 0, 1, s)),
         "spmm_tl10_nd": lambda: chk(lib.mrgcn_spmm_transposed_live_f32(h, dYz.data_ptr(), 10, 10, dM.data_ptr(), 12, scratch.data_ptr(), clive.data_ptr(), 0, 0, s)),
-        "xf_fwd0": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, X.data_ptr(), K, K, W0.data_ptr(), F, M2.data_ptr(), 12, 0, s)),
+        "xf_fwd0": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, X.data_ptr(), ldx, K, W0.data_ptr(), F, M2.data_ptr(), 12, 0, s)),
         "xf_fwd1": lambda: chk(lib.mrgcn_rel_transform_fwd_f32(h, H.data_ptr(), F, F, W1.data_ptr(), C, M.data_ptr(), ld, 1, s)),
-        "xf_bwd0": lambda: chk(lib.mrgcn_rel_transform_bwd_f32(h, dM.data_ptr(), 12, X.data_ptr(), K, K, W0.data_ptr(), F, 0, K, dW0.data_ptr(), ws.data_ptr(), nws, s)),
+        "xf_bwd0": lambda: chk(lib.mrgcn_rel_transform_bwd_f32(h, dM.data_ptr(), 12, X.data_ptr(), ldx, K, W0.data_ptr(), F, 0, K, dW0.data_ptr(), ws.data_ptr(), nws, s)),
         "xf_bwd1": lambda: chk(lib.mrgcn_rel_transform_bwd_f32(h, dM1.data_ptr(), 12, H.data_ptr(), F, F, W1.data_ptr(), C, dH.data_ptr(), F, dW1.data_ptr(), ws.data_ptr(), nws, s)),
         "spmm": lambda: plan.spmm(L.VIEW_COMPACT, M, F=F, out=Y),
         "spmm_t10": lambda: plan.spmm(L.VIEW_TRANSPOSED, dY10, F=10, out=dM),
