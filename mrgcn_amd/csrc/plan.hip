@@ -327,6 +327,44 @@ hipError_t pool_alloc(void **p, size_t bytes, hipStream_t s) {
   return hipMallocAsync(p, bytes, s);
 }
 
+// Operand rows of 48 bytes (ld = 12: the F = 10 / 11 / 12 layers) straddle a 128-byte line at two of every eight
+// positions (p % 8 in {2, 5}).  A column read by ONE row sits in that row's sequential run, where the second line
+// is fetched anyway; a column with several readers pays both lines on every re-read.  Inside each aligned group
+// of eight positions the re-read columns therefore trade places with single-reader ones until none of them sits
+// on a straddling slot (the group stays the same three lines; other row sizes: a harmless local permutation).
+__global__ void k_avoid_straddle(int32_t *__restrict__ order, const int32_t *__restrict__ cptr, int64_t ncols) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t p0 = g * 8;
+  if (p0 + 8 > ncols) return;  // (a ragged last group stays as it is)
+  int32_t c[8];
+  bool multi[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c[i] = order[p0 + i];
+    multi[i] = cptr[c[i] + 1] - cptr[c[i]] > 1;
+  }
+  bool changed = false;
+#pragma unroll
+  for (int si = 0; si < 2; ++si) {
+    const int sl = si == 0 ? 2 : 5;
+    if (!multi[sl]) continue;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i == 2 || i == 5 || multi[i] || !multi[sl]) continue;
+      const int32_t t = c[sl];
+      c[sl] = c[i];
+      c[i] = t;
+      multi[sl] = false;
+      multi[i] = true;
+      changed = true;
+    }
+  }
+  if (changed) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) order[p0 + i] = c[i];
+  }
+}
+
 struct Scratch {  // returns its allocations to the pool on scope exit, ordered after the build's work on `s`
   hipStream_t s = nullptr;
   std::vector<void *> ptrs;
@@ -664,6 +702,10 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
     MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, mk, mk_s, ids, order, (int)ncols, 0,
                                                      end_bit, s));
+    {
+      static const bool swap_on = !(getenv("MRGCN_AVOID_STRADDLE") && atoi(getenv("MRGCN_AVOID_STRADDLE")) == 0);
+      if (swap_on && ncols >= 8) k_avoid_straddle<<<nblocks(ncols / 8), kTB, 0, s>>>(order, p->cptr, ncols);
+    }
     k_invert_perm<<<nblocks(ncols), kTB, 0, s>>>(order, ncols, p->mpos);
     MRGCN_HIP_TRY(hipGetLastError());
     // the COMPACT view walks the rows in class-major order (ptr3 / rowmap) and a row's entries in rising

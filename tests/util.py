@@ -121,6 +121,20 @@ def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False):
         max_count = int(cnt.max()) + 1
         hi = np.where(cnt >= HOT_MIN_REFS, max_count - cnt, max_count + 1 + firstrow)
         order = np.lexsort((np.arange(ncols), hi))
+        # inside every aligned group of eight positions, columns with several readers leave the two slots whose
+        # 48-byte rows straddle a 128-byte line (2 and 5) to single-reader columns (plan.hip::k_avoid_straddle)
+        order = order.copy()
+        for g0 in range(0, ncols - 7, 8):
+            grp = order[g0:g0 + 8]
+            multi = cnt[grp] > 1
+            for sl in (2, 5):
+                if not multi[sl]:
+                    continue
+                for i in (0, 1, 3, 4, 6, 7):
+                    if not multi[i]:
+                        grp[sl], grp[i] = grp[i], grp[sl]
+                        multi[sl], multi[i] = False, True
+                        break
         mpos = np.empty(ncols, dtype=np.int32)
         mpos[order] = np.arange(ncols, dtype=np.int32)
     else:
