@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import util
+
 pytestmark = pytest.mark.gpu
 
 
@@ -73,3 +75,91 @@ def test_config4_fb15k_encoder_quarter_shape():
 def test_l1_l2_regularisation_terms():
     # node_classification.py:172-188: penalties over parameters whose name contains 'weight'
     _run_pair("aifb", 0.5, [(5, 8), (8, 4)], 3, False, "norm_f32", labelled=100, l1=1e-4, l2=1e-3)
+
+
+def test_config2_mutag_full_shape_with_the_encoders_in_front():
+    """BASELINE config 2/3 with the modality encoders actually feeding `X` (not random columns): MRGCN(FullBatch) at
+    the full MUTAG shape (23 644 nodes, 47 relations, 30 bases) with an xsd.numeric MLP over 6 000 literal nodes
+    and an ogc.wktLiteral TCNN over 500, through `FullBatch.as_tensors_() / .to()`.  Reference on the host: the same
+    encoder modules in float64 (torch CPU), the gate multiply + scatter of mrgcn.py:250-305 written out, then the
+    float64 R-GCN oracle; logits at 1e-4, loss, and the gradients that travel back through X into the encoders
+    (gates, first MLP layer, first TCNN convolution) via the oracle's dX."""
+    import copy
+    import scipy.sparse as sp
+    from mrgcn_amd import synth
+    from mrgcn_amd.data.batch import FullBatch
+    from mrgcn_amd.models.mrgcn import MRGCN
+    from oracle import rgcn_oracle as O
+    g = synth.make_graph("mutag", seed=5, scale=1.0, value_mode="norm_f32")
+    N, R, B = g.num_nodes, g.num_relations, 30
+    rng = np.random.default_rng(8)
+    num_idx = np.sort(rng.choice(N, 6000, replace=False))
+    num = rng.standard_normal((6000, 4)).astype(np.float32)
+    wkt_idx = np.sort(rng.choice(N, 500, replace=False))
+    wkt = (rng.random((500, 9, 20)) < 0.15).astype(np.float32)
+    torch.manual_seed(12)
+    emb_cfg = sorted([("ogc.wktLiteral", (9, 5, "S", 0.0), False), ("xsd.numeric", (4, 3, 0.0), False)],
+                     key=lambda t: t[0])
+    modules = [(8, 16, "mrgcn", torch.nn.ReLU()), (16, 2, "mrgcn", None)]
+    model = MRGCN(modules, emb_cfg, R, N, num_bases=B, p_dropout=0.0, featureless=False, bias=True,
+                  gcn_gpu_acceleration=True)
+    A = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
+    X = [np.empty((N, 0), dtype=np.float32),
+         ["ogc.wktLiteral", [[wkt, wkt_idx, np.full(500, 20)]], False],
+         ["xsd.numeric", [[num, num_idx, np.ones(6000, dtype=int)]], False]]
+    batch = FullBatch(A, X, np.arange(N), value_mode="norm_f32")
+    batch.as_tensors_()
+    batch.to(model.devices)
+    model.train()   # batch-statistics BatchNorm in the TCNN, as in a training epoch
+    logits = model(batch)
+    idx = np.sort(rng.choice(N, 340, replace=False))
+    y = rng.integers(0, 2, 340)
+    from mrgcn_amd.train import categorical_crossentropy
+    loss = categorical_crossentropy(logits, torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda())
+    loss.backward()
+
+    # ---- host reference -------------------------------------------------------------------------------------
+    tcnn = copy.deepcopy(model.module_dict["ogc_wktLiteral_0"]).cpu().double().train()
+    mlp = copy.deepcopy(model.module_dict["xsd_numeric_0"]).cpu().double().train()
+    for m in tcnn.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):   # the GPU forward above already moved the running statistics
+            m.momentum = 0.0
+    gates = model.gate_weights.detach().cpu().double().requires_grad_(True)
+    XF = torch.zeros((N, 8), dtype=torch.float64)
+    off = 0
+    for name, mod, enc, nidx in (("ogc.wktLiteral", tcnn, wkt, wkt_idx), ("xsd.numeric", mlp, num, num_idx)):
+        _, _, out_dim, i_gate = model.modality_modules[name][0]
+        out = mod(torch.from_numpy(enc).double())
+        XF = XF.index_put((torch.from_numpy(nidx)[:, None], torch.arange(off, off + out_dim)[None, :]),
+                          gates[i_gate] * out)
+        off += out_dim
+    cfgs = [O.LayerCfg(8, 16, R, N, B, bias=True, input_layer=True, featureless=False),
+            O.LayerCfg(16, 2, R, N, B, bias=True, input_layer=False, featureless=False)]
+    sd = {k: v.detach().cpu().numpy() for k, v in model.rgcn.state_dict().items()}
+    params = [{k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith(f"layers.layer_{i}.")} for i in range(2)]
+    A64 = sp.csr_matrix((g.vals.astype(np.float64), (g.rows, g.cols)), shape=(N, R * N))
+    Xn = XF.detach().numpy()
+    pre0, c0 = O.layer_forward(cfgs[0], params[0], Xn, A64)
+    H = np.maximum(pre0, 0)
+    pre1, c1 = O.layer_forward(cfgs[1], params[1], H, A64)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), pre1, rtol=1e-4, atol=1e-4)
+    z = pre1[idx] - pre1[idx].max(1, keepdims=True)
+    logp = z - np.log(np.exp(z).sum(1, keepdims=True))
+    want_loss = -logp[np.arange(340), y].mean()
+    np.testing.assert_allclose(float(loss), want_loss, rtol=2e-5, atol=1e-6)
+    dlog = np.zeros_like(pre1)
+    sm = np.exp(logp)
+    sm[np.arange(340), y] -= 1.0
+    np.add.at(dlog, idx, sm / 340)
+    g1, dH = O.layer_backward(cfgs[1], params[1], H, A64, dlog, c1)
+    g0, dX = O.layer_backward(cfgs[0], params[0], Xn, A64, dH * (pre0 > 0), c0)
+    XF.backward(torch.from_numpy(dX))
+    got_w = util.ref_layout(model.rgcn.layers["layer_0"].weight_F.grad, "weight_F").cpu().numpy()
+    np.testing.assert_allclose(got_w, g0["weight_F"], rtol=2e-3, atol=2e-6 * max(1.0, np.abs(g0["weight_F"]).max()))
+    for got, want, name in ((model.gate_weights.grad, gates.grad, "gates"),
+                            (model.module_dict["xsd_numeric_0"].mlp[0].weight.grad, mlp.mlp[0].weight.grad, "mlp"),
+                            (model.module_dict["ogc_wktLiteral_0"].conv[0].weight.grad, tcnn.conv[0].weight.grad,
+                             "tcnn conv0")):
+        want = want.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=5e-3, atol=5e-4 * float(np.abs(want).max()) + 1e-9,
+                                   err_msg=name)
