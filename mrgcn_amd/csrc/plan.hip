@@ -604,7 +604,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
         end.push_back(std::min(b0 + rel_chunk, h_gptr[g + 1]));
       }
     }
-    {  // the relation with the most compact columns: k_mix_bwd_node keeps its dcomp row in registers
+    {  // the relation with the most compact columns: k_mix_bwd_nm keeps its dcomp row in registers
       std::vector<int64_t> per_rel(R, 0);
       for (int64_t g = 0; g < ngroups; ++g) per_rel[g % R] += h_gptr[g + 1] - h_gptr[g];
       int64_t best = 0;

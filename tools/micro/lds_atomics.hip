@@ -1,5 +1,5 @@
 // Microbenchmark: LDS atomic-add throughput on gfx950 for float / uint32 / uint64 / double operands,
-// 40 active lanes per wave to consecutive addresses (the dcomp pattern of k_mix_bwd_node), one
+// 40 active lanes per wave to consecutive addresses (the dcomp pattern of k_mix_bwd_nm), one
 // 1024-thread block per CU.   hipcc -O3 --offload-arch=gfx950 tools/micro/lds_atomics.hip -o lds_atomics
 #include <hip/hip_runtime.h>
 #include <cstdio>
