@@ -3,10 +3,10 @@
 With a handful of labelled nodes only the nodes within `num_layers` in-neighbour steps of a label
 ever receive gradient in the input layer's node table (`weight_I`, graph.py:62-75): every other
 row of it has a zero gradient, zero Adam moments and never moves.  The HIP backward and `ClipAdam`
-skip such rows at the granularity of 4 KB chunks of the table (functional.sparse_weight_grad), so
-the saving depends on how the reachable nodes are numbered: scattered over the id range (any KG
-whose ids follow first appearance in the dump) nearly every chunk holds one; numbered first, the
-rest of the table is never touched.  The reference numbers nodes arbitrarily (the order of
+skip such rows per node (the node-major table keeps a node's block contiguous: functional.py, row-sparse
+gradient), in any numbering; numbering the reachable nodes first additionally makes the touched blocks one
+contiguous range (whole pages of the table and of its moments are then never touched: `bench.py`'s
+`extra.epoch_ms_nodes_renumbered`).  The reference numbers nodes arbitrarily (the order of
 `mkdataset`'s entity index), so renumbering is a pure relabelling of the dataset:
 
     order, inv = label_reach_order(rows, cols, N, R, idx, hops=num_layers)
