@@ -326,3 +326,52 @@ def test_model_on_a_plan_with_replicas_matches_the_golden():
     for step in range(1, int(c["meta.n_adam"]) + 1):
         loss = train_step(model, lambda: model(X, A), idx, tgt, opt)
         np.testing.assert_allclose(float(loss), float(c[f"loss_step{step}"]), rtol=2e-4, atol=2e-5)
+
+
+def test_operand_order_keeps_reread_rows_off_the_straddling_slots():
+    """plan.hip::k_avoid_straddle on a graph with many multi-reader columns: the operand order stays a permutation,
+    every aligned group of eight positions holds the same columns as the plain hot / first-touch order (a local
+    exchange), and no column with several readers sits on position 2 or 5 of a group that still has a single-reader
+    column elsewhere; MRGCN_AVOID_STRADDLE=0 gives the plain order.  The product is the same on both."""
+    import os
+    import subprocess
+    import sys
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd import synth
+    from mrgcn_amd.plan import GraphPlan
+    g = synth.make_graph("am", seed=2, scale=0.02)
+    N, R = g.num_nodes, g.num_relations
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals), (N, R * N)).cuda()
+    plan = GraphPlan(A, N, R)
+    mpos = plan.export(L.ARR_MPOS).astype(np.int64)
+    cptr = plan.export(L.ARR_CPTR).astype(np.int64)
+    nc = plan.ncols
+    assert np.array_equal(np.sort(mpos), np.arange(nc))
+    readers = np.diff(cptr)
+    at = np.empty(nc, dtype=np.int64)
+    at[mpos] = np.arange(nc)                     # column at each position
+    multi = (readers[at] > 1)[: nc // 8 * 8].reshape(-1, 8)
+    single_elsewhere = (~multi[:, [0, 1, 3, 4, 6, 7]]).any(1)
+    assert not (multi[:, 2] & single_elsewhere).any() and not (multi[:, 5] & single_elsewhere).any()
+    assert multi.any()                            # the case is not vacuous
+    code = ("import numpy as np, torch\n"
+            "from mrgcn_amd import synth, _lib as L\nfrom mrgcn_amd.plan import GraphPlan\n"
+            "g = synth.make_graph('am', seed=2, scale=0.02)\nN, R = g.num_nodes, g.num_relations\n"
+            "A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals), (N, R * N)).cuda()\n"
+            "p = GraphPlan(A, N, R)\nnp.save('/tmp/_mpos_plain.npy', p.export(L.ARR_MPOS))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=root, env=dict(os.environ, MRGCN_AVOID_STRADDLE="0"))
+    plain = np.load("/tmp/_mpos_plain.npy").astype(np.int64)
+    assert not np.array_equal(plain, mpos)
+    assert np.array_equal(plain // 8, mpos // 8)   # every column stayed inside its group of eight
+    M = torch.randn((nc, 12), device="cuda")
+    Y = plan.spmm(L.VIEW_COMPACT, M, F=10).cpu().numpy()
+    # the same product with the operand rows laid out in the plain order
+    Mp = torch.empty_like(M)
+    Mp[torch.from_numpy(plain).cuda()] = M[torch.from_numpy(mpos).cuda()]
+    import scipy.sparse as sp
+    ccol = plan.export(L.ARR_CCOL).astype(np.int64)
+    rowidx = plan.export(L.ARR_ROWIDX).astype(np.int64)
+    val = plan.export(L.ARR_VAL).astype(np.float64)
+    want = sp.csr_matrix((val, (rowidx, mpos[ccol])), shape=(N, nc)) @ M[:, :10].double().cpu().numpy()
+    np.testing.assert_allclose(Y, want, rtol=1e-4, atol=1e-5)
