@@ -1,7 +1,7 @@
 #!/bin/bash
 # Separate rocprofv3 --pmc passes (one small counter set each, every pass under its own timeout:
 # a counter set the hardware cannot schedule makes rocprofv3 abort and then hang).
-#   tools/pmc_passes.sh <out_prefix> [mem|sq|all] -- <program> [args...]
+#   tools/pmc_passes.sh <out_prefix> [mem|sq|all|mfma] -- <program> [args...]
 out=$1; which=$2; shift; shift; shift
 mem=(
  "FETCH_SIZE"
@@ -28,9 +28,16 @@ sq=(
  "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum"
  "MeanOccupancyPerActiveCU"
 )
+mfma=(
+ "SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32"
+ "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"
+ "MfmaUtil"
+ "GRBM_GUI_ACTIVE"
+)
 sets=()
 [ "$which" = mem ] || [ "$which" = all ] && sets+=("${mem[@]}")
 [ "$which" = sq ] || [ "$which" = all ] && sets+=("${sq[@]}")
+[ "$which" = mfma ] && sets+=("${mfma[@]}")
 i=0
 for set in "${sets[@]}"; do
   d=${out}_$i
