@@ -51,14 +51,18 @@ def _single():
     return state, logits0, losses, {k: v.cpu() for k, v in model.state_dict().items()}
 
 
-def _worker(rank, world, port, state, out):
+def _worker(rank, world, port, state, out, backend="gloo"):
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     from mrgcn_amd.partition import NodePartition, PartitionedRGCN, partitioned_train_step
     from mrgcn_amd.train import ClipAdam
-    dist.init_process_group("gloo")
     dev = torch.device("cuda:0")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
     g, X, idx, y, mods = _problem()
     N, R = g.num_nodes, g.num_relations
     part = NodePartition(N, world, rank)
@@ -97,6 +101,24 @@ def test_partitioned_ranks_equal_single_gpu(world):
     for r in ranks:
         d = np.abs(out[r][3] - final["layers.layer_1.weight_F"].numpy())
         assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.045
+
+
+@pytest.mark.timeout(600)
+def test_partitioned_engine_over_rccl_with_one_rank():
+    """The RCCL branches of the engine (reduce_scatter_tensor, all_gather_into_tensor, the asynchronous all-reduce
+    of the replicated gradients from post-accumulate hooks, the sharded clip norm) executed on the one GPU this box
+    has: a process group of world size 1 over the nccl backend.  The collectives are identities there, but tensor
+    layouts, contiguity, stream ordering and the work handles are the ones an 8-GPU run uses — and the result must
+    equal the single-GPU model's."""
+    state, logits0, losses, final = _single()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(1, _free_port(), state, out, "nccl"), nprocs=1, join=True)
+    np.testing.assert_allclose(out[0][0], logits0, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out[0][1], losses, rtol=2e-4, atol=2e-5)
+    N = logits0.shape[0]
+    d = np.abs(out[0][2].reshape(5 * N, -1) - final["layers.layer_0.weight_I"].numpy())
+    assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.045
 
 
 def _lp_problem():
