@@ -561,7 +561,7 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_nm(const int32_t *__restric
     for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_dc[t] = 0.f;
     __syncthreads();
   }
-  float *dc = dc_in_lds ? s_dc : dcomp;
+  // (the two address spaces are kept apart in the code: through one generic pointer the adds become flat atomics)
   const bool on = lane < B;
   const int b = on ? lane : 0;
   const int64_t ngroups = (N + kGroup - 1) / kGroup;
@@ -662,7 +662,10 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_nm(const int32_t *__restric
             // LDS float atomics cost ~3 cycles per lane whatever the addresses: the most frequent
             // relation (a fifth of all columns on the AM shape) adds up in a register instead
             if (r[kk] == top_rel) hid += dot;
-            else if (on) atomicAdd(&dc[r[kk] * B + b], dot);
+            else if (on) {
+              if (dc_in_lds) atomicAdd(&s_dc[r[kk] * B + b], dot);  // ds_add_f32
+              else atomicAdd(&dcomp[r[kk] * B + b], dot);
+            }
 #pragma unroll
             for (int o = 0; o < FT; ++o) acc[o] = fmaf(w[kk], d[o], acc[o]);
           }
@@ -689,7 +692,10 @@ __global__ __launch_bounds__(kNodeTB) void k_mix_bwd_nm(const int32_t *__restric
       atomicAdd(sumsq, (double)t);
     }
   }
-  if (top_rel >= 0 && on && hid != 0.f) atomicAdd(&dc[top_rel * B + b], hid);
+  if (top_rel >= 0 && on && hid != 0.f) {
+    if (dc_in_lds) atomicAdd(&s_dc[top_rel * B + b], hid);
+    else atomicAdd(&dcomp[top_rel * B + b], hid);
+  }
   if (dc_in_lds) {
     __syncthreads();
     for (int t = threadIdx.x; t < R * B; t += blockDim.x) {
