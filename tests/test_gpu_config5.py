@@ -145,9 +145,15 @@ def test_config5_captured_epoch_equals_eager_epoch(s10m):
     np.testing.assert_allclose(l2, l1[1:], rtol=2e-4, atol=2e-5)
     with torch.no_grad():
         a, b = m1(X, A), m2(X, A)
-    # the two runs differ in the order of their float atomics (dcomp, norms): Adam's first steps turn a gradient
-    # at rounding level into an lr-sized move, so a few logits differ at the 1e-2 level; the rest agree tightly
+    # Two runs of the SAME path already differ in the order of their float atomics (dcomp, norms), and Adam turns a
+    # gradient entry at rounding level into an lr-sized move of random sign: a hundred of layer 0's 250 k weight_F
+    # entries then differ by 1e-3 and shift a quarter of the logits past 1e-4 (measured, eager vs eager: median
+    # 4.5e-5, 99th percentile 4e-4, maximum 1.1e-2 in such a run; 5e-8 / 6e-7 / 6e-5 in a run without such a flip).
+    # The bound is therefore statistical: the bulk agrees, nothing is far off.
     d = (a - b).abs() / max(1.0, float(a.abs().max()))
-    assert float((d > 1e-4).float().mean()) < 0.02 and float(d.max()) < 2e-2, (float(d.max()), float((d > 1e-4).float().mean()))
+    sample = d.flatten()[::97].float()
+    med, q99 = float(torch.quantile(sample, 0.5)), float(torch.quantile(sample, 0.99))
+    far = float((d > 2e-3).float().mean())
+    assert med < 2e-4 and q99 < 2e-3 and far < 5e-3 and float(d.max()) < 3e-2, (med, q99, far, float(d.max()))
     del m1, m2, o1, o2, step
     torch.cuda.empty_cache()
