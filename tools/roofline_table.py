@@ -22,7 +22,8 @@ def spmm_bytes(rows, ncols, F):
     return NNZ * 8 + (rows + 1) * 4 + ncols * F * 4 + rows * F * 4
 
 
-LIVE_NODES = 0.52  # share of the nodes with a live column on this graph (1 000 labels, two hops)
+LIVE_NODES = 0.497  # share of the nodes with a live column on this graph (1 000 labels, two hops)
+LIVE_COLS = 0.2485  # share of the compact columns with gradient in layer 0
 
 ALG = {  # kernel-name prefix -> (label, bytes)
     "mrgcn::k_adam<false>": ("Adam on weight_I: 7 streams x 4 B x B*N*F0", 7 * 4 * B * N * F0),
@@ -30,11 +31,14 @@ ALG = {  # kernel-name prefix -> (label, bytes)
                                                     4 * B * N * F0 + 2 * NCOLS * LD * 4 + NCOLS * 8 + N * 4),
     "mrgcn::k_mix_fwd<40, float>": ("V read once + addend read + M written + 3 index arrays",
                                     4 * B * N * F0 + 2 * NCOLS * LD * 4 + NCOLS * 8 + N * 4),
-    "mrgcn::k_mix_bwd_nm<10>": ("dV (node blocks of the live nodes only) + dcomp: V read for the live nodes + dV "
-                                "written + live dM rows + flags",
-                                int(2 * 4 * B * N * F0 * LIVE_NODES) + NCOLS * 2 + N * 5),
-    "mrgcn::k_adam_rows<4>": ("row-sparse Adam: p, g, m, v read and p, m, v written for the node blocks that ever "
-                              "had gradient", int(7 * 4 * B * N * F0 * LIVE_NODES)),
+    "mrgcn::k_mix_bwd_nm<10>": ("norm-only pass (dcomp, ||dV||^2, node flags): V read for the live nodes + live dM "
+                                "rows + flags", int(4 * B * N * F0 * LIVE_NODES) + int(NCOLS * LIVE_COLS) * LD * 4
+                                + NCOLS * 2 + N * 5),
+    "mrgcn::k_adam_rows_fused": ("Adam with the gradient formed on the fly: p, m, v read and written for the node "
+                                 "blocks that ever had gradient + their live dM rows",
+                                 int(6 * 4 * B * N * F0 * LIVE_NODES) + int(NCOLS * LIVE_COLS) * LD * 4 + N * 10),
+    "mrgcn::k_adam_rows<4>": ("row-sparse Adam from a stored gradient: p, g, m, v read and p, m, v written for the "
+                              "node blocks that ever had gradient", int(7 * 4 * B * N * F0 * LIVE_NODES)),
     "mrgcn::k_spmm3<4, 4, false, float>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
     "mrgcn::k_spmm<4, 4, true, float, false>": ("general transposed product, F=10 (probe leg only; the epoch runs k_spmm_t_live)",
                                                 spmm_bytes(NCOLS, N, F0)),
