@@ -386,15 +386,18 @@ int mrgcn_colsum_f32(const float *X, int64_t ld, int32_t M, int32_t N, float *ou
  * pool_kind 0: none (Tout = T), 1: MaxPool1d(pool_arg, stride pool_arg), 2: AdaptiveMaxPool1d(pool_arg).
  * training != 0: mean / var (biased) are the batch statistics, computed and written by the call; otherwise they are
  * read (running statistics).  argmax [B][C][Tout] (needed when pooled) keeps the winning position for the backward.
- * Backward: dz is a [B][C][T] workspace; dgamma / dbeta are written; dx = d loss / d x. */
+ * Backward: dz is a [B][C][T] workspace; dgamma / dbeta are written; dx = d loss / d x.
+ * workspace: mrgcn_bn_workspace_bytes(C) bytes (fp64 partial sums of the per-channel reductions; forward: training only). */
 int32_t mrgcn_pool_out_len(int32_t pool_kind, int32_t pool_arg, int32_t T);
+size_t mrgcn_bn_workspace_bytes(int32_t C);
 int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, const float *gamma,
                                const float *beta, float eps, int32_t training, float *mean, float *var,
-                               int32_t pool_kind, int32_t pool_arg, float *y, int32_t *argmax, void *stream);
+                               int32_t pool_kind, int32_t pool_arg, float *y, int32_t *argmax, void *workspace,
+                               void *stream);
 int mrgcn_bn_relu_pool_bwd_f32(const float *x, const float *y, const float *dy, const int32_t *argmax, int32_t B,
                                int32_t C, int32_t T, const float *gamma, const float *mean, const float *var,
                                float eps, int32_t training, int32_t pool_kind, int32_t pool_arg, float *dz,
-                               float *dx, float *dgamma, float *dbeta, void *stream);
+                               float *dx, float *dgamma, float *dbeta, void *workspace, void *stream);
 
 /* ---- mini-batch frontier on the resident CSR of the stacked adjacency ---------------------
  * Replaces, per layer of a batch, the host loops of mrgcn/data/batch.py:185-263 (`A[sample_idx]`,

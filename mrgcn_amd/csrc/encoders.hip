@@ -232,6 +232,7 @@ struct GemmArgs {
   const float *mask;        // nullable: C *= (mask > 0), same addressing as C
   float alpha;
   ConvGeom cg;
+  int kchunk = 0;           // > 0: split K — block z takes k in [z kchunk, (z + 1) kchunk) and ADDS into a zeroed C
 };
 
 __device__ __forceinline__ float gemm_a(const GemmArgs &g, int m, int k) {
@@ -316,6 +317,236 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
         if (g.bias) v += g.bias[n];
         if (g.relu) v = fmaxf(v, 0.f);
         const int64_t ci = gemm_c_index(g, m, n);
+        if (g.mask && !(g.mask[ci] > 0.f)) v = 0.f;
+        g.C[ci] = v;
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same product for shapes that can fill it: block tile 128 x 128, K step 16, four waves of 64 x 64 (4 x 4 MFMA
+// tiles each, 64 MFMAs per wave and K step).  Every operand element is  base[ rowoff(i) + coloff(k) ]  with the
+// conv coordinate carried along (valid while 0 <= t_row + t_col < Tin), so that the loaders need one division per
+// thread and K step at most; an operand is staged in LDS in the direction it is contiguous in memory
+//   KC  contiguous along k (A modes 0, 3; B modes 1, 2):  Xs[row][k],  thread = (row, half of the K step), 2 x 16 B
+//   MC  contiguous along the tile row (A modes 1, 2; B mode 0):  Xs[k][row],  thread = (k, 8 consecutive rows)
+// with 16-byte global loads where the eight elements are contiguous and in range (dword alignment is all the vector
+// memory path needs) and element loads at the edges; the next K step's elements are fetched into registers while the
+// current one is multiplied.
+// ---------------------------------------------------------------------------------------------------
+struct Idx2 {
+  int32_t off;   // element offset contribution
+  int32_t t;     // conv coordinate contribution (0 when the mode has none)
+  int32_t room;  // column maps only: how many consecutive k from this one on advance `off` (and `t`) by one each
+};
+__device__ __forceinline__ Idx2 ga_row(const GemmArgs &g, int m) {
+  switch (g.amode) {
+    case 0: return Idx2{(int32_t)(m * g.lda), 0, 0};
+    case 1: return Idx2{m, 0, 0};
+    case 2: { const int b = m / g.cg.Tout, t = m - b * g.cg.Tout; return Idx2{b * g.cg.Cin * g.cg.Tin + t, t, 0}; }
+    default: { const int ci = m / g.cg.KW, kw = m - ci * g.cg.KW; return Idx2{ci * g.cg.Tin + kw - g.cg.pad, kw - g.cg.pad, 0}; }
+  }
+}
+__device__ __forceinline__ Idx2 ga_col(const GemmArgs &g, int k) {
+  switch (g.amode) {
+    case 0: return Idx2{k, 0, 1 << 30};
+    case 1: return Idx2{(int32_t)(k * g.lda), 0, 1};
+    case 2: { const int ci = k / g.cg.KW, kw = k - ci * g.cg.KW; return Idx2{ci * g.cg.Tin + kw - g.cg.pad, kw - g.cg.pad, g.cg.KW - kw}; }
+    default: { const int b = k / g.cg.Tout, t = k - b * g.cg.Tout; return Idx2{b * g.cg.Cin * g.cg.Tin + t, t, g.cg.Tout - t}; }
+  }
+}
+__device__ __forceinline__ Idx2 gb_row(const GemmArgs &g, int n) {
+  switch (g.bmode) {
+    case 0: return Idx2{n, 0, 0};
+    case 1: return Idx2{(int32_t)(n * g.ldb), 0, 0};
+    default: return Idx2{n * g.cg.Tout, 0, 0};
+  }
+}
+__device__ __forceinline__ Idx2 gb_col(const GemmArgs &g, int k) {
+  switch (g.bmode) {
+    case 0: return Idx2{(int32_t)(k * g.ldb), 0, 1};
+    case 1: return Idx2{k, 0, 1 << 30};
+    default: { const int b = k / g.cg.Tout, t = k - b * g.cg.Tout; return Idx2{b * g.cg.Cout * g.cg.Tout + t, 0, g.cg.Tout - t}; }
+  }
+}
+
+constexpr int kBT = 128, kBK = 16, kMCP = kBT + 4;  // (KC rows are padded to BK + 4 floats)
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+// one operand's loader: IS_A picks the index maps, MC the staging direction
+template <bool IS_A, bool MC, int BK>
+struct TileLoader {
+  static constexpr int NV = BK / 2;      // elements per thread and K step
+  static constexpr int KCP = BK + 4;     // padded KC row
+  Idx2 fix[MC ? 8 : 1];  // the index that stays with the thread: MC: its 8 tile rows, KC: its one tile row
+  bool fix_ok[MC ? 8 : 1];
+  bool run_ok;           // MC: the 8 rows are contiguous in memory and inside the matrix
+  int conv;              // the mode carries a conv range check
+  int lim;               // Tin
+  __device__ __forceinline__ Idx2 rowf(const GemmArgs &g, int i) const { return IS_A ? ga_row(g, i) : gb_row(g, i); }
+  __device__ __forceinline__ Idx2 colf(const GemmArgs &g, int k) const { return IS_A ? ga_col(g, k) : gb_col(g, k); }
+  __device__ __forceinline__ void init(const GemmArgs &g, int row0, int rows_in_tile) {
+    const int R = min(IS_A ? g.M : g.N, row0 + rows_in_tile);
+    conv = IS_A && g.amode >= 2;
+    lim = g.cg.Tin;
+    if constexpr (MC) {
+      const int r0 = row0 + (threadIdx.x & 15) * 8;
+      run_ok = r0 + 7 < R;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        fix_ok[i] = r0 + i < R;
+        fix[i] = rowf(g, fix_ok[i] ? r0 + i : 0);
+        if (i > 0) run_ok = run_ok && fix[i].off == fix[0].off + i && fix[i].t == fix[0].t + (conv ? i : 0);
+      }
+    } else {
+      const int r = row0 + (threadIdx.x >> 1);
+      fix_ok[0] = r < R;
+      fix[0] = rowf(g, fix_ok[0] ? r : 0);
+      run_ok = false;
+    }
+  }
+  // the 8 elements of this thread for the K step at k0
+  __device__ __forceinline__ void load(const GemmArgs &g, int k0, int kend, float (&v)[NV]) const {
+    const float *base = IS_A ? g.A : g.B;
+    if constexpr (MC) {
+      const int k = k0 + (threadIdx.x >> 4);
+      const bool kin = k < kend;
+      const Idx2 c = colf(g, kin ? k : 0);
+      const int lo = fix[0].t + c.t, hi = fix[7].t + c.t;
+      if (kin && run_ok && (!conv || (lo >= 0 && hi < lim))) {
+        const float *p = base + (int64_t)fix[0].off + c.off;
+        const f32x4_u a = *reinterpret_cast<const f32x4_u *>(p), b = *reinterpret_cast<const f32x4_u *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int tt = fix[i].t + c.t;
+          const bool ok = kin && fix_ok[i] && (!conv || (tt >= 0 && tt < lim));
+          v[i] = ok ? base[(int64_t)fix[i].off + c.off] : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < NV / 8; ++h) {  // chunks of 8 consecutive k
+        const int kb = k0 + (threadIdx.x & 1) * NV + 8 * h;
+        // one index decomposition per chunk: the map says how far its run of consecutive k reaches
+        const Idx2 c0 = colf(g, kb < kend ? kb : 0);
+        const int tstep = conv ? 1 : 0;  // (A mode 3: the conv coordinate of the columns advances with k)
+        const int lo = fix[0].t + c0.t, hi = lo + 7 * tstep;
+        if (fix_ok[0] && kb + 7 < kend && c0.room >= 8 && (!conv || (lo >= 0 && hi < lim))) {
+          const float *p = base + (int64_t)fix[0].off + c0.off;
+          const f32x4_u a = *reinterpret_cast<const f32x4_u *>(p), b = *reinterpret_cast<const f32x4_u *>(p + 4);
+          v[8 * h + 0] = a.x; v[8 * h + 1] = a.y; v[8 * h + 2] = a.z; v[8 * h + 3] = a.w;
+          v[8 * h + 4] = b.x; v[8 * h + 5] = b.y; v[8 * h + 6] = b.z; v[8 * h + 7] = b.w;
+        } else {  // an edge of the matrix, of a sequence or of the padding: element by element
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const Idx2 c = colf(g, kb + i < kend ? kb + i : 0);
+            const int tt = fix[0].t + c.t;
+            const bool ok = fix_ok[0] && kb + i < kend && (!conv || (tt >= 0 && tt < lim));
+            v[8 * h + i] = ok ? base[(int64_t)fix[0].off + c.off] : 0.f;
+          }
+        }
+      }
+    }
+  }
+  // registers -> LDS (Xs: KC [128][KCP], MC [16][kMCP])
+  __device__ __forceinline__ void stage(float *Xs, const float (&v)[NV]) const {
+    float *dst = MC ? Xs + (threadIdx.x >> 4) * kMCP + (threadIdx.x & 15) * 8
+                    : Xs + (threadIdx.x >> 1) * KCP + (threadIdx.x & 1) * NV;
+#pragma unroll
+    for (int h = 0; h < NV / 4; ++h)
+      *reinterpret_cast<f32x4 *>(dst + 4 * h) = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+  }
+  // MFMA fragment of tile row `row` (0..127) for the 16-wide K group kg: k slot kq of the s-th MFMA stands for
+  // k = 16 kg + 4 kq + s
+  __device__ __forceinline__ static f32x4 frag(const float *Xs, int row, int kq, int kg) {
+    if constexpr (MC) {
+      const float *q = Xs + (16 * kg + 4 * kq) * kMCP + row;
+      return f32x4{q[0], q[kMCP], q[2 * kMCP], q[3 * kMCP]};
+    } else {
+      return *reinterpret_cast<const f32x4 *>(Xs + row * KCP + 16 * kg + 4 * kq);
+    }
+  }
+};
+
+// NT: 16-column MFMA tiles per wave along n (4: block tile 128 x 128; 2: 128 x 64 for products with N <= 64 per
+// tile column, e.g. the 64-channel convolutions that hold a third of the TCNN's arithmetic)
+// BK: K step (32 when both operands are contiguous along k — the convolutions' dW, whose rows are 1 200 bytes apart:
+// a step then takes a whole 128-byte line of every row instead of half of one)
+template <bool A_MC, bool B_MC, int NT, int BK>
+__global__ __launch_bounds__(256) void k_gemm128_f32(GemmArgs g) {
+  static_assert(BK == 16 || (!A_MC && !B_MC), "the MC loaders cover 16 k per step");
+  constexpr int ASZ = A_MC ? BK * kMCP : kBT * (BK + 4), BSZ = B_MC ? BK * kMCP : kBT * (BK + 4);
+  __shared__ __align__(16) float As[2][ASZ];  // two stages: one barrier per K step
+  __shared__ __align__(16) float Bs[2][BSZ];
+  constexpr int BN = 32 * NT;
+  const int m0 = blockIdx.y * kBT, n0 = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wm = (wv >> 1) * 64, wn = (wv & 1) * (16 * NT);  // this wave's 64 x (16 NT) part
+  const int lm = lane & 15, kq = lane >> 4;
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  TileLoader<true, A_MC, BK> la;
+  TileLoader<false, B_MC, BK> lb;
+  la.init(g, m0, kBT);
+  lb.init(g, n0, BN);
+  const int kbeg = g.kchunk > 0 ? blockIdx.z * g.kchunk : 0;
+  const int kend = g.kchunk > 0 ? min(g.K, kbeg + g.kchunk) : g.K;
+  float va[BK / 2], vb[BK / 2];
+  la.load(g, kbeg, kend, va);
+  lb.load(g, kbeg, kend, vb);
+  la.stage(As[0], va);
+  lb.stage(Bs[0], vb);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;  // block uniform
+    if (more) {  // the next step's elements fly under this step's products
+      la.load(g, k0 + BK, kend, va);
+      lb.load(g, k0 + BK, kend, vb);
+    }
+#pragma unroll
+    for (int kg = 0; kg < BK / 16; ++kg) {
+      f32x4 a[4], b[NT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = TileLoader<true, A_MC, BK>::frag(As[cur], wm + 16 * i + lm, kq, kg);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = TileLoader<false, B_MC, BK>::frag(Bs[cur], wn + 16 * j + lm, kq, kg);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) {  // into the other stage: nobody reads it before the barrier
+      la.stage(As[cur ^ 1], va);
+      lb.stage(Bs[cur ^ 1], vb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // D: lane (n = lane & 15, q = lane >> 4) holds rows 4q + reg of its 16 x 16 tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = m0 + wm + i * 16 + 4 * kq + reg, n = n0 + wn + j * 16 + lm;
+        if (m >= g.M || n >= g.N) continue;
+        float v = acc[i][j][reg] * g.alpha;
+        if (g.bias) v += g.bias[n];
+        if (g.relu) v = fmaxf(v, 0.f);
+        const int64_t ci = gemm_c_index(g, m, n);
+        if (g.kchunk > 0) {  // split K: partial sums meet in C (zeroed by the launcher; no epilogue in this form)
+          atomicAdd(&g.C[ci], v);
+          continue;
+        }
         if (g.mask && !(g.mask[ci] > 0.f)) v = 0.f;
         g.C[ci] = v;
       }
@@ -415,6 +646,48 @@ int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32
   if (M == 0 || N == 0) return MRGCN_OK;
   GemmArgs g{A, B, C, lda, ldb, ldc, M, N, K, amode, bmode, cmode, bias, relu, mask, alpha, ConvGeom{}};
   if (conv_geom) g.cg = ConvGeom{conv_geom[0], conv_geom[1], conv_geom[2], conv_geom[3], conv_geom[4], conv_geom[5]};
+  // operands whose element offsets fit 31 bits and whose tile grid fills the chip: 128 x 128 tiles with vector
+  // loaders; small products (the heads' few output columns) and anything larger keep the 64 x 64 kernel
+  static const bool big_on = !(getenv("MRGCN_GEMM128") && atoi(getenv("MRGCN_GEMM128")) == 0);
+  int64_t amax = 0, bmax = 0;
+  if (amode < 2) amax = (amode == 0 ? (int64_t)M * lda + K : (int64_t)K * lda + M);
+  else amax = (int64_t)((amode == 2 ? M : K) / g.cg.Tout + 1) * g.cg.Cin * g.cg.Tin;
+  if (bmode < 2) bmax = (bmode == 0 ? (int64_t)K * ldb + N : (int64_t)N * ldb + K);
+  else bmax = (int64_t)(K / g.cg.Tout + 1) * g.cg.Cout * g.cg.Tout;
+  // tile columns of 64 when N leaves a 128-wide column more than a third empty
+  const int BN = (N <= 64 || (N % 128 != 0 && N % 128 <= 80)) ? 64 : 128;
+  const int64_t tiles128 = (int64_t)((M + kBT - 1) / kBT) * ((N + BN - 1) / BN);
+  // few tiles but a long reduction (the convolutions' dW: K = batch x positions): split K over the grid's z
+  int splits = 1;
+  const bool linear_epilogue = !bias && !relu && !mask && cmode == 0;
+  if (tiles128 < 256 && linear_epilogue && K >= 4096 && ldc == N) {
+    splits = (int)((512 + tiles128 - 1) / tiles128);
+    const int max_splits = K / 1024;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  if (big_on && amax < ((int64_t)1 << 31) && bmax < ((int64_t)1 << 31) && M >= 48 && N >= 48 &&
+      (tiles128 >= 64 || splits > 1)) {
+    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + kBT - 1) / kBT), (unsigned)splits);
+    if (splits > 1) {
+      g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
+      grid.z = (unsigned)((K + g.kchunk - 1) / g.kchunk);
+      MRGCN_HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), (hipStream_t)stream));
+    }
+    const bool a_mc = amode == 1 || amode == 2, b_mc = bmode == 0;
+#define GEMM128_GO(AM_, BM_, BK_)                                                                               \
+  do {                                                                                                          \
+    if (BN == 64) k_gemm128_f32<AM_, BM_, 2, BK_><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);              \
+    else k_gemm128_f32<AM_, BM_, 4, BK_><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);                       \
+  } while (0)
+    if (a_mc && b_mc) GEMM128_GO(true, true, 16);
+    else if (a_mc) GEMM128_GO(true, false, 16);
+    else if (b_mc) GEMM128_GO(false, true, 16);
+    else GEMM128_GO(false, false, 32);
+#undef GEMM128_GO
+    MRGCN_HIP_TRY(hipGetLastError());
+    return MRGCN_OK;
+  }
   dim3 grid((unsigned)((N + kGT - 1) / kGT), (unsigned)((M + kGT - 1) / kGT));
   k_gemm_f32<<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);
   MRGCN_HIP_TRY(hipGetLastError());

@@ -37,27 +37,38 @@ __device__ inline double block_sum(double v, double *s) {  // 256 threads
   return s[0] + s[1] + s[2] + s[3];
 }
 
-// block per channel: mean and biased variance over (B, T)
-__global__ __launch_bounds__(256) void k_bn_stats(const float *__restrict__ x, int B, int C, int T,
-                                                  float *__restrict__ mean, float *__restrict__ var) {
+// batch statistics: block (c, y) sums channel c over the batch slab y (a wave per batch row, lanes along t:
+// coalesced), fp64 partials meet in acc[c][2] (zeroed by the launcher); a second tiny kernel turns them into mean
+// and biased variance.  (One block per channel left 64-channel layers on a quarter of the chip.)
+__global__ __launch_bounds__(256) void k_bn_stats_part(const float *__restrict__ x, int B, int C, int T,
+                                                       double *__restrict__ acc) {
   __shared__ double s[4];
   const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double a = 0.0, q = 0.0;
-  const int64_t n = (int64_t)B * T;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const int64_t b = i / T, t = i - b * T;
-    const double v = x[(b * C + c) * T + t];
-    a += v;
-    q += v * v;
+  for (int b = blockIdx.y * 4 + wv; b < B; b += gridDim.y * 4) {
+    const float *row = x + ((int64_t)b * C + c) * T;
+    for (int t = lane; t < T; t += 64) {
+      const double v = row[t];
+      a += v;
+      q += v * v;
+    }
   }
   a = block_sum(a, s);
   q = block_sum(q, s);
   if (threadIdx.x == 0) {
-    const double m = a / (double)n;
-    mean[c] = (float)m;
-    const double vv = q / (double)n - m * m;
-    var[c] = (float)(vv > 0.0 ? vv : 0.0);
+    atomicAdd(&acc[2 * c], a);
+    atomicAdd(&acc[2 * c + 1], q);
   }
+}
+__global__ void k_bn_stats_fin(const double *__restrict__ acc, int C, int64_t n, float *__restrict__ mean,
+                               float *__restrict__ var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = acc[2 * c] / (double)n;
+  const double vv = acc[2 * c + 1] / (double)n - m * m;
+  mean[c] = (float)m;
+  var[c] = (float)(vv > 0.0 ? vv : 0.0);
 }
 
 // thread per output element
@@ -101,29 +112,37 @@ __global__ void k_pool_relu_bwd(const float *__restrict__ y, const float *__rest
   else dz[bc * T + t] = dy[o];
 }
 
-// block per channel: dbeta = sum dz, dgamma = sum dz * xhat
-__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float *__restrict__ x, const float *__restrict__ dz,
-                                                       int B, int C, int T, const float *__restrict__ mean,
-                                                       const float *__restrict__ var, float eps,
-                                                       float *__restrict__ dgamma, float *__restrict__ dbeta) {
+// dbeta = sum dz, dgamma = sum dz * xhat: the same two-stage reduction as the statistics
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce_part(const float *__restrict__ x, const float *__restrict__ dz,
+                                                            int B, int C, int T, const float *__restrict__ mean,
+                                                            const float *__restrict__ var, float eps,
+                                                            double *__restrict__ acc) {
   __shared__ double s[4];
   const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const double m = mean[c], istd = 1.0 / sqrt((double)var[c] + (double)eps);
   double a = 0.0, q = 0.0;
-  const int64_t n = (int64_t)B * T;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const int64_t b = i / T, t = i - b * T;
-    const int64_t e = (b * C + c) * T + t;
-    const double g = dz[e];
-    a += g;
-    q += g * ((double)x[e] - m) * istd;
+  for (int b = blockIdx.y * 4 + wv; b < B; b += gridDim.y * 4) {
+    const int64_t base = ((int64_t)b * C + c) * T;
+    for (int t = lane; t < T; t += 64) {
+      const double gg = dz[base + t];
+      a += gg;
+      q += gg * ((double)x[base + t] - m) * istd;
+    }
   }
   a = block_sum(a, s);
   q = block_sum(q, s);
   if (threadIdx.x == 0) {
-    dbeta[c] = (float)a;
-    dgamma[c] = (float)q;
+    atomicAdd(&acc[2 * c], a);
+    atomicAdd(&acc[2 * c + 1], q);
   }
+}
+__global__ void k_bn_bwd_reduce_fin(const double *__restrict__ acc, int C, float *__restrict__ dgamma,
+                                    float *__restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)acc[2 * c];
+  dgamma[c] = (float)acc[2 * c + 1];
 }
 
 // training: dx = gamma istd (dz - mean(dz) - xhat mean(dz xhat));  eval: dx = gamma istd dz
@@ -159,17 +178,33 @@ int32_t mrgcn_pool_out_len(int32_t pool_kind, int32_t pool_arg, int32_t T) {
   return pool_out_len(pool_kind, pool_arg, T);
 }
 
+size_t mrgcn_bn_workspace_bytes(int32_t C) { return C > 0 ? (size_t)C * 2 * sizeof(double) : 0; }
+
+static inline unsigned bn_slabs(int B, int C) {
+  int s = 2048 / (C > 0 ? C : 1);
+  if (s < 1) s = 1;
+  if (s > (B + 3) / 4) s = (B + 3) / 4;
+  return (unsigned)(s < 1 ? 1 : s);
+}
+
 int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, const float *gamma,
                                const float *beta, float eps, int32_t training, float *mean, float *var,
-                               int32_t pool_kind, int32_t pool_arg, float *y, int32_t *argmax, void *stream) {
+                               int32_t pool_kind, int32_t pool_arg, float *y, int32_t *argmax, void *workspace,
+                               void *stream) {
   MRGCN_REQUIRE(x && y && mean && var, "NULL");
+  MRGCN_REQUIRE(!training || workspace, "training mode needs the workspace (mrgcn_bn_workspace_bytes)");
   MRGCN_REQUIRE(B > 0 && C > 0 && T > 0, "B / C / T");
   MRGCN_REQUIRE(pool_kind >= 0 && pool_kind <= 2 && (pool_kind == POOL_NONE || pool_arg > 0), "pool");
   MRGCN_REQUIRE(pool_kind == POOL_NONE || argmax, "a pooled block needs the argmax buffer");
   const int Tout = pool_out_len(pool_kind, pool_arg, T);
   MRGCN_REQUIRE(Tout > 0, "the pooling window is longer than the sequence");
   hipStream_t s = (hipStream_t)stream;
-  if (training) k_bn_stats<<<dim3(C), dim3(256), 0, s>>>(x, B, C, T, mean, var);
+  if (training) {
+    double *acc = (double *)workspace;
+    MRGCN_HIP_TRY(hipMemsetAsync(acc, 0, mrgcn_bn_workspace_bytes(C), s));
+    k_bn_stats_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, acc);
+    k_bn_stats_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, (int64_t)B * T, mean, var);
+  }
   const int64_t n_out = (int64_t)B * C * Tout;
   k_bn_relu_pool_fwd<<<dim3(nb(n_out)), dim3(256), 0, s>>>(x, B, C, T, Tout, gamma, beta, mean, var, eps,
                                                          pool_kind, pool_arg, y, argmax);
@@ -180,8 +215,8 @@ int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, 
 int mrgcn_bn_relu_pool_bwd_f32(const float *x, const float *y, const float *dy, const int32_t *argmax, int32_t B,
                                int32_t C, int32_t T, const float *gamma, const float *mean, const float *var,
                                float eps, int32_t training, int32_t pool_kind, int32_t pool_arg, float *dz,
-                               float *dx, float *dgamma, float *dbeta, void *stream) {
-  MRGCN_REQUIRE(x && y && dy && mean && var && dz && dx && dgamma && dbeta, "NULL");
+                               float *dx, float *dgamma, float *dbeta, void *workspace, void *stream) {
+  MRGCN_REQUIRE(x && y && dy && mean && var && dz && dx && dgamma && dbeta && workspace, "NULL");
   MRGCN_REQUIRE(B > 0 && C > 0 && T > 0, "B / C / T");
   MRGCN_REQUIRE(pool_kind >= 0 && pool_kind <= 2 && (pool_kind == POOL_NONE || (pool_arg > 0 && argmax)), "pool");
   const int Tout = pool_out_len(pool_kind, pool_arg, T);
@@ -190,7 +225,10 @@ int mrgcn_bn_relu_pool_bwd_f32(const float *x, const float *y, const float *dy, 
   const int64_t n_in = (int64_t)B * C * T, n_out = (int64_t)B * C * Tout;
   MRGCN_HIP_TRY(hipMemsetAsync(dz, 0, (size_t)n_in * sizeof(float), s));
   k_pool_relu_bwd<<<dim3(nb(n_out)), dim3(256), 0, s>>>(y, dy, argmax, n_out, T, Tout, pool_kind, dz);
-  k_bn_bwd_reduce<<<dim3(C), dim3(256), 0, s>>>(x, dz, B, C, T, mean, var, eps, dgamma, dbeta);
+  double *acc = (double *)workspace;
+  MRGCN_HIP_TRY(hipMemsetAsync(acc, 0, mrgcn_bn_workspace_bytes(C), s));
+  k_bn_bwd_reduce_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, dz, B, C, T, mean, var, eps, acc);
+  k_bn_bwd_reduce_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, dgamma, dbeta);
   k_bn_bwd_dx<<<dim3(nb(n_in)), dim3(256), 0, s>>>(x, dz, B, C, T, gamma, mean, var, eps, dgamma, dbeta, training,
                                                   dx);
   MRGCN_HIP_TRY(hipGetLastError());

@@ -147,11 +147,12 @@ class _BnReluPool(torch.autograd.Function):
             raise L.MrgcnError("bn_relu_pool: the pooling window is longer than the sequence")
         y = torch.empty((Bn, Cn, Tout), dtype=torch.float32, device=x.device)
         am = torch.empty((Bn, Cn, Tout), dtype=torch.int32, device=x.device) if kind != POOL_NONE else None
+        ws = torch.empty(int(lib.mrgcn_bn_workspace_bytes(Cn)), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
             L.check(lib.mrgcn_bn_relu_pool_fwd_f32(
                 x.data_ptr(), Bn, Cn, T, gamma.data_ptr() if gamma is not None else 0,
                 beta.data_ptr() if beta is not None else 0, float(eps), int(training), mean.data_ptr(),
-                var.data_ptr(), kind, arg, y.data_ptr(), am.data_ptr() if am is not None else 0,
+                var.data_ptr(), kind, arg, y.data_ptr(), am.data_ptr() if am is not None else 0, ws.data_ptr(),
                 _stream(x.device)), "mrgcn_bn_relu_pool_fwd_f32")
         ctx.meta = (float(eps), bool(training), kind, arg)
         ctx.save_for_backward(x, y, am, gamma, mean, var)
@@ -168,12 +169,14 @@ class _BnReluPool(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty(Cn, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(Cn, dtype=torch.float32, device=x.device)
+        lib = L.load()
+        ws = torch.empty(int(lib.mrgcn_bn_workspace_bytes(Cn)), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
-            L.check(L.load().mrgcn_bn_relu_pool_bwd_f32(
+            L.check(lib.mrgcn_bn_relu_pool_bwd_f32(
                 x.data_ptr(), y.data_ptr(), dy.data_ptr(), am.data_ptr() if am is not None else 0, Bn, Cn, T,
                 gamma.data_ptr() if gamma is not None else 0, mean.data_ptr(), var.data_ptr(), eps, int(training),
-                kind, arg, dz.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _stream(x.device)),
-                "mrgcn_bn_relu_pool_bwd_f32")
+                kind, arg, dz.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                _stream(x.device)), "mrgcn_bn_relu_pool_bwd_f32")
         return dx, (dgamma if gamma is not None else None), (dbeta if gamma is not None else None), None, None, \
             None, None, None, None
 

@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Measurements for the SURVEY §8(f) rows around the hot path (one JSON object on stdout):
+  mini-batch   device-built batch structure, slice plans and a train step on a re-sampled batch (AM/4 shape)
+  encoders     fused MLP + gate + scatter; TCNN (implicit-im2col MFMA convolutions + fused BatchNorm / ReLU / pool)
+               forward + backward, next to the same modules on torch.nn (MIOpen / rocBLAS) on the same GPU
+  ingestion    CSR of the dataset archive -> graph plan on the device (AM shape)
+    python tools/next_rows_probe.py > profiles/rNN_next_rows.json"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mrgcn_amd import synth  # noqa: E402
+
+
+def timed(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def minibatch():
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, categorical_crossentropy
+    g = synth.make_graph("am", seed=0, scale=0.25)
+    N, R = g.num_nodes, g.num_relations
+    A = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
+    dcsr = mb.DeviceCSR(A)
+    rng = np.random.default_rng(0)
+    dims = synth.layer_dims("am")
+    mods = [(dims[0][0], dims[0][1], "mrgcn", torch.nn.ReLU()), (dims[1][0], dims[1][1], "mrgcn", None)]
+    torch.manual_seed(0)
+    model = RGCN(mods, R, N, synth.SHAPES["am"]["bases"], 0.0, False, True, False).cuda()
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    X = torch.randn((N, dims[0][0]), device="cuda")
+    out = {"graph": f"am x 0.25 (N={N}, R={R}, nnz={A.nnz})", "batch_nodes": 1024, "layers": 2}
+    t_build, t_step, sizes = [], [], None
+    for it in range(6):
+        idx = np.sort(rng.choice(N, 1024, replace=False))
+        y = torch.from_numpy(rng.integers(0, dims[-1][1], 1024)).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ab = mb.A_BatchDevice(dcsr, idx, 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        logits = model(X[ab.neighbours[-1]], ab)           # builds the slice plans on first use
+        loss = categorical_crossentropy(logits, torch.arange(1024, device="cuda"), y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if it >= 2:
+            t_build.append((t1 - t0) * 1e3)
+            t_step.append((t2 - t1) * 1e3)
+        sizes = [int(n.numel()) for n in ab.neighbours]
+    out.update(neighbours=sizes, batch_build_ms=round(float(np.median(t_build)), 2),
+               plans_fwd_bwd_adam_ms=round(float(np.median(t_step)), 2),
+               note="a re-sampled batch every step: structure on the device, four slice plans, forward, backward, "
+                    "dense Adam on the full node table (mini-batch steps do not use the row-sparse update)")
+    return out
+
+
+def encoders():
+    from mrgcn_amd import dense
+    from mrgcn_amd.models.perceptron import MLP
+    from mrgcn_amd.models.temporal_cnn import TCNN
+    out = {}
+    # fused MLP + gate + scatter: 1 M numeric literals, 4 -> 3
+    n = 1_000_000
+    torch.manual_seed(0)
+    mlp = MLP(4, 3, num_layers=1).cuda()
+    enc = torch.randn((n, 4), device="cuda")
+    rows = torch.randperm(2 * n, device="cuda")[:n].sort().values
+    gates = torch.full((2,), 0.1, device="cuda", requires_grad=True)
+    lin = mlp.linears()
+
+    def fused():
+        XF = torch.zeros((2 * n, 8), device="cuda")
+        y = dense.mlp_gate_scatter(XF, enc, rows, gates, 0, 2, [l.weight for l in lin], [l.bias for l in lin])
+        y.square().sum().backward()
+
+    def library():
+        XF = torch.zeros((2 * n, 8), device="cuda")
+        XF[rows, 2:5] = gates[0] * mlp(enc)
+        XF.square().sum().backward()
+
+    out["mlp_gate_scatter_1M_literals"] = {"hip_fwd_bwd_ms": round(timed(fused), 3),
+                                           "torch_nn_fwd_bwd_ms": round(timed(library), 3)}
+    # TCNN M: 2048 WKT literals, 37-symbol alphabet, 300 positions
+    torch.manual_seed(0)
+    m = TCNN(37, 16, p_dropout=0.0, size="M").cuda().train()
+    x = (torch.rand((2048, 37, 300), device="cuda") < 0.03).float()
+
+    def hip():
+        for p in m.parameters():
+            p.grad = None
+        m(x).square().sum().backward()
+
+    def lib():
+        for p in m.parameters():
+            p.grad = None
+        y = m.conv(x)
+        m.fc(y.view(y.size(0), -1)).square().sum().backward()
+
+    # multiply-adds of the convolutions and the fully connected tail, forward; backward = 2x
+    flops, T, cin = 0, 300, 37
+    for mod in m.conv:
+        if isinstance(mod, torch.nn.Conv1d):
+            Tout = T + 2 * mod.padding[0] - mod.kernel_size[0] + 1
+            flops += 2 * 2048 * Tout * mod.out_channels * cin * mod.kernel_size[0]
+            T, cin = Tout, mod.out_channels
+        elif isinstance(mod, torch.nn.MaxPool1d):
+            T = (T - mod.kernel_size) // mod.kernel_size + 1
+        elif isinstance(mod, torch.nn.AdaptiveMaxPool1d):
+            T = mod.output_size
+    flops += 2 * 2048 * (cin * cin + cin * 16)
+    t_h, t_l = timed(hip, 5, 2), timed(lib, 5, 2)
+    out["tcnn_M_2048x37x300"] = {"hip_fwd_bwd_ms": round(t_h, 2), "torch_nn_fwd_bwd_ms": round(t_l, 2),
+                                 "gflop_fwd": round(flops / 1e9, 1),
+                                 "hip_tflops_f32": round(3 * flops / (t_h * 1e-3) / 1e12, 1),
+                                 "note": "fp32 throughout (v_mfma_f32_16x16x4_f32, exact; 157 TFLOP/s peak); the library "
+                                         "path is MIOpen's fp32 Conv1d / BatchNorm and rocBLAS"}
+    return out
+
+
+def ingestion():
+    from mrgcn_amd.plan import GraphPlan
+    g = synth.make_graph("am", seed=0, scale=1.0)
+    N, R = g.num_nodes, g.num_relations
+    A = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
+    A.sort_indices()
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p = GraphPlan.from_csr(A, N, R, value_mode="norm_f32")
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+        mb_ = p.device_bytes / 2 ** 20
+        del p
+    return {"graph": f"am (N={N}, R={R}, nnz={A.nnz})", "csr_upload_and_plan_build_ms": round(min(ts), 1),
+            "plan_device_mb": round(mb_, 1)}
+
+
+def main():
+    res = {"device": torch.cuda.get_device_name(0)}
+    for name, fn in (("minibatch", minibatch), ("encoders", encoders), ("ingestion", ingestion)):
+        try:
+            res[name] = fn()
+        except Exception as e:  # noqa: BLE001
+            res[name] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
