@@ -8,8 +8,13 @@ import argparse
 import json
 import time
 
+import os
+import sys
+
 import numpy as np
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from mrgcn_amd import synth
 from mrgcn_amd.models.rgcn import RGCN

@@ -5,8 +5,13 @@ import argparse
 import json
 import time
 
+import os
+import sys
+
 import numpy as np
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from mrgcn_amd.tasks import link_prediction as lp
 
