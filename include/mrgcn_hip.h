@@ -373,7 +373,10 @@ int mrgcn_mlp_gate_scatter_bwd_f32(int32_t L, const int32_t *dims, const float *
  *         3: the transpose of mode 2 (m = ci*KW + kw, k = b*Tout + t)
  *   bmode 0: B[k*ldb + n]   1: B[n*ldb + k]   2: y[b][n][t] read as [k = b*Tout + t][n]
  *   cmode 0: C[m*ldc + n]   2: y[b][n][t], m = b*Tout + t
- *   conv_geom (HOST, modes 2 / 3): {Cin, Tin, KW, pad, Tout, Cout}.  mask: nullable, addressed like C. */
+ *   conv_geom (HOST, modes 2 / 3): {Cin, Tin, KW, pad, Tout, Cout}.  mask: nullable, addressed like C.
+ * Products with few output tiles and a long reduction (the convolutions' dW) split K over the grid: C (dense,
+ * ldc == N) is zeroed and the partial tiles are added with float atomics — the result is exact to the last bits only
+ * up to the order of those adds. */
 int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32_t N, int32_t K, const float *A,
                    int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias,
                    int32_t relu, const float *mask, float alpha, const int32_t *conv_geom, void *stream);
