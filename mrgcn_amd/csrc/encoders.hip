@@ -437,13 +437,22 @@ struct TileLoader {
           const f32x4_u a = *reinterpret_cast<const f32x4_u *>(p), b = *reinterpret_cast<const f32x4_u *>(p + 4);
           v[8 * h + 0] = a.x; v[8 * h + 1] = a.y; v[8 * h + 2] = a.z; v[8 * h + 3] = a.w;
           v[8 * h + 4] = b.x; v[8 * h + 5] = b.y; v[8 * h + 6] = b.z; v[8 * h + 7] = b.w;
-        } else {  // an edge of the matrix, of a sequence or of the padding: element by element
+        } else {  // an edge of the matrix, of a sequence or of the padding: element by element, walking the column
+                  // map (one index decomposition per run of consecutive k, not per element)
+          Idx2 c = c0;
+          int room = c0.room;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const Idx2 c = colf(g, kb + i < kend ? kb + i : 0);
             const int tt = fix[0].t + c.t;
             const bool ok = fix_ok[0] && kb + i < kend && (!conv || (tt >= 0 && tt < lim));
             v[8 * h + i] = ok ? base[(int64_t)fix[0].off + c.off] : 0.f;
+            if (--room > 0) {
+              c.off += 1;
+              c.t += tstep;
+            } else if (i < 7) {
+              c = colf(g, kb + i + 1 < kend ? kb + i + 1 : 0);
+              room = c.room;
+            }
           }
         }
       }
@@ -646,8 +655,11 @@ int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32
   if (M == 0 || N == 0) return MRGCN_OK;
   GemmArgs g{A, B, C, lda, ldb, ldc, M, N, K, amode, bmode, cmode, bias, relu, mask, alpha, ConvGeom{}};
   if (conv_geom) g.cg = ConvGeom{conv_geom[0], conv_geom[1], conv_geom[2], conv_geom[3], conv_geom[4], conv_geom[5]};
-  // operands whose element offsets fit 31 bits and whose tile grid fills the chip: 128 x 128 tiles with vector
-  // loaders; small products (the heads' few output columns) and anything larger keep the 64 x 64 kernel
+  // operands whose element offsets fit 31 bits: 128 x 128 (128 x 64) tiles with vector loaders — also for grids
+  // that do not fill the chip (a 40-tile product still finishes several times sooner than on the element loaders);
+  // products with fewer than 48 rows or columns and a short reduction (the heads' few outputs) and anything larger
+  // keep the 64 x 64 kernel; a narrow product with a long reduction (the first convolution's dW: 64 x 27 over
+  // batch x positions) goes to the split form
   static const bool big_on = !(getenv("MRGCN_GEMM128") && atoi(getenv("MRGCN_GEMM128")) == 0);
   int64_t amax = 0, bmax = 0;
   if (amode < 2) amax = (amode == 0 ? (int64_t)M * lda + K : (int64_t)K * lda + M);
@@ -660,14 +672,13 @@ int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32
   // few tiles but a long reduction (the convolutions' dW: K = batch x positions): split K over the grid's z
   int splits = 1;
   const bool linear_epilogue = !bias && !relu && !mask && cmode == 0;
-  if (tiles128 < 256 && linear_epilogue && K >= 4096 && ldc == N) {
+  if (tiles128 < 256 && linear_epilogue && K >= 1024 && ldc == N) {
     splits = (int)((512 + tiles128 - 1) / tiles128);
-    const int max_splits = K / 1024;
+    const int max_splits = K / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
   }
-  if (big_on && amax < ((int64_t)1 << 31) && bmax < ((int64_t)1 << 31) && M >= 48 && N >= 48 &&
-      (tiles128 >= 64 || splits > 1)) {
+  if (big_on && amax < ((int64_t)1 << 31) && bmax < ((int64_t)1 << 31) && ((M >= 48 && N >= 48) || splits > 1)) {
     dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + kBT - 1) / kBT), (unsigned)splits);
     if (splits > 1) {
       g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;

@@ -259,12 +259,17 @@ class _MlpGateScatter(torch.autograd.Function):
                 enc.stride(0), enc.shape[0], gate.data_ptr(), rows.data_ptr() if rows is not None else 0,
                 dXF.data_ptr(), dXF.stride(0), offset, _ptr_array(dW, n_layers), _ptr_array(db, n_layers),
                 dg_view.data_ptr(), _stream(dXF.device)), "mrgcn_mlp_gate_scatter_bwd_f32")
-        # the block this op wrote does not depend on what XF held before
-        dXF_in = dXF.clone()
-        if rows is not None:
-            dXF_in[rows, offset:offset + dims[-1]] = 0
-        else:
-            dXF_in[:, offset:offset + dims[-1]] = 0
+        # the block this op wrote does not depend on what XF held before (index_fill_ / fill_ take the zero as a
+        # kernel argument: indexed assignment of a Python scalar stages it through a host copy, which a stream
+        # capture refuses)
+        dXF_in = None
+        if ctx.needs_input_grad[0]:
+            dXF_in = dXF.clone()
+            blk = dXF_in[:, offset:offset + dims[-1]]
+            if rows is not None:
+                blk.index_fill_(0, rows, 0.0)
+            else:
+                blk.fill_(0.0)
         return (dXF_in, None, None, dgate, None, None, None, *dW, *db)
 
 

@@ -140,40 +140,73 @@ class MRGCN(nn.Module):
         X = None
         if self.compute_modality_embeddings:
             batch_idx = torch.arange(self.num_nodes)
-            XF = self._compute_modality_embeddings(F, batch_idx)
+            XF = self._compute_modality_embeddings(F, batch_idx, full_batch=True)
             X = torch.cat([X0.to(dev), XF], dim=1).float()
         return self.rgcn(X, batch.A)
 
-    def _compute_modality_embeddings(self, F, batch_idx):
+    def _compute_modality_embeddings(self, F, batch_idx, full_batch=False):
         """XF[node, off:off+dim] = gate * encoder(encodings[node]) per encoding set
-        (mrgcn.py:250-305)."""
+        (mrgcn.py:250-305).
+
+        The reference resolves, per call and per set, which rows of the batch carry the encoding
+        (`torch_intersect1d` + two `isin` masks) and reads every gate back to test it against zero.
+        Here the gates are read back once per forward (one host wait instead of one per set), a
+        full batch resolves its sets once (the row positions are the node ids, the encodings do
+        not change between epochs) and a mini-batch matches node ids on the device the encodings
+        live on."""
         dev = self.devices["relational"]
         X = torch.zeros((len(batch_idx), self.modality_out_dim), dtype=torch.float32, device=dev)
+        if isinstance(self.gate_weights, nn.Parameter):
+            if X.is_cuda and torch.cuda.is_current_stream_capturing():
+                # a captured epoch (train.GraphedTrainStep) cannot read back: it keeps the decisions of the
+                # warm-up step before it
+                gate_is_zero = self.__dict__.get("_gate_is_zero")
+            else:
+                gate_is_zero = torch.isclose(self.gate_weights.detach(),
+                                             torch.zeros((), device=self.gate_weights.device)).cpu().tolist()
+                self.__dict__["_gate_is_zero"] = gate_is_zero
+        else:
+            gate_is_zero = None             # ungated: constant ones (mrgcn.py:150-156)
+        cache = self.__dict__.setdefault("_full_batch_sets", {}) if full_batch else None
+        bidx = None
         offset = 0
         for datatype, encoding_sets, _ in F:
             if datatype not in self.modality_modules:
                 continue
             for i, encoding_set in enumerate(encoding_sets):
                 module, _, out_dim, i_gate = self.modality_modules[datatype][i]
-                gate = self.gate_weights[i_gate]
-                if torch.isclose(gate.detach().cpu(), torch.tensor(0.0)):
+                if gate_is_zero is not None and gate_is_zero[i_gate]:
                     offset += out_dim
                     continue
                 encodings, node_idx, _ = encoding_set
-                bidx = torch.as_tensor(batch_idx).cpu()
-                keep = torch.isin(node_idx.cpu(), bidx)
-                if not bool(keep.any()):
+                hit = cache.get((datatype, i)) if cache is not None else None
+                if hit is not None and hit[0] is encodings and hit[1] is node_idx and hit[2] == len(batch_idx):
+                    rows, data = hit[3], hit[4]
+                else:
+                    # rows of the batch that carry this encoding (mrgcn.py:276-277, :303); in a full
+                    # batch the position equals the node id
+                    nidx = torch.as_tensor(node_idx)
+                    if bidx is None or bidx.device != nidx.device:
+                        bidx = torch.as_tensor(batch_idx).to(nidx.device)
+                    keep = torch.isin(nidx, bidx)
+                    rows = torch.isin(bidx, nidx[keep]).nonzero().squeeze(1).to(dev)
+                    if rows.numel() == 0:
+                        rows = data = None
+                    else:
+                        data = encodings[keep.to(encodings.device)]
+                        if datatype in ("xsd.string", "xsd.anyURI"):   # token ids (mrgcn.py:287-288)
+                            data = data.int()
+                        elif datatype != "blob.image":
+                            data = data.float()
+                    if cache is not None:
+                        cache[(datatype, i)] = (encodings, node_idx, len(batch_idx), rows, data)
+                if rows is None:            # no node of this batch has the datatype
                     offset += out_dim
                     continue
-                # rows of the batch that carry this encoding (mrgcn.py:276-277, :303); in a full
-                # batch the position equals the node id
-                rows = torch.isin(bidx, node_idx.cpu()[keep]).nonzero().squeeze(1).to(dev)
-                data = encodings[keep.to(encodings.device)]
-                if datatype in ("xsd.string", "xsd.anyURI"):   # token ids (mrgcn.py:287-288)
-                    data = data.int()
-                elif datatype == "blob.image" and self.im_norm is not None:
+                gate = self.gate_weights[i_gate]
+                if datatype == "blob.image" and self.im_norm is not None:
                     data = self.im_norm.normalize_(data)
-                else:
+                elif datatype == "blob.image":
                     data = data.float()
                 if isinstance(module, MLP) and X.is_cuda and data.device == X.device and module.fused_ok(data):
                     # every Linear + ReLU, the gate and the scatter in one kernel (csrc/encoders.hip)

@@ -126,6 +126,49 @@ def test_mrgcn_with_tcnn_and_mlp_encoders_vs_reference():
                                g["mrgcn.grad.tcnn_conv0"], rtol=2e-3, atol=1e-6)
 
 
+@pytest.mark.gpu
+def test_mrgcn_epoch_with_encoders_replays_from_a_hipgraph():
+    """A full-batch MRGCN epoch (TCNN + MLP encoders, gates, two R-GCN layers, CE, clip, Adam) captured by
+    GraphedTrainStep follows the eager epochs of an identically initialised model: the encoder sets of a full batch
+    are resolved once and the gates are not read back inside the capture."""
+    from mrgcn_amd.data.batch import FullBatch
+    from mrgcn_amd.models.mrgcn import MRGCN
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
+    g = np.load(GOLD, allow_pickle=True)
+    _, A = util.load_graph("graph_small")
+    N = A.shape[0]
+    R = A.shape[1] // N
+    emb_cfg = sorted([("ogc.wktLiteral", (9, 5, "S", 0.0), False), ("xsd.numeric", (4, 3, 0.0), False)],
+                     key=lambda t: t[0])
+    modules = [(8, 6, "mrgcn", nn.ReLU()), (6, 4, "mrgcn", None)]
+    X = [np.empty((N, 0), dtype=np.float32),
+         ["ogc.wktLiteral", [[g["mrgcn.wkt"], g["mrgcn.wkt_idx"], np.full(14, 20)]], False],
+         ["xsd.numeric", [[g["mrgcn.num"], g["mrgcn.num_idx"], np.ones(25, dtype=int)]], False]]
+    idx = torch.arange(0, N, 3, device="cuda")
+    y = (idx % 4).to(torch.int64)
+    losses, gates = [], []
+    for graphed in (False, True):
+        torch.manual_seed(6)
+        model = MRGCN(modules, emb_cfg, R, N, num_bases=3, p_dropout=0.0, featureless=False, bias=True,
+                      gcn_gpu_acceleration=True)
+        batch = FullBatch(A, X, np.arange(N))
+        batch.as_tensors_()
+        batch.to(model.devices)
+        model.train()
+        opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0, capturable=graphed)
+        if graphed:
+            step = GraphedTrainStep(model, lambda: model(batch), idx, y, opt, warmup=2)
+            ls = [float(step()) for _ in range(3)]
+        else:
+            ls = [float(train_step(model, lambda: model(batch), idx, y, opt)) for _ in range(5)][2:]
+        losses.append(ls)
+        gates.append(model.gate_weights.detach().cpu().numpy().copy())
+        assert ("ogc.wktLiteral", 0) in model._full_batch_sets and ("xsd.numeric", 0) in model._full_batch_sets
+    np.testing.assert_allclose(losses[1], losses[0], rtol=2e-3)
+    np.testing.assert_allclose(gates[1], gates[0], rtol=2e-3, atol=1e-5)
+    assert losses[0][-1] < losses[0][0]
+
+
 # ---- the same encoders on the HIP kernels (csrc/encoders.hip through mrgcn_amd.dense) ---------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("size", ["S", "M", "L"])
@@ -198,7 +241,12 @@ def test_linear_on_the_matrix_cores_vs_float64(shape, relu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Cin,T,Cout,KW,pad", [(2, 3, 20, 5, 3, 1), (7, 9, 33, 64, 7, 3), (3, 64, 10, 128, 3, 0),
-                                                 (1, 1, 2, 1, 2, 0), (5, 16, 3, 32, 3, 1)])
+                                                 (1, 1, 2, 1, 2, 0), (5, 16, 3, 32, 3, 1),
+                                                 # the TCNN S shapes of a 500-literal set: a narrow dW with a long
+                                                 # reduction (split K), sequences shorter than a loader's run of 8
+                                                 # positions, one-position outputs
+                                                 (500, 9, 20, 64, 3, 1), (300, 64, 5, 128, 3, 1),
+                                                 (600, 128, 2, 256, 2, 0)])
 def test_conv1d_on_the_matrix_cores_vs_torch(B, Cin, T, Cout, KW, pad):
     from mrgcn_amd import dense
     gen = torch.Generator("cuda").manual_seed(B + T)
@@ -212,8 +260,8 @@ def test_conv1d_on_the_matrix_cores_vs_torch(B, Cin, T, Cout, KW, pad):
     r = torch.nn.functional.conv1d(x64, W64, b64, padding=pad)
     (r * w.double().cpu()).sum().backward()
     torch.testing.assert_close(y.double().cpu(), r, rtol=1e-5, atol=1e-4)
-    for a, c in ((x, x64), (W, W64), (b, b64)):
-        torch.testing.assert_close(a.grad.double().cpu(), c.grad, rtol=1e-5, atol=2e-4)
+    for a, c in ((x, x64), (W, W64), (b, b64)):   # (dW / db sum over batch x positions terms of unit scale)
+        torch.testing.assert_close(a.grad.double().cpu(), c.grad, rtol=1e-5, atol=2e-4 * max(1.0, (B * T / 100) ** 0.5))
 
 
 @pytest.mark.gpu

@@ -135,6 +135,48 @@ def encoders():
     return out
 
 
+def mrgcn_epoch():
+    """BASELINE config 1 / 2 style: MRGCN(FullBatch) at the MUTAG shape with a numeric MLP over 6 000 literal nodes and
+    a WKT TCNN (S) over 500, full-batch epoch = encoders + gates + 2 R-GCN layers + CE + backward + clip + Adam."""
+    from mrgcn_amd.data.batch import FullBatch
+    from mrgcn_amd.models.mrgcn import MRGCN
+    from mrgcn_amd.train import ClipAdam, train_step
+    g = synth.make_graph("mutag", seed=5, scale=1.0, value_mode="norm_f32")
+    N, R = g.num_nodes, g.num_relations
+    rng = np.random.default_rng(8)
+    num_idx = np.sort(rng.choice(N, 6000, replace=False))
+    num = rng.standard_normal((6000, 4)).astype(np.float32)
+    wkt_idx = np.sort(rng.choice(N, 500, replace=False))
+    wkt = (rng.random((500, 9, 20)) < 0.15).astype(np.float32)
+    torch.manual_seed(12)
+    emb_cfg = sorted([("ogc.wktLiteral", (9, 5, "S", 0.0), False), ("xsd.numeric", (4, 3, 0.0), False)],
+                     key=lambda t: t[0])
+    modules = [(8, 16, "mrgcn", torch.nn.ReLU()), (16, 2, "mrgcn", None)]
+    model = MRGCN(modules, emb_cfg, R, N, num_bases=30, p_dropout=0.0, featureless=False, bias=True,
+                  gcn_gpu_acceleration=True)
+    A = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
+    X = [np.empty((N, 0), dtype=np.float32),
+         ["ogc.wktLiteral", [[wkt, wkt_idx, np.full(500, 20)]], False],
+         ["xsd.numeric", [[num, num_idx, np.ones(6000, dtype=int)]], False]]
+    batch = FullBatch(A, X, np.arange(N), value_mode="norm_f32")
+    batch.as_tensors_()
+    batch.to(model.devices)
+    model.train()
+    idx = torch.from_numpy(np.sort(rng.choice(N, 340, replace=False))).cuda()
+    y = torch.from_numpy(rng.integers(0, 2, 340)).cuda()
+    from mrgcn_amd.train import GraphedTrainStep
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0, capturable=True)
+    ms = timed(lambda: train_step(model, lambda: model(batch), idx, y, opt), iters=30, warm=3)
+    out = {"graph": f"mutag (N={N}, R={R}, nnz={A.nnz}), 30 bases, 8 -> 16 -> 2",
+           "literals": "6000 numeric (MLP), 500 WKT (TCNN S)", "epoch_ms_eager": round(ms, 3)}
+    try:
+        step = GraphedTrainStep(model, lambda: model(batch), idx, y, opt, warmup=1)
+        out["epoch_ms_hipgraph"] = round(timed(step, iters=30, warm=3), 3)
+    except Exception as e:  # noqa: BLE001
+        out["hipgraph_error"] = repr(e)[:200]
+    return out
+
+
 def ingestion():
     from mrgcn_amd.plan import GraphPlan
     g = synth.make_graph("am", seed=0, scale=1.0)
@@ -156,7 +198,8 @@ def ingestion():
 
 def main():
     res = {"device": torch.cuda.get_device_name(0)}
-    for name, fn in (("minibatch", minibatch), ("encoders", encoders), ("ingestion", ingestion)):
+    for name, fn in (("minibatch", minibatch), ("encoders", encoders), ("mrgcn_with_encoders", mrgcn_epoch),
+                     ("ingestion", ingestion)):
         try:
             res[name] = fn()
         except Exception as e:  # noqa: BLE001
