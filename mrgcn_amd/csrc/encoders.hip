@@ -667,12 +667,15 @@ int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32
   if (bmode < 2) bmax = (bmode == 0 ? (int64_t)K * ldb + N : (int64_t)N * ldb + K);
   else bmax = (int64_t)(K / g.cg.Tout + 1) * g.cg.Cout * g.cg.Tout;
   // tile columns of 64 when N leaves a 128-wide column more than a third empty
-  const int BN = (N <= 64 || (N % 128 != 0 && N % 128 <= 80)) ? 64 : 128;
-  const int64_t tiles128 = (int64_t)((M + kBT - 1) / kBT) * ((N + BN - 1) / BN);
+  // ... and when 128-wide columns would leave most of the 256 CUs without a tile and the reduction cannot be split
+  const bool linear_epilogue = !bias && !relu && !mask && cmode == 0;
+  const bool can_split = linear_epilogue && K >= 1024 && ldc == N;
+  const int64_t mt = (M + kBT - 1) / kBT;
+  const int BN = (N <= 64 || (N % 128 != 0 && N % 128 <= 80) || (!can_split && mt * ((N + 127) / 128) < 128)) ? 64 : 128;
+  const int64_t tiles128 = mt * ((N + BN - 1) / BN);
   // few tiles but a long reduction (the convolutions' dW: K = batch x positions): split K over the grid's z
   int splits = 1;
-  const bool linear_epilogue = !bias && !relu && !mask && cmode == 0;
-  if (tiles128 < 256 && linear_epilogue && K >= 1024 && ldc == N) {
+  if (tiles128 < 256 && can_split) {
     splits = (int)((512 + tiles128 - 1) / tiles128);
     const int max_splits = K / 256;
     if (splits > max_splits) splits = max_splits;
