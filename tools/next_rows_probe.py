@@ -65,6 +65,14 @@ def minibatch():
             t_build.append((t1 - t0) * 1e3)
             t_step.append((t2 - t1) * 1e3)
         sizes = [int(n.numel()) for n in ab.neighbours]
+    # the reference builds its batches once and walks the same ones every epoch (node_classification.py: mkbatches
+    # before the epoch loop): a step on a batch whose slice plans already exist
+    def again():
+        loss = categorical_crossentropy(model(X[ab.neighbours[-1]], ab), torch.arange(1024, device="cuda"), y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    out["reused_batch_fwd_bwd_adam_ms"] = round(timed(again, iters=10, warm=2), 2)
     out.update(neighbours=sizes, batch_build_ms=round(float(np.median(t_build)), 2),
                plans_fwd_bwd_adam_ms=round(float(np.median(t_step)), 2),
                note="a re-sampled batch every step: structure on the device, four slice plans, forward, backward, "
