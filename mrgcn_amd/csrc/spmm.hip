@@ -306,16 +306,23 @@ constexpr int kShort3 = kShort3Rows;    // S: rows of at most this many entries
 constexpr int kMid3 = kMid3Rows;        // M: up to this many
 constexpr int kChunk3 = kChunk3Entries; // L: entries per chunk (8 gathers per lane at G = 4)
 
-template <int NT, int VEC, bool TAIL, typename DT, typename GetFn, typename OnFn>
+// OFF32: the operand is smaller than 4 GB — a gather address is the uniform base (a scalar register pair) plus a
+// 32-bit byte offset (one vector register instead of two per gather in flight)
+template <int NT, int VEC, bool TAIL, typename DT, bool OFF32, typename GetFn, typename OnFn>
 __device__ __forceinline__ void gather_batch(const DT *__restrict__ Dq, int64_t ldD, bool active, int nvalid,
-                                             float (&acc)[VEC], GetFn get, OnFn on) {
+                                             float (&acc)[VEC], GetFn get, OnFn on, const DT *__restrict__ Dbase,
+                                             uint32_t ldb, uint32_t qoff) {
   float x[NT][VEC];
   float a[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     int32_t c;
     get(t, c, a[t]);
-    const DT *p = Dq + (int64_t)c * ldD;
+    const DT *p;
+    if constexpr (OFF32)
+      p = reinterpret_cast<const DT *>(reinterpret_cast<const char *>(Dbase) + ((uint32_t)c * ldb + qoff));
+    else
+      p = Dq + (int64_t)c * ldD;
     if constexpr (TAIL) {
       if (nvalid < VEC) {
 #pragma unroll
@@ -335,18 +342,19 @@ __device__ __forceinline__ void gather_batch(const DT *__restrict__ Dq, int64_t 
   }
 }
 
-template <int VEC, bool TAIL, typename DT, typename GetFn, typename OnFn>
+template <int VEC, bool TAIL, typename DT, bool OFF32, typename GetFn, typename OnFn>
 __device__ __forceinline__ void gather_rounds(int nr, const DT *__restrict__ Dq, int64_t ldD, bool active,
-                                              int nvalid, float (&acc)[VEC], GetFn get, OnFn on) {
+                                              int nvalid, float (&acc)[VEC], GetFn get, OnFn on,
+                                              const DT *__restrict__ Dbase, uint32_t ldb, uint32_t qoff) {
   switch (nr) {  // wave uniform
-    case 1: gather_batch<1, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
-    case 2: gather_batch<2, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
-    case 3: gather_batch<3, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
-    case 4: gather_batch<4, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
-    case 5: gather_batch<5, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
-    case 6: gather_batch<6, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
-    case 7: gather_batch<7, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
-    case 8: gather_batch<8, VEC, TAIL, DT>(Dq, ldD, active, nvalid, acc, get, on); break;
+    case 1: gather_batch<1, VEC, TAIL, DT, OFF32>(Dq, ldD, active, nvalid, acc, get, on, Dbase, ldb, qoff); break;
+    case 2: gather_batch<2, VEC, TAIL, DT, OFF32>(Dq, ldD, active, nvalid, acc, get, on, Dbase, ldb, qoff); break;
+    case 3: gather_batch<3, VEC, TAIL, DT, OFF32>(Dq, ldD, active, nvalid, acc, get, on, Dbase, ldb, qoff); break;
+    case 4: gather_batch<4, VEC, TAIL, DT, OFF32>(Dq, ldD, active, nvalid, acc, get, on, Dbase, ldb, qoff); break;
+    case 5: gather_batch<5, VEC, TAIL, DT, OFF32>(Dq, ldD, active, nvalid, acc, get, on, Dbase, ldb, qoff); break;
+    case 6: gather_batch<6, VEC, TAIL, DT, OFF32>(Dq, ldD, active, nvalid, acc, get, on, Dbase, ldb, qoff); break;
+    case 7: gather_batch<7, VEC, TAIL, DT, OFF32>(Dq, ldD, active, nvalid, acc, get, on, Dbase, ldb, qoff); break;
+    case 8: gather_batch<8, VEC, TAIL, DT, OFF32>(Dq, ldD, active, nvalid, acc, get, on, Dbase, ldb, qoff); break;
     default: break;
   }
 }
@@ -357,10 +365,15 @@ struct View3 {  // what k_spmm3 needs beyond the COMPACT SparseView (whose rows 
   const int32_t *rowmap = nullptr;     // [rows] rank -> output row
   const int32_t *chunk_beg = nullptr, *chunk_end = nullptr, *chunk_row = nullptr;  // [n_chunks], rows = ranks
   const int32_t *long_row = nullptr, *long_cptr = nullptr;                   // [n_long] ranks, [n_long + 1]
+  int64_t op_rows = 0;                 // rows of the operand the indices point into
 };
 
-template <int G, int VEC, bool TAIL, typename DT>
-__global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *__restrict__ D, int64_t ldD,
+// OFF32: gathers address the operand with 32-bit byte offsets (operand < 4 GB).  WPE: waves per SIMD the register
+// allocation must leave room for (7 at F = 10 / 16: 72 registers instead of 76, a seventh wave of gathers in flight
+// per SIMD: -4 %; 8 would take the batch of eight gathers apart: no gain).  Three-lane slots for the S rows at
+// F <= 12 (21 rows per wave) gain the same 3-4 % on their own and nothing on top: measured, not kept.
+template <int G, int VEC, bool TAIL, typename DT, bool OFF32 = false, int WPE = 1>
+__global__ __launch_bounds__(256, WPE) void k_spmm3(SparseView v, View3 w, const DT *__restrict__ D, int64_t ldD,
                                                int F, float *__restrict__ Y, int64_t ldY,
                                                const float *__restrict__ bias, int relu, int store_vec_ok,
                                                float *__restrict__ partials, int ldP, int chunk_blocks,
@@ -372,6 +385,7 @@ __global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *
   const bool active = f0 < F;
   const DT *Dq = D + (active ? f0 : 0);  // idle feature lanes shadow lane 0 (always in bounds)
   const int nvalid = active ? min(VEC, F - f0) : VEC;
+  const uint32_t ldb = (uint32_t)ldD * (uint32_t)sizeof(DT), qoff = (uint32_t)(active ? f0 : 0) * (uint32_t)sizeof(DT);
   float acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
@@ -393,14 +407,14 @@ __global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *
         ca[t] = (m < n) ? v.val[b + m] : 0.f;
       }
       const int nr = __builtin_amdgcn_readfirstlane((n + SLOTS - 1) / SLOTS);
-      gather_rounds<VEC, TAIL, DT>(
+      gather_rounds<VEC, TAIL, DT, OFF32>(
           nr, Dq, ldD, active, nvalid, acc,
           [&](int t, int32_t &cc, float &aa) {
             const int src = (t % PER) * SLOTS + slot;
             cc = __shfl(ci[t / PER], src, kWave);
             aa = __shfl(ca[t / PER], src, kWave);
           },
-          [&](int t) { return t * SLOTS + slot < n; });
+          [&](int t) { return t * SLOTS + slot < n; }, D, ldb, qoff);
     }
 #pragma unroll
     for (int off = G; off < kWave; off <<= 1) {
@@ -448,14 +462,14 @@ __global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *
     for (int t = 0; t < kMid3 / SS; ++t)
       if (t < 8 && __any(t * SS < n)) nr = t + 1;
     const int base = rsel * 16;
-    gather_rounds<VEC, TAIL, DT>(
+    gather_rounds<VEC, TAIL, DT, OFF32>(
         nr, Dq, ldD, active, nvalid, acc,
         [&](int t, int32_t &cc, float &aa) {  // sub-slot ss takes entry t*SS + ss of its row
           const int e = t * SS + ss;
           cc = __shfl(ci[e / 16 < T ? e / 16 : T - 1], base + (e & 15), kWave);
           aa = __shfl(ca[e / 16 < T ? e / 16 : T - 1], base + (e & 15), kWave);
         },
-        [&](int t) { return t * SS + ss < n; });
+        [&](int t) { return t * SS + ss < n; }, D, ldb, qoff);
 #pragma unroll
     for (int off = G; off < 16; off <<= 1) {
 #pragma unroll
@@ -495,13 +509,13 @@ __global__ __launch_bounds__(256) void k_spmm3(SparseView v, View3 w, const DT *
   for (int t = 0; t < kShort3; ++t)
     if (__any(t < n)) nr = t + 1;
   const int sbase = slot * G;
-  gather_rounds<VEC, TAIL, DT>(
+  gather_rounds<VEC, TAIL, DT, OFF32>(
       nr, Dq, ldD, active, nvalid, acc,
       [&](int t, int32_t &cc, float &aa) {
         cc = __shfl(ci[t / G], sbase + (t % G), kWave);
         aa = __shfl(ca[t / G], sbase + (t % G), kWave);
       },
-      [&](int t) { return t < n; });
+      [&](int t) { return t < n; }, D, ldb, qoff);
   if (mine && active) store_row<VEC>(Y + row * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
 }
 
@@ -809,15 +823,30 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
   if constexpr (G <= 4 && VEC == 4) {
     static const bool v3_on = !(getenv("MRGCN_SPMM_V3") && atoi(getenv("MRGCN_SPMM_V3")) == 0);
     if (w3 && v3_on && v.rows > 0) {  // one gather batch per wave (k_spmm3); rows = class-major ranks
+      static const int wpe = getenv("MRGCN_SPMM_WPE") ? atoi(getenv("MRGCN_SPMM_WPE")) : 7;  // 0: the plain form
+      const bool off32 = !TAIL && w3->op_rows > 0 && wpe > 0 &&
+                         (uint64_t)w3->op_rows * (uint64_t)ldD * sizeof(DT) < ((uint64_t)1 << 32);
       const int64_t short_waves = ((int64_t)w3->n_short + SLOTS - 1) / SLOTS;
       const int64_t short_blocks = (short_waves + 3) / 4;
       const int chunk_blocks = (w3->n_chunks + 3) / 4;
       const int mid_blocks = ((w3->n_mid + 3) / 4 + 3) / 4;
       const int64_t xcd_per = (short_blocks + 7) / 8;
       if (xcd_per * 8 + chunk_blocks + mid_blocks > 0) {
-        k_spmm3<G, VEC, TAIL, DT><<<dim3((unsigned)(xcd_per * 8 + chunk_blocks + mid_blocks)), dim3(256), 0, s>>>(
-            v, *w3, D, ldD, F, Y, ldY, bias, relu, store_vec_ok ? 1 : 0, partials, 16, chunk_blocks, mid_blocks,
-            short_blocks, xcd_per);
+        const dim3 grid((unsigned)(xcd_per * 8 + chunk_blocks + mid_blocks));
+#define SPMM3_GO(O_, W_)                                                                                           \
+  k_spmm3<G, VEC, TAIL, DT, O_, W_><<<grid, dim3(256), 0, s>>>(v, *w3, D, ldD, F, Y, ldY, bias, relu,               \
+                                                               store_vec_ok ? 1 : 0, partials, 16, chunk_blocks,   \
+                                                               mid_blocks, short_blocks, xcd_per)
+        bool done = false;
+        if constexpr (G == 4 && !TAIL && sizeof(DT) == 4) {
+          if (off32) {
+            done = true;
+            if (wpe == 7) SPMM3_GO(true, 7);
+            else SPMM3_GO(true, 1);
+          }
+        }
+        if (!done) SPMM3_GO(false, 1);
+#undef SPMM3_GO
         MRGCN_HIP_TRY(hipGetLastError());
       }
       if (w3->n_multi > 0) {
@@ -956,6 +985,7 @@ View3 view3_of(const mrgcn_plan *p) {
   w.n_chunks = p->r3_n_chunks; w.n_long = p->r3_n_long; w.n_multi = p->r3_n_chunks - p->r3_n_long;
   w.chunk_beg = p->r3_chunk_beg; w.chunk_end = p->r3_chunk_end; w.chunk_row = p->r3_chunk_row;
   w.long_row = p->r3_long_row; w.long_cptr = p->r3_long_cptr;
+  w.op_rows = p->n_op;
   return w;
 }
 
