@@ -39,7 +39,7 @@ ALG = {  # kernel-name prefix -> (label, bytes)
                                  int(6 * 4 * B * N * F0 * LIVE_NODES) + int(NCOLS * LIVE_COLS) * LD * 4 + N * 10),
     "mrgcn::k_adam_rows<4>": ("row-sparse Adam from a stored gradient: p, g, m, v read and p, m, v written for the "
                               "node blocks that ever had gradient", int(7 * 4 * B * N * F0 * LIVE_NODES)),
-    "mrgcn::k_spmm3<4, 4, false, float>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
+    "mrgcn::k_spmm3<4, 4, false, float, true, 7>": ("forward product, F=10 (SURVEY 8d formula)", spmm_bytes(N, NCOLS, F0)),
     "mrgcn::k_spmm<4, 4, true, float, false>": ("general transposed product, F=10 (probe leg only; the epoch runs k_spmm_t_live)",
                                                 spmm_bytes(NCOLS, N, F0)),
     "mrgcn::k_xform_mfma_fwd<1, false, 16, float, false>": ("layer-0 transform: X read once + W + M2 written + indices",
