@@ -287,8 +287,10 @@ def main():
         from mrgcn_amd.functional import _ld_for
         ld = _ld_for(F)
         M = torch.randn((plan.ncols, ld), device=dev)
-        Y = torch.empty((plan.num_rows, F), device=dev)
-        t_c = event_time_ms(lambda: plan.spmm(L.VIEW_COMPACT, M, F=F, out=Y), args.spmm_iters, stream)
+        # the output as the layer holds it: the first F columns of rows padded to whole 16-byte pieces
+        Y = torch.empty((plan.num_rows, (F + 3) // 4 * 4), device=dev)[:, :F]
+        t_c = event_time_ms(lambda: plan.spmm(L.VIEW_COMPACT, M, F=F, out=Y, pad_writable=True), args.spmm_iters,
+                            stream)
         bytes_alg = plan.spmm_bytes(F)
         ach = bytes_alg / (t_c * 1e-3) / 1e9
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/pmc_passes.sh ->

@@ -139,7 +139,14 @@ int mrgcn_plan_array(const mrgcn_plan_t *plan, int32_t which, const void **d_ptr
  *                     (SparseAddmmBackward: dDense = A^T dY)
  * `out_index` (nullable, int32 [rows of view]) redirects output row i to
  * Y[out_index[i]] — used to scatter compact rows into the literal (R*N) x F gradient.
- * D, Y row-major with leading dimensions ldD, ldY (in floats).                      */
+ * D, Y row-major with leading dimensions ldD, ldY (in floats).
+ * `relu` is a flag word: MRGCN_SPMM_RELU (= 1, what callers always passed for "apply ReLU") and
+ * MRGCN_SPMM_PAD_WRITABLE: columns F .. min(ldY, 4*ceil(F/4)) - 1 of every row of Y belong to the
+ * caller's buffer and may be overwritten with zeros.  Rows of F = 10 / 11 in a buffer of ldY = 12 then
+ * leave as three 16-byte stores and consecutive rows complete their 128-byte lines (COMPACT view,
+ * F <= 16: the product runs 5 % faster); without the flag nothing outside [0, F) is touched. */
+#define MRGCN_SPMM_RELU 1
+#define MRGCN_SPMM_PAD_WRITABLE 2
 int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const float *D, int64_t ldD,
                    int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu,
                    const int32_t *out_index, void *stream);
@@ -264,6 +271,10 @@ int mrgcn_rows_nonzero_f32(const float *X, int64_t ld, int32_t F, int64_t nrows,
 /* ---- epoch kernels around the layers ----------------------------------------------
  * out = dY * (Y > 0): backward of the nn.ReLU between layers (rgcn.py:86-87) */
 int mrgcn_relu_bwd_f32(const float *dY, const float *Y, int64_t n, float *out, void *stream);
+/* the same with row-strided operands: out[r, 0:F] = dY[r, 0:F] * (Y[r, 0:F] > 0) — the layer output Y of the
+ * COMPACT product may live in a buffer with padded rows (MRGCN_SPMM_PAD_WRITABLE) */
+int mrgcn_relu_bwd_rows_f32(const float *dY, int64_t ld_dY, const float *Y, int64_t ldY, int64_t rows, int32_t F,
+                            float *out, int64_t ld_out, void *stream);
 /* loss = mean_i CE(logits[idx[i]], target[i]); dlogits (nullable, [num_rows, ldd]) is zeroed
  * and receives d loss / d logits.  nn.CrossEntropyLoss over Y_hat[idx]
  * (node_classification.py:439-444) and its backward. */

@@ -21,6 +21,7 @@ OK = 0
 VAL_I8, VAL_F32 = 0, 1
 PLAN_PRUNE_ZEROS, PLAN_REPLICATE, PLAN_NO_REPLICATE = 1, 2, 4
 VIEW_LITERAL, VIEW_COMPACT, VIEW_TRANSPOSED = 0, 1, 2
+SPMM_RELU, SPMM_PAD_WRITABLE = 1, 2  # flag word of mrgcn_spmm_f32 / _bf16 (`relu` argument)
 (ARR_ROWPTR, ARR_LCOL, ARR_CCOL, ARR_VAL, ARR_CPTR, ARR_CROW, ARR_CVAL, ARR_UREL, ARR_UNODE,
  ARR_NPTR, ARR_ROWIDX, ARR_ULCOL, ARR_RPERM, ARR_RELPTR, ARR_MPOS, ARR_MCOL, ARR_MVAL, ARR_ROWMAP,
  ARR_PTR3) = range(19)
@@ -74,6 +75,7 @@ SIGNATURES = {
     "mrgcn_spmm_transposed_live_scratch": (C.c_int64, [_p]),
     "mrgcn_spmm_transposed_live_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p]),
     "mrgcn_relu_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "mrgcn_relu_bwd_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _i64, _p]),
     "mrgcn_softmax_xent_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _i64, _i64, _p]),
     "mrgcn_sumsq_accum_f32": (C.c_int, [_p, _i64, _p, _p]),
     "mrgcn_clip_coef_f32": (C.c_int, [_p, C.c_float, _p, _p, _p]),

@@ -38,6 +38,15 @@ __device__ __forceinline__ float block_sum(float x) {  // result valid in thread
   return t;
 }
 
+// the same on row-strided operands (a layer output kept in a buffer with padded rows): 16 lanes per row
+__global__ void k_relu_bwd_rows(const float *__restrict__ dY, int64_t ldd, const float *__restrict__ Y, int64_t ldy,
+                                int64_t rows, int F, float *__restrict__ out, int64_t ldo) {
+  const int f0 = threadIdx.x & 15;
+  const int64_t step = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; r < rows; r += step)
+    for (int f = f0; f < F; f += 16) out[r * ldo + f] = Y[r * ldy + f] > 0.f ? dY[r * ldd + f] : 0.f;
+}
+
 // out = dY * (Y > 0)
 __global__ void k_relu_bwd(const float *__restrict__ dY, const float *__restrict__ Y, int64_t n,
                            float *__restrict__ out) {
@@ -300,6 +309,17 @@ int mrgcn_relu_bwd_f32(const float *dY, const float *Y, int64_t n, float *out, v
   MRGCN_REQUIRE((((uintptr_t)dY | (uintptr_t)Y | (uintptr_t)out) & 15) == 0, "16-byte alignment");
   if (n == 0) return MRGCN_OK;
   k_relu_bwd<<<dim3(stream_grid(n >> 2)), dim3(kTB), 0, (hipStream_t)stream>>>(dY, Y, n, out);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_relu_bwd_rows_f32(const float *dY, int64_t ld_dY, const float *Y, int64_t ldY, int64_t rows, int32_t F,
+                            float *out, int64_t ld_out, void *stream) {
+  MRGCN_REQUIRE(dY && Y && out, "NULL");
+  MRGCN_REQUIRE(rows >= 0 && F > 0 && ld_dY >= F && ldY >= F && ld_out >= F, "F / leading dimensions");
+  if (rows == 0) return MRGCN_OK;
+  k_relu_bwd_rows<<<dim3(stream_grid(rows * 16)), dim3(kTB), 0, (hipStream_t)stream>>>(dY, ld_dY, Y, ldY, rows, F, out,
+                                                                                      ld_out);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -54,16 +54,16 @@ template <int VEC, typename DT> __device__ __forceinline__ void load_vec(const D
 
 template <int VEC>
 __device__ __forceinline__ void store_row(float *y, const float (&acc)[VEC], int f0, int F,
-                                          const float *bias, int relu, bool vec_ok) {
+                                          const float *bias, int relu, bool vec_ok, int room = 0) {
   float o[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     float v = acc[i];
     if (bias && f0 + i < F) v += bias[f0 + i];
     if (relu) v = fmaxf(v, 0.f);
-    o[i] = v;
+    o[i] = (f0 + i < F) ? v : 0.f;
   }
-  if (vec_ok && f0 + VEC <= F) {
+  if (vec_ok && f0 + VEC <= (room > F ? room : F)) {
     if constexpr (VEC == 8) {
       *reinterpret_cast<float4 *>(y + f0) = *reinterpret_cast<const float4 *>(o);
       *reinterpret_cast<float4 *>(y + f0 + 4) = *reinterpret_cast<const float4 *>(o + 4);
@@ -366,6 +366,7 @@ struct View3 {  // what k_spmm3 needs beyond the COMPACT SparseView (whose rows 
   const int32_t *chunk_beg = nullptr, *chunk_end = nullptr, *chunk_row = nullptr;  // [n_chunks], rows = ranks
   const int32_t *long_row = nullptr, *long_cptr = nullptr;                   // [n_long] ranks, [n_long + 1]
   int64_t op_rows = 0;                 // rows of the operand the indices point into
+  int32_t pad_ok = 0;                  // columns F..ldY-1 of Y belong to the caller's buffer and may be zeroed
 };
 
 // OFF32: gathers address the operand with 32-bit byte offsets (operand < 4 GB).  WPE: waves per SIMD the register
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256, WPE) void k_spmm3(SparseView v, View3 w, const
       const int32_t rk = w.chunk_row[c];
       if (rk >= 0) {  // the whole row was this chunk: finished
         const int64_t orow = w.rowmap[rk];
-        store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
+        store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, (store_vec_ok & 1) != 0, (store_vec_ok & 2) ? (int)ldY : 0);
       } else {
         float *p = partials + (int64_t)c * ldP + f0;
 #pragma unroll
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256, WPE) void k_spmm3(SparseView v, View3 w, const
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
     }
-    if (ss == 0 && row >= 0 && active) store_row<VEC>(Y + (int64_t)row * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
+    if (ss == 0 && row >= 0 && active) store_row<VEC>(Y + (int64_t)row * ldY, acc, f0, F, bias, relu, (store_vec_ok & 1) != 0, (store_vec_ok & 2) ? (int)ldY : 0);
     return;
   }
   // ---- S: 64/G consecutive ranks per wave, all of them rows of <= kShort3 entries
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256, WPE) void k_spmm3(SparseView v, View3 w, const
         aa = __shfl(ca[t / G], sbase + (t % G), kWave);
       },
       [&](int t) { return t < n; }, D, ldb, qoff);
-  if (mine && active) store_row<VEC>(Y + row * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
+  if (mine && active) store_row<VEC>(Y + row * ldY, acc, f0, F, bias, relu, (store_vec_ok & 1) != 0, (store_vec_ok & 2) ? (int)ldY : 0);
 }
 
 // rows of several chunks: one wave per long row; lane = (chunk mod 64/FP, feature), eight partials in flight
@@ -548,6 +549,8 @@ __global__ __launch_bounds__(256) void k_spmm3_finalize(View3 w, const float *__
     if (bias) t += bias[f];
     if (relu) t = fmaxf(t, 0.f);
     Y[row * ldY + f] = t;
+  } else if (k == 0 && w.pad_ok && f < ldY && f < (F + 3) / 4 * 4) {
+    Y[(int64_t)w.rowmap[w.long_row[li]] * ldY + f] = 0.f;
   }
 }
 
@@ -823,6 +826,9 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
   if constexpr (G <= 4 && VEC == 4) {
     static const bool v3_on = !(getenv("MRGCN_SPMM_V3") && atoi(getenv("MRGCN_SPMM_V3")) == 0);
     if (w3 && v3_on && v.rows > 0) {  // one gather batch per wave (k_spmm3); rows = class-major ranks
+      // the caller owns the pad of Y's rows: whole 16-byte pieces are stored (zeros past F) — rows of ld = 12 at
+      // F = 10 / 11 then leave as three vector stores and consecutive rows fill their lines (-5 % on the product)
+      const int padw = (w3->pad_ok && store_vec_ok) ? 2 : 0;
       static const int wpe = getenv("MRGCN_SPMM_WPE") ? atoi(getenv("MRGCN_SPMM_WPE")) : 7;  // 0: the plain form
       const bool off32 = !TAIL && w3->op_rows > 0 && wpe > 0 &&
                          (uint64_t)w3->op_rows * (uint64_t)ldD * sizeof(DT) < ((uint64_t)1 << 32);
@@ -835,7 +841,7 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
         const dim3 grid((unsigned)(xcd_per * 8 + chunk_blocks + mid_blocks));
 #define SPMM3_GO(O_, W_)                                                                                           \
   k_spmm3<G, VEC, TAIL, DT, O_, W_><<<grid, dim3(256), 0, s>>>(v, *w3, D, ldD, F, Y, ldY, bias, relu,               \
-                                                               store_vec_ok ? 1 : 0, partials, 16, chunk_blocks,   \
+                                                               (store_vec_ok ? 1 : 0) | padw, partials, 16, chunk_blocks,   \
                                                                mid_blocks, short_blocks, xcd_per)
         bool done = false;
         if constexpr (G == 4 && !TAIL && sizeof(DT) == 4) {
@@ -1113,13 +1119,17 @@ extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uin
     MRGCN_REQUIRE(out_index == nullptr, "out_index is not available on the COMPACT view");
     out_index = plan->rowmap;
   }
+  MRGCN_REQUIRE((relu & ~(MRGCN_SPMM_RELU | MRGCN_SPMM_PAD_WRITABLE)) == 0, "flags");
+  const int pad_ok = (relu & MRGCN_SPMM_PAD_WRITABLE) != 0;
+  relu &= MRGCN_SPMM_RELU;
   int tile = 64;
   if (ldD % 8 == 0 && ((uintptr_t)D) % 16 == 0) tile = 256;  // kWsFeatures floats of partials per chunk
   else if (ldD % 4 == 0 && ((uintptr_t)D) % 8 == 0) tile = 256;
   else if (ldD % 2 == 0 && ((uintptr_t)D) % 4 == 0) tile = 128;
   for (int f = 0; f < F; f += tile) {
     const int w = (F - f < tile) ? (F - f) : tile;
-    const View3 w3 = view3_of(plan);
+    View3 w3 = view3_of(plan);
+    w3.pad_ok = pad_ok;
     int rc = dispatch_bf16(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu, out_index,
                            plan->partials, (hipStream_t)stream, (view == MRGCN_VIEW_COMPACT && F <= 16) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
@@ -1140,6 +1150,9 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     MRGCN_REQUIRE(out_index == nullptr, "out_index is not available on the COMPACT view");
     out_index = plan->rowmap;
   }
+  MRGCN_REQUIRE((relu & ~(MRGCN_SPMM_RELU | MRGCN_SPMM_PAD_WRITABLE)) == 0, "flags");
+  const int pad_ok = (relu & MRGCN_SPMM_PAD_WRITABLE) != 0;
+  relu &= MRGCN_SPMM_RELU;
   hipStream_t s = (hipStream_t)stream;
   // feature tiles: one pass covers up to 64 lanes x VEC floats; the split-row workspace
   // holds kWsFeatures floats per chunk
@@ -1158,7 +1171,8 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     // that straddles two lines there fetches lines its neighbours need anyway)
     const bool operand_cached = operand_rows * ldD * 4 <= (int64_t)200 << 20 || view == MRGCN_VIEW_COMPACT;
     // the COMPACT view of a narrow layer takes k_spmm3
-    const View3 w3 = view3_of(plan);
+    View3 w3 = view3_of(plan);
+    w3.pad_ok = pad_ok;
     int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu,
                       out_index, plan->partials, use_tiny, operand_cached, s,
                       (view == MRGCN_VIEW_COMPACT && F <= 16) ? &w3 : nullptr);

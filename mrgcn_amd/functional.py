@@ -174,10 +174,17 @@ def spmm_literal(plan: GraphPlan, D: torch.Tensor, bias=None, relu: bool = False
 
 
 def relu_bwd(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
-    out = torch.empty_like(dY)
+    """dY * (Y > 0); Y may be the first F columns of a buffer with padded rows (plan.spmm)."""
+    out = torch.empty(dY.shape, dtype=torch.float32, device=dY.device)
     with torch.cuda.device(dY.device):
-        L.check(L.load().mrgcn_relu_bwd_f32(dY.data_ptr(), Y.data_ptr(), dY.numel(), out.data_ptr(),
-                                            _stream(dY.device)), "mrgcn_relu_bwd_f32")
+        if dY.is_contiguous() and Y.is_contiguous():
+            L.check(L.load().mrgcn_relu_bwd_f32(dY.data_ptr(), Y.data_ptr(), dY.numel(), out.data_ptr(),
+                                                _stream(dY.device)), "mrgcn_relu_bwd_f32")
+        else:
+            assert dY.dim() == 2 and dY.stride(1) == 1 and Y.stride(1) == 1 and Y.shape == dY.shape
+            L.check(L.load().mrgcn_relu_bwd_rows_f32(dY.data_ptr(), dY.stride(0), Y.data_ptr(), Y.stride(0),
+                                                     dY.shape[0], dY.shape[1], out.data_ptr(), out.stride(0),
+                                                     _stream(dY.device)), "mrgcn_relu_bwd_rows_f32")
     return out
 
 

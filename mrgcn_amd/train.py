@@ -30,10 +30,11 @@ class _SoftmaxXent(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, idx, targets):
-        logits = logits.contiguous()
+        if logits.stride(1) != 1:        # (rows may be strided: a layer output in a buffer with padded rows)
+            logits = logits.contiguous()
         N, C = logits.shape
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
-        dlogits = torch.empty_like(logits)
+        dlogits = torch.empty((N, C), dtype=torch.float32, device=logits.device)
         with torch.cuda.device(logits.device):
             L.check(L.load().mrgcn_softmax_xent_f32(
                 logits.data_ptr(), logits.stride(0), C, idx.data_ptr(), targets.data_ptr(),

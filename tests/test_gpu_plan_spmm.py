@@ -143,6 +143,43 @@ def test_spmm_literal_compact_transposed(skewed, F):
     np.testing.assert_allclose(dD.cpu().numpy(), A.T @ dY.astype(np.float64), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("F", [3, 10, 11, 13])
+def test_compact_product_into_rows_with_a_writable_pad(skewed, F):
+    """MRGCN_SPMM_PAD_WRITABLE: the product may zero columns F .. 4*ceil(F/4)-1 of Y's rows (whole 16-byte
+    stores) and nothing else; without the flag nothing outside [0, F) is touched; the values are bitwise those of
+    the dense output either way (rows of all three classes, rows of several chunks)."""
+    from mrgcn_amd import _lib as L
+    plan, A, ref, rng = skewed
+    rows, ld4 = A.shape[0], (F + 3) // 4 * 4
+    M = torch.from_numpy(rng.standard_normal((plan.nop, ld4)).astype(np.float32)).cuda()
+    M[:, F:] = 1e30
+    b = torch.from_numpy(rng.standard_normal(F).astype(np.float32)).cuda()
+    for bias, relu in ((None, False), (b, True)):
+        dense = torch.full((rows, F), float("nan"), device="cuda")
+        plan.spmm(L.VIEW_COMPACT, M, F=F, out=dense, bias=bias, relu=relu)
+        assert torch.isfinite(dense).all()
+        for ld, flag in ((ld4, True), (ld4, False), (ld4 + 4, True)):
+            buf = torch.full((rows, ld), 7.0, device="cuda")
+            plan.spmm(L.VIEW_COMPACT, M, F=F, out=buf[:, :F], bias=bias, relu=relu, pad_writable=flag)
+            assert torch.equal(buf[:, :F], dense)
+            if flag:
+                assert (buf[:, F:ld4] == 0).all() and (buf[:, ld4:] == 7.0).all()
+            else:
+                assert (buf[:, F:] == 7.0).all()
+        own = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu)   # the plan's own buffer: padded rows
+        assert own.shape == (rows, F) and own.stride(0) == ld4 and torch.equal(own, dense)
+
+
+def test_relu_backward_on_row_strided_operands():
+    from mrgcn_amd.functional import relu_bwd
+    g = torch.Generator("cuda").manual_seed(4)
+    for rows, F, ld in ((1, 1, 4), (1000, 10, 12), (777, 33, 36)):
+        Y = torch.randn((rows, ld), device="cuda", generator=g)[:, :F]
+        dY = torch.randn((rows, F), device="cuda", generator=g)
+        assert torch.equal(relu_bwd(dY, Y), dY * (Y > 0))
+        assert torch.equal(relu_bwd(dY, Y.contiguous()), dY * (Y > 0))
+
+
 def test_spmm_is_deterministic_and_linear(skewed):
     from mrgcn_amd import _lib as L
     plan, A, ref, rng = skewed

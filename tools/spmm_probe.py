@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--prune", action="store_true")
     ap.add_argument("--value-mode", default="norm_f32")
+    ap.add_argument("--ldy", type=int, default=0, help="leading dimension of the compact product's output (0 = F rounded up to 4, pad writable; F = dense rows)")
     ap.add_argument("--replicate", type=int, default=-1, help="1 / 0: operand replicas on / off (default: library)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -44,8 +45,9 @@ def main():
     for ld in a.ld:
         if a.view == "compact":
             D = torch.randn((plan.nop * ld + 8,), device=dev)[:plan.nop * ld].view(plan.nop, ld)
-            Y = torch.empty((N, F), device=dev)
-            fn = lambda: plan.spmm(L.VIEW_COMPACT, D, F=F, out=Y)  # noqa: E731
+            ldy = a.ldy if a.ldy else (F + 3) // 4 * 4   # default: the layer's own layout (rows padded to 16 bytes)
+            Y = torch.empty((N, max(ldy, F)), device=dev)[:, :F]
+            fn = lambda: plan.spmm(L.VIEW_COMPACT, D, F=F, out=Y, pad_writable=ldy > F)  # noqa: E731
             if plan.n_rep:
                 ms_r = event_time_ms(lambda: plan.replicate(D), a.iters, stream)
                 print(f"replicate ld={ld}: {ms_r*1e3:.1f} us for {plan.n_rep} rows")
