@@ -236,7 +236,10 @@ class _RgcnLayer(torch.autograd.Function):
                     L.check(gather_rows(plan.handle, wI.data_ptr(), F, addend, ldA, M.data_ptr(), ld, s),
                             "mrgcn_gather_rows_" + sfx)
         plan.replicate(M)  # (plans with operand replicas only)
-        Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu)
+        # a hidden layer's output stays in rows padded to whole 16-byte pieces (the product stores whole pieces: -5 %);
+        # an output the caller sees is dense like the reference's
+        Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu,
+                      padded_rows=bool(getattr(owner, "padded_output", False)))
         ctx.plan, ctx.F, ctx.ld, ctx.relu, ctx.owner = plan, F, ld, relu, owner
         ctx.has = (weight_I is not None, comp_I is not None, X is not None, bias is not None)
         ctx.save_for_backward(weight_I, comp_I, Xc, Wc, Y if relu else None)

@@ -30,6 +30,10 @@ class RGCN(nn.Module):
                 input_layer=first, bias=bias)
             self.activations[f"layer_{i}"] = f_activation
         self.num_layers = len(self.layers)
+        # hidden layers keep their output in rows padded to whole 16-byte pieces (plan.spmm: the product stores whole
+        # pieces); the model's own output is dense like the reference's
+        for key in list(self.layers)[:-1]:
+            self.layers[key].padded_output = True
 
         if link_prediction:
             # DistMult diagonal relation embeddings (rgcn.py:55-61)

@@ -151,19 +151,20 @@ class GraphPlan:
 
     def spmm(self, view: int, D: torch.Tensor, F: int | None = None, out: torch.Tensor | None = None,
              bias: torch.Tensor | None = None, relu: bool = False, out_index: int = 0,
-             out_rows: int | None = None, pad_writable: bool = False) -> torch.Tensor:
+             out_rows: int | None = None, pad_writable: bool = False, padded_rows: bool = False) -> torch.Tensor:
         """Y[i, :F] = sum_e val[e] * D[idx[e], :F] over row i of `view` (see mrgcn_spmm_f32).
         `out_index` is a device pointer (int) to an int32 row redirection table or 0.
-        Without `out`, the COMPACT product of a narrow layer whose F is not a multiple of four returns
-        the first F columns of a buffer with rows padded to whole 16-byte pieces (row stride
+        `padded_rows` (without `out`): the COMPACT product of a narrow layer whose F is not a multiple of
+        four returns the first F columns of a buffer with rows padded to whole 16-byte pieces (row stride
         4*ceil(F/4)): the kernel then stores whole pieces and consecutive rows fill their lines
-        (MRGCN_SPMM_PAD_WRITABLE).  `pad_writable` says the same of a caller's `out`."""
+        (MRGCN_SPMM_PAD_WRITABLE) — what a hidden layer's output is kept in.  `pad_writable` says the same of
+        a caller's `out`."""
         assert D.is_cuda and D.dtype in (torch.float32, torch.bfloat16) and D.dim() == 2 and D.stride(1) == 1
         bf16 = D.dtype == torch.bfloat16  # dense operand in bf16: fp32 values, accumulation and Y
         F = int(D.shape[1] if F is None else F)
         if out is None:
             rows = self.view_rows(view) if out_rows is None else out_rows
-            if view == L.VIEW_COMPACT and F <= 16 and F % 4 and not out_index:
+            if padded_rows and view == L.VIEW_COMPACT and F <= 16 and F % 4 and not out_index:
                 out = torch.empty((rows, (F + 3) // 4 * 4), dtype=torch.float32, device=D.device)[:, :F]
                 pad_writable = True
             else:

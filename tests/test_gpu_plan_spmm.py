@@ -166,8 +166,9 @@ def test_compact_product_into_rows_with_a_writable_pad(skewed, F):
                 assert (buf[:, F:ld4] == 0).all() and (buf[:, ld4:] == 7.0).all()
             else:
                 assert (buf[:, F:] == 7.0).all()
-        own = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu)   # the plan's own buffer: padded rows
+        own = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu, padded_rows=True)   # the plan's own buffer
         assert own.shape == (rows, F) and own.stride(0) == ld4 and torch.equal(own, dense)
+        assert plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu).is_contiguous()
 
 
 def test_relu_backward_on_row_strided_operands():
