@@ -95,6 +95,61 @@ def test_mrgcn_rejects_hub_configs_but_builds_the_rest():
     assert set(m.gate_map) == {"blob_image_0", "xsd_anyURI_0"} and m.im_norm is not None and m.modality_out_dim == 5
 
 
+def test_modality_embeddings_resolution_full_batch_cache_and_mini_batch():
+    """`MRGCN._compute_modality_embeddings` (mrgcn.py:250-305) on the host: which batch rows carry an encoding,
+    the gate multiply, zero gates skipped; a full batch resolves its sets once and notices new tensors; a mini-batch
+    (partial overlap with the set's nodes) matches a row-by-row restatement of the reference's masks."""
+    from mrgcn_amd.models.mrgcn import MRGCN
+    N, R = 40, 3
+    torch.manual_seed(1)
+    emb_cfg = sorted([("xsd.boolean", (2, 2, 0.0), False), ("xsd.numeric", (4, 3, 0.0), False)], key=lambda t: t[0])
+    model = MRGCN([(5, 4, "mrgcn", None)], emb_cfg, R, N, num_bases=0, p_dropout=0.0, featureless=False, bias=False,
+                  gcn_gpu_acceleration=False)
+    model.devices["relational"] = torch.device("cpu")   # (the embeddings alone run anywhere; the R-GCN needs the GPU)
+    model.gate_weights.data = model.gate_weights.data.cpu()
+    rng = np.random.default_rng(3)
+    num_idx = torch.from_numpy(np.sort(rng.choice(N, 12, replace=False)))
+    boo_idx = torch.from_numpy(np.sort(rng.choice(N, 7, replace=False)))
+    num, boo = torch.randn((12, 4)), torch.randn((7, 2))
+    F = [["xsd.boolean", [[boo, boo_idx, None]], False], ["xsd.numeric", [[num, num_idx, None]], False]]
+
+    def restated(batch_idx):
+        X = torch.zeros((len(batch_idx), model.modality_out_dim))
+        off = 0
+        for dt, sets, _ in F:
+            for i, (enc, nidx, _) in enumerate(sets):
+                module, _, dim, ig = model.modality_modules[dt][i]
+                if not torch.isclose(model.gate_weights[ig], torch.tensor(0.0)):
+                    for pos, node in enumerate(batch_idx.tolist()):
+                        hit = (nidx == node).nonzero()
+                        if hit.numel():
+                            X[pos, off:off + dim] = module(enc[hit[0, 0]][None].float())[0] * model.gate_weights[ig]
+                off += dim
+        return X
+
+    full = torch.arange(N)
+    with torch.no_grad():
+        a = model._compute_modality_embeddings(F, full, full_batch=True)
+        torch.testing.assert_close(a, restated(full))
+        cached = dict(model._full_batch_sets)
+        b = model._compute_modality_embeddings(F, full, full_batch=True)
+        assert torch.equal(a, b) and all(model._full_batch_sets[k][3] is cached[k][3] for k in cached)   # resolved once
+        num2 = torch.randn((12, 4))
+        F[1][1][0][0] = num2                                                                      # new encodings
+        c = model._compute_modality_embeddings(F, full, full_batch=True)
+        torch.testing.assert_close(c, restated(full))
+        assert model._full_batch_sets[("xsd.numeric", 0)][0] is num2
+        # a mini-batch: ascending node ids, as the neighbour lists are (the reference pairs the k-th selected encoding
+        # with the k-th selected batch position, mrgcn.py:276-303, which is the same node only in that order)
+        mb = torch.from_numpy(np.sort(rng.permutation(N)[:17]))
+        torch.testing.assert_close(model._compute_modality_embeddings(F, mb), restated(mb))
+        none = torch.tensor([n for n in range(N) if n not in set(num_idx.tolist()) | set(boo_idx.tolist())][:5])
+        assert float(model._compute_modality_embeddings(F, none).abs().sum()) == 0.0
+        model.gate_weights.data[model.modality_modules["xsd.numeric"][0][3]] = 0.0                 # a closed gate
+        d = model._compute_modality_embeddings(F, full, full_batch=True)
+        torch.testing.assert_close(d, restated(full))
+
+
 @pytest.mark.gpu
 def test_mrgcn_with_tcnn_and_mlp_encoders_vs_reference():
     """MRGCN(FullBatch) with an ogc.wktLiteral (TCNN) and an xsd.numeric (MLP) encoder: state-dict
