@@ -437,6 +437,18 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   return MRGCN_OK;
 }
 
+// long rows of several chunks: flag, (scan), positions
+__global__ void k_multi_flag(const int32_t *__restrict__ long_cptr, int64_t n_long, int32_t *__restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_long) flag[i] = long_cptr[i + 1] - long_cptr[i] > 1 ? 1 : 0;
+  if (i == n_long) flag[i] = 0;
+}
+__global__ void k_multi_fill(const int32_t *__restrict__ flag, const int32_t *__restrict__ pos, int64_t n_long,
+                             int32_t *__restrict__ multi) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_long && flag[i]) multi[pos[i]] = (int32_t)i;
+}
+
 int bits_for(int64_t max_value) {
   int b = 1;
   while (b < 63 && (max_value >> b) != 0) ++b;
@@ -796,6 +808,24 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
                          kChunk3Entries, kChunk3Cap)))
       return rc;
   }
+  {  // the rows k_spmm3 leaves partial sums of: the finalize pass launches one wave for each of these, not for each long row
+    const int64_t nl = p->r3_n_long;
+    int32_t *flag, *pos;
+    MRGCN_HIP_TRY(sc.alloc(&flag, nl + 1));
+    MRGCN_HIP_TRY(sc.alloc(&pos, nl + 1));
+    k_multi_flag<<<nblocks(nl + 1), kTB, 0, s>>>(p->r3_long_cptr, nl, flag);
+    MRGCN_HIP_TRY(hipGetLastError());
+    int rc2;
+    if ((rc2 = exclusive_scan_i32(flag, pos, nl + 1, s, sc))) return rc2;
+    int32_t h = 0;
+    MRGCN_HIP_TRY(hipMemcpyAsync(&h, pos + nl, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MRGCN_HIP_TRY(hipStreamSynchronize(s));
+    p->r3_n_multi = h;
+    MRGCN_HIP_TRY(plan_alloc(p, &p->r3_multi, h));
+    if (h > 0) k_multi_fill<<<nblocks(nl), kTB, 0, s>>>(flag, pos, nl, p->r3_multi);
+    MRGCN_HIP_TRY(hipGetLastError());
+    MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  }
   int64_t ws = (int64_t)std::max(std::max(p->r_n_chunks, p->q_n_chunks), p->c_n_chunks) * kWsFeatures;
   ws = std::max<int64_t>(ws, (int64_t)p->r3_n_chunks * 16);
   MRGCN_HIP_TRY(plan_alloc(p, &p->partials, ws));
@@ -809,7 +839,7 @@ void free_plan(mrgcn_plan *p) {
                   p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->r_chunk_row, p->c_chunk_row,
                   p->r3_long_row, p->r3_long_cptr, p->r3_chunk_beg, p->r3_chunk_end, p->r3_chunk_row,
                   p->q_long_row, p->q_long_cptr, p->q_chunk_beg, p->q_chunk_end, p->q_chunk_row, p->rowmap, p->ptr3,
-                  p->rep_src, p->rep_dst, p->partials};
+                  p->rep_src, p->rep_dst, p->partials, p->r3_multi};
   // the caller guarantees nothing that uses the plan is still to be SUBMITTED; work already in flight on any
   // stream is waited for (what hipFree did implicitly), then the blocks go back to the pool
   (void)hipDeviceSynchronize();

@@ -367,6 +367,8 @@ struct View3 {  // what k_spmm3 needs beyond the COMPACT SparseView (whose rows 
   const int32_t *long_row = nullptr, *long_cptr = nullptr;                   // [n_long] ranks, [n_long + 1]
   int64_t op_rows = 0;                 // rows of the operand the indices point into
   int32_t pad_ok = 0;                  // columns F..ldY-1 of Y belong to the caller's buffer and may be zeroed
+  const int32_t *multi = nullptr;      // [n_multi_rows] positions in long_row of the rows of several chunks
+  int32_t n_multi_rows = 0;
 };
 
 // OFF32: gathers address the operand with 32-bit byte offsets (operand < 4 GB).  WPE: waves per SIMD the register
@@ -525,10 +527,10 @@ __global__ __launch_bounds__(256) void k_spmm3_finalize(View3 w, const float *__
                                                         float *__restrict__ Y, int64_t ldY,
                                                         const float *__restrict__ bias, int relu) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t li = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-  if (li >= w.n_long) return;
+  const int64_t wi = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  if (wi >= w.n_multi_rows) return;
+  const int64_t li = w.multi[wi];  // (single-chunk rows were stored by their chunk's wave: they are not in the list)
   const int32_t c0 = w.long_cptr[li], c1 = w.long_cptr[li + 1];
-  if (c1 - c0 <= 1) return;  // single-chunk rows were stored by the chunk wave
   const int f = lane & 15, k = lane >> 4;  // F <= 16 here: four chunks per step, at most kChunk3Cap = 64 per row
   float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -856,7 +858,7 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
         MRGCN_HIP_TRY(hipGetLastError());
       }
       if (w3->n_multi > 0) {
-        k_spmm3_finalize<<<dim3((unsigned)((w3->n_long + 3) / 4)), dim3(256), 0, s>>>(*w3, partials, 16, F, Y, ldY,
+        k_spmm3_finalize<<<dim3((unsigned)((w3->n_multi_rows + 3) / 4)), dim3(256), 0, s>>>(*w3, partials, 16, F, Y, ldY,
                                                                                       bias, relu);
         MRGCN_HIP_TRY(hipGetLastError());
       }
@@ -992,6 +994,7 @@ View3 view3_of(const mrgcn_plan *p) {
   w.chunk_beg = p->r3_chunk_beg; w.chunk_end = p->r3_chunk_end; w.chunk_row = p->r3_chunk_row;
   w.long_row = p->r3_long_row; w.long_cptr = p->r3_long_cptr;
   w.op_rows = p->n_op;
+  w.multi = p->r3_multi; w.n_multi_rows = p->r3_n_multi;
   return w;
 }
 
