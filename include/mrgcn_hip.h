@@ -147,6 +147,10 @@ int mrgcn_plan_array(const mrgcn_plan_t *plan, int32_t which, const void **d_ptr
  * F <= 16: the product runs 5 % faster); without the flag nothing outside [0, F) is touched. */
 #define MRGCN_SPMM_RELU 1
 #define MRGCN_SPMM_PAD_WRITABLE 2
+/* COMPACT view, F <= 16: rows cut into several chunks are by default finished inside the product kernel by the
+ * wave that delivers the row's last partial sum (fixed summation order: results are bitwise reproducible and equal
+ * to the two-pass form's).  This flag asks for the two-pass form: a second launch adds the partial sums. */
+#define MRGCN_SPMM_TWO_PASS 4
 int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const float *D, int64_t ldD,
                    int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu,
                    const int32_t *out_index, void *stream);

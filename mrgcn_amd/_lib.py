@@ -21,7 +21,7 @@ OK = 0
 VAL_I8, VAL_F32 = 0, 1
 PLAN_PRUNE_ZEROS, PLAN_REPLICATE, PLAN_NO_REPLICATE = 1, 2, 4
 VIEW_LITERAL, VIEW_COMPACT, VIEW_TRANSPOSED = 0, 1, 2
-SPMM_RELU, SPMM_PAD_WRITABLE = 1, 2  # flag word of mrgcn_spmm_f32 / _bf16 (`relu` argument)
+SPMM_RELU, SPMM_PAD_WRITABLE, SPMM_TWO_PASS = 1, 2, 4  # flag word of mrgcn_spmm_f32 / _bf16 (`relu` argument)
 (ARR_ROWPTR, ARR_LCOL, ARR_CCOL, ARR_VAL, ARR_CPTR, ARR_CROW, ARR_CVAL, ARR_UREL, ARR_UNODE,
  ARR_NPTR, ARR_ROWIDX, ARR_ULCOL, ARR_RPERM, ARR_RELPTR, ARR_MPOS, ARR_MCOL, ARR_MVAL, ARR_ROWMAP,
  ARR_PTR3) = range(19)

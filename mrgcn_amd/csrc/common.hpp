@@ -153,6 +153,7 @@ struct mrgcn_plan {
   int32_t r3_n_long = 0, r3_n_chunks = 0;
   int32_t *r3_multi = nullptr;  // [r3_n_multi] positions in r3_long_row of the rows that span several chunks
   int32_t r3_n_multi = 0;       // (k_spmm3_finalize runs over these only)
+  int32_t *r3_ticket = nullptr;  // [r3_n_long] arrival counters of the in-kernel finalize (zero between launches)
   float *partials = nullptr;  // [max(r_n_chunks, c_n_chunks) * kWsFeatures]
 
   mrgcn::SparseView view(int which) const {

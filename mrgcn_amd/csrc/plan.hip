@@ -293,7 +293,8 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
                             const int32_t *__restrict__ is_long, const int32_t *__restrict__ long_pos,
                             const int32_t *__restrict__ chunk_pos, int32_t *__restrict__ long_row,
                             int32_t *__restrict__ long_cptr, int32_t *__restrict__ chunk_beg,
-                            int32_t *__restrict__ chunk_end, int32_t *__restrict__ chunk_row) {
+                            int32_t *__restrict__ chunk_end, int32_t *__restrict__ chunk_row,
+                            int neg_long_pos) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows || !is_long[i]) return;
   int32_t li = long_pos[i], c0 = chunk_pos[i];
@@ -304,7 +305,9 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
   for (int32_t s = b, c = c0; s < e; s += chunk, ++c) {
     chunk_beg[c] = s;
     chunk_end[c] = min(s + chunk, e);
-    chunk_row[c] = (e - b <= chunk) ? (int32_t)i : -((int32_t)i + 2);  // < 0: one of several chunks of row -x - 2
+    // < 0: one of several chunks of row -x - 2 (neg_long_pos: of the long row at position -x - 2 of long_row — what
+    // the in-kernel finalize of k_spmm3 needs: its ticket and its chunk range)
+    chunk_row[c] = (e - b <= chunk) ? (int32_t)i : -((neg_long_pos ? li : (int32_t)i) + 2);
   }
 }
 
@@ -397,7 +400,7 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
                int32_t **long_cptr, int32_t **chunk_beg, int32_t **chunk_end, int32_t **chunk_row,
                int32_t *n_long,
                int32_t *n_chunks, int64_t *max_len, int threshold = kLongThreshold, int chunk = kChunk,
-               int cap = 0) {
+               int cap = 0, int neg_long_pos = 0) {
   Scratch sc;
   sc.s = s;
   int32_t *is_long, *nchunk, *long_pos, *chunk_pos, *d_max;
@@ -431,7 +434,8 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(hipMemcpyAsync(*long_cptr + h[0], &h[1], sizeof(int32_t), hipMemcpyHostToDevice, s));
   if (rows > 0 && h[0] > 0)
     k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, chunk, cap, is_long, long_pos, chunk_pos,
-                                              *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row);
+                                              *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row,
+                                              neg_long_pos);
   MRGCN_HIP_TRY(hipGetLastError());
   MRGCN_HIP_TRY(hipStreamSynchronize(s));
   return MRGCN_OK;
@@ -805,8 +809,12 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
       return rc;
     if ((rc = build_long(p, p->ptr3, p->num_rows, s, &p->r3_long_row, &p->r3_long_cptr, &p->r3_chunk_beg,
                          &p->r3_chunk_end, &p->r3_chunk_row, &p->r3_n_long, &p->r3_n_chunks, &dummy, kMid3Rows,
-                         kChunk3Entries, kChunk3Cap)))
+                         kChunk3Entries, kChunk3Cap, 1)))
       return rc;
+    // one arrival counter per long row (k_spmm3: the wave that brings a row's last partial sum adds them up);
+    // zero between launches — the last arriver puts its row's counter back
+    MRGCN_HIP_TRY(plan_alloc(p, &p->r3_ticket, p->r3_n_long));
+    MRGCN_HIP_TRY(hipMemsetAsync(p->r3_ticket, 0, (size_t)std::max<int64_t>(p->r3_n_long, 1) * sizeof(int32_t), s));
   }
   {  // the rows k_spmm3 leaves partial sums of: the finalize pass launches one wave for each of these, not for each long row
     const int64_t nl = p->r3_n_long;
@@ -839,7 +847,7 @@ void free_plan(mrgcn_plan *p) {
                   p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->r_chunk_row, p->c_chunk_row,
                   p->r3_long_row, p->r3_long_cptr, p->r3_chunk_beg, p->r3_chunk_end, p->r3_chunk_row,
                   p->q_long_row, p->q_long_cptr, p->q_chunk_beg, p->q_chunk_end, p->q_chunk_row, p->rowmap, p->ptr3,
-                  p->rep_src, p->rep_dst, p->partials, p->r3_multi};
+                  p->rep_src, p->rep_dst, p->partials, p->r3_multi, p->r3_ticket};
   // the caller guarantees nothing that uses the plan is still to be SUBMITTED; work already in flight on any
   // stream is waited for (what hipFree did implicitly), then the blocks go back to the pool
   (void)hipDeviceSynchronize();

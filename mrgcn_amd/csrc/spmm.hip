@@ -369,6 +369,8 @@ struct View3 {  // what k_spmm3 needs beyond the COMPACT SparseView (whose rows 
   int32_t pad_ok = 0;                  // columns F..ldY-1 of Y belong to the caller's buffer and may be zeroed
   const int32_t *multi = nullptr;      // [n_multi_rows] positions in long_row of the rows of several chunks
   int32_t n_multi_rows = 0;
+  int32_t *ticket = nullptr;           // [n_long] arrival counters (zero between launches)
+  int32_t fold = 0;                    // rows of several chunks are finished inside k_spmm3 by their last chunk's wave
 };
 
 // OFF32: gathers address the operand with 32-bit byte offsets (operand < 4 GB).  WPE: waves per SIMD the register
@@ -394,9 +396,12 @@ __global__ __launch_bounds__(256, WPE) void k_spmm3(SparseView v, View3 w, const
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
 
   if ((int)blockIdx.x < chunk_blocks) {  // ---- L: one wave per chunk: pieces of <= kChunk3 entries, one batch each
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // wave uniform: scalar loads below
     if (c >= w.n_chunks) return;
     const int32_t cb = w.chunk_beg[c], ce = w.chunk_end[c];
+    const int32_t rk = w.chunk_row[c];           // >= 0: the rank of a row that is this one chunk; else -(li + 2)
+    const int32_t li = rk < 0 ? -rk - 2 : 0;     // position of the row among the long rows (unconditional loads)
+    const int32_t lc0 = w.long_cptr[li], lc1 = w.long_cptr[li + 1];
     constexpr int T = kChunk3 / kWave;
     constexpr int PER = kWave / SLOTS;  // = G gather rounds per staged register
     for (int32_t b = cb; b < ce; b += kChunk3) {  // (rows of more than 64 * kChunk3 entries: several pieces)
@@ -424,17 +429,63 @@ __global__ __launch_bounds__(256, WPE) void k_spmm3(SparseView v, View3 w, const
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
     }
-    if (slot == 0 && active) {
-      const int32_t rk = w.chunk_row[c];
-      if (rk >= 0) {  // the whole row was this chunk: finished
-        const int64_t orow = w.rowmap[rk];
-        store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, (store_vec_ok & 1) != 0, (store_vec_ok & 2) ? (int)ldY : 0);
-      } else {
-        float *p = partials + (int64_t)c * ldP + f0;
+    if (rk >= 0) {  // the whole row was this chunk: finished
+      if (slot == 0 && active)
+        store_row<VEC>(Y + (int64_t)w.rowmap[rk] * ldY, acc, f0, F, bias, relu, (store_vec_ok & 1) != 0, (store_vec_ok & 2) ? (int)ldY : 0);
+      return;
+    }
+    float *p = partials + (int64_t)c * ldP + f0;
+    if (!w.fold) {  // two-pass form: k_spmm3_finalize adds the partial sums
+      if (slot == 0 && active) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i)
           if (f0 + i < F) p[i] = acc[i];
       }
+      return;
+    }
+    // ---- in-kernel finalize: the wave that brings a row's LAST partial sum adds them all, in chunk order (the
+    // sums do not depend on which wave that is: bitwise reproducible).  Hand-off across CUs / XCDs
+    // (MI355X_MICROARCH.md, "inter-workgroup visibility"): partial sums leave as agent-scope (sc1, write-through)
+    // stores, the storing wave waits for them, then adds to the row's arrival counter with an agent-scope atomic;
+    // the wave whose add returns "all others were here" reads the partials back with agent-scope (sc1) loads,
+    // which bypass its CU's L1 — and puts the counter back to zero for the next launch.
+    if (slot == 0 && active) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) __hip_atomic_store(p + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int32_t old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(w.ticket + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    asm volatile("" ::: "memory");
+    if (old != lc1 - lc0 - 1) return;
+    {
+      const int f = lane & 15, k = lane >> 4;  // F <= 16: four chunks per step, at most kChunk3Cap = 64 per row
+      float sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int32_t cc = lc0 + k + 16 * u;
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // unconditional loads at clamped addresses: all sixteen in flight at once
+          const int32_t ck = min(cc + 4 * i, lc1 - 1);
+          x[i] = __hip_atomic_load(partials + (int64_t)ck * ldP + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sm[u] += (cc + 4 * i < lc1) ? x[i] : 0.f;
+      }
+      float t = (sm[0] + sm[1]) + (sm[2] + sm[3]);  // fixed order, as k_spmm3_finalize
+      t += __shfl_xor(t, 16, kWave);
+      t += __shfl_xor(t, 32, kWave);
+      const int64_t orow = w.rowmap[w.long_row[li]];
+      if (k == 0 && f < F) {
+        if (bias) t += bias[f];
+        if (relu) t = fmaxf(t, 0.f);
+        Y[orow * ldY + f] = t;
+      } else if (k == 0 && w.pad_ok && f < ldY && f < (F + 3) / 4 * 4) {
+        Y[orow * ldY + f] = 0.f;
+      }
+      if (lane == 0) __hip_atomic_store(w.ticket + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return;
   }
@@ -857,7 +908,7 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
 #undef SPMM3_GO
         MRGCN_HIP_TRY(hipGetLastError());
       }
-      if (w3->n_multi > 0) {
+      if (w3->n_multi > 0 && !w3->fold) {
         k_spmm3_finalize<<<dim3((unsigned)((w3->n_multi_rows + 3) / 4)), dim3(256), 0, s>>>(*w3, partials, 16, F, Y, ldY,
                                                                                       bias, relu);
         MRGCN_HIP_TRY(hipGetLastError());
@@ -987,6 +1038,12 @@ int dispatch_bf16(const SparseView &v, const uint16_t *D, int64_t ldD, int64_t a
   return MRGCN_ERR_UNSUPPORTED;
 }
 
+// MRGCN_SPMM_FOLD=0: the separate finalize launch for every call (A/B)
+bool spmm3_fold_default() {
+  static const bool on = !(getenv("MRGCN_SPMM_FOLD") && atoi(getenv("MRGCN_SPMM_FOLD")) == 0);
+  return on;
+}
+
 View3 view3_of(const mrgcn_plan *p) {
   View3 w;
   w.n_short = p->n_short3; w.n_mid = p->n_mid3; w.rowmap = p->rowmap;
@@ -995,6 +1052,7 @@ View3 view3_of(const mrgcn_plan *p) {
   w.long_row = p->r3_long_row; w.long_cptr = p->r3_long_cptr;
   w.op_rows = p->n_op;
   w.multi = p->r3_multi; w.n_multi_rows = p->r3_n_multi;
+  w.ticket = p->r3_ticket;
   return w;
 }
 
@@ -1122,8 +1180,9 @@ extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uin
     MRGCN_REQUIRE(out_index == nullptr, "out_index is not available on the COMPACT view");
     out_index = plan->rowmap;
   }
-  MRGCN_REQUIRE((relu & ~(MRGCN_SPMM_RELU | MRGCN_SPMM_PAD_WRITABLE)) == 0, "flags");
+  MRGCN_REQUIRE((relu & ~(MRGCN_SPMM_RELU | MRGCN_SPMM_PAD_WRITABLE | MRGCN_SPMM_TWO_PASS)) == 0, "flags");
   const int pad_ok = (relu & MRGCN_SPMM_PAD_WRITABLE) != 0;
+  const int fold = (relu & MRGCN_SPMM_TWO_PASS) == 0 && spmm3_fold_default();
   relu &= MRGCN_SPMM_RELU;
   int tile = 64;
   if (ldD % 8 == 0 && ((uintptr_t)D) % 16 == 0) tile = 256;  // kWsFeatures floats of partials per chunk
@@ -1133,6 +1192,7 @@ extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uin
     const int w = (F - f < tile) ? (F - f) : tile;
     View3 w3 = view3_of(plan);
     w3.pad_ok = pad_ok;
+    w3.fold = fold;
     int rc = dispatch_bf16(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu, out_index,
                            plan->partials, (hipStream_t)stream, (view == MRGCN_VIEW_COMPACT && F <= 16) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
@@ -1153,8 +1213,9 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     MRGCN_REQUIRE(out_index == nullptr, "out_index is not available on the COMPACT view");
     out_index = plan->rowmap;
   }
-  MRGCN_REQUIRE((relu & ~(MRGCN_SPMM_RELU | MRGCN_SPMM_PAD_WRITABLE)) == 0, "flags");
+  MRGCN_REQUIRE((relu & ~(MRGCN_SPMM_RELU | MRGCN_SPMM_PAD_WRITABLE | MRGCN_SPMM_TWO_PASS)) == 0, "flags");
   const int pad_ok = (relu & MRGCN_SPMM_PAD_WRITABLE) != 0;
+  const int fold = (relu & MRGCN_SPMM_TWO_PASS) == 0 && spmm3_fold_default();
   relu &= MRGCN_SPMM_RELU;
   hipStream_t s = (hipStream_t)stream;
   // feature tiles: one pass covers up to 64 lanes x VEC floats; the split-row workspace
@@ -1176,6 +1237,7 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     // the COMPACT view of a narrow layer takes k_spmm3
     View3 w3 = view3_of(plan);
     w3.pad_ok = pad_ok;
+    w3.fold = fold;
     int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu,
                       out_index, plan->partials, use_tiny, operand_cached, s,
                       (view == MRGCN_VIEW_COMPACT && F <= 16) ? &w3 : nullptr);

@@ -151,14 +151,15 @@ class GraphPlan:
 
     def spmm(self, view: int, D: torch.Tensor, F: int | None = None, out: torch.Tensor | None = None,
              bias: torch.Tensor | None = None, relu: bool = False, out_index: int = 0,
-             out_rows: int | None = None, pad_writable: bool = False, padded_rows: bool = False) -> torch.Tensor:
+             out_rows: int | None = None, pad_writable: bool = False, padded_rows: bool = False,
+             two_pass: bool = False) -> torch.Tensor:
         """Y[i, :F] = sum_e val[e] * D[idx[e], :F] over row i of `view` (see mrgcn_spmm_f32).
         `out_index` is a device pointer (int) to an int32 row redirection table or 0.
         `padded_rows` (without `out`): the COMPACT product of a narrow layer whose F is not a multiple of
         four returns the first F columns of a buffer with rows padded to whole 16-byte pieces (row stride
         4*ceil(F/4)): the kernel then stores whole pieces and consecutive rows fill their lines
         (MRGCN_SPMM_PAD_WRITABLE) — what a hidden layer's output is kept in.  `pad_writable` says the same of
-        a caller's `out`."""
+        a caller's `out`.  `two_pass`: MRGCN_SPMM_TWO_PASS (rows of several chunks finished by a second launch)."""
         assert D.is_cuda and D.dtype in (torch.float32, torch.bfloat16) and D.dim() == 2 and D.stride(1) == 1
         bf16 = D.dtype == torch.bfloat16  # dense operand in bf16: fp32 values, accumulation and Y
         F = int(D.shape[1] if F is None else F)
@@ -172,7 +173,8 @@ class GraphPlan:
         assert out.dtype == torch.float32 and out.stride(1) == 1 and out.is_cuda
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() >= F
-        flags = (L.SPMM_RELU if relu else 0) | (L.SPMM_PAD_WRITABLE if pad_writable else 0)
+        flags = ((L.SPMM_RELU if relu else 0) | (L.SPMM_PAD_WRITABLE if pad_writable else 0)
+                 | (L.SPMM_TWO_PASS if two_pass else 0))
         with torch.cuda.device(D.device):
             fn = L.load().mrgcn_spmm_bf16 if bf16 else L.load().mrgcn_spmm_f32
             L.check(fn(self.handle, view, D.data_ptr(), D.stride(0), F, out.data_ptr(), out.stride(0),

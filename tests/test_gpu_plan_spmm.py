@@ -413,3 +413,51 @@ def test_operand_order_keeps_reread_rows_off_the_straddling_slots():
     val = plan.export(L.ARR_VAL).astype(np.float64)
     want = sp.csr_matrix((val, (rowidx, mpos[ccol])), shape=(N, nc)) @ M[:, :10].double().cpu().numpy()
     np.testing.assert_allclose(Y, want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("F", [10, 16, 3])
+def test_rows_of_several_chunks_finished_inside_the_product_equal_the_two_pass_form(F):
+    """k_spmm3 finishes a row cut into several chunks in the wave that delivers its last partial sum (arrival counter
+    per row, agent-scope stores / loads of the partial sums across the XCDs).  The summation order is fixed, so the
+    result must be bitwise that of the two-pass form (MRGCN_SPMM_TWO_PASS: a second launch adds the partials) —
+    for every launch of a back-to-back series whose operands change from launch to launch (a stale partial sum of
+    the previous launch would show), while another stream keeps the memory system busy."""
+    from mrgcn_amd import _lib as L
+    rng = np.random.default_rng(5)
+    N, R, num_rows = 60000, 3, 60000
+    RN = R * N
+    lens = np.concatenate([rng.integers(129, 1500, 1500), rng.integers(1500, 9000, 40), [70000],
+                           rng.integers(33, 128, 500)])
+    hub = rng.choice(num_rows, len(lens), replace=False)
+    rows = np.concatenate([rng.integers(0, num_rows, 200000)] + [np.full(n, h) for n, h in zip(lens, hub)])
+    cols = np.concatenate([rng.integers(0, RN, 200000)] + [rng.choice(RN, n, replace=False) for n in lens])
+    key = np.unique(rows.astype(np.int64) * RN + cols)
+    rows, cols = key // RN, key % RN
+    vals = rng.standard_normal(len(rows)).astype(np.float32)
+    plan = _plan_from_coo(rows, cols, vals, num_rows, N, R)
+    ld = (F + 3) // 4 * 4
+    g = torch.Generator("cuda").manual_seed(1)
+    Ms = [torch.randn((plan.nop, ld), device="cuda", generator=g) for _ in range(3)]
+    bias = torch.randn(F, device="cuda", generator=g)
+    want = [plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=True, two_pass=True) for M in Ms]
+    A = sp.csr_matrix((vals.astype(np.float64), (rows, cols)), shape=(num_rows, RN))
+    ref = util.numpy_plan(rows, cols, vals, num_rows, N, R)
+    D = np.zeros((RN, F))
+    D[ref["ulcol"]] = Ms[0].cpu().numpy()[ref["mpos"], :F]
+    np.testing.assert_allclose(want[0].cpu().numpy(), np.maximum(A @ D + bias.cpu().numpy(), 0), rtol=1e-4, atol=2e-3)
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 27, device="cuda")
+    outs = []
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            big.add_(1.0)
+    for it in range(60):
+        outs.append(plan.spmm(L.VIEW_COMPACT, Ms[it % 3], F=F, bias=bias, relu=True))
+    torch.cuda.synchronize()
+    for it, y in enumerate(outs):
+        assert torch.equal(y, want[it % 3]), f"launch {it}"
+    # into padded rows as well (the pad of a finished row is zeroed by the finishing wave)
+    if F % 4:
+        buf = torch.full((num_rows, ld), 7.0, device="cuda")
+        plan.spmm(L.VIEW_COMPACT, Ms[1], F=F, out=buf[:, :F], bias=bias, relu=True, pad_writable=True)
+        assert torch.equal(buf[:, :F], want[1]) and (buf[:, F:] == 0).all()

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--value-mode", default="norm_f32")
     ap.add_argument("--ldy", type=int, default=0, help="leading dimension of the compact product's output (0 = F rounded up to 4, pad writable; F = dense rows)")
     ap.add_argument("--replicate", type=int, default=-1, help="1 / 0: operand replicas on / off (default: library)")
+    ap.add_argument("--ab-two-pass", type=int, default=0, help="compact view: alternate N rounds of the two-pass "
+                    "form (MRGCN_SPMM_TWO_PASS) and the default in-kernel finalize, in this process")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     g = synth.make_graph(a.workload, seed=0, scale=a.scale, value_mode=a.value_mode)
@@ -48,6 +50,11 @@ def main():
             ldy = a.ldy if a.ldy else (F + 3) // 4 * 4   # default: the layer's own layout (rows padded to 16 bytes)
             Y = torch.empty((N, max(ldy, F)), device=dev)[:, :F]
             fn = lambda: plan.spmm(L.VIEW_COMPACT, D, F=F, out=Y, pad_writable=ldy > F)  # noqa: E731
+            fn2 = lambda: plan.spmm(L.VIEW_COMPACT, D, F=F, out=Y, pad_writable=ldy > F, two_pass=True)  # noqa: E731
+            for r in range(a.ab_two_pass):
+                t2 = event_time_ms(fn2, a.iters, stream)
+                t1 = event_time_ms(fn, a.iters, stream)
+                print(f"round {r}: two-pass {t2*1e3:.1f} us, in-kernel finalize {t1*1e3:.1f} us")
             if plan.n_rep:
                 ms_r = event_time_ms(lambda: plan.replicate(D), a.iters, stream)
                 print(f"replicate ld={ld}: {ms_r*1e3:.1f} us for {plan.n_rep} rows")
