@@ -231,7 +231,7 @@ def main():
         idx = torch.from_numpy(idx_np).to(dev)
         tgt = torch.from_numpy(y_np).to(dev)
         opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=args.graph)
-        plan = plan_of(A, N, R)
+        plan = plan_of(A, N, R, operand_row_bytes=model.operand_row_bytes())
 
         def step():
             return train_step(model, lambda: model(X, A), idx, tgt, opt)

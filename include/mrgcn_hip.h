@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MRGCN_ABI_VERSION 1
+#define MRGCN_ABI_VERSION 2
 
 enum mrgcn_status {
   MRGCN_OK = 0,
@@ -123,6 +123,22 @@ int mrgcn_plan_create_csr(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nod
                           int32_t num_relations, int64_t nnz, const int32_t *indptr,
                           const int32_t *indices, const float *data, int32_t boundary_cast_i8,
                           uint32_t flags, void *stream);
+/* The same two constructors with a hint: the row sizes (bytes) of the compact operands M the plan's COMPACT
+ * products will read — 4 * F for the packed rows of a layer of F outputs (F not a multiple of four), 4 * roundup(F, 4)
+ * for padded rows, 2 * ld for bf16 rows.  The order of M keeps columns that several rows read off the positions
+ * whose row would straddle a 128-byte line for any of these sizes (a re-read then costs one line, not two; AM
+ * shape, F = 10: 158 -> 148 us with 40-byte rows).  Results never depend on the hint.  At most four sizes are
+ * used; without a hint (or through the plain constructors) 48-byte rows are assumed. */
+int mrgcn_plan_create_hinted(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes,
+                             int32_t num_relations, int64_t nnz, const int64_t *coo_rows,
+                             const int64_t *coo_cols, const void *coo_vals, int32_t val_dtype,
+                             uint32_t flags, const int32_t *operand_row_bytes, int32_t n_row_bytes,
+                             void *stream);
+int mrgcn_plan_create_csr_hinted(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes,
+                                 int32_t num_relations, int64_t nnz, const int32_t *indptr,
+                                 const int32_t *indices, const float *data, int32_t boundary_cast_i8,
+                                 uint32_t flags, const int32_t *operand_row_bytes, int32_t n_row_bytes,
+                                 void *stream);
 int mrgcn_plan_destroy(mrgcn_plan_t *plan);
 int mrgcn_plan_info(const mrgcn_plan_t *plan, mrgcn_plan_info_t *h_info);
 /* copies one plan array to HOST memory (tests: index parity is bit-exact) */

@@ -21,6 +21,7 @@ OK = 0
 VAL_I8, VAL_F32 = 0, 1
 PLAN_PRUNE_ZEROS, PLAN_REPLICATE, PLAN_NO_REPLICATE = 1, 2, 4
 VIEW_LITERAL, VIEW_COMPACT, VIEW_TRANSPOSED = 0, 1, 2
+ABI_VERSION = 2  # include/mrgcn_hip.h: MRGCN_ABI_VERSION
 SPMM_RELU, SPMM_PAD_WRITABLE, SPMM_TWO_PASS = 1, 2, 4  # flag word of mrgcn_spmm_f32 / _bf16 (`relu` argument)
 (ARR_ROWPTR, ARR_LCOL, ARR_CCOL, ARR_VAL, ARR_CPTR, ARR_CROW, ARR_CVAL, ARR_UREL, ARR_UNODE,
  ARR_NPTR, ARR_ROWIDX, ARR_ULCOL, ARR_RPERM, ARR_RELPTR, ARR_MPOS, ARR_MCOL, ARR_MVAL, ARR_ROWMAP,
@@ -48,6 +49,9 @@ SIGNATURES = {
     "mrgcn_last_error": (C.c_char_p, []),
     "mrgcn_plan_create": (C.c_int, [C.POINTER(_p), _i64, _i64, _i32, _i64, _p, _p, _p, _i32, _u32, _p]),
     "mrgcn_plan_create_csr": (C.c_int, [C.POINTER(_p), _i64, _i64, _i32, _i64, _p, _p, _p, _i32, _u32, _p]),
+    "mrgcn_plan_create_hinted": (C.c_int, [C.POINTER(_p), _i64, _i64, _i32, _i64, _p, _p, _p, _i32, _u32, _p, _i32, _p]),
+    "mrgcn_plan_create_csr_hinted": (C.c_int, [C.POINTER(_p), _i64, _i64, _i32, _i64, _p, _p, _p, _i32, _u32, _p, _i32,
+                                               _p]),
     "mrgcn_plan_destroy": (C.c_int, [_p]),
     "mrgcn_plan_info": (C.c_int, [_p, C.POINTER(PlanInfo)]),
     "mrgcn_plan_export": (C.c_int, [_p, _i32, _p, _i64]),
@@ -130,7 +134,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.mrgcn_abi_version() != 1:
+    if lib.mrgcn_abi_version() != ABI_VERSION:
         raise MrgcnError("libmrgcn_hip.so ABI version mismatch")
     _lib = lib
     return lib

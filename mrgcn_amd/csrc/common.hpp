@@ -39,6 +39,10 @@ constexpr int kWsFeatures = 256;   // split-row workspace is sized for this many
 constexpr int kShort3Rows = 8;
 constexpr int kMid3Rows = 32;
 constexpr int kChunk3Entries = 128;
+// class S / M rows ordered by length inside windows of this many row ids (0 = plain id order, the default: measured
+// neutral to -1 % on the AM shape — the masked filler gathers of mixed-length waves cost nothing)
+constexpr int kLenWindowS = 0;
+constexpr int kLenWindowM = 0;
 constexpr int kChunk3Cap = 64;  // chunks per row at most: longer rows get chunks of several pieces of 128
 constexpr int kHotMinRefs = 16;    // columns read by >= this many rows go to the dense hot region of M
 constexpr int kNodeBand = 131072;  // source nodes per band of the transform order (see plan.hip)
@@ -154,6 +158,10 @@ struct mrgcn_plan {
   int32_t *r3_multi = nullptr;  // [r3_n_multi] positions in r3_long_row of the rows that span several chunks
   int32_t r3_n_multi = 0;       // (k_spmm3_finalize runs over these only)
   int32_t *r3_ticket = nullptr;  // [r3_n_long] arrival counters of the in-kernel finalize (zero between launches)
+  // k_spmm3's one-wave rows (kMid3Rows < len <= kChunk3Entries); r3_* above describe the longer, blockwise rows
+  int32_t *r3s_long_row = nullptr, *r3s_long_cptr = nullptr, *r3s_chunk_beg = nullptr, *r3s_chunk_end = nullptr,
+          *r3s_chunk_row = nullptr;
+  int32_t r3s_n_chunks = 0;
   float *partials = nullptr;  // [max(r_n_chunks, c_n_chunks) * kWsFeatures]
 
   mrgcn::SparseView view(int which) const {

@@ -216,13 +216,17 @@ __global__ void k_fill_i32(int32_t *__restrict__ a, int64_t n, int32_t v) {
 // of <= kMid3Rows, then the long ones, each class in row order.  Rows of different classes are served by
 // different waves (k_spmm3), so with this order no two classes share a line of the index / value arrays or
 // of the operand's first-touch region.  key = class * rows + row; sorting gives rank -> row.
-__global__ void k_class_keys(const int32_t *__restrict__ ptr, int64_t rows, int s_max, int m_max,
-                             int64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+__global__ void k_class_keys(const int32_t *__restrict__ ptr, int64_t rows, int s_max, int m_max, int64_t win_s,
+                             int64_t win_m, int64_t cstride, int64_t *__restrict__ keys, int32_t *__restrict__ ids) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   const int32_t n = ptr[i + 1] - ptr[i];
   const int64_t cls = n <= s_max ? 0 : (n <= m_max ? 1 : 2);
-  keys[i] = cls * rows + i;
+  // inside a class: windows of consecutive row ids, rows of a window by length (S and M: a wave's rows then need the
+  // same number of gather rounds and none of its gathers is a masked filler), then by id
+  const int64_t win = cls == 0 ? win_s : (cls == 1 ? win_m : 0);
+  const int64_t sub = win > 0 ? (i / win) * 64 + n : 0;
+  keys[i] = cls * cstride + sub * rows + i;
   ids[i] = (int32_t)i;
 }
 __global__ void k_rank_len(const int32_t *__restrict__ ptr, const int32_t *__restrict__ rowmap, int64_t rows,
@@ -276,38 +280,61 @@ __device__ __forceinline__ int32_t row_chunk(int32_t len, int chunk, int cap) {
   return n <= cap ? chunk : chunk * ((n + cap - 1) / cap);
 }
 
-__global__ void k_long_count(const int32_t *__restrict__ ptr, int64_t rows, int thresh, int chunk, int cap,
-                             int32_t *__restrict__ is_long, int32_t *__restrict__ nchunk,
+// blockwise rows (k_spmm3's rows of more than kChunk3Entries entries): a row is cut into 4 * nb chunks — nb blocks
+// of four waves, at most `cap` / 4 blocks — of equal size (a multiple of 16 entries, the last ones may be empty)
+__device__ __forceinline__ int32_t row_blocks(int32_t len, int chunk, int cap) {
+  const int32_t nb = (len + 4 * chunk - 1) / (4 * chunk);
+  return nb < 1 ? 1 : (nb > cap / 4 ? cap / 4 : nb);
+}
+__device__ __forceinline__ int32_t row_chunk_blockwise(int32_t len, int chunk, int cap) {
+  const int32_t nc = 4 * row_blocks(len, chunk, cap);
+  return ((len + nc - 1) / nc + 15) / 16 * 16;
+}
+
+// rows of thresh < len (<= upper when upper > 0) are "long"
+__global__ void k_long_count(const int32_t *__restrict__ ptr, int64_t rows, int thresh, int upper, int chunk, int cap,
+                             int blockwise, int32_t *__restrict__ is_long, int32_t *__restrict__ nchunk,
                              int32_t *__restrict__ maxlen) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   int32_t len = ptr[i + 1] - ptr[i];
-  int32_t lg = len > thresh;
+  int32_t lg = len > thresh && (upper <= 0 || len <= upper);
   is_long[i] = lg;
-  const int32_t rc = row_chunk(len, chunk, cap);
-  nchunk[i] = lg ? (len + rc - 1) / rc : 0;
+  if (blockwise) {
+    nchunk[i] = lg ? 4 * row_blocks(len, chunk, cap) : 0;
+  } else {
+    const int32_t rc = row_chunk(len, chunk, cap);
+    nchunk[i] = lg ? (len + rc - 1) / rc : 0;
+  }
   atomicMax(maxlen, len);
 }
 
-__global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int chunk0, int cap,
+__global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int chunk0, int cap, int blockwise,
                             const int32_t *__restrict__ is_long, const int32_t *__restrict__ long_pos,
                             const int32_t *__restrict__ chunk_pos, int32_t *__restrict__ long_row,
                             int32_t *__restrict__ long_cptr, int32_t *__restrict__ chunk_beg,
-                            int32_t *__restrict__ chunk_end, int32_t *__restrict__ chunk_row,
-                            int neg_long_pos) {
+                            int32_t *__restrict__ chunk_end, int32_t *__restrict__ chunk_row) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows || !is_long[i]) return;
   int32_t li = long_pos[i], c0 = chunk_pos[i];
   long_row[li] = (int32_t)i;
   long_cptr[li] = c0;
   int32_t b = ptr[i], e = ptr[i + 1];
+  if (blockwise) {  // every chunk names its row by position: chunk_row = -(li + 2)
+    const int32_t nc = 4 * row_blocks(e - b, chunk0, cap), rc = row_chunk_blockwise(e - b, chunk0, cap);
+    for (int32_t j = 0; j < nc; ++j) {
+      const int32_t s = min(b + j * rc, e);
+      chunk_beg[c0 + j] = s;
+      chunk_end[c0 + j] = min(s + rc, e);
+      chunk_row[c0 + j] = -(li + 2);
+    }
+    return;
+  }
   const int32_t chunk = row_chunk(e - b, chunk0, cap);
   for (int32_t s = b, c = c0; s < e; s += chunk, ++c) {
     chunk_beg[c] = s;
     chunk_end[c] = min(s + chunk, e);
-    // < 0: one of several chunks of row -x - 2 (neg_long_pos: of the long row at position -x - 2 of long_row — what
-    // the in-kernel finalize of k_spmm3 needs: its ticket and its chunk range)
-    chunk_row[c] = (e - b <= chunk) ? (int32_t)i : -((neg_long_pos ? li : (int32_t)i) + 2);
+    chunk_row[c] = (e - b <= chunk) ? (int32_t)i : -((int32_t)i + 2);  // < 0: one of several chunks of row -x - 2
   }
 }
 
@@ -330,41 +357,40 @@ hipError_t pool_alloc(void **p, size_t bytes, hipStream_t s) {
   return hipMallocAsync(p, bytes, s);
 }
 
-// Operand rows of 48 bytes (ld = 12: the F = 10 / 11 / 12 layers) straddle a 128-byte line at two of every eight
-// positions (p % 8 in {2, 5}).  A column read by ONE row sits in that row's sequential run, where the second line
-// is fetched anyway; a column with several readers pays both lines on every re-read.  Inside each aligned group
-// of eight positions the re-read columns therefore trade places with single-reader ones until none of them sits
-// on a straddling slot (the group stays the same three lines; other row sizes: a harmless local permutation).
-__global__ void k_avoid_straddle(int32_t *__restrict__ order, const int32_t *__restrict__ cptr, int64_t ncols) {
+// An operand row that straddles a 128-byte line costs a re-reading row two line fetches instead of one.  A column read
+// by ONE row sits in that row's sequential run, where the second line is fetched anyway; so inside each aligned group
+// of 32 positions (4F-byte rows repeat their alignment every 32 rows at most) the columns with several readers trade
+// places with single-reader ones until none of them sits on a straddling slot — for every row size in `row_bytes`
+// (the operand layouts the plan's users announced: 48 = rows of 10..12 floats padded to 16 bytes, the default;
+// 40 / 44 = packed rows of 10 / 11 floats).  In order: straddling multi-reader slots ascending, each takes the next
+// free straddle-free single-reader slot.  A ragged last group stays as it is.
+struct StraddleSizes { int32_t n; int32_t bytes[4]; };
+__global__ void k_avoid_straddle(int32_t *__restrict__ order, const int32_t *__restrict__ cptr, int64_t ncols,
+                                 StraddleSizes sz, const int32_t *__restrict__ n_hot_d) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t p0 = g * 8;
-  if (p0 + 8 > ncols) return;  // (a ragged last group stays as it is)
-  int32_t c[8];
-  bool multi[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    c[i] = order[p0 + i];
-    multi[i] = cptr[c[i] + 1] - cptr[c[i]] > 1;
-  }
-  bool changed = false;
-#pragma unroll
-  for (int si = 0; si < 2; ++si) {
-    const int sl = si == 0 ? 2 : 5;
-    if (!multi[sl]) continue;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (i == 2 || i == 5 || multi[i] || !multi[sl]) continue;
-      const int32_t t = c[sl];
-      c[sl] = c[i];
-      c[i] = t;
-      multi[sl] = false;
-      multi[i] = true;
-      changed = true;
+  const int64_t p0 = g * 32;
+  if (p0 + 32 > ncols) return;
+  // the group that holds the end of the hot region stays as it is: positions below n_hot are hot columns, the
+  // replica path classifies by position
+  const int64_t n_hot = n_hot_d[1];
+  if (p0 < n_hot && p0 + 32 > n_hot) return;
+  uint32_t bad = 0, multi = 0;
+  for (int i = 0; i < 32; ++i) {
+    for (int k = 0; k < sz.n; ++k) {
+      const int64_t lo = (p0 + i) * sz.bytes[k], hi = lo + sz.bytes[k] - 1;
+      if ((lo >> 7) != (hi >> 7)) bad |= 1u << i;
     }
+    const int32_t c = order[p0 + i];
+    if (cptr[c + 1] - cptr[c] > 1) multi |= 1u << i;
   }
-  if (changed) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) order[p0 + i] = c[i];
+  uint32_t todo = bad & multi, free_slots = ~bad & ~multi;
+  while (todo && free_slots) {
+    const int i = __ffs(todo) - 1, j = __ffs(free_slots) - 1;
+    todo &= todo - 1;
+    free_slots &= free_slots - 1;
+    const int32_t t = order[p0 + i];
+    order[p0 + i] = order[p0 + j];
+    order[p0 + j] = t;
   }
 }
 
@@ -400,7 +426,7 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
                int32_t **long_cptr, int32_t **chunk_beg, int32_t **chunk_end, int32_t **chunk_row,
                int32_t *n_long,
                int32_t *n_chunks, int64_t *max_len, int threshold = kLongThreshold, int chunk = kChunk,
-               int cap = 0, int neg_long_pos = 0) {
+               int cap = 0, int upper = 0, int blockwise = 0) {
   Scratch sc;
   sc.s = s;
   int32_t *is_long, *nchunk, *long_pos, *chunk_pos, *d_max;
@@ -413,7 +439,7 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(hipMemsetAsync(is_long, 0, (rows + 1) * sizeof(int32_t), s));
   MRGCN_HIP_TRY(hipMemsetAsync(nchunk, 0, (rows + 1) * sizeof(int32_t), s));
   if (rows > 0)
-    k_long_count<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, threshold, chunk, cap, is_long, nchunk, d_max);
+    k_long_count<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, threshold, upper, chunk, cap, blockwise, is_long, nchunk, d_max);
   // scan over rows+1 elements so that position [rows] holds the totals
   int rc;
   if ((rc = exclusive_scan_i32(is_long, long_pos, rows + 1, s, sc))) return rc;
@@ -433,18 +459,18 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(plan_alloc(p, chunk_row, h[1]));
   MRGCN_HIP_TRY(hipMemcpyAsync(*long_cptr + h[0], &h[1], sizeof(int32_t), hipMemcpyHostToDevice, s));
   if (rows > 0 && h[0] > 0)
-    k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, chunk, cap, is_long, long_pos, chunk_pos,
-                                              *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row,
-                                              neg_long_pos);
+    k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, chunk, cap, blockwise, is_long, long_pos, chunk_pos,
+                                              *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row);
   MRGCN_HIP_TRY(hipGetLastError());
   MRGCN_HIP_TRY(hipStreamSynchronize(s));
   return MRGCN_OK;
 }
 
 // long rows of several chunks: flag, (scan), positions
-__global__ void k_multi_flag(const int32_t *__restrict__ long_cptr, int64_t n_long, int32_t *__restrict__ flag) {
+__global__ void k_multi_flag(const int32_t *__restrict__ long_cptr, int64_t n_long, int more_than,
+                             int32_t *__restrict__ flag) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_long) flag[i] = long_cptr[i + 1] - long_cptr[i] > 1 ? 1 : 0;
+  if (i < n_long) flag[i] = long_cptr[i + 1] - long_cptr[i] > more_than ? 1 : 0;
   if (i == n_long) flag[i] = 0;
 }
 __global__ void k_multi_fill(const int32_t *__restrict__ flag, const int32_t *__restrict__ pos, int64_t n_long,
@@ -460,7 +486,7 @@ int bits_for(int64_t max_value) {
 }
 
 int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_t *cols,
-                const void *vals, int val_dtype, uint32_t flags, hipStream_t s) {
+                const void *vals, int val_dtype, uint32_t flags, hipStream_t s, const StraddleSizes &hint) {
   const int64_t N = p->num_nodes, R = p->num_relations, RN = R * N;
   static const bool rep_default = getenv("MRGCN_REPLICATE") && atoi(getenv("MRGCN_REPLICATE")) != 0;
   const bool replicate = !(flags & MRGCN_PLAN_NO_REPLICATE) && ((flags & MRGCN_PLAN_REPLICATE) || rep_default);
@@ -669,11 +695,17 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     MRGCN_HIP_TRY(sc.alloc(&ids, rows));
     MRGCN_HIP_TRY(sc.alloc(&len3, rows + 1));
     MRGCN_HIP_TRY(sc.alloc(&cls_ptr, 4));
+    // length-sorted windows inside the S and M classes (kLenWindowS / kLenWindowM row ids; 0 = plain id order)
+    static const int64_t win_s = getenv("MRGCN_LEN_WINDOW_S") ? atoll(getenv("MRGCN_LEN_WINDOW_S")) : kLenWindowS;
+    static const int64_t win_m = getenv("MRGCN_LEN_WINDOW_M") ? atoll(getenv("MRGCN_LEN_WINDOW_M")) : kLenWindowM;
+    const int64_t wmin = std::min(win_s > 0 ? win_s : rows + 1, win_m > 0 ? win_m : rows + 1);
+    const int64_t cstride = ((rows + wmin - 1) / wmin + 1) * 64 * std::max<int64_t>(rows, 1);
     if (rows > 0) {
-      k_class_keys<<<nblocks(rows), kTB, 0, s>>>(p->rowptr, rows, kShort3Rows, kMid3Rows, ck, ids);
+      k_class_keys<<<nblocks(rows), kTB, 0, s>>>(p->rowptr, rows, kShort3Rows, kMid3Rows, win_s, win_m, cstride, ck, ids);
       MRGCN_HIP_TRY(hipGetLastError());
       size_t tb = 0;
-      const int eb = bits_for(3 * rows + rows);
+      const int eb = bits_for(3 * cstride + cstride);
+      MRGCN_REQUIRE(eb <= 62, "graph too large for the row-order key");
       MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ck, ck_s, ids, p->rowmap, (int)rows, 0, eb, s));
       char *tmp;
       MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
@@ -681,7 +713,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
       k_invert_perm<<<nblocks(rows), kTB, 0, s>>>(p->rowmap, rows, rank3);
       MRGCN_HIP_TRY(hipGetLastError());
     }
-    k_lower_bound_ptr<<<1, kTB, 0, s>>>(ck_s, rows, 3, rows, cls_ptr);  // first rank of each class
+    k_lower_bound_ptr<<<1, kTB, 0, s>>>(ck_s, rows, 3, cstride, cls_ptr);  // first rank of each class
     k_rank_len<<<nblocks(rows + 1), kTB, 0, s>>>(p->rowptr, p->rowmap, rows, len3);
     MRGCN_HIP_TRY(hipGetLastError());
     int rc2;
@@ -698,7 +730,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   MRGCN_HIP_TRY(plan_alloc(p, &p->mval, nnz));
   if (ncols > 0) {
     int64_t *mk, *mk_s;
-    int32_t *ids, *order;
+    int32_t *ids, *order, *n_hot_d = nullptr;
     MRGCN_HIP_TRY(sc.alloc(&mk, ncols));
     MRGCN_HIP_TRY(sc.alloc(&mk_s, ncols));
     MRGCN_HIP_TRY(sc.alloc(&ids, ncols));
@@ -720,7 +752,20 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
                                                      end_bit, s));
     {
       static const bool swap_on = !(getenv("MRGCN_AVOID_STRADDLE") && atoi(getenv("MRGCN_AVOID_STRADDLE")) == 0);
-      if (swap_on && ncols >= 8) k_avoid_straddle<<<nblocks(ncols / 8), kTB, 0, s>>>(order, p->cptr, ncols);
+      StraddleSizes sz = hint;
+      if (const char *e = getenv("MRGCN_STRADDLE_ROW_BYTES")) {  // experiments: "40,44"
+        sz.n = 0;
+        for (const char *q = e; *q && sz.n < 4;) {
+          sz.bytes[sz.n++] = atoi(q);
+          while (*q && *q != ',') ++q;
+          if (*q == ',') ++q;
+        }
+      }
+      // hot columns are the sorted keys below max_count << shift
+      MRGCN_HIP_TRY(sc.alloc(&n_hot_d, 2));
+      k_lower_bound_ptr<<<1, kTB, 0, s>>>(mk_s, ncols, 1, max_count << shift, n_hot_d);
+      if (swap_on && ncols >= 32)
+        k_avoid_straddle<<<nblocks(ncols / 32), kTB, 0, s>>>(order, p->cptr, ncols, sz, n_hot_d);
     }
     k_invert_perm<<<nblocks(ncols), kTB, 0, s>>>(order, ncols, p->mpos);
     MRGCN_HIP_TRY(hipGetLastError());
@@ -752,16 +797,13 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     p->n_op = ncols;
     if (replicate && hot_min > 1) {
       // every entry of a non-hot column gets its own operand row, in processing order
-      int32_t *n_hot_d, *flag, *spos, *ecol, *mpos_new, *rflag, *rpos;
-      MRGCN_HIP_TRY(sc.alloc(&n_hot_d, 2));
+      int32_t *flag, *spos, *ecol, *mpos_new, *rflag, *rpos;
       MRGCN_HIP_TRY(sc.alloc(&flag, nnz + 1));
       MRGCN_HIP_TRY(sc.alloc(&spos, nnz + 1));
       MRGCN_HIP_TRY(sc.alloc(&ecol, nnz));
       MRGCN_HIP_TRY(sc.alloc(&mpos_new, ncols));
       MRGCN_HIP_TRY(sc.alloc(&rflag, nnz + 1));
       MRGCN_HIP_TRY(sc.alloc(&rpos, nnz + 1));
-      // hot columns are the sorted keys below max_count << shift
-      k_lower_bound_ptr<<<1, kTB, 0, s>>>(mk_s, ncols, 1, max_count << shift, n_hot_d);
       int32_t h2[2] = {0, 0};
       MRGCN_HIP_TRY(hipMemcpyAsync(h2, n_hot_d, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
       MRGCN_HIP_TRY(hipStreamSynchronize(s));
@@ -807,21 +849,30 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     if ((rc = build_long(p, p->ptr3, p->num_rows, s, &p->q_long_row, &p->q_long_cptr, &p->q_chunk_beg,
                          &p->q_chunk_end, &p->q_chunk_row, &p->q_n_long, &p->q_n_chunks, &dummy)))
       return rc;
-    if ((rc = build_long(p, p->ptr3, p->num_rows, s, &p->r3_long_row, &p->r3_long_cptr, &p->r3_chunk_beg,
-                         &p->r3_chunk_end, &p->r3_chunk_row, &p->r3_n_long, &p->r3_n_chunks, &dummy, kMid3Rows,
-                         kChunk3Entries, kChunk3Cap, 1)))
+    // k_spmm3: rows of kMid3Rows < len <= kChunk3Entries are one chunk = one wave each (r3s_*); longer rows are cut
+    // blockwise (r3_*: 4 * nb equal chunks, a block of four waves adds its four sums in LDS)
+    int32_t *lr = nullptr, *lc = nullptr;
+    int32_t nl = 0;
+    if ((rc = build_long(p, p->ptr3, p->num_rows, s, &lr, &lc, &p->r3s_chunk_beg, &p->r3s_chunk_end,
+                         &p->r3s_chunk_row, &nl, &p->r3s_n_chunks, &dummy, kMid3Rows, kChunk3Entries, 0,
+                         kChunk3Entries, 0)))
       return rc;
-    // one arrival counter per long row (k_spmm3: the wave that brings a row's last partial sum adds them up);
+    p->r3s_long_row = lr; p->r3s_long_cptr = lc;
+    if ((rc = build_long(p, p->ptr3, p->num_rows, s, &p->r3_long_row, &p->r3_long_cptr, &p->r3_chunk_beg,
+                         &p->r3_chunk_end, &p->r3_chunk_row, &p->r3_n_long, &p->r3_n_chunks, &dummy, kChunk3Entries,
+                         kChunk3Entries, kChunk3Cap, 0, 1)))
+      return rc;
+    // one arrival counter per blockwise row (k_spmm3: the block that brings a row's last partial sum adds them up);
     // zero between launches — the last arriver puts its row's counter back
     MRGCN_HIP_TRY(plan_alloc(p, &p->r3_ticket, p->r3_n_long));
     MRGCN_HIP_TRY(hipMemsetAsync(p->r3_ticket, 0, (size_t)std::max<int64_t>(p->r3_n_long, 1) * sizeof(int32_t), s));
   }
-  {  // the rows k_spmm3 leaves partial sums of: the finalize pass launches one wave for each of these, not for each long row
+  {  // the rows k_spmm3 leaves partial sums of (more than one block): the two-pass form's finalize launches one wave for each
     const int64_t nl = p->r3_n_long;
     int32_t *flag, *pos;
     MRGCN_HIP_TRY(sc.alloc(&flag, nl + 1));
     MRGCN_HIP_TRY(sc.alloc(&pos, nl + 1));
-    k_multi_flag<<<nblocks(nl + 1), kTB, 0, s>>>(p->r3_long_cptr, nl, flag);
+    k_multi_flag<<<nblocks(nl + 1), kTB, 0, s>>>(p->r3_long_cptr, nl, 4, flag);
     MRGCN_HIP_TRY(hipGetLastError());
     int rc2;
     if ((rc2 = exclusive_scan_i32(flag, pos, nl + 1, s, sc))) return rc2;
@@ -847,7 +898,8 @@ void free_plan(mrgcn_plan *p) {
                   p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->r_chunk_row, p->c_chunk_row,
                   p->r3_long_row, p->r3_long_cptr, p->r3_chunk_beg, p->r3_chunk_end, p->r3_chunk_row,
                   p->q_long_row, p->q_long_cptr, p->q_chunk_beg, p->q_chunk_end, p->q_chunk_row, p->rowmap, p->ptr3,
-                  p->rep_src, p->rep_dst, p->partials, p->r3_multi, p->r3_ticket};
+                  p->rep_src, p->rep_dst, p->partials, p->r3_multi, p->r3_ticket,
+                  p->r3s_long_row, p->r3s_long_cptr, p->r3s_chunk_beg, p->r3s_chunk_end, p->r3s_chunk_row};
   // the caller guarantees nothing that uses the plan is still to be SUBMITTED; work already in flight on any
   // stream is waited for (what hipFree did implicitly), then the blocks go back to the pool
   (void)hipDeviceSynchronize();
@@ -865,9 +917,26 @@ int mrgcn_abi_version(void) { return MRGCN_ABI_VERSION; }
 const char *mrgcn_arch(void) { return "gfx950"; }
 const char *mrgcn_last_error(void) { return mrgcn::g_last_error.c_str(); }
 
-int mrgcn_plan_create(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, int32_t num_relations,
-                      int64_t nnz, const int64_t *coo_rows, const int64_t *coo_cols, const void *coo_vals,
-                      int32_t val_dtype, uint32_t flags, void *stream) {
+static int straddle_hint(const int32_t *row_bytes, int32_t n, mrgcn::StraddleSizes *out) {
+  // no hint: rows of 10..12 floats padded to 48 bytes, the layout of the F = 10 / 11 layers before packed rows
+  mrgcn::StraddleSizes sz{1, {48, 0, 0, 0}};
+  if (n > 0) {
+    MRGCN_REQUIRE(row_bytes != nullptr, "operand_row_bytes is NULL");
+    sz.n = 0;
+    for (int32_t i = 0; i < n && sz.n < 4; ++i) {
+      MRGCN_REQUIRE(row_bytes[i] > 0 && row_bytes[i] % 2 == 0, "operand_row_bytes: positive, even");
+      if (row_bytes[i] % 128 == 0 || 128 % row_bytes[i] == 0) continue;  // such rows never straddle a line
+      sz.bytes[sz.n++] = row_bytes[i];
+    }
+  }
+  *out = sz;
+  return MRGCN_OK;
+}
+
+int mrgcn_plan_create_hinted(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, int32_t num_relations,
+                             int64_t nnz, const int64_t *coo_rows, const int64_t *coo_cols, const void *coo_vals,
+                             int32_t val_dtype, uint32_t flags, const int32_t *operand_row_bytes,
+                             int32_t n_row_bytes, void *stream) {
   MRGCN_REQUIRE(plan != nullptr, "plan is NULL");
   *plan = nullptr;
   MRGCN_REQUIRE(num_rows >= 0 && num_nodes > 0 && num_relations > 0, "bad shape");
@@ -877,13 +946,16 @@ int mrgcn_plan_create(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, 
   MRGCN_REQUIRE(num_rows < (int64_t)INT32_MAX, "num_rows must be < 2^31");
   MRGCN_REQUIRE(val_dtype == MRGCN_VAL_I8 || val_dtype == MRGCN_VAL_F32, "val_dtype");
   MRGCN_REQUIRE(nnz == 0 || (coo_rows && coo_cols && coo_vals), "NULL COO array");
+  mrgcn::StraddleSizes hint;
+  int rc = straddle_hint(operand_row_bytes, n_row_bytes, &hint);
+  if (rc != MRGCN_OK) return rc;
   mrgcn_plan *p = new mrgcn_plan();
   p->num_rows = num_rows;
   p->num_nodes = num_nodes;
   p->num_relations = num_relations;
   (void)hipGetDevice(&p->device);
   p->build_stream = (hipStream_t)stream;
-  int rc = mrgcn::create_impl(p, nnz, coo_rows, coo_cols, coo_vals, val_dtype, flags, (hipStream_t)stream);
+  rc = mrgcn::create_impl(p, nnz, coo_rows, coo_cols, coo_vals, val_dtype, flags, (hipStream_t)stream, hint);
   if (rc != MRGCN_OK) {
     mrgcn::free_plan(p);
     return rc;
@@ -892,9 +964,17 @@ int mrgcn_plan_create(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, 
   return MRGCN_OK;
 }
 
-int mrgcn_plan_create_csr(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, int32_t num_relations,
-                          int64_t nnz, const int32_t *indptr, const int32_t *indices, const float *data,
-                          int32_t boundary_cast_i8, uint32_t flags, void *stream) {
+int mrgcn_plan_create(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, int32_t num_relations,
+                      int64_t nnz, const int64_t *coo_rows, const int64_t *coo_cols, const void *coo_vals,
+                      int32_t val_dtype, uint32_t flags, void *stream) {
+  return mrgcn_plan_create_hinted(plan, num_rows, num_nodes, num_relations, nnz, coo_rows, coo_cols, coo_vals,
+                                  val_dtype, flags, nullptr, 0, stream);
+}
+
+int mrgcn_plan_create_csr_hinted(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, int32_t num_relations,
+                                 int64_t nnz, const int32_t *indptr, const int32_t *indices, const float *data,
+                                 int32_t boundary_cast_i8, uint32_t flags, const int32_t *operand_row_bytes,
+                                 int32_t n_row_bytes, void *stream) {
   MRGCN_REQUIRE(plan != nullptr, "plan is NULL");
   *plan = nullptr;
   MRGCN_REQUIRE(nnz >= 0 && nnz < (int64_t)INT32_MAX, "nnz must be < 2^31");
@@ -915,13 +995,20 @@ int mrgcn_plan_create_csr(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nod
     if (nnz > 0)
       mrgcn::k_csr_to_coo<<<mrgcn::nblocks(nnz), mrgcn::kTB, 0, s>>>(indptr, indices, data, num_rows, nnz,
                                                                      boundary_cast_i8 ? 1 : 0, rows, cols, vals);
-    rc = mrgcn_plan_create(plan, num_rows, num_nodes, num_relations, nnz, rows, cols, vals, MRGCN_VAL_F32,
-                           flags, stream);
+    rc = mrgcn_plan_create_hinted(plan, num_rows, num_nodes, num_relations, nnz, rows, cols, vals, MRGCN_VAL_F32,
+                                  flags, operand_row_bytes, n_row_bytes, stream);
   }
   if (rows) (void)hipFreeAsync(rows, s);  // stream ordered: after the build's last read
   if (cols) (void)hipFreeAsync(cols, s);
   if (vals) (void)hipFreeAsync(vals, s);
   return rc;
+}
+
+int mrgcn_plan_create_csr(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes, int32_t num_relations,
+                          int64_t nnz, const int32_t *indptr, const int32_t *indices, const float *data,
+                          int32_t boundary_cast_i8, uint32_t flags, void *stream) {
+  return mrgcn_plan_create_csr_hinted(plan, num_rows, num_nodes, num_relations, nnz, indptr, indices, data,
+                                      boundary_cast_i8, flags, nullptr, 0, stream);
 }
 
 int mrgcn_plan_destroy(mrgcn_plan_t *plan) {

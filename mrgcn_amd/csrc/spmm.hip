@@ -369,9 +369,22 @@ struct View3 {  // what k_spmm3 needs beyond the COMPACT SparseView (whose rows 
   int32_t pad_ok = 0;                  // columns F..ldY-1 of Y belong to the caller's buffer and may be zeroed
   const int32_t *multi = nullptr;      // [n_multi_rows] positions in long_row of the rows of several chunks
   int32_t n_multi_rows = 0;
+  int32_t s_n = 0;                     // rows of one wave each (kMid3 < n <= kChunk3): first entry, end, rank
+  const int32_t *s_beg = nullptr, *s_end = nullptr, *s_row = nullptr;
   int32_t *ticket = nullptr;           // [n_long] arrival counters (zero between launches)
   int32_t fold = 0;                    // rows of several chunks are finished inside k_spmm3 by their last chunk's wave
 };
+
+// sum of a blockwise row's block sums, lane (k, f): x[u] = sum of block j0 + 4u (j0 = first block + k); blocks are
+// added in a fixed order — u first, then the butterfly over k — by k_spmm3's last arriver and by k_spmm3_finalize alike
+__device__ __forceinline__ float xl_row_sum(const float (&x)[4], int32_t j0, int32_t b1) {
+  float s = j0 < b1 ? x[0] : 0.f;
+#pragma unroll
+  for (int u = 1; u < 4; ++u) s += (j0 + 4 * u < b1) ? x[u] : 0.f;
+  s += __shfl_xor(s, 16, kWave);
+  s += __shfl_xor(s, 32, kWave);
+  return s;
+}
 
 // OFF32: gathers address the operand with 32-bit byte offsets (operand < 4 GB).  WPE: waves per SIMD the register
 // allocation must leave room for (7 at F = 10 / 16: 72 registers instead of 76, a seventh wave of gathers in flight
@@ -382,29 +395,50 @@ __global__ __launch_bounds__(256, WPE) void k_spmm3(SparseView v, View3 w, const
                                                int F, float *__restrict__ Y, int64_t ldY,
                                                const float *__restrict__ bias, int relu, int store_vec_ok,
                                                float *__restrict__ partials, int ldP, int chunk_blocks,
-                                               int mid_blocks, int64_t short_blocks, int64_t xcd_per) {
+                                               int single_blocks, int mid_blocks, int64_t short_blocks,
+                                               int64_t xcd_per, int pack) {
   constexpr int SLOTS = kWave / G;
   const int lane = threadIdx.x & (kWave - 1);
   const int slot = lane / G, q = lane % G;
   const int f0 = q * VEC;
   const bool active = f0 < F;
-  const DT *Dq = D + (active ? f0 : 0);  // idle feature lanes shadow lane 0 (always in bounds)
-  const int nvalid = active ? min(VEC, F - f0) : VEC;
-  const uint32_t ldb = (uint32_t)ldD * (uint32_t)sizeof(DT), qoff = (uint32_t)(active ? f0 : 0) * (uint32_t)sizeof(DT);
+  // pack: operand rows of exactly F floats (no pad, only dword aligned; F >= VEC).  Lane q loads the floats
+  // [lo, lo + VEC) with lo = min(f0, F - VEC): the row's last vector overlaps its neighbour's instead of reaching past
+  // the row (F = 10: bytes 0-15, 16-31, 24-39 of a 40-byte row) — every gather stays one 16-byte load inside its row.
+  // The sums are kept in the loaded layout and moved to the lane's own features (f0 ..) once, before they leave.
+  const int lo = pack ? min(f0, F - VEC) : f0;
+  const int shift = f0 - lo;
+  const DT *Dq = D + (active ? lo : 0);  // idle feature lanes shadow lane 0 (always in bounds)
+  const int nvalid = active ? (pack ? VEC : min(VEC, F - f0)) : VEC;
+  const uint32_t ldb = (uint32_t)ldD * (uint32_t)sizeof(DT), qoff = (uint32_t)(active ? lo : 0) * (uint32_t)sizeof(DT);
   float acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  auto unpack = [&]() {  // acc[i] <- the sum of feature f0 + i (zero past the row)
+    if (shift) {
+      float r[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        r[i] = 0.f;
+#pragma unroll
+        for (int j = 1; j < VEC; ++j)
+          if (shift == j && i + j < VEC) r[i] = acc[i + j];
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = r[i];
+    }
+  };
 
-  if ((int)blockIdx.x < chunk_blocks) {  // ---- L: one wave per chunk: pieces of <= kChunk3 entries, one batch each
-    const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // wave uniform: scalar loads below
-    if (c >= w.n_chunks) return;
+  if ((int)blockIdx.x < chunk_blocks) {  // ---- XL: a block = four equal chunks of ONE row of > kChunk3 entries
+    __shared__ float s_part[4][16];
+    const int wv = threadIdx.x >> 6;
+    const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);  // wave uniform: scalar loads below
     const int32_t cb = w.chunk_beg[c], ce = w.chunk_end[c];
-    const int32_t rk = w.chunk_row[c];           // >= 0: the rank of a row that is this one chunk; else -(li + 2)
-    const int32_t li = rk < 0 ? -rk - 2 : 0;     // position of the row among the long rows (unconditional loads)
+    const int32_t li = -w.chunk_row[c] - 2;     // position of the row among the blockwise rows
     const int32_t lc0 = w.long_cptr[li], lc1 = w.long_cptr[li + 1];
     constexpr int T = kChunk3 / kWave;
     constexpr int PER = kWave / SLOTS;  // = G gather rounds per staged register
-    for (int32_t b = cb; b < ce; b += kChunk3) {  // (rows of more than 64 * kChunk3 entries: several pieces)
+    for (int32_t b = cb; b < ce; b += kChunk3) {  // (chunks of more than kChunk3 entries: several pieces)
       const int32_t n = min(ce - b, kChunk3);
       int32_t ci[T];
       float ca[T];
@@ -429,69 +463,92 @@ __global__ __launch_bounds__(256, WPE) void k_spmm3(SparseView v, View3 w, const
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
     }
-    if (rk >= 0) {  // the whole row was this chunk: finished
-      if (slot == 0 && active)
-        store_row<VEC>(Y + (int64_t)w.rowmap[rk] * ldY, acc, f0, F, bias, relu, (store_vec_ok & 1) != 0, (store_vec_ok & 2) ? (int)ldY : 0);
-      return;
-    }
-    float *p = partials + (int64_t)c * ldP + f0;
-    if (!w.fold) {  // two-pass form: k_spmm3_finalize adds the partial sums
-      if (slot == 0 && active) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i)
-          if (f0 + i < F) p[i] = acc[i];
-      }
-      return;
-    }
-    // ---- in-kernel finalize: the wave that brings a row's LAST partial sum adds them all, in chunk order (the
-    // sums do not depend on which wave that is: bitwise reproducible).  Hand-off across CUs / XCDs
-    // (MI355X_MICROARCH.md, "inter-workgroup visibility"): partial sums leave as agent-scope (sc1, write-through)
-    // stores, the storing wave waits for them, then adds to the row's arrival counter with an agent-scope atomic;
-    // the wave whose add returns "all others were here" reads the partials back with agent-scope (sc1) loads,
-    // which bypass its CU's L1 — and puts the counter back to zero for the next launch.
+    // the block's four sums meet in LDS; wave 0 adds them in wave order
+    unpack();
     if (slot == 0 && active) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) __hip_atomic_store(p + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < VEC; ++i) s_part[wv][f0 + i] = acc[i];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int32_t old = 0;
-    if (lane == 0) old = __hip_atomic_fetch_add(w.ticket + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    old = __builtin_amdgcn_readfirstlane(old);
-    asm volatile("" ::: "memory");
-    if (old != lc1 - lc0 - 1) return;
-    {
-      const int f = lane & 15, k = lane >> 4;  // F <= 16: four chunks per step, at most kChunk3Cap = 64 per row
-      float sm[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int32_t cc = lc0 + k + 16 * u;
-        float x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // unconditional loads at clamped addresses: all sixteen in flight at once
-          const int32_t ck = min(cc + 4 * i, lc1 - 1);
-          x[i] = __hip_atomic_load(partials + (int64_t)ck * ldP + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sm[u] += (cc + 4 * i < lc1) ? x[i] : 0.f;
+    __syncthreads();
+    if (wv != 0) return;
+    const int f = lane & 15, k = lane >> 4;
+    float t = ((s_part[0][f] + s_part[1][f]) + s_part[2][f]) + s_part[3][f];
+    const int32_t b0 = lc0 >> 2, b1 = lc1 >> 2;  // the row's blocks (blockwise rows start on a multiple of four chunks)
+    if (b1 - b0 > 1) {
+      float *pp = partials + (int64_t)blockIdx.x * ldP + f;
+      if (!w.fold) {  // two-pass form: k_spmm3_finalize adds the blocks' sums
+        if (k == 0 && f < F) *pp = t;
+        return;
       }
-      float t = (sm[0] + sm[1]) + (sm[2] + sm[3]);  // fixed order, as k_spmm3_finalize
-      t += __shfl_xor(t, 16, kWave);
-      t += __shfl_xor(t, 32, kWave);
-      const int64_t orow = w.rowmap[w.long_row[li]];
-      if (k == 0 && f < F) {
-        if (bias) t += bias[f];
-        if (relu) t = fmaxf(t, 0.f);
-        Y[orow * ldY + f] = t;
-      } else if (k == 0 && w.pad_ok && f < ldY && f < (F + 3) / 4 * 4) {
-        Y[orow * ldY + f] = 0.f;
+      // ---- in-kernel finalize: the block that brings a row's LAST partial sum adds them all, in block order (the
+      // result does not depend on which block that is: bitwise reproducible).  Hand-off across CUs / XCDs
+      // (MI355X_MICROARCH.md, "inter-workgroup visibility"): the block's sum leaves as agent-scope (sc1,
+      // write-through) stores, the storing wave waits for them, then adds to the row's arrival counter with an
+      // agent-scope atomic; the wave whose add returns "all others were here" reads the sums back with
+      // agent-scope (sc1) loads, which bypass its CU's L1 — and puts the counter back to zero for the next launch.
+      if (k == 0 && f < F) __hip_atomic_store(pp, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int32_t old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(w.ticket + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      asm volatile("" ::: "memory");
+      if (old != b1 - b0 - 1) return;
+      float x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // unconditional loads at clamped addresses: all in flight at once
+        const int32_t j = min(b0 + k + 4 * u, b1 - 1);
+        x[u] = __hip_atomic_load(partials + (int64_t)j * ldP + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      t = xl_row_sum(x, b0 + k, b1);
       if (lane == 0) __hip_atomic_store(w.ticket + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int64_t orow = w.rowmap[w.long_row[li]];
+    if (k == 0 && f < F) {
+      if (bias) t += bias[f];
+      if (relu) t = fmaxf(t, 0.f);
+      Y[orow * ldY + f] = t;
+    } else if (k == 0 && w.pad_ok && f < ldY && f < (F + 3) / 4 * 4) {
+      Y[orow * ldY + f] = 0.f;
     }
     return;
   }
-  if ((int)blockIdx.x < chunk_blocks + mid_blocks) {  // ---- M: four rows per wave, 16 lanes each
+  if ((int)blockIdx.x < chunk_blocks + single_blocks) {  // ---- L: rows of kMid3 < n <= kChunk3 entries, one wave each
+    const int c = __builtin_amdgcn_readfirstlane((blockIdx.x - chunk_blocks) * 4 + (threadIdx.x >> 6));
+    if (c >= w.s_n) return;
+    const int32_t b = w.s_beg[c], n = w.s_end[c] - b;
+    const int32_t rk = w.s_row[c];
+    constexpr int T = kChunk3 / kWave;
+    constexpr int PER = kWave / SLOTS;
+    int32_t ci[T];
+    float ca[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int32_t m = t * kWave + lane;
+      ci[t] = (m < n) ? v.idx[b + m] : 0;
+      ca[t] = (m < n) ? v.val[b + m] : 0.f;
+    }
+    const int nr = __builtin_amdgcn_readfirstlane((n + SLOTS - 1) / SLOTS);
+    gather_rounds<VEC, TAIL, DT, OFF32>(
+        nr, Dq, ldD, active, nvalid, acc,
+        [&](int t, int32_t &cc, float &aa) {
+          const int src = (t % PER) * SLOTS + slot;
+          cc = __shfl(ci[t / PER], src, kWave);
+          aa = __shfl(ca[t / PER], src, kWave);
+        },
+        [&](int t) { return t * SLOTS + slot < n; }, D, ldb, qoff);
+#pragma unroll
+    for (int off = G; off < kWave; off <<= 1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
+    }
+    unpack();
+    if (slot == 0 && active)
+      store_row<VEC>(Y + (int64_t)w.rowmap[rk] * ldY, acc, f0, F, bias, relu, (store_vec_ok & 1) != 0, (store_vec_ok & 2) ? (int)ldY : 0);
+    return;
+  }
+  if ((int)blockIdx.x < chunk_blocks + single_blocks + mid_blocks) {  // ---- M: four rows per wave, 16 lanes each
     constexpr int SS = 16 / G;                          // sub-slots per row
-    const int wv = (blockIdx.x - chunk_blocks) * 4 + (threadIdx.x >> 6);
+    const int wv = (blockIdx.x - chunk_blocks - single_blocks) * 4 + (threadIdx.x >> 6);
     const int rsel = lane >> 4, l16 = lane & 15, ss = slot % SS;
     const int mi = wv * 4 + rsel;
     int32_t b = 0, n = 0, row = -1;
@@ -529,12 +586,13 @@ __global__ __launch_bounds__(256, WPE) void k_spmm3(SparseView v, View3 w, const
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
     }
+    unpack();
     if (ss == 0 && row >= 0 && active) store_row<VEC>(Y + (int64_t)row * ldY, acc, f0, F, bias, relu, (store_vec_ok & 1) != 0, (store_vec_ok & 2) ? (int)ldY : 0);
     return;
   }
   // ---- S: 64/G consecutive ranks per wave, all of them rows of <= kShort3 entries
   // blocks b and b+8 share an XCD (round-robin dispatch): every XCD gets one contiguous run of ranks
-  int64_t sb = (int64_t)blockIdx.x - chunk_blocks - mid_blocks;
+  int64_t sb = (int64_t)blockIdx.x - chunk_blocks - single_blocks - mid_blocks;
   if (xcd_per > 0) {
     sb = (sb & 7) * xcd_per + (sb >> 3);
     if (sb >= short_blocks) return;
@@ -570,33 +628,24 @@ __global__ __launch_bounds__(256, WPE) void k_spmm3(SparseView v, View3 w, const
         aa = __shfl(ca[t / G], sbase + (t % G), kWave);
       },
       [&](int t) { return t < n; }, D, ldb, qoff);
+  unpack();
   if (mine && active) store_row<VEC>(Y + row * ldY, acc, f0, F, bias, relu, (store_vec_ok & 1) != 0, (store_vec_ok & 2) ? (int)ldY : 0);
 }
 
-// rows of several chunks: one wave per long row; lane = (chunk mod 64/FP, feature), eight partials in flight
+// two-pass form: rows of several blocks — one wave per row adds the blocks' sums exactly as the last arriver would
 __global__ __launch_bounds__(256) void k_spmm3_finalize(View3 w, const float *__restrict__ partials, int ldP, int F,
                                                         float *__restrict__ Y, int64_t ldY,
                                                         const float *__restrict__ bias, int relu) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t wi = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   if (wi >= w.n_multi_rows) return;
-  const int64_t li = w.multi[wi];  // (single-chunk rows were stored by their chunk's wave: they are not in the list)
-  const int32_t c0 = w.long_cptr[li], c1 = w.long_cptr[li + 1];
-  const int f = lane & 15, k = lane >> 4;  // F <= 16 here: four chunks per step, at most kChunk3Cap = 64 per row
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t li = w.multi[wi];  // (rows of one block were stored by that block: they are not in the list)
+  const int32_t b0 = w.long_cptr[li] >> 2, b1 = w.long_cptr[li + 1] >> 2;
+  const int f = lane & 15, k = lane >> 4;  // F <= 16 here; at most kChunk3Cap / 4 = 16 blocks per row
+  float x[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {  // all loads of a lane in flight at once
-    const int32_t c = c0 + k + 16 * u;
-    float x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = (c + 4 * i < c1) ? partials[(int64_t)(c + 4 * i) * ldP + f] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s[u] += x[i];
-  }
-  // fixed order: (k = 0..3) joined by the butterfly
-  float t = (s[0] + s[1]) + (s[2] + s[3]);
-  t += __shfl_xor(t, 16, kWave);
-  t += __shfl_xor(t, 32, kWave);
+  for (int u = 0; u < 4; ++u) x[u] = partials[(int64_t)min(b0 + k + 4 * u, b1 - 1) * ldP + (f < F ? f : 0)];
+  float t = xl_row_sum(x, b0 + k, b1);
   if (k == 0 && f < F) {
     const int64_t row = w.rowmap[w.long_row[li]];
     if (bias) t += bias[f];
@@ -887,24 +936,33 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
                          (uint64_t)w3->op_rows * (uint64_t)ldD * sizeof(DT) < ((uint64_t)1 << 32);
       const int64_t short_waves = ((int64_t)w3->n_short + SLOTS - 1) / SLOTS;
       const int64_t short_blocks = (short_waves + 3) / 4;
-      const int chunk_blocks = (w3->n_chunks + 3) / 4;
+      const int chunk_blocks = w3->n_chunks / 4;  // blockwise rows: four chunks of one row per block
+      const int single_blocks = (w3->s_n + 3) / 4;
       const int mid_blocks = ((w3->n_mid + 3) / 4 + 3) / 4;
       const int64_t xcd_per = (short_blocks + 7) / 8;
-      if (xcd_per * 8 + chunk_blocks + mid_blocks > 0) {
-        const dim3 grid((unsigned)(xcd_per * 8 + chunk_blocks + mid_blocks));
-#define SPMM3_GO(O_, W_)                                                                                           \
-  k_spmm3<G, VEC, TAIL, DT, O_, W_><<<grid, dim3(256), 0, s>>>(v, *w3, D, ldD, F, Y, ldY, bias, relu,               \
+      if (xcd_per * 8 + chunk_blocks + single_blocks + mid_blocks > 0) {
+        const dim3 grid((unsigned)(xcd_per * 8 + chunk_blocks + single_blocks + mid_blocks));
+        // rows of exactly F >= 4 floats (TAIL): the padded-row instantiation with overlapping last vectors (`pack`)
+        constexpr bool PACKED = TAIL && sizeof(DT) == 4;
+        const int pack = (PACKED && F >= VEC) ? 1 : 0;
+#define SPMM3_GO(T_, O_, W_)                                                                                       \
+  k_spmm3<G, VEC, T_, DT, O_, W_><<<grid, dim3(256), 0, s>>>(v, *w3, D, ldD, F, Y, ldY, bias, relu,                \
                                                                (store_vec_ok ? 1 : 0) | padw, partials, 16, chunk_blocks,   \
-                                                               mid_blocks, short_blocks, xcd_per)
+                                                               single_blocks, mid_blocks, short_blocks, xcd_per, pack)
         bool done = false;
-        if constexpr (G == 4 && !TAIL && sizeof(DT) == 4) {
-          if (off32) {
+        const bool off32p = (off32 || (pack && w3->op_rows > 0 && wpe > 0 &&
+                                       (uint64_t)w3->op_rows * (uint64_t)ldD * sizeof(DT) < ((uint64_t)1 << 32)));
+        if constexpr (G == 4 && sizeof(DT) == 4) {
+          if (off32p && (!TAIL || pack)) {
             done = true;
-            if (wpe == 7) SPMM3_GO(true, 7);
-            else SPMM3_GO(true, 1);
+            if (wpe == 7) SPMM3_GO(false, true, 7);
+            else SPMM3_GO(false, true, 1);
           }
         }
-        if (!done) SPMM3_GO(false, 1);
+        if (!done) {
+          if (pack) SPMM3_GO(false, false, 1);
+          else SPMM3_GO(TAIL, false, 1);
+        }
 #undef SPMM3_GO
         MRGCN_HIP_TRY(hipGetLastError());
       }
@@ -1047,12 +1105,13 @@ bool spmm3_fold_default() {
 View3 view3_of(const mrgcn_plan *p) {
   View3 w;
   w.n_short = p->n_short3; w.n_mid = p->n_mid3; w.rowmap = p->rowmap;
-  w.n_chunks = p->r3_n_chunks; w.n_long = p->r3_n_long; w.n_multi = p->r3_n_chunks - p->r3_n_long;
+  w.n_chunks = p->r3_n_chunks; w.n_long = p->r3_n_long; w.n_multi = p->r3_n_multi;
   w.chunk_beg = p->r3_chunk_beg; w.chunk_end = p->r3_chunk_end; w.chunk_row = p->r3_chunk_row;
   w.long_row = p->r3_long_row; w.long_cptr = p->r3_long_cptr;
   w.op_rows = p->n_op;
   w.multi = p->r3_multi; w.n_multi_rows = p->r3_n_multi;
   w.ticket = p->r3_ticket;
+  w.s_n = p->r3s_n_chunks; w.s_beg = p->r3s_chunk_beg; w.s_end = p->r3s_chunk_end; w.s_row = p->r3s_chunk_row;
   return w;
 }
 

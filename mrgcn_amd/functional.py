@@ -122,12 +122,21 @@ def _side_stream(device) -> torch.cuda.Stream:
 
 
 def _ld_for(F: int) -> int:
-    """Leading dimension of the compact operand: rows padded to a multiple of 4 floats (16-byte
-    float4 gathers).  Measured on the AM shape: 12 vs 16 floats per 10-feature row gather within
-    2 % of each other, while the 12-float rows make the producers' scattered pass ~8 % cheaper.
-    MRGCN_LDM_ALIGN overrides (floats, multiple of 4)."""
-    a = int(os.environ.get("MRGCN_LDM_ALIGN", "4"))
+    """Leading dimension of the fp32 compact operand.  Layers of 4 <= F <= 16 outputs with F not a multiple of
+    four keep PACKED rows (ld = F: 40-byte rows at F = 10): the product's gathers stay single 16-byte loads — the
+    row's last vector overlaps its neighbour's (k_spmm3 `pack`) — and the first-touch stream of the operand
+    shrinks by the pad (AM shape: 158 -> 148 us with the plan's operand order hinted for 40-byte rows).  Other
+    widths: rows padded to a multiple of 4 floats.  MRGCN_LDM_ALIGN overrides (floats: 4 = always padded)."""
+    a = os.environ.get("MRGCN_LDM_ALIGN")
+    if a is None:
+        return F if (F % 4 and 4 <= F <= 16) else (F + 3) // 4 * 4
+    a = int(a)
     return (F + a - 1) // a * a
+
+
+def operand_row_bytes(F: int, bf16: bool = False) -> int:
+    """Row size of a layer's compact operand — the hint GraphPlan takes."""
+    return 2 * _ld_for_bf16(F) if bf16 else 4 * _ld_for(F)
 
 
 def _ld_for_bf16(F: int) -> int:

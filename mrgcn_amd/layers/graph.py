@@ -128,7 +128,7 @@ class GraphConvolution(nn.Module):
     def forward(self, X, A, A_idx=None):
         if A_idx is not None:
             return self._forward_mini_batch(X, A, A_idx)
-        plan = plan_of(A, self.num_nodes, self.num_relations)
+        plan = plan_of(A, self.num_nodes, self.num_relations, operand_row_bytes=[self.operand_row_bytes()])
         if self.engine == "literal":
             return self._forward_literal(X, plan)
         return self._forward_fused(X, plan)
@@ -166,10 +166,10 @@ class GraphConvolution(nn.Module):
         if cached is None or cached[0] is not A_idx:
             cached = (A_idx, sliceSparseCOO(A, A_idx))
             A._mrgcn_slice = cached
-        plan_F = plan_of(cached[1], n_b, R)
+        plan_F = plan_of(cached[1], n_b, R, operand_row_bytes=[self.operand_row_bytes()])
         Y = None
         if self.input_layer:
-            plan_I = plan_of(A, self.num_nodes, R)
+            plan_I = plan_of(A, self.num_nodes, R, operand_row_bytes=[self.operand_row_bytes()])
             if self.engine == "literal":
                 W_I = self.weight_I_reference()
                 if B > 0:
@@ -189,6 +189,10 @@ class GraphConvolution(nn.Module):
         else:
             YF = Fn.rgcn_layer(plan_F, self, X, input_term=False)
         return YF if Y is None else Y + YF
+
+    def operand_row_bytes(self) -> int:
+        """Row size of this layer's compact operand: the layout hint its graph plan takes (plan.plan_of)."""
+        return Fn.operand_row_bytes(self.outdim, getattr(self, "operand_dtype", "f32") == "bf16")
 
     # -- fused engine ----------------------------------------------------------------------
     def _forward_fused(self, X, plan, relu=False):

@@ -82,7 +82,13 @@ class RGCN(nn.Module):
                 X = f_activation(X)
         return X
 
+    def operand_row_bytes(self):
+        """Row sizes of the layers' compact operands: the layout hint of the adjacency's graph plan."""
+        return sorted({layer.operand_row_bytes() for layer in self.layers.values()})
+
     def _forward_full_batch(self, X, A):
+        # the plan all layers share is built (on first use) for every layer's operand layout
+        plan_of(A, self.num_nodes, self.layers["layer_0"].num_relations, operand_row_bytes=self.operand_row_bytes())
         for key, layer in self.layers.items():
             f_activation = self.activations[key] if key in self.activations else None
             fuse_relu = (isinstance(f_activation, nn.ReLU) and self.p_dropout <= 0.0

@@ -185,7 +185,8 @@ class PartitionedRGCN(nn.Module):
         lr, lc, lv = self.part.local_coo(rows, cols, vals, self.num_relations)
         A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([lr, lc])), torch.from_numpy(lv),
                                     (self.part.Np, self.num_relations * self.part.S)).to(device)
-        self.plan = GraphPlan(A, self.part.S, self.num_relations)
+        self.plan = GraphPlan(A, self.part.S, self.num_relations,
+                              operand_row_bytes=sorted({l.operand_row_bytes() for l in self.layers.values()}))
         return self.plan
 
     def forward(self, X_local):

@@ -26,9 +26,19 @@ def _flags(prune_zeros, replicate) -> int:
     return f
 
 
+def _row_bytes_arg(operand_row_bytes):
+    """(ctypes array or None, count) for the hinted constructors: at most four distinct sizes."""
+    sizes = sorted({int(b) for b in (operand_row_bytes or ())})[:4]
+    if not sizes:
+        return None, 0
+    return (C.c_int32 * len(sizes))(*sizes), len(sizes)
+
+
 class GraphPlan:
     def __init__(self, A: torch.Tensor, num_nodes: int, num_relations: int,
-                 prune_zeros: bool = False, replicate=None):
+                 prune_zeros: bool = False, replicate=None, operand_row_bytes=None):
+        """`operand_row_bytes`: row sizes (bytes) of the compact operands the plan's products will read
+        (mrgcn_plan_create_hinted): a layout hint for the operand order, never for results."""
         if not A.is_sparse:
             raise TypeError("A must be a torch sparse COO tensor")
         if not A.is_cuda:
@@ -54,12 +64,14 @@ class GraphPlan:
         if int(A.shape[1]) != self.num_nodes * self.num_relations:
             raise ValueError("A.shape[1] != num_relations * num_nodes")
         handle = C.c_void_p()
+        rb, nrb = _row_bytes_arg(operand_row_bytes)
         with torch.cuda.device(self.device):
-            L.check(lib.mrgcn_plan_create(
+            L.check(lib.mrgcn_plan_create_hinted(
                 C.byref(handle), self.num_rows, self.num_nodes, self.num_relations,
                 int(val.numel()), rows.data_ptr(), cols.data_ptr(), val.data_ptr(), vd,
-                _flags(prune_zeros, replicate), _stream_ptr(self.device)),
-                "mrgcn_plan_create")
+                _flags(prune_zeros, replicate), C.cast(rb, C.c_void_p) if nrb else None, nrb,
+                _stream_ptr(self.device)), "mrgcn_plan_create_hinted")
+        self.operand_row_bytes = tuple(rb) if nrb else ()
         self._adopt(handle)
 
     def _adopt(self, handle):
@@ -77,7 +89,7 @@ class GraphPlan:
 
     @classmethod
     def from_csr(cls, A_csr, num_nodes: int, num_relations: int, value_mode: str = "ref_int8",
-                 device="cuda", prune_zeros: bool = False, replicate=None) -> "GraphPlan":
+                 device="cuda", prune_zeros: bool = False, replicate=None, operand_row_bytes=None) -> "GraphPlan":
         """Plan straight from a scipy CSR (what the dataset archive holds, tarball.py:151-157): the
         three arrays are uploaded as they are and expanded on the device — no host `.nonzero()`, no
         int64 COO.  `value_mode="ref_int8"` applies the reference's boundary cast (batch.py:144-149)."""
@@ -94,11 +106,14 @@ class GraphPlan:
         indices = torch.from_numpy(np.ascontiguousarray(A_csr.indices, dtype=np.int32)).to(self.device)
         data = torch.from_numpy(np.ascontiguousarray(A_csr.data, dtype=np.float32)).to(self.device)
         handle = C.c_void_p()
+        rb, nrb = _row_bytes_arg(operand_row_bytes)
         with torch.cuda.device(self.device):
-            L.check(lib.mrgcn_plan_create_csr(
+            L.check(lib.mrgcn_plan_create_csr_hinted(
                 C.byref(handle), self.num_rows, self.num_nodes, self.num_relations, int(data.numel()),
                 indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), 1 if value_mode == "ref_int8" else 0,
-                _flags(prune_zeros, replicate), _stream_ptr(self.device)), "mrgcn_plan_create_csr")
+                _flags(prune_zeros, replicate), C.cast(rb, C.c_void_p) if nrb else None, nrb,
+                _stream_ptr(self.device)), "mrgcn_plan_create_csr_hinted")
+        self.operand_row_bytes = tuple(rb) if nrb else ()
         self._adopt(handle)
         return self
 
@@ -207,10 +222,12 @@ class GraphPlan:
                 + self.ncols * F * elem_bytes + self.num_rows * F * elem_bytes)
 
 
-def plan_of(A: torch.Tensor, num_nodes: int, num_relations: int) -> GraphPlan:
-    """Returns the plan cached on the adjacency tensor, building it on first use."""
+def plan_of(A: torch.Tensor, num_nodes: int, num_relations: int, operand_row_bytes=None) -> GraphPlan:
+    """Returns the plan cached on the adjacency tensor, building it on first use.  `operand_row_bytes` (the row
+    sizes of the compact operands its users will multiply with: a layout hint, see GraphPlan) only matters to the
+    call that builds the plan."""
     p = getattr(A, "_mrgcn_plan", None)
     if p is None or p._h is None or p.num_nodes != num_nodes or p.num_relations != num_relations:
-        p = GraphPlan(A, num_nodes, num_relations)
+        p = GraphPlan(A, num_nodes, num_relations, operand_row_bytes=operand_row_bytes)
         A._mrgcn_plan = p
     return p

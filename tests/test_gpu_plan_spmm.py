@@ -13,12 +13,12 @@ ARRAYS = ["rowptr", "lcol", "ccol", "val", "cptr", "crow", "cval", "urel", "unod
           "rowidx", "ulcol", "rperm", "relptr", "mpos", "mcol", "mval", "rowmap", "ptr3"]
 
 
-def _plan_from_coo(rows, cols, vals, num_rows, N, R, prune=False):
+def _plan_from_coo(rows, cols, vals, num_rows, N, R, prune=False, row_bytes=None):
     from mrgcn_amd.plan import GraphPlan
     idx = torch.from_numpy(np.stack([rows, cols]).astype(np.int64))
     v = torch.from_numpy(np.asarray(vals))
     A = torch.sparse_coo_tensor(idx, v, (num_rows, R * N)).cuda()
-    return GraphPlan(A, N, R, prune_zeros=prune)
+    return GraphPlan(A, N, R, prune_zeros=prune, operand_row_bytes=row_bytes)
 
 
 def _check_plan(plan, ref):
@@ -368,9 +368,10 @@ def test_model_on_a_plan_with_replicas_matches_the_golden():
 
 def test_operand_order_keeps_reread_rows_off_the_straddling_slots():
     """plan.hip::k_avoid_straddle on a graph with many multi-reader columns: the operand order stays a permutation,
-    every aligned group of eight positions holds the same columns as the plain hot / first-touch order (a local
-    exchange), and no column with several readers sits on position 2 or 5 of a group that still has a single-reader
-    column elsewhere; MRGCN_AVOID_STRADDLE=0 gives the plain order.  The product is the same on both."""
+    every aligned group of 32 positions holds the same columns as the plain hot / first-touch order (a local
+    exchange), and no column with several readers sits on a slot whose 48-byte row straddles a 128-byte line while
+    its group still has a single-reader column on a straddle-free slot; MRGCN_AVOID_STRADDLE=0 gives the plain order.
+    The product is the same on both."""
     import os
     import subprocess
     import sys
@@ -388,9 +389,11 @@ def test_operand_order_keeps_reread_rows_off_the_straddling_slots():
     readers = np.diff(cptr)
     at = np.empty(nc, dtype=np.int64)
     at[mpos] = np.arange(nc)                     # column at each position
-    multi = (readers[at] > 1)[: nc // 8 * 8].reshape(-1, 8)
-    single_elsewhere = (~multi[:, [0, 1, 3, 4, 6, 7]]).any(1)
-    assert not (multi[:, 2] & single_elsewhere).any() and not (multi[:, 5] & single_elsewhere).any()
+    multi = (readers[at] > 1)[: nc // 32 * 32].reshape(-1, 32)
+    pos = np.arange(32, dtype=np.int64)
+    bad = (pos * 48) // 128 != (pos * 48 + 47) // 128
+    single_elsewhere = (~multi[:, ~bad]).any(1)
+    assert not (multi[:, bad].any(1) & single_elsewhere).any()
     assert multi.any()                            # the case is not vacuous
     code = ("import numpy as np, torch\n"
             "from mrgcn_amd import synth, _lib as L\nfrom mrgcn_amd.plan import GraphPlan\n"
@@ -401,7 +404,7 @@ def test_operand_order_keeps_reread_rows_off_the_straddling_slots():
     subprocess.run([sys.executable, "-c", code], check=True, cwd=root, env=dict(os.environ, MRGCN_AVOID_STRADDLE="0"))
     plain = np.load("/tmp/_mpos_plain.npy").astype(np.int64)
     assert not np.array_equal(plain, mpos)
-    assert np.array_equal(plain // 8, mpos // 8)   # every column stayed inside its group of eight
+    assert np.array_equal(plain // 32, mpos // 32)   # every column stayed inside its group of 32
     M = torch.randn((nc, 12), device="cuda")
     Y = plan.spmm(L.VIEW_COMPACT, M, F=10).cpu().numpy()
     # the same product with the operand rows laid out in the plain order
@@ -461,3 +464,45 @@ def test_rows_of_several_chunks_finished_inside_the_product_equal_the_two_pass_f
         buf = torch.full((num_rows, ld), 7.0, device="cuda")
         plan.spmm(L.VIEW_COMPACT, Ms[1], F=F, out=buf[:, :F], bias=bias, relu=True, pad_writable=True)
         assert torch.equal(buf[:, :F], want[1]) and (buf[:, F:] == 0).all()
+
+
+@pytest.mark.parametrize("row_bytes", [(40,), (40, 44), (44, 24), (64, 128, 32)])
+def test_plan_hinted_for_packed_operand_rows(row_bytes):
+    """mrgcn_plan_create_hinted: the operand order keeps re-read columns off the positions whose row would straddle
+    a 128-byte line for EVERY announced row size (bit-exact against the numpy plan); sizes that never straddle
+    (divisors / multiples of 128) leave the plain order; the product on packed rows (ld = F: the last 16-byte vector
+    of a row overlaps its neighbour's) equals scipy's for every F."""
+    from mrgcn_amd import _lib as L
+    rng = np.random.default_rng(3)
+    N, R, num_rows = 4000, 4, 4000
+    rows, cols, vals = _random_graph(rng, num_rows, N, R, 40000, hub_rows=2, hub_len=900, hub_cols=3)
+    plan = _plan_from_coo(rows, cols, vals, num_rows, N, R, row_bytes=row_bytes)
+    eff = tuple(b for b in row_bytes if 128 % b and b % 128)
+    ref = util.numpy_plan(rows, cols, vals, num_rows, N, R, row_bytes=eff)
+    _check_plan(plan, ref)
+    if eff:
+        cnt = np.diff(ref["cptr"])
+        at = np.empty(plan.ncols, dtype=np.int64)
+        at[ref["mpos"]] = np.arange(plan.ncols)
+        pos = np.arange(plan.ncols, dtype=np.int64)
+        bad = np.zeros(plan.ncols, dtype=bool)
+        for b in eff:
+            bad |= (pos * b) // 128 != (pos * b + b - 1) // 128
+        lukewarm = (cnt[at] > 1) & (cnt[at] < util.HOT_MIN_REFS)
+        plain = util.numpy_plan(rows, cols, vals, num_rows, N, R, row_bytes=())
+        at0 = np.empty(plan.ncols, dtype=np.int64)
+        at0[plain["mpos"]] = np.arange(plan.ncols)
+        assert (bad & lukewarm).sum() < ((cnt[at0] > 1) & (cnt[at0] < util.HOT_MIN_REFS) & bad).sum()
+    A = sp.csr_matrix((vals.astype(np.float64), (rows, cols)), shape=(num_rows, R * N))
+    for F in (4, 5, 7, 10, 11, 13, 15, 16):
+        D = rng.standard_normal((R * N, F)).astype(np.float32)
+        M = np.full((plan.ncols + 1, F), 1e30, dtype=np.float32)   # (nothing may be read past the last row)
+        M[ref["mpos"]] = D[ref["ulcol"]]
+        Mg = torch.from_numpy(M).cuda()[: plan.ncols]
+        b = torch.from_numpy(rng.standard_normal(F).astype(np.float32)).cuda()
+        want = np.maximum(A @ D.astype(np.float64) + b.cpu().numpy(), 0)
+        Y = plan.spmm(L.VIEW_COMPACT, Mg, F=F, bias=b, relu=True)
+        np.testing.assert_allclose(Y.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+        Yp = plan.spmm(L.VIEW_COMPACT, Mg, F=F, bias=b, relu=True, padded_rows=True)
+        assert torch.equal(Yp, Y)
+        assert torch.equal(plan.spmm(L.VIEW_COMPACT, Mg, F=F, bias=b, relu=True, two_pass=True), Y)

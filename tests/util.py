@@ -7,6 +7,8 @@ import torch
 
 HOT_MIN_REFS = 16  # csrc/common.hpp: kHotMinRefs
 NODE_BAND = 131072  # csrc/common.hpp: kNodeBand
+STRADDLE_ROW_BYTES = (48,)  # plan.hip: the default operand row size of k_avoid_straddle
+LEN_WINDOW_S, LEN_WINDOW_M = 0, 0  # csrc/common.hpp: kLenWindowS / kLenWindowM (0 = off)
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -69,7 +71,7 @@ def load_state_from_case(model, c, prefix="init."):
 # ---------------------------------------------------------------------------------------
 # numpy reference of the graph plan (index arrays must match the device plan bit for bit)
 # ---------------------------------------------------------------------------------------
-def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False):
+def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False, row_bytes=STRADDLE_ROW_BYTES):
     rows = np.asarray(rows, dtype=np.int64)
     cols = np.asarray(cols, dtype=np.int64)
     v = np.asarray(vals).astype(np.float32)
@@ -109,7 +111,11 @@ def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False):
     # COMPACT view: rows in class-major order (<= 8 entries, <= 32, more; row order inside a class)
     lens = np.diff(rowptr.astype(np.int64))
     cls = np.where(lens <= 8, 0, np.where(lens <= 32, 1, 2))
-    rowmap = np.lexsort((np.arange(num_rows), cls)).astype(np.int32)
+    # inside the S / M classes: windows of LEN_WINDOW_S / _M consecutive row ids, a window's rows by length, then by id
+    ids = np.arange(num_rows)
+    sub = np.where(cls == 0, (ids // LEN_WINDOW_S) * 64 + lens if LEN_WINDOW_S else 0,
+                   np.where(cls == 1, (ids // LEN_WINDOW_M) * 64 + lens if LEN_WINDOW_M else 0, 0))
+    rowmap = np.lexsort((ids, sub, cls)).astype(np.int32)
     rank = np.empty(num_rows, dtype=np.int64)
     rank[rowmap] = np.arange(num_rows)
     ptr3 = np.concatenate([[0], np.cumsum(lens[rowmap])]).astype(np.int32)
@@ -121,20 +127,23 @@ def numpy_plan(rows, cols, vals, num_rows, N, R, prune=False):
         max_count = int(cnt.max()) + 1
         hi = np.where(cnt >= HOT_MIN_REFS, max_count - cnt, max_count + 1 + firstrow)
         order = np.lexsort((np.arange(ncols), hi))
-        # inside every aligned group of eight positions, columns with several readers leave the two slots whose
-        # 48-byte rows straddle a 128-byte line (2 and 5) to single-reader columns (plan.hip::k_avoid_straddle)
+        # inside every aligned group of 32 positions, columns with several readers leave the slots whose rows straddle a
+        # 128-byte line to single-reader columns (plan.hip::k_avoid_straddle; row sizes STRADDLE_ROW_BYTES)
         order = order.copy()
-        for g0 in range(0, ncols - 7, 8):
-            grp = order[g0:g0 + 8]
+        n_hot = int((cnt >= HOT_MIN_REFS).sum())
+        for g0 in range(0, ncols - 31, 32):
+            if g0 < n_hot < g0 + 32:
+                continue  # the group that holds the end of the hot region stays as it is
+            grp = order[g0:g0 + 32]
             multi = cnt[grp] > 1
-            for sl in (2, 5):
-                if not multi[sl]:
-                    continue
-                for i in (0, 1, 3, 4, 6, 7):
-                    if not multi[i]:
-                        grp[sl], grp[i] = grp[i], grp[sl]
-                        multi[sl], multi[i] = False, True
-                        break
+            pos = g0 + np.arange(32, dtype=np.int64)
+            bad = np.zeros(32, dtype=bool)
+            for sz in row_bytes:
+                bad |= (pos * sz) // 128 != (pos * sz + sz - 1) // 128
+            todo = [i for i in range(32) if bad[i] and multi[i]]
+            free = [j for j in range(32) if not bad[j] and not multi[j]]
+            for i, j in zip(todo, free):
+                grp[i], grp[j] = grp[j], grp[i]
         mpos = np.empty(ncols, dtype=np.int32)
         mpos[order] = np.arange(ncols, dtype=np.int32)
     else:

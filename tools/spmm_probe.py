@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="am")
     ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--ld", type=int, nargs="+", default=[16])
+    ap.add_argument("--ld", type=int, nargs="+", default=[10])
     ap.add_argument("--F", type=int, default=10)
     ap.add_argument("--view", default="compact")
     ap.add_argument("--iters", type=int, default=20)
@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--value-mode", default="norm_f32")
     ap.add_argument("--ldy", type=int, default=0, help="leading dimension of the compact product's output (0 = F rounded up to 4, pad writable; F = dense rows)")
     ap.add_argument("--replicate", type=int, default=-1, help="1 / 0: operand replicas on / off (default: library)")
+    ap.add_argument("--row-bytes", type=int, nargs="*", default=None, help="operand row sizes the plan's operand order is "
+                    "built for (GraphPlan operand_row_bytes; default: 4 * the first --ld)")
     ap.add_argument("--ab-two-pass", type=int, default=0, help="compact view: alternate N rounds of the two-pass "
                     "form (MRGCN_SPMM_TWO_PASS) and the default in-kernel finalize, in this process")
     a = ap.parse_args()
@@ -38,7 +40,8 @@ def main():
     N, R = g.num_nodes, g.num_relations
     A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
                                 (N, R * N)).to(dev)
-    plan = GraphPlan(A, N, R, prune_zeros=a.prune, replicate=None if a.replicate < 0 else bool(a.replicate))
+    plan = GraphPlan(A, N, R, prune_zeros=a.prune, replicate=None if a.replicate < 0 else bool(a.replicate),
+                     operand_row_bytes=a.row_bytes if a.row_bytes is not None else [4 * a.ld[0]])
     stream = torch.cuda.current_stream(dev).cuda_stream
     F = a.F
     alg = plan.spmm_bytes(F)
