@@ -6,6 +6,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -344,15 +345,16 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
 constexpr uint64_t kPoolKeep = 4ull << 30;
 
 hipError_t pool_alloc(void **p, size_t bytes, hipStream_t s) {
-  static bool configured = false;
-  if (!configured) {
-    int dev = 0;
+  static bool configured[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !configured[dev]) {
     hipMemPool_t pool;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-      uint64_t keep = kPoolKeep;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+      // bytes the pool keeps between builds (MRGCN_POOL_KEEP_MB; default 4096)
+      uint64_t keep = getenv("MRGCN_POOL_KEEP_MB") ? (uint64_t)atoll(getenv("MRGCN_POOL_KEEP_MB")) << 20 : kPoolKeep;
       (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     }
-    configured = true;
+    configured[dev] = true;
   }
   return hipMallocAsync(p, bytes, s);
 }
@@ -892,20 +894,39 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
 }
 
 void free_plan(mrgcn_plan *p) {
-  void *ptrs[] = {p->rowptr, p->lcol, p->ccol, p->rowidx, p->val, p->cptr, p->crow, p->urel, p->unode,
-                  p->nptr, p->ulcol, p->mpos, p->mcol, p->mval, p->rperm, p->relptr, p->rnode, p->rmpos, p->relchunk_ptr, p->relchunk_ids, p->relchunk_rel, p->relchunk_beg, p->relchunk_end,
-                  p->cval, p->r_long_row, p->r_long_cptr, p->r_chunk_beg, p->r_chunk_end,
-                  p->c_long_row, p->c_long_cptr, p->c_chunk_beg, p->c_chunk_end, p->r_chunk_row, p->c_chunk_row,
-                  p->r3_long_row, p->r3_long_cptr, p->r3_chunk_beg, p->r3_chunk_end, p->r3_chunk_row,
-                  p->q_long_row, p->q_long_cptr, p->q_chunk_beg, p->q_chunk_end, p->q_chunk_row, p->rowmap, p->ptr3,
-                  p->rep_src, p->rep_dst, p->partials, p->r3_multi, p->r3_ticket,
-                  p->r3s_long_row, p->r3s_long_cptr, p->r3s_chunk_beg, p->r3s_chunk_end, p->r3s_chunk_row};
-  // the caller guarantees nothing that uses the plan is still to be SUBMITTED; work already in flight on any
-  // stream is waited for (what hipFree did implicitly), then the blocks go back to the pool
-  (void)hipDeviceSynchronize();
-  for (void *q : ptrs)
-    if (q) (void)hipFreeAsync(q, nullptr);
-  delete p;
+  // the caller guarantees nothing that uses the plan is still to be SUBMITTED; work already in flight on any stream of
+  // the plan's device is waited for (what hipFree did implicitly), then the blocks go back to that device's pool.
+  // A plan dropped while a stream capture is under way (the wait is not allowed then) is parked and released by the
+  // next plan that is created or destroyed outside a capture.
+  static std::vector<mrgcn_plan *> parked;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  parked.push_back(p);
+  std::vector<mrgcn_plan *> keep;
+  for (mrgcn_plan *q : parked) {
+    const int qdev = q->device;
+    if (qdev != cur) (void)hipSetDevice(qdev);
+    if (hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      keep.push_back(q);
+    } else {
+      void *ptrs[] = {q->rowptr, q->lcol, q->ccol, q->rowidx, q->val, q->cptr, q->crow, q->urel, q->unode,
+                      q->nptr, q->ulcol, q->mpos, q->mcol, q->mval, q->rperm, q->relptr, q->rnode, q->rmpos, q->relchunk_ptr, q->relchunk_ids, q->relchunk_rel, q->relchunk_beg, q->relchunk_end,
+                      q->cval, q->r_long_row, q->r_long_cptr, q->r_chunk_beg, q->r_chunk_end,
+                      q->c_long_row, q->c_long_cptr, q->c_chunk_beg, q->c_chunk_end, q->r_chunk_row, q->c_chunk_row,
+                      q->r3_long_row, q->r3_long_cptr, q->r3_chunk_beg, q->r3_chunk_end, q->r3_chunk_row,
+                      q->q_long_row, q->q_long_cptr, q->q_chunk_beg, q->q_chunk_end, q->q_chunk_row, q->rowmap, q->ptr3,
+                      q->rep_src, q->rep_dst, q->partials, q->r3_multi, q->r3_ticket,
+                      q->r3s_long_row, q->r3s_long_cptr, q->r3s_chunk_beg, q->r3s_chunk_end, q->r3s_chunk_row};
+      for (void *a : ptrs)
+        if (a) (void)hipFreeAsync(a, nullptr);
+      delete q;
+    }
+    if (qdev != cur) (void)hipSetDevice(cur);
+  }
+  parked.swap(keep);
 }
 
 }  // namespace

@@ -31,14 +31,45 @@ _POISON_DEAD = False
 # mrgcn_adam_step_rows_f32, which never touches a node that never had gradient.  The state hangs on the
 # Parameter object itself.  Outside train_step (plain `loss.backward()`) the gradient is dense and arrives
 # in `weight_I.grad` as usual.
-_ROW_SPARSE = False
+# The same happens under a plain `loss.backward()` when the parameter's optimizer announced that it reads the
+# row-sparse form (mrgcn_amd.optim.Adam registers itself as `weight_I._mrgcn_row_consumer`: the reference's own loop,
+# tasks/node_classification.py:190-193, then runs the fast path with `optim.Adam` / `clip_grad_norm_` swapped).
+# None = decided per parameter (consumer registered?), True / False = forced (train_step).
+_ROW_SPARSE = None
+_ROW_SPARSE_ENV = os.environ.get("MRGCN_ROW_SPARSE", "1") != "0"
 
 
-def row_sparse_weight_grad(enabled: bool) -> bool:
-    """Returns the previous setting."""
+def row_sparse_weight_grad(enabled):
+    """Forces the row-sparse form on / off (None: per parameter).  Returns the previous setting."""
     global _ROW_SPARSE
-    prev, _ROW_SPARSE = _ROW_SPARSE, bool(enabled)
+    prev, _ROW_SPARSE = _ROW_SPARSE, (None if enabled is None else bool(enabled))
     return prev
+
+
+def _row_sparse_for(param) -> bool:
+    if not _ROW_SPARSE_ENV:
+        return False
+    if _ROW_SPARSE is not None:
+        return _ROW_SPARSE
+    consumer = getattr(param, "_mrgcn_row_consumer", None)
+    return consumer is not None and consumer() is not None
+
+
+def dense_from_rows(param: torch.Tensor, ent) -> torch.Tensor:
+    """The dense gradient a row-sparse entry stands for (zeros for the nodes without gradient): for the rare step
+    that needs it after all — another term (a weight regulariser) put a dense gradient on the same parameter."""
+    lib = L.load()
+    fz = ent.get("fused")
+    if fz is None:
+        return torch.where(ent["cur"].bool().view(-1, *([1] * (param.dim() - 1))), ent["g"], torch.zeros_like(ent["g"]))
+    g = torch.empty_like(param)
+    d_comp = torch.empty_like(fz["comp"])
+    with torch.cuda.device(param.device):
+        L.check(lib.mrgcn_basis_mix_bwd_f32(
+            fz["plan"].handle, fz["dM"].data_ptr(), fz["ld"], fz["live"].data_ptr(), param.data_ptr(),
+            fz["comp"].data_ptr(), fz["B"], fz["F"], g.data_ptr(), 0, d_comp.data_ptr(), 0, _stream(param.device)),
+            "mrgcn_basis_mix_bwd_f32")
+    return g
 
 
 def pop_row_grad(param: torch.Tensor):
@@ -305,8 +336,8 @@ class _RgcnLayer(torch.autograd.Function):
                 d_comp = torch.empty_like(comp_I)
                 param = getattr(ctx.owner, "weight_I", None)
                 rows = None
-                if (_ROW_SPARSE and live is not None and param is not None and weight_I.is_contiguous()
-                        and param.shape == weight_I.shape):
+                if (live is not None and param is not None and weight_I.is_contiguous()
+                        and param.shape == weight_I.shape and _row_sparse_for(param)):
                     rows = getattr(param, "_mrgcn_rows", None)
                     if rows is not None and rows["fresh"]:
                         raise L.MrgcnError("row-sparse weight_I gradient: the layer ran twice in one train_step "

@@ -94,12 +94,31 @@ class GraphConvolution(nn.Module):
                 self.weight_F_comp = self.weight_I_comp
             elif name == "weight_I" and self.weight_I_node_major:
                 self.weight_I = nn.Parameter(torch.empty((num_nodes, num_bases, outdim)))
-                self.weight_I._mrgcn_node_major = True  # optimizers hand its state out in the reference's layout
             else:
                 setattr(self, name, nn.Parameter(torch.empty(shape)))
         self._register_state_dict_hook(_weight_I_to_reference)
         self._register_load_state_dict_pre_hook(_weight_I_from_reference, with_module=True)
+        self._tag_parameters()
         self.reset_parameters()
+
+    def _tag_parameters(self):
+        """Marks the node-major `weight_I` Parameter: optimizers (mrgcn_amd.train / mrgcn_amd.optim) hand its state
+        out in the reference's layout.  The mark is a Python attribute of the Parameter object, which copies of the
+        module do not inherit — `copy.deepcopy(model)`, unpickling and parameter-replacing conversions re-create the
+        Parameter — so it is re-applied wherever a module can come by a new one (`__setstate__`, `_apply`); the
+        module's own `weight_I_node_major` is the source of truth."""
+        w = self._parameters.get("weight_I")
+        if w is not None and self.weight_I_node_major:
+            w._mrgcn_node_major = True
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tag_parameters()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._tag_parameters()
+        return out
 
     def reset_parameters(self):
         """Glorot-uniform on every tensor but the bias, zeros on the bias (graph.py:104-116); the values

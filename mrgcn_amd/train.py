@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import _lib as L
-from .functional import clear_row_grads, pop_row_grad, row_sparse_weight_grad
+from .functional import clear_row_grads, dense_from_rows, pop_row_grad, row_sparse_weight_grad
 
 # MRGCN_ROW_SPARSE=0 switches the row-sparse weight_I gradient off (A/B runs)
 _ROW_SPARSE_DEFAULT = os.environ.get("MRGCN_ROW_SPARSE", "1") != "0"
@@ -129,12 +129,19 @@ class ClipAdam(torch.optim.Optimizer):
         sd["state"] = dict(sd["state"])
         for k, st in sd["state"].items():
             p = params[k]
-            if getattr(p, "_mrgcn_node_major", False) and "exp_avg" in st and st["exp_avg"].dim() == 2:
+            if "exp_avg" not in st:
+                continue
+            if getattr(p, "_mrgcn_node_major", False) and st["exp_avg"].dim() == 2:
                 N, B, F = p.shape
                 st = dict(st)
                 for key in ("exp_avg", "exp_avg_sq"):
                     st[key] = st[key].view(B, N, F).permute(1, 0, 2).contiguous()
                 sd["state"][k] = st
+            elif tuple(st["exp_avg"].shape) != tuple(p.shape):
+                # same element count in another layout (a reference-shaped moment for a parameter this optimizer
+                # does not know to be node-major) would load silently permuted
+                raise L.MrgcnError(f"optimizer state {k}: moments of shape {tuple(st['exp_avg'].shape)} for a "
+                                   f"parameter of shape {tuple(p.shape)}")
         super().load_state_dict(sd)
         self._state_gen += 1
         self._dev_step = {}  # re-seeded from the loaded `step` entries at the next step
@@ -166,14 +173,17 @@ class ClipAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         lib = L.load()
-        live = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
         rowsparse = []  # gradient left on the parameter in row-sparse form (functional._ROW_SPARSE)
         for g in self.param_groups:
             for p in g["params"]:
-                if p.grad is None:
-                    ent = pop_row_grad(p)
-                    if ent is not None:
-                        rowsparse.append((g, p, ent))
+                ent = pop_row_grad(p)
+                if ent is None:
+                    continue
+                if p.grad is None and float(g["weight_decay"]) == 0.0:
+                    rowsparse.append((g, p, ent))
+                else:  # another term left a dense gradient on the same parameter (a regulariser): one dense step
+                    merge_row_grad(p, ent)
+        live = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
         if not live and not rowsparse:
             return None
         device = (live[0][1] if live else rowsparse[0][1]).device
@@ -203,7 +213,7 @@ class ClipAdam(torch.optim.Optimizer):
                 L.check(lib.mrgcn_clip_coef_f32(sc["sumsq"].data_ptr(), float(self.max_norm),
                                                 sc["coef"].data_ptr(), sc["norm"].data_ptr(), s),
                         "mrgcn_clip_coef_f32")
-            coef_ptr = sc["coef"].data_ptr() if use_clip else 0
+            coef_ptr = step_coef_ptr = sc["coef"].data_ptr() if use_clip else 0
             bias = {}
             if self.capturable:
                 for group in self.param_groups:  # one device counter per distinct (beta1, beta2)
@@ -241,6 +251,9 @@ class ClipAdam(torch.optim.Optimizer):
                 bc = bias[(float(b1), float(b2))].data_ptr() if self.capturable else 0
                 nrows = p.shape[0]
                 fz = ent.get("fused")
+                # the coefficient of a clip that ran between backward and step (mrgcn_amd.optim.clip_grad_norm_)
+                pre = ent.pop("coef", None)
+                coef_ptr = pre.data_ptr() if pre is not None else step_coef_ptr
                 if fz is not None:  # no gradient tensor: the blocks are rebuilt from dM inside the Adam pass
                     L.check(lib.mrgcn_adam_step_rows_fused_f32(
                         fz["plan"].handle, fz["dM"].data_ptr(), fz["ld"], fz["live"].data_ptr(), fz["comp"].data_ptr(),
@@ -253,6 +266,7 @@ class ClipAdam(torch.optim.Optimizer):
                     nrows, p.numel() // max(nrows, 1), ent["cur"].data_ptr(), ent["ever"].data_ptr(),
                     float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), bc, coef_ptr, s),
                     "mrgcn_adam_step_rows_f32")
+            coef_ptr = step_coef_ptr
             for (group, p), g in zip(live, grads):
                 st = self._new_state(p)
                 st["step"] += 1
@@ -277,6 +291,15 @@ class ClipAdam(torch.optim.Optimizer):
         """Total gradient norm of the last step (synchronises)."""
         dev = next(iter(self._scratch))
         return float(self._scratch[dev]["norm"].item())
+
+
+def merge_row_grad(p, ent):
+    """Adds the gradient a row-sparse entry stands for (scaled by the clip coefficient it may carry) to `p.grad`."""
+    g = dense_from_rows(p, ent)
+    pre = ent.pop("coef", None)
+    if pre is not None:
+        g = g * pre
+    p.grad = g if p.grad is None else p.grad.add_(g)
 
 
 def weight_regularisation(model, l1_lambda: float = 0.0, l2_lambda: float = 0.0):
@@ -357,7 +380,12 @@ class GraphedTrainStep:
         # capturing executes nothing on the device: `warmup` optimizer steps have been taken so far (the
         # optimizer's device counter says the same; ClipAdam.state_dict() reads it back)
         self.warmup_steps = max(warmup, 1)
+        self._optimizer, self._state_gen = optimizer, optimizer._state_gen
 
     def __call__(self):
+        if self._optimizer._state_gen != self._state_gen:
+            # load_state_dict replaced the moment tensors and the device step counter the graph was captured on
+            raise L.MrgcnError("GraphedTrainStep: the optimizer's state was loaded after the capture; build a new "
+                               "GraphedTrainStep (the captured graph still updates the old moment buffers)")
         self.graph.replay()
         return self.loss

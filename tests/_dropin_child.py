@@ -24,9 +24,16 @@ elif order == "after_leaf":  # replaced modules were already imported from the r
     import mrgcn.data.batch
     import mrgcn.models.mrgcn
     mrgcn_amd.install_as_mrgcn()
+elif order == "patched_first":   # the optimizer drop-ins: task modules imported after the call ...
+    mrgcn_amd.install_as_mrgcn(patch_optimizer=True)
+elif order == "patched_after":   # ... and before it (after a first, plain install)
+    mrgcn_amd.install_as_mrgcn()
+    import mrgcn.tasks.node_classification
+    import mrgcn.tasks.link_prediction
+    mrgcn_amd.install_as_mrgcn(patch_optimizer=True)
 else:
     raise SystemExit("order?")
-mrgcn_amd.install_as_mrgcn()  # idempotent
+mrgcn_amd.install_as_mrgcn(patch_optimizer=order.startswith("patched"))  # idempotent
 
 import mrgcn.data.io.tsv  # noqa: E402,F401  (reference modules that are not replaced stay importable)
 import mrgcn.data.utils  # noqa: E402,F401
@@ -38,6 +45,18 @@ import mrgcn_amd.data.batch as my_batch  # noqa: E402
 import mrgcn_amd.models.mrgcn as my_mrgcn  # noqa: E402
 
 assert nc.__file__.startswith(REF) and lp.__file__.startswith(REF)
+import torch  # noqa: E402
+if order.startswith("patched"):
+    # exactly two names differ from torch's inside the reference's task modules (node_classification.py:35, :192;
+    # link_prediction.py:325); everything else passes through, and torch itself is untouched
+    import mrgcn_amd.optim as fast
+    for mod in (nc, lp):
+        assert mod.optim.Adam is fast.Adam and mod.nn.utils.clip_grad_norm_ is fast.clip_grad_norm_
+        assert mod.optim.SGD is torch.optim.SGD and mod.nn.CrossEntropyLoss is torch.nn.CrossEntropyLoss
+        assert mod.nn.utils.clip_grad_value_ is torch.nn.utils.clip_grad_value_
+    assert torch.optim.Adam is not fast.Adam and torch.nn.utils.clip_grad_norm_ is not fast.clip_grad_norm_
+else:
+    assert nc.optim is torch.optim and nc.nn is torch.nn
 assert nc.MRGCN is my_mrgcn.MRGCN and lp.MRGCN is my_mrgcn.MRGCN
 assert nc.FullBatch is my_batch.FullBatch and nc.MiniBatch is my_batch.MiniBatch
 import mrgcn.layers.graph  # noqa: E402

@@ -14,7 +14,7 @@ REF = "/root/reference"
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "mrgcn")), reason="reference tree not on this machine")
-@pytest.mark.parametrize("order", ["first", "after_pkg", "after_leaf"])
+@pytest.mark.parametrize("order", ["first", "after_pkg", "after_leaf", "patched_first", "patched_after"])
 def test_install_as_mrgcn_leaves_the_rest_of_the_reference_importable(order):
     """run.py:12-19 / tasks/node_classification.py:9-16: whatever is imported first, the task modules
     come from the reference, the seven replaced leaves from this package, and the reference's own

@@ -393,7 +393,10 @@ def test_operand_order_keeps_reread_rows_off_the_straddling_slots():
     pos = np.arange(32, dtype=np.int64)
     bad = (pos * 48) // 128 != (pos * 48 + 47) // 128
     single_elsewhere = (~multi[:, ~bad]).any(1)
-    assert not (multi[:, bad].any(1) & single_elsewhere).any()
+    n_hot = int((readers >= util.HOT_MIN_REFS).sum())
+    inner = np.ones(len(multi), dtype=bool)
+    inner[n_hot // 32] = n_hot % 32 == 0         # (the group that holds the end of the hot region stays as it is)
+    assert not (multi[:, bad].any(1) & single_elsewhere & inner).any()
     assert multi.any()                            # the case is not vacuous
     code = ("import numpy as np, torch\n"
             "from mrgcn_amd import synth, _lib as L\nfrom mrgcn_amd.plan import GraphPlan\n"
