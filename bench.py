@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-scale", type=float, default=1.0 / 8,
                     help="fraction of the workload the CPU baseline runs (a second run takes a quarter of it)")
+    ap.add_argument("--no-reference-loop", dest="reference_loop", action="store_false",
+                    help="skip the informational eager measurements of the reference's own loop (extra.epoch_ms_eager, "
+                         "epoch_ms_reference_loop = mrgcn_amd.optim drop-ins, epoch_ms_reference_loop_torch_optim = "
+                         "torch.optim.Adam + torch's clip, epoch_ms_dense_path = train_step(row_sparse=False))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal-spmm", action="store_true")
     ap.add_argument("--partition", dest="partition", action="store_true", default=None,
@@ -179,6 +183,51 @@ def renumbered_epoch_ms(args, g, idx_np, y_np, dims, modules, R, N, B, featurele
         step()
     torch.cuda.synchronize(dev)
     return (time.perf_counter() - t0) / args.steps * 1e3
+
+
+def reference_loop_ms(args, kind, A, X, idx, tgt, modules, R, N, B, featureless, dev):
+    """Informational: the epoch as the reference's own loop drives it (tasks/node_classification.py:35-37, :190-193:
+    `optim.Adam`, `CrossEntropyLoss`, `zero_grad / backward / clip_grad_norm_(1.0) / step`, launched eagerly) on a
+    fresh model — `kind` = "torch" (torch.optim.Adam + torch's clip: dense node-table gradient), "fast" (the
+    drop-ins of mrgcn_amd.optim: row-sparse, what install_as_mrgcn(patch_optimizer=True) gives that loop),
+    "train_step" / "train_step_dense" (this package's own step, eager, row-sparse / row_sparse=False).  Logits and
+    loss stay on the device (the reference copies the logits to the host first, :166)."""
+    import torch
+    from mrgcn_amd import optim as fast
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, train_step
+    torch.manual_seed(args.seed)
+    model = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
+    model.set_engine(args.engine)
+    model.set_operand_dtype(args.operand)
+    groups = [{"params": [p for p in model.parameters() if p.requires_grad]}]
+    if kind.startswith("train_step"):
+        opt = ClipAdam(groups, lr=0.01, weight_decay=0.0, max_norm=1.0)
+
+        def step():
+            return train_step(model, lambda: model(X, A), idx, tgt, opt, row_sparse=None if kind == "train_step" else False)
+    else:
+        Adam, clip = ((torch.optim.Adam, torch.nn.utils.clip_grad_norm_) if kind == "torch"
+                      else (fast.Adam, fast.clip_grad_norm_))
+        opt = Adam(groups, lr=0.01, weight_decay=0.0)
+        criterion = torch.nn.CrossEntropyLoss()
+
+        def step():
+            loss = criterion(model(X, A)[idx], tgt)
+            opt.zero_grad()
+            loss.backward()
+            clip(model.parameters(), 1.0)
+            opt.step()
+            return loss
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize(dev)
+    n = max(args.steps // 2, 3)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / n * 1e3
 
 
 def main():
@@ -325,6 +374,15 @@ def main():
                     args, g, idx_np, y_np, dims, modules, R, N, B, featureless, sh["x_width"], dev)
             except Exception as e:  # noqa: BLE001  (informational leg only)
                 extra["epoch_ms_nodes_renumbered_error"] = str(e)[:200]
+        if args.reference_loop and world == 1 and not partitioned and plan.nnz <= 40_000_000:
+            for kind, key in (("train_step", "epoch_ms_eager"), ("fast", "epoch_ms_reference_loop"),
+                              ("torch", "epoch_ms_reference_loop_torch_optim"),
+                              ("train_step_dense", "epoch_ms_dense_path")):
+                try:
+                    extra[key] = reference_loop_ms(args, kind, A, X, idx, tgt, modules, R, N, B, featureless, dev)
+                except Exception as e:  # noqa: BLE001  (informational leg only)
+                    extra[key + "_error"] = str(e)[:200]
+                torch.cuda.empty_cache()
         if not args.no_literal_spmm:
             try:  # the reference's own operand layout: dense (R*N) x F, 17.8 GB at AM scale
                 D = torch.randn((R * plan.num_nodes, F), device=dev)

@@ -346,3 +346,24 @@ def rgcn_forward_at_rows(cfgs, params, X, A: sp.csr_matrix, rows, relu_last=Fals
         return np.maximum(Y, 0.0) if act else Y
 
     return layer_at(len(cfgs) - 1, rows)
+
+
+def input_term_comp_grad_at_rows(cfg: LayerCfg, p: dict, A: sp.csr_matrix, rows, dY_rows, dtype=np.float64):
+    """d(loss)/d(weight_I_comp) of an input layer with bases when only `rows` of the layer's output carry gradient
+    (`dY_rows`: [len(rows), out], the gradient at the layer's PRE-activation output) — the backward of
+    graph.py:69-75 restricted to the columns those rows touch: dW_I[c] = sum_i A[i, c] dY[i];
+    dcomp[r, b] = sum_{c = (r, j)} <dW_I[c], V[b, j]>.  Never forms the (R*N) x out gradient, so it runs at the
+    FB15k-237 / AM shapes.  Pinned against `layer_backward` by tests/test_oracle_golden.py."""
+    rows = np.asarray(rows, dtype=np.int64)
+    R, N, B, out = cfg.R, cfg.N, cfg.B, cfg.outdim
+    assert cfg.input_layer and B > 0
+    sub = A.tocsr()[rows, :].tocoo()
+    ucol, inv = np.unique(sub.col.astype(np.int64), return_inverse=True)
+    r_u, j_u = ucol // N, ucol % N
+    sub_c = sp.csr_matrix((sub.data.astype(dtype), (sub.row, inv)), shape=(len(rows), len(ucol)))
+    dD = sub_c.T @ np.asarray(dY_rows, dtype=dtype)                      # [touched columns, out]
+    V = p["weight_I"].reshape(B, N, out)
+    dots = np.einsum("cf,bcf->cb", dD, V[:, j_u, :].astype(dtype))       # [touched columns, B]
+    dcomp = np.zeros((R, B), dtype=dtype)
+    np.add.at(dcomp, r_u, dots)
+    return dcomp

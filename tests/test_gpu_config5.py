@@ -157,3 +157,35 @@ def test_config5_captured_epoch_equals_eager_epoch(s10m):
     assert med < 2e-4 and q99 < 2e-3 and far < 5e-3 and float(d.max()) < 3e-2, (med, q99, far, float(d.max()))
     del m1, m2, o1, o2, step
     torch.cuda.empty_cache()
+
+
+def test_config5_model_logits_against_the_float64_oracle_at_sampled_rows(s10m):
+    """BASELINE config 5's model (155 -> 16 -> 11, 10 bases, 1.6 G parameters) on the 10 M-node graph: logits
+    before training — deterministic — at 200 sampled rows (labelled nodes, the largest hubs, random ones) against
+    the float64 oracle on their 2-hop receptive field (oracle.rgcn_forward_at_rows; graph.py:62-102, rgcn.py:69-89).
+    Tolerance 1e-4, the north_star's."""
+    import scipy.sparse as sp
+    from mrgcn_amd import synth
+    from mrgcn_amd.models.rgcn import RGCN
+    from oracle import rgcn_oracle as O
+    g, A, plan = s10m
+    N, R = g.num_nodes, g.num_relations
+    dims = synth.layer_dims("synth10m")
+    B = synth.SHAPES["synth10m"]["bases"]
+    idx, _ = synth.make_labels("synth10m", N, seed=0)
+    torch.manual_seed(3)
+    mods = [(dims[0][0], dims[0][1], "mrgcn", torch.nn.ReLU()), (dims[1][0], dims[1][1], "mrgcn", None)]
+    model = RGCN(mods, R, N, B, 0.0, False, True, False).cuda()
+    X = torch.randn((N, dims[0][0]), device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    deg = np.bincount(g.rows, minlength=N)
+    rng = np.random.default_rng(6)
+    rows = np.unique(np.concatenate([idx[:80], np.argsort(deg)[-10:], rng.choice(N, 110)]))
+    with torch.no_grad():
+        got = model(X, A)[torch.from_numpy(rows).cuda()].cpu().numpy()
+    A_csr = sp.csr_matrix((g.vals.astype(np.float64), (g.rows, g.cols)), shape=(N, R * N))
+    state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    cfgs = O.rgcn_cfgs(dims, R, N, B, True, False)
+    ref = O.rgcn_forward_at_rows(cfgs, O.split_params(state, len(cfgs)), X.cpu().numpy(), A_csr, rows)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    del model, X
+    torch.cuda.empty_cache()

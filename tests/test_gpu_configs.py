@@ -163,3 +163,121 @@ def test_config2_mutag_full_shape_with_the_encoders_in_front():
         want = want.numpy()
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=5e-3, atol=5e-4 * float(np.abs(want).max()) + 1e-9,
                                    err_msg=name)
+
+
+@pytest.mark.parametrize("value_mode", ["ref_int8", "norm_f32"])
+def test_config4_fb15k_encoder_full_shape_at_sampled_rows(value_mode):
+    """configs/fb15k-237.toml:85-97 at the FULL shape (N = 14 541, R = 475, one featureless layer -> 200 with ReLU,
+    2 bases; the reference's `W_I` would be 5.5 GB): embeddings of 300 sampled rows (the largest hubs among them)
+    against the float64 oracle on their receptive field, and the gradients of `weight_I_comp`, `b` and `relations`
+    of a loss that lives on those rows against the oracle's backward restricted to them
+    (oracle.input_term_comp_grad_at_rows, pinned to the reference's autograd in tests/test_oracle_golden.py).
+    F = 200 takes the wide-row product (k_spmm<G >= 16>) and the scalar mix kernels."""
+    import scipy.sparse as sp
+    from mrgcn_amd import synth
+    from mrgcn_amd.models.rgcn import RGCN
+    from oracle import rgcn_oracle as O
+    g = synth.make_graph("fb15k", seed=5, scale=1.0, value_mode=value_mode)
+    N, R, B, F = g.num_nodes, g.num_relations, 2, 200
+    assert (N, R) == (14541, 475)
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                (N, R * N)).cuda()
+    torch.manual_seed(4)
+    model = RGCN([(0, F, "mrgcn", torch.nn.ReLU())], R, N, B, 0.0, True, True, True).cuda()
+    with torch.no_grad():
+        model.layers["layer_0"].b.normal_(0.0, 0.1)      # (zeros at init: make the bias term visible)
+    deg = np.bincount(g.rows, minlength=N)
+    rng = np.random.default_rng(2)
+    rows = np.unique(np.concatenate([np.argsort(deg)[-20:], rng.choice(N, 280, replace=False)]))
+    sel = torch.from_numpy(rows).cuda()
+    E = model(None, A)
+    w = torch.randn((len(rows), F), device="cuda", generator=torch.Generator("cuda").manual_seed(7))
+    (E[sel] * w).sum().backward()
+    A_csr = sp.csr_matrix((g.vals.astype(np.float64), (g.rows, g.cols)), shape=(N, R * N))
+    state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    cfgs = O.rgcn_cfgs([(0, F)], R, N, B, True, True)
+    params = O.split_params(state, 1)
+    ref = O.rgcn_forward_at_rows(cfgs, params, None, A_csr, rows, relu_last=True)
+    got = E.detach()[sel].cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    dpre = w.cpu().numpy().astype(np.float64) * (ref > 0)
+    want_comp = O.input_term_comp_grad_at_rows(cfgs[0], params[0], A_csr, rows, dpre)
+    got_comp = model.layers["layer_0"].weight_I_comp.grad.cpu().numpy()
+    np.testing.assert_allclose(got_comp, want_comp, rtol=1e-3, atol=1e-4 * float(np.abs(want_comp).max()) + 1e-9)
+    np.testing.assert_allclose(model.layers["layer_0"].b.grad.cpu().numpy(), dpre.sum(0), rtol=1e-3,
+                               atol=1e-4 * float(np.abs(dpre.sum(0)).max()))
+    assert model.relations.grad is None     # the decoder's table is not on this loss's path
+
+
+def test_config3_am_quarter_full_multimodal_with_the_encoders_in_front():
+    """BASELINE config 3 "full multimodal": MRGCN(FullBatch) on an AM/4-shaped graph (417 k nodes, R = 267, 40 bases)
+    with every kind of encoder in front of the R-GCN instead of random feature columns — an image head on a
+    (stand-in) CNN backbone with the pixel normaliser, a string head on a (stand-in) language model, a WKT TCNN and
+    a numeric MLP, gated and scattered into X (mrgcn.py:250-305) through `FullBatch.as_tensors_() / .to()`.
+    Reference on the host: the same encoder modules in float64, the gate multiply + scatter written out, then the
+    float64 R-GCN oracle on the receptive field of 200 sampled rows (oracle.rgcn_forward_at_rows).  Logits 1e-4."""
+    import copy
+    import scipy.sparse as sp
+    from mrgcn_amd import synth
+    from mrgcn_amd.data.batch import FullBatch
+    from mrgcn_amd.models.mrgcn import MRGCN
+    from oracle import rgcn_oracle as O
+    from tests.test_encoders import TinyImageNet, TinyLM
+    g = synth.make_graph("am", seed=3, scale=0.25, value_mode="norm_f32")
+    N, R, B = g.num_nodes, g.num_relations, 40
+    rng = np.random.default_rng(8)
+
+    def nodes(k):
+        return np.sort(rng.choice(N, k, replace=False))
+    img_idx, str_idx, wkt_idx, num_idx = nodes(3000), nodes(20000), nodes(800), nodes(60000)
+    img = rng.integers(0, 256, (3000, 3, 12, 12)).astype(np.uint8)
+    toks = rng.integers(1, 50, (20000, 16)).astype(np.int64)
+    wkt = (rng.random((800, 9, 20)) < 0.15).astype(np.float32)
+    num = rng.standard_normal((60000, 4)).astype(np.float32)
+    torch.manual_seed(12)
+    emb_cfg = sorted([("blob.image", (TinyImageNet(), {"mean": [0.485, 0.456, 0.406], "std": [0.229, 0.224, 0.225]}, 6, 0.0), False),
+                      ("xsd.string", (TinyLM(), 4, 0.0), False),
+                      ("ogc.wktLiteral", (9, 5, "S", 0.0), False),
+                      ("xsd.numeric", (4, 3, 0.0), False)], key=lambda t: t[0])
+    W = 6 + 5 + 3 + 4
+    modules = [(W, 10, "mrgcn", torch.nn.ReLU()), (10, 11, "mrgcn", None)]
+    model = MRGCN(modules, emb_cfg, R, N, num_bases=B, p_dropout=0.0, featureless=False, bias=True,
+                  gcn_gpu_acceleration=True)
+    A = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
+    enc = {"blob.image": (img, img_idx, np.ones(3000, dtype=int)), "ogc.wktLiteral": (wkt, wkt_idx, np.full(800, 20)),
+           "xsd.numeric": (num, num_idx, np.ones(60000, dtype=int)), "xsd.string": (toks, str_idx, np.full(20000, 16))}
+    X = [np.empty((N, 0), dtype=np.float32)] + [[dt, [list(enc[dt])], False] for dt, _, _ in emb_cfg]
+    batch = FullBatch(A, X, np.arange(N), value_mode="norm_f32")
+    batch.as_tensors_()
+    batch.to(model.devices)
+    model.eval()        # (running statistics in the TCNN's BatchNorm: a deterministic forward on both sides)
+    with torch.no_grad():
+        logits = model(batch)
+    # ---- host reference: the same encoders in float64, gate * output scattered into X --------------------------
+    XF = np.zeros((N, W))
+    gates = model.gate_weights.detach().cpu().double()
+    off = 0
+    for dt, _, _ in emb_cfg:
+        module, _, out_dim, i_gate = model.modality_modules[dt][0]
+        ref_mod = copy.deepcopy(module).cpu().double().eval()
+        data, nidx, _ = enc[dt]
+        with torch.no_grad():
+            if dt == "blob.image":
+                x = model.im_norm.normalize_(torch.from_numpy(data)).double()
+            elif dt == "xsd.string":
+                x = torch.from_numpy(data).int()
+            else:
+                x = torch.from_numpy(data).double()
+            out = ref_mod(x)
+        XF[nidx, off:off + out_dim] = (gates[i_gate] * out).numpy()
+        off += out_dim
+    deg = np.bincount(g.rows, minlength=N)
+    rows = np.unique(np.concatenate([np.argsort(deg)[-20:], rng.choice(N, 180, replace=False),
+                                     rng.choice(img_idx, 20), rng.choice(wkt_idx, 20)]))
+    A64 = sp.csr_matrix((g.vals.astype(np.float64), (g.rows, g.cols)), shape=(N, R * N))
+    state = {k: v.detach().cpu().numpy() for k, v in model.rgcn.state_dict().items()}
+    cfgs = O.rgcn_cfgs([(W, 10), (10, 11)], R, N, B, True, False)
+    ref = O.rgcn_forward_at_rows(cfgs, O.split_params(state, 2), XF, A64, rows)
+    got = logits[torch.from_numpy(rows).cuda()].cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    assert float(np.abs(XF).max()) > 0 and len(np.unique(np.nonzero(XF)[1])) == W   # every encoder contributed
