@@ -26,7 +26,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6.29 TB/s measured copy
-PARTITIONED_WORKLOADS = ("synth10m",)  # BASELINE.json configs[4]: one graph over the GPUs of the node
+# BASELINE.json configs[4] (synthetic 10 M-node graph) and configs[3] (FB15k-237 link prediction, "node-partitioned
+# 1 -> 8"): one graph over the GPUs of the node
+PARTITIONED_WORKLOADS = ("synth10m", "fb15k")
 
 
 def parse():
@@ -34,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="am", help="am | mutag | aifb | synth10m")
+    ap.add_argument("--workload", default="am", help="am | mutag | aifb | synth10m | fb15k (link prediction: R-GCN encoder + DistMult decoder, BASELINE config 4)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
     ap.add_argument("--value-mode", default="norm_f32", choices=["norm_f32", "ref_int8"])
     ap.add_argument("--engine", default="fused", choices=["fused", "literal"])
@@ -230,8 +232,199 @@ def reference_loop_ms(args, kind, A, X, idx, tgt, modules, R, N, B, featureless,
     return (time.perf_counter() - t0) / n * 1e3
 
 
+def lp_cpu_baseline(args, sh, train_frac):
+    """The reference's op sequence for one full-batch link-prediction epoch on the host (encoder: the literal ATen
+    port of graph.py:62-102; decoder, loss, clip and Adam: the torch ops of tasks/link_prediction.py:244-326) on a
+    bounded sample of the workload."""
+    import torch
+    from mrgcn_amd import synth
+    from mrgcn_amd.tasks import link_prediction as lp
+    from oracle import aten_literal as ref
+    sc = min(1.0, max(args.cpu_scale * 2, 1e-3)) * args.scale
+    g = synth.make_graph("fb15k", seed=args.seed, scale=sc, value_mode=args.value_mode)
+    N, R, H, B = g.num_nodes, g.num_relations, sh["hidden"], sh["bases"]
+    tr = g.triples
+    rng = np.random.RandomState(args.seed)
+    train = tr[rng.permutation(len(tr))[:int(train_frac * len(tr))]]
+    cores = os.cpu_count() or 1
+    threads = min(cores, 32)
+    torch.set_num_threads(threads)
+    p = ref.make_params([(0, H)], R, N, B, False, True, seed=args.seed)
+    p["relations"] = torch.nn.init.xavier_uniform_(torch.empty((R, H))).requires_grad_(True)
+    Ac = ref.coo_tensor(g.rows, g.cols, g.vals, (N, R * N))
+    opt = torch.optim.Adam(list(p.values()), lr=0.01)
+    crit = torch.nn.BCEWithLogitsLoss()
+
+    def step():
+        neg, Y = lp.sample_negatives(train, rng)
+        tt = torch.from_numpy(np.concatenate([train, neg])).long()
+        emb = torch.relu(ref.layer_forward(p, "layers.layer_0.", None, Ac, R, N, B, True, True))
+        score = torch.sum(emb[tt[:, 0]] * p["relations"][tt[:, 1]] * emb[tt[:, 2]], dim=-1)
+        loss = crit(score, torch.from_numpy(Y))
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(p.values()), 1.0)
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        step()
+    ms = (time.perf_counter() - t0) / 2 * 1e3
+    return {"value": ms / sc * args.scale, "unit": "ms/epoch", "cores": threads, "kind": "port",
+            "sample": (f"fb15k x {sc:.4g} (N={N}, R={R}, nnz={g.nnz}, {len(train)} training triples + 20 % negatives): "
+                       f"{ms:.1f} ms/epoch over 2 epochs after 1 warm-up with the reference's op sequence (literal ATen "
+                       f"encoder + torch decoder / BCE / clip / Adam) on {threads} of {cores} host threads; value = "
+                       f"measured / {sc:.4g} (linear in the triples; the encoder's (R*N) x out operand grows with N too)"),
+            "measured_ms": ms, "sample_scale": sc, "host_cores": cores}
+
+
+def main_lp(args):
+    """BASELINE config 4: FB15k-237-shaped link prediction.  One step = one full-batch epoch of
+    tasks/link_prediction.py:231-326 — 20 % in-batch negatives (drawn on the device), featureless R-GCN encoder
+    (N x 200, 2 bases, ReLU), DistMult scores of positives + negatives, BCE-with-logits, backward,
+    clip_grad_norm_(1.0), Adam — with everything resident in HBM.  N > 1: the node-partitioned encoder with
+    all-gathered embeddings and triples scored rank::world (mrgcn_amd.partition.partitioned_lp_step)."""
+    import torch
+    import torch.distributed as dist
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd import dist as mdist
+    from mrgcn_amd import synth
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.plan import plan_of
+    from mrgcn_amd.tasks import link_prediction as lp
+    from mrgcn_amd.train import ClipAdam
+
+    world, rank, local_rank = mdist.env_world()
+    ngpu = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", (local_rank % ngpu) if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    backend = os.environ.get("MRGCN_DIST_BACKEND", "nccl" if ngpu >= world else "gloo")
+    mdist.init(backend, dev if backend == "nccl" else None)
+    sh = synth.SHAPES["fb15k"]
+    t0 = time.time()
+    g = synth.make_graph("fb15k", seed=args.seed, scale=args.scale, value_mode=args.value_mode)
+    N, R, H, B = g.num_nodes, g.num_relations, sh["hidden"], sh["bases"]
+    train_frac = 272115 / 310116   # mkdataset.py:46-49: train / valid / test of FB15k-237
+    rng = np.random.RandomState(args.seed)
+    perm = rng.permutation(len(g.triples))
+    ntrain = int(train_frac * len(g.triples))
+    train, test = g.triples[perm[:ntrain]], g.triples[perm[ntrain:ntrain + 500]]
+    train_dev = torch.from_numpy(train).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(args.seed)   # the same draws on every rank
+    modules = [(0, H, "mrgcn", torch.nn.ReLU())]
+    if args.partition is None:
+        args.partition = True
+    partitioned = args.partition and world > 1
+    torch.manual_seed(args.seed)
+    if not partitioned:
+        A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                    (N, R * N)).to(dev)
+        model = RGCN(modules, R, N, B, 0.0, True, False, True).to(dev)
+        model.set_engine(args.engine)
+        opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+        plan = plan_of(A, N, R, operand_row_bytes=model.operand_row_bytes())
+
+        def step():
+            neg, Y = lp.sample_negatives_device(train_dev, gen)
+            t = torch.cat([train_dev, neg])
+            emb = model(None, A)
+            score = lp.score_distmult_bc((t[:, 0], t[:, 1], t[:, 2]), emb, model.relations)
+            loss = lp.binary_crossentropy(score, Y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+    else:
+        from mrgcn_amd.partition import NodePartition, PartitionedRGCN, partitioned_lp_step
+        part = NodePartition(N, world, rank)
+        model = PartitionedRGCN(modules, R, N, B, True, False, part, link_prediction=True).to(dev)
+        model.sync_replicated()
+        plan = model.build_plan(g.rows, g.cols, g.vals, dev)
+        opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+        opt.set_distributed(None, model.sharded_parameters())
+
+        def step():
+            neg, Y = lp.sample_negatives_device(train_dev, gen)
+            return partitioned_lp_step(model, None, torch.cat([train_dev, neg]), Y, opt)
+    setup_s = time.time() - t0
+    for _ in range(args.warmup):
+        step()
+    mdist.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    mdist.barrier(dev)
+    dt = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+    ms_per_step = dt / args.steps * 1e3
+    out = None
+    if rank == 0:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        from mrgcn_amd.functional import _ld_for
+        ld = _ld_for(H)
+        # the encoder's stacked-CSR product at this shape: rows of 800 bytes, the wide-row kernel (k_spmm<G = 64>)
+        M = torch.randn((plan.nop, ld), device=dev)
+        Yb = torch.empty((plan.num_rows, H), device=dev)
+        t_c = event_time_ms(lambda: plan.spmm(L.VIEW_COMPACT, M, F=H, out=Yb), args.spmm_iters, stream)
+        bytes_alg = plan.spmm_bytes(H)
+        ach = bytes_alg / (t_c * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "traffic_source": "no counter file for this workload",
+                    "kernel": "mrgcn::k_spmm<G,VEC> (+k_spmm_finalize) on the compact view, F=%d, ld=%d" % (H, ld),
+                    "algorithmic_bytes": bytes_alg, "avg_ms": t_c}
+        del M, Yb
+        extra = {}
+        if not partitioned:
+            with torch.no_grad():
+                emb = model(None, A)
+                rel = model.relations
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                raw = lp.compute_ranks_fast(test, emb, rel, filtered=False)
+                torch.cuda.synchronize(dev)
+                t2 = time.perf_counter()
+                flt = lp.compute_ranks_fast(test, emb, rel, filtered=True)
+                torch.cuda.synchronize(dev)
+                t3 = time.perf_counter()
+            # link_prediction.py:398-404: both corruption directions of every fact against all N nodes
+            flop = 2.0 * len(test) * N * H * 3
+            extra.update(rank_500_raw_ms=(t2 - t1) * 1e3, rank_500_filtered_ms=(t3 - t2) * 1e3,
+                         rank_raw_tflops=flop / (t2 - t1) / 1e12, mrr_raw=lp.mrr_hits(raw)[0],
+                         mrr_filtered=lp.mrr_hits(flt)[0])
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cpu = lp_cpu_baseline(args, sh, train_frac)
+            except Exception as e:  # noqa: BLE001
+                cpu = {"value": None, "unit": "ms/epoch", "cores": os.cpu_count(), "kind": "port",
+                       "sample": "failed: " + str(e)[:200]}
+        n_params = sum(p.numel() for p in model.parameters())
+        out = {
+            "metric": "full-batch R-GCN link-prediction epoch time (ms), fb15k-shaped graph",
+            "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong" if partitioned else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"fb15k-237-shaped synthetic KG, link prediction (SURVEY §8d config 4), scale {args.scale:g}",
+                       "N": N, "R": R, "nnz": g.nnz, "ncols_touched": plan.ncols, "layers": [[0, H]], "num_bases": B,
+                       "train_triples": int(ntrain), "negatives": "20 % in-batch, drawn on the device each epoch",
+                       "decoder": "DistMult + BCE-with-logits", "value_mode": args.value_mode, "engine": args.engine,
+                       "launch": "eager", "params": n_params,
+                       "parallelism": ("node-partitioned x%d" % world if partitioned else "replicas x%d" % world)
+                       if world > 1 else "1 GPU"},
+            "roofline": roofline, "cpu_baseline": cpu, "spmm_hbm_gbps": ach,
+            "extra": dict(extra, final_loss=float(loss), setup_s=setup_s, plan_device_mb=plan.device_bytes / 2**20),
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "fb15k":
+        return main_lp(args)
     import torch
     import torch.distributed as dist
     from mrgcn_amd import dist as mdist

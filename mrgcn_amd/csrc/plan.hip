@@ -946,7 +946,8 @@ static int straddle_hint(const int32_t *row_bytes, int32_t n, mrgcn::StraddleSiz
     sz.n = 0;
     for (int32_t i = 0; i < n && sz.n < 4; ++i) {
       MRGCN_REQUIRE(row_bytes[i] > 0 && row_bytes[i] % 2 == 0, "operand_row_bytes: positive, even");
-      if (row_bytes[i] % 128 == 0 || 128 % row_bytes[i] == 0) continue;  // such rows never straddle a line
+      // rows that never straddle a line (divisors of 128) or always do (>= 128 bytes) have nothing to choose
+      if (row_bytes[i] >= 128 || 128 % row_bytes[i] == 0) continue;
       sz.bytes[sz.n++] = row_bytes[i];
     }
   }

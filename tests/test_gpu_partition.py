@@ -229,3 +229,38 @@ def test_bench_runs_the_partitioned_engine_for_the_partitioned_workload():
     assert rep.returncode == 0, rep.stderr[-2000:]
     jr = json.loads([ln for ln in rep.stdout.splitlines() if ln.startswith("{")][-1])
     assert jr["config"]["parallelism"] == "replicas x2" and jr["scaling"] == "weak"
+
+
+@pytest.mark.timeout(900)
+def test_bench_link_prediction_workload_single_and_partitioned():
+    """`bench.py --workload fb15k` (BASELINE config 4: R-GCN encoder + DistMult decoder, one step = one full-batch
+    epoch of tasks/link_prediction.py:231-326 with device-drawn negatives, plus the ranking pass of :398-404): one
+    process prints a line with the encoder product's roofline and the ranking figures; launched as the driver
+    launches N > 1 it takes the node-partitioned encoder (`partitioned_lp_step`: all-gathered embeddings, triples
+    scored rank::world) unprompted — two ranks on this box's one GPU, collectives over gloo — and reaches the same
+    loss as the single process (same seed: identical replicated parameters and negatives; the node table's shards
+    are drawn per rank, so the trajectories are close, not equal)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "fb15k", "--scale", "0.1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+              "--spmm-iters", "3"]
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common,
+                            capture_output=True, text=True, cwd=root, timeout=800)
+    assert single.returncode == 0, single.stderr[-2000:]
+    j1 = json.loads([ln for ln in single.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "link-prediction" in j1["metric"] and j1["config"]["parallelism"] == "1 GPU"
+    assert j1["roofline"]["frac"] > 0 and j1["value"] > 0 and j1["config"]["layers"] == [[0, 200]]
+    assert j1["extra"]["rank_500_raw_ms"] > 0 and 0 < j1["extra"]["mrr_filtered"] <= 1
+    env = dict(os.environ, MRGCN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    multi = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                            os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                           capture_output=True, text=True, cwd=root, env=env, timeout=800)
+    assert multi.returncode == 0, multi.stderr[-2000:]
+    lines = [ln for ln in multi.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, multi.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["parallelism"] == "node-partitioned x2"
+    assert abs(j["extra"]["final_loss"] - j1["extra"]["final_loss"]) < 0.05 * abs(j1["extra"]["final_loss"])

@@ -469,18 +469,18 @@ def test_rows_of_several_chunks_finished_inside_the_product_equal_the_two_pass_f
         assert torch.equal(buf[:, :F], want[1]) and (buf[:, F:] == 0).all()
 
 
-@pytest.mark.parametrize("row_bytes", [(40,), (40, 44), (44, 24), (64, 128, 32)])
+@pytest.mark.parametrize("row_bytes", [(40,), (40, 44), (44, 24), (64, 128, 32, 800)])
 def test_plan_hinted_for_packed_operand_rows(row_bytes):
     """mrgcn_plan_create_hinted: the operand order keeps re-read columns off the positions whose row would straddle
     a 128-byte line for EVERY announced row size (bit-exact against the numpy plan); sizes that never straddle
-    (divisors / multiples of 128) leave the plain order; the product on packed rows (ld = F: the last 16-byte vector
+    (divisors of 128; rows of 128 bytes and more always span lines) leave the plain order; the product on packed rows (ld = F: the last 16-byte vector
     of a row overlaps its neighbour's) equals scipy's for every F."""
     from mrgcn_amd import _lib as L
     rng = np.random.default_rng(3)
     N, R, num_rows = 4000, 4, 4000
     rows, cols, vals = _random_graph(rng, num_rows, N, R, 40000, hub_rows=2, hub_len=900, hub_cols=3)
     plan = _plan_from_coo(rows, cols, vals, num_rows, N, R, row_bytes=row_bytes)
-    eff = tuple(b for b in row_bytes if 128 % b and b % 128)
+    eff = tuple(b for b in row_bytes if 128 % b and b < 128)
     ref = util.numpy_plan(rows, cols, vals, num_rows, N, R, row_bytes=eff)
     _check_plan(plan, ref)
     if eff:
