@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""The kernels of ONE epoch in launch order, from a rocprofv3 kernel_trace.csv: the last stretch between two
+launches of the epoch's first kernel (default: the layer-0 relation transform).  Shows every launch — this package's
+kernels, torch's, the runtime's fill / copy kernels — with its start offset, duration, grid and stream (queue), and
+the gaps in which the device idled.
+usage: python tools/epoch_sequence.py <dir> [first-kernel-substring]"""
+import csv
+import glob
+import sys
+
+sys.path.insert(0, __file__.rsplit("/", 1)[0])
+from prof_summary import short  # noqa: E402
+
+
+def main():
+    f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]
+    first = sys.argv[2] if len(sys.argv) > 2 else "k_xform_mfma_fwd<1, false, 16"
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
+    if len(starts) < 2:
+        raise SystemExit("fewer than two epochs in the trace")
+    a, b = starts[-2], starts[-1]
+    t0 = int(rows[a]["Start_Timestamp"])
+    print(f"source: {f}\nepoch = launches {a}..{b - 1}: {(int(rows[b]['Start_Timestamp']) - t0) / 1e3:.1f} us from first "
+          f"kernel to the next epoch's first kernel\n")
+    print("| # | start us | dur us | idle before us | queue | grid | kernel |")
+    print("|---:|---:|---:|---:|---:|---:|---|")
+    busy_until, other = t0, 0.0
+    for i, r in enumerate(rows[a:b]):
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        gap = max(0, s - busy_until) / 1e3
+        busy_until = max(busy_until, e)
+        name = short(r["Kernel_Name"])
+        if "mrgcn::" not in name:
+            other += (e - s) / 1e3
+        print(f"| {i} | {(s - t0) / 1e3:.1f} | {(e - s) / 1e3:.1f} | {gap:.1f} | {r.get('Queue_Id', '')} | "
+              f"{r['Grid_Size_X']} | {name} |")
+    print(f"\nkernels that are not this package's (fills, copies, torch elementwise, library GEMMs): {other:.1f} us")
+
+
+if __name__ == "__main__":
+    main()

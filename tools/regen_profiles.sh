@@ -8,20 +8,23 @@ cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 o=gpurun_out/$tag
 mkdir -p $o
-bash tools/pmc_passes.sh $o/pmc_spmm mem -- python3 tools/spmm_probe.py --ld 12 --iters 10
+bash tools/pmc_passes.sh $o/pmc_spmm mem -- python3 tools/spmm_probe.py --ld 10 --row-bytes 40 44 --iters 10
 python3 tools/make_spmm_pmc_json.py $o/pmc_spmm "k_spmm3<" > $o/spmm_pmc_latest.json
 python3 tools/pmc_summary.py $o k_spmm3 > $o/spmm_pmc.md
 rm -rf $o/pmc_spmm_*/
 cp $o/spmm_pmc_latest.json profiles/spmm_pmc_latest.json   # the bench line quotes it (digest-checked)
 python3 bench.py --steps 20 --warmup 3 > $o/bench_line.json 2> $o/bench_line.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-renumbered-extra > $o/bench_under_rocprof.json 2> $o/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-renumbered-extra --no-reference-loop > $o/bench_under_rocprof.json 2> $o/bench_under_rocprof.err
 python3 tools/prof_summary.py $o/stats 40 > $o/epoch_kernel_stats.md
 python3 tools/trace_summary.py $o/stats > $o/epoch_kernel_trace_medians.md 2>/dev/null
+python3 tools/epoch_sequence.py $o/stats > $o/epoch_sequence.md 2>/dev/null
 rm -rf $o/stats
-bash tools/pmc_passes.sh $o/pmc_epoch all -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-renumbered-extra --no-literal-spmm --no-graph
+bash tools/pmc_passes.sh $o/pmc_epoch all -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-literal-spmm --no-graph
 for k in k_mix_fwd k_mix_bwd k_adam_rows k_xform_mfma_fwd k_xform_mfma_dw k_spmm_t_live; do
   echo "## $k"; python3 tools/pmc_summary.py $o $k | tail -n +3
 done > $o/epoch_pmc.md
 rm -rf $o/pmc_epoch_*/
 python3 tools/seed_median.py > $o/seeds.json 2> $o/seeds.err
+python3 bench.py --workload fb15k > $o/bench_fb15k.json 2> $o/bench_fb15k.err
+python3 bench.py --value-mode ref_int8 --no-cpu-baseline > $o/bench_ref_int8.json 2> $o/bench_ref_int8.err
 ls -la $o

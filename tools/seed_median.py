@@ -22,7 +22,7 @@ def main():
     for seed in a.seeds:
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup",
                               str(a.warmup), "--seed", str(seed), "--no-cpu-baseline", "--no-renumbered-extra",
-                              "--no-literal-spmm"], capture_output=True, text=True, cwd=ROOT)
+                              "--no-literal-spmm", "--no-reference-loop"], capture_output=True, text=True, cwd=ROOT)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
         if out.returncode != 0 or not line:
             runs.append({"seed": seed, "error": (out.stderr or out.stdout)[-400:]})
