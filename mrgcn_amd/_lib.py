@@ -77,6 +77,10 @@ SIGNATURES = {
                                                    _i64, _p]),
     "mrgcn_rows_nonzero_f32": (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
     "mrgcn_spmm_transposed_live_scratch": (C.c_int64, [_p]),
+    "mrgcn_spmm_transposed_live_flagged_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _p]),
+    "mrgcn_rel_transform_bwd_masked_supported": (C.c_int32, [_p, _i32, _i32, _i64]),
+    "mrgcn_rel_transform_bwd_masked_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p,
+                                                     _i64, _i32, _p, _p]),
     "mrgcn_spmm_transposed_live_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p]),
     "mrgcn_relu_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "mrgcn_relu_bwd_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _i64, _p]),

@@ -71,6 +71,21 @@ struct SparseView {
 
 struct mrgcn_plan;
 namespace mrgcn {
+// One relation-major order of the compact columns: (node band, relation, node), cut into chunks of <= kRelChunk
+// columns of one (band, relation) group — what the per-relation dense transforms walk.  A plan keeps two: bands of
+// kNodeBand nodes for wide inputs (layer 0's X rows) and bands of kNodeBandNarrow nodes for narrow ones (a hidden
+// layer's 40-byte rows: a band of them then stays inside one XCD's L2).
+struct RelOrder {
+  const int32_t *rperm = nullptr;   // [ncols] compact ids in the order
+  const int32_t *rnode = nullptr;   // [ncols] source node of each
+  const int32_t *rmpos = nullptr;   // [ncols] operand row of each
+  const int32_t *relchunk_rel = nullptr, *relchunk_beg = nullptr, *relchunk_end = nullptr;  // [n_relchunks]
+  const int32_t *relchunk_ptr = nullptr;  // [R+1] range of each relation inside relchunk_ids
+  const int32_t *relchunk_ids = nullptr;  // [n_relchunks] chunk ids grouped by relation
+  int32_t n_relchunks = 0, max_relchunks = 0;
+};
+constexpr int kNarrowInput = 32;       // inputs of up to this many floats per row take the narrow order
+constexpr int kNodeBandNarrow = 32768; // source nodes per band of the narrow order
 // bf16 <-> f32 (raw uint16_t storage; round to nearest even, NaN kept quiet)
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
@@ -91,14 +106,16 @@ template <typename OT> __device__ __forceinline__ float load_operand(const OT *p
 bool xform_mfma_fwd_supported(int K, int F);
 bool xform_mfma_dw_supported(int K, int F);
 bool xform_mfma_dw_live_supported(int K, int F);
-int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
-                   int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out, int64_t ldOut,
-                   hipStream_t s, bool out_bf16 = false, const uint8_t *col_live = nullptr);
-int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, int64_t ldIn, int K,
-                  const float *G, int64_t ldG, int F, float *dW, float *workspace,
+// `o`: the relation-major order to walk; rin_idx / rout_idx (nullable) must belong to the same order
+int xform_mfma_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const int32_t *rout_idx,
+                   const float *In, int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out,
+                   int64_t ldOut, hipStream_t s, bool out_bf16 = false, const uint8_t *col_live = nullptr);
+int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const float *In, int64_t ldIn,
+                  int K, const float *G, int64_t ldG, int F, float *dW, float *workspace,
                   int64_t workspace_floats, hipStream_t s, const uint8_t *col_live = nullptr);
 int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *dX, int64_t lddX,
-                hipStream_t s, const uint8_t *col_live = nullptr);
+                hipStream_t s, const uint8_t *col_live = nullptr, const float *mask_src = nullptr,
+                int64_t ldMask = 0, uint8_t *row_live = nullptr);
 }  // namespace mrgcn
 
 struct mrgcn_plan {
@@ -138,6 +155,25 @@ struct mrgcn_plan {
   int32_t *relchunk_ids = nullptr;  // [n_relchunks] chunk ids grouped by relation
   int32_t n_relchunks = 0, max_relchunks = 0;
   int32_t top_rel = -1;  // relation with the most compact columns (the identity block in the reference's layout)
+  // the same order with narrow bands (kNodeBandNarrow) for transforms of narrow inputs; empty when the graph has a
+  // single band either way
+  int32_t *n_rperm = nullptr, *n_relptr = nullptr, *n_rnode = nullptr, *n_rmpos = nullptr, *n_relchunk_rel = nullptr,
+          *n_relchunk_beg = nullptr, *n_relchunk_end = nullptr, *n_relchunk_ptr = nullptr, *n_relchunk_ids = nullptr;
+  int32_t n_n_relchunks = 0, n_max_relchunks = 0;
+  int64_t n_node_band = 0, n_n_bands = 0;
+  mrgcn::RelOrder order_for(int input_width) const {
+    mrgcn::RelOrder o;
+    if (input_width <= mrgcn::kNarrowInput && n_rperm) {
+      o.rperm = n_rperm; o.rnode = n_rnode; o.rmpos = n_rmpos; o.relchunk_rel = n_relchunk_rel;
+      o.relchunk_beg = n_relchunk_beg; o.relchunk_end = n_relchunk_end; o.relchunk_ptr = n_relchunk_ptr;
+      o.relchunk_ids = n_relchunk_ids; o.n_relchunks = n_n_relchunks; o.max_relchunks = n_max_relchunks;
+    } else {
+      o.rperm = rperm; o.rnode = rnode; o.rmpos = rmpos; o.relchunk_rel = relchunk_rel;
+      o.relchunk_beg = relchunk_beg; o.relchunk_end = relchunk_end; o.relchunk_ptr = relchunk_ptr;
+      o.relchunk_ids = relchunk_ids; o.n_relchunks = n_relchunks; o.max_relchunks = max_relchunks;
+    }
+    return o;
+  }
   // split-row descriptors, one set per orientation
   int32_t *r_long_row = nullptr, *r_long_cptr = nullptr, *r_chunk_beg = nullptr, *r_chunk_end = nullptr,
           *r_chunk_row = nullptr;

@@ -487,6 +487,85 @@ int bits_for(int64_t max_value) {
   return b;
 }
 
+// one relation-major order of the compact columns with bands of `band` source nodes (common.hpp: RelOrder)
+int build_rel_order(mrgcn_plan *p, Scratch &sc, hipStream_t s, int64_t band, bool set_top_rel, int32_t **rperm,
+                    int32_t **relptr, int32_t **rc_rel, int32_t **rc_beg, int32_t **rc_end, int32_t **rc_ptr,
+                    int32_t **rc_ids, int32_t *n_chunks, int32_t *max_chunks, int64_t *band_out,
+                    int64_t *nbands_out) {
+  const int64_t N = p->num_nodes, R = p->num_relations, ncols = p->ncols;
+  MRGCN_HIP_TRY(plan_alloc(p, rperm, ncols));
+  const int64_t nbands = (N + band - 1) / band;
+  *band_out = band;
+  *nbands_out = nbands;
+  const int64_t ngroups = nbands * R;
+  MRGCN_HIP_TRY(plan_alloc(p, relptr, ngroups + 1));
+  int32_t *ids;
+  int64_t *k3, *k3_s;
+  MRGCN_HIP_TRY(sc.alloc(&ids, ncols));
+  MRGCN_HIP_TRY(sc.alloc(&k3, ncols));
+  MRGCN_HIP_TRY(sc.alloc(&k3_s, ncols));
+  if (ncols > 0) {
+    k_band_keys<<<nblocks(ncols), kTB, 0, s>>>(p->unode, p->urel, ncols, R, band, k3, ids);
+    MRGCN_HIP_TRY(hipGetLastError());
+    size_t tb = 0;
+    const int end_bit = bits_for(ngroups * band + band);
+    MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k3, k3_s, ids, *rperm, (int)ncols, 0, end_bit, s));
+    char *tmp;
+    MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
+    MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k3, k3_s, ids, *rperm, (int)ncols, 0, end_bit, s));
+  }
+  k_lower_bound_ptr<<<nblocks(ngroups + 1), kTB, 0, s>>>(k3_s, ncols, ngroups, band, *relptr);
+  MRGCN_HIP_TRY(hipGetLastError());
+  // chunks (<= kRelChunk columns of one (band, relation) group each), built on the host
+  std::vector<int32_t> h_gptr(ngroups + 1);
+  MRGCN_HIP_TRY(hipMemcpyAsync(h_gptr.data(), *relptr, (ngroups + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  int rel_chunk = kRelChunk;
+  if (const char *e = getenv("MRGCN_REL_CHUNK"))  // experiments; the live-column lists hold kRelChunk
+    rel_chunk = (atoi(e) > 15 && atoi(e) <= kRelChunk) ? atoi(e) : rel_chunk;
+  std::vector<int32_t> rel, beg, end;
+  std::vector<std::vector<int32_t>> by_rel(R);
+  for (int64_t g = 0; g < ngroups; ++g) {
+    const int32_t r = (int32_t)(g % R);
+    for (int32_t b0 = h_gptr[g]; b0 < h_gptr[g + 1]; b0 += rel_chunk) {
+      by_rel[r].push_back((int32_t)rel.size());
+      rel.push_back(r);
+      beg.push_back(b0);
+      end.push_back(std::min(b0 + rel_chunk, h_gptr[g + 1]));
+    }
+  }
+  if (set_top_rel) {  // the relation with the most compact columns: k_mix_bwd_nm keeps its dcomp row in registers
+    std::vector<int64_t> per_rel(R, 0);
+    for (int64_t g = 0; g < ngroups; ++g) per_rel[g % R] += h_gptr[g + 1] - h_gptr[g];
+    int64_t best = 0;
+    for (int64_t r = 0; r < R; ++r)
+      if (per_rel[r] > best) { best = per_rel[r]; p->top_rel = (int32_t)r; }
+  }
+  std::vector<int32_t> cptr_rel(R + 1, 0), ids_by_rel;
+  *max_chunks = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    cptr_rel[r] = (int32_t)ids_by_rel.size();
+    ids_by_rel.insert(ids_by_rel.end(), by_rel[r].begin(), by_rel[r].end());
+    *max_chunks = std::max(*max_chunks, (int32_t)by_rel[r].size());
+  }
+  cptr_rel[R] = (int32_t)ids_by_rel.size();
+  *n_chunks = (int32_t)rel.size();
+  MRGCN_HIP_TRY(plan_alloc(p, rc_ptr, R + 1));
+  MRGCN_HIP_TRY(hipMemcpy(*rc_ptr, cptr_rel.data(), (R + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  MRGCN_HIP_TRY(plan_alloc(p, rc_ids, *n_chunks));
+  MRGCN_HIP_TRY(plan_alloc(p, rc_rel, *n_chunks));
+  MRGCN_HIP_TRY(plan_alloc(p, rc_beg, *n_chunks));
+  MRGCN_HIP_TRY(plan_alloc(p, rc_end, *n_chunks));
+  if (*n_chunks > 0) {
+    size_t nb = rel.size() * sizeof(int32_t);
+    MRGCN_HIP_TRY(hipMemcpy(*rc_ids, ids_by_rel.data(), nb, hipMemcpyHostToDevice));
+    MRGCN_HIP_TRY(hipMemcpy(*rc_rel, rel.data(), nb, hipMemcpyHostToDevice));
+    MRGCN_HIP_TRY(hipMemcpy(*rc_beg, beg.data(), nb, hipMemcpyHostToDevice));
+    MRGCN_HIP_TRY(hipMemcpy(*rc_end, end.data(), nb, hipMemcpyHostToDevice));
+  }
+  return MRGCN_OK;
+}
+
 int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_t *cols,
                 const void *vals, int val_dtype, uint32_t flags, hipStream_t s, const StraddleSizes &hint) {
   const int64_t N = p->num_nodes, R = p->num_relations, RN = R * N;
@@ -599,82 +678,23 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   // node).  Within a band of kNodeBand source nodes the columns are relation-major (one weight
   // tile per group); banding keeps the input rows a group gathers (X / H / dM) inside a window
   // that stays cache resident while every relation of the band is processed, instead of
-  // re-streaming the whole input once per relation.
-  MRGCN_HIP_TRY(plan_alloc(p, &p->rperm, ncols));
+  // re-streaming the whole input once per relation.  Two orders: wide bands for wide inputs, narrow bands
+  // (kNodeBandNarrow) for narrow ones — a band of 40-byte rows then fits one XCD's L2 (common.hpp: RelOrder).
   int64_t band = kNodeBand;
   if (const char *e = getenv("MRGCN_NODE_BAND")) band = atoll(e) > 0 ? atoll(e) : band;  // experiments
   if (band > N) band = N;
-  const int64_t nbands = (N + band - 1) / band;
-  p->node_band = band;
-  p->n_bands = nbands;
-  const int64_t ngroups = nbands * R;
-  MRGCN_HIP_TRY(plan_alloc(p, &p->relptr, ngroups + 1));
   {
-    int32_t *ids;
-    int64_t *k3, *k3_s;
-    MRGCN_HIP_TRY(sc.alloc(&ids, ncols));
-    MRGCN_HIP_TRY(sc.alloc(&k3, ncols));
-    MRGCN_HIP_TRY(sc.alloc(&k3_s, ncols));
-    if (ncols > 0) {
-      k_band_keys<<<nblocks(ncols), kTB, 0, s>>>(p->unode, p->urel, ncols, R, band, k3, ids);
-      MRGCN_HIP_TRY(hipGetLastError());
-      size_t tb = 0;
-      const int end_bit = bits_for(ngroups * band + band);
-      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k3, k3_s, ids, p->rperm, (int)ncols, 0,
-                                                       end_bit, s));
-      char *tmp;
-      MRGCN_HIP_TRY(sc.alloc(&tmp, (int64_t)tb));
-      MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k3, k3_s, ids, p->rperm, (int)ncols, 0,
-                                                       end_bit, s));
-    }
-    k_lower_bound_ptr<<<nblocks(ngroups + 1), kTB, 0, s>>>(k3_s, ncols, ngroups, band, p->relptr);
-    MRGCN_HIP_TRY(hipGetLastError());
-    // chunks (<= kRelChunk columns of one (band, relation) group each), built on the host
-    std::vector<int32_t> h_gptr(ngroups + 1);
-    MRGCN_HIP_TRY(hipMemcpyAsync(h_gptr.data(), p->relptr, (ngroups + 1) * sizeof(int32_t),
-                                 hipMemcpyDeviceToHost, s));
-    MRGCN_HIP_TRY(hipStreamSynchronize(s));
-    int rel_chunk = kRelChunk;
-    if (const char *e = getenv("MRGCN_REL_CHUNK"))  // experiments; the live-column lists hold kRelChunk
-      rel_chunk = (atoi(e) > 15 && atoi(e) <= kRelChunk) ? atoi(e) : rel_chunk;
-    std::vector<int32_t> rel, beg, end;
-    std::vector<std::vector<int32_t>> by_rel(R);
-    for (int64_t g = 0; g < ngroups; ++g) {
-      const int32_t r = (int32_t)(g % R);
-      for (int32_t b0 = h_gptr[g]; b0 < h_gptr[g + 1]; b0 += rel_chunk) {
-        by_rel[r].push_back((int32_t)rel.size());
-        rel.push_back(r);
-        beg.push_back(b0);
-        end.push_back(std::min(b0 + rel_chunk, h_gptr[g + 1]));
-      }
-    }
-    {  // the relation with the most compact columns: k_mix_bwd_nm keeps its dcomp row in registers
-      std::vector<int64_t> per_rel(R, 0);
-      for (int64_t g = 0; g < ngroups; ++g) per_rel[g % R] += h_gptr[g + 1] - h_gptr[g];
-      int64_t best = 0;
-      for (int64_t r = 0; r < R; ++r)
-        if (per_rel[r] > best) { best = per_rel[r]; p->top_rel = (int32_t)r; }
-    }
-    std::vector<int32_t> cptr_rel(R + 1, 0), ids_by_rel;
-    for (int64_t r = 0; r < R; ++r) {
-      cptr_rel[r] = (int32_t)ids_by_rel.size();
-      ids_by_rel.insert(ids_by_rel.end(), by_rel[r].begin(), by_rel[r].end());
-      p->max_relchunks = std::max(p->max_relchunks, (int32_t)by_rel[r].size());
-    }
-    cptr_rel[R] = (int32_t)ids_by_rel.size();
-    p->n_relchunks = (int32_t)rel.size();
-    MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_ptr, R + 1));
-    MRGCN_HIP_TRY(hipMemcpy(p->relchunk_ptr, cptr_rel.data(), (R + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-    MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_ids, p->n_relchunks));
-    MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_rel, p->n_relchunks));
-    MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_beg, p->n_relchunks));
-    MRGCN_HIP_TRY(plan_alloc(p, &p->relchunk_end, p->n_relchunks));
-    if (p->n_relchunks > 0) {
-      size_t nb = rel.size() * sizeof(int32_t);
-      MRGCN_HIP_TRY(hipMemcpy(p->relchunk_ids, ids_by_rel.data(), nb, hipMemcpyHostToDevice));
-      MRGCN_HIP_TRY(hipMemcpy(p->relchunk_rel, rel.data(), nb, hipMemcpyHostToDevice));
-      MRGCN_HIP_TRY(hipMemcpy(p->relchunk_beg, beg.data(), nb, hipMemcpyHostToDevice));
-      MRGCN_HIP_TRY(hipMemcpy(p->relchunk_end, end.data(), nb, hipMemcpyHostToDevice));
+    int rc0 = build_rel_order(p, sc, s, band, true, &p->rperm, &p->relptr, &p->relchunk_rel, &p->relchunk_beg,
+                              &p->relchunk_end, &p->relchunk_ptr, &p->relchunk_ids, &p->n_relchunks,
+                              &p->max_relchunks, &p->node_band, &p->n_bands);
+    if (rc0 != MRGCN_OK) return rc0;
+    int64_t nband = kNodeBandNarrow;
+    if (const char *e = getenv("MRGCN_NODE_BAND_NARROW")) nband = atoll(e);  // experiments; <= 0: no second order
+    if (nband > 0 && nband < band) {
+      rc0 = build_rel_order(p, sc, s, nband, false, &p->n_rperm, &p->n_relptr, &p->n_relchunk_rel, &p->n_relchunk_beg,
+                            &p->n_relchunk_end, &p->n_relchunk_ptr, &p->n_relchunk_ids, &p->n_n_relchunks,
+                            &p->n_max_relchunks, &p->n_node_band, &p->n_n_bands);
+      if (rc0 != MRGCN_OK) return rc0;
     }
   }
   MRGCN_HIP_TRY(hipStreamSynchronize(s));
@@ -838,6 +858,12 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   if (ncols > 0) {
     k_gather_i32<<<nblocks(ncols), kTB, 0, s>>>(p->unode, p->rperm, ncols, p->rnode);
     k_gather_i32<<<nblocks(ncols), kTB, 0, s>>>(p->mpos, p->rperm, ncols, p->rmpos);
+    if (p->n_rperm) {
+      MRGCN_HIP_TRY(plan_alloc(p, &p->n_rnode, ncols));
+      MRGCN_HIP_TRY(plan_alloc(p, &p->n_rmpos, ncols));
+      k_gather_i32<<<nblocks(ncols), kTB, 0, s>>>(p->unode, p->n_rperm, ncols, p->n_rnode);
+      k_gather_i32<<<nblocks(ncols), kTB, 0, s>>>(p->mpos, p->n_rperm, ncols, p->n_rmpos);
+    }
     MRGCN_HIP_TRY(hipGetLastError());
     MRGCN_HIP_TRY(hipStreamSynchronize(s));
   }
@@ -919,7 +945,9 @@ void free_plan(mrgcn_plan *p) {
                       q->r3_long_row, q->r3_long_cptr, q->r3_chunk_beg, q->r3_chunk_end, q->r3_chunk_row,
                       q->q_long_row, q->q_long_cptr, q->q_chunk_beg, q->q_chunk_end, q->q_chunk_row, q->rowmap, q->ptr3,
                       q->rep_src, q->rep_dst, q->partials, q->r3_multi, q->r3_ticket,
-                      q->r3s_long_row, q->r3s_long_cptr, q->r3s_chunk_beg, q->r3s_chunk_end, q->r3s_chunk_row};
+                      q->r3s_long_row, q->r3s_long_cptr, q->r3s_chunk_beg, q->r3s_chunk_end, q->r3s_chunk_row,
+                      q->n_rperm, q->n_relptr, q->n_rnode, q->n_rmpos, q->n_relchunk_rel, q->n_relchunk_beg,
+                      q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids};
       for (void *a : ptrs)
         if (a) (void)hipFreeAsync(a, nullptr);
       delete q;

@@ -1243,14 +1243,15 @@ int rel_transform_fwd_impl(const mrgcn_plan_t *p, const float *X, int64_t ldX, i
   MRGCN_REQUIRE(p && X && W && Out, "NULL");
   MRGCN_REQUIRE(K > 0 && F > 0 && ldX >= K && ldOut >= F, "K / F / leading dimensions");
   MRGCN_REQUIRE(F <= 64, "rel_transform supports F <= 64 (tile the feature dimension)");
-  if (p->n_relchunks == 0) return MRGCN_OK;
+  const RelOrder o = p->order_for(K);  // narrow inputs: the order with narrow node bands
+  if (o.n_relchunks == 0) return MRGCN_OK;
   const int32_t *oidx = operand_order ? p->mpos : nullptr;
   if (use_mfma() && xform_mfma_fwd_supported(K, F))
-    return xform_mfma_fwd(p, p->rnode, operand_order ? p->rmpos : nullptr, X, ldX, K, W, false, F, Out,
+    return xform_mfma_fwd(p, o, o.rnode, operand_order ? o.rmpos : nullptr, X, ldX, K, W, false, F, Out,
                           ldOut, (hipStream_t)stream, sizeof(OT) == 2);
   size_t lds = ((size_t)kKS * F + (size_t)kTK * (kKS + 1)) * sizeof(float);
-  k_xform_fwd<OT><<<dim3(p->n_relchunks), dim3(kTB), lds, (hipStream_t)stream>>>(
-      p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, p->unode, oidx, X, ldX, K, W, F,
+  k_xform_fwd<OT><<<dim3(o.n_relchunks), dim3(kTB), lds, (hipStream_t)stream>>>(
+      o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, p->unode, oidx, X, ldX, K, W, F,
       (int)ldOut, Out, ldOut);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
@@ -1519,7 +1520,7 @@ int64_t mrgcn_rel_transform_bwd_workspace(const mrgcn_plan_t *p, int32_t K, int3
                                           int32_t need_dW) {
   if (!p) return 0;
   int64_t a = need_dX ? p->ncols * (((int64_t)K + 3) / 4 * 4) : 0;
-  int64_t b = need_dW ? (int64_t)p->n_relchunks * K * F : 0;
+  int64_t b = need_dW ? (int64_t)p->order_for(K).n_relchunks * K * F : 0;
   return a > b ? a : b;
 }
 
@@ -1535,7 +1536,24 @@ int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *p, float *dM, int64_t l
                                      const uint8_t *col_live, const float *X, int64_t ldX, int32_t K,
                                      const float *W, int32_t F, float *dX, int64_t lddX, float *dW,
                                      float *workspace, int64_t workspace_floats, void *stream) {
+  return mrgcn_rel_transform_bwd_masked_f32(p, dM, ldM, col_live, X, ldX, K, W, F, dX, lddX, dW, workspace,
+                                            workspace_floats, 0, nullptr, stream);
+}
+
+int32_t mrgcn_rel_transform_bwd_masked_supported(const mrgcn_plan_t *p, int32_t K, int32_t F, int64_t workspace_floats) {
+  const int64_t ldZ = ((int64_t)K + 3) / 4 * 4;
+  return p && K <= 16 && use_mfma() && workspace_floats >= p->ncols * ldZ && xform_mfma_fwd_supported(F, K);
+}
+
+int mrgcn_rel_transform_bwd_masked_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM,
+                                       const uint8_t *col_live, const float *X, int64_t ldX, int32_t K,
+                                       const float *W, int32_t F, float *dX, int64_t lddX, float *dW,
+                                       float *workspace, int64_t workspace_floats, int32_t relu_mask_from_x,
+                                       uint8_t *row_live_out, void *stream) {
   MRGCN_REQUIRE(p && dM && X && W, "NULL");
+  MRGCN_REQUIRE(!(relu_mask_from_x || row_live_out) ||
+                    (dX && mrgcn_rel_transform_bwd_masked_supported(p, K, F, workspace ? workspace_floats : 0)),
+                "the masked / flagged dX needs K <= 16 and the matrix-core path (see ..._masked_supported)");
   MRGCN_REQUIRE(K > 0 && F > 0 && ldX >= K && ldM >= F, "K / F / leading dimensions");
   MRGCN_REQUIRE(F <= 64, "rel_transform supports F <= 64 (tile the feature dimension)");
   hipStream_t s = (hipStream_t)stream;
@@ -1554,7 +1572,8 @@ int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *p, float *dM, int64_t l
   if (dW) {
     MRGCN_HIP_TRY(hipMemsetAsync(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
     if (use_mfma() && xform_mfma_dw_supported(K, F)) {
-      int rc = xform_mfma_dw(p, p->rnode, X, ldX, K, dM, ldM, F, dW, workspace, workspace_floats, s, col_live);
+      const RelOrder o = p->order_for(K);
+      int rc = xform_mfma_dw(p, o, o.rnode, X, ldX, K, dM, ldM, F, dW, workspace, workspace_floats, s, col_live);
       if (rc != MRGCN_OK) return rc;
     } else if (p->n_relchunks > 0) {
       size_t lds = ((size_t)kTK * (kKS + 1) + (size_t)kTK * F) * sizeof(float);
@@ -1567,9 +1586,11 @@ int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *p, float *dM, int64_t l
   if (dX && use_mfma() && workspace && workspace_floats >= p->ncols * ldZ && xform_mfma_fwd_supported(F, K)) {
     // Z[c, 0:K] = dM[c, 0:F] . W[r_c]^T on the matrix cores, then dX[j] = sum of node j's Z rows
     MRGCN_REQUIRE(lddX >= K, "lddX");
-    int rc = xform_mfma_fwd(p, nullptr, nullptr, dM, ldM, F, W, true, K, workspace, ldZ, s, false, col_live);
+    // (rows of dM and of Z in plain compact order; the walk follows the order of the narrower of the two)
+    int rc = xform_mfma_fwd(p, p->order_for(F), nullptr, nullptr, dM, ldM, F, W, true, K, workspace, ldZ, s, false,
+                            col_live);
     if (rc != MRGCN_OK) return rc;
-    rc = segment_sum(p, workspace, ldZ, K, dX, lddX, s, col_live);
+    rc = segment_sum(p, workspace, ldZ, K, dX, lddX, s, col_live, relu_mask_from_x ? X : nullptr, ldX, row_live_out);
     if (rc != MRGCN_OK) return rc;
   } else if (dX) {
     MRGCN_REQUIRE(lddX >= K, "lddX");

@@ -758,18 +758,24 @@ __global__ __launch_bounds__(256) void k_spmm_tiny(SparseView v, const float *__
 // every compact column in them (`ccol`: the compact column of each entry, row-major order).
 // Plain byte stores of the same value: no atomics.  Rows longer than kLongThreshold are left to
 // k_long_rows_mark.  `col_live` was zeroed before.
+// `flags_in` (nullable): the row flags are known already (the producer of D wrote them) — D is not scanned
 __global__ __launch_bounds__(256) void k_rows_live_mark(const float *__restrict__ D, int64_t ldD, int F,
                                                         int64_t nrows, const int32_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ ccol,
                                                         uint8_t *__restrict__ row_live,
                                                         uint8_t *__restrict__ col_live,
-                                                        int32_t *__restrict__ n_live) {
+                                                        int32_t *__restrict__ n_live,
+                                                        const uint8_t *__restrict__ flags_in) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   bool nz = false;
   if (i < nrows) {
-    const float *row = D + i * ldD;
-    for (int q = 0; q < F; ++q) nz |= row[q] != 0.f;
+    if (flags_in) {
+      nz = flags_in[i] != 0;
+    } else {
+      const float *row = D + i * ldD;
+      for (int q = 0; q < F; ++q) nz |= row[q] != 0.f;
+    }
     row_live[i] = nz ? 1 : 0;
   }
   if (n_live) {
@@ -1168,6 +1174,15 @@ extern "C" int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const fl
                                               int32_t F, float *Y, int64_t ldY, uint8_t *scratch,
                                               uint8_t *col_live, int32_t *live_rows,
                                               int32_t write_dead_rows, void *stream) {
+  return mrgcn_spmm_transposed_live_flagged_f32(plan, D, ldD, F, Y, ldY, scratch, col_live, live_rows,
+                                                write_dead_rows, nullptr, stream);
+}
+
+extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, const float *D, int64_t ldD,
+                                                      int32_t F, float *Y, int64_t ldY, uint8_t *scratch,
+                                                      uint8_t *col_live, int32_t *live_rows,
+                                                      int32_t write_dead_rows, const uint8_t *row_flags,
+                                                      void *stream) {
   using namespace mrgcn;
   MRGCN_REQUIRE(plan, "plan is NULL");
   MRGCN_REQUIRE(F > 0 && ldD >= F && ldY >= F, "F / leading dimensions");
@@ -1187,7 +1202,8 @@ extern "C" int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const fl
   if (write_dead_rows && v.rows > 0) MRGCN_HIP_TRY(hipMemsetAsync(Y, 0, (size_t)v.rows * ldY * sizeof(float), s));
   if (plan->num_rows > 0 && v.rows > 0) {
     k_rows_live_mark<<<dim3((unsigned)((plan->num_rows + 255) / 256)), dim3(256), 0, s>>>(
-        D, ldD, F, plan->num_rows, plan->rowptr, plan->ccol, row_live, col_live, live_rows);
+        D, ldD, F, plan->num_rows, plan->rowptr, plan->ccol, row_live, col_live, live_rows,
+        F <= 16 ? row_flags : nullptr);
     MRGCN_HIP_TRY(hipGetLastError());
     SparseView rv = plan->view(MRGCN_VIEW_LITERAL);  // row-major entry coordinates, as `ccol`
     if (rv.n_chunks > 0) {

@@ -407,6 +407,59 @@ __global__ void k_segment_sum_live(const int32_t *__restrict__ nptr, const float
   }
 }
 
+// The layer-input gradient of a hidden layer, finished in one pass: dX[j] = sum of node j's live Z rows, times the
+// ReLU mask of the layer's input when that input is the output of a fused ReLU (mask_src = the input itself:
+// H > 0 is the mask of the ReLU that produced H — the producing layer's backward then has nothing left to mask),
+// plus one byte per row: does it hold anything but zeros (what mrgcn_spmm_transposed_live_flagged_f32 of the layer
+// below takes instead of scanning dX again).  A thread sums one node; the 256 rows of a block leave through LDS as
+// coalesced stores (thread-per-row stores of 40-byte rows were the cost of k_segment_sum_live).  Dead rows are
+// written as zeros: the result is a complete gradient tensor.
+template <int KT>
+__global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restrict__ nptr, const float *__restrict__ Z,
+                                                          int64_t ldZ, int64_t N, int K, float *__restrict__ dX,
+                                                          int64_t lddX, const uint8_t *__restrict__ col_live,
+                                                          const float *__restrict__ mask_src, int64_t ldMask,
+                                                          uint8_t *__restrict__ row_live) {
+  __shared__ float tile[256][KT + 1];
+  const int64_t j0 = (int64_t)blockIdx.x * 256;
+  const int64_t j = j0 + threadIdx.x;
+  float acc[KT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i) acc[i] = 0.f;
+  if (j < N) {
+    bool any = false;
+    const int32_t c1 = nptr[j + 1];
+    for (int32_t c = nptr[j]; c < c1; ++c) {
+      if (col_live && !col_live[c]) continue;
+      any = true;
+      const float *z = Z + (int64_t)c * ldZ;
+#pragma unroll
+      for (int i = 0; i < KT; ++i)
+        if (i < K) acc[i] += z[i];
+    }
+    bool nz = false;
+    if (any) {
+      if (mask_src) {
+        const float *m = mask_src + j * ldMask;
+#pragma unroll
+        for (int i = 0; i < KT; ++i)
+          if (i < K && !(m[i] > 0.f)) acc[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < KT; ++i) nz |= acc[i] != 0.f;
+    }
+    if (row_live) row_live[j] = nz ? 1 : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < KT; ++i) tile[threadIdx.x][i] = acc[i];
+  __syncthreads();
+  const int64_t rows = min((int64_t)256, N - j0);
+  for (int e = threadIdx.x; e < rows * K; e += 256) {
+    const int node = e / K, i = e - node * K;
+    dX[(j0 + node) * lddX + i] = tile[node][i];
+  }
+}
+
 }  // namespace
 
 // ---- launchers used by the C ABI entry points in rgcn_fused.hip -------------------------------
@@ -418,10 +471,10 @@ bool xform_mfma_dw_live_supported(int K, int F) {
 }
 
 
-int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *rout_idx, const float *In,
-                   int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out, int64_t ldOut,
-                   hipStream_t s, bool out_bf16, const uint8_t *col_live) {
-  if (p->n_relchunks == 0) return MRGCN_OK;
+int xform_mfma_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const int32_t *rout_idx,
+                   const float *In, int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out,
+                   int64_t ldOut, hipStream_t s, bool out_bf16, const uint8_t *col_live) {
+  if (o.n_relchunks == 0) return MRGCN_OK;
   int NT = (int)((ldOut < 64 ? ldOut : 64) + 15) / 16;  // tiles that cover the padded row
   if (NT < (F + 15) / 16) NT = (F + 15) / 16;
   const int ksteps = (K + 15) / 16;
@@ -435,12 +488,12 @@ int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *r
 #define XF_LIVE(N_)                                                                                        \
   do {                                                                                                     \
     if (ksteps <= 1)                                                                                       \
-      k_xform_mfma_fwd<N_, true, 1, float, true><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(             \
-          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, nullptr, nullptr, In, ldIn, K, W,   \
+      k_xform_mfma_fwd<N_, true, 1, float, true><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(             \
+          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, nullptr, nullptr, In, ldIn, K, W,   \
           F, (float *)Out, ldOut, col_live);                                                               \
     else                                                                                                   \
-      k_xform_mfma_fwd<N_, true, 4, float, true><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(             \
-          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, nullptr, nullptr, In, ldIn, K, W,   \
+      k_xform_mfma_fwd<N_, true, 4, float, true><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(             \
+          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, nullptr, nullptr, In, ldIn, K, W,   \
           F, (float *)Out, ldOut, col_live);                                                               \
   } while (0)
     switch (NT) { case 1: XF_LIVE(1); break; case 2: XF_LIVE(2); break;
@@ -452,16 +505,16 @@ int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *r
 #define XF_GO3(N_, T_, O_)                                                                              \
   do {                                                                                                  \
     if (ksteps <= 1)                                                                                    \
-      k_xform_mfma_fwd<N_, T_, 1, O_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                     \
-          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn,     \
+      k_xform_mfma_fwd<N_, T_, 1, O_><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                     \
+          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn,     \
           K, W, F, (O_ *)Out, ldOut, nullptr);                                                          \
     else if (ksteps <= 4)                                                                               \
-      k_xform_mfma_fwd<N_, T_, 4, O_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                     \
-          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn,     \
+      k_xform_mfma_fwd<N_, T_, 4, O_><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                     \
+          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn,     \
           K, W, F, (O_ *)Out, ldOut, nullptr);                                                          \
     else                                                                                                \
-      k_xform_mfma_fwd<N_, T_, kMaxKSteps, O_><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(            \
-          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, rout_idx, In, ldIn,     \
+      k_xform_mfma_fwd<N_, T_, kMaxKSteps, O_><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(            \
+          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn,     \
           K, W, F, (O_ *)Out, ldOut, nullptr);                                                          \
   } while (0)
 #define XF_GO(N_, T_)                                                  \
@@ -482,14 +535,14 @@ int xform_mfma_fwd(const mrgcn_plan *p, const int32_t *rin_idx, const int32_t *r
   return MRGCN_OK;
 }
 
-int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, int64_t ldIn, int K,
-                  const float *G, int64_t ldG, int F, float *dW, float *workspace,
+int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const float *In, int64_t ldIn,
+                  int K, const float *G, int64_t ldG, int F, float *dW, float *workspace,
                   int64_t workspace_floats, hipStream_t s, const uint8_t *col_live) {
-  if (p->n_relchunks == 0) return MRGCN_OK;
+  if (o.n_relchunks == 0) return MRGCN_OK;
   size_t lds = (size_t)4 * K * F * sizeof(float);
   if (col_live && lds + kLiveLds <= 64 * 1024) lds += kLiveLds;
   else col_live = nullptr;  // no room for the list: every column is swept (same result)
-  float *slab = (workspace && workspace_floats >= (int64_t)p->n_relchunks * K * F) ? workspace : nullptr;
+  float *slab = (workspace && workspace_floats >= (int64_t)o.n_relchunks * K * F) ? workspace : nullptr;
   // Unroll U (columns in flight per wave = 4 U) and tile count are chosen for registers, i.e. for
   // waves per SIMD — the pass waits on the gathered input rows (PMC: profiles/r01_xform_pmc.md).
   // AM shape, same run: K = 10: U = 8 / 4 / 2 -> 1.42 / 1.20 / 1.11 ms (with the dX half);
@@ -497,12 +550,12 @@ int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, 
 #define DW_GO(TQ_, U_)                                                                                   \
   do {                                                                                                   \
     if (col_live)                                                                                        \
-      k_xform_mfma_dw<TQ_, U_, true><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                       \
-          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F,  \
+      k_xform_mfma_dw<TQ_, U_, true><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                       \
+          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, In, ldIn, K, G, ldG, F,  \
           dW, slab, col_live);                                                                           \
     else                                                                                                 \
-      k_xform_mfma_dw<TQ_, U_, false><<<dim3(p->n_relchunks), dim3(256), lds, s>>>(                      \
-          p->relchunk_rel, p->relchunk_beg, p->relchunk_end, p->rperm, rin_idx, In, ldIn, K, G, ldG, F,  \
+      k_xform_mfma_dw<TQ_, U_, false><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                      \
+          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, In, ldIn, K, G, ldG, F,  \
           dW, slab, nullptr);                                                                            \
   } while (0)
   // (live form, K = 155, columns in flight per wave 4 / 8 / 16: 591 / 463 / 485 us)
@@ -512,10 +565,10 @@ int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, 
 #undef DW_GO
   MRGCN_HIP_TRY(hipGetLastError());
   if (slab) {
-    const int n_seg_max = (p->max_relchunks + kDwSeg - 1) / kDwSeg;
+    const int n_seg_max = (o.max_relchunks + kDwSeg - 1) / kDwSeg;
     if (n_seg_max > 0) {
       k_dw_reduce<<<dim3((unsigned)(p->num_relations * n_seg_max)), dim3(256), 0, s>>>(
-          p->relchunk_ids, p->relchunk_ptr, n_seg_max, slab, K * F, dW, (int)p->num_relations);
+          o.relchunk_ids, o.relchunk_ptr, n_seg_max, slab, K * F, dW, (int)p->num_relations);
       MRGCN_HIP_TRY(hipGetLastError());
     }
   }
@@ -523,7 +576,22 @@ int xform_mfma_dw(const mrgcn_plan *p, const int32_t *rin_idx, const float *In, 
 }
 
 int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *dX, int64_t lddX,
-                hipStream_t s, const uint8_t *col_live) {
+                hipStream_t s, const uint8_t *col_live, const float *mask_src, int64_t ldMask, uint8_t *row_live) {
+  if (K <= 16 && (mask_src || row_live || col_live) && p->num_nodes > 0) {  // the one-pass form
+    const dim3 grid((unsigned)((p->num_nodes + 255) / 256));
+    if (K <= 8)
+      k_segment_sum_mask<8><<<grid, dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, col_live, mask_src,
+                                                       ldMask, row_live);
+    else
+      k_segment_sum_mask<16><<<grid, dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, col_live, mask_src,
+                                                        ldMask, row_live);
+    MRGCN_HIP_TRY(hipGetLastError());
+    return MRGCN_OK;
+  }
+  if (mask_src || row_live) {
+    set_error("segment_sum: the masked / flagged form needs K <= 16");
+    return MRGCN_ERR_UNSUPPORTED;
+  }
   int64_t work = p->num_nodes * K;
   int64_t blocks = (work + 255) / 256;
   if (blocks > 4096) blocks = 4096;

@@ -228,6 +228,21 @@ def relu_bwd(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# Side channel between the backward passes of two stacked layers.  The upper layer's backward returns its input
+# gradient with a note attached to the tensor object: the ReLU mask of the lower layer's output is already applied,
+# and a byte per row says which rows hold anything.  The lower layer's backward trusts the note only while the tensor
+# is the very object, unchanged, that the upper layer returned: autograd hands a sole consumer's gradient through as
+# it is, and sums the gradients of several consumers either into a new tensor (no note) or in place (the tensor's
+# version counter moves) — in both cases the lower layer falls back to masking and scanning by itself.
+def _set_grad_meta(t, row_live, relu_applied: bool):
+    t._mrgcn_grad_meta = {"version": t._version, "row_live": row_live, "relu_applied": bool(relu_applied)}
+
+
+def _grad_meta(t):
+    m = getattr(t, "_mrgcn_grad_meta", None)
+    return m if (m is not None and m["version"] == t._version) else None
+
+
 class _RgcnLayer(torch.autograd.Function):
     """Y = relu?( A' . M + b ),  M[c] = comp_I[r_c] . V_I[j_c, :, :]  (or weight_I[r_c*N + j_c])
                                        + X[j_c] . W_F[r_c]
@@ -281,6 +296,9 @@ class _RgcnLayer(torch.autograd.Function):
         Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu,
                       padded_rows=bool(getattr(owner, "padded_output", False)))
         ctx.plan, ctx.F, ctx.ld, ctx.relu, ctx.owner = plan, F, ld, relu, owner
+        # the layer's input is the output of a fused ReLU (marked by the layer that made it): its own sign is that
+        # ReLU's mask, so this layer's backward can hand its input gradient on already masked
+        ctx.x_is_relu_out = X is not None and bool(getattr(X, "_mrgcn_relu_out", False))
         ctx.has = (weight_I is not None, comp_I is not None, X is not None, bias is not None)
         ctx.save_for_backward(weight_I, comp_I, Xc, Wc, Y if relu else None)
         return Y
@@ -294,8 +312,13 @@ class _RgcnLayer(torch.autograd.Function):
         dev = plan.device
         s = _stream(dev)
         dY = dY.contiguous()
-        if ctx.relu:
+        # what the layer above knows about this gradient (see `_grad_meta`): its ReLU mask is applied already, and
+        # which of its rows hold anything
+        meta = _grad_meta(dY)
+        row_flags = meta["row_live"] if meta else None
+        if ctx.relu and not (meta and meta["relu_applied"]):
             dY = relu_bwd(dY, Y)
+            row_flags = None
         dbias = dY.sum(0) if has_bias else None
         # dM = A'^T dY over touched columns only, plain compact order (its consumers are node-major)
         ld = (F + 3) // 4 * 4
@@ -313,10 +336,13 @@ class _RgcnLayer(torch.autograd.Function):
             # rows of dM without gradient are not even written when every consumer goes by the flags
             # (the no-bases scatter reads dM itself)
             write_dead = int(has_I and not has_comp)
+            if row_flags is not None and (row_flags.numel() != plan.num_rows or row_flags.device != dev):
+                row_flags = None
             with torch.cuda.device(dev):
-                L.check(lib.mrgcn_spmm_transposed_live_f32(
+                L.check(lib.mrgcn_spmm_transposed_live_flagged_f32(
                     plan.handle, dY.data_ptr(), dY.stride(0), F, dM.data_ptr(), ld, scratch.data_ptr(),
-                    live.data_ptr(), gauge.dev.data_ptr(), write_dead, s), "mrgcn_spmm_transposed_live_f32")
+                    live.data_ptr(), gauge.dev.data_ptr(), write_dead,
+                    row_flags.data_ptr() if row_flags is not None else 0, s), "mrgcn_spmm_transposed_live_flagged_f32")
             gauge.publish()
         else:
             plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)
@@ -380,6 +406,7 @@ class _RgcnLayer(torch.autograd.Function):
                 need_dX = ctx.needs_input_grad[4]
                 need_dW = ctx.needs_input_grad[5]
                 K = X.shape[1]
+                dx_flags = None
                 with torch.cuda.stream(side):
                     if need_dX:
                         dX = torch.empty((X.shape[0], K), dtype=torch.float32, device=dev)
@@ -391,15 +418,23 @@ class _RgcnLayer(torch.autograd.Function):
                                                                         int(need_dW)))
                         if nws > 0:
                             ws = torch.empty((nws,), dtype=torch.float32, device=dev)
-                        L.check(lib.mrgcn_rel_transform_bwd_live_f32(
+                        # the input gradient leaves finished: masked by the ReLU that produced X (when X is such an
+                        # output) and with a flag per row — the layer below then neither masks nor scans it
+                        finish = need_dX and bool(lib.mrgcn_rel_transform_bwd_masked_supported(
+                            plan.handle, K, F, ws.numel() if ws is not None else 0))
+                        dx_flags = torch.empty((X.shape[0],), dtype=torch.uint8, device=dev) if finish else None
+                        L.check(lib.mrgcn_rel_transform_bwd_masked_f32(
                             plan.handle, dM.data_ptr(), ld, live.data_ptr() if live is not None else 0,
                             X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
                             dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0,
                             ws.data_ptr() if ws is not None else 0, ws.numel() if ws is not None else 0,
-                            side.cuda_stream), "mrgcn_rel_transform_bwd_live_f32")
+                            int(finish and ctx.x_is_relu_out), dx_flags.data_ptr() if finish else 0,
+                            side.cuda_stream), "mrgcn_rel_transform_bwd_masked_f32")
+                        if finish:
+                            _set_grad_meta(dX, dx_flags, finish and ctx.x_is_relu_out)
                 if overlap:
                     main.wait_stream(side)
-                    for t in (dX, dW, ws, dM, live):  # allocated / used on `side`: keep the allocator honest
+                    for t in (dX, dW, ws, dM, live, dx_flags):  # allocated / used on `side`: keep the allocator honest
                         if t is not None:
                             t.record_stream(side if (t is dM or t is live) else main)
         return None, None, d_wI, d_comp, dX, dW, dbias, None, None, None
@@ -431,4 +466,7 @@ def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False, input_term: bool =
     if weight_I is not None and comp_I is None and Xin is None and not bf16:
         # featureless layer without bases: weight_I already *is* the literal operand
         return spmm_literal(plan, weight_I, bias=bias, relu=relu)
-    return _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, bias, relu, bf16, layer)
+    Y = _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, bias, relu, bf16, layer)
+    if relu:
+        Y._mrgcn_relu_out = True  # (a Python attribute of this tensor object: a copy or a view does not carry it)
+    return Y

@@ -718,3 +718,75 @@ def test_adam_with_the_gradient_formed_on_the_fly_through_the_c_abi(N, R, B, F, 
     assert torch.equal(p[untouched], V[untouched])
     if zero_frac > 0:
         assert int(untouched.sum()) > 0 and int(((cur == 0) & (ever0 == 1)).sum()) > 0
+
+
+def test_layers_on_plans_with_many_narrow_and_wide_node_bands():
+    """The relation-major orders of the transforms (common.hpp: RelOrder — wide node bands for wide inputs, narrow
+    ones for inputs of <= 32 floats per row) only come apart on graphs of more than 32 768 nodes.  Here the band sizes
+    are shrunk through the environment (wide 512 nodes, narrow 64) and the golden / oracle layer tests run again in a
+    child process: forward, backward and epoch parity on plans where layer 0 (wide input) and layer 1 (narrow input)
+    walk different orders with many bands each."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRGCN_NODE_BAND="512", MRGCN_NODE_BAND_NARROW="64")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "tests/test_gpu_layers.py", "-k",
+                        "forward_backward_vs_reference or fused_layer_vs_oracle or epoch_steps_vs_reference or "
+                        "transform_backward_over_live"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
+def test_input_gradient_handed_down_masked_and_flagged_equals_the_plain_hand_off():
+    """A hidden layer's backward hands its input gradient to the layer below already multiplied by that layer's
+    ReLU mask and with a byte per row (functional._grad_meta) — the layer below then skips its own masking pass and
+    the scan for live rows.  Three stacked layers (two hand-offs), few labelled nodes: every gradient must be
+    bitwise what the plain hand-off gives (the note ignored).  And when a hidden activation has TWO consumers
+    autograd sums their gradients: the note of the first must not be trusted (version check) — again equal to the
+    plain path."""
+    from mrgcn_amd import functional as Fn
+    from mrgcn_amd.layers.graph import GraphConvolution
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.plan import plan_of
+    from mrgcn_amd.train import categorical_crossentropy
+    N, R = 5000, 3
+    rows, cols, vals, idx, y = _sparse_label_problem(N, R, labelled=8)
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    ig, yg = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
+    torch.manual_seed(2)
+    model = RGCN([(6, 10, "mrgcn", torch.nn.ReLU()), (10, 7, "mrgcn", torch.nn.ReLU()), (7, 4, "mrgcn", None)],
+                 R, N, 4, 0.0, False, True, False).cuda()
+    extra = GraphConvolution(10, 7, R, N, num_bases=4, bias=True).cuda()   # a second consumer of layer 0's output
+    X = torch.randn((N, 6), device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    params = list(model.parameters()) + list(extra.parameters())
+
+    def run(two_consumers, trust):
+        for p in params:
+            p.grad = None
+        seen = []
+        orig = Fn._grad_meta
+        Fn._grad_meta = (lambda t: seen.append(orig(t)) or seen[-1]) if trust else (lambda t: None)
+        try:
+            if two_consumers:
+                plan = plan_of(A, N, R)
+                H = model.layers["layer_0"]._forward_fused(X, plan, relu=True)
+                H2 = model.layers["layer_1"]._forward_fused(H, plan, relu=True) + Fn.rgcn_layer(plan, extra, H, relu=True)
+                out = model.layers["layer_2"](H2, A)
+            else:
+                out = model(X, A)
+            categorical_crossentropy(out, ig, yg).backward()
+        finally:
+            Fn._grad_meta = orig
+        return [None if p.grad is None else p.grad.clone() for p in params], seen
+
+    plain, _ = run(False, False)
+    fast, seen = run(False, True)
+    assert sum(m is not None and m["relu_applied"] for m in seen) == 2      # both hand-offs carried the note
+    for a, b in zip(plain, fast):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+    plain2, _ = run(True, False)
+    fast2, seen2 = run(True, True)
+    assert any(m is None for m in seen2)                                    # the summed gradient lost its note
+    for a, b in zip(plain2, fast2):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
