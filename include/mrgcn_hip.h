@@ -324,6 +324,23 @@ int mrgcn_sumsq_accum_f32(const float *x, int64_t n, double *accum, void *stream
 /* clip_grad_norm_(…, max_norm) (node_classification.py:192): norm = sqrt(*sumsq),
  * coef = min(1, max_norm / (norm + 1e-6)); both stay on the device */
 int mrgcn_clip_coef_f32(const double *sumsq, float max_norm, float *coef, float *norm, void *stream);
+/* The clip of the SMALL dense parameters in one launch (<= 16 tensors; host arrays of device pointers / sizes):
+ * sum of squares of every gradient, plus `extra` device doubles (squared norms that arrived from elsewhere: the
+ * row-sparse node table's), -> *sumsq_out (nullable), the coefficient min(1, max_norm / (norm + 1e-6)) -> *coef
+ * (nullable; max_norm <= 0: 1), the norm -> *norm (nullable) and — with `step_dev` — the device step counter and
+ * bias corrections of mrgcn_adam_bias_f32.  `accum` (double) and `ticket` (uint32) are scratch words that must be
+ * zero at the first call; the kernel leaves them zero.  Replaces n mrgcn_sumsq_accum_f32 + mrgcn_clip_coef_f32 +
+ * mrgcn_adam_bias_f32 launches (each ~6 us inside a replayed hipGraph). */
+int mrgcn_sumsq_clip_multi_f32(int32_t n_tensors, const float *const *grads, const int64_t *numel, int32_t n_extra,
+                               const double *const *extra, double *accum, uint32_t *ticket, float max_norm,
+                               double *sumsq_out, float *coef, float *norm, int64_t *step_dev, float beta1,
+                               float beta2, float *bc_dev, void *stream);
+/* mrgcn_adam_step_f32 / _dev_f32 for <= 16 small tensors in one launch (per-tensor lr / weight_decay; bc_dev
+ * nullable: host-side bias corrections from `step`). */
+int mrgcn_adam_step_multi_f32(int32_t n_tensors, float *const *params, const float *const *grads,
+                              float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numel, const float *lr,
+                              const float *weight_decay, float beta1, float beta2, float eps, int64_t step,
+                              const float *bc_dev, const float *grad_scale, void *stream);
 /* torch.optim.Adam step (node_classification.py:35-37, :193) on one tensor; the gradient is
  * multiplied by *grad_scale (device float, nullable) first, i.e. the clip is folded in. */
 int mrgcn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,

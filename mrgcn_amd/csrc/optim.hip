@@ -268,6 +268,108 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
     }
 }
 
+// ---- the optimizer tail of the SMALL parameters in two launches --------------------------------------------------
+// An epoch's dense parameters besides the node table are a handful of KB-sized tensors (comp tables, W_F, biases,
+// the decoder's relations).  One kernel per tensor and phase (sum of squares, Adam) is ~6 us of launch each inside a
+// replayed hipGraph — 15 nodes for 5 tensors.  Here: ONE launch squares every tensor, adds the sums that arrived
+// from elsewhere (the row-sparse node table's ||g||^2: device doubles), and its last block turns the total into the
+// clip coefficient and advances the device step counter; ONE launch applies Adam to all of them.
+constexpr int kMultiMax = 16;
+struct MultiSumsq {
+  const float *g[kMultiMax];
+  int64_t n[kMultiMax];
+  int32_t blk0[kMultiMax + 1];  // first block of each tensor
+  int32_t n_tensors;
+  const double *extra[kMultiMax];  // further squared norms to add (device doubles)
+  int32_t n_extra;
+};
+// `accum` / `ticket` must be zero on entry; the last block leaves them zero again (self-cleaning)
+__global__ __launch_bounds__(kTB) void k_sumsq_multi(MultiSumsq a, double *__restrict__ accum,
+                                                     unsigned int *__restrict__ ticket, float max_norm,
+                                                     double *__restrict__ sumsq_out, float *__restrict__ coef,
+                                                     float *__restrict__ norm, int64_t *__restrict__ step, float b1,
+                                                     float b2, float *__restrict__ bc) {
+  int t = 0;
+  while (t + 1 < a.n_tensors && (int)blockIdx.x >= a.blk0[t + 1]) ++t;
+  const int nb = a.blk0[t + 1] - a.blk0[t], b = blockIdx.x - a.blk0[t];
+  const float *x = a.g[t];
+  const int64_t n = a.n[t], nv = n >> 2;
+  const float4 *x4 = reinterpret_cast<const float4 *>(x);
+  float s = 0.f;
+  for (int64_t i = (int64_t)b * kTB + threadIdx.x; i < nv; i += (int64_t)nb * kTB) {
+    float4 v = x4[i];
+    s = fmaf(v.x, v.x, s);
+    s = fmaf(v.y, v.y, s);
+    s = fmaf(v.z, v.z, s);
+    s = fmaf(v.w, v.w, s);
+  }
+  if (b == 0)
+    for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += kTB) s = fmaf(x[i], x[i], s);
+  const float tot = block_sum(s);
+  if (threadIdx.x == 0) {
+    atomicAdd(accum, (double)tot);
+    __threadfence();
+    const unsigned int seen = atomicAdd(ticket, 1u);
+    if (seen == gridDim.x - 1) {  // every block's sum is in
+      double total = atomicAdd(accum, 0.0);
+      for (int e = 0; e < a.n_extra; ++e) total += *a.extra[e];
+      if (sumsq_out) *sumsq_out = total;
+      const float nrm = (float)sqrt(total);
+      if (coef) {
+        const float c = max_norm / (nrm + 1e-6f);
+        *coef = (max_norm > 0.f && c < 1.f) ? c : 1.f;
+      }
+      if (norm) *norm = nrm;
+      if (step) {  // ++*step; bc = {1 - b1^step, sqrt(1 - b2^step)} (k_adam_bias)
+        const int64_t tt = *step + 1;
+        *step = tt;
+        bc[0] = (float)(1.0 - pow((double)b1, (double)tt));
+        bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)tt));
+      }
+      *accum = 0.0;
+      *ticket = 0u;
+    }
+  }
+}
+
+struct MultiAdam {
+  float *p[kMultiMax];
+  const float *g[kMultiMax];
+  float *m[kMultiMax];
+  float *v[kMultiMax];
+  int64_t n[kMultiMax];
+  float lr[kMultiMax], wd[kMultiMax];
+  int32_t blk0[kMultiMax + 1];
+  int32_t n_tensors;
+};
+__global__ __launch_bounds__(kTB) void k_adam_multi(MultiAdam a, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                    const float *__restrict__ scale, const float *__restrict__ bc_dev) {
+  if (bc_dev) {
+    bc1 = bc_dev[0];
+    bc2_sqrt = bc_dev[1];
+  }
+  int t = 0;
+  while (t + 1 < a.n_tensors && (int)blockIdx.x >= a.blk0[t + 1]) ++t;
+  const int nb = a.blk0[t + 1] - a.blk0[t], b = blockIdx.x - a.blk0[t];
+  float *p = a.p[t];
+  const float *g = a.g[t];
+  float *m = a.m[t], *v = a.v[t];
+  const int64_t n = a.n[t];
+  const float sc = scale ? *scale : 1.f, wd = a.wd[t];
+  const float step = a.lr[t] / bc1;
+  for (int64_t i = (int64_t)b * kTB + threadIdx.x; i < n; i += (int64_t)nb * kTB) {  // == k_adam's update
+    float gg = g[i] * sc, pp = p[i], mm = m[i], vv = v[i];
+    if (wd != 0.f) gg = fmaf(wd, pp, gg);
+    mm = fmaf(b1, mm, (1.f - b1) * gg);
+    vv = fmaf(b2, vv, (1.f - b2) * gg * gg);
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= step * (mm / denom);
+    p[i] = pp;
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
 // mean cross-entropy over labelled rows + its gradient w.r.t. the logits.
 // one thread per labelled row (C is small: the number of classes)
 __global__ void k_xent(const float *__restrict__ logits, int64_t ld, int C,
@@ -475,6 +577,65 @@ int mrgcn_softmax_xent_f32(const float *logits, int64_t ld, int32_t C, const int
   int grid = (int)((n + kTB - 1) / kTB);
   if (grid > 1024) grid = 1024;
   k_xent<<<dim3(grid), dim3(kTB), 0, s>>>(logits, ld, C, idx, target, n, loss, dlogits, ldd);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+
+int mrgcn_sumsq_clip_multi_f32(int32_t n_tensors, const float *const *grads, const int64_t *numel, int32_t n_extra,
+                               const double *const *extra, double *accum, uint32_t *ticket, float max_norm,
+                               double *sumsq_out, float *coef, float *norm, int64_t *step_dev, float beta1,
+                               float beta2, float *bc_dev, void *stream) {
+  MRGCN_REQUIRE(n_tensors >= 1 && n_tensors <= mrgcn::kMultiMax && n_extra >= 0 && n_extra <= mrgcn::kMultiMax,
+                "at most 16 tensors / extra sums per call, at least one tensor");
+  MRGCN_REQUIRE(grads && numel && accum && ticket && (n_extra == 0 || extra), "NULL");
+  MRGCN_REQUIRE(!step_dev || bc_dev, "bc_dev is NULL");
+  mrgcn::MultiSumsq a{};
+  a.n_tensors = n_tensors;
+  a.n_extra = n_extra;
+  int blk = 0;
+  for (int t = 0; t < n_tensors; ++t) {
+    MRGCN_REQUIRE(grads[t] && numel[t] >= 0 && ((uintptr_t)grads[t] & 15) == 0, "gradient: NULL / 16-byte alignment");
+    a.g[t] = grads[t];
+    a.n[t] = numel[t];
+    a.blk0[t] = blk;
+    int64_t nb = ((numel[t] >> 2) + kTB - 1) / kTB;
+    blk += (int)(nb < 1 ? 1 : (nb > 64 ? 64 : nb));
+  }
+  a.blk0[n_tensors] = blk;
+  for (int e = 0; e < n_extra; ++e) {
+    MRGCN_REQUIRE(extra[e], "extra sum is NULL");
+    a.extra[e] = extra[e];
+  }
+  mrgcn::k_sumsq_multi<<<dim3(blk), dim3(kTB), 0, (hipStream_t)stream>>>(a, accum, ticket, max_norm, sumsq_out, coef,
+                                                                        norm, step_dev, beta1, beta2, bc_dev);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_adam_step_multi_f32(int32_t n_tensors, float *const *params, const float *const *grads,
+                              float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numel, const float *lr,
+                              const float *weight_decay, float beta1, float beta2, float eps, int64_t step,
+                              const float *bc_dev, const float *grad_scale, void *stream) {
+  MRGCN_REQUIRE(n_tensors >= 1 && n_tensors <= mrgcn::kMultiMax, "1..16 tensors per call");
+  MRGCN_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && lr && weight_decay, "NULL");
+  MRGCN_REQUIRE(step >= 1 || bc_dev, "step counts from 1");
+  mrgcn::MultiAdam a{};
+  a.n_tensors = n_tensors;
+  int blk = 0;
+  for (int t = 0; t < n_tensors; ++t) {
+    MRGCN_REQUIRE(params[t] && grads[t] && exp_avg[t] && exp_avg_sq[t] && numel[t] >= 0, "NULL tensor");
+    a.p[t] = params[t]; a.g[t] = grads[t]; a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t];
+    a.n[t] = numel[t]; a.lr[t] = lr[t]; a.wd[t] = weight_decay[t];
+    a.blk0[t] = blk;
+    int64_t nb = (numel[t] + kTB - 1) / kTB;
+    blk += (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+  }
+  a.blk0[n_tensors] = blk;
+  const double bc1 = bc_dev ? 1.0 : 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = bc_dev ? 1.0 : 1.0 - pow((double)beta2, (double)step);
+  mrgcn::k_adam_multi<<<dim3(blk), dim3(kTB), 0, (hipStream_t)stream>>>(a, beta1, beta2, eps, (float)bc1,
+                                                                       (float)sqrt(bc2), grad_scale, bc_dev);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -1551,6 +1551,7 @@ int mrgcn_rel_transform_bwd_masked_f32(const mrgcn_plan_t *p, float *dM, int64_t
                                        float *workspace, int64_t workspace_floats, int32_t relu_mask_from_x,
                                        uint8_t *row_live_out, void *stream) {
   MRGCN_REQUIRE(p && dM && X && W, "NULL");
+  MRGCN_REQUIRE(!col_live || ((uintptr_t)col_live & 7) == 0, "col_live must be 8-byte aligned");
   MRGCN_REQUIRE(!(relu_mask_from_x || row_live_out) ||
                     (dX && mrgcn_rel_transform_bwd_masked_supported(p, K, F, workspace ? workspace_floats : 0)),
                 "the masked / flagged dX needs K <= 16 and the matrix-core path (see ..._masked_supported)");

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restr
                                                           int64_t ldZ, int64_t N, int K, float *__restrict__ dX,
                                                           int64_t lddX, const uint8_t *__restrict__ col_live,
                                                           const float *__restrict__ mask_src, int64_t ldMask,
-                                                          uint8_t *__restrict__ row_live) {
+                                                          uint8_t *__restrict__ row_live, int64_t ncols) {
   __shared__ float tile[256][KT + 1];
   const int64_t j0 = (int64_t)blockIdx.x * 256;
   const int64_t j = j0 + threadIdx.x;
@@ -427,15 +427,32 @@ __global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restr
 #pragma unroll
   for (int i = 0; i < KT; ++i) acc[i] = 0.f;
   if (j < N) {
-    bool any = false;
-    const int32_t c1 = nptr[j + 1];
-    for (int32_t c = nptr[j]; c < c1; ++c) {
-      if (col_live && !col_live[c]) continue;
-      any = true;
-      const float *z = Z + (int64_t)c * ldZ;
+    const int32_t c0 = nptr[j], c1 = nptr[j + 1];
+    // nearly every node of a semi-supervised epoch has no live column: look at its flag bytes eight at a time
+    // (aligned 8-byte words; the bytes of neighbouring nodes are masked off, the array's last partial word is read
+    // byte by byte) and walk the columns only when one is set
+    bool any = col_live == nullptr && c1 > c0;
+    if (col_live) {
+      for (int32_t w0 = c0 & ~7; w0 < c1 && !any; w0 += 8) {
+        uint64_t bits = 0;
+        if (w0 + 8 <= ncols) {
+          bits = *reinterpret_cast<const uint64_t *>(col_live + w0);
+        } else {
+          for (int b = 0; b < 8 && w0 + b < ncols; ++b) bits |= (uint64_t)col_live[w0 + b] << (8 * b);
+        }
+        if (w0 < c0) bits &= ~uint64_t(0) << (8 * (c0 - w0));
+        if (w0 + 8 > c1) bits &= ~uint64_t(0) >> (8 * (w0 + 8 - c1));
+        any = bits != 0;
+      }
+    }
+    if (any) {
+      for (int32_t c = c0; c < c1; ++c) {
+        if (col_live && !col_live[c]) continue;
+        const float *z = Z + (int64_t)c * ldZ;
 #pragma unroll
-      for (int i = 0; i < KT; ++i)
-        if (i < K) acc[i] += z[i];
+        for (int i = 0; i < KT; ++i)
+          if (i < K) acc[i] += z[i];
+      }
     }
     bool nz = false;
     if (any) {
@@ -581,10 +598,10 @@ int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *
     const dim3 grid((unsigned)((p->num_nodes + 255) / 256));
     if (K <= 8)
       k_segment_sum_mask<8><<<grid, dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, col_live, mask_src,
-                                                       ldMask, row_live);
+                                                       ldMask, row_live, p->ncols);
     else
       k_segment_sum_mask<16><<<grid, dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, col_live, mask_src,
-                                                        ldMask, row_live);
+                                                        ldMask, row_live, p->ncols);
     MRGCN_HIP_TRY(hipGetLastError());
     return MRGCN_OK;
   }

@@ -9,6 +9,7 @@ with the loss, the global gradient norm, the clip and Adam running as HIP kernel
 host synchronisation."""
 from __future__ import annotations
 
+import ctypes as C
 import os
 
 import torch
@@ -16,6 +17,9 @@ import torch
 from . import _lib as L
 from .functional import clear_row_grads, dense_from_rows, pop_row_grad, row_sparse_weight_grad
 
+# MRGCN_MULTI=0: one launch per small tensor and phase (sum of squares, Adam) instead of the two multi-tensor launches
+_MULTI = os.environ.get("MRGCN_MULTI", "1") != "0"
+_MULTI_MAX_NUMEL = 1 << 20
 # MRGCN_ROW_SPARSE=0 switches the row-sparse weight_I gradient off (A/B runs)
 _ROW_SPARSE_DEFAULT = os.environ.get("MRGCN_ROW_SPARSE", "1") != "0"
 
@@ -155,7 +159,9 @@ class ClipAdam(torch.optim.Optimizer):
     def _dev_scratch(self, device):
         s = self._scratch.get(device)
         if s is None:
-            s = dict(sumsq=torch.zeros((), dtype=torch.float64, device=device),
+            s = dict(accum=torch.zeros((), dtype=torch.float64, device=device),   # (self-cleaning: zero between steps)
+                     ticket=torch.zeros((), dtype=torch.int32, device=device),
+                     sumsq=torch.zeros((), dtype=torch.float64, device=device),
                      sumsq_sharded=torch.zeros((), dtype=torch.float64, device=device),
                      coef=torch.ones((), dtype=torch.float32, device=device),
                      norm=torch.zeros((), dtype=torch.float32, device=device))
@@ -191,29 +197,17 @@ class ClipAdam(torch.optim.Optimizer):
             raise L.MrgcnError("ClipAdam: all parameters must live on one GPU")
         sc = self._dev_scratch(device)
         s = _stream(device)
+        use_clip = self.max_norm is not None and self.max_norm > 0
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for _, p in live]
+        # The dense parameters besides the node table are a handful of small tensors: their squared norms, the
+        # row-sparse gradients' norms, the clip coefficient and the device step counter take ONE launch
+        # (mrgcn_sumsq_clip_multi_f32) and their Adam updates another (mrgcn_adam_step_multi_f32) when every group
+        # shares (beta1, beta2, eps) — the reference's groups do (tasks/utils.py:8-45 vary lr / weight_decay only).
+        hyper = {(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g, _ in live} | \
+                {(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g, _, _ in rowsparse}
+        small = [i for i, g in enumerate(grads) if g.numel() <= _MULTI_MAX_NUMEL]
+        multi = (_MULTI and self._dist is None and len(hyper) == 1 and 1 <= len(small) <= 16 and len(rowsparse) <= 16)
         with torch.cuda.device(device):
-            sc["sumsq"].zero_()
-            sc["sumsq_sharded"].zero_()
-            sharded = self._dist[1] if self._dist else ()
-            grads = []
-            for _, p in live:
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                grads.append(g)
-                acc = sc["sumsq_sharded"] if id(p) in sharded else sc["sumsq"]
-                L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), acc.data_ptr(), s),
-                        "mrgcn_sumsq_accum_f32")
-            for _, p, ent in rowsparse:  # ||g||^2 came for free with the gradient
-                (sc["sumsq_sharded"] if id(p) in sharded else sc["sumsq"]).add_(ent["sumsq"])
-            if self._dist:
-                from .partition import all_reduce_sum_
-                all_reduce_sum_(sc["sumsq_sharded"], self._dist[0])
-            sc["sumsq"] += sc["sumsq_sharded"]
-            use_clip = self.max_norm is not None and self.max_norm > 0
-            if use_clip:
-                L.check(lib.mrgcn_clip_coef_f32(sc["sumsq"].data_ptr(), float(self.max_norm),
-                                                sc["coef"].data_ptr(), sc["norm"].data_ptr(), s),
-                        "mrgcn_clip_coef_f32")
-            coef_ptr = step_coef_ptr = sc["coef"].data_ptr() if use_clip else 0
             bias = {}
             if self.capturable:
                 for group in self.param_groups:  # one device counter per distinct (beta1, beta2)
@@ -229,9 +223,44 @@ class ClipAdam(torch.optim.Optimizer):
                         ent = (torch.full((), t0, dtype=torch.int64, device=device),
                                torch.ones(2, dtype=torch.float32, device=device))
                         self._dev_step[key] = ent
-                    L.check(lib.mrgcn_adam_bias_f32(ent[0].data_ptr(), key[0], key[1], ent[1].data_ptr(), s),
-                            "mrgcn_adam_bias_f32")
                     bias[key] = ent[1]
+            if multi:
+                b1m, b2m, _ = next(iter(hyper))
+                for i, g in enumerate(grads):
+                    if i not in small:  # (a large dense gradient: its own streaming pass into the same accumulator)
+                        L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), sc["accum"].data_ptr(), s),
+                                "mrgcn_sumsq_accum_f32")
+                gp = (C.c_void_p * len(small))(*[grads[i].data_ptr() for i in small])
+                gn = (C.c_int64 * len(small))(*[grads[i].numel() for i in small])
+                ex = (C.c_void_p * max(len(rowsparse), 1))(*[ent["sumsq"].data_ptr() for _, _, ent in rowsparse])
+                dstep = self._dev_step.get((b1m, b2m)) if self.capturable else None
+                L.check(lib.mrgcn_sumsq_clip_multi_f32(
+                    len(small), gp, gn, len(rowsparse), ex, sc["accum"].data_ptr(), sc["ticket"].data_ptr(),
+                    float(self.max_norm) if use_clip else 0.0, sc["sumsq"].data_ptr(), sc["coef"].data_ptr(),
+                    sc["norm"].data_ptr(), dstep[0].data_ptr() if dstep else 0, b1m, b2m,
+                    dstep[1].data_ptr() if dstep else 0, s), "mrgcn_sumsq_clip_multi_f32")
+            else:
+                sc["sumsq"].zero_()
+                sc["sumsq_sharded"].zero_()
+                sharded = self._dist[1] if self._dist else ()
+                for (_, p), g in zip(live, grads):
+                    acc = sc["sumsq_sharded"] if id(p) in sharded else sc["sumsq"]
+                    L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), acc.data_ptr(), s),
+                            "mrgcn_sumsq_accum_f32")
+                for _, p, ent in rowsparse:  # ||g||^2 came for free with the gradient
+                    (sc["sumsq_sharded"] if id(p) in sharded else sc["sumsq"]).add_(ent["sumsq"])
+                if self._dist:
+                    from .partition import all_reduce_sum_
+                    all_reduce_sum_(sc["sumsq_sharded"], self._dist[0])
+                sc["sumsq"] += sc["sumsq_sharded"]
+                if use_clip:
+                    L.check(lib.mrgcn_clip_coef_f32(sc["sumsq"].data_ptr(), float(self.max_norm),
+                                                    sc["coef"].data_ptr(), sc["norm"].data_ptr(), s),
+                            "mrgcn_clip_coef_f32")
+                for key, bc_t in bias.items():
+                    L.check(lib.mrgcn_adam_bias_f32(self._dev_step[key][0].data_ptr(), key[0], key[1], bc_t.data_ptr(), s),
+                            "mrgcn_adam_bias_f32")
+            coef_ptr = step_coef_ptr = sc["coef"].data_ptr() if use_clip else 0
             for group, p, ent in rowsparse:
                 if float(group["weight_decay"]) != 0.0:
                     raise L.MrgcnError("row-sparse gradients need weight_decay = 0 (a decayed parameter "
@@ -267,13 +296,33 @@ class ClipAdam(torch.optim.Optimizer):
                     float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), bc, coef_ptr, s),
                     "mrgcn_adam_step_rows_f32")
             coef_ptr = step_coef_ptr
-            for (group, p), g in zip(live, grads):
+            for (group, p) in live:
                 st = self._new_state(p)
                 st["step"] += 1
-                b1, b2 = group["betas"]
                 rows = getattr(p, "_mrgcn_rows", None)
                 if rows is not None:
                     rows["seeded_for"] = None  # a dense step may put moments where the row flags never looked
+            # (host-side bias corrections are per step count: the one launch needs the tensors to share it)
+            adam_multi = multi and (self.capturable or len({int(self.state[live[i][1]]["step"]) for i in small}) == 1)
+            if adam_multi:
+                b1m, b2m, epsm = next(iter(hyper))
+                sel = [(live[i][0], live[i][1], grads[i]) for i in small]
+                n = len(sel)
+                arr = lambda ptrs: (C.c_void_p * n)(*ptrs)  # noqa: E731
+                L.check(lib.mrgcn_adam_step_multi_f32(
+                    n, arr([p.data_ptr() for _, p, _ in sel]), arr([g.data_ptr() for _, _, g in sel]),
+                    arr([self.state[p]["exp_avg"].data_ptr() for _, p, _ in sel]),
+                    arr([self.state[p]["exp_avg_sq"].data_ptr() for _, p, _ in sel]),
+                    (C.c_int64 * n)(*[p.numel() for _, p, _ in sel]),
+                    (C.c_float * n)(*[float(g["lr"]) for g, _, _ in sel]),
+                    (C.c_float * n)(*[float(g["weight_decay"]) for g, _, _ in sel]), b1m, b2m, epsm,
+                    int(self.state[sel[0][1]]["step"]), bias[(b1m, b2m)].data_ptr() if self.capturable else 0,
+                    coef_ptr, s), "mrgcn_adam_step_multi_f32")
+            for i, ((group, p), g) in enumerate(zip(live, grads)):
+                if adam_multi and i in small:
+                    continue
+                st = self.state[p]
+                b1, b2 = group["betas"]
                 if self.capturable:
                     L.check(lib.mrgcn_adam_step_dev_f32(
                         p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
