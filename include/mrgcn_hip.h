@@ -207,6 +207,14 @@ int mrgcn_basis_mix_fwd_f32(const mrgcn_plan_t *plan, const float *V, const floa
 /* no-bases input term (graph.py:67-68): M[MPOS[c], 0:F] = addend[c, 0:F] + W[r_c*N + j_c, 0:F] */
 int mrgcn_gather_rows_f32(const mrgcn_plan_t *plan, const float *W, int32_t F, const float *addend,
                           int64_t ldA, float *M, int64_t ldM, void *stream);
+/* Basis contraction of weight_F (graph.py:83-85): W[r, :] = sum_b comp[r, b] * V[b, :] with V = weight_F viewed as
+ * (B, X = in * out), W = (R, X) — and its backward: dV[b, :] = sum_r comp[r, b] * dW[r, :], dcomp[r, b] =
+ * <dW[r, :], V[b, :]> (either output nullable).  One launch each; fixed summation order. */
+int mrgcn_basis_contract_f32(const float *comp, const float *V, int32_t R, int32_t B, int64_t X, float *W,
+                             void *stream);
+int mrgcn_basis_contract_bwd_f32(const float *comp, const float *V, const float *dW, int32_t R, int32_t B, int64_t X,
+                                 float *dcomp, float *dV, void *stream);
+
 /* relation transform — replaces einsum('ij,bjk->bik', X, W_F) + reshape of graph.py:93-94,
  * restricted to touched columns (f32 MFMA 16x16x4 when K <= 256 and F <= 64):
  *     Out[o(c), 0:F] = X[j_c, 0:K] . W[r_c, 0:K, 0:F]          X: [N, ldX], W: [R, K, F]
@@ -319,6 +327,14 @@ int mrgcn_relu_bwd_rows_f32(const float *dY, int64_t ld_dY, const float *Y, int6
 int mrgcn_softmax_xent_f32(const float *logits, int64_t ld, int32_t C, const int64_t *idx,
                            const int64_t *target, int64_t n, float *loss, float *dlogits,
                            int64_t ldd, int64_t num_rows, void *stream);
+/* The same loss with its gradient kept compact — drows (nullable, [n, C]) = d loss / d logits[idx[i], :] — and the
+ * backward that forms the dense gradient from it: dlogits = 0, dlogits[idx[i], :] += *g * drows[i, :] (g: device
+ * float, nullable = 1), row_flags (nullable, [num_rows] bytes) = 1 at the labelled rows, 0 elsewhere (the flags
+ * mrgcn_spmm_transposed_live_flagged_f32 takes).  No dense pass besides the zero fill. */
+int mrgcn_softmax_xent_rows_f32(const float *logits, int64_t ld, int32_t C, const int64_t *idx, const int64_t *target,
+                                int64_t n, float *loss, float *drows, void *stream);
+int mrgcn_softmax_xent_bwd_f32(const float *drows, const int64_t *idx, int64_t n, int32_t C, const float *g,
+                               float *dlogits, int64_t ldd, int64_t num_rows, uint8_t *row_flags, void *stream);
 /* *accum += sum(x^2)  (accum is a device double, zeroed by the caller once per step) */
 int mrgcn_sumsq_accum_f32(const float *x, int64_t n, double *accum, void *stream);
 /* clip_grad_norm_(…, max_norm) (node_classification.py:192): norm = sqrt(*sumsq),

@@ -76,6 +76,10 @@ SIGNATURES = {
     "mrgcn_rel_transform_bwd_live_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p,
                                                    _i64, _p]),
     "mrgcn_rows_nonzero_f32": (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
+    "mrgcn_softmax_xent_rows_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p]),
+    "mrgcn_softmax_xent_bwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _p]),
+    "mrgcn_basis_contract_f32": (C.c_int, [_p, _p, _i32, _i32, _i64, _p, _p]),
+    "mrgcn_basis_contract_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _i64, _p, _p, _p]),
     "mrgcn_sumsq_clip_multi_f32": (C.c_int, [_i32, _p, _p, _i32, _p, _p, _p, C.c_float, _p, _p, _p, _p, C.c_float,
                                              C.c_float, _p, _p]),
     "mrgcn_adam_step_multi_f32": (C.c_int, [_i32, _p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, C.c_float, _i64,

@@ -268,6 +268,53 @@ __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float
     }
 }
 
+// The same with the gradient kept COMPACT: drows[i, :] = d loss / d logits[idx[i], :] (n x C) — the dense N x C
+// gradient (73 MB at the AM shape, all zeros but n rows) is only formed by the backward (k_xent_scatter), scaled by
+// the upstream gradient on the way: no dense multiply, and the rows that hold anything are known (row flags).
+__global__ __launch_bounds__(1024) void k_xent_rows(const float *__restrict__ logits, int64_t ld, int C,
+                                                    const int64_t *__restrict__ idx, const int64_t *__restrict__ target,
+                                                    int64_t n, float *__restrict__ loss, float *__restrict__ drows,
+                                                    int single_block) {
+  float my = 0.f;
+  const float inv_n = 1.f / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float *z = logits + idx[i] * ld;
+    float mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+    const float lse = logf(se) + mx;
+    const int64_t t = target[i];
+    my += (lse - z[t]) * inv_n;
+    if (drows)
+      for (int c = 0; c < C; ++c) drows[i * C + c] = (expf(z[c] - lse) - (c == t ? 1.f : 0.f)) * inv_n;
+  }
+  // block sum over up to 16 waves
+  __shared__ float s_part[16];
+  my = wave_sum(my);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = my;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += s_part[i];
+    if (single_block) *loss = t; else atomicAdd(loss, t);
+  }
+}
+
+// dlogits[idx[i], :] += g * drows[i, :] (a node may be listed twice: atomics), flags[idx[i]] = 1
+__global__ void k_xent_scatter(const float *__restrict__ drows, const int64_t *__restrict__ idx, int64_t n, int C,
+                               const float *__restrict__ g, float *__restrict__ dlogits, int64_t ldd,
+                               uint8_t *__restrict__ flags) {
+  const float gg = g ? *g : 1.f;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / C;
+    const int c = (int)(t - i * C);
+    const float v = gg * drows[t];
+    atomicAdd(&dlogits[idx[i] * ldd + c], v);
+    if (flags && c == 0) flags[idx[i]] = 1;
+  }
+}
+
 // ---- the optimizer tail of the SMALL parameters in two launches --------------------------------------------------
 // An epoch's dense parameters besides the node table are a handful of KB-sized tensors (comp tables, W_F, biases,
 // the decoder's relations).  One kernel per tensor and phase (sum of squares, Adam) is ~6 us of launch each inside a
@@ -581,6 +628,34 @@ int mrgcn_softmax_xent_f32(const float *logits, int64_t ld, int32_t C, const int
   return MRGCN_OK;
 }
 
+
+int mrgcn_softmax_xent_rows_f32(const float *logits, int64_t ld, int32_t C, const int64_t *idx, const int64_t *target,
+                                int64_t n, float *loss, float *drows, void *stream) {
+  MRGCN_REQUIRE(logits && idx && target && loss, "NULL");
+  MRGCN_REQUIRE(C > 0 && ld >= C && n > 0, "C / ld / n");
+  hipStream_t s = (hipStream_t)stream;
+  const int single = n <= 16384;
+  if (!single) MRGCN_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), s));
+  int grid = single ? 1 : (int)((n + 1023) / 1024);
+  if (grid > 256) grid = 256;
+  mrgcn::k_xent_rows<<<dim3(grid), dim3(1024), 0, s>>>(logits, ld, C, idx, target, n, loss, drows, single);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_softmax_xent_bwd_f32(const float *drows, const int64_t *idx, int64_t n, int32_t C, const float *g,
+                               float *dlogits, int64_t ldd, int64_t num_rows, uint8_t *row_flags, void *stream) {
+  MRGCN_REQUIRE(drows && idx && dlogits, "NULL");
+  MRGCN_REQUIRE(C > 0 && ldd >= C && n > 0 && num_rows > 0, "C / ldd / n / num_rows");
+  hipStream_t s = (hipStream_t)stream;
+  MRGCN_HIP_TRY(hipMemsetAsync(dlogits, 0, (size_t)num_rows * ldd * sizeof(float), s));
+  if (row_flags) MRGCN_HIP_TRY(hipMemsetAsync(row_flags, 0, (size_t)num_rows, s));
+  int grid = (int)((n * C + kTB - 1) / kTB);
+  if (grid > 1024) grid = 1024;
+  mrgcn::k_xent_scatter<<<dim3(grid), dim3(kTB), 0, s>>>(drows, idx, n, C, g, dlogits, ldd, row_flags);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
 
 int mrgcn_sumsq_clip_multi_f32(int32_t n_tensors, const float *const *grads, const int64_t *numel, int32_t n_extra,
                                const double *const *extra, double *accum, uint32_t *ticket, float max_norm,

@@ -1224,6 +1224,61 @@ int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32
   return MRGCN_OK;
 }
 
+// ---- basis contraction of weight_F (graph.py:83-85): W[r] = sum_b comp[r, b] V[b] --------------------------------
+// (R x B) . (B x X), X = in * out: a few hundred thousand outputs of B terms each — one small launch of this
+// package instead of a library GEMM; backward: dV[b] = sum_r comp[r, b] dW[r] and dcomp[r, b] = <dW[r], V[b]> in one
+// launch (two block ranges).  Sums in a fixed order: bitwise reproducible.
+__global__ __launch_bounds__(kTB) void k_basis_contract(const float *__restrict__ comp, const float *__restrict__ V,
+                                                        int R, int B, int64_t X, float *__restrict__ W) {
+  const int64_t total = (int64_t)R * X;
+  for (int64_t t = (int64_t)blockIdx.x * kTB + threadIdx.x; t < total; t += (int64_t)gridDim.x * kTB) {
+    const int64_t r = t / X, x = t - r * X;
+    const float *c = comp + r * B;
+    float s0 = 0.f, s1 = 0.f;
+    int b = 0;
+    for (; b + 2 <= B; b += 2) {
+      s0 = fmaf(c[b], V[(int64_t)b * X + x], s0);
+      s1 = fmaf(c[b + 1], V[(int64_t)(b + 1) * X + x], s1);
+    }
+    if (b < B) s0 = fmaf(c[b], V[(int64_t)b * X + x], s0);
+    W[t] = s0 + s1;
+  }
+}
+
+__global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restrict__ comp, const float *__restrict__ V,
+                                                            const float *__restrict__ dW, int R, int B, int64_t X,
+                                                            float *__restrict__ dcomp, float *__restrict__ dV,
+                                                            int dv_blocks) {
+  if ((int)blockIdx.x < dv_blocks) {  // dV[b, x] = sum_r comp[r, b] dW[r, x]: a thread per output
+    if (!dV) return;
+    const int64_t total = (int64_t)B * X;
+    for (int64_t t = (int64_t)blockIdx.x * kTB + threadIdx.x; t < total; t += (int64_t)dv_blocks * kTB) {
+      const int64_t b = t / X, x = t - b * X;
+      float s0 = 0.f, s1 = 0.f;
+      int r = 0;
+      for (; r + 2 <= R; r += 2) {
+        s0 = fmaf(comp[(int64_t)r * B + b], dW[(int64_t)r * X + x], s0);
+        s1 = fmaf(comp[(int64_t)(r + 1) * B + b], dW[(int64_t)(r + 1) * X + x], s1);
+      }
+      if (r < R) s0 = fmaf(comp[(int64_t)r * B + b], dW[(int64_t)r * X + x], s0);
+      dV[t] = s0 + s1;
+    }
+    return;
+  }
+  if (!dcomp) return;
+  // dcomp[r, b] = <dW[r, :], V[b, :]>: a wave per output, lanes over x
+  const int lane = threadIdx.x & 63;
+  const int64_t w = ((int64_t)(blockIdx.x - dv_blocks) * kTB + threadIdx.x) >> 6;
+  if (w >= (int64_t)R * B) return;
+  const int64_t r = w / B, b = w - r * B;
+  const float *a = dW + r * X, *v = V + b * X;
+  float s = 0.f;
+  for (int64_t x = lane; x < X; x += 64) s = fmaf(a[x], v[x], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) dcomp[w] = s;
+}
+
 template <typename OT>
 int gather_rows_impl(const mrgcn_plan_t *p, const float *W, int32_t F, const float *addend, int64_t ldA,
                      OT *M, int64_t ldM, void *stream) {
@@ -1501,6 +1556,28 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const
       MRGCN_HIP_TRY(hipGetLastError());
     }
   }
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_basis_contract_f32(const float *comp, const float *V, int32_t R, int32_t B, int64_t X, float *W,
+                             void *stream) {
+  MRGCN_REQUIRE(comp && V && W, "NULL");
+  MRGCN_REQUIRE(R > 0 && B > 0 && X > 0, "R / B / X");
+  k_basis_contract<<<dim3(grid_for((int64_t)R * X)), dim3(kTB), 0, (hipStream_t)stream>>>(comp, V, R, B, X, W);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_basis_contract_bwd_f32(const float *comp, const float *V, const float *dW, int32_t R, int32_t B, int64_t X,
+                                 float *dcomp, float *dV, void *stream) {
+  MRGCN_REQUIRE(comp && V && dW, "NULL");
+  MRGCN_REQUIRE(R > 0 && B > 0 && X > 0, "R / B / X");
+  const int dv_blocks = dV ? grid_for((int64_t)B * X) : 0;
+  const int dc_blocks = dcomp ? (int)(((int64_t)R * B * 64 + kTB - 1) / kTB) : 0;
+  if (dv_blocks + dc_blocks == 0) return MRGCN_OK;
+  k_basis_contract_bwd<<<dim3(dv_blocks + dc_blocks), dim3(kTB), 0, (hipStream_t)stream>>>(comp, V, dW, R, B, X, dcomp,
+                                                                                          dV, dv_blocks);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

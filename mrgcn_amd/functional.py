@@ -440,6 +440,37 @@ class _RgcnLayer(torch.autograd.Function):
         return None, None, d_wI, d_comp, dX, dW, dbias, None, None, None
 
 
+class _BasisContract(torch.autograd.Function):
+    """W_F[r] = sum_b comp[r, b] V_F[b] (graph.py:83-85) and its backward on this package's kernels
+    (mrgcn_basis_contract_f32 / _bwd_f32): comp (R, B), V (B, in, out) -> (R, in, out)."""
+
+    @staticmethod
+    def forward(ctx, comp, V):
+        comp_c, V_c = comp.contiguous(), V.contiguous()
+        R, B = comp_c.shape
+        X = V_c.numel() // B
+        W = torch.empty((R,) + tuple(V_c.shape[1:]), dtype=torch.float32, device=V_c.device)
+        with torch.cuda.device(V_c.device):
+            L.check(L.load().mrgcn_basis_contract_f32(comp_c.data_ptr(), V_c.data_ptr(), R, B, X, W.data_ptr(),
+                                                      _stream(V_c.device)), "mrgcn_basis_contract_f32")
+        ctx.save_for_backward(comp_c, V_c)
+        return W
+
+    @staticmethod
+    def backward(ctx, dW):
+        comp, V = ctx.saved_tensors
+        R, B = comp.shape
+        X = V.numel() // B
+        dW = dW.contiguous()
+        dcomp = torch.empty_like(comp) if ctx.needs_input_grad[0] else None
+        dV = torch.empty_like(V) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(V.device):
+            L.check(L.load().mrgcn_basis_contract_bwd_f32(
+                comp.data_ptr(), V.data_ptr(), dW.data_ptr(), R, B, X, dcomp.data_ptr() if dcomp is not None else 0,
+                dV.data_ptr() if dV is not None else 0, _stream(V.device)), "mrgcn_basis_contract_bwd_f32")
+        return dcomp, dV
+
+
 def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False, input_term: bool = True,
                feature_term: bool = True, use_bias: bool = True) -> torch.Tensor:
     """Fused forward of one `GraphConvolution` (graph.py:62-102).  `input_term` / `feature_term`
@@ -456,8 +487,8 @@ def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False, input_term: bool =
             raise L.MrgcnError("rgcn_layer: the feature term needs X")
         Xin = X
         W_F = layer.weight_F
-        if B > 0:  # graph.py:83-85: tiny (R x B) . (B x in*out) contraction -> library GEMM
-            W_F = (layer.weight_F_comp @ W_F.reshape(B, -1)).view(layer.num_relations, layer.indim, F)
+        if B > 0:  # graph.py:83-85: the (R x B) . (B x in*out) contraction
+            W_F = _BasisContract.apply(layer.weight_F_comp, W_F)
     if weight_I is None and Xin is None:
         raise L.MrgcnError("rgcn_layer: neither the input term nor the feature term is selected "
                            "(a featureless layer only has the input term)")

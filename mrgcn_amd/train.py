@@ -29,8 +29,10 @@ def _stream(device) -> int:
 
 
 class _SoftmaxXent(torch.autograd.Function):
-    """nn.CrossEntropyLoss()(Y_hat[idx], targets) (node_classification.py:439-444) with the
-    gradient produced in the same pass."""
+    """nn.CrossEntropyLoss()(Y_hat[idx], targets) (node_classification.py:439-444).  The forward keeps the
+    gradient of the labelled rows only (n x C); the backward forms the dense N x C gradient from it, scaled by the
+    upstream gradient in the same pass, and notes which rows hold anything (functional._set_grad_meta: the last
+    layer's backward then does not scan 73 MB of zeros for them)."""
 
     @staticmethod
     def forward(ctx, logits, idx, targets):
@@ -38,19 +40,30 @@ class _SoftmaxXent(torch.autograd.Function):
             logits = logits.contiguous()
         N, C = logits.shape
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
-        dlogits = torch.empty((N, C), dtype=torch.float32, device=logits.device)
+        drows = torch.empty((idx.numel(), C), dtype=torch.float32, device=logits.device)
         with torch.cuda.device(logits.device):
-            L.check(L.load().mrgcn_softmax_xent_f32(
-                logits.data_ptr(), logits.stride(0), C, idx.data_ptr(), targets.data_ptr(),
-                idx.numel(), loss.data_ptr(), dlogits.data_ptr(), dlogits.stride(0), N,
-                _stream(logits.device)), "mrgcn_softmax_xent_f32")
-        ctx.save_for_backward(dlogits)
+            L.check(L.load().mrgcn_softmax_xent_rows_f32(
+                logits.data_ptr(), logits.stride(0), C, idx.data_ptr(), targets.data_ptr(), idx.numel(),
+                loss.data_ptr(), drows.data_ptr(), _stream(logits.device)), "mrgcn_softmax_xent_rows_f32")
+        ctx.save_for_backward(drows, idx)
+        ctx.shape = (N, C)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        (dlogits,) = ctx.saved_tensors
-        return dlogits * g, None, None
+        from .functional import _set_grad_meta
+        drows, idx = ctx.saved_tensors
+        N, C = ctx.shape
+        dev = drows.device
+        g = g.to(torch.float32).contiguous()
+        dlogits = torch.empty((N, C), dtype=torch.float32, device=dev)
+        flags = torch.empty((N,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.load().mrgcn_softmax_xent_bwd_f32(
+                drows.data_ptr(), idx.data_ptr(), idx.numel(), C, g.data_ptr(), dlogits.data_ptr(), C, N,
+                flags.data_ptr(), _stream(dev)), "mrgcn_softmax_xent_bwd_f32")
+        _set_grad_meta(dlogits, flags, False)
+        return dlogits, None, None
 
 
 def categorical_crossentropy(Y_hat: torch.Tensor, idx: torch.Tensor, targets: torch.Tensor):

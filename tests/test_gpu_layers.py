@@ -794,3 +794,53 @@ def test_input_gradient_handed_down_masked_and_flagged_equals_the_plain_hand_off
     fast2, seen2 = run(True, True)
     assert any(m is None for m in seen2)                                    # the summed gradient lost its note
     same(plain2, fast2)
+
+
+@pytest.mark.parametrize("R,B,K,F", [(267, 40, 155, 10), (5, 3, 7, 4), (47, 30, 8, 16), (475, 2, 1, 200)])
+def test_basis_contraction_of_weight_F_through_the_c_abi(R, B, K, F):
+    """graph.py:83-85: W_F[r] = sum_b comp[r, b] V_F[b] and its backward on this package's kernels
+    (mrgcn_basis_contract_f32 / _bwd_f32) against float64 torch; reproducible bit for bit."""
+    from mrgcn_amd import functional as Fn
+    g = torch.Generator("cuda").manual_seed(R)
+    comp = torch.randn((R, B), device="cuda", generator=g, requires_grad=True)
+    V = torch.randn((B, K, F), device="cuda", generator=g, requires_grad=True)
+    w = torch.randn((R, K, F), device="cuda", generator=g)
+    W = Fn._BasisContract.apply(comp, V)
+    (W * w).sum().backward()
+    c64, v64 = comp.detach().double().requires_grad_(True), V.detach().double().requires_grad_(True)
+    W64 = (c64 @ v64.reshape(B, -1)).view(R, K, F)
+    (W64 * w.double()).sum().backward()
+    torch.testing.assert_close(W.detach().double(), W64.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(comp.grad.double(), c64.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(V.grad.double(), v64.grad, rtol=1e-4, atol=1e-4)
+    assert torch.equal(Fn._BasisContract.apply(comp, V), W)
+
+
+@pytest.mark.parametrize("N,C,n,scale", [(5000, 11, 1000, 1.0), (300, 2, 340, 0.25), (100000, 4, 40000, 3.0)])
+def test_cross_entropy_with_compact_gradient_matches_torch(N, C, n, scale):
+    """categorical_crossentropy (node_classification.py:439-444): loss and d loss / d logits against torch's
+    CrossEntropyLoss in float64 — labelled nodes listed twice among them (n > N case: `Y.nonzero()` never does that,
+    the kernel must still add), an upstream gradient other than 1, and the row flags that travel with the gradient."""
+    from mrgcn_amd import functional as Fn
+    from mrgcn_amd.train import categorical_crossentropy
+    g = torch.Generator("cuda").manual_seed(N)
+    buf = torch.randn((N, C + 1), device="cuda", generator=g)
+    logits = buf[:, :C].clone().requires_grad_(True)           # dense; the strided form below
+    idx = torch.randint(0, N, (n,), device="cuda", generator=g)
+    tgt = torch.randint(0, C, (n,), device="cuda", generator=g)
+    seen = {}
+    loss = categorical_crossentropy(logits, idx, tgt)
+    hook = logits.register_hook(lambda gr: seen.update(meta=Fn._grad_meta(gr)))
+    (loss * scale).backward()
+    hook.remove()
+    l64 = logits.detach().double().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss()(l64[idx], tgt)
+    (ref * scale).backward()
+    torch.testing.assert_close(loss.double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(logits.grad.double(), l64.grad, rtol=1e-4, atol=1e-7)
+    flags = seen["meta"]["row_live"]
+    want = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    want[idx] = 1
+    assert torch.equal(flags, want) and not seen["meta"]["relu_applied"]
+    strided = buf[:, :C].detach().requires_grad_(True)          # rows with a pad (a layer's padded output)
+    torch.testing.assert_close(categorical_crossentropy(strided, idx, tgt), loss.detach(), rtol=1e-6, atol=1e-7)
