@@ -279,12 +279,34 @@ __global__ __launch_bounds__(1024) void k_xent_rows(const float *__restrict__ lo
   const float inv_n = 1.f / (float)n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float *z = logits + idx[i] * ld;
+    const int64_t t = target[i];
+    if (C <= 16) {  // the row in registers: all its loads in flight at once (a loop over z[c] waits for each)
+      float zz[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) zz[c] = c < C ? z[c] : -INFINITY;
+      float mx = zz[0];
+#pragma unroll
+      for (int c = 1; c < 16; ++c) mx = fmaxf(mx, zz[c]);
+      float se = 0.f, zt = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if (c < C) se += expf(zz[c] - mx);
+        if (c == t) zt = zz[c];
+      }
+      const float lse = logf(se) + mx;
+      my += (lse - zt) * inv_n;
+      if (drows) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+          if (c < C) drows[i * C + c] = (expf(zz[c] - lse) - (c == t ? 1.f : 0.f)) * inv_n;
+      }
+      continue;
+    }
     float mx = z[0];
     for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
     const float lse = logf(se) + mx;
-    const int64_t t = target[i];
     my += (lse - z[t]) * inv_n;
     if (drows)
       for (int c = 0; c < C; ++c) drows[i * C + c] = (expf(z[c] - lse) - (c == t ? 1.f : 0.f)) * inv_n;

@@ -1245,23 +1245,64 @@ __global__ __launch_bounds__(kTB) void k_basis_contract(const float *__restrict_
   }
 }
 
+// backward: block ranges [0, dv_blocks): dV; the rest: dcomp.
+//   dV[b, x] = sum_r comp[r, b] dW[r, x]: a block owns 64 columns x and every basis b; comp lives in LDS (R * B floats),
+//   thread (x, q) sums the relations r = q mod 4 into B register accumulators (one coalesced load of dW per relation,
+//   B broadcast LDS reads), the four partial sums meet in LDS in a fixed order.  B <= kContractMaxB, R * B * 4 bytes
+//   of LDS; otherwise the plain thread-per-output walk.
+constexpr int kContractMaxB = 64;
+template <int BT>
 __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restrict__ comp, const float *__restrict__ V,
                                                             const float *__restrict__ dW, int R, int B, int64_t X,
                                                             float *__restrict__ dcomp, float *__restrict__ dV,
-                                                            int dv_blocks) {
-  if ((int)blockIdx.x < dv_blocks) {  // dV[b, x] = sum_r comp[r, b] dW[r, x]: a thread per output
+                                                            int dv_blocks, int tiled) {
+  extern __shared__ float s_mem[];
+  if ((int)blockIdx.x < dv_blocks) {
     if (!dV) return;
-    const int64_t total = (int64_t)B * X;
-    for (int64_t t = (int64_t)blockIdx.x * kTB + threadIdx.x; t < total; t += (int64_t)dv_blocks * kTB) {
-      const int64_t b = t / X, x = t - b * X;
-      float s0 = 0.f, s1 = 0.f;
-      int r = 0;
-      for (; r + 2 <= R; r += 2) {
-        s0 = fmaf(comp[(int64_t)r * B + b], dW[(int64_t)r * X + x], s0);
-        s1 = fmaf(comp[(int64_t)(r + 1) * B + b], dW[(int64_t)(r + 1) * X + x], s1);
+    if (!tiled) {  // dV[b, x]: a thread per output
+      const int64_t total = (int64_t)B * X;
+      for (int64_t t = (int64_t)blockIdx.x * kTB + threadIdx.x; t < total; t += (int64_t)dv_blocks * kTB) {
+        const int64_t b = t / X, x = t - b * X;
+        float s0 = 0.f, s1 = 0.f;
+        int r = 0;
+        for (; r + 2 <= R; r += 2) {
+          s0 = fmaf(comp[(int64_t)r * B + b], dW[(int64_t)r * X + x], s0);
+          s1 = fmaf(comp[(int64_t)(r + 1) * B + b], dW[(int64_t)(r + 1) * X + x], s1);
+        }
+        if (r < R) s0 = fmaf(comp[(int64_t)r * B + b], dW[(int64_t)r * X + x], s0);
+        dV[t] = s0 + s1;
       }
-      if (r < R) s0 = fmaf(comp[(int64_t)r * B + b], dW[(int64_t)r * X + x], s0);
-      dV[t] = s0 + s1;
+      return;
+    }
+    float *s_comp = s_mem;                 // [R][B]
+    float *s_part = s_mem + (size_t)R * B; // [4][BT][64]
+    for (int t = threadIdx.x; t < R * B; t += kTB) s_comp[t] = comp[t];
+    __syncthreads();
+    const int xl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t x = (int64_t)blockIdx.x * 64 + xl;
+    float acc[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) acc[b] = 0.f;
+    if (x < X) {
+#pragma unroll 4
+      for (int r = q; r < R; r += 4) {
+        const float d = dW[(int64_t)r * X + x];
+        const float *c = s_comp + r * B;
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+          if (b < B) acc[b] = fmaf(c[b], d, acc[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+      if (b < B) s_part[(q * BT + b) * 64 + xl] = acc[b];
+    __syncthreads();
+    for (int t = threadIdx.x; t < B * 64; t += kTB) {
+      const int b = t >> 6, xx = t & 63;
+      const int64_t xo = (int64_t)blockIdx.x * 64 + xx;
+      if (xo < X)
+        dV[(int64_t)b * X + xo] = (s_part[(0 * BT + b) * 64 + xx] + s_part[(1 * BT + b) * 64 + xx]) +
+                                  (s_part[(2 * BT + b) * 64 + xx] + s_part[(3 * BT + b) * 64 + xx]);
     }
     return;
   }
@@ -1573,11 +1614,29 @@ int mrgcn_basis_contract_bwd_f32(const float *comp, const float *V, const float 
                                  float *dcomp, float *dV, void *stream) {
   MRGCN_REQUIRE(comp && V && dW, "NULL");
   MRGCN_REQUIRE(R > 0 && B > 0 && X > 0, "R / B / X");
-  const int dv_blocks = dV ? grid_for((int64_t)B * X) : 0;
+  const int BT = B <= 16 ? 16 : (B <= 32 ? 32 : (B <= 48 ? 48 : 64));
+  const size_t lds = ((size_t)R * B + (size_t)4 * BT * 64) * sizeof(float);
+  const int tiled = B <= kContractMaxB && lds <= 150 * 1024;
+  const int dv_blocks = !dV ? 0 : (tiled ? (int)((X + 63) / 64) : grid_for((int64_t)B * X));
   const int dc_blocks = dcomp ? (int)(((int64_t)R * B * 64 + kTB - 1) / kTB) : 0;
   if (dv_blocks + dc_blocks == 0) return MRGCN_OK;
-  k_basis_contract_bwd<<<dim3(dv_blocks + dc_blocks), dim3(kTB), 0, (hipStream_t)stream>>>(comp, V, dW, R, B, X, dcomp,
-                                                                                          dV, dv_blocks);
+  const dim3 grid(dv_blocks + dc_blocks);
+  const size_t sh = tiled ? lds : 0;
+#define CONTRACT_BWD(BT_)                                                                                          \
+  do {                                                                                                             \
+    auto kfn = k_basis_contract_bwd<BT_>;                                                                          \
+    static size_t lds_allowed = 48 * 1024; /* per instantiation: raise the dynamic-LDS limit once */               \
+    if (sh > lds_allowed) {                                                                                        \
+      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));  \
+      lds_allowed = sh;                                                                                            \
+    }                                                                                                              \
+    kfn<<<grid, dim3(kTB), sh, (hipStream_t)stream>>>(comp, V, dW, R, B, X, dcomp, dV, dv_blocks, tiled);          \
+  } while (0)
+  if (BT == 16) CONTRACT_BWD(16);
+  else if (BT == 32) CONTRACT_BWD(32);
+  else if (BT == 48) CONTRACT_BWD(48);
+  else CONTRACT_BWD(64);
+#undef CONTRACT_BWD
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
