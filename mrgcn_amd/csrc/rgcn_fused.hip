@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dv(const int32_t *__restrict
 }
 
 // ---- wave over nodes, lane = basis ---------------------------------------------------------------
-constexpr int kNodeTB = 512;  // 8 waves share one LDS copy of the dcomp accumulators
+constexpr int kNodeTB = 1024;  // launch bound; the block size is picked at launch (MRGCN_MIX_BWD_TB): its waves share one LDS copy of the dcomp accumulators
 constexpr int kGroup = 4;     // consecutive nodes whose pointers / flags / relation ids a wave fetches at once
 
 // F floats of one basis row, rows only 4 * F bytes apart: 8-byte aligned when F is even.  The vector memory
@@ -1420,10 +1420,13 @@ int mix_bwd_nm_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const
   if (!dc_in_lds) lds = 0;
   // register arrays of exactly F features for the hidden sizes of the BASELINE configs (10, 11)
   const int FT = (F == 10 || F == 11) ? F : (F + 3) / 4 * 4;
+  static const int tb = (getenv("MRGCN_MIX_BWD_TB") && atoi(getenv("MRGCN_MIX_BWD_TB")) >= 64 &&
+                         atoi(getenv("MRGCN_MIX_BWD_TB")) <= kNodeTB) ? atoi(getenv("MRGCN_MIX_BWD_TB")) / 64 * 64 : 512;
   int per_cu = lds > 0 ? (int)((160 * 1024) / (lds + 1024)) : 4;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
-  const int64_t want = ((N + kGroup - 1) / kGroup + (kNodeTB / 64) - 1) / (kNodeTB / 64);
+  if (per_cu * tb > 2048) per_cu = 2048 / tb;  // 32 waves per CU at most
+  const int64_t want = ((N + kGroup - 1) / kGroup + (tb / 64) - 1) / (tb / 64);
   int64_t grid = (int64_t)256 * per_cu;
   if (grid > want) grid = want;
 #define NODE_GO(T)                                                                                        \
@@ -1435,7 +1438,7 @@ int mix_bwd_nm_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const
                                         (int)lds));                                                       \
       lds_allowed = lds;                                                                                  \
     }                                                                                                     \
-    kfn<<<dim3((unsigned)grid), dim3(kNodeTB), lds, s>>>(p->nptr, p->urel, dM, ldM, V, comp, N, R, B, F, dV, \
+    kfn<<<dim3((unsigned)grid), dim3(tb), lds, s>>>(p->nptr, p->urel, dM, ldM, V, comp, N, R, B, F, dV, \
                                                          dcomp, dV_sumsq, (int)p->top_rel, col_live,     \
                                                          node_cur, dc_in_lds);                           \
   } while (0)

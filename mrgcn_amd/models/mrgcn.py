@@ -208,6 +208,11 @@ class MRGCN(nn.Module):
                     data = self.im_norm.normalize_(data)
                 elif datatype == "blob.image":
                     data = data.float()
+                if X.is_cuda and any(not q.is_cuda for q in module.parameters()):
+                    from .. import _lib
+                    raise _lib.MrgcnError(f"{datatype}: the encoder lives on the CPU while the R-GCN runs on the GPU — "
+                                          "mrgcn_amd has no CPU encoder path on a GPU box (move the module: "
+                                          "batch.to(model.devices) / model.to(device))")
                 if isinstance(module, MLP) and X.is_cuda and data.device == X.device and module.fused_ok(data):
                     # every Linear + ReLU, the gate and the scatter in one kernel (csrc/encoders.hip)
                     from .. import dense

@@ -4,10 +4,15 @@ whose widths step linearly from `input_dim` down to `output_dim`, every weight a
 from U(0, 1) in parameter order (so the same seed gives the reference's values; state-dict keys
 `mlp.<3k>.weight|bias`).  Inside `MRGCN` the whole encoder — every Linear + ReLU, the gate multiply and
 the scatter into the feature matrix — is ONE HIP kernel (`dense.mlp_gate_scatter`, csrc/encoders.hip) when
-the literals live on the GPU, the widths are <= 16 and dropout is inactive; `forward` below (nn.Linear) is
-what runs otherwise (CPU-side tooling, wider layers, p_dropout > 0 in training)."""
+the literals live on the GPU, the widths are <= 16 and dropout is inactive.  Otherwise on the GPU (wider layers,
+p_dropout > 0 in training, a stand-alone call) `forward` runs every Linear + ReLU on the matrix-core GEMM of
+csrc/encoders.hip (`dense.linear`), with torch's dropout mask between layers — ReLU and inverted dropout commute
+(the mask zeroes, the scale is positive), so Linear -> Dropout -> ReLU is computed as Linear+ReLU -> Dropout.
+CPU tensors (host-side tooling, a GPU-less test box) take nn.Linear; inside `MRGCN` on a GPU box that never happens
+(the encoders are placed next to the R-GCN, `MRGCN._compute_modality_embeddings` refuses a CPU encoder there)."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 
 def layer_widths(input_dim: int, output_dim: int, num_layers: int):
@@ -33,7 +38,16 @@ class MLP(nn.Module):
             tensor.uniform_(0.0, 1.0)
 
     def forward(self, X):
-        return self.mlp(X)
+        from .. import dense
+        lin = self.linears()
+        if not (X.is_cuda and all(l.weight.is_cuda for l in lin)):
+            return self.mlp(X)                      # host-side tooling only (see the module docstring)
+        X = X.float()
+        for l in lin:
+            X = dense.linear(X, l.weight, l.bias, relu=True)
+            if self.training and self.p_dropout > 0:
+                X = F.dropout(X, self.p_dropout, True)
+        return X
 
     def linears(self):
         return [m for m in self.mlp if isinstance(m, nn.Linear)]

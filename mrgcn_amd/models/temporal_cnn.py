@@ -76,8 +76,9 @@ class TCNN(nn.Module):
                 X = dense.bn_relu_pool(X, m, kind, arg)
                 i += used
             else:
-                X = m(X)
-                i += 1
+                from .. import _lib
+                raise _lib.MrgcnError(f"TCNN: no HIP kernel for {type(m).__name__} at position {i} of the "
+                                      "convolution stack (expected Conv1d, BatchNorm1d + ReLU [+ pooling])")
         X = dense.linear(X.view(X.size(0), -1), self.fc[0].weight, self.fc[0].bias, relu=True)
         return dense.linear(self.fc[2](X), self.fc[3].weight, self.fc[3].bias)
 

@@ -401,3 +401,64 @@ def test_batchnorm_relu_pool_block_vs_torch(B, C, T, kind, arg):
     (ye * w.float().cuda()).sum().backward()
     (yre * w).sum().backward()
     np.testing.assert_allclose(xe.grad.cpu().numpy(), xre.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_mlp_beyond_the_fused_kernel_runs_on_hip_kernels_too():
+    """perceptron.py:6-46 outside the limits of the one-kernel form (layer widths > 16; dropout active in training):
+    on the GPU every Linear + ReLU is the matrix-core GEMM of csrc/encoders.hip — never torch.nn's — and equals the
+    same module in float64 on the host: values, input gradient, weight gradients.  With dropout the HIP products
+    still run (the autograd graph shows them), a fraction p of the outputs is zeroed and the rest scaled by
+    1 / (1 - p), like Linear -> Dropout -> ReLU."""
+    import copy
+    from mrgcn_amd import dense
+    from mrgcn_amd.models.perceptron import MLP
+    torch.manual_seed(5)
+    m = MLP(input_dim=40, output_dim=22, num_layers=3, p_dropout=0.0).cuda()
+    assert not m.fused_ok(torch.zeros((3, 40), device="cuda"))           # too wide for the fused kernel
+    with torch.no_grad():
+        for l in m.linears():                                             # (U(0,1) weights blow up 40 -> 22: rescale)
+            l.weight.mul_(0.1)
+    x = (torch.randn((500, 40), device="cuda") * 0.5).requires_grad_(True)
+    y = m(x)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+
+    def nodes(fn, seen=None):
+        seen = set() if seen is None else seen
+        if fn is None or fn in seen:
+            return seen
+        seen.add(fn)
+        for nxt, _ in fn.next_functions:
+            nodes(nxt, seen)
+        return seen
+    assert sum(type(f).__name__.startswith("_Linear") for f in nodes(y.grad_fn)) == 3
+    ref = copy.deepcopy(m).cpu().double()
+    x64 = x.detach().cpu().double().requires_grad_(True)
+    y64 = ref.mlp(x64)
+    (y64 * w.cpu().double()).sum().backward()
+    torch.testing.assert_close(y.detach().cpu().double(), y64.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(x.grad.cpu().double(), x64.grad, rtol=1e-3, atol=1e-4)
+    for a, b in zip(m.linears(), [l for l in ref.mlp if isinstance(l, nn.Linear)]):
+        torch.testing.assert_close(a.weight.grad.cpu().double(), b.weight.grad, rtol=1e-3, atol=1e-3)
+    # dropout active: HIP products + torch's mask
+    md = MLP(input_dim=8, output_dim=4, num_layers=2, p_dropout=0.5).cuda().train()
+    assert not md.fused_ok(torch.zeros((3, 8), device="cuda"))
+    xd = torch.rand((20000, 8), device="cuda") + 0.5                      # positive inputs and weights: no ReLU zeros
+    yd = md(xd)
+    assert sum(type(f).__name__.startswith("_Linear") for f in nodes(yd.grad_fn)) == 2
+    assert 0.45 < float((yd == 0).float().mean()) < 0.55
+    md.eval()
+    assert md.fused_ok(xd) and float((md(xd) == 0).float().mean()) == 0.0
+
+
+@pytest.mark.gpu
+def test_a_cpu_encoder_next_to_a_gpu_rgcn_is_refused():
+    """No silent host detour on a GPU box: MRGCN refuses an encoder whose parameters live on the CPU."""
+    from mrgcn_amd import _lib
+    from mrgcn_amd.models.mrgcn import MRGCN
+    model = MRGCN([(3, 4, "mrgcn", None)], [("xsd.numeric", (4, 3, 0.0), False)], 3, 20, num_bases=0, featureless=False)
+    model.module_dict["xsd_numeric_0"].cpu()
+    F = [["xsd.numeric", [[torch.randn((5, 4), device="cuda"), torch.arange(5, device="cuda"), None]], False]]
+    with pytest.raises(_lib.MrgcnError, match="CPU"):
+        model._compute_modality_embeddings(F, torch.arange(20), full_batch=True)

@@ -85,6 +85,7 @@ def main():
         "mix_fwd_add": lambda: chk(lib.mrgcn_basis_mix_fwd_f32(h, V.data_ptr(), comp.data_ptr(), B, F, M2.data_ptr(), 12, M.data_ptr(), ld, s)),
         "mix_bwd": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, 0, V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), 0, dcomp.data_ptr(), 0, s)),
         "mix_bwd_rows": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, clive.data_ptr(), V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), ncur.data_ptr(), dcomp.data_ptr(), sq.data_ptr(), s)),
+        "mix_bwd_norm": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, clive.data_ptr(), V.data_ptr(), comp.data_ptr(), B, F, 0, ncur.data_ptr(), dcomp.data_ptr(), sq.data_ptr(), s)),
         "adam_rows": lambda: chk(lib.mrgcn_adam_step_rows_f32(P.data_ptr(), dV.data_ptr(), M_.data_ptr(), V_.abs_().data_ptr(), N, B * F, ncur.data_ptr(), never.data_ptr(), 0.01, 0.9, 0.999, 1e-8, 1, 0, coef.data_ptr(), s)),
         "spmm_tl10": lambda: chk(lib.mrgcn_spmm_transposed_live_f32(h, dYz.data_ptr(), 10, 10, dM.data_ptr(), 12, scratch.data_ptr(), clive.data_ptr(), 0, 1, s)),
         "spmm_tl10_nd": lambda: chk(lib.mrgcn_spmm_transposed_live_f32(h, dYz.data_ptr(), 10, 10, dM.data_ptr(), 12, scratch.data_ptr(), clive.data_ptr(), 0, 0, s)),
