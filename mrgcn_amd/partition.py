@@ -261,17 +261,35 @@ class _NoBias:
         return getattr(self._l, k)
 
 
+def _label_shard(idx_global, targets, part: NodePartition, dev):
+    """This rank's labelled rows (local row index, target) as device tensors + its share of the mean, built ONCE per
+    label set and kept on the partition object: a step then uploads nothing and builds no host masks
+    (the label set of a run is fixed: node_classification.py:378-381)."""
+    cache = part.__dict__.setdefault("_label_shards", {})
+    key = (id(idx_global), id(targets), str(dev))
+    ent = cache.get(key)
+    if ent is not None and ent[0] is idx_global and ent[1] is targets:
+        return ent[2]
+    idx_np = idx_global.detach().cpu().numpy() if torch.is_tensor(idx_global) else np.asarray(idx_global)
+    tgt_np = targets.detach().cpu().numpy() if torch.is_tensor(targets) else np.asarray(targets)
+    mine = (idx_np >= part.j0) & (idx_np < part.j1)
+    if mine.any():
+        shard = (torch.from_numpy(idx_np[mine] - part.j0).to(dev), torch.from_numpy(tgt_np[mine]).to(dev),
+                 float(mine.sum()) / len(idx_np))
+    else:
+        shard = (None, None, 0.0)
+    if len(cache) > 16:
+        cache.clear()
+    cache[key] = (idx_global, targets, shard)
+    return shard
+
+
 def partitioned_loss(logits_local, idx_global, targets, part: NodePartition, group=None):
     """Mean cross-entropy over ALL labelled nodes; each rank differentiates its own rows."""
     from .train import categorical_crossentropy
-    idx_global = np.asarray(idx_global)
-    mine = (idx_global >= part.j0) & (idx_global < part.j1)
-    n_total = len(idx_global)
-    dev = logits_local.device
-    if mine.any():
-        li = torch.from_numpy(idx_global[mine] - part.j0).to(dev)
-        lt = torch.from_numpy(np.asarray(targets)[mine]).to(dev)
-        local = categorical_crossentropy(logits_local, li, lt) * (float(mine.sum()) / n_total)
+    li, lt, share = _label_shard(idx_global, targets, part, logits_local.device)
+    if li is not None:
+        local = categorical_crossentropy(logits_local, li, lt) * share
     else:
         local = (logits_local * 0.0).sum()
     total = local.detach().clone()
