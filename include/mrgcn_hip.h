@@ -127,7 +127,8 @@ int mrgcn_plan_create_csr(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nod
  * products will read — 4 * F for the packed rows of a layer of F outputs (F not a multiple of four), 4 * roundup(F, 4)
  * for padded rows, 2 * ld for bf16 rows.  The order of M keeps columns that several rows read off the positions
  * whose row would straddle a 128-byte line for any of these sizes (a re-read then costs one line, not two; AM
- * shape, F = 10: 158 -> 148 us with 40-byte rows).  Results never depend on the hint.  At most four sizes are
+ * shape, F = 10: 158 -> 148 us with 40-byte rows).  The hint only permutes the operand rows (MPOS): products are
+ * the same up to the order in which a row's terms are added.  At most four sizes are
  * used; without a hint (or through the plain constructors) 48-byte rows are assumed. */
 int mrgcn_plan_create_hinted(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nodes,
                              int32_t num_relations, int64_t nnz, const int64_t *coo_rows,

@@ -231,3 +231,42 @@ def plan_of(A: torch.Tensor, num_nodes: int, num_relations: int, operand_row_byt
         p = GraphPlan(A, num_nodes, num_relations, operand_row_bytes=operand_row_bytes)
         A._mrgcn_plan = p
     return p
+
+
+def build_plans_parallel(jobs) -> None:
+    """Builds the plans of several adjacency tensors at once: `jobs` = [(A, num_nodes, num_relations,
+    operand_row_bytes), ...]; those that carry a plan already are skipped.  A plan build is a chain of short device
+    passes with host read-backs of sizes in between (a few ms of mostly waiting for a small slice); the builds of a
+    re-sampled mini-batch's slices (two per layer) are independent, so each runs in its own host thread on its own
+    stream — the waits overlap — and the caller's stream waits for all of them.  The C ABI is thread-safe per plan
+    handle; ctypes releases the GIL for the duration of a call."""
+    import threading
+    todo = [j for j in jobs if getattr(j[0], "_mrgcn_plan", None) is None or j[0]._mrgcn_plan._h is None]
+    if len(todo) <= 1:
+        for j in todo:
+            plan_of(*j)
+        return
+    dev = todo[0][0].device
+    cur = torch.cuda.current_stream(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in todo]
+    errors = []
+
+    def work(job, st):
+        try:
+            with torch.cuda.device(dev), torch.cuda.stream(st):
+                plan_of(*job)
+        except BaseException as e:  # noqa: BLE001  (re-raised on the caller's thread)
+            errors.append(e)
+
+    threads = []
+    for job, st in zip(todo, streams):
+        st.wait_stream(cur)
+        t = threading.Thread(target=work, args=(job, st), daemon=True)
+        t.start()
+        threads.append(t)
+    for t in threads:
+        t.join()
+    for st in streams:
+        cur.wait_stream(st)
+    if errors:
+        raise errors[0]

@@ -105,7 +105,9 @@ def test_model_on_adjacency_handle_from_tarball():
     out_ref = model(ref)
     b1.X[0] = torch.from_numpy(b1.X[0])
     out = model(b1)
-    torch.testing.assert_close(out, out_ref, rtol=0, atol=0)
+    # (two plans of the same adjacency: built from the CSR without a layout hint and from the COO with the model's —
+    # the operand order, hence the order in which a row's terms are added, may differ)
+    torch.testing.assert_close(out, out_ref, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("gname", ["graph_small", "graph_smoke"])
