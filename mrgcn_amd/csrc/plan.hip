@@ -6,7 +6,9 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -339,24 +341,104 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
   }
 }
 
-// Device memory of a plan build comes from the device's stream-ordered pool (hipMallocAsync): building the plans of
-// re-sampled mini-batch slices over and over then reuses the same blocks instead of paying a driver allocation and
-// an implicit device synchronisation (hipFree) per array.  The pool keeps up to kPoolKeep bytes between builds.
+// Device memory of a plan build: a small caching allocator in front of the device's stream-ordered pool
+// (hipMallocAsync).  Building the plans of re-sampled mini-batch slices over and over asks for the same ~140 blocks
+// (60 plan arrays, 80 scratch arrays) again and again; through the driver's pool every hipMallocAsync / hipFreeAsync
+// costs tens of microseconds of host time once blocks have been freed (measured: 6-8 ms per slice plan against
+// 1.5-3.4 ms while nothing had been freed yet).  Freed blocks therefore park here, tagged with the stream whose order
+// protects them and the device's synchronisation epoch at the time: a request takes the smallest parked block of at
+// least its size (and at most four times it) that was freed on the SAME stream (stream order: the block's last
+// user runs before the new one) or before the last device-wide wait.  The cache keeps up to MRGCN_POOL_KEEP_MB
+// (default 4096) per device; what does not fit goes back to the driver's pool.
 constexpr uint64_t kPoolKeep = 4ull << 30;
 
+struct ParkedBlock { void *ptr; size_t bytes; hipStream_t stream; uint64_t epoch; };
+struct BlockCache {
+  std::mutex mu;
+  std::multimap<size_t, ParkedBlock> free_blocks;   // by size
+  std::unordered_map<void *, size_t> live;            // blocks handed out: their real size
+  uint64_t parked_bytes = 0, epoch = 1, safe_epoch = 0;  // blocks parked with epoch <= safe_epoch: free for any stream
+  uint64_t keep = kPoolKeep;
+  bool configured = false;
+};
+BlockCache &cache_of(int dev) {
+  static BlockCache caches[64];
+  return caches[(dev >= 0 && dev < 64) ? dev : 0];
+}
+
 hipError_t pool_alloc(void **p, size_t bytes, hipStream_t s) {
-  static bool configured[64] = {};
   int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !configured[dev]) {
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-      // bytes the pool keeps between builds (MRGCN_POOL_KEEP_MB; default 4096)
-      uint64_t keep = getenv("MRGCN_POOL_KEEP_MB") ? (uint64_t)atoll(getenv("MRGCN_POOL_KEEP_MB")) << 20 : kPoolKeep;
-      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+  (void)hipGetDevice(&dev);
+  BlockCache &c = cache_of(dev);
+  bytes = (bytes + 255) / 256 * 256;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (!c.configured) {
+      hipMemPool_t pool;
+      if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+        c.keep = getenv("MRGCN_POOL_KEEP_MB") ? (uint64_t)atoll(getenv("MRGCN_POOL_KEEP_MB")) << 20 : kPoolKeep;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &c.keep);
+      }
+      c.configured = true;
     }
-    configured[dev] = true;
+    for (auto it = c.free_blocks.lower_bound(bytes); it != c.free_blocks.end() && it->first <= 4 * bytes + 4096; ++it) {
+      const ParkedBlock &b = it->second;
+      if (b.stream == s || b.epoch <= c.safe_epoch) {
+        *p = b.ptr;
+        c.live[b.ptr] = b.bytes;
+        c.parked_bytes -= b.bytes;
+        c.free_blocks.erase(it);
+        return hipSuccess;
+      }
+    }
   }
-  return hipMallocAsync(p, bytes, s);
+  hipError_t e = hipMallocAsync(p, bytes, s);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.live[*p] = bytes;
+  }
+  return e;
+}
+
+// stream ordered free: the block may be reused by later work on `s`, or by anyone once a device-wide wait that began
+// after this call has completed (`covered_epoch` != 0: such a wait — pool_sync_begin's return value — has completed
+// already)
+void pool_free(void *p, hipStream_t s, uint64_t covered_epoch = 0) {
+  if (!p) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  BlockCache &c = cache_of(dev);
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto it = c.live.find(p);
+    if (it != c.live.end()) {
+      bytes = it->second;
+      c.live.erase(it);
+      if (c.parked_bytes + bytes <= c.keep) {
+        c.free_blocks.emplace(bytes, ParkedBlock{p, bytes, s, covered_epoch ? covered_epoch : c.epoch});
+        c.parked_bytes += bytes;
+        return;
+      }
+    }
+  }
+  (void)hipFreeAsync(p, s);
+}
+
+// around a device-wide wait: blocks parked BEFORE pool_sync_begin are free for any stream once pool_sync_done ran
+uint64_t pool_sync_begin() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  BlockCache &c = cache_of(dev);
+  std::lock_guard<std::mutex> lock(c.mu);
+  return c.epoch++;
+}
+void pool_sync_done(uint64_t e) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  BlockCache &c = cache_of(dev);
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (e > c.safe_epoch) c.safe_epoch = e;
 }
 
 // An operand row that straddles a 128-byte line costs a re-reading row two line fetches instead of one.  A column read
@@ -399,7 +481,7 @@ __global__ void k_avoid_straddle(int32_t *__restrict__ order, const int32_t *__r
 struct Scratch {  // returns its allocations to the pool on scope exit, ordered after the build's work on `s`
   hipStream_t s = nullptr;
   std::vector<void *> ptrs;
-  ~Scratch() { for (void *p : ptrs) (void)hipFreeAsync(p, s); }
+  ~Scratch() { for (void *p : ptrs) pool_free(p, s); }
   template <typename T> hipError_t alloc(T **p, int64_t n) {
     hipError_t e = pool_alloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(T), s);
     if (e == hipSuccess) ptrs.push_back(*p);
@@ -934,10 +1016,12 @@ void free_plan(mrgcn_plan *p) {
   for (mrgcn_plan *q : parked) {
     const int qdev = q->device;
     if (qdev != cur) (void)hipSetDevice(qdev);
+    const uint64_t ep = pool_sync_begin();
     if (hipDeviceSynchronize() != hipSuccess) {
       (void)hipGetLastError();
       keep.push_back(q);
     } else {
+      pool_sync_done(ep);
       void *ptrs[] = {q->rowptr, q->lcol, q->ccol, q->rowidx, q->val, q->cptr, q->crow, q->urel, q->unode,
                       q->nptr, q->ulcol, q->mpos, q->mcol, q->mval, q->rperm, q->relptr, q->rnode, q->rmpos, q->relchunk_ptr, q->relchunk_ids, q->relchunk_rel, q->relchunk_beg, q->relchunk_end,
                       q->cval, q->r_long_row, q->r_long_cptr, q->r_chunk_beg, q->r_chunk_end,
@@ -948,8 +1032,9 @@ void free_plan(mrgcn_plan *p) {
                       q->r3s_long_row, q->r3s_long_cptr, q->r3s_chunk_beg, q->r3s_chunk_end, q->r3s_chunk_row,
                       q->n_rperm, q->n_relptr, q->n_rnode, q->n_rmpos, q->n_relchunk_rel, q->n_relchunk_beg,
                       q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids};
-      for (void *a : ptrs)
-        if (a) (void)hipFreeAsync(a, nullptr);
+      // (after the device-wide wait any stream may take the blocks; the plan's own build stream is where the next
+      // build of a similar slice will ask for them again: the pool hands them back without a driver call)
+      for (void *a : ptrs) pool_free(a, q->build_stream, ep);
       delete q;
     }
     if (qdev != cur) (void)hipSetDevice(cur);
@@ -1048,9 +1133,9 @@ int mrgcn_plan_create_csr_hinted(mrgcn_plan_t **plan, int64_t num_rows, int64_t 
     rc = mrgcn_plan_create_hinted(plan, num_rows, num_nodes, num_relations, nnz, rows, cols, vals, MRGCN_VAL_F32,
                                   flags, operand_row_bytes, n_row_bytes, stream);
   }
-  if (rows) (void)hipFreeAsync(rows, s);  // stream ordered: after the build's last read
-  if (cols) (void)hipFreeAsync(cols, s);
-  if (vals) (void)hipFreeAsync(vals, s);
+  mrgcn::pool_free(rows, s);  // stream ordered: after the build's last read
+  mrgcn::pool_free(cols, s);
+  mrgcn::pool_free(vals, s);
   return rc;
 }
 

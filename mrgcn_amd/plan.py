@@ -233,6 +233,9 @@ def plan_of(A: torch.Tensor, num_nodes: int, num_relations: int, operand_row_byt
     return p
 
 
+_BUILD_STREAMS: dict = {}
+
+
 def build_plans_parallel(jobs) -> None:
     """Builds the plans of several adjacency tensors at once: `jobs` = [(A, num_nodes, num_relations,
     operand_row_bytes), ...]; those that carry a plan already are skipped.  A plan build is a chain of short device
@@ -248,7 +251,12 @@ def build_plans_parallel(jobs) -> None:
         return
     dev = todo[0][0].device
     cur = torch.cuda.current_stream(dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in todo]
+    # the same few streams every time: the stream-ordered pool hands a freed block back without a driver call only to
+    # the stream that freed it
+    pool = _BUILD_STREAMS.setdefault(dev, [])
+    while len(pool) < len(todo):
+        pool.append(torch.cuda.Stream(device=dev))
+    streams = pool[: len(todo)]
     errors = []
 
     def work(job, st):
