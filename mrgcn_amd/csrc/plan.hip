@@ -541,13 +541,12 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(plan_alloc(p, chunk_beg, h[1]));
   MRGCN_HIP_TRY(plan_alloc(p, chunk_end, h[1]));
   MRGCN_HIP_TRY(plan_alloc(p, chunk_row, h[1]));
-  MRGCN_HIP_TRY(hipMemcpyAsync(*long_cptr + h[0], &h[1], sizeof(int32_t), hipMemcpyHostToDevice, s));
+  k_fill_i32<<<1, 1, 0, s>>>(*long_cptr + h[0], 1, h[1]);  // the total closes the chunk ranges (no host pointer: no wait)
   if (rows > 0 && h[0] > 0)
     k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, chunk, cap, blockwise, is_long, long_pos, chunk_pos,
                                               *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row);
   MRGCN_HIP_TRY(hipGetLastError());
-  MRGCN_HIP_TRY(hipStreamSynchronize(s));
-  return MRGCN_OK;
+  return MRGCN_OK;  // (stream ordered from here on: the scratch goes back tagged with the stream)
 }
 
 // long rows of several chunks: flag, (scan), positions
@@ -779,7 +778,6 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
       if (rc0 != MRGCN_OK) return rc0;
     }
   }
-  MRGCN_HIP_TRY(hipStreamSynchronize(s));
 
   int rc;
   if ((rc = build_long(p, p->cptr, p->ncols, s, &p->c_long_row, &p->c_long_cptr, &p->c_chunk_beg,
@@ -897,7 +895,6 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     }
     k_keys_to_pos<<<nblocks(nnz), kTB, 0, s>>>(rk_s, nnz, ncols, p->mcol);
     MRGCN_HIP_TRY(hipGetLastError());
-    MRGCN_HIP_TRY(hipStreamSynchronize(s));
     p->n_op = ncols;
     if (replicate && hot_min > 1) {
       // every entry of a non-hot column gets its own operand row, in processing order
@@ -947,7 +944,6 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
       k_gather_i32<<<nblocks(ncols), kTB, 0, s>>>(p->mpos, p->n_rperm, ncols, p->n_rmpos);
     }
     MRGCN_HIP_TRY(hipGetLastError());
-    MRGCN_HIP_TRY(hipStreamSynchronize(s));
   }
   if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r_long_row, &p->r_long_cptr, &p->r_chunk_beg,
                        &p->r_chunk_end, &p->r_chunk_row, &p->r_n_long, &p->r_n_chunks, &p->max_row_nnz)))
@@ -993,7 +989,6 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     MRGCN_HIP_TRY(plan_alloc(p, &p->r3_multi, h));
     if (h > 0) k_multi_fill<<<nblocks(nl), kTB, 0, s>>>(flag, pos, nl, p->r3_multi);
     MRGCN_HIP_TRY(hipGetLastError());
-    MRGCN_HIP_TRY(hipStreamSynchronize(s));
   }
   int64_t ws = (int64_t)std::max(std::max(p->r_n_chunks, p->q_n_chunks), p->c_n_chunks) * kWsFeatures;
   ws = std::max<int64_t>(ws, (int64_t)p->r3_n_chunks * 16);
@@ -1210,6 +1205,8 @@ int mrgcn_plan_export(const mrgcn_plan_t *p, int32_t which, void *h_dst, int64_t
   int rc = plan_lookup(p, which, &src, &n);
   if (rc != MRGCN_OK) return rc;
   MRGCN_REQUIRE(capacity_bytes >= n * 4, "destination too small");
+  // (the build ends stream ordered, not synchronised: wait for its stream before the blocking copy)
+  MRGCN_HIP_TRY(hipStreamSynchronize(p->build_stream));
   if (n > 0) MRGCN_HIP_TRY(hipMemcpy(h_dst, src, (size_t)n * 4, hipMemcpyDeviceToHost));
   return MRGCN_OK;
 }

@@ -75,8 +75,9 @@ def minibatch():
     out["reused_batch_fwd_bwd_adam_ms"] = round(timed(again, iters=10, warm=2), 2)
     out.update(neighbours=sizes, batch_build_ms=round(float(np.median(t_build)), 2),
                plans_fwd_bwd_adam_ms=round(float(np.median(t_step)), 2),
-               note="a re-sampled batch every step: structure on the device, four slice plans, forward, backward, "
-                    "dense Adam on the full node table (mini-batch steps do not use the row-sparse update)")
+               note="a re-sampled batch every step: structure on the device, its slice plans (built side by side, "
+                    "blocks from the plan allocator's cache), forward, backward, dense Adam on the full node table "
+                    "(mini-batch steps do not use the row-sparse update)")
     return out
 
 
