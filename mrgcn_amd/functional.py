@@ -147,7 +147,9 @@ _SIDE_STREAMS: dict = {}
 def _side_stream(device) -> torch.cuda.Stream:
     st = _SIDE_STREAMS.get(device)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        # MRGCN_SIDE_PRIORITY (default 0 = the current stream's): -1 lets the side stream's kernels (the transforms'
+        # dW / dX) take compute units ahead of the mix backward they run beside
+        st = torch.cuda.Stream(device=device, priority=int(os.environ.get("MRGCN_SIDE_PRIORITY", "0")))
         _SIDE_STREAMS[device] = st
     return st
 
