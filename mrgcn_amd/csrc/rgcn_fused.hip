@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(kTB) void k_basis_contract(const float *__restrict_
   }
 }
 
-// backward: block ranges [0, dv_blocks): dV; the rest: dcomp.
+// backward, dV (dcomp: k_basis_contract_dcomp below).
 //   dV[b, x] = sum_r comp[r, b] dW[r, x]: a block owns 64 columns x and every basis b; comp lives in LDS (R * B floats),
 //   thread (x, q) sums the relations r = q mod 4 into B register accumulators (one coalesced load of dW per relation,
 //   B broadcast LDS reads), the four partial sums meet in LDS in a fixed order.  B <= kContractMaxB, R * B * 4 bytes
@@ -1257,8 +1257,7 @@ __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restr
                                                             float *__restrict__ dcomp, float *__restrict__ dV,
                                                             int dv_blocks, int tiled) {
   extern __shared__ float s_mem[];
-  if ((int)blockIdx.x < dv_blocks) {
-    if (!dV) return;
+  {
     if (!tiled) {  // dV[b, x]: a thread per output
       const int64_t total = (int64_t)B * X;
       for (int64_t t = (int64_t)blockIdx.x * kTB + threadIdx.x; t < total; t += (int64_t)dv_blocks * kTB) {
@@ -1304,20 +1303,31 @@ __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restr
         dV[(int64_t)b * X + xo] = (s_part[(0 * BT + b) * 64 + xx] + s_part[(1 * BT + b) * 64 + xx]) +
                                   (s_part[(2 * BT + b) * 64 + xx] + s_part[(3 * BT + b) * 64 + xx]);
     }
-    return;
   }
-  if (!dcomp) return;
-  // dcomp[r, b] = <dW[r, :], V[b, :]>: a wave per output, lanes over x
+}
+
+// dcomp[r, b] = <dW[r, :], V[b, :]>: a wave per output, lanes over x, eight loads of each operand in flight.  Its own
+// launch: sharing one with the dV blocks would give every block their 90 KB of LDS (one block per CU).
+__global__ __launch_bounds__(kTB) void k_basis_contract_dcomp(const float *__restrict__ V, const float *__restrict__ dW,
+                                                              int R, int B, int64_t X, float *__restrict__ dcomp) {
   const int lane = threadIdx.x & 63;
-  const int64_t w = ((int64_t)(blockIdx.x - dv_blocks) * kTB + threadIdx.x) >> 6;
+  const int64_t w = ((int64_t)blockIdx.x * kTB + threadIdx.x) >> 6;
   if (w >= (int64_t)R * B) return;
   const int64_t r = w / B, b = w - r * B;
   const float *a = dW + r * X, *v = V + b * X;
-  float s = 0.f;
-  for (int64_t x = lane; x < X; x += 64) s = fmaf(a[x], v[x], s);
+  float s[8];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) dcomp[w] = s;
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  int64_t x = lane;
+  for (; x + 7 * 64 < X; x += 8 * 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = fmaf(a[x + u * 64], v[x + u * 64], s[u]);
+  }
+  for (; x < X; x += 64) s[0] = fmaf(a[x], v[x], s[0]);
+  float t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  if (lane == 0) dcomp[w] = t;
 }
 
 template <typename OT>
@@ -1622,8 +1632,12 @@ int mrgcn_basis_contract_bwd_f32(const float *comp, const float *V, const float 
   const int tiled = B <= kContractMaxB && lds <= 150 * 1024;
   const int dv_blocks = !dV ? 0 : (tiled ? (int)((X + 63) / 64) : grid_for((int64_t)B * X));
   const int dc_blocks = dcomp ? (int)(((int64_t)R * B * 64 + kTB - 1) / kTB) : 0;
-  if (dv_blocks + dc_blocks == 0) return MRGCN_OK;
-  const dim3 grid(dv_blocks + dc_blocks);
+  if (dc_blocks > 0) {
+    k_basis_contract_dcomp<<<dim3(dc_blocks), dim3(kTB), 0, (hipStream_t)stream>>>(V, dW, R, B, X, dcomp);
+    MRGCN_HIP_TRY(hipGetLastError());
+  }
+  if (dv_blocks == 0) return MRGCN_OK;
+  const dim3 grid(dv_blocks);
   const size_t sh = tiled ? lds : 0;
 #define CONTRACT_BWD(BT_)                                                                                          \
   do {                                                                                                             \

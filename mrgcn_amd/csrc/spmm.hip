@@ -778,10 +778,8 @@ __global__ __launch_bounds__(256) void k_rows_live_mark(const float *__restrict_
     }
     row_live[i] = nz ? 1 : 0;
   }
-  if (n_live) {
-    const uint64_t m = __ballot(nz);
-    if (lane == 0 && m) atomicAdd(n_live, (int32_t)__popcll(m));
-  }
+  // (the count of live rows is taken by k_count_flags afterwards: one atomic per live wave on ONE address cost
+  // ~10 ns each — 56 us for the 5 565 live rows of the AM epoch's layer 0)
   int32_t b = 0, n = 0;
   if (nz) {
     b = rowptr[i];
@@ -793,6 +791,23 @@ __global__ __launch_bounds__(256) void k_rows_live_mark(const float *__restrict_
     todo &= todo - 1;
     const int32_t bb = __shfl(b, L, kWave), nn = __shfl(n, L, kWave);
     if (lane < nn) col_live[ccol[bb + lane]] = 1;
+  }
+}
+
+// number of set flag bytes: a few blocks, one atomic each
+__global__ __launch_bounds__(256) void k_count_flags(const uint8_t *__restrict__ flags, int64_t n,
+                                                     int32_t *__restrict__ out) {
+  int32_t c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    c += flags[i] != 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
+  __shared__ int32_t s_c[4];
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int32_t t = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    if (t) atomicAdd(out, t);
   }
 }
 
@@ -1205,6 +1220,10 @@ extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, 
         D, ldD, F, plan->num_rows, plan->rowptr, plan->ccol, row_live, col_live, live_rows,
         F <= 16 ? row_flags : nullptr);
     MRGCN_HIP_TRY(hipGetLastError());
+    if (live_rows) {
+      k_count_flags<<<dim3(64), dim3(256), 0, s>>>(row_live, plan->num_rows, live_rows);
+      MRGCN_HIP_TRY(hipGetLastError());
+    }
     SparseView rv = plan->view(MRGCN_VIEW_LITERAL);  // row-major entry coordinates, as `ccol`
     if (rv.n_chunks > 0) {
       const int64_t waves = rv.n_chunks;
