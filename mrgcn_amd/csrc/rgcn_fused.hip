@@ -1246,10 +1246,10 @@ __global__ __launch_bounds__(kTB) void k_basis_contract(const float *__restrict_
 }
 
 // backward, dV (dcomp: k_basis_contract_dcomp below).
-//   dV[b, x] = sum_r comp[r, b] dW[r, x]: a block owns 64 columns x and every basis b; comp lives in LDS (R * B floats),
-//   thread (x, q) sums the relations r = q mod 4 into B register accumulators (one coalesced load of dW per relation,
-//   B broadcast LDS reads), the four partial sums meet in LDS in a fixed order.  B <= kContractMaxB, R * B * 4 bytes
-//   of LDS; otherwise the plain thread-per-output walk.
+//   dV[b, x] = sum_r comp[r, b] dW[r, x]: a block owns 64 columns x and every basis b; thread (x, q = wave) sums the
+//   relations r = q mod 4 into B register accumulators (one coalesced load of dW per relation, eight in flight; the
+//   comp row of a relation is wave uniform: scalar loads), the four partial sums meet in LDS in a fixed order.
+//   B <= kContractMaxB; otherwise the plain thread-per-output walk.
 constexpr int kContractMaxB = 64;
 template <int BT>
 __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restrict__ comp, const float *__restrict__ V,
@@ -1273,24 +1273,33 @@ __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restr
       }
       return;
     }
-    float *s_comp = s_mem;                 // [R][B]
-    float *s_part = s_mem + (size_t)R * B; // [4][BT][64]
-    for (int t = threadIdx.x; t < R * B; t += kTB) s_comp[t] = comp[t];
-    __syncthreads();
-    const int xl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    float *s_part = s_mem;  // [4][BT][64]
+    const int xl = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave id: comp rows are wave uniform
     const int64_t x = (int64_t)blockIdx.x * 64 + xl;
     float acc[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[b] = 0.f;
-    if (x < X) {
-#pragma unroll 4
-      for (int r = q; r < R; r += 4) {
-        const float d = dW[(int64_t)r * X + x];
-        const float *c = s_comp + r * B;
+    const int64_t xc = x < X ? x : X - 1;  // (clamped: unconditional loads, eight relations in flight)
+    int r = q;
+    for (; r + 28 < R; r += 32) {
+      float d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d[u] = dW[(int64_t)(r + 4 * u) * X + xc];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float *c = comp + (int64_t)(r + 4 * u) * B;  // uniform address: scalar loads
 #pragma unroll
         for (int b = 0; b < BT; ++b)
-          if (b < B) acc[b] = fmaf(c[b], d, acc[b]);
+          if (b < B) acc[b] = fmaf(c[b], d[u], acc[b]);
       }
+    }
+    for (; r < R; r += 4) {
+      const float d = dW[(int64_t)r * X + xc];
+      const float *c = comp + (int64_t)r * B;
+#pragma unroll
+      for (int b = 0; b < BT; ++b)
+        if (b < B) acc[b] = fmaf(c[b], d, acc[b]);
     }
 #pragma unroll
     for (int b = 0; b < BT; ++b)
@@ -1628,8 +1637,8 @@ int mrgcn_basis_contract_bwd_f32(const float *comp, const float *V, const float 
   MRGCN_REQUIRE(comp && V && dW, "NULL");
   MRGCN_REQUIRE(R > 0 && B > 0 && X > 0, "R / B / X");
   const int BT = B <= 16 ? 16 : (B <= 32 ? 32 : (B <= 48 ? 48 : 64));
-  const size_t lds = ((size_t)R * B + (size_t)4 * BT * 64) * sizeof(float);
-  const int tiled = B <= kContractMaxB && lds <= 150 * 1024;
+  const size_t lds = (size_t)4 * BT * 64 * sizeof(float);
+  const int tiled = B <= kContractMaxB;
   const int dv_blocks = !dV ? 0 : (tiled ? (int)((X + 63) / 64) : grid_for((int64_t)B * X));
   const int dc_blocks = dcomp ? (int)(((int64_t)R * B * 64 + kTB - 1) / kTB) : 0;
   if (dc_blocks > 0) {

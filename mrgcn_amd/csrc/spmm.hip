@@ -798,8 +798,14 @@ __global__ __launch_bounds__(256) void k_rows_live_mark(const float *__restrict_
 __global__ __launch_bounds__(256) void k_count_flags(const uint8_t *__restrict__ flags, int64_t n,
                                                      int32_t *__restrict__ out) {
   int32_t c = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    c += flags[i] != 0;
+  const int64_t nw = n >> 3;  // eight flags per load (the array is 16-byte aligned scratch)
+  const uint64_t *w = reinterpret_cast<const uint64_t *>(flags);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t v = w[i];
+    v |= v >> 4; v |= v >> 2; v |= v >> 1;             // any bit of a byte -> its lowest bit
+    c += __popcll(v & 0x0101010101010101ull);
+  }
+  if (blockIdx.x == 0 && (int64_t)threadIdx.x < n - (nw << 3)) c += flags[(nw << 3) + threadIdx.x] != 0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
   __shared__ int32_t s_c[4];
@@ -1221,7 +1227,7 @@ extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, 
         F <= 16 ? row_flags : nullptr);
     MRGCN_HIP_TRY(hipGetLastError());
     if (live_rows) {
-      k_count_flags<<<dim3(64), dim3(256), 0, s>>>(row_live, plan->num_rows, live_rows);
+      k_count_flags<<<dim3(128), dim3(256), 0, s>>>(row_live, plan->num_rows, live_rows);
       MRGCN_HIP_TRY(hipGetLastError());
     }
     SparseView rv = plan->view(MRGCN_VIEW_LITERAL);  // row-major entry coordinates, as `ccol`
