@@ -1246,10 +1246,12 @@ __global__ __launch_bounds__(kTB) void k_basis_contract(const float *__restrict_
 }
 
 // backward, dV (dcomp: k_basis_contract_dcomp below).
-//   dV[b, x] = sum_r comp[r, b] dW[r, x]: a block owns 64 columns x and every basis b; thread (x, q = wave) sums the
-//   relations r = q mod 4 into B register accumulators (one coalesced load of dW per relation, eight in flight; the
-//   comp row of a relation is wave uniform: scalar loads), the four partial sums meet in LDS in a fixed order.
-//   B <= kContractMaxB; otherwise the plain thread-per-output walk.
+//   dV[b, x] = sum_r comp[r, b] dW[r, x]: a block owns 64 columns x and every basis b; comp lives in LDS (rows padded
+//   to BT floats), thread (x, q = wave) sums the relations r = q mod 4 into B register accumulators (one coalesced
+//   load of dW per relation, eight in flight; broadcast 16-byte LDS reads of the comp row), the four partial sums meet
+//   in LDS in a fixed order.  B <= kContractMaxB and R * BT * 4 + 4 * BT * 256 bytes of LDS; otherwise the plain
+//   thread-per-output walk.  (Measured on the way: comp through 4-byte loads in a loop 120 us, through scalar loads per
+//   relation 150 us — both a chain of dependent round trips.)
 constexpr int kContractMaxB = 64;
 template <int BT>
 __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restrict__ comp, const float *__restrict__ V,
@@ -1273,14 +1275,30 @@ __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restr
       }
       return;
     }
-    float *s_part = s_mem;  // [4][BT][64]
-    const int xl = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave id: comp rows are wave uniform
+    float *s_comp = s_mem;                         // [R][BT], rows padded to BT (a multiple of four) floats
+    float *s_part = s_mem + (size_t)R * BT;        // [4][BT][64]
+    // comp into LDS: every thread's loads in flight at once (a loop of dependent 4-byte loads cost 40 us here)
+    for (int t0 = 0; t0 < R * BT; t0 += kTB * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u * kTB + threadIdx.x;
+        const int r = t / BT, b = t - r * BT;
+        v[u] = (t < R * BT && b < B) ? comp[(int64_t)r * B + b] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u * kTB + threadIdx.x;
+        if (t < R * BT) s_comp[t] = v[u];
+      }
+    }
+    __syncthreads();
+    const int xl = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t x = (int64_t)blockIdx.x * 64 + xl;
+    const int64_t xc = x < X ? x : X - 1;  // (clamped: unconditional loads, eight relations in flight)
     float acc[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[b] = 0.f;
-    const int64_t xc = x < X ? x : X - 1;  // (clamped: unconditional loads, eight relations in flight)
     int r = q;
     for (; r + 28 < R; r += 32) {
       float d[8];
@@ -1288,18 +1306,28 @@ __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restr
       for (int u = 0; u < 8; ++u) d[u] = dW[(int64_t)(r + 4 * u) * X + xc];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const float *c = comp + (int64_t)(r + 4 * u) * B;  // uniform address: scalar loads
+        const float4 *c4 = reinterpret_cast<const float4 *>(s_comp + (r + 4 * u) * BT);  // broadcast 16-byte LDS reads
 #pragma unroll
-        for (int b = 0; b < BT; ++b)
-          if (b < B) acc[b] = fmaf(c[b], d[u], acc[b]);
+        for (int b = 0; b < BT; b += 4) {
+          const float4 c = c4[b >> 2];
+          acc[b] = fmaf(c.x, d[u], acc[b]);
+          acc[b + 1] = fmaf(c.y, d[u], acc[b + 1]);
+          acc[b + 2] = fmaf(c.z, d[u], acc[b + 2]);
+          acc[b + 3] = fmaf(c.w, d[u], acc[b + 3]);
+        }
       }
     }
     for (; r < R; r += 4) {
       const float d = dW[(int64_t)r * X + xc];
-      const float *c = comp + (int64_t)r * B;
+      const float4 *c4 = reinterpret_cast<const float4 *>(s_comp + r * BT);
 #pragma unroll
-      for (int b = 0; b < BT; ++b)
-        if (b < B) acc[b] = fmaf(c[b], d, acc[b]);
+      for (int b = 0; b < BT; b += 4) {
+        const float4 c = c4[b >> 2];
+        acc[b] = fmaf(c.x, d, acc[b]);
+        acc[b + 1] = fmaf(c.y, d, acc[b + 1]);
+        acc[b + 2] = fmaf(c.z, d, acc[b + 2]);
+        acc[b + 3] = fmaf(c.w, d, acc[b + 3]);
+      }
     }
 #pragma unroll
     for (int b = 0; b < BT; ++b)
@@ -1637,8 +1665,8 @@ int mrgcn_basis_contract_bwd_f32(const float *comp, const float *V, const float 
   MRGCN_REQUIRE(comp && V && dW, "NULL");
   MRGCN_REQUIRE(R > 0 && B > 0 && X > 0, "R / B / X");
   const int BT = B <= 16 ? 16 : (B <= 32 ? 32 : (B <= 48 ? 48 : 64));
-  const size_t lds = (size_t)4 * BT * 64 * sizeof(float);
-  const int tiled = B <= kContractMaxB;
+  const size_t lds = ((size_t)R * BT + (size_t)4 * BT * 64) * sizeof(float);
+  const int tiled = B <= kContractMaxB && lds <= 150 * 1024;
   const int dv_blocks = !dV ? 0 : (tiled ? (int)((X + 63) / 64) : grid_for((int64_t)B * X));
   const int dc_blocks = dcomp ? (int)(((int64_t)R * B * 64 + kTB - 1) / kTB) : 0;
   if (dc_blocks > 0) {
