@@ -1473,6 +1473,8 @@ int mix_bwd_nm_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
   if (per_cu * tb > 2048) per_cu = 2048 / tb;  // 32 waves per CU at most
+  static const int per_cu_cap = getenv("MRGCN_MIX_BWD_PER_CU") ? atoi(getenv("MRGCN_MIX_BWD_PER_CU")) : 0;  // experiments
+  if (per_cu_cap > 0 && per_cu > per_cu_cap) per_cu = per_cu_cap;
   const int64_t want = ((N + kGroup - 1) / kGroup + (tb / 64) - 1) / (tb / 64);
   int64_t grid = (int64_t)256 * per_cu;
   if (grid > want) grid = want;

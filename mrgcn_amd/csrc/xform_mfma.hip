@@ -426,13 +426,16 @@ __global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restr
   float acc[KT];
 #pragma unroll
   for (int i = 0; i < KT; ++i) acc[i] = 0.f;
+  bool any_out = false, wide_out = false;
+  int32_t c0_out = 0, c1_out = 0;
   if (j < N) {
     const int32_t c0 = nptr[j], c1 = nptr[j + 1];
     // nearly every node of a semi-supervised epoch has no live column: look at its flag bytes eight at a time
     // (aligned 8-byte words; the bytes of neighbouring nodes are masked off, the array's last partial word is read
     // byte by byte) and walk the columns only when one is set
     bool any = col_live == nullptr && c1 > c0;
-    if (col_live) {
+    const bool wide = col_live != nullptr && c1 - c0 > 24;  // a node with many columns: the wave looks together (below)
+    if (col_live && !wide) {
       for (int32_t w0 = c0 & ~7; w0 < c1 && !any; w0 += 8) {
         uint64_t bits = 0;
         if (w0 + 8 <= ncols) {
@@ -445,6 +448,38 @@ __global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restr
         any = bits != 0;
       }
     }
+    any_out = any; c0_out = c0; c1_out = c1; wide_out = wide;
+  }
+  // nodes with many columns (a source node of dozens of relations): their flag bytes are read by the whole wave, 512
+  // per step — a lane walking 30 dependent words alone held its block for 30 round trips (85 -> 40 us at the AM shape)
+  {
+    const int lane = threadIdx.x & 63;
+    uint64_t todo = __ballot(wide_out);
+    while (todo) {
+      const int L = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      const int32_t a0 = __shfl(c0_out, L, 64), a1 = __shfl(c1_out, L, 64);
+      bool hit = false;
+      for (int32_t base = a0 & ~7; base < a1 && !hit; base += 512) {
+        const int32_t w0 = base + 8 * lane;
+        uint64_t bits = 0;
+        if (w0 < a1) {
+          if (w0 + 8 <= ncols) {
+            bits = *reinterpret_cast<const uint64_t *>(col_live + w0);
+          } else {
+            for (int b = 0; b < 8 && w0 + b < ncols; ++b) bits |= (uint64_t)col_live[w0 + b] << (8 * b);
+          }
+          if (w0 < a0) bits &= ~uint64_t(0) << (8 * (a0 - w0));
+          if (w0 + 8 > a1) bits &= ~uint64_t(0) >> (8 * (w0 + 8 - a1));
+        }
+        hit = __ballot(bits != 0) != 0;
+      }
+      if (lane == L) any_out = hit;
+    }
+  }
+  if (j < N) {
+    const bool any = any_out;
+    const int32_t c0 = c0_out, c1 = c1_out;
     if (any) {
       for (int32_t c = c0; c < c1; ++c) {
         if (col_live && !col_live[c]) continue;
