@@ -279,14 +279,15 @@ int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *plan, float *dM, int64_
  * path: ask mrgcn_rel_transform_bwd_masked_supported): `relu_mask_from_x` != 0 multiplies dX by the mask X > 0 — X
  * is then the output of a ReLU (a hidden layer's input, rgcn.py:86-87), and X > 0 is that ReLU's own mask, so the
  * layer that produced X has nothing left to mask; `row_live_out` (nullable, one byte per node) receives "this row
- * of dX holds anything but zeros" — the flags mrgcn_spmm_transposed_live_flagged_f32 takes. */
+ * of dX holds anything but zeros" — the flags mrgcn_spmm_transposed_live_flagged_f32 takes; `node_live` (nullable;
+ * with `col_live`): the per-node flags that call wrote next to `col_live`, read instead of every node's column flags. */
 int32_t mrgcn_rel_transform_bwd_masked_supported(const mrgcn_plan_t *plan, int32_t K, int32_t F,
                                                  int64_t workspace_floats);
 int mrgcn_rel_transform_bwd_masked_f32(const mrgcn_plan_t *plan, float *dM, int64_t ldM, const uint8_t *col_live,
                                        const float *X, int64_t ldX, int32_t K, const float *W, int32_t F,
                                        float *dX, int64_t lddX, float *dW, float *workspace,
                                        int64_t workspace_floats, int32_t relu_mask_from_x,
-                                       uint8_t *row_live_out, void *stream);
+                                       uint8_t *row_live_out, const uint8_t *node_live, void *stream);
 /* Y[c, 0:F] = sum_i A'[i, c] * D[i, 0:F] — mrgcn_spmm_f32 on MRGCN_VIEW_TRANSPOSED (the autograd
  * of torch.mm(A, .), graph.py:75,:95) for an operand whose rows are mostly zeros, as the output
  * gradient of a layer is when few nodes are labelled: rows of D that hold only zeros are not
@@ -306,11 +307,13 @@ int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const float *D, int
                                    float *Y, int64_t ldY, uint8_t *scratch, uint8_t *col_live,
                                    int32_t *live_rows, int32_t write_dead_rows, void *stream);
 /* The same with the row flags of D given (`row_flags`, nullable: one byte per row of D, 0 = the row is all
- * zeros — written by the producer of D, mrgcn_rel_transform_bwd_masked_f32): D is not scanned for them. */
+ * zeros — written by the producer of D, mrgcn_rel_transform_bwd_masked_f32): D is not scanned for them.
+ * `node_live` (nullable, one byte per source node) receives "this node has a live column" — what
+ * mrgcn_rel_transform_bwd_masked_f32 takes to skip the nodes without any. */
 int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, const float *D, int64_t ldD, int32_t F,
                                            float *Y, int64_t ldY, uint8_t *scratch, uint8_t *col_live,
                                            int32_t *live_rows, int32_t write_dead_rows,
-                                           const uint8_t *row_flags, void *stream);
+                                           const uint8_t *row_flags, uint8_t *node_live, void *stream);
 /* flags[i] = 1 when X[i, 0:F] holds anything but (+-)0 — NaN counts — else 0. */
 int mrgcn_rows_nonzero_f32(const float *X, int64_t ld, int32_t F, int64_t nrows, uint8_t *flags,
                            void *stream);

@@ -85,10 +85,10 @@ SIGNATURES = {
     "mrgcn_adam_step_multi_f32": (C.c_int, [_i32, _p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, C.c_float, _i64,
                                             _p, _p, _p]),
     "mrgcn_spmm_transposed_live_scratch": (C.c_int64, [_p]),
-    "mrgcn_spmm_transposed_live_flagged_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _p]),
+    "mrgcn_spmm_transposed_live_flagged_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p, _p, _p]),
     "mrgcn_rel_transform_bwd_masked_supported": (C.c_int32, [_p, _i32, _i32, _i64]),
     "mrgcn_rel_transform_bwd_masked_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p,
-                                                     _i64, _i32, _p, _p]),
+                                                     _i64, _i32, _p, _p, _p]),
     "mrgcn_spmm_transposed_live_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p]),
     "mrgcn_relu_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "mrgcn_relu_bwd_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _i64, _p]),

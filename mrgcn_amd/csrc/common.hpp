@@ -115,7 +115,7 @@ int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx
                   int64_t workspace_floats, hipStream_t s, const uint8_t *col_live = nullptr);
 int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *dX, int64_t lddX,
                 hipStream_t s, const uint8_t *col_live = nullptr, const float *mask_src = nullptr,
-                int64_t ldMask = 0, uint8_t *row_live = nullptr);
+                int64_t ldMask = 0, uint8_t *row_live = nullptr, const uint8_t *node_live = nullptr);
 }  // namespace mrgcn
 
 struct mrgcn_plan {

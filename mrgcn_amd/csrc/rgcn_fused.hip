@@ -1729,7 +1729,7 @@ int mrgcn_rel_transform_bwd_live_f32(const mrgcn_plan_t *p, float *dM, int64_t l
                                      const float *W, int32_t F, float *dX, int64_t lddX, float *dW,
                                      float *workspace, int64_t workspace_floats, void *stream) {
   return mrgcn_rel_transform_bwd_masked_f32(p, dM, ldM, col_live, X, ldX, K, W, F, dX, lddX, dW, workspace,
-                                            workspace_floats, 0, nullptr, stream);
+                                            workspace_floats, 0, nullptr, nullptr, stream);
 }
 
 int32_t mrgcn_rel_transform_bwd_masked_supported(const mrgcn_plan_t *p, int32_t K, int32_t F, int64_t workspace_floats) {
@@ -1741,7 +1741,7 @@ int mrgcn_rel_transform_bwd_masked_f32(const mrgcn_plan_t *p, float *dM, int64_t
                                        const uint8_t *col_live, const float *X, int64_t ldX, int32_t K,
                                        const float *W, int32_t F, float *dX, int64_t lddX, float *dW,
                                        float *workspace, int64_t workspace_floats, int32_t relu_mask_from_x,
-                                       uint8_t *row_live_out, void *stream) {
+                                       uint8_t *row_live_out, const uint8_t *node_live, void *stream) {
   MRGCN_REQUIRE(p && dM && X && W, "NULL");
   MRGCN_REQUIRE(!col_live || ((uintptr_t)col_live & 7) == 0, "col_live must be 8-byte aligned");
   MRGCN_REQUIRE(!(relu_mask_from_x || row_live_out) ||
@@ -1783,7 +1783,8 @@ int mrgcn_rel_transform_bwd_masked_f32(const mrgcn_plan_t *p, float *dM, int64_t
     int rc = xform_mfma_fwd(p, p->order_for(F), nullptr, nullptr, dM, ldM, F, W, true, K, workspace, ldZ, s, false,
                             col_live);
     if (rc != MRGCN_OK) return rc;
-    rc = segment_sum(p, workspace, ldZ, K, dX, lddX, s, col_live, relu_mask_from_x ? X : nullptr, ldX, row_live_out);
+    rc = segment_sum(p, workspace, ldZ, K, dX, lddX, s, col_live, relu_mask_from_x ? X : nullptr, ldX, row_live_out,
+                     col_live ? node_live : nullptr);
     if (rc != MRGCN_OK) return rc;
   } else if (dX) {
     MRGCN_REQUIRE(lddX >= K, "lddX");

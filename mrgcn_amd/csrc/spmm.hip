@@ -841,7 +841,8 @@ __global__ __launch_bounds__(kLiveTB) void k_spmm_t_live(SparseView v, const flo
                                                          int64_t ldD, int F, float *__restrict__ Y,
                                                          int64_t ldY, const uint8_t *__restrict__ row_live,
                                                          const uint8_t *__restrict__ col_live,
-                                                         int store_vec_ok) {
+                                                         int store_vec_ok, const int32_t *__restrict__ unode,
+                                                         uint8_t *__restrict__ node_live) {
   __shared__ int32_t s_cid[kLiveTB];
   __shared__ int32_t s_cnt[kLiveTB / 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -861,6 +862,7 @@ __global__ __launch_bounds__(kLiveTB) void k_spmm_t_live(SparseView v, const flo
   __syncthreads();
   if ((int)threadIdx.x >= tot) return;
   const int64_t row = s_cid[threadIdx.x];
+  if (node_live) node_live[unode[row]] = 1;  // the source node of a live column (same value from every writer)
   const int32_t b = v.ptr[row];
   const int32_t n = v.ptr[row + 1] - b;
   if (n > kLongThreshold) return;  // the split-row blocks of k_spmm write it
@@ -1196,14 +1198,14 @@ extern "C" int mrgcn_spmm_transposed_live_f32(const mrgcn_plan_t *plan, const fl
                                               uint8_t *col_live, int32_t *live_rows,
                                               int32_t write_dead_rows, void *stream) {
   return mrgcn_spmm_transposed_live_flagged_f32(plan, D, ldD, F, Y, ldY, scratch, col_live, live_rows,
-                                                write_dead_rows, nullptr, stream);
+                                                write_dead_rows, nullptr, nullptr, stream);
 }
 
 extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, const float *D, int64_t ldD,
                                                       int32_t F, float *Y, int64_t ldY, uint8_t *scratch,
                                                       uint8_t *col_live, int32_t *live_rows,
                                                       int32_t write_dead_rows, const uint8_t *row_flags,
-                                                      void *stream) {
+                                                      uint8_t *node_live, void *stream) {
   using namespace mrgcn;
   MRGCN_REQUIRE(plan, "plan is NULL");
   MRGCN_REQUIRE(F > 0 && ldD >= F && ldY >= F, "F / leading dimensions");
@@ -1216,10 +1218,12 @@ extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, 
     int rc = mrgcn_spmm_f32(plan, MRGCN_VIEW_TRANSPOSED, D, ldD, F, Y, ldY, nullptr, 0, nullptr, stream);
     if (rc != MRGCN_OK) return rc;
     if (live_rows) MRGCN_HIP_TRY(hipMemsetAsync(live_rows, 0xff, sizeof(int32_t), s));  // -1: not counted
+    if (node_live) MRGCN_HIP_TRY(hipMemsetAsync(node_live, 1, (size_t)plan->num_nodes, s));  // (not looked at: all)
     return mrgcn_rows_nonzero_f32(Y, ldY, F, v.rows, col_live, stream);
   }
   uint8_t *row_live = scratch;
   MRGCN_HIP_TRY(hipMemsetAsync(col_live, 0, (size_t)v.rows, s));
+  if (node_live && F <= 16) MRGCN_HIP_TRY(hipMemsetAsync(node_live, 0, (size_t)plan->num_nodes, s));
   if (write_dead_rows && v.rows > 0) MRGCN_HIP_TRY(hipMemsetAsync(Y, 0, (size_t)v.rows * ldY * sizeof(float), s));
   if (plan->num_rows > 0 && v.rows > 0) {
     k_rows_live_mark<<<dim3((unsigned)((plan->num_rows + 255) / 256)), dim3(256), 0, s>>>(
@@ -1238,10 +1242,10 @@ extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, 
     }
     const int vec_ok = (ldY % 4 == 0) && (ldY >= (F + 3) / 4 * 4) && (((uintptr_t)Y) % 16 == 0);
     const dim3 grid((unsigned)((v.rows + kLiveTB - 1) / kLiveTB));
-    if (F <= 4) k_spmm_t_live<4><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok);
-    else if (F <= 8) k_spmm_t_live<8><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok);
-    else if (F <= 12) k_spmm_t_live<12><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok);
-    else k_spmm_t_live<16><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok);
+    if (F <= 4) k_spmm_t_live<4><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok, plan->unode, node_live);
+    else if (F <= 8) k_spmm_t_live<8><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok, plan->unode, node_live);
+    else if (F <= 12) k_spmm_t_live<12><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok, plan->unode, node_live);
+    else k_spmm_t_live<16><<<grid, dim3(kLiveTB), 0, s>>>(v, D, ldD, F, Y, ldY, row_live, col_live, vec_ok, plan->unode, node_live);
     MRGCN_HIP_TRY(hipGetLastError());
   }
   // long rows: the split-row blocks of the general kernel only (its short-row blocks are not launched)

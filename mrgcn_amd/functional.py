@@ -327,12 +327,15 @@ class _RgcnLayer(torch.autograd.Function):
         dM = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
         if _POISON_DEAD:
             dM.fill_(float("nan"))
-        live = None
+        live = node_live = None
         gauge = _live_gauge(plan, F, ctx.relu, dev) if _LIVE_COLS else None
         if gauge is not None and gauge.sparse():
             # with few labelled nodes most rows of dY are zeros: gather the others only, and keep one
             # byte per compact column: does it carry any gradient?
             live = torch.empty((plan.ncols,), dtype=torch.uint8, device=dev)
+            # (a layer whose input wants a gradient also gets a flag per source node: its dX pass skips by it)
+            node_live = (torch.empty((plan.num_nodes,), dtype=torch.uint8, device=dev)
+                         if (has_X and ctx.needs_input_grad[4]) else None)
             scratch = torch.empty((int(lib.mrgcn_spmm_transposed_live_scratch(plan.handle)),),
                                   dtype=torch.uint8, device=dev)
             # rows of dM without gradient are not even written when every consumer goes by the flags
@@ -344,7 +347,8 @@ class _RgcnLayer(torch.autograd.Function):
                 L.check(lib.mrgcn_spmm_transposed_live_flagged_f32(
                     plan.handle, dY.data_ptr(), dY.stride(0), F, dM.data_ptr(), ld, scratch.data_ptr(),
                     live.data_ptr(), gauge.dev.data_ptr(), write_dead,
-                    row_flags.data_ptr() if row_flags is not None else 0, s), "mrgcn_spmm_transposed_live_flagged_f32")
+                    row_flags.data_ptr() if row_flags is not None else 0,
+                    node_live.data_ptr() if node_live is not None else 0, s), "mrgcn_spmm_transposed_live_flagged_f32")
             gauge.publish()
         else:
             plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)
@@ -431,14 +435,15 @@ class _RgcnLayer(torch.autograd.Function):
                             dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0,
                             ws.data_ptr() if ws is not None else 0, ws.numel() if ws is not None else 0,
                             int(finish and ctx.x_is_relu_out), dx_flags.data_ptr() if finish else 0,
+                            node_live.data_ptr() if (finish and node_live is not None and live is not None) else 0,
                             side.cuda_stream), "mrgcn_rel_transform_bwd_masked_f32")
                         if finish:
                             _set_grad_meta(dX, dx_flags, finish and ctx.x_is_relu_out)
                 if overlap:
                     main.wait_stream(side)
-                    for t in (dX, dW, ws, dM, live, dx_flags):  # allocated / used on `side`: keep the allocator honest
+                    for t in (dX, dW, ws, dM, live, dx_flags, node_live):  # allocated / used on `side`: keep the allocator honest
                         if t is not None:
-                            t.record_stream(side if (t is dM or t is live) else main)
+                            t.record_stream(side if (t is dM or t is live or t is node_live) else main)
         return None, None, d_wI, d_comp, dX, dW, dbias, None, None, None
 
 
