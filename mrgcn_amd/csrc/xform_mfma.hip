@@ -481,18 +481,39 @@ __global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restr
       if (lane == L) any_out = hit;
     }
   }
-  if (j < N) {
-    const bool any = any_out;
-    const int32_t c0 = c0_out, c1 = c1_out;
-    if (any) {
-      for (int32_t c = c0; c < c1; ++c) {
+  // the (few) nodes with a live column: the wave sums a node's Z rows together, lane l the columns l, l + 64, ...
+  // (a lane walking the 100+ columns of a live hub alone — two dependent round trips per column — held its block, and
+  // the kernel's tail, for 70 us at the AM shape)
+  {
+    const int lane = threadIdx.x & 63;
+    uint64_t todo = __ballot(any_out);
+    while (todo) {
+      const int L = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      const int32_t a0 = __shfl(c0_out, L, 64), a1 = __shfl(c1_out, L, 64);
+      float part[KT];
+#pragma unroll
+      for (int i = 0; i < KT; ++i) part[i] = 0.f;
+      for (int32_t c = a0 + lane; c < a1; c += 64) {
         if (col_live && !col_live[c]) continue;
         const float *z = Z + (int64_t)c * ldZ;
 #pragma unroll
         for (int i = 0; i < KT; ++i)
-          if (i < K) acc[i] += z[i];
+          if (i < K) part[i] += z[i];
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < KT; ++i) part[i] += __shfl_xor(part[i], off, 64);
+      }
+      if (lane == L) {
+#pragma unroll
+        for (int i = 0; i < KT; ++i) acc[i] = part[i];
       }
     }
+  }
+  if (j < N) {
+    const bool any = any_out;
     bool nz = false;
     if (any) {
       if (mask_src) {
