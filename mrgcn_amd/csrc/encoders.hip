@@ -13,6 +13,8 @@
 //       (temporal_cnn.py:147-153) run forward and backward on it, and so does the TCNN's Conv1d in implicit
 //       im2col form (A-loader modes below).
 //   k_colsum_f32 bias gradients (column sums).
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -561,6 +563,304 @@ __global__ __launch_bounds__(256) void k_gemm128_f32(GemmArgs g) {
       }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Third form of the product: the loader modes are template parameters, every element is fetched by a dword
+// buffer load whose lanes run along the direction the operand is contiguous in memory, and there is no branch in
+// the K loop.
+//   * element (row i, column k) of an operand sits at byte offset  roff(i) + coff(k)  of its base; a row or a column
+//     outside the matrix gets the offset kOOB, so that the sum falls behind the buffer descriptor's range and the
+//     load returns 0 by itself (operands of at most 2^29 bytes: kOOB minus the few bytes by which the conv modes'
+//     row offsets can be negative still lies behind them).  The conv modes carry the position inside the sequence
+//     (rt + ct) and select kOOB where it leaves [0, Tin): the zero padding.
+//   * index decompositions (m -> (b, t), k -> (ci, kw), ...) are a multiply-high by a magic number the launcher
+//     computed (exact while x * d < 2^32, which it checks).
+//   * ROWL operands (A modes 1, 2; B mode 0: memory runs along the tile rows): thread = (row, NE consecutive k);
+//     the k of a wave are uniform, their decomposition is scalar work.  KL operands (A modes 0, 3; B modes 1, 2:
+//     memory runs along k): thread = (k, NE rows).  Both leave Xs[row][k] (row stride BK + 4 floats) in LDS, from
+//     which every MFMA fragment is one conflict-free ds_read_b128.
+//   * two LDS stages, one barrier per K step; the next step's elements fly under this step's products.
+//   * the conv output (cmode 2: y[b][n][t], contiguous along m = (b, t)) goes through LDS per wave so that a store
+//     instruction writes 64 consecutive positions of one channel.
+//   * split K (kchunk > 0): the partial tiles are added into a zeroed C with float atomics, block z = 0 adds the
+//     bias; a ReLU / mask epilogue then runs as k_mm_finish.
+// ---------------------------------------------------------------------------------------------------
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr uint32_t kOOB = 1u << 30;
+constexpr int64_t kMmMaxBytes = (int64_t)1 << 29;
+
+struct MmArgs {
+  const float *A, *B;
+  float *C;
+  uint32_t a_bytes, b_bytes;
+  int M, N, K;
+  int32_t lda, ldb;
+  int64_t ldc;
+  const float *bias;
+  int relu;
+  const float *mask;
+  float alpha;
+  ConvGeom cg;
+  int kchunk;
+  int dry;  // timing experiments only (MRGCN_MM_DRY): 2 = the K loop issues no loads
+  uint32_t mg_tout, mg_kw, mg_tout16;  // floor(2^32 / d) + 1 for d = Tout, KW, 16 Tout (0 stands for d == 1)
+};
+
+struct Coord {
+  uint32_t off;  // bytes
+  int32_t t;     // conv position contribution
+};
+
+__device__ __forceinline__ uint32_t mdiv(uint32_t x, uint32_t magic) { return magic ? __umulhi(x, magic) : x; }
+
+template <bool IS_A, int MODE>
+__device__ __forceinline__ Coord mm_row(const MmArgs &g, int i) {
+  if (i >= (IS_A ? g.M : g.N)) return Coord{kOOB, 0};
+  if constexpr (IS_A) {
+    if constexpr (MODE == 0) return Coord{(uint32_t)(i * g.lda) * 4u, 0};
+    else if constexpr (MODE == 1) return Coord{(uint32_t)i * 4u, 0};
+    else if constexpr (MODE == 2) {
+      const int b = (int)mdiv((uint32_t)i, g.mg_tout), t = i - b * g.cg.Tout;
+      return Coord{(uint32_t)(b * g.cg.Cin * g.cg.Tin + t) * 4u, t};
+    } else {
+      const int ci = (int)mdiv((uint32_t)i, g.mg_kw), kw = i - ci * g.cg.KW;
+      return Coord{(uint32_t)(ci * g.cg.Tin + kw - g.cg.pad) * 4u, kw - g.cg.pad};
+    }
+  } else {
+    if constexpr (MODE == 0) return Coord{(uint32_t)i * 4u, 0};
+    else if constexpr (MODE == 1) return Coord{(uint32_t)(i * g.ldb) * 4u, 0};
+    else return Coord{(uint32_t)(i * g.cg.Tout) * 4u, 0};
+  }
+}
+template <bool IS_A, int MODE>
+__device__ __forceinline__ Coord mm_col(const MmArgs &g, int k, int kend) {
+  if (k >= kend) return Coord{kOOB, 0};
+  if constexpr (IS_A) {
+    if constexpr (MODE == 0) return Coord{(uint32_t)k * 4u, 0};
+    else if constexpr (MODE == 1) return Coord{(uint32_t)(k * g.lda) * 4u, 0};
+    else if constexpr (MODE == 2) {
+      const int ci = (int)mdiv((uint32_t)k, g.mg_kw), kw = k - ci * g.cg.KW;
+      return Coord{(uint32_t)(ci * g.cg.Tin + kw - g.cg.pad) * 4u, kw - g.cg.pad};
+    } else {
+      const int b = (int)mdiv((uint32_t)k, g.mg_tout), t = k - b * g.cg.Tout;
+      return Coord{(uint32_t)(b * g.cg.Cin * g.cg.Tin + t) * 4u, t};
+    }
+  } else {
+    if constexpr (MODE == 0) return Coord{(uint32_t)(k * g.ldb) * 4u, 0};
+    else if constexpr (MODE == 1) return Coord{(uint32_t)k * 4u, 0};
+    else {
+      const int b = (int)mdiv((uint32_t)k, g.mg_tout), t = k - b * g.cg.Tout;
+      return Coord{(uint32_t)(b * g.cg.Cout * g.cg.Tout + t) * 4u, 0};
+    }
+  }
+}
+
+template <bool IS_A, int MODE, int ROWS, int BK>
+struct MmLoader {
+  static constexpr bool ROWL = IS_A ? (MODE == 1 || MODE == 2) : (MODE == 0);
+  static constexpr bool CONV = IS_A && MODE >= 2;
+  static constexpr int NE = ROWS * BK / 256;  // elements per thread and K step
+  static constexpr int LDK = BK + 4;
+  static constexpr int RS = 256 / BK;         // KL: distance of a thread's rows
+  static constexpr int NR = ROWL ? 1 : NE;
+  uint32_t roff[NR];
+  int32_t rt[CONV ? NR : 1];
+  __device__ __forceinline__ void init(const MmArgs &g, int row0) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = ROWL ? (int)(threadIdx.x % ROWS) : (int)(threadIdx.x / BK) + RS * i;
+      const Coord c = mm_row<IS_A, MODE>(g, row0 + r);
+      roff[i] = c.off;
+      if constexpr (CONV) rt[i] = c.t;
+    }
+  }
+  __device__ __forceinline__ uint32_t at(const MmArgs &g, int i, const Coord &c) const {
+    uint32_t off = roff[i] + c.off;
+    if constexpr (CONV) off = (uint32_t)(rt[i] + c.t) < (uint32_t)g.cg.Tin ? off : kOOB;
+    return off;
+  }
+  __device__ __forceinline__ void load(const MmArgs &g, rsrc_t rs, int k0, int kend, float (&v)[NE]) const {
+    if constexpr (ROWL) {
+      // the wave's NE columns are the same for all its lanes (ROWS >= 64): lane j decomposes column j once, on the
+      // vector unit, and the loads read its result by lane index (as scalar work the decompositions of the 20 waves
+      // of a CU kept its one scalar unit as busy as the matrix cores)
+      static_assert((NE & (NE - 1)) == 0, "NE is a power of two");
+      const int ks = (int)(threadIdx.x / ROWS) * NE;
+      const Coord cl = mm_col<IS_A, MODE>(g, k0 + ks + (int)(threadIdx.x & (NE - 1)), kend);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        Coord c;
+        c.off = (uint32_t)__builtin_amdgcn_readlane((int)cl.off, j);
+        c.t = CONV ? __builtin_amdgcn_readlane(cl.t, j) : 0;
+        v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, at(g, 0, c), 0, 0));
+      }
+    } else {
+      const Coord c = mm_col<IS_A, MODE>(g, k0 + (int)(threadIdx.x % BK), kend);
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, at(g, i, c), 0, 0));
+    }
+  }
+  __device__ __forceinline__ void stage(float *Xs, const float (&v)[NE]) const {
+    if constexpr (ROWL) {
+      float *dst = Xs + (threadIdx.x % ROWS) * LDK + (threadIdx.x / ROWS) * NE;
+#pragma unroll
+      for (int h = 0; h < NE / 4; ++h)
+        *reinterpret_cast<f32x4 *>(dst + 4 * h) = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+    } else {
+      float *dst = Xs + (threadIdx.x / BK) * LDK + (threadIdx.x % BK);
+#pragma unroll
+      for (int i = 0; i < NE; ++i) dst[RS * i * LDK] = v[i];
+    }
+  }
+};
+
+// MT / NT: 16 x 16 MFMA tiles per wave along m / n — block tile 32 MT x 32 NT (128 x 128, 128 x 64, 64 x 64)
+template <int AMODE, int BMODE, int CMODE, int MT, int NT, int BK>
+__global__ __launch_bounds__(256) void k_mm_tile(MmArgs g) {
+  constexpr int BM = 32 * MT, BN = 32 * NT, LDK = BK + 4, ASZ = BM * LDK, BSZ = BN * LDK;
+  constexpr int WR = 16 * MT, CST = WR + 4;  // rows of a wave; row stride of its transposition buffer
+  static_assert(2 * (ASZ + BSZ) >= 4 * 16 * CST, "the epilogue's transposition buffer fits the stages");
+  __shared__ __align__(16) float smem[2 * (ASZ + BSZ)];
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = (wv >> 1) * WR, wn = (wv & 1) * (16 * NT);
+  const int lm = lane & 15, kq = lane >> 4;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, g.a_bytes, 0x00020000);
+  const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)g.B, 0, g.b_bytes, 0x00020000);
+  MmLoader<true, AMODE, BM, BK> la;
+  MmLoader<false, BMODE, BN, BK> lb;
+  la.init(g, m0);
+  lb.init(g, n0);
+  const int kbeg = g.kchunk > 0 ? blockIdx.z * g.kchunk : 0;
+  const int kend = g.kchunk > 0 ? min(g.K, kbeg + g.kchunk) : g.K;
+  float va[decltype(la)::NE], vb[decltype(lb)::NE];
+  la.load(g, ra, kbeg, kend, va);
+  lb.load(g, rb, kbeg, kend, vb);
+  la.stage(smem, va);
+  lb.stage(smem + ASZ, vb);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more && g.dry < 2) {
+      la.load(g, ra, k0 + BK, kend, va);
+      lb.load(g, rb, k0 + BK, kend, vb);
+    }
+    const float *Ac = smem + cur * (ASZ + BSZ), *Bc = Ac + ASZ;
+#pragma unroll
+    for (int kg = 0; kg < BK / 16; ++kg) {
+      f32x4 a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4 *>(Ac + (wm + 16 * i + lm) * LDK + 16 * kg + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4 *>(Bc + (wn + 16 * j + lm) * LDK + 16 * kg + 4 * kq);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      float *An = smem + (cur ^ 1) * (ASZ + BSZ);
+      la.stage(An, va);
+      lb.stage(An + ASZ, vb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const bool split = g.kchunk > 0;
+  const bool add_bias = g.bias && (!split || blockIdx.z == 0);
+  auto emit = [&](float v, int n, int64_t ci) {   // one finished element (alpha applied) to its place in C
+    if (add_bias) v += g.bias[n];
+    if (split) {
+      atomicAdd(g.C + ci, v);
+      return;
+    }
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (g.mask && !(g.mask[ci] > 0.f)) v = 0.f;
+    g.C[ci] = v;
+  };
+  if constexpr (CMODE == 0) {
+    // D: lane (n = lane & 15, q = lane >> 4) holds rows 4q + reg of its 16 x 16 tile
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn + 16 * j + lm;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int m = m0 + wm + 16 * i + 4 * kq + reg;
+          if (m < g.M && n < g.N) emit(acc[i][j][reg] * g.alpha, n, (int64_t)m * g.ldc + n);
+        }
+    }
+  } else {
+    // y[b][n][t]: the wave's rows (b, t) x 16 columns pass through LDS (Cs[column][row]) and leave in the order
+    // memory has them
+    float *Cs = smem + wv * (16 * CST);
+    const int Tout = g.cg.Tout, mw = m0 + wm;
+    if (Tout >= 64) {
+      // long sequences: lane = row; a store instruction writes up to 64 consecutive positions of one channel
+      const int m = mw + lane, mc = min(m, g.M - 1);
+      const int b = (int)mdiv((uint32_t)mc, g.mg_tout), t = mc - b * Tout;
+      const int64_t base = (int64_t)b * g.cg.Cout * Tout + t;
+      const bool on = lane < WR && m < g.M;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4 *>(Cs + lm * CST + 16 * i + 4 * kq) = acc[i][j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const int n = n0 + wn + 16 * j + c;   // wave uniform
+          if (on && n < g.N) emit(Cs[c * CST + min(lane, WR - 1)] * g.alpha, n, base + (int64_t)n * Tout);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+      // short sequences: the 16 channels x Tout positions of one b are contiguous in y; lanes enumerate
+      // (b, channel, t) of the sequences the wave's rows touch
+      const int mhi = min(g.M, mw + WR) - 1;   // last row of the wave inside the matrix (may be < mw)
+      const int blo = (int)mdiv((uint32_t)min(mw, g.M - 1), g.mg_tout);
+      const int bhi = (int)mdiv((uint32_t)max(mhi, 0), g.mg_tout);
+      const int per_b = 16 * Tout, total = mhi >= mw ? (bhi - blo + 1) * per_b : 0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4 *>(Cs + lm * CST + 16 * i + 4 * kq) = acc[i][j];
+        __builtin_amdgcn_wave_barrier();
+        for (int f = lane; f < total; f += 64) {
+          const int bl = (int)mdiv((uint32_t)f, g.mg_tout16), rem = f - bl * per_b;
+          const int c = (int)mdiv((uint32_t)rem, g.mg_tout), t = rem - c * Tout;
+          const int b = blo + bl, row = b * Tout + t - mw, n = n0 + wn + 16 * j + c;
+          if (row >= 0 && row <= mhi - mw && n < g.N)
+            emit(Cs[c * CST + row] * g.alpha, n, ((int64_t)b * g.cg.Cout + n) * Tout + t);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+}
+
+// ReLU / mask epilogue of a split product (the bias went in with block z = 0)
+__global__ __launch_bounds__(256) void k_mm_finish(float *__restrict__ C, int64_t ldc, int M, int N, int relu,
+                                                   const float *__restrict__ mask) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = e / N, ci = m * ldc + (e - m * N);
+    float v = C[ci];
+    if (relu) v = fmaxf(v, 0.f);
+    if (mask && !(mask[ci] > 0.f)) v = 0.f;
+    C[ci] = v;
+  }
+}
+
 // out[n] = sum_m X[m][n] (row major, ld) — bias gradients; one block per 64 columns
 __global__ __launch_bounds__(256) void k_colsum_f32(const float *__restrict__ X, int64_t ld, int M, int N,
                                                     float *__restrict__ out) {
@@ -572,6 +872,119 @@ __global__ __launch_bounds__(256) void k_colsum_f32(const float *__restrict__ X,
   s[part][threadIdx.x & 63] = t;
   __syncthreads();
   if (part == 0 && n < N) out[n] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+
+}  // namespace
+}  // namespace mrgcn
+
+namespace mrgcn {
+namespace {
+
+// launch of k_mm_tile; MRGCN_ERR_UNSUPPORTED = not a shape / mode combination it takes (the caller goes on to the
+// older forms)
+int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
+  const int amode = o.amode, bmode = o.bmode, M = o.M, N = o.N, K = o.K;
+  int cmode = o.cmode;
+  int64_t ldc = o.ldc;
+  if (cmode == 2 && o.cg.Tout == 1) {  // y[b][n][0] is a row-major [b][n]
+    cmode = 0;
+    ldc = o.cg.Cout;
+  }
+  const bool conv = amode >= 2 || bmode == 2 || cmode == 2;
+  int combo = -1;
+  if (amode < 2 && bmode < 2 && cmode == 0) combo = amode * 2 + bmode;
+  else if (amode == 2 && bmode < 2) combo = (cmode == 2 ? 4 : 7) + (bmode == 0 ? 1 : 0);   // 4, 5 / 7, 8
+  else if (amode == 3 && bmode == 2 && cmode == 0) combo = 6;
+  if (combo < 0) return MRGCN_ERR_UNSUPPORTED;
+  int64_t amax, bmax;
+  if (amode < 2) amax = (amode == 0 ? (int64_t)(M - 1) * o.lda + K : (int64_t)(K - 1) * o.lda + M);
+  else amax = (int64_t)((amode == 2 ? M : K) / o.cg.Tout + 1) * o.cg.Cin * o.cg.Tin;
+  if (bmode < 2) bmax = (bmode == 0 ? (int64_t)(K - 1) * o.ldb + N : (int64_t)(N - 1) * o.ldb + K);
+  else bmax = (int64_t)(K / o.cg.Tout + 1) * o.cg.Cout * o.cg.Tout;
+  if (amax * 4 > kMmMaxBytes || bmax * 4 > kMmMaxBytes || K < 1) return MRGCN_ERR_UNSUPPORTED;
+  if (conv && (int64_t)std::max(M, K) * std::max(16 * o.cg.Tout, o.cg.KW) >= ((int64_t)1 << 32)) return MRGCN_ERR_UNSUPPORTED;
+  if (!((M >= 48 && N >= 48) || (K >= 1024 && M >= 16 && N >= 16))) return MRGCN_ERR_UNSUPPORTED;
+  MmArgs g{};
+  g.A = o.A; g.B = o.B; g.C = o.C;
+  g.a_bytes = (uint32_t)(amax * 4); g.b_bytes = (uint32_t)(bmax * 4);
+  g.M = M; g.N = N; g.K = K;
+  g.lda = (int32_t)o.lda; g.ldb = (int32_t)o.ldb; g.ldc = ldc;
+  g.bias = o.bias; g.relu = o.relu; g.mask = o.mask; g.alpha = o.alpha;
+  g.cg = o.cg;
+  auto magic = [](int64_t d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1) << 32) / (uint64_t)d + 1); };
+  g.mg_tout = magic(o.cg.Tout);
+  g.mg_kw = magic(o.cg.KW);
+  g.mg_tout16 = magic((int64_t)16 * o.cg.Tout);
+  static const int dry = getenv("MRGCN_MM_DRY") ? atoi(getenv("MRGCN_MM_DRY")) : 0;
+  g.dry = dry;
+  if (dry == 1) g.a_bytes = g.b_bytes = 0;  // every load falls behind the descriptor's range: no memory access
+  // Tile shape and K split.  A candidate's cost = the padded tile area over the shape's efficiency, times what it
+  // pays for its grid: a grid of fewer than two blocks per CU either splits K (the partial tiles meet in a zeroed C
+  // through float atomics: about 145 splits / K of the product's own time) or leaves CUs idle or with one wave per
+  // SIMD, whose load latencies nothing covers.
+  static const int target = getenv("MRGCN_MM_BLOCKS") ? atoi(getenv("MRGCN_MM_BLOCKS")) : 768;
+  static const int force_tile = getenv("MRGCN_MM_TILE") ? atoi(getenv("MRGCN_MM_TILE")) : -1;
+  const bool dense_c = cmode == 2 || ldc == N;
+  const bool can_split = dense_c && K >= 512 && !(cmode == 2 && (o.relu || o.mask));
+  struct Cand { int bm, bn; double eff; };
+  const Cand cands[3] = {{128, 128, 1.0}, {128, 64, 0.95}, {64, 64, 0.85}};
+  int best = -1, best_splits = 1;
+  double best_cost = 0;
+  for (int c = 0; c < 3; ++c) {
+    if (force_tile >= 0 && c != force_tile) continue;
+    if (cands[c].bn == 128 && N <= 64) continue;
+    const int64_t tm = (M + cands[c].bm - 1) / cands[c].bm, tn = (N + cands[c].bn - 1) / cands[c].bn, t = tm * tn;
+    double cost = (double)tm * cands[c].bm * tn * cands[c].bn / cands[c].eff;
+    int splits = 1;
+    if (t < 512) {
+      if (can_split) {
+        splits = (int)std::max<int64_t>(1, std::min<int64_t>((target + t / 2) / t, K / 256));
+        cost *= 1.0 + 145.0 * splits / K;
+      }
+      if (t * splits < 512) cost *= std::max(1.0, 256.0 / (double)(t * splits)) * 1.4;
+    }
+    if (best < 0 || cost < best_cost) best = c, best_cost = cost, best_splits = splits;
+  }
+  if (best < 0) return MRGCN_ERR_UNSUPPORTED;
+  const int BM = cands[best].bm, BN = cands[best].bn, splits = best_splits;
+  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), 1);
+  static const bool log_on = getenv("MRGCN_MM_LOG") && atoi(getenv("MRGCN_MM_LOG"));
+  if (log_on) fprintf(stderr, "mm_tile %d/%d/%d  %d x %d x %d: tile %d x %d, %d splits\n", amode, bmode, cmode, M, N, K, BM, BN, splits);
+  if (splits > 1) {
+    g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
+    grid.z = (unsigned)((K + g.kchunk - 1) / g.kchunk);
+    const int64_t celems = cmode == 2 ? (int64_t)(M / o.cg.Tout) * o.cg.Cout * o.cg.Tout : (int64_t)M * N;
+    MRGCN_HIP_TRY(hipMemsetAsync(o.C, 0, (size_t)celems * sizeof(float), stream));
+  }
+  static const size_t pad_lds = getenv("MRGCN_MM_PADLDS") ? (size_t)atoi(getenv("MRGCN_MM_PADLDS")) : 0;  // experiments
+#define MM_GO1(AM_, BM_, CM_, MT_, NT_, BK_) k_mm_tile<AM_, BM_, CM_, MT_, NT_, BK_><<<grid, dim3(256), pad_lds, stream>>>(g)
+#define MM_GO(AM_, BM_, CM_)                                     \
+  do {                                                           \
+    if (BM == 64) MM_GO1(AM_, BM_, CM_, 2, 2, 32);               \
+    else if (BN == 64) MM_GO1(AM_, BM_, CM_, 4, 2, 16);          \
+    else MM_GO1(AM_, BM_, CM_, 4, 4, 16);                        \
+  } while (0)
+  switch (combo) {
+    case 0: MM_GO(0, 0, 0); break;
+    case 1: MM_GO(0, 1, 0); break;
+    case 2: MM_GO(1, 0, 0); break;
+    case 3: MM_GO(1, 1, 0); break;
+    case 4: MM_GO(2, 1, 2); break;
+    case 5: MM_GO(2, 0, 2); break;
+    case 6: MM_GO(3, 2, 0); break;
+    case 7: MM_GO(2, 1, 0); break;
+    default: MM_GO(2, 0, 0); break;
+  }
+#undef MM_GO
+#undef MM_GO1
+  MRGCN_HIP_TRY(hipGetLastError());
+  if (splits > 1 && (o.relu || o.mask)) {
+    const int64_t total = (int64_t)M * N;
+    k_mm_finish<<<dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, stream>>>(o.C, ldc, M, N,
+                                                                                                     o.relu, o.mask);
+    MRGCN_HIP_TRY(hipGetLastError());
+  }
+  return MRGCN_OK;
 }
 
 }  // namespace
@@ -660,7 +1073,12 @@ int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32
   // products with fewer than 48 rows or columns and a short reduction (the heads' few outputs) and anything larger
   // keep the 64 x 64 kernel; a narrow product with a long reduction (the first convolution's dW: 64 x 27 over
   // batch x positions) goes to the split form
-  static const bool big_on = !(getenv("MRGCN_GEMM128") && atoi(getenv("MRGCN_GEMM128")) == 0);
+  static const int tile_form = getenv("MRGCN_GEMM128") ? atoi(getenv("MRGCN_GEMM128")) : 2;
+  const bool big_on = tile_form != 0;
+  if (tile_form >= 2) {
+    const int rc = mm_tile_launch(g, (hipStream_t)stream);
+    if (rc != MRGCN_ERR_UNSUPPORTED) return rc;
+  }
   int64_t amax = 0, bmax = 0;
   if (amode < 2) amax = (amode == 0 ? (int64_t)M * lda + K : (int64_t)K * lda + M);
   else amax = (int64_t)((amode == 2 ? M : K) / g.cg.Tout + 1) * g.cg.Cin * g.cg.Tin;

@@ -303,7 +303,13 @@ def test_linear_on_the_matrix_cores_vs_float64(shape, relu):
                                                  # reduction (split K), sequences shorter than a loader's run of 8
                                                  # positions, one-position outputs
                                                  (500, 9, 20, 64, 3, 1), (300, 64, 5, 128, 3, 1),
-                                                 (600, 128, 2, 256, 2, 0)])
+                                                 (600, 128, 2, 256, 2, 0),
+                                                 # the TCNN M shapes on a smaller batch: 128-row tiles with ragged last
+                                                 # tiles (M = 37 * 7 = 259 rows of dW), sequences that end inside a
+                                                 # tile, the closing valid convolution (one output position)
+                                                 (24, 37, 300, 64, 7, 3), (24, 64, 100, 128, 3, 1),
+                                                 (40, 128, 33, 256, 3, 1), (90, 256, 3, 512, 3, 1),
+                                                 (150, 512, 3, 1024, 3, 0)])
 def test_conv1d_on_the_matrix_cores_vs_torch(B, Cin, T, Cout, KW, pad):
     from mrgcn_amd import dense
     gen = torch.Generator("cuda").manual_seed(B + T)

@@ -15,7 +15,12 @@ from mrgcn_amd import dense  # noqa: E402
 from mrgcn_amd.models.temporal_cnn import _SPECS  # noqa: E402
 
 
-def timed(fn, iters):
+ONLY = ""
+
+
+def timed(fn, iters, name=""):
+    if ONLY not in name:
+        return None
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -38,7 +43,10 @@ def main():
     ap.add_argument("--length", type=int, default=300)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--only", default="", help="substring of the product names to time")
     a = ap.parse_args()
+    global ONLY
+    ONLY = a.only
     dev = torch.device("cuda:0")
     Bn, T, C = a.batch, a.length, a.features
     rows = []
@@ -61,16 +69,16 @@ def main():
         flop = 2.0 * Bn * Tout * Cout * C * KW
         tag = f"conv {C}->{Cout} k{KW} T{T}"
         Wv = W.view(Cout, C * KW)
-        ms = timed(lambda: dense._gemm(2, 1, 2, Bn * Tout, Cout, C * KW, x, 0, Wv, C * KW, y, 0, bias=b, geom=geom), a.iters)
+        ms = timed(lambda: dense._gemm(2, 1, 2, Bn * Tout, Cout, C * KW, x, 0, Wv, C * KW, y, 0, bias=b, geom=geom), a.iters, tag + " fwd")
         rows.append((tag + " fwd", Bn * Tout, Cout, C * KW, flop, ms))
         if not first:
             Wf = W.flip(2).permute(0, 2, 1).reshape(Cout * KW, C).contiguous()
             dx = torch.empty_like(x)
             g2 = (Cout, Tout, KW, KW - 1 - pad, T, C)
-            ms = timed(lambda: dense._gemm(2, 0, 2, Bn * T, C, Cout * KW, dy, 0, Wf, C, dx, 0, geom=g2), a.iters)
+            ms = timed(lambda: dense._gemm(2, 0, 2, Bn * T, C, Cout * KW, dy, 0, Wf, C, dx, 0, geom=g2), a.iters, tag + " dX")
             rows.append((tag + " dX", Bn * T, C, Cout * KW, 2.0 * Bn * T * C * Cout * KW, ms))
         dWt = torch.empty(C * KW, Cout, device=dev)
-        ms = timed(lambda: dense._gemm(3, 2, 0, C * KW, Cout, Bn * Tout, x, 0, dy, 0, dWt, Cout, geom=geom), a.iters)
+        ms = timed(lambda: dense._gemm(3, 2, 0, C * KW, Cout, Bn * Tout, x, 0, dy, 0, dWt, Cout, geom=geom), a.iters, tag + " dW")
         rows.append((tag + " dW", C * KW, Cout, Bn * Tout, flop, ms))
         C, T, first = Cout, Tout, False
     # fully connected tail: C -> C (ReLU), the closing C -> 16 is too small to matter
@@ -79,14 +87,15 @@ def main():
     b = torch.randn(C, device=dev)
     y = torch.empty(Bn, C, device=dev)
     flop = 2.0 * Bn * C * C
-    ms = timed(lambda: dense._gemm(0, 1, 0, Bn, C, C, x, C, W, C, y, C, bias=b, relu=True), a.iters)
+    ms = timed(lambda: dense._gemm(0, 1, 0, Bn, C, C, x, C, W, C, y, C, bias=b, relu=True), a.iters, f"fc {C}->{C} fwd")
     rows.append((f"fc {C}->{C} fwd", Bn, C, C, flop, ms))
-    ms = timed(lambda: dense._gemm(0, 0, 0, Bn, C, C, y, C, W, C, x, C), a.iters)
+    ms = timed(lambda: dense._gemm(0, 0, 0, Bn, C, C, y, C, W, C, x, C), a.iters, f"fc {C}->{C} dX")
     rows.append((f"fc {C}->{C} dX", Bn, C, C, flop, ms))
     dW = torch.empty(C, C, device=dev)
-    ms = timed(lambda: dense._gemm(1, 0, 0, C, C, Bn, y, C, x, C, dW, C), a.iters)
+    ms = timed(lambda: dense._gemm(1, 0, 0, C, C, Bn, y, C, x, C, dW, C), a.iters, f"fc {C}->{C} dW")
     rows.append((f"fc {C}->{C} dW", C, C, Bn, flop, ms))
 
+    rows = [r for r in rows if r[5] is not None]
     tot_f = sum(r[4] for r in rows)
     tot_ms = sum(r[5] for r in rows)
     if a.json:
