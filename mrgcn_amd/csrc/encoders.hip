@@ -14,6 +14,7 @@
 //       im2col form (A-loader modes below).
 //   k_colsum_f32 bias gradients (column sums).
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -325,246 +326,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The same product for shapes that can fill it: block tile 128 x 128, K step 16, four waves of 64 x 64 (4 x 4 MFMA
-// tiles each, 64 MFMAs per wave and K step).  Every operand element is  base[ rowoff(i) + coloff(k) ]  with the
-// conv coordinate carried along (valid while 0 <= t_row + t_col < Tin), so that the loaders need one division per
-// thread and K step at most; an operand is staged in LDS in the direction it is contiguous in memory
-//   KC  contiguous along k (A modes 0, 3; B modes 1, 2):  Xs[row][k],  thread = (row, half of the K step), 2 x 16 B
-//   MC  contiguous along the tile row (A modes 1, 2; B mode 0):  Xs[k][row],  thread = (k, 8 consecutive rows)
-// with 16-byte global loads where the eight elements are contiguous and in range (dword alignment is all the vector
-// memory path needs) and element loads at the edges; the next K step's elements are fetched into registers while the
-// current one is multiplied.
-// ---------------------------------------------------------------------------------------------------
-struct Idx2 {
-  int32_t off;   // element offset contribution
-  int32_t t;     // conv coordinate contribution (0 when the mode has none)
-  int32_t room;  // column maps only: how many consecutive k from this one on advance `off` (and `t`) by one each
-};
-__device__ __forceinline__ Idx2 ga_row(const GemmArgs &g, int m) {
-  switch (g.amode) {
-    case 0: return Idx2{(int32_t)(m * g.lda), 0, 0};
-    case 1: return Idx2{m, 0, 0};
-    case 2: { const int b = m / g.cg.Tout, t = m - b * g.cg.Tout; return Idx2{b * g.cg.Cin * g.cg.Tin + t, t, 0}; }
-    default: { const int ci = m / g.cg.KW, kw = m - ci * g.cg.KW; return Idx2{ci * g.cg.Tin + kw - g.cg.pad, kw - g.cg.pad, 0}; }
-  }
-}
-__device__ __forceinline__ Idx2 ga_col(const GemmArgs &g, int k) {
-  switch (g.amode) {
-    case 0: return Idx2{k, 0, 1 << 30};
-    case 1: return Idx2{(int32_t)(k * g.lda), 0, 1};
-    case 2: { const int ci = k / g.cg.KW, kw = k - ci * g.cg.KW; return Idx2{ci * g.cg.Tin + kw - g.cg.pad, kw - g.cg.pad, g.cg.KW - kw}; }
-    default: { const int b = k / g.cg.Tout, t = k - b * g.cg.Tout; return Idx2{b * g.cg.Cin * g.cg.Tin + t, t, g.cg.Tout - t}; }
-  }
-}
-__device__ __forceinline__ Idx2 gb_row(const GemmArgs &g, int n) {
-  switch (g.bmode) {
-    case 0: return Idx2{n, 0, 0};
-    case 1: return Idx2{(int32_t)(n * g.ldb), 0, 0};
-    default: return Idx2{n * g.cg.Tout, 0, 0};
-  }
-}
-__device__ __forceinline__ Idx2 gb_col(const GemmArgs &g, int k) {
-  switch (g.bmode) {
-    case 0: return Idx2{(int32_t)(k * g.ldb), 0, 1};
-    case 1: return Idx2{k, 0, 1 << 30};
-    default: { const int b = k / g.cg.Tout, t = k - b * g.cg.Tout; return Idx2{b * g.cg.Cout * g.cg.Tout + t, 0, g.cg.Tout - t}; }
-  }
-}
-
-constexpr int kBT = 128, kBK = 16, kMCP = kBT + 4;  // (KC rows are padded to BK + 4 floats)
-typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-
-// one operand's loader: IS_A picks the index maps, MC the staging direction
-template <bool IS_A, bool MC, int BK>
-struct TileLoader {
-  static constexpr int NV = BK / 2;      // elements per thread and K step
-  static constexpr int KCP = BK + 4;     // padded KC row
-  Idx2 fix[MC ? 8 : 1];  // the index that stays with the thread: MC: its 8 tile rows, KC: its one tile row
-  bool fix_ok[MC ? 8 : 1];
-  bool run_ok;           // MC: the 8 rows are contiguous in memory and inside the matrix
-  int conv;              // the mode carries a conv range check
-  int lim;               // Tin
-  __device__ __forceinline__ Idx2 rowf(const GemmArgs &g, int i) const { return IS_A ? ga_row(g, i) : gb_row(g, i); }
-  __device__ __forceinline__ Idx2 colf(const GemmArgs &g, int k) const { return IS_A ? ga_col(g, k) : gb_col(g, k); }
-  __device__ __forceinline__ void init(const GemmArgs &g, int row0, int rows_in_tile) {
-    const int R = min(IS_A ? g.M : g.N, row0 + rows_in_tile);
-    conv = IS_A && g.amode >= 2;
-    lim = g.cg.Tin;
-    if constexpr (MC) {
-      const int r0 = row0 + (threadIdx.x & 15) * 8;
-      run_ok = r0 + 7 < R;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        fix_ok[i] = r0 + i < R;
-        fix[i] = rowf(g, fix_ok[i] ? r0 + i : 0);
-        if (i > 0) run_ok = run_ok && fix[i].off == fix[0].off + i && fix[i].t == fix[0].t + (conv ? i : 0);
-      }
-    } else {
-      const int r = row0 + (threadIdx.x >> 1);
-      fix_ok[0] = r < R;
-      fix[0] = rowf(g, fix_ok[0] ? r : 0);
-      run_ok = false;
-    }
-  }
-  // the 8 elements of this thread for the K step at k0
-  __device__ __forceinline__ void load(const GemmArgs &g, int k0, int kend, float (&v)[NV]) const {
-    const float *base = IS_A ? g.A : g.B;
-    if constexpr (MC) {
-      const int k = k0 + (threadIdx.x >> 4);
-      const bool kin = k < kend;
-      const Idx2 c = colf(g, kin ? k : 0);
-      const int lo = fix[0].t + c.t, hi = fix[7].t + c.t;
-      if (kin && run_ok && (!conv || (lo >= 0 && hi < lim))) {
-        const float *p = base + (int64_t)fix[0].off + c.off;
-        const f32x4_u a = *reinterpret_cast<const f32x4_u *>(p), b = *reinterpret_cast<const f32x4_u *>(p + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int tt = fix[i].t + c.t;
-          const bool ok = kin && fix_ok[i] && (!conv || (tt >= 0 && tt < lim));
-          v[i] = ok ? base[(int64_t)fix[i].off + c.off] : 0.f;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int h = 0; h < NV / 8; ++h) {  // chunks of 8 consecutive k
-        const int kb = k0 + (threadIdx.x & 1) * NV + 8 * h;
-        // one index decomposition per chunk: the map says how far its run of consecutive k reaches
-        const Idx2 c0 = colf(g, kb < kend ? kb : 0);
-        const int tstep = conv ? 1 : 0;  // (A mode 3: the conv coordinate of the columns advances with k)
-        const int lo = fix[0].t + c0.t, hi = lo + 7 * tstep;
-        if (fix_ok[0] && kb + 7 < kend && c0.room >= 8 && (!conv || (lo >= 0 && hi < lim))) {
-          const float *p = base + (int64_t)fix[0].off + c0.off;
-          const f32x4_u a = *reinterpret_cast<const f32x4_u *>(p), b = *reinterpret_cast<const f32x4_u *>(p + 4);
-          v[8 * h + 0] = a.x; v[8 * h + 1] = a.y; v[8 * h + 2] = a.z; v[8 * h + 3] = a.w;
-          v[8 * h + 4] = b.x; v[8 * h + 5] = b.y; v[8 * h + 6] = b.z; v[8 * h + 7] = b.w;
-        } else {  // an edge of the matrix, of a sequence or of the padding: element by element, walking the column
-                  // map (one index decomposition per run of consecutive k, not per element)
-          Idx2 c = c0;
-          int room = c0.room;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int tt = fix[0].t + c.t;
-            const bool ok = fix_ok[0] && kb + i < kend && (!conv || (tt >= 0 && tt < lim));
-            v[8 * h + i] = ok ? base[(int64_t)fix[0].off + c.off] : 0.f;
-            if (--room > 0) {
-              c.off += 1;
-              c.t += tstep;
-            } else if (i < 7) {
-              c = colf(g, kb + i + 1 < kend ? kb + i + 1 : 0);
-              room = c.room;
-            }
-          }
-        }
-      }
-    }
-  }
-  // registers -> LDS (Xs: KC [128][KCP], MC [16][kMCP])
-  __device__ __forceinline__ void stage(float *Xs, const float (&v)[NV]) const {
-    float *dst = MC ? Xs + (threadIdx.x >> 4) * kMCP + (threadIdx.x & 15) * 8
-                    : Xs + (threadIdx.x >> 1) * KCP + (threadIdx.x & 1) * NV;
-#pragma unroll
-    for (int h = 0; h < NV / 4; ++h)
-      *reinterpret_cast<f32x4 *>(dst + 4 * h) = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
-  }
-  // MFMA fragment of tile row `row` (0..127) for the 16-wide K group kg: k slot kq of the s-th MFMA stands for
-  // k = 16 kg + 4 kq + s
-  __device__ __forceinline__ static f32x4 frag(const float *Xs, int row, int kq, int kg) {
-    if constexpr (MC) {
-      const float *q = Xs + (16 * kg + 4 * kq) * kMCP + row;
-      return f32x4{q[0], q[kMCP], q[2 * kMCP], q[3 * kMCP]};
-    } else {
-      return *reinterpret_cast<const f32x4 *>(Xs + row * KCP + 16 * kg + 4 * kq);
-    }
-  }
-};
-
-// NT: 16-column MFMA tiles per wave along n (4: block tile 128 x 128; 2: 128 x 64 for products with N <= 64 per
-// tile column, e.g. the 64-channel convolutions that hold a third of the TCNN's arithmetic)
-// BK: K step (32 when both operands are contiguous along k — the convolutions' dW, whose rows are 1 200 bytes apart:
-// a step then takes a whole 128-byte line of every row instead of half of one)
-template <bool A_MC, bool B_MC, int NT, int BK>
-__global__ __launch_bounds__(256) void k_gemm128_f32(GemmArgs g) {
-  static_assert(BK == 16 || (!A_MC && !B_MC), "the MC loaders cover 16 k per step");
-  constexpr int ASZ = A_MC ? BK * kMCP : kBT * (BK + 4), BSZ = B_MC ? BK * kMCP : kBT * (BK + 4);
-  __shared__ __align__(16) float As[2][ASZ];  // two stages: one barrier per K step
-  __shared__ __align__(16) float Bs[2][BSZ];
-  constexpr int BN = 32 * NT;
-  const int m0 = blockIdx.y * kBT, n0 = blockIdx.x * BN;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wm = (wv >> 1) * 64, wn = (wv & 1) * (16 * NT);  // this wave's 64 x (16 NT) part
-  const int lm = lane & 15, kq = lane >> 4;
-  f32x4 acc[4][NT];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  TileLoader<true, A_MC, BK> la;
-  TileLoader<false, B_MC, BK> lb;
-  la.init(g, m0, kBT);
-  lb.init(g, n0, BN);
-  const int kbeg = g.kchunk > 0 ? blockIdx.z * g.kchunk : 0;
-  const int kend = g.kchunk > 0 ? min(g.K, kbeg + g.kchunk) : g.K;
-  float va[BK / 2], vb[BK / 2];
-  la.load(g, kbeg, kend, va);
-  lb.load(g, kbeg, kend, vb);
-  la.stage(As[0], va);
-  lb.stage(Bs[0], vb);
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;  // block uniform
-    if (more) {  // the next step's elements fly under this step's products
-      la.load(g, k0 + BK, kend, va);
-      lb.load(g, k0 + BK, kend, vb);
-    }
-#pragma unroll
-    for (int kg = 0; kg < BK / 16; ++kg) {
-      f32x4 a[4], b[NT];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = TileLoader<true, A_MC, BK>::frag(As[cur], wm + 16 * i + lm, kq, kg);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = TileLoader<false, B_MC, BK>::frag(Bs[cur], wn + 16 * j + lm, kq, kg);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-    }
-    if (more) {  // into the other stage: nobody reads it before the barrier
-      la.stage(As[cur ^ 1], va);
-      lb.stage(Bs[cur ^ 1], vb);
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-  // D: lane (n = lane & 15, q = lane >> 4) holds rows 4q + reg of its 16 x 16 tile
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int m = m0 + wm + i * 16 + 4 * kq + reg, n = n0 + wn + j * 16 + lm;
-        if (m >= g.M || n >= g.N) continue;
-        float v = acc[i][j][reg] * g.alpha;
-        if (g.bias) v += g.bias[n];
-        if (g.relu) v = fmaxf(v, 0.f);
-        const int64_t ci = gemm_c_index(g, m, n);
-        if (g.kchunk > 0) {  // split K: partial sums meet in C (zeroed by the launcher; no epilogue in this form)
-          atomicAdd(&g.C[ci], v);
-          continue;
-        }
-        if (g.mask && !(g.mask[ci] > 0.f)) v = 0.f;
-        g.C[ci] = v;
-      }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Third form of the product: the loader modes are template parameters, every element is fetched by a dword
+// The tiled form of the product (128 x 128, 128 x 64 or 64 x 64 block tiles): the loader modes are template parameters, every element is fetched by a dword
 // buffer load whose lanes run along the direction the operand is contiguous in memory, and there is no branch in
 // the K loop.
 //   * element (row i, column k) of an operand sits at byte offset  roff(i) + coff(k)  of its base; a row or a column
@@ -601,7 +363,6 @@ struct MmArgs {
   float alpha;
   ConvGeom cg;
   int kchunk;
-  int dry;  // timing experiments only (MRGCN_MM_DRY): 2 = the K loop issues no loads
   uint32_t mg_tout, mg_kw, mg_tout16;  // floor(2^32 / d) + 1 for d = Tout, KW, 16 Tout (0 stands for d == 1)
 };
 
@@ -654,9 +415,8 @@ __device__ __forceinline__ Coord mm_col(const MmArgs &g, int k, int kend) {
   }
 }
 
-template <bool IS_A, int MODE, int ROWS, int BK>
+template <bool IS_A, int MODE, bool ROWL, int ROWS, int BK>
 struct MmLoader {
-  static constexpr bool ROWL = IS_A ? (MODE == 1 || MODE == 2) : (MODE == 0);
   static constexpr bool CONV = IS_A && MODE >= 2;
   static constexpr int NE = ROWS * BK / 256;  // elements per thread and K step
   static constexpr int LDK = BK + 4;
@@ -715,7 +475,8 @@ struct MmLoader {
 };
 
 // MT / NT: 16 x 16 MFMA tiles per wave along m / n — block tile 32 MT x 32 NT (128 x 128, 128 x 64, 64 x 64)
-template <int AMODE, int BMODE, int CMODE, int MT, int NT, int BK>
+// AR / BR: the lanes of the A / B loader run along the tile rows (else along k)
+template <int AMODE, int BMODE, int CMODE, bool AR, bool BR, int MT, int NT, int BK>
 __global__ __launch_bounds__(256) void k_mm_tile(MmArgs g) {
   constexpr int BM = 32 * MT, BN = 32 * NT, LDK = BK + 4, ASZ = BM * LDK, BSZ = BN * LDK;
   constexpr int WR = 16 * MT, CST = WR + 4;  // rows of a wave; row stride of its transposition buffer
@@ -732,8 +493,8 @@ __global__ __launch_bounds__(256) void k_mm_tile(MmArgs g) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, g.a_bytes, 0x00020000);
   const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)g.B, 0, g.b_bytes, 0x00020000);
-  MmLoader<true, AMODE, BM, BK> la;
-  MmLoader<false, BMODE, BN, BK> lb;
+  MmLoader<true, AMODE, AR, BM, BK> la;
+  MmLoader<false, BMODE, BR, BN, BK> lb;
   la.init(g, m0);
   lb.init(g, n0);
   const int kbeg = g.kchunk > 0 ? blockIdx.z * g.kchunk : 0;
@@ -747,7 +508,7 @@ __global__ __launch_bounds__(256) void k_mm_tile(MmArgs g) {
   int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
-    if (more && g.dry < 2) {
+    if (more) {
       la.load(g, ra, k0 + BK, kend, va);
       lb.load(g, rb, k0 + BK, kend, vb);
     }
@@ -883,41 +644,56 @@ namespace {
 // launch of k_mm_tile; MRGCN_ERR_UNSUPPORTED = not a shape / mode combination it takes (the caller goes on to the
 // older forms)
 int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
-  const int amode = o.amode, bmode = o.bmode, M = o.M, N = o.N, K = o.K;
+  const int M = o.M, N = o.N, K = o.K;
   int cmode = o.cmode;
   int64_t ldc = o.ldc;
   if (cmode == 2 && o.cg.Tout == 1) {  // y[b][n][0] is a row-major [b][n]
     cmode = 0;
     ldc = o.cg.Cout;
   }
+  // a convolution whose kernel covers the whole (unpadded) sequence is a plain product: x[b][(ci, kw)] and
+  // y[b][n] are row-major matrices
+  int amode = o.amode, bmode = o.bmode;
+  int64_t lda = o.lda, ldb = o.ldb;
+  if (amode >= 2 && o.cg.Tout == 1 && o.cg.pad == 0 && o.cg.Tin == o.cg.KW) {
+    lda = (int64_t)o.cg.Cin * o.cg.KW;
+    amode = amode == 2 ? 0 : 1;
+  }
+  if (bmode == 2 && o.cg.Tout == 1 && amode < 2) {
+    ldb = o.cg.Cout;
+    bmode = 0;
+  }
   const bool conv = amode >= 2 || bmode == 2 || cmode == 2;
+  // lanes along the tile rows where memory runs along them — and for the (b, t)-indexed reductions of short
+  // sequences (dW: k = (b, t)), whose runs along k are Tout elements long while the rows are contiguous or evenly
+  // strided
+  const bool short_seq = conv && o.cg.Tout < 16;
+  const bool ar = amode == 1 || amode == 2 || (amode == 3 && short_seq);
+  const bool br = bmode == 0 || (bmode == 2 && short_seq);
   int combo = -1;
   if (amode < 2 && bmode < 2 && cmode == 0) combo = amode * 2 + bmode;
   else if (amode == 2 && bmode < 2) combo = (cmode == 2 ? 4 : 7) + (bmode == 0 ? 1 : 0);   // 4, 5 / 7, 8
-  else if (amode == 3 && bmode == 2 && cmode == 0) combo = 6;
+  else if (amode == 3 && bmode == 2 && cmode == 0 && ar == br) combo = ar ? 9 : 6;
   if (combo < 0) return MRGCN_ERR_UNSUPPORTED;
   int64_t amax, bmax;
-  if (amode < 2) amax = (amode == 0 ? (int64_t)(M - 1) * o.lda + K : (int64_t)(K - 1) * o.lda + M);
+  if (amode < 2) amax = (amode == 0 ? (int64_t)(M - 1) * lda + K : (int64_t)(K - 1) * lda + M);
   else amax = (int64_t)((amode == 2 ? M : K) / o.cg.Tout + 1) * o.cg.Cin * o.cg.Tin;
-  if (bmode < 2) bmax = (bmode == 0 ? (int64_t)(K - 1) * o.ldb + N : (int64_t)(N - 1) * o.ldb + K);
+  if (bmode < 2) bmax = (bmode == 0 ? (int64_t)(K - 1) * ldb + N : (int64_t)(N - 1) * ldb + K);
   else bmax = (int64_t)(K / o.cg.Tout + 1) * o.cg.Cout * o.cg.Tout;
   if (amax * 4 > kMmMaxBytes || bmax * 4 > kMmMaxBytes || K < 1) return MRGCN_ERR_UNSUPPORTED;
   if (conv && (int64_t)std::max(M, K) * std::max(16 * o.cg.Tout, o.cg.KW) >= ((int64_t)1 << 32)) return MRGCN_ERR_UNSUPPORTED;
-  if (!((M >= 48 && N >= 48) || (K >= 1024 && M >= 16 && N >= 16))) return MRGCN_ERR_UNSUPPORTED;
+  if (!((M >= 48 && N >= 48) || K >= 1024)) return MRGCN_ERR_UNSUPPORTED;
   MmArgs g{};
   g.A = o.A; g.B = o.B; g.C = o.C;
   g.a_bytes = (uint32_t)(amax * 4); g.b_bytes = (uint32_t)(bmax * 4);
   g.M = M; g.N = N; g.K = K;
-  g.lda = (int32_t)o.lda; g.ldb = (int32_t)o.ldb; g.ldc = ldc;
+  g.lda = (int32_t)lda; g.ldb = (int32_t)ldb; g.ldc = ldc;
   g.bias = o.bias; g.relu = o.relu; g.mask = o.mask; g.alpha = o.alpha;
   g.cg = o.cg;
   auto magic = [](int64_t d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1) << 32) / (uint64_t)d + 1); };
   g.mg_tout = magic(o.cg.Tout);
   g.mg_kw = magic(o.cg.KW);
   g.mg_tout16 = magic((int64_t)16 * o.cg.Tout);
-  static const int dry = getenv("MRGCN_MM_DRY") ? atoi(getenv("MRGCN_MM_DRY")) : 0;
-  g.dry = dry;
-  if (dry == 1) g.a_bytes = g.b_bytes = 0;  // every load falls behind the descriptor's range: no memory access
   // Tile shape and K split.  A candidate's cost = the padded tile area over the shape's efficiency, times what it
   // pays for its grid: a grid of fewer than two blocks per CU either splits K (the partial tiles meet in a zeroed C
   // through float atomics: about 145 splits / K of the product's own time) or leaves CUs idle or with one wave per
@@ -926,8 +702,8 @@ int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
   static const int force_tile = getenv("MRGCN_MM_TILE") ? atoi(getenv("MRGCN_MM_TILE")) : -1;
   const bool dense_c = cmode == 2 || ldc == N;
   const bool can_split = dense_c && K >= 512 && !(cmode == 2 && (o.relu || o.mask));
-  struct Cand { int bm, bn; double eff; };
-  const Cand cands[3] = {{128, 128, 1.0}, {128, 64, 0.95}, {64, 64, 0.85}};
+  struct Cand { int bm, bn; double eff; int occ; };  // occ: blocks per CU (registers / LDS)
+  const Cand cands[3] = {{128, 128, 1.0, 3}, {128, 64, 0.95, 5}, {64, 64, 0.85, 4}};
   int best = -1, best_splits = 1;
   double best_cost = 0;
   for (int c = 0; c < 3; ++c) {
@@ -943,6 +719,9 @@ int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
       }
       if (t * splits < 512) cost *= std::max(1.0, 256.0 / (double)(t * splits)) * 1.4;
     }
+    // the last round of blocks leaves part of the chip idle
+    const double per_round = 256.0 * cands[c].occ, blocks = (double)t * splits;
+    if (blocks > per_round) cost *= std::ceil(blocks / per_round) * per_round / blocks;
     if (best < 0 || cost < best_cost) best = c, best_cost = cost, best_splits = splits;
   }
   if (best < 0) return MRGCN_ERR_UNSUPPORTED;
@@ -956,24 +735,25 @@ int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
     const int64_t celems = cmode == 2 ? (int64_t)(M / o.cg.Tout) * o.cg.Cout * o.cg.Tout : (int64_t)M * N;
     MRGCN_HIP_TRY(hipMemsetAsync(o.C, 0, (size_t)celems * sizeof(float), stream));
   }
-  static const size_t pad_lds = getenv("MRGCN_MM_PADLDS") ? (size_t)atoi(getenv("MRGCN_MM_PADLDS")) : 0;  // experiments
-#define MM_GO1(AM_, BM_, CM_, MT_, NT_, BK_) k_mm_tile<AM_, BM_, CM_, MT_, NT_, BK_><<<grid, dim3(256), pad_lds, stream>>>(g)
-#define MM_GO(AM_, BM_, CM_)                                     \
-  do {                                                           \
-    if (BM == 64) MM_GO1(AM_, BM_, CM_, 2, 2, 32);               \
-    else if (BN == 64) MM_GO1(AM_, BM_, CM_, 4, 2, 16);          \
-    else MM_GO1(AM_, BM_, CM_, 4, 4, 16);                        \
+#define MM_GO1(AM_, BM_, CM_, AR_, BR_, MT_, NT_, BK_) \
+  k_mm_tile<AM_, BM_, CM_, AR_, BR_, MT_, NT_, BK_><<<grid, dim3(256), 0, stream>>>(g)
+#define MM_GO(AM_, BM_, CM_, AR_, BR_)                                     \
+  do {                                                                     \
+    if (BM == 64) MM_GO1(AM_, BM_, CM_, AR_, BR_, 2, 2, 32);               \
+    else if (BN == 64) MM_GO1(AM_, BM_, CM_, AR_, BR_, 4, 2, 16);          \
+    else MM_GO1(AM_, BM_, CM_, AR_, BR_, 4, 4, 16);                        \
   } while (0)
   switch (combo) {
-    case 0: MM_GO(0, 0, 0); break;
-    case 1: MM_GO(0, 1, 0); break;
-    case 2: MM_GO(1, 0, 0); break;
-    case 3: MM_GO(1, 1, 0); break;
-    case 4: MM_GO(2, 1, 2); break;
-    case 5: MM_GO(2, 0, 2); break;
-    case 6: MM_GO(3, 2, 0); break;
-    case 7: MM_GO(2, 1, 0); break;
-    default: MM_GO(2, 0, 0); break;
+    case 0: MM_GO(0, 0, 0, false, true); break;
+    case 1: MM_GO(0, 1, 0, false, false); break;
+    case 2: MM_GO(1, 0, 0, true, true); break;
+    case 3: MM_GO(1, 1, 0, true, false); break;
+    case 4: MM_GO(2, 1, 2, true, false); break;
+    case 5: MM_GO(2, 0, 2, true, true); break;
+    case 6: MM_GO(3, 2, 0, false, false); break;
+    case 7: MM_GO(2, 1, 0, true, false); break;
+    case 8: MM_GO(2, 0, 0, true, true); break;
+    default: MM_GO(3, 2, 0, true, true); break;
   }
 #undef MM_GO
 #undef MM_GO1
@@ -1068,57 +848,13 @@ int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32
   if (M == 0 || N == 0) return MRGCN_OK;
   GemmArgs g{A, B, C, lda, ldb, ldc, M, N, K, amode, bmode, cmode, bias, relu, mask, alpha, ConvGeom{}};
   if (conv_geom) g.cg = ConvGeom{conv_geom[0], conv_geom[1], conv_geom[2], conv_geom[3], conv_geom[4], conv_geom[5]};
-  // operands whose element offsets fit 31 bits: 128 x 128 (128 x 64) tiles with vector loaders — also for grids
-  // that do not fill the chip (a 40-tile product still finishes several times sooner than on the element loaders);
-  // products with fewer than 48 rows or columns and a short reduction (the heads' few outputs) and anything larger
-  // keep the 64 x 64 kernel; a narrow product with a long reduction (the first convolution's dW: 64 x 27 over
-  // batch x positions) goes to the split form
-  static const int tile_form = getenv("MRGCN_GEMM128") ? atoi(getenv("MRGCN_GEMM128")) : 2;
-  const bool big_on = tile_form != 0;
-  if (tile_form >= 2) {
+  // the tiled form takes every product with at least 48 rows and columns or a long reduction (operands of at most
+  // 2^29 bytes); the heads' few output columns over a short reduction, larger operands and MRGCN_GEMM_TILED=0 take
+  // the 64 x 64 kernel with element loaders
+  static const bool tiled_on = !(getenv("MRGCN_GEMM_TILED") && atoi(getenv("MRGCN_GEMM_TILED")) == 0);
+  if (tiled_on) {
     const int rc = mm_tile_launch(g, (hipStream_t)stream);
     if (rc != MRGCN_ERR_UNSUPPORTED) return rc;
-  }
-  int64_t amax = 0, bmax = 0;
-  if (amode < 2) amax = (amode == 0 ? (int64_t)M * lda + K : (int64_t)K * lda + M);
-  else amax = (int64_t)((amode == 2 ? M : K) / g.cg.Tout + 1) * g.cg.Cin * g.cg.Tin;
-  if (bmode < 2) bmax = (bmode == 0 ? (int64_t)K * ldb + N : (int64_t)N * ldb + K);
-  else bmax = (int64_t)(K / g.cg.Tout + 1) * g.cg.Cout * g.cg.Tout;
-  // tile columns of 64 when N leaves a 128-wide column more than a third empty
-  // ... and when 128-wide columns would leave most of the 256 CUs without a tile and the reduction cannot be split
-  const bool linear_epilogue = !bias && !relu && !mask && cmode == 0;
-  const bool can_split = linear_epilogue && K >= 1024 && ldc == N;
-  const int64_t mt = (M + kBT - 1) / kBT;
-  const int BN = (N <= 64 || (N % 128 != 0 && N % 128 <= 80) || (!can_split && mt * ((N + 127) / 128) < 128)) ? 64 : 128;
-  const int64_t tiles128 = mt * ((N + BN - 1) / BN);
-  // few tiles but a long reduction (the convolutions' dW: K = batch x positions): split K over the grid's z
-  int splits = 1;
-  if (tiles128 < 256 && can_split) {
-    splits = (int)((512 + tiles128 - 1) / tiles128);
-    const int max_splits = K / 256;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-  }
-  if (big_on && amax < ((int64_t)1 << 31) && bmax < ((int64_t)1 << 31) && ((M >= 48 && N >= 48) || splits > 1)) {
-    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + kBT - 1) / kBT), (unsigned)splits);
-    if (splits > 1) {
-      g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
-      grid.z = (unsigned)((K + g.kchunk - 1) / g.kchunk);
-      MRGCN_HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), (hipStream_t)stream));
-    }
-    const bool a_mc = amode == 1 || amode == 2, b_mc = bmode == 0;
-#define GEMM128_GO(AM_, BM_, BK_)                                                                               \
-  do {                                                                                                          \
-    if (BN == 64) k_gemm128_f32<AM_, BM_, 2, BK_><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);              \
-    else k_gemm128_f32<AM_, BM_, 4, BK_><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);                       \
-  } while (0)
-    if (a_mc && b_mc) GEMM128_GO(true, true, 16);
-    else if (a_mc) GEMM128_GO(true, false, 16);
-    else if (b_mc) GEMM128_GO(false, true, 16);
-    else GEMM128_GO(false, false, 32);
-#undef GEMM128_GO
-    MRGCN_HIP_TRY(hipGetLastError());
-    return MRGCN_OK;
   }
   dim3 grid((unsigned)((N + kGT - 1) / kGT), (unsigned)((M + kGT - 1) / kGT));
   k_gemm_f32<<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);

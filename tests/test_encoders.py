@@ -273,7 +273,9 @@ def test_backbone_heads_on_the_matrix_cores_match_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(1, 1, 1), (5, 3, 2), (70, 130, 65), (257, 64, 7), (33, 768, 16)])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (5, 3, 2), (70, 130, 65), (257, 64, 7), (33, 768, 16),
+                                   # tiled form: K split + the ReLU pass behind it, ragged 64- and 128-row tiles
+                                   (300, 1100, 200), (1000, 96, 520), (130, 2050, 70)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_linear_on_the_matrix_cores_vs_float64(shape, relu):
     """dense.linear (f32 MFMA 16x16x4: exact fp32 arithmetic) forward and all three gradients, edge tiles included."""
@@ -309,7 +311,10 @@ def test_linear_on_the_matrix_cores_vs_float64(shape, relu):
                                                  # tile, the closing valid convolution (one output position)
                                                  (24, 37, 300, 64, 7, 3), (24, 64, 100, 128, 3, 1),
                                                  (40, 128, 33, 256, 3, 1), (90, 256, 3, 512, 3, 1),
-                                                 (150, 512, 3, 1024, 3, 0)])
+                                                 (150, 512, 3, 1024, 3, 0),
+                                                 # one position in, one out, padded: the transposed loaders with
+                                                 # runs of one element
+                                                 (64, 32, 1, 48, 3, 1)])
 def test_conv1d_on_the_matrix_cores_vs_torch(B, Cin, T, Cout, KW, pad):
     from mrgcn_amd import dense
     gen = torch.Generator("cuda").manual_seed(B + T)

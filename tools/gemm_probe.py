@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--length", type=int, default=300)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--wt", action="store_true", help="forward products read the transposed weight ([Cin KW][Cout])")
     ap.add_argument("--only", default="", help="substring of the product names to time")
     a = ap.parse_args()
     global ONLY
@@ -69,7 +70,11 @@ def main():
         flop = 2.0 * Bn * Tout * Cout * C * KW
         tag = f"conv {C}->{Cout} k{KW} T{T}"
         Wv = W.view(Cout, C * KW)
-        ms = timed(lambda: dense._gemm(2, 1, 2, Bn * Tout, Cout, C * KW, x, 0, Wv, C * KW, y, 0, bias=b, geom=geom), a.iters, tag + " fwd")
+        if a.wt:
+            Wt = Wv.t().contiguous()
+            ms = timed(lambda: dense._gemm(2, 0, 2, Bn * Tout, Cout, C * KW, x, 0, Wt, Cout, y, 0, bias=b, geom=geom), a.iters, tag + " fwd")
+        else:
+            ms = timed(lambda: dense._gemm(2, 1, 2, Bn * Tout, Cout, C * KW, x, 0, Wv, C * KW, y, 0, bias=b, geom=geom), a.iters, tag + " fwd")
         rows.append((tag + " fwd", Bn * Tout, Cout, C * KW, flop, ms))
         if not first:
             Wf = W.flip(2).permute(0, 2, 1).reshape(Cout * KW, C).contiguous()
