@@ -47,6 +47,11 @@ enum mrgcn_val_dtype { MRGCN_VAL_I8 = 0, MRGCN_VAL_F32 = 1 };
                                      16 rows gets an operand row of its own, placed where its reader streams
                                      (see mrgcn_operand_replicate); hot columns keep one shared row */
 #define MRGCN_PLAN_NO_REPLICATE 4u /* never replicate, whatever the default (env MRGCN_REPLICATE) says */
+#define MRGCN_PLAN_LEAN 8u        /* a plan for a small, short-lived adjacency (the slices of a re-sampled mini-batch):
+                                   * the COMPACT view keeps the rows in their own order and the operand in compact-column
+                                   * order (no class-major ranks, no first-touch operand order, no replicas, one
+                                   * transform order), its products run on the general row kernel.  Same results up to
+                                   * the summation order inside a row; about half the build passes and host round trips. */
 
 /* which sparse view of the plan a product runs on */
 enum mrgcn_view {
@@ -475,7 +480,8 @@ int mrgcn_colsum_f32(const float *X, int64_t ld, int32_t M, int32_t N, float *ou
  * pool_kind 0: none (Tout = T), 1: MaxPool1d(pool_arg, stride pool_arg), 2: AdaptiveMaxPool1d(pool_arg).
  * training != 0: mean / var (biased) are the batch statistics, computed and written by the call; otherwise they are
  * read (running statistics).  argmax [B][C][Tout] (needed when pooled) keeps the winning position for the backward.
- * Backward: dz is a [B][C][T] workspace; dgamma / dbeta are written; dx = d loss / d x.
+ * Backward: dz is a [B][C][T] workspace that only adaptive pooling uses (overlapping windows; NULL otherwise);
+ * dgamma / dbeta are written; dx = d loss / d x.
  * workspace: mrgcn_bn_workspace_bytes(C) bytes (fp64 partial sums of the per-channel reductions; forward: training only). */
 int32_t mrgcn_pool_out_len(int32_t pool_kind, int32_t pool_arg, int32_t T);
 size_t mrgcn_bn_workspace_bytes(int32_t C);
@@ -483,6 +489,9 @@ int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, 
                                const float *beta, float eps, int32_t training, float *mean, float *var,
                                int32_t pool_kind, int32_t pool_arg, float *y, int32_t *argmax, void *workspace,
                                void *stream);
+/* out[c] = sum over (b, t) of x[b][c][t] — the bias gradient of a Conv1d (torch: dy.sum(dim=(0, 2))); fp64 sums per
+ * block, one float atomic per block into the zeroed out. */
+int mrgcn_channel_sum_f32(const float *x, int32_t B, int32_t C, int32_t T, float *out, void *stream);
 int mrgcn_bn_relu_pool_bwd_f32(const float *x, const float *y, const float *dy, const int32_t *argmax, int32_t B,
                                int32_t C, int32_t T, const float *gamma, const float *mean, const float *var,
                                float eps, int32_t training, int32_t pool_kind, int32_t pool_arg, float *dz,

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmrgcn_hip.so")
 # enums of include/mrgcn_hip.h
 OK = 0
 VAL_I8, VAL_F32 = 0, 1
-PLAN_PRUNE_ZEROS, PLAN_REPLICATE, PLAN_NO_REPLICATE = 1, 2, 4
+PLAN_PRUNE_ZEROS, PLAN_REPLICATE, PLAN_NO_REPLICATE, PLAN_LEAN = 1, 2, 4, 8
 VIEW_LITERAL, VIEW_COMPACT, VIEW_TRANSPOSED = 0, 1, 2
 ABI_VERSION = 2  # include/mrgcn_hip.h: MRGCN_ABI_VERSION
 SPMM_RELU, SPMM_PAD_WRITABLE, SPMM_TWO_PASS = 1, 2, 4  # flag word of mrgcn_spmm_f32 / _bf16 (`relu` argument)
@@ -114,6 +114,7 @@ SIGNATURES = {
     "mrgcn_gemm_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i32, _p,
                                  C.c_float, _p, _p]),
     "mrgcn_colsum_f32": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
+    "mrgcn_channel_sum_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "mrgcn_pool_out_len": (_i32, [_i32, _i32, _i32]),
     "mrgcn_bn_workspace_bytes": (C.c_size_t, [_i32]),
     "mrgcn_bn_relu_pool_fwd_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, C.c_float, _i32, _p, _p, _i32, _i32, _p, _p,

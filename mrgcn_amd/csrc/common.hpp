@@ -184,6 +184,7 @@ struct mrgcn_plan {
   // <= kShort3Rows entries, the next n_mid3 <= kMid3Rows, the rest more), ptr3 = row pointer over ranks into
   // mcol / mval; split-row descriptors over ranks for k_spmm (q_*) and k_spmm3 (r3_*)
   int32_t *rowmap = nullptr, *ptr3 = nullptr;
+  bool lean = false;  // MRGCN_PLAN_LEAN: ptr3 / mcol / mval / q_* alias rowptr / ccol / val / r_*, rowmap and mpos are identities
   int32_t n_short3 = 0, n_mid3 = 0;
   int32_t *q_long_row = nullptr, *q_long_cptr = nullptr, *q_chunk_beg = nullptr, *q_chunk_end = nullptr,
           *q_chunk_row = nullptr;

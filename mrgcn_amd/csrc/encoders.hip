@@ -622,17 +622,23 @@ __global__ __launch_bounds__(256) void k_mm_finish(float *__restrict__ C, int64_
   }
 }
 
-// out[n] = sum_m X[m][n] (row major, ld) — bias gradients; one block per 64 columns
+// out[n] = sum_m X[m][n] (row major, ld) — bias gradients.  Block (x, y): 64 columns x the y-th slab of rows; a tall
+// matrix (gridDim.y > 1) adds its slab sums into the zeroed out with float atomics
 __global__ __launch_bounds__(256) void k_colsum_f32(const float *__restrict__ X, int64_t ld, int M, int N,
                                                     float *__restrict__ out) {
   __shared__ float s[4][64];
   const int n = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int per = (M + gridDim.y - 1) / gridDim.y, mb = blockIdx.y * per, me = min(M, mb + per);
   float t = 0.f;
   if (n < N)
-    for (int m = part; m < M; m += 4) t += X[(int64_t)m * ld + n];
+    for (int m = mb + part; m < me; m += 4) t += X[(int64_t)m * ld + n];
   s[part][threadIdx.x & 63] = t;
   __syncthreads();
-  if (part == 0 && n < N) out[n] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+  if (part == 0 && n < N) {
+    const float v = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+    if (gridDim.y > 1) atomicAdd(&out[n], v);
+    else out[n] = v;
+  }
 }
 
 }  // namespace
@@ -865,7 +871,10 @@ int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32
 int mrgcn_colsum_f32(const float *X, int64_t ld, int32_t M, int32_t N, float *out, void *stream) {
   MRGCN_REQUIRE(X && out && ld >= N, "operands");
   if (N == 0) return MRGCN_OK;
-  k_colsum_f32<<<dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream>>>(X, ld, M, N, out);
+  const unsigned cols = (unsigned)((N + 63) / 64);
+  unsigned slabs = M >= 512 ? std::min<unsigned>((unsigned)(M / 128), std::max(1u, 512u / cols)) : 1u;
+  if (slabs > 1) MRGCN_HIP_TRY(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream));
+  k_colsum_f32<<<dim3(cols, slabs), dim3(256), 0, (hipStream_t)stream>>>(X, ld, M, N, out);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -210,6 +210,10 @@ __global__ void k_rep_fill(const int32_t *__restrict__ m, const int32_t *__restr
     dst[pos[e]] = m[e];
   }
 }
+__global__ void k_iota_i32(int32_t *__restrict__ a, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = (int32_t)i;
+}
 __global__ void k_fill_i32(int32_t *__restrict__ a, int64_t n, int32_t v) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = v;
@@ -771,7 +775,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     if (rc0 != MRGCN_OK) return rc0;
     int64_t nband = kNodeBandNarrow;
     if (const char *e = getenv("MRGCN_NODE_BAND_NARROW")) nband = atoll(e);  // experiments; <= 0: no second order
-    if (nband > 0 && nband < band) {
+    if (nband > 0 && nband < band && !(flags & MRGCN_PLAN_LEAN)) {
       rc0 = build_rel_order(p, sc, s, nband, false, &p->n_rperm, &p->n_relptr, &p->n_relchunk_rel, &p->n_relchunk_beg,
                             &p->n_relchunk_end, &p->n_relchunk_ptr, &p->n_relchunk_ids, &p->n_n_relchunks,
                             &p->n_max_relchunks, &p->n_node_band, &p->n_n_bands);
@@ -783,6 +787,34 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   if ((rc = build_long(p, p->cptr, p->ncols, s, &p->c_long_row, &p->c_long_cptr, &p->c_chunk_beg,
                        &p->c_chunk_end, &p->c_chunk_row, &p->c_n_long, &p->c_n_chunks, &p->max_col_nnz)))
     return rc;
+  if (flags & MRGCN_PLAN_LEAN) {
+    // rows and operand keep their own orders: the COMPACT view is the row-major compact CSR itself
+    p->lean = true;
+    MRGCN_HIP_TRY(plan_alloc(p, &p->rowmap, p->num_rows));
+    MRGCN_HIP_TRY(plan_alloc(p, &p->mpos, ncols));
+    if (p->num_rows > 0) k_iota_i32<<<nblocks(p->num_rows), kTB, 0, s>>>(p->rowmap, p->num_rows);
+    if (ncols > 0) k_iota_i32<<<nblocks(ncols), kTB, 0, s>>>(p->mpos, ncols);
+    p->ptr3 = p->rowptr;
+    p->mcol = p->ccol;
+    p->mval = p->val;
+    p->n_op = ncols;
+    MRGCN_HIP_TRY(plan_alloc(p, &p->rnode, ncols));
+    MRGCN_HIP_TRY(plan_alloc(p, &p->rmpos, ncols));
+    if (ncols > 0) {
+      k_gather_i32<<<nblocks(ncols), kTB, 0, s>>>(p->unode, p->rperm, ncols, p->rnode);
+      k_gather_i32<<<nblocks(ncols), kTB, 0, s>>>(p->mpos, p->rperm, ncols, p->rmpos);
+    }
+    MRGCN_HIP_TRY(hipGetLastError());
+    if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r_long_row, &p->r_long_cptr, &p->r_chunk_beg,
+                         &p->r_chunk_end, &p->r_chunk_row, &p->r_n_long, &p->r_n_chunks, &p->max_row_nnz)))
+      return rc;
+    p->q_long_row = p->r_long_row; p->q_long_cptr = p->r_long_cptr; p->q_chunk_beg = p->r_chunk_beg;
+    p->q_chunk_end = p->r_chunk_end; p->q_chunk_row = p->r_chunk_row;
+    p->q_n_long = p->r_n_long; p->q_n_chunks = p->r_n_chunks;
+    const int64_t ws_l = (int64_t)std::max(p->r_n_chunks, p->c_n_chunks) * kWsFeatures;
+    MRGCN_HIP_TRY(plan_alloc(p, &p->partials, ws_l));
+    return MRGCN_OK;
+  }
   // class-major processing order of the rows (COMPACT view)
   MRGCN_HIP_TRY(plan_alloc(p, &p->rowmap, p->num_rows));
   MRGCN_HIP_TRY(plan_alloc(p, &p->ptr3, p->num_rows + 1));
@@ -1017,6 +1049,10 @@ void free_plan(mrgcn_plan *p) {
       keep.push_back(q);
     } else {
       pool_sync_done(ep);
+      if (q->lean) {  // aliases of rowptr / ccol / val / r_*: one owner each
+        q->ptr3 = nullptr; q->mcol = nullptr; q->mval = nullptr;
+        q->q_long_row = q->q_long_cptr = q->q_chunk_beg = q->q_chunk_end = q->q_chunk_row = nullptr;
+      }
       void *ptrs[] = {q->rowptr, q->lcol, q->ccol, q->rowidx, q->val, q->cptr, q->crow, q->urel, q->unode,
                       q->nptr, q->ulcol, q->mpos, q->mcol, q->mval, q->rperm, q->relptr, q->rnode, q->rmpos, q->relchunk_ptr, q->relchunk_ids, q->relchunk_rel, q->relchunk_beg, q->relchunk_end,
                       q->cval, q->r_long_row, q->r_long_cptr, q->r_chunk_beg, q->r_chunk_end,

@@ -1298,7 +1298,7 @@ extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uin
     w3.pad_ok = pad_ok;
     w3.fold = fold;
     int rc = dispatch_bf16(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu, out_index,
-                           plan->partials, (hipStream_t)stream, (view == MRGCN_VIEW_COMPACT && F <= 16) ? &w3 : nullptr);
+                           plan->partials, (hipStream_t)stream, (view == MRGCN_VIEW_COMPACT && F <= 16 && !plan->lean) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;
@@ -1344,7 +1344,7 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     w3.fold = fold;
     int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu,
                       out_index, plan->partials, use_tiny, operand_cached, s,
-                      (view == MRGCN_VIEW_COMPACT && F <= 16) ? &w3 : nullptr);
+                      (view == MRGCN_VIEW_COMPACT && F <= 16 && !plan->lean) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;

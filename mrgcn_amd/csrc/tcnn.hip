@@ -1,7 +1,8 @@
 // The elementwise half of a TCNN block (reference mrgcn/models/temporal_cnn.py:6-156: Conv1d -> BatchNorm1d -> ReLU
 // [-> MaxPool1d(k, stride k) | AdaptiveMaxPool1d(n)]): batch statistics, normalisation, ReLU and the pooling
-// window in ONE pass over the convolution's output, and the matching backward (pool scatter + ReLU mask + batch-norm
-// backward).  The convolutions themselves are implicit-im2col products on the matrix cores (encoders.hip).
+// window in ONE pass over the convolution's output, and the matching backward (pooled gradient read back through the
+// saved argmax + ReLU mask + batch-norm backward: two passes over x, no intermediate buffer unless the windows of an
+// adaptive pool overlap).  The convolutions themselves are implicit-im2col products on the matrix cores (encoders.hip).
 // x / dx: [B][C][T] float32; y / dy / argmax: [B][C][Tout].  All of it is HBM-bound elementwise / reduction work.
 #include "common.hpp"
 
@@ -112,9 +113,32 @@ __global__ void k_pool_relu_bwd(const float *__restrict__ y, const float *__rest
   else dz[bc * T + t] = dy[o];
 }
 
+// gradient at the block's pre-pool activation z = relu(bn(x)) for position (bc, t), read straight from the pooled
+// gradient: a non-overlapping window (POOL_NONE, POOL_MAX) hands its dy to its argmax where y > 0 — no dz buffer,
+// no zero fill, no scatter.  (Adaptive windows may overlap: they keep the scatter into dz.)
+template <int KIND>
+__device__ __forceinline__ float dz_at(const float *__restrict__ y, const float *__restrict__ dy,
+                                       const int32_t *__restrict__ argmax, const float *__restrict__ dz, int64_t bc,
+                                       int t, int T, int Tout, int arg) {
+  if constexpr (KIND == POOL_ADAPTIVE) {
+    return dz[bc * T + t];
+  } else if constexpr (KIND == POOL_NONE) {
+    const int64_t o = bc * T + t;
+    return y[o] > 0.f ? dy[o] : 0.f;
+  } else {
+    const int to = t / arg;
+    if (to >= Tout) return 0.f;   // positions behind the last whole window
+    const int64_t o = bc * Tout + to;
+    return (y[o] > 0.f && argmax[o] == t) ? dy[o] : 0.f;
+  }
+}
+
 // dbeta = sum dz, dgamma = sum dz * xhat: the same two-stage reduction as the statistics
+template <int KIND>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce_part(const float *__restrict__ x, const float *__restrict__ dz,
-                                                            int B, int C, int T, const float *__restrict__ mean,
+                                                            const float *__restrict__ y, const float *__restrict__ dy,
+                                                            const int32_t *__restrict__ argmax, int B, int C, int T,
+                                                            int Tout, int arg, const float *__restrict__ mean,
                                                             const float *__restrict__ var, float eps,
                                                             double *__restrict__ acc) {
   __shared__ double s[4];
@@ -123,9 +147,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_part(const float *__restr
   const double m = mean[c], istd = 1.0 / sqrt((double)var[c] + (double)eps);
   double a = 0.0, q = 0.0;
   for (int b = blockIdx.y * 4 + wv; b < B; b += gridDim.y * 4) {
-    const int64_t base = ((int64_t)b * C + c) * T;
+    const int64_t bc = (int64_t)b * C + c, base = bc * T;
     for (int t = lane; t < T; t += 64) {
-      const double gg = dz[base + t];
+      const double gg = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg);
       a += gg;
       q += gg * ((double)x[base + t] - m) * istd;
     }
@@ -146,22 +170,41 @@ __global__ void k_bn_bwd_reduce_fin(const double *__restrict__ acc, int C, float
 }
 
 // training: dx = gamma istd (dz - mean(dz) - xhat mean(dz xhat));  eval: dx = gamma istd dz
-__global__ void k_bn_bwd_dx(const float *__restrict__ x, const float *__restrict__ dz, int B, int C, int T,
-                            const float *__restrict__ gamma, const float *__restrict__ mean,
+template <int KIND>
+__global__ void k_bn_bwd_dx(const float *__restrict__ x, const float *__restrict__ dz, const float *__restrict__ y,
+                            const float *__restrict__ dy, const int32_t *__restrict__ argmax, int B, int C, int T,
+                            int Tout, int arg, const float *__restrict__ gamma, const float *__restrict__ mean,
                             const float *__restrict__ var, float eps, const float *__restrict__ dgamma,
                             const float *__restrict__ dbeta, int training, float *__restrict__ dx) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (int64_t)B * C * T) return;
-  const int c = (int)((e / T) % C);
+  const int64_t bc = e / T;
+  const int t = (int)(e - bc * T), c = (int)(bc % C);
   const float istd = 1.f / sqrtf(var[c] + eps);
   const float g = gamma ? gamma[c] : 1.f;
-  float v = dz[e];
+  float v = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg);
   if (training) {
     const float inv_n = 1.f / (float)((int64_t)B * T);
     const float xhat = (x[e] - mean[c]) * istd;
     v = v - dbeta[c] * inv_n - xhat * dgamma[c] * inv_n;
   }
   dx[e] = g * istd * v;
+}
+
+// out[c] += sum over (b, t) of x[b][c][t] (out zeroed by the launcher): the bias gradient of a Conv1d.  Block (c, y)
+// sums its batch slab in fp64, one float atomic per block
+__global__ __launch_bounds__(256) void k_chan_sum_part(const float *__restrict__ x, int B, int C, int T,
+                                                       float *__restrict__ out) {
+  __shared__ double s[4];
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double a = 0.0;
+  for (int b = blockIdx.y * 4 + wv; b < B; b += gridDim.y * 4) {
+    const float *row = x + ((int64_t)b * C + c) * T;
+    for (int t = lane; t < T; t += 64) a += (double)row[t];
+  }
+  a = block_sum(a, s);
+  if (threadIdx.x == 0) atomicAdd(&out[c], (float)a);
 }
 
 inline unsigned nb(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
@@ -212,25 +255,48 @@ int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, 
   return MRGCN_OK;
 }
 
+int mrgcn_channel_sum_f32(const float *x, int32_t B, int32_t C, int32_t T, float *out, void *stream) {
+  MRGCN_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "operands");
+  hipStream_t s = (hipStream_t)stream;
+  MRGCN_HIP_TRY(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s));
+  k_chan_sum_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, out);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
 int mrgcn_bn_relu_pool_bwd_f32(const float *x, const float *y, const float *dy, const int32_t *argmax, int32_t B,
                                int32_t C, int32_t T, const float *gamma, const float *mean, const float *var,
                                float eps, int32_t training, int32_t pool_kind, int32_t pool_arg, float *dz,
                                float *dx, float *dgamma, float *dbeta, void *workspace, void *stream) {
-  MRGCN_REQUIRE(x && y && dy && mean && var && dz && dx && dgamma && dbeta && workspace, "NULL");
+  MRGCN_REQUIRE(x && y && dy && mean && var && dx && dgamma && dbeta && workspace, "NULL");
+  MRGCN_REQUIRE(dz || pool_kind != POOL_ADAPTIVE, "adaptive pooling needs the dz workspace");
   MRGCN_REQUIRE(B > 0 && C > 0 && T > 0, "B / C / T");
   MRGCN_REQUIRE(pool_kind >= 0 && pool_kind <= 2 && (pool_kind == POOL_NONE || (pool_arg > 0 && argmax)), "pool");
   const int Tout = pool_out_len(pool_kind, pool_arg, T);
   MRGCN_REQUIRE(Tout > 0, "the pooling window is longer than the sequence");
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_in = (int64_t)B * C * T, n_out = (int64_t)B * C * Tout;
-  MRGCN_HIP_TRY(hipMemsetAsync(dz, 0, (size_t)n_in * sizeof(float), s));
-  k_pool_relu_bwd<<<dim3(nb(n_out)), dim3(256), 0, s>>>(y, dy, argmax, n_out, T, Tout, pool_kind, dz);
   double *acc = (double *)workspace;
   MRGCN_HIP_TRY(hipMemsetAsync(acc, 0, mrgcn_bn_workspace_bytes(C), s));
-  k_bn_bwd_reduce_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, dz, B, C, T, mean, var, eps, acc);
-  k_bn_bwd_reduce_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, dgamma, dbeta);
-  k_bn_bwd_dx<<<dim3(nb(n_in)), dim3(256), 0, s>>>(x, dz, B, C, T, gamma, mean, var, eps, dgamma, dbeta, training,
-                                                  dx);
+  const dim3 rgrid(C, bn_slabs(B, C));
+#define BN_BWD_GO(KIND_)                                                                                             \
+  do {                                                                                                               \
+    k_bn_bwd_reduce_part<KIND_><<<rgrid, dim3(256), 0, s>>>(x, dz, y, dy, argmax, B, C, T, Tout, pool_arg, mean,    \
+                                                            var, eps, acc);                                          \
+    k_bn_bwd_reduce_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, dgamma, dbeta);                          \
+    k_bn_bwd_dx<KIND_><<<dim3(nb(n_in)), dim3(256), 0, s>>>(x, dz, y, dy, argmax, B, C, T, Tout, pool_arg, gamma,    \
+                                                            mean, var, eps, dgamma, dbeta, training, dx);            \
+  } while (0)
+  if (pool_kind == POOL_ADAPTIVE) {  // windows may overlap: scatter into dz first
+    MRGCN_HIP_TRY(hipMemsetAsync(dz, 0, (size_t)n_in * sizeof(float), s));
+    k_pool_relu_bwd<<<dim3(nb(n_out)), dim3(256), 0, s>>>(y, dy, argmax, n_out, T, Tout, pool_kind, dz);
+    BN_BWD_GO(POOL_ADAPTIVE);
+  } else if (pool_kind == POOL_MAX) {
+    BN_BWD_GO(POOL_MAX);
+  } else {
+    BN_BWD_GO(POOL_NONE);
+  }
+#undef BN_BWD_GO
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -335,9 +335,13 @@ class A_BatchDevice(A_Batch):
     comes out of the same kernel pass and is attached to `row[i]`, so the layers never run the searchsorted
     slicer."""
 
-    def __init__(self, A_dev: DeviceCSR, batch_idx, num_layers, value_mode="ref_int8"):
+    def __init__(self, A_dev: DeviceCSR, batch_idx, num_layers, value_mode="ref_int8", short_lived=False):
+        """`short_lived`: the batch is used for one step and dropped (batches re-sampled every step): its slices ask for
+        the quick plan build (plan.GraphPlan(lean=True)) instead of the layout passes that pay off over many epochs
+        on the same batch (the reference's flow: `mkbatches` once, then every epoch over the same batches)."""
         assert value_mode in VALUE_MODES
         self.value_mode = value_mode
+        self.short_lived = bool(short_lived)
         self.neighbours, self.row = [], []
         self._a_idx = {}
         dev = A_dev.indptr.device
@@ -354,6 +358,8 @@ class A_BatchDevice(A_Batch):
                                              torch.ones(col_sl.numel(), dtype=torch.float32, device=dev),
                                              (sample.numel(), R * nb.numel()))
             self._a_idx[i] = a_idx
+            if self.short_lived:
+                a._mrgcn_lean = sliced._mrgcn_lean = True
             a._mrgcn_slice = (a_idx, sliced)   # what GraphConvolution._forward_mini_batch looks up
             self.row.append(a)
             self.neighbours.append(nb)

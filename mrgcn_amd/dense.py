@@ -120,7 +120,10 @@ class _Conv1d(torch.autograd.Function):
             _gemm(3, 2, 0, Cin * KW, Cout, Bn * Tout, x, 0, dy, 0, dWt, Cout, geom=ctx.geom)
             dW = dWt.t().reshape(Cout, Cin, KW).contiguous()
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = dy.sum(dim=(0, 2))
+            db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+            with torch.cuda.device(dy.device):
+                L.check(L.load().mrgcn_channel_sum_f32(dy.data_ptr(), Bn, Cout, Tout, db.data_ptr(), _stream(dy.device)),
+                        "mrgcn_channel_sum_f32")
         return dx, dW, db, None
 
 
@@ -165,7 +168,7 @@ class _BnReluPool(torch.autograd.Function):
         eps, training, kind, arg = ctx.meta
         Bn, Cn, T = x.shape
         dy = dy.contiguous()
-        dz = torch.empty_like(x)
+        dz = torch.empty_like(x) if kind == POOL_ADAPTIVE else None   # scatter target of overlapping windows only
         dx = torch.empty_like(x)
         dgamma = torch.empty(Cn, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(Cn, dtype=torch.float32, device=x.device)
@@ -175,7 +178,7 @@ class _BnReluPool(torch.autograd.Function):
             L.check(lib.mrgcn_bn_relu_pool_bwd_f32(
                 x.data_ptr(), y.data_ptr(), dy.data_ptr(), am.data_ptr() if am is not None else 0, Bn, Cn, T,
                 gamma.data_ptr() if gamma is not None else 0, mean.data_ptr(), var.data_ptr(), eps, int(training),
-                kind, arg, dz.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                kind, arg, dz.data_ptr() if dz is not None else 0, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
                 _stream(x.device)), "mrgcn_bn_relu_pool_bwd_f32")
         return dx, (dgamma if gamma is not None else None), (dbeta if gamma is not None else None), None, None, \
             None, None, None, None

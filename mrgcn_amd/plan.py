@@ -16,9 +16,9 @@ def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _flags(prune_zeros, replicate) -> int:
+def _flags(prune_zeros, replicate, lean=False) -> int:
     """replicate: None = the library's default (env MRGCN_REPLICATE), True / False = force."""
-    f = L.PLAN_PRUNE_ZEROS if prune_zeros else 0
+    f = (L.PLAN_PRUNE_ZEROS if prune_zeros else 0) | (L.PLAN_LEAN if lean else 0)
     if replicate is True:
         f |= L.PLAN_REPLICATE
     elif replicate is False:
@@ -36,9 +36,11 @@ def _row_bytes_arg(operand_row_bytes):
 
 class GraphPlan:
     def __init__(self, A: torch.Tensor, num_nodes: int, num_relations: int,
-                 prune_zeros: bool = False, replicate=None, operand_row_bytes=None):
+                 prune_zeros: bool = False, replicate=None, operand_row_bytes=None, lean: bool = False):
         """`operand_row_bytes`: row sizes (bytes) of the compact operands the plan's products will read
-        (mrgcn_plan_create_hinted): a layout hint for the operand order, never for results."""
+        (mrgcn_plan_create_hinted): a layout hint for the operand order, never for results.
+        `lean` (MRGCN_PLAN_LEAN): the quick build for a small, short-lived adjacency — the slices of a re-sampled
+        mini-batch — without the layout passes that pay off on a graph that is multiplied many times."""
         if not A.is_sparse:
             raise TypeError("A must be a torch sparse COO tensor")
         if not A.is_cuda:
@@ -69,8 +71,9 @@ class GraphPlan:
             L.check(lib.mrgcn_plan_create_hinted(
                 C.byref(handle), self.num_rows, self.num_nodes, self.num_relations,
                 int(val.numel()), rows.data_ptr(), cols.data_ptr(), val.data_ptr(), vd,
-                _flags(prune_zeros, replicate), C.cast(rb, C.c_void_p) if nrb else None, nrb,
+                _flags(prune_zeros, replicate, lean), C.cast(rb, C.c_void_p) if nrb else None, nrb,
                 _stream_ptr(self.device)), "mrgcn_plan_create_hinted")
+        self.lean = bool(lean)
         self.operand_row_bytes = tuple(rb) if nrb else ()
         self._adopt(handle)
 
@@ -222,13 +225,15 @@ class GraphPlan:
                 + self.ncols * F * elem_bytes + self.num_rows * F * elem_bytes)
 
 
-def plan_of(A: torch.Tensor, num_nodes: int, num_relations: int, operand_row_bytes=None) -> GraphPlan:
+def plan_of(A: torch.Tensor, num_nodes: int, num_relations: int, operand_row_bytes=None, lean: bool = False) -> GraphPlan:
     """Returns the plan cached on the adjacency tensor, building it on first use.  `operand_row_bytes` (the row
-    sizes of the compact operands its users will multiply with: a layout hint, see GraphPlan) only matters to the
-    call that builds the plan."""
+    sizes of the compact operands its users will multiply with: a layout hint, see GraphPlan) and `lean` (the quick
+    build of a mini-batch slice) only matter to the call that builds the plan."""
     p = getattr(A, "_mrgcn_plan", None)
     if p is None or p._h is None or p.num_nodes != num_nodes or p.num_relations != num_relations:
-        p = GraphPlan(A, num_nodes, num_relations, operand_row_bytes=operand_row_bytes)
+        # (a slice of a short-lived batch carries the request itself: data/batch.py A_BatchDevice(short_lived=True))
+        lean = lean or bool(getattr(A, "_mrgcn_lean", False))
+        p = GraphPlan(A, num_nodes, num_relations, operand_row_bytes=operand_row_bytes, lean=lean)
         A._mrgcn_plan = p
     return p
 
@@ -238,7 +243,7 @@ _BUILD_STREAMS: dict = {}
 
 def build_plans_parallel(jobs) -> None:
     """Builds the plans of several adjacency tensors at once: `jobs` = [(A, num_nodes, num_relations,
-    operand_row_bytes), ...]; those that carry a plan already are skipped.  A plan build is a chain of short device
+    operand_row_bytes[, lean]), ...]; those that carry a plan already are skipped.  A plan build is a chain of short device
     passes with host read-backs of sizes in between (a few ms of mostly waiting for a small slice); the builds of a
     re-sampled mini-batch's slices (two per layer) are independent, so each runs in its own host thread on its own
     stream — the waits overlap — and the caller's stream waits for all of them.  The C ABI is thread-safe per plan

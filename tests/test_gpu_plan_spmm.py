@@ -13,12 +13,12 @@ ARRAYS = ["rowptr", "lcol", "ccol", "val", "cptr", "crow", "cval", "urel", "unod
           "rowidx", "ulcol", "rperm", "relptr", "mpos", "mcol", "mval", "rowmap", "ptr3"]
 
 
-def _plan_from_coo(rows, cols, vals, num_rows, N, R, prune=False, row_bytes=None):
+def _plan_from_coo(rows, cols, vals, num_rows, N, R, prune=False, row_bytes=None, lean=False):
     from mrgcn_amd.plan import GraphPlan
     idx = torch.from_numpy(np.stack([rows, cols]).astype(np.int64))
     v = torch.from_numpy(np.asarray(vals))
     A = torch.sparse_coo_tensor(idx, v, (num_rows, R * N)).cuda()
-    return GraphPlan(A, N, R, prune_zeros=prune, operand_row_bytes=row_bytes)
+    return GraphPlan(A, N, R, prune_zeros=prune, operand_row_bytes=row_bytes, lean=lean)
 
 
 def _check_plan(plan, ref):
@@ -141,6 +141,40 @@ def test_spmm_literal_compact_transposed(skewed, F):
     ptr, _ = plan.array_ptr(L.ARR_ULCOL)
     plan.spmm(L.VIEW_TRANSPOSED, torch.from_numpy(dY).cuda(), out=dD, out_index=ptr)
     np.testing.assert_allclose(dD.cpu().numpy(), A.T @ dY.astype(np.float64), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("F", [1, 10, 16, 33])
+def test_lean_plan_products(F):
+    """MRGCN_PLAN_LEAN (the quick build for mini-batch slices): identity row / operand orders, the three views
+    multiply like the full plan's (hub rows and hub columns included), the structure arrays equal the numpy plan's."""
+    from mrgcn_amd import _lib as L
+    rng = np.random.default_rng(5)
+    N, R, num_rows = 1500, 4, 700
+    rows, cols, vals = _random_graph(rng, num_rows, N, R, 20000, hub_rows=2, hub_len=1300, hub_cols=2)
+    plan = _plan_from_coo(rows, cols, vals, num_rows, N, R, lean=True)
+    ref = util.numpy_plan(rows, cols, vals, num_rows, N, R)
+    assert plan.lean and plan.nop == plan.ncols == ref["ncols"] and plan.n_rep == 0
+    for name in ("rowptr", "lcol", "ccol", "cptr", "crow", "ulcol", "urel", "unode"):
+        np.testing.assert_array_equal(plan.export(getattr(L, "ARR_" + name.upper())), ref[name], err_msg=name)
+    np.testing.assert_array_equal(plan.export(L.ARR_MPOS), np.arange(plan.ncols))
+    A = sp.csr_matrix((vals.astype(np.float64), (rows, cols)), shape=(num_rows, R * N))
+    D = rng.standard_normal((R * N, F)).astype(np.float32)
+    Y_ref = A @ D.astype(np.float64)
+    np.testing.assert_allclose(plan.spmm(L.VIEW_LITERAL, torch.from_numpy(D).cuda()).cpu().numpy(), Y_ref, rtol=1e-4,
+                               atol=1e-4)
+    for ld in sorted({F, (F + 3) // 4 * 4}):
+        M = np.full((plan.ncols, ld), 1e30, dtype=np.float32)
+        M[:, :F] = D[ref["ulcol"]]   # operand row c = compact column c
+        b = rng.standard_normal(F).astype(np.float32)
+        Yc = plan.spmm(L.VIEW_COMPACT, torch.from_numpy(M).cuda(), F=F, bias=torch.from_numpy(b).cuda(), relu=True)
+        np.testing.assert_allclose(Yc.cpu().numpy(), np.maximum(Y_ref + b, 0), rtol=1e-4, atol=1e-4)
+        Yp = plan.spmm(L.VIEW_COMPACT, torch.from_numpy(M).cuda(), F=F, padded_rows=True)
+        np.testing.assert_allclose(Yp.cpu().numpy(), Y_ref, rtol=1e-4, atol=1e-4)
+    dY = rng.standard_normal((num_rows, F)).astype(np.float32)
+    dM = plan.spmm(L.VIEW_TRANSPOSED, torch.from_numpy(dY).cuda()).cpu().numpy()
+    np.testing.assert_allclose(dM, (A.T @ dY.astype(np.float64))[ref["ulcol"]], rtol=1e-4, atol=1e-4)
+    del plan   # (aliased arrays are released once)
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("F", [3, 10, 11, 13])

@@ -161,6 +161,43 @@ def test_device_built_batch_equals_host_built(tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["ft_b3", "ft_b0_l3", "fl_b0"])
+def test_short_lived_batch_on_lean_plans_equals_the_goldens(tag):
+    """A batch built for one step (A_BatchDevice(short_lived=True): its slices take the quick plan build,
+    MRGCN_PLAN_LEAN) gives the reference's logits, loss and gradients like a batch on full plans."""
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import categorical_crossentropy
+    g = np.load(GOLD)
+    _, A = util.load_graph("graph_small")
+    fl, B, bias, nl, hidden, classes, xw = [int(v) for v in g[tag + ".meta"]]
+    N = A.shape[0]
+    R = A.shape[1] // N
+    dims = [(xw if li == 0 else hidden, hidden if li < nl - 1 else classes) for li in range(nl)]
+    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li < nl - 1 else None) for li, (i, o) in enumerate(dims)]
+    model = RGCN(modules, R, N, B, 0.0, bool(fl), bool(bias), False)
+    model.load_state_dict({k[len(tag) + 6:]: torch.from_numpy(np.array(g[k])) for k in g.files
+                           if k.startswith(tag + ".init.")})
+    model = model.cuda()
+    dcsr = mb.DeviceCSR(A)
+    for _ in range(2):  # a fresh batch object (fresh plans) each time
+        ab = mb.A_BatchDevice(dcsr, g["batch_idx"], nl, short_lived=True)
+        X = None if fl else torch.from_numpy(g[tag + ".X_full"]).cuda()[ab.neighbours[-1]]
+        model.zero_grad()
+        logits = model(X, ab)
+        plans = [t._mrgcn_plan for a in ab.row for t in (a, a._mrgcn_slice[1]) if getattr(t, "_mrgcn_plan", None)]
+        assert plans and all(p.lean for p in plans)
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), g[tag + ".logits"], rtol=1e-4, atol=1e-4)
+        idx = torch.arange(len(g["batch_idx"]), device="cuda")
+        loss = categorical_crossentropy(logits, idx, torch.from_numpy(g[tag + ".y"]).cuda())
+        assert abs(float(loss.detach()) - float(g[tag + ".loss"])) < 1e-5
+        loss.backward()
+        for n, p in model.named_parameters():
+            np.testing.assert_allclose(util.ref_layout(p.grad, n).cpu().numpy(), g[f"{tag}.grad.{n}"], rtol=1e-3, atol=1e-5,
+                                       err_msg=n)
+
+
+@pytest.mark.gpu
 def test_frontier_kernels_edge_cases_through_the_c_abi():
     """mrgcn_frontier_count / _emit against the host functions on a graph with isolated rows, a hub row longer
     than several waves, duplicated sample rows and an empty sample; float32 and int8 (truncating) values."""

@@ -51,7 +51,7 @@ def minibatch():
         y = torch.from_numpy(rng.integers(0, dims[-1][1], 1024)).cuda()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ab = mb.A_BatchDevice(dcsr, idx, 2)
+        ab = mb.A_BatchDevice(dcsr, idx, 2, short_lived=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         logits = model(X[ab.neighbours[-1]], ab)           # builds the slice plans on first use
