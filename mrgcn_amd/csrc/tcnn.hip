@@ -119,17 +119,22 @@ __global__ void k_pool_relu_bwd(const float *__restrict__ y, const float *__rest
 template <int KIND>
 __device__ __forceinline__ float dz_at(const float *__restrict__ y, const float *__restrict__ dy,
                                        const int32_t *__restrict__ argmax, const float *__restrict__ dz, int64_t bc,
-                                       int t, int T, int Tout, int arg) {
+                                       int t, int T, int Tout, uint32_t arg_magic) {
   if constexpr (KIND == POOL_ADAPTIVE) {
     return dz[bc * T + t];
   } else if constexpr (KIND == POOL_NONE) {
     const int64_t o = bc * T + t;
-    return y[o] > 0.f ? dy[o] : 0.f;
+    const float yy = y[o], dd = dy[o];   // both loads issue together (a branch on y would chain them)
+    return yy > 0.f ? dd : 0.f;
   } else {
-    const int to = t / arg;
-    if (to >= Tout) return 0.f;   // positions behind the last whole window
+    // window of t: t / arg as a multiply-high (exact while t * arg < 2^32; 0 stands for arg == 1)
+    int to = arg_magic ? (int)__umulhi((uint32_t)t, arg_magic) : t;
+    const bool in = to < Tout;            // positions behind the last whole window have none
+    to = in ? to : 0;
     const int64_t o = bc * Tout + to;
-    return (y[o] > 0.f && argmax[o] == t) ? dy[o] : 0.f;
+    const float yy = y[o], dd = dy[o];
+    const int am = argmax[o];
+    return (in && yy > 0.f && am == t) ? dd : 0.f;
   }
 }
 
@@ -138,7 +143,8 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce_part(const float *__restrict__ x, const float *__restrict__ dz,
                                                             const float *__restrict__ y, const float *__restrict__ dy,
                                                             const int32_t *__restrict__ argmax, int B, int C, int T,
-                                                            int Tout, int arg, const float *__restrict__ mean,
+                                                            int Tout, uint32_t arg_magic, int tp_log2,
+                                                            const float *__restrict__ mean,
                                                             const float *__restrict__ var, float eps,
                                                             double *__restrict__ acc) {
   __shared__ double s[4];
@@ -146,10 +152,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_part(const float *__restr
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const double m = mean[c], istd = 1.0 / sqrt((double)var[c] + (double)eps);
   double a = 0.0, q = 0.0;
-  for (int b = blockIdx.y * 4 + wv; b < B; b += gridDim.y * 4) {
+  // a wave takes 64 / tp batch rows at a time (tp = the power of two >= min(T, 64)): short sequences fill the lanes
+  const int rpw = 64 >> tp_log2, sub = lane >> tp_log2, t0 = lane & ((1 << tp_log2) - 1);
+  for (int b = (blockIdx.y * 4 + wv) * rpw + sub; b < B; b += gridDim.y * 4 * rpw) {
     const int64_t bc = (int64_t)b * C + c, base = bc * T;
-    for (int t = lane; t < T; t += 64) {
-      const double gg = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg);
+    for (int t = t0; t < T; t += 1 << tp_log2) {
+      const double gg = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg_magic);
       a += gg;
       q += gg * ((double)x[base + t] - m) * istd;
     }
@@ -169,26 +177,32 @@ __global__ void k_bn_bwd_reduce_fin(const double *__restrict__ acc, int C, float
   dgamma[c] = (float)acc[2 * c + 1];
 }
 
-// training: dx = gamma istd (dz - mean(dz) - xhat mean(dz xhat));  eval: dx = gamma istd dz
+// training: dx = gamma istd (dz - mean(dz) - xhat mean(dz xhat));  eval: dx = gamma istd dz.  A wave per (b, c) row,
+// lanes along t (no per-element index divisions)
 template <int KIND>
-__global__ void k_bn_bwd_dx(const float *__restrict__ x, const float *__restrict__ dz, const float *__restrict__ y,
-                            const float *__restrict__ dy, const int32_t *__restrict__ argmax, int B, int C, int T,
-                            int Tout, int arg, const float *__restrict__ gamma, const float *__restrict__ mean,
-                            const float *__restrict__ var, float eps, const float *__restrict__ dgamma,
-                            const float *__restrict__ dbeta, int training, float *__restrict__ dx) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (int64_t)B * C * T) return;
-  const int64_t bc = e / T;
-  const int t = (int)(e - bc * T), c = (int)(bc % C);
+__global__ __launch_bounds__(256) void k_bn_bwd_dx(const float *__restrict__ x, const float *__restrict__ dz,
+                                                   const float *__restrict__ y, const float *__restrict__ dy,
+                                                   const int32_t *__restrict__ argmax, int B, int C, int T, int Tout,
+                                                   uint32_t arg_magic, int tp_log2, const float *__restrict__ gamma,
+                                                   const float *__restrict__ mean, const float *__restrict__ var,
+                                                   float eps, const float *__restrict__ dgamma,
+                                                   const float *__restrict__ dbeta, int training,
+                                                   float *__restrict__ dx) {
+  // a wave takes 64 / tp rows (tp = the power of two >= min(T, 64))
+  const int lane = threadIdx.x & 63, rpw = 64 >> tp_log2;
+  const int64_t bc = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> tp_log2);
+  if (bc >= (int64_t)B * C) return;
+  const int c = (int)(bc % C);
   const float istd = 1.f / sqrtf(var[c] + eps);
-  const float g = gamma ? gamma[c] : 1.f;
-  float v = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg);
-  if (training) {
-    const float inv_n = 1.f / (float)((int64_t)B * T);
-    const float xhat = (x[e] - mean[c]) * istd;
-    v = v - dbeta[c] * inv_n - xhat * dgamma[c] * inv_n;
+  const float g = (gamma ? gamma[c] : 1.f) * istd;
+  const float inv_n = 1.f / (float)((int64_t)B * T);
+  const float mu = mean[c], k_b = training ? dbeta[c] * inv_n : 0.f, k_g = training ? dgamma[c] * inv_n : 0.f;
+  const int64_t base = bc * T;
+  for (int t = lane & ((1 << tp_log2) - 1); t < T; t += 1 << tp_log2) {
+    float v = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg_magic);
+    if (training) v = v - k_b - (x[base + t] - mu) * istd * k_g;
+    dx[base + t] = g * v;
   }
-  dx[e] = g * istd * v;
 }
 
 // out[c] += sum over (b, t) of x[b][c][t] (out zeroed by the launcher): the bias gradient of a Conv1d.  Block (c, y)
@@ -279,13 +293,19 @@ int mrgcn_bn_relu_pool_bwd_f32(const float *x, const float *y, const float *dy, 
   double *acc = (double *)workspace;
   MRGCN_HIP_TRY(hipMemsetAsync(acc, 0, mrgcn_bn_workspace_bytes(C), s));
   const dim3 rgrid(C, bn_slabs(B, C));
+  const uint32_t arg_magic = (pool_kind == POOL_MAX && pool_arg > 1) ? (uint32_t)((((uint64_t)1) << 32) / (uint64_t)pool_arg + 1) : 0u;
+  MRGCN_REQUIRE(pool_kind != POOL_MAX || (int64_t)T * pool_arg < ((int64_t)1 << 32), "sequence too long");
+  int tp_log2 = 0;
+  while (tp_log2 < 6 && (1 << tp_log2) < T) ++tp_log2;
+  const int rpw = 64 >> tp_log2;
+  const dim3 xgrid((unsigned)(((int64_t)B * C + 4 * rpw - 1) / (4 * rpw)));
 #define BN_BWD_GO(KIND_)                                                                                             \
   do {                                                                                                               \
-    k_bn_bwd_reduce_part<KIND_><<<rgrid, dim3(256), 0, s>>>(x, dz, y, dy, argmax, B, C, T, Tout, pool_arg, mean,    \
-                                                            var, eps, acc);                                          \
+    k_bn_bwd_reduce_part<KIND_><<<rgrid, dim3(256), 0, s>>>(x, dz, y, dy, argmax, B, C, T, Tout, arg_magic,         \
+                                                            tp_log2, mean, var, eps, acc);                                          \
     k_bn_bwd_reduce_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, dgamma, dbeta);                          \
-    k_bn_bwd_dx<KIND_><<<dim3(nb(n_in)), dim3(256), 0, s>>>(x, dz, y, dy, argmax, B, C, T, Tout, pool_arg, gamma,    \
-                                                            mean, var, eps, dgamma, dbeta, training, dx);            \
+    k_bn_bwd_dx<KIND_><<<xgrid, dim3(256), 0, s>>>(x, dz, y, dy, argmax, B, C, T, Tout, arg_magic, tp_log2, gamma,   \
+                                                   mean, var, eps, dgamma, dbeta, training, dx);                                \
   } while (0)
   if (pool_kind == POOL_ADAPTIVE) {  // windows may overlap: scatter into dz first
     MRGCN_HIP_TRY(hipMemsetAsync(dz, 0, (size_t)n_in * sizeof(float), s));
