@@ -239,6 +239,7 @@ def plan_of(A: torch.Tensor, num_nodes: int, num_relations: int, operand_row_byt
 
 
 _BUILD_STREAMS: dict = {}
+_PLAN_THREADS = __import__("os").environ.get("MRGCN_PLAN_THREADS", "1") != "0"   # 0: one after the other on the caller's stream
 
 
 def build_plans_parallel(jobs) -> None:
@@ -250,7 +251,7 @@ def build_plans_parallel(jobs) -> None:
     handle; ctypes releases the GIL for the duration of a call."""
     import threading
     todo = [j for j in jobs if getattr(j[0], "_mrgcn_plan", None) is None or j[0]._mrgcn_plan._h is None]
-    if len(todo) <= 1:
+    if len(todo) <= 1 or not _PLAN_THREADS:
         for j in todo:
             plan_of(*j)
         return

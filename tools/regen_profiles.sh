@@ -2,7 +2,8 @@
 # Regenerates every measurement artefact under profiles/ from the tree it runs in (on a GPU box):
 #   tools/regen_profiles.sh <round-tag, e.g. r02>      -> gpurun_out/<tag>/...   (copy into profiles/ afterwards)
 # Passes: (1) SpMM PMC -> spmm_pmc_latest.json, (2) bench line, (3) rocprofv3 --kernel-trace --stats of the same command,
-# (4) epoch PMC (memory + SQ sets) for the weight_I streamers and the transforms, (5) seeds 0,1,2.
+# (4) epoch PMC (memory + SQ sets) for the weight_I streamers and the transforms, (5) seeds 0,1,2, fb15k, ref_int8,
+# (6) the encoders' product probe + MFMA counters, (7) the next-rows probe (mini-batch, encoders, ingestion).
 tag=${1:-rXX}
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
@@ -27,4 +28,11 @@ rm -rf $o/pmc_epoch_*/
 python3 tools/seed_median.py > $o/seeds.json 2> $o/seeds.err
 python3 bench.py --workload fb15k > $o/bench_fb15k.json 2> $o/bench_fb15k.err
 python3 bench.py --value-mode ref_int8 --no-cpu-baseline > $o/bench_ref_int8.json 2> $o/bench_ref_int8.err
+# (6) the encoders' tiled product over the TCNN-M shapes: per-product rates, MFMA counters; (7) the next-rows probe
+python3 tools/gemm_probe.py > $o/gemm_probe.txt 2> $o/gemm_probe.err
+python3 tools/gemm_probe.py --json > $o/gemm_probe.json 2>> $o/gemm_probe.err
+bash tools/pmc_passes.sh $o/pmc_mm mfma -- python3 tools/gemm_probe.py --iters 3
+python3 tools/pmc_summary.py $o k_mm_tile > $o/mfma_mm.md
+rm -rf $o/pmc_mm_*/
+python3 tools/next_rows_probe.py > $o/next_rows.json 2> $o/next_rows.err
 ls -la $o
