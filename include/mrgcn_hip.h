@@ -146,6 +146,11 @@ int mrgcn_plan_create_csr_hinted(mrgcn_plan_t **plan, int64_t num_rows, int64_t 
                                  uint32_t flags, const int32_t *operand_row_bytes, int32_t n_row_bytes,
                                  void *stream);
 int mrgcn_plan_destroy(mrgcn_plan_t *plan);
+/* mrgcn_plan_destroy waits for ALL work in flight on the plan's device.  _destroy_after waits only for `event` (a
+ * hipEvent_t the caller recorded behind the last work that uses the plan, on whichever stream; NULL: nothing used it)
+ * and for the plan's own build: other streams keep running — for callers that drop the plans of finished mini-batch
+ * steps while the next batch is being built (mrgcn_amd.data.batch.BatchPrefetcher). */
+int mrgcn_plan_destroy_after(mrgcn_plan_t *plan, void *event);
 int mrgcn_plan_info(const mrgcn_plan_t *plan, mrgcn_plan_info_t *h_info);
 /* copies one plan array to HOST memory (tests: index parity is bit-exact) */
 int mrgcn_plan_export(const mrgcn_plan_t *plan, int32_t which, void *h_dst, int64_t capacity_bytes);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mrgcn_plan_create_csr_hinted": (C.c_int, [C.POINTER(_p), _i64, _i64, _i32, _i64, _p, _p, _p, _i32, _u32, _p, _i32,
                                                _p]),
     "mrgcn_plan_destroy": (C.c_int, [_p]),
+    "mrgcn_plan_destroy_after": (C.c_int, [_p, _p]),
     "mrgcn_plan_info": (C.c_int, [_p, C.POINTER(PlanInfo)]),
     "mrgcn_plan_export": (C.c_int, [_p, _i32, _p, _i64]),
     "mrgcn_plan_array": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_i64)]),

@@ -407,6 +407,7 @@ hipError_t pool_alloc(void **p, size_t bytes, hipStream_t s) {
 // stream ordered free: the block may be reused by later work on `s`, or by anyone once a device-wide wait that began
 // after this call has completed (`covered_epoch` != 0: such a wait — pool_sync_begin's return value — has completed
 // already)
+constexpr uint64_t kSafeNow = ~0ull;
 void pool_free(void *p, hipStream_t s, uint64_t covered_epoch = 0) {
   if (!p) return;
   int dev = 0;
@@ -420,7 +421,8 @@ void pool_free(void *p, hipStream_t s, uint64_t covered_epoch = 0) {
       bytes = it->second;
       c.live.erase(it);
       if (c.parked_bytes + bytes <= c.keep) {
-        c.free_blocks.emplace(bytes, ParkedBlock{p, bytes, s, covered_epoch ? covered_epoch : c.epoch});
+        // (kSafeNow: every user has finished already — epoch 0 is below any safe_epoch)
+        c.free_blocks.emplace(bytes, ParkedBlock{p, bytes, s, covered_epoch == kSafeNow ? 0 : covered_epoch ? covered_epoch : c.epoch});
         c.parked_bytes += bytes;
         return;
       }
@@ -1028,6 +1030,29 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   return MRGCN_OK;
 }
 
+// hands every array of the plan back to its device's pool (`ep`: a wait that covers all users of the plan has completed:
+// pool_free's covered_epoch) and deletes the descriptor
+void release_plan(mrgcn_plan *q, uint64_t ep) {
+  if (q->lean) {  // aliases of rowptr / ccol / val / r_*: one owner each
+    q->ptr3 = nullptr; q->mcol = nullptr; q->mval = nullptr;
+    q->q_long_row = q->q_long_cptr = q->q_chunk_beg = q->q_chunk_end = q->q_chunk_row = nullptr;
+  }
+  void *ptrs[] = {q->rowptr, q->lcol, q->ccol, q->rowidx, q->val, q->cptr, q->crow, q->urel, q->unode,
+                  q->nptr, q->ulcol, q->mpos, q->mcol, q->mval, q->rperm, q->relptr, q->rnode, q->rmpos, q->relchunk_ptr, q->relchunk_ids, q->relchunk_rel, q->relchunk_beg, q->relchunk_end,
+                  q->cval, q->r_long_row, q->r_long_cptr, q->r_chunk_beg, q->r_chunk_end,
+                  q->c_long_row, q->c_long_cptr, q->c_chunk_beg, q->c_chunk_end, q->r_chunk_row, q->c_chunk_row,
+                  q->r3_long_row, q->r3_long_cptr, q->r3_chunk_beg, q->r3_chunk_end, q->r3_chunk_row,
+                  q->q_long_row, q->q_long_cptr, q->q_chunk_beg, q->q_chunk_end, q->q_chunk_row, q->rowmap, q->ptr3,
+                  q->rep_src, q->rep_dst, q->partials, q->r3_multi, q->r3_ticket,
+                  q->r3s_long_row, q->r3s_long_cptr, q->r3s_chunk_beg, q->r3s_chunk_end, q->r3s_chunk_row,
+                  q->n_rperm, q->n_relptr, q->n_rnode, q->n_rmpos, q->n_relchunk_rel, q->n_relchunk_beg,
+                  q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids};
+  // (after the wait any stream may take the blocks; the plan's own build stream is where the next build of a
+  // similar slice will ask for them again: the pool hands them back without a driver call)
+  for (void *a : ptrs) pool_free(a, q->build_stream, ep);
+  delete q;
+}
+
 void free_plan(mrgcn_plan *p) {
   // the caller guarantees nothing that uses the plan is still to be SUBMITTED; work already in flight on any stream of
   // the plan's device is waited for (what hipFree did implicitly), then the blocks go back to that device's pool.
@@ -1049,28 +1074,33 @@ void free_plan(mrgcn_plan *p) {
       keep.push_back(q);
     } else {
       pool_sync_done(ep);
-      if (q->lean) {  // aliases of rowptr / ccol / val / r_*: one owner each
-        q->ptr3 = nullptr; q->mcol = nullptr; q->mval = nullptr;
-        q->q_long_row = q->q_long_cptr = q->q_chunk_beg = q->q_chunk_end = q->q_chunk_row = nullptr;
-      }
-      void *ptrs[] = {q->rowptr, q->lcol, q->ccol, q->rowidx, q->val, q->cptr, q->crow, q->urel, q->unode,
-                      q->nptr, q->ulcol, q->mpos, q->mcol, q->mval, q->rperm, q->relptr, q->rnode, q->rmpos, q->relchunk_ptr, q->relchunk_ids, q->relchunk_rel, q->relchunk_beg, q->relchunk_end,
-                      q->cval, q->r_long_row, q->r_long_cptr, q->r_chunk_beg, q->r_chunk_end,
-                      q->c_long_row, q->c_long_cptr, q->c_chunk_beg, q->c_chunk_end, q->r_chunk_row, q->c_chunk_row,
-                      q->r3_long_row, q->r3_long_cptr, q->r3_chunk_beg, q->r3_chunk_end, q->r3_chunk_row,
-                      q->q_long_row, q->q_long_cptr, q->q_chunk_beg, q->q_chunk_end, q->q_chunk_row, q->rowmap, q->ptr3,
-                      q->rep_src, q->rep_dst, q->partials, q->r3_multi, q->r3_ticket,
-                      q->r3s_long_row, q->r3s_long_cptr, q->r3s_chunk_beg, q->r3s_chunk_end, q->r3s_chunk_row,
-                      q->n_rperm, q->n_relptr, q->n_rnode, q->n_rmpos, q->n_relchunk_rel, q->n_relchunk_beg,
-                      q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids};
-      // (after the device-wide wait any stream may take the blocks; the plan's own build stream is where the next
-      // build of a similar slice will ask for them again: the pool hands them back without a driver call)
-      for (void *a : ptrs) pool_free(a, q->build_stream, ep);
-      delete q;
+      release_plan(q, ep);
     }
     if (qdev != cur) (void)hipSetDevice(cur);
   }
   parked.swap(keep);
+}
+
+// the same without the device-wide wait: the caller names an event recorded behind the LAST work that uses the plan
+// (on whichever stream); the host waits for that event and for the plan's own build stream only — other streams of the
+// device keep running (a batch prefetcher drops the plans of finished steps while the next batch is being built)
+int free_plan_after(mrgcn_plan *p, hipEvent_t ev) {
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  const int qdev = p->device;
+  if (qdev != cur) (void)hipSetDevice(qdev);
+  hipError_t e = ev ? hipEventSynchronize(ev) : hipSuccess;
+  if (e == hipSuccess) e = hipStreamSynchronize(p->build_stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (qdev != cur) (void)hipSetDevice(cur);
+    free_plan(p);  // (e.g. a capture under way: the parking path)
+    return MRGCN_OK;
+  }
+  // every user of THESE blocks has finished (nothing is said about other parked blocks: no epoch moves)
+  release_plan(p, kSafeNow);
+  if (qdev != cur) (void)hipSetDevice(cur);
+  return MRGCN_OK;
 }
 
 }  // namespace
@@ -1180,6 +1210,11 @@ int mrgcn_plan_create_csr(mrgcn_plan_t **plan, int64_t num_rows, int64_t num_nod
 int mrgcn_plan_destroy(mrgcn_plan_t *plan) {
   if (plan) mrgcn::free_plan(plan);
   return MRGCN_OK;
+}
+
+int mrgcn_plan_destroy_after(mrgcn_plan_t *plan, void *event) {
+  if (!plan) return MRGCN_OK;
+  return mrgcn::free_plan_after(plan, (hipEvent_t)event);
 }
 
 int mrgcn_plan_info(const mrgcn_plan_t *p, mrgcn_plan_info_t *h) {

@@ -370,3 +370,148 @@ class A_BatchDevice(A_Batch):
 
     def to(self, device):
         return self if torch.device(device) == self.device else super().to(device)
+
+
+class BatchPrefetcher:
+    """Iterates over device-built mini-batches that worker threads prepare ahead — batch structure (frontier
+    kernels) and, when `model` is given, the slice plans — on their own streams while the caller trains on the
+    previous one:
+
+        for ab in BatchPrefetcher(dcsr, sampler, num_layers, model=model):
+            loss = criterion(model(X[ab.neighbours[-1]], ab), ...)
+            ...
+
+    `batches`: an iterable of node-index arrays (one per step: a sampler); batches come out in its order.  Every
+    batch is short-lived (lean slice plans).  A batch build is mostly waiting (host round trips of sizes between
+    short device passes), so `workers` threads (default 2) build consecutive batches side by side; at most `depth`
+    batches (default: `workers`) exist ahead of the caller.  What the hand-over guarantees: the caller's current
+    stream waits for the batch's build (an event, no host wait); every tensor of the batch is registered with the
+    caller's stream (`record_stream`), so the allocator does not hand its memory to a worker again before the
+    caller's kernels have run; the plans of a finished batch are released by a worker behind an event the iterator
+    records on the caller's stream when the NEXT batch is asked for (mrgcn_plan_destroy_after: no device-wide wait,
+    the builds under way are not stalled).
+    The reference has no counterpart (its batches are built once on the host, node_classification.py:128)."""
+
+    def __init__(self, A_dev: DeviceCSR, batches, num_layers, value_mode="ref_int8", model=None, workers=2,
+                 depth=None):
+        import queue
+        import threading
+        self.num_layers, self.value_mode, self.model = num_layers, value_mode, model
+        self.dev = A_dev.indptr.device
+        self._it = enumerate(iter(batches))
+        self._lock = threading.Lock()            # the sampler
+        self._cv = threading.Condition()         # slots / counters below
+        self._slots = {}                         # step -> (batch, event behind its build)
+        self._taken = 0                          # steps handed to the caller
+        self._next_step = 0                      # steps drawn from the sampler
+        self._total = None                       # number of steps, once the sampler is exhausted
+        self._depth = max(1, int(depth if depth is not None else workers))
+        self._done = queue.Queue()               # (batch, event behind its last use) for a worker to release
+        self._err = None
+        self._last = None
+        self._threads = []
+        for _ in range(max(1, int(workers))):
+            csr = DeviceCSR.__new__(DeviceCSR)   # the resident arrays, a workspace of its own
+            csr.shape, csr.indptr, csr.indices, csr.data, csr._ws = A_dev.shape, A_dev.indptr, A_dev.indices, A_dev.data, None
+            t = threading.Thread(target=self._work, args=(csr, torch.cuda.Stream(device=self.dev)), daemon=True)
+            t.start()
+            self._threads.append(t)
+
+    # -- workers --------------------------------------------------------------------------------------------
+    def _release_finished(self):
+        import queue
+        while True:
+            try:
+                ab, ev = self._done.get_nowait()
+            except queue.Empty:
+                return
+            for a in ab.row:
+                for t in (a, getattr(a, "_mrgcn_slice", (None, None))[1]):
+                    p = getattr(t, "_mrgcn_plan", None) if t is not None else None
+                    if p is not None:
+                        p.close(after_event=ev)
+
+    def _work(self, csr, stream):
+        try:
+            with torch.cuda.device(self.dev), torch.cuda.stream(stream):
+                while self._err is None:
+                    with self._lock:
+                        try:
+                            k, idx = next(self._it)
+                        except StopIteration:
+                            with self._cv:
+                                if self._total is None:
+                                    self._total = self._next_step
+                                self._cv.notify_all()
+                            break
+                        self._next_step = k + 1
+                    with self._cv:               # bounded look-ahead
+                        self._cv.wait_for(lambda: k < self._taken + self._depth or self._err is not None)
+                    ab = A_BatchDevice(csr, idx, self.num_layers, self.value_mode, short_lived=True)
+                    if self.model is not None:
+                        self.model.prepare_batch(ab)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    with self._cv:
+                        self._slots[k] = (ab, ev)
+                        self._cv.notify_all()
+                    self._release_finished()
+        except BaseException as e:  # noqa: BLE001  (re-raised on the caller's thread)
+            with self._cv:
+                self._err = e
+                self._cv.notify_all()
+        finally:
+            self._release_finished()
+
+    # -- caller ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _tensors(ab):
+        yield ab.node_index
+        for i, a in enumerate(ab.row):
+            yield ab.neighbours[i]
+            yield ab._a_idx[i]
+            for t in (a, a._mrgcn_slice[1]):
+                yield t._indices()
+                yield t._values()
+
+    def _retire_last(self, cur):
+        if self._last is not None:
+            ev = torch.cuda.Event()
+            ev.record(cur)               # behind everything the caller submitted with the previous batch
+            self._done.put((self._last, ev))
+            self._last = None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        cur = torch.cuda.current_stream(self.dev)
+        self._retire_last(cur)
+        k = self._taken
+        with self._cv:
+            self._cv.wait_for(lambda: k in self._slots or self._err is not None
+                              or (self._total is not None and k >= self._total))
+            if self._err is not None:
+                raise self._err
+            if k not in self._slots:
+                raise StopIteration
+            ab, ev = self._slots.pop(k)
+            self._taken = k + 1
+            self._cv.notify_all()
+        cur.wait_event(ev)
+        for t in self._tensors(ab):
+            t.record_stream(cur)
+        self._last = ab
+        return ab
+
+    def close(self):
+        """Hands the last batch back, stops the workers and waits for them (call after the loop)."""
+        self._retire_last(torch.cuda.current_stream(self.dev))
+        with self._cv:
+            if self._err is None and self._total is None:
+                self._err = StopIteration()      # (an early exit of the loop: no further batch is started)
+            self._cv.notify_all()
+        for t in self._threads:
+            t.join(timeout=30.0)
+        self._slots.clear()
+        self._release_finished()

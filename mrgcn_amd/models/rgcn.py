@@ -61,20 +61,7 @@ class RGCN(nn.Module):
         """rgcn.py:91-128: layer l computes the embeddings of the nodes (L-1-l) hops from the batch
         nodes out of those one hop further, on the matching row slice of A."""
         from ..data.batch import getAdjacencyNodeColumnIdx
-        # the slice plans a fresh batch still lacks (two per layer at most) are built side by side
-        jobs = []
-        for layer_idx, layer in enumerate(self.layers.values()):
-            A_sl = A.row[self.num_layers - (layer_idx + 1)]
-            if not (isinstance(A_sl, torch.Tensor) and A_sl.is_cuda):
-                continue
-            rb = [layer.operand_row_bytes()]
-            if layer.input_layer:
-                jobs.append((A_sl, layer.num_nodes, layer.num_relations, rb))
-            sl = getattr(A_sl, "_mrgcn_slice", None)
-            if sl is not None and not (layer.input_layer and layer.featureless):
-                jobs.append((sl[1], int(A.neighbours[self.num_layers - (layer_idx + 1)].numel()), layer.num_relations, rb))
-        if len(jobs) > 1:
-            build_plans_parallel(jobs)
+        self.prepare_batch(A)
         for layer_idx, (key, layer) in enumerate(self.layers.items()):
             f_activation = self.activations[key] if key in self.activations else None
             i = self.num_layers - (layer_idx + 1)
@@ -95,6 +82,24 @@ class RGCN(nn.Module):
             if f_activation is not None:
                 X = f_activation(X)
         return X
+
+    def prepare_batch(self, A):
+        """Builds the slice plans a (fresh) batch still lacks — two per layer at most — side by side.  Called by the
+        forward; a prefetcher calls it ahead of time on its own stream (data/batch.py BatchPrefetcher)."""
+        jobs = []
+        for layer_idx, layer in enumerate(self.layers.values()):
+            A_sl = A.row[self.num_layers - (layer_idx + 1)]
+            if not (isinstance(A_sl, torch.Tensor) and A_sl.is_cuda):
+                continue
+            rb = [layer.operand_row_bytes()]
+            if layer.input_layer:
+                jobs.append((A_sl, layer.num_nodes, layer.num_relations, rb))
+            sl = getattr(A_sl, "_mrgcn_slice", None)
+            if sl is not None and not (layer.input_layer and layer.featureless):
+                jobs.append((sl[1], int(A.neighbours[self.num_layers - (layer_idx + 1)].numel()), layer.num_relations, rb))
+        if len(jobs) > 1:
+            build_plans_parallel(jobs)
+        return A
 
     def operand_row_bytes(self):
         """Row sizes of the layers' compact operands: the layout hint of the adjacency's graph plan."""

@@ -131,9 +131,15 @@ class GraphPlan:
         return A
 
     # -- lifetime -------------------------------------------------------------------
-    def close(self):
+    def close(self, after_event=None):
+        """Releases the plan's device memory.  Default: after a wait for everything in flight on the device.
+        `after_event`: a torch.cuda.Event recorded behind the last work that uses the plan — the host then waits for
+        that event only and other streams keep running (mrgcn_plan_destroy_after)."""
         if getattr(self, "_h", None) is not None and self._h:
-            L.load().mrgcn_plan_destroy(self._h)
+            if after_event is not None:
+                L.load().mrgcn_plan_destroy_after(self._h, after_event.cuda_event)
+            else:
+                L.load().mrgcn_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -259,7 +265,7 @@ def build_plans_parallel(jobs) -> None:
     cur = torch.cuda.current_stream(dev)
     # the same few streams every time: the stream-ordered pool hands a freed block back without a driver call only to
     # the stream that freed it
-    pool = _BUILD_STREAMS.setdefault(dev, [])
+    pool = _BUILD_STREAMS.setdefault((dev, threading.get_ident()), [])   # (per calling thread: batch prefetch workers)
     while len(pool) < len(todo):
         pool.append(torch.cuda.Stream(device=dev))
     streams = pool[: len(todo)]

@@ -198,6 +198,52 @@ def test_short_lived_batch_on_lean_plans_equals_the_goldens(tag):
 
 
 @pytest.mark.gpu
+def test_prefetched_batches_train_like_batches_built_in_line():
+    """BatchPrefetcher (next batch + its slice plans built by a worker thread on its own stream, plans of finished
+    steps released behind an event): the same losses and parameters as building every batch in line."""
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, categorical_crossentropy
+    import scipy.sparse as sp
+    from mrgcn_amd import synth
+    g = synth.make_graph("aifb", seed=1, scale=0.2)
+    N, R = g.num_nodes, g.num_relations
+    A = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
+    rng = np.random.default_rng(3)
+    steps, nb, K, C = 8, 24, 6, 4
+    idxs = [np.sort(rng.choice(N, nb, replace=False)) for _ in range(steps)]
+    ys = [torch.from_numpy(rng.integers(0, C, nb)).cuda() for _ in range(steps)]
+    X = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
+    dcsr = mb.DeviceCSR(A)
+    rows = torch.arange(nb, device="cuda")
+
+    def run(prefetch):
+        torch.manual_seed(0)
+        model = RGCN([(K, 8, "mrgcn", torch.nn.ReLU()), (8, C, "mrgcn", None)], R, N, 3, 0.0, False, True, False).cuda()
+        opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+        it = (mb.BatchPrefetcher(dcsr, iter(idxs), 2, value_mode="norm_f32", model=model) if prefetch
+              else (mb.A_BatchDevice(dcsr, i, 2, value_mode="norm_f32", short_lived=True) for i in idxs))
+        losses = []
+        for k, ab in enumerate(it):
+            loss = categorical_crossentropy(model(X[ab.neighbours[-1]], ab), rows, ys[k])
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        if prefetch:
+            it.close()
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], {n: p.detach().cpu().numpy() for n, p in model.named_parameters()}
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert len(l1) == steps
+    np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-6)
+    for n in p0:
+        np.testing.assert_allclose(p1[n], p0[n], rtol=1e-4, atol=1e-6, err_msg=n)
+
+
+@pytest.mark.gpu
 def test_frontier_kernels_edge_cases_through_the_c_abi():
     """mrgcn_frontier_count / _emit against the host functions on a graph with isolated rows, a hub row longer
     than several waves, duplicated sample rows and an empty sample; float32 and int8 (truncating) values."""

@@ -73,11 +73,34 @@ def minibatch():
         loss.backward()
         opt.step()
     out["reused_batch_fwd_bwd_adam_ms"] = round(timed(again, iters=10, warm=2), 2)
+    # the same re-sampled steps with the next batch (structure + slice plans) prepared by a worker thread on its own
+    # stream while the current one trains: steady-state time per step, every step on a fresh batch
+    steps, warm = 24, 6
+    ys = torch.from_numpy(rng.integers(0, dims[-1][1], 1024)).cuda()
+    rows1024 = torch.arange(1024, device="cuda")
+    out["resampled_step_prefetched_ms"] = {}
+    for workers in (1, 2, 3):
+        pf = mb.BatchPrefetcher(dcsr, (np.sort(rng.choice(N, 1024, replace=False)) for _ in range(steps)), 2,
+                                model=model, workers=workers)
+        t0 = None
+        for k, b in enumerate(pf):
+            if k == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            loss = categorical_crossentropy(model(X[b.neighbours[-1]], b), rows1024, ys)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        out["resampled_step_prefetched_ms"][f"workers={workers}"] = round((time.perf_counter() - t0) / (steps - warm) * 1e3, 2)
+        pf.close()
     out.update(neighbours=sizes, batch_build_ms=round(float(np.median(t_build)), 2),
                plans_fwd_bwd_adam_ms=round(float(np.median(t_step)), 2),
-               note="a re-sampled batch every step: structure on the device, its slice plans (built side by side, "
-                    "blocks from the plan allocator's cache), forward, backward, dense Adam on the full node table "
-                    "(mini-batch steps do not use the row-sparse update)")
+               note="a re-sampled batch every step: structure on the device (batch_build_ms), then its lean slice plans "
+                    "(built side by side, blocks from the plan allocator's cache), forward, backward, clip, Adam "
+                    "(plans_fwd_bwd_adam_ms); resampled_step_prefetched_ms = the whole of it per step (structure + plans + "
+                    "training step, every step on a fresh batch) when worker threads prepare the next batches "
+                    "meanwhile (data.batch.BatchPrefetcher, default 2 workers)")
     return out
 
 
