@@ -31,6 +31,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6.29 TB/s measured c
 PARTITIONED_WORKLOADS = ("synth10m", "fb15k")
 
 
+
+def _env_switches():
+    """The MRGCN_* environment switches set for this run (they select kernels and layouts: DESIGN.md, switches table)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("MRGCN_")}
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -412,7 +417,8 @@ def main_lp(args):
                        "parallelism": ("node-partitioned x%d" % world if partitioned else "replicas x%d" % world)
                        if world > 1 else "1 GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "spmm_hbm_gbps": ach,
-            "extra": dict(extra, final_loss=float(loss), setup_s=setup_s, plan_device_mb=plan.device_bytes / 2**20),
+            "extra": dict(extra, final_loss=float(loss), setup_s=setup_s, plan_device_mb=plan.device_bytes / 2**20,
+                          env_switches=_env_switches()),
         }
     if world > 1:
         dist.barrier()
@@ -623,7 +629,7 @@ def main():
             "spmm_hbm_gbps": ach,
             "extra": dict(extra, final_loss=final_loss, setup_s=setup_s,
                           plan_device_mb=plan.device_bytes / 2**20, long_rows=plan.long_rows,
-                          long_cols=plan.long_cols, max_row_nnz=plan.max_row_nnz),
+                          long_cols=plan.long_cols, max_row_nnz=plan.max_row_nnz, env_switches=_env_switches()),
         }
     if world > 1:
         dist.barrier()

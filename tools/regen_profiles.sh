@@ -14,7 +14,11 @@ python3 tools/make_spmm_pmc_json.py $o/pmc_spmm "k_spmm3<" > $o/spmm_pmc_latest.
 python3 tools/pmc_summary.py $o k_spmm3 > $o/spmm_pmc.md
 rm -rf $o/pmc_spmm_*/
 cp $o/spmm_pmc_latest.json profiles/spmm_pmc_latest.json   # the bench line quotes it (digest-checked)
+# clocks / power beside the bench line (one sample per 0.5 s while it runs; needs nothing but read access)
+( for i in $(seq 1 200); do rocm-smi --showclocks --showpower --csv 2>/dev/null | tr '\n' ' '; echo; sleep 0.5; done > $o/rocm_smi_during_bench.txt ) &
+smi_pid=$!
 python3 bench.py --steps 20 --warmup 3 > $o/bench_line.json 2> $o/bench_line.err
+kill $smi_pid 2>/dev/null; wait $smi_pid 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-renumbered-extra --no-reference-loop > $o/bench_under_rocprof.json 2> $o/bench_under_rocprof.err
 python3 tools/prof_summary.py $o/stats 40 > $o/epoch_kernel_stats.md
 python3 tools/trace_summary.py $o/stats > $o/epoch_kernel_trace_medians.md 2>/dev/null
