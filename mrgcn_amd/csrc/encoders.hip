@@ -725,9 +725,11 @@ int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
       }
       if (t * splits < 512) cost *= std::max(1.0, 256.0 / (double)(t * splits)) * 1.4;
     }
-    // the last round of blocks leaves part of the chip idle
+    // the last round of blocks leaves part of the chip idle; a grid that is resident all at once is as slow as
+    // its fullest CU (the blocks of a CU share its matrix cores)
     const double per_round = 256.0 * cands[c].occ, blocks = (double)t * splits;
     if (blocks > per_round) cost *= std::ceil(blocks / per_round) * per_round / blocks;
+    else if (blocks > 256.0) cost *= std::ceil(blocks / 256.0) * 256.0 / blocks;
     if (best < 0 || cost < best_cost) best = c, best_cost = cost, best_splits = splits;
   }
   if (best < 0) return MRGCN_ERR_UNSUPPORTED;
