@@ -383,7 +383,7 @@ class BatchPrefetcher:
 
     `batches`: an iterable of node-index arrays (one per step: a sampler); batches come out in its order.  Every
     batch is short-lived (lean slice plans).  A batch build is mostly waiting (host round trips of sizes between
-    short device passes), so `workers` threads (default 2) build consecutive batches side by side; at most `depth`
+    short device passes), so `workers` threads (default 3) build consecutive batches side by side; at most `depth`
     batches (default: `workers`) exist ahead of the caller.  What the hand-over guarantees: the caller's current
     stream waits for the batch's build (an event, no host wait); every tensor of the batch is registered with the
     caller's stream (`record_stream`), so the allocator does not hand its memory to a worker again before the
@@ -392,7 +392,7 @@ class BatchPrefetcher:
     the builds under way are not stalled).
     The reference has no counterpart (its batches are built once on the host, node_classification.py:128)."""
 
-    def __init__(self, A_dev: DeviceCSR, batches, num_layers, value_mode="ref_int8", model=None, workers=2,
+    def __init__(self, A_dev: DeviceCSR, batches, num_layers, value_mode="ref_int8", model=None, workers=3,
                  depth=None):
         import queue
         import threading
@@ -447,6 +447,8 @@ class BatchPrefetcher:
                         self._next_step = k + 1
                     with self._cv:               # bounded look-ahead
                         self._cv.wait_for(lambda: k < self._taken + self._depth or self._err is not None)
+                    if self._err is not None:
+                        break
                     ab = A_BatchDevice(csr, idx, self.num_layers, self.value_mode, short_lived=True)
                     if self.model is not None:
                         self.model.prepare_batch(ab)

@@ -244,6 +244,38 @@ def test_prefetched_batches_train_like_batches_built_in_line():
 
 
 @pytest.mark.gpu
+def test_prefetcher_edge_cases():
+    """No batches at all, a loop left early, a sampler that raises: the iterator ends / closes / re-raises on the
+    caller's thread and its workers exit."""
+    import scipy.sparse as sp
+    from mrgcn_amd import synth
+    from mrgcn_amd.data import batch as mb
+    g = synth.make_graph("aifb", seed=1, scale=0.1)
+    N, R = g.num_nodes, g.num_relations
+    dcsr = mb.DeviceCSR(sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N)))
+    pf = mb.BatchPrefetcher(dcsr, iter(()), 2, value_mode="norm_f32")
+    assert list(pf) == []
+    pf.close()
+    rng = np.random.default_rng(0)
+    pf = mb.BatchPrefetcher(dcsr, (np.sort(rng.choice(N, 8, replace=False)) for _ in range(50)), 2, value_mode="norm_f32")
+    for k, ab in enumerate(pf):
+        assert len(ab.row) == 2 and int(ab.node_index.numel()) == 8
+        if k == 2:
+            break
+    pf.close()
+    assert not any(t.is_alive() for t in pf._threads)
+
+    def bad():
+        yield np.arange(4)
+        raise RuntimeError("sampler failed")
+    pf = mb.BatchPrefetcher(dcsr, bad(), 1, value_mode="norm_f32", workers=1)
+    with pytest.raises(RuntimeError, match="sampler failed"):
+        for _ in pf:
+            pass
+    pf.close()
+
+
+@pytest.mark.gpu
 def test_frontier_kernels_edge_cases_through_the_c_abi():
     """mrgcn_frontier_count / _emit against the host functions on a graph with isolated rows, a hub row longer
     than several waves, duplicated sample rows and an empty sample; float32 and int8 (truncating) values."""

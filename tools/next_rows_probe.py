@@ -100,7 +100,7 @@ def minibatch():
                     "(built side by side, blocks from the plan allocator's cache), forward, backward, clip, Adam "
                     "(plans_fwd_bwd_adam_ms); resampled_step_prefetched_ms = the whole of it per step (structure + plans + "
                     "training step, every step on a fresh batch) when worker threads prepare the next batches "
-                    "meanwhile (data.batch.BatchPrefetcher, default 2 workers)")
+                    "meanwhile (data.batch.BatchPrefetcher, default 3 workers)")
     return out
 
 
