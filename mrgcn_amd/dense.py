@@ -39,6 +39,20 @@ def usable(*tensors) -> bool:
     return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors)
 
 
+# The tiled product addresses its operands through 32-bit byte offsets: an operand of a single launch holds at most
+# 2^29 bytes (csrc/encoders.hip kMmMaxBytes; larger ones would fall to the element-loader kernel, ~40x slower).  A
+# convolution over a large batch (a linear layer over many rows) is therefore cut along the batch: samples are
+# independent in the forward and dX products, and dW is the sum of the per-piece products.
+_MM_MAX_BYTES = 1 << 29
+
+
+def _batch_pieces(Bn: int, *elems_per_sample: int):
+    """[(b0, b1), ...]: batch ranges whose operands (elements per sample given) each stay within _MM_MAX_BYTES."""
+    per = max(1, max(elems_per_sample)) * 4
+    step = max(1, _MM_MAX_BYTES // per - 1)   # (the launcher's size estimate counts one sample more)
+    return [(b0, min(Bn, b0 + step)) for b0 in range(0, Bn, step)]
+
+
 # ---------------------------------------------------------------------------------------------------------
 class _Linear(torch.autograd.Function):
     """y = relu?(x W^T + b) on the matrix cores (nn.Linear semantics: W is [out, in])."""
@@ -50,7 +64,9 @@ class _Linear(torch.autograd.Function):
         n, K = x2.shape
         N = Wc.shape[0]
         y = torch.empty((n, N), dtype=torch.float32, device=x.device)
-        _gemm(0, 1, 0, n, N, K, x2, K, Wc, K, y, N, bias=b.contiguous() if b is not None else None, relu=relu)
+        bc = b.contiguous() if b is not None else None
+        for r0, r1 in _batch_pieces(n, K, N):
+            _gemm(0, 1, 0, r1 - r0, N, K, x2[r0:r1], K, Wc, K, y[r0:r1], N, bias=bc, relu=relu)
         ctx.relu, ctx.shape, ctx.has_b = relu, x.shape, b is not None
         ctx.save_for_backward(x2, Wc, y if relu else None)
         return y.view(*x.shape[:-1], N)
@@ -67,11 +83,16 @@ class _Linear(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((n, K), dtype=torch.float32, device=dy.device)
-            _gemm(0, 0, 0, n, K, N, dy2, N, W, K, dx, K)                      # dx = dy . W
+            for r0, r1 in _batch_pieces(n, K, N):
+                _gemm(0, 0, 0, r1 - r0, K, N, dy2[r0:r1], N, W, K, dx[r0:r1], K)   # dx = dy . W
             dx = dx.view(ctx.shape)
         if ctx.needs_input_grad[1]:
-            dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            _gemm(1, 0, 0, N, K, n, dy2, N, x2, K, dW, K)                     # dW = dy^T . x
+            for r0, r1 in _batch_pieces(n, K, N):
+                part = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+                _gemm(1, 0, 0, N, K, r1 - r0, dy2[r0:r1], N, x2[r0:r1], K, part, K)   # dW = dy^T . x
+                dW = part if dW is None else dW.add_(part)
+            if dW is None:
+                dW = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = _colsum(dy2)
         return dx, dW, db, None
@@ -81,7 +102,6 @@ def linear(x, W, b=None, relu: bool = False):
     return _Linear.apply(x, W, b, relu)
 
 
-# ---------------------------------------------------------------------------------------------------------
 class _Conv1d(torch.autograd.Function):
     """nn.Conv1d (stride 1, dilation 1, zero padding) as an implicit-im2col product on the matrix cores:
     y[b, co, t] = bias[co] + sum_{ci, kw} W[co, ci, kw] x[b, ci, t + kw - pad]."""
@@ -95,8 +115,10 @@ class _Conv1d(torch.autograd.Function):
         Tout = Tin + 2 * pad - KW + 1
         y = torch.empty((Bn, Cout, Tout), dtype=torch.float32, device=x.device)
         geom = (Cin, Tin, KW, pad, Tout, Cout)
-        _gemm(2, 1, 2, Bn * Tout, Cout, Cin * KW, x, 0, Wc.view(Cout, Cin * KW), Cin * KW, y, 0,
-              bias=b.contiguous() if b is not None else None, geom=geom)
+        bc = b.contiguous() if b is not None else None
+        for b0, b1 in _batch_pieces(Bn, Cin * Tin, Cout * Tout):
+            _gemm(2, 1, 2, (b1 - b0) * Tout, Cout, Cin * KW, x[b0:b1], 0, Wc.view(Cout, Cin * KW), Cin * KW, y[b0:b1], 0,
+                  bias=bc, geom=geom)
         ctx.geom, ctx.has_b = geom, b is not None
         ctx.save_for_backward(x, Wc)
         return y
@@ -112,12 +134,18 @@ class _Conv1d(torch.autograd.Function):
             # dx[b, ci, t] = sum_{co, kw'} dy[b, co, t + kw' - (KW-1-pad)] W[co, ci, KW-1-kw']: a convolution of dy
             Wf = W.flip(2).permute(0, 2, 1).reshape(Cout * KW, Cin).contiguous()   # [(co, kw')][ci]
             dx = torch.empty_like(x)
-            _gemm(2, 0, 2, Bn * Tin, Cin, Cout * KW, dy, 0, Wf, Cin, dx, 0,
-                  geom=(Cout, Tout, KW, KW - 1 - pad, Tin, Cin))
+            for b0, b1 in _batch_pieces(Bn, Cin * Tin, Cout * Tout):
+                _gemm(2, 0, 2, (b1 - b0) * Tin, Cin, Cout * KW, dy[b0:b1], 0, Wf, Cin, dx[b0:b1], 0,
+                      geom=(Cout, Tout, KW, KW - 1 - pad, Tin, Cin))
         if ctx.needs_input_grad[1]:
             # dW^T[(ci, kw)][co] = sum_{b, t} x[b, ci, t + kw - pad] dy[b, co, t]
-            dWt = torch.empty((Cin * KW, Cout), dtype=torch.float32, device=dy.device)
-            _gemm(3, 2, 0, Cin * KW, Cout, Bn * Tout, x, 0, dy, 0, dWt, Cout, geom=ctx.geom)
+            dWt = None
+            for b0, b1 in _batch_pieces(Bn, Cin * Tin, Cout * Tout):
+                part = torch.empty((Cin * KW, Cout), dtype=torch.float32, device=dy.device)
+                _gemm(3, 2, 0, Cin * KW, Cout, (b1 - b0) * Tout, x[b0:b1], 0, dy[b0:b1], 0, part, Cout, geom=ctx.geom)
+                dWt = part if dWt is None else dWt.add_(part)
+            if dWt is None:
+                dWt = torch.zeros((Cin * KW, Cout), dtype=torch.float32, device=dy.device)
             dW = dWt.t().reshape(Cout, Cin, KW).contiguous()
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = torch.empty(Cout, dtype=torch.float32, device=dy.device)

@@ -333,6 +333,32 @@ def test_conv1d_on_the_matrix_cores_vs_torch(B, Cin, T, Cout, KW, pad):
 
 
 @pytest.mark.gpu
+def test_products_cut_along_the_batch_equal_the_single_launch(monkeypatch):
+    """Operands beyond the tiled product's 2^29-byte reach are multiplied piece by piece along the batch
+    (dense._batch_pieces): forced here with a small limit, the results equal the single launch."""
+    from mrgcn_amd import dense
+    gen = torch.Generator("cuda").manual_seed(4)
+
+    def run():
+        x = torch.randn((37, 16, 40), device="cuda", generator=gen, requires_grad=True)
+        W = torch.randn((24, 16, 3), device="cuda", generator=gen, requires_grad=True)
+        b = torch.randn((24,), device="cuda", generator=gen, requires_grad=True)
+        y = dense.conv1d(x, W, b, padding=1)
+        z = dense.linear(y.transpose(1, 2).reshape(-1, 24), W.reshape(24, 48)[:, :24].contiguous(), None, relu=True)
+        (y.square().sum() + z.sum()).backward()
+        return [t.detach().clone() for t in (y, z, x.grad, W.grad, b.grad)]
+
+    gen.manual_seed(4)
+    ref = run()
+    monkeypatch.setattr(dense, "_MM_MAX_BYTES", 16 * 40 * 4 * 6)   # ~5 samples per piece
+    assert len(dense._batch_pieces(37, 16 * 40, 24 * 40)) > 5
+    gen.manual_seed(4)
+    got = run()
+    for a, c in zip(got, ref):
+        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dims,with_rows", [([1, 4], True), ([6, 4, 3], True), ([16, 16, 16, 16, 16], False),
                                             ([3, 1], False)])
 def test_fused_mlp_gate_scatter_vs_torch(dims, with_rows):
