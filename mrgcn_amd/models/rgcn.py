@@ -61,7 +61,7 @@ class RGCN(nn.Module):
         """rgcn.py:91-128: layer l computes the embeddings of the nodes (L-1-l) hops from the batch
         nodes out of those one hop further, on the matching row slice of A."""
         from ..data.batch import getAdjacencyNodeColumnIdx
-        if X is not None and X.is_cuda and torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             from .. import _lib
             raise _lib.MrgcnError("the mini-batch forward cannot be captured into a hipGraph (its backward decides by "
                                   "counts read back from the device); GraphedTrainStep is for full-batch steps")
