@@ -393,6 +393,13 @@ int mrgcn_distmult_score_bwd_f32(const float *E, int64_t ldE, const float *Rel, 
  * within ties).  Runs of equal targets are summed in registers, so the float atomics of the
  * scatter form (which collide on the few hundred relation rows) shrink by the run length.
  * dE needs order_s and order_o, dRel needs order_p; both are ACCUMULATED into. */
+/* ... and those three permutations (any may be NULL): stable radix sorts of the subject / predicate / object columns
+ * over the bits ids below num_nodes / num_relations can have (replaces three torch.argsort calls of the run loop's
+ * autograd: a merge sort of ~30 launches per column).  workspace: mrgcn_distmult_orders_workspace(n) bytes. */
+int64_t mrgcn_distmult_orders_workspace(int64_t n);
+int mrgcn_distmult_orders(const int64_t *triples, int64_t n, int64_t num_nodes, int64_t num_relations,
+                          int64_t *order_s, int64_t *order_p, int64_t *order_o, void *workspace,
+                          int64_t workspace_bytes, void *stream);
 int mrgcn_distmult_score_bwd_sorted_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR,
                                         int32_t H, const int64_t *triples, int64_t n,
                                         const float *dscores, const int64_t *order_s,

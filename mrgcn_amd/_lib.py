@@ -103,6 +103,8 @@ SIGNATURES = {
     "mrgcn_distmult_score_bwd_sorted_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64,
                                                       _p, _i64, _p]),
     "mrgcn_bce_logits_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p]),
+    "mrgcn_distmult_orders_workspace": (C.c_int64, [_i64]),
+    "mrgcn_distmult_orders": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "mrgcn_distmult_ranks_workspace": (C.c_int64, [_i64, _i32, _i64]),
     "mrgcn_distmult_ranks": (C.c_int, [_p, _i64, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "mrgcn_adam_bias_f32": (C.c_int, [_p, C.c_float, C.c_float, _p, _p]),

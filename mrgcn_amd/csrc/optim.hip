@@ -86,6 +86,21 @@ __global__ void k_rows_nonzero(const float *__restrict__ X, int64_t ld, int F, i
   }
 }
 
+// the same for wide rows (F > 32): a wave per row, lanes along the row (a thread per row reads 64 rows of F floats
+// with a stride of F: 104 us for 14 541 x 200 at the FB15k-237 shape against a few us of bytes)
+__global__ __launch_bounds__(256) void k_rows_nonzero_wide(const float *__restrict__ X, int64_t ld, int F, int64_t nrows,
+                                                           uint8_t *__restrict__ flags) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < nrows;
+       i += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const float *row = X + i * ld;
+    bool nz = false;
+    for (int q = lane; q < F; q += 64) nz |= row[q] != 0.f;
+    const uint64_t any = __ballot(nz);
+    if (lane == 0) flags[i] = any ? 1 : 0;
+  }
+}
+
 // sum of squares -> double accumulator (one atomic per block)
 __global__ void k_sumsq(const float *__restrict__ x, int64_t n, double *__restrict__ accum) {
   const int64_t nv = n >> 2;
@@ -501,7 +516,8 @@ int mrgcn_rows_nonzero_f32(const float *X, int64_t ld, int32_t F, int64_t nrows,
   MRGCN_REQUIRE(F > 0 && ld >= F, "F / ld");
   if (nrows == 0) return MRGCN_OK;
   const int vec_ok = (ld % 4 == 0) && (((uintptr_t)X & 15) == 0);
-  k_rows_nonzero<<<dim3(stream_grid(nrows)), dim3(kTB), 0, (hipStream_t)stream>>>(X, ld, F, nrows, flags, vec_ok);
+  if (F > 32) k_rows_nonzero_wide<<<dim3(stream_grid(nrows * 64)), dim3(256), 0, (hipStream_t)stream>>>(X, ld, F, nrows, flags);
+  else k_rows_nonzero<<<dim3(stream_grid(nrows)), dim3(kTB), 0, (hipStream_t)stream>>>(X, ld, F, nrows, flags, vec_ok);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

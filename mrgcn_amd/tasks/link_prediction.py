@@ -70,7 +70,11 @@ class _DistMultScore(torch.autograd.Function):
         if n >= _SORTED_BWD_MIN and os.environ.get("MRGCN_LP_SORTED_BWD", "1") != "0":
             # runs of equal subject / predicate / object are summed in registers (three passes over
             # sorted triples) instead of one float atomic per triple and feature
-            order = [torch.argsort(triples[:, k]) for k in range(3)]
+            order = [torch.empty(n, dtype=torch.int64, device=E.device) for _ in range(3)]
+            ws = torch.empty(int(lib.mrgcn_distmult_orders_workspace(n)), dtype=torch.uint8, device=E.device)
+            _lib.check(lib.mrgcn_distmult_orders(_ptr(triples), n, E.shape[0], Rel.shape[0], _ptr(order[0]),
+                                                 _ptr(order[1]), _ptr(order[2]), _ptr(ws), ws.numel(), _stream()),
+                       "distmult_orders")
             _lib.check(lib.mrgcn_distmult_score_bwd_sorted_f32(
                 _ptr(E), E.stride(0), _ptr(Rel), Rel.stride(0), E.shape[1], _ptr(triples), n, _ptr(g),
                 _ptr(order[0]), _ptr(order[1]), _ptr(order[2]), _ptr(dE), dE.stride(0) if dE is not None else 0,
