@@ -150,7 +150,17 @@ def sample_negatives_device(batch_data: torch.Tensor, generator=None):
     [n // 5, 3], labels float32 [n + n // 5]), no host round trip."""
     n = batch_data.shape[0]
     dev = batch_data.device
-    nodes = torch.unique(torch.cat([batch_data[:, 0], batch_data[:, 2]]))
+    # the nodes of the batch: a sort-based unique (half of this function's device time) — kept for the tensor it was
+    # computed from while that tensor is unchanged (a full-batch run passes the same training facts every epoch)
+    cached = getattr(batch_data, "_mrgcn_nodes", None)
+    if cached is not None and cached[0] == batch_data._version:
+        nodes = cached[1]
+    else:
+        nodes = torch.unique(torch.cat([batch_data[:, 0], batch_data[:, 2]]))
+        try:
+            batch_data._mrgcn_nodes = (batch_data._version, nodes)
+        except AttributeError:
+            pass
     ncorrupt = n // 5
     neg_idx = torch.randperm(n, device=dev, generator=generator)[:ncorrupt]
     nhead = ncorrupt // 2
