@@ -155,3 +155,24 @@ def test_device_negative_sampling_shapes():
     nodes = torch.unique(torch.cat([facts[:, 0], facts[:, 2]]))
     assert bool(torch.isin(neg[:, 0], nodes).all()) and bool(torch.isin(neg[:, 2], nodes).all())
     assert bool(torch.isin(neg[:, 1], facts[:, 1]).all())
+
+
+@pytest.mark.parametrize("n,N,R", [(1, 1, 1), (1000, 50, 7), (70000, 14541, 475), (5000, 3, 2)])
+@pytest.mark.parametrize("which", [(1, 1, 1), (1, 0, 1), (0, 1, 0)])
+def test_triple_orders_equal_a_stable_argsort(n, N, R, which):
+    """mrgcn_distmult_orders (the permutations of the sorted decoder backward): stable sorts of the subject /
+    predicate / object columns, any subset of the three."""
+    import ctypes as C
+
+    from mrgcn_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(n + N)
+    t = np.stack([rng.integers(0, N, n), rng.integers(0, R, n), rng.integers(0, N, n)], 1).astype(np.int64)
+    td = torch.from_numpy(t).cuda()
+    outs = [torch.full((n,), -1, dtype=torch.int64, device="cuda") if w else None for w in which]
+    ws = torch.empty(int(lib.mrgcn_distmult_orders_workspace(n)), dtype=torch.uint8, device="cuda")
+    L.check(lib.mrgcn_distmult_orders(td.data_ptr(), n, N, R, *[o.data_ptr() if o is not None else 0 for o in outs],
+                                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+    for c, o in enumerate(outs):
+        if o is not None:
+            np.testing.assert_array_equal(o.cpu().numpy(), np.argsort(t[:, c], kind="stable"))
