@@ -2,7 +2,7 @@
 # Copies what tools/regen_profiles.sh left under gpurun_out/<tag>/ into profiles/<tag>_* (the tracked artefacts).
 tag=${1:-rXX}
 o=gpurun_out/$tag
-for f in bench_line.json bench_fb15k.json bench_ref_int8.json bench_under_rocprof.json epoch_kernel_stats.md \
+for f in bench_line.json bench_fb15k.json bench_ref_int8.json bench_aifb.json bench_mutag.json bench_synth10m.json bench_under_rocprof.json epoch_kernel_stats.md \
          epoch_kernel_trace_medians.md epoch_sequence.md epoch_pmc.md seeds.json spmm_pmc.md next_rows.json \
          gemm_probe.txt gemm_probe.json rocm_smi_during_bench.txt; do
   [ -s $o/$f ] && cp $o/$f profiles/${tag}_$f

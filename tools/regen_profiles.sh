@@ -32,6 +32,7 @@ rm -rf $o/pmc_epoch_*/
 python3 tools/seed_median.py > $o/seeds.json 2> $o/seeds.err
 python3 bench.py --workload fb15k > $o/bench_fb15k.json 2> $o/bench_fb15k.err
 python3 bench.py --value-mode ref_int8 --no-cpu-baseline > $o/bench_ref_int8.json 2> $o/bench_ref_int8.err
+for w in aifb mutag synth10m; do python3 bench.py --workload $w --no-cpu-baseline > $o/bench_$w.json 2> $o/bench_$w.err; done
 # (6) the encoders' tiled product over the TCNN-M shapes: per-product rates, MFMA counters; (7) the next-rows probe
 python3 tools/gemm_probe.py > $o/gemm_probe.txt 2> $o/gemm_probe.err
 python3 tools/gemm_probe.py --json > $o/gemm_probe.json 2>> $o/gemm_probe.err
