@@ -361,6 +361,10 @@ int mrgcn_clip_coef_f32(const double *sumsq, float max_norm, float *coef, float 
  * bias corrections of mrgcn_adam_bias_f32.  `accum` (double) and `ticket` (uint32) are scratch words that must be
  * zero at the first call; the kernel leaves them zero.  Replaces n mrgcn_sumsq_accum_f32 + mrgcn_clip_coef_f32 +
  * mrgcn_adam_bias_f32 launches (each ~6 us inside a replayed hipGraph). */
+/* *accum += the squared norms of <= 16 tensors in one launch (the launches in front of mrgcn_sumsq_clip_multi_f32 for a
+ * model with more small tensors than one call takes; `accum` is the same scratch word, which that call reads and clears) */
+int mrgcn_sumsq_accum_multi_f32(int32_t n_tensors, const float *const *grads, const int64_t *numel, double *accum,
+                                void *stream);
 int mrgcn_sumsq_clip_multi_f32(int32_t n_tensors, const float *const *grads, const int64_t *numel, int32_t n_extra,
                                const double *const *extra, double *accum, uint32_t *ticket, float max_norm,
                                double *sumsq_out, float *coef, float *norm, int64_t *step_dev, float beta1,
@@ -501,6 +505,10 @@ int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, 
                                const float *beta, float eps, int32_t training, float *mean, float *var,
                                int32_t pool_kind, int32_t pool_arg, float *y, int32_t *argmax, void *workspace,
                                void *stream);
+/* nn.BatchNorm1d's running statistics after a training-mode forward over n = B * T values per channel:
+ * running = (1 - momentum) running + momentum stat, the (biased) batch variance scaled by n / (n - 1). */
+int mrgcn_bn_running_stats_f32(const float *mean, const float *var, int32_t C, int64_t n, float momentum,
+                               float *running_mean, float *running_var, void *stream);
 /* out[c] = sum over (b, t) of x[b][c][t] — the bias gradient of a Conv1d (torch: dy.sum(dim=(0, 2))); fp64 sums per
  * block, one float atomic per block into the zeroed out. */
 int mrgcn_channel_sum_f32(const float *x, int32_t B, int32_t C, int32_t T, float *out, void *stream);

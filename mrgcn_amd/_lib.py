@@ -81,6 +81,7 @@ SIGNATURES = {
     "mrgcn_softmax_xent_bwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _p]),
     "mrgcn_basis_contract_f32": (C.c_int, [_p, _p, _i32, _i32, _i64, _p, _p]),
     "mrgcn_basis_contract_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _i64, _p, _p, _p]),
+    "mrgcn_sumsq_accum_multi_f32": (C.c_int, [_i32, _p, _p, _p, _p]),
     "mrgcn_sumsq_clip_multi_f32": (C.c_int, [_i32, _p, _p, _i32, _p, _p, _p, C.c_float, _p, _p, _p, _p, C.c_float,
                                              C.c_float, _p, _p]),
     "mrgcn_adam_step_multi_f32": (C.c_int, [_i32, _p, _p, _p, _p, _p, _p, _p, C.c_float, C.c_float, C.c_float, _i64,
@@ -118,6 +119,7 @@ SIGNATURES = {
                                  C.c_float, _p, _p]),
     "mrgcn_colsum_f32": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "mrgcn_channel_sum_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "mrgcn_bn_running_stats_f32": (C.c_int, [_p, _p, _i32, _i64, C.c_float, _p, _p, _p]),
     "mrgcn_pool_out_len": (_i32, [_i32, _i32, _i32]),
     "mrgcn_bn_workspace_bytes": (C.c_size_t, [_i32]),
     "mrgcn_bn_relu_pool_fwd_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, C.c_float, _i32, _p, _p, _i32, _i32, _p, _p,

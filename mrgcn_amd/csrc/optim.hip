@@ -367,6 +367,29 @@ struct MultiSumsq {
   const double *extra[kMultiMax];  // further squared norms to add (device doubles)
   int32_t n_extra;
 };
+// *accum += the squared norms of up to kMultiMax tensors: the launches in front of k_sumsq_multi when a model has more
+// small tensors than one launch takes (an MRGCN with encoders: ~40)
+__global__ __launch_bounds__(kTB) void k_sumsq_multi_accum(MultiSumsq a, double *__restrict__ accum) {
+  int t = 0;
+  while (t + 1 < a.n_tensors && (int)blockIdx.x >= a.blk0[t + 1]) ++t;
+  const int nb = a.blk0[t + 1] - a.blk0[t], b = blockIdx.x - a.blk0[t];
+  const float *x = a.g[t];
+  const int64_t n = a.n[t], nv = n >> 2;
+  const float4 *x4 = reinterpret_cast<const float4 *>(x);
+  float s = 0.f;
+  for (int64_t i = (int64_t)b * kTB + threadIdx.x; i < nv; i += (int64_t)nb * kTB) {
+    float4 v = x4[i];
+    s = fmaf(v.x, v.x, s);
+    s = fmaf(v.y, v.y, s);
+    s = fmaf(v.z, v.z, s);
+    s = fmaf(v.w, v.w, s);
+  }
+  if (b == 0)
+    for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += kTB) s = fmaf(x[i], x[i], s);
+  const float tot = block_sum(s);
+  if (threadIdx.x == 0 && tot != 0.f) atomicAdd(accum, (double)tot);
+}
+
 // `accum` / `ticket` must be zero on entry; the last block leaves them zero again (self-cleaning)
 __global__ __launch_bounds__(kTB) void k_sumsq_multi(MultiSumsq a, double *__restrict__ accum,
                                                      unsigned int *__restrict__ ticket, float max_norm,
@@ -722,6 +745,27 @@ int mrgcn_sumsq_clip_multi_f32(int32_t n_tensors, const float *const *grads, con
   }
   mrgcn::k_sumsq_multi<<<dim3(blk), dim3(kTB), 0, (hipStream_t)stream>>>(a, accum, ticket, max_norm, sumsq_out, coef,
                                                                         norm, step_dev, beta1, beta2, bc_dev);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_sumsq_accum_multi_f32(int32_t n_tensors, const float *const *grads, const int64_t *numel, double *accum,
+                                void *stream) {
+  MRGCN_REQUIRE(n_tensors >= 1 && n_tensors <= mrgcn::kMultiMax && grads && numel && accum, "1..16 tensors per call");
+  mrgcn::MultiSumsq a{};
+  a.n_tensors = n_tensors;
+  int blk = 0;
+  for (int t = 0; t < n_tensors; ++t) {
+    MRGCN_REQUIRE(grads[t] && numel[t] >= 0, "NULL tensor");
+    a.g[t] = grads[t];
+    a.n[t] = numel[t];
+    a.blk0[t] = blk;
+    int64_t nb = (numel[t] / 4 + kTB - 1) / kTB;
+    blk += (int)(nb < 1 ? 1 : (nb > 64 ? 64 : nb));
+  }
+  a.blk0[n_tensors] = blk;
+  a.n_extra = 0;
+  mrgcn::k_sumsq_multi_accum<<<dim3(blk), dim3(kTB), 0, (hipStream_t)stream>>>(a, accum);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -221,6 +221,16 @@ __global__ __launch_bounds__(256) void k_chan_sum_part(const float *__restrict__
   if (threadIdx.x == 0) atomicAdd(&out[c], (float)a);
 }
 
+// running statistics of nn.BatchNorm1d in training mode: r = (1 - momentum) r + momentum stat, the variance unbiased
+// (one launch instead of the six elementwise kernels of the module's own update)
+__global__ void k_bn_running(const float *__restrict__ mean, const float *__restrict__ var, int C, float momentum,
+                             float unbias, float *__restrict__ rmean, float *__restrict__ rvar) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
+  rvar[c] = (1.f - momentum) * rvar[c] + momentum * (var[c] * unbias);
+}
+
 inline unsigned nb(int64_t n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
 
 }  // namespace
@@ -265,6 +275,16 @@ int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, 
   const int64_t n_out = (int64_t)B * C * Tout;
   k_bn_relu_pool_fwd<<<dim3(nb(n_out)), dim3(256), 0, s>>>(x, B, C, T, Tout, gamma, beta, mean, var, eps,
                                                          pool_kind, pool_arg, y, argmax);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_bn_running_stats_f32(const float *mean, const float *var, int32_t C, int64_t n, float momentum,
+                               float *running_mean, float *running_var, void *stream) {
+  MRGCN_REQUIRE(mean && var && running_mean && running_var && C > 0 && n > 0, "operands");
+  const float unbias = n > 1 ? (float)((double)n / (double)(n - 1)) : 1.f;
+  k_bn_running<<<dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(mean, var, C, momentum, unbias, running_mean,
+                                                                            running_var);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

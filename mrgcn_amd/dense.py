@@ -225,10 +225,18 @@ def bn_relu_pool(x, bn, pool_kind: int = POOL_NONE, pool_arg: int = 0):
     if bn.training and bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
             bn.num_batches_tracked += 1
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             n = x.shape[0] * x.shape[2]
-            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+            if (bn.momentum is not None and bn.running_mean.is_cuda and bn.running_mean.dtype == torch.float32
+                    and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous()):
+                with torch.cuda.device(x.device):
+                    L.check(L.load().mrgcn_bn_running_stats_f32(
+                        mean.data_ptr(), var.data_ptr(), bn.num_features, n, float(bn.momentum),
+                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _stream(x.device)),
+                        "mrgcn_bn_running_stats_f32")
+            else:  # cumulative average (momentum None): the factor depends on the counter
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
     return y
 
 

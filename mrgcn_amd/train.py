@@ -219,7 +219,8 @@ class ClipAdam(torch.optim.Optimizer):
         hyper = {(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g, _ in live} | \
                 {(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g, _, _ in rowsparse}
         small = [i for i, g in enumerate(grads) if g.numel() <= _MULTI_MAX_NUMEL]
-        multi = (_MULTI and self._dist is None and len(hyper) == 1 and 1 <= len(small) <= 16 and len(rowsparse) <= 16)
+        # (16 tensors per launch: a model with more — an MRGCN with encoders has ~40 — takes a few launches, not 2 x 40)
+        multi = (_MULTI and self._dist is None and len(hyper) == 1 and len(small) >= 1 and len(rowsparse) <= 16)
         with torch.cuda.device(device):
             bias = {}
             if self.capturable:
@@ -243,12 +244,19 @@ class ClipAdam(torch.optim.Optimizer):
                     if i not in small:  # (a large dense gradient: its own streaming pass into the same accumulator)
                         L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), sc["accum"].data_ptr(), s),
                                 "mrgcn_sumsq_accum_f32")
-                gp = (C.c_void_p * len(small))(*[grads[i].data_ptr() for i in small])
-                gn = (C.c_int64 * len(small))(*[grads[i].numel() for i in small])
+                for c0 in range(0, len(small) - 16, 16) if len(small) > 16 else ():
+                    part = small[c0:c0 + 16]
+                    L.check(lib.mrgcn_sumsq_accum_multi_f32(
+                        len(part), (C.c_void_p * len(part))(*[grads[i].data_ptr() for i in part]),
+                        (C.c_int64 * len(part))(*[grads[i].numel() for i in part]), sc["accum"].data_ptr(), s),
+                        "mrgcn_sumsq_accum_multi_f32")
+                last = small[(len(small) - 1) // 16 * 16:]   # the launch that also closes the norm
+                gp = (C.c_void_p * len(last))(*[grads[i].data_ptr() for i in last])
+                gn = (C.c_int64 * len(last))(*[grads[i].numel() for i in last])
                 ex = (C.c_void_p * max(len(rowsparse), 1))(*[ent["sumsq"].data_ptr() for _, _, ent in rowsparse])
                 dstep = self._dev_step.get((b1m, b2m)) if self.capturable else None
                 L.check(lib.mrgcn_sumsq_clip_multi_f32(
-                    len(small), gp, gn, len(rowsparse), ex, sc["accum"].data_ptr(), sc["ticket"].data_ptr(),
+                    len(last), gp, gn, len(rowsparse), ex, sc["accum"].data_ptr(), sc["ticket"].data_ptr(),
                     float(self.max_norm) if use_clip else 0.0, sc["sumsq"].data_ptr(), sc["coef"].data_ptr(),
                     sc["norm"].data_ptr(), dstep[0].data_ptr() if dstep else 0, b1m, b2m,
                     dstep[1].data_ptr() if dstep else 0, s), "mrgcn_sumsq_clip_multi_f32")
@@ -319,18 +327,19 @@ class ClipAdam(torch.optim.Optimizer):
             adam_multi = multi and (self.capturable or len({int(self.state[live[i][1]]["step"]) for i in small}) == 1)
             if adam_multi:
                 b1m, b2m, epsm = next(iter(hyper))
-                sel = [(live[i][0], live[i][1], grads[i]) for i in small]
-                n = len(sel)
-                arr = lambda ptrs: (C.c_void_p * n)(*ptrs)  # noqa: E731
-                L.check(lib.mrgcn_adam_step_multi_f32(
-                    n, arr([p.data_ptr() for _, p, _ in sel]), arr([g.data_ptr() for _, _, g in sel]),
-                    arr([self.state[p]["exp_avg"].data_ptr() for _, p, _ in sel]),
-                    arr([self.state[p]["exp_avg_sq"].data_ptr() for _, p, _ in sel]),
-                    (C.c_int64 * n)(*[p.numel() for _, p, _ in sel]),
-                    (C.c_float * n)(*[float(g["lr"]) for g, _, _ in sel]),
-                    (C.c_float * n)(*[float(g["weight_decay"]) for g, _, _ in sel]), b1m, b2m, epsm,
-                    int(self.state[sel[0][1]]["step"]), bias[(b1m, b2m)].data_ptr() if self.capturable else 0,
-                    coef_ptr, s), "mrgcn_adam_step_multi_f32")
+                for c0 in range(0, len(small), 16):
+                    sel = [(live[i][0], live[i][1], grads[i]) for i in small[c0:c0 + 16]]
+                    n = len(sel)
+                    arr = lambda ptrs: (C.c_void_p * n)(*ptrs)  # noqa: E731
+                    L.check(lib.mrgcn_adam_step_multi_f32(
+                        n, arr([p.data_ptr() for _, p, _ in sel]), arr([g.data_ptr() for _, _, g in sel]),
+                        arr([self.state[p]["exp_avg"].data_ptr() for _, p, _ in sel]),
+                        arr([self.state[p]["exp_avg_sq"].data_ptr() for _, p, _ in sel]),
+                        (C.c_int64 * n)(*[p.numel() for _, p, _ in sel]),
+                        (C.c_float * n)(*[float(g["lr"]) for g, _, _ in sel]),
+                        (C.c_float * n)(*[float(g["weight_decay"]) for g, _, _ in sel]), b1m, b2m, epsm,
+                        int(self.state[sel[0][1]]["step"]), bias[(b1m, b2m)].data_ptr() if self.capturable else 0,
+                        coef_ptr, s), "mrgcn_adam_step_multi_f32")
             for i, ((group, p), g) in enumerate(zip(live, grads)):
                 if adam_multi and i in small:
                     continue
