@@ -77,6 +77,17 @@ def _worker(rank, world, port, state, out, backend="gloo"):
     # the local shard is node-major (S, B, out): back to [B][own nodes][out]
     wI = model.layers["layer_0"].weight_I.detach().cpu().permute(1, 0, 2)[:, : part.n_local]
     out[rank] = (logits0, losses, wI.numpy(), model.layers["layer_1"].weight_F.detach().cpu().numpy())
+    if backend == "nccl":
+        # a step submits its work without waiting for the device anywhere: torch raises on any synchronising call
+        # (the label shard, the plan and the optimizer state exist after the steps above)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            for _ in range(2):
+                partitioned_train_step(model, Xl, idx, y, opt)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
     dist.destroy_process_group()
 
 
