@@ -505,6 +505,17 @@ def main():
         mdist.barrier(dev)
 
     graph_used = False
+    if (partitioned and os.environ.get("MRGCN_PARTITION_GRAPH") == "1" and args.graph
+            and torch.distributed.get_backend() == "nccl"):
+        # opt-in: the partitioned step, collectives included, replayed from a hipGraph (exercised with one rank only)
+        from mrgcn_amd.partition import GraphedPartitionedStep
+        popt = ClipAdam(pmodel.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=True)
+        popt.set_distributed(None, pmodel.sharded_parameters())
+        graphed = GraphedPartitionedStep(pmodel, Xl, idx_np, y_np, popt, warmup=max(args.warmup, 1))
+        graph_used = True
+
+        def step():  # noqa: F811
+            return graphed()
     if args.graph and not partitioned:
         from mrgcn_amd.train import GraphedTrainStep
         try:

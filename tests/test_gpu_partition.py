@@ -132,6 +132,51 @@ def test_partitioned_engine_over_rccl_with_one_rank():
     assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.045
 
 
+def _graphed_worker(rank, world, port, state, out):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from mrgcn_amd.partition import GraphedPartitionedStep, NodePartition, PartitionedRGCN, partitioned_train_step
+    from mrgcn_amd.train import ClipAdam
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev)
+    g, X, idx, y, mods = _problem()
+    N, R = g.num_nodes, g.num_relations
+    part = NodePartition(N, world, rank)
+    res = []
+    for graphed in (False, True):
+        model = PartitionedRGCN(mods, R, N, 5, False, True, part).to(dev)
+        model.load_full_state(state)
+        model.build_plan(g.rows, g.cols, g.vals, dev)
+        Xl = part.shard_rows(torch.from_numpy(X)).to(dev)
+        opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0, capturable=graphed)
+        opt.set_distributed(None, model.sharded_parameters())
+        if graphed:
+            step = GraphedPartitionedStep(model, Xl, idx, y, opt, warmup=2)
+            losses = [float(step()) for _ in range(3)]
+        else:
+            for _ in range(2):
+                partitioned_train_step(model, Xl, idx, y, opt)
+            losses = [float(partitioned_train_step(model, Xl, idx, y, opt)) for _ in range(3)]
+        res.append((losses, model.layers["layer_1"].weight_F.detach().cpu().numpy()))
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_graphed_partitioned_step_over_rccl_with_one_rank():
+    """GraphedPartitionedStep: the partitioned step with its RCCL collectives captured into a hipGraph and replayed
+    gives the eager steps' losses and weights (one rank over the nccl backend: what this box can run)."""
+    state, _, _, _ = _single()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_graphed_worker, args=(1, _free_port(), state, out), nprocs=1, join=True)
+    (l_e, w_e), (l_g, w_g) = out[0]
+    np.testing.assert_allclose(l_g, l_e, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(w_g, w_e, rtol=1e-3, atol=2e-5)
+
+
 def _lp_problem():
     from mrgcn_amd import synth
     g = synth.make_graph("aifb", seed=4, scale=0.25, value_mode="ref_int8")
