@@ -885,6 +885,47 @@ __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dcomp(const int32_t *__restr
   }
 }
 
+// the same for wide layers (F > 64): a WAVE per compact column, lanes along the features — the rows of dM and V are
+// read as whole contiguous rows (a thread per column reads 64 different lines per load: 3 x 110 us at the FB15k-237
+// shape, F = 200), the dot products meet by shuffles, one LDS (or global) atomic per (column, basis)
+__global__ __launch_bounds__(256) void k_mix_bwd_dcomp_wide(const int32_t *__restrict__ urel,
+                                                            const int32_t *__restrict__ unode,
+                                                            const float *__restrict__ dM, int64_t ldM,
+                                                            const float *__restrict__ V, int64_t ldV, int R, int B,
+                                                            int F, int64_t ncols, float *__restrict__ dcomp,
+                                                            int dcomp_in_lds) {
+  extern __shared__ float s_dcomp[];  // [R][B]
+  if (dcomp_in_lds) {
+    for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_dcomp[t] = 0.f;
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < ncols;
+       c += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int r = urel[c];
+    const int64_t j = unode[c];
+    const float *dp = dM + c * ldM;
+    for (int b = 0; b < B; ++b) {
+      const float *vp = V + ((int64_t)j * B + b) * ldV;
+      float dot = 0.f;
+      for (int o = lane; o < F; o += 64) dot = fmaf(dp[o], vp[o], dot);
+#pragma unroll
+      for (int sh = 32; sh > 0; sh >>= 1) dot += __shfl_xor(dot, sh, 64);
+      if (lane == 0 && dot != 0.f) {
+        if (dcomp_in_lds) atomicAdd(&s_dcomp[r * B + b], dot);
+        else atomicAdd(&dcomp[(int64_t)r * B + b], dot);
+      }
+    }
+  }
+  if (dcomp_in_lds) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < R * B; t += blockDim.x) {
+      const float x = s_dcomp[t];
+      if (x != 0.f) atomicAdd(&dcomp[t], x);
+    }
+  }
+}
+
 // =====================================================================================
 // no-bases input term: M[mpos[c], :] = W[ulcol[c], :] (+ addend[c, :])
 // =====================================================================================
@@ -1624,6 +1665,15 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
     int grid = mix_grid(lds, p->ncols);
+    static const bool wide_on = !(getenv("MRGCN_DCOMP_WIDE") && atoi(getenv("MRGCN_DCOMP_WIDE")) == 0);
+    if (F > 64 && wide_on) {  // a wave per column over whole rows
+      const size_t lds_w = in_lds ? (size_t)R * B * sizeof(float) : 0;
+      int64_t blocks = (p->ncols + 3) / 4;
+      if (blocks > 8192) blocks = 8192;
+      k_mix_bwd_dcomp_wide<<<dim3((unsigned)blocks), dim3(256), lds_w, s>>>(p->urel, p->unode, dM, ldM, V, F, R, B, F,
+                                                                         p->ncols, dcomp, in_lds);
+      MRGCN_HIP_TRY(hipGetLastError());
+    } else
     for (int f0 = 0; f0 < F; f0 += 64) {
       const int Ft = (F - f0 < 64) ? (F - f0) : 64;
       const float *dMt = dM + f0, *Vt = V + f0;
