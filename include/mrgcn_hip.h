@@ -516,6 +516,12 @@ int mrgcn_bn_relu_pool_bwd_f32(const float *x, const float *y, const float *dy, 
                                int32_t C, int32_t T, const float *gamma, const float *mean, const float *var,
                                float eps, int32_t training, int32_t pool_kind, int32_t pool_arg, float *dz,
                                float *dx, float *dgamma, float *dbeta, void *workspace, void *stream);
+/* the same, and dx_chan_sum[c] (nullable) = sum over (b, t) of dx[b][c][t]: the bias gradient of the Conv1d in front of
+ * the block, taken inside the pass that writes dx (float atomics, one per (b, c) row) instead of another pass over it */
+int mrgcn_bn_relu_pool_bwd_sum_f32(const float *x, const float *y, const float *dy, const int32_t *argmax, int32_t B,
+                               int32_t C, int32_t T, const float *gamma, const float *mean, const float *var,
+                               float eps, int32_t training, int32_t pool_kind, int32_t pool_arg, float *dz,
+                               float *dx, float *dgamma, float *dbeta, float *dx_chan_sum, void *workspace, void *stream);
 
 /* ---- mini-batch frontier on the resident CSR of the stacked adjacency ---------------------
  * Replaces, per layer of a batch, the host loops of mrgcn/data/batch.py:185-263 (`A[sample_idx]`,

@@ -126,6 +126,8 @@ SIGNATURES = {
                                              _p, _p]),
     "mrgcn_bn_relu_pool_bwd_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, C.c_float, _i32, _i32, _i32,
                                              _p, _p, _p, _p, _p, _p]),
+    "mrgcn_bn_relu_pool_bwd_sum_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, C.c_float, _i32, _i32,
+                                                 _i32, _p, _p, _p, _p, _p, _p, _p]),
     "mrgcn_frontier_workspace_bytes": (C.c_size_t, [_i64, _i64]),
     "mrgcn_frontier_count": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _p, _p, C.c_size_t, _p]),
     "mrgcn_frontier_emit": (C.c_int, [_p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),

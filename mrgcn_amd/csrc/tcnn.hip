@@ -4,6 +4,8 @@
 // saved argmax + ReLU mask + batch-norm backward: two passes over x, no intermediate buffer unless the windows of an
 // adaptive pool overlap).  The convolutions themselves are implicit-im2col products on the matrix cores (encoders.hip).
 // x / dx: [B][C][T] float32; y / dy / argmax: [B][C][Tout].  All of it is HBM-bound elementwise / reduction work.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace mrgcn {
@@ -187,21 +189,32 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const float *__restrict__ x, 
                                                    const float *__restrict__ mean, const float *__restrict__ var,
                                                    float eps, const float *__restrict__ dgamma,
                                                    const float *__restrict__ dbeta, int training,
-                                                   float *__restrict__ dx) {
-  // a wave takes 64 / tp rows (tp = the power of two >= min(T, 64))
-  const int lane = threadIdx.x & 63, rpw = 64 >> tp_log2;
-  const int64_t bc = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> tp_log2);
-  if (bc >= (int64_t)B * C) return;
-  const int c = (int)(bc % C);
+                                                   float *__restrict__ dx, float *__restrict__ chan_sum) {
+  // block (c, y): channel c over the y-th slab of the batch (as the reductions above), a wave takes 64 / tp batch rows
+  // at a time (tp = the power of two >= min(T, 64)); the block's sum of dx goes to chan_sum[c] with ONE atomic
+  // (an atomic per row put 131 k - 1 M of them on two cache lines: +3.8 ms on the TCNN-M step)
+  __shared__ double s_sum[4];
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rpw = 64 >> tp_log2, sub = lane >> tp_log2, t0 = lane & ((1 << tp_log2) - 1);
   const float istd = 1.f / sqrtf(var[c] + eps);
   const float g = (gamma ? gamma[c] : 1.f) * istd;
   const float inv_n = 1.f / (float)((int64_t)B * T);
   const float mu = mean[c], k_b = training ? dbeta[c] * inv_n : 0.f, k_g = training ? dgamma[c] * inv_n : 0.f;
-  const int64_t base = bc * T;
-  for (int t = lane & ((1 << tp_log2) - 1); t < T; t += 1 << tp_log2) {
-    float v = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg_magic);
-    if (training) v = v - k_b - (x[base + t] - mu) * istd * k_g;
-    dx[base + t] = g * v;
+  double rsum = 0.0;
+  for (int b = (blockIdx.y * 4 + wv) * rpw + sub; b < B; b += gridDim.y * 4 * rpw) {
+    const int64_t bc = (int64_t)b * C + c, base = bc * T;
+    for (int t = t0; t < T; t += 1 << tp_log2) {
+      float v = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg_magic);
+      if (training) v = v - k_b - (x[base + t] - mu) * istd * k_g;
+      v *= g;
+      dx[base + t] = v;
+      rsum += (double)v;
+    }
+  }
+  if (chan_sum) {
+    rsum = block_sum(rsum, s_sum);
+    if (threadIdx.x == 0 && rsum != 0.0) atomicAdd(&chan_sum[c], (float)rsum);
   }
 }
 
@@ -302,6 +315,15 @@ int mrgcn_bn_relu_pool_bwd_f32(const float *x, const float *y, const float *dy, 
                                int32_t C, int32_t T, const float *gamma, const float *mean, const float *var,
                                float eps, int32_t training, int32_t pool_kind, int32_t pool_arg, float *dz,
                                float *dx, float *dgamma, float *dbeta, void *workspace, void *stream) {
+  return mrgcn_bn_relu_pool_bwd_sum_f32(x, y, dy, argmax, B, C, T, gamma, mean, var, eps, training, pool_kind, pool_arg,
+                                        dz, dx, dgamma, dbeta, nullptr, workspace, stream);
+}
+
+int mrgcn_bn_relu_pool_bwd_sum_f32(const float *x, const float *y, const float *dy, const int32_t *argmax, int32_t B,
+                                   int32_t C, int32_t T, const float *gamma, const float *mean, const float *var,
+                                   float eps, int32_t training, int32_t pool_kind, int32_t pool_arg, float *dz,
+                                   float *dx, float *dgamma, float *dbeta, float *dx_chan_sum, void *workspace,
+                                   void *stream) {
   MRGCN_REQUIRE(x && y && dy && mean && var && dx && dgamma && dbeta && workspace, "NULL");
   MRGCN_REQUIRE(dz || pool_kind != POOL_ADAPTIVE, "adaptive pooling needs the dz workspace");
   MRGCN_REQUIRE(B > 0 && C > 0 && T > 0, "B / C / T");
@@ -312,20 +334,22 @@ int mrgcn_bn_relu_pool_bwd_f32(const float *x, const float *y, const float *dy, 
   const int64_t n_in = (int64_t)B * C * T, n_out = (int64_t)B * C * Tout;
   double *acc = (double *)workspace;
   MRGCN_HIP_TRY(hipMemsetAsync(acc, 0, mrgcn_bn_workspace_bytes(C), s));
+  if (dx_chan_sum) MRGCN_HIP_TRY(hipMemsetAsync(dx_chan_sum, 0, (size_t)C * sizeof(float), s));
   const dim3 rgrid(C, bn_slabs(B, C));
   const uint32_t arg_magic = (pool_kind == POOL_MAX && pool_arg > 1) ? (uint32_t)((((uint64_t)1) << 32) / (uint64_t)pool_arg + 1) : 0u;
   MRGCN_REQUIRE(pool_kind != POOL_MAX || (int64_t)T * pool_arg < ((int64_t)1 << 32), "sequence too long");
   int tp_log2 = 0;
   while (tp_log2 < 6 && (1 << tp_log2) < T) ++tp_log2;
   const int rpw = 64 >> tp_log2;
-  const dim3 xgrid((unsigned)(((int64_t)B * C + 4 * rpw - 1) / (4 * rpw)));
+  unsigned xslabs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(((int64_t)B + 4 * rpw - 1) / (4 * rpw), std::max<int64_t>(1, 8192 / C)));
+  const dim3 xgrid(C, xslabs);
 #define BN_BWD_GO(KIND_)                                                                                             \
   do {                                                                                                               \
     k_bn_bwd_reduce_part<KIND_><<<rgrid, dim3(256), 0, s>>>(x, dz, y, dy, argmax, B, C, T, Tout, arg_magic,         \
                                                             tp_log2, mean, var, eps, acc);                                          \
     k_bn_bwd_reduce_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, dgamma, dbeta);                          \
     k_bn_bwd_dx<KIND_><<<xgrid, dim3(256), 0, s>>>(x, dz, y, dy, argmax, B, C, T, Tout, arg_magic, tp_log2, gamma,   \
-                                                   mean, var, eps, dgamma, dbeta, training, dx);                                \
+                                                   mean, var, eps, dgamma, dbeta, training, dx, dx_chan_sum);         \
   } while (0)
   if (pool_kind == POOL_ADAPTIVE) {  // windows may overlap: scatter into dz first
     MRGCN_HIP_TRY(hipMemsetAsync(dz, 0, (size_t)n_in * sizeof(float), s));

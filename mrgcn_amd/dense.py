@@ -102,6 +102,15 @@ def linear(x, W, b=None, relu: bool = False):
     return _Linear.apply(x, W, b, relu)
 
 
+def _chan_sum_of(dy, C):
+    """The per-channel sums the producer of this gradient tensor left on it (the batch-norm block's backward writes
+    them beside dx), or None: valid only for the very tensor they were computed for, unmodified since."""
+    m = getattr(dy, "_mrgcn_chan_sum", None)
+    if m is not None and m[0] == dy._version and m[1].numel() == C and m[1].device == dy.device:
+        return m[1]
+    return None
+
+
 class _Conv1d(torch.autograd.Function):
     """nn.Conv1d (stride 1, dilation 1, zero padding) as an implicit-im2col product on the matrix cores:
     y[b, co, t] = bias[co] + sum_{ci, kw} W[co, ci, kw] x[b, ci, t + kw - pad]."""
@@ -148,6 +157,8 @@ class _Conv1d(torch.autograd.Function):
                 dWt = torch.zeros((Cin * KW, Cout), dtype=torch.float32, device=dy.device)
             dW = dWt.t().reshape(Cout, Cin, KW).contiguous()
         if ctx.has_b and ctx.needs_input_grad[2]:
+            db = _chan_sum_of(dy, Cout)
+        if ctx.has_b and ctx.needs_input_grad[2] and db is None:
             db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
             with torch.cuda.device(dy.device):
                 L.check(L.load().mrgcn_channel_sum_f32(dy.data_ptr(), Bn, Cout, Tout, db.data_ptr(), _stream(dy.device)),
@@ -202,12 +213,16 @@ class _BnReluPool(torch.autograd.Function):
         dbeta = torch.empty(Cn, dtype=torch.float32, device=x.device)
         lib = L.load()
         ws = torch.empty(int(lib.mrgcn_bn_workspace_bytes(Cn)), dtype=torch.uint8, device=x.device)
+        # per-channel sums of dx, taken in the pass that writes it: what the convolution in front of this block needs as
+        # its bias gradient (handed over on the gradient tensor, _chan_sum_of)
+        cs = torch.empty(Cn, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            L.check(lib.mrgcn_bn_relu_pool_bwd_f32(
+            L.check(lib.mrgcn_bn_relu_pool_bwd_sum_f32(
                 x.data_ptr(), y.data_ptr(), dy.data_ptr(), am.data_ptr() if am is not None else 0, Bn, Cn, T,
                 gamma.data_ptr() if gamma is not None else 0, mean.data_ptr(), var.data_ptr(), eps, int(training),
-                kind, arg, dz.data_ptr() if dz is not None else 0, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
-                _stream(x.device)), "mrgcn_bn_relu_pool_bwd_f32")
+                kind, arg, dz.data_ptr() if dz is not None else 0, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                cs.data_ptr(), ws.data_ptr(), _stream(x.device)), "mrgcn_bn_relu_pool_bwd_sum_f32")
+        dx._mrgcn_chan_sum = (dx._version, cs)
         return dx, (dgamma if gamma is not None else None), (dbeta if gamma is not None else None), None, None, \
             None, None, None, None
 

@@ -499,3 +499,33 @@ def test_a_cpu_encoder_next_to_a_gpu_rgcn_is_refused():
     F = [["xsd.numeric", [[torch.randn((5, 4), device="cuda"), torch.arange(5, device="cuda"), None]], False]]
     with pytest.raises(_lib.MrgcnError, match="CPU"):
         model._compute_modality_embeddings(F, torch.arange(20), full_batch=True)
+
+
+@pytest.mark.gpu
+def test_conv_bias_gradient_handed_over_by_the_batchnorm_block(monkeypatch):
+    """Conv1d -> BatchNorm1d/ReLU/pool: the block's backward leaves the per-channel sums of its dx on the gradient
+    tensor and the convolution's backward takes them as its bias gradient (no second pass over dx) — equal to the sum
+    computed from dx, and not used when the gradient tensor is another one."""
+    from mrgcn_amd import dense
+    gen = torch.Generator("cuda").manual_seed(9)
+    taken = []
+    real = dense._chan_sum_of
+
+    def spy(dy, C):
+        r = real(dy, C)
+        taken.append(r is not None)
+        return r
+
+    monkeypatch.setattr(dense, "_chan_sum_of", spy)
+    for (B, Cin, T, Cout, kind, arg) in [(6, 5, 40, 7, 1, 3), (9, 4, 3, 130, 0, 0), (3, 3, 70, 64, 2, 3)]:
+        x = torch.randn((B, Cin, T), device="cuda", generator=gen, requires_grad=True)
+        W = torch.randn((Cout, Cin, 3), device="cuda", generator=gen, requires_grad=True)
+        b = torch.randn((Cout,), device="cuda", generator=gen, requires_grad=True)
+        bn = torch.nn.BatchNorm1d(Cout).cuda().train()
+        y = dense.conv1d(x, W, b, padding=1)
+        y.retain_grad()
+        z = dense.bn_relu_pool(y, bn, kind, arg)
+        (z * torch.randn(z.shape, device="cuda", generator=gen)).sum().backward()
+        assert taken and taken[-1]                                     # the hand-over happened
+        torch.testing.assert_close(b.grad, y.grad.sum(dim=(0, 2)), rtol=1e-4, atol=1e-4)
+        assert real(y.grad.clone(), Cout) is None                      # another tensor carries nothing
