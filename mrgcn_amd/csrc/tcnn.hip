@@ -43,15 +43,17 @@ __device__ inline double block_sum(double v, double *s) {  // 256 threads
 // batch statistics: block (c, y) sums channel c over the batch slab y (a wave per batch row, lanes along t:
 // coalesced), fp64 partials meet in acc[c][2] (zeroed by the launcher); a second tiny kernel turns them into mean
 // and biased variance.  (One block per channel left 64-channel layers on a quarter of the chip.)
-__global__ __launch_bounds__(256) void k_bn_stats_part(const float *__restrict__ x, int B, int C, int T,
+__global__ __launch_bounds__(256) void k_bn_stats_part(const float *__restrict__ x, int B, int C, int T, int tp_log2,
                                                        double *__restrict__ acc) {
   __shared__ double s[4];
   const int c = blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // a wave takes 64 / tp batch rows at a time (tp = the power of two >= min(T, 64)): short sequences fill the lanes
+  const int rpw = 64 >> tp_log2, sub = lane >> tp_log2, t0 = lane & ((1 << tp_log2) - 1);
   double a = 0.0, q = 0.0;
-  for (int b = blockIdx.y * 4 + wv; b < B; b += gridDim.y * 4) {
+  for (int b = (blockIdx.y * 4 + wv) * rpw + sub; b < B; b += gridDim.y * 4 * rpw) {
     const float *row = x + ((int64_t)b * C + c) * T;
-    for (int t = lane; t < T; t += 64) {
+    for (int t = t0; t < T; t += 1 << tp_log2) {
       const double v = row[t];
       a += v;
       q += v * v;
@@ -74,32 +76,39 @@ __global__ void k_bn_stats_fin(const double *__restrict__ acc, int C, int64_t n,
   var[c] = (float)(vv > 0.0 ? vv : 0.0);
 }
 
-// thread per output element
-__global__ void k_bn_relu_pool_fwd(const float *__restrict__ x, int B, int C, int T, int Tout,
-                                   const float *__restrict__ gamma, const float *__restrict__ beta,
-                                   const float *__restrict__ mean, const float *__restrict__ var, float eps,
-                                   int kind, int arg, float *__restrict__ y, int32_t *__restrict__ argmax) {
-  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= (int64_t)B * C * Tout) return;
-  const int to = (int)(o % Tout);
-  const int64_t bc = o / Tout;
-  const int c = (int)(bc % C);
+// block (c, y): channel c over the y-th slab of the batch; a wave takes 64 / tp rows of OUTPUT positions at a time
+// (tp = the power of two >= min(Tout, 64)), a lane walks its pooling window (no per-element index divisions)
+__global__ __launch_bounds__(256) void k_bn_relu_pool_fwd(const float *__restrict__ x, int B, int C, int T, int Tout,
+                                                          int tp_log2, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta,
+                                                          const float *__restrict__ mean, const float *__restrict__ var,
+                                                          float eps, int kind, int arg, float *__restrict__ y,
+                                                          int32_t *__restrict__ argmax) {
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rpw = 64 >> tp_log2, sub = lane >> tp_log2, o0 = lane & ((1 << tp_log2) - 1);
   // (x - mean) first: folding the mean into a bias (x * sc + sh) cancels badly when |mean| >> std
   const float mu = mean[c], sc = (gamma ? gamma[c] : 1.f) / sqrtf(var[c] + eps), sh = beta ? beta[c] : 0.f;
-  int t0, t1;
-  pool_window(kind, arg, T, to, t0, t1);
-  const float *row = x + bc * T;
-  float best = -1.f;
-  int bi = t0;
-  for (int t = t0; t < t1; ++t) {
-    const float z = fmaxf((row[t] - mu) * sc + sh, 0.f);
-    if (z > best) {  // first maximum wins (ATen's order)
-      best = z;
-      bi = t;
+  for (int b = (blockIdx.y * 4 + wv) * rpw + sub; b < B; b += gridDim.y * 4 * rpw) {
+    const int64_t bc = (int64_t)b * C + c;
+    const float *row = x + bc * T;
+    for (int to = o0; to < Tout; to += 1 << tp_log2) {
+      int t0, t1;
+      pool_window(kind, arg, T, to, t0, t1);
+      float best = -1.f;
+      int bi = t0;
+      for (int t = t0; t < t1; ++t) {
+        const float z = fmaxf((row[t] - mu) * sc + sh, 0.f);
+        if (z > best) {  // first maximum wins (ATen's order)
+          best = z;
+          bi = t;
+        }
+      }
+      const int64_t o = bc * Tout + to;
+      y[o] = best;
+      if (argmax) argmax[o] = bi;
     }
   }
-  y[o] = best;
-  if (argmax) argmax[o] = bi;
 }
 
 // dz[b][c][argmax] += dy where y > 0 (dz zeroed by the caller); windows of an adaptive pool may overlap
@@ -220,15 +229,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const float *__restrict__ x, 
 
 // out[c] += sum over (b, t) of x[b][c][t] (out zeroed by the launcher): the bias gradient of a Conv1d.  Block (c, y)
 // sums its batch slab in fp64, one float atomic per block
-__global__ __launch_bounds__(256) void k_chan_sum_part(const float *__restrict__ x, int B, int C, int T,
+__global__ __launch_bounds__(256) void k_chan_sum_part(const float *__restrict__ x, int B, int C, int T, int tp_log2,
                                                        float *__restrict__ out) {
   __shared__ double s[4];
   const int c = blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rpw = 64 >> tp_log2, sub = lane >> tp_log2, t0 = lane & ((1 << tp_log2) - 1);
   double a = 0.0;
-  for (int b = blockIdx.y * 4 + wv; b < B; b += gridDim.y * 4) {
+  for (int b = (blockIdx.y * 4 + wv) * rpw + sub; b < B; b += gridDim.y * 4 * rpw) {
     const float *row = x + ((int64_t)b * C + c) * T;
-    for (int t = lane; t < T; t += 64) a += (double)row[t];
+    for (int t = t0; t < T; t += 1 << tp_log2) a += (double)row[t];
   }
   a = block_sum(a, s);
   if (threadIdx.x == 0) atomicAdd(&out[c], (float)a);
@@ -260,6 +270,12 @@ int32_t mrgcn_pool_out_len(int32_t pool_kind, int32_t pool_arg, int32_t T) {
 
 size_t mrgcn_bn_workspace_bytes(int32_t C) { return C > 0 ? (size_t)C * 2 * sizeof(double) : 0; }
 
+static inline int tp_log2_of(int T) {  // log2 of the power of two >= min(T, 64)
+  int l = 0;
+  while (l < 6 && (1 << l) < T) ++l;
+  return l;
+}
+
 static inline unsigned bn_slabs(int B, int C) {
   int s = 2048 / (C > 0 ? C : 1);
   if (s < 1) s = 1;
@@ -282,12 +298,16 @@ int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, 
   if (training) {
     double *acc = (double *)workspace;
     MRGCN_HIP_TRY(hipMemsetAsync(acc, 0, mrgcn_bn_workspace_bytes(C), s));
-    k_bn_stats_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, acc);
+    k_bn_stats_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, tp_log2_of(T), acc);
     k_bn_stats_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, (int64_t)B * T, mean, var);
   }
-  const int64_t n_out = (int64_t)B * C * Tout;
-  k_bn_relu_pool_fwd<<<dim3(nb(n_out)), dim3(256), 0, s>>>(x, B, C, T, Tout, gamma, beta, mean, var, eps,
-                                                         pool_kind, pool_arg, y, argmax);
+  {
+    const int tpo = tp_log2_of(Tout), rpw = 64 >> tpo;
+    const unsigned slabs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(((int64_t)B + 4 * rpw - 1) / (4 * rpw),
+                                                                             std::max<int64_t>(1, 8192 / C)));
+    k_bn_relu_pool_fwd<<<dim3(C, slabs), dim3(256), 0, s>>>(x, B, C, T, Tout, tpo, gamma, beta, mean, var, eps, pool_kind,
+                                                           pool_arg, y, argmax);
+  }
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
@@ -306,7 +326,7 @@ int mrgcn_channel_sum_f32(const float *x, int32_t B, int32_t C, int32_t T, float
   MRGCN_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "operands");
   hipStream_t s = (hipStream_t)stream;
   MRGCN_HIP_TRY(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s));
-  k_chan_sum_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, out);
+  k_chan_sum_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, tp_log2_of(T), out);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
@@ -338,8 +358,7 @@ int mrgcn_bn_relu_pool_bwd_sum_f32(const float *x, const float *y, const float *
   const dim3 rgrid(C, bn_slabs(B, C));
   const uint32_t arg_magic = (pool_kind == POOL_MAX && pool_arg > 1) ? (uint32_t)((((uint64_t)1) << 32) / (uint64_t)pool_arg + 1) : 0u;
   MRGCN_REQUIRE(pool_kind != POOL_MAX || (int64_t)T * pool_arg < ((int64_t)1 << 32), "sequence too long");
-  int tp_log2 = 0;
-  while (tp_log2 < 6 && (1 << tp_log2) < T) ++tp_log2;
+  const int tp_log2 = tp_log2_of(T);
   const int rpw = 64 >> tp_log2;
   unsigned xslabs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(((int64_t)B + 4 * rpw - 1) / (4 * rpw), std::max<int64_t>(1, 8192 / C)));
   const dim3 xgrid(C, xslabs);
