@@ -400,6 +400,10 @@ int mrgcn_distmult_score_bwd_f32(const float *E, int64_t ldE, const float *Rel, 
 /* ... and those three permutations (any may be NULL): stable radix sorts of the subject / predicate / object columns
  * over the bits ids below num_nodes / num_relations can have (replaces three torch.argsort calls of the run loop's
  * autograd: a merge sort of ~30 launches per column).  workspace: mrgcn_distmult_orders_workspace(n) bytes. */
+/* out[i] = pi(i) for i < k, pi a bijection of [0, n) keyed by the device word *seed_dev (a Feistel network with cycle
+ * walking): k distinct pseudo-random indices below n in one launch — the corrupted facts of the device-side negative
+ * sampler (tasks/link_prediction.py sample_negatives_device; torch.randperm(n)[:k] sorts n keys). */
+int mrgcn_random_subset_i64(int64_t n, int64_t k, const int64_t *seed_dev, int64_t *out, void *stream);
 int64_t mrgcn_distmult_orders_workspace(int64_t n);
 int mrgcn_distmult_orders(const int64_t *triples, int64_t n, int64_t num_nodes, int64_t num_relations,
                           int64_t *order_s, int64_t *order_p, int64_t *order_o, void *workspace,

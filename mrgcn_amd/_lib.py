@@ -104,6 +104,7 @@ SIGNATURES = {
     "mrgcn_distmult_score_bwd_sorted_f32": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64,
                                                       _p, _i64, _p]),
     "mrgcn_bce_logits_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p]),
+    "mrgcn_random_subset_i64": (C.c_int, [_i64, _i64, _p, _p, _p]),
     "mrgcn_distmult_orders_workspace": (C.c_int64, [_i64]),
     "mrgcn_distmult_orders": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "mrgcn_distmult_ranks_workspace": (C.c_int64, [_i64, _i32, _i64]),

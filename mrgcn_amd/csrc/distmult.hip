@@ -347,7 +347,58 @@ inline size_t orders_sort_temp(int64_t n) {
 }
 }  // namespace
 
+namespace {
+// out[i] = pi(i), i < k: pi a keyed bijection of [0, n) — a six-round Feistel network over the next even number of bits,
+// walked along its cycle until it lands below n.  A random subset without replacement in ONE launch; torch.randperm(n)[:k]
+// sorts n random keys (a merge sort of 19 launches at n = 272 k: 0.13 ms of the 1.9 ms FB15k-237 epoch).
+__device__ __forceinline__ uint32_t feistel_f(uint32_t r, uint32_t key) {
+  uint32_t h = r * 0x9E3779B1u + key;
+  h ^= h >> 15;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+__global__ void k_random_subset(int64_t n, int64_t k, const int64_t *__restrict__ seed, int half_bits,
+                                int64_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const uint64_t sd = (uint64_t)*seed;
+  uint32_t key[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) key[r] = feistel_f((uint32_t)(sd >> (r & 1 ? 32 : 0)) + 0x632BE5ABu * (r + 1), (uint32_t)(sd >> 17) ^ (r * 0x27D4EB2Fu));
+  const uint64_t mask = (1ull << half_bits) - 1;
+  uint64_t x = (uint64_t)i;
+  do {
+    uint32_t L = (uint32_t)(x >> half_bits), R = (uint32_t)(x & mask);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const uint32_t t = L ^ (uint32_t)(feistel_f(R, key[r]) & mask);
+      L = R;
+      R = t;
+    }
+    x = ((uint64_t)L << half_bits) | R;
+  } while (x >= (uint64_t)n);
+  out[i] = (int64_t)x;
+}
+}  // namespace
+
 extern "C" {
+
+int mrgcn_random_subset_i64(int64_t n, int64_t k, const int64_t *seed_dev, int64_t *out, void *stream) {
+  MRGCN_REQUIRE(n >= 0 && k >= 0 && k <= n && n < ((int64_t)1 << 62), "0 <= k <= n");
+  if (k == 0) return MRGCN_OK;
+  MRGCN_REQUIRE(seed_dev && out, "NULL");
+  int bits = 2;
+  while (bits < 62 && ((int64_t)1 << bits) < n) ++bits;
+  if (bits & 1) ++bits;
+  MRGCN_REQUIRE(bits / 2 <= 32, "n too large");
+  k_random_subset<<<dim3((unsigned)((k + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(n, k, seed_dev, bits / 2, out);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
 
 int mrgcn_distmult_score_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR, int32_t H,
                              const int64_t *triples, int64_t n, float *scores, void *stream) {

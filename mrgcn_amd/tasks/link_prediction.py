@@ -162,7 +162,11 @@ def sample_negatives_device(batch_data: torch.Tensor, generator=None):
         except AttributeError:
             pass
     ncorrupt = n // 5
-    neg_idx = torch.randperm(n, device=dev, generator=generator)[:ncorrupt]
+    # ncorrupt distinct facts: a keyed bijection of [0, n) evaluated at 0..ncorrupt-1 (one launch; a randperm sorts n keys)
+    seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=dev, generator=generator)
+    neg_idx = torch.empty(ncorrupt, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mrgcn_random_subset_i64(n, ncorrupt, _ptr(seed), _ptr(neg_idx), _stream()), "random_subset")
     nhead = ncorrupt // 2
     ntail = ncorrupt - nhead
     corrupted = batch_data[neg_idx].clone()

@@ -176,3 +176,23 @@ def test_triple_orders_equal_a_stable_argsort(n, N, R, which):
     for c, o in enumerate(outs):
         if o is not None:
             np.testing.assert_array_equal(o.cpu().numpy(), np.argsort(t[:, c], kind="stable"))
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (2, 2), (103, 20), (1000, 1000), (272115, 54423), (5, 0)])
+def test_random_subset_is_a_keyed_bijection(n, k):
+    """mrgcn_random_subset_i64 (the corrupted facts of the device-side negative sampler): k distinct indices below n;
+    k = n gives a permutation; another seed gives another one."""
+    from mrgcn_amd import _lib as L
+    lib = L.load()
+    outs = []
+    for seed in (12345, 987654321):
+        sd = torch.tensor([seed], dtype=torch.int64, device="cuda")
+        out = torch.full((max(k, 1),), -1, dtype=torch.int64, device="cuda")
+        L.check(lib.mrgcn_random_subset_i64(n, k, sd.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        o = out[:k].cpu().numpy()
+        assert ((o >= 0) & (o < n)).all() and len(np.unique(o)) == k
+        outs.append(o)
+    if k >= 20:
+        assert (outs[0] != outs[1]).mean() > 0.5
+        if k < n:   # not simply the first k indices, and spread over the range
+            assert outs[0].max() > n // 2 and (outs[0] != np.arange(k)).mean() > 0.75
