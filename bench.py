@@ -75,6 +75,12 @@ def parse():
                          "partitioned (synth10m = config 5), off (replicas, weak scaling) for the others")
     ap.add_argument("--no-partition", dest="partition", action="store_false")
     ap.add_argument("--spmm-iters", type=int, default=30)
+    ap.add_argument("--probe-child", default="", help=argparse.SUPPRESS)   # (internal: run_probe_child)
+    ap.add_argument("--no-seeds", dest="seeds", action="store_false",
+                    help="skip extra.seeds_ms_per_step (the same K epochs on the graphs of seeds 0-2; default AM run only)")
+    ap.add_argument("--no-side-workloads", dest="side_workloads", action="store_false",
+                    help="skip extra.workloads (fb15k, synth10m, aifb, mutag, AM ref_int8, AM bf16 as compact records; "
+                         "default AM run only)")
     return ap.parse_args()
 
 
@@ -98,6 +104,222 @@ def event_time_ms(fn, iters, stream_ptr):
     lib.mrgcn_event_destroy(e0)
     lib.mrgcn_event_destroy(e1)
     return ms.value / iters
+
+
+def spmm_roofline(plan, F, operand, iters, dev, workload, scale, pmc_ok=True):
+    """`roofline` of the stacked-CSR product of a layer of F outputs on the COMPACT view, with the operand as the
+    layer keeps it: fp32 rows (packed or padded, functional._ld_for) or bf16 rows (`--operand bf16`: 2-byte elements in
+    SURVEY §8d's formula).  HIP events on the launch stream around `iters` back-to-back launches."""
+    import torch
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.functional import _ld_for, _ld_for_bf16
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    bf16 = operand == "bf16"
+    ld = _ld_for_bf16(F) if bf16 else _ld_for(F)
+    M = torch.randn((plan.nop, ld), device=dev)
+    if bf16:
+        M = M.to(torch.bfloat16)
+    if F <= 16 and F % 4:
+        # the output as the layer holds it: the first F columns of rows padded to whole 16-byte pieces
+        Y = torch.empty((plan.num_rows, (F + 3) // 4 * 4), device=dev)[:, :F]
+        t_c = event_time_ms(lambda: plan.spmm(L.VIEW_COMPACT, M, F=F, out=Y, pad_writable=True), iters, stream)
+    else:
+        Y = torch.empty((plan.num_rows, F), device=dev)
+        t_c = event_time_ms(lambda: plan.spmm(L.VIEW_COMPACT, M, F=F, out=Y), iters, stream)
+    bytes_alg = plan.spmm_bytes(F, elem_bytes=2 if bf16 else 4)
+    ach = bytes_alg / (t_c * 1e-3) / 1e9
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/pmc_passes.sh ->
+    # tools/make_spmm_pmc_json.py); the file records the digest of the kernel's sources and is only quoted
+    # when that equals this tree's — otherwise traffic is null
+    traffic, traffic_note = None, "no counter file for this workload"
+    if pmc_ok:
+        try:
+            from mrgcn_amd.build import source_digest
+            fname = {"am": "spmm_pmc_latest.json", "fb15k": "spmm_pmc_fb15k.json"}.get(workload)
+            pm = json.load(open(os.path.join(ROOT, "profiles", fname))) if fname else {}
+            if (pm.get("workload") == workload and pm.get("F") == F and scale == 1.0
+                    and pm.get("operand", "f32") == operand):
+                if pm.get("source_digest") == source_digest():
+                    traffic, traffic_note = pm["hbm_bytes_per_launch"], f"profiles/{fname} (PMC pass of this tree)"
+                else:
+                    traffic_note = f"profiles/{fname} predates the current spmm.hip / plan.hip: not quoted"
+        except Exception as e:  # noqa: BLE001
+            traffic_note = "counter file unreadable: " + str(e)[:80]
+    kern = ("mrgcn::k_spmm3<G,VEC> (one launch: rows of several blocks are finished in-kernel)" if F <= 16
+            else "mrgcn::k_spmm<G,VEC> (+k_spmm_finalize)")
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_note,
+            "kernel": "%s on the compact view, F=%d, ld=%d, %s operand" % (kern, F, ld, operand),
+            "algorithmic_bytes": bytes_alg, "avg_ms": t_c}
+
+
+def epoch_algorithmic_bytes(plan, dims, B, R, N, operand="f32"):
+    """ALGORITHMIC bytes of one epoch of the two-layer node-classification model (every operand counted once, gathered
+    rows counted once however often they are re-read; the per-kernel terms of DESIGN.md §3): forward operand
+    construction + the two products, the backward over the columns / nodes that carry gradient (their counts come from
+    the gradient supports the epoch ran on), clip + Adam on the node blocks with gradient.  None when the epoch did
+    not run on supports (the counts are then unknown without a device read-back)."""
+    sups = sorted(plan.__dict__.get("_supports", {}).values(), key=lambda q: -q.L)
+    if len(dims) != 2 or B <= 0 or len(sups) < 2:
+        return None
+    s0, s1 = sups[0], sups[-1]            # layer 0 (the larger support), layer 1 (the labelled rows')
+    (K0, F0), (_, F1) = dims
+    e = 2 if operand == "bf16" else 4
+    ncols, nnz = plan.ncols, plan.nnz
+    ld0, ld1 = (F0 + 3) // 4 * 4, (F1 + 3) // 4 * 4
+    fwd = 0
+    if K0 > 0:
+        fwd += N * K0 * 4 + R * K0 * F0 * 4 + ncols * (ld0 * 4 + 8)          # layer-0 transform: X once, W, addend out
+    fwd += N * B * F0 * 4 + ncols * ((ld0 * 4 if K0 > 0 else 0) + F0 * e + 8) + N * 4   # basis mix: V once, M out
+    fwd += plan.spmm_bytes(F0, elem_bytes=e)
+    fwd += N * F0 * 4 + R * F0 * F1 * 4 + ncols * (F1 * e + 12)              # layer-1 transform: H once, M out
+    fwd += plan.spmm_bytes(F1, elem_bytes=e)
+    bwd = 0
+    for q, ld, F in ((s1, ld1, F1), (s0, ld0, F0)):
+        bwd += q.E * 8 + q.L * (ld * 4 + 4)                                   # dM over the support
+    bwd += s1.NL * F0 * 4 + s1.L * ld1 * 4 + R * F0 * F1 * 4 * 2 + N * F0 * 4  # layer 1: dW, dX (every row written)
+    bwd += s0.NL * B * F0 * 4 + s0.L * (ld0 * 4 + 2 * B * 4)                   # layer 0: V of the live nodes, D out + in
+    if K0 > 0:
+        bwd += s0.NL * K0 * 4 + s0.L * ld0 * 4 + R * K0 * F0 * 4               # layer 0: dW (X rows of the live nodes)
+    adam = 6 * s0.NL * B * F0 * 4 + s0.L * ld0 * 4                            # p, m, v of the blocks with gradient
+    return {"forward": fwd, "backward": bwd, "adam": adam, "total": fwd + bwd + adam,
+            "live_cols": [s0.L, s1.L], "live_nodes": [s0.NL, s1.NL], "live_entries": [s0.E, s1.E]}
+
+
+def nc_workload(args, name, dev, value_mode=None, operand=None, seed=None, scale=None, steps=None, warmup=None,
+                keep=False):
+    """One node-classification workload on this GPU: synthetic graph of the BASELINE shape, model, ClipAdam, the epoch
+    (hipGraph replay unless --no-graph), `warmup` untimed and `steps` timed epochs.  Returns a record; with `keep`
+    nothing is timed here and the record carries the live objects (the headline: main() times `step` under the
+    contract's barriers and runs its extras on them)."""
+    import torch
+    from mrgcn_amd import synth
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.plan import plan_of
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
+    value_mode = value_mode or args.value_mode
+    operand = operand or args.operand
+    seed = args.seed if seed is None else seed
+    scale = args.scale if scale is None else scale
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    sh = synth.SHAPES[name]
+    t0 = time.time()
+    g = synth.make_graph(name, seed=seed, scale=scale, value_mode=value_mode)
+    N, R, B = g.num_nodes, g.num_relations, sh["bases"]
+    dims = synth.layer_dims(name)
+    featureless = sh["x_width"] == 0
+    idx_np, y_np = synth.make_labels(name, N, seed, scale)
+    if args.reorder:
+        from mrgcn_amd.data import reorder
+        order, inv = reorder.label_reach_order(g.rows, g.cols, N, R, idx_np, hops=len(dims))
+        g.rows, g.cols = reorder.relabel_coo(g.rows, g.cols, N, inv)
+        idx_np = inv[idx_np]
+    torch.manual_seed(seed)
+    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li < len(dims) - 1 else None) for li, (i, o) in enumerate(dims)]
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                (N, R * N)).to(dev)
+    model = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
+    model.set_engine(args.engine)
+    model.set_operand_dtype(operand)
+    X = None if featureless else torch.randn((N, sh["x_width"]), device=dev)
+    idx = torch.from_numpy(idx_np).to(dev)
+    tgt = torch.from_numpy(y_np).to(dev)
+    opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=args.graph)
+    plan = plan_of(A, N, R, operand_row_bytes=model.operand_row_bytes())
+
+    def step():
+        return train_step(model, lambda: model(X, A), idx, tgt, opt)
+    graph_used = False
+    if args.graph:
+        try:
+            graphed = GraphedTrainStep(model, lambda: model(X, A), idx, tgt, opt, warmup=max(warmup, 1))
+            graph_used = True
+
+            def step():  # noqa: F811
+                return graphed()
+        except Exception as e:  # noqa: BLE001  (measurement harness only: time the eager epoch instead)
+            print("bench: hipGraph capture failed (%s); timing eager launches" % str(e)[:200], file=sys.stderr)
+            opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+    setup_s = time.time() - t0
+    ms = final = None
+    if not keep:   # (the headline's timed region is main()'s own: warm-ups, barrier, K steps, barrier)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        final = float(loss)
+    rec = dict(ms_per_step=ms, final_loss=final, setup_s=setup_s, graph_used=graph_used, N=N, R=R, B=B, dims=dims,
+               nnz=plan.nnz, ncols=plan.ncols, featureless=featureless, labelled=int(idx.numel()),
+               params=sum(p.numel() for p in model.parameters()), value_mode=value_mode, operand=operand,
+               scale=scale, seed=seed, x_width=sh["x_width"])
+    if keep:
+        rec.update(g=g, A=A, X=X, idx=idx, tgt=tgt, idx_np=idx_np, y_np=y_np, model=model, opt=opt, plan=plan,
+                   modules=modules, step=step)
+    else:
+        rec["_plan"] = plan  # (the caller measures the product on it, then drops it)
+    return rec
+
+
+def side_workloads(args, dev):
+    """extra.workloads of the default line: the other BASELINE configs, AM with the reference's int8 boundary cast and
+    AM with the bf16 operand, each as a compact record {ms_per_step, spmm_frac, spmm_avg_ms, config}; a workload that
+    fails leaves {"error": ...} and the rest still run."""
+    import gc
+
+    import torch
+    out = {}
+
+    def compact(rec, roof, extra_cfg=None):
+        cfg = {"N": rec["N"], "R": rec["R"], "nnz": rec["nnz"], "layers": rec["dims"], "num_bases": rec["B"],
+               "value_mode": rec["value_mode"], "operand": rec["operand"], "labelled": rec["labelled"],
+               "launch": "hipGraph replay" if rec["graph_used"] else "eager", "steps": rec["steps"]}
+        cfg.update(extra_cfg or {})
+        return {"ms_per_step": rec["ms_per_step"], "spmm_frac": roof["frac"], "spmm_avg_ms": roof["avg_ms"],
+                "spmm_gbps": roof["achieved"], "spmm_algorithmic_bytes": roof["algorithmic_bytes"],
+                "spmm_kernel": roof["kernel"], "final_loss": rec["final_loss"], "setup_s": rec["setup_s"], "config": cfg}
+
+    plan_nc = [("aifb", dict(name="aifb"), 40), ("mutag", dict(name="mutag"), 40),
+               ("am_ref_int8", dict(name="am", value_mode="ref_int8"), 10),
+               ("am_bf16", dict(name="am", operand="bf16"), 10),
+               ("synth10m", dict(name="synth10m"), 5)]
+    for key, kw, steps in plan_nc:
+        try:
+            rec = nc_workload(args, kw["name"], dev, value_mode=kw.get("value_mode", "norm_f32"),
+                              operand=kw.get("operand", "f32"), scale=1.0, steps=steps, warmup=2)
+            rec["steps"] = steps
+            plan = rec.pop("_plan")
+            roof = spmm_roofline(plan, rec["dims"][0][1], rec["operand"], 10, dev, kw["name"], 1.0, pmc_ok=False)
+            ab = epoch_algorithmic_bytes(plan, rec["dims"], rec["B"], rec["R"], rec["N"], rec["operand"])
+            out[key] = compact(rec, roof)
+            if ab:
+                out[key]["epoch_algorithmic_bytes"] = ab["total"]
+                out[key]["epoch_frac"] = ab["total"] / (rec["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
+            del rec, plan
+        except Exception as e:  # noqa: BLE001  (fail-soft: the headline line must still print)
+            out[key] = {"error": (type(e).__name__ + ": " + str(e))[:300]}
+        gc.collect()
+        torch.cuda.empty_cache()
+    try:
+        sub = argparse.Namespace(**vars(args))
+        sub.workload, sub.steps, sub.warmup, sub.no_cpu_baseline, sub.scale = "fb15k", 20, 3, True, 1.0
+        sub.value_mode = "norm_f32"
+        line = main_lp(sub, emit=False)
+        out["fb15k"] = {"ms_per_step": line["ms_per_step"], "spmm_frac": line["roofline"]["frac"],
+                        "spmm_avg_ms": line["roofline"]["avg_ms"], "spmm_gbps": line["roofline"]["achieved"],
+                        "spmm_algorithmic_bytes": line["roofline"]["algorithmic_bytes"],
+                        "spmm_kernel": line["roofline"]["kernel"], "final_loss": line["extra"]["final_loss"],
+                        "rank_500_raw_ms": line["extra"].get("rank_500_raw_ms"),
+                        "rank_500_filtered_ms": line["extra"].get("rank_500_filtered_ms"), "config": line["config"]}
+    except Exception as e:  # noqa: BLE001
+        out["fb15k"] = {"error": (type(e).__name__ + ": " + str(e))[:300]}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(args, shape_name):
@@ -215,7 +437,7 @@ def reference_loop_ms(args, kind, A, X, idx, tgt, modules, R, N, B, featureless,
             return train_step(model, lambda: model(X, A), idx, tgt, opt, row_sparse=None if kind == "train_step" else False)
     else:
         Adam, clip = ((torch.optim.Adam, torch.nn.utils.clip_grad_norm_) if kind == "torch"
-                      else (fast.Adam, fast.clip_grad_norm_))
+                      else (fast.RowSparseAdam, fast.clip_grad_norm_))
         opt = Adam(groups, lr=0.01, weight_decay=0.0)
         criterion = torch.nn.CrossEntropyLoss()
 
@@ -284,7 +506,7 @@ def lp_cpu_baseline(args, sh, train_frac):
             "measured_ms": ms, "sample_scale": sc, "host_cores": cores}
 
 
-def main_lp(args):
+def main_lp(args, emit=True):
     """BASELINE config 4: FB15k-237-shaped link prediction.  One step = one full-batch epoch of
     tasks/link_prediction.py:231-326 — 20 % in-batch negatives (drawn on the device), featureless R-GCN encoder
     (N x 200, 2 bases, ReLU), DistMult scores of positives + negatives, BCE-with-logits, backward,
@@ -364,20 +586,9 @@ def main_lp(args):
     ms_per_step = dt / args.steps * 1e3
     out = None
     if rank == 0:
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        from mrgcn_amd.functional import _ld_for
-        ld = _ld_for(H)
         # the encoder's stacked-CSR product at this shape: rows of 800 bytes, the wide-row kernel (k_spmm<G = 64>)
-        M = torch.randn((plan.nop, ld), device=dev)
-        Yb = torch.empty((plan.num_rows, H), device=dev)
-        t_c = event_time_ms(lambda: plan.spmm(L.VIEW_COMPACT, M, F=H, out=Yb), args.spmm_iters, stream)
-        bytes_alg = plan.spmm_bytes(H)
-        ach = bytes_alg / (t_c * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "traffic_source": "no counter file for this workload",
-                    "kernel": "mrgcn::k_spmm<G,VEC> (+k_spmm_finalize) on the compact view, F=%d, ld=%d" % (H, ld),
-                    "algorithmic_bytes": bytes_alg, "avg_ms": t_c}
-        del M, Yb
+        roofline = spmm_roofline(plan, H, "f32", args.spmm_iters, dev, "fb15k", args.scale)
+        ach = roofline["achieved"]
         extra = {}
         if not partitioned:
             with torch.no_grad():
@@ -420,6 +631,8 @@ def main_lp(args):
             "extra": dict(extra, final_loss=float(loss), setup_s=setup_s, plan_device_mb=plan.device_bytes / 2**20,
                           env_switches=_env_switches()),
         }
+    if not emit:
+        return out
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -427,8 +640,149 @@ def main_lp(args):
         print(json.dumps(out), flush=True)
 
 
+def partitioned_probe(args, name, dev, world, rank, steps=5, warmup=2):
+    """--gpus N on a replica workload: ONE graph of the shape node-partitioned over the N ranks (mrgcn_amd.partition:
+    reduce-scatter of every layer's output rows, all-gather of their gradients, sharded node table) next to the replica
+    line, so that the first multi-GPU run of the driver exercises the partitioned engine on real xGMI links:
+    epoch time, the share of it spent in the collectives, and — the parity requirement of SURVEY §8e — the largest
+    difference between the N-GPU logits and a single-GPU model holding the same parameters."""
+    import torch
+    import torch.distributed as dist
+    from mrgcn_amd import dist as mdist
+    from mrgcn_amd import synth
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.partition import NodePartition, PartitionedRGCN, all_gather_rows, partitioned_train_step
+    from mrgcn_amd.train import ClipAdam
+    sh = synth.SHAPES[name]
+    g = synth.make_graph(name, seed=args.seed, scale=args.scale, value_mode=args.value_mode)
+    N, R, B = g.num_nodes, g.num_relations, sh["bases"]
+    dims = synth.layer_dims(name)
+    featureless = sh["x_width"] == 0
+    idx_np, y_np = synth.make_labels(name, N, args.seed, args.scale)
+    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li < len(dims) - 1 else None) for li, (i, o) in enumerate(dims)]
+    part = NodePartition(N, world, rank)
+    torch.manual_seed(args.seed)
+    pmodel = PartitionedRGCN(modules, R, N, B, featureless, False, part).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(args.seed)   # the same X on every rank
+    X = None if featureless else torch.randn((N, sh["x_width"]), device=dev, generator=gen)
+    out = {"workload": name, "rccl_world": world, "backend": dist.get_backend(), "N": N, "nnz": g.nnz}
+    # parity first (single-GPU graphs only: every rank can hold the whole model): rank 0's full-size model gives the
+    # state every rank shards, and the logits to compare with
+    if g.nnz <= 40_000_000:
+        torch.manual_seed(args.seed)
+        full = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
+        state = {k: v for k, v in full.state_dict().items()}
+        pmodel.load_full_state(state)
+        pmodel.build_plan(g.rows, g.cols, g.vals, dev)
+        Xl = None if X is None else part.shard_rows(X)
+        with torch.no_grad():
+            mine = pmodel(Xl)
+            allrows = all_gather_rows(mine.contiguous())[:N]
+            if rank == 0:
+                A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                            (N, R * N)).to(dev)
+                ref = full(X, A)
+                out["logits_maxdiff_vs_single"] = float((allrows - ref).abs().max())
+                out["logits_absmax"] = float(ref.abs().max())
+                del A, ref
+        del full, state, allrows, mine
+        torch.cuda.empty_cache()
+    else:
+        pmodel.sync_replicated()
+        pmodel.build_plan(g.rows, g.cols, g.vals, dev)
+        Xl = None if X is None else part.shard_rows(X)
+    del X
+    opt = ClipAdam(pmodel.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+    opt.set_distributed(None, pmodel.sharded_parameters())
+
+    def step():
+        return partitioned_train_step(pmodel, Xl, idx_np, y_np, opt)
+    for _ in range(warmup):
+        step()
+    mdist.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    mdist.barrier(dev)
+    out["ms_per_step"] = mdist.max_over_ranks(time.perf_counter() - t0, dev) / steps * 1e3
+    out["final_loss"] = float(loss)
+    # the collectives of one step timed alone, on buffers of the step's sizes: per layer a reduce-scatter of
+    # [Np, out] partial rows (forward) and an all-gather of [S, out] gradient rows (backward)
+    from mrgcn_amd.partition import reduce_scatter_rows
+    bufs = [(torch.randn((part.Np, o), device=dev), torch.randn((part.S, o), device=dev)) for _, o in dims]
+    for _ in range(2):
+        for full_rows, own in bufs:
+            reduce_scatter_rows(full_rows)
+            all_gather_rows(own)
+    mdist.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for full_rows, own in bufs:
+            reduce_scatter_rows(full_rows)
+            all_gather_rows(own)
+    mdist.barrier(dev)
+    out["collective_ms"] = mdist.max_over_ranks(time.perf_counter() - t0, dev) / steps * 1e3
+    out["collective_bytes_per_step"] = sum(2 * part.Np * o * 4 for _, o in dims)
+    return out
+
+
+def run_probe_child(args, workload, k, world, rank, local_rank):
+    """Runs `partitioned_probe` in a CHILD process per rank, with a process group of its own (the parent's rendezvous
+    port + 1 + k): whatever happens in there — an RCCL failure, a rank that runs out of memory while the others wait
+    in a collective — ends with the child (killed after a time limit at the latest) and leaves the parent, its
+    process group and the replica line untouched.  Rank 0 returns the child's record (or the error), the others None."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 1 + k
+    env = dict(os.environ, MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world))
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe-child", workload, "--gpus", str(world),
+           "--seed", str(args.seed), "--value-mode", args.value_mode,
+           "--scale", str(args.scale if workload == args.workload else 1.0)]
+    limit = float(os.environ.get("MRGCN_BENCH_PROBE_TIMEOUT", "420" if workload == "synth10m" else "240"))
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %.0f s" % limit, "rccl_world": world} if rank == 0 else None
+    if rank != 0:
+        return None
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except Exception:  # noqa: BLE001
+                break
+    return {"error": ("exit %d: " % r.returncode) + (r.stderr.strip().splitlines() or ["no output"])[-1][:300],
+            "rccl_world": world}
+
+
+def probe_child_main(args):
+    import torch
+    import torch.distributed as dist
+    from mrgcn_amd import dist as mdist
+    world, rank, local_rank = mdist.env_world()
+    ngpu = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", local_rank % ngpu)
+    torch.cuda.set_device(dev)
+    backend = os.environ.get("MRGCN_DIST_BACKEND", "nccl" if ngpu >= world else "gloo")
+    mdist.init(backend, dev if backend == "nccl" else None)
+    try:
+        rec = partitioned_probe(args, args.probe_child, dev, world, rank)
+    except Exception as e:  # noqa: BLE001
+        rec = {"error": (type(e).__name__ + ": " + str(e))[:300], "rccl_world": world}
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    try:
+        if "error" not in rec:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def main():
     args = parse()
+    if args.probe_child:
+        return probe_child_main(args)
     if args.workload == "fb15k":
         return main_lp(args)
     import torch
@@ -446,87 +800,68 @@ def main():
 
     from mrgcn_amd import _lib as L
     from mrgcn_amd import synth
-    from mrgcn_amd.models.rgcn import RGCN
-    from mrgcn_amd.plan import plan_of
-    from mrgcn_amd.train import ClipAdam, train_step
+    from mrgcn_amd.train import ClipAdam
 
     name = args.workload
     sh = synth.SHAPES[name]
-    t0 = time.time()
-    g = synth.make_graph(name, seed=args.seed, scale=args.scale, value_mode=args.value_mode)
-    N, R, B = g.num_nodes, g.num_relations, sh["bases"]
-    dims = synth.layer_dims(name)
-    featureless = sh["x_width"] == 0
-    idx_np, y_np = synth.make_labels(name, N, args.seed, args.scale)
-    if args.reorder:
-        from mrgcn_amd.data import reorder
-        order, inv = reorder.label_reach_order(g.rows, g.cols, N, R, idx_np, hops=len(dims))
-        g.rows, g.cols = reorder.relabel_coo(g.rows, g.cols, N, inv)
-        idx_np = inv[idx_np]
     if args.partition is None:
         args.partition = name in PARTITIONED_WORKLOADS
     partitioned = args.partition and world > 1
-    torch.manual_seed(args.seed)
-    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li < len(dims) - 1 else None)
-               for li, (i, o) in enumerate(dims)]
-    if not partitioned:
-        A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
-                                    (N, R * N)).to(dev)
-        model = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
-        model.set_engine(args.engine)
-        model.set_operand_dtype(args.operand)
-        X = None if featureless else torch.randn((N, sh["x_width"]), device=dev)
-        idx = torch.from_numpy(idx_np).to(dev)
-        tgt = torch.from_numpy(y_np).to(dev)
-        opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=args.graph)
-        plan = plan_of(A, N, R, operand_row_bytes=model.operand_row_bytes())
-
-        def step():
-            return train_step(model, lambda: model(X, A), idx, tgt, opt)
-    else:
-        # strong scaling: rank g owns node range g, its weight_I rows / Adam state and its columns of A; only
-        # the rank's shard of the model and of the plan is ever built
-        from mrgcn_amd.partition import NodePartition, PartitionedRGCN, partitioned_train_step
-        part = NodePartition(N, world, rank)
-        pmodel = PartitionedRGCN(modules, R, N, B, featureless, False, part).to(dev)
-        pmodel.sync_replicated()
-        plan = pmodel.build_plan(g.rows, g.cols, g.vals, dev)
-        Xl = None if featureless else part.shard_rows(torch.randn((N, sh["x_width"]), device=dev))
-        popt = ClipAdam(pmodel.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
-        popt.set_distributed(None, pmodel.sharded_parameters())
-        model = pmodel
-        idx = torch.from_numpy(idx_np)
-
-        def step():
-            return partitioned_train_step(pmodel, Xl, idx_np, y_np, popt)
-    setup_s = time.time() - t0
 
     def barrier():
         mdist.barrier(dev)
 
     graph_used = False
-    if (partitioned and os.environ.get("MRGCN_PARTITION_GRAPH") == "1" and args.graph
-            and torch.distributed.get_backend() == "nccl"):
-        # opt-in: the partitioned step, collectives included, replayed from a hipGraph (exercised with one rank only)
-        from mrgcn_amd.partition import GraphedPartitionedStep
-        popt = ClipAdam(pmodel.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=True)
-        popt.set_distributed(None, pmodel.sharded_parameters())
-        graphed = GraphedPartitionedStep(pmodel, Xl, idx_np, y_np, popt, warmup=max(args.warmup, 1))
-        graph_used = True
+    live = {}   # the headline's model, plan and inputs: the extras run on them until a leg needs the memory
 
-        def step():  # noqa: F811
-            return graphed()
-    if args.graph and not partitioned:
-        from mrgcn_amd.train import GraphedTrainStep
-        try:
-            graphed = GraphedTrainStep(model, lambda: model(X, A), idx, tgt, opt, warmup=max(args.warmup, 1))
+    def drop_live():
+        import gc
+        live.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    if not partitioned:
+        # the headline: N > 1 runs N replicas of it
+        live = nc_workload(args, name, dev, keep=True)
+        step = live.pop("step")
+        g, idx_np, y_np, modules = live["g"], live["idx_np"], live["y_np"], live["modules"]
+        N, R, B, dims, featureless = live["N"], live["R"], live["B"], live["dims"], live["featureless"]
+        graph_used, setup_s = live["graph_used"], live["setup_s"]
+    else:
+        # strong scaling: rank g owns node range g, its weight_I rows / Adam state and its columns of A; only
+        # the rank's shard of the model and of the plan is ever built
+        from mrgcn_amd.partition import NodePartition, PartitionedRGCN, partitioned_train_step
+        t0 = time.time()
+        g = synth.make_graph(name, seed=args.seed, scale=args.scale, value_mode=args.value_mode)
+        N, R, B = g.num_nodes, g.num_relations, sh["bases"]
+        dims = synth.layer_dims(name)
+        featureless = sh["x_width"] == 0
+        idx_np, y_np = synth.make_labels(name, N, args.seed, args.scale)
+        torch.manual_seed(args.seed)
+        modules = [(i, o, "mrgcn", torch.nn.ReLU() if li < len(dims) - 1 else None)
+                   for li, (i, o) in enumerate(dims)]
+        part = NodePartition(N, world, rank)
+        pmodel = PartitionedRGCN(modules, R, N, B, featureless, False, part).to(dev)
+        pmodel.sync_replicated()
+        live["plan"] = pmodel.build_plan(g.rows, g.cols, g.vals, dev)
+        Xl = None if featureless else part.shard_rows(torch.randn((N, sh["x_width"]), device=dev))
+        popt = ClipAdam(pmodel.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+        popt.set_distributed(None, pmodel.sharded_parameters())
+        live["model"] = pmodel
+
+        def step():
+            return partitioned_train_step(pmodel, Xl, idx_np, y_np, popt)
+        if (os.environ.get("MRGCN_PARTITION_GRAPH") == "1" and args.graph and torch.distributed.get_backend() == "nccl"):
+            # opt-in: the partitioned step, collectives included, replayed from a hipGraph (exercised with one rank only)
+            from mrgcn_amd.partition import GraphedPartitionedStep
+            popt = ClipAdam(pmodel.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=True)
+            popt.set_distributed(None, pmodel.sharded_parameters())
+            graphed = GraphedPartitionedStep(pmodel, Xl, idx_np, y_np, popt, warmup=max(args.warmup, 1))
             graph_used = True
 
             def step():  # noqa: F811
                 return graphed()
-        except Exception as e:  # noqa: BLE001  (measurement harness only: time the eager epoch instead)
-            print("bench: hipGraph capture failed (%s); timing eager launches" % str(e)[:200], file=sys.stderr)
-            opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+        setup_s = time.time() - t0
     for _ in range(args.warmup):
         step()
     barrier()
@@ -538,70 +873,73 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     final_loss = float(loss)
 
+    # --gpus N on a replica workload: the node-partitioned engine on the same graph (and on the 10 M-node graph),
+    # every rank takes part; a failure (RCCL, memory) leaves its message and the replica line still prints
+    part_records = None
+    if world > 1 and not partitioned and os.environ.get("MRGCN_BENCH_PARTITION_PROBE", "1") != "0":
+        part_records = {}
+        probes = [name] + (["synth10m"] if name == "am" and args.scale == 1.0 else [])
+        for k, wl in enumerate(probes):
+            if wl != name:   # drop the replica's model first: the big graph wants the memory
+                step = None
+                drop_live()
+            part_records[wl] = run_probe_child(args, wl, k, world, rank, local_rank)
+            barrier()
+
     out = None
     if rank == 0:
-        # ---- roofline of the dominant sparse kernel: the stacked-CSR SpMM of layer 0 ----
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        F = dims[0][1]
-        from mrgcn_amd.functional import _ld_for
-        ld = _ld_for(F)
-        M = torch.randn((plan.ncols, ld), device=dev)
-        # the output as the layer holds it: the first F columns of rows padded to whole 16-byte pieces
-        Y = torch.empty((plan.num_rows, (F + 3) // 4 * 4), device=dev)[:, :F]
-        t_c = event_time_ms(lambda: plan.spmm(L.VIEW_COMPACT, M, F=F, out=Y, pad_writable=True), args.spmm_iters,
-                            stream)
-        bytes_alg = plan.spmm_bytes(F)
-        ach = bytes_alg / (t_c * 1e-3) / 1e9
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/pmc_passes.sh ->
-        # tools/make_spmm_pmc_json.py); the file records the digest of the kernel's sources and is only quoted
-        # when that equals this tree's — otherwise traffic is null
-        traffic, traffic_note = None, "no counter file for this workload"
-        try:
-            from mrgcn_amd.build import source_digest
-            pm = json.load(open(os.path.join(ROOT, "profiles", "spmm_pmc_latest.json")))
-            if pm.get("workload") == name and pm.get("F") == F and args.scale == 1.0:
-                if pm.get("source_digest") == source_digest():
-                    traffic, traffic_note = pm["hbm_bytes_per_launch"], "profiles/spmm_pmc_latest.json (PMC pass of this tree)"
-                else:
-                    traffic_note = "profiles/spmm_pmc_latest.json predates the current spmm.hip / plan.hip: not quoted"
-        except Exception as e:  # noqa: BLE001
-            traffic_note = "counter file unreadable: " + str(e)[:80]
-        roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                    "kernel": "mrgcn::k_spmm3<G,VEC> (+k_spmm3_finalize) on the compact view, F=%d, ld=%d" % (F, ld),
-                    "algorithmic_bytes": bytes_alg, "avg_ms": t_c}
         extra = {}
-        dY = torch.randn((plan.num_rows, F), device=dev)
-        dM = torch.empty((plan.ncols, ld), device=dev)
-        t_t = event_time_ms(lambda: plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM), args.spmm_iters, stream)
-        extra["spmm_transposed_ms"] = t_t
-        extra["spmm_transposed_gbps"] = bytes_alg / (t_t * 1e-3) / 1e9
-        del dY, dM
-        if (args.renumbered_extra and world == 1 and not args.reorder and not partitioned
-                and plan.nnz <= 40_000_000):
-            try:
-                extra["epoch_ms_nodes_renumbered"] = renumbered_epoch_ms(
-                    args, g, idx_np, y_np, dims, modules, R, N, B, featureless, sh["x_width"], dev)
-            except Exception as e:  # noqa: BLE001  (informational leg only)
-                extra["epoch_ms_nodes_renumbered_error"] = str(e)[:200]
-        if args.reference_loop and world == 1 and not partitioned and plan.nnz <= 40_000_000:
-            for kind, key in (("train_step", "epoch_ms_eager"), ("fast", "epoch_ms_reference_loop"),
-                              ("torch", "epoch_ms_reference_loop_torch_optim"),
-                              ("train_step_dense", "epoch_ms_dense_path")):
+        F = dims[0][1]
+        have_model = "plan" in live
+        plan, model = live.get("plan"), live.get("model")
+        A, X, idx, tgt = live.get("A"), live.get("X"), live.get("idx"), live.get("tgt")
+        if have_model:
+            # ---- roofline of the dominant sparse kernel: the stacked-CSR SpMM of layer 0 ----
+            roofline = spmm_roofline(plan, F, args.operand if not partitioned else "f32", args.spmm_iters, dev, name,
+                                     args.scale)
+        else:
+            roofline = None
+        ach = roofline["achieved"] if roofline else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if have_model and world == 1:
+            bytes_alg_f32 = plan.spmm_bytes(F)
+            dY = torch.randn((plan.num_rows, F), device=dev)
+            dM = torch.empty((plan.ncols, (F + 3) // 4 * 4), device=dev)
+            t_t = event_time_ms(lambda: plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM), args.spmm_iters, stream)
+            extra["spmm_transposed_ms"] = t_t
+            extra["spmm_transposed_gbps"] = bytes_alg_f32 / (t_t * 1e-3) / 1e9
+            del dY, dM
+            ab = epoch_algorithmic_bytes(plan, dims, B, R, N, args.operand)
+            if ab:
+                extra["epoch_algorithmic_bytes"] = ab["total"]
+                extra["epoch_algorithmic_bytes_parts"] = {k: ab[k] for k in ("forward", "backward", "adam")}
+                extra["epoch_frac"] = ab["total"] / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)
+                extra["gradient_support"] = {k: ab[k] for k in ("live_cols", "live_nodes", "live_entries")}
+            if args.renumbered_extra and not args.reorder and plan.nnz <= 40_000_000:
                 try:
-                    extra[key] = reference_loop_ms(args, kind, A, X, idx, tgt, modules, R, N, B, featureless, dev)
+                    extra["epoch_ms_nodes_renumbered"] = renumbered_epoch_ms(
+                        args, g, idx_np, y_np, dims, modules, R, N, B, featureless, sh["x_width"], dev)
                 except Exception as e:  # noqa: BLE001  (informational leg only)
-                    extra[key + "_error"] = str(e)[:200]
-                torch.cuda.empty_cache()
-        if not args.no_literal_spmm:
-            try:  # the reference's own operand layout: dense (R*N) x F, 17.8 GB at AM scale
-                D = torch.randn((R * plan.num_nodes, F), device=dev)
-                t_l = event_time_ms(lambda: plan.spmm(L.VIEW_LITERAL, D, out=Y), args.spmm_iters, stream)
-                extra["spmm_literal_ms"] = t_l
-                extra["spmm_literal_gbps"] = bytes_alg / (t_l * 1e-3) / 1e9
-                del D
-            except Exception as e:  # noqa: BLE001
-                extra["spmm_literal_error"] = str(e)[:200]
+                    extra["epoch_ms_nodes_renumbered_error"] = str(e)[:200]
+            if args.reference_loop and plan.nnz <= 40_000_000:
+                for kind, key in (("train_step", "epoch_ms_eager"), ("fast", "epoch_ms_reference_loop"),
+                                  ("torch", "epoch_ms_reference_loop_torch_optim"),
+                                  ("train_step_dense", "epoch_ms_dense_path")):
+                    try:
+                        extra[key] = reference_loop_ms(args, kind, A, X, idx, tgt, modules, R, N, B, featureless, dev)
+                    except Exception as e:  # noqa: BLE001  (informational leg only)
+                        extra[key + "_error"] = str(e)[:200]
+                    torch.cuda.empty_cache()
+            if not args.no_literal_spmm:
+                try:  # the reference's own operand layout: dense (R*N) x F, 17.8 GB at AM scale
+                    D = torch.randn((R * plan.num_nodes, F), device=dev)
+                    Yl = torch.empty((plan.num_rows, F), device=dev)
+                    t_l = event_time_ms(lambda: plan.spmm(L.VIEW_LITERAL, D, out=Yl), args.spmm_iters, stream)
+                    extra["spmm_literal_ms"] = t_l
+                    extra["spmm_literal_gbps"] = bytes_alg_f32 / (t_l * 1e-3) / 1e9
+                    del D, Yl
+                except Exception as e:  # noqa: BLE001
+                    extra["spmm_literal_error"] = str(e)[:200]
         # the roofline denominator next to what a plain device copy reaches on this
         # box, and the bytes the parameter tail of an epoch has to move
         src = torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB
@@ -609,9 +947,43 @@ def main():
         t_cp = event_time_ms(lambda: dst.copy_(src), 5, stream)
         extra["device_copy_gbps"] = 2 * src.numel() * 4 / (t_cp * 1e-3) / 1e9  # read + write
         del src, dst
-        n_theta = sum(p.numel() for p in model.parameters())
-        extra["param_bytes"] = 4 * n_theta * (1 + 1 + 6)  # grad write, clip read, Adam 3 reads + 3 writes
+        if have_model:
+            n_params = sum(p.numel() for p in model.parameters())
+            extra["param_bytes"] = 4 * n_params * (1 + 1 + 6)  # grad write, clip read, Adam 3 reads + 3 writes
+            extra.update(plan_device_mb=plan.device_bytes / 2**20, long_rows=plan.long_rows,
+                         long_cols=plan.long_cols, max_row_nnz=plan.max_row_nnz)
+            nnz, ncols = plan.nnz, plan.ncols
+        else:
+            n_params, nnz, ncols = None, g.nnz, None
+        if part_records is not None:
+            extra["partitioned"] = part_records
         torch.cuda.synchronize(dev)
+        # seeds 0-2 (report the median): the headline is the seed of --seed, the others run the same
+        # K steps on their own graph / labels / parameters
+        if (world == 1 and name == "am" and args.scale == 1.0 and args.seeds and not partitioned):
+            seeds = {str(args.seed): ms_per_step}
+            import gc
+            step = plan = model = A = X = idx = tgt = None
+            drop_live()
+            for sd in (0, 1, 2):
+                if str(sd) in seeds:
+                    continue
+                try:
+                    r2 = nc_workload(args, name, dev, seed=sd, steps=args.steps, warmup=args.warmup)
+                    seeds[str(sd)] = r2["ms_per_step"]
+                    del r2
+                except Exception as e:  # noqa: BLE001
+                    seeds[str(sd)] = None
+                    extra["seeds_error"] = str(e)[:200]
+                gc.collect()
+                torch.cuda.empty_cache()
+            vals = sorted(v for v in seeds.values() if v is not None)
+            extra["seeds_ms_per_step"] = seeds
+            extra["seeds_median_ms"] = vals[len(vals) // 2] if vals else None
+        if world == 1 and name == "am" and args.scale == 1.0 and args.side_workloads and not partitioned:
+            step = plan = model = A = X = idx = tgt = None
+            drop_live()
+            extra["workloads"] = side_workloads(args, dev)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:
@@ -619,7 +991,6 @@ def main():
             except Exception as e:  # noqa: BLE001
                 cpu = {"value": None, "unit": "ms/epoch", "cores": os.cpu_count(), "kind": "port",
                        "sample": "failed: " + str(e)[:200]}
-        n_params = sum(p.numel() for p in model.parameters())
         out = {
             "metric": "full-batch R-GCN epoch time (ms), AM-shaped graph" if name == "am" else
                       "full-batch R-GCN epoch time (ms), %s-shaped graph" % name,
@@ -628,19 +999,18 @@ def main():
             "scaling": "strong" if partitioned else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{name}-shaped synthetic KG (SURVEY §8d), scale {args.scale:g}",
-                       "N": N, "R": R, "nnz": plan.nnz, "ncols_touched": plan.ncols,
+                       "N": N, "R": R, "nnz": nnz, "ncols_touched": ncols,
                        "layers": dims, "num_bases": B, "value_mode": args.value_mode,
                        "engine": args.engine, "operand": args.operand, "weight_I": "node-major (N, B, out); row-sparse gradient + Adam",
                        "node_order": "label reach first" if args.reorder else "generator (random)",
-                       "launch": "hipGraph replay" if graph_used else "eager", "labelled": int(idx.numel()), "params": n_params,
+                       "launch": "hipGraph replay" if graph_used else "eager", "labelled": int(len(idx_np)), "params": n_params,
+                       "seed": args.seed,
                        "parallelism": ("node-partitioned x%d" % world if partitioned else
                                        "replicas x%d" % world) if world > 1 else "1 GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "spmm_hbm_gbps": ach,
-            "extra": dict(extra, final_loss=final_loss, setup_s=setup_s,
-                          plan_device_mb=plan.device_bytes / 2**20, long_rows=plan.long_rows,
-                          long_cols=plan.long_cols, max_row_nnz=plan.max_row_nnz, env_switches=_env_switches()),
+            "extra": dict(extra, final_loss=final_loss, setup_s=setup_s, env_switches=_env_switches()),
         }
     if world > 1:
         dist.barrier()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MRGCN_ABI_VERSION 2
+#define MRGCN_ABI_VERSION 3
 
 enum mrgcn_status {
   MRGCN_OK = 0,
@@ -327,6 +327,81 @@ int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, const float
 /* flags[i] = 1 when X[i, 0:F] holds anything but (+-)0 — NaN counts — else 0. */
 int mrgcn_rows_nonzero_f32(const float *X, int64_t ld, int32_t F, int64_t nrows, uint8_t *flags,
                            void *stream);
+
+/* ---- gradient support: the backward of a semi-supervised epoch on dense index spaces -------------------------
+ * The reference's autograd multiplies the zeros of a layer's output gradient like everything else
+ * (node_classification.py:439-444 takes the loss over the labelled rows Y_hat[idx] only; graph.py:75,:95 then run
+ * dense).  Which rows of that gradient CAN hold anything follows from the label set and the graph alone: the
+ * labelled rows at the last layer, and below it the source nodes of the columns those rows read.  A support fixes
+ * that knowledge once per (plan, row set): `row_flags` (device, one byte per output row: 1 = the row of dY may be
+ * non-zero) -> the LIVE compact columns (touched by a flagged row), numbered 0..L-1 in (node, relation) order, the
+ * entries of those columns that sit in flagged rows, the nodes that own a live column (NODE_FLAGS: the row set of
+ * the layer below) and the live columns in the plan's relation-major orders.  The calls below then take dM and
+ * every per-column product as [L, ld] arrays indexed by live number: nothing is marked, scanned or skipped per epoch.
+ * Results equal those of the plan-level calls with the matching liveness flags (dead entries add exact zeros).
+ * A support is immutable after creation and refers to its plan (destroy the support first).  create / destroy
+ * allocate and synchronise; the compute calls are stream ordered and capturable. */
+typedef struct mrgcn_support mrgcn_support_t;
+typedef struct mrgcn_support_info {
+  int64_t live_cols;    /* L                                             */
+  int64_t live_entries; /* entries of live columns inside flagged rows   */
+  int64_t live_nodes;   /* nodes that own a live column                  */
+  int64_t device_bytes;
+  int64_t chunks_wide, chunks_narrow; /* relation-major chunks of the two transform orders */
+} mrgcn_support_info_t;
+enum mrgcn_support_array_id {
+  MRGCN_SUP_COL_FLAGS = 0,  /* uint8 [ncols]     1 = live                                   */
+  MRGCN_SUP_NODE_FLAGS = 1, /* uint8 [num_nodes] 1 = owns a live column                     */
+  MRGCN_SUP_LCOL = 2,       /* int32 [L]         compact column of each live column, rising  */
+  MRGCN_SUP_LREL = 3,       /* int32 [L]         its relation                                */
+  MRGCN_SUP_NLPTR = 4,      /* int32 [num_nodes+1] node -> range of live numbers             */
+  MRGCN_SUP_LPTR = 5,       /* int32 [L+1]       entry range of each live column             */
+  MRGCN_SUP_LROW = 6,       /* int32 [E]         output row of each kept entry               */
+  MRGCN_SUP_LVAL = 7,       /* float [E]         its value                                   */
+  MRGCN_SUP_LNODE = 8,      /* int32 [live_nodes] nodes that own a live column, rising       */
+  MRGCN_SUP_LPERM = 9       /* int32 [L]         live numbers in (node band, relation, node) order */
+};
+int mrgcn_support_create(mrgcn_support_t **support, const mrgcn_plan_t *plan, const uint8_t *row_flags,
+                         void *stream);
+int mrgcn_support_destroy(mrgcn_support_t *support);
+int mrgcn_support_info(const mrgcn_support_t *support, mrgcn_support_info_t *h_info);
+int mrgcn_support_array(const mrgcn_support_t *support, int32_t which, const void **d_ptr, int64_t *h_count);
+/* dM[k, 0:F] = sum over the kept entries e of live column k of val[e] * dY[row[e], 0:F] — the TRANSPOSED product
+ * (autograd of torch.mm(A, .), graph.py:75,:95) restricted to the support; rows of dY outside the row set are never
+ * read (they may be unwritten). */
+int mrgcn_support_spmm_t_f32(const mrgcn_support_t *support, const float *dY, int64_t ldY, int32_t F, float *dM,
+                             int64_t ldM, void *stream);
+/* mrgcn_basis_mix_bwd_f32 on the support (dM: [L, ldM] by live number).
+ *   dV == NULL : the norm-only pass in front of mrgcn_support_adam_rows_fused_f32: dcomp and *dV_sumsq (both
+ *                WRITTEN, not accumulated: no zeroing by the caller, fixed summation order) — one pass over the
+ *                live nodes' V blocks that stores each live column's B products, then a relation-major sum of
+ *                those rows: no atomics anywhere.  `workspace`: mrgcn_support_mix_bwd_workspace(support, B) floats.
+ *   dV != NULL : the gradient itself; `dense` != 0 writes every block (zeros for nodes outside the support),
+ *                dense == 0 only the blocks of the support's nodes (row-sparse: mrgcn_adam_step_rows_f32 with
+ *                NODE_FLAGS as row_cur).  dcomp written; *dV_sumsq (nullable) ACCUMULATED into. */
+int64_t mrgcn_support_mix_bwd_workspace(const mrgcn_support_t *support, int32_t B); /* floats */
+int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *support, const float *dM, int64_t ldM, const float *V,
+                              const float *comp, int32_t B, int32_t F, float *dV, int32_t dense, float *dcomp,
+                              double *dV_sumsq, float *workspace, int64_t workspace_floats, void *stream);
+/* mrgcn_adam_step_rows_fused_f32 on the support: row_cur = NODE_FLAGS */
+int mrgcn_support_adam_rows_fused_f32(const mrgcn_support_t *support, const float *dM, int64_t ldM, const float *comp,
+                                      int32_t B, int32_t F, float *param, float *exp_avg, float *exp_avg_sq,
+                                      uint8_t *row_ever, float lr, float beta1, float beta2, float eps, int64_t step,
+                                      const float *bc_dev, const float *grad_scale, void *stream);
+/* mrgcn_rel_transform_bwd_masked_f32 on the support: dW (nullable; written whole) and dX (nullable; every row
+ * written, zeros outside NODE_FLAGS; `relu_mask_from_x` as there).  workspace:
+ * mrgcn_support_rel_transform_bwd_workspace floats. */
+int64_t mrgcn_support_rel_transform_bwd_workspace(const mrgcn_support_t *support, int32_t K, int32_t F,
+                                                  int32_t need_dX, int32_t need_dW);
+int mrgcn_support_rel_transform_bwd_f32(const mrgcn_support_t *support, const float *dM, int64_t ldM, const float *X,
+                                        int64_t ldX, int32_t K, const float *W, int32_t F, float *dX, int64_t lddX,
+                                        float *dW, float *workspace, int64_t workspace_floats,
+                                        int32_t relu_mask_from_x, void *stream);
+/* dlogits[idx[i], 0:C] = *g * drows[i, 0:C] for the n labelled rows ONLY (idx without repeats): the rest of dlogits
+ * is not touched — for a consumer that reads the labelled rows only (mrgcn_support_spmm_t_f32).  The 73 MB zero fill
+ * of mrgcn_softmax_xent_bwd_f32 (AM shape) goes away. */
+int mrgcn_softmax_xent_bwd_rows_f32(const float *drows, const int64_t *idx, int64_t n, int32_t C, const float *g,
+                                    float *dlogits, int64_t ldd, void *stream);
 
 /* ---- epoch kernels around the layers ----------------------------------------------
  * out = dY * (Y > 0): backward of the nn.ReLU between layers (rgcn.py:86-87) */

@@ -27,7 +27,8 @@ _TASK_MODULES = ("mrgcn.tasks.node_classification", "mrgcn.tasks.link_prediction
 
 def patch_task_optimizer(module) -> None:
     """Gives one of the reference's task modules (`mrgcn.tasks.node_classification`, `...link_prediction`) this
-    package's `optim.Adam` and `nn.utils.clip_grad_norm_` (mrgcn_amd.optim): the module's names `optim` and `nn`
+    package's `optim.RowSparseAdam` (as `optim.Adam`) and `nn.utils.clip_grad_norm_` (mrgcn_amd.optim) — the pair that
+    understands the row-sparse node-table gradient; bound together, never one without the other: the module's names `optim` and `nn`
     — `import torch.optim as optim`, `import torch.nn as nn` at its top — are rebound to pass-through namespaces that
     differ from torch's in exactly those two attributes.  The training loop of the module
     (node_classification.py:35-37, :190-193; link_prediction.py:325) then runs unchanged on the row-sparse fast
@@ -47,7 +48,7 @@ def patch_task_optimizer(module) -> None:
             return getattr(self.__dict__["_base"], name)
 
     if hasattr(module, "optim"):
-        module.optim = _Through(torch.optim, Adam=fast.Adam)
+        module.optim = _Through(torch.optim, Adam=fast.RowSparseAdam)
     if hasattr(module, "nn"):
         module.nn = _Through(torch.nn, utils=_Through(torch.nn.utils, clip_grad_norm_=fast.clip_grad_norm_))
 

@@ -21,7 +21,7 @@ OK = 0
 VAL_I8, VAL_F32 = 0, 1
 PLAN_PRUNE_ZEROS, PLAN_REPLICATE, PLAN_NO_REPLICATE, PLAN_LEAN = 1, 2, 4, 8
 VIEW_LITERAL, VIEW_COMPACT, VIEW_TRANSPOSED = 0, 1, 2
-ABI_VERSION = 2  # include/mrgcn_hip.h: MRGCN_ABI_VERSION
+ABI_VERSION = 3  # include/mrgcn_hip.h: MRGCN_ABI_VERSION
 SPMM_RELU, SPMM_PAD_WRITABLE, SPMM_TWO_PASS = 1, 2, 4  # flag word of mrgcn_spmm_f32 / _bf16 (`relu` argument)
 (ARR_ROWPTR, ARR_LCOL, ARR_CCOL, ARR_VAL, ARR_CPTR, ARR_CROW, ARR_CVAL, ARR_UREL, ARR_UNODE,
  ARR_NPTR, ARR_ROWIDX, ARR_ULCOL, ARR_RPERM, ARR_RELPTR, ARR_MPOS, ARR_MCOL, ARR_MVAL, ARR_ROWMAP,
@@ -38,6 +38,14 @@ class PlanInfo(C.Structure):
         "num_rows", "num_nodes", "num_relations", "nnz", "ncols", "max_row_nnz", "max_col_nnz",
         "long_rows", "long_cols", "device_bytes", "operand_rows", "replicas")]
 
+
+class SupportInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "live_cols", "live_entries", "live_nodes", "device_bytes", "chunks_wide", "chunks_narrow")]
+
+
+(SUP_COL_FLAGS, SUP_NODE_FLAGS, SUP_LCOL, SUP_LREL, SUP_NLPTR, SUP_LPTR, SUP_LROW, SUP_LVAL, SUP_LNODE,
+ SUP_LPERM) = range(10)
 
 _p = C.c_void_p
 _i32, _i64, _u32 = C.c_int32, C.c_int64, C.c_uint32
@@ -132,6 +140,19 @@ SIGNATURES = {
     "mrgcn_frontier_workspace_bytes": (C.c_size_t, [_i64, _i64]),
     "mrgcn_frontier_count": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _p, _p, C.c_size_t, _p]),
     "mrgcn_frontier_emit": (C.c_int, [_p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "mrgcn_support_create": (C.c_int, [C.POINTER(_p), _p, _p, _p]),
+    "mrgcn_support_destroy": (C.c_int, [_p]),
+    "mrgcn_support_info": (C.c_int, [_p, C.POINTER(SupportInfo)]),
+    "mrgcn_support_array": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_i64)]),
+    "mrgcn_support_spmm_t_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p]),
+    "mrgcn_support_mix_bwd_workspace": (C.c_int64, [_p, _i32]),
+    "mrgcn_support_mix_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _p, _i32, _p, _p, _p, _i64, _p]),
+    "mrgcn_support_adam_rows_fused_f32": (C.c_int, [_p, _p, _i64, _p, _i32, _i32, _p, _p, _p, _p, C.c_float, C.c_float,
+                                                    C.c_float, C.c_float, _i64, _p, _p, _p]),
+    "mrgcn_support_rel_transform_bwd_workspace": (C.c_int64, [_p, _i32, _i32, _i32, _i32]),
+    "mrgcn_support_rel_transform_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _i64,
+                                                      _i32, _p]),
+    "mrgcn_softmax_xent_bwd_rows_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _i64, _p]),
     "mrgcn_event_create": (C.c_int, [C.POINTER(_p)]),
     "mrgcn_event_destroy": (C.c_int, [_p]),
     "mrgcn_event_record": (C.c_int, [_p, _p]),

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/mrgcn_hip.h"
 
@@ -116,6 +117,25 @@ int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx
 int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *dX, int64_t lddX,
                 hipStream_t s, const uint8_t *col_live = nullptr, const float *mask_src = nullptr,
                 int64_t ldMask = 0, uint8_t *row_live = nullptr, const uint8_t *node_live = nullptr);
+// the same over explicit arrays (a gradient support's live columns: nptr = node -> range of Z rows)
+int segment_sum_arrays(const int32_t *nptr, int64_t num_nodes, int64_t nz_rows, const float *Z, int64_t ldZ, int K,
+                       float *dX, int64_t lddX, hipStream_t s, const float *mask_src, int64_t ldMask);
+
+// internal launchers shared with support.hip
+// Y = v . D on an arbitrary CSR-shaped view (spmm.hip); `partials`: v.n_chunks * kWsFeatures floats
+int spmm_on_view(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, int64_t ldY, float *partials,
+                 hipStream_t s);
+// k_mix_bwd_nm over explicit node -> column-range / relation arrays (rgcn_fused.hip); -1: shape outside its limits
+int mix_bwd_nm_arrays(const int32_t *nptr, const int32_t *urel, int64_t N, int R, int top_rel, const float *dM,
+                      int64_t ldM, const float *V, const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
+                      double *dV_sumsq, hipStream_t s, const uint8_t *col_live, uint8_t *node_cur);
+// k_adam_rows_fused over explicit arrays (rgcn_fused.hip)
+int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8_t *col_live, int64_t N, int R,
+                           const float *dM, int64_t ldM, const float *comp, int32_t B, int32_t F, float *param,
+                           float *exp_avg, float *exp_avg_sq, const uint8_t *row_cur, uint8_t *row_ever, float lr,
+                           float beta1, float beta2, float eps, int64_t step, const float *bc_dev,
+                           const float *grad_scale, hipStream_t s);
+bool xform_use_mfma();
 }  // namespace mrgcn
 
 struct mrgcn_plan {
@@ -220,5 +240,58 @@ struct mrgcn_plan {
       v.chunk_row = r_chunk_row; v.n_multi = r_n_chunks - r_n_long;
     }
     return v;
+  }
+};
+
+// The GRADIENT SUPPORT of a set of output rows on a plan (plan.hip builds it, support.hip computes on it): in a
+// semi-supervised epoch the loss touches the labelled rows only (node_classification.py:439-444), so the rows of a
+// layer's output gradient that can hold anything are known from the label set and the graph alone — and with them the
+// compact columns that receive gradient (the LIVE columns), their source nodes and, among a live column's entries,
+// the ones that multiply a live row.  Built once per (plan, row set); the backward of every epoch then runs on dense
+// index spaces: live columns numbered 0..L-1 in (node, relation) order, dM / the per-column products stored by that
+// number.  Nothing is scanned, marked or skipped per epoch.
+struct mrgcn_support {
+  const mrgcn_plan *plan = nullptr;
+  int device = 0;
+  hipStream_t build_stream = nullptr;
+  int64_t device_bytes = 0;
+  int64_t L = 0, E = 0, NL = 0;  // live columns, live entries (of live columns, in live rows), live nodes
+  uint8_t *col_flags = nullptr;   // [ncols]  1 = live
+  uint8_t *node_flags = nullptr;  // [N]      1 = the node has a live column (the row set of the layer below)
+  uint8_t *node_scratch = nullptr;  // [N]    scratch for kernels that report the nodes they wrote
+  int32_t *lcol = nullptr;        // [L]      compact column id, ascending
+  int32_t *lrel = nullptr;        // [L]      its relation
+  int32_t *nlptr = nullptr;       // [N+1]    node -> range of live columns
+  int32_t *lnode = nullptr;       // [NL]     nodes with a live column, ascending
+  int32_t *lnptr = nullptr;       // [NL+1]   their ranges
+  // the transposed view restricted to live columns x live rows (entries keep the plan's order)
+  int32_t *lptr = nullptr, *lrow = nullptr;
+  float *lval = nullptr;
+  int32_t *t_long_row = nullptr, *t_long_cptr = nullptr, *t_chunk_beg = nullptr, *t_chunk_end = nullptr,
+          *t_chunk_row = nullptr;
+  int32_t t_n_long = 0, t_n_chunks = 0;
+  float *partials = nullptr;
+  struct Order {  // live columns in (node band, relation, node) order, cut like common.hpp: RelOrder
+    int32_t *lperm = nullptr, *lrin = nullptr;  // [L] live index / source node
+    int32_t *chunk_rel = nullptr, *chunk_beg = nullptr, *chunk_end = nullptr, *chunk_ptr = nullptr, *chunk_ids = nullptr;
+    int32_t n_chunks = 0, max_chunks = 0;
+  } wide, narrow;
+  bool has_narrow = false;
+  std::vector<void *> owned;
+  mrgcn::SparseView tview() const {
+    mrgcn::SparseView v;
+    v.rows = L; v.ptr = lptr; v.idx = lrow; v.val = lval;
+    v.n_long = t_n_long; v.n_chunks = t_n_chunks; v.long_row = t_long_row; v.long_cptr = t_long_cptr;
+    v.chunk_beg = t_chunk_beg; v.chunk_end = t_chunk_end; v.chunk_row = t_chunk_row;
+    v.n_multi = t_n_chunks - t_n_long;
+    return v;
+  }
+  mrgcn::RelOrder order_for(int input_width) const {
+    const Order &q = (input_width <= mrgcn::kNarrowInput && has_narrow) ? narrow : wide;
+    mrgcn::RelOrder o;
+    o.rperm = q.lperm; o.rnode = q.lrin; o.rmpos = nullptr; o.relchunk_rel = q.chunk_rel; o.relchunk_beg = q.chunk_beg;
+    o.relchunk_end = q.chunk_end; o.relchunk_ptr = q.chunk_ptr; o.relchunk_ids = q.chunk_ids;
+    o.n_relchunks = q.n_chunks; o.max_relchunks = q.max_chunks;
+    return o;
   }
 };

@@ -756,7 +756,7 @@ int mrgcn_sumsq_accum_multi_f32(int32_t n_tensors, const float *const *grads, co
   a.n_tensors = n_tensors;
   int blk = 0;
   for (int t = 0; t < n_tensors; ++t) {
-    MRGCN_REQUIRE(grads[t] && numel[t] >= 0, "NULL tensor");
+    MRGCN_REQUIRE(grads[t] && numel[t] >= 0 && ((uintptr_t)grads[t] & 15) == 0, "gradient: NULL / 16-byte alignment");
     a.g[t] = grads[t];
     a.n[t] = numel[t];
     a.blk0[t] = blk;

@@ -1113,10 +1113,335 @@ int free_plan_after(mrgcn_plan *p, hipEvent_t ev) {
   return MRGCN_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Gradient support (common.hpp: mrgcn_support): one-off build per (plan, set of live output rows)
+// ---------------------------------------------------------------------------------------------
+// compact columns touched by a live row: one thread per row finds the live ones, the wave walks their entries
+__global__ void k_sup_mark_cols(const uint8_t *__restrict__ row_flags, int64_t nrows, const int32_t *__restrict__ rowptr,
+                                const int32_t *__restrict__ ccol, uint8_t *__restrict__ col_flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool nz = i < nrows && row_flags[i] != 0;
+  int32_t b = 0, n = 0;
+  if (nz) {
+    b = rowptr[i];
+    n = rowptr[i + 1] - b;
+  }
+  uint64_t todo = __ballot(nz);
+  while (todo) {
+    const int L = __ffsll((unsigned long long)todo) - 1;
+    todo &= todo - 1;
+    const int32_t bb = __shfl(b, L, kWave), nn = __shfl(n, L, kWave);
+    for (int32_t e = lane; e < nn; e += kWave) col_flags[ccol[bb + e]] = 1;  // (same value from every writer)
+  }
+}
+// out[i] = flags[idx ? idx[i] : i] != 0 for i < n, out[n] = 0 (so that an exclusive scan over n + 1 ends in the total)
+__global__ void k_sup_flags_i32(const uint8_t *__restrict__ flags, const int32_t *__restrict__ idx, int64_t n,
+                                int32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = flags[idx ? idx[i] : i] != 0;
+  else if (i == n) out[i] = 0;
+}
+// per live column: its number, relation and how many of its entries sit in live rows
+__global__ void k_sup_cols(const uint8_t *__restrict__ col_flags, const int32_t *__restrict__ lpos, int64_t ncols,
+                           const int32_t *__restrict__ urel, const int32_t *__restrict__ cptr,
+                           const int32_t *__restrict__ crow, const uint8_t *__restrict__ row_flags,
+                           int32_t *__restrict__ lcol, int32_t *__restrict__ lrel, int32_t *__restrict__ cnt) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols || !col_flags[c]) return;
+  const int32_t k = lpos[c];
+  lcol[k] = (int32_t)c;
+  lrel[k] = urel[c];
+  int32_t n = 0;
+  for (int32_t e = cptr[c]; e < cptr[c + 1]; ++e) n += row_flags[crow[e]] != 0;
+  cnt[k] = n;
+}
+__global__ void k_sup_entries(const int32_t *__restrict__ lcol, const int32_t *__restrict__ lptr, int64_t L,
+                              const int32_t *__restrict__ cptr, const int32_t *__restrict__ crow,
+                              const float *__restrict__ cval, const uint8_t *__restrict__ row_flags,
+                              int32_t *__restrict__ lrow, float *__restrict__ lval) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= L) return;
+  const int32_t c = lcol[k];
+  int32_t o = lptr[k];
+  for (int32_t e = cptr[c]; e < cptr[c + 1]; ++e) {  // the plan's entry order is kept
+    const int32_t i = crow[e];
+    if (row_flags[i]) {
+      lrow[o] = i;
+      lval[o] = cval[e];
+      ++o;
+    }
+  }
+}
+// the compact columns of a node are contiguous, so are its live ones: nlptr[j] = lpos[nptr[j]]
+__global__ void k_sup_nodes(const int32_t *__restrict__ nptr, const int32_t *__restrict__ lpos, int64_t N,
+                            int32_t *__restrict__ nlptr, uint8_t *__restrict__ node_flags,
+                            int32_t *__restrict__ nflag_i32) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > N) return;
+  const int32_t a = lpos[nptr[j]];
+  nlptr[j] = a;
+  if (j < N) {
+    const int32_t live = lpos[nptr[j + 1]] > a;
+    node_flags[j] = (uint8_t)live;
+    nflag_i32[j] = live;
+  } else {
+    nflag_i32[j] = 0;
+  }
+}
+__global__ void k_sup_lnodes(const int32_t *__restrict__ nflag_i32, const int32_t *__restrict__ npos, int64_t N,
+                             const int32_t *__restrict__ nlptr, int32_t *__restrict__ lnode,
+                             int32_t *__restrict__ lnptr) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > N) return;
+  if (j == N) { lnptr[npos[N]] = nlptr[N]; return; }
+  if (!nflag_i32[j]) return;
+  lnode[npos[j]] = (int32_t)j;
+  lnptr[npos[j]] = nlptr[j];
+}
+// live columns in a relation-major order of the plan: position i of `rperm` -> live position rpos[i]
+__global__ void k_sup_rfill(const int32_t *__restrict__ rperm, const int32_t *__restrict__ rnode,
+                            const int32_t *__restrict__ rflag, const int32_t *__restrict__ rpos, int64_t ncols,
+                            const int32_t *__restrict__ lpos, int32_t *__restrict__ lperm, int32_t *__restrict__ lrin) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncols || !rflag[i]) return;
+  lperm[rpos[i]] = lpos[rperm[i]];
+  lrin[rpos[i]] = rnode[i];
+}
+
+template <typename T> hipError_t sup_alloc(mrgcn_support *q, T **dst, int64_t n) {
+  size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T);
+  hipError_t e = pool_alloc((void **)dst, bytes, q->build_stream);
+  if (e == hipSuccess) {
+    q->device_bytes += (int64_t)bytes;
+    q->owned.push_back(*dst);
+  }
+  return e;
+}
+
+int build_support_order(mrgcn_support *q, Scratch &sc, hipStream_t s, const int32_t *lpos, const int32_t *rperm,
+                        const int32_t *rnode, const int32_t *relptr, int64_t nbands, mrgcn_support::Order *out) {
+  const mrgcn_plan *p = q->plan;
+  const int64_t ncols = p->ncols, R = p->num_relations, ngroups = nbands * R;
+  int32_t *rflag, *rpos, *gptr;
+  MRGCN_HIP_TRY(sc.alloc(&rflag, ncols + 1));
+  MRGCN_HIP_TRY(sc.alloc(&rpos, ncols + 1));
+  MRGCN_HIP_TRY(sc.alloc(&gptr, ngroups + 1));
+  k_sup_flags_i32<<<nblocks(ncols + 1), kTB, 0, s>>>(q->col_flags, rperm, ncols, rflag);
+  MRGCN_HIP_TRY(hipGetLastError());
+  int rc;
+  if ((rc = exclusive_scan_i32(rflag, rpos, ncols + 1, s, sc))) return rc;
+  MRGCN_HIP_TRY(sup_alloc(q, &out->lperm, q->L));
+  MRGCN_HIP_TRY(sup_alloc(q, &out->lrin, q->L));
+  if (ncols > 0) k_sup_rfill<<<nblocks(ncols), kTB, 0, s>>>(rperm, rnode, rflag, rpos, ncols, lpos, out->lperm, out->lrin);
+  k_gather_i32<<<nblocks(ngroups + 1), kTB, 0, s>>>(rpos, relptr, ngroups + 1, gptr);
+  MRGCN_HIP_TRY(hipGetLastError());
+  std::vector<int32_t> h_gptr(ngroups + 1);
+  MRGCN_HIP_TRY(hipMemcpyAsync(h_gptr.data(), gptr, (ngroups + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  std::vector<int32_t> rel, beg, end, ids_by_rel, cptr_rel(R + 1, 0);
+  std::vector<std::vector<int32_t>> by_rel(R);
+  for (int64_t g = 0; g < ngroups; ++g) {
+    const int32_t r = (int32_t)(g % R);
+    for (int32_t b0 = h_gptr[g]; b0 < h_gptr[g + 1]; b0 += kRelChunk) {
+      by_rel[r].push_back((int32_t)rel.size());
+      rel.push_back(r);
+      beg.push_back(b0);
+      end.push_back(std::min(b0 + kRelChunk, h_gptr[g + 1]));
+    }
+  }
+  out->max_chunks = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    cptr_rel[r] = (int32_t)ids_by_rel.size();
+    ids_by_rel.insert(ids_by_rel.end(), by_rel[r].begin(), by_rel[r].end());
+    out->max_chunks = std::max(out->max_chunks, (int32_t)by_rel[r].size());
+  }
+  cptr_rel[R] = (int32_t)ids_by_rel.size();
+  out->n_chunks = (int32_t)rel.size();
+  MRGCN_HIP_TRY(sup_alloc(q, &out->chunk_ptr, R + 1));
+  MRGCN_HIP_TRY(hipMemcpy(out->chunk_ptr, cptr_rel.data(), (R + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  MRGCN_HIP_TRY(sup_alloc(q, &out->chunk_ids, out->n_chunks));
+  MRGCN_HIP_TRY(sup_alloc(q, &out->chunk_rel, out->n_chunks));
+  MRGCN_HIP_TRY(sup_alloc(q, &out->chunk_beg, out->n_chunks));
+  MRGCN_HIP_TRY(sup_alloc(q, &out->chunk_end, out->n_chunks));
+  if (out->n_chunks > 0) {
+    const size_t nb = rel.size() * sizeof(int32_t);
+    MRGCN_HIP_TRY(hipMemcpy(out->chunk_ids, ids_by_rel.data(), nb, hipMemcpyHostToDevice));
+    MRGCN_HIP_TRY(hipMemcpy(out->chunk_rel, rel.data(), nb, hipMemcpyHostToDevice));
+    MRGCN_HIP_TRY(hipMemcpy(out->chunk_beg, beg.data(), nb, hipMemcpyHostToDevice));
+    MRGCN_HIP_TRY(hipMemcpy(out->chunk_end, end.data(), nb, hipMemcpyHostToDevice));
+  }
+  return MRGCN_OK;
+}
+
+int build_support(mrgcn_support *q, const uint8_t *row_flags, hipStream_t s) {
+  const mrgcn_plan *p = q->plan;
+  const int64_t N = p->num_nodes, ncols = p->ncols, rows = p->num_rows;
+  Scratch sc;
+  sc.s = s;
+  MRGCN_HIP_TRY(sup_alloc(q, &q->col_flags, ncols));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->node_flags, N));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->nlptr, N + 1));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->node_scratch, N));
+  MRGCN_HIP_TRY(hipMemsetAsync(q->col_flags, 0, (size_t)std::max<int64_t>(ncols, 1), s));
+  if (rows > 0 && ncols > 0) k_sup_mark_cols<<<nblocks(rows), kTB, 0, s>>>(row_flags, rows, p->rowptr, p->ccol, q->col_flags);
+  MRGCN_HIP_TRY(hipGetLastError());
+  int32_t *cflag, *lpos;
+  MRGCN_HIP_TRY(sc.alloc(&cflag, ncols + 1));
+  MRGCN_HIP_TRY(sc.alloc(&lpos, ncols + 1));
+  k_sup_flags_i32<<<nblocks(ncols + 1), kTB, 0, s>>>(q->col_flags, nullptr, ncols, cflag);
+  MRGCN_HIP_TRY(hipGetLastError());
+  int rc;
+  if ((rc = exclusive_scan_i32(cflag, lpos, ncols + 1, s, sc))) return rc;
+  int32_t hL = 0;
+  MRGCN_HIP_TRY(hipMemcpyAsync(&hL, lpos + ncols, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  q->L = hL;
+  MRGCN_HIP_TRY(sup_alloc(q, &q->lcol, q->L));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->lrel, q->L));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->lptr, q->L + 1));
+  int32_t *cnt;
+  MRGCN_HIP_TRY(sc.alloc(&cnt, q->L + 1));
+  MRGCN_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)(q->L + 1) * sizeof(int32_t), s));
+  if (ncols > 0)
+    k_sup_cols<<<nblocks(ncols), kTB, 0, s>>>(q->col_flags, lpos, ncols, p->urel, p->cptr, p->crow, row_flags, q->lcol,
+                                              q->lrel, cnt);
+  MRGCN_HIP_TRY(hipGetLastError());
+  if ((rc = exclusive_scan_i32(cnt, q->lptr, q->L + 1, s, sc))) return rc;
+  int32_t hE = 0;
+  MRGCN_HIP_TRY(hipMemcpyAsync(&hE, q->lptr + q->L, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  q->E = hE;
+  MRGCN_HIP_TRY(sup_alloc(q, &q->lrow, q->E));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->lval, q->E));
+  if (q->L > 0)
+    k_sup_entries<<<nblocks(q->L), kTB, 0, s>>>(q->lcol, q->lptr, q->L, p->cptr, p->crow, p->cval, row_flags, q->lrow,
+                                                q->lval);
+  MRGCN_HIP_TRY(hipGetLastError());
+  // nodes
+  int32_t *nflag, *npos;
+  MRGCN_HIP_TRY(sc.alloc(&nflag, N + 1));
+  MRGCN_HIP_TRY(sc.alloc(&npos, N + 1));
+  k_sup_nodes<<<nblocks(N + 1), kTB, 0, s>>>(p->nptr, lpos, N, q->nlptr, q->node_flags, nflag);
+  MRGCN_HIP_TRY(hipGetLastError());
+  if ((rc = exclusive_scan_i32(nflag, npos, N + 1, s, sc))) return rc;
+  int32_t hNL = 0;
+  MRGCN_HIP_TRY(hipMemcpyAsync(&hNL, npos + N, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  q->NL = hNL;
+  MRGCN_HIP_TRY(sup_alloc(q, &q->lnode, q->NL));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->lnptr, q->NL + 1));
+  k_sup_lnodes<<<nblocks(N + 1), kTB, 0, s>>>(nflag, npos, N, q->nlptr, q->lnode, q->lnptr);
+  MRGCN_HIP_TRY(hipGetLastError());
+  // split rows of the filtered transposed view (live columns read by more than kLongThreshold live rows)
+  {
+    mrgcn_plan acct;  // build_long charges its arrays to a plan: this one only carries the stream and the byte count
+    acct.build_stream = s;
+    int64_t max_len = 0;
+    rc = build_long(&acct, q->lptr, q->L, s, &q->t_long_row, &q->t_long_cptr, &q->t_chunk_beg, &q->t_chunk_end,
+                    &q->t_chunk_row, &q->t_n_long, &q->t_n_chunks, &max_len);
+    for (void *a : {(void *)q->t_long_row, (void *)q->t_long_cptr, (void *)q->t_chunk_beg, (void *)q->t_chunk_end,
+                    (void *)q->t_chunk_row})
+      if (a) q->owned.push_back(a);
+    q->device_bytes += acct.device_bytes;
+    if (rc != MRGCN_OK) return rc;
+    MRGCN_HIP_TRY(sup_alloc(q, &q->partials, (int64_t)std::max(q->t_n_chunks, 1) * kWsFeatures));
+  }
+  // the two relation-major orders
+  rc = build_support_order(q, sc, s, lpos, p->rperm, p->rnode, p->relptr, p->n_bands, &q->wide);
+  if (rc != MRGCN_OK) return rc;
+  q->has_narrow = p->n_rperm != nullptr;
+  if (q->has_narrow) {
+    rc = build_support_order(q, sc, s, lpos, p->n_rperm, p->n_rnode, p->n_relptr, p->n_n_bands, &q->narrow);
+    if (rc != MRGCN_OK) return rc;
+  }
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));  // (the scratch arrays go back to the pool behind finished work)
+  return MRGCN_OK;
+}
+
+void release_support(mrgcn_support *q) {
+  // like free_plan: wait for the work in flight on the device, then hand the blocks back; a support dropped while a
+  // capture is under way is parked until the next one is released outside a capture
+  static std::vector<mrgcn_support *> parked;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  parked.push_back(q);
+  std::vector<mrgcn_support *> keep;
+  for (mrgcn_support *x : parked) {
+    if (x->device != cur) (void)hipSetDevice(x->device);
+    const uint64_t ep = pool_sync_begin();
+    if (hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      keep.push_back(x);
+    } else {
+      pool_sync_done(ep);
+      for (void *a : x->owned) pool_free(a, x->build_stream, ep);
+      delete x;
+    }
+    if (x->device != cur) (void)hipSetDevice(cur);
+  }
+  parked.swap(keep);
+}
+
 }  // namespace
 }  // namespace mrgcn
 
 extern "C" {
+
+int mrgcn_support_create(mrgcn_support_t **out, const mrgcn_plan_t *plan, const uint8_t *row_flags, void *stream) {
+  using namespace mrgcn;
+  MRGCN_REQUIRE(out && plan && row_flags, "NULL");
+  MRGCN_REQUIRE(!plan->lean, "a lean plan (mini-batch slice) keeps no transposed view to build a support on");
+  mrgcn_support *q = new mrgcn_support();
+  q->plan = plan;
+  (void)hipGetDevice(&q->device);
+  q->build_stream = (hipStream_t)stream;
+  int rc = build_support(q, row_flags, (hipStream_t)stream);
+  if (rc != MRGCN_OK) {
+    release_support(q);
+    return rc;
+  }
+  *out = q;
+  return MRGCN_OK;
+}
+
+int mrgcn_support_destroy(mrgcn_support_t *sup) {
+  if (sup) mrgcn::release_support(sup);
+  return MRGCN_OK;
+}
+
+int mrgcn_support_info(const mrgcn_support_t *q, mrgcn_support_info_t *h) {
+  MRGCN_REQUIRE(q && h, "NULL");
+  h->live_cols = q->L;
+  h->live_entries = q->E;
+  h->live_nodes = q->NL;
+  h->device_bytes = q->device_bytes;
+  h->chunks_wide = q->wide.n_chunks;
+  h->chunks_narrow = q->has_narrow ? q->narrow.n_chunks : 0;
+  return MRGCN_OK;
+}
+
+int mrgcn_support_array(const mrgcn_support_t *q, int32_t which, const void **d_ptr, int64_t *h_count) {
+  MRGCN_REQUIRE(q && d_ptr && h_count, "NULL");
+  const mrgcn_plan *p = q->plan;
+  switch (which) {
+    case MRGCN_SUP_COL_FLAGS: *d_ptr = q->col_flags; *h_count = p->ncols; break;
+    case MRGCN_SUP_NODE_FLAGS: *d_ptr = q->node_flags; *h_count = p->num_nodes; break;
+    case MRGCN_SUP_LCOL: *d_ptr = q->lcol; *h_count = q->L; break;
+    case MRGCN_SUP_LREL: *d_ptr = q->lrel; *h_count = q->L; break;
+    case MRGCN_SUP_NLPTR: *d_ptr = q->nlptr; *h_count = p->num_nodes + 1; break;
+    case MRGCN_SUP_LPTR: *d_ptr = q->lptr; *h_count = q->L + 1; break;
+    case MRGCN_SUP_LROW: *d_ptr = q->lrow; *h_count = q->E; break;
+    case MRGCN_SUP_LVAL: *d_ptr = q->lval; *h_count = q->E; break;
+    case MRGCN_SUP_LNODE: *d_ptr = q->lnode; *h_count = q->NL; break;
+    case MRGCN_SUP_LPERM: *d_ptr = q->wide.lperm; *h_count = q->L; break;
+    default: MRGCN_REQUIRE(false, "unknown support array");
+  }
+  return MRGCN_OK;
+}
 
 int mrgcn_abi_version(void) { return MRGCN_ABI_VERSION; }
 const char *mrgcn_arch(void) { return "gfx950"; }

@@ -1494,12 +1494,11 @@ static int zero_dead_rows(float *dM, int64_t ldM, int F, const uint8_t *col_live
 }
 
 // wave-over-nodes form (k_mix_bwd_nm); MRGCN_OK when it ran, -1 when the shape is outside its limits
-int mix_bwd_nm_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V, const float *comp,
-                      int32_t B, int32_t F, float *dV, float *dcomp, double *dV_sumsq, hipStream_t s,
-                      const uint8_t *col_live, uint8_t *node_cur) {
+int mix_bwd_nm_launch_arrays(const int32_t *nptr, const int32_t *urel, int64_t N, int R, int top_rel, const float *dM,
+                             int64_t ldM, const float *V, const float *comp, int32_t B, int32_t F, float *dV,
+                             float *dcomp, double *dV_sumsq, hipStream_t s, const uint8_t *col_live,
+                             uint8_t *node_cur) {
   static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
-  const int R = (int)p->num_relations;
-  const int64_t N = p->num_nodes;
   bool ok = node_on && F <= 16 && B <= 64 && N > 0;
   if ((F & 1) == 0) ok = ok && (((uintptr_t)V | (uintptr_t)dV) & 7) == 0;  // 8-byte row accesses
   if (!ok) return -1;
@@ -1528,8 +1527,8 @@ int mix_bwd_nm_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const
                                         (int)lds));                                                       \
       lds_allowed = lds;                                                                                  \
     }                                                                                                     \
-    kfn<<<dim3((unsigned)grid), dim3(tb), lds, s>>>(p->nptr, p->urel, dM, ldM, V, comp, N, R, B, F, dV, \
-                                                         dcomp, dV_sumsq, (int)p->top_rel, col_live,     \
+    kfn<<<dim3((unsigned)grid), dim3(tb), lds, s>>>(nptr, urel, dM, ldM, V, comp, N, R, B, F, dV,        \
+                                                         dcomp, dV_sumsq, top_rel, col_live,              \
                                                          node_cur, dc_in_lds);                           \
   } while (0)
   switch (FT) {
@@ -1543,6 +1542,13 @@ int mix_bwd_nm_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const
 #undef NODE_GO
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
+}
+
+int mix_bwd_nm_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *V, const float *comp,
+                      int32_t B, int32_t F, float *dV, float *dcomp, double *dV_sumsq, hipStream_t s,
+                      const uint8_t *col_live, uint8_t *node_cur) {
+  return mix_bwd_nm_launch_arrays(p->nptr, p->urel, p->num_nodes, (int)p->num_relations, (int)p->top_rel, dM, ldM, V,
+                                  comp, B, F, dV, dcomp, dV_sumsq, s, col_live, node_cur);
 }
 
 int mix_bwd_dv_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const float *comp, int32_t B,
@@ -1597,12 +1603,31 @@ int mrgcn_adam_step_rows_fused_f32(const mrgcn_plan_t *p, const float *dM, int64
   MRGCN_REQUIRE(((((uintptr_t)param) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15) == 0,
                 "param / moments must be 16-byte aligned");
   MRGCN_REQUIRE(bc_dev || step >= 1, "step");
-  hipStream_t s = (hipStream_t)stream;
-  const int R = (int)p->num_relations;
-  const int64_t N = p->num_nodes;
   if (p->ncols == 0)  // no column, no gradient: moments of `ever` nodes decay (the gradient pointer is never read)
-    return mrgcn_adam_step_rows_f32(param, param, exp_avg, exp_avg_sq, N, B * F, row_cur, row_ever, lr, beta1,
-                                    beta2, eps, step, bc_dev, grad_scale, stream);
+    return mrgcn_adam_step_rows_f32(param, param, exp_avg, exp_avg_sq, p->num_nodes, B * F, row_cur, row_ever, lr,
+                                    beta1, beta2, eps, step, bc_dev, grad_scale, stream);
+  return mrgcn::adam_rows_fused_arrays(p->nptr, p->urel, col_live, p->num_nodes, (int)p->num_relations, dM, ldM, comp,
+                                       B, F, param, exp_avg, exp_avg_sq, row_cur, row_ever, lr, beta1, beta2, eps,
+                                       step, bc_dev, grad_scale, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace mrgcn {
+bool xform_use_mfma() { return use_mfma(); }
+
+int mix_bwd_nm_arrays(const int32_t *nptr, const int32_t *urel, int64_t N, int R, int top_rel, const float *dM,
+                      int64_t ldM, const float *V, const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
+                      double *dV_sumsq, hipStream_t s, const uint8_t *col_live, uint8_t *node_cur) {
+  return mix_bwd_nm_launch_arrays(nptr, urel, N, R, top_rel, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, s, col_live,
+                                  node_cur);
+}
+
+int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8_t *col_live, int64_t N, int R,
+                           const float *dM, int64_t ldM, const float *comp, int32_t B, int32_t F, float *param,
+                           float *exp_avg, float *exp_avg_sq, const uint8_t *row_cur, uint8_t *row_ever, float lr,
+                           float beta1, float beta2, float eps, int64_t step, const float *bc_dev,
+                           const float *grad_scale, hipStream_t s) {
   float bc1 = 1.f, bc2s = 1.f;
   if (!bc_dev) {
     bc1 = (float)(1.0 - pow((double)beta1, (double)step));
@@ -1623,13 +1648,16 @@ int mrgcn_adam_step_rows_fused_f32(const mrgcn_plan_t *p, const float *dM, int64
       MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       lds_allowed = lds;
     }
-    kfn<<<dim3((unsigned)grid), dim3(kFusedTB), lds, s>>>(p->nptr, p->urel, col_live, dM, ldM, comp, N, R, B, F,
+    kfn<<<dim3((unsigned)grid), dim3(kFusedTB), lds, s>>>(nptr, urel, col_live, dM, ldM, comp, N, R, B, F,
                                                           param, exp_avg, exp_avg_sq, row_cur, row_ever, lr, beta1,
                                                           beta2, eps, bc1, bc2s, grad_scale, bc_dev);
   }
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
+}  // namespace mrgcn
+
+extern "C" {
 
 int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const uint8_t *col_live,
                             const float *V, const float *comp, int32_t B, int32_t F, float *dV,
@@ -1813,9 +1841,12 @@ int mrgcn_rel_transform_bwd_masked_f32(const mrgcn_plan_t *p, float *dM, int64_t
     }
   }
   if (dW) {
-    MRGCN_HIP_TRY(hipMemsetAsync(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
+    const RelOrder o = p->order_for(K);
+    // (the matrix-core form with a slab workspace zeroes dW inside its first launch)
+    const bool self_zero = use_mfma() && xform_mfma_dw_supported(K, F) && workspace &&
+                           workspace_floats >= (int64_t)o.n_relchunks * K * F;
+    if (!self_zero) MRGCN_HIP_TRY(hipMemsetAsync(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
     if (use_mfma() && xform_mfma_dw_supported(K, F)) {
-      const RelOrder o = p->order_for(K);
       int rc = xform_mfma_dw(p, o, o.rnode, X, ldX, K, dM, ldM, F, dW, workspace, workspace_floats, s, col_live);
       if (rc != MRGCN_OK) return rc;
     } else if (p->n_relchunks > 0) {

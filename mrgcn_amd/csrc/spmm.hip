@@ -1145,6 +1145,23 @@ View3 view3_of(const mrgcn_plan *p) {
 }
 
 }  // namespace
+
+// Y = v . D for any CSR-shaped view (the filtered transposed view of a gradient support): mrgcn_spmm_f32's tiling
+// without bias / ReLU / redirection.  The operand rows such a view reads are few (the live rows of a layer's output
+// gradient) and stay cache resident.
+int spmm_on_view(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, int64_t ldY, float *partials,
+                 hipStream_t s) {
+  if (v.rows == 0) return MRGCN_OK;
+  int tile = 64;
+  if (ldD % 4 == 0 && ((uintptr_t)D) % 16 == 0) tile = 256;
+  else if (ldD % 2 == 0 && ((uintptr_t)D) % 8 == 0) tile = 128;
+  for (int f = 0; f < F; f += tile) {
+    const int w = (F - f < tile) ? (F - f) : tile;
+    int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, nullptr, 0, nullptr, partials, false, true, s, nullptr);
+    if (rc != MRGCN_OK) return rc;
+  }
+  return MRGCN_OK;
+}
 }  // namespace mrgcn
 
 namespace mrgcn {

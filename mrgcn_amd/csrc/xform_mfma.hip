@@ -218,9 +218,14 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
     const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
     const int32_t *__restrict__ rin_idx, const float *__restrict__ In, int64_t ldIn, int K,
     const float *__restrict__ G, int64_t ldG, int F, float *__restrict__ dW,
-    float *__restrict__ slab, const uint8_t *__restrict__ col_live) {
+    float *__restrict__ slab, const uint8_t *__restrict__ col_live, int64_t zero_dw) {
   extern __shared__ float dWs[];  // [4 waves][K*F]: every wave stores its own partial tile set
   const int chunk = blockIdx.x;
+  if (slab && zero_dw > 0) {  // k_dw_reduce, the next launch, adds into dW: the zero fill rides along here
+    const int64_t per = (zero_dw + gridDim.x - 1) / gridDim.x;
+    const int64_t z0 = (int64_t)chunk * per, z1 = min(z0 + per, zero_dw);
+    for (int64_t t = z0 + threadIdx.x; t < z1; t += blockDim.x) dW[t] = 0.f;
+  }
   const int r = relchunk_rel[chunk];
   int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
   int32_t *s_cid = reinterpret_cast<int32_t *>(dWs + 4 * K * F);  // LIVE: [kRelChunk] | [kRelChunk] | [4]
@@ -615,11 +620,17 @@ int xform_mfma_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_id
 int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const float *In, int64_t ldIn,
                   int K, const float *G, int64_t ldG, int F, float *dW, float *workspace,
                   int64_t workspace_floats, hipStream_t s, const uint8_t *col_live) {
-  if (o.n_relchunks == 0) return MRGCN_OK;
+  if (o.n_relchunks == 0) {
+    MRGCN_HIP_TRY(hipMemsetAsync(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
+    return MRGCN_OK;
+  }
   size_t lds = (size_t)4 * K * F * sizeof(float);
   if (col_live && lds + kLiveLds <= 64 * 1024) lds += kLiveLds;
   else col_live = nullptr;  // no room for the list: every column is swept (same result)
   float *slab = (workspace && workspace_floats >= (int64_t)o.n_relchunks * K * F) ? workspace : nullptr;
+  // dW is zeroed inside the first launch in the slab form (no fill node per call); the atomic form adds into a dW
+  // the caller zeroed
+  const int64_t zero_dw = slab ? (int64_t)p->num_relations * K * F : 0;
   // Unroll U (columns in flight per wave = 4 U) and tile count are chosen for registers, i.e. for
   // waves per SIMD — the pass waits on the gathered input rows (PMC: profiles/r01_xform_pmc.md).
   // AM shape, same run: K = 10: U = 8 / 4 / 2 -> 1.42 / 1.20 / 1.11 ms (with the dX half);
@@ -629,11 +640,11 @@ int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx
     if (col_live)                                                                                        \
       k_xform_mfma_dw<TQ_, U_, true><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                       \
           o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, In, ldIn, K, G, ldG, F,  \
-          dW, slab, col_live);                                                                           \
+          dW, slab, col_live, zero_dw);                                                                  \
     else                                                                                                 \
       k_xform_mfma_dw<TQ_, U_, false><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                      \
           o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, In, ldIn, K, G, ldG, F,  \
-          dW, slab, nullptr);                                                                            \
+          dW, slab, nullptr, zero_dw);                                                                   \
   } while (0)
   // (live form, K = 155, columns in flight per wave 4 / 8 / 16: 591 / 463 / 485 us)
   if (K <= 64) DW_GO(1, 2);
@@ -685,6 +696,32 @@ int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *
     k_segment_sum<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, col_live);
   else
     k_segment_sum<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p->nptr, Z, ldZ, p->num_nodes, K, dX, lddX, nullptr);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+
+int segment_sum_arrays(const int32_t *nptr, int64_t num_nodes, int64_t nz_rows, const float *Z, int64_t ldZ, int K,
+                       float *dX, int64_t lddX, hipStream_t s, const float *mask_src, int64_t ldMask) {
+  if (num_nodes == 0) return MRGCN_OK;
+  if (K <= 16) {  // every row of dX written (zeros for nodes without a row of Z), masked in the same pass
+    const dim3 grid((unsigned)((num_nodes + 255) / 256));
+    if (K <= 8)
+      k_segment_sum_mask<8><<<grid, dim3(256), 0, s>>>(nptr, Z, ldZ, num_nodes, K, dX, lddX, nullptr, mask_src, ldMask,
+                                                       nullptr, nz_rows, nullptr);
+    else
+      k_segment_sum_mask<16><<<grid, dim3(256), 0, s>>>(nptr, Z, ldZ, num_nodes, K, dX, lddX, nullptr, mask_src, ldMask,
+                                                        nullptr, nz_rows, nullptr);
+    MRGCN_HIP_TRY(hipGetLastError());
+    return MRGCN_OK;
+  }
+  if (mask_src) {
+    set_error("segment_sum: the masked form needs K <= 16");
+    return MRGCN_ERR_UNSUPPORTED;
+  }
+  int64_t blocks = (num_nodes * K + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  k_segment_sum<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(nptr, Z, ldZ, num_nodes, K, dX, lddX, nullptr);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

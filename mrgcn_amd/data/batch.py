@@ -409,6 +409,7 @@ class BatchPrefetcher:
         self._done = queue.Queue()               # (batch, event behind its last use) for a worker to release
         self._err = None
         self._last = None
+        self._closed = False
         self._threads = []
         for _ in range(max(1, int(workers))):
             csr = DeviceCSR.__new__(DeviceCSR)   # the resident arrays, a workspace of its own
@@ -494,12 +495,22 @@ class BatchPrefetcher:
             self._cv.wait_for(lambda: k in self._slots or self._err is not None
                               or (self._total is not None and k >= self._total))
             if self._err is not None:
-                raise self._err
+                err, self._err = self._err, StopIteration()  # (raised once, here; the workers have stopped)
+                if isinstance(err, StopIteration):
+                    raise StopIteration
+                raise err
             if k not in self._slots:
-                raise StopIteration
-            ab, ev = self._slots.pop(k)
-            self._taken = k + 1
-            self._cv.notify_all()
+                done = True
+            else:
+                done = False
+                ab, ev = self._slots.pop(k)
+                self._taken = k + 1
+                self._cv.notify_all()
+        if done:
+            # the workers exit with the sampler: what the caller retired since then is released here, not at a later
+            # close() nobody may call
+            self._release_finished()
+            raise StopIteration
         cur.wait_event(ev)
         for t in self._tensors(ab):
             t.record_stream(cur)
@@ -515,5 +526,25 @@ class BatchPrefetcher:
             self._cv.notify_all()
         for t in self._threads:
             t.join(timeout=30.0)
-        self._slots.clear()
+        # batches built ahead that the caller never took: their plans go back behind the events of their builds (not
+        # through GraphPlan.__del__ from the garbage collector, which waits for the whole device)
+        with self._cv:
+            left, self._slots = list(self._slots.values()), {}
+        for ab, ev in left:
+            self._done.put((ab, ev))
         self._release_finished()
+        self._closed = True
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            if not getattr(self, "_closed", True):
+                self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass

@@ -20,6 +20,12 @@ _OVERLAP = os.environ.get("MRGCN_OVERLAP", "1") != "0"  # AM epoch 6.72-6.76 -> 
 # Skip the compact columns without gradient in the backward (exact: they add zeros).
 _LIVE_COLS = os.environ.get("MRGCN_LIVE_COLS", "1") != "0"
 
+# The backward on a gradient support (plan.GraphPlan.support_for): when the rows of a layer's output gradient that can
+# hold anything are known structurally — the labelled rows, and below them the nodes of the upper layer's support —
+# the live columns, their kept entries and the relation-major lists are built once and every epoch runs on dense index
+# spaces (csrc/support.hip).  MRGCN_SUPPORT=0: the per-epoch marking path for every backward (A/B).
+_SUPPORT = os.environ.get("MRGCN_SUPPORT", "1") != "0"
+
 # tests: start dM as NaNs, so that any read of a row the producer left unwritten shows
 _POISON_DEAD = False
 
@@ -64,6 +70,13 @@ def dense_from_rows(param: torch.Tensor, ent) -> torch.Tensor:
         return torch.where(ent["cur"].bool().view(-1, *([1] * (param.dim() - 1))), ent["g"], torch.zeros_like(ent["g"]))
     g = torch.empty_like(param)
     d_comp = torch.empty_like(fz["comp"])
+    if fz.get("sup") is not None:
+        with torch.cuda.device(param.device):
+            L.check(lib.mrgcn_support_mix_bwd_f32(
+                fz["sup"].handle, fz["dM"].data_ptr(), fz["ld"], param.data_ptr(), fz["comp"].data_ptr(), fz["B"],
+                fz["F"], g.data_ptr(), 1, d_comp.data_ptr(), 0, 0, 0, _stream(param.device)),
+                "mrgcn_support_mix_bwd_f32")
+        return g
     with torch.cuda.device(param.device):
         L.check(lib.mrgcn_basis_mix_bwd_f32(
             fz["plan"].handle, fz["dM"].data_ptr(), fz["ld"], fz["live"].data_ptr(), param.data_ptr(),
@@ -236,8 +249,12 @@ def relu_bwd(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
 # is the very object, unchanged, that the upper layer returned: autograd hands a sole consumer's gradient through as
 # it is, and sums the gradients of several consumers either into a new tensor (no note) or in place (the tensor's
 # version counter moves) — in both cases the lower layer falls back to masking and scanning by itself.
-def _set_grad_meta(t, row_live, relu_applied: bool):
-    t._mrgcn_grad_meta = {"version": t._version, "row_live": row_live, "relu_applied": bool(relu_applied)}
+def _set_grad_meta(t, row_live, relu_applied: bool, structural: bool = False, sparse_rows: bool = False):
+    """`structural`: `row_live` is a row set fixed by the label set and the graph (the same tensor every epoch; rows
+    outside it are certainly zero, rows inside it may be): the key of a gradient support.  `sparse_rows`: the rows
+    outside `row_live` were not even written — only a consumer that goes by the flags may read this tensor."""
+    t._mrgcn_grad_meta = {"version": t._version, "row_live": row_live, "relu_applied": bool(relu_applied),
+                          "structural": bool(structural), "sparse_rows": bool(sparse_rows)}
 
 
 def _grad_meta(t):
@@ -321,7 +338,15 @@ class _RgcnLayer(torch.autograd.Function):
         if ctx.relu and not (meta and meta["relu_applied"]):
             dY = relu_bwd(dY, Y)
             row_flags = None
+        sparse_rows = bool(meta and meta.get("sparse_rows"))
+        if sparse_rows and has_bias:
+            raise L.MrgcnError("internal: an output gradient with unwritten rows reached a layer with a bias")
         dbias = dY.sum(0) if has_bias else None
+        sup = _support_of(plan, meta, F, dev) if (_SUPPORT and _LIVE_COLS) else None
+        if sup is not None:
+            out = _RgcnLayer._backward_on_support(ctx, sup, dY, dbias)
+            if out is not None:
+                return out
         # dM = A'^T dY over touched columns only, plain compact order (its consumers are node-major)
         ld = (F + 3) // 4 * 4
         dM = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
@@ -329,7 +354,10 @@ class _RgcnLayer(torch.autograd.Function):
             dM.fill_(float("nan"))
         live = node_live = None
         gauge = _live_gauge(plan, F, ctx.relu, dev) if _LIVE_COLS else None
-        if gauge is not None and gauge.sparse():
+        if sparse_rows and (gauge is None or F > 16):
+            raise L.MrgcnError("internal: an output gradient with unwritten rows needs the live-row backward")
+        # (unwritten rows outside the flags: only the live-row form may read this gradient, whatever the gauge says)
+        if gauge is not None and (gauge.sparse() or sparse_rows):
             # with few labelled nodes most rows of dY are zeros: gather the others only, and keep one
             # byte per compact column: does it carry any gradient?
             live = torch.empty((plan.ncols,), dtype=torch.uint8, device=dev)
@@ -447,6 +475,119 @@ class _RgcnLayer(torch.autograd.Function):
         return None, None, d_wI, d_comp, dX, dW, dbias, None, None, None
 
 
+def _support_of(plan, meta, F, dev):
+    """The gradient support for an output gradient whose live rows are known structurally, or None."""
+    if not meta or not meta.get("structural") or F > 16:
+        return None
+    rf = meta["row_live"]
+    if rf is None or rf.numel() != plan.num_rows or rf.device != dev or rf.dtype != torch.uint8:
+        return None
+    return plan.support_for(rf)
+
+
+def _backward_on_support(ctx, sup, dY, dbias):
+    """_RgcnLayer.backward on a gradient support: dM and every per-column product are [L, ld] arrays by live number;
+    no marking, no flags, no zero fills (csrc/support.hip).  None when a shape is outside what the support calls
+    take (the caller then runs the per-epoch marking path)."""
+    lib = L.load()
+    plan, F = ctx.plan, ctx.F
+    weight_I, comp_I, X, W_F, Y = ctx.saved_tensors
+    has_I, has_comp, has_X, has_bias = ctx.has
+    dev = plan.device
+    if has_I and not has_comp:
+        return None  # (the literal (R*N) x F gradient is scattered from plain compact order)
+    need_dX = has_X and ctx.needs_input_grad[4]
+    need_dW = has_X and ctx.needs_input_grad[5]
+    K = X.shape[1] if has_X else 0
+    nws = 0
+    if need_dX or need_dW:
+        nws = int(lib.mrgcn_support_rel_transform_bwd_workspace(sup.handle, K, F, int(need_dX), int(need_dW)))
+        if nws < 0:
+            return None
+    s = _stream(dev)
+    ld = (F + 3) // 4 * 4
+    dM = torch.empty((max(sup.L, 1), ld), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.mrgcn_support_spmm_t_f32(sup.handle, dY.data_ptr(), dY.stride(0), F, dM.data_ptr(), ld, s),
+                "mrgcn_support_spmm_t_f32")
+    d_wI = d_comp = dX = dW = None
+    overlap = has_I and has_X and _OVERLAP
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev) if overlap else main
+    if overlap:
+        side.wait_stream(main)
+    with torch.cuda.device(dev):
+        if has_I:
+            N_, Bn, _ = weight_I.shape
+            wI = weight_I.contiguous()
+            d_comp = torch.empty_like(comp_I)
+            param = getattr(ctx.owner, "weight_I", None)
+            rows = None
+            if (param is not None and weight_I.is_contiguous() and param.shape == weight_I.shape
+                    and _row_sparse_for(param)):
+                rows = getattr(param, "_mrgcn_rows", None)
+                if rows is not None and rows["fresh"]:
+                    raise L.MrgcnError("row-sparse weight_I gradient: the layer ran twice in one train_step "
+                                       "(use train_step(..., row_sparse=False))")
+                fused = bool(lib.mrgcn_adam_rows_fused_supported(plan.handle, Bn, F))
+                if rows is None or rows["shape"] != tuple(weight_I.shape) or rows["ever"].device != dev:
+                    rows = dict(g=None, shape=tuple(weight_I.shape), cur=None,
+                                ever=torch.zeros(N_, dtype=torch.uint8, device=dev), sumsq=None, fresh=False,
+                                seeded_for=None, fused=None)
+                    param._mrgcn_rows = rows
+                if not fused and rows["g"] is None:
+                    rows["g"] = torch.empty_like(wI)
+            if rows is not None:
+                rows["cur"] = sup.node_flags()  # the nodes of the support: the same set every epoch
+                if fused:
+                    # norm-only: dcomp and ||dV||^2 are written whole (no zero fills), nothing is accumulated
+                    sq = torch.empty((), dtype=torch.float64, device=dev)
+                    ws = sup.workspace(("mix", Bn), int(lib.mrgcn_support_mix_bwd_workspace(sup.handle, Bn)))
+                    L.check(lib.mrgcn_support_mix_bwd_f32(
+                        sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, 0, 0,
+                        d_comp.data_ptr(), sq.data_ptr(), ws.data_ptr(), ws.numel(), s), "mrgcn_support_mix_bwd_f32")
+                else:
+                    sq = torch.zeros((), dtype=torch.float64, device=dev)
+                    L.check(lib.mrgcn_support_mix_bwd_f32(
+                        sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, rows["g"].data_ptr(), 0,
+                        d_comp.data_ptr(), sq.data_ptr(), 0, 0, s), "mrgcn_support_mix_bwd_f32")
+                rows["sumsq"], rows["fresh"] = sq, True
+                # what the fused update reads: dM of this backward and the coefficients as they were (ClipAdam steps
+                # the node table before weight_I_comp; the version is checked there)
+                rows["fused"] = dict(sup=sup, plan=plan, dM=dM, ld=ld, live=None, comp=comp_I.detach(),
+                                     comp_version=comp_I._version, B=Bn, F=F) if fused else None
+            else:
+                d_wI = torch.empty_like(wI)
+                L.check(lib.mrgcn_support_mix_bwd_f32(
+                    sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, d_wI.data_ptr(), 1,
+                    d_comp.data_ptr(), 0, 0, 0, s), "mrgcn_support_mix_bwd_f32")
+        if need_dX or need_dW:
+            with torch.cuda.stream(side):
+                if need_dX:
+                    dX = torch.empty((X.shape[0], K), dtype=torch.float32, device=dev)
+                if need_dW:
+                    dW = torch.empty_like(W_F)
+                ws = sup.workspace(("xform", K, F), nws)
+                mask = bool(need_dX and ctx.x_is_relu_out and K <= 16)
+                L.check(lib.mrgcn_support_rel_transform_bwd_f32(
+                    sup.handle, dM.data_ptr(), ld, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
+                    dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0, ws.data_ptr(), ws.numel(),
+                    int(mask), side.cuda_stream), "mrgcn_support_rel_transform_bwd_f32")
+                if need_dX:
+                    # the rows that can hold anything: the nodes of this support — the row set of the layer below
+                    _set_grad_meta(dX, sup.node_flags(), mask, structural=True)
+            if overlap:
+                main.wait_stream(side)
+                for t in (dX, dW):
+                    if t is not None:
+                        t.record_stream(main)
+                dM.record_stream(side)
+    return None, None, d_wI, d_comp, dX, dW, dbias, None, None, None
+
+
+_RgcnLayer._backward_on_support = staticmethod(_backward_on_support)
+
+
 class _BasisContract(torch.autograd.Function):
     """W_F[r] = sum_b comp[r, b] V_F[b] (graph.py:83-85) and its backward on this package's kernels
     (mrgcn_basis_contract_f32 / _bwd_f32): comp (R, B), V (B, in, out) -> (R, in, out)."""
@@ -507,4 +648,8 @@ def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False, input_term: bool =
     Y = _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, bias, relu, bf16, layer)
     if relu:
         Y._mrgcn_relu_out = True  # (a Python attribute of this tensor object: a copy or a view does not carry it)
+    if bias is None and F <= 16 and _SUPPORT and _LIVE_COLS and not plan.lean:
+        # this layer's backward reads the flagged rows of its output gradient only: a loss that knows the rows it
+        # touches (train.categorical_crossentropy) need not zero-fill the rest (AM shape: 73 MB per epoch)
+        Y._mrgcn_sparse_grad_ok = True
     return Y

@@ -4,9 +4,11 @@ state-dict keys; full-batch forward = gated literal encoders -> concatenation wi
 R-GCN on the MI355X kernels.
 
 Encoders: MLPs for the numeric / boolean / temporal datatypes, the TCNN for
-`ogc.wktLiteral`, and the string / image heads on a caller-supplied backbone module (the reference
-loads those from torch.hub; there is no network path here, so a hub config is rejected with a
-clear error).  In a mini-batch the encoders run for the outermost neighbours only."""
+`ogc.wktLiteral`, and the string / image heads on a backbone: either the reference's own hub config
+list (`embedding_modules` as graph_features.py produces them: the backbone is then fetched with
+`torch.hub.load` exactly as models/utils.py:32-44 does, ONE language model and ONE image model shared by
+all encoding sets, mrgcn.py:83-105) or an `nn.Module` the caller supplies (a box without network).
+In a mini-batch the encoders run for the outermost neighbours only."""
 from __future__ import annotations
 
 import logging
@@ -26,6 +28,36 @@ _MLP_LAYERS = {"xsd.boolean": 1, "xsd.numeric": 1, "xsd.date": 2, "xsd.dateTime"
 _COUNTER_GROUP = {"xsd.boolean": "num", "xsd.numeric": "num", "xsd.date": "temp",
                   "xsd.dateTime": "temp", "xsd.gYear": "temp", "xsd.string": "llm", "xsd.anyURI": "llm",
                   "blob.image": "img", "ogc.wktLiteral": "geo"}
+
+
+def loadFromHub(config):
+    """models/utils.py:32-44: the entries of a hub config without '=' are torch.hub.load's positional arguments,
+    `key=value` entries its keyword arguments (values stay strings, as in the reference)."""
+    parameters, named_parameters = [], {}
+    for param in config:
+        if "=" not in param:
+            parameters.append(param)
+            continue
+        key, value = param.split("=")
+        named_parameters[key.strip()] = value.strip()
+    return torch.hub.load(*parameters, **named_parameters)
+
+
+def _backbone(config_or_module, shared, datatype):
+    """The backbone behind a string / image head: a module as it is, or the hub config of the reference loaded once
+    and shared (`shared`: the language / image model already loaded for an earlier encoding set, mrgcn.py:83-84, :95-96)."""
+    if isinstance(config_or_module, nn.Module):
+        return config_or_module
+    if shared is not None:
+        return shared
+    if isinstance(config_or_module, (list, tuple)) and all(isinstance(x, str) for x in config_or_module):
+        try:
+            return loadFromHub(config_or_module)
+        except Exception as e:  # noqa: BLE001  (no network, unknown repository, ...)
+            raise RuntimeError(
+                f"{datatype}: torch.hub.load{tuple(config_or_module)} failed ({type(e).__name__}: {e}); on a box without "
+                "network pass the backbone nn.Module in place of the hub config (models/utils.py:32-44)") from e
+    raise TypeError(f"{datatype}: expected a hub config (list of str) or an nn.Module, got {type(config_or_module).__name__}")
 
 
 def _pick_device(want_gpu: bool):
@@ -55,6 +87,7 @@ class MRGCN(nn.Module):
 
         counters = {"num": 0, "temp": 0, "llm": 0, "img": 0, "geo": 0}
         i_gate = 0
+        language_model = image_model = None  # one of each, shared by every encoding set (mrgcn.py:43-44)
         for datatype, args, gpu_acceleration in embedding_modules:
             seq_length = -1
             if datatype in _MLP_LAYERS:
@@ -66,18 +99,19 @@ class MRGCN(nn.Module):
                 module = TCNN(features_in=nrows, features_out=dim_out, p_dropout=p_drop, size=model_size)
                 seq_length = module.minimal_length
             elif datatype in ("xsd.string", "xsd.anyURI", "blob.image"):  # mrgcn.py:80-107
-                backbone = args[0]
-                if not isinstance(backbone, nn.Module):
-                    raise NotImplementedError(
-                        f"{datatype}: the reference loads its backbone with torch.hub (models/utils.py:32-44); "
-                        "mrgcn_amd has no network path — pass the backbone nn.Module in place of the hub config")
                 if datatype == "blob.image":
-                    _, transform_config, dim_out, p_drop = args
+                    model_config, transform_config, dim_out, p_drop = args
+                    backbone = _backbone(model_config, image_model, datatype)
+                    if not isinstance(model_config, nn.Module):
+                        image_model = backbone
                     module = ImageCNN(backbone, output_dim=dim_out, p_dropout=p_drop)
                     if "mean" in transform_config and "std" in transform_config:
                         self.im_norm = Normalizer(transform_config["mean"], transform_config["std"])
                 else:
-                    _, dim_out, p_drop = args
+                    model_config, dim_out, p_drop = args
+                    backbone = _backbone(model_config, language_model, datatype)
+                    if not isinstance(model_config, nn.Module):
+                        language_model = backbone
                     module = Transformer(backbone, output_dim=dim_out, p_dropout=p_drop)
             else:
                 raise Exception("Datatype not supported: " + datatype)

@@ -33,11 +33,19 @@ from .train import ClipAdam, _stream, _to_reference_layout, merge_row_grad
 class Adam(ClipAdam):
     """`torch.optim.Adam(params, lr, betas, eps, weight_decay)` on HIP kernels; no clipping of its own (the
     reference clips with `nn.utils.clip_grad_norm_` between backward and step).  `state_dict()` /
-    `load_state_dict()` speak the reference's layout (ClipAdam).  `row_sparse=False` keeps every gradient dense."""
+    `load_state_dict()` speak the reference's layout (ClipAdam).
+
+    `row_sparse` (default False: every gradient dense, `.grad` of every parameter as torch leaves it — any clip,
+    scaler or inspection code sees all of it).  True: the optimizer announces itself on the node-major `weight_I`
+    parameters it owns and a plain `loss.backward()` then leaves their gradient in ROW-SPARSE form (`weight_I.grad`
+    stays None; flags, `dM` and the squared norm travel on the parameter).  Only this module's `clip_grad_norm_`
+    knows that form — torch's would skip the node table, i.e. leave its norm out of the total and step it unclipped —
+    so the two go together: `RowSparseAdam` + `clip_grad_norm_`, which is what `install_as_mrgcn(patch_optimizer=True)`
+    binds inside the reference's task modules."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, *,
                  foreach=None, maximize=False, capturable=False, differentiable=False, fused=None,
-                 row_sparse=True):
+                 row_sparse=False):
         if amsgrad or maximize or differentiable:
             raise L.MrgcnError("mrgcn_amd.optim.Adam: amsgrad / maximize / differentiable are not implemented")
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=None,
@@ -56,11 +64,21 @@ class Adam(ClipAdam):
         super().zero_grad(set_to_none=set_to_none)
 
 
+class RowSparseAdam(Adam):
+    """`Adam(row_sparse=True)` under the constructor signature of `torch.optim.Adam`: what the reference's loop gets
+    for `optim.Adam` next to this module's `clip_grad_norm_` (mrgcn_amd.patch_task_optimizer)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, **kw):
+        kw.setdefault("row_sparse", True)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
+
+
 def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=False, foreach=None):
     """`torch.nn.utils.clip_grad_norm_` that also sees gradients in row-sparse form.  The total norm, the
     coefficient `max_norm / (norm + 1e-6)` (clamped to 1) and the scaling stay on the device; the returned norm
     is a 0-dim device tensor like torch's.  Anything this path does not cover (other norm types, no row-sparse
-    gradient among the parameters, CPU tensors) goes to torch's implementation."""
+    gradient among the parameters, gradients on the CPU / another GPU / of another dtype) goes to torch's
+    implementation, row-sparse entries densified first."""
     if isinstance(parameters, torch.Tensor):
         parameters = [parameters]
     params = list(parameters)
@@ -77,9 +95,18 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
             e["fresh"] = False
             merge_row_grad(p, e)
     rows = [(p, e) for p, e in rows if e["fresh"]]
-    lib = L.load()
     dev = (rows[0][0] if rows else params[0]).device
     dense = [p.grad for p in params if p.grad is not None]
+    if dev.type != "cuda" or any(g.device != dev or g.dtype != torch.float32 or g.is_sparse for g in dense) \
+            or any(p.device != dev for p, _ in rows):
+        # gradients on another device (the reference spreads modules over model.devices) or of another type: the
+        # kernels below would read them as float32 pointers of `dev` — densify and let torch do it
+        for p, e in rows:
+            e["fresh"] = False
+            merge_row_grad(p, e)
+        return torch.nn.utils.clip_grad_norm_(params, max_norm, norm_type=norm_type,
+                                              error_if_nonfinite=error_if_nonfinite, foreach=foreach)
+    lib = L.load()
     sumsq = torch.zeros((), dtype=torch.float64, device=dev)
     coef = torch.ones((), dtype=torch.float32, device=dev)
     norm = torch.zeros((), dtype=torch.float32, device=dev)

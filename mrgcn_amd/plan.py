@@ -136,6 +136,8 @@ class GraphPlan:
         `after_event`: a torch.cuda.Event recorded behind the last work that uses the plan — the host then waits for
         that event only and other streams keep running (mrgcn_plan_destroy_after)."""
         if getattr(self, "_h", None) is not None and self._h:
+            for sup in self.__dict__.pop("_supports", {}).values():  # (they read the plan's arrays: first)
+                sup.close()
             if after_event is not None:
                 L.load().mrgcn_plan_destroy_after(self._h, after_event.cuda_event)
             else:
@@ -224,11 +226,116 @@ class GraphPlan:
             self._ulcol_long = t
         return t
 
+    # -- gradient support (include/mrgcn_hip.h: mrgcn_support_*) --------------------------------
+    def support_for(self, row_flags: torch.Tensor):
+        """The gradient support of the output rows flagged in `row_flags` (uint8 [num_rows], device), built on first
+        use and kept on the plan under the identity of the flags tensor — a STRUCTURAL row set (the labelled rows, or
+        the node flags of the support of the layer above) is the same tensor, unchanged, every epoch.  None while a
+        stream capture is under way and the support does not exist yet (the build synchronises): the caller then
+        takes the per-epoch marking path."""
+        if self.lean or row_flags is None:
+            return None
+        key = (row_flags.data_ptr(), row_flags._version, int(row_flags.numel()))
+        cache = self.__dict__.setdefault("_supports", {})
+        sup = cache.get(key)
+        if sup is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            if row_flags.dtype != torch.uint8 or row_flags.numel() != self.num_rows or row_flags.device != self.device:
+                return None
+            sup = GraphSupport(self, row_flags)
+            while len(cache) >= 4:  # (a handful of label sets per plan: train / valid / test)
+                cache.pop(next(iter(cache))).close()
+            cache[key] = sup
+        return sup
+
     # -- algorithmic traffic (SURVEY §8d) ------------------------------------------------
     def spmm_bytes(self, F: int, value_bytes: int = 4, elem_bytes: int = 4) -> int:
         """nnz*(4+v) + (rows+1)*4 + ncols*F*e + rows*F*e"""
         return (self.nnz * (4 + value_bytes) + (self.num_rows + 1) * 4
                 + self.ncols * F * elem_bytes + self.num_rows * F * elem_bytes)
+
+
+class GraphSupport:
+    """Host handle of a gradient support (mrgcn_support_t): the live columns / entries / nodes of a plan for a fixed
+    set of output rows that can carry gradient.  Holds on to the flags tensor it was built from (its identity is the
+    cache key) and to its plan."""
+
+    def __init__(self, plan: GraphPlan, row_flags: torch.Tensor):
+        lib = L.load()
+        self.plan, self.row_flags, self.device = plan, row_flags, plan.device
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(lib.mrgcn_support_create(C.byref(h), plan.handle, row_flags.data_ptr(), _stream_ptr(self.device)),
+                    "mrgcn_support_create")
+        self._h = h
+        info = L.SupportInfo()
+        L.check(lib.mrgcn_support_info(self._h, C.byref(info)))
+        self.L, self.E, self.NL = int(info.live_cols), int(info.live_entries), int(info.live_nodes)
+        self.device_bytes = int(info.device_bytes)
+        self.chunks_wide, self.chunks_narrow = int(info.chunks_wide), int(info.chunks_narrow)
+        self._node_flags = None
+        self._ws = {}
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise L.MrgcnError("support already destroyed")
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.load().mrgcn_support_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def array_ptr(self, which: int):
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(L.load().mrgcn_support_array(self.handle, which, C.byref(p), C.byref(n)))
+        return p.value or 0, int(n.value)
+
+    def export(self, which: int) -> np.ndarray:
+        ptr, n = self.array_ptr(which)
+        dt = {L.SUP_COL_FLAGS: torch.uint8, L.SUP_NODE_FLAGS: torch.uint8, L.SUP_LVAL: torch.float32}.get(which, torch.int32)
+        out = torch.empty((n,), dtype=dt, device=self.device)
+        if n:
+            out = _device_array(ptr, n, dt, self.device).clone()
+        return out.cpu().numpy()
+
+    def node_flags(self) -> torch.Tensor:
+        """uint8 [num_nodes]: the nodes that own a live column — a view of the support's own array (valid while the
+        support lives): the row set of the layer below, and `row_cur` of the row-sparse Adam."""
+        if self._node_flags is None:
+            ptr, n = self.array_ptr(L.SUP_NODE_FLAGS)
+            self._node_flags = _device_array(ptr, n, torch.uint8, self.device)
+            self._node_flags._mrgcn_owner = self  # (keeps the support alive as long as the view)
+        return self._node_flags
+
+    def workspace(self, key, numel: int) -> torch.Tensor:
+        """A float32 scratch tensor kept on the support (one per use: the same buffer every epoch)."""
+        t = self._ws.get(key)
+        if t is None or t.numel() < numel:
+            t = torch.empty((max(int(numel), 2),), dtype=torch.float32, device=self.device)
+            self._ws[key] = t
+        return t
+
+
+def _device_array(ptr: int, n: int, dtype, device) -> torch.Tensor:
+    """A tensor over `n` elements of device memory the library owns (no copy, no ownership)."""
+    if n == 0:
+        return torch.empty((0,), dtype=dtype, device=device)
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    typestr = {torch.uint8: "|u1", torch.int32: "<i4", torch.float32: "<f4"}[dtype]
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2,
+                                    "strides": (itemsize,)}
+    return torch.as_tensor(_Raw(), device=device)
 
 
 def plan_of(A: torch.Tensor, num_nodes: int, num_relations: int, operand_row_bytes=None, lean: bool = False) -> GraphPlan:

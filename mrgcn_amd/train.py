@@ -28,14 +28,39 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_LABEL_FLAGS: dict = {}
+
+
+def _label_flags(idx: torch.Tensor, num_rows: int):
+    """(flags, unique): uint8 [num_rows] with a 1 at every labelled row, kept under the identity of `idx` — the same
+    tensor object, unchanged, gives the same flags tensor every epoch, which is what keys the gradient support of
+    the label set (plan.GraphPlan.support_for).  None while a stream capture is under way and the flags do not
+    exist yet (their check for repeated rows synchronises)."""
+    key = (idx.data_ptr(), idx._version, int(idx.numel()), int(num_rows), idx.device)
+    ent = _LABEL_FLAGS.get(key)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        flags = torch.zeros((num_rows,), dtype=torch.uint8, device=idx.device)
+        flags[idx] = 1
+        unique = int(flags.sum(dtype=torch.int64)) == int(idx.numel())
+        while len(_LABEL_FLAGS) >= 8:
+            _LABEL_FLAGS.pop(next(iter(_LABEL_FLAGS)))
+        ent = _LABEL_FLAGS[key] = (flags, unique, idx)  # (holds `idx`: its address cannot be handed to another tensor)
+    return ent[0], ent[1]
+
+
 class _SoftmaxXent(torch.autograd.Function):
     """nn.CrossEntropyLoss()(Y_hat[idx], targets) (node_classification.py:439-444).  The forward keeps the
-    gradient of the labelled rows only (n x C); the backward forms the dense N x C gradient from it, scaled by the
+    gradient of the labelled rows only (n x C); the backward forms the N x C gradient from it, scaled by the
     upstream gradient in the same pass, and notes which rows hold anything (functional._set_grad_meta: the last
-    layer's backward then does not scan 73 MB of zeros for them)."""
+    layer's backward then does not scan 73 MB of zeros for them).  `flags` (from _label_flags): the labelled rows
+    as a persistent flags tensor — the note then names a structural row set; `sparse`: the rows outside it are not
+    written at all (only for a consumer that reads the flagged rows: functional.rgcn_layer marks such outputs)."""
 
     @staticmethod
-    def forward(ctx, logits, idx, targets):
+    def forward(ctx, logits, idx, targets, flags=None, sparse=False):
+        ctx.flags, ctx.sparse = flags, bool(sparse and flags is not None)
         if logits.stride(1) != 1:        # (rows may be strided: a layer output in a buffer with padded rows)
             logits = logits.contiguous()
         N, C = logits.shape
@@ -57,19 +82,36 @@ class _SoftmaxXent(torch.autograd.Function):
         dev = drows.device
         g = g.to(torch.float32).contiguous()
         dlogits = torch.empty((N, C), dtype=torch.float32, device=dev)
-        flags = torch.empty((N,), dtype=torch.uint8, device=dev)
+        if ctx.sparse:  # the labelled rows only: no zero fill of the other N - n
+            with torch.cuda.device(dev):
+                L.check(L.load().mrgcn_softmax_xent_bwd_rows_f32(
+                    drows.data_ptr(), idx.data_ptr(), idx.numel(), C, g.data_ptr(), dlogits.data_ptr(), C,
+                    _stream(dev)), "mrgcn_softmax_xent_bwd_rows_f32")
+            _set_grad_meta(dlogits, ctx.flags, False, structural=True, sparse_rows=True)
+            return dlogits, None, None, None, None
+        flags = ctx.flags if ctx.flags is not None else torch.empty((N,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             L.check(L.load().mrgcn_softmax_xent_bwd_f32(
                 drows.data_ptr(), idx.data_ptr(), idx.numel(), C, g.data_ptr(), dlogits.data_ptr(), C, N,
-                flags.data_ptr(), _stream(dev)), "mrgcn_softmax_xent_bwd_f32")
-        _set_grad_meta(dlogits, flags, False)
-        return dlogits, None, None
+                0 if ctx.flags is not None else flags.data_ptr(), _stream(dev)), "mrgcn_softmax_xent_bwd_f32")
+        _set_grad_meta(dlogits, flags, False, structural=ctx.flags is not None)
+        return dlogits, None, None, None, None
 
 
-def categorical_crossentropy(Y_hat: torch.Tensor, idx: torch.Tensor, targets: torch.Tensor):
-    """`idx`, `targets`: int64 device tensors (the `Y.nonzero()` pair of the reference)."""
+def categorical_crossentropy(Y_hat: torch.Tensor, idx: torch.Tensor, targets: torch.Tensor, sole_consumer: bool = False):
+    """`idx`, `targets`: int64 device tensors (the `Y.nonzero()` pair of the reference).  `sole_consumer`: nothing
+    but this loss reads `Y_hat` (train_step): when `Y_hat` comes straight out of a layer whose backward goes by the
+    row flags, the gradient's unlabelled rows are then not even zero-filled."""
     assert idx.dtype == torch.int64 and targets.dtype == torch.int64
-    return _SoftmaxXent.apply(Y_hat, idx.contiguous(), targets.contiguous())
+    from .functional import _SUPPORT
+    flags = sparse = None
+    if _SUPPORT and Y_hat.is_cuda and idx.is_contiguous():
+        ent = _label_flags(idx, Y_hat.shape[0])
+        if ent is not None:
+            flags = ent[0]
+            sparse = bool(sole_consumer and ent[1] and getattr(Y_hat, "_mrgcn_sparse_grad_ok", False)
+                          and Y_hat.grad_fn is not None and type(Y_hat.grad_fn).__name__ == "_RgcnLayerBackward")
+    return _SoftmaxXent.apply(Y_hat, idx.contiguous(), targets.contiguous(), flags, sparse)
 
 
 def categorical_accuracy(Y_hat, idx, targets):
@@ -211,7 +253,10 @@ class ClipAdam(torch.optim.Optimizer):
         sc = self._dev_scratch(device)
         s = _stream(device)
         use_clip = self.max_norm is not None and self.max_norm > 0
-        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for _, p in live]
+        # (contiguous and 16-byte aligned, as the vector kernels read them: a gradient that is a view into a flat
+        # bucket at an odd offset is copied)
+        grads = [p.grad if (p.grad.is_contiguous() and p.grad.data_ptr() % 16 == 0) else p.grad.contiguous().clone()
+                 for _, p in live]
         # The dense parameters besides the node table are a handful of small tensors: their squared norms, the
         # row-sparse gradients' norms, the clip coefficient and the device step counter take ONE launch
         # (mrgcn_sumsq_clip_multi_f32) and their Adam updates another (mrgcn_adam_step_multi_f32) when every group
@@ -239,27 +284,38 @@ class ClipAdam(torch.optim.Optimizer):
                         self._dev_step[key] = ent
                     bias[key] = ent[1]
             if multi:
-                b1m, b2m, _ = next(iter(hyper))
-                for i, g in enumerate(grads):
-                    if i not in small:  # (a large dense gradient: its own streaming pass into the same accumulator)
-                        L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), sc["accum"].data_ptr(), s),
-                                "mrgcn_sumsq_accum_f32")
-                for c0 in range(0, len(small) - 16, 16) if len(small) > 16 else ():
-                    part = small[c0:c0 + 16]
-                    L.check(lib.mrgcn_sumsq_accum_multi_f32(
-                        len(part), (C.c_void_p * len(part))(*[grads[i].data_ptr() for i in part]),
-                        (C.c_int64 * len(part))(*[grads[i].numel() for i in part]), sc["accum"].data_ptr(), s),
-                        "mrgcn_sumsq_accum_multi_f32")
-                last = small[(len(small) - 1) // 16 * 16:]   # the launch that also closes the norm
-                gp = (C.c_void_p * len(last))(*[grads[i].data_ptr() for i in last])
-                gn = (C.c_int64 * len(last))(*[grads[i].numel() for i in last])
-                ex = (C.c_void_p * max(len(rowsparse), 1))(*[ent["sumsq"].data_ptr() for _, _, ent in rowsparse])
-                dstep = self._dev_step.get((b1m, b2m)) if self.capturable else None
-                L.check(lib.mrgcn_sumsq_clip_multi_f32(
-                    len(last), gp, gn, len(rowsparse), ex, sc["accum"].data_ptr(), sc["ticket"].data_ptr(),
-                    float(self.max_norm) if use_clip else 0.0, sc["sumsq"].data_ptr(), sc["coef"].data_ptr(),
-                    sc["norm"].data_ptr(), dstep[0].data_ptr() if dstep else 0, b1m, b2m,
-                    dstep[1].data_ptr() if dstep else 0, s), "mrgcn_sumsq_clip_multi_f32")
+                try:
+                    b1m, b2m, _ = next(iter(hyper))
+                    for i, g in enumerate(grads):
+                        if i not in small:  # (a large dense gradient: its own streaming pass into the same accumulator)
+                            L.check(lib.mrgcn_sumsq_accum_f32(g.data_ptr(), g.numel(), sc["accum"].data_ptr(), s),
+                                    "mrgcn_sumsq_accum_f32")
+                    for c0 in range(0, len(small) - 16, 16) if len(small) > 16 else ():
+                        part = small[c0:c0 + 16]
+                        L.check(lib.mrgcn_sumsq_accum_multi_f32(
+                            len(part), (C.c_void_p * len(part))(*[grads[i].data_ptr() for i in part]),
+                            (C.c_int64 * len(part))(*[grads[i].numel() for i in part]), sc["accum"].data_ptr(), s),
+                            "mrgcn_sumsq_accum_multi_f32")
+                    last = small[(len(small) - 1) // 16 * 16:]   # the launch that also closes the norm
+                    gp = (C.c_void_p * len(last))(*[grads[i].data_ptr() for i in last])
+                    gn = (C.c_int64 * len(last))(*[grads[i].numel() for i in last])
+                    ex = (C.c_void_p * max(len(rowsparse), 1))(*[ent["sumsq"].data_ptr() for _, _, ent in rowsparse])
+                    dstep = self._dev_step.get((b1m, b2m)) if self.capturable else None
+                    L.check(lib.mrgcn_sumsq_clip_multi_f32(
+                        len(last), gp, gn, len(rowsparse), ex, sc["accum"].data_ptr(), sc["ticket"].data_ptr(),
+                        float(self.max_norm) if use_clip else 0.0, sc["sumsq"].data_ptr(), sc["coef"].data_ptr(),
+                        sc["norm"].data_ptr(), dstep[0].data_ptr() if dstep else 0, b1m, b2m,
+                        dstep[1].data_ptr() if dstep else 0, s), "mrgcn_sumsq_clip_multi_f32")
+                    for key, bc_t in bias.items():  # groups with other betas (no gradient this step): their counters too
+                        if key != (b1m, b2m):
+                            L.check(lib.mrgcn_adam_bias_f32(self._dev_step[key][0].data_ptr(), key[0], key[1],
+                                                            bc_t.data_ptr(), s), "mrgcn_adam_bias_f32")
+                except BaseException:
+                    # the scratch words are self-cleaning only when the closing launch ran: a failure in between must not
+                    # leak a partial sum into every later norm
+                    sc["accum"].zero_()
+                    sc["ticket"].zero_()
+                    raise
             else:
                 sc["sumsq"].zero_()
                 sc["sumsq_sharded"].zero_()
@@ -304,6 +360,16 @@ class ClipAdam(torch.optim.Optimizer):
                 # the coefficient of a clip that ran between backward and step (mrgcn_amd.optim.clip_grad_norm_)
                 pre = ent.pop("coef", None)
                 coef_ptr = pre.data_ptr() if pre is not None else step_coef_ptr
+                if fz is not None and fz.get("comp_version") is not None and fz["comp"]._version != fz["comp_version"]:
+                    raise L.MrgcnError("row-sparse weight_I gradient: weight_I_comp was modified between backward and "
+                                       "the node table's update (the fused update re-reads it)")
+                if fz is not None and fz.get("sup") is not None:  # the same on the gradient support of the label set
+                    L.check(lib.mrgcn_support_adam_rows_fused_f32(
+                        fz["sup"].handle, fz["dM"].data_ptr(), fz["ld"], fz["comp"].data_ptr(), fz["B"], fz["F"],
+                        p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), ent["ever"].data_ptr(),
+                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), bc, coef_ptr,
+                        s), "mrgcn_support_adam_rows_fused_f32")
+                    continue
                 if fz is not None:  # no gradient tensor: the blocks are rebuilt from dM inside the Adam pass
                     L.check(lib.mrgcn_adam_step_rows_fused_f32(
                         fz["plan"].handle, fz["dM"].data_ptr(), fz["ld"], fz["live"].data_ptr(), fz["comp"].data_ptr(),
@@ -391,6 +457,18 @@ def weight_regularisation(model, l1_lambda: float = 0.0, l2_lambda: float = 0.0)
     return reg
 
 
+_ONES: dict = {}
+
+
+def _ones_like_loss(loss):
+    """The seed gradient of `loss.backward()`: one cached scalar per (device, dtype) instead of a fill per epoch."""
+    key = (loss.device, loss.dtype)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    return t
+
+
 def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.0, l2_lambda: float = 0.0,
                row_sparse=None):
     """One full-batch epoch.  `forward_fn()` returns the logits (e.g. `lambda: model(batch)`).
@@ -401,7 +479,7 @@ def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.
     params = [p for g in optimizer.param_groups for p in g["params"]]
     clear_row_grads(params)
     logits = forward_fn()
-    loss = categorical_crossentropy(logits, idx, targets)
+    loss = categorical_crossentropy(logits, idx, targets, sole_consumer=True)
     reg = l1_lambda > 0 or l2_lambda > 0
     if reg:
         loss = loss + weight_regularisation(model, l1_lambda, l2_lambda)
@@ -412,7 +490,7 @@ def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.
                  and all(float(g["weight_decay"]) == 0.0 for g in optimizer.param_groups))
     prev = row_sparse_weight_grad(sparse_ok)
     try:
-        loss.backward()
+        loss.backward(gradient=_ones_like_loss(loss))
     finally:
         row_sparse_weight_grad(prev)
     optimizer.step()

@@ -51,10 +51,10 @@ if order.startswith("patched"):
     # link_prediction.py:325); everything else passes through, and torch itself is untouched
     import mrgcn_amd.optim as fast
     for mod in (nc, lp):
-        assert mod.optim.Adam is fast.Adam and mod.nn.utils.clip_grad_norm_ is fast.clip_grad_norm_
+        assert mod.optim.Adam is fast.RowSparseAdam and mod.nn.utils.clip_grad_norm_ is fast.clip_grad_norm_
         assert mod.optim.SGD is torch.optim.SGD and mod.nn.CrossEntropyLoss is torch.nn.CrossEntropyLoss
         assert mod.nn.utils.clip_grad_value_ is torch.nn.utils.clip_grad_value_
-    assert torch.optim.Adam is not fast.Adam and torch.nn.utils.clip_grad_norm_ is not fast.clip_grad_norm_
+    assert torch.optim.Adam is not fast.RowSparseAdam and torch.nn.utils.clip_grad_norm_ is not fast.clip_grad_norm_
 else:
     assert nc.optim is torch.optim and nc.nn is torch.nn
 assert nc.MRGCN is my_mrgcn.MRGCN and lp.MRGCN is my_mrgcn.MRGCN
@@ -84,4 +84,53 @@ assert names == ["rgcn.layers.layer_0.b", "rgcn.layers.layer_0.weight_I", "rgcn.
 # ... and its optimizer grouping (tasks/utils.py:8-45) accepts the model
 groups = mrgcn.tasks.utils.optimizer_params(model, {}, True)
 assert sum(len(g["params"]) for g in groups) == len(names)
+
+# ... and an am.toml-shaped config with its hub tuples (configs/am.toml: distilbert for strings, mobilenet_v2 for
+# images; graph_features.py:184-236 turns them into `modules_config`) builds unchanged: torch.hub.load is the one
+# network call, replaced here by small stand-ins
+import torch.nn as tnn  # noqa: E402
+
+
+class _TinyLM(tnn.Module):
+    def __init__(self):
+        super().__init__()
+        self.emb = tnn.Embedding(50, 12)
+        self.lin = tnn.Linear(12, 12)
+
+    def forward(self, ids):
+        return (self.lin(self.emb(ids)),)
+
+
+class _TinyImageNet(tnn.Module):
+    def __init__(self):
+        super().__init__()
+        self.features = tnn.Sequential(tnn.Conv2d(3, 6, 3, padding=1), tnn.ReLU(), tnn.Conv2d(6, 8, 3, padding=1))
+        self.classifier = tnn.Linear(8, 5)
+
+
+hub_calls = []
+
+
+def _fake_hub(*a, **k):
+    hub_calls.append(a)
+    return _TinyLM() if a[1] == "model" else _TinyImageNet()
+
+
+torch.hub.load = _fake_hub
+modules_config = [("blob.image", (["pytorch/vision:v0.10.0", "mobilenet_v2", "MobileNet_V2_Weights.IMAGENET1K_V1"],
+                                  {"mode": "RGB", "mean": [0.485, 0.456, 0.406], "std": [0.229, 0.224, 0.225]}, 128, 0.0), False),
+                  ("xsd.date", (3, 3, 0.0), False), ("xsd.numeric", (1, 4, 0.0), False), ("xsd.numeric", (1, 4, 0.0), False),
+                  ("xsd.string", (["huggingface/pytorch-transformers", "model", "distilbert-base-multilingual-cased"], 16, 0.0), False)]
+am_config = {"model": {"layers": [{"hidden_nodes": 10, "type": "mrgcn"}, {"hidden_nodes": 10, "type": "mrgcn"}],
+                       "num_bases": 40, "p_dropout": 0.0, "bias": False}, "task": {}}
+Y11 = {"train": sp.csr_matrix((N, 11), dtype=np.int8)}
+am_model = nc.build_model(155, Y11, A, modules_config, am_config, False)
+assert type(am_model) is my_mrgcn.MRGCN and len(hub_calls) == 2, hub_calls
+assert am_model.modality_out_dim == 155 and am_model.rgcn.layers["layer_0"].weight_F.shape == (40, 155, 10)
+# tasks/utils.py:8-45: one optimizer group per datatype (named by the module_dict keys), one for the gates; frozen
+# backbone parameters are left out (imagecnn.py:18-20, transformer.py:17-19)
+optim_config = {dt: {"lr": 0.001} for dt in ("blob.image", "xsd.date", "xsd.numeric", "xsd.string", "gate_weights")}
+am_groups = mrgcn.tasks.utils.optimizer_params(am_model, optim_config, False)
+assert sum(len(g["params"]) for g in am_groups) == sum(p.requires_grad for p in am_model.parameters())
+assert len(am_groups) == 6, len(am_groups)
 print("dropin ok", order)

@@ -83,11 +83,46 @@ def test_backbone_heads_and_normalizer_match_reference():
     np.testing.assert_allclose(nz.normalize_(x[0]).numpy(), g["norm.single"], rtol=1e-6)
 
 
-def test_mrgcn_rejects_hub_configs_but_builds_the_rest():
-    from mrgcn_amd.models.mrgcn import MRGCN
+def test_mrgcn_takes_the_reference_hub_configs(monkeypatch):
+    """embedding_modules as graph_features.py:184-236 produces them for configs/am.toml: hub config lists for the
+    string and image backbones.  loadFromHub (models/utils.py:32-44) splits positional from key=value entries; ONE
+    language model and ONE image model are loaded and shared by all encoding sets (mrgcn.py:83-105)."""
+    from mrgcn_amd.models import mrgcn as M
+    calls = []
+
+    def fake_hub_load(*args, **kwargs):
+        calls.append((args, kwargs))
+        return TinyLM() if args[1] == "model" else TinyImageNet()
+    monkeypatch.setattr(torch.hub, "load", fake_hub_load)
+    lm_cfg = ["huggingface/pytorch-transformers", "model", "distilbert-base-multilingual-cased", "force_reload = False"]
+    im_cfg = ["pytorch/vision:v0.10.0", "mobilenet_v2", "MobileNet_V2_Weights.IMAGENET1K_V1"]
+    tr_cfg = {"mode": "RGB", "mean": [0.485, 0.456, 0.406], "std": [0.229, 0.224, 0.225]}
     modules = [(5, 4, "mrgcn", nn.ReLU()), (4, 2, "mrgcn", None)]
-    with pytest.raises(NotImplementedError):
+    emb = [("blob.image", (im_cfg, tr_cfg, 6, 0.0), False), ("blob.image", (im_cfg, tr_cfg, 6, 0.0), False),
+           ("xsd.numeric", (4, 4, 0.0), False),
+           ("xsd.anyURI", (lm_cfg, 3, 0.0), False), ("xsd.string", (lm_cfg, 5, 0.0), False)]
+    m = M.MRGCN(modules, emb, 3, 10)
+    assert calls == [(tuple(im_cfg), {}), (tuple(lm_cfg[:3]), {"force_reload": "False"})]  # one load per modality
+    assert set(m.gate_map) == {"blob_image_0", "blob_image_1", "xsd_numeric_0", "xsd_anyURI_0", "xsd_string_1"}
+    assert m.module_dict["xsd_anyURI_0"].base_model is m.module_dict["xsd_string_1"].base_model
+    assert m.im_norm is not None and m.modality_out_dim == 24
+    # the reference's parameter names (tasks/utils.py:20-43 splits them on '.')
+    names = [n for n, _ in m.named_parameters()]   # (the shared backbone is listed once, under its first head)
+    assert any(n.startswith("module_dict.xsd_anyURI_0.base_model.") for n in names)
+    assert "module_dict.xsd_string_1.fc.weight" in names
+
+
+def test_mrgcn_reports_a_failed_hub_load_and_builds_from_modules(monkeypatch):
+    from mrgcn_amd.models.mrgcn import MRGCN
+
+    def no_network(*a, **k):
+        raise OSError("no route to host")
+    monkeypatch.setattr(torch.hub, "load", no_network)
+    modules = [(5, 4, "mrgcn", nn.ReLU()), (4, 2, "mrgcn", None)]
+    with pytest.raises(RuntimeError, match="torch.hub.load.*pass the backbone nn.Module"):
         MRGCN(modules, [("xsd.string", (["huggingface/pytorch-transformers", "model", "distilbert"], 5, 0.0), False)], 3, 10)
+    with pytest.raises(TypeError):
+        MRGCN(modules, [("xsd.string", (42, 5, 0.0), False)], 3, 10)
     with pytest.raises(Exception, match="Datatype not supported"):
         MRGCN(modules, [("xsd.unknown", (1, 1, 0.0), False)], 3, 10)
     m = MRGCN(modules, [("blob.image", (TinyImageNet(), {"mean": [0.5] * 3, "std": [0.2] * 3}, 3, 0.0), False),

@@ -59,7 +59,7 @@ def test_reference_loop_vs_reference_goldens(name, flavour):
     tgt = torch.from_numpy(c["labels_y"]).cuda()
     n_adam = int(c["meta.n_adam"])
     Adam, clip = ((torch.optim.Adam, torch.nn.utils.clip_grad_norm_) if flavour == "torch"
-                  else (O.Adam, O.clip_grad_norm_))
+                  else (O.RowSparseAdam, O.clip_grad_norm_))
     node_major = [m.weight_I for m in model.layers.values() if m.weight_I_node_major]
 
     def check(step, model):
@@ -115,7 +115,7 @@ def test_fast_reference_loop_equals_the_dense_one_and_checkpoints_interchange():
     A, X, idx, tgt, N, R = _problem()
     ma, mb = _model(N, R), _model(N, R)
     oa, la = _reference_loop(ma, X, A, idx, tgt, torch.optim.Adam, torch.nn.utils.clip_grad_norm_, 3)
-    ob, lb = _reference_loop(mb, X, A, idx, tgt, O.Adam, O.clip_grad_norm_, 3)
+    ob, lb = _reference_loop(mb, X, A, idx, tgt, O.RowSparseAdam, O.clip_grad_norm_, 3)
     np.testing.assert_allclose(np.array(lb), np.array(la), rtol=1e-5, atol=1e-7)
     for (k, va), vb in zip(ma.state_dict().items(), mb.state_dict().values()):
         torch.testing.assert_close(vb, va, rtol=1e-6, atol=1e-7, msg=k)
@@ -128,7 +128,7 @@ def test_fast_reference_loop_equals_the_dense_one_and_checkpoints_interchange():
     # cross-load: the dense run continues on the fast path and the other way round (deep copies: the tags that mark
     # the node-major table must survive copy.deepcopy)
     mc, md = copy.deepcopy(ma), copy.deepcopy(mb)
-    oc, od = O.Adam(_groups(mc), lr=0.01), torch.optim.Adam(_groups(md), lr=0.01)
+    oc, od = O.RowSparseAdam(_groups(mc), lr=0.01), torch.optim.Adam(_groups(md), lr=0.01)
     O.load_reference_state_dict(oc, sa)
     O.load_reference_state_dict(od, sb)
     crit = torch.nn.CrossEntropyLoss()
@@ -152,8 +152,8 @@ def test_fast_loop_with_a_weight_regulariser_and_weight_decay_falls_back_to_dens
     from mrgcn_amd import optim as O
     A, X, idx, tgt, N, R = _problem(N=3000)
     res = []
-    for Adam, clip, wd in ((torch.optim.Adam, torch.nn.utils.clip_grad_norm_, 0.0), (O.Adam, O.clip_grad_norm_, 0.0),
-                           (torch.optim.Adam, torch.nn.utils.clip_grad_norm_, 0.01), (O.Adam, O.clip_grad_norm_, 0.01)):
+    for Adam, clip, wd in ((torch.optim.Adam, torch.nn.utils.clip_grad_norm_, 0.0), (O.RowSparseAdam, O.clip_grad_norm_, 0.0),
+                           (torch.optim.Adam, torch.nn.utils.clip_grad_norm_, 0.01), (O.RowSparseAdam, O.clip_grad_norm_, 0.01)):
         m = _model(N, R)
         opt = Adam(_groups(m), lr=0.01, weight_decay=wd)
         crit = torch.nn.CrossEntropyLoss()
@@ -172,3 +172,41 @@ def test_fast_loop_with_a_weight_regulariser_and_weight_decay_falls_back_to_dens
     for a, b in ((0, 1), (2, 3)):
         for k in res[a]:
             torch.testing.assert_close(res[b][k], res[a][k], rtol=1e-5, atol=1e-7, msg=k)
+
+
+def test_plain_adam_keeps_dense_gradients_so_that_torchs_clip_sees_the_node_table():
+    """`mrgcn_amd.optim.Adam` constructed directly (row_sparse=False by default) next to TORCH's clip_grad_norm_: the
+    node table's gradient stays in `.grad`, its norm is part of the total and it is scaled like every other gradient —
+    the loop equals torch's own.  (With the row-sparse form torch's clip would skip the node table: that form is only
+    announced by RowSparseAdam, which install_as_mrgcn(patch_optimizer=True) binds together with this package's clip.)"""
+    from mrgcn_amd import optim as O
+    A, X, idx, tgt, N, R = _problem(N=3000)
+    ma, mb = _model(N, R), _model(N, R)
+    oa, la = _reference_loop(ma, X, A, idx, tgt, torch.optim.Adam, torch.nn.utils.clip_grad_norm_, 3)
+    ob, lb = _reference_loop(mb, X, A, idx, tgt, O.Adam, torch.nn.utils.clip_grad_norm_, 3)
+    assert mb.layers["layer_0"].weight_I.grad is not None
+    np.testing.assert_allclose(np.array(lb), np.array(la), rtol=1e-5, atol=1e-7)
+    for (k, va), vb in zip(ma.state_dict().items(), mb.state_dict().values()):
+        torch.testing.assert_close(vb, va, rtol=1e-5, atol=1e-7, msg=k)
+
+
+def test_clip_with_a_gradient_on_another_device_goes_through_torch():
+    """a parameter whose gradient lives on the CPU (the reference spreads modules over model.devices) next to a
+    row-sparse node table: the fast clip must not read it as a device pointer — the entries are densified and torch's
+    clip runs"""
+    from mrgcn_amd import optim as O
+    A, X, idx, tgt, N, R = _problem(N=2000)
+    m = _model(N, R)
+    extra = torch.nn.Parameter(torch.ones(3))          # CPU parameter with a CPU gradient
+    opt = O.RowSparseAdam(_groups(m), lr=0.01)
+    loss = torch.nn.CrossEntropyLoss()(m(X, A)[idx], tgt) + (extra.sum() * 0.5).cuda()
+    opt.zero_grad()
+    loss.backward()
+    assert m.layers["layer_0"].weight_I.grad is None and extra.grad is not None
+    params = list(m.parameters()) + [extra]
+    # torch's own clip refuses tensors on several devices unless foreach=False; that is the call the fallback makes
+    norm = O.clip_grad_norm_(params, 1e9, foreach=False)   # (max_norm huge: gradients stay as they are)
+    assert m.layers["layer_0"].weight_I.grad is not None   # densified for torch's clip
+    want = torch.sqrt(sum((p.grad.double().cpu() ** 2).sum() for p in params if p.grad is not None))
+    assert abs(float(want) - float(norm)) < 1e-4 * float(norm) + 1e-6
+    opt.step()

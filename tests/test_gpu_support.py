@@ -1,0 +1,164 @@
+"""Gradient support (include/mrgcn_hip.h: mrgcn_support_*): its index arrays against a numpy restatement (bit-exact),
+its products through the C ABI against dense float64 arithmetic, and the epoch that runs on it against the epoch on
+the per-epoch marking path and against the float64 oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from tests.test_gpu_plan_spmm import _plan_from_coo, _random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _numpy_support(ref, row_flags, N, R):
+    """live columns / kept entries / nodes of `row_flags` on the numpy plan `ref` (tests/util.numpy_plan)"""
+    rowidx, ccol = ref["rowidx"].astype(np.int64), ref["ccol"].astype(np.int64)
+    live_entry = row_flags[rowidx] != 0
+    col_flags = np.zeros(ref["ncols"], dtype=np.uint8)
+    col_flags[ccol[live_entry]] = 1
+    lcol = np.nonzero(col_flags)[0].astype(np.int32)
+    lpos = np.cumsum(col_flags) - col_flags
+    cptr, crow, cval = ref["cptr"], ref["crow"], ref["cval"]
+    lptr, lrow, lval = [0], [], []
+    for c in lcol:
+        for e in range(cptr[c], cptr[c + 1]):
+            if row_flags[crow[e]]:
+                lrow.append(crow[e])
+                lval.append(cval[e])
+        lptr.append(len(lrow))
+    nptr = ref["nptr"].astype(np.int64)
+    lpos_ext = np.concatenate([lpos, [len(lcol)]])
+    nlptr = lpos_ext[nptr].astype(np.int32)
+    node_flags = (np.diff(nlptr) > 0).astype(np.uint8)
+    return dict(col_flags=col_flags, lcol=lcol, lrel=ref["urel"][lcol], nlptr=nlptr, node_flags=node_flags,
+                lptr=np.asarray(lptr, dtype=np.int32), lrow=np.asarray(lrow, dtype=np.int32),
+                lval=np.asarray(lval, dtype=np.float32), lnode=np.nonzero(node_flags)[0].astype(np.int32))
+
+
+@pytest.mark.parametrize("seed,N,R,nnz,hubs,labelled", [(0, 300, 7, 2500, 0, 12), (1, 1500, 11, 20000, 3, 40),
+                                                        (2, 200, 3, 600, 1, 200), (3, 4000, 9, 30000, 2, 1)])
+def test_support_arrays_equal_the_numpy_restatement(seed, N, R, nnz, hubs, labelled):
+    from mrgcn_amd import _lib as L
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = _random_graph(rng, N, N, R, nnz, hub_rows=hubs, hub_len=min(400, N), hub_cols=hubs)
+    plan = _plan_from_coo(rows, cols, vals, N, N, R)
+    ref = util.numpy_plan(rows, cols, vals, N, N, R)
+    flags = np.zeros(N, dtype=np.uint8)
+    flags[rng.choice(N, labelled, replace=False)] = 1
+    ft = torch.from_numpy(flags).cuda()
+    sup = plan.support_for(ft)
+    assert sup is plan.support_for(ft)  # kept under the identity of the flags tensor
+    want = _numpy_support(ref, flags, N, R)
+    assert (sup.L, sup.E, sup.NL) == (len(want["lcol"]), len(want["lrow"]), int(want["node_flags"].sum()))
+    for name in ("col_flags", "node_flags", "lcol", "lrel", "nlptr", "lptr", "lrow", "lval", "lnode"):
+        np.testing.assert_array_equal(sup.export(getattr(L, "SUP_" + name.upper())), want[name], err_msg=name)
+    # the relation-major list: a permutation of the live numbers, relations rising inside a node band
+    lperm = sup.export(L.SUP_LPERM)
+    np.testing.assert_array_equal(np.sort(lperm), np.arange(sup.L))
+    band = min(util.NODE_BAND, N)
+    unode = ref["unode"][want["lcol"][lperm]].astype(np.int64)
+    key = ((unode // band) * R + want["lrel"][lperm]) * band + unode % band
+    assert np.all(np.diff(key) > 0)
+    ft2 = ft.clone()
+    assert plan.support_for(ft2) is not sup  # another tensor: another support
+    plan.close()
+
+
+@pytest.mark.parametrize("F", [4, 10, 11, 16])
+def test_support_transposed_product_reads_the_flagged_rows_only(F):
+    from mrgcn_amd import _lib as L
+    rng = np.random.default_rng(5)
+    N, R = 2500, 13
+    rows, cols, vals = _random_graph(rng, N, N, R, 30000, hub_rows=2, hub_len=1500, hub_cols=3)
+    plan = _plan_from_coo(rows, cols, vals, N, N, R)
+    ref = util.numpy_plan(rows, cols, vals, N, N, R)
+    flags = np.zeros(N, dtype=np.uint8)
+    flags[rng.choice(N, 900, replace=False)] = 1  # (hub columns then keep hundreds of entries: the split-row path)
+    sup = plan.support_for(torch.from_numpy(flags).cuda())
+    dY = rng.standard_normal((N, F)).astype(np.float32)
+    dYp = dY.copy()
+    dYp[flags == 0] = np.nan  # rows outside the set must never be read
+    ld = (F + 3) // 4 * 4
+    dM = torch.full((sup.L, ld), 7.0, device="cuda")
+    d = torch.from_numpy(dYp).cuda()
+    L.check(L.load().mrgcn_support_spmm_t_f32(sup.handle, d.data_ptr(), d.stride(0), F, dM.data_ptr(), ld,
+                                              torch.cuda.current_stream().cuda_stream))
+    want = _numpy_support(ref, flags, N, R)
+    exp = np.zeros((sup.L, F))
+    for k in range(sup.L):
+        for e in range(want["lptr"][k], want["lptr"][k + 1]):
+            exp[k] += float(want["lval"][e]) * dY[want["lrow"][e]].astype(np.float64)
+    got = dM.cpu().numpy()[:, :F]
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5)
+    plan.close()
+
+
+def _epoch_runs(case_name, support, steps=3, row_sparse=None):
+    import mrgcn_amd.functional as Fn
+    from mrgcn_amd.train import ClipAdam, train_step
+    from tests.test_gpu_layers import _adjacency
+    c = util.load_case(case_name)
+    model, dims = util.build_rgcn_from_case(c, "cuda")
+    util.load_state_from_case(model, c)
+    model = model.cuda()
+    At = _adjacency(c, case_name)
+    X = None if bool(c["meta.featureless"]) else torch.from_numpy(c["X"]).cuda()
+    idx = torch.from_numpy(c["labels_idx"]).cuda()
+    tgt = torch.from_numpy(c["labels_y"]).cuda()
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    prev, Fn._SUPPORT = Fn._SUPPORT, support
+    try:
+        losses = [float(train_step(model, lambda: model(X, At), idx, tgt, opt, row_sparse=row_sparse))
+                  for _ in range(steps)]
+    finally:
+        Fn._SUPPORT = prev
+    return losses, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+def _cases():
+    return [n for n in util.rgcn_cases() if "labels_idx" in util.load_case(n).files]
+
+
+@pytest.mark.parametrize("case_name", _cases())
+@pytest.mark.parametrize("row_sparse", [None, False])
+def test_epochs_on_the_support_equal_epochs_on_the_marking_path(case_name, row_sparse):
+    l1, p1 = _epoch_runs(case_name, True, row_sparse=row_sparse)
+    l0, p0 = _epoch_runs(case_name, False, row_sparse=row_sparse)
+    np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-6)
+    for k in p0:
+        # (Adam's first steps are sign-like: a gradient entry whose sign flips between two summation orders moves
+        # by 2 lr; everything else agrees to rounding)
+        diff = np.abs(p1[k] - p0[k])
+        assert (diff > 2e-5).mean() <= 2e-3, (k, float(diff.max()))
+
+
+def test_the_default_epoch_runs_its_backward_on_supports(monkeypatch):
+    """a labelled model's train_step takes the support path in every layer: the C entry points are called, the
+    per-epoch marking product is not"""
+    import mrgcn_amd.functional as Fn
+    from mrgcn_amd import _lib as L
+    assert Fn._SUPPORT
+    lib = L.load()
+    seen = []
+
+    class _Spy:
+        def __init__(self, real):
+            self._real = real
+
+        def __getattr__(self, name):
+            fn = getattr(self._real, name)
+            if name.startswith("mrgcn_support_") or name.startswith("mrgcn_spmm_transposed_live"):
+                def wrapped(*a, **k):
+                    seen.append(name)
+                    return fn(*a, **k)
+                return wrapped
+            return fn
+    monkeypatch.setattr(L, "_lib", _Spy(lib))
+    name = [n for n in _cases() if "smoke" in n][0]
+    _epoch_runs(name, True, steps=2)
+    assert "mrgcn_support_spmm_t_f32" in seen
+    assert not any(n.startswith("mrgcn_spmm_transposed_live") for n in seen), seen
