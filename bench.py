@@ -549,8 +549,11 @@ def main_lp(args, emit=True):
                                     (N, R * N)).to(dev)
         model = RGCN(modules, R, N, B, 0.0, True, False, True).to(dev)
         model.set_engine(args.engine)
-        opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+        use_graph = bool(args.graph) and world == 1
+        opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=use_graph)
         plan = plan_of(A, N, R, operand_row_bytes=model.operand_row_bytes())
+        if use_graph:
+            gen = None   # torch's default generator: its state is registered with a captured graph and advances per replay
 
         def step():
             neg, Y = lp.sample_negatives_device(train_dev, gen)
@@ -574,6 +577,19 @@ def main_lp(args, emit=True):
         def step():
             neg, Y = lp.sample_negatives_device(train_dev, gen)
             return partitioned_lp_step(model, None, torch.cat([train_dev, neg]), Y, opt)
+    launch = "eager"
+    if not partitioned and use_graph:
+        from mrgcn_amd.train import GraphedStep
+        try:
+            graphed = GraphedStep(step, warmup=max(args.warmup, 2))
+            launch = "hipGraph replay"
+
+            def step():  # noqa: F811
+                return graphed()
+        except Exception as e:  # noqa: BLE001  (measurement harness only: time the eager epoch instead)
+            print("bench: hipGraph capture of the link-prediction epoch failed (%s); timing eager launches" % str(e)[:300],
+                  file=sys.stderr)
+            opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
     setup_s = time.time() - t0
     for _ in range(args.warmup):
         step()
@@ -624,7 +640,7 @@ def main_lp(args, emit=True):
                        "N": N, "R": R, "nnz": g.nnz, "ncols_touched": plan.ncols, "layers": [[0, H]], "num_bases": B,
                        "train_triples": int(ntrain), "negatives": "20 % in-batch, drawn on the device each epoch",
                        "decoder": "DistMult + BCE-with-logits", "value_mode": args.value_mode, "engine": args.engine,
-                       "launch": "eager", "params": n_params,
+                       "launch": launch, "params": n_params,
                        "parallelism": ("node-partitioned x%d" % world if partitioned else "replicas x%d" % world)
                        if world > 1 else "1 GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "spmm_hbm_gbps": ach,

@@ -16,8 +16,15 @@
  *     synchronise, so they may be captured into a hipGraph;
  *   - mrgcn_plan_create / _destroy / _export / mrgcn_event_* may allocate and
  *     synchronise;
- *   - buffers are caller owned; a plan owns only its own index copies and is
- *     immutable after creation (safe to share between threads / streams).
+ *   - buffers are caller owned; a plan owns its index copies, which are immutable after
+ *     creation, and the SCRATCH of its products (partial sums of rows cut into chunks, the
+ *     arrival counters of the in-kernel finalize), which every product launch writes.  The
+ *     plan keeps one scratch set PER STREAM: products of one plan may be in flight on several
+ *     streams (and be submitted from several threads) at once; products submitted to the same
+ *     stream are ordered by it.  The first product a plan sees on a second, third, ... stream
+ *     allocates that stream's set — the one exception to "compute calls never allocate": make
+ *     that first call outside a stream capture (it fails with MRGCN_ERR_INVALID inside one).
+ *     A gradient support (mrgcn_support_*) keeps ONE scratch set: one product in flight per support.
  */
 #ifndef MRGCN_HIP_H
 #define MRGCN_HIP_H

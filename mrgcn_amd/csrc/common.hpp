@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -136,6 +137,9 @@ int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8
                            float beta1, float beta2, float eps, int64_t step, const float *bc_dev,
                            const float *grad_scale, hipStream_t s);
 bool xform_use_mfma();
+// the product scratch of `p` for work submitted on stream `s` (see mrgcn_plan::stream_scratch); the first product of a
+// second, third ... stream allocates that stream's set and must therefore not run inside a stream capture
+int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t **ticket);
 }  // namespace mrgcn
 
 struct mrgcn_plan {
@@ -220,6 +224,13 @@ struct mrgcn_plan {
           *r3s_chunk_row = nullptr;
   int32_t r3s_n_chunks = 0;
   float *partials = nullptr;  // [max(r_n_chunks, c_n_chunks) * kWsFeatures]
+  // `partials` and `r3_ticket` are SCRATCH of the products, written by every launch: one set per stream that runs
+  // products on the plan, so that products on different streams never share it (mrgcn::plan_scratch).  The set above
+  // serves the first stream that asks; another stream gets its own at its first product on the plan.
+  struct StreamScratch { hipStream_t stream; float *partials; int32_t *ticket; };
+  mutable std::vector<StreamScratch> stream_scratch;
+  mutable std::mutex scratch_mu;
+  int64_t partials_floats = 0;
 
   mrgcn::SparseView view(int which) const {
     mrgcn::SparseView v;

@@ -825,6 +825,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     p->q_n_long = p->r_n_long; p->q_n_chunks = p->r_n_chunks;
     const int64_t ws_l = (int64_t)std::max(p->r_n_chunks, p->c_n_chunks) * kWsFeatures;
     MRGCN_HIP_TRY(plan_alloc(p, &p->partials, ws_l));
+    p->partials_floats = std::max<int64_t>(ws_l, 1);
     return MRGCN_OK;
   }
   // class-major processing order of the rows (COMPACT view)
@@ -996,8 +997,16 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   // (rows beyond kMid3Rows in chunks of kChunk3Entries, at most kChunk3Cap per row).  Descriptor "rows" are ranks.
   {
     int64_t dummy = 0;
+    // chunk size of k_spmm's split rows on this view: 512 entries of 40-byte operand rows are 20 KB per wave, 512
+    // entries of the 800-byte rows of a wide layer (FB15k-237: F = 200) are 410 KB walked by ONE wave while most of
+    // the chip idles (634 k entries / 512 = 1 240 waves for 1 024 SIMDs).  A plan hinted with wide operand rows cuts
+    // its long rows into chunks of 64 entries: ~10 k waves of 51 KB each.
+    int wide_bytes = 0;
+    for (int k = 0; k < hint.n; ++k) wide_bytes = std::max(wide_bytes, (int)hint.bytes[k]);
+    const int q_chunk = wide_bytes >= 256 ? 64 : kChunk;
     if ((rc = build_long(p, p->ptr3, p->num_rows, s, &p->q_long_row, &p->q_long_cptr, &p->q_chunk_beg,
-                         &p->q_chunk_end, &p->q_chunk_row, &p->q_n_long, &p->q_n_chunks, &dummy)))
+                         &p->q_chunk_end, &p->q_chunk_row, &p->q_n_long, &p->q_n_chunks, &dummy, kLongThreshold,
+                         q_chunk)))
       return rc;
     // k_spmm3: rows of kMid3Rows < len <= kChunk3Entries are one chunk = one wave each (r3s_*); longer rows are cut
     // blockwise (r3_*: 4 * nb equal chunks, a block of four waves adds its four sums in LDS)
@@ -1037,6 +1046,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   int64_t ws = (int64_t)std::max(std::max(p->r_n_chunks, p->q_n_chunks), p->c_n_chunks) * kWsFeatures;
   ws = std::max<int64_t>(ws, (int64_t)p->r3_n_chunks * 16);
   MRGCN_HIP_TRY(plan_alloc(p, &p->partials, ws));
+  p->partials_floats = std::max<int64_t>(ws, 1);
   return MRGCN_OK;
 }
 
@@ -1060,6 +1070,10 @@ void release_plan(mrgcn_plan *q, uint64_t ep) {
   // (after the wait any stream may take the blocks; the plan's own build stream is where the next build of a
   // similar slice will ask for them again: the pool hands them back without a driver call)
   for (void *a : ptrs) pool_free(a, q->build_stream, ep);
+  for (size_t i = 1; i < q->stream_scratch.size(); ++i) {  // (set 0 is `partials` / `r3_ticket` above)
+    pool_free(q->stream_scratch[i].partials, q->build_stream, ep);
+    pool_free(q->stream_scratch[i].ticket, q->build_stream, ep);
+  }
   delete q;
 }
 
@@ -1209,6 +1223,42 @@ __global__ void k_sup_rfill(const int32_t *__restrict__ rperm, const int32_t *__
   lperm[rpos[i]] = lpos[rperm[i]];
   lrin[rpos[i]] = rnode[i];
 }
+
+}  // namespace
+
+int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t **ticket) {
+  std::lock_guard<std::mutex> lock(p->scratch_mu);
+  for (const auto &e : p->stream_scratch)
+    if (e.stream == s) {
+      *partials = e.partials;
+      *ticket = e.ticket;
+      return MRGCN_OK;
+    }
+  if (p->stream_scratch.empty()) {  // the set the plan was built with
+    p->stream_scratch.push_back({s, p->partials, p->r3_ticket});
+    *partials = p->partials;
+    *ticket = p->r3_ticket;
+    return MRGCN_OK;
+  }
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+    set_error("the first product of a plan on a new stream allocates that stream's scratch: run one product on this "
+              "stream before capturing it");
+    return MRGCN_ERR_INVALID;
+  }
+  float *pa = nullptr;
+  int32_t *ti = nullptr;
+  MRGCN_HIP_TRY(pool_alloc((void **)&pa, (size_t)std::max<int64_t>(p->partials_floats, 1) * sizeof(float), s));
+  const size_t tb = (size_t)std::max<int64_t>(p->r3_n_long, 1) * sizeof(int32_t);
+  MRGCN_HIP_TRY(pool_alloc((void **)&ti, tb, s));
+  MRGCN_HIP_TRY(hipMemsetAsync(ti, 0, tb, s));  // arrival counters start at zero (and return to zero after every launch)
+  p->stream_scratch.push_back({s, pa, ti});
+  *partials = pa;
+  *ticket = ti;
+  return MRGCN_OK;
+}
+
+namespace {
 
 template <typename T> hipError_t sup_alloc(mrgcn_support *q, T **dst, int64_t n) {
   size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T);

@@ -93,7 +93,7 @@ __device__ __forceinline__ void gather_fma(const DT *Dq, int64_t ldD, int32_t c,
     if (nvalid < VEC) {
       const DT *p = Dq + (int64_t)c * ldD;
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) x[i] = (i < nvalid) ? (float)p[i] : 0.f;
+      for (int i = 0; i < VEC; ++i) x[i] = (i < nvalid) ? load_operand<DT>(p + i) : 0.f;
     } else {
       load_vec<VEC, DT>(Dq + (int64_t)c * ldD, x);
     }
@@ -182,11 +182,17 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const DT *__restrict
           gather_fma<VEC, TAIL, DT>(Dq, ldD, c, a, active && (t * kWave + src < n), acc, nvalid);
         }
       } else {
-        for (int u = 0; u < UPT; ++u) {
-          const int src = u * SLOTS + slot;
-          const int32_t c = __shfl(ci[t], src, kWave);
-          const float a = __shfl(ca[t], src, kWave);
-          gather_fma<VEC, TAIL, DT>(Dq, ldD, c, a, active && (t * kWave + src < n), acc, nvalid);
+        // few slots per wave (wide rows: G >= 16): eight gathers in flight per slot — one at a time the wave waited a
+        // full round trip per 800-byte row (FB15k-237 shape, F = 200: 128 -> see DESIGN §5)
+        for (int u0 = 0; u0 < UPT; u0 += 8) {
+          if (t * kWave + u0 * SLOTS >= n) break;  // wave uniform
+#pragma unroll
+          for (int u = u0; u < u0 + 8; ++u) {
+            const int src = u * SLOTS + slot;
+            const int32_t c = __shfl(ci[t], src, kWave);
+            const float a = __shfl(ca[t], src, kWave);
+            gather_fma<VEC, TAIL, DT>(Dq, ldD, c, a, active && (t * kWave + src < n), acc, nvalid);
+          }
         }
       }
     }
@@ -255,28 +261,31 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const DT *__restrict
       }
     }
   } else {
-    // wide rows (G >= 16): a row is already several cache lines; plain walk, four deep
-    int32_t k = b;
-    const int32_t e = b + n;
-    for (; k + 4 <= e; k += 4) {
-      const int32_t c0 = v.idx[k], c1 = v.idx[k + 1], c2 = v.idx[k + 2], c3 = v.idx[k + 3];
-      const float a0 = v.val[k], a1 = v.val[k + 1], a2 = v.val[k + 2], a3 = v.val[k + 3];
-      if (active) {
-        float x0[VEC], x1[VEC], x2[VEC], x3[VEC];
-        load_vec<VEC, DT>(Dq + (int64_t)c0 * ldD, x0);
-        load_vec<VEC, DT>(Dq + (int64_t)c1 * ldD, x1);
-        load_vec<VEC, DT>(Dq + (int64_t)c2 * ldD, x2);
-        load_vec<VEC, DT>(Dq + (int64_t)c3 * ldD, x3);
+    // wide rows (G >= 16): the slot's <= 32 entries are staged with coalesced loads (lane q of the slot holds
+    // entries q, q + G), then gathered eight at a time — index and gather are no longer two dependent round trips
+    constexpr int T2 = (kLongThreshold + G - 1) / G;
+    int32_t ci[T2];
+    float ca[T2];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          acc[i] = fmaf(a0, x0[i], acc[i]);
-          acc[i] = fmaf(a1, x1[i], acc[i]);
-          acc[i] = fmaf(a2, x2[i], acc[i]);
-          acc[i] = fmaf(a3, x3[i], acc[i]);
+    for (int t = 0; t < T2; ++t) {
+      const int32_t m = t * G + q;
+      ci[t] = (m < n) ? v.idx[b + m] : 0;
+      ca[t] = (m < n) ? v.val[b + m] : 0.f;
+    }
+    const int sbase = slot * G;
+    constexpr int GB = G < kLongThreshold ? G : kLongThreshold;  // entries a register of the slot can hold
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+      for (int u0 = 0; u0 < GB; u0 += 8) {
+        if (!__any(t * G + u0 < n)) break;  // wave uniform
+#pragma unroll
+        for (int u = u0; u < u0 + 8; ++u) {
+          const int32_t c = __shfl(ci[t], sbase + u, kWave);
+          const float a = __shfl(ca[t], sbase + u, kWave);
+          gather_fma<VEC, TAIL, DT>(Dq, ldD, c, a, active && (t * G + u < n), acc, nvalid);
         }
       }
     }
-    for (; k < e; ++k) gather_fma<VEC, TAIL, DT>(Dq, ldD, v.idx[k], v.val[k], active, acc, nvalid);
   }
   if (mine && active) {
     const int64_t orow = out_index ? (int64_t)out_index[row] : row;
@@ -972,7 +981,7 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
       if (xcd_per * 8 + chunk_blocks + single_blocks + mid_blocks > 0) {
         const dim3 grid((unsigned)(xcd_per * 8 + chunk_blocks + single_blocks + mid_blocks));
         // rows of exactly F >= 4 floats (TAIL): the padded-row instantiation with overlapping last vectors (`pack`)
-        constexpr bool PACKED = TAIL && sizeof(DT) == 4;
+        constexpr bool PACKED = TAIL;  // (fp32 rows of 4 F bytes, bf16 rows of 2 F bytes: F = 10 -> 40 / 20 bytes)
         const int pack = (PACKED && F >= VEC) ? 1 : 0;
 #define SPMM3_GO(T_, O_, W_)                                                                                       \
   k_spmm3<G, VEC, T_, DT, O_, W_><<<grid, dim3(256), 0, s>>>(v, *w3, D, ldD, F, Y, ldY, bias, relu,                \
@@ -1103,6 +1112,14 @@ int dispatch_bf16(const SparseView &v, const uint16_t *D, int64_t ldD, int64_t a
     int64_t padded = ((int64_t)F + w - 1) / w * w;
     return ldD % w == 0 && ((uintptr_t)D) % (w * 2) == 0 && avail >= padded;
   };
+  // packed bf16 rows of a narrow layer (ld = F, F not a multiple of four: 20-byte rows at F = 10): k_spmm3 with 8-byte
+  // gathers whose last vector overlaps its neighbour's (`pack`) — rows are only 4-byte aligned, which is all a global
+  // load needs.  COMPACT view only (w3): the general kernel keeps its 4-byte lanes for such rows.
+  if (w3 && ldD == F && F >= 4 && F <= 16 && (F & 3) && (F & 1) == 0 && ((uintptr_t)D) % 4 == 0 && avail >= F) {
+    const int l4 = (F + 3) / 4;
+    if (l4 <= 2) return launch<2, 4, true, uint16_t>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, false, s, w3);
+    return launch<4, 4, true, uint16_t>(v, D, ldD, F, Y, ldY, bias, relu, out_index, partials, false, s, w3);
+  }
   const int vec = ok(8) ? 8 : ok(4) ? 4 : ok(2) ? 2 : 1;
   const int lanes = (F + vec - 1) / vec;
 #define MRGCN_GO(G, V) \
@@ -1230,6 +1247,12 @@ extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, 
   MRGCN_REQUIRE(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   SparseView v = plan->view(MRGCN_VIEW_TRANSPOSED);
+  float *partials;
+  int32_t *ticket;
+  {
+    int rc = plan_scratch(plan, s, &partials, &ticket);
+    if (rc != MRGCN_OK) return rc;
+  }
   if (live_rows) MRGCN_HIP_TRY(hipMemsetAsync(live_rows, 0, sizeof(int32_t), s));
   if (F > 16) {  // wide layers: the general product, then the flags from its result
     int rc = mrgcn_spmm_f32(plan, MRGCN_VIEW_TRANSPOSED, D, ldD, F, Y, ldY, nullptr, 0, nullptr, stream);
@@ -1272,7 +1295,7 @@ extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, 
     // lanes per row as mrgcn_spmm_f32 picks them for 16-byte loads: the same summation order
 #define LIVE_LONG(G_)                                                                               \
   k_spmm<G_, 4, true, float, true><<<dim3((unsigned)chunk_blocks), dim3(256), 0, s>>>(              \
-      v, D, ldD, F, Y, ldY, nullptr, 0, nullptr, store_vec_ok ? 1 : 0, plan->partials, kWsFeatures, \
+      v, D, ldD, F, Y, ldY, nullptr, 0, nullptr, store_vec_ok ? 1 : 0, partials, kWsFeatures,       \
       (int)chunk_blocks, 0, 0, 0, row_live, col_live)
     if (F <= 4) LIVE_LONG(1);
     else if (F <= 8) LIVE_LONG(2);
@@ -1281,7 +1304,7 @@ extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, 
     MRGCN_HIP_TRY(hipGetLastError());
     if (v.n_multi > 0) {
       k_spmm_finalize<<<dim3((unsigned)(((int64_t)v.n_long + 3) / 4)), dim3(256), 0, s>>>(
-          v, plan->partials, kWsFeatures, F, Y, ldY, nullptr, 0, nullptr);
+          v, partials, kWsFeatures, F, Y, ldY, nullptr, 0, nullptr);
       MRGCN_HIP_TRY(hipGetLastError());
     }
   }
@@ -1305,6 +1328,12 @@ extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uin
   const int pad_ok = (relu & MRGCN_SPMM_PAD_WRITABLE) != 0;
   const int fold = (relu & MRGCN_SPMM_TWO_PASS) == 0 && spmm3_fold_default();
   relu &= MRGCN_SPMM_RELU;
+  float *partials;
+  int32_t *ticket;
+  {
+    int rc = plan_scratch(plan, (hipStream_t)stream, &partials, &ticket);
+    if (rc != MRGCN_OK) return rc;
+  }
   int tile = 64;
   if (ldD % 8 == 0 && ((uintptr_t)D) % 16 == 0) tile = 256;  // kWsFeatures floats of partials per chunk
   else if (ldD % 4 == 0 && ((uintptr_t)D) % 8 == 0) tile = 256;
@@ -1314,8 +1343,9 @@ extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uin
     View3 w3 = view3_of(plan);
     w3.pad_ok = pad_ok;
     w3.fold = fold;
+    w3.ticket = ticket;
     int rc = dispatch_bf16(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu, out_index,
-                           plan->partials, (hipStream_t)stream, (view == MRGCN_VIEW_COMPACT && F <= 16 && !plan->lean) ? &w3 : nullptr);
+                           partials, (hipStream_t)stream, (view == MRGCN_VIEW_COMPACT && F <= 16 && !plan->lean) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;
@@ -1339,6 +1369,12 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
   const int fold = (relu & MRGCN_SPMM_TWO_PASS) == 0 && spmm3_fold_default();
   relu &= MRGCN_SPMM_RELU;
   hipStream_t s = (hipStream_t)stream;
+  float *partials;
+  int32_t *ticket;
+  {
+    int rc = plan_scratch(plan, s, &partials, &ticket);
+    if (rc != MRGCN_OK) return rc;
+  }
   // feature tiles: one pass covers up to 64 lanes x VEC floats; the split-row workspace
   // holds kWsFeatures floats per chunk
   int tile = 64;  // scalar-load worst case
@@ -1359,8 +1395,9 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     View3 w3 = view3_of(plan);
     w3.pad_ok = pad_ok;
     w3.fold = fold;
+    w3.ticket = ticket;
     int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu,
-                      out_index, plan->partials, use_tiny, operand_cached, s,
+                      out_index, partials, use_tiny, operand_cached, s,
                       (view == MRGCN_VIEW_COMPACT && F <= 16 && !plan->lean) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
   }

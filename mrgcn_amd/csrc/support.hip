@@ -14,6 +14,8 @@
 //   Adam       = k_adam_rows_fused with (node -> live range, relation per live column) in place of the plan's arrays
 //
 // No atomics, no flags, no zero fills: every output is written whole, in a fixed order.
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -24,10 +26,30 @@ namespace {
 constexpr int kSupTB = 512;
 constexpr int kSqParts = 2048;  // per-block partial sums of ||dV||^2 (doubles), added in block order by k_dcomp_final
 
-// F floats of one basis row (rows 4 F bytes apart: 8-byte aligned when F is even)
+// F floats of one basis row (rows 4 F bytes apart: 8-byte aligned when F is even).  EXACT: F == FT, known at compile
+// time — the loads are then straight-line code (a run-time F puts every piece behind a branch, and the waitcnt pass
+// drains all outstanding loads at the first use behind a merge: DESIGN §3, "straight-line loads")
 typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-template <int FT>
+template <int FT, bool EXACT>
 __device__ __forceinline__ void load_basis_row(const float *__restrict__ p, int F, float (&v)[FT]) {
+  if constexpr (EXACT) {
+    if constexpr ((FT & 1) == 0) {
+#pragma unroll
+      for (int o = 0; o + 4 <= FT; o += 4) {
+        const f32x4_a8 t = *reinterpret_cast<const f32x4_a8 *>(p + o);
+        v[o] = t.x; v[o + 1] = t.y; v[o + 2] = t.z; v[o + 3] = t.w;
+      }
+      if constexpr ((FT & 3) != 0) {
+        const float2 t = *reinterpret_cast<const float2 *>(p + (FT & ~3));
+        v[FT & ~3] = t.x;
+        v[(FT & ~3) + 1] = t.y;
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < FT; ++o) v[o] = p[o];
+    }
+    return;
+  }
   if ((F & 1) == 0) {
 #pragma unroll
     for (int o = 0; o < FT; o += 4) {
@@ -55,74 +77,113 @@ __device__ __forceinline__ void load_basis_row(const float *__restrict__ p, int 
 }
 
 // Norm-only backward of the basis mix over the live nodes (see the file comment).  A wave fetches the (node, live
-// range) pairs of 64 live nodes with one coalesced load each and walks them; per node: lane b reads its row of the
-// node's V block, the node's dM rows arrive four at a time (16-lane group q reads row kb + q) and are handed round with
-// v_readlane; lane b stores D[k][b] (a live column's B products: one 4 B-byte row per column, coalesced) and keeps
-// the column's share of its dV row for the squared norm.
-template <int FT>
-__global__ __launch_bounds__(kSupTB) void k_mix_bwd_sup(const int32_t *__restrict__ lnode,
+// range) pairs of 64 live nodes with one coalesced load each and walks them NB at a time: the loads of NB nodes — lane
+// b its 4 F-byte row of each node's V block, the 16-lane group q row klo + q of each node's dM rows and its relation —
+// are issued back to back at clamped addresses in one basic block, then the nodes are finished one after the other
+// (the pass is bound by bytes in flight per wave: one node at a time it ran at 2.9 TB/s of its own traffic).  `comp`
+// lives in LDS (the relation ids arrive with the loads; a dependent global load per column would put a second round
+// trip on every node).  v_readlane hands a dM row and its relation round; lane b stores D[k][b] (a live column's B
+// products: one 4 B-byte row per column, coalesced) and keeps the column's share of its dV row for the squared norm.
+// Nodes with more than four live columns (9 % at the AM shape) walk the rest of their columns with direct loads.
+template <int FT, int NB, int TB, bool EXACT>
+__global__ __launch_bounds__(TB) void k_mix_bwd_sup(const int32_t *__restrict__ lnode,
                                                         const int32_t *__restrict__ lnptr,
                                                         const int32_t *__restrict__ lrel,
                                                         const float *__restrict__ dM, int64_t ldM,
                                                         const float *__restrict__ V, const float *__restrict__ comp,
-                                                        int64_t NL, int B, int F, float *__restrict__ D,
+                                                        int64_t NL, int R, int B, int F_, float *__restrict__ D,
                                                         double *__restrict__ sq_part) {
+  const int F = EXACT ? FT : F_;  // (a compile-time constant in the shapes that matter)
+  extern __shared__ __align__(16) float s_comp[];  // [R][B]
+  for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_comp[t] = comp[t];
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = blockDim.x >> 6;
   const bool on = lane < B;
   const int b = on ? lane : 0;
   const int kq = lane >> 4, oq = lane & 15;
+  const int oqc = oq < F ? oq : F - 1;
   const int64_t nwaves = (int64_t)gridDim.x * nw;
   float sq = 0.f;
   for (int64_t base = ((int64_t)blockIdx.x * nw + wv) * 64; base < NL; base += nwaves * 64) {
     const int64_t me = (base + lane < NL) ? base + lane : NL - 1;
     const int32_t jn = lnode[me], k0v = lnptr[me], k1v = lnptr[me + 1];
     const int cnt = (int)((NL - base < 64) ? NL - base : 64);
-    for (int i = 0; i < cnt; ++i) {
-      const int32_t j = __builtin_amdgcn_readlane(jn, i);
-      const int32_t klo = __builtin_amdgcn_readlane(k0v, i), khi = __builtin_amdgcn_readlane(k1v, i);
-      float v[FT];
-      load_basis_row<FT>(V + ((int64_t)j * B + b) * F, F, v);
-      float acc[FT];
+    for (int i0 = 0; i0 < cnt; i0 += NB) {
+      int32_t klo[NB], khi[NB], rmine[NB];
+      float v[NB][FT], dmine[NB];
 #pragma unroll
-      for (int o = 0; o < FT; ++o) acc[o] = 0.f;
-      for (int32_t kb = klo; kb < khi; kb += 4) {
-        const int32_t kk = kb + kq;
-        const bool cin = kk < khi;
-        const float dmine = (cin && oq < F) ? dM[(int64_t)kk * ldM + oq] : 0.f;
-        const int32_t rmine = cin ? lrel[kk] : 0;
-        int r[4];
-        float w[4];
+      for (int u = 0; u < NB; ++u) {  // every load of the step, unconditional at clamped addresses
+        const int ii = (i0 + u < cnt) ? i0 + u : cnt - 1;
+        const int32_t j = __builtin_amdgcn_readlane(jn, ii);
+        klo[u] = __builtin_amdgcn_readlane(k0v, ii);
+        khi[u] = __builtin_amdgcn_readlane(k1v, ii);
+        load_basis_row<FT, EXACT>(V + ((int64_t)j * B + b) * F, F, v[u]);
+        const int32_t kk = (klo[u] + kq < khi[u]) ? klo[u] + kq : klo[u];
+        dmine[u] = dM[(int64_t)kk * ldM + oqc];
+        rmine[u] = lrel[kk];
+      }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) r[t] = __builtin_amdgcn_readlane(rmine, 16 * t);
+      for (int u = 0; u < NB; ++u) {
+        if (i0 + u < cnt) {  // wave uniform
+          float acc[FT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) w[t] = comp[(int64_t)r[t] * B + b];  // R * B floats: cache resident
-        const int nc = (khi - kb < 4) ? khi - kb : 4;
+          for (int o = 0; o < FT; ++o) acc[o] = 0.f;
+          const int nc = (khi[u] - klo[u] < 4) ? khi[u] - klo[u] : 4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (t < nc) {  // wave uniform
-            float d[FT];
+          for (int t = 0; t < 4; ++t) {
+            if (t < nc) {  // wave uniform
+              const int r = __builtin_amdgcn_readlane(rmine[u], 16 * t);
+              const float w = s_comp[r * B + b];
+              float d[FT];
+#pragma unroll
+              for (int o = 0; o < FT; ++o)
+                d[o] = (o < F) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dmine[u]),
+                                                                                      16 * t + o))
+                               : 0.f;
+              float dot = 0.f;
+#pragma unroll
+              for (int o = 0; o < FT; ++o) dot = fmaf(d[o], v[u][o], dot);
+              if (on) D[(int64_t)(klo[u] + t) * B + b] = dot;
+#pragma unroll
+              for (int o = 0; o < FT; ++o) acc[o] = fmaf(w, d[o], acc[o]);
+            }
+          }
+          for (int32_t kb = klo[u] + 4; kb < khi[u]; kb += 4) {  // (few nodes have more than four live columns)
+            const int32_t kk = (kb + kq < khi[u]) ? kb + kq : kb;
+            const float dm = dM[(int64_t)kk * ldM + oqc];
+            const int32_t rm = lrel[kk];
+            const int nc2 = (khi[u] - kb < 4) ? khi[u] - kb : 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              if (t < nc2) {
+                const int r = __builtin_amdgcn_readlane(rm, 16 * t);
+                const float w = s_comp[r * B + b];
+                float d[FT];
+#pragma unroll
+                for (int o = 0; o < FT; ++o)
+                  d[o] = (o < F) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dm), 16 * t + o))
+                                 : 0.f;
+                float dot = 0.f;
+#pragma unroll
+                for (int o = 0; o < FT; ++o) dot = fmaf(d[o], v[u][o], dot);
+                if (on) D[(int64_t)(kb + t) * B + b] = dot;
+#pragma unroll
+                for (int o = 0; o < FT; ++o) acc[o] = fmaf(w, d[o], acc[o]);
+              }
+            }
+          }
+          if (on) {
 #pragma unroll
             for (int o = 0; o < FT; ++o)
-              d[o] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dmine), 16 * t + o));
-            float dot = 0.f;
-#pragma unroll
-            for (int o = 0; o < FT; ++o) dot = fmaf(d[o], v[o], dot);
-            if (on) D[(int64_t)(kb + t) * B + b] = dot;
-#pragma unroll
-            for (int o = 0; o < FT; ++o) acc[o] = fmaf(w[t], d[o], acc[o]);
+              if (o < F) sq = fmaf(acc[o], acc[o], sq);
           }
         }
       }
-      if (on) {
-#pragma unroll
-        for (int o = 0; o < FT; ++o)
-          if (o < F) sq = fmaf(acc[o], acc[o], sq);
-      }
     }
   }
-  __shared__ float s_sq[kSupTB / 64];
+  __shared__ float s_sq[TB / 64];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
   if (lane == 0) s_sq[wv] = sq;
@@ -135,12 +196,63 @@ __global__ __launch_bounds__(kSupTB) void k_mix_bwd_sup(const int32_t *__restric
 }
 
 // slab[chunk][b] = sum of D[k][b] over the live columns k of one relation-major chunk (<= kRelChunk columns of one
-// relation).  Lane = basis; the four waves take a quarter of the chunk each, 64 row numbers per load, eight row
-// gathers in flight.
+// (node band, relation) group).  A row of D is B floats = P = B / 4 16-byte pieces: lane l takes piece l % P of row
+// slot l / P, so one load instruction brings 64 / P rows (six at B = 40) and eight of them are in flight per wave; the
+// four waves take a quarter of the chunk each.  The row slots meet in LDS, added in a fixed order.
+using f32x4s = __attribute__((ext_vector_type(4))) float;
+template <int P>
 __global__ __launch_bounds__(256) void k_dcomp_chunks(const int32_t *__restrict__ chunk_beg,
                                                       const int32_t *__restrict__ chunk_end,
                                                       const int32_t *__restrict__ lperm, const float *__restrict__ D,
-                                                      int B, float *__restrict__ slab) {
+                                                      float *__restrict__ slab) {
+  constexpr int RPI = 64 / P;  // rows per load instruction
+  constexpr int B = 4 * P;
+  __shared__ f32x4s s_acc[4][RPI][P];
+  const int chunk = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int slot = lane / P, piece = lane - slot * P;
+  const bool on = slot < RPI;
+  const int32_t beg = chunk_beg[chunk], end = chunk_end[chunk];
+  const int32_t per = (end - beg + 3) >> 2;
+  const int32_t a0 = beg + wv * per, a1 = (a0 + per < end) ? a0 + per : end;
+  const f32x4s *D4 = reinterpret_cast<const f32x4s *>(D);
+  constexpr int U = (64 / RPI) < 8 ? (64 / RPI) : 8;  // load instructions per step (U * RPI <= 64 row numbers)
+  f32x4s acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int32_t e0 = a0; e0 < a1; e0 += U * RPI) {
+    const int32_t mine = (e0 + lane < a1) ? lperm[e0 + lane] : 0;
+    f32x4s x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = u * RPI + (on ? slot : 0);
+      const int32_t k = __shfl(mine, t, 64);
+      x[u] = D4[(int64_t)k * P + piece];  // (row 0 where the chunk has ended: masked below)
+    }
+#pragma unroll
+    for (int u = 0; u < U; u += 2) {
+      if (on && e0 + u * RPI + slot < a1) acc0 += x[u];
+      if (u + 1 < U && on && e0 + (u + 1) * RPI + slot < a1) acc1 += x[u + 1 < U ? u + 1 : u];
+    }
+  }
+  if (on) s_acc[wv][slot][piece] = acc0 + acc1;
+  __syncthreads();
+  if (threadIdx.x < (unsigned)B) {
+    const int pc = threadIdx.x >> 2, el = threadIdx.x & 3;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int sl = 0; sl < RPI; ++sl) t += s_acc[w][sl][pc][el];
+    slab[(int64_t)chunk * B + threadIdx.x] = t;
+  }
+}
+
+// any B: lane = basis, one row per load instruction
+__global__ __launch_bounds__(256) void k_dcomp_chunks_any(const int32_t *__restrict__ chunk_beg,
+                                                          const int32_t *__restrict__ chunk_end,
+                                                          const int32_t *__restrict__ lperm,
+                                                          const float *__restrict__ D, int B,
+                                                          float *__restrict__ slab) {
   __shared__ float s_part[4][64];
   const int chunk = blockIdx.x;
   const int lane = threadIdx.x & 63;
@@ -175,33 +287,41 @@ __global__ __launch_bounds__(256) void k_dcomp_chunks(const int32_t *__restrict_
         (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
 }
 
-// dcomp[r][b] = sum of relation r's chunk slabs (in chunk order; zeros for a relation without live columns);
-// the block after the last relation adds the per-block parts of ||dV||^2
-__global__ __launch_bounds__(64) void k_dcomp_final(const int32_t *__restrict__ chunk_ptr,
-                                                    const int32_t *__restrict__ chunk_ids,
-                                                    const float *__restrict__ slab, int R, int B,
-                                                    float *__restrict__ dcomp, const double *__restrict__ sq_part,
-                                                    int n_parts, double *__restrict__ sumsq) {
+// dcomp[r][b] = sum of relation r's chunk slabs (wave w adds chunks w, w + 4, ... in order, the four partial sums
+// meet in LDS; zeros for a relation without live columns); the block after the last relation adds the per-block parts
+// of ||dV||^2
+__global__ __launch_bounds__(256) void k_dcomp_final(const int32_t *__restrict__ chunk_ptr,
+                                                     const int32_t *__restrict__ chunk_ids,
+                                                     const float *__restrict__ slab, int R, int B,
+                                                     float *__restrict__ dcomp, const double *__restrict__ sq_part,
+                                                     int n_parts, double *__restrict__ sumsq) {
+  __shared__ float s_part[4][64];
   const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (r == R) {
-    if (!sumsq) return;
+    if (!sumsq || wv != 0) return;
     double t = 0.0;
-    for (int i = threadIdx.x; i < n_parts; i += 64) t += sq_part[i];
+    for (int i = lane; i < n_parts; i += 64) t += sq_part[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-    if (threadIdx.x == 0) *sumsq = t;
+    if (lane == 0) *sumsq = t;
     return;
   }
-  if ((int)threadIdx.x >= B) return;
   float s0 = 0.f, s1 = 0.f;
-  int c = chunk_ptr[r];
-  const int c1 = chunk_ptr[r + 1];
-  for (; c + 2 <= c1; c += 2) {
-    s0 += slab[(int64_t)chunk_ids[c] * B + threadIdx.x];
-    s1 += slab[(int64_t)chunk_ids[c + 1] * B + threadIdx.x];
+  if (lane < B) {
+    int c = chunk_ptr[r] + wv;
+    const int c1 = chunk_ptr[r + 1];
+    for (; c + 4 < c1; c += 8) {
+      s0 += slab[(int64_t)chunk_ids[c] * B + lane];
+      s1 += slab[(int64_t)chunk_ids[c + 4] * B + lane];
+    }
+    if (c < c1) s0 += slab[(int64_t)chunk_ids[c] * B + lane];
   }
-  if (c < c1) s0 += slab[(int64_t)chunk_ids[c] * B + threadIdx.x];
-  dcomp[(int64_t)r * B + threadIdx.x] = s0 + s1;
+  s_part[wv][lane] = s0 + s1;
+  __syncthreads();
+  if (threadIdx.x < (unsigned)B)
+    dcomp[(int64_t)r * B + threadIdx.x] =
+        (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
 }
 
 __global__ void k_xent_scatter_rows(const float *__restrict__ drows, const int64_t *__restrict__ idx, int64_t n, int C,
@@ -230,8 +350,8 @@ int mrgcn_support_spmm_t_f32(const mrgcn_support_t *q, const float *dY, int64_t 
 
 int64_t mrgcn_support_mix_bwd_workspace(const mrgcn_support_t *q, int32_t B) {
   if (!q || B <= 0) return 0;
-  // D [L][B] | slab [chunks][B] | parts of ||dV||^2 (doubles, 8-byte aligned)
-  return ((q->L + q->wide.n_chunks) * (int64_t)B + 1) / 2 * 2 + 2 * (int64_t)kSqParts;
+  // D [L][B] (16-byte aligned rows when B % 4 == 0) | slab [chunks][B] | parts of ||dV||^2 (doubles, 8-byte aligned)
+  return ((q->L + q->wide.n_chunks) * (int64_t)B + 3) / 4 * 4 + 2 * (int64_t)kSqParts;
 }
 
 int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t ldM, const float *V,
@@ -257,19 +377,52 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
   MRGCN_REQUIRE((F & 1) || (((uintptr_t)V) & 7) == 0, "V must be 8-byte aligned");
   MRGCN_REQUIRE(workspace && workspace_floats >= mrgcn_support_mix_bwd_workspace(q, B) && (((uintptr_t)workspace) & 7) == 0,
                 "workspace (mrgcn_support_mix_bwd_workspace floats, 8-byte aligned)");
+  const mrgcn_support::Order &o = q->wide;
   float *D = workspace;
   float *slab = D + q->L * (int64_t)B;
-  double *sq_part = reinterpret_cast<double *>(workspace + ((q->L + q->wide.n_chunks) * (int64_t)B + 1) / 2 * 2);
-  const int nw = kSupTB / 64;
+  double *sq_part = reinterpret_cast<double *>(workspace + ((q->L + o.n_chunks) * (int64_t)B + 3) / 4 * 4);
+  const size_t lds = (size_t)R * B * sizeof(float);
+  MRGCN_REQUIRE(lds <= 64 * 1024, "R * B * 4 must fit 64 KB of LDS");
+  // nodes in flight per wave (NB) x waves per CU.  512-thread blocks with two nodes per step (62 VGPRs at F = 10: three
+  // blocks of eight waves per CU, bounded by the 42 KB of comp in LDS); MRGCN_SUP_MIX = "<threads>x<nodes>" picks
+  // another shape (experiments)
+  static const char *cfg = getenv("MRGCN_SUP_MIX");
+  int tb = 512, nb = 2;  // AM shape, kernel alone on one box: 512x1 598 us, 512x2 512, 512x4 557, 1024x2 501
+  if (cfg && sscanf(cfg, "%dx%d", &tb, &nb) != 2) { tb = 512; nb = 2; }
+  if (tb != 1024) tb = 512;
+  if (tb == 1024 && nb > 2) nb = 2;
+  const int nw = tb / 64;
   int64_t grid = (q->NL + 64 * nw - 1) / (64 * nw);
-  static const int per_cu = getenv("MRGCN_SUP_MIX_PER_CU") ? atoi(getenv("MRGCN_SUP_MIX_PER_CU")) : 4;
+  int per_cu = (int)std::min<size_t>(tb == 1024 ? 2 : 4, (160 * 1024) / (lds + 1024));
+  if (per_cu < 1) per_cu = 1;
   if (grid > 256 * per_cu) grid = 256 * per_cu;
   if (grid > kSqParts) grid = kSqParts;
   if (grid < 1) grid = 1;
   const int FT = (F == 10 || F == 11) ? F : (F + 3) / 4 * 4;
-#define SUP_GO(T)                                                                                                  \
-  k_mix_bwd_sup<T><<<dim3((unsigned)grid), dim3(kSupTB), 0, s>>>(q->lnode, q->lnptr, q->lrel, dM, ldM, V, comp,   \
-                                                                  q->NL, B, F, D, sq_part)
+#define SUP_GO3(T, NB_, TB_)                                                                                        \
+  do {                                                                                                              \
+    if (F == T) SUP_GO4(T, NB_, TB_, true);                                                                         \
+    else SUP_GO4(T, 1, 512, false);                                                                                 \
+  } while (0)
+#define SUP_GO4(T, NB_, TB_, EX_)                                                                                   \
+  do {                                                                                                              \
+    auto kfn = k_mix_bwd_sup<T, NB_, TB_, EX_>;                                                                     \
+    static size_t lds_allowed = 48 * 1024; /* per instantiation: raise the dynamic-LDS limit once */                \
+    if (lds > lds_allowed) {                                                                                        \
+      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+      lds_allowed = lds;                                                                                            \
+    }                                                                                                               \
+    kfn<<<dim3((unsigned)grid), dim3(TB_), lds, s>>>(q->lnode, q->lnptr, q->lrel, dM, ldM, V, comp, q->NL, R, B, F, \
+                                                     D, sq_part);                                                   \
+  } while (0)
+#define SUP_GO(T)                                  \
+  do {                                             \
+    if (tb == 1024 && nb >= 2) SUP_GO3(T, 2, 1024); \
+    else if (tb == 1024) SUP_GO3(T, 1, 1024);      \
+    else if (nb >= 4) SUP_GO3(T, 4, 512);          \
+    else if (nb >= 2) SUP_GO3(T, 2, 512);          \
+    else SUP_GO3(T, 1, 512);                       \
+  } while (0)
   if (q->NL > 0) {
     switch (FT) {
       case 4: SUP_GO(4); break;
@@ -281,14 +434,21 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
     }
   }
 #undef SUP_GO
+#undef SUP_GO3
+#undef SUP_GO4
   MRGCN_HIP_TRY(hipGetLastError());
-  const mrgcn_support::Order &o = q->wide;
   if (o.n_chunks > 0) {
-    k_dcomp_chunks<<<dim3((unsigned)o.n_chunks), dim3(256), 0, s>>>(o.chunk_beg, o.chunk_end, o.lperm, D, B, slab);
+    const dim3 cg((unsigned)o.n_chunks);
+    const bool vec = (B % 4 == 0) && (((uintptr_t)D) % 16 == 0);
+    if (vec && B == 40) k_dcomp_chunks<10><<<cg, dim3(256), 0, s>>>(o.chunk_beg, o.chunk_end, o.lperm, D, slab);
+    else if (vec && B == 32) k_dcomp_chunks<8><<<cg, dim3(256), 0, s>>>(o.chunk_beg, o.chunk_end, o.lperm, D, slab);
+    else if (vec && B == 16) k_dcomp_chunks<4><<<cg, dim3(256), 0, s>>>(o.chunk_beg, o.chunk_end, o.lperm, D, slab);
+    else if (vec && B == 8) k_dcomp_chunks<2><<<cg, dim3(256), 0, s>>>(o.chunk_beg, o.chunk_end, o.lperm, D, slab);
+    else k_dcomp_chunks_any<<<cg, dim3(256), 0, s>>>(o.chunk_beg, o.chunk_end, o.lperm, D, B, slab);
     MRGCN_HIP_TRY(hipGetLastError());
   }
-  k_dcomp_final<<<dim3((unsigned)(R + 1)), dim3(64), 0, s>>>(o.chunk_ptr, o.chunk_ids, slab, R, B, dcomp, sq_part,
-                                                            q->NL > 0 ? (int)grid : 0, dV_sumsq);
+  k_dcomp_final<<<dim3((unsigned)(R + 1)), dim3(256), 0, s>>>(o.chunk_ptr, o.chunk_ids, slab, R, B, dcomp, sq_part,
+                                                             q->NL > 0 ? (int)grid : 0, dV_sumsq);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

@@ -186,10 +186,16 @@ def operand_row_bytes(F: int, bf16: bool = False) -> int:
 
 
 def _ld_for_bf16(F: int) -> int:
-    """bf16 operand rows: padded to a multiple of MRGCN_LDM_BF16_ALIGN elements.  4 (8-byte gathers,
-    rows no wider than the fp32 operand's, so the producers run no extra lanes) measured 0.15 ms per
-    AM epoch better than 8 (16-byte gathers)."""
-    a = int(os.environ.get("MRGCN_LDM_BF16_ALIGN", "4"))
+    """bf16 operand rows.  Narrow layers whose F is even and not a multiple of four keep PACKED rows (ld = F: 20-byte
+    rows at F = 10, 8-byte gathers with the row's last vector overlapping its neighbour's — k_spmm3 `pack`, as for the
+    fp32 operand); other widths are padded to a multiple of MRGCN_LDM_BF16_ALIGN elements (4: 8-byte gathers, rows no
+    wider than the fp32 operand's; measured 0.15 ms per AM epoch better than 8).  MRGCN_LDM_BF16_ALIGN set: always padded."""
+    a = os.environ.get("MRGCN_LDM_BF16_ALIGN")
+    if a is None:
+        if 4 <= F <= 16 and F % 4 and F % 2 == 0:
+            return F
+        a = "4"
+    a = int(a)
     return (F + a - 1) // a * a
 
 

@@ -110,6 +110,20 @@ def all_reduce_sum_(x: torch.Tensor, group=None) -> torch.Tensor:
     return x
 
 
+def _gathered_flags(flags: torch.Tensor, group) -> torch.Tensor:
+    """The row flags of every rank, gathered once and kept on the local flags tensor (a structural row set: the same
+    tensor every epoch).  A collective: every rank reaches it in the same backward (partitioned_loss gives every rank
+    structural flags, all-zero ones where a rank has no labelled node)."""
+    full = getattr(flags, "_mrgcn_gathered", None)
+    if full is None or full[0] != flags._version:
+        full = (flags._version, all_gather_rows(flags.contiguous(), group).contiguous())
+        try:
+            flags._mrgcn_gathered = full
+        except AttributeError:
+            pass
+    return full[1]
+
+
 class _ReduceScatterRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
@@ -118,7 +132,52 @@ class _ReduceScatterRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return all_gather_rows(g.contiguous(), ctx.group), None
+        g = g.contiguous()
+        meta = Fn._grad_meta(g)
+        out = all_gather_rows(g, ctx.group)
+        if meta is not None and meta.get("structural") and not meta.get("sparse_rows") and meta["row_live"] is not None:
+            # the rows that can hold anything are known on every rank: the gathered gradient carries the gathered
+            # flags, and the local layer's backward runs on the gradient support of that row set (functional.py)
+            Fn._set_grad_meta(out, _gathered_flags(meta["row_live"], ctx.group), meta["relu_applied"], structural=True)
+        return out, None
+
+
+class _ReluRows(torch.autograd.Function):
+    """relu(Y) whose backward hands the note on its gradient (functional._grad_meta: which rows can hold anything)
+    on to the masked gradient — torch.relu's backward returns a fresh tensor without it."""
+
+    @staticmethod
+    def forward(ctx, Y):
+        H = torch.relu(Y)
+        ctx.save_for_backward(H)
+        return H
+
+    @staticmethod
+    def backward(ctx, g):
+        (H,) = ctx.saved_tensors
+        meta = Fn._grad_meta(g)
+        if meta is not None and meta.get("relu_applied"):
+            return g
+        out = Fn.relu_bwd(g.contiguous(), H) if g.is_cuda else g * (H > 0)
+        if meta is not None and meta.get("structural") and not meta.get("sparse_rows"):
+            Fn._set_grad_meta(out, meta["row_live"], True, structural=True)
+        return out
+
+
+class _ZeroLoss(torch.autograd.Function):
+    """The loss share of a rank without a labelled node: 0, with a zero gradient that says so structurally (all-zero
+    row flags), so that this rank takes the same path through the backward — and the same collectives — as the others."""
+
+    @staticmethod
+    def forward(ctx, logits, flags):
+        ctx.flags, ctx.shape = flags, tuple(logits.shape)
+        return torch.zeros((), dtype=torch.float32, device=logits.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        d = torch.zeros(ctx.shape, dtype=torch.float32, device=ctx.flags.device)
+        Fn._set_grad_meta(d, ctx.flags, False, structural=True)
+        return d, None
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -198,7 +257,7 @@ class PartitionedRGCN(nn.Module):
             Y = _ReduceScatterRows.apply(Yp, self.group)                   # [S, out] own rows
             if layer.bias:
                 Y = Y + layer.b
-            H = torch.relu(Y) if self.relu[i] else Y
+            H = _ReluRows.apply(Y) if self.relu[i] else Y
         return H
 
     @torch.no_grad()
@@ -290,6 +349,12 @@ def partitioned_loss(logits_local, idx_global, targets, part: NodePartition, gro
     li, lt, share = _label_shard(idx_global, targets, part, logits_local.device)
     if li is not None:
         local = categorical_crossentropy(logits_local, li, lt) * share
+    elif logits_local.is_cuda:
+        zf = part.__dict__.get("_zero_flags")
+        if zf is None or zf.numel() != logits_local.shape[0] or zf.device != logits_local.device:
+            zf = part.__dict__["_zero_flags"] = torch.zeros((logits_local.shape[0],), dtype=torch.uint8,
+                                                            device=logits_local.device)
+        local = _ZeroLoss.apply(logits_local, zf)
     else:
         local = (logits_local * 0.0).sum()
     total = local.detach().clone()
@@ -346,7 +411,7 @@ class GraphedPartitionedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             self.loss = partitioned_train_step(*args)
         self.warmup_steps = max(warmup, 1)
 

@@ -16,6 +16,35 @@ def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# Handles whose owner was dropped while a stream capture was under way in this thread (typically the garbage collector
+# running a __del__ in the middle of a capture): releasing them waits for the device, which would invalidate the
+# capture, so they wait here for the next release outside one.
+_PARKED: list = []
+
+
+def _capturing() -> bool:
+    try:
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    except Exception:  # noqa: BLE001  (interpreter shutdown)
+        return False
+
+
+def _release(kind: str, handle, after_event=None):
+    lib = L.load()
+    if _capturing():
+        _PARKED.append((kind, handle))
+        return
+    while _PARKED:
+        k, h = _PARKED.pop()
+        (lib.mrgcn_support_destroy if k == "support" else lib.mrgcn_plan_destroy)(h)
+    if kind == "support":
+        lib.mrgcn_support_destroy(handle)
+    elif after_event is not None:
+        lib.mrgcn_plan_destroy_after(handle, after_event.cuda_event)
+    else:
+        lib.mrgcn_plan_destroy(handle)
+
+
 def _flags(prune_zeros, replicate, lean=False) -> int:
     """replicate: None = the library's default (env MRGCN_REPLICATE), True / False = force."""
     f = (L.PLAN_PRUNE_ZEROS if prune_zeros else 0) | (L.PLAN_LEAN if lean else 0)
@@ -116,6 +145,7 @@ class GraphPlan:
                 indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), 1 if value_mode == "ref_int8" else 0,
                 _flags(prune_zeros, replicate), C.cast(rb, C.c_void_p) if nrb else None, nrb,
                 _stream_ptr(self.device)), "mrgcn_plan_create_csr_hinted")
+        self.lean = False
         self.operand_row_bytes = tuple(rb) if nrb else ()
         self._adopt(handle)
         return self
@@ -138,10 +168,7 @@ class GraphPlan:
         if getattr(self, "_h", None) is not None and self._h:
             for sup in self.__dict__.pop("_supports", {}).values():  # (they read the plan's arrays: first)
                 sup.close()
-            if after_event is not None:
-                L.load().mrgcn_plan_destroy_after(self._h, after_event.cuda_event)
-            else:
-                L.load().mrgcn_plan_destroy(self._h)
+            _release("plan", self._h, after_event)
             self._h = None
 
     def __del__(self):
@@ -262,8 +289,12 @@ class GraphSupport:
     cache key) and to its plan."""
 
     def __init__(self, plan: GraphPlan, row_flags: torch.Tensor):
+        import weakref
         lib = L.load()
-        self.plan, self.row_flags, self.device = plan, row_flags, plan.device
+        # (a weak reference: the plan keeps its supports, not the other way round — no reference cycle, so both are
+        # released by reference counting when the plan goes, not by a collector run at an arbitrary moment)
+        self._plan = weakref.ref(plan)
+        self.row_flags, self.device = row_flags, plan.device
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(lib.mrgcn_support_create(C.byref(h), plan.handle, row_flags.data_ptr(), _stream_ptr(self.device)),
@@ -278,14 +309,18 @@ class GraphSupport:
         self._ws = {}
 
     @property
+    def plan(self):
+        return self._plan()
+
+    @property
     def handle(self):
         if self._h is None:
-            raise L.MrgcnError("support already destroyed")
+            raise L.MrgcnError("support already destroyed (its plan was closed)")
         return self._h
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            L.load().mrgcn_support_destroy(self._h)
+            _release("support", self._h)
             self._h = None
 
     def __del__(self):
@@ -308,12 +343,12 @@ class GraphSupport:
         return out.cpu().numpy()
 
     def node_flags(self) -> torch.Tensor:
-        """uint8 [num_nodes]: the nodes that own a live column — a view of the support's own array (valid while the
-        support lives): the row set of the layer below, and `row_cur` of the row-sparse Adam."""
+        """uint8 [num_nodes]: the nodes that own a live column (a copy of the support's array, made once: an ordinary
+        tensor with a lifetime of its own) — the row set of the layer below, and `row_cur` of the row-sparse Adam.
+        The same tensor object every call: its identity keys the support of the layer below."""
         if self._node_flags is None:
             ptr, n = self.array_ptr(L.SUP_NODE_FLAGS)
-            self._node_flags = _device_array(ptr, n, torch.uint8, self.device)
-            self._node_flags._mrgcn_owner = self  # (keeps the support alive as long as the view)
+            self._node_flags = _device_array(ptr, n, torch.uint8, self.device).clone()
         return self._node_flags
 
     def workspace(self, key, numel: int) -> torch.Tensor:

@@ -497,6 +497,31 @@ def train_step(model, forward_fn, idx, targets, optimizer, l1_lambda: float = 0.
     return loss.detach()
 
 
+class GraphedStep:
+    """Any allocation-stable, synchronisation-free step `fn()` (returning a device scalar) captured into a hipGraph and
+    replayed — e.g. one full-batch link-prediction epoch: negatives drawn on the device from torch's default generator
+    (whose state torch advances per replay), encoder, DistMult scores, BCE, backward, `ClipAdam(capturable=True)`.
+    `warmup` real calls run first, on the stream the capture then uses (plans and their per-stream scratch exist, lazily
+    built caches are filled)."""
+
+    def __init__(self, fn, warmup: int = 3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+            self.out = fn()
+        self.warmup_steps = max(warmup, 1)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out
+
+
 class GraphedTrainStep:
     """One full-batch epoch captured into a hipGraph (torch.cuda.CUDAGraph) and replayed: the ~40
     kernel launches of a step become one graph launch, which is what bounds the small shapes
@@ -523,8 +548,9 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: calls other threads make while this one captures (e.g. the process group's
-        # watchdog in a multi-rank job) do not invalidate the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        # watchdog in a multi-rank job) do not invalidate the capture.  Captured on the stream the warm-up steps ran
+        # on: whatever keeps scratch per stream (a plan's product scratch) has met this stream already.
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             self.loss = train_step(*args)
         # capturing executes nothing on the device: `warmup` optimizer steps have been taken so far (the
         # optimizer's device counter says the same; ClipAdam.state_dict() reads it back)

@@ -543,3 +543,61 @@ def test_plan_hinted_for_packed_operand_rows(row_bytes):
         Yp = plan.spmm(L.VIEW_COMPACT, Mg, F=F, bias=b, relu=True, padded_rows=True)
         assert torch.equal(Yp, Y)
         assert torch.equal(plan.spmm(L.VIEW_COMPACT, Mg, F=F, bias=b, relu=True, two_pass=True), Y)
+
+
+def test_products_of_one_plan_on_two_streams_at_once_equal_the_serial_results():
+    """include/mrgcn_hip.h: a plan keeps its product scratch (partial sums of split rows, arrival counters of the
+    in-kernel finalize) per stream.  Two COMPACT products with different operands run side by side on two streams,
+    many times over, on a graph with rows of several blocks; each must equal its own serial result bit for bit (a
+    shared scratch would mix the partial sums of the two, or let one launch's last arriver consume the other's
+    counter)."""
+    from mrgcn_amd import _lib as L
+    rng = np.random.default_rng(11)
+    N, R, F = 6000, 7, 10
+    rows, cols, vals = _random_graph(rng, N, N, R, 60000, hub_rows=6, hub_len=5000, hub_cols=2)
+    plan = _plan_from_coo(rows, cols, vals, N, N, R, row_bytes=[40])
+    assert plan.long_rows > 0
+    Ma = torch.randn((plan.nop, F), device="cuda")
+    Mb = torch.randn((plan.nop, F), device="cuda")
+    ref_a = plan.spmm(L.VIEW_COMPACT, Ma, F=F).clone()
+    ref_b = plan.spmm(L.VIEW_COMPACT, Mb, F=F).clone()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs_a, outs_b = [], []
+    for _ in range(40):
+        with torch.cuda.stream(sa):
+            outs_a.append(plan.spmm(L.VIEW_COMPACT, Ma, F=F))
+        with torch.cuda.stream(sb):
+            outs_b.append(plan.spmm(L.VIEW_COMPACT, Mb, F=F))
+    torch.cuda.synchronize()
+    for ya, yb in zip(outs_a, outs_b):
+        assert torch.equal(ya, ref_a) and torch.equal(yb, ref_b)
+    # the transposed (split-column) product too
+    dY = torch.randn((N, F), device="cuda")
+    ref_t = plan.spmm(L.VIEW_TRANSPOSED, dY, F=F).clone()
+    outs = []
+    for _ in range(20):
+        with torch.cuda.stream(sa):
+            outs.append(plan.spmm(L.VIEW_TRANSPOSED, dY, F=F))
+        with torch.cuda.stream(sb):
+            outs.append(plan.spmm(L.VIEW_COMPACT, Mb, F=F))
+    torch.cuda.synchronize()
+    for i, y in enumerate(outs):
+        assert torch.equal(y, ref_t if i % 2 == 0 else ref_b)
+    plan.close()
+
+
+def test_a_new_stream_cannot_take_its_first_product_inside_a_capture():
+    from mrgcn_amd import _lib as L
+    rng = np.random.default_rng(12)
+    N, R, F = 500, 3, 10
+    rows, cols, vals = _random_graph(rng, N, N, R, 3000)
+    plan = _plan_from_coo(rows, cols, vals, N, N, R)
+    M = torch.randn((plan.nop, F), device="cuda")
+    plan.spmm(L.VIEW_COMPACT, M, F=F)               # the build stream's own set
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(L.MrgcnError, match="before capturing"):
+        with torch.cuda.graph(g):                   # (torch captures on a side stream the plan has not seen)
+            plan.spmm(L.VIEW_COMPACT, M, F=F)
+    torch.cuda.synchronize()
+    plan.close()

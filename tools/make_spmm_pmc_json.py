@@ -26,14 +26,19 @@ def avg(dirpat, kernel_sub):
 
 
 def main():
+    """make_spmm_pmc_json.py <pass prefix> <kernel substring> [workload=am] [F=10] [operand=f32]"""
     base, kernel = sys.argv[1], sys.argv[2]
+    workload = sys.argv[3] if len(sys.argv) > 3 else "am"
+    F = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+    operand = sys.argv[5] if len(sys.argv) > 5 else "f32"
     c = {}
     for d in glob.glob(base + "*"):
         c.update(avg(d, kernel))
     rd = c.get("TCC_EA0_RDREQ_32B_sum", 0) * 32 + c.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 \
         + c.get("TCC_EA0_RDREQ_128B_sum", 0) * 128
     wr = c.get("WRITE_SIZE", 0) * 1024
-    out = {"workload": "am", "F": 10, "kernel": kernel, "source_digest": source_digest(), "counters": c,
+    out = {"workload": workload, "F": F, "operand": operand, "kernel": kernel, "source_digest": source_digest(),
+           "counters": c,
            "read_bytes_from_rdreq_sizes": rd, "read_bytes_fetch_size_x2": c.get("FETCH_SIZE", 0) * 1024 * 2,
            "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
     json.dump(out, sys.stdout, indent=1)
