@@ -554,12 +554,15 @@ def main_lp(args, emit=True):
         plan = plan_of(A, N, R, operand_row_bytes=model.operand_row_bytes())
         if use_graph:
             gen = None   # torch's default generator: its state is registered with a captured graph and advances per replay
+        # the training facts are the same every epoch: they sit at the head of one buffer, their orders for the decoder's
+        # backward are stored once, and one launch per epoch writes the 20 % corrupted copies behind them
+        sampler = lp.DeviceNegativeSampler(train_dev, gen)
+        static = lp.SortedTriples(sampler.facts, N, R)
 
         def step():
-            neg, Y = lp.sample_negatives_device(train_dev, gen)
-            t = torch.cat([train_dev, neg])
+            t, Y = sampler()
             emb = model(None, A)
-            score = lp.score_distmult_bc((t[:, 0], t[:, 1], t[:, 2]), emb, model.relations)
+            score = lp.score_distmult_bc(t, emb, model.relations, static=static)
             loss = lp.binary_crossentropy(score, Y)
             opt.zero_grad(set_to_none=True)
             loss.backward()
@@ -739,6 +742,15 @@ def partitioned_probe(args, name, dev, world, rank, steps=5, warmup=2):
     mdist.barrier(dev)
     out["collective_ms"] = mdist.max_over_ranks(time.perf_counter() - t0, dev) / steps * 1e3
     out["collective_bytes_per_step"] = sum(2 * part.Np * o * 4 for _, o in dims)
+    # the forward reduce-scatters alone: what a step cannot avoid — its backward all-gathers move the rows with
+    # gradient only (partition._live_row_exchange), a few thousand rows at these label counts
+    mdist.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for full_rows, _own in bufs:
+            reduce_scatter_rows(full_rows)
+    mdist.barrier(dev)
+    out["reduce_scatter_ms"] = mdist.max_over_ranks(time.perf_counter() - t0, dev) / steps * 1e3
     return out
 
 

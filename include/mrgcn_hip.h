@@ -269,6 +269,23 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *plan, float *dM, int64_t ldM, co
                             const float *V, const float *comp, int32_t B, int32_t F, float *dV,
                             uint8_t *node_cur, float *dcomp, double *dV_sumsq, void *stream);
 
+/* The same two gradients for a WIDE featureless layer with few bases (B <= 4, 16 < F <= 256, F % 4 == 0: the
+ * link-prediction encoder of configs/fb15k-237.toml, N x 200 with 2 bases) straight from the layer's output gradient,
+ * without the compact operand dM (one 4 F-byte row per touched column, written once and read twice by the pair
+ * mrgcn_spmm_f32(TRANSPOSED) + mrgcn_basis_mix_bwd_f32):
+ *     dV[j][b][:] = sum_{entries e = (i, (j, r), a)} comp[r][b] * a * dY[i][:]     (every block written)
+ *     dcomp[r][b] = sum_{entries of relation r} a * <dY[i][:], V[j][b][:]>
+ * over the plan's CSC entries, which are contiguous per source node.  The caller cuts the nodes' entry ranges into
+ * UNITS of a few hundred entries (unit_node / unit_beg / unit_end, entry numbers of the CSC order; unit_multi[u] != 0
+ * when its node has several units: those add with float atomics, the others store) and provides `erel`, the relation
+ * of every CSC entry (mrgcn_plan_entry_relations, once per plan).  dY: [num_rows, ldY], 16-byte aligned rows. */
+int mrgcn_plan_entry_relations(const mrgcn_plan_t *plan, int32_t *erel, void *stream);
+int32_t mrgcn_wide_input_bwd_supported(const mrgcn_plan_t *plan, int32_t B, int32_t F);
+int mrgcn_wide_input_bwd_f32(const mrgcn_plan_t *plan, const int32_t *erel, const int32_t *unit_node,
+                             const int32_t *unit_beg, const int32_t *unit_end, const uint8_t *unit_multi,
+                             int64_t n_units, const float *dY, int64_t ldY, const float *V, const float *comp,
+                             int32_t B, int32_t F, float *dV, float *dcomp, void *stream);
+
 /*     dX[j, 0:K]  = sum_{c in node j} W[r_c] . dM[c, :]     (nullable; every row written)
  *     dW[r, :, :] = sum_{c: r_c = r} X[j_c, :]^T dM[c, :]    (nullable; zeroed inside)
  * `workspace` (nullable; size from mrgcn_rel_transform_bwd_workspace) lets dX run on the matrix
@@ -355,6 +372,7 @@ typedef struct mrgcn_support_info {
   int64_t live_nodes;   /* nodes that own a live column                  */
   int64_t device_bytes;
   int64_t chunks_wide, chunks_narrow; /* relation-major chunks of the two transform orders */
+  int64_t flagged_rows; /* NR (MRGCN_SUPPORT_FORWARD supports; -1 otherwise) */
 } mrgcn_support_info_t;
 enum mrgcn_support_array_id {
   MRGCN_SUP_COL_FLAGS = 0,  /* uint8 [ncols]     1 = live                                   */
@@ -366,11 +384,27 @@ enum mrgcn_support_array_id {
   MRGCN_SUP_LROW = 6,       /* int32 [E]         output row of each kept entry               */
   MRGCN_SUP_LVAL = 7,       /* float [E]         its value                                   */
   MRGCN_SUP_LNODE = 8,      /* int32 [live_nodes] nodes that own a live column, rising       */
-  MRGCN_SUP_LPERM = 9       /* int32 [L]         live numbers in (node band, relation, node) order */
+  MRGCN_SUP_LPERM = 9,      /* int32 [L]         live numbers in (node band, relation, node) order */
+  /* MRGCN_SUPPORT_FORWARD supports only (count 0 otherwise): */
+  MRGCN_SUP_FROW = 10,      /* int32 [NR]        flagged rows, rising                        */
+  MRGCN_SUP_FPTR = 11,      /* int32 [NR+1]      entry range of each flagged row             */
+  MRGCN_SUP_FCOL = 12,      /* int32 [E]         live number of each entry's column (the plan's row order) */
+  MRGCN_SUP_FVAL = 13,      /* float [E]         its stored value                            */
+  MRGCN_SUP_LNODE_ORD = 14, /* int32 [L]         rank of the live column's node in LNODE     */
+  MRGCN_SUP_ROWRANK = 15    /* int32 [num_rows]  rank in FROW, -1 for rows outside the set   */
 };
 int mrgcn_support_create(mrgcn_support_t **support, const mrgcn_plan_t *plan, const uint8_t *row_flags,
                          void *stream);
+/* flags: MRGCN_SUPPORT_FORWARD also keeps the flagged rows as a CSR over (flagged row, live column), the ranks of
+ * rows and nodes and the relation-major orders by live-node rank: what the masked-pass calls below need. */
+#define MRGCN_SUPPORT_FORWARD 1u
+int mrgcn_support_create_ex(mrgcn_support_t **support, const mrgcn_plan_t *plan, const uint8_t *row_flags,
+                            uint32_t flags, void *stream);
 int mrgcn_support_destroy(mrgcn_support_t *support);
+/* The same without waiting for the device, for a support that lived for one step (a mini-batch): the caller states
+ * that every call that used the support was submitted to the stream it was created on (or is ordered before that
+ * stream's tail); its memory is handed to later work on that stream. */
+int mrgcn_support_destroy_ordered(mrgcn_support_t *support);
 int mrgcn_support_info(const mrgcn_support_t *support, mrgcn_support_info_t *h_info);
 int mrgcn_support_array(const mrgcn_support_t *support, int32_t which, const void **d_ptr, int64_t *h_count);
 /* dM[k, 0:F] = sum over the kept entries e of live column k of val[e] * dY[row[e], 0:F] — the TRANSPOSED product
@@ -409,6 +443,43 @@ int mrgcn_support_rel_transform_bwd_f32(const mrgcn_support_t *support, const fl
  * of mrgcn_softmax_xent_bwd_f32 (AM shape) goes away. */
 int mrgcn_softmax_xent_bwd_rows_f32(const float *drows, const int64_t *idx, int64_t n, int32_t C, const float *g,
                                     float *dlogits, int64_t ldd, void *stream);
+
+/* ---- a mini-batch layer as a masked pass over the full graph's plan ------------------------
+ * Replaces, for a re-sampled batch, the slice tensors and the per-batch plans of the frontier path below
+ * (mrgcn/data/batch.py:185-263, mrgcn/models/rgcn.py:91-128, mrgcn/layers/graph.py:62-102 with A_idx): the sample of
+ * a layer is the row-flag array of a MRGCN_SUPPORT_FORWARD support, its neighbours are the support's live nodes
+ * (LNODE = getNeighboursSparse(A, sample)), and every array is compact: activations [NR, F] by FROW rank, the
+ * neighbours' features / embeddings [live_nodes, K] by LNODE rank, per-column operands [L, ld] by live number.
+ * The sample of the layer below is NODE_FLAGS of this one.
+ *   spmm_fwd       Y[q] = act(bias + sum_e v[e] D[FCOL[e]]) over row FROW[q]'s entries; v = the stored values
+ *                  (use_values != 0: the input term, graph.py:75) or all ones (the feature term on the sliced
+ *                  adjacency, whose values sliceSparseCOO drops: batch.py:258-270).
+ *   spmm_t_compact dM[k] = sum over live column k's entries of v[e] dY[ROWRANK[row[e]]]  (dY: [NR, ldY])
+ *   mix_fwd        M[k] = sum_b comp[LREL[k], b] V[node of k, b]        (graph.py:66-74 on the live columns)
+ *   rel_transform_fwd / _bwd_compact   T[k] = X[LNODE_ORD[k]] . W[LREL[k]] (graph.py:83-95) and its backward: dW
+ *                  (nullable, written whole), dX [live_nodes, lddX] (nullable, every row written;
+ *                  `relu_mask_from_x` as mrgcn_rel_transform_bwd_masked_f32); workspace:
+ *                  mrgcn_support_rel_transform_bwd_workspace floats.  Shapes: mrgcn_support_rel_transform_supported
+ *                  (need_dX: the input gradient is wanted too — inputs of up to 64 floats per row).
+ * The weight_I gradient of the input term is mrgcn_support_mix_bwd_f32 / mrgcn_support_adam_rows_fused_f32 above
+ * (dM by live number, V blocks by node id).  One product per support in flight. */
+int mrgcn_support_spmm_fwd_f32(const mrgcn_support_t *support, int32_t use_values, const float *D, int64_t ldD,
+                               int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu, void *stream);
+int mrgcn_support_spmm_t_compact_f32(const mrgcn_support_t *support, int32_t use_values, const float *dY, int64_t ldY,
+                                     int32_t F, float *dM, int64_t ldM, void *stream);
+int mrgcn_support_mix_fwd_f32(const mrgcn_support_t *support, const float *V, const float *comp, int32_t B, int32_t F,
+                              float *M, int64_t ldM, void *stream);
+/* weight_I WITHOUT bases (the reference's literal (R*N) x F table, graph.py:72-74) on the live columns:
+ * scatter == 0: M[k] = table[LREL[k] * N + node(k)];  scatter != 0: table is zeroed whole, then those rows = M[k]. */
+int mrgcn_support_literal_rows_f32(const mrgcn_support_t *support, int32_t scatter, float *table, int32_t F, float *M,
+                                   int64_t ldM, void *stream);
+int32_t mrgcn_support_rel_transform_supported(const mrgcn_support_t *support, int32_t K, int32_t F, int32_t need_dX);
+int mrgcn_support_rel_transform_fwd_f32(const mrgcn_support_t *support, const float *X, int64_t ldX, int32_t K,
+                                        const float *W, int32_t F, float *T, int64_t ldT, void *stream);
+int mrgcn_support_rel_transform_bwd_compact_f32(const mrgcn_support_t *support, const float *dM, int64_t ldM,
+                                                const float *X, int64_t ldX, int32_t K, const float *W, int32_t F,
+                                                float *dX, int64_t lddX, float *dW, float *workspace,
+                                                int64_t workspace_floats, int32_t relu_mask_from_x, void *stream);
 
 /* ---- epoch kernels around the layers ----------------------------------------------
  * out = dY * (Y > 0): backward of the nn.ReLU between layers (rgcn.py:86-87) */
@@ -486,10 +557,22 @@ int mrgcn_distmult_score_bwd_f32(const float *E, int64_t ldE, const float *Rel, 
  * walking): k distinct pseudo-random indices below n in one launch — the corrupted facts of the device-side negative
  * sampler (tasks/link_prediction.py sample_negatives_device; torch.randperm(n)[:k] sorts n keys). */
 int mrgcn_random_subset_i64(int64_t n, int64_t k, const int64_t *seed_dev, int64_t *out, void *stream);
+/* The in-batch corruption of train_model (tasks/link_prediction.py:239-263) in one launch: out[k] (k < ncorrupt), rows
+ * (s, p, o), is a copy of fact pi(k) — ncorrupt DISTINCT facts of the n given, pi keyed by *seed_dev as above — with
+ * its head (k < nhead) or its tail replaced by nodes[u], u uniform in [0, n_nodes) (`nodes`: the batch's node set). */
+int mrgcn_corrupt_triples_i64(const int64_t *facts, int64_t n, const int64_t *nodes, int64_t n_nodes,
+                              const int64_t *seed_dev, int64_t ncorrupt, int64_t nhead, int64_t *out, void *stream);
 int64_t mrgcn_distmult_orders_workspace(int64_t n);
 int mrgcn_distmult_orders(const int64_t *triples, int64_t n, int64_t num_nodes, int64_t num_relations,
                           int64_t *order_s, int64_t *order_p, int64_t *order_o, void *workspace,
                           int64_t workspace_bytes, void *stream);
+/* the same three permutations for a SMALL triple set (the corrupted facts drawn anew every epoch) by a counting sort:
+ * a histogram pass, one scan block per column, a fill pass — four launches where the radix sort takes ~25
+ * launch-bound ones.  Ties in no particular order.  workspace: mrgcn_distmult_orders_counting_workspace bytes. */
+int64_t mrgcn_distmult_orders_counting_workspace(int64_t num_nodes, int64_t num_relations);
+int mrgcn_distmult_orders_counting(const int64_t *triples, int64_t n, int64_t num_nodes, int64_t num_relations,
+                                   int64_t *order_s, int64_t *order_p, int64_t *order_o, void *workspace,
+                                   int64_t workspace_bytes, void *stream);
 int mrgcn_distmult_score_bwd_sorted_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR,
                                         int32_t H, const int64_t *triples, int64_t n,
                                         const float *dscores, const int64_t *order_s,

@@ -41,11 +41,12 @@ class PlanInfo(C.Structure):
 
 class SupportInfo(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
-        "live_cols", "live_entries", "live_nodes", "device_bytes", "chunks_wide", "chunks_narrow")]
+        "live_cols", "live_entries", "live_nodes", "device_bytes", "chunks_wide", "chunks_narrow", "flagged_rows")]
 
 
 (SUP_COL_FLAGS, SUP_NODE_FLAGS, SUP_LCOL, SUP_LREL, SUP_NLPTR, SUP_LPTR, SUP_LROW, SUP_LVAL, SUP_LNODE,
- SUP_LPERM) = range(10)
+ SUP_LPERM, SUP_FROW, SUP_FPTR, SUP_FCOL, SUP_FVAL, SUP_LNODE_ORD, SUP_ROWRANK) = range(16)
+SUPPORT_FORWARD = 1
 
 _p = C.c_void_p
 _i32, _i64, _u32 = C.c_int32, C.c_int64, C.c_uint32
@@ -113,8 +114,11 @@ SIGNATURES = {
                                                       _p, _i64, _p]),
     "mrgcn_bce_logits_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p]),
     "mrgcn_random_subset_i64": (C.c_int, [_i64, _i64, _p, _p, _p]),
+    "mrgcn_corrupt_triples_i64": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _p, _p]),
     "mrgcn_distmult_orders_workspace": (C.c_int64, [_i64]),
     "mrgcn_distmult_orders": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
+    "mrgcn_distmult_orders_counting_workspace": (C.c_int64, [_i64, _i64]),
+    "mrgcn_distmult_orders_counting": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "mrgcn_distmult_ranks_workspace": (C.c_int64, [_i64, _i32, _i64]),
     "mrgcn_distmult_ranks": (C.c_int, [_p, _i64, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "mrgcn_adam_bias_f32": (C.c_int, [_p, C.c_float, C.c_float, _p, _p]),
@@ -140,8 +144,21 @@ SIGNATURES = {
     "mrgcn_frontier_workspace_bytes": (C.c_size_t, [_i64, _i64]),
     "mrgcn_frontier_count": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _p, _p, C.c_size_t, _p]),
     "mrgcn_frontier_emit": (C.c_int, [_p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "mrgcn_plan_entry_relations": (C.c_int, [_p, _p, _p]),
+    "mrgcn_wide_input_bwd_supported": (_i32, [_p, _i32, _i32]),
+    "mrgcn_wide_input_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "mrgcn_support_create": (C.c_int, [C.POINTER(_p), _p, _p, _p]),
+    "mrgcn_support_create_ex": (C.c_int, [C.POINTER(_p), _p, _p, _u32, _p]),
     "mrgcn_support_destroy": (C.c_int, [_p]),
+    "mrgcn_support_destroy_ordered": (C.c_int, [_p]),
+    "mrgcn_support_spmm_fwd_f32": (C.c_int, [_p, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _p]),
+    "mrgcn_support_spmm_t_compact_f32": (C.c_int, [_p, _i32, _p, _i64, _i32, _p, _i64, _p]),
+    "mrgcn_support_mix_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _i64, _p]),
+    "mrgcn_support_literal_rows_f32": (C.c_int, [_p, _i32, _p, _i32, _p, _i64, _p]),
+    "mrgcn_support_rel_transform_supported": (_i32, [_p, _i32, _i32, _i32]),
+    "mrgcn_support_rel_transform_fwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _i64, _p]),
+    "mrgcn_support_rel_transform_bwd_compact_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p,
+                                                              _i64, _i32, _p]),
     "mrgcn_support_info": (C.c_int, [_p, C.POINTER(SupportInfo)]),
     "mrgcn_support_array": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_i64)]),
     "mrgcn_support_spmm_t_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p]),

@@ -125,7 +125,12 @@ int segment_sum_arrays(const int32_t *nptr, int64_t num_nodes, int64_t nz_rows, 
 // internal launchers shared with support.hip
 // Y = v . D on an arbitrary CSR-shaped view (spmm.hip); `partials`: v.n_chunks * kWsFeatures floats
 int spmm_on_view(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, int64_t ldY, float *partials,
-                 hipStream_t s);
+                 hipStream_t s, const float *bias = nullptr, int relu = 0);
+// the basis mix over explicit arrays (rgcn_fused.hip): entry t of a node list owns columns nptr[t] .. nptr[t+1] (their
+// relations in urel) and reads V block node_ids[t] (NULL: t); row c of M is column c's
+int mix_fwd_arrays(const int32_t *nptr, const int32_t *urel, const int32_t *node_ids, int64_t n_nodes, int64_t ncols,
+                   int R, const float *V, const float *comp, int32_t B, int32_t F, float *M, int64_t ldM,
+                   hipStream_t s);
 // k_mix_bwd_nm over explicit node -> column-range / relation arrays (rgcn_fused.hip); -1: shape outside its limits
 int mix_bwd_nm_arrays(const int32_t *nptr, const int32_t *urel, int64_t N, int R, int top_rel, const float *dM,
                       int64_t ldM, const float *V, const float *comp, int32_t B, int32_t F, float *dV, float *dcomp,
@@ -137,6 +142,11 @@ int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8
                            float beta1, float beta2, float eps, int64_t step, const float *bc_dev,
                            const float *grad_scale, hipStream_t s);
 bool xform_use_mfma();
+// hipMemsetAsync for the compute calls (plan.hip).  On a capturing stream the fill is one kernel of this package:
+// a captured hipMemsetAsync whose size is not a whole number of 16-byte pieces becomes a memset node that ROCm 7.2
+// replays once and then faults on ("write access to a read-only page", second replay; found with the 174 504-byte
+// histogram of mrgcn_distmult_orders_counting) — kernel nodes replay fine.
+hipError_t fill_async(void *dst, int byte_value, size_t bytes, hipStream_t s);
 // the product scratch of `p` for work submitted on stream `s` (see mrgcn_plan::stream_scratch); the first product of a
 // second, third ... stream allocates that stream's set and must therefore not run inside a stream capture
 int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t **ticket);
@@ -282,8 +292,26 @@ struct mrgcn_support {
           *t_chunk_row = nullptr;
   int32_t t_n_long = 0, t_n_chunks = 0;
   float *partials = nullptr;
+  // FORWARD arrays (MRGCN_SUPPORT_FORWARD: a mini-batch layer as a masked pass over the full plan — the flagged rows
+  // are the batch's sample, the live nodes its neighbours): the flagged rows in rising order with their entries in the
+  // plan's row order, columns by live number; ranks so that activations / gradients can stay compact
+  // ([flagged rows] x F, [live nodes] x K)
+  int64_t NR = 0;                  // flagged rows
+  int32_t *frow = nullptr;         // [NR]       flagged row ids, rising
+  int32_t *rowrank = nullptr;      // [num_rows] rank among the flagged rows, -1 elsewhere
+  int32_t *fptr = nullptr, *fcol = nullptr;  // [NR+1], [E]  CSR over the flagged rows, column = live number
+  float *fval = nullptr;           // [E]        stored values in that order
+  float *ones = nullptr;           // [E]        1.0f (the feature term of a mini-batch multiplies the all-ones slice)
+  int32_t *lrow_rank = nullptr;    // [E]        rowrank of lrow (the transposed view over compact gradients)
+  int32_t *lnode_ord = nullptr;    // [L]        rank of the live column's node among the live nodes
+  int32_t *f_long_row = nullptr, *f_long_cptr = nullptr, *f_chunk_beg = nullptr, *f_chunk_end = nullptr,
+          *f_chunk_row = nullptr;
+  int32_t f_n_long = 0, f_n_chunks = 0;
+  float *f_partials = nullptr;
+  bool has_forward = false;
   struct Order {  // live columns in (node band, relation, node) order, cut like common.hpp: RelOrder
     int32_t *lperm = nullptr, *lrin = nullptr;  // [L] live index / source node
+    int32_t *lrin_ord = nullptr;                // [L] (forward arrays) rank of that node among the live nodes
     int32_t *chunk_rel = nullptr, *chunk_beg = nullptr, *chunk_end = nullptr, *chunk_ptr = nullptr, *chunk_ids = nullptr;
     int32_t n_chunks = 0, max_chunks = 0;
   } wide, narrow;
@@ -297,10 +325,26 @@ struct mrgcn_support {
     v.n_multi = t_n_chunks - t_n_long;
     return v;
   }
-  mrgcn::RelOrder order_for(int input_width) const {
+  // the forward view (rows = flagged rows by rank) and the transposed view over compact gradients; `use_values` = the
+  // stored values, else all ones
+  mrgcn::SparseView fview(bool use_values) const {
+    mrgcn::SparseView v;
+    v.rows = NR; v.ptr = fptr; v.idx = fcol; v.val = use_values ? fval : ones;
+    v.n_long = f_n_long; v.n_chunks = f_n_chunks; v.long_row = f_long_row; v.long_cptr = f_long_cptr;
+    v.chunk_beg = f_chunk_beg; v.chunk_end = f_chunk_end; v.chunk_row = f_chunk_row;
+    v.n_multi = f_n_chunks - f_n_long;
+    return v;
+  }
+  mrgcn::SparseView tview_ranked(bool use_values) const {
+    mrgcn::SparseView v = tview();
+    v.idx = lrow_rank;
+    v.val = use_values ? lval : ones;
+    return v;
+  }
+  mrgcn::RelOrder order_for(int input_width, bool by_ordinal = false) const {
     const Order &q = (input_width <= mrgcn::kNarrowInput && has_narrow) ? narrow : wide;
     mrgcn::RelOrder o;
-    o.rperm = q.lperm; o.rnode = q.lrin; o.rmpos = nullptr; o.relchunk_rel = q.chunk_rel; o.relchunk_beg = q.chunk_beg;
+    o.rperm = q.lperm; o.rnode = by_ordinal ? q.lrin_ord : q.lrin; o.rmpos = nullptr; o.relchunk_rel = q.chunk_rel; o.relchunk_beg = q.chunk_beg;
     o.relchunk_end = q.chunk_end; o.relchunk_ptr = q.chunk_ptr; o.relchunk_ids = q.chunk_ids;
     o.n_relchunks = q.n_chunks; o.max_relchunks = q.max_chunks;
     return o;

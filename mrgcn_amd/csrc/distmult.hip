@@ -120,6 +120,104 @@ __global__ void k_distmult_bwd_sorted(const float *__restrict__ E, int64_t ldE, 
   flush();
 }
 
+// ---- the same two kernels for rows of whole 16-byte pieces (H % 4 == 0, H <= 256, 16-byte aligned rows) ----------
+// lane = four features: a row is ONE load instruction, and the index words of a wave's triples are fetched with one
+// coalesced load each up front — the kernels above chase order -> triple -> row through three dependent round trips
+// per triple with one row in flight (145 us per sorted pass at the FB15k-237 shape, all of it latency).
+using f32x4d = __attribute__((ext_vector_type(4))) float;
+constexpr int kFwdTPW = 4;  // triples per wave of the forward
+
+__global__ __launch_bounds__(kTB) void k_distmult_fwd4(const float *__restrict__ E, int64_t ldE,
+                                                       const float *__restrict__ Rel, int64_t ldR, int H,
+                                                       const int64_t *__restrict__ tr, int64_t n,
+                                                       float *__restrict__ scores) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * (kTB / kWave) + (threadIdx.x >> 6);
+  const int64_t t0 = w * kFwdTPW;
+  if (t0 >= n) return;
+  const int cnt = (int)((n - t0 < kFwdTPW) ? n - t0 : kFwdTPW);
+  // lane l < 3 * cnt holds word l of the wave's triples
+  const int32_t mine = (lane < 3 * cnt) ? (int32_t)tr[3 * t0 + lane] : 0;
+  const bool on = 4 * lane < H;
+  const int f0 = on ? 4 * lane : 0;
+  f32x4d sv[kFwdTPW], pv[kFwdTPW], ov[kFwdTPW];
+#pragma unroll
+  for (int u = 0; u < kFwdTPW; ++u) {
+    const int uu = u < cnt ? u : cnt - 1;
+    const int64_t si = __builtin_amdgcn_readlane(mine, 3 * uu), pi = __builtin_amdgcn_readlane(mine, 3 * uu + 1),
+                  oi = __builtin_amdgcn_readlane(mine, 3 * uu + 2);
+    sv[u] = *reinterpret_cast<const f32x4d *>(E + si * ldE + f0);
+    pv[u] = *reinterpret_cast<const f32x4d *>(Rel + pi * ldR + f0);
+    ov[u] = *reinterpret_cast<const f32x4d *>(E + oi * ldE + f0);
+  }
+#pragma unroll
+  for (int u = 0; u < kFwdTPW; ++u) {
+    const f32x4d q = sv[u] * pv[u] * ov[u];
+    float acc = on ? (q.x + q.y) + (q.z + q.w) : 0.f;
+    acc = wave_sum(acc);
+    if (lane == 0 && u < cnt) scores[t0 + u] = acc;
+  }
+}
+
+template <int WHICH>
+__global__ __launch_bounds__(kTB) void k_distmult_bwd_sorted4(const float *__restrict__ E, int64_t ldE,
+                                                              const float *__restrict__ Rel, int64_t ldR, int H,
+                                                              const int64_t *__restrict__ tr,
+                                                              const int64_t *__restrict__ order, int64_t n,
+                                                              const float *__restrict__ g, float *__restrict__ out,
+                                                              int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * (kTB / kWave) + (threadIdx.x >> 6);
+  const int64_t t0 = w * kRun;
+  if (t0 >= n) return;
+  const int cnt = (int)((n - t0 < kRun) ? n - t0 : kRun);
+  // lane l < cnt holds sorted triple t0 + l: its three ids and its score gradient (two dependent loads for the whole
+  // wave instead of three per triple)
+  const int64_t i = order[t0 + (lane < cnt ? lane : cnt - 1)];
+  const int32_t si = (int32_t)tr[3 * i], pi = (int32_t)tr[3 * i + 1], oi = (int32_t)tr[3 * i + 2];
+  const float gi = g[i];
+  const bool on = 4 * lane < H;
+  const int f0 = on ? 4 * lane : 0;
+  f32x4d acc = {0.f, 0.f, 0.f, 0.f};
+  int32_t cur = -1;
+  auto flush = [&]() {
+    if (cur >= 0 && on) {
+      float *o = out + (int64_t)cur * ldo + f0;
+      if (acc.x != 0.f) atomicAdd(o + 0, acc.x);
+      if (acc.y != 0.f) atomicAdd(o + 1, acc.y);
+      if (acc.z != 0.f) atomicAdd(o + 2, acc.z);
+      if (acc.w != 0.f) atomicAdd(o + 3, acc.w);
+    }
+    acc = f32x4d{0.f, 0.f, 0.f, 0.f};
+  };
+  for (int tb = 0; tb < cnt; tb += 4) {
+    f32x4d a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // four triples' rows in flight
+      const int tt = (tb + u < cnt) ? tb + u : cnt - 1;
+      const int64_t s_ = __builtin_amdgcn_readlane(si, tt), p_ = __builtin_amdgcn_readlane(pi, tt),
+                    o_ = __builtin_amdgcn_readlane(oi, tt);
+      const float *ap = WHICH == 0 ? Rel + p_ * ldR : E + s_ * ldE;  // the two rows that are multiplied
+      const float *bp = WHICH == 2 ? Rel + p_ * ldR : E + o_ * ldE;
+      a[u] = *reinterpret_cast<const f32x4d *>(ap + f0);
+      b[u] = *reinterpret_cast<const f32x4d *>(bp + f0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (tb + u < cnt) {  // wave uniform
+        const int32_t key = __builtin_amdgcn_readlane(WHICH == 0 ? si : WHICH == 1 ? pi : oi, tb + u);
+        const float gt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gi), tb + u));
+        if (key != cur) {
+          flush();
+          cur = key;
+        }
+        acc += (a[u] * gt) * b[u];
+      }
+    }
+  }
+  flush();
+}
+
 // loss = mean(max(x,0) - x y + log1p(exp(-|x|))),  dx = (sigmoid(x) - y) / n
 __global__ void k_bce_logits(const float *__restrict__ x, const float *__restrict__ y, int64_t n,
                              float *__restrict__ loss, float *__restrict__ dx) {
@@ -334,6 +432,54 @@ __global__ void k_widen_i32(const int32_t *__restrict__ a, int64_t n, int64_t *_
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i];
 }
+// ---- the three orders of a SMALL triple set by counting sort (the freshly drawn corrupted facts of an epoch: 54 k at
+// the FB15k-237 shape).  A radix sort of so few keys is ~25 launch-bound kernels; here: one histogram pass, one scan
+// block per column, one fill pass.  Ties keep no particular order (none is needed).
+__global__ void k_count3(const int64_t *__restrict__ tr, int64_t n, int32_t *__restrict__ cnt, int64_t stride) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  atomicAdd(&cnt[tr[3 * i]], 1);
+  atomicAdd(&cnt[stride + tr[3 * i + 1]], 1);
+  atomicAdd(&cnt[2 * stride + tr[3 * i + 2]], 1);
+}
+// exclusive scan of cnt[c * stride .. + bins_c) in place, one 1024-thread block per column
+__global__ __launch_bounds__(1024) void k_scan3(int32_t *__restrict__ cnt, int64_t stride, int64_t bins_n, int64_t bins_r) {
+  __shared__ int32_t s_sum[1024];
+  const int c = blockIdx.x;
+  const int64_t bins = c == 1 ? bins_r : bins_n;
+  int32_t *a = cnt + c * stride;
+  const int64_t per = (bins + 1023) / 1024;
+  const int64_t b0 = threadIdx.x * per, b1 = min(b0 + per, bins);
+  int32_t t = 0;
+  for (int64_t k = b0; k < b1; ++k) t += a[k];
+  s_sum[threadIdx.x] = t;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele over the 1024 partial sums
+    const int32_t v = (int)threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0;
+    __syncthreads();
+    s_sum[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int32_t run = s_sum[threadIdx.x] - t;  // exclusive prefix of this thread's slice
+  for (int64_t k = b0; k < b1; ++k) {
+    const int32_t v = a[k];
+    a[k] = run;
+    run += v;
+  }
+}
+__global__ void k_fill3(const int64_t *__restrict__ tr, int64_t n, int32_t *__restrict__ off, int64_t stride,
+                        int64_t *__restrict__ o0, int64_t *__restrict__ o1, int64_t *__restrict__ o2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  o0[atomicAdd(&off[tr[3 * i]], 1)] = i;
+  o1[atomicAdd(&off[stride + tr[3 * i + 1]], 1)] = i;
+  o2[atomicAdd(&off[2 * stride + tr[3 * i + 2]], 1)] = i;
+}
+
+inline bool rows_vec4_ok(const float *E, int64_t ldE, const float *Rel, int64_t ldR, int H) {
+  static const bool on = !(getenv("MRGCN_LP_VEC4") && atoi(getenv("MRGCN_LP_VEC4")) == 0);
+  return on && H % 4 == 0 && H <= 256 && ldE % 4 == 0 && ldR % 4 == 0 && (((uintptr_t)E | (uintptr_t)Rel) & 15) == 0;
+}
 inline int key_bits(int64_t bound) {
   int b = 1;
   while (b < 31 && (bound >> b) != 0) ++b;
@@ -382,9 +528,59 @@ __global__ void k_random_subset(int64_t n, int64_t k, const int64_t *__restrict_
   } while (x >= (uint64_t)n);
   out[i] = (int64_t)x;
 }
+
+// The whole in-batch corruption of train_model (tasks/link_prediction.py:239-263) in one launch: corrupted fact k
+// (k < ncorrupt = n / 5) is a copy of fact pi(k) — pi the keyed bijection above, i.e. ncorrupt DISTINCT facts — whose
+// head (k < nhead) or tail is replaced by a node of the batch drawn with replacement (`nodes`: the batch's node set).
+__global__ void k_corrupt_triples(const int64_t *__restrict__ facts, int64_t n, const int64_t *__restrict__ nodes,
+                                  int64_t n_nodes, const int64_t *__restrict__ seed, int half_bits, int64_t ncorrupt,
+                                  int64_t nhead, int64_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncorrupt) return;
+  const uint64_t sd = (uint64_t)*seed;
+  uint32_t key[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) key[r] = feistel_f((uint32_t)(sd >> (r & 1 ? 32 : 0)) + 0x632BE5ABu * (r + 1), (uint32_t)(sd >> 17) ^ (r * 0x27D4EB2Fu));
+  const uint64_t mask = (1ull << half_bits) - 1;
+  uint64_t x = (uint64_t)i;
+  do {
+    uint32_t L = (uint32_t)(x >> half_bits), R = (uint32_t)(x & mask);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const uint32_t t = L ^ (uint32_t)(feistel_f(R, key[r]) & mask);
+      L = R;
+      R = t;
+    }
+    x = ((uint64_t)L << half_bits) | R;
+  } while (x >= (uint64_t)n);
+  int64_t s_ = facts[3 * x], p_ = facts[3 * x + 1], o_ = facts[3 * x + 2];
+  // a 64-bit draw per corrupted fact, reduced to [0, n_nodes) by multiply-shift (no modulo bias worth the name)
+  const uint64_t h = ((uint64_t)feistel_f((uint32_t)i, key[0] ^ 0x9E3779B9u) << 32) | feistel_f((uint32_t)i ^ 0x5bd1e995u, key[3]);
+  const int64_t pick = nodes[(int64_t)(((unsigned __int128)h * (unsigned __int128)(uint64_t)n_nodes) >> 64)];
+  if (i < nhead) s_ = pick; else o_ = pick;
+  out[3 * i] = s_;
+  out[3 * i + 1] = p_;
+  out[3 * i + 2] = o_;
+}
 }  // namespace
 
 extern "C" {
+
+int mrgcn_corrupt_triples_i64(const int64_t *facts, int64_t n, const int64_t *nodes, int64_t n_nodes,
+                              const int64_t *seed_dev, int64_t ncorrupt, int64_t nhead, int64_t *out, void *stream) {
+  MRGCN_REQUIRE(n >= 0 && ncorrupt >= 0 && ncorrupt <= n && nhead >= 0 && nhead <= ncorrupt && n < ((int64_t)1 << 62),
+                "0 <= nhead <= ncorrupt <= n");
+  if (ncorrupt == 0) return MRGCN_OK;
+  MRGCN_REQUIRE(facts && nodes && seed_dev && out && n_nodes > 0, "NULL / empty node set");
+  int bits = 2;
+  while (bits < 62 && ((int64_t)1 << bits) < n) ++bits;
+  if (bits & 1) ++bits;
+  MRGCN_REQUIRE(bits / 2 <= 32, "n too large");
+  k_corrupt_triples<<<dim3((unsigned)((ncorrupt + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      facts, n, nodes, n_nodes, seed_dev, bits / 2, ncorrupt, nhead, out);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
 
 int mrgcn_random_subset_i64(int64_t n, int64_t k, const int64_t *seed_dev, int64_t *out, void *stream) {
   MRGCN_REQUIRE(n >= 0 && k >= 0 && k <= n && n < ((int64_t)1 << 62), "0 <= k <= n");
@@ -406,7 +602,12 @@ int mrgcn_distmult_score_f32(const float *E, int64_t ldE, const float *Rel, int6
   if (n == 0) return MRGCN_OK;
   hipStream_t st = (hipStream_t)stream;
   const int per = kTB / kWave;
-  k_distmult_fwd<<<(unsigned)((n + per - 1) / per), kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, n, scores);
+  if (rows_vec4_ok(E, ldE, Rel, ldR, H)) {
+    const int64_t waves = (n + kFwdTPW - 1) / kFwdTPW;
+    k_distmult_fwd4<<<(unsigned)((waves + per - 1) / per), kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, n, scores);
+  } else {
+    k_distmult_fwd<<<(unsigned)((n + per - 1) / per), kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, n, scores);
+  }
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
@@ -470,6 +671,32 @@ int mrgcn_distmult_orders(const int64_t *triples, int64_t n, int64_t num_nodes, 
   return MRGCN_OK;
 }
 
+int64_t mrgcn_distmult_orders_counting_workspace(int64_t num_nodes, int64_t num_relations) {
+  const int64_t stride = std::max(num_nodes, num_relations) + 1;
+  return 3 * stride * (int64_t)sizeof(int32_t);
+}
+
+int mrgcn_distmult_orders_counting(const int64_t *triples, int64_t n, int64_t num_nodes, int64_t num_relations,
+                                   int64_t *order_s, int64_t *order_p, int64_t *order_o, void *workspace,
+                                   int64_t workspace_bytes, void *stream) {
+  MRGCN_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && num_nodes > 0 && num_relations > 0, "sizes");
+  MRGCN_REQUIRE(num_nodes <= (1 << 22) && num_relations <= (1 << 22), "counting sort: at most 4 M bins per column");
+  if (n == 0) return MRGCN_OK;
+  MRGCN_REQUIRE(triples && order_s && order_p && order_o && workspace &&
+                    workspace_bytes >= mrgcn_distmult_orders_counting_workspace(num_nodes, num_relations),
+                "NULL / workspace");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t stride = std::max(num_nodes, num_relations) + 1;
+  int32_t *cnt = (int32_t *)workspace;
+  MRGCN_HIP_TRY(mrgcn::fill_async(cnt, 0, (size_t)(3 * stride) * sizeof(int32_t), s));
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  k_count3<<<dim3(blocks), dim3(256), 0, s>>>(triples, n, cnt, stride);
+  k_scan3<<<dim3(3), dim3(1024), 0, s>>>(cnt, stride, num_nodes, num_relations);
+  k_fill3<<<dim3(blocks), dim3(256), 0, s>>>(triples, n, cnt, stride, order_s, order_p, order_o);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
 int mrgcn_distmult_score_bwd_sorted_f32(const float *E, int64_t ldE, const float *Rel, int64_t ldR, int32_t H,
                                         const int64_t *triples, int64_t n, const float *dscores,
                                         const int64_t *order_s, const int64_t *order_p, const int64_t *order_o,
@@ -480,6 +707,18 @@ int mrgcn_distmult_score_bwd_sorted_f32(const float *E, int64_t ldE, const float
   hipStream_t st = (hipStream_t)stream;
   const int64_t waves = (n + kRun - 1) / kRun;
   dim3 grid((unsigned)((waves + kTB / kWave - 1) / (kTB / kWave)), (unsigned)((H + kRunF - 1) / kRunF));
+  if (rows_vec4_ok(E, ldE, Rel, ldR, H) && (!dE || (lddE % 4 == 0 && ((uintptr_t)dE & 15) == 0)) &&
+      (!dRel || (lddR % 4 == 0 && ((uintptr_t)dRel & 15) == 0))) {
+    dim3 g4((unsigned)((waves + kTB / kWave - 1) / (kTB / kWave)));
+    if (dE) {
+      k_distmult_bwd_sorted4<0><<<g4, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_s, n, dscores, dE, lddE);
+      k_distmult_bwd_sorted4<2><<<g4, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_o, n, dscores, dE, lddE);
+    }
+    if (dRel)
+      k_distmult_bwd_sorted4<1><<<g4, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_p, n, dscores, dRel, lddR);
+    MRGCN_HIP_TRY(hipGetLastError());
+    return MRGCN_OK;
+  }
   if (dE) {
     k_distmult_bwd_sorted<0><<<grid, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_s, n, dscores, dE, lddE);
     k_distmult_bwd_sorted<2><<<grid, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_o, n, dscores, dE, lddE);
@@ -493,7 +732,7 @@ int mrgcn_distmult_score_bwd_sorted_f32(const float *E, int64_t ldE, const float
 int mrgcn_bce_logits_f32(const float *x, const float *y, int64_t n, float *loss, float *dx, void *stream) {
   MRGCN_REQUIRE(x && y && loss && n > 0, "bce_logits: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  MRGCN_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
+  MRGCN_HIP_TRY(mrgcn::fill_async(loss, 0, sizeof(float), st));
   int64_t b = (n + kTB - 1) / kTB;
   if (b > 1024) b = 1024;
   k_bce_logits<<<(unsigned)b, kTB, 0, st>>>(x, y, n, loss, dx);

@@ -741,7 +741,7 @@ int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
     g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
     grid.z = (unsigned)((K + g.kchunk - 1) / g.kchunk);
     const int64_t celems = cmode == 2 ? (int64_t)(M / o.cg.Tout) * o.cg.Cout * o.cg.Tout : (int64_t)M * N;
-    MRGCN_HIP_TRY(hipMemsetAsync(o.C, 0, (size_t)celems * sizeof(float), stream));
+    MRGCN_HIP_TRY(mrgcn::fill_async(o.C, 0, (size_t)celems * sizeof(float), stream));
   }
 #define MM_GO1(AM_, BM_, CM_, AR_, BR_, MT_, NT_, BK_) \
   k_mm_tile<AM_, BM_, CM_, AR_, BR_, MT_, NT_, BK_><<<grid, dim3(256), 0, stream>>>(g)
@@ -875,7 +875,7 @@ int mrgcn_colsum_f32(const float *X, int64_t ld, int32_t M, int32_t N, float *ou
   if (N == 0) return MRGCN_OK;
   const unsigned cols = (unsigned)((N + 63) / 64);
   unsigned slabs = M >= 512 ? std::min<unsigned>((unsigned)(M / 128), std::max(1u, 512u / cols)) : 1u;
-  if (slabs > 1) MRGCN_HIP_TRY(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream));
+  if (slabs > 1) MRGCN_HIP_TRY(mrgcn::fill_async(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream));
   k_colsum_f32<<<dim3(cols, slabs), dim3(256), 0, (hipStream_t)stream>>>(X, ld, M, N, out);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;

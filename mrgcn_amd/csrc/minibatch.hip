@@ -136,7 +136,7 @@ int mrgcn_frontier_count(const int64_t *indptr, const int64_t *indices, int64_t 
   k_fr_len<<<nblocks(n_sample + 1), kTB, 0, s>>>(indptr, sample, n_sample, w.len);
   size_t tb = w.tmp_bytes;
   MRGCN_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w.tmp, tb, w.len, row_off, (int)(n_sample + 1), s));
-  MRGCN_HIP_TRY(hipMemsetAsync(w.flag, 0, (size_t)(num_nodes + 1) * sizeof(int32_t), s));
+  MRGCN_HIP_TRY(mrgcn::fill_async(w.flag, 0, (size_t)(num_nodes + 1) * sizeof(int32_t), s));
   if (n_sample > 0) {
     const int64_t waves = n_sample;
     int64_t grid = (waves * 64 + kTB - 1) / kTB;

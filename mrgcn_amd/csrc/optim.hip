@@ -677,10 +677,10 @@ int mrgcn_softmax_xent_f32(const float *logits, int64_t ld, int32_t C, const int
   MRGCN_REQUIRE(logits && idx && target && loss, "NULL");
   MRGCN_REQUIRE(C > 0 && ld >= C && n > 0, "C / ld / n");
   hipStream_t s = (hipStream_t)stream;
-  MRGCN_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), s));
+  MRGCN_HIP_TRY(mrgcn::fill_async(loss, 0, sizeof(float), s));
   if (dlogits) {
     MRGCN_REQUIRE(ldd >= C && num_rows > 0, "ldd / num_rows");
-    MRGCN_HIP_TRY(hipMemsetAsync(dlogits, 0, (size_t)num_rows * ldd * sizeof(float), s));
+    MRGCN_HIP_TRY(mrgcn::fill_async(dlogits, 0, (size_t)num_rows * ldd * sizeof(float), s));
   }
   int grid = (int)((n + kTB - 1) / kTB);
   if (grid > 1024) grid = 1024;
@@ -696,7 +696,7 @@ int mrgcn_softmax_xent_rows_f32(const float *logits, int64_t ld, int32_t C, cons
   MRGCN_REQUIRE(C > 0 && ld >= C && n > 0, "C / ld / n");
   hipStream_t s = (hipStream_t)stream;
   const int single = n <= 16384;
-  if (!single) MRGCN_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), s));
+  if (!single) MRGCN_HIP_TRY(mrgcn::fill_async(loss, 0, sizeof(float), s));
   int grid = single ? 1 : (int)((n + 1023) / 1024);
   if (grid > 256) grid = 256;
   mrgcn::k_xent_rows<<<dim3(grid), dim3(1024), 0, s>>>(logits, ld, C, idx, target, n, loss, drows, single);
@@ -709,8 +709,8 @@ int mrgcn_softmax_xent_bwd_f32(const float *drows, const int64_t *idx, int64_t n
   MRGCN_REQUIRE(drows && idx && dlogits, "NULL");
   MRGCN_REQUIRE(C > 0 && ldd >= C && n > 0 && num_rows > 0, "C / ldd / n / num_rows");
   hipStream_t s = (hipStream_t)stream;
-  MRGCN_HIP_TRY(hipMemsetAsync(dlogits, 0, (size_t)num_rows * ldd * sizeof(float), s));
-  if (row_flags) MRGCN_HIP_TRY(hipMemsetAsync(row_flags, 0, (size_t)num_rows, s));
+  MRGCN_HIP_TRY(mrgcn::fill_async(dlogits, 0, (size_t)num_rows * ldd * sizeof(float), s));
+  if (row_flags) MRGCN_HIP_TRY(mrgcn::fill_async(row_flags, 0, (size_t)num_rows, s));
   int grid = (int)((n * C + kTB - 1) / kTB);
   if (grid > 1024) grid = 1024;
   mrgcn::k_xent_scatter<<<dim3(grid), dim3(kTB), 0, s>>>(drows, idx, n, C, g, dlogits, ldd, row_flags);

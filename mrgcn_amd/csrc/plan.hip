@@ -1226,6 +1226,29 @@ __global__ void k_sup_rfill(const int32_t *__restrict__ rperm, const int32_t *__
 
 }  // namespace
 
+namespace {
+__global__ void k_fill_bytes(uint8_t *__restrict__ dst, uint32_t word, size_t head, size_t words, size_t tail) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < words) reinterpret_cast<uint32_t *>(dst + head)[t] = word;
+  if (t < head) dst[t] = (uint8_t)word;
+  if (t < tail) dst[head + 4 * words + t] = (uint8_t)word;
+}
+}  // namespace
+
+hipError_t fill_async(void *dst, int byte_value, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st == hipStreamCaptureStatusNone)
+    return hipMemsetAsync(dst, byte_value, bytes, s);
+  const uint32_t b = (uint32_t)(byte_value & 0xff);
+  size_t head = (4 - ((uintptr_t)dst & 3)) & 3;
+  if (head > bytes) head = bytes;
+  const size_t words = (bytes - head) / 4, tail = bytes - head - 4 * words;
+  const size_t n = words > 4 ? words : 4;
+  k_fill_bytes<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>((uint8_t *)dst, b * 0x01010101u, head, words, tail);
+  return hipGetLastError();
+}
+
 int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t **ticket) {
   std::lock_guard<std::mutex> lock(p->scratch_mu);
   for (const auto &e : p->stream_scratch)
@@ -1260,6 +1283,47 @@ int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t *
 
 namespace {
 
+// forward arrays of a support: rank of every row among the flagged ones (-1 elsewhere) and the flagged rows' lengths
+__global__ void k_sup_rowrank(const uint8_t *__restrict__ row_flags, const int32_t *__restrict__ rpos, int64_t rows,
+                              const int32_t *__restrict__ rowptr, int32_t *__restrict__ rowrank,
+                              int32_t *__restrict__ frow, int32_t *__restrict__ flen) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const bool on = row_flags[i] != 0;
+  rowrank[i] = on ? rpos[i] : -1;
+  if (on) {
+    frow[rpos[i]] = (int32_t)i;
+    flen[rpos[i]] = rowptr[i + 1] - rowptr[i];
+  }
+}
+// a wave per flagged row copies its entries (plan order), columns renumbered to live numbers
+__global__ void k_sup_fwd_entries(const int32_t *__restrict__ frow, const int32_t *__restrict__ fptr, int64_t NR,
+                                  const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ccol,
+                                  const float *__restrict__ val, const int32_t *__restrict__ lpos,
+                                  int32_t *__restrict__ fcol, float *__restrict__ fval) {
+  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int lane = threadIdx.x & 63;
+  if (q >= NR) return;
+  const int32_t i = frow[q], b = rowptr[i], n = rowptr[i + 1] - b, o = fptr[q];
+  for (int32_t e = lane; e < n; e += kWave) {
+    fcol[o + e] = lpos[ccol[b + e]];
+    fval[o + e] = val[b + e];
+  }
+}
+__global__ void k_sup_rank_entries(const int32_t *__restrict__ lrow, const int32_t *__restrict__ rowrank, int64_t E,
+                                   int32_t *__restrict__ lrow_rank, float *__restrict__ ones) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  lrow_rank[e] = rowrank[lrow[e]];
+  ones[e] = 1.f;
+}
+// out[k] = npos[node[k]] (rank of a node among the live nodes)
+__global__ void k_sup_node_ord(const int32_t *__restrict__ node, const int32_t *__restrict__ idx,
+                               const int32_t *__restrict__ npos, int64_t n, int32_t *__restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = npos[node[idx ? idx[k] : k]];
+}
+
 template <typename T> hipError_t sup_alloc(mrgcn_support *q, T **dst, int64_t n) {
   size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T);
   hipError_t e = pool_alloc((void **)dst, bytes, q->build_stream);
@@ -1271,7 +1335,8 @@ template <typename T> hipError_t sup_alloc(mrgcn_support *q, T **dst, int64_t n)
 }
 
 int build_support_order(mrgcn_support *q, Scratch &sc, hipStream_t s, const int32_t *lpos, const int32_t *rperm,
-                        const int32_t *rnode, const int32_t *relptr, int64_t nbands, mrgcn_support::Order *out) {
+                        const int32_t *rnode, const int32_t *relptr, int64_t nbands, mrgcn_support::Order *out,
+                        const int32_t *npos = nullptr) {
   const mrgcn_plan *p = q->plan;
   const int64_t ncols = p->ncols, R = p->num_relations, ngroups = nbands * R;
   int32_t *rflag, *rpos, *gptr;
@@ -1285,6 +1350,10 @@ int build_support_order(mrgcn_support *q, Scratch &sc, hipStream_t s, const int3
   MRGCN_HIP_TRY(sup_alloc(q, &out->lperm, q->L));
   MRGCN_HIP_TRY(sup_alloc(q, &out->lrin, q->L));
   if (ncols > 0) k_sup_rfill<<<nblocks(ncols), kTB, 0, s>>>(rperm, rnode, rflag, rpos, ncols, lpos, out->lperm, out->lrin);
+  if (npos) {  // (forward arrays: the same list by rank among the live nodes)
+    MRGCN_HIP_TRY(sup_alloc(q, &out->lrin_ord, q->L));
+    if (q->L > 0) k_sup_node_ord<<<nblocks(q->L), kTB, 0, s>>>(out->lrin, nullptr, npos, q->L, out->lrin_ord);
+  }
   k_gather_i32<<<nblocks(ngroups + 1), kTB, 0, s>>>(rpos, relptr, ngroups + 1, gptr);
   MRGCN_HIP_TRY(hipGetLastError());
   std::vector<int32_t> h_gptr(ngroups + 1);
@@ -1325,7 +1394,7 @@ int build_support_order(mrgcn_support *q, Scratch &sc, hipStream_t s, const int3
   return MRGCN_OK;
 }
 
-int build_support(mrgcn_support *q, const uint8_t *row_flags, hipStream_t s) {
+int build_support(mrgcn_support *q, const uint8_t *row_flags, hipStream_t s, bool forward) {
   const mrgcn_plan *p = q->plan;
   const int64_t N = p->num_nodes, ncols = p->ncols, rows = p->num_rows;
   Scratch sc;
@@ -1398,12 +1467,58 @@ int build_support(mrgcn_support *q, const uint8_t *row_flags, hipStream_t s) {
     if (rc != MRGCN_OK) return rc;
     MRGCN_HIP_TRY(sup_alloc(q, &q->partials, (int64_t)std::max(q->t_n_chunks, 1) * kWsFeatures));
   }
+  if (forward) {
+    q->has_forward = true;
+    int32_t *rflag, *rpos, *flen;
+    MRGCN_HIP_TRY(sc.alloc(&rflag, rows + 1));
+    MRGCN_HIP_TRY(sc.alloc(&rpos, rows + 1));
+    k_sup_flags_i32<<<nblocks(rows + 1), kTB, 0, s>>>(row_flags, nullptr, rows, rflag);
+    MRGCN_HIP_TRY(hipGetLastError());
+    if ((rc = exclusive_scan_i32(rflag, rpos, rows + 1, s, sc))) return rc;
+    int32_t hNR = 0;
+    MRGCN_HIP_TRY(hipMemcpyAsync(&hNR, rpos + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MRGCN_HIP_TRY(hipStreamSynchronize(s));
+    q->NR = hNR;
+    MRGCN_HIP_TRY(sup_alloc(q, &q->rowrank, rows));
+    MRGCN_HIP_TRY(sup_alloc(q, &q->frow, q->NR));
+    MRGCN_HIP_TRY(sup_alloc(q, &q->fptr, q->NR + 1));
+    MRGCN_HIP_TRY(sc.alloc(&flen, q->NR + 1));
+    MRGCN_HIP_TRY(hipMemsetAsync(flen, 0, (size_t)(q->NR + 1) * sizeof(int32_t), s));
+    if (rows > 0) k_sup_rowrank<<<nblocks(rows), kTB, 0, s>>>(row_flags, rpos, rows, p->rowptr, q->rowrank, q->frow, flen);
+    MRGCN_HIP_TRY(hipGetLastError());
+    if ((rc = exclusive_scan_i32(flen, q->fptr, q->NR + 1, s, sc))) return rc;
+    // (every entry of a flagged row touches a live column and every kept entry of a live column sits in a flagged row:
+    // the forward view holds the same E entries as the transposed one)
+    MRGCN_HIP_TRY(sup_alloc(q, &q->fcol, q->E));
+    MRGCN_HIP_TRY(sup_alloc(q, &q->fval, q->E));
+    MRGCN_HIP_TRY(sup_alloc(q, &q->ones, q->E));
+    MRGCN_HIP_TRY(sup_alloc(q, &q->lrow_rank, q->E));
+    MRGCN_HIP_TRY(sup_alloc(q, &q->lnode_ord, q->L));
+    if (q->NR > 0)
+      k_sup_fwd_entries<<<nblocks(q->NR * kWave), kTB, 0, s>>>(q->frow, q->fptr, q->NR, p->rowptr, p->ccol, p->val, lpos,
+                                                              q->fcol, q->fval);
+    if (q->E > 0) k_sup_rank_entries<<<nblocks(q->E), kTB, 0, s>>>(q->lrow, q->rowrank, q->E, q->lrow_rank, q->ones);
+    if (q->L > 0) k_sup_node_ord<<<nblocks(q->L), kTB, 0, s>>>(p->unode, q->lcol, npos, q->L, q->lnode_ord);
+    MRGCN_HIP_TRY(hipGetLastError());
+    mrgcn_plan acct;
+    acct.build_stream = s;
+    int64_t max_len = 0;
+    rc = build_long(&acct, q->fptr, q->NR, s, &q->f_long_row, &q->f_long_cptr, &q->f_chunk_beg, &q->f_chunk_end,
+                    &q->f_chunk_row, &q->f_n_long, &q->f_n_chunks, &max_len);
+    for (void *a : {(void *)q->f_long_row, (void *)q->f_long_cptr, (void *)q->f_chunk_beg, (void *)q->f_chunk_end,
+                    (void *)q->f_chunk_row})
+      if (a) q->owned.push_back(a);
+    q->device_bytes += acct.device_bytes;
+    if (rc != MRGCN_OK) return rc;
+    MRGCN_HIP_TRY(sup_alloc(q, &q->f_partials, (int64_t)std::max(q->f_n_chunks, 1) * kWsFeatures));
+  }
   // the two relation-major orders
-  rc = build_support_order(q, sc, s, lpos, p->rperm, p->rnode, p->relptr, p->n_bands, &q->wide);
+  rc = build_support_order(q, sc, s, lpos, p->rperm, p->rnode, p->relptr, p->n_bands, &q->wide, forward ? npos : nullptr);
   if (rc != MRGCN_OK) return rc;
   q->has_narrow = p->n_rperm != nullptr;
   if (q->has_narrow) {
-    rc = build_support_order(q, sc, s, lpos, p->n_rperm, p->n_rnode, p->n_relptr, p->n_n_bands, &q->narrow);
+    rc = build_support_order(q, sc, s, lpos, p->n_rperm, p->n_rnode, p->n_relptr, p->n_n_bands, &q->narrow,
+                             forward ? npos : nullptr);
     if (rc != MRGCN_OK) return rc;
   }
   MRGCN_HIP_TRY(hipStreamSynchronize(s));  // (the scratch arrays go back to the pool behind finished work)
@@ -1442,14 +1557,20 @@ void release_support(mrgcn_support *q) {
 extern "C" {
 
 int mrgcn_support_create(mrgcn_support_t **out, const mrgcn_plan_t *plan, const uint8_t *row_flags, void *stream) {
+  return mrgcn_support_create_ex(out, plan, row_flags, 0, stream);
+}
+
+int mrgcn_support_create_ex(mrgcn_support_t **out, const mrgcn_plan_t *plan, const uint8_t *row_flags, uint32_t flags,
+                            void *stream) {
   using namespace mrgcn;
   MRGCN_REQUIRE(out && plan && row_flags, "NULL");
+  MRGCN_REQUIRE((flags & ~MRGCN_SUPPORT_FORWARD) == 0, "flags");
   MRGCN_REQUIRE(!plan->lean, "a lean plan (mini-batch slice) keeps no transposed view to build a support on");
   mrgcn_support *q = new mrgcn_support();
   q->plan = plan;
   (void)hipGetDevice(&q->device);
   q->build_stream = (hipStream_t)stream;
-  int rc = build_support(q, row_flags, (hipStream_t)stream);
+  int rc = build_support(q, row_flags, (hipStream_t)stream, (flags & MRGCN_SUPPORT_FORWARD) != 0);
   if (rc != MRGCN_OK) {
     release_support(q);
     return rc;
@@ -1463,6 +1584,20 @@ int mrgcn_support_destroy(mrgcn_support_t *sup) {
   return MRGCN_OK;
 }
 
+int mrgcn_support_destroy_ordered(mrgcn_support_t *sup) {
+  using namespace mrgcn;
+  if (!sup) return MRGCN_OK;
+  // no wait: the blocks go back to the pool under the order of the stream the support was built on — later work on
+  // that stream may take them at once, anyone else after the next device-wide wait (pool_free)
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (sup->device != cur) (void)hipSetDevice(sup->device);
+  for (void *a : sup->owned) pool_free(a, sup->build_stream);
+  if (sup->device != cur) (void)hipSetDevice(cur);
+  delete sup;
+  return MRGCN_OK;
+}
+
 int mrgcn_support_info(const mrgcn_support_t *q, mrgcn_support_info_t *h) {
   MRGCN_REQUIRE(q && h, "NULL");
   h->live_cols = q->L;
@@ -1471,6 +1606,7 @@ int mrgcn_support_info(const mrgcn_support_t *q, mrgcn_support_info_t *h) {
   h->device_bytes = q->device_bytes;
   h->chunks_wide = q->wide.n_chunks;
   h->chunks_narrow = q->has_narrow ? q->narrow.n_chunks : 0;
+  h->flagged_rows = q->has_forward ? q->NR : -1;
   return MRGCN_OK;
 }
 
@@ -1488,6 +1624,12 @@ int mrgcn_support_array(const mrgcn_support_t *q, int32_t which, const void **d_
     case MRGCN_SUP_LVAL: *d_ptr = q->lval; *h_count = q->E; break;
     case MRGCN_SUP_LNODE: *d_ptr = q->lnode; *h_count = q->NL; break;
     case MRGCN_SUP_LPERM: *d_ptr = q->wide.lperm; *h_count = q->L; break;
+    case MRGCN_SUP_FROW: *d_ptr = q->frow; *h_count = q->has_forward ? q->NR : 0; break;
+    case MRGCN_SUP_FPTR: *d_ptr = q->fptr; *h_count = q->has_forward ? q->NR + 1 : 0; break;
+    case MRGCN_SUP_FCOL: *d_ptr = q->fcol; *h_count = q->has_forward ? q->E : 0; break;
+    case MRGCN_SUP_FVAL: *d_ptr = q->fval; *h_count = q->has_forward ? q->E : 0; break;
+    case MRGCN_SUP_LNODE_ORD: *d_ptr = q->lnode_ord; *h_count = q->has_forward ? q->L : 0; break;
+    case MRGCN_SUP_ROWRANK: *d_ptr = q->rowrank; *h_count = q->has_forward ? p->num_rows : 0; break;
     default: MRGCN_REQUIRE(false, "unknown support array");
   }
   return MRGCN_OK;

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(kMixFwdTB) void k_mix_fwd(const int32_t *__restrict
                                                     int B, int b0, int F, int FW,
                                                     const float *__restrict__ addend, int64_t ldA,
                                                     OT *__restrict__ M, int64_t ldM, int accumulate,
-                                                    int comp_in_lds) {
+                                                    int comp_in_lds,
+                                                    const int32_t *__restrict__ node_ids = nullptr) {
   extern __shared__ __align__(16) float s_comp[];  // [R][CS] slice b0..b0+BT of comp when it fits
   constexpr int CS = comp_stride(BT);
   const int nb = min(BT, B - b0);
@@ -86,9 +87,10 @@ __global__ __launch_bounds__(kMixFwdTB) void k_mix_fwd(const int32_t *__restrict
     const int32_t c0 = nptr[j], c1 = nptr[j + 1];
     if (c0 == c1) continue;
     float v[BT];
+    const int64_t jv = node_ids ? (int64_t)node_ids[j] : j;  // (a node list: entry j of it owns columns nptr[j] ..)
 #pragma unroll
     for (int b = 0; b < BT; ++b)
-      v[b] = (live && b < nb) ? V[((int64_t)j * B + (b0 + b)) * F + o] : 0.f;
+      v[b] = (live && b < nb) ? V[(jv * B + (b0 + b)) * F + o] : 0.f;
 
     // the node's columns in chunks of kPre: everything a chunk needs (relation id, operand row,
     // addend) is requested up front, so a chunk costs one round trip however long the node is
@@ -222,11 +224,14 @@ __device__ __forceinline__ void mix_node_tiles(int32_t c0, int32_t c1, int32_t b
   }
 }
 
-template <int KS, int NQ, int TN, bool ADD, typename OT>
+// IDS: the nodes are a list (a gradient support's live nodes): entry t owns columns nptr[t] .. nptr[t+1] and its V
+// block is node_ids[t]'s; the ids travel with the node pointers, two steps ahead of their use.
+template <int KS, int NQ, int TN, bool ADD, typename OT, bool IDS = false>
 __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
     const int32_t *__restrict__ nptr, const int32_t *__restrict__ urel, const int32_t *__restrict__ mpos,
     const float *__restrict__ V, const float *__restrict__ comp, int64_t N, int R, int B, int F,
-    const float *__restrict__ addend, int64_t ldA, OT *__restrict__ M, int64_t ldM) {
+    const float *__restrict__ addend, int64_t ldA, OT *__restrict__ M, int64_t ldM,
+    const int32_t *__restrict__ node_ids = nullptr) {
   extern __shared__ __align__(16) float s_mem[];
   constexpr int KP = KS * 16 + 4;  // padded comp row: rows start on different banks
   float *s_comp = s_mem;           // [R][KP], zero beyond B
@@ -251,9 +256,11 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
   // node's first tile run one step ahead, so the loads of step s+1 fly under the products of step s.  All of
   // them are unconditional at clamped addresses: predicated pieces would send the registers to scratch.
 #define MIX_LOAD_NP(gg) nptr[min(min((gg), ngroups - 1) * TN + min(lane, TN), N)]
-#define MIX_LOAD_V(gg)                                                                                      \
+#define MIX_LOAD_ID(gg) (IDS ? node_ids[min(min((gg), ngroups - 1) * TN + min(lane, TN - 1), N - 1)] : 0)
+#define MIX_LOAD_V(gg, idreg)                                                                               \
   _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                          \
-    const f32x4m *src = reinterpret_cast<const f32x4m *>(V) + min((gg) * TN + i, N - 1) * (int64_t)nf4;     \
+    const int64_t nid = IDS ? (int64_t)__builtin_amdgcn_readlane(idreg, i) : min((gg) * TN + i, N - 1);     \
+    const f32x4m *src = reinterpret_cast<const f32x4m *>(V) + nid * (int64_t)nf4;                           \
     _Pragma("unroll") for (int q = 0; q < NQ; ++q) pv[i][q] = src[min(lane + 64 * q, nf4 - 1)];            \
   }
 #define MIX_LOAD_IDX(np, ur, mp)                                                                            \
@@ -273,13 +280,15 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
   f32x4m pv[TN][NQ];
   float pa_n1[TN][4], pa_cur[TN][4];
   int32_t np_cur = MIX_LOAD_NP(g), np_n1 = MIX_LOAD_NP(g + nwaves);
+  int32_t id_cur = MIX_LOAD_ID(g), id_n1 = MIX_LOAD_ID(g + nwaves);
   int32_t ur_cur, mp_cur, ur_n1, mp_n1;
   MIX_LOAD_IDX(np_cur, ur_n1, mp_n1)
-  MIX_LOAD_V(g)
+  MIX_LOAD_V(g, id_cur)
   for (; g < ngroups; g += nwaves) {
     const int32_t np_now = np_cur;
     const int32_t cbase = __builtin_amdgcn_readlane(np_now, 0), cend = __builtin_amdgcn_readlane(np_now, TN);
     const int32_t np_n2 = MIX_LOAD_NP(g + 2 * nwaves);
+    const int32_t id_n2 = MIX_LOAD_ID(g + 2 * nwaves);
     ur_cur = ur_n1;
     mp_cur = mp_n1;
     bool near = cend - cbase <= 64;  // wave uniform
@@ -297,10 +306,11 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
         if (lane + 64 * q < nf4) dst[lane + 64 * q] = pv[i][q];
     }
     wave_lds_fence();
-    MIX_LOAD_V(g + nwaves)  // next step's blocks (the last step re-reads its own)
+    MIX_LOAD_V(g + nwaves, id_n1)  // next step's blocks (the last step re-reads its own)
     MIX_LOAD_IDX(np_n1, ur_n1, mp_n1)
     np_cur = np_n1;
     np_n1 = np_n2;
+    id_n1 = id_n2;
     if (near) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
@@ -320,6 +330,7 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
     wave_lds_fence();  // the tile is rewritten by the next step
   }
 #undef MIX_LOAD_NP
+#undef MIX_LOAD_ID
 #undef MIX_LOAD_V
 #undef MIX_LOAD_IDX
 }
@@ -1146,16 +1157,24 @@ using namespace mrgcn;
 
 namespace {
 
+// the columns a basis mix walks: a plan's (every node) or a gradient support's (a node list, rows by live number)
+struct MixCols {
+  const int32_t *nptr, *urel, *mpos, *unode, *node_ids;
+  int64_t N, ncols;
+  int R;
+};
+
 template <typename OT>
-int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32_t B, int32_t F,
+int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B, int32_t F,
                  const float *addend, int64_t ldA, OT *M, int64_t ldM, void *stream) {
-  MRGCN_REQUIRE(p && V && comp && M, "NULL");
+  MRGCN_REQUIRE(V && comp && M, "NULL");
   MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
   MRGCN_REQUIRE(!addend || ldA >= F, "ldA");
-  if (p->ncols == 0) return MRGCN_OK;
+  if (p->ncols == 0 || p->N == 0) return MRGCN_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int R = (int)p->num_relations;
-  const int64_t N = p->num_nodes;
+  const int R = p->R;
+  const int64_t N = p->N;
+  const int32_t *node_ids = p->node_ids;
   // Columns F..ldM of M are padding that only the SpMM's 16-byte gathers touch, and their
   // products land in accumulator lanes that are never stored (test: padding set to 1e30 does
   // not leak): by default only the F real features are computed and written (a sixth fewer
@@ -1167,7 +1186,7 @@ int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32
   // timing experiments only (wrong results): write rows in compact order instead of operand order
   static const bool dbg_seq = getenv("MRGCN_DEBUG_MIX_SEQ") && atoi(getenv("MRGCN_DEBUG_MIX_SEQ")) != 0;
   const int32_t *mpos_arg = dbg_seq ? nullptr : p->mpos;
-  if constexpr (sizeof(OT) == 4) if (by_cols && B <= 64 && F <= 64 && FW <= 64) {
+  if constexpr (sizeof(OT) == 4) if (by_cols && !node_ids && B <= 64 && F <= 64 && FW <= 64) {
     size_t lds = (size_t)R * (B | 1) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
@@ -1201,13 +1220,14 @@ int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32
     const size_t lds =
         ((size_t)((R * (KS * 16 + 4) + 3) & ~3) + (size_t)(kFwdTB / 64) * tn * B * F) * sizeof(float);
     if (mfma_on && B <= 64 && F <= 16 && (B * F) % 4 == 0 && (((uintptr_t)V) & 15) == 0 &&
-        lds <= 150 * 1024) {
+        lds <= 150 * 1024 && !(node_ids && (addend || sizeof(OT) != 4))) {
       const int64_t want = ((N + tn - 1) / tn + (kFwdTB / 64) - 1) / (kFwdTB / 64);
       int64_t grid = 256;  // one block of 16 waves per CU (LDS and the 128-register budget allow no second)
       if (grid > want) grid = want;
 #define MIXM_GO(KS_, NQ_, TN_)                                                                              \
   do {                                                                                                      \
     auto kfn = addend ? k_mix_fwd_mfma<KS_, NQ_, TN_, true, OT> : k_mix_fwd_mfma<KS_, NQ_, TN_, false, OT>; \
+    if constexpr (sizeof(OT) == 4) if (node_ids) kfn = k_mix_fwd_mfma<KS_, NQ_, TN_, false, OT, true>;      \
     static size_t lds_allowed = 48 * 1024;                                                                  \
     if (lds > lds_allowed) {                                                                                \
       MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,      \
@@ -1215,7 +1235,7 @@ int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32
       lds_allowed = lds;                                                                                    \
     }                                                                                                       \
     kfn<<<dim3((unsigned)grid), dim3(kFwdTB), lds, s>>>(p->nptr, p->urel, mpos_arg, V, comp, N, R, B, F,     \
-                                                        addend, ldA, M, ldM);                               \
+                                                        addend, ldA, M, ldM, node_ids);                     \
   } while (0)
 #define MIXM_TN(KS_, NQ_) MIXM_GO(KS_, NQ_, tn)
       switch (KS * 8 + NQ) {
@@ -1248,7 +1268,7 @@ int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32
     const float *add = acc ? nullptr : addend;
 #define MIX_GO(T)                                                                                    \
   k_mix_fwd<T, OT><<<dim3(grid), dim3(fwd_tb), lds, s>>>(p->nptr, p->urel, mpos_arg, V, comp, N, R, B, b0, \
-                                                     F, FW, add, ldA, M, ldM, acc, in_lds)
+                                                     F, FW, add, ldA, M, ldM, acc, in_lds, node_ids)
     switch (BT) {
       case 2: MIX_GO(2); break;
       case 4: MIX_GO(4); break;
@@ -1264,6 +1284,26 @@ int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32
   }
   return MRGCN_OK;
 }
+
+template <typename OT>
+int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32_t B, int32_t F,
+                 const float *addend, int64_t ldA, OT *M, int64_t ldM, void *stream) {
+  MRGCN_REQUIRE(p, "NULL");
+  const MixCols c{p->nptr, p->urel, p->mpos, p->unode, nullptr, p->num_nodes, p->ncols, (int)p->num_relations};
+  return mix_fwd_cols<OT>(&c, V, comp, B, F, addend, ldA, M, ldM, stream);
+}
+}  // namespace
+
+namespace mrgcn {
+int mix_fwd_arrays(const int32_t *nptr, const int32_t *urel, const int32_t *node_ids, int64_t n_nodes, int64_t ncols,
+                   int R, const float *V, const float *comp, int32_t B, int32_t F, float *M, int64_t ldM,
+                   hipStream_t s) {
+  const MixCols c{nptr, urel, nullptr, nullptr, node_ids, n_nodes, ncols, R};
+  return mix_fwd_cols<float>(&c, V, comp, B, F, nullptr, 0, M, ldM, (void *)s);
+}
+}  // namespace mrgcn
+
+namespace {
 
 // ---- basis contraction of weight_F (graph.py:83-85): W[r] = sum_b comp[r, b] V[b] --------------------------------
 // (R x B) . (B x X), X = in * out: a few hundred thousand outputs of B terms each — one small launch of this
@@ -1670,7 +1710,7 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const
   hipStream_t s = (hipStream_t)stream;
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
-  MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)R * B * sizeof(float), s));
+  MRGCN_HIP_TRY(mrgcn::fill_async(dcomp, 0, (size_t)R * B * sizeof(float), s));
   {  // one pass for dV and dcomp when the shape allows it
     int rc = mix_bwd_nm_launch(p, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, s, col_live, node_cur);
     if (rc >= 0) return rc;
@@ -1682,7 +1722,7 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const
     int rc = zero_dead_rows(dM, ldM, F, col_live, p->ncols, s);
     if (rc != MRGCN_OK) return rc;
   }
-  if (node_cur && N > 0) MRGCN_HIP_TRY(hipMemsetAsync(node_cur, 1, (size_t)N, s));
+  if (node_cur && N > 0) MRGCN_HIP_TRY(mrgcn::fill_async(node_cur, 1, (size_t)N, s));
   {
     int rc = mix_bwd_dv_launch(p, dM, ldM, comp, B, F, dV, dV_sumsq, s);
     if (rc != MRGCN_OK) return rc;
@@ -1845,7 +1885,7 @@ int mrgcn_rel_transform_bwd_masked_f32(const mrgcn_plan_t *p, float *dM, int64_t
     // (the matrix-core form with a slab workspace zeroes dW inside its first launch)
     const bool self_zero = use_mfma() && xform_mfma_dw_supported(K, F) && workspace &&
                            workspace_floats >= (int64_t)o.n_relchunks * K * F;
-    if (!self_zero) MRGCN_HIP_TRY(hipMemsetAsync(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
+    if (!self_zero) MRGCN_HIP_TRY(mrgcn::fill_async(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
     if (use_mfma() && xform_mfma_dw_supported(K, F)) {
       int rc = xform_mfma_dw(p, o, o.rnode, X, ldX, K, dM, ldM, F, dW, workspace, workspace_floats, s, col_live);
       if (rc != MRGCN_OK) return rc;

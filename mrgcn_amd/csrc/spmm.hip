@@ -1167,14 +1167,15 @@ View3 view3_of(const mrgcn_plan *p) {
 // without bias / ReLU / redirection.  The operand rows such a view reads are few (the live rows of a layer's output
 // gradient) and stay cache resident.
 int spmm_on_view(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, int64_t ldY, float *partials,
-                 hipStream_t s) {
+                 hipStream_t s, const float *bias, int relu) {
   if (v.rows == 0) return MRGCN_OK;
   int tile = 64;
   if (ldD % 4 == 0 && ((uintptr_t)D) % 16 == 0) tile = 256;
   else if (ldD % 2 == 0 && ((uintptr_t)D) % 8 == 0) tile = 128;
   for (int f = 0; f < F; f += tile) {
     const int w = (F - f < tile) ? (F - f) : tile;
-    int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, nullptr, 0, nullptr, partials, false, true, s, nullptr);
+    int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu, nullptr, partials, false,
+                      true, s, nullptr);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;
@@ -1253,18 +1254,18 @@ extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, 
     int rc = plan_scratch(plan, s, &partials, &ticket);
     if (rc != MRGCN_OK) return rc;
   }
-  if (live_rows) MRGCN_HIP_TRY(hipMemsetAsync(live_rows, 0, sizeof(int32_t), s));
+  if (live_rows) MRGCN_HIP_TRY(mrgcn::fill_async(live_rows, 0, sizeof(int32_t), s));
   if (F > 16) {  // wide layers: the general product, then the flags from its result
     int rc = mrgcn_spmm_f32(plan, MRGCN_VIEW_TRANSPOSED, D, ldD, F, Y, ldY, nullptr, 0, nullptr, stream);
     if (rc != MRGCN_OK) return rc;
-    if (live_rows) MRGCN_HIP_TRY(hipMemsetAsync(live_rows, 0xff, sizeof(int32_t), s));  // -1: not counted
-    if (node_live) MRGCN_HIP_TRY(hipMemsetAsync(node_live, 1, (size_t)plan->num_nodes, s));  // (not looked at: all)
+    if (live_rows) MRGCN_HIP_TRY(mrgcn::fill_async(live_rows, 0xff, sizeof(int32_t), s));  // -1: not counted
+    if (node_live) MRGCN_HIP_TRY(mrgcn::fill_async(node_live, 1, (size_t)plan->num_nodes, s));  // (not looked at: all)
     return mrgcn_rows_nonzero_f32(Y, ldY, F, v.rows, col_live, stream);
   }
   uint8_t *row_live = scratch;
-  MRGCN_HIP_TRY(hipMemsetAsync(col_live, 0, (size_t)v.rows, s));
-  if (node_live && F <= 16) MRGCN_HIP_TRY(hipMemsetAsync(node_live, 0, (size_t)plan->num_nodes, s));
-  if (write_dead_rows && v.rows > 0) MRGCN_HIP_TRY(hipMemsetAsync(Y, 0, (size_t)v.rows * ldY * sizeof(float), s));
+  MRGCN_HIP_TRY(mrgcn::fill_async(col_live, 0, (size_t)v.rows, s));
+  if (node_live && F <= 16) MRGCN_HIP_TRY(mrgcn::fill_async(node_live, 0, (size_t)plan->num_nodes, s));
+  if (write_dead_rows && v.rows > 0) MRGCN_HIP_TRY(mrgcn::fill_async(Y, 0, (size_t)v.rows * ldY * sizeof(float), s));
   if (plan->num_rows > 0 && v.rows > 0) {
     k_rows_live_mark<<<dim3((unsigned)((plan->num_rows + 255) / 256)), dim3(256), 0, s>>>(
         D, ldD, F, plan->num_rows, plan->rowptr, plan->ccol, row_live, col_live, live_rows,

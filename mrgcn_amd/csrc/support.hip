@@ -364,7 +364,7 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
   const int R = (int)p->num_relations;
   const int64_t N = p->num_nodes;
   if (dV) {  // the gradient itself: the wave-over-nodes kernel of rgcn_fused.hip on the support's arrays
-    MRGCN_HIP_TRY(hipMemsetAsync(dcomp, 0, (size_t)R * B * sizeof(float), s));
+    MRGCN_HIP_TRY(mrgcn::fill_async(dcomp, 0, (size_t)R * B * sizeof(float), s));
     int rc = mix_bwd_nm_arrays(q->nlptr, q->lrel, N, R, -1, dM, ldM, V, comp, B, F, dV, dcomp, dV_sumsq, s, nullptr,
                                dense ? nullptr : q->node_scratch);
     if (rc < 0) {

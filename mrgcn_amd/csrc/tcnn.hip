@@ -297,7 +297,7 @@ int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, 
   hipStream_t s = (hipStream_t)stream;
   if (training) {
     double *acc = (double *)workspace;
-    MRGCN_HIP_TRY(hipMemsetAsync(acc, 0, mrgcn_bn_workspace_bytes(C), s));
+    MRGCN_HIP_TRY(mrgcn::fill_async(acc, 0, mrgcn_bn_workspace_bytes(C), s));
     k_bn_stats_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, tp_log2_of(T), acc);
     k_bn_stats_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, (int64_t)B * T, mean, var);
   }
@@ -325,7 +325,7 @@ int mrgcn_bn_running_stats_f32(const float *mean, const float *var, int32_t C, i
 int mrgcn_channel_sum_f32(const float *x, int32_t B, int32_t C, int32_t T, float *out, void *stream) {
   MRGCN_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "operands");
   hipStream_t s = (hipStream_t)stream;
-  MRGCN_HIP_TRY(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s));
+  MRGCN_HIP_TRY(mrgcn::fill_async(out, 0, (size_t)C * sizeof(float), s));
   k_chan_sum_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, tp_log2_of(T), out);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
@@ -353,8 +353,8 @@ int mrgcn_bn_relu_pool_bwd_sum_f32(const float *x, const float *y, const float *
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_in = (int64_t)B * C * T, n_out = (int64_t)B * C * Tout;
   double *acc = (double *)workspace;
-  MRGCN_HIP_TRY(hipMemsetAsync(acc, 0, mrgcn_bn_workspace_bytes(C), s));
-  if (dx_chan_sum) MRGCN_HIP_TRY(hipMemsetAsync(dx_chan_sum, 0, (size_t)C * sizeof(float), s));
+  MRGCN_HIP_TRY(mrgcn::fill_async(acc, 0, mrgcn_bn_workspace_bytes(C), s));
+  if (dx_chan_sum) MRGCN_HIP_TRY(mrgcn::fill_async(dx_chan_sum, 0, (size_t)C * sizeof(float), s));
   const dim3 rgrid(C, bn_slabs(B, C));
   const uint32_t arg_magic = (pool_kind == POOL_MAX && pool_arg > 1) ? (uint32_t)((((uint64_t)1) << 32) / (uint64_t)pool_arg + 1) : 0u;
   MRGCN_REQUIRE(pool_kind != POOL_MAX || (int64_t)T * pool_arg < ((int64_t)1 << 32), "sequence too long");
@@ -371,7 +371,7 @@ int mrgcn_bn_relu_pool_bwd_sum_f32(const float *x, const float *y, const float *
                                                    mean, var, eps, dgamma, dbeta, training, dx, dx_chan_sum);         \
   } while (0)
   if (pool_kind == POOL_ADAPTIVE) {  // windows may overlap: scatter into dz first
-    MRGCN_HIP_TRY(hipMemsetAsync(dz, 0, (size_t)n_in * sizeof(float), s));
+    MRGCN_HIP_TRY(mrgcn::fill_async(dz, 0, (size_t)n_in * sizeof(float), s));
     k_pool_relu_bwd<<<dim3(nb(n_out)), dim3(256), 0, s>>>(y, dy, argmax, n_out, T, Tout, pool_kind, dz);
     BN_BWD_GO(POOL_ADAPTIVE);
   } else if (pool_kind == POOL_MAX) {

@@ -621,7 +621,7 @@ int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx
                   int K, const float *G, int64_t ldG, int F, float *dW, float *workspace,
                   int64_t workspace_floats, hipStream_t s, const uint8_t *col_live) {
   if (o.n_relchunks == 0) {
-    MRGCN_HIP_TRY(hipMemsetAsync(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
+    MRGCN_HIP_TRY(mrgcn::fill_async(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
     return MRGCN_OK;
   }
   size_t lds = (size_t)4 * K * F * sizeof(float);

@@ -16,6 +16,8 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from .. import _lib as L_
+
 VALUE_MODES = ("ref_int8", "norm_f32")
 
 
@@ -370,6 +372,51 @@ class A_BatchDevice(A_Batch):
 
     def to(self, device):
         return self if torch.device(device) == self.device else super().to(device)
+
+
+class A_BatchMasked:
+    """The mini-batch structure of `A_Batch` (batch.py:166-231) WITHOUT slices: every layer's sample is a row set on
+    the full graph's plan (a forward gradient support, csrc/masked.hip) —
+        supports[0]   the batch nodes' rows,   neighbours[0] = the source nodes those rows touch
+        supports[i+1] the rows of neighbours[i], ...
+    `neighbours[i]` are the same sorted node ids `getNeighboursSparse` returns (int64, on the plan's device), so the
+    caller's `X[batch.neighbours[-1]]` is unchanged; `row[i]` is the support (what `RGCN.forward` hands to layer
+    num_layers-1-i).  A re-sampled batch costs `num_layers` support builds on the existing plan: no slice tensors, no
+    per-batch plans, no worker threads.  Rows of the output follow `batch_idx` (any order, repeats allowed)."""
+
+    def __init__(self, plan, batch_idx, num_layers):
+        from ..plan import GraphSupport
+        dev = plan.device
+        if plan.num_rows != plan.num_nodes:
+            raise ValueError("the masked batch needs the square stacked adjacency (rows = nodes)")
+        idx = torch.as_tensor(np.asarray(batch_idx) if not isinstance(batch_idx, torch.Tensor) else batch_idx,
+                              dtype=torch.long).to(dev)
+        self.plan, self.node_index, self.device = plan, idx, dev
+        self.value_mode = None
+        flags = torch.zeros(plan.num_rows, dtype=torch.uint8, device=dev)
+        flags[idx] = 1
+        self.supports, self.neighbours = [], []
+        for _ in range(num_layers):
+            sup = GraphSupport(plan, flags, forward=True)
+            self.supports.append(sup)
+            self.neighbours.append(sup.view(L_.SUP_LNODE).long())
+            flags = sup.node_flags()
+        self.row = self.supports
+        # position of every batch node among the (sorted, distinct) rows the top layer computes
+        self.out_rank = self.supports[0].view(L_.SUP_ROWRANK)[idx].long() if num_layers else idx
+
+    def as_tensors_(self):
+        return None
+
+    def to(self, device):
+        if torch.device(device) != self.device and torch.device(device).index is not None:
+            raise ValueError("a masked batch lives on its plan's device")
+        return self
+
+    def close(self):
+        for s in self.supports:
+            s.close()
+        self.supports, self.row = [], []
 
 
 class BatchPrefetcher:

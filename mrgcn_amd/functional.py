@@ -353,6 +353,25 @@ class _RgcnLayer(torch.autograd.Function):
             out = _RgcnLayer._backward_on_support(ctx, sup, dY, dbias)
             if out is not None:
                 return out
+        # (the units of the wide-layer backward are built on first use, with host round trips: not inside a capture)
+        if (has_I and has_comp and not has_X and not sparse_rows and weight_I.dim() == 3 and not plan.lean
+                and dY.stride(0) % 4 == 0
+                and ("_wide_units" in plan.__dict__ or not torch.cuda.is_current_stream_capturing())):
+            Bn = weight_I.shape[1]
+            param = getattr(ctx.owner, "weight_I", None)
+            if (lib.mrgcn_wide_input_bwd_supported(plan.handle, Bn, F)
+                    and not (param is not None and _row_sparse_for(param) and _LIVE_COLS)):
+                # a wide featureless layer with few bases (the link-prediction encoder): dV and dcomp straight from
+                # dY over the plan's entries — the 4 F-byte rows of dM are never written (csrc/wide_input.hip)
+                erel, un, ub, ue, um, nu = plan.wide_units()
+                wI = weight_I.contiguous()
+                d_wI, d_comp = torch.empty_like(wI), torch.empty_like(comp_I)
+                with torch.cuda.device(dev):
+                    L.check(lib.mrgcn_wide_input_bwd_f32(
+                        plan.handle, erel.data_ptr(), un.data_ptr(), ub.data_ptr(), ue.data_ptr(), um.data_ptr(), nu,
+                        dY.data_ptr(), dY.stride(0), wI.data_ptr(), comp_I.contiguous().data_ptr(), Bn, F,
+                        d_wI.data_ptr(), d_comp.data_ptr(), s), "mrgcn_wide_input_bwd_f32")
+                return None, None, d_wI, d_comp, None, None, dbias, None, None, None
         # dM = A'^T dY over touched columns only, plain compact order (its consumers are node-major)
         ld = (F + 3) // 4 * 4
         dM = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dev)
@@ -363,7 +382,7 @@ class _RgcnLayer(torch.autograd.Function):
         if sparse_rows and (gauge is None or F > 16):
             raise L.MrgcnError("internal: an output gradient with unwritten rows needs the live-row backward")
         # (unwritten rows outside the flags: only the live-row form may read this gradient, whatever the gauge says)
-        if gauge is not None and (gauge.sparse() or sparse_rows):
+        if gauge is not None and (sparse_rows or (F <= 16 and gauge.sparse())):
             # with few labelled nodes most rows of dY are zeros: gather the others only, and keep one
             # byte per compact column: does it carry any gradient?
             live = torch.empty((plan.ncols,), dtype=torch.uint8, device=dev)
@@ -491,6 +510,59 @@ def _support_of(plan, meta, F, dev):
     return plan.support_for(rf)
 
 
+def _support_weight_I_grads(owner, sup, plan, dM, ld, weight_I, comp_I, F, s):
+    """(d weight_I, d weight_I_comp) of the input term from dM ([L, ld] by the support's live numbers).  With a
+    row-sparse consumer on the parameter (mrgcn_amd.optim / ClipAdam) d weight_I is None: the entry left on the
+    parameter (`_mrgcn_rows`) holds what the optimizer's row update reads.  (Call under torch.cuda.device.)"""
+    lib = L.load()
+    dev = plan.device
+    d_wI = None
+    N_, Bn, _ = weight_I.shape
+    wI = weight_I.contiguous()
+    d_comp = torch.empty_like(comp_I)
+    param = getattr(owner, "weight_I", None)
+    rows = None
+    if (param is not None and weight_I.is_contiguous() and param.shape == weight_I.shape
+            and _row_sparse_for(param)):
+        rows = getattr(param, "_mrgcn_rows", None)
+        if rows is not None and rows["fresh"]:
+            raise L.MrgcnError("row-sparse weight_I gradient: the layer ran twice in one train_step "
+                               "(use train_step(..., row_sparse=False))")
+        fused = bool(lib.mrgcn_adam_rows_fused_supported(plan.handle, Bn, F))
+        if rows is None or rows["shape"] != tuple(weight_I.shape) or rows["ever"].device != dev:
+            rows = dict(g=None, shape=tuple(weight_I.shape), cur=None,
+                        ever=torch.zeros(N_, dtype=torch.uint8, device=dev), sumsq=None, fresh=False,
+                        seeded_for=None, fused=None)
+            param._mrgcn_rows = rows
+        if not fused and rows["g"] is None:
+            rows["g"] = torch.empty_like(wI)
+    if rows is not None:
+        rows["cur"] = sup.node_flags()  # the nodes of the support: the same set every epoch
+        if fused:
+            # norm-only: dcomp and ||dV||^2 are written whole (no zero fills), nothing is accumulated
+            sq = torch.empty((), dtype=torch.float64, device=dev)
+            ws = sup.workspace(("mix", Bn), int(lib.mrgcn_support_mix_bwd_workspace(sup.handle, Bn)))
+            L.check(lib.mrgcn_support_mix_bwd_f32(
+                sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, 0, 0,
+                d_comp.data_ptr(), sq.data_ptr(), ws.data_ptr(), ws.numel(), s), "mrgcn_support_mix_bwd_f32")
+        else:
+            sq = torch.zeros((), dtype=torch.float64, device=dev)
+            L.check(lib.mrgcn_support_mix_bwd_f32(
+                sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, rows["g"].data_ptr(), 0,
+                d_comp.data_ptr(), sq.data_ptr(), 0, 0, s), "mrgcn_support_mix_bwd_f32")
+        rows["sumsq"], rows["fresh"] = sq, True
+        # what the fused update reads: dM of this backward and the coefficients as they were (ClipAdam steps
+        # the node table before weight_I_comp; the version is checked there)
+        rows["fused"] = dict(sup=sup, plan=plan, dM=dM, ld=ld, live=None, comp=comp_I.detach(),
+                             comp_version=comp_I._version, B=Bn, F=F) if fused else None
+    else:
+        d_wI = torch.empty_like(wI)
+        L.check(lib.mrgcn_support_mix_bwd_f32(
+            sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, d_wI.data_ptr(), 1,
+            d_comp.data_ptr(), 0, 0, 0, s), "mrgcn_support_mix_bwd_f32")
+    return d_wI, d_comp
+
+
 def _backward_on_support(ctx, sup, dY, dbias):
     """_RgcnLayer.backward on a gradient support: dM and every per-column product are [L, ld] arrays by live number;
     no marking, no flags, no zero fills (csrc/support.hip).  None when a shape is outside what the support calls
@@ -524,49 +596,7 @@ def _backward_on_support(ctx, sup, dY, dbias):
         side.wait_stream(main)
     with torch.cuda.device(dev):
         if has_I:
-            N_, Bn, _ = weight_I.shape
-            wI = weight_I.contiguous()
-            d_comp = torch.empty_like(comp_I)
-            param = getattr(ctx.owner, "weight_I", None)
-            rows = None
-            if (param is not None and weight_I.is_contiguous() and param.shape == weight_I.shape
-                    and _row_sparse_for(param)):
-                rows = getattr(param, "_mrgcn_rows", None)
-                if rows is not None and rows["fresh"]:
-                    raise L.MrgcnError("row-sparse weight_I gradient: the layer ran twice in one train_step "
-                                       "(use train_step(..., row_sparse=False))")
-                fused = bool(lib.mrgcn_adam_rows_fused_supported(plan.handle, Bn, F))
-                if rows is None or rows["shape"] != tuple(weight_I.shape) or rows["ever"].device != dev:
-                    rows = dict(g=None, shape=tuple(weight_I.shape), cur=None,
-                                ever=torch.zeros(N_, dtype=torch.uint8, device=dev), sumsq=None, fresh=False,
-                                seeded_for=None, fused=None)
-                    param._mrgcn_rows = rows
-                if not fused and rows["g"] is None:
-                    rows["g"] = torch.empty_like(wI)
-            if rows is not None:
-                rows["cur"] = sup.node_flags()  # the nodes of the support: the same set every epoch
-                if fused:
-                    # norm-only: dcomp and ||dV||^2 are written whole (no zero fills), nothing is accumulated
-                    sq = torch.empty((), dtype=torch.float64, device=dev)
-                    ws = sup.workspace(("mix", Bn), int(lib.mrgcn_support_mix_bwd_workspace(sup.handle, Bn)))
-                    L.check(lib.mrgcn_support_mix_bwd_f32(
-                        sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, 0, 0,
-                        d_comp.data_ptr(), sq.data_ptr(), ws.data_ptr(), ws.numel(), s), "mrgcn_support_mix_bwd_f32")
-                else:
-                    sq = torch.zeros((), dtype=torch.float64, device=dev)
-                    L.check(lib.mrgcn_support_mix_bwd_f32(
-                        sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, rows["g"].data_ptr(), 0,
-                        d_comp.data_ptr(), sq.data_ptr(), 0, 0, s), "mrgcn_support_mix_bwd_f32")
-                rows["sumsq"], rows["fresh"] = sq, True
-                # what the fused update reads: dM of this backward and the coefficients as they were (ClipAdam steps
-                # the node table before weight_I_comp; the version is checked there)
-                rows["fused"] = dict(sup=sup, plan=plan, dM=dM, ld=ld, live=None, comp=comp_I.detach(),
-                                     comp_version=comp_I._version, B=Bn, F=F) if fused else None
-            else:
-                d_wI = torch.empty_like(wI)
-                L.check(lib.mrgcn_support_mix_bwd_f32(
-                    sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, d_wI.data_ptr(), 1,
-                    d_comp.data_ptr(), 0, 0, 0, s), "mrgcn_support_mix_bwd_f32")
+            d_wI, d_comp = _support_weight_I_grads(ctx.owner, sup, plan, dM, ld, weight_I, comp_I, F, s)
         if need_dX or need_dW:
             with torch.cuda.stream(side):
                 if need_dX:
@@ -592,6 +622,141 @@ def _backward_on_support(ctx, sup, dY, dbias):
 
 
 _RgcnLayer._backward_on_support = staticmethod(_backward_on_support)
+
+
+class _MaskedLayer(torch.autograd.Function):
+    """One `GraphConvolution` of a mini-batch (graph.py:62-102 with A_idx) as a masked pass over the FULL graph's plan
+    (csrc/masked.hip): `sup` is the forward support of the layer's sample on that plan — Y has one row per flagged row
+    (rising row id), X one row per live node (the layer's neighbours, rising node id).  The input term multiplies the
+    stored values, the feature term the all-ones slice (batch.py:258-270)."""
+
+    @staticmethod
+    def forward(ctx, sup, F: int, weight_I, comp_I, X, W_F, bias, relu: bool, owner=None):
+        lib = L.load()
+        plan = sup.plan
+        dev = sup.device
+        s = _stream(dev)
+        ld = (F + 3) // 4 * 4
+        NR, Lc = sup.NR, max(sup.L, 1)
+        has_I, has_X = weight_I is not None, X is not None
+        Y = torch.empty((NR, F), dtype=torch.float32, device=dev)
+        Xc = Wc = wI = cI = None
+        with torch.cuda.device(dev):
+            if has_X:
+                Xc = X if (X.dim() == 2 and X.stride(1) == 1) else X.contiguous()
+                Wc = W_F.contiguous()
+                if Xc.shape[0] != sup.NL:
+                    raise L.MrgcnError(f"masked layer: X has {Xc.shape[0]} rows, the sample has {sup.NL} neighbours")
+                T = torch.empty((Lc, ld), dtype=torch.float32, device=dev)
+                L.check(lib.mrgcn_support_rel_transform_fwd_f32(sup.handle, Xc.data_ptr(), Xc.stride(0), Xc.shape[1],
+                                                                Wc.data_ptr(), F, T.data_ptr(), ld, s),
+                        "mrgcn_support_rel_transform_fwd_f32")
+            if has_I:
+                wI = weight_I.contiguous()
+                M = torch.empty((Lc, ld), dtype=torch.float32, device=dev)
+                if comp_I is not None:
+                    cI = comp_I.contiguous()
+                    L.check(lib.mrgcn_support_mix_fwd_f32(sup.handle, wI.data_ptr(), cI.data_ptr(), cI.shape[1], F,
+                                                          M.data_ptr(), ld, s), "mrgcn_support_mix_fwd_f32")
+                else:  # no bases: the literal (R*N) x F table, a row per live column
+                    L.check(lib.mrgcn_support_literal_rows_f32(sup.handle, 0, wI.data_ptr(), F, M.data_ptr(), ld, s),
+                            "mrgcn_support_literal_rows_f32")
+            b = bias.data_ptr() if bias is not None else 0
+            if has_I and has_X:
+                YI = torch.empty((NR, F), dtype=torch.float32, device=dev)
+                L.check(lib.mrgcn_support_spmm_fwd_f32(sup.handle, 1, M.data_ptr(), ld, F, YI.data_ptr(), F, 0, 0, s),
+                        "mrgcn_support_spmm_fwd_f32")
+                L.check(lib.mrgcn_support_spmm_fwd_f32(sup.handle, 0, T.data_ptr(), ld, F, Y.data_ptr(), F, b, 0, s),
+                        "mrgcn_support_spmm_fwd_f32")
+                # (graph.py:95-101: AIW + AFW, the bias inside AFW)
+                Y = torch.add(YI, Y, out=Y)
+                if relu:
+                    Y.relu_()
+            else:
+                L.check(lib.mrgcn_support_spmm_fwd_f32(sup.handle, int(has_I), (M if has_I else T).data_ptr(), ld, F,
+                                                       Y.data_ptr(), F, b, int(relu), s), "mrgcn_support_spmm_fwd_f32")
+        ctx.sup, ctx.plan, ctx.F, ctx.ld, ctx.relu, ctx.owner = sup, plan, F, ld, relu, owner
+        ctx.x_is_relu_out = has_X and bool(getattr(X, "_mrgcn_relu_out", False))
+        ctx.has = (has_I, has_X, bias is not None)
+        ctx.save_for_backward(wI, cI, Xc, Wc, Y if relu else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = L.load()
+        sup, plan, F, ld = ctx.sup, ctx.plan, ctx.F, ctx.ld
+        weight_I, comp_I, X, W_F, Y = ctx.saved_tensors
+        has_I, has_X, has_bias = ctx.has
+        dev = sup.device
+        s = _stream(dev)
+        dY = dY.contiguous()
+        meta = _grad_meta(dY)
+        if ctx.relu and not (meta and meta["relu_applied"]):
+            dY = relu_bwd(dY, Y)
+        dbias = dY.sum(0) if has_bias else None
+        d_wI = d_comp = dX = dW = None
+        Lc = max(sup.L, 1)
+        with torch.cuda.device(dev):
+            if has_I:
+                dM = torch.empty((Lc, ld), dtype=torch.float32, device=dev)
+                L.check(lib.mrgcn_support_spmm_t_compact_f32(sup.handle, 1, dY.data_ptr(), dY.stride(0), F,
+                                                             dM.data_ptr(), ld, s), "mrgcn_support_spmm_t_compact_f32")
+                if comp_I is not None:
+                    d_wI, d_comp = _support_weight_I_grads(ctx.owner, sup, plan, dM, ld, weight_I, comp_I, F, s)
+                else:
+                    d_wI = torch.empty_like(weight_I)
+                    L.check(lib.mrgcn_support_literal_rows_f32(sup.handle, 1, d_wI.data_ptr(), F, dM.data_ptr(), ld, s),
+                            "mrgcn_support_literal_rows_f32")
+            need_dX = has_X and ctx.needs_input_grad[4]
+            need_dW = has_X and ctx.needs_input_grad[5]
+            if need_dX or need_dW:
+                K = X.shape[1]
+                dT = torch.empty((Lc, ld), dtype=torch.float32, device=dev)
+                L.check(lib.mrgcn_support_spmm_t_compact_f32(sup.handle, 0, dY.data_ptr(), dY.stride(0), F,
+                                                             dT.data_ptr(), ld, s), "mrgcn_support_spmm_t_compact_f32")
+                nws = int(lib.mrgcn_support_rel_transform_bwd_workspace(sup.handle, K, F, int(need_dX), int(need_dW)))
+                ws = sup.workspace(("xform", K, F), nws)
+                if need_dX:
+                    dX = torch.empty((sup.NL, K), dtype=torch.float32, device=dev)
+                if need_dW:
+                    dW = torch.empty_like(W_F)
+                mask = bool(need_dX and ctx.x_is_relu_out and K <= 16)
+                L.check(lib.mrgcn_support_rel_transform_bwd_compact_f32(
+                    sup.handle, dT.data_ptr(), ld, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
+                    dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0, ws.data_ptr(), ws.numel(),
+                    int(mask), s), "mrgcn_support_rel_transform_bwd_compact_f32")
+                if need_dX and mask:
+                    _set_grad_meta(dX, None, True)
+        return None, None, d_wI, d_comp, dX, dW, dbias, None, None
+
+
+def masked_layer_supported(sup, layer, K: int, need_dX: bool = False) -> bool:
+    """Can `masked_layer` run this layer?  (narrow f32 rows, the matrix-core transforms' shapes.)"""
+    if layer.outdim > 16 or getattr(layer, "operand_dtype", "f32") != "f32":
+        return False
+    if not (layer.input_layer and layer.featureless):
+        return bool(L.load().mrgcn_support_rel_transform_supported(sup.handle, int(K), int(layer.outdim), int(need_dX)))
+    return True
+
+
+def masked_layer(sup, layer, X, relu: bool = False) -> torch.Tensor:
+    """One `GraphConvolution` on a mini-batch sample given as a forward support of the full graph's plan
+    (data.batch.A_BatchMasked): graph.py:62-102 with A_idx, both terms."""
+    F, B = layer.outdim, layer.num_bases
+    weight_I = comp_I = Xin = W_F = None
+    if layer.input_layer:
+        weight_I, comp_I = layer.weight_I, (layer.weight_I_comp if B > 0 else None)
+    if not (layer.input_layer and layer.featureless):
+        if X is None:
+            raise L.MrgcnError("masked_layer: the feature term needs X")
+        Xin, W_F = X, layer.weight_F
+        if B > 0:
+            W_F = _BasisContract.apply(layer.weight_F_comp, W_F)
+    bias = layer.b if layer.bias else None
+    Y = _MaskedLayer.apply(sup, F, weight_I, comp_I, Xin, W_F, bias, relu, layer)
+    if relu:
+        Y._mrgcn_relu_out = True
+    return Y
 
 
 class _BasisContract(torch.autograd.Function):

@@ -60,7 +60,9 @@ class RGCN(nn.Module):
     def _forward_mini_batch(self, X, A):
         """rgcn.py:91-128: layer l computes the embeddings of the nodes (L-1-l) hops from the batch
         nodes out of those one hop further, on the matching row slice of A."""
-        from ..data.batch import getAdjacencyNodeColumnIdx
+        from ..data.batch import A_BatchMasked, getAdjacencyNodeColumnIdx
+        if isinstance(A, A_BatchMasked):
+            return self._forward_masked(X, A)
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             from .. import _lib
             raise _lib.MrgcnError("the mini-batch forward cannot be captured into a hipGraph (its backward decides by "
@@ -86,6 +88,31 @@ class RGCN(nn.Module):
             if f_activation is not None:
                 X = f_activation(X)
         return X
+
+    def _forward_masked(self, X, A):
+        """The same walk on a masked batch (data.batch.A_BatchMasked): every layer is a masked pass over the full
+        graph's plan (functional.masked_layer) on compact arrays — X: one row per node of A.neighbours[-1], hidden
+        activations one row per node of the sample they belong to, the result one row per batch node."""
+        from .. import _lib
+        from .. import functional as Fn
+        for layer_idx, (key, layer) in enumerate(self.layers.items()):
+            f_activation = self.activations[key] if key in self.activations else None
+            sup = A.row[self.num_layers - (layer_idx + 1)]
+            K = 0 if (layer.input_layer and layer.featureless) else int(X.shape[1])
+            need_dX = K > 0 and bool(X.requires_grad) and torch.is_grad_enabled()
+            if layer.engine != "fused" or not Fn.masked_layer_supported(sup, layer, K, need_dX):
+                raise _lib.MrgcnError(
+                    f"{key}: outside the masked mini-batch pass (fused engine, out <= 16, f32 operand, matrix-core "
+                    "transform shapes: an input that wants its gradient has at most 64 columns); use "
+                    "data.batch.A_BatchDevice / MiniBatch for it")
+            fuse_relu = isinstance(f_activation, nn.ReLU) and self.p_dropout <= 0.0
+            X = Fn.masked_layer(sup, layer, None if K == 0 else X, relu=fuse_relu)
+            if self.p_dropout > 0.0:
+                ones = dropout(torch.ones(X.shape[0]), p=self.p_dropout).to(X.device)
+                X = X * ones.unsqueeze(1)
+            if f_activation is not None and not fuse_relu:
+                X = f_activation(X)
+        return X.index_select(0, A.out_rank)
 
     def prepare_batch(self, A):
         """Builds the slice plans a (fresh) batch still lacks — two per layer at most — side by side.  Called by the

@@ -20,9 +20,14 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+import os
+
 from . import functional as Fn
 from .layers.graph import GraphConvolution
 from .plan import GraphPlan
+
+# MRGCN_PART_COMPACT_GATHER=0: the backward all-gather moves every row of the output gradient (A/B)
+_COMPACT_GATHER = os.environ.get("MRGCN_PART_COMPACT_GATHER", "1") != "0"
 
 
 class NodePartition:
@@ -124,6 +129,33 @@ def _gathered_flags(flags: torch.Tensor, group) -> torch.Tensor:
     return full[1]
 
 
+def _live_row_exchange(flags: torch.Tensor, group):
+    """What the backward all-gather of a gradient with structurally known live rows needs, built once per flags tensor
+    (collectives: every rank reaches it in the same backward): this rank's live row numbers, the largest count over the
+    ranks (all-gather wants equal parts) and, for the gathered [world * n_max] rows, which are real and where they go in
+    the [world * S] row space."""
+    ent = getattr(flags, "_mrgcn_exchange", None)
+    if ent is not None and ent[0] == flags._version:
+        return ent[1]
+    world, S = dist.get_world_size(group), int(flags.numel())
+    dev = flags.device
+    mine = torch.nonzero(flags, as_tuple=False).flatten()
+    counts = all_gather_rows(torch.tensor([int(mine.numel())], dtype=torch.int64, device=dev), group).cpu().tolist()
+    n_max = max(max(counts), 1)
+    send_idx = torch.zeros(n_max, dtype=torch.int64, device=dev)
+    send_idx[: mine.numel()] = mine
+    all_idx = all_gather_rows(send_idx, group).view(world, n_max)           # every rank's (padded) local row numbers
+    valid = (torch.arange(n_max, device=dev)[None, :] < torch.tensor(counts, device=dev)[:, None])
+    dst = (all_idx + torch.arange(world, device=dev)[:, None] * S)[valid]      # global row of every real gathered row
+    src = torch.nonzero(valid.flatten(), as_tuple=False).flatten()             # its position among the gathered rows
+    info = dict(send_idx=send_idx, n_max=n_max, src=src, dst=dst, total=int(sum(counts)))
+    try:
+        flags._mrgcn_exchange = (flags._version, info)
+    except AttributeError:
+        pass
+    return info
+
+
 class _ReduceScatterRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
@@ -134,8 +166,24 @@ class _ReduceScatterRows(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         meta = Fn._grad_meta(g)
+        structural = (meta is not None and meta.get("structural") and not meta.get("sparse_rows")
+                      and meta["row_live"] is not None)
+        if structural and g.is_cuda and g.shape[1] <= 16 and Fn._SUPPORT and Fn._LIVE_COLS and _COMPACT_GATHER:
+            # only the rows that can hold anything travel (AM shape, layer 0: 5 565 of 1.67 M rows): the ranks exchange
+            # their live rows, the rest of the gathered gradient stays unwritten — the local layer's backward reads the
+            # flagged rows only (functional._backward_on_support)
+            flags = meta["row_live"]
+            full_flags = _gathered_flags(flags, ctx.group)
+            ex = _live_row_exchange(flags, ctx.group)
+            world = dist.get_world_size(ctx.group)
+            send = g.index_select(0, ex["send_idx"])
+            recv = all_gather_rows(send, ctx.group)
+            out = torch.empty((world * g.shape[0], g.shape[1]), dtype=g.dtype, device=g.device)
+            out.index_copy_(0, ex["dst"], recv.index_select(0, ex["src"]))
+            Fn._set_grad_meta(out, full_flags, meta["relu_applied"], structural=True, sparse_rows=True)
+            return out, None
         out = all_gather_rows(g, ctx.group)
-        if meta is not None and meta.get("structural") and not meta.get("sparse_rows") and meta["row_live"] is not None:
+        if structural:
             # the rows that can hold anything are known on every rank: the gathered gradient carries the gathered
             # flags, and the local layer's backward runs on the gradient support of that row set (functional.py)
             Fn._set_grad_meta(out, _gathered_flags(meta["row_live"], ctx.group), meta["relu_applied"], structural=True)

@@ -36,8 +36,10 @@ def _release(kind: str, handle, after_event=None):
         return
     while _PARKED:
         k, h = _PARKED.pop()
-        (lib.mrgcn_support_destroy if k == "support" else lib.mrgcn_plan_destroy)(h)
-    if kind == "support":
+        (lib.mrgcn_support_destroy if k.startswith("support") else lib.mrgcn_plan_destroy)(h)
+    if kind == "support_ordered":
+        lib.mrgcn_support_destroy_ordered(handle)
+    elif kind == "support":
         lib.mrgcn_support_destroy(handle)
     elif after_event is not None:
         lib.mrgcn_plan_destroy_after(handle, after_event.cuda_event)
@@ -253,6 +255,33 @@ class GraphPlan:
             self._ulcol_long = t
         return t
 
+    # -- per-node entry units of the wide-layer backward (mrgcn_wide_input_bwd_f32) ---------------------
+    def wide_units(self, unit_entries: int = 256):
+        """(erel, unit_node, unit_beg, unit_end, unit_multi, n_units): the plan's CSC entries cut into per-node units
+        of at most `unit_entries` entries (a source node's entries are contiguous), built once and kept."""
+        ent = self.__dict__.get("_wide_units")
+        if ent is None:
+            nptr = self.export(L.ARR_NPTR).astype(np.int64)
+            cptr = self.export(L.ARR_CPTR).astype(np.int64)
+            eptr = cptr[nptr]                                   # entry range of every node
+            n = np.diff(eptr)
+            k = (n + unit_entries - 1) // unit_entries          # units per node (0 for a node without entries)
+            node = np.repeat(np.arange(self.num_nodes), k)
+            first = np.cumsum(k) - k
+            idx = np.arange(int(k.sum())) - np.repeat(first, k)  # unit number inside its node
+            beg = eptr[node] + idx * unit_entries
+            end = np.minimum(beg + unit_entries, eptr[node + 1])
+            dev = self.device
+            erel = torch.empty((max(self.nnz, 1),), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                L.check(L.load().mrgcn_plan_entry_relations(self.handle, erel.data_ptr(), _stream_ptr(dev)),
+                        "mrgcn_plan_entry_relations")
+            up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(dev)  # noqa: E731
+            ent = (erel, up(node, np.int32), up(beg, np.int32), up(end, np.int32), up(k[node] > 1, np.uint8),
+                   int(len(node)))
+            self.__dict__["_wide_units"] = ent
+        return ent
+
     # -- gradient support (include/mrgcn_hip.h: mrgcn_support_*) --------------------------------
     def support_for(self, row_flags: torch.Tensor):
         """The gradient support of the output rows flagged in `row_flags` (uint8 [num_rows], device), built on first
@@ -288,16 +317,21 @@ class GraphSupport:
     set of output rows that can carry gradient.  Holds on to the flags tensor it was built from (its identity is the
     cache key) and to its plan."""
 
-    def __init__(self, plan: GraphPlan, row_flags: torch.Tensor):
+    def __init__(self, plan: GraphPlan, row_flags: torch.Tensor, forward: bool = False):
+        """`forward`: also keep the flagged rows' forward arrays (MRGCN_SUPPORT_FORWARD: a mini-batch layer as a
+        masked pass over the plan, csrc/masked.hip)."""
         import weakref
         lib = L.load()
+        if row_flags.dtype != torch.uint8 or row_flags.numel() != plan.num_rows or not row_flags.is_contiguous():
+            raise L.MrgcnError(f"row_flags must be a contiguous uint8 tensor of {plan.num_rows} rows")
         # (a weak reference: the plan keeps its supports, not the other way round — no reference cycle, so both are
         # released by reference counting when the plan goes, not by a collector run at an arbitrary moment)
         self._plan = weakref.ref(plan)
         self.row_flags, self.device = row_flags, plan.device
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            L.check(lib.mrgcn_support_create(C.byref(h), plan.handle, row_flags.data_ptr(), _stream_ptr(self.device)),
+            L.check(lib.mrgcn_support_create_ex(C.byref(h), plan.handle, row_flags.data_ptr(),
+                                                L.SUPPORT_FORWARD if forward else 0, _stream_ptr(self.device)),
                     "mrgcn_support_create")
         self._h = h
         info = L.SupportInfo()
@@ -305,6 +339,10 @@ class GraphSupport:
         self.L, self.E, self.NL = int(info.live_cols), int(info.live_entries), int(info.live_nodes)
         self.device_bytes = int(info.device_bytes)
         self.chunks_wide, self.chunks_narrow = int(info.chunks_wide), int(info.chunks_narrow)
+        self.forward, self.NR = bool(forward), int(info.flagged_rows)
+        # a forward support is a mini-batch's: it lives for one step on the stream that built it, and is released
+        # under that stream's order, without a device-wide wait (mrgcn_support_destroy_ordered)
+        self.ordered_release = bool(forward)
         self._node_flags = None
         self._ws = {}
 
@@ -320,7 +358,7 @@ class GraphSupport:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            _release("support", self._h)
+            _release("support_ordered" if getattr(self, "ordered_release", False) else "support", self._h)
             self._h = None
 
     def __del__(self):
@@ -336,7 +374,8 @@ class GraphSupport:
 
     def export(self, which: int) -> np.ndarray:
         ptr, n = self.array_ptr(which)
-        dt = {L.SUP_COL_FLAGS: torch.uint8, L.SUP_NODE_FLAGS: torch.uint8, L.SUP_LVAL: torch.float32}.get(which, torch.int32)
+        dt = {L.SUP_COL_FLAGS: torch.uint8, L.SUP_NODE_FLAGS: torch.uint8, L.SUP_LVAL: torch.float32,
+              L.SUP_FVAL: torch.float32}.get(which, torch.int32)
         out = torch.empty((n,), dtype=dt, device=self.device)
         if n:
             out = _device_array(ptr, n, dt, self.device).clone()
@@ -350,6 +389,11 @@ class GraphSupport:
             ptr, n = self.array_ptr(L.SUP_NODE_FLAGS)
             self._node_flags = _device_array(ptr, n, torch.uint8, self.device).clone()
         return self._node_flags
+
+    def view(self, which: int) -> torch.Tensor:
+        """One of the support's int32 arrays as a tensor over the library's memory (valid while the support lives)."""
+        ptr, n = self.array_ptr(which)
+        return _device_array(ptr, n, torch.int32, self.device)
 
     def workspace(self, key, numel: int) -> torch.Tensor:
         """A float32 scratch tensor kept on the support (one per use: the same buffer every epoch)."""

@@ -48,9 +48,56 @@ def _triples(data, device) -> torch.Tensor:
     return t.to(device).contiguous()
 
 
+class SortedTriples:
+    """The orders of a FIXED triple set by subject / predicate / object (what the sorted decoder backward walks), built
+    once: a full-batch run scores the same training facts every epoch (tasks/link_prediction.py:231-263 — only the 20 %
+    corrupted copies are drawn anew), so three per-epoch sorts of 326 k keys (0.16 ms of a 1.7 ms epoch at the
+    FB15k-237 shape) shrink to nothing.  Pass it to `score_distmult_bc(..., static=...)` when the first
+    `len(static)` rows of the scored triples ARE these facts, in this order (checked by identity / version)."""
+
+    def __init__(self, triples: torch.Tensor, num_nodes: int, num_relations: int):
+        t = triples.contiguous()
+        if not t.is_cuda or t.dtype != torch.int64 or t.dim() != 2 or t.shape[1] != 3:
+            raise TypeError("SortedTriples: int64 [n, 3] triples on the GPU")
+        self.triples, self.version, self.n = t, t._version, int(t.shape[0])
+        # built once, so the sorts may be anything: stable argsorts with a secondary key — inside a run of equal
+        # predicate the facts follow their subject (the subject's embedding row repeats for consecutive facts instead of
+        # being gathered anew), inside a run of equal subject / object the other end rises
+        s_, p_, o_ = t[:, 0], t[:, 1], t[:, 2]
+        nn_ = int(num_nodes)
+        self.order = [torch.argsort(s_ * nn_ + o_, stable=True), torch.argsort(p_ * nn_ + s_, stable=True),
+                      torch.argsort(o_ * nn_ + s_, stable=True)]
+        self._tail = None
+
+    def tail_orders(self, nt: int, num_nodes: int, num_relations: int):
+        """Buffers for the orders of the `nt` triples behind the fixed facts (+ the counting sort's workspace), kept."""
+        if self._tail is None or self._tail[0] != (nt, num_nodes, num_relations):
+            dev = self.triples.device
+            ws = torch.empty(int(_lib.load().mrgcn_distmult_orders_counting_workspace(num_nodes, num_relations)),
+                             dtype=torch.uint8, device=dev)
+            self._tail = ((nt, num_nodes, num_relations),
+                          [torch.empty(nt, dtype=torch.int64, device=dev) for _ in range(3)] + [ws])
+        return self._tail[1]
+
+    def __len__(self):
+        return self.n
+
+    def covers(self, triples: torch.Tensor) -> bool:
+        """May the stored orders serve `triples`?  The facts are unchanged since the orders were built and `triples`
+        starts with them (compared once, outside stream captures; afterwards the caller's contract)."""
+        if self.triples._version != self.version or triples.shape[0] < self.n:
+            return False
+        if not getattr(self, "_checked", False) and not torch.cuda.is_current_stream_capturing():
+            if not torch.equal(triples[: self.n], self.triples):
+                return False
+            self._checked = True
+        return True
+
+
 class _DistMultScore(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, E, Rel, triples):
+    def forward(ctx, E, Rel, triples, static=None):
+        ctx.static = static
         lib = _lib.load()
         n, H = triples.shape[0], E.shape[1]
         scores = torch.empty(n, dtype=torch.float32, device=E.device)
@@ -67,6 +114,35 @@ class _DistMultScore(torch.autograd.Function):
         dE = torch.zeros_like(E, memory_format=torch.contiguous_format) if ctx.needs_input_grad[0] else None
         dR = torch.zeros_like(Rel, memory_format=torch.contiguous_format) if ctx.needs_input_grad[1] else None
         n = triples.shape[0]
+        st = ctx.static
+        if st is not None and st.covers(triples) and os.environ.get("MRGCN_LP_SORTED_BWD", "1") != "0":
+            # the fixed facts through their stored orders (runs of equal targets summed in registers), the few
+            # freshly drawn ones behind them through the scatter kernel: no sort in the epoch
+            ns = len(st)
+            _lib.check(lib.mrgcn_distmult_score_bwd_sorted_f32(
+                _ptr(E), E.stride(0), _ptr(Rel), Rel.stride(0), E.shape[1], _ptr(triples), ns, _ptr(g),
+                _ptr(st.order[0]), _ptr(st.order[1]), _ptr(st.order[2]), _ptr(dE), dE.stride(0) if dE is not None else 0,
+                _ptr(dR), dR.stride(0) if dR is not None else 0, _stream()), "distmult_score_bwd_sorted")
+            if n > ns:
+                tail, gtail, nt = C.c_void_p(triples.data_ptr() + 24 * ns), C.c_void_p(g.data_ptr() + 4 * ns), n - ns
+                if (nt >= 1024 and E.shape[0] <= (1 << 22) and Rel.shape[0] <= (1 << 22)
+                        and os.environ.get("MRGCN_LP_COUNTING", "1") != "0"):
+                    # enough of them to collide in the scatter kernel's atomics (54 k corrupted facts on 237 relation
+                    # rows: 310 us at the FB15k-237 shape): a counting sort (four launches) and the sorted passes
+                    o3 = st.tail_orders(nt, E.shape[0], Rel.shape[0])
+                    _lib.check(lib.mrgcn_distmult_orders_counting(
+                        tail, nt, E.shape[0], Rel.shape[0], _ptr(o3[0]), _ptr(o3[1]), _ptr(o3[2]), _ptr(o3[3]),
+                        o3[3].numel(), _stream()), "distmult_orders_counting")
+                    _lib.check(lib.mrgcn_distmult_score_bwd_sorted_f32(
+                        _ptr(E), E.stride(0), _ptr(Rel), Rel.stride(0), E.shape[1], tail, nt, gtail, _ptr(o3[0]),
+                        _ptr(o3[1]), _ptr(o3[2]), _ptr(dE), dE.stride(0) if dE is not None else 0, _ptr(dR),
+                        dR.stride(0) if dR is not None else 0, _stream()), "distmult_score_bwd_sorted")
+                else:
+                    _lib.check(lib.mrgcn_distmult_score_bwd_f32(
+                        _ptr(E), E.stride(0), _ptr(Rel), Rel.stride(0), E.shape[1], tail, nt, gtail, _ptr(dE),
+                        dE.stride(0) if dE is not None else 0, _ptr(dR), dR.stride(0) if dR is not None else 0,
+                        _stream()), "distmult_score_bwd")
+            return dE, dR, None, None
         if n >= _SORTED_BWD_MIN and os.environ.get("MRGCN_LP_SORTED_BWD", "1") != "0":
             # runs of equal subject / predicate / object are summed in registers (three passes over
             # sorted triples) instead of one float atomic per triple and feature
@@ -84,14 +160,15 @@ class _DistMultScore(torch.autograd.Function):
                 _ptr(E), E.stride(0), _ptr(Rel), Rel.stride(0), E.shape[1], _ptr(triples), n,
                 _ptr(g), _ptr(dE), dE.stride(0) if dE is not None else 0, _ptr(dR),
                 dR.stride(0) if dR is not None else 0, _stream()), "distmult_score_bwd")
-        return dE, dR, None
+        return dE, dR, None, None
 
 
-def score_distmult_bc(data, node_embeddings, edge_embeddings):
-    """link_prediction.py:645-665 for the 1-D (s, p, o) index tensors train_model passes."""
+def score_distmult_bc(data, node_embeddings, edge_embeddings, static: "SortedTriples | None" = None):
+    """link_prediction.py:645-665 for the 1-D (s, p, o) index tensors train_model passes (or an int64 [n, 3] tensor).
+    `static`: the stored orders of the facts the triples START with (SortedTriples): the backward then sorts nothing."""
     E = _f32_rows(node_embeddings, "node_embeddings")
     Rel = _f32_rows(edge_embeddings, "edge_embeddings")
-    return _DistMultScore.apply(E, Rel, _triples(data, E.device))
+    return _DistMultScore.apply(E, Rel, _triples(data, E.device), static)
 
 
 class _BceLogits(torch.autograd.Function):
@@ -177,6 +254,35 @@ def sample_negatives_device(batch_data: torch.Tensor, generator=None):
     Y = torch.ones(n + ncorrupt, dtype=torch.float32, device=dev)
     Y[n:] = 0
     return corrupted, Y
+
+
+class DeviceNegativeSampler:
+    """`sample_negatives_device` for a FIXED fact set, without its per-epoch torch traffic: the facts sit at the head of
+    one [n + n // 5, 3] buffer, a single launch (mrgcn_corrupt_triples_i64) writes the corrupted copies behind them, the
+    labels are built once.  `triples, labels = sampler()` — the same tensors every call (their contents change): what a
+    captured epoch wants.  The draws come from a 64-bit seed taken from torch's generator per call."""
+
+    def __init__(self, facts: torch.Tensor, generator=None):
+        n = int(facts.shape[0])
+        dev = facts.device
+        self.n, self.ncorrupt = n, n // 5
+        self.nhead = self.ncorrupt // 2
+        self.generator = generator
+        self.buf = torch.empty((n + self.ncorrupt, 3), dtype=torch.int64, device=dev)
+        self.buf[:n] = facts
+        self.facts = self.buf[:n]
+        self.nodes = torch.unique(torch.cat([facts[:, 0], facts[:, 2]]))
+        self.labels = torch.ones(n + self.ncorrupt, dtype=torch.float32, device=dev)
+        self.labels[n:] = 0
+
+    def __call__(self):
+        dev = self.buf.device
+        seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=dev, generator=self.generator)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mrgcn_corrupt_triples_i64(
+                _ptr(self.buf), self.n, _ptr(self.nodes), int(self.nodes.numel()), _ptr(seed), self.ncorrupt, self.nhead,
+                C.c_void_p(self.buf.data_ptr() + 24 * self.n), _stream()), "corrupt_triples")
+        return self.buf, self.labels
 
 
 def filter_lists(data: np.ndarray):

@@ -156,15 +156,19 @@ def test_mrgcn_through_fullbatch_boundary(name):
                 assert (diff > 2e-5).mean() < 5e-3 and diff.max() <= 0.021 * step, k
 
 
-@pytest.mark.parametrize("N,R,B,F,bias", [(400, 5, 2, 200, False), (300, 7, 3, 130, True), (200, 4, 0, 96, True)])
-def test_featureless_wide_layer_vs_oracle(N, R, B, F, bias):
+@pytest.mark.parametrize("N,R,B,F,bias,hub", [(400, 5, 2, 200, False, 150), (300, 7, 3, 130, True, 150),
+                                              (200, 4, 0, 96, True, 150), (900, 6, 4, 64, False, 700),
+                                              (700, 5, 1, 256, True, 600), (500, 3, 2, 20, False, 400)])
+def test_featureless_wide_layer_vs_oracle(N, R, B, F, bias, hub):
     """FB15k-237-style encoder layer: featureless input layer with a wide hidden size
-    (configs/fb15k-237.toml: 2 bases, hidden 200) — forward and every gradient."""
+    (configs/fb15k-237.toml: 2 bases, hidden 200) — forward and every gradient.  B <= 4 with F % 4 == 0 takes the
+    backward that never forms dM (csrc/wide_input.hip); hubs of several hundred entries per source node span several
+    of its units (float atomics on their dV blocks)."""
     from oracle import rgcn_oracle as O
     from mrgcn_amd.layers.graph import GraphConvolution
     from mrgcn_amd.plan import plan_of
     rng = np.random.default_rng(F)
-    rows, cols, vals, A = _oracle_layer_case(rng, N, R, max(B, 1), 1, F, 8 * N, 150)
+    rows, cols, vals, A = _oracle_layer_case(rng, N, R, max(B, 1), 1, F, 8 * N, hub)
     At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals),
                                  (N, R * N)).cuda()
     torch.manual_seed(F)

@@ -146,6 +146,86 @@ def test_sorted_backward_equals_scatter_backward():
         np.testing.assert_allclose(dR, dR_ref, rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("H", [200, 64, 70])
+def test_stored_orders_of_fixed_facts_and_vector_rows_against_the_oracle(H):
+    """A run scores the same training facts every epoch: their orders are stored once (SortedTriples), the corrupted
+    facts behind them take the scatter kernel — no sort per backward.  Rows of whole 16-byte pieces (H = 200, 64) go
+    through the pipelined kernels (k_distmult_fwd4 / _bwd_sorted4), H = 70 through the element-wise ones; scores and
+    both gradients against the float64 oracle."""
+    from mrgcn_amd.tasks import link_prediction as lp
+    rng = np.random.default_rng(H)
+    N, P, n = 500, 9, 9000
+    E = rng.standard_normal((N, H)).astype(np.float32)
+    Rel = rng.standard_normal((2 * P + 1, H)).astype(np.float32)
+    facts = np.stack([rng.integers(0, N, n), rng.integers(0, P, n), rng.integers(0, N, n)], 1).astype(np.int64)
+    facts[:3000, 1] = 2          # long runs of one predicate, and of one subject
+    facts[3000:3400, 0] = 7
+    sampler = lp.DeviceNegativeSampler(torch.from_numpy(facts).cuda(), torch.Generator(device="cuda").manual_seed(1))
+    static = lp.SortedTriples(sampler.facts, N, 2 * P + 1)
+    for _ in range(2):           # two draws of negatives on the same buffers
+        t, y = sampler()
+        tn, yn = t.cpu().numpy(), y.cpu().numpy()
+        dE_ref, dR_ref = lo.distmult_bce_grads(tn, E, Rel, yn)
+        Et, Rt = torch.from_numpy(E).cuda().requires_grad_(True), torch.from_numpy(Rel).cuda().requires_grad_(True)
+        sc = lp.score_distmult_bc(t, Et, Rt, static=static)
+        ref_sc = (E[tn[:, 0]].astype(np.float64) * Rel[tn[:, 1]] * E[tn[:, 2]]).sum(1)
+        np.testing.assert_allclose(sc.detach().cpu().numpy(), ref_sc, rtol=1e-4, atol=1e-4)
+        lp.binary_crossentropy(sc, y).backward()
+        np.testing.assert_allclose(Et.grad.cpu().numpy(), dE_ref, rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(Rt.grad.cpu().numpy(), dR_ref, rtol=1e-3, atol=1e-6)
+    # a triple tensor that does not start with the stored facts is refused (the general path runs)
+    other = torch.from_numpy(facts[::-1].copy()).cuda()
+    assert not lp.SortedTriples(torch.from_numpy(facts).cuda(), N, 2 * P + 1).covers(other)
+
+
+@pytest.mark.parametrize("n,N,R", [(1, 5, 3), (5000, 700, 19), (54423, 14541, 475)])
+def test_counting_sort_orders_are_sorted_permutations(n, N, R):
+    import ctypes as C
+    from mrgcn_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(n)
+    tr = torch.from_numpy(np.stack([rng.integers(0, N, n), rng.integers(0, R, n), rng.integers(0, N, n)], 1)).cuda()
+    orders = [torch.empty(n, dtype=torch.int64, device="cuda") for _ in range(3)]
+    ws = torch.empty(int(lib.mrgcn_distmult_orders_counting_workspace(N, R)), dtype=torch.uint8, device="cuda")
+    for _ in range(2):   # (the workspace is re-zeroed inside: a second call on the same buffers)
+        L.check(lib.mrgcn_distmult_orders_counting(tr.data_ptr(), n, N, R, orders[0].data_ptr(), orders[1].data_ptr(),
+                                                   orders[2].data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   torch.cuda.current_stream().cuda_stream))
+    t = tr.cpu().numpy()
+    for c, o in enumerate(orders):
+        o = o.cpu().numpy()
+        np.testing.assert_array_equal(np.sort(o), np.arange(n))
+        assert np.all(np.diff(t[o, c]) >= 0)
+
+
+def test_device_negative_sampler_draws_distinct_facts_with_in_batch_replacements():
+    from mrgcn_amd.tasks import link_prediction as lp
+    rs = np.random.RandomState(1)
+    f = np.unique(np.stack([rs.randint(0, 500, 5003), rs.randint(0, 40, 5003), rs.randint(0, 500, 5003)], 1), axis=0)
+    facts = torch.from_numpy(f).cuda()
+    n = len(f)
+    sampler = lp.DeviceNegativeSampler(facts, torch.Generator(device="cuda").manual_seed(0))
+    t1, y1 = sampler()
+    neg1 = t1[n:].clone()
+    t2, y2 = sampler()
+    assert t1 is t2 and y1 is y2 and t1.shape == (n + n // 5, 3)
+    assert bool((t2[:n] == facts).all()) and bool(y1[:n].all()) and not bool(y1[n:].any())
+    neg2 = t2[n:]
+    assert not bool((neg1 == neg2).all())                      # another seed, another draw
+    nodes = torch.unique(torch.cat([facts[:, 0], facts[:, 2]]))
+    nh = (n // 5) // 2
+    for neg in (neg1, neg2):
+        assert bool(torch.isin(neg[:, 0], nodes).all()) and bool(torch.isin(neg[:, 2], nodes).all())
+        # every corrupted fact is a copy of a DISTINCT fact with one end replaced: (p, o) of the head-corrupted ones
+        # and (s, p) of the tail-corrupted ones still belong to facts, and the source facts do not repeat
+        key = lambda a, b: a * 100003 + b  # noqa: E731
+        po = set(key(f[:, 1], f[:, 2]).tolist())
+        sp = set(key(f[:, 0], f[:, 1]).tolist())
+        ng = neg.cpu().numpy()
+        assert all(k in po for k in key(ng[:nh, 1], ng[:nh, 2]).tolist())
+        assert all(k in sp for k in key(ng[nh:, 0], ng[nh:, 1]).tolist())
+
+
 def test_device_negative_sampling_shapes():
     from mrgcn_amd.tasks import link_prediction as lp
     rs = np.random.RandomState(1)

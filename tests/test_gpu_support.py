@@ -162,3 +162,130 @@ def test_the_default_epoch_runs_its_backward_on_supports(monkeypatch):
     _epoch_runs(name, True, steps=2)
     assert "mrgcn_support_spmm_t_f32" in seen
     assert not any(n.startswith("mrgcn_spmm_transposed_live") for n in seen), seen
+
+
+# ---- forward supports: a mini-batch layer as a masked pass over the full plan (csrc/masked.hip) -------------------
+def _dense(rows, cols, vals, N, R):
+    A = np.zeros((N, R * N), dtype=np.float64)
+    np.add.at(A, (rows, cols), vals.astype(np.float64))
+    return A
+
+
+@pytest.mark.parametrize("seed,N,R,nnz,hubs,sample", [(0, 300, 7, 2500, 0, 12), (1, 1500, 11, 20000, 3, 40),
+                                                      (2, 200, 3, 600, 1, 200), (3, 4000, 9, 30000, 2, 1)])
+def test_forward_support_arrays_and_products(seed, N, R, nnz, hubs, sample):
+    """FROW / FPTR / FCOL / FVAL = A[sample] over live columns (bit-exact against numpy); the forward and transposed
+    products through the C ABI, with the stored values and with the all-ones slice, against dense float64."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphSupport
+    lib = L.load()
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = _random_graph(rng, N, N, R, nnz, hub_rows=hubs, hub_len=min(400, N), hub_cols=hubs)
+    plan = _plan_from_coo(rows, cols, vals, N, N, R)
+    ref = util.numpy_plan(rows, cols, vals, N, N, R)
+    flags = np.zeros(N, dtype=np.uint8)
+    flags[rng.choice(N, sample, replace=False)] = 1
+    sup = GraphSupport(plan, torch.from_numpy(flags).cuda(), forward=True)
+    want = _numpy_support(ref, flags, N, R)
+    frow = np.nonzero(flags)[0]
+    assert (sup.NR, sup.L, sup.NL) == (len(frow), len(want["lcol"]), len(want["lnode"]))
+    np.testing.assert_array_equal(sup.export(L.SUP_FROW), frow)
+    rank = np.full(N, -1, dtype=np.int32)
+    rank[frow] = np.arange(len(frow))
+    np.testing.assert_array_equal(sup.export(L.SUP_ROWRANK), rank)
+    # the flagged rows of the plan's CSR, columns by live number
+    lpos = np.cumsum(want["col_flags"]) - want["col_flags"]
+    rowptr, ccol, val = ref["rowptr"], ref["ccol"], ref["val"]
+    fptr, fcol, fval = [0], [], []
+    for i in frow:
+        fcol.extend(lpos[ccol[rowptr[i]:rowptr[i + 1]]])
+        fval.extend(val[rowptr[i]:rowptr[i + 1]])
+        fptr.append(len(fcol))
+    np.testing.assert_array_equal(sup.export(L.SUP_FPTR), np.asarray(fptr, dtype=np.int32))
+    np.testing.assert_array_equal(sup.export(L.SUP_FCOL), np.asarray(fcol, dtype=np.int32))
+    np.testing.assert_array_equal(sup.export(L.SUP_FVAL), np.asarray(fval, dtype=np.float32))
+    node_of_col = ref["unode"][want["lcol"]]
+    np.testing.assert_array_equal(sup.export(L.SUP_LNODE_ORD), np.searchsorted(want["lnode"], node_of_col))
+    assert sup.E == len(fcol)
+    # products
+    A = _dense(rows, cols, vals, N, R)
+    gcols = ref["urel"][want["lcol"]].astype(np.int64) * N + node_of_col
+    As = A[np.ix_(frow, gcols)]                       # [NR, L] stored values
+    Aones = (np.zeros_like(As))
+    for q, i in enumerate(frow):                      # the entries (incl. stored zeros) as ones
+        np.add.at(Aones[q], lpos[ccol[rowptr[i]:rowptr[i + 1]]], 1.0)
+    s = torch.cuda.current_stream().cuda_stream
+    for F in (10, 16, 3):
+        ld = (F + 3) // 4 * 4
+        D = rng.standard_normal((max(sup.L, 1), ld)).astype(np.float32)
+        Dt = torch.from_numpy(D).cuda()
+        bias = rng.standard_normal(F).astype(np.float32)
+        bt = torch.from_numpy(bias).cuda()
+        for use_values, M in ((1, As), (0, Aones)):
+            Y = torch.full((sup.NR, F), 7.0, device="cuda")
+            L.check(lib.mrgcn_support_spmm_fwd_f32(sup.handle, use_values, Dt.data_ptr(), ld, F, Y.data_ptr(), F,
+                                                   bt.data_ptr(), 1, s))
+            want_Y = np.maximum(M @ D[:sup.L, :F].astype(np.float64) + bias, 0.0)
+            np.testing.assert_allclose(Y.cpu().numpy(), want_Y, rtol=1e-4, atol=1e-4)
+            dY = rng.standard_normal((sup.NR, F)).astype(np.float32)
+            dM = torch.full((max(sup.L, 1), ld), 7.0, device="cuda")
+            L.check(lib.mrgcn_support_spmm_t_compact_f32(sup.handle, use_values, torch.from_numpy(dY).cuda().data_ptr(), F,
+                                                         F, dM.data_ptr(), ld, s))
+            np.testing.assert_allclose(dM.cpu().numpy()[:sup.L, :F], M.T @ dY.astype(np.float64), rtol=1e-4, atol=1e-4)
+    sup.close()
+
+
+@pytest.mark.parametrize("B,F,K", [(3, 10, 12), (40, 10, 155), (2, 16, 5)])
+def test_forward_support_mix_and_transform(B, F, K):
+    """mix_fwd (live columns of weight_I x comp), rel_transform_fwd (X by live-node rank) and the compact backward of
+    the transform against float64."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphSupport
+    lib = L.load()
+    rng = np.random.default_rng(B)
+    N, R = 1200, 9
+    rows, cols, vals = _random_graph(rng, N, N, R, 15000, hub_rows=2, hub_len=300, hub_cols=2)
+    plan = _plan_from_coo(rows, cols, vals, N, N, R)
+    ref = util.numpy_plan(rows, cols, vals, N, N, R)
+    flags = np.zeros(N, dtype=np.uint8)
+    flags[rng.choice(N, 50, replace=False)] = 1
+    sup = GraphSupport(plan, torch.from_numpy(flags).cuda(), forward=True)
+    want = _numpy_support(ref, flags, N, R)
+    lrel, lnode = want["lrel"].astype(np.int64), want["lnode"]
+    node_of_col = ref["unode"][want["lcol"]].astype(np.int64)
+    ordn = np.searchsorted(lnode, node_of_col)
+    s = torch.cuda.current_stream().cuda_stream
+    ld = (F + 3) // 4 * 4
+    V = rng.standard_normal((N, B, F)).astype(np.float32)
+    comp = rng.standard_normal((R, B)).astype(np.float32)
+    M = torch.zeros((sup.L, ld), device="cuda")
+    L.check(lib.mrgcn_support_mix_fwd_f32(sup.handle, torch.from_numpy(V).cuda().data_ptr(),
+                                          torch.from_numpy(comp).cuda().data_ptr(), B, F, M.data_ptr(), ld, s))
+    want_M = np.einsum("kb,kbf->kf", comp[lrel].astype(np.float64), V[node_of_col].astype(np.float64))
+    np.testing.assert_allclose(M.cpu().numpy()[:, :F], want_M, rtol=1e-4, atol=1e-4)
+    need_dX = K <= 64
+    assert lib.mrgcn_support_rel_transform_supported(sup.handle, K, F, int(need_dX))
+    assert need_dX or not lib.mrgcn_support_rel_transform_supported(sup.handle, K, F, 1)
+    X = rng.standard_normal((sup.NL, K)).astype(np.float32)
+    W = rng.standard_normal((R, K, F)).astype(np.float32)
+    Xt, Wt = torch.from_numpy(X).cuda(), torch.from_numpy(W).cuda()
+    T = torch.zeros((sup.L, ld), device="cuda")
+    L.check(lib.mrgcn_support_rel_transform_fwd_f32(sup.handle, Xt.data_ptr(), K, K, Wt.data_ptr(), F, T.data_ptr(), ld, s))
+    want_T = np.einsum("kc,kcf->kf", X[ordn].astype(np.float64), W[lrel].astype(np.float64))
+    np.testing.assert_allclose(T.cpu().numpy()[:, :F], want_T, rtol=1e-4, atol=1e-4)
+    dT = rng.standard_normal((sup.L, ld)).astype(np.float32)
+    nws = int(lib.mrgcn_support_rel_transform_bwd_workspace(sup.handle, K, F, int(need_dX), 1))
+    ws = torch.empty(max(nws, 2), device="cuda")
+    dX = torch.full((sup.NL, K), 7.0, device="cuda")
+    dW = torch.full((R, K, F), 7.0, device="cuda")
+    L.check(lib.mrgcn_support_rel_transform_bwd_compact_f32(
+        sup.handle, torch.from_numpy(dT).cuda().data_ptr(), ld, Xt.data_ptr(), K, K, Wt.data_ptr(), F,
+        dX.data_ptr() if need_dX else 0, K, dW.data_ptr(), ws.data_ptr(), ws.numel(), 0, s))
+    want_dW = np.zeros((R, K, F))
+    np.add.at(want_dW, lrel, np.einsum("kc,kf->kcf", X[ordn].astype(np.float64), dT[:, :F].astype(np.float64)))
+    want_dX = np.zeros((sup.NL, K))
+    np.add.at(want_dX, ordn, np.einsum("kf,kcf->kc", dT[:, :F].astype(np.float64), W[lrel].astype(np.float64)))
+    np.testing.assert_allclose(dW.cpu().numpy(), want_dW, rtol=1e-3, atol=1e-3)
+    if need_dX:
+        np.testing.assert_allclose(dX.cpu().numpy(), want_dX, rtol=1e-3, atol=1e-3)
+    sup.close()

@@ -197,6 +197,118 @@ def test_short_lived_batch_on_lean_plans_equals_the_goldens(tag):
                                        err_msg=n)
 
 
+def _golden_model(g, tag, A):
+    from mrgcn_amd.models.rgcn import RGCN
+    fl, B, bias, nl, hidden, classes, xw = [int(v) for v in g[tag + ".meta"]]
+    N = A.shape[0]
+    R = A.shape[1] // N
+    dims = [(xw if li == 0 else hidden, hidden if li < nl - 1 else classes) for li in range(nl)]
+    modules = [(i, o, "mrgcn", torch.nn.ReLU() if li < nl - 1 else None) for li, (i, o) in enumerate(dims)]
+    model = RGCN(modules, R, N, B, 0.0, bool(fl), bool(bias), False)
+    model.load_state_dict({k[len(tag) + 6:]: torch.from_numpy(np.array(g[k])) for k in g.files
+                           if k.startswith(tag + ".init.")})
+    return model.cuda(), fl, nl, N, R
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_masked_batch_on_the_full_plan_equals_the_goldens(tag):
+    """A_BatchMasked: the batch as row sets on the FULL graph's plan (no slices, no per-batch plans; csrc/masked.hip) —
+    the reference's neighbour sets, logits, loss and gradients."""
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.data.batch import scipy_sparse_to_pytorch_sparse
+    from mrgcn_amd.plan import plan_of
+    from mrgcn_amd.train import categorical_crossentropy
+    g = np.load(GOLD)
+    _, A = util.load_graph("graph_small")
+    model, fl, nl, N, R = _golden_model(g, tag, A)
+    plan = plan_of(scipy_sparse_to_pytorch_sparse(A, dtype=torch.int8).cuda(), N, R)   # the reference's boundary cast
+    Xfull = None if fl else torch.from_numpy(g[tag + ".X_full"]).cuda()
+    for _ in range(2):  # a fresh batch object each time, the one plan
+        ab = mb.A_BatchMasked(plan, g["batch_idx"], nl)
+        for i in range(nl):
+            assert np.array_equal(ab.neighbours[i].cpu().numpy(), g[f"{tag}.neighbours_{i}"])
+        X = None if fl else Xfull[ab.neighbours[-1]].requires_grad_(True)
+        model.zero_grad()
+        logits = model(X, ab)
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), g[tag + ".logits"], rtol=1e-4, atol=1e-4)
+        idx = torch.arange(len(g["batch_idx"]), device="cuda")
+        loss = categorical_crossentropy(logits, idx, torch.from_numpy(g[tag + ".y"]).cuda())
+        assert abs(float(loss.detach()) - float(g[tag + ".loss"])) < 1e-5
+        loss.backward()
+        for n, p in model.named_parameters():
+            np.testing.assert_allclose(util.ref_layout(p.grad, n).cpu().numpy(), g[f"{tag}.grad.{n}"], rtol=1e-3, atol=1e-5,
+                                       err_msg=n)
+        if X is not None:
+            np.testing.assert_allclose(X.grad.cpu().numpy(), g[tag + ".grad.X"], rtol=1e-3, atol=1e-5)
+        ab.close()
+
+
+@pytest.mark.gpu
+def test_masked_batch_rows_follow_the_batch_order_with_repeats():
+    """Output rows follow batch_idx (unsorted, with a repeated node) exactly like A[sample] does on the slice path."""
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.data.batch import scipy_sparse_to_pytorch_sparse
+    from mrgcn_amd.plan import plan_of
+    g = np.load(GOLD)
+    tag = "ft_b3"
+    _, A = util.load_graph("graph_small")
+    model, fl, nl, N, R = _golden_model(g, tag, A)
+    idx = np.asarray(g["batch_idx"])
+    shuffled = np.concatenate([idx[::-1], idx[:2]])
+    plan = plan_of(scipy_sparse_to_pytorch_sparse(A, dtype=torch.int8).cuda(), N, R)
+    ab = mb.A_BatchMasked(plan, shuffled, nl)
+    X = torch.from_numpy(g[tag + ".X_full"]).cuda()[ab.neighbours[-1]]
+    logits = model(X, ab).detach().cpu().numpy()
+    want = np.concatenate([g[tag + ".logits"][::-1], g[tag + ".logits"][:2]])
+    np.testing.assert_allclose(logits, want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_masked_batches_train_like_slice_batches():
+    """Re-sampled batches through ClipAdam (row-sparse weight_I update on the support's node flags): the same losses
+    and parameters as the slice path with per-batch plans."""
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.plan import GraphPlan
+    from mrgcn_amd.train import ClipAdam, categorical_crossentropy
+    import scipy.sparse as sp
+    from mrgcn_amd import synth
+    g = synth.make_graph("aifb", seed=1, scale=0.2)
+    N, R = g.num_nodes, g.num_relations
+    A = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
+    rng = np.random.default_rng(3)
+    steps, nb, K, C = 8, 24, 6, 4
+    idxs = [np.sort(rng.choice(N, nb, replace=False)) for _ in range(steps)]
+    ys = [torch.from_numpy(rng.integers(0, C, nb)).cuda() for _ in range(steps)]
+    X = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
+    dcsr = mb.DeviceCSR(A)
+    plan = GraphPlan.from_csr(A, N, R, value_mode="norm_f32")
+    rows = torch.arange(nb, device="cuda")
+
+    def run(masked):
+        torch.manual_seed(0)
+        model = RGCN([(K, 8, "mrgcn", torch.nn.ReLU()), (8, C, "mrgcn", None)], R, N, 3, 0.0, False, True, False).cuda()
+        opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+        losses = []
+        for k, i in enumerate(idxs):
+            ab = (mb.A_BatchMasked(plan, i, 2) if masked
+                  else mb.A_BatchDevice(dcsr, i, 2, value_mode="norm_f32", short_lived=True))
+            loss = categorical_crossentropy(model(X[ab.neighbours[-1]], ab), rows, ys[k])
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], {n: p.detach().cpu().numpy() for n, p in model.named_parameters()}
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-6)
+    for n in p0:
+        np.testing.assert_allclose(p1[n], p0[n], rtol=1e-4, atol=1e-6, err_msg=n)
+
+
 @pytest.mark.gpu
 def test_prefetched_batches_train_like_batches_built_in_line():
     """BatchPrefetcher (next batch + its slice plans built by a worker thread on its own stream, plans of finished

@@ -94,6 +94,47 @@ def minibatch():
         torch.cuda.synchronize()
         out["resampled_step_prefetched_ms"][f"workers={workers}"] = round((time.perf_counter() - t0) / (steps - warm) * 1e3, 2)
         pf.close()
+    # the batch as a masked pass over the FULL graph's plan (data.batch.A_BatchMasked, csrc/masked.hip): a re-sampled
+    # step = two support builds on the existing plan + forward / backward / clip / Adam on compact arrays; no slices, no
+    # per-batch plans, no worker threads
+    from mrgcn_amd.plan import GraphPlan
+    plan = GraphPlan.from_csr(A, N, R, value_mode="ref_int8", operand_row_bytes=model.operand_row_bytes())
+    mb_build, mb_step = [], []
+    for it in range(8):
+        idx = np.sort(rng.choice(N, 1024, replace=False))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        am = mb.A_BatchMasked(plan, idx, 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loss = categorical_crossentropy(model(X[am.neighbours[-1]], am), rows1024, ys)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if it >= 2:
+            mb_build.append((t1 - t0) * 1e3)
+            mb_step.append((t2 - t1) * 1e3)
+        am.close()
+    steps, warm = 24, 6
+    idxs = [np.sort(rng.choice(N, 1024, replace=False)) for _ in range(steps)]
+    for k, idx in enumerate(idxs):
+        if k == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        am = mb.A_BatchMasked(plan, idx, 2)
+        loss = categorical_crossentropy(model(X[am.neighbours[-1]], am), rows1024, ys)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    out["masked_pass"] = dict(
+        resampled_step_in_line_ms=round((time.perf_counter() - t0) / (steps - warm) * 1e3, 2),
+        support_builds_ms=round(float(np.median(mb_build)), 2), fwd_bwd_adam_ms=round(float(np.median(mb_step)), 2),
+        supports=[dict(rows=s_.NR, live_cols=s_.L, entries=s_.E, live_nodes=s_.NL) for s_ in am.supports],
+        note="every step on a fresh batch, nothing prepared ahead: the batch is a pair of forward supports on the full "
+             "graph's plan (data.batch.A_BatchMasked)")
     out.update(neighbours=sizes, batch_build_ms=round(float(np.median(t_build)), 2),
                plans_fwd_bwd_adam_ms=round(float(np.median(t_step)), 2),
                note="a re-sampled batch every step: structure on the device (batch_build_ms), then its lean slice plans "
@@ -229,13 +270,18 @@ def ingestion():
 
 
 def main():
+    import sys
     res = {"device": torch.cuda.get_device_name(0)}
+    only = set(sys.argv[1:])  # e.g. `next_rows_probe.py minibatch`
     for name, fn in (("minibatch", minibatch), ("encoders", encoders), ("mrgcn_with_encoders", mrgcn_epoch),
                      ("ingestion", ingestion)):
+        if only and name not in only:
+            continue
         try:
             res[name] = fn()
         except Exception as e:  # noqa: BLE001
-            res[name] = {"error": repr(e)[:300]}
+            import traceback
+            res[name] = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:]}
         torch.cuda.empty_cache()
     print(json.dumps(res, indent=1))
 
