@@ -400,6 +400,10 @@ int mrgcn_support_create(mrgcn_support_t **support, const mrgcn_plan_t *plan, co
 #define MRGCN_SUPPORT_FORWARD 1u
 int mrgcn_support_create_ex(mrgcn_support_t **support, const mrgcn_plan_t *plan, const uint8_t *row_flags,
                             uint32_t flags, void *stream);
+/* n supports at once: supports[0] on row_flags, supports[i+1] on NODE_FLAGS of supports[i] (the samples of the n layers
+ * of a mini-batch, batch.py:222-231).  One host wait for the whole chain.  rows = nodes (the stacked adjacency). */
+int mrgcn_support_create_chain(mrgcn_support_t **supports, int32_t n, const mrgcn_plan_t *plan,
+                               const uint8_t *row_flags, uint32_t flags, void *stream);
 int mrgcn_support_destroy(mrgcn_support_t *support);
 /* The same without waiting for the device, for a support that lived for one step (a mini-batch): the caller states
  * that every call that used the support was submitted to the stream it was created on (or is ordered before that
@@ -459,7 +463,9 @@ int mrgcn_softmax_xent_bwd_rows_f32(const float *drows, const int64_t *idx, int6
  *   rel_transform_fwd / _bwd_compact   T[k] = X[LNODE_ORD[k]] . W[LREL[k]] (graph.py:83-95) and its backward: dW
  *                  (nullable, written whole), dX [live_nodes, lddX] (nullable, every row written;
  *                  `relu_mask_from_x` as mrgcn_rel_transform_bwd_masked_f32); workspace:
- *                  mrgcn_support_rel_transform_bwd_workspace floats.  Shapes: mrgcn_support_rel_transform_supported
+ *                  mrgcn_support_rel_transform_bwd_workspace floats.  x_by_node != 0: X is the whole feature
+ *                  matrix, one row per NODE (the rows X[LNODE] are picked inside the transform instead of by a
+ *                  gather in front of it; dX stays by LNODE rank).  Shapes: mrgcn_support_rel_transform_supported
  *                  (need_dX: the input gradient is wanted too — inputs of up to 64 floats per row).
  * The weight_I gradient of the input term is mrgcn_support_mix_bwd_f32 / mrgcn_support_adam_rows_fused_f32 above
  * (dM by live number, V blocks by node id).  One product per support in flight. */
@@ -474,10 +480,11 @@ int mrgcn_support_mix_fwd_f32(const mrgcn_support_t *support, const float *V, co
 int mrgcn_support_literal_rows_f32(const mrgcn_support_t *support, int32_t scatter, float *table, int32_t F, float *M,
                                    int64_t ldM, void *stream);
 int32_t mrgcn_support_rel_transform_supported(const mrgcn_support_t *support, int32_t K, int32_t F, int32_t need_dX);
-int mrgcn_support_rel_transform_fwd_f32(const mrgcn_support_t *support, const float *X, int64_t ldX, int32_t K,
-                                        const float *W, int32_t F, float *T, int64_t ldT, void *stream);
+int mrgcn_support_rel_transform_fwd_f32(const mrgcn_support_t *support, const float *X, int64_t ldX, int32_t x_by_node,
+                                        int32_t K, const float *W, int32_t F, float *T, int64_t ldT, void *stream);
 int mrgcn_support_rel_transform_bwd_compact_f32(const mrgcn_support_t *support, const float *dM, int64_t ldM,
-                                                const float *X, int64_t ldX, int32_t K, const float *W, int32_t F,
+                                                const float *X, int64_t ldX, int32_t x_by_node, int32_t K,
+                                                const float *W, int32_t F,
                                                 float *dX, int64_t lddX, float *dW, float *workspace,
                                                 int64_t workspace_floats, int32_t relu_mask_from_x, void *stream);
 

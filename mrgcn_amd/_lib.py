@@ -149,6 +149,7 @@ SIGNATURES = {
     "mrgcn_wide_input_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "mrgcn_support_create": (C.c_int, [C.POINTER(_p), _p, _p, _p]),
     "mrgcn_support_create_ex": (C.c_int, [C.POINTER(_p), _p, _p, _u32, _p]),
+    "mrgcn_support_create_chain": (C.c_int, [C.POINTER(_p), _i32, _p, _p, _u32, _p]),
     "mrgcn_support_destroy": (C.c_int, [_p]),
     "mrgcn_support_destroy_ordered": (C.c_int, [_p]),
     "mrgcn_support_spmm_fwd_f32": (C.c_int, [_p, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _p]),
@@ -156,9 +157,9 @@ SIGNATURES = {
     "mrgcn_support_mix_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _i64, _p]),
     "mrgcn_support_literal_rows_f32": (C.c_int, [_p, _i32, _p, _i32, _p, _i64, _p]),
     "mrgcn_support_rel_transform_supported": (_i32, [_p, _i32, _i32, _i32]),
-    "mrgcn_support_rel_transform_fwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _i64, _p]),
-    "mrgcn_support_rel_transform_bwd_compact_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p,
-                                                              _i64, _i32, _p]),
+    "mrgcn_support_rel_transform_fwd_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _i32, _p, _i64, _p]),
+    "mrgcn_support_rel_transform_bwd_compact_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _i64, _p,
+                                                              _p, _i64, _i32, _p]),
     "mrgcn_support_info": (C.c_int, [_p, C.POINTER(SupportInfo)]),
     "mrgcn_support_array": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_i64)]),
     "mrgcn_support_spmm_t_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p]),

@@ -120,7 +120,8 @@ int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *
                 int64_t ldMask = 0, uint8_t *row_live = nullptr, const uint8_t *node_live = nullptr);
 // the same over explicit arrays (a gradient support's live columns: nptr = node -> range of Z rows)
 int segment_sum_arrays(const int32_t *nptr, int64_t num_nodes, int64_t nz_rows, const float *Z, int64_t ldZ, int K,
-                       float *dX, int64_t lddX, hipStream_t s, const float *mask_src, int64_t ldMask);
+                       float *dX, int64_t lddX, hipStream_t s, const float *mask_src, int64_t ldMask,
+                       int lane_max = 0);  // > 0: every node is live, a lane sums a node of up to lane_max rows itself
 
 // internal launchers shared with support.hip
 // Y = v . D on an arbitrary CSR-shaped view (spmm.hip); `partials`: v.n_chunks * kWsFeatures floats

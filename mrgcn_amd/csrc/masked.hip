@@ -97,8 +97,8 @@ int32_t mrgcn_support_rel_transform_supported(const mrgcn_support_t *q, int32_t 
           (!need_dX || xform_mfma_fwd_supported(F, K))) ? 1 : 0;
 }
 
-int mrgcn_support_rel_transform_fwd_f32(const mrgcn_support_t *q, const float *X, int64_t ldX, int32_t K,
-                                        const float *W, int32_t F, float *T, int64_t ldT, void *stream) {
+int mrgcn_support_rel_transform_fwd_f32(const mrgcn_support_t *q, const float *X, int64_t ldX, int32_t x_by_node,
+                                        int32_t K, const float *W, int32_t F, float *T, int64_t ldT, void *stream) {
   REQUIRE_FORWARD(q);
   MRGCN_REQUIRE(X && W && T, "NULL");
   MRGCN_REQUIRE(K > 0 && F > 0 && ldX >= K && ldT >= F, "K / F / leading dimensions");
@@ -106,14 +106,15 @@ int mrgcn_support_rel_transform_fwd_f32(const mrgcn_support_t *q, const float *X
     set_error("mrgcn_support_rel_transform_fwd_f32: shape outside the matrix-core transforms' limits");
     return MRGCN_ERR_UNSUPPORTED;
   }
-  const RelOrder o = q->order_for(K, true);
-  // row t of the order: input = X[rank of its node among the live nodes], output row = its live number
+  const RelOrder o = q->order_for(K, x_by_node == 0);
+  // row t of the order: input = X[rank of its node among the live nodes] (x_by_node: X[its node]), output row = its
+  // live number
   return xform_mfma_fwd(q->plan, o, o.rnode, nullptr, X, ldX, K, W, false, F, T, ldT, (hipStream_t)stream, false,
                         nullptr);
 }
 
 int mrgcn_support_rel_transform_bwd_compact_f32(const mrgcn_support_t *q, const float *dM, int64_t ldM, const float *X,
-                                                int64_t ldX, int32_t K, const float *W, int32_t F, float *dX,
+                                                int64_t ldX, int32_t x_by_node, int32_t K, const float *W, int32_t F, float *dX,
                                                 int64_t lddX, float *dW, float *workspace, int64_t workspace_floats,
                                                 int32_t relu_mask_from_x, void *stream) {
   REQUIRE_FORWARD(q);
@@ -126,9 +127,10 @@ int mrgcn_support_rel_transform_bwd_compact_f32(const mrgcn_support_t *q, const 
   }
   MRGCN_REQUIRE(workspace && workspace_floats >= need, "workspace (mrgcn_support_rel_transform_bwd_workspace floats)");
   MRGCN_REQUIRE(!relu_mask_from_x || (dX && K <= 16), "the masked dX needs K <= 16");
+  MRGCN_REQUIRE(!(relu_mask_from_x && x_by_node), "the masked dX reads X by live-node rank");
   hipStream_t s = (hipStream_t)stream;
   if (dW) {
-    const RelOrder o = q->order_for(K, true);
+    const RelOrder o = q->order_for(K, x_by_node == 0);
     int rc = xform_mfma_dw(q->plan, o, o.rnode, X, ldX, K, dM, ldM, F, dW, workspace, workspace_floats, s, nullptr);
     if (rc != MRGCN_OK) return rc;
   }
@@ -140,7 +142,7 @@ int mrgcn_support_rel_transform_bwd_compact_f32(const mrgcn_support_t *q, const 
                             false, nullptr);
     if (rc != MRGCN_OK) return rc;
     rc = segment_sum_arrays(q->lnptr, q->NL, q->L, workspace, ldZ, K, dX, lddX, s, relu_mask_from_x ? X : nullptr,
-                            ldX);
+                            ldX, 8);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;

@@ -309,6 +309,10 @@ __global__ void k_long_count(const int32_t *__restrict__ ptr, int64_t rows, int 
   const bool on = i < rows;   // (every lane stays for the shuffles below)
   int32_t len = on ? ptr[i + 1] - ptr[i] : 0;
   int32_t lg = len > thresh && (upper <= 0 || len <= upper);
+  if (i == rows) {  // the slot behind the last row: where the scans leave the totals
+    is_long[i] = 0;
+    nchunk[i] = 0;
+  }
   if (on) {
     is_long[i] = lg;
     if (blockwise) {
@@ -320,6 +324,7 @@ __global__ void k_long_count(const int32_t *__restrict__ ptr, int64_t rows, int 
   }
   // longest row: the wave's maximum by shuffles, and an atomic only if it beats what the word already holds (127 k
   // same-address atomics were 1.45 ms of the AM plan build)
+  if (!maxlen) return;  // (wave uniform: a caller that does not ask)
   int32_t m = len;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, kWave));
@@ -526,7 +531,20 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
                int32_t **long_cptr, int32_t **chunk_beg, int32_t **chunk_end, int32_t **chunk_row,
                int32_t *n_long,
                int32_t *n_chunks, int64_t *max_len, int threshold = kLongThreshold, int chunk = kChunk,
-               int cap = 0, int upper = 0, int blockwise = 0) {
+               int cap = 0, int upper = 0, int blockwise = 0, const int32_t *known = nullptr) {
+  if (known && known[0] == 0) {  // no long row (counted by the caller): the arrays keep one element each
+    *n_long = 0;
+    *n_chunks = 0;
+    *max_len = 0;
+    MRGCN_HIP_TRY(plan_alloc(p, long_row, 0));
+    MRGCN_HIP_TRY(plan_alloc(p, long_cptr, 1));
+    MRGCN_HIP_TRY(plan_alloc(p, chunk_beg, 0));
+    MRGCN_HIP_TRY(plan_alloc(p, chunk_end, 0));
+    MRGCN_HIP_TRY(plan_alloc(p, chunk_row, 0));
+    k_fill_i32<<<1, 1, 0, s>>>(*long_cptr, 1, 0);
+    MRGCN_HIP_TRY(hipGetLastError());
+    return MRGCN_OK;
+  }
   Scratch sc;
   sc.s = s;
   int32_t *is_long, *nchunk, *long_pos, *chunk_pos, *d_max;
@@ -535,20 +553,23 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(sc.alloc(&long_pos, rows + 1));
   MRGCN_HIP_TRY(sc.alloc(&chunk_pos, rows + 1));
   MRGCN_HIP_TRY(sc.alloc(&d_max, 1));
-  MRGCN_HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
-  MRGCN_HIP_TRY(hipMemsetAsync(is_long, 0, (rows + 1) * sizeof(int32_t), s));
-  MRGCN_HIP_TRY(hipMemsetAsync(nchunk, 0, (rows + 1) * sizeof(int32_t), s));
-  if (rows > 0)
-    k_long_count<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, threshold, upper, chunk, cap, blockwise, is_long, nchunk, d_max);
+  if (!known) MRGCN_HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
+  k_long_count<<<nblocks(rows + 1), kTB, 0, s>>>(ptr, rows, threshold, upper, chunk, cap, blockwise, is_long, nchunk,
+                                                 known ? nullptr : d_max);
   // scan over rows+1 elements so that position [rows] holds the totals
   int rc;
   if ((rc = exclusive_scan_i32(is_long, long_pos, rows + 1, s, sc))) return rc;
   if ((rc = exclusive_scan_i32(nchunk, chunk_pos, rows + 1, s, sc))) return rc;
-  int32_t h[3];
-  MRGCN_HIP_TRY(hipMemcpyAsync(&h[0], long_pos + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MRGCN_HIP_TRY(hipMemcpyAsync(&h[1], chunk_pos + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MRGCN_HIP_TRY(hipMemcpyAsync(&h[2], d_max, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  int32_t h[3] = {0, 0, 0};
+  if (known) {  // the caller counted already (a gradient support's build): no wait, max_len stays unknown
+    h[0] = known[0];
+    h[1] = known[1];
+  } else {
+    MRGCN_HIP_TRY(hipMemcpyAsync(&h[0], long_pos + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MRGCN_HIP_TRY(hipMemcpyAsync(&h[1], chunk_pos + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MRGCN_HIP_TRY(hipMemcpyAsync(&h[2], d_max, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  }
   *n_long = h[0];
   *n_chunks = h[1];
   *max_len = h[2];
@@ -1131,62 +1152,12 @@ int free_plan_after(mrgcn_plan *p, hipEvent_t ev) {
 // ---------------------------------------------------------------------------------------------
 // Gradient support (common.hpp: mrgcn_support): one-off build per (plan, set of live output rows)
 // ---------------------------------------------------------------------------------------------
-// compact columns touched by a live row: one thread per row finds the live ones, the wave walks their entries
-__global__ void k_sup_mark_cols(const uint8_t *__restrict__ row_flags, int64_t nrows, const int32_t *__restrict__ rowptr,
-                                const int32_t *__restrict__ ccol, uint8_t *__restrict__ col_flags) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const bool nz = i < nrows && row_flags[i] != 0;
-  int32_t b = 0, n = 0;
-  if (nz) {
-    b = rowptr[i];
-    n = rowptr[i + 1] - b;
-  }
-  uint64_t todo = __ballot(nz);
-  while (todo) {
-    const int L = __ffsll((unsigned long long)todo) - 1;
-    todo &= todo - 1;
-    const int32_t bb = __shfl(b, L, kWave), nn = __shfl(n, L, kWave);
-    for (int32_t e = lane; e < nn; e += kWave) col_flags[ccol[bb + e]] = 1;  // (same value from every writer)
-  }
-}
 // out[i] = flags[idx ? idx[i] : i] != 0 for i < n, out[n] = 0 (so that an exclusive scan over n + 1 ends in the total)
 __global__ void k_sup_flags_i32(const uint8_t *__restrict__ flags, const int32_t *__restrict__ idx, int64_t n,
                                 int32_t *__restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = flags[idx ? idx[i] : i] != 0;
   else if (i == n) out[i] = 0;
-}
-// per live column: its number, relation and how many of its entries sit in live rows
-__global__ void k_sup_cols(const uint8_t *__restrict__ col_flags, const int32_t *__restrict__ lpos, int64_t ncols,
-                           const int32_t *__restrict__ urel, const int32_t *__restrict__ cptr,
-                           const int32_t *__restrict__ crow, const uint8_t *__restrict__ row_flags,
-                           int32_t *__restrict__ lcol, int32_t *__restrict__ lrel, int32_t *__restrict__ cnt) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols || !col_flags[c]) return;
-  const int32_t k = lpos[c];
-  lcol[k] = (int32_t)c;
-  lrel[k] = urel[c];
-  int32_t n = 0;
-  for (int32_t e = cptr[c]; e < cptr[c + 1]; ++e) n += row_flags[crow[e]] != 0;
-  cnt[k] = n;
-}
-__global__ void k_sup_entries(const int32_t *__restrict__ lcol, const int32_t *__restrict__ lptr, int64_t L,
-                              const int32_t *__restrict__ cptr, const int32_t *__restrict__ crow,
-                              const float *__restrict__ cval, const uint8_t *__restrict__ row_flags,
-                              int32_t *__restrict__ lrow, float *__restrict__ lval) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= L) return;
-  const int32_t c = lcol[k];
-  int32_t o = lptr[k];
-  for (int32_t e = cptr[c]; e < cptr[c + 1]; ++e) {  // the plan's entry order is kept
-    const int32_t i = crow[e];
-    if (row_flags[i]) {
-      lrow[o] = i;
-      lval[o] = cval[e];
-      ++o;
-    }
-  }
 }
 // the compact columns of a node are contiguous, so are its live ones: nlptr[j] = lpos[nptr[j]]
 __global__ void k_sup_nodes(const int32_t *__restrict__ nptr, const int32_t *__restrict__ lpos, int64_t N,
@@ -1283,40 +1254,6 @@ int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t *
 
 namespace {
 
-// forward arrays of a support: rank of every row among the flagged ones (-1 elsewhere) and the flagged rows' lengths
-__global__ void k_sup_rowrank(const uint8_t *__restrict__ row_flags, const int32_t *__restrict__ rpos, int64_t rows,
-                              const int32_t *__restrict__ rowptr, int32_t *__restrict__ rowrank,
-                              int32_t *__restrict__ frow, int32_t *__restrict__ flen) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
-  const bool on = row_flags[i] != 0;
-  rowrank[i] = on ? rpos[i] : -1;
-  if (on) {
-    frow[rpos[i]] = (int32_t)i;
-    flen[rpos[i]] = rowptr[i + 1] - rowptr[i];
-  }
-}
-// a wave per flagged row copies its entries (plan order), columns renumbered to live numbers
-__global__ void k_sup_fwd_entries(const int32_t *__restrict__ frow, const int32_t *__restrict__ fptr, int64_t NR,
-                                  const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ccol,
-                                  const float *__restrict__ val, const int32_t *__restrict__ lpos,
-                                  int32_t *__restrict__ fcol, float *__restrict__ fval) {
-  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-  const int lane = threadIdx.x & 63;
-  if (q >= NR) return;
-  const int32_t i = frow[q], b = rowptr[i], n = rowptr[i + 1] - b, o = fptr[q];
-  for (int32_t e = lane; e < n; e += kWave) {
-    fcol[o + e] = lpos[ccol[b + e]];
-    fval[o + e] = val[b + e];
-  }
-}
-__global__ void k_sup_rank_entries(const int32_t *__restrict__ lrow, const int32_t *__restrict__ rowrank, int64_t E,
-                                   int32_t *__restrict__ lrow_rank, float *__restrict__ ones) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  lrow_rank[e] = rowrank[lrow[e]];
-  ones[e] = 1.f;
-}
 // out[k] = npos[node[k]] (rank of a node among the live nodes)
 __global__ void k_sup_node_ord(const int32_t *__restrict__ node, const int32_t *__restrict__ idx,
                                const int32_t *__restrict__ npos, int64_t n, int32_t *__restrict__ out) {
@@ -1334,31 +1271,264 @@ template <typename T> hipError_t sup_alloc(mrgcn_support *q, T **dst, int64_t n)
   return e;
 }
 
-int build_support_order(mrgcn_support *q, Scratch &sc, hipStream_t s, const int32_t *lpos, const int32_t *rperm,
-                        const int32_t *rnode, const int32_t *relptr, int64_t nbands, mrgcn_support::Order *out,
-                        const int32_t *npos = nullptr) {
-  const mrgcn_plan *p = q->plan;
-  const int64_t ncols = p->ncols, R = p->num_relations, ngroups = nbands * R;
-  int32_t *rflag, *rpos, *gptr;
-  MRGCN_HIP_TRY(sc.alloc(&rflag, ncols + 1));
-  MRGCN_HIP_TRY(sc.alloc(&rpos, ncols + 1));
-  MRGCN_HIP_TRY(sc.alloc(&gptr, ngroups + 1));
-  k_sup_flags_i32<<<nblocks(ncols + 1), kTB, 0, s>>>(q->col_flags, rperm, ncols, rflag);
+// ---- the build in two stages with ONE host wait between them -------------------------------------------------------
+// Stage 1 needs nothing from the host: flags, scans and counts leave every size the arrays of stage 2 need — live
+// columns / kept entries / live nodes / flagged rows, the split-row totals of both views, the live columns per (band,
+// relation) group of both orders — in one small block that is copied to pinned host memory.  The row set of the next
+// support of a chain (a mini-batch's next layer) is this one's NODE_FLAGS, on the device after stage 1: a chain queues
+// every level's stage 1, waits once, and runs every stage 2.
+// Work is proportional to the entries of the FLAGGED ROWS (E) plus a few passes over the plan's columns / nodes / rows:
+// the entries are walked row-major (the flagged rows' CSR ranges), the kept entries per column come from a histogram,
+// and the transposed arrays from one stable radix sort of the E (live column, entry) pairs — rows keep rising inside a
+// column, the plan's own entry order.  (Going through the live COLUMNS instead walks every entry of a hub column —
+// rdf:type with 10^5 entries is live for almost any sample: 0.2-0.4 ms per pass at the AM/4 shape; and the
+// one-array-at-a-time build before that waited eight times per support: 3.2 ms for a mini-batch level.)
+struct SupStage {
+  mrgcn_support *q = nullptr;
+  const uint8_t *row_flags = nullptr;
+  bool forward = false;
+  Scratch sc;
+  int32_t *lpos = nullptr, *ckept = nullptr, *nflag = nullptr, *npos = nullptr;
+  int32_t *rpos_rows = nullptr;
+  struct Ord { int32_t *rflag = nullptr, *rpos = nullptr, *gptr = nullptr; int64_t ngroups = 0; } ow, on;
+  int32_t *totals_d = nullptr;
+  int64_t land_off = 0;  // this level's block in the pinned landing area (ints): totals[16] | gptr wide | gptr narrow
+  int32_t *blk = nullptr;  // the orders' chunk lists on the device, at these offsets
+  size_t offs_w[5] = {0, 0, 0, 0, 0}, offs_n[5] = {0, 0, 0, 0, 0};
+};
+enum { kTotL = 0, kTotE, kTotNL, kTotNR, kTotTLong, kTotTChunks, kTotFLong, kTotFChunks, kTotCount = 16 };
+
+// per row: flag as an int, entries if flagged (position rows: 0), and the split-row totals of the forward view
+__global__ void k_sup_rowcount(const uint8_t *__restrict__ row_flags, int64_t rows, const int32_t *__restrict__ rowptr,
+                               int thresh, int chunk, int32_t *__restrict__ rflag, int32_t *__restrict__ rlen,
+                               int32_t *__restrict__ totals) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool on = i < rows && row_flags[i] != 0;
+  const int32_t len = on ? rowptr[i + 1] - rowptr[i] : 0;
+  if (i <= rows) {
+    rflag[i] = on;
+    rlen[i] = len;
+  }
+  const bool lg = len > thresh;
+  const int32_t nlong = __popcll(__ballot(lg));
+  int32_t nch = lg ? (len + chunk - 1) / chunk : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nch += __shfl_xor(nch, o, kWave);
+  if (lane == 0 && nlong > 0) {
+    atomicAdd(&totals[kTotFLong], nlong);
+    atomicAdd(&totals[kTotFChunks], nch);
+  }
+}
+// compact list of the flagged rows (arrays sized for every row): rank / id / entry range
+__global__ void k_sup_rows2(const uint8_t *__restrict__ row_flags, const int32_t *__restrict__ rpos, int64_t rows,
+                            const int32_t *__restrict__ funp, int32_t *__restrict__ rowrank,
+                            int32_t *__restrict__ frow, int32_t *__restrict__ fptr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > rows) return;
+  if (i == rows) { fptr[rpos[i]] = funp[i]; return; }
+  const bool on = row_flags[i] != 0;
+  rowrank[i] = on ? rpos[i] : -1;
+  if (on) {
+    frow[rpos[i]] = (int32_t)i;
+    fptr[rpos[i]] = funp[i];
+  }
+}
+// the flagged row (by rank) of forward entry t: one search per wave for its first entry, then a short walk per lane
+__device__ __forceinline__ int32_t sup_row_of(const int32_t *__restrict__ fptr, int32_t NR, int32_t t, int32_t t_wave0) {
+  int32_t lo = 0, hi = NR;  // last q with fptr[q] <= t_wave0
+  while (hi - lo > 1) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (fptr[mid] <= t_wave0) lo = mid; else hi = mid;
+  }
+  int32_t q = lo;
+  while (q + 1 < NR && fptr[q + 1] <= t) ++q;
+  return q;
+}
+// stage 1, over the forward entries (count and rows read from device memory: grid-stride): marks the touched columns
+// and counts the kept entries of each
+__global__ void k_sup_fwd_mark(const int32_t *__restrict__ frow, const int32_t *__restrict__ fptr,
+                               const int32_t *__restrict__ rpos_rows, int64_t rows, const int32_t *__restrict__ rowptr,
+                               const int32_t *__restrict__ ccol, uint8_t *__restrict__ col_flags,
+                               int32_t *__restrict__ ccnt) {
+  const int32_t NR = rpos_rows[rows];
+  if (NR == 0) return;
+  const int32_t E = fptr[NR];
+  const int lane = threadIdx.x & 63;
+  for (int64_t t0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; t0 < E; t0 += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t t = (int32_t)t0 + lane;
+    if (t >= E) continue;
+    const int32_t qr = sup_row_of(fptr, NR, t, (int32_t)t0);
+    const int32_t c = ccol[rowptr[frow[qr]] + (t - fptr[qr])];
+    col_flags[c] = 1;  // (same value from every writer)
+    atomicAdd(&ccnt[c], 1);
+  }
+}
+// per column: flag as an int (position ncols: 0) and the split-row totals of the transposed view from the kept counts
+__global__ void k_sup_colflags(const uint8_t *__restrict__ col_flags, const int32_t *__restrict__ ccnt, int64_t ncols,
+                               int thresh, int chunk, int32_t *__restrict__ cflag, int32_t *__restrict__ totals) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int32_t cnt = c < ncols ? ccnt[c] : 0;
+  if (c <= ncols) cflag[c] = c < ncols && col_flags[c] != 0;
+  const bool lg = cnt > thresh;
+  const int32_t nlong = __popcll(__ballot(lg));
+  int32_t nch = lg ? (cnt + chunk - 1) / chunk : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nch += __shfl_xor(nch, o, kWave);
+  if (lane == 0 && nlong > 0) {
+    atomicAdd(&totals[kTotTLong], nlong);
+    atomicAdd(&totals[kTotTChunks], nch);
+  }
+}
+__global__ void k_sup_totals(const int32_t *__restrict__ lpos, int64_t ncols, const int32_t *__restrict__ ckept,
+                             const int32_t *__restrict__ npos, int64_t N, const int32_t *__restrict__ rpos_rows,
+                             int64_t rows, int32_t *__restrict__ totals) {
+  totals[kTotL] = lpos[ncols];
+  totals[kTotE] = ckept[ncols];
+  totals[kTotNL] = npos[N];
+  totals[kTotNR] = rpos_rows[rows];
+}
+// stage 2: number, relation and entry range of every live column (ckept: exclusive kept-entry offsets by column)
+__global__ void k_sup_cols2(const uint8_t *__restrict__ col_flags, const int32_t *__restrict__ lpos, int64_t ncols,
+                            const int32_t *__restrict__ urel, const int32_t *__restrict__ ckept,
+                            int32_t *__restrict__ lcol, int32_t *__restrict__ lrel, int32_t *__restrict__ lptr) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > ncols) return;
+  if (c == ncols) { lptr[lpos[c]] = ckept[c]; return; }
+  if (!col_flags[c]) return;
+  const int32_t k = lpos[c];
+  lcol[k] = (int32_t)c;
+  lrel[k] = urel[c];
+  lptr[k] = ckept[c];
+}
+// stage 2, over the forward entries: live number of the column, value, rank of the row; the entry's own index as the
+// payload of the transposing sort
+__global__ void k_sup_fwd_fill(const int32_t *__restrict__ frow, const int32_t *__restrict__ fptr, int32_t NR, int32_t E,
+                               const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ccol,
+                               const float *__restrict__ val, const int32_t *__restrict__ lpos,
+                               int32_t *__restrict__ fcol, float *__restrict__ fval, int32_t *__restrict__ frank,
+                               int32_t *__restrict__ ident, float *__restrict__ ones) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
+  const int32_t t = (int32_t)t0 + lane;
+  if (t0 >= E || t >= E) return;
+  const int32_t qr = sup_row_of(fptr, NR, t, (int32_t)t0);
+  const int32_t src = rowptr[frow[qr]] + (t - fptr[qr]);
+  fcol[t] = lpos[ccol[src]];
+  fval[t] = val[src];
+  frank[t] = qr;
+  ident[t] = t;
+  if (ones) ones[t] = 1.f;
+}
+// the transposed arrays from the sorted (live column, forward entry) pairs
+__global__ void k_sup_t_fill(const int32_t *__restrict__ perm, int32_t E, const int32_t *__restrict__ frank,
+                             const int32_t *__restrict__ frow, const float *__restrict__ fval,
+                             int32_t *__restrict__ lrow, int32_t *__restrict__ lrow_rank, float *__restrict__ lval) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= E) return;
+  const int32_t t = perm[o], qr = frank[t];
+  lrow[o] = frow[qr];
+  if (lrow_rank) lrow_rank[o] = qr;
+  lval[o] = fval[t];
+}
+
+// pinned landing area of the builds' size blocks (grow-only; a build holds g_land_mu from its first copy to its wait)
+int32_t *g_land = nullptr;
+size_t g_land_ints = 0;
+std::mutex g_land_mu;
+
+int stage1_order(SupStage &b, hipStream_t s, const int32_t *rperm, const int32_t *relptr, int64_t nbands,
+                 SupStage::Ord *o) {
+  const mrgcn_plan *p = b.q->plan;
+  const int64_t ncols = p->ncols;
+  o->ngroups = nbands * p->num_relations;
+  MRGCN_HIP_TRY(b.sc.alloc(&o->rflag, ncols + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&o->rpos, ncols + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&o->gptr, o->ngroups + 1));
+  k_sup_flags_i32<<<nblocks(ncols + 1), kTB, 0, s>>>(b.q->col_flags, rperm, ncols, o->rflag);
   MRGCN_HIP_TRY(hipGetLastError());
   int rc;
-  if ((rc = exclusive_scan_i32(rflag, rpos, ncols + 1, s, sc))) return rc;
-  MRGCN_HIP_TRY(sup_alloc(q, &out->lperm, q->L));
-  MRGCN_HIP_TRY(sup_alloc(q, &out->lrin, q->L));
-  if (ncols > 0) k_sup_rfill<<<nblocks(ncols), kTB, 0, s>>>(rperm, rnode, rflag, rpos, ncols, lpos, out->lperm, out->lrin);
-  if (npos) {  // (forward arrays: the same list by rank among the live nodes)
-    MRGCN_HIP_TRY(sup_alloc(q, &out->lrin_ord, q->L));
-    if (q->L > 0) k_sup_node_ord<<<nblocks(q->L), kTB, 0, s>>>(out->lrin, nullptr, npos, q->L, out->lrin_ord);
-  }
-  k_gather_i32<<<nblocks(ngroups + 1), kTB, 0, s>>>(rpos, relptr, ngroups + 1, gptr);
+  if ((rc = exclusive_scan_i32(o->rflag, o->rpos, ncols + 1, s, b.sc))) return rc;
+  k_gather_i32<<<nblocks(o->ngroups + 1), kTB, 0, s>>>(o->rpos, relptr, o->ngroups + 1, o->gptr);
   MRGCN_HIP_TRY(hipGetLastError());
-  std::vector<int32_t> h_gptr(ngroups + 1);
-  MRGCN_HIP_TRY(hipMemcpyAsync(h_gptr.data(), gptr, (ngroups + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MRGCN_HIP_TRY(hipStreamSynchronize(s));
+  return MRGCN_OK;
+}
+
+int64_t stage_land_ints(const mrgcn_plan *p) {
+  const int64_t R = p->num_relations;
+  return kTotCount + (p->n_bands * R + 1) + (p->n_rperm ? p->n_n_bands * R + 1 : 0);
+}
+
+int support_stage1(SupStage &b, hipStream_t s) {
+  mrgcn_support *q = b.q;
+  const mrgcn_plan *p = q->plan;
+  const int64_t N = p->num_nodes, ncols = p->ncols, rows = p->num_rows;
+  b.sc.s = s;
+  MRGCN_HIP_TRY(sup_alloc(q, &q->col_flags, ncols));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->node_flags, N));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->nlptr, N + 1));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->node_scratch, N));
+  // (the flagged rows' list is at most every row: these three are sized for that, no host count needed)
+  MRGCN_HIP_TRY(sup_alloc(q, &q->rowrank, rows));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->frow, rows));
+  MRGCN_HIP_TRY(sup_alloc(q, &q->fptr, rows + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&b.totals_d, kTotCount));
+  int32_t *rflag, *rlen, *funp, *cflag, *ccnt;
+  MRGCN_HIP_TRY(b.sc.alloc(&rflag, rows + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&rlen, rows + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&b.rpos_rows, rows + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&funp, rows + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&cflag, ncols + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&b.lpos, ncols + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&ccnt, ncols + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&b.ckept, ncols + 1));
+  MRGCN_HIP_TRY(hipMemsetAsync(b.totals_d, 0, kTotCount * sizeof(int32_t), s));
+  MRGCN_HIP_TRY(hipMemsetAsync(q->col_flags, 0, (size_t)std::max<int64_t>(ncols, 1), s));
+  MRGCN_HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(ncols + 1) * sizeof(int32_t), s));
+  int rc;
+  // the flagged rows and their entry ranges
+  k_sup_rowcount<<<nblocks(rows + 1), kTB, 0, s>>>(b.row_flags, rows, p->rowptr, kLongThreshold, kChunk, rflag, rlen,
+                                                  b.totals_d);
+  MRGCN_HIP_TRY(hipGetLastError());
+  if ((rc = exclusive_scan_i32(rflag, b.rpos_rows, rows + 1, s, b.sc))) return rc;
+  if ((rc = exclusive_scan_i32(rlen, funp, rows + 1, s, b.sc))) return rc;
+  k_sup_rows2<<<nblocks(rows + 1), kTB, 0, s>>>(b.row_flags, b.rpos_rows, rows, funp, q->rowrank, q->frow, q->fptr);
+  // touched columns and their kept entries
+  if (ncols > 0 && p->nnz > 0) {
+    int64_t grid = (p->nnz + kTB - 1) / kTB;
+    if (grid > 2048) grid = 2048;
+    k_sup_fwd_mark<<<dim3((unsigned)grid), kTB, 0, s>>>(q->frow, q->fptr, b.rpos_rows, rows, p->rowptr, p->ccol,
+                                                       q->col_flags, ccnt);
+  }
+  k_sup_colflags<<<nblocks(ncols + 1), kTB, 0, s>>>(q->col_flags, ccnt, ncols, kLongThreshold, kChunk, cflag, b.totals_d);
+  MRGCN_HIP_TRY(hipGetLastError());
+  if ((rc = exclusive_scan_i32(cflag, b.lpos, ncols + 1, s, b.sc))) return rc;
+  if ((rc = exclusive_scan_i32(ccnt, b.ckept, ncols + 1, s, b.sc))) return rc;
+  // nodes (NODE_FLAGS: the row set of the next support of a chain)
+  MRGCN_HIP_TRY(b.sc.alloc(&b.nflag, N + 1));
+  MRGCN_HIP_TRY(b.sc.alloc(&b.npos, N + 1));
+  k_sup_nodes<<<nblocks(N + 1), kTB, 0, s>>>(p->nptr, b.lpos, N, q->nlptr, q->node_flags, b.nflag);
+  MRGCN_HIP_TRY(hipGetLastError());
+  if ((rc = exclusive_scan_i32(b.nflag, b.npos, N + 1, s, b.sc))) return rc;
+  k_sup_totals<<<1, 1, 0, s>>>(b.lpos, ncols, b.ckept, b.npos, N, b.rpos_rows, rows, b.totals_d);
+  MRGCN_HIP_TRY(hipGetLastError());
+  if ((rc = stage1_order(b, s, p->rperm, p->relptr, p->n_bands, &b.ow))) return rc;
+  q->has_narrow = p->n_rperm != nullptr;
+  if (q->has_narrow && (rc = stage1_order(b, s, p->n_rperm, p->n_relptr, p->n_n_bands, &b.on))) return rc;
+  // the size block -> pinned host memory
+  int32_t *land = g_land + b.land_off;
+  MRGCN_HIP_TRY(hipMemcpyAsync(land, b.totals_d, kTotCount * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MRGCN_HIP_TRY(hipMemcpyAsync(land + kTotCount, b.ow.gptr, (b.ow.ngroups + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (q->has_narrow)
+    MRGCN_HIP_TRY(hipMemcpyAsync(land + kTotCount + b.ow.ngroups + 1, b.on.gptr, (b.on.ngroups + 1) * sizeof(int32_t),
+                                 hipMemcpyDeviceToHost, s));
+  return MRGCN_OK;
+}
+
+// the chunk lists of one order from its group pointers (host), appended to `up` as chunk_ptr[R+1] | ids | rel | beg | end
+void order_chunks_host(const int32_t *h_gptr, int64_t ngroups, int64_t R, mrgcn_support::Order *out,
+                       std::vector<int32_t> *up, size_t offs[5]) {
   std::vector<int32_t> rel, beg, end, ids_by_rel, cptr_rel(R + 1, 0);
   std::vector<std::vector<int32_t>> by_rel(R);
   for (int64_t g = 0; g < ngroups; ++g) {
@@ -1378,151 +1548,169 @@ int build_support_order(mrgcn_support *q, Scratch &sc, hipStream_t s, const int3
   }
   cptr_rel[R] = (int32_t)ids_by_rel.size();
   out->n_chunks = (int32_t)rel.size();
-  MRGCN_HIP_TRY(sup_alloc(q, &out->chunk_ptr, R + 1));
-  MRGCN_HIP_TRY(hipMemcpy(out->chunk_ptr, cptr_rel.data(), (R + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-  MRGCN_HIP_TRY(sup_alloc(q, &out->chunk_ids, out->n_chunks));
-  MRGCN_HIP_TRY(sup_alloc(q, &out->chunk_rel, out->n_chunks));
-  MRGCN_HIP_TRY(sup_alloc(q, &out->chunk_beg, out->n_chunks));
-  MRGCN_HIP_TRY(sup_alloc(q, &out->chunk_end, out->n_chunks));
-  if (out->n_chunks > 0) {
-    const size_t nb = rel.size() * sizeof(int32_t);
-    MRGCN_HIP_TRY(hipMemcpy(out->chunk_ids, ids_by_rel.data(), nb, hipMemcpyHostToDevice));
-    MRGCN_HIP_TRY(hipMemcpy(out->chunk_rel, rel.data(), nb, hipMemcpyHostToDevice));
-    MRGCN_HIP_TRY(hipMemcpy(out->chunk_beg, beg.data(), nb, hipMemcpyHostToDevice));
-    MRGCN_HIP_TRY(hipMemcpy(out->chunk_end, end.data(), nb, hipMemcpyHostToDevice));
+  const std::vector<int32_t> *parts[5] = {&cptr_rel, &ids_by_rel, &rel, &beg, &end};
+  for (int i = 0; i < 5; ++i) {
+    offs[i] = up->size();
+    up->insert(up->end(), parts[i]->begin(), parts[i]->end());
+    if (parts[i]->empty()) up->push_back(0);  // (every array keeps at least one element)
   }
+}
+
+int stage2_order(SupStage &b, hipStream_t s, const SupStage::Ord &o, const int32_t *rperm, const int32_t *rnode,
+                 const int32_t *blk, const size_t *offs, mrgcn_support::Order *out) {
+  mrgcn_support *q = b.q;
+  const int64_t ncols = q->plan->ncols;
+  out->chunk_ptr = const_cast<int32_t *>(blk) + offs[0];
+  out->chunk_ids = const_cast<int32_t *>(blk) + offs[1];
+  out->chunk_rel = const_cast<int32_t *>(blk) + offs[2];
+  out->chunk_beg = const_cast<int32_t *>(blk) + offs[3];
+  out->chunk_end = const_cast<int32_t *>(blk) + offs[4];
+  MRGCN_HIP_TRY(sup_alloc(q, &out->lperm, q->L));
+  MRGCN_HIP_TRY(sup_alloc(q, &out->lrin, q->L));
+  if (ncols > 0)
+    k_sup_rfill<<<nblocks(ncols), kTB, 0, s>>>(rperm, rnode, o.rflag, o.rpos, ncols, b.lpos, out->lperm, out->lrin);
+  if (b.forward) {  // (forward arrays: the same list by rank among the live nodes)
+    MRGCN_HIP_TRY(sup_alloc(q, &out->lrin_ord, q->L));
+    if (q->L > 0) k_sup_node_ord<<<nblocks(q->L), kTB, 0, s>>>(out->lrin, nullptr, b.npos, q->L, out->lrin_ord);
+  }
+  MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
 
-int build_support(mrgcn_support *q, const uint8_t *row_flags, hipStream_t s, bool forward) {
+int long_rows_known(mrgcn_support *q, const int32_t *ptr, int64_t rows, hipStream_t s, int32_t n_long, int32_t n_chunks,
+                    int32_t **long_row, int32_t **long_cptr, int32_t **chunk_beg, int32_t **chunk_end,
+                    int32_t **chunk_row) {
+  mrgcn_plan acct;  // build_long charges its arrays to a plan: this one only carries the stream and the byte count
+  acct.build_stream = s;
+  const int32_t known[2] = {n_long, n_chunks};
+  int32_t nl = 0, nc = 0;
+  int64_t max_len = 0;
+  int rc = build_long(&acct, ptr, rows, s, long_row, long_cptr, chunk_beg, chunk_end, chunk_row, &nl, &nc, &max_len,
+                      kLongThreshold, kChunk, 0, 0, 0, known);
+  for (void *a : {(void *)*long_row, (void *)*long_cptr, (void *)*chunk_beg, (void *)*chunk_end, (void *)*chunk_row})
+    if (a) q->owned.push_back(a);
+  q->device_bytes += acct.device_bytes;
+  return rc;
+}
+
+// the orders' chunk lists: host work on the landed group pointers + one upload per support, all of them before any
+// stage-2 kernel is queued (the device is idle after the wait: the blocking copies cost their latency only)
+int support_upload(SupStage &b) {
+  mrgcn_support *q = b.q;
+  const int64_t R = q->plan->num_relations;
+  const int32_t *land = g_land + b.land_off;
+  std::vector<int32_t> up;
+  order_chunks_host(land + kTotCount, b.ow.ngroups, R, &q->wide, &up, b.offs_w);
+  if (q->has_narrow) order_chunks_host(land + kTotCount + b.ow.ngroups + 1, b.on.ngroups, R, &q->narrow, &up, b.offs_n);
+  MRGCN_HIP_TRY(sup_alloc(q, &b.blk, (int64_t)up.size()));
+  MRGCN_HIP_TRY(hipMemcpy(b.blk, up.data(), up.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  return MRGCN_OK;
+}
+
+// a template for the forward-only arrays: owned by the support when it keeps them, scratch of the build otherwise
+template <typename T> hipError_t stage_alloc(SupStage &b, bool keep, T **dst, int64_t n) {
+  return keep ? sup_alloc(b.q, dst, n) : b.sc.alloc(dst, n);
+}
+
+int support_stage2(SupStage &b, hipStream_t s) {
+  mrgcn_support *q = b.q;
   const mrgcn_plan *p = q->plan;
-  const int64_t N = p->num_nodes, ncols = p->ncols, rows = p->num_rows;
-  Scratch sc;
-  sc.s = s;
-  MRGCN_HIP_TRY(sup_alloc(q, &q->col_flags, ncols));
-  MRGCN_HIP_TRY(sup_alloc(q, &q->node_flags, N));
-  MRGCN_HIP_TRY(sup_alloc(q, &q->nlptr, N + 1));
-  MRGCN_HIP_TRY(sup_alloc(q, &q->node_scratch, N));
-  MRGCN_HIP_TRY(hipMemsetAsync(q->col_flags, 0, (size_t)std::max<int64_t>(ncols, 1), s));
-  if (rows > 0 && ncols > 0) k_sup_mark_cols<<<nblocks(rows), kTB, 0, s>>>(row_flags, rows, p->rowptr, p->ccol, q->col_flags);
-  MRGCN_HIP_TRY(hipGetLastError());
-  int32_t *cflag, *lpos;
-  MRGCN_HIP_TRY(sc.alloc(&cflag, ncols + 1));
-  MRGCN_HIP_TRY(sc.alloc(&lpos, ncols + 1));
-  k_sup_flags_i32<<<nblocks(ncols + 1), kTB, 0, s>>>(q->col_flags, nullptr, ncols, cflag);
-  MRGCN_HIP_TRY(hipGetLastError());
-  int rc;
-  if ((rc = exclusive_scan_i32(cflag, lpos, ncols + 1, s, sc))) return rc;
-  int32_t hL = 0;
-  MRGCN_HIP_TRY(hipMemcpyAsync(&hL, lpos + ncols, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MRGCN_HIP_TRY(hipStreamSynchronize(s));
-  q->L = hL;
+  const int64_t N = p->num_nodes, ncols = p->ncols;
+  const int32_t *land = g_land + b.land_off;
+  const int32_t *blk = b.blk;
+  const size_t *offs_w = b.offs_w, *offs_n = b.offs_n;
+  q->L = land[kTotL];
+  q->E = land[kTotE];
+  q->NL = land[kTotNL];
+  q->NR = land[kTotNR];
+  q->has_forward = b.forward;
+  const bool fw = b.forward;
+  const int32_t E = (int32_t)q->E;
   MRGCN_HIP_TRY(sup_alloc(q, &q->lcol, q->L));
   MRGCN_HIP_TRY(sup_alloc(q, &q->lrel, q->L));
   MRGCN_HIP_TRY(sup_alloc(q, &q->lptr, q->L + 1));
-  int32_t *cnt;
-  MRGCN_HIP_TRY(sc.alloc(&cnt, q->L + 1));
-  MRGCN_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)(q->L + 1) * sizeof(int32_t), s));
-  if (ncols > 0)
-    k_sup_cols<<<nblocks(ncols), kTB, 0, s>>>(q->col_flags, lpos, ncols, p->urel, p->cptr, p->crow, row_flags, q->lcol,
-                                              q->lrel, cnt);
-  MRGCN_HIP_TRY(hipGetLastError());
-  if ((rc = exclusive_scan_i32(cnt, q->lptr, q->L + 1, s, sc))) return rc;
-  int32_t hE = 0;
-  MRGCN_HIP_TRY(hipMemcpyAsync(&hE, q->lptr + q->L, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MRGCN_HIP_TRY(hipStreamSynchronize(s));
-  q->E = hE;
   MRGCN_HIP_TRY(sup_alloc(q, &q->lrow, q->E));
   MRGCN_HIP_TRY(sup_alloc(q, &q->lval, q->E));
-  if (q->L > 0)
-    k_sup_entries<<<nblocks(q->L), kTB, 0, s>>>(q->lcol, q->lptr, q->L, p->cptr, p->crow, p->cval, row_flags, q->lrow,
-                                                q->lval);
-  MRGCN_HIP_TRY(hipGetLastError());
-  // nodes
-  int32_t *nflag, *npos;
-  MRGCN_HIP_TRY(sc.alloc(&nflag, N + 1));
-  MRGCN_HIP_TRY(sc.alloc(&npos, N + 1));
-  k_sup_nodes<<<nblocks(N + 1), kTB, 0, s>>>(p->nptr, lpos, N, q->nlptr, q->node_flags, nflag);
-  MRGCN_HIP_TRY(hipGetLastError());
-  if ((rc = exclusive_scan_i32(nflag, npos, N + 1, s, sc))) return rc;
-  int32_t hNL = 0;
-  MRGCN_HIP_TRY(hipMemcpyAsync(&hNL, npos + N, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MRGCN_HIP_TRY(hipStreamSynchronize(s));
-  q->NL = hNL;
   MRGCN_HIP_TRY(sup_alloc(q, &q->lnode, q->NL));
   MRGCN_HIP_TRY(sup_alloc(q, &q->lnptr, q->NL + 1));
-  k_sup_lnodes<<<nblocks(N + 1), kTB, 0, s>>>(nflag, npos, N, q->nlptr, q->lnode, q->lnptr);
-  MRGCN_HIP_TRY(hipGetLastError());
-  // split rows of the filtered transposed view (live columns read by more than kLongThreshold live rows)
-  {
-    mrgcn_plan acct;  // build_long charges its arrays to a plan: this one only carries the stream and the byte count
-    acct.build_stream = s;
-    int64_t max_len = 0;
-    rc = build_long(&acct, q->lptr, q->L, s, &q->t_long_row, &q->t_long_cptr, &q->t_chunk_beg, &q->t_chunk_end,
-                    &q->t_chunk_row, &q->t_n_long, &q->t_n_chunks, &max_len);
-    for (void *a : {(void *)q->t_long_row, (void *)q->t_long_cptr, (void *)q->t_chunk_beg, (void *)q->t_chunk_end,
-                    (void *)q->t_chunk_row})
-      if (a) q->owned.push_back(a);
-    q->device_bytes += acct.device_bytes;
-    if (rc != MRGCN_OK) return rc;
-    MRGCN_HIP_TRY(sup_alloc(q, &q->partials, (int64_t)std::max(q->t_n_chunks, 1) * kWsFeatures));
-  }
-  if (forward) {
-    q->has_forward = true;
-    int32_t *rflag, *rpos, *flen;
-    MRGCN_HIP_TRY(sc.alloc(&rflag, rows + 1));
-    MRGCN_HIP_TRY(sc.alloc(&rpos, rows + 1));
-    k_sup_flags_i32<<<nblocks(rows + 1), kTB, 0, s>>>(row_flags, nullptr, rows, rflag);
-    MRGCN_HIP_TRY(hipGetLastError());
-    if ((rc = exclusive_scan_i32(rflag, rpos, rows + 1, s, sc))) return rc;
-    int32_t hNR = 0;
-    MRGCN_HIP_TRY(hipMemcpyAsync(&hNR, rpos + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    MRGCN_HIP_TRY(hipStreamSynchronize(s));
-    q->NR = hNR;
-    MRGCN_HIP_TRY(sup_alloc(q, &q->rowrank, rows));
-    MRGCN_HIP_TRY(sup_alloc(q, &q->frow, q->NR));
-    MRGCN_HIP_TRY(sup_alloc(q, &q->fptr, q->NR + 1));
-    MRGCN_HIP_TRY(sc.alloc(&flen, q->NR + 1));
-    MRGCN_HIP_TRY(hipMemsetAsync(flen, 0, (size_t)(q->NR + 1) * sizeof(int32_t), s));
-    if (rows > 0) k_sup_rowrank<<<nblocks(rows), kTB, 0, s>>>(row_flags, rpos, rows, p->rowptr, q->rowrank, q->frow, flen);
-    MRGCN_HIP_TRY(hipGetLastError());
-    if ((rc = exclusive_scan_i32(flen, q->fptr, q->NR + 1, s, sc))) return rc;
-    // (every entry of a flagged row touches a live column and every kept entry of a live column sits in a flagged row:
-    // the forward view holds the same E entries as the transposed one)
-    MRGCN_HIP_TRY(sup_alloc(q, &q->fcol, q->E));
-    MRGCN_HIP_TRY(sup_alloc(q, &q->fval, q->E));
+  MRGCN_HIP_TRY(stage_alloc(b, fw, &q->fcol, q->E));
+  MRGCN_HIP_TRY(stage_alloc(b, fw, &q->fval, q->E));
+  if (fw) {
     MRGCN_HIP_TRY(sup_alloc(q, &q->ones, q->E));
     MRGCN_HIP_TRY(sup_alloc(q, &q->lrow_rank, q->E));
     MRGCN_HIP_TRY(sup_alloc(q, &q->lnode_ord, q->L));
-    if (q->NR > 0)
-      k_sup_fwd_entries<<<nblocks(q->NR * kWave), kTB, 0, s>>>(q->frow, q->fptr, q->NR, p->rowptr, p->ccol, p->val, lpos,
-                                                              q->fcol, q->fval);
-    if (q->E > 0) k_sup_rank_entries<<<nblocks(q->E), kTB, 0, s>>>(q->lrow, q->rowrank, q->E, q->lrow_rank, q->ones);
-    if (q->L > 0) k_sup_node_ord<<<nblocks(q->L), kTB, 0, s>>>(p->unode, q->lcol, npos, q->L, q->lnode_ord);
+  }
+  int32_t *frank, *ident, *perm, *keys_out;
+  MRGCN_HIP_TRY(b.sc.alloc(&frank, q->E));
+  MRGCN_HIP_TRY(b.sc.alloc(&ident, q->E));
+  MRGCN_HIP_TRY(b.sc.alloc(&perm, q->E));
+  MRGCN_HIP_TRY(b.sc.alloc(&keys_out, q->E));
+  k_sup_cols2<<<nblocks(ncols + 1), kTB, 0, s>>>(q->col_flags, b.lpos, ncols, p->urel, b.ckept, q->lcol, q->lrel, q->lptr);
+  k_sup_lnodes<<<nblocks(N + 1), kTB, 0, s>>>(b.nflag, b.npos, N, q->nlptr, q->lnode, q->lnptr);
+  MRGCN_HIP_TRY(hipGetLastError());
+  if (E > 0) {
+    // the flagged rows' entries (the forward view), then the same entries by (live column, row): one stable sort
+    k_sup_fwd_fill<<<nblocks(E), kTB, 0, s>>>(q->frow, q->fptr, (int32_t)q->NR, E, p->rowptr, p->ccol, p->val, b.lpos,
+                                             q->fcol, q->fval, frank, ident, fw ? q->ones : nullptr);
     MRGCN_HIP_TRY(hipGetLastError());
-    mrgcn_plan acct;
-    acct.build_stream = s;
-    int64_t max_len = 0;
-    rc = build_long(&acct, q->fptr, q->NR, s, &q->f_long_row, &q->f_long_cptr, &q->f_chunk_beg, &q->f_chunk_end,
-                    &q->f_chunk_row, &q->f_n_long, &q->f_n_chunks, &max_len);
-    for (void *a : {(void *)q->f_long_row, (void *)q->f_long_cptr, (void *)q->f_chunk_beg, (void *)q->f_chunk_end,
-                    (void *)q->f_chunk_row})
-      if (a) q->owned.push_back(a);
-    q->device_bytes += acct.device_bytes;
-    if (rc != MRGCN_OK) return rc;
+    size_t tb = 0;
+    const int end_bit = bits_for(std::max<int64_t>(q->L - 1, 1));
+    MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, q->fcol, keys_out, ident, perm, E, 0, end_bit, s));
+    char *tmp = nullptr;
+    MRGCN_HIP_TRY(b.sc.alloc(&tmp, (int64_t)tb));
+    MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, q->fcol, keys_out, ident, perm, E, 0, end_bit, s));
+    k_sup_t_fill<<<nblocks(E), kTB, 0, s>>>(perm, E, frank, q->frow, q->fval, q->lrow, fw ? q->lrow_rank : nullptr, q->lval);
+    MRGCN_HIP_TRY(hipGetLastError());
+  }
+  int rc;
+  // split rows of the filtered transposed view (live columns read by more than kLongThreshold live rows)
+  q->t_n_long = land[kTotTLong];
+  q->t_n_chunks = land[kTotTChunks];
+  if ((rc = long_rows_known(q, q->lptr, q->L, s, q->t_n_long, q->t_n_chunks, &q->t_long_row, &q->t_long_cptr,
+                            &q->t_chunk_beg, &q->t_chunk_end, &q->t_chunk_row)))
+    return rc;
+  MRGCN_HIP_TRY(sup_alloc(q, &q->partials, (int64_t)std::max(q->t_n_chunks, 1) * kWsFeatures));
+  if (fw) {
+    if (q->L > 0) k_sup_node_ord<<<nblocks(q->L), kTB, 0, s>>>(p->unode, q->lcol, b.npos, q->L, q->lnode_ord);
+    MRGCN_HIP_TRY(hipGetLastError());
+    q->f_n_long = land[kTotFLong];
+    q->f_n_chunks = land[kTotFChunks];
+    if ((rc = long_rows_known(q, q->fptr, q->NR, s, q->f_n_long, q->f_n_chunks, &q->f_long_row, &q->f_long_cptr,
+                              &q->f_chunk_beg, &q->f_chunk_end, &q->f_chunk_row)))
+      return rc;
     MRGCN_HIP_TRY(sup_alloc(q, &q->f_partials, (int64_t)std::max(q->f_n_chunks, 1) * kWsFeatures));
   }
-  // the two relation-major orders
-  rc = build_support_order(q, sc, s, lpos, p->rperm, p->rnode, p->relptr, p->n_bands, &q->wide, forward ? npos : nullptr);
-  if (rc != MRGCN_OK) return rc;
-  q->has_narrow = p->n_rperm != nullptr;
-  if (q->has_narrow) {
-    rc = build_support_order(q, sc, s, lpos, p->n_rperm, p->n_rnode, p->n_relptr, p->n_n_bands, &q->narrow,
-                             forward ? npos : nullptr);
-    if (rc != MRGCN_OK) return rc;
-  }
-  MRGCN_HIP_TRY(hipStreamSynchronize(s));  // (the scratch arrays go back to the pool behind finished work)
+  if ((rc = stage2_order(b, s, b.ow, p->rperm, p->rnode, blk, offs_w, &q->wide))) return rc;
+  if (q->has_narrow && (rc = stage2_order(b, s, b.on, p->n_rperm, p->n_rnode, blk, offs_n, &q->narrow))) return rc;
   return MRGCN_OK;
+}
+
+// builds the supports qs[0..n): qs[0] on `row_flags`, qs[i+1] on NODE_FLAGS of qs[i]
+int build_support_chain(mrgcn_support **qs, int n, const uint8_t *row_flags, hipStream_t s, bool forward) {
+  std::vector<SupStage> st(n);
+  std::lock_guard<std::mutex> lock(g_land_mu);
+  const int64_t per = stage_land_ints(qs[0]->plan);
+  if ((size_t)(per * n) > g_land_ints) {
+    if (g_land) (void)hipHostFree(g_land);
+    g_land = nullptr;
+    g_land_ints = 0;
+    MRGCN_HIP_TRY(hipHostMalloc((void **)&g_land, (size_t)(per * n) * sizeof(int32_t), hipHostMallocDefault));
+    g_land_ints = (size_t)(per * n);
+  }
+  int rc;
+  for (int i = 0; i < n; ++i) {
+    st[i].q = qs[i];
+    st[i].forward = forward;
+    st[i].row_flags = i == 0 ? row_flags : qs[i - 1]->node_flags;
+    st[i].land_off = per * i;
+    if ((rc = support_stage1(st[i], s))) return rc;
+  }
+  MRGCN_HIP_TRY(hipStreamSynchronize(s));  // the one wait of the build
+  for (int i = 0; i < n; ++i)
+    if ((rc = support_upload(st[i]))) return rc;
+  for (int i = 0; i < n; ++i)
+    if ((rc = support_stage2(st[i], s))) return rc;
+  return MRGCN_OK;  // (stream ordered from here on: the scratch goes back tagged with the stream)
 }
 
 void release_support(mrgcn_support *q) {
@@ -1566,16 +1754,29 @@ int mrgcn_support_create_ex(mrgcn_support_t **out, const mrgcn_plan_t *plan, con
   MRGCN_REQUIRE(out && plan && row_flags, "NULL");
   MRGCN_REQUIRE((flags & ~MRGCN_SUPPORT_FORWARD) == 0, "flags");
   MRGCN_REQUIRE(!plan->lean, "a lean plan (mini-batch slice) keeps no transposed view to build a support on");
-  mrgcn_support *q = new mrgcn_support();
-  q->plan = plan;
-  (void)hipGetDevice(&q->device);
-  q->build_stream = (hipStream_t)stream;
-  int rc = build_support(q, row_flags, (hipStream_t)stream, (flags & MRGCN_SUPPORT_FORWARD) != 0);
+  return mrgcn_support_create_chain(out, 1, plan, row_flags, flags, stream);
+}
+
+int mrgcn_support_create_chain(mrgcn_support_t **out, int32_t n, const mrgcn_plan_t *plan, const uint8_t *row_flags,
+                               uint32_t flags, void *stream) {
+  using namespace mrgcn;
+  MRGCN_REQUIRE(out && plan && row_flags && n >= 1 && n <= 64, "NULL / n");
+  MRGCN_REQUIRE((flags & ~MRGCN_SUPPORT_FORWARD) == 0, "flags");
+  MRGCN_REQUIRE(!plan->lean, "a lean plan (mini-batch slice) keeps no transposed view to build a support on");
+  MRGCN_REQUIRE(n == 1 || plan->num_rows == plan->num_nodes, "a chain needs rows = nodes (the stacked adjacency)");
+  std::vector<mrgcn_support *> qs(n);
+  for (int i = 0; i < n; ++i) {
+    qs[i] = new mrgcn_support();
+    qs[i]->plan = plan;
+    (void)hipGetDevice(&qs[i]->device);
+    qs[i]->build_stream = (hipStream_t)stream;
+  }
+  int rc = build_support_chain(qs.data(), n, row_flags, (hipStream_t)stream, (flags & MRGCN_SUPPORT_FORWARD) != 0);
   if (rc != MRGCN_OK) {
-    release_support(q);
+    for (mrgcn_support *q : qs) release_support(q);
     return rc;
   }
-  *out = q;
+  for (int i = 0; i < n; ++i) out[i] = qs[i];
   return MRGCN_OK;
 }
 

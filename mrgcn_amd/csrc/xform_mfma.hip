@@ -425,14 +425,17 @@ __global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restr
                                                           int64_t lddX, const uint8_t *__restrict__ col_live,
                                                           const float *__restrict__ mask_src, int64_t ldMask,
                                                           uint8_t *__restrict__ row_live, int64_t ncols,
-                                                          const uint8_t *__restrict__ node_live) {
+                                                          const uint8_t *__restrict__ node_live, int lane_max = 0) {
+  // lane_max > 0 (a node list where every node is live — a gradient support's compact arrays): a node of up to
+  // lane_max columns is summed by its own lane; the wave-by-wave walk below, made for a few live nodes among many, took
+  // 125 us for the 6.8 k nodes of a mini-batch layer
   __shared__ float tile[256][KT + 1];
   const int64_t j0 = (int64_t)blockIdx.x * 256;
   const int64_t j = j0 + threadIdx.x;
   float acc[KT];
 #pragma unroll
   for (int i = 0; i < KT; ++i) acc[i] = 0.f;
-  bool any_out = false, wide_out = false;
+  bool any_out = false, wide_out = false, own_out = false;
   int32_t c0_out = 0, c1_out = 0;
   if (j < N) {
     const int32_t c0 = nptr[j], c1 = nptr[j + 1];
@@ -456,6 +459,16 @@ __global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restr
         if (w0 + 8 > c1) bits &= ~uint64_t(0) >> (8 * (w0 + 8 - c1));
         any = bits != 0;
       }
+    }
+    if (any && lane_max > 0 && c1 - c0 <= lane_max) {
+      for (int32_t c = c0; c < c1; ++c) {
+        const float *z = Z + (int64_t)c * ldZ;
+#pragma unroll
+        for (int i = 0; i < KT; ++i)
+          if (i < K) acc[i] += z[i];
+      }
+      any = false;
+      own_out = true;
     }
     any_out = any; c0_out = c0; c1_out = c1; wide_out = wide;
   }
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restr
     }
   }
   if (j < N) {
-    const bool any = any_out;
+    const bool any = any_out || own_out;
     bool nz = false;
     if (any) {
       if (mask_src) {
@@ -702,16 +715,16 @@ int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *
 
 
 int segment_sum_arrays(const int32_t *nptr, int64_t num_nodes, int64_t nz_rows, const float *Z, int64_t ldZ, int K,
-                       float *dX, int64_t lddX, hipStream_t s, const float *mask_src, int64_t ldMask) {
+                       float *dX, int64_t lddX, hipStream_t s, const float *mask_src, int64_t ldMask, int lane_max) {
   if (num_nodes == 0) return MRGCN_OK;
   if (K <= 16) {  // every row of dX written (zeros for nodes without a row of Z), masked in the same pass
     const dim3 grid((unsigned)((num_nodes + 255) / 256));
     if (K <= 8)
       k_segment_sum_mask<8><<<grid, dim3(256), 0, s>>>(nptr, Z, ldZ, num_nodes, K, dX, lddX, nullptr, mask_src, ldMask,
-                                                       nullptr, nz_rows, nullptr);
+                                                       nullptr, nz_rows, nullptr, lane_max);
     else
       k_segment_sum_mask<16><<<grid, dim3(256), 0, s>>>(nptr, Z, ldZ, num_nodes, K, dX, lddX, nullptr, mask_src, ldMask,
-                                                        nullptr, nz_rows, nullptr);
+                                                        nullptr, nz_rows, nullptr, lane_max);
     MRGCN_HIP_TRY(hipGetLastError());
     return MRGCN_OK;
   }

@@ -395,12 +395,9 @@ class A_BatchMasked:
         self.value_mode = None
         flags = torch.zeros(plan.num_rows, dtype=torch.uint8, device=dev)
         flags[idx] = 1
-        self.supports, self.neighbours = [], []
-        for _ in range(num_layers):
-            sup = GraphSupport(plan, flags, forward=True)
-            self.supports.append(sup)
-            self.neighbours.append(sup.view(L_.SUP_LNODE).long())
-            flags = sup.node_flags()
+        # every layer's support in one build (one host wait): level i+1's rows are level i's NODE_FLAGS
+        self.supports = GraphSupport.chain(plan, flags, num_layers, forward=True) if num_layers else []
+        self.neighbours = [sup.view(L_.SUP_LNODE).long() for sup in self.supports]
         self.row = self.supports
         # position of every batch node among the (sorted, distinct) rows the top layer computes
         self.out_rank = self.supports[0].view(L_.SUP_ROWRANK)[idx].long() if num_layers else idx

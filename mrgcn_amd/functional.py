@@ -645,11 +645,15 @@ class _MaskedLayer(torch.autograd.Function):
             if has_X:
                 Xc = X if (X.dim() == 2 and X.stride(1) == 1) else X.contiguous()
                 Wc = W_F.contiguous()
-                if Xc.shape[0] != sup.NL:
-                    raise L.MrgcnError(f"masked layer: X has {Xc.shape[0]} rows, the sample has {sup.NL} neighbours")
+                # X: one row per neighbour (the reference's mksubset form) or the WHOLE feature matrix, one row per node
+                # — the transform then picks the neighbours' rows itself (no X[batch.neighbours[-1]] copy in front)
+                x_by_node = Xc.shape[0] == plan.num_nodes and sup.NL != plan.num_nodes
+                if Xc.shape[0] != sup.NL and not x_by_node:
+                    raise L.MrgcnError(f"masked layer: X has {Xc.shape[0]} rows, the sample has {sup.NL} neighbours "
+                                       f"(or hand over all {plan.num_nodes} rows)")
                 T = torch.empty((Lc, ld), dtype=torch.float32, device=dev)
-                L.check(lib.mrgcn_support_rel_transform_fwd_f32(sup.handle, Xc.data_ptr(), Xc.stride(0), Xc.shape[1],
-                                                                Wc.data_ptr(), F, T.data_ptr(), ld, s),
+                L.check(lib.mrgcn_support_rel_transform_fwd_f32(sup.handle, Xc.data_ptr(), Xc.stride(0), int(x_by_node),
+                                                                Xc.shape[1], Wc.data_ptr(), F, T.data_ptr(), ld, s),
                         "mrgcn_support_rel_transform_fwd_f32")
             if has_I:
                 wI = weight_I.contiguous()
@@ -676,6 +680,7 @@ class _MaskedLayer(torch.autograd.Function):
                 L.check(lib.mrgcn_support_spmm_fwd_f32(sup.handle, int(has_I), (M if has_I else T).data_ptr(), ld, F,
                                                        Y.data_ptr(), F, b, int(relu), s), "mrgcn_support_spmm_fwd_f32")
         ctx.sup, ctx.plan, ctx.F, ctx.ld, ctx.relu, ctx.owner = sup, plan, F, ld, relu, owner
+        ctx.x_by_node = bool(has_X and x_by_node)
         ctx.x_is_relu_out = has_X and bool(getattr(X, "_mrgcn_relu_out", False))
         ctx.has = (has_I, has_X, bias is not None)
         ctx.save_for_backward(wI, cI, Xc, Wc, Y if relu else None)
@@ -720,13 +725,17 @@ class _MaskedLayer(torch.autograd.Function):
                     dX = torch.empty((sup.NL, K), dtype=torch.float32, device=dev)
                 if need_dW:
                     dW = torch.empty_like(W_F)
-                mask = bool(need_dX and ctx.x_is_relu_out and K <= 16)
+                mask = bool(need_dX and ctx.x_is_relu_out and K <= 16 and not ctx.x_by_node)
                 L.check(lib.mrgcn_support_rel_transform_bwd_compact_f32(
-                    sup.handle, dT.data_ptr(), ld, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
+                    sup.handle, dT.data_ptr(), ld, X.data_ptr(), X.stride(0), int(ctx.x_by_node), K, W_F.data_ptr(), F,
                     dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0, ws.data_ptr(), ws.numel(),
                     int(mask), s), "mrgcn_support_rel_transform_bwd_compact_f32")
                 if need_dX and mask:
                     _set_grad_meta(dX, None, True)
+                if need_dX and ctx.x_by_node:  # the whole matrix wants its gradient: zeros outside the neighbours
+                    full = torch.zeros((X.shape[0], K), dtype=torch.float32, device=dev)
+                    full.index_copy_(0, sup.view(L.SUP_LNODE).long(), dX)
+                    dX = full
         return None, None, d_wI, d_comp, dX, dW, dbias, None, None
 
 

@@ -317,22 +317,25 @@ class GraphSupport:
     set of output rows that can carry gradient.  Holds on to the flags tensor it was built from (its identity is the
     cache key) and to its plan."""
 
-    def __init__(self, plan: GraphPlan, row_flags: torch.Tensor, forward: bool = False):
+    def __init__(self, plan: GraphPlan, row_flags, forward: bool = False, _handle=None):
         """`forward`: also keep the flagged rows' forward arrays (MRGCN_SUPPORT_FORWARD: a mini-batch layer as a
-        masked pass over the plan, csrc/masked.hip)."""
+        masked pass over the plan, csrc/masked.hip).  (`_handle`: adopt a support that exists — GraphSupport.chain.)"""
         import weakref
         lib = L.load()
-        if row_flags.dtype != torch.uint8 or row_flags.numel() != plan.num_rows or not row_flags.is_contiguous():
+        if _handle is None and (row_flags.dtype != torch.uint8 or row_flags.numel() != plan.num_rows
+                                or not row_flags.is_contiguous()):
             raise L.MrgcnError(f"row_flags must be a contiguous uint8 tensor of {plan.num_rows} rows")
         # (a weak reference: the plan keeps its supports, not the other way round — no reference cycle, so both are
         # released by reference counting when the plan goes, not by a collector run at an arbitrary moment)
         self._plan = weakref.ref(plan)
         self.row_flags, self.device = row_flags, plan.device
-        h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            L.check(lib.mrgcn_support_create_ex(C.byref(h), plan.handle, row_flags.data_ptr(),
-                                                L.SUPPORT_FORWARD if forward else 0, _stream_ptr(self.device)),
-                    "mrgcn_support_create")
+        h = _handle
+        if h is None:
+            h = C.c_void_p()
+            with torch.cuda.device(self.device):
+                L.check(lib.mrgcn_support_create_ex(C.byref(h), plan.handle, row_flags.data_ptr(),
+                                                    L.SUPPORT_FORWARD if forward else 0, _stream_ptr(self.device)),
+                        "mrgcn_support_create")
         self._h = h
         info = L.SupportInfo()
         L.check(lib.mrgcn_support_info(self._h, C.byref(info)))
@@ -345,6 +348,24 @@ class GraphSupport:
         self.ordered_release = bool(forward)
         self._node_flags = None
         self._ws = {}
+
+    @classmethod
+    def chain(cls, plan: GraphPlan, row_flags: torch.Tensor, n: int, forward: bool = True):
+        """`n` supports in one build (one host wait): the first on `row_flags`, each next one on the NODE_FLAGS of the
+        one before — the samples of the n layers of a mini-batch (mrgcn_support_create_chain)."""
+        lib = L.load()
+        if row_flags.dtype != torch.uint8 or row_flags.numel() != plan.num_rows or not row_flags.is_contiguous():
+            raise L.MrgcnError(f"row_flags must be a contiguous uint8 tensor of {plan.num_rows} rows")
+        hs = (C.c_void_p * n)()
+        with torch.cuda.device(plan.device):
+            L.check(lib.mrgcn_support_create_chain(hs, n, plan.handle, row_flags.data_ptr(),
+                                                   L.SUPPORT_FORWARD if forward else 0, _stream_ptr(plan.device)),
+                    "mrgcn_support_create_chain")
+        out = []
+        for i in range(n):
+            # (level i+1 reads the flags array level i owns: it keeps that support alive through `row_flags`)
+            out.append(cls(plan, row_flags if i == 0 else out[-1], forward, _handle=C.c_void_p(hs[i])))
+        return out
 
     @property
     def plan(self):

@@ -270,16 +270,23 @@ def test_forward_support_mix_and_transform(B, F, K):
     W = rng.standard_normal((R, K, F)).astype(np.float32)
     Xt, Wt = torch.from_numpy(X).cuda(), torch.from_numpy(W).cuda()
     T = torch.zeros((sup.L, ld), device="cuda")
-    L.check(lib.mrgcn_support_rel_transform_fwd_f32(sup.handle, Xt.data_ptr(), K, K, Wt.data_ptr(), F, T.data_ptr(), ld, s))
+    L.check(lib.mrgcn_support_rel_transform_fwd_f32(sup.handle, Xt.data_ptr(), K, 0, K, Wt.data_ptr(), F, T.data_ptr(), ld, s))
     want_T = np.einsum("kc,kcf->kf", X[ordn].astype(np.float64), W[lrel].astype(np.float64))
     np.testing.assert_allclose(T.cpu().numpy()[:, :F], want_T, rtol=1e-4, atol=1e-4)
+    # the whole feature matrix, one row per node: the same rows picked inside the transform
+    Xfull = np.zeros((N, K), dtype=np.float32)
+    Xfull[lnode] = X
+    Xf = torch.from_numpy(Xfull).cuda()
+    T2 = torch.zeros((sup.L, ld), device="cuda")
+    L.check(lib.mrgcn_support_rel_transform_fwd_f32(sup.handle, Xf.data_ptr(), K, 1, K, Wt.data_ptr(), F, T2.data_ptr(), ld, s))
+    assert torch.equal(T2[:, :F], T[:, :F])
     dT = rng.standard_normal((sup.L, ld)).astype(np.float32)
     nws = int(lib.mrgcn_support_rel_transform_bwd_workspace(sup.handle, K, F, int(need_dX), 1))
     ws = torch.empty(max(nws, 2), device="cuda")
     dX = torch.full((sup.NL, K), 7.0, device="cuda")
     dW = torch.full((R, K, F), 7.0, device="cuda")
     L.check(lib.mrgcn_support_rel_transform_bwd_compact_f32(
-        sup.handle, torch.from_numpy(dT).cuda().data_ptr(), ld, Xt.data_ptr(), K, K, Wt.data_ptr(), F,
+        sup.handle, torch.from_numpy(dT).cuda().data_ptr(), ld, Xt.data_ptr(), K, 0, K, Wt.data_ptr(), F,
         dX.data_ptr() if need_dX else 0, K, dW.data_ptr(), ws.data_ptr(), ws.numel(), 0, s))
     want_dW = np.zeros((R, K, F))
     np.add.at(want_dW, lrel, np.einsum("kc,kf->kcf", X[ordn].astype(np.float64), dT[:, :F].astype(np.float64)))
@@ -288,4 +295,9 @@ def test_forward_support_mix_and_transform(B, F, K):
     np.testing.assert_allclose(dW.cpu().numpy(), want_dW, rtol=1e-3, atol=1e-3)
     if need_dX:
         np.testing.assert_allclose(dX.cpu().numpy(), want_dX, rtol=1e-3, atol=1e-3)
+    dW2 = torch.full((R, K, F), 7.0, device="cuda")
+    L.check(lib.mrgcn_support_rel_transform_bwd_compact_f32(
+        sup.handle, torch.from_numpy(dT).cuda().data_ptr(), ld, Xf.data_ptr(), K, 1, K, Wt.data_ptr(), F, 0, K,
+        dW2.data_ptr(), ws.data_ptr(), ws.numel(), 0, s))
+    assert torch.equal(dW2, dW)
     sup.close()

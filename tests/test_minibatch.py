@@ -241,6 +241,14 @@ def test_masked_batch_on_the_full_plan_equals_the_goldens(tag):
                                        err_msg=n)
         if X is not None:
             np.testing.assert_allclose(X.grad.cpu().numpy(), g[tag + ".grad.X"], rtol=1e-3, atol=1e-5)
+            # the whole feature matrix instead of the neighbours' rows: the transform picks the rows itself
+            Xw = Xfull.clone().requires_grad_(True)
+            logits2 = model(Xw, ab)
+            assert torch.equal(logits2, logits)
+            logits2.sum().backward()
+            gx = Xw.grad
+            assert bool((gx[ab.neighbours[-1]].abs().sum() > 0)) and float(gx.abs().sum()) == pytest.approx(
+                float(gx[ab.neighbours[-1]].abs().sum()), rel=1e-6)
         ab.close()
 
 
@@ -307,6 +315,21 @@ def test_masked_batches_train_like_slice_batches():
     np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-6)
     for n in p0:
         np.testing.assert_allclose(p1[n], p0[n], rtol=1e-4, atol=1e-6, err_msg=n)
+
+    # the package's own step (train_step: weight_I's gradient stays row-sparse on the support's node flags, fused
+    # clip + Adam on those rows), X handed over whole
+    from mrgcn_amd.train import train_step
+    torch.manual_seed(0)
+    model = RGCN([(K, 8, "mrgcn", torch.nn.ReLU()), (8, C, "mrgcn", None)], R, N, 3, 0.0, False, True, False).cuda()
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    l2 = []
+    for k, i in enumerate(idxs):
+        ab = mb.A_BatchMasked(plan, i, 2)
+        l2.append(float(train_step(model, lambda: model(X, ab), rows, ys[k], opt)))
+        ab.close()
+    np.testing.assert_allclose(l2, l0, rtol=1e-5, atol=1e-6)
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.detach().cpu().numpy(), p0[n], rtol=1e-4, atol=1e-6, err_msg=n)
 
 
 @pytest.mark.gpu

@@ -116,25 +116,41 @@ def minibatch():
         if it >= 2:
             mb_build.append((t1 - t0) * 1e3)
             mb_step.append((t2 - t1) * 1e3)
+        sup_sizes = [(s_.NR, s_.L, s_.E, s_.NL) for s_ in am.supports]
         am.close()
+    from mrgcn_amd.train import train_step
     steps, warm = 24, 6
     idxs = [np.sort(rng.choice(N, 1024, replace=False)) for _ in range(steps)]
-    for k, idx in enumerate(idxs):
-        if k == warm:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        am = mb.A_BatchMasked(plan, idx, 2)
+
+    def in_line(step_fn):
+        for k, idx in enumerate(idxs):
+            if k == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            am = mb.A_BatchMasked(plan, idx, 2)
+            step_fn(am)
+            am.close()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / (steps - warm) * 1e3, 2), am
+
+    def raw_loop(am):  # the reference's loop shape: neighbours' rows gathered by the caller, backward, clip + Adam
         loss = categorical_crossentropy(model(X[am.neighbours[-1]], am), rows1024, ys)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-    torch.cuda.synchronize()
+
+    raw_ms, _ = in_line(raw_loop)
+    # the package's step: weight_I's gradient stays row-sparse (fused clip + Adam on the rows that have one or ever
+    # had), X handed over whole (the transform picks the neighbours' rows)
+    step_ms, am = in_line(lambda am: train_step(model, lambda: model(X, am), rows1024, ys, opt))
     out["masked_pass"] = dict(
-        resampled_step_in_line_ms=round((time.perf_counter() - t0) / (steps - warm) * 1e3, 2),
+        resampled_step_in_line_ms=step_ms, resampled_step_in_line_raw_loop_ms=raw_ms,
         support_builds_ms=round(float(np.median(mb_build)), 2), fwd_bwd_adam_ms=round(float(np.median(mb_step)), 2),
-        supports=[dict(rows=s_.NR, live_cols=s_.L, entries=s_.E, live_nodes=s_.NL) for s_ in am.supports],
+        supports=[dict(rows=s_[0], live_cols=s_[1], entries=s_[2], live_nodes=s_[3]) for s_ in sup_sizes],
         note="every step on a fresh batch, nothing prepared ahead: the batch is a pair of forward supports on the full "
-             "graph's plan (data.batch.A_BatchMasked)")
+             "graph's plan (data.batch.A_BatchMasked), built in one call with one host wait; resampled_step_in_line_ms = "
+             "mrgcn_amd.train.train_step on it, _raw_loop_ms = gather + backward + ClipAdam.step written out like the "
+             "reference's loop (dense weight_I gradient)")
     out.update(neighbours=sizes, batch_build_ms=round(float(np.median(t_build)), 2),
                plans_fwd_bwd_adam_ms=round(float(np.median(t_step)), 2),
                note="a re-sampled batch every step: structure on the device (batch_build_ms), then its lean slice plans "
