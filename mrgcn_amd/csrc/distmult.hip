@@ -435,12 +435,33 @@ __global__ void k_widen_i32(const int32_t *__restrict__ a, int64_t n, int64_t *_
 // ---- the three orders of a SMALL triple set by counting sort (the freshly drawn corrupted facts of an epoch: 54 k at
 // the FB15k-237 shape).  A radix sort of so few keys is ~25 launch-bound kernels; here: one histogram pass, one scan
 // block per column, one fill pass.  Ties keep no particular order (none is needed).
-__global__ void k_count3(const int64_t *__restrict__ tr, int64_t n, int32_t *__restrict__ cnt, int64_t stride) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  atomicAdd(&cnt[tr[3 * i]], 1);
-  atomicAdd(&cnt[stride + tr[3 * i + 1]], 1);
-  atomicAdd(&cnt[2 * stride + tr[3 * i + 2]], 1);
+// Histogram of one column (blockIdx.y) of the triples.  The bins of a block's slice are counted in LDS first and
+// flushed with one global add per touched bin: a hub node is the subject of thousands of the corrupted facts, and as
+// many same-address global atomics in a row were most of the first version's 120 us (FB15k-237 shape).  Columns with
+// more bins than fit LDS go straight to global memory.
+constexpr int kCountLdsBins = 16384;  // two arrays of them in k_fill3: 128 KB
+constexpr int kCountTB = 1024, kCountPer = 4;
+__global__ __launch_bounds__(kCountTB) void k_count3(const int64_t *__restrict__ tr, int64_t n, int32_t *__restrict__ cnt,
+                                                     int64_t stride, int64_t bins_n, int64_t bins_r) {
+  extern __shared__ int32_t s_bins[];
+  const int c = blockIdx.y;
+  const int64_t bins = c == 1 ? bins_r : bins_n;
+  int32_t *g = cnt + c * stride;
+  const bool lds = bins <= kCountLdsBins;
+  if (lds) {
+    for (int64_t t = threadIdx.x; t < bins; t += kCountTB) s_bins[t] = 0;
+    __syncthreads();
+  }
+  const int64_t i0 = (int64_t)blockIdx.x * kCountTB * kCountPer;
+  for (int u = 0; u < kCountPer; ++u) {
+    const int64_t i = i0 + u * kCountTB + threadIdx.x;
+    if (i < n) atomicAdd(lds ? &s_bins[tr[3 * i + c]] : &g[tr[3 * i + c]], 1);
+  }
+  if (lds) {
+    __syncthreads();
+    for (int64_t t = threadIdx.x; t < bins; t += kCountTB)
+      if (s_bins[t]) atomicAdd(&g[t], s_bins[t]);
+  }
 }
 // exclusive scan of cnt[c * stride .. + bins_c) in place, one 1024-thread block per column
 __global__ __launch_bounds__(1024) void k_scan3(int32_t *__restrict__ cnt, int64_t stride, int64_t bins_n, int64_t bins_r) {
@@ -467,13 +488,46 @@ __global__ __launch_bounds__(1024) void k_scan3(int32_t *__restrict__ cnt, int64
     run += v;
   }
 }
-__global__ void k_fill3(const int64_t *__restrict__ tr, int64_t n, int32_t *__restrict__ off, int64_t stride,
-                        int64_t *__restrict__ o0, int64_t *__restrict__ o1, int64_t *__restrict__ o2) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  o0[atomicAdd(&off[tr[3 * i]], 1)] = i;
-  o1[atomicAdd(&off[stride + tr[3 * i + 1]], 1)] = i;
-  o2[atomicAdd(&off[2 * stride + tr[3 * i + 2]], 1)] = i;
+// positions: a block counts its slice per bin (LDS), reserves one range per touched bin behind the bin's offset, and
+// hands the range out to its own triples
+__global__ __launch_bounds__(kCountTB) void k_fill3(const int64_t *__restrict__ tr, int64_t n, int32_t *__restrict__ off,
+                                                    int64_t stride, int64_t bins_n, int64_t bins_r,
+                                                    int64_t *__restrict__ o0, int64_t *__restrict__ o1,
+                                                    int64_t *__restrict__ o2) {
+  extern __shared__ int32_t s_bins[];  // counts, then cursors | bases
+  const int c = blockIdx.y;
+  const int64_t bins = c == 1 ? bins_r : bins_n;
+  int32_t *g = off + c * stride;
+  int64_t *out = c == 0 ? o0 : c == 1 ? o1 : o2;
+  const bool lds = bins <= kCountLdsBins;
+  const int64_t i0 = (int64_t)blockIdx.x * kCountTB * kCountPer;
+  if (!lds) {
+    for (int u = 0; u < kCountPer; ++u) {
+      const int64_t i = i0 + u * kCountTB + threadIdx.x;
+      if (i < n) out[atomicAdd(&g[tr[3 * i + c]], 1)] = i;
+    }
+    return;
+  }
+  int32_t *s_base = s_bins + bins;
+  for (int64_t t = threadIdx.x; t < bins; t += kCountTB) s_bins[t] = 0;
+  __syncthreads();
+  int64_t key[kCountPer];
+  for (int u = 0; u < kCountPer; ++u) {
+    const int64_t i = i0 + u * kCountTB + threadIdx.x;
+    key[u] = i < n ? tr[3 * i + c] : -1;
+    if (key[u] >= 0) atomicAdd(&s_bins[key[u]], 1);
+  }
+  __syncthreads();
+  for (int64_t t = threadIdx.x; t < bins; t += kCountTB) {
+    const int32_t k = s_bins[t];
+    if (k) s_base[t] = atomicAdd(&g[t], k);
+    s_bins[t] = 0;
+  }
+  __syncthreads();
+  for (int u = 0; u < kCountPer; ++u) {
+    const int64_t i = i0 + u * kCountTB + threadIdx.x;
+    if (key[u] >= 0) out[s_base[key[u]] + atomicAdd(&s_bins[key[u]], 1)] = i;
+  }
 }
 
 inline bool rows_vec4_ok(const float *E, int64_t ldE, const float *Rel, int64_t ldR, int H) {
@@ -689,10 +743,22 @@ int mrgcn_distmult_orders_counting(const int64_t *triples, int64_t n, int64_t nu
   const int64_t stride = std::max(num_nodes, num_relations) + 1;
   int32_t *cnt = (int32_t *)workspace;
   MRGCN_HIP_TRY(mrgcn::fill_async(cnt, 0, (size_t)(3 * stride) * sizeof(int32_t), s));
-  const unsigned blocks = (unsigned)((n + 255) / 256);
-  k_count3<<<dim3(blocks), dim3(256), 0, s>>>(triples, n, cnt, stride);
+  const unsigned blocks = (unsigned)((n + kCountTB * kCountPer - 1) / (kCountTB * kCountPer));
+  // (the columns whose bins fit LDS: the array is sized for the larger of them)
+  const int64_t big = std::max(num_nodes <= kCountLdsBins ? num_nodes : 0, num_relations <= kCountLdsBins ? num_relations : 0);
+  const size_t lds1 = (size_t)big * sizeof(int32_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)k_count3, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kCountLdsBins * (int)sizeof(int32_t)));
+    MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)k_fill3, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      2 * kCountLdsBins * (int)sizeof(int32_t)));
+    attr_set = true;
+  }
+  k_count3<<<dim3(blocks, 3), dim3(kCountTB), lds1, s>>>(triples, n, cnt, stride, num_nodes, num_relations);
   k_scan3<<<dim3(3), dim3(1024), 0, s>>>(cnt, stride, num_nodes, num_relations);
-  k_fill3<<<dim3(blocks), dim3(256), 0, s>>>(triples, n, cnt, stride, order_s, order_p, order_o);
+  k_fill3<<<dim3(blocks, 3), dim3(kCountTB), 2 * lds1, s>>>(triples, n, cnt, stride, num_nodes, num_relations, order_s,
+                                                          order_p, order_o);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

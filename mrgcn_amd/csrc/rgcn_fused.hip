@@ -224,6 +224,49 @@ __device__ __forceinline__ void mix_node_tiles(int32_t c0, int32_t c1, int32_t b
   }
 }
 
+// Wide rows with few bases (the link-prediction encoder: F = 200, B = 2): a wave per node, lane = four features.  The
+// node's B blocks of V stay in registers, the relation / operand-row words of 64 columns are loaded together and read
+// back lane by lane, and every column leaves as ONE 4F-byte row store (16 bytes per lane) — the scalar form stored
+// four bytes per lane and spent 135 us on the 260 MB of M at the FB15k-237 shape.
+template <int BT>
+__global__ __launch_bounds__(256) void k_mix_fwd_wide(const int32_t *__restrict__ nptr, const int32_t *__restrict__ urel,
+                                                      const int32_t *__restrict__ mpos, const float *__restrict__ V,
+                                                      const float *__restrict__ comp, int64_t N, int R, int B, int F,
+                                                      float *__restrict__ M, int64_t ldM,
+                                                      const int32_t *__restrict__ node_ids) {
+  extern __shared__ __align__(16) float s_comp[];  // [R][B]
+  for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_comp[t] = comp[t];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int f0 = 4 * lane;
+  const bool active = f0 < F;
+  const f32x4m zero = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t j = (int64_t)blockIdx.x * 4 + wv; j < N; j += (int64_t)gridDim.x * 4) {
+    const int32_t c0 = nptr[j], c1 = nptr[j + 1];
+    if (c0 == c1) continue;
+    const int64_t jv = node_ids ? (int64_t)node_ids[j] : j;
+    f32x4m v[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+      v[b] = (active && b < B) ? *reinterpret_cast<const f32x4m *>(V + (jv * B + b) * F + f0) : zero;
+    for (int32_t cb = c0; cb < c1; cb += 64) {
+      const int32_t my = (cb + lane < c1) ? cb + lane : c1 - 1;
+      const int32_t mr = urel[my], mp = mpos ? mpos[my] : my;
+      const int cnt = (c1 - cb < 64) ? c1 - cb : 64;
+      for (int t = 0; t < cnt; ++t) {
+        const int r = __builtin_amdgcn_readlane(mr, t);
+        const int64_t pos = __builtin_amdgcn_readlane(mp, t);
+        f32x4m sum = zero;
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+          if (b < B) sum += v[b] * s_comp[r * B + b];
+        if (active) *reinterpret_cast<f32x4m *>(M + pos * ldM + f0) = sum;
+      }
+    }
+  }
+}
+
 // IDS: the nodes are a list (a gradient support's live nodes): entry t owns columns nptr[t] .. nptr[t+1] and its V
 // block is node_ids[t]'s; the ids travel with the node pointers, two steps ahead of their use.
 template <int KS, int NQ, int TN, bool ADD, typename OT, bool IDS = false>
@@ -1211,6 +1254,24 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
 #undef MIXC_GO
     MRGCN_HIP_TRY(hipGetLastError());
     return MRGCN_OK;
+  }
+  if constexpr (sizeof(OT) == 4) {
+    static const bool wide_on = !(getenv("MRGCN_MIX_WIDE") && atoi(getenv("MRGCN_MIX_WIDE")) == 0);
+    if (wide_on && !addend && F > 16 && F <= 256 && F % 4 == 0 && B <= 4 && ldM % 4 == 0 &&
+        ((((uintptr_t)V) | ((uintptr_t)M)) & 15) == 0 && (size_t)R * B * sizeof(float) <= 64 * 1024) {
+      const size_t lds = (size_t)R * B * sizeof(float);
+      int64_t grid = (N + 3) / 4;
+      if (grid > 256 * 8) grid = 256 * 8;
+#define MIXW_GO(BT_)                                                                                            \
+  k_mix_fwd_wide<BT_><<<dim3((unsigned)grid), dim3(256), lds, s>>>(p->nptr, p->urel, mpos_arg, V, comp, N, R, B, F, \
+                                                                    (float *)M, ldM, node_ids)
+      if (B == 1) MIXW_GO(1);
+      else if (B == 2) MIXW_GO(2);
+      else MIXW_GO(4);
+#undef MIXW_GO
+      MRGCN_HIP_TRY(hipGetLastError());
+      return MRGCN_OK;
+    }
   }
   {
     static const bool mfma_on = !(getenv("MRGCN_MIX_MFMA") && atoi(getenv("MRGCN_MIX_MFMA")) == 0);

@@ -1,6 +1,9 @@
-"""Multi-GPU glue.  This round the path runs as independent replicas: the only
-cross-rank traffic is the barrier and the max-over-ranks of the timed region, over
-torch.distributed (RCCL on GPUs, gloo in the CPU tests)."""
+"""Process-group glue shared by both multi-GPU modes, over torch.distributed (RCCL on GPUs, gloo in
+the CPU tests): process-group start-up from the torchrun environment, the barrier and the max-over-ranks around a
+timed region.  Replicas (`bench.py --gpus N` on a shape that fits one GPU) use nothing else; the node-partitioned
+engine (`mrgcn_amd/partition.py`: reduce-scatter of a layer's output rows in the forward, all-gather of the rows with
+gradient in the backward, all-reduce of the small replicated gradients) issues its collectives itself on the group
+this module initialises."""
 from __future__ import annotations
 
 import os

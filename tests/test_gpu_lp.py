@@ -178,7 +178,7 @@ def test_stored_orders_of_fixed_facts_and_vector_rows_against_the_oracle(H):
     assert not lp.SortedTriples(torch.from_numpy(facts).cuda(), N, 2 * P + 1).covers(other)
 
 
-@pytest.mark.parametrize("n,N,R", [(1, 5, 3), (5000, 700, 19), (54423, 14541, 475)])
+@pytest.mark.parametrize("n,N,R", [(1, 5, 3), (5000, 700, 19), (54423, 14541, 475), (30000, 40000, 7), (9000, 50, 20000)])
 def test_counting_sort_orders_are_sorted_permutations(n, N, R):
     import ctypes as C
     from mrgcn_amd import _lib as L

@@ -1,9 +1,13 @@
 #!/bin/bash
 # Regenerates every measurement artefact under profiles/ from the tree it runs in (on a GPU box):
-#   tools/regen_profiles.sh <round-tag, e.g. r02>      -> gpurun_out/<tag>/...   (copy into profiles/ afterwards)
-# Passes: (1) SpMM PMC -> spmm_pmc_latest.json, (2) bench line, (3) rocprofv3 --kernel-trace --stats of the same command,
-# (4) epoch PMC (memory + SQ sets) for the weight_I streamers and the transforms, (5) seeds 0,1,2, fb15k, ref_int8,
-# (6) the encoders' product probe + MFMA counters, (7) the next-rows probe (mini-batch, encoders, ingestion).
+#   tools/regen_profiles.sh <round-tag, e.g. r04>      -> gpurun_out/<tag>/...   (copy into profiles/ afterwards)
+# Passes: (1) SpMM PMC for the two headline shapes -> spmm_pmc_latest.json (AM, F = 10, k_spmm3) and
+# spmm_pmc_fb15k.json (FB15k-237, F = 200, k_spmm<64>): the bench lines quote them (digest-checked),
+# (2) the default bench line (headline + seeds 0-2 + the six side workloads under extra.workloads),
+# (3) rocprofv3 --kernel-trace --stats of the same command -> kernel stats, trace medians, the epoch's launch sequence,
+# (4) epoch PMC (memory + SQ sets) for the weight_I streamers and the transforms -> epoch_pmc.md and, with (3),
+# kernel_roofline.md, (5) the fb15k line + its launch sequence, (6) the encoders' product probe + MFMA counters,
+# (7) the next-rows probe (mini-batch incl. the masked pass, encoders, ingestion), (8) the halo-size probe.
 tag=${1:-rXX}
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
@@ -13,26 +17,31 @@ bash tools/pmc_passes.sh $o/pmc_spmm mem -- python3 tools/spmm_probe.py --ld 10 
 python3 tools/make_spmm_pmc_json.py $o/pmc_spmm "k_spmm3<" > $o/spmm_pmc_latest.json
 python3 tools/pmc_summary.py $o k_spmm3 > $o/spmm_pmc.md
 rm -rf $o/pmc_spmm_*/
-cp $o/spmm_pmc_latest.json profiles/spmm_pmc_latest.json   # the bench line quotes it (digest-checked)
+bash tools/pmc_passes.sh $o/pmc_spfb mem -- python3 tools/spmm_probe.py --workload fb15k --F 200 --ld 200 --row-bytes 800 --iters 10
+python3 tools/make_spmm_pmc_json.py $o/pmc_spfb "k_spmm<64" fb15k 200 > $o/spmm_pmc_fb15k.json
+python3 tools/pmc_summary.py $o "k_spmm<64" > $o/spmm_pmc_fb15k.md
+rm -rf $o/pmc_spfb_*/
+cp $o/spmm_pmc_latest.json profiles/spmm_pmc_latest.json   # the bench lines quote them (digest-checked)
+cp $o/spmm_pmc_fb15k.json profiles/spmm_pmc_fb15k.json
 # clocks / power beside the bench line (one sample per 0.5 s while it runs; needs nothing but read access)
-( for i in $(seq 1 200); do rocm-smi --showclocks --showpower --csv 2>/dev/null | tr '\n' ' '; echo; sleep 0.5; done > $o/rocm_smi_during_bench.txt ) &
+( for i in $(seq 1 400); do rocm-smi --showclocks --showpower --csv 2>/dev/null | tr '\n' ' '; echo; sleep 0.5; done > $o/rocm_smi_during_bench.txt ) &
 smi_pid=$!
-python3 bench.py --steps 20 --warmup 3 > $o/bench_line.json 2> $o/bench_line.err
+python3 bench.py > $o/bench_line.json 2> $o/bench_line.err
 kill $smi_pid 2>/dev/null; wait $smi_pid 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-renumbered-extra --no-reference-loop > $o/bench_under_rocprof.json 2> $o/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-seeds --no-side-workloads > $o/bench_under_rocprof.json 2> $o/bench_under_rocprof.err
 python3 tools/prof_summary.py $o/stats 40 > $o/epoch_kernel_stats.md
 python3 tools/trace_summary.py $o/stats > $o/epoch_kernel_trace_medians.md 2>/dev/null
 python3 tools/epoch_sequence.py $o/stats > $o/epoch_sequence.md 2>/dev/null
-rm -rf $o/stats
-bash tools/pmc_passes.sh $o/pmc_epoch all -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-literal-spmm --no-graph
-for k in k_mix_fwd k_mix_bwd k_adam_rows k_xform_mfma_fwd k_xform_mfma_dw k_spmm_t_live; do
-  echo "## $k"; python3 tools/pmc_summary.py $o $k | tail -n +3
+bash tools/pmc_passes.sh $o/pmc_epoch all -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-literal-spmm --no-graph --no-seeds --no-side-workloads
+for k in k_mix_fwd k_mix_bwd_sup k_dcomp k_adam_rows k_xform_mfma_fwd k_xform_mfma_dw "k_spmm<" k_spmm3; do
+  echo "## $k"; python3 tools/pmc_summary.py $o "$k" | tail -n +3
 done > $o/epoch_pmc.md
-rm -rf $o/pmc_epoch_*/
-python3 tools/seed_median.py > $o/seeds.json 2> $o/seeds.err
+python3 tools/roofline_table.py $o/stats $o/bench_line.json $o > $o/kernel_roofline.md 2> $o/kernel_roofline.err
+rm -rf $o/stats $o/pmc_epoch_*/
 python3 bench.py --workload fb15k > $o/bench_fb15k.json 2> $o/bench_fb15k.err
-python3 bench.py --value-mode ref_int8 --no-cpu-baseline > $o/bench_ref_int8.json 2> $o/bench_ref_int8.err
-for w in aifb mutag synth10m; do python3 bench.py --workload $w --no-cpu-baseline > $o/bench_$w.json 2> $o/bench_$w.err; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_lp -o run -- python3 bench.py --workload fb15k --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $o/bench_fb15k_prof.err
+python3 tools/epoch_sequence.py $o/stats_lp k_corrupt_triples > $o/lp_epoch_sequence.md 2>&1
+rm -rf $o/stats_lp
 # (6) the encoders' tiled product over the TCNN-M shapes: per-product rates, MFMA counters; (7) the next-rows probe
 python3 tools/gemm_probe.py > $o/gemm_probe.txt 2> $o/gemm_probe.err
 python3 tools/gemm_probe.py --json > $o/gemm_probe.json 2>> $o/gemm_probe.err
@@ -40,4 +49,5 @@ bash tools/pmc_passes.sh $o/pmc_mm mfma -- python3 tools/gemm_probe.py --iters 3
 python3 tools/pmc_summary.py $o k_mm_tile > $o/mfma_mm.md
 rm -rf $o/pmc_mm_*/
 python3 tools/next_rows_probe.py > $o/next_rows.json 2> $o/next_rows.err
+python3 tools/halo_probe.py > $o/halo.json 2> $o/halo.err
 ls -la $o
