@@ -641,17 +641,52 @@ int build_rel_order(mrgcn_plan *p, Scratch &sc, hipStream_t s, int64_t band, boo
   int rel_chunk = kRelChunk;
   if (const char *e = getenv("MRGCN_REL_CHUNK"))  // experiments; the live-column lists hold kRelChunk
     rel_chunk = (atoi(e) > 15 && atoi(e) <= kRelChunk) ? atoi(e) : rel_chunk;
-  std::vector<int32_t> rel, beg, end;
+  std::vector<int32_t> rel, beg, end, cband;
   std::vector<std::vector<int32_t>> by_rel(R);
   for (int64_t g = 0; g < ngroups; ++g) {
     const int32_t r = (int32_t)(g % R);
     for (int32_t b0 = h_gptr[g]; b0 < h_gptr[g + 1]; b0 += rel_chunk) {
-      by_rel[r].push_back((int32_t)rel.size());
       rel.push_back(r);
       beg.push_back(b0);
       end.push_back(std::min(b0 + rel_chunk, h_gptr[g + 1]));
+      cband.push_back((int32_t)(g / R));
     }
   }
+  // XCD-aware chunk order: workgroup b of a launch runs on XCD b mod 8 (MI355X_MICROARCH.md), each with its own L2.
+  // With the chunks in plain (band, relation) order the ~2 k resident blocks of a transform spread every active band
+  // over all eight L2s; dealt out so that the chunks of band k all get block ids = k mod 8, a band's source rows are
+  // fetched into ONE L2 and the re-reads of a row by the node's other relations hit there — which is what lets a band
+  // be small enough to fit (MRGCN_NODE_BAND).  Positions a short list leaves open take the next chunk of another list
+  // (the pattern degrades, nothing breaks).
+  static const int xcd_order = getenv("MRGCN_XCD_ORDER") ? atoi(getenv("MRGCN_XCD_ORDER")) : 0;
+  if (xcd_order > 0 && !rel.empty()) {
+    const int X = 8;
+    std::vector<std::vector<int32_t>> lists(X);
+    for (size_t c = 0; c < rel.size(); ++c) lists[cband[c] % X].push_back((int32_t)c);
+    std::vector<size_t> at(X, 0);
+    std::vector<int32_t> order;
+    order.reserve(rel.size());
+    while (order.size() < rel.size()) {
+      const int x = (int)(order.size() % X);
+      int pick = x;
+      if (at[pick] >= lists[pick].size()) {  // this XCD's list is used up: the longest remaining one gives
+        size_t best = 0;
+        for (int y = 0; y < X; ++y)
+          if (lists[y].size() - at[y] > best) { best = lists[y].size() - at[y]; pick = y; }
+      }
+      order.push_back(lists[pick][at[pick]++]);
+    }
+    std::vector<int32_t> rel2(rel.size()), beg2(rel.size()), end2(rel.size());
+    for (size_t b = 0; b < order.size(); ++b) {
+      rel2[b] = rel[order[b]];
+      beg2[b] = beg[order[b]];
+      end2[b] = end[order[b]];
+    }
+    rel.swap(rel2);
+    beg.swap(beg2);
+    end.swap(end2);
+  }
+  for (size_t c = 0; c < rel.size(); ++c) by_rel[rel[c]].push_back((int32_t)c);
   if (set_top_rel) {  // the relation with the most compact columns: k_mix_bwd_nm keeps its dcomp row in registers
     std::vector<int64_t> per_rel(R, 0);
     for (int64_t g = 0; g < ngroups; ++g) per_rel[g % R] += h_gptr[g + 1] - h_gptr[g];
