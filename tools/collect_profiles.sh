@@ -1,13 +1,16 @@
 #!/bin/bash
 # Copies what tools/regen_profiles.sh left under gpurun_out/<tag>/ into profiles/<tag>_* (the tracked artefacts).
-tag=${1:-rXX}
-o=gpurun_out/$tag
-for f in bench_line.json bench_fb15k.json bench_ref_int8.json bench_aifb.json bench_mutag.json bench_synth10m.json bench_under_rocprof.json epoch_kernel_stats.md \
-         epoch_kernel_trace_medians.md epoch_sequence.md epoch_pmc.md seeds.json spmm_pmc.md next_rows.json \
-         gemm_probe.txt gemm_probe.json rocm_smi_during_bench.txt; do
+#   tools/collect_profiles.sh <tag of the regen run> [<tag under profiles/>, default the same]
+src=${1:-rXX}
+tag=${2:-$src}
+o=gpurun_out/$src
+for f in bench_line.json bench_fb15k.json bench_under_rocprof.json epoch_kernel_stats.md \
+         epoch_kernel_trace_medians.md epoch_sequence.md epoch_pmc.md kernel_roofline.md lp_epoch_sequence.md spmm_pmc.md \
+         spmm_pmc_fb15k.md next_rows.json halo.json gemm_probe.txt gemm_probe.json rocm_smi_during_bench.txt; do
   [ -s $o/$f ] && cp $o/$f profiles/${tag}_$f
 done
 cp $o/spmm_pmc_latest.json profiles/spmm_pmc_latest.json
+cp $o/spmm_pmc_fb15k.json profiles/spmm_pmc_fb15k.json
 {
   echo "# MFMA counters of the tiled product (k_mm_tile) over the TCNN-M products (tools/gemm_probe.py, 2 048 literals of 37 x 300), rocprofv3 --pmc passes (tools/pmc_passes.sh <out> mfma)"
   echo
