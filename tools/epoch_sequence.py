@@ -12,6 +12,10 @@ sys.path.insert(0, __file__.rsplit("/", 1)[0])
 from prof_summary import short  # noqa: E402
 
 
+# kernels of this package that live outside namespace mrgcn (file-local helpers of rgcn_fused.hip / distmult.hip)
+OWN_UNSCOPED = ("k_basis_contract", "k_corrupt_triples", "k_count3", "k_scan3", "k_fill3", "k_random_subset")
+
+
 def main():
     f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]
     first = sys.argv[2] if len(sys.argv) > 2 else "k_xform_mfma_fwd<1, false, 16"
@@ -32,7 +36,7 @@ def main():
         gap = max(0, s - busy_until) / 1e3
         busy_until = max(busy_until, e)
         name = short(r["Kernel_Name"])
-        if "mrgcn::" not in name:
+        if "mrgcn::" not in name and not any(k in name for k in OWN_UNSCOPED):
             other += (e - s) / 1e3
         print(f"| {i} | {(s - t0) / 1e3:.1f} | {(e - s) / 1e3:.1f} | {gap:.1f} | {r.get('Queue_Id', '')} | "
               f"{r['Grid_Size_X']} | {name} |")
