@@ -322,6 +322,49 @@ def side_workloads(args, dev):
     return out
 
 
+def minibatch_record(args, dev, scale=0.25, batch_nodes=1024, steps=24, warm=6):
+    """extra.minibatch of the default line: a two-layer model on the AM/4 graph trained on a
+    freshly sampled batch of 1 024 nodes every step, nothing prepared ahead — the batch is a chain of forward supports on
+    the full graph's plan (data.batch.A_BatchMasked, csrc/masked.hip), the step is mrgcn_amd.train.train_step.
+    ms_per_step covers everything between two steps: sampling the ids on the host, the two support builds (one host
+    wait), forward, backward, clip, Adam."""
+    import scipy.sparse as sp
+    import torch
+    from mrgcn_amd import synth
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.plan import GraphPlan
+    from mrgcn_amd.train import ClipAdam, train_step
+    g = synth.make_graph("am", seed=args.seed, scale=scale)
+    N, R = g.num_nodes, g.num_relations
+    A = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
+    dims = synth.layer_dims("am")
+    mods = [(dims[0][0], dims[0][1], "mrgcn", torch.nn.ReLU()), (dims[1][0], dims[1][1], "mrgcn", None)]
+    torch.manual_seed(args.seed)
+    model = RGCN(mods, R, N, synth.SHAPES["am"]["bases"], 0.0, False, True, False).to(dev)
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    X = torch.randn((N, dims[0][0]), device=dev)
+    plan = GraphPlan.from_csr(A, N, R, value_mode="ref_int8", device=dev, operand_row_bytes=model.operand_row_bytes())
+    rng = np.random.default_rng(args.seed)
+    ys = torch.from_numpy(rng.integers(0, dims[-1][1], batch_nodes)).to(dev)
+    rows = torch.arange(batch_nodes, device=dev)
+    sizes = None
+    for k in range(steps):
+        if k == warm:
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+        am = mb.A_BatchMasked(plan, np.sort(rng.choice(N, batch_nodes, replace=False)), 2)
+        loss = train_step(model, lambda: model(X, am), rows, ys, opt)
+        sizes = [(s_.NR, s_.NL, s_.E) for s_ in am.supports]
+        am.close()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / (steps - warm) * 1e3
+    return {"ms_per_step": ms, "graph": "am x %g (N=%d, R=%d, nnz=%d)" % (scale, N, R, A.nnz), "batch_nodes": batch_nodes,
+            "layers": dims, "resampled_every_step": True, "prepared_ahead": False,
+            "levels_rows_neighbours_entries": sizes, "final_loss": float(loss),
+            "path": "masked pass over the full graph's plan (A_BatchMasked + train_step), in line"}
+
+
 def cpu_baseline(args, shape_name):
     """The reference's ATen op sequence (oracle/aten_literal.py, pinned against the reference's golden vectors)
     timed on this host's cores on bounded samples of the workload: the thread count is the best of a short sweep
@@ -1012,6 +1055,12 @@ def main():
             step = plan = model = A = X = idx = tgt = None
             drop_live()
             extra["workloads"] = side_workloads(args, dev)
+            try:  # (fail-soft like the side workloads)
+                extra["minibatch"] = minibatch_record(args, dev)
+            except Exception as e:  # noqa: BLE001
+                extra["minibatch"] = {"error": (type(e).__name__ + ": " + str(e))[:300]}
+            gc.collect()
+            torch.cuda.empty_cache()
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:

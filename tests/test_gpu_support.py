@@ -301,3 +301,59 @@ def test_forward_support_mix_and_transform(B, F, K):
         dW2.data_ptr(), ws.data_ptr(), ws.numel(), 0, s))
     assert torch.equal(dW2, dW)
     sup.close()
+
+
+def test_support_chain_equals_supports_built_one_by_one():
+    """mrgcn_support_create_chain (one host wait for all levels): level i + 1 is the support of level i's NODE_FLAGS,
+    array for array what building them one after the other gives."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphSupport
+    rng = np.random.default_rng(11)
+    N, R = 2500, 6
+    rows, cols, vals = _random_graph(rng, N, N, R, 9000, hub_rows=2, hub_len=600, hub_cols=3)
+    plan = _plan_from_coo(rows, cols, vals, N, N, R)
+    flags = np.zeros(N, dtype=np.uint8)
+    flags[rng.choice(N, 5, replace=False)] = 1
+    ft = torch.from_numpy(flags).cuda()
+    chain = GraphSupport.chain(plan, ft, 3, forward=True)
+    f = ft
+    for lvl in range(3):
+        one = GraphSupport(plan, f, forward=True)
+        c = chain[lvl]
+        assert (c.NR, c.L, c.E, c.NL) == (one.NR, one.L, one.E, one.NL)
+        for which in (L.SUP_COL_FLAGS, L.SUP_NODE_FLAGS, L.SUP_LCOL, L.SUP_LREL, L.SUP_NLPTR, L.SUP_LPTR, L.SUP_LROW,
+                      L.SUP_LVAL, L.SUP_LNODE, L.SUP_LPERM, L.SUP_FROW, L.SUP_FPTR, L.SUP_FCOL, L.SUP_FVAL,
+                      L.SUP_LNODE_ORD, L.SUP_ROWRANK):
+            np.testing.assert_array_equal(c.export(which), one.export(which), err_msg=f"level {lvl} array {which}")
+        f = one.node_flags()
+    assert chain[0].NR == 5 and chain[1].NR == chain[0].NL and chain[2].NR == chain[1].NL
+
+
+def test_support_of_an_empty_row_set_and_of_rows_without_entries():
+    """No flagged row at all, and flagged rows that hold no entry: every count is zero, the products write nothing
+    (or zeros + bias), nothing faults."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphSupport
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    N, R = 400, 3
+    rows, cols, vals = _random_graph(rng, N, N, R, 900, hub_rows=0, hub_len=10, hub_cols=0)
+    keep = rows >= 20              # rows 0..19 hold no entry
+    rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    plan = _plan_from_coo(rows, cols, vals, N, N, R)
+    s = torch.cuda.current_stream().cuda_stream
+    for flagged in ([], [3, 7, 11]):
+        flags = np.zeros(N, dtype=np.uint8)
+        flags[flagged] = 1
+        chain = GraphSupport.chain(plan, torch.from_numpy(flags).cuda(), 2, forward=True)
+        assert chain[0].NR == len(flagged) and chain[0].L == chain[0].E == chain[0].NL == 0
+        assert chain[1].NR == 0 and chain[1].L == 0
+        F = 10
+        D = torch.zeros((1, 12), device="cuda")
+        Y = torch.full((max(len(flagged), 1), F), 7.0, device="cuda")
+        bias = torch.arange(F, dtype=torch.float32, device="cuda")
+        L.check(lib.mrgcn_support_spmm_fwd_f32(chain[0].handle, 0, D.data_ptr(), 12, F, Y.data_ptr(), F, bias.data_ptr(), 0, s))
+        if flagged:
+            np.testing.assert_array_equal(Y.cpu().numpy(), np.tile(np.arange(F, dtype=np.float32), (len(flagged), 1)))
+        for c in chain:
+            c.close()

@@ -449,3 +449,40 @@ def test_frontier_kernels_edge_cases_through_the_c_abi():
                 assert np.array_equal(col_sl.cpu().numpy(), (c_h // N) * nb_h.size + pos)
             else:
                 assert col_sl.numel() == 0
+
+
+@pytest.mark.gpu
+def test_masked_batch_with_node_dropout_and_three_layers_matches_the_slice_path():
+    """Three layers (the hidden one takes both the feature term's compact input gradient and the ReLU mask hand-over)
+    and the unfused activation path (ReLU applied outside the product when dropout is on, p = 0 draws kept equal by
+    seeding): masked pass = slice path, logits and gradients."""
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.plan import GraphPlan
+    import scipy.sparse as sp
+    from mrgcn_amd import synth
+    g = synth.make_graph("aifb", seed=2, scale=0.2)
+    N, R = g.num_nodes, g.num_relations
+    A = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
+    rng = np.random.default_rng(7)
+    K, C = 5, 3
+    X = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
+    idx = rng.choice(N, 17, replace=False)        # unsorted on purpose
+    torch.manual_seed(0)
+    model = RGCN([(K, 8, "mrgcn", torch.nn.ReLU()), (8, 6, "mrgcn", torch.nn.ReLU()), (6, C, "mrgcn", None)], R, N, 2, 0.0,
+                 False, True, False).cuda()
+    plan = GraphPlan.from_csr(A, N, R, value_mode="norm_f32")
+    outs = []
+    for masked in (False, True):
+        ab = (mb.A_BatchMasked(plan, idx, 3) if masked
+              else mb.A_BatchDevice(mb.DeviceCSR(A), idx, 3, value_mode="norm_f32"))
+        model.zero_grad()
+        Xb = X[ab.neighbours[-1]].clone().requires_grad_(True)
+        logits = model(Xb, ab)
+        (logits * torch.arange(1, C + 1, device="cuda")).sum().backward()
+        outs.append((logits.detach().cpu().numpy(), Xb.grad.cpu().numpy(),
+                     {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()}))
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-3, atol=1e-5)
+    for n in outs[0][2]:
+        np.testing.assert_allclose(outs[1][2][n], outs[0][2][n], rtol=1e-3, atol=1e-5, err_msg=n)
