@@ -11,6 +11,9 @@
 #include <unordered_map>
 #include <vector>
 
+#include <chrono>
+#include <cstdio>
+
 #include "common.hpp"
 
 namespace mrgcn {
@@ -1350,9 +1353,19 @@ __global__ void k_sup_rowcount(const uint8_t *__restrict__ row_flags, int64_t ro
   int32_t nch = lg ? (len + chunk - 1) / chunk : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nch += __shfl_xor(nch, o, kWave);
+  // one pair of global adds per BLOCK: the sample of a lower mini-batch layer is mostly hubs (thousands of long rows:
+  // a pair of same-address atomics per wave was 28 of this kernel's 33 us)
+  __shared__ int32_t s_tot[2];
+  if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
+  __syncthreads();
   if (lane == 0 && nlong > 0) {
-    atomicAdd(&totals[kTotFLong], nlong);
-    atomicAdd(&totals[kTotFChunks], nch);
+    atomicAdd(&s_tot[0], nlong);
+    atomicAdd(&s_tot[1], nch);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_tot[0] > 0) {
+    atomicAdd(&totals[kTotFLong], s_tot[0]);
+    atomicAdd(&totals[kTotFChunks], s_tot[1]);
   }
 }
 // compact list of the flagged rows (arrays sized for every row): rank / id / entry range
@@ -1411,9 +1424,17 @@ __global__ void k_sup_colflags(const uint8_t *__restrict__ col_flags, const int3
   int32_t nch = lg ? (cnt + chunk - 1) / chunk : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nch += __shfl_xor(nch, o, kWave);
+  __shared__ int32_t s_tot[2];  // (one pair of global adds per block, as in k_sup_rowcount)
+  if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
+  __syncthreads();
   if (lane == 0 && nlong > 0) {
-    atomicAdd(&totals[kTotTLong], nlong);
-    atomicAdd(&totals[kTotTChunks], nch);
+    atomicAdd(&s_tot[0], nlong);
+    atomicAdd(&s_tot[1], nch);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_tot[0] > 0) {
+    atomicAdd(&totals[kTotTLong], s_tot[0]);
+    atomicAdd(&totals[kTotTChunks], s_tot[1]);
   }
 }
 __global__ void k_sup_totals(const int32_t *__restrict__ lpos, int64_t ncols, const int32_t *__restrict__ ckept,
@@ -1561,33 +1582,53 @@ int support_stage1(SupStage &b, hipStream_t s) {
   return MRGCN_OK;
 }
 
-// the chunk lists of one order from its group pointers (host), appended to `up` as chunk_ptr[R+1] | ids | rel | beg | end
-void order_chunks_host(const int32_t *h_gptr, int64_t ngroups, int64_t R, mrgcn_support::Order *out,
-                       std::vector<int32_t> *up, size_t offs[5]) {
-  std::vector<int32_t> rel, beg, end, ids_by_rel, cptr_rel(R + 1, 0);
-  std::vector<std::vector<int32_t>> by_rel(R);
+// the chunk lists of one order from its group pointers (host): chunk_ptr[R+1] | ids | rel | beg | end, every array
+// with at least one element.  Two passes, no allocation per call: `count` sizes, `write` fills `dst` (pinned memory).
+size_t order_chunks_count(const int32_t *h_gptr, int64_t ngroups, int64_t R, std::vector<int32_t> &cnt_rel,
+                          int32_t *n_chunks, int32_t *max_chunks) {
+  cnt_rel.assign((size_t)R, 0);
+  int32_t n = 0;
+  for (int64_t g = 0; g < ngroups; ++g) {
+    const int32_t len = h_gptr[g + 1] - h_gptr[g];
+    if (len <= 0) continue;
+    const int32_t c = (len + kRelChunk - 1) / kRelChunk;
+    cnt_rel[(size_t)(g % R)] += c;
+    n += c;
+  }
+  int32_t mx = 0;
+  for (int64_t r = 0; r < R; ++r) mx = std::max(mx, cnt_rel[(size_t)r]);
+  *n_chunks = n;
+  *max_chunks = mx;
+  return (size_t)(R + 1) + 4 * (size_t)std::max(n, 1);
+}
+void order_chunks_write(const int32_t *h_gptr, int64_t ngroups, int64_t R, const std::vector<int32_t> &cnt_rel,
+                        int32_t n_chunks, int32_t *dst, size_t base, size_t offs[5], std::vector<int32_t> &fill) {
+  const size_t m = (size_t)std::max(n_chunks, 1);
+  offs[0] = base;
+  offs[1] = offs[0] + (size_t)(R + 1);
+  offs[2] = offs[1] + m;
+  offs[3] = offs[2] + m;
+  offs[4] = offs[3] + m;
+  int32_t *cptr = dst + offs[0], *ids = dst + offs[1], *rel = dst + offs[2], *beg = dst + offs[3], *end = dst + offs[4];
+  fill.assign((size_t)R, 0);
+  int32_t run = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    cptr[r] = run;
+    fill[(size_t)r] = run;
+    run += cnt_rel[(size_t)r];
+  }
+  cptr[R] = run;
+  if (n_chunks == 0) ids[0] = rel[0] = beg[0] = end[0] = 0;
+  int32_t ci = 0;
   for (int64_t g = 0; g < ngroups; ++g) {
     const int32_t r = (int32_t)(g % R);
     for (int32_t b0 = h_gptr[g]; b0 < h_gptr[g + 1]; b0 += kRelChunk) {
-      by_rel[r].push_back((int32_t)rel.size());
-      rel.push_back(r);
-      beg.push_back(b0);
-      end.push_back(std::min(b0 + kRelChunk, h_gptr[g + 1]));
+      ids[fill[(size_t)r]++] = ci;
+      rel[ci] = r;
+      beg[ci] = b0;
+      end[ci] = std::min(b0 + kRelChunk, h_gptr[g + 1]);
+      ++ci;
     }
-  }
-  out->max_chunks = 0;
-  for (int64_t r = 0; r < R; ++r) {
-    cptr_rel[r] = (int32_t)ids_by_rel.size();
-    ids_by_rel.insert(ids_by_rel.end(), by_rel[r].begin(), by_rel[r].end());
-    out->max_chunks = std::max(out->max_chunks, (int32_t)by_rel[r].size());
-  }
-  cptr_rel[R] = (int32_t)ids_by_rel.size();
-  out->n_chunks = (int32_t)rel.size();
-  const std::vector<int32_t> *parts[5] = {&cptr_rel, &ids_by_rel, &rel, &beg, &end};
-  for (int i = 0; i < 5; ++i) {
-    offs[i] = up->size();
-    up->insert(up->end(), parts[i]->begin(), parts[i]->end());
-    if (parts[i]->empty()) up->push_back(0);  // (every array keeps at least one element)
   }
 }
 
@@ -1628,17 +1669,61 @@ int long_rows_known(mrgcn_support *q, const int32_t *ptr, int64_t rows, hipStrea
   return rc;
 }
 
-// the orders' chunk lists: host work on the landed group pointers + one upload per support, all of them before any
-// stage-2 kernel is queued (the device is idle after the wait: the blocking copies cost their latency only)
-int support_upload(SupStage &b) {
-  mrgcn_support *q = b.q;
-  const int64_t R = q->plan->num_relations;
-  const int32_t *land = g_land + b.land_off;
-  std::vector<int32_t> up;
-  order_chunks_host(land + kTotCount, b.ow.ngroups, R, &q->wide, &up, b.offs_w);
-  if (q->has_narrow) order_chunks_host(land + kTotCount + b.ow.ngroups + 1, b.on.ngroups, R, &q->narrow, &up, b.offs_n);
-  MRGCN_HIP_TRY(sup_alloc(q, &b.blk, (int64_t)up.size()));
-  MRGCN_HIP_TRY(hipMemcpy(b.blk, up.data(), up.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+// pinned staging of the chunk lists on their way to the device (grow-only; the event says when the last upload has
+// been read)
+int32_t *g_up = nullptr;
+size_t g_up_ints = 0;
+hipEvent_t g_up_done = nullptr;
+bool g_up_pending = false;
+
+// the orders' chunk lists of every level: host work on the landed group pointers, then one asynchronous upload per
+// support out of pinned memory, queued in front of the stage-2 kernels
+int supports_upload(std::vector<SupStage> &st, hipStream_t s) {
+  const int n = (int)st.size();
+  static thread_local std::vector<int32_t> fill;
+  struct Sz { size_t w = 0, n = 0; std::vector<int32_t> cw, cn; };
+  std::vector<Sz> sz(n);
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    mrgcn_support *q = st[i].q;
+    const int64_t R = q->plan->num_relations;
+    const int32_t *land = g_land + st[i].land_off;
+    sz[i].w = order_chunks_count(land + kTotCount, st[i].ow.ngroups, R, sz[i].cw, &q->wide.n_chunks, &q->wide.max_chunks);
+    if (q->has_narrow)
+      sz[i].n = order_chunks_count(land + kTotCount + st[i].ow.ngroups + 1, st[i].on.ngroups, R, sz[i].cn,
+                                   &q->narrow.n_chunks, &q->narrow.max_chunks);
+    total += sz[i].w + sz[i].n;
+  }
+  if (g_up_pending) {  // (the previous build's uploads: long done by now)
+    MRGCN_HIP_TRY(hipEventSynchronize(g_up_done));
+    g_up_pending = false;
+  }
+  if (total > g_up_ints) {
+    if (g_up) (void)hipHostFree(g_up);
+    g_up = nullptr;
+    g_up_ints = 0;
+    const size_t want = total + total / 2 + 4096;
+    MRGCN_HIP_TRY(hipHostMalloc((void **)&g_up, want * sizeof(int32_t), hipHostMallocDefault));
+    g_up_ints = want;
+  }
+  if (!g_up_done) MRGCN_HIP_TRY(hipEventCreateWithFlags(&g_up_done, hipEventDisableTiming));
+  size_t at = 0;
+  for (int i = 0; i < n; ++i) {
+    mrgcn_support *q = st[i].q;
+    const int64_t R = q->plan->num_relations;
+    const int32_t *land = g_land + st[i].land_off;
+    int32_t *dst = g_up + at;  // offsets are relative to this level's block
+    order_chunks_write(land + kTotCount, st[i].ow.ngroups, R, sz[i].cw, q->wide.n_chunks, dst, 0, st[i].offs_w, fill);
+    if (q->has_narrow)
+      order_chunks_write(land + kTotCount + st[i].ow.ngroups + 1, st[i].on.ngroups, R, sz[i].cn, q->narrow.n_chunks, dst,
+                         sz[i].w, st[i].offs_n, fill);
+    const size_t ints = sz[i].w + sz[i].n;
+    MRGCN_HIP_TRY(sup_alloc(q, &st[i].blk, (int64_t)ints));
+    MRGCN_HIP_TRY(hipMemcpyAsync(st[i].blk, dst, ints * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    at += ints;
+  }
+  MRGCN_HIP_TRY(hipEventRecord(g_up_done, s));
+  g_up_pending = true;
   return MRGCN_OK;
 }
 
@@ -1732,6 +1817,9 @@ int build_support_chain(mrgcn_support **qs, int n, const uint8_t *row_flags, hip
     MRGCN_HIP_TRY(hipHostMalloc((void **)&g_land, (size_t)(per * n) * sizeof(int32_t), hipHostMallocDefault));
     g_land_ints = (size_t)(per * n);
   }
+  static const bool timing = getenv("MRGCN_SUP_TIMING") && atoi(getenv("MRGCN_SUP_TIMING")) != 0;
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
   int rc;
   for (int i = 0; i < n; ++i) {
     st[i].q = qs[i];
@@ -1740,11 +1828,20 @@ int build_support_chain(mrgcn_support **qs, int n, const uint8_t *row_flags, hip
     st[i].land_off = per * i;
     if ((rc = support_stage1(st[i], s))) return rc;
   }
+  const auto t1 = clk::now();
   MRGCN_HIP_TRY(hipStreamSynchronize(s));  // the one wait of the build
-  for (int i = 0; i < n; ++i)
-    if ((rc = support_upload(st[i]))) return rc;
+  const auto t2 = clk::now();
+  if ((rc = supports_upload(st, s))) return rc;
+  const auto t3 = clk::now();
   for (int i = 0; i < n; ++i)
     if ((rc = support_stage2(st[i], s))) return rc;
+  if (timing) {
+    const auto us = [](clk::time_point a, clk::time_point b) {
+      return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count();
+    };
+    fprintf(stderr, "mrgcn support chain (%d): stage 1 queued %ld us, wait %ld us, chunk lists + uploads %ld us, stage 2 queued %ld us\n",
+            n, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, clk::now()));
+  }
   return MRGCN_OK;  // (stream ordered from here on: the scratch goes back tagged with the stream)
 }
 
