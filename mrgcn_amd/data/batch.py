@@ -252,9 +252,16 @@ class A_Batch:
 
 
 class MiniBatch(Batch):
-    def __init__(self, A=None, X=None, batch_node_idx=None, num_layers=None, value_mode="ref_int8"):
+    def __init__(self, A=None, X=None, batch_node_idx=None, num_layers=None, value_mode="ref_int8", plan=None):
+        """`plan` (a GraphPlan of the FULL graph on the GPU) instead of `A`: the batch structure is a masked batch on
+        that plan (A_BatchMasked: no slices, no per-batch plans); everything else — `X` subset to the outermost
+        neighbours, `as_tensors_`, `to(devices)`, `MRGCN.forward(batch)` — is unchanged."""
         super().__init__(batch_node_idx)
-        if A is not None:
+        if plan is not None:
+            self.A = A_BatchMasked(plan, self.node_index, num_layers)
+            if X is not None:
+                self.X = mksubset(X, self.A.neighbours[-1].cpu().numpy())
+        elif A is not None:
             self.A = A_Batch(A, self.node_index, num_layers, value_mode=value_mode)
             if X is not None:  # not featureless: features of the outermost neighbours
                 self.X = mksubset(X, self.A.neighbours[-1])

@@ -125,6 +125,32 @@ def test_mrgcn_minibatch_boundary():
 
 
 @pytest.mark.gpu
+def test_mrgcn_minibatch_boundary_on_the_full_plan():
+    """The same boundary with the batch as a masked batch on the full graph's plan: MiniBatch(plan=...)."""
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.data.batch import scipy_sparse_to_pytorch_sparse
+    from mrgcn_amd.models.mrgcn import MRGCN
+    from mrgcn_amd.plan import plan_of
+    g = np.load(GOLD)
+    tag = "fl_b0"
+    fl, B, bias, nl, hidden, classes, xw = [int(v) for v in g[tag + ".meta"]]
+    _, A = util.load_graph("graph_small")
+    N = A.shape[0]
+    R = A.shape[1] // N
+    modules = [(0, hidden, "mrgcn", torch.nn.ReLU()), (hidden, classes, "mrgcn", None)]
+    model = MRGCN(modules, [], R, N, num_bases=B, p_dropout=0.0, featureless=True, bias=False,
+                  gcn_gpu_acceleration=True)
+    model.load_state_dict({"rgcn." + k[len(tag) + 6:]: torch.from_numpy(np.array(g[k])) for k in g.files
+                           if k.startswith(tag + ".init.")}, strict=False)
+    plan = plan_of(scipy_sparse_to_pytorch_sparse(A, dtype=torch.int8).cuda(), N, R)
+    batch = mb.MiniBatch(None, [np.empty((N, 0))], g["batch_idx"], nl, plan=plan)
+    batch.as_tensors_()
+    batch.to(model.devices)
+    logits = model(batch)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g[tag + ".logits"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["ft_b3", "ft_b0_l3"])
 def test_device_built_batch_equals_host_built(tag):
     """A_BatchDevice (gathers + torch.unique on the GPU) against the reference's goldens: same
@@ -328,6 +354,25 @@ def test_masked_batches_train_like_slice_batches():
         l2.append(float(train_step(model, lambda: model(X, ab), rows, ys[k], opt)))
         ab.close()
     np.testing.assert_allclose(l2, l0, rtol=1e-5, atol=1e-6)
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.detach().cpu().numpy(), p0[n], rtol=1e-4, atol=1e-6, err_msg=n)
+
+    # the reference's own loop shape (zero_grad / backward / clip_grad_norm_ / step) with the drop-in optimizer pair
+    from mrgcn_amd import optim as fast
+    torch.manual_seed(0)
+    model = RGCN([(K, 8, "mrgcn", torch.nn.ReLU()), (8, C, "mrgcn", None)], R, N, 3, 0.0, False, True, False).cuda()
+    opt = fast.RowSparseAdam(model.parameters(), lr=0.01)
+    l3 = []
+    for k, i in enumerate(idxs):
+        ab = mb.A_BatchMasked(plan, i, 2)
+        opt.zero_grad()
+        loss = categorical_crossentropy(model(X[ab.neighbours[-1]], ab), rows, ys[k])
+        loss.backward()
+        fast.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        l3.append(float(loss))
+        ab.close()
+    np.testing.assert_allclose(l3, l0, rtol=1e-5, atol=1e-6)
     for n, p in model.named_parameters():
         np.testing.assert_allclose(p.detach().cpu().numpy(), p0[n], rtol=1e-4, atol=1e-6, err_msg=n)
 
