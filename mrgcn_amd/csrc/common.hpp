@@ -67,6 +67,9 @@ struct SparseView {
   const int32_t *chunk_beg = nullptr;  // [n_chunks] first entry
   const int32_t *chunk_end = nullptr;  // [n_chunks] one past last entry
   const int32_t *chunk_row = nullptr;  // [n_chunks] row id when the row is this single chunk, else -(row + 2)
+  // [n_long] arrival counters (zero between launches): with them the wave that delivers the LAST partial sum of a row
+  // of several chunks adds them all, in chunk order, inside the product — no finalize launch.  NULL: two passes.
+  int32_t *ticket = nullptr;
 };
 
 }  // namespace mrgcn
@@ -126,7 +129,7 @@ int segment_sum_arrays(const int32_t *nptr, int64_t num_nodes, int64_t nz_rows, 
 // internal launchers shared with support.hip
 // Y = v . D on an arbitrary CSR-shaped view (spmm.hip); `partials`: v.n_chunks * kWsFeatures floats
 int spmm_on_view(const SparseView &v, const float *D, int64_t ldD, int F, float *Y, int64_t ldY, float *partials,
-                 hipStream_t s, const float *bias = nullptr, int relu = 0);
+                 hipStream_t s, const float *bias = nullptr, int relu = 0);  // (v.ticket set: one launch)
 // the basis mix over explicit arrays (rgcn_fused.hip): entry t of a node list owns columns nptr[t] .. nptr[t+1] (their
 // relations in urel) and reads V block node_ids[t] (NULL: t); row c of M is column c's
 int mix_fwd_arrays(const int32_t *nptr, const int32_t *urel, const int32_t *node_ids, int64_t n_nodes, int64_t ncols,
@@ -229,7 +232,9 @@ struct mrgcn_plan {
   int32_t r3_n_long = 0, r3_n_chunks = 0;
   int32_t *r3_multi = nullptr;  // [r3_n_multi] positions in r3_long_row of the rows that span several chunks
   int32_t r3_n_multi = 0;       // (k_spmm3_finalize runs over these only)
-  int32_t *r3_ticket = nullptr;  // [r3_n_long] arrival counters of the in-kernel finalize (zero between launches)
+  int32_t *r3_ticket = nullptr;  // [ticket_ints] arrival counters of the in-kernel finalize (zero between launches):
+                                 // one per long row of whichever view a product runs on
+  int64_t ticket_ints = 1;
   // k_spmm3's one-wave rows (kMid3Rows < len <= kChunk3Entries); r3_* above describe the longer, blockwise rows
   int32_t *r3s_long_row = nullptr, *r3s_long_cptr = nullptr, *r3s_chunk_beg = nullptr, *r3s_chunk_end = nullptr,
           *r3s_chunk_row = nullptr;
@@ -293,6 +298,7 @@ struct mrgcn_support {
           *t_chunk_row = nullptr;
   int32_t t_n_long = 0, t_n_chunks = 0;
   float *partials = nullptr;
+  int32_t *ticket = nullptr;  // [max(t_n_long, f_n_long)] arrival counters of the products' in-kernel finalize
   // FORWARD arrays (MRGCN_SUPPORT_FORWARD: a mini-batch layer as a masked pass over the full plan — the flagged rows
   // are the batch's sample, the live nodes its neighbours): the flagged rows in rising order with their entries in the
   // plan's row order, columns by live number; ranks so that activations / gradients can stay compact
@@ -324,6 +330,7 @@ struct mrgcn_support {
     v.n_long = t_n_long; v.n_chunks = t_n_chunks; v.long_row = t_long_row; v.long_cptr = t_long_cptr;
     v.chunk_beg = t_chunk_beg; v.chunk_end = t_chunk_end; v.chunk_row = t_chunk_row;
     v.n_multi = t_n_chunks - t_n_long;
+    v.ticket = ticket;
     return v;
   }
   // the forward view (rows = flagged rows by rank) and the transposed view over compact gradients; `use_values` = the
@@ -334,6 +341,7 @@ struct mrgcn_support {
     v.n_long = f_n_long; v.n_chunks = f_n_chunks; v.long_row = f_long_row; v.long_cptr = f_long_cptr;
     v.chunk_beg = f_chunk_beg; v.chunk_end = f_chunk_end; v.chunk_row = f_chunk_row;
     v.n_multi = f_n_chunks - f_n_long;
+    v.ticket = ticket;
     return v;
   }
   mrgcn::SparseView tview_ranked(bool use_values) const {

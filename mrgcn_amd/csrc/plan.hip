@@ -1082,8 +1082,10 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
       return rc;
     // one arrival counter per blockwise row (k_spmm3: the block that brings a row's last partial sum adds them up);
     // zero between launches — the last arriver puts its row's counter back
-    MRGCN_HIP_TRY(plan_alloc(p, &p->r3_ticket, p->r3_n_long));
-    MRGCN_HIP_TRY(hipMemsetAsync(p->r3_ticket, 0, (size_t)std::max<int64_t>(p->r3_n_long, 1) * sizeof(int32_t), s));
+    // (and one per long row of the other views: the general product finishes its split rows the same way)
+    p->ticket_ints = std::max<int64_t>(std::max<int64_t>(std::max(p->r3_n_long, p->r_n_long), std::max(p->q_n_long, p->c_n_long)), 1);
+    MRGCN_HIP_TRY(plan_alloc(p, &p->r3_ticket, p->ticket_ints));
+    MRGCN_HIP_TRY(hipMemsetAsync(p->r3_ticket, 0, (size_t)p->ticket_ints * sizeof(int32_t), s));
   }
   {  // the rows k_spmm3 leaves partial sums of (more than one block): the two-pass form's finalize launches one wave for each
     const int64_t nl = p->r3_n_long;
@@ -1281,7 +1283,7 @@ int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t *
   float *pa = nullptr;
   int32_t *ti = nullptr;
   MRGCN_HIP_TRY(pool_alloc((void **)&pa, (size_t)std::max<int64_t>(p->partials_floats, 1) * sizeof(float), s));
-  const size_t tb = (size_t)std::max<int64_t>(p->r3_n_long, 1) * sizeof(int32_t);
+  const size_t tb = (size_t)std::max<int64_t>(p->ticket_ints, 1) * sizeof(int32_t);
   MRGCN_HIP_TRY(pool_alloc((void **)&ti, tb, s));
   MRGCN_HIP_TRY(hipMemsetAsync(ti, 0, tb, s));  // arrival counters start at zero (and return to zero after every launch)
   p->stream_scratch.push_back({s, pa, ti});
@@ -1799,6 +1801,11 @@ int support_stage2(SupStage &b, hipStream_t s) {
                               &q->f_chunk_beg, &q->f_chunk_end, &q->f_chunk_row)))
       return rc;
     MRGCN_HIP_TRY(sup_alloc(q, &q->f_partials, (int64_t)std::max(q->f_n_chunks, 1) * kWsFeatures));
+  }
+  {
+    const int64_t nt = std::max<int64_t>(std::max(q->t_n_long, q->f_n_long), 1);
+    MRGCN_HIP_TRY(sup_alloc(q, &q->ticket, nt));
+    MRGCN_HIP_TRY(hipMemsetAsync(q->ticket, 0, (size_t)nt * sizeof(int32_t), s));
   }
   if ((rc = stage2_order(b, s, b.ow, p->rperm, p->rnode, blk, offs_w, &q->wide))) return rc;
   if (q->has_narrow && (rc = stage2_order(b, s, b.on, p->n_rperm, p->n_rnode, blk, offs_n, &q->narrow))) return rc;

@@ -104,6 +104,47 @@ __device__ __forceinline__ void gather_fma(const DT *Dq, int64_t ldD, int32_t c,
   for (int i = 0; i < VEC; ++i) acc[i] = fmaf(a, on ? x[i] : 0.f, acc[i]);
 }
 
+// The sum of a split row's partial sums (chunks c0 .. c1 of one row), by one wave, in a FIXED order — the arithmetic of
+// the two-pass form (k_spmm_finalize) and of the in-kernel finalize (the last arriving chunk of k_spmm) alike, so that
+// both give the same bits.  AGENT: the partial sums were written by other CUs / XCDs a moment ago: agent-scope loads.
+template <bool AGENT>
+__device__ __forceinline__ float load_partial(const float *p) {
+  if constexpr (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool AGENT>
+__device__ __forceinline__ void finish_split_row(int32_t c0, int32_t c1, int64_t row, const float *partials, int ldP,
+                                                 int F, float *__restrict__ Y, int64_t ldY,
+                                                 const float *__restrict__ bias, int relu, int lane) {
+  if (F >= 32) {  // wide rows: lanes over features (coalesced), chunks in order
+    for (int f = lane; f < F; f += kWave) {
+      float s0 = 0.f, s1 = 0.f;
+      int32_t c = c0;
+      for (; c + 2 <= c1; c += 2) {
+        s0 += load_partial<AGENT>(partials + (int64_t)c * ldP + f);
+        s1 += load_partial<AGENT>(partials + (int64_t)(c + 1) * ldP + f);
+      }
+      if (c < c1) s0 += load_partial<AGENT>(partials + (int64_t)c * ldP + f);
+      float s = s0 + s1;
+      if (bias) s += bias[f];
+      if (relu) s = fmaxf(s, 0.f);
+      Y[row * ldY + f] = s;
+    }
+    return;
+  }
+  for (int f = 0; f < F; ++f) {
+    float s = 0.f;
+    for (int32_t c = c0 + lane; c < c1; c += kWave) s += load_partial<AGENT>(partials + (int64_t)c * ldP + f);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+    if (lane == 0) {
+      if (bias) s += bias[f];
+      if (relu) s = fmaxf(s, 0.f);
+      Y[row * ldY + f] = s;
+    }
+  }
+}
+
 // Latency, not bandwidth, bounds a naive row walk (pointer -> index -> gather is three dependent
 // round trips per few entries).  Both paths therefore first pull *all* indices and values of
 // their row / chunk into registers with coalesced loads (one round trip), then hand them to the
@@ -202,18 +243,50 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const DT *__restrict
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
     }
-    if (slot == 0 && active) {
-      const int32_t row = v.chunk_row[chunk];
-      if (row >= 0) {  // the whole row was this chunk: finished
+    const int32_t row = v.chunk_row[chunk];  // (wave uniform)
+    if (row >= 0) {  // the whole row was this chunk: finished
+      if (slot == 0 && active) {
         const int64_t orow = out_index ? (int64_t)out_index[row] : (int64_t)row;
         store_row<VEC>(Y + orow * ldY, acc, f0, F, bias, relu, store_vec_ok != 0);
-      } else {
-        float *p = partials + chunk * (int64_t)ldP + f0;
+      }
+      return;
+    }
+    float *p = partials + chunk * (int64_t)ldP + f0;
+    if (LIVE || !v.ticket) {  // two-pass form: k_spmm_finalize adds the chunks' sums
+      if (slot == 0 && active) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i)
           if (f0 + i < F) p[i] = acc[i];
       }
+      return;
     }
+    // ---- in-kernel finalize (as in k_spmm3): the wave that brings a row's LAST partial sum adds them all, in chunk
+    // order — the result does not depend on which wave that is.  Hand-off across CUs / XCDs (MI355X_MICROARCH.md,
+    // "inter-workgroup visibility"): agent-scope stores, wait, agent-scope add to the row's arrival counter; the last
+    // arriver reads the sums with agent-scope loads and puts the counter back to zero for the next launch.
+    if (slot == 0 && active) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        if (f0 + i < F) __hip_atomic_store(p + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // position of the row among the long rows: the last li with long_cptr[li] <= chunk (scalar search)
+    const int32_t ck = __builtin_amdgcn_readfirstlane((int32_t)chunk);
+    int32_t lo = 0, hi = v.n_long;
+    while (hi - lo > 1) {
+      const int32_t mid = (lo + hi) >> 1;
+      if (v.long_cptr[mid] <= ck) lo = mid; else hi = mid;
+    }
+    const int32_t li = lo, c0 = v.long_cptr[li], c1 = v.long_cptr[li + 1];
+    int32_t old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(v.ticket + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    asm volatile("" ::: "memory");
+    if (old != c1 - c0 - 1) return;
+    const int32_t lrow = -row - 2;
+    const int64_t orow = out_index ? (int64_t)out_index[lrow] : (int64_t)lrow;
+    finish_split_row<true>(c0, c1, orow, partials, ldP, F, Y, ldY, bias, relu, lane);
+    if (lane == 0) __hip_atomic_store(v.ticket + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
 
@@ -927,33 +1000,7 @@ __global__ __launch_bounds__(256) void k_spmm_finalize(SparseView v, const float
   if (c1 - c0 <= 1) return;  // single-chunk rows were stored by the chunk wave
   int64_t row = v.long_row[li];
   if (out_index) row = out_index[row];
-  if (F >= 32) {  // wide rows: lanes over features (coalesced), chunks in order
-    for (int f = lane; f < F; f += kWave) {
-      float s0 = 0.f, s1 = 0.f;
-      int32_t c = c0;
-      for (; c + 2 <= c1; c += 2) {
-        s0 += partials[(int64_t)c * ldP + f];
-        s1 += partials[(int64_t)(c + 1) * ldP + f];
-      }
-      if (c < c1) s0 += partials[(int64_t)c * ldP + f];
-      float s = s0 + s1;
-      if (bias) s += bias[f];
-      if (relu) s = fmaxf(s, 0.f);
-      Y[row * ldY + f] = s;
-    }
-    return;
-  }
-  for (int f = 0; f < F; ++f) {
-    float s = 0.f;
-    for (int32_t c = c0 + lane; c < c1; c += kWave) s += partials[(int64_t)c * ldP + f];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
-    if (lane == 0) {
-      if (bias) s += bias[f];
-      if (relu) s = fmaxf(s, 0.f);
-      Y[row * ldY + f] = s;
-    }
-  }
+  finish_split_row<false>(c0, c1, row, partials, ldP, F, Y, ldY, bias, relu, lane);
 }
 
 template <int G, int VEC, bool TAIL = false, typename DT = float>
@@ -1036,7 +1083,7 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
         (int)chunk_blocks, short_blocks, xcd_per, min_len);
     MRGCN_HIP_TRY(hipGetLastError());
   }
-  if (v.n_multi > 0) {
+  if (v.n_multi > 0 && !v.ticket) {  // (with arrival counters the product finished its split rows itself)
     const int64_t blocks = ((int64_t)v.n_long + 3) / 4;
     k_spmm_finalize<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(v, partials, kWsFeatures, F, Y, ldY, bias,
                                                                  relu, out_index);
@@ -1335,6 +1382,7 @@ extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uin
     int rc = plan_scratch(plan, (hipStream_t)stream, &partials, &ticket);
     if (rc != MRGCN_OK) return rc;
   }
+  v.ticket = (fold && plan->ticket_ints >= v.n_long) ? ticket : nullptr;
   int tile = 64;
   if (ldD % 8 == 0 && ((uintptr_t)D) % 16 == 0) tile = 256;  // kWsFeatures floats of partials per chunk
   else if (ldD % 4 == 0 && ((uintptr_t)D) % 8 == 0) tile = 256;
@@ -1376,6 +1424,7 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     int rc = plan_scratch(plan, s, &partials, &ticket);
     if (rc != MRGCN_OK) return rc;
   }
+  v.ticket = (fold && plan->ticket_ints >= v.n_long) ? ticket : nullptr;  // split rows finished inside the product
   // feature tiles: one pass covers up to 64 lanes x VEC floats; the split-row workspace
   // holds kWsFeatures floats per chunk
   int tile = 64;  // scalar-load worst case

@@ -601,3 +601,45 @@ def test_a_new_stream_cannot_take_its_first_product_inside_a_capture():
             plan.spmm(L.VIEW_COMPACT, M, F=F)
     torch.cuda.synchronize()
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [10, 40, 200])
+def test_the_general_product_finishes_split_rows_in_kernel_like_the_two_pass_form(F):
+    """k_spmm (LITERAL / TRANSPOSED views, and the COMPACT view beyond 16 features): a row of several chunks is summed
+    by the wave that delivers its last partial sum, in chunk order (arrival counter per long row, agent-scope hand-off)
+    — bitwise the two-pass form (MRGCN_SPMM_TWO_PASS), launch after launch with changing operands under memory load."""
+    from mrgcn_amd import _lib as L
+    rng = np.random.default_rng(9)
+    N, R, num_rows = 20000, 3, 20000
+    RN = R * N
+    lens = np.concatenate([rng.integers(600, 3000, 60), [30000], rng.integers(33, 500, 300)])
+    hub = rng.choice(num_rows, len(lens), replace=False)
+    rows = np.concatenate([rng.integers(0, num_rows, 60000)] + [np.full(n, h) for n, h in zip(lens, hub)])
+    cols = np.concatenate([rng.integers(0, RN, 60000)] + [rng.choice(RN, n, replace=False) for n in lens])
+    # hub COLUMNS too (long rows of the transposed view)
+    hc = rng.choice(RN, 20, replace=False)
+    rows = np.concatenate([rows] + [rng.choice(num_rows, 2500, replace=False) for _ in hc])
+    cols = np.concatenate([cols] + [np.full(2500, c) for c in hc])
+    key = np.unique(rows.astype(np.int64) * RN + cols)
+    rows, cols = key // RN, key % RN
+    vals = rng.standard_normal(len(rows)).astype(np.float32)
+    plan = _plan_from_coo(rows, cols, vals, num_rows, N, R, row_bytes=[4 * F] if F > 16 else None)
+    assert plan.long_rows > 0 and plan.long_cols > 0
+    g = torch.Generator("cuda").manual_seed(2)
+    bias = torch.randn(F, device="cuda", generator=g)
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 26, device="cuda")
+    for view, nrows_in in ((L.VIEW_LITERAL, RN), (L.VIEW_TRANSPOSED, num_rows), (L.VIEW_COMPACT, plan.nop)):
+        if view == L.VIEW_COMPACT and F <= 16:
+            continue  # (k_spmm3's own path: the test above)
+        Ds = [torch.randn((nrows_in, F), device="cuda", generator=g) for _ in range(2)]
+        kw = dict(bias=bias, relu=True) if view != L.VIEW_TRANSPOSED else {}
+        want = [plan.spmm(view, D, F=F, two_pass=True, **kw) for D in Ds]
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                big.add_(1.0)
+        outs = [plan.spmm(view, Ds[it % 2], F=F, **kw) for it in range(24)]
+        torch.cuda.synchronize()
+        for it, y in enumerate(outs):
+            assert torch.equal(y, want[it % 2]), f"view {view} launch {it}"
