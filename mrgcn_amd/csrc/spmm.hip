@@ -116,19 +116,45 @@ template <bool AGENT>
 __device__ __forceinline__ void finish_split_row(int32_t c0, int32_t c1, int64_t row, const float *partials, int ldP,
                                                  int F, float *__restrict__ Y, int64_t ldY,
                                                  const float *__restrict__ bias, int relu, int lane) {
-  if (F >= 32) {  // wide rows: lanes over features (coalesced), chunks in order
-    for (int f = lane; f < F; f += kWave) {
-      float s0 = 0.f, s1 = 0.f;
-      int32_t c = c0;
-      for (; c + 2 <= c1; c += 2) {
-        s0 += load_partial<AGENT>(partials + (int64_t)c * ldP + f);
-        s1 += load_partial<AGENT>(partials + (int64_t)(c + 1) * ldP + f);
+  if (F >= 32) {
+    // wide rows: lanes over features (coalesced: lane l owns features l, l + 64, l + 128, l + 192 of a tile of up to
+    // 256); chunk c adds into accumulator c mod 8 of its feature, and the loads of eight chunks x four features are
+    // in flight together (a hub row of the FB15k-237 shape has 300+ partial sums of 200 floats: with two accumulators
+    // and one feature at a time this wave's chain of round trips was the last 17 us of the product)
+    for (int fb = 0; fb < F; fb += 4 * kWave) {
+      float a[4][8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[t][u] = 0.f;
+      int fo[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fo[t] = min(fb + t * kWave + lane, F - 1);  // (clamped: lanes past F read feature F-1)
+      for (int32_t c = c0; c < c1; c += 8) {
+        float x[4][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float *pr = partials + (int64_t)min(c + u, c1 - 1) * ldP;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) x[t][u] = load_partial<AGENT>(pr + fo[t]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (c + u < c1) {  // wave uniform
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t][u] += x[t][u];
+          }
       }
-      if (c < c1) s0 += load_partial<AGENT>(partials + (int64_t)c * ldP + f);
-      float s = s0 + s1;
-      if (bias) s += bias[f];
-      if (relu) s = fmaxf(s, 0.f);
-      Y[row * ldY + f] = s;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int f = fb + t * kWave + lane;
+        if (f < F) {
+          float s = ((a[t][0] + a[t][1]) + (a[t][2] + a[t][3])) + ((a[t][4] + a[t][5]) + (a[t][6] + a[t][7]));
+          if (bias) s += bias[f];
+          if (relu) s = fmaxf(s, 0.f);
+          Y[row * ldY + f] = s;
+        }
+      }
     }
     return;
   }
