@@ -66,7 +66,8 @@ struct SparseView {
   const int32_t *long_cptr = nullptr;  // [n_long+1] chunk range of each long row
   const int32_t *chunk_beg = nullptr;  // [n_chunks] first entry
   const int32_t *chunk_end = nullptr;  // [n_chunks] one past last entry
-  const int32_t *chunk_row = nullptr;  // [n_chunks] row id when the row is this single chunk, else -(row + 2)
+  const int32_t *chunk_row = nullptr;  // [n_chunks] row id when the row is this single chunk, else -(row + 2);
+                                       // [n_chunks .. 2 n_chunks) the position of the chunk's row in long_row
   // [n_long] arrival counters (zero between launches): with them the wave that delivers the LAST partial sum of a row
   // of several chunks adds them all, in chunk order, inside the product — no finalize launch.  NULL: two passes.
   int32_t *ticket = nullptr;

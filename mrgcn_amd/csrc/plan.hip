@@ -338,7 +338,9 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
                             const int32_t *__restrict__ is_long, const int32_t *__restrict__ long_pos,
                             const int32_t *__restrict__ chunk_pos, int32_t *__restrict__ long_row,
                             int32_t *__restrict__ long_cptr, int32_t *__restrict__ chunk_beg,
-                            int32_t *__restrict__ chunk_end, int32_t *__restrict__ chunk_row) {
+                            int32_t *__restrict__ chunk_end, int32_t *__restrict__ chunk_row, int32_t n_chunks) {
+  // chunk_row holds 2 * n_chunks words: [c] the row (see below), [n_chunks + c] the position li of the chunk's row
+  // among the long rows (the in-kernel finalize of the products finds its arrival counter there)
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows || !is_long[i]) return;
   int32_t li = long_pos[i], c0 = chunk_pos[i];
@@ -352,6 +354,7 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
       chunk_beg[c0 + j] = s;
       chunk_end[c0 + j] = min(s + rc, e);
       chunk_row[c0 + j] = -(li + 2);
+      chunk_row[n_chunks + c0 + j] = li;
     }
     return;
   }
@@ -360,6 +363,7 @@ __global__ void k_long_fill(const int32_t *__restrict__ ptr, int64_t rows, int c
     chunk_beg[c] = s;
     chunk_end[c] = min(s + chunk, e);
     chunk_row[c] = (e - b <= chunk) ? (int32_t)i : -((int32_t)i + 2);  // < 0: one of several chunks of row -x - 2
+    chunk_row[n_chunks + c] = li;
   }
 }
 
@@ -580,11 +584,11 @@ int build_long(mrgcn_plan *p, const int32_t *ptr, int64_t rows, hipStream_t s, i
   MRGCN_HIP_TRY(plan_alloc(p, long_cptr, h[0] + 1));
   MRGCN_HIP_TRY(plan_alloc(p, chunk_beg, h[1]));
   MRGCN_HIP_TRY(plan_alloc(p, chunk_end, h[1]));
-  MRGCN_HIP_TRY(plan_alloc(p, chunk_row, h[1]));
+  MRGCN_HIP_TRY(plan_alloc(p, chunk_row, 2 * (int64_t)h[1]));  // (row | position among the long rows: k_long_fill)
   k_fill_i32<<<1, 1, 0, s>>>(*long_cptr + h[0], 1, h[1]);  // the total closes the chunk ranges (no host pointer: no wait)
   if (rows > 0 && h[0] > 0)
     k_long_fill<<<nblocks(rows), kTB, 0, s>>>(ptr, rows, chunk, cap, blockwise, is_long, long_pos, chunk_pos,
-                                              *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row);
+                                              *long_row, *long_cptr, *chunk_beg, *chunk_end, *chunk_row, h[1]);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;  // (stream ordered from here on: the scratch goes back tagged with the stream)
 }

@@ -112,41 +112,44 @@ __device__ __forceinline__ float load_partial(const float *p) {
   if constexpr (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else return *p;
 }
-template <bool AGENT>
+// WIDE: the caller's feature tile can hold 32 or more features (compile time: the wide path's 64 registers of loads in
+// flight would otherwise set the register count — and the occupancy — of the narrow instantiations too: 54 -> 96 VGPRs,
+// eight -> five waves per SIMD, the TRANSPOSED product at F = 10 443 -> 626 us)
+template <bool AGENT, int NFT = 4>  // NFT: 64-feature groups whose loads fly together (0: the narrow path only)
 __device__ __forceinline__ void finish_split_row(int32_t c0, int32_t c1, int64_t row, const float *partials, int ldP,
                                                  int F, float *__restrict__ Y, int64_t ldY,
                                                  const float *__restrict__ bias, int relu, int lane) {
-  if (F >= 32) {
+  if constexpr (NFT > 0) if (F >= 32) {
     // wide rows: lanes over features (coalesced: lane l owns features l, l + 64, l + 128, l + 192 of a tile of up to
     // 256); chunk c adds into accumulator c mod 8 of its feature, and the loads of eight chunks x four features are
     // in flight together (a hub row of the FB15k-237 shape has 300+ partial sums of 200 floats: with two accumulators
     // and one feature at a time this wave's chain of round trips was the last 17 us of the product)
-    for (int fb = 0; fb < F; fb += 4 * kWave) {
-      float a[4][8];
+    for (int fb = 0; fb < F; fb += NFT * kWave) {
+      float a[NFT][8];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < NFT; ++t)
 #pragma unroll
         for (int u = 0; u < 8; ++u) a[t][u] = 0.f;
-      int fo[4];
+      int fo[NFT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fo[t] = min(fb + t * kWave + lane, F - 1);  // (clamped: lanes past F read feature F-1)
+      for (int t = 0; t < NFT; ++t) fo[t] = min(fb + t * kWave + lane, F - 1);  // (clamped: lanes past F read feature F-1)
       for (int32_t c = c0; c < c1; c += 8) {
-        float x[4][8];
+        float x[NFT][8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const float *pr = partials + (int64_t)min(c + u, c1 - 1) * ldP;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) x[t][u] = load_partial<AGENT>(pr + fo[t]);
+          for (int t = 0; t < NFT; ++t) x[t][u] = load_partial<AGENT>(pr + fo[t]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (c + u < c1) {  // wave uniform
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a[t][u] += x[t][u];
+            for (int t = 0; t < NFT; ++t) a[t][u] += x[t][u];
           }
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NFT; ++t) {
         const int f = fb + t * kWave + lane;
         if (f < F) {
           float s = ((a[t][0] + a[t][1]) + (a[t][2] + a[t][3])) + ((a[t][4] + a[t][5]) + (a[t][6] + a[t][7]));
@@ -296,14 +299,9 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const DT *__restrict
         if (f0 + i < F) __hip_atomic_store(p + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // position of the row among the long rows: the last li with long_cptr[li] <= chunk (scalar search)
+    // position of the row among the long rows (second half of chunk_row: plan.hip k_long_fill)
     const int32_t ck = __builtin_amdgcn_readfirstlane((int32_t)chunk);
-    int32_t lo = 0, hi = v.n_long;
-    while (hi - lo > 1) {
-      const int32_t mid = (lo + hi) >> 1;
-      if (v.long_cptr[mid] <= ck) lo = mid; else hi = mid;
-    }
-    const int32_t li = lo, c0 = v.long_cptr[li], c1 = v.long_cptr[li + 1];
+    const int32_t li = v.chunk_row[v.n_chunks + ck], c0 = v.long_cptr[li], c1 = v.long_cptr[li + 1];
     int32_t old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(v.ticket + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     old = __builtin_amdgcn_readfirstlane(old);
@@ -311,7 +309,9 @@ __global__ __launch_bounds__(256) void k_spmm(SparseView v, const DT *__restrict
     if (old != c1 - c0 - 1) return;
     const int32_t lrow = -row - 2;
     const int64_t orow = out_index ? (int64_t)out_index[lrow] : (int64_t)lrow;
-    finish_split_row<true>(c0, c1, orow, partials, ldP, F, Y, ldY, bias, relu, lane);
+    // (loads in flight sized to the tile: the finishing path must not set the register count of the product)
+    constexpr int NFT = G * VEC < 32 ? 0 : G * VEC <= 64 ? 1 : G * VEC <= 128 ? 2 : 4;
+    finish_split_row<true, NFT>(c0, c1, orow, partials, ldP, F, Y, ldY, bias, relu, lane);
     if (lane == 0) __hip_atomic_store(v.ticket + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
