@@ -7,7 +7,8 @@
 # (3) rocprofv3 --kernel-trace --stats of the same command -> kernel stats, trace medians, the epoch's launch sequence,
 # (4) epoch PMC (memory + SQ sets) for the weight_I streamers and the transforms -> epoch_pmc.md and, with (3),
 # kernel_roofline.md, (5) the fb15k line + its launch sequence, (6) the encoders' product probe + MFMA counters,
-# (7) the next-rows probe (mini-batch incl. the masked pass, encoders, ingestion), (8) the halo-size probe.
+# (7) the next-rows probe (mini-batch incl. the masked pass, encoders, ingestion) + the launch sequence of one
+# re-sampled mini-batch step, (8) the halo-size probe.
 tag=${1:-rXX}
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
@@ -49,5 +50,8 @@ bash tools/pmc_passes.sh $o/pmc_mm mfma -- python3 tools/gemm_probe.py --iters 3
 python3 tools/pmc_summary.py $o k_mm_tile > $o/mfma_mm.md
 rm -rf $o/pmc_mm_*/
 python3 tools/next_rows_probe.py > $o/next_rows.json 2> $o/next_rows.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_mb -o run -- python3 tools/minibatch_step.py 10 > $o/minibatch_step.txt 2> $o/minibatch_step.err
+python3 tools/epoch_sequence.py $o/stats_mb k_sup_rowcount 2 > $o/minibatch_step_sequence.md 2>&1
+rm -rf $o/stats_mb
 python3 tools/halo_probe.py > $o/halo.json 2> $o/halo.err
 ls -la $o
