@@ -804,8 +804,12 @@ def run_probe_child(args, workload, k, world, rank, local_rank):
     process group and the replica line untouched.  Rank 0 returns the child's record (or the error), the others None."""
     import subprocess
     port = int(os.environ.get("MASTER_PORT", "29500")) + 1 + k
-    env = dict(os.environ, MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world))
-    env.pop("TORCHELASTIC_RUN_ID", None)
+    # (none of the elastic agent's variables: with TORCHELASTIC_USE_AGENT_STORE the child's env:// rendezvous would wait
+    # for a store the agent hosts on the PARENT's port — rank 0 of the child group hosts its own on port + 1 + k)
+    env = {k_: v for k_, v in os.environ.items() if not k_.startswith("TORCHELASTIC")}
+    env.update(MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port), RANK=str(rank),
+               LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), GROUP_RANK="0",
+               ROLE_RANK=str(rank))
     cmd = [sys.executable, os.path.abspath(__file__), "--probe-child", workload, "--gpus", str(world),
            "--seed", str(args.seed), "--value-mode", args.value_mode,
            "--scale", str(args.scale if workload == args.workload else 1.0)]

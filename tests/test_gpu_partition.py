@@ -320,3 +320,29 @@ def test_bench_link_prediction_workload_single_and_partitioned():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["parallelism"] == "node-partitioned x2"
     assert abs(j["extra"]["final_loss"] - j1["extra"]["final_loss"]) < 0.05 * abs(j1["extra"]["final_loss"])
+
+
+@pytest.mark.gpu
+def test_bench_replicas_also_run_the_partitioned_engine_in_child_processes():
+    """`bench.py --gpus 2` on the DEFAULT workload (replicas) as the driver launches it: after the replica timing every
+    rank spawns a child that joins a process group of its own and runs the node-partitioned engine on the same graph
+    (`extra.partitioned`).  The children must not inherit the elastic agent's rendezvous variables (they would wait for
+    a store nobody hosts: the probe then only ever reported "timed out")."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRGCN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MRGCN_BENCH_PROBE_TIMEOUT="200")
+    multi = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                            os.path.join(root, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline", "--spmm-iters", "3"],
+                           capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    assert multi.returncode == 0, multi.stderr[-2000:]
+    lines = [ln for ln in multi.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, multi.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["parallelism"].startswith("replicas")
+    rec = j["extra"]["partitioned"]["am"]
+    assert "error" not in rec, rec
+    assert rec["rccl_world"] == 2 and rec["ms_per_step"] > 0 and rec["logits_maxdiff_vs_single"] < 1e-4
