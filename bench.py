@@ -702,7 +702,7 @@ def main_lp(args, emit=True):
         print(json.dumps(out), flush=True)
 
 
-def partitioned_probe(args, name, dev, world, rank, steps=5, warmup=2):
+def partitioned_probe(args, name, dev, world, rank, steps=5, warmup=2, emit=None):
     """--gpus N on a replica workload: ONE graph of the shape node-partitioned over the N ranks (mrgcn_amd.partition:
     reduce-scatter of every layer's output rows, all-gather of their gradients, sharded node table) next to the replica
     line, so that the first multi-GPU run of the driver exercises the partitioned engine on real xGMI links:
@@ -794,6 +794,28 @@ def partitioned_probe(args, name, dev, world, rank, steps=5, warmup=2):
             reduce_scatter_rows(full_rows)
     mdist.barrier(dev)
     out["reduce_scatter_ms"] = mdist.max_over_ranks(time.perf_counter() - t0, dev) / steps * 1e3
+    if emit is not None:
+        emit(out)   # the eager record is safe (printed) before anything below can go wrong
+    # the same step captured into a hipGraph, RCCL collectives included (partition.GraphedPartitionedStep): at 8 ranks a
+    # rank's share of the graph is launch-latency territory.  Exercised with one rank only so far, hence after the
+    # eager record and fail-soft; MRGCN_BENCH_PROBE_GRAPH=0 skips it.
+    if dist.get_backend() == "nccl" and os.environ.get("MRGCN_BENCH_PROBE_GRAPH", "1") != "0":
+        try:
+            from mrgcn_amd.partition import GraphedPartitionedStep
+            opt2 = ClipAdam(pmodel.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=True)
+            opt2.set_distributed(None, pmodel.sharded_parameters())
+            graphed = GraphedPartitionedStep(pmodel, Xl, idx_np, y_np, opt2, warmup=2)
+            for _ in range(warmup):
+                graphed()
+            mdist.barrier(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = graphed()
+            mdist.barrier(dev)
+            out["ms_per_step_hipgraph"] = mdist.max_over_ranks(time.perf_counter() - t0, dev) / steps * 1e3
+            out["final_loss_hipgraph"] = float(loss)
+        except Exception as e:  # noqa: BLE001
+            out["hipgraph_error"] = (type(e).__name__ + ": " + str(e))[:200]
     return out
 
 
@@ -814,18 +836,31 @@ def run_probe_child(args, workload, k, world, rank, local_rank):
            "--seed", str(args.seed), "--value-mode", args.value_mode,
            "--scale", str(args.scale if workload == args.workload else 1.0)]
     limit = float(os.environ.get("MRGCN_BENCH_PROBE_TIMEOUT", "420" if workload == "synth10m" else "240"))
+    def last_record(text):
+        for line in reversed((text or "").strip().splitlines()):
+            if line.startswith("{"):
+                try:
+                    return json.loads(line)
+                except Exception:  # noqa: BLE001
+                    return None
+        return None
+
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
-    except subprocess.TimeoutExpired:
-        return {"error": "timed out after %.0f s" % limit, "rccl_world": world} if rank == 0 else None
+    except subprocess.TimeoutExpired as e:
+        if rank != 0:
+            return None
+        so = e.stdout.decode(errors="replace") if isinstance(e.stdout, bytes) else e.stdout
+        rec = last_record(so)   # (the eager record is printed before the captured attempt: a hang there loses only that)
+        if rec is not None:
+            rec["note"] = "timed out after %.0f s behind this record" % limit
+            return rec
+        return {"error": "timed out after %.0f s" % limit, "rccl_world": world}
     if rank != 0:
         return None
-    for line in reversed(r.stdout.strip().splitlines()):
-        if line.startswith("{"):
-            try:
-                return json.loads(line)
-            except Exception:  # noqa: BLE001
-                break
+    rec = last_record(r.stdout)
+    if rec is not None:
+        return rec
     return {"error": ("exit %d: " % r.returncode) + (r.stderr.strip().splitlines() or ["no output"])[-1][:300],
             "rccl_world": world}
 
@@ -840,8 +875,16 @@ def probe_child_main(args):
     torch.cuda.set_device(dev)
     backend = os.environ.get("MRGCN_DIST_BACKEND", "nccl" if ngpu >= world else "gloo")
     mdist.init(backend, dev if backend == "nccl" else None)
+    if world == 1 and not dist.is_initialized():   # (a one-rank group: the probe run by hand on a one-GPU box)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        dist.init_process_group(backend, rank=0, world_size=1)
+
+    def emit(rec_):
+        if rank == 0:
+            print(json.dumps(rec_), flush=True)
     try:
-        rec = partitioned_probe(args, args.probe_child, dev, world, rank)
+        rec = partitioned_probe(args, args.probe_child, dev, world, rank, emit=emit)
     except Exception as e:  # noqa: BLE001
         rec = {"error": (type(e).__name__ + ": " + str(e))[:300], "rccl_world": world}
     if rank == 0:
