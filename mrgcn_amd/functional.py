@@ -348,6 +348,12 @@ class _RgcnLayer(torch.autograd.Function):
         if sparse_rows and has_bias:
             raise L.MrgcnError("internal: an output gradient with unwritten rows reached a layer with a bias")
         dbias = dY.sum(0) if has_bias else None
+        if meta is None and _SUPPORT and _LIVE_COLS and _DISCOVER and F <= 16:
+            # a plain dense gradient (the reference's own loss: CrossEntropyLoss on Y_hat[idx] leaves zeros + the
+            # labelled rows): which rows hold anything is looked up, and while that set equals last epoch's the
+            # backward runs on the support built for it
+            meta = _discovered_rows(ctx.owner, plan, dY, F, dev)
+            row_flags = meta["row_live"] if meta else row_flags
         sup = _support_of(plan, meta, F, dev) if (_SUPPORT and _LIVE_COLS) else None
         if sup is not None:
             out = _RgcnLayer._backward_on_support(ctx, sup, dY, dbias)
@@ -498,6 +504,33 @@ class _RgcnLayer(torch.autograd.Function):
                         if t is not None:
                             t.record_stream(side if (t is dM or t is live or t is node_live) else main)
         return None, None, d_wI, d_comp, dX, dW, dbias, None, None, None
+
+
+_DISCOVER = os.environ.get("MRGCN_DISCOVER_ROWS", "1") != "0"
+
+
+def _discovered_rows(owner, plan, dY, F, dev):
+    """Row flags of a dense output gradient that carries no note about its live rows (it comes from torch's own
+    autograd: the reference's loop, `criterion(model(X, A)[idx], y)`), as a `structural` note when they are the SAME set
+    as the last time this layer looked — the label set of a training run does not change, so from the second epoch on
+    the gradient support of that set is reused.  One pass over dY and a 1-byte read-back per call (hence not inside a
+    stream capture, and only for the layer whose gradient arrives without a note: the layers below get theirs from the
+    layer above).  None: no stable set (yet) — the caller takes the per-epoch marking path."""
+    if (owner is None or torch.cuda.is_current_stream_capturing() or dY.shape[0] != plan.num_rows
+            or getattr(plan, "lean", False)):   # (a lean plan is a one-step mini-batch slice: its row set never comes back)
+        return None
+    if dY.dim() != 2 or dY.stride(1) != 1 or dY.dtype != torch.float32:
+        return None
+    flags = torch.empty((dY.shape[0],), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.load().mrgcn_rows_nonzero_f32(dY.data_ptr(), dY.stride(0), F, dY.shape[0], flags.data_ptr(),
+                                                _stream(dev)), "mrgcn_rows_nonzero_f32")
+    ent = owner.__dict__.get("_mrgcn_found_rows")
+    if ent is not None and ent.shape == flags.shape and ent.device == flags.device and bool(torch.equal(ent, flags)):
+        # (rows outside the set are exact zeros in THIS gradient too: it was just looked at)
+        return {"version": dY._version, "row_live": ent, "relu_applied": False, "structural": True, "sparse_rows": False}
+    owner.__dict__["_mrgcn_found_rows"] = flags   # the set to meet again next epoch
+    return None
 
 
 def _support_of(plan, meta, F, dev):
