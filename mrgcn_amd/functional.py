@@ -510,12 +510,13 @@ _DISCOVER = os.environ.get("MRGCN_DISCOVER_ROWS", "1") != "0"
 
 
 def _discovered_rows(owner, plan, dY, F, dev):
-    """Row flags of a dense output gradient that carries no note about its live rows (it comes from torch's own
-    autograd: the reference's loop, `criterion(model(X, A)[idx], y)`), as a `structural` note when they are the SAME set
-    as the last time this layer looked — the label set of a training run does not change, so from the second epoch on
-    the gradient support of that set is reused.  One pass over dY and a 1-byte read-back per call (hence not inside a
-    stream capture, and only for the layer whose gradient arrives without a note: the layers below get theirs from the
-    layer above).  None: no stable set (yet) — the caller takes the per-epoch marking path."""
+    """Row flags for a dense output gradient that carries no note about its live rows (it comes from torch's own
+    autograd: the reference's loop, `criterion(model(X, A)[idx], y)`), as a `structural` note: the UNION of the rows
+    that held anything whenever this layer looked.  The label set of a training run does not change, so the union stops
+    growing after an epoch or two (a labelled row whose gradient underflows to exact zeros in some epoch stays in it: a
+    structural set may contain zero rows) and the gradient support built for it is reused from then on.  One pass
+    over dY and a 1-byte read-back per call — hence not inside a stream capture, and only for the layer whose
+    gradient arrives without a note: the layers below get theirs from the layer above.  None: not applicable."""
     if (owner is None or torch.cuda.is_current_stream_capturing() or dY.shape[0] != plan.num_rows
             or getattr(plan, "lean", False)):   # (a lean plan is a one-step mini-batch slice: its row set never comes back)
         return None
@@ -526,11 +527,13 @@ def _discovered_rows(owner, plan, dY, F, dev):
         L.check(L.load().mrgcn_rows_nonzero_f32(dY.data_ptr(), dY.stride(0), F, dY.shape[0], flags.data_ptr(),
                                                 _stream(dev)), "mrgcn_rows_nonzero_f32")
     ent = owner.__dict__.get("_mrgcn_found_rows")
-    if ent is not None and ent.shape == flags.shape and ent.device == flags.device and bool(torch.equal(ent, flags)):
-        # (rows outside the set are exact zeros in THIS gradient too: it was just looked at)
-        return {"version": dY._version, "row_live": ent, "relu_applied": False, "structural": True, "sparse_rows": False}
-    owner.__dict__["_mrgcn_found_rows"] = flags   # the set to meet again next epoch
-    return None
+    if ent is None or ent.shape != flags.shape or ent.device != flags.device:
+        ent = flags
+    elif bool((flags > ent).any()):   # a row outside the set so far: the set grows (a new tensor: a new support)
+        ent = torch.maximum(ent, flags)
+    owner.__dict__["_mrgcn_found_rows"] = ent
+    # (rows outside the set are exact zeros in THIS gradient: it was just looked at)
+    return {"version": dY._version, "row_live": ent, "relu_applied": False, "structural": True, "sparse_rows": False}
 
 
 def _support_of(plan, meta, F, dev):
@@ -607,6 +610,8 @@ def _backward_on_support(ctx, sup, dY, dbias):
     dev = plan.device
     if has_I and not has_comp:
         return None  # (the literal (R*N) x F gradient is scattered from plain compact order)
+    if has_I and (comp_I.shape[1] > 64 or F > 16):
+        return None  # (outside the support's node-major mix backward: mrgcn_support_mix_bwd_f32)
     need_dX = has_X and ctx.needs_input_grad[4]
     need_dW = has_X and ctx.needs_input_grad[5]
     K = X.shape[1] if has_X else 0

@@ -401,12 +401,14 @@ def test_basis_mix_backward_with_rows_without_gradient(N, R, B, F, hub, zero_fra
     np.testing.assert_allclose(float(sq), (want_dV ** 2).sum(), rtol=1e-4, atol=1e-6)
 
 
-def test_backward_is_the_same_on_the_sparse_and_the_general_transposed_product():
+def test_backward_is_the_same_on_the_sparse_and_the_general_transposed_product(monkeypatch):
     """The layer's backward picks mrgcn_spmm_transposed_live_f32 while few rows of dY are live
     and the general product otherwise (functional._LiveGauge); both must give the same gradients.
     Dense dY: the first call takes the sparse path (nothing known yet), the second the general one;
-    sparse dY (few 'labelled' rows): both take the sparse path."""
+    sparse dY (few 'labelled' rows): both take the sparse path.  (The per-epoch marking path: the look-up that would
+    send a plain dense gradient to a gradient support — functional._discovered_rows — is switched off here.)"""
     from mrgcn_amd import functional as Fn
+    monkeypatch.setattr(Fn, "_DISCOVER", False)
     from mrgcn_amd.layers.graph import GraphConvolution
     from mrgcn_amd.plan import plan_of
     N, R, B, K, F = 1200, 6, 5, 9, 10
@@ -848,3 +850,51 @@ def test_cross_entropy_with_compact_gradient_matches_torch(N, C, n, scale):
     assert torch.equal(flags, want) and not seen["meta"]["relu_applied"]
     strided = buf[:, :C].detach().requires_grad_(True)          # rows with a pad (a layer's padded output)
     torch.testing.assert_close(categorical_crossentropy(strided, idx, tgt), loss.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_a_plain_dense_gradient_finds_its_gradient_support():
+    """A loss built with torch's own ops hands the layer a dense gradient without a note.  The layer looks up its live
+    rows (functional._discovered_rows), keeps their union as a structural row set and runs on the gradient support of
+    that set: same gradients as the per-epoch marking path, also when a row of the set holds zeros in some epoch and
+    when the set grows."""
+    from mrgcn_amd import functional as Fn
+    from mrgcn_amd.layers.graph import GraphConvolution
+    from mrgcn_amd.plan import plan_of
+    N, R, B, K, F = 1500, 5, 4, 7, 10
+    rng = np.random.default_rng(11)
+    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, K, F, 6 * N, 300)
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    plan = plan_of(At, N, R)
+    torch.manual_seed(0)
+    layer = GraphConvolution(K, F, R, N, num_bases=B, bias=False, input_layer=True, featureless=False).cuda()
+    X = torch.randn(N, K, device="cuda", requires_grad=True)
+    idx = torch.randperm(N, device="cuda")[:40]
+    sets = [idx, idx, idx[:30], torch.cat([idx, torch.tensor([3, 5], device="cuda")]), idx]   # steady, shrinks, grows, steady
+
+    def grads(w):
+        layer.zero_grad(); X.grad = None
+        (layer._forward_fused(X, plan, relu=False) * w).sum().backward()
+        return [p.grad.clone() for p in layer.parameters() if p.grad is not None] + [X.grad.clone()]
+
+    taken = []
+    orig = Fn._RgcnLayer._backward_on_support
+
+    def spy(ctx, sup, dY, dbias):
+        out = orig(ctx, sup, dY, dbias)
+        taken.append(out is not None)
+        return out
+    for rows_ in sets:
+        w = torch.zeros(N, F, device="cuda")
+        w[rows_] = torch.randn(len(rows_), F, device="cuda")
+        Fn._DISCOVER = False
+        want = grads(w)
+        Fn._DISCOVER = True
+        Fn._RgcnLayer._backward_on_support = staticmethod(spy)
+        try:
+            got = grads(w)
+        finally:
+            Fn._RgcnLayer._backward_on_support = staticmethod(orig)
+        for a, b in zip(want, got):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)   # (another summation order)
+    assert taken == [True] * len(sets), taken
+    assert int(layer.__dict__["_mrgcn_found_rows"].sum()) == 42   # the union of every set seen
