@@ -147,3 +147,40 @@ def test_overlapped_reduction_of_replicated_gradients_gloo_world2():
         assert rep == [3.0]                    # 1 + 2 on both ranks
         assert sh == [10.0 * (r + 1)]          # never communicated
         assert again == [1.0]
+
+
+def _exchange_worker(rank, world, port, out):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from mrgcn_amd import partition as P
+    dist.init_process_group("gloo")
+    S, F = 7, 3
+    # uneven live sets: rank 0 has three live rows, rank 1 none at all (a rank without a labelled node in reach)
+    flags = torch.zeros(S, dtype=torch.uint8)
+    if rank == 0:
+        flags[[1, 4, 6]] = 1
+    g = torch.arange(S * F, dtype=torch.float32).view(S, F) + 100 * rank
+    g = g * flags[:, None].float()                       # rows outside the set hold zeros
+    ex = P._live_row_exchange(flags, None)
+    recv = P.all_gather_rows(g.index_select(0, ex["send_idx"]))
+    compact = torch.zeros((world * S, F))
+    compact.index_copy_(0, ex["dst"], recv.index_select(0, ex["src"]))
+    dense = P.all_gather_rows(g)
+    again = P._live_row_exchange(flags, None)            # kept on the flags tensor: no second round of collectives
+    out[rank] = (compact.tolist(), dense.tolist(), ex["total"], ex["n_max"], again is ex)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_live_row_exchange_equals_the_dense_all_gather_gloo_world2():
+    """partition._live_row_exchange: the backward all-gather that moves the rows with gradient only (padded to the
+    largest count over the ranks) puts exactly the dense all-gather's rows where they belong — with uneven counts and a
+    rank that has no live row."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in (0, 1):
+        compact, dense, total, n_max, cached = out[r]
+        assert compact == dense
+        assert total == 3 and n_max == 3 and cached
