@@ -1253,7 +1253,9 @@ __global__ void k_fill_bytes(uint8_t *__restrict__ dst, uint32_t word, size_t he
 hipError_t fill_async(void *dst, int byte_value, size_t bytes, hipStream_t s) {
   if (bytes == 0) return hipSuccess;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &st) != hipSuccess || st == hipStreamCaptureStatusNone)
+  // (MRGCN_DEBUG_CAPTURED_MEMSET=1: the runtime's memset also inside a capture — tools/memset_node_repro.py shows the fault)
+  static const bool raw = getenv("MRGCN_DEBUG_CAPTURED_MEMSET") && atoi(getenv("MRGCN_DEBUG_CAPTURED_MEMSET")) != 0;
+  if (raw || hipStreamIsCapturing(s, &st) != hipSuccess || st == hipStreamCaptureStatusNone)
     return hipMemsetAsync(dst, byte_value, bytes, s);
   const uint32_t b = (uint32_t)(byte_value & 0xff);
   size_t head = (4 - ((uintptr_t)dst & 3)) & 3;
