@@ -367,3 +367,224 @@ def input_term_comp_grad_at_rows(cfg: LayerCfg, p: dict, A: sp.csr_matrix, rows,
     dcomp = np.zeros((R, B), dtype=dtype)
     np.add.at(dcomp, r_u, dots)
     return dcomp
+
+
+# ---------------------------------------------------------------------------
+# the whole train step, evaluated on the receptive field of the labelled rows
+# (node_classification.py:166-193 over graph.py:62-102 / rgcn.py:69-89)
+# ---------------------------------------------------------------------------
+def _node_groups(j_u):
+    """The touched columns grouped by source node: (order, live, groups) with `order` the columns sorted by node,
+    `live` the distinct nodes (rising) and `groups` a list of (k, node positions in `live` [n], column ids [n, k]) — the
+    nodes with exactly k columns, so that per-node products run as batched matrix products."""
+    order = np.argsort(j_u, kind="stable")
+    jo = j_u[order]
+    starts = np.flatnonzero(np.concatenate([[True], jo[1:] != jo[:-1]])) if len(jo) else np.zeros(0, np.int64)
+    counts = np.diff(np.concatenate([starts, [len(jo)]]))
+    live = jo[starts]
+    groups = []
+    for k in np.unique(counts):
+        at = np.flatnonzero(counts == k)
+        groups.append((int(k), at, order[starts[at][:, None] + np.arange(int(k))[None, :]]))
+    return order, live, groups
+
+
+def _levels_forward(cfgs, params, X, A: sp.csr_matrix, rows, relu_last, chunk, dtype):
+    """Forward on the receptive field of `rows`: level l holds what layer l needs to produce its output at the
+    row set S_l (S_last = rows; S_{l-1} = the source nodes of the columns the rows of S_l read).  Returns the
+    per-layer records, bottom layer first."""
+    A = A.tocsr()
+    nl = len(cfgs)
+    subs = [None] * nl
+    rws = np.unique(np.asarray(rows, dtype=np.int64))
+    for li in reversed(range(nl)):                       # the row sets, top down
+        sub = A[rws, :].tocoo()
+        ucol, inv = np.unique(sub.col.astype(np.int64), return_inverse=True)
+        N = cfgs[li].N
+        r_u, j_u = ucol // N, ucol % N
+        src = np.unique(j_u)
+        sub_c = sp.csr_matrix((sub.data.astype(dtype), (sub.row, inv)), shape=(len(rws), len(ucol)))
+        subs[li] = dict(rows=rws, ucol=ucol, r_u=r_u, j_u=j_u, src=src, pos=np.searchsorted(src, j_u), sub_c=sub_c)
+        rws = src
+    H = None
+    for li in range(nl):                                 # the activations, bottom up
+        cfg, p, lv = cfgs[li], params[li], subs[li]
+        R, N, B, out = cfg.R, cfg.N, cfg.B, cfg.outdim
+        r_u, j_u = lv["r_u"], lv["j_u"]
+        D = np.zeros((len(lv["ucol"]), out), dtype=dtype)
+        if cfg.input_layer:
+            W_I = p["weight_I"]
+            if B > 0:   # graph.py:69-72 for the touched columns only: D[c] = comp[r_c] . V[:, j_c, :]
+                order, live, groups = _node_groups(j_u)
+                # the live nodes' blocks, node-major [live, B, out] (kept in the parameter's dtype; widened per chunk)
+                Vl = np.ascontiguousarray(np.transpose(W_I.reshape(B, N, out)[:, live, :], (1, 0, 2)))
+                comp = p["weight_I_comp"].astype(dtype)
+                per = max(chunk // max(B, 1), 1)
+                for k, at, cols in groups:
+                    for s in range(0, len(at), per):
+                        e = slice(s, s + per)
+                        D[cols[e]] = np.matmul(comp[r_u[cols[e]]], Vl[at[e]].astype(dtype))   # [n,k,B] @ [n,B,out]
+                lv.update(live=live, groups=groups, Vl=Vl)
+            else:
+                D += W_I[lv["ucol"]].astype(dtype)
+        feat = not (cfg.input_layer and cfg.featureless)
+        if feat:
+            W_F = p["weight_F"].astype(dtype)
+            if B > 0:   # graph.py:83-85
+                W_F = np.einsum("rb,bij->rij", p["weight_F_comp"].astype(dtype), W_F)
+            # the layer's input at the source nodes: X itself for the bottom layer, else the layer below at S_{l-1} = src
+            H_src = X[lv["src"]].astype(dtype) if li == 0 else H
+            order = np.argsort(r_u, kind="stable")
+            bounds = np.flatnonzero(np.diff(r_u[order])) + 1
+            rgroups = [g for g in np.split(order, bounds) if len(g)]
+            for grp in rgroups:   # graph.py:93-94, one relation at a time
+                D[grp] += H_src[lv["pos"][grp]] @ W_F[r_u[grp[0]]]
+            lv.update(W_F=W_F, H_src=H_src, rgroups=rgroups)
+        pre = lv["sub_c"] @ D    # graph.py:75, :95
+        if cfg.bias:
+            pre = pre + p["b"].astype(dtype)
+        act = (li < nl - 1) or relu_last
+        lv.update(pre=pre, act=act, feat=feat)
+        H = np.maximum(pre, 0.0) if act else pre
+    return subs, H
+
+
+def rgcn_train_step_at_rows(cfgs, params, X, A: sp.csr_matrix, idx, targets, sample_nodes=None, moments=None, t=1,
+                            lr=0.01, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, relu_last=False, chunk=65536,
+                            dtype=np.float64, loss_fn=None, extra_params=None):
+    """One epoch of node_classification.py:166-193 (forward, CE on the labelled rows, backward, clip_grad_norm_ 1.0,
+    Adam) in float64 WITHOUT any (R*N) x out array: everything is evaluated on the receptive field of the labelled
+    rows, so the AM shape (1.67 M nodes) and the 10 M-node stress shape run on a host in tens of seconds.  The mirror of
+    `rgcn_forward_at_rows` for the backward; pinned against `train_steps` / the reference's own gradients and
+    post-Adam parameters by tests/test_oracle_golden.py.
+
+    `params[l]`: the reference's shapes (weight_I `(B*N, out)` or `(R*N, out)`).  `idx` must not repeat a row.
+    `sample_nodes` (distinct): node ids whose `weight_I` blocks are returned (gradient, updated parameter, updated
+    moments); the squared norm over ALL blocks enters the clip.  `moments`: None (step 1 from zeros) or, per layer, a
+    dict name -> (exp_avg, exp_avg_sq) in the reference's shapes for the small parameters and, under "weight_I",
+    `(m, v)` of the SAMPLED blocks `[len(sample_nodes), B, out]` (bases; without bases the whole `(R*N, out)` arrays) —
+    the state the step starts from.
+
+    `loss_fn(rows, H) -> (loss, dH, extra_grads)`: another loss on the top layer's output `H` at the sorted distinct
+    `rows` of `idx` (`targets` unused) — the link-prediction decoder (oracle.lp_oracle: DistMult + BCE over the
+    embeddings, link_prediction.py:266-275); `extra_grads` / `extra_params` {name: array}: parameters outside the
+    layers (the decoder's `relations`): they enter the clip norm and get their Adam step under `new_extra`
+    (`moments_extra` would be all that is missing for t > 1: not needed so far).
+
+    Returns dict(loss, logits [len(idx), C], grads [per layer {name: array}] for every parameter but weight_I,
+    wI [per layer: rows / grad — bases: the sampled node ids and their `[n, B, out]` blocks; no bases: the touched
+    literal rows `r*N+j` and their gradient rows — and live_nodes, the ids with any weight_I gradient], grad_norm, coef,
+    new [per layer {name: (param, exp_avg, exp_avg_sq)}] (weight_I: the sampled blocks / touched rows only))."""
+    idx = np.asarray(idx, dtype=np.int64)
+    assert len(np.unique(idx)) == len(idx), "repeated labelled rows"
+    nl = len(cfgs)
+    levels, H_top = _levels_forward(cfgs, params, X, A, idx, relu_last, chunk, dtype)
+    top_rows = levels[-1]["rows"]
+    at_lab = np.searchsorted(top_rows, idx)
+    extra_grads = {}
+    if loss_fn is None:
+        loss, d_sorted = cross_entropy(H_top, at_lab, np.asarray(targets))   # node_classification.py:439-444
+    else:
+        loss, d_sorted, extra_grads = loss_fn(top_rows, H_top)
+    logits = H_top[at_lab]
+    sample_nodes = None if sample_nodes is None else np.asarray(sample_nodes, dtype=np.int64)
+    if sample_nodes is not None:
+        assert len(np.unique(sample_nodes)) == len(sample_nodes), "repeated sample nodes"
+
+    grads = [dict() for _ in range(nl)]
+    wI = [None] * nl
+    sumsq = 0.0
+    dH = d_sorted                                         # gradient at the rows of the top level
+    for li in reversed(range(nl)):
+        cfg, p, lv = cfgs[li], params[li], levels[li]
+        R, N, B, out = cfg.R, cfg.N, cfg.B, cfg.outdim
+        r_u, j_u = lv["r_u"], lv["j_u"]
+        dPre = dH * (lv["pre"] > 0) if lv["act"] else dH
+        g = grads[li]
+        if cfg.bias:
+            g["b"] = dPre.sum(0)
+        dD = lv["sub_c"].T @ dPre                         # [touched columns, out]: autograd of graph.py:75,:95
+        if cfg.input_layer:
+            if B > 0:
+                comp = p["weight_I_comp"].astype(dtype)
+                dcomp = np.zeros((R, B), dtype=dtype)
+                live, Vl = lv["live"], lv["Vl"]
+                keep = None
+                if sample_nodes is not None:
+                    keep = np.zeros((len(sample_nodes), B, out), dtype=dtype)
+                    s_order = np.argsort(sample_nodes, kind="stable")
+                    s_sorted = sample_nodes[s_order]
+                per = max(chunk // max(B, 1), 1)
+                for k, at, cols in lv["groups"]:          # the nodes with k touched columns, `per` of them at a time
+                    for s in range(0, len(at), per):
+                        cs, ns = cols[s:s + per], at[s:s + per]
+                        dDc = dD[cs]                                                  # [n, k, out]
+                        cr = comp[r_u[cs]]                                            # [n, k, B]
+                        # a node's block: sum_c comp[r_c]^T (x) dD[c]   (einsum 'rb,rij->bij' restricted to the node)
+                        blocks = np.matmul(np.transpose(cr, (0, 2, 1)), dDc)          # [n, B, out]
+                        sumsq += float((blocks ** 2).sum())
+                        # dcomp[r, b] += <dD[c], V[b, j_c]>
+                        dots = np.matmul(dDc, np.transpose(Vl[ns].astype(dtype), (0, 2, 1)))   # [n, k, B]
+                        np.add.at(dcomp, r_u[cs].ravel(), dots.reshape(-1, B))
+                        if keep is not None and len(s_sorted):
+                            nd = live[ns]
+                            at_s = np.minimum(np.searchsorted(s_sorted, nd), len(s_sorted) - 1)
+                            hit = s_sorted[at_s] == nd
+                            keep[s_order[at_s[hit]]] = blocks[hit]
+                g["weight_I_comp"] = dcomp
+                wI[li] = dict(rows=sample_nodes, grad=keep, live_nodes=live)
+            else:   # the literal (R*N, out) table: its gradient IS dD at the touched rows, zero elsewhere
+                sumsq += float((dD ** 2).sum())
+                wI[li] = dict(rows=lv["ucol"], grad=dD, live_nodes=np.unique(j_u))
+        dH = None
+        if lv["feat"]:
+            W_F, H_src, pos = lv["W_F"], lv["H_src"], lv["pos"]
+            K = H_src.shape[1]
+            dW = np.zeros((R, K, out), dtype=dtype)
+            dH = np.zeros((len(lv["src"]), K), dtype=dtype)
+            for grp in lv["rgroups"]:
+                r = int(r_u[grp[0]])
+                dW[r] = H_src[pos[grp]].T @ dD[grp]
+                dH[pos[grp]] += dD[grp] @ W_F[r].T             # (a node appears once per relation: no repeats)
+            if B > 0:
+                g["weight_F"] = np.einsum("rb,rio->bio", p["weight_F_comp"].astype(dtype), dW)
+                g["weight_F_comp"] = np.einsum("rio,bio->rb", dW, p["weight_F"].astype(dtype))
+            else:
+                g["weight_F"] = dW
+    for g in grads + [extra_grads]:
+        for v in g.values():
+            sumsq += float((v.astype(np.float64) ** 2).sum())
+    total = np.sqrt(sumsq)
+    coef = min(1.0, max_norm / (total + 1e-6)) if max_norm else 1.0   # clip_grad_norm_
+
+    b1, b2 = betas
+
+    def adam(pv, gv, mv, vv):
+        gv = gv * coef
+        m = b1 * mv + (1 - b1) * gv
+        v = b2 * vv + (1 - b2) * gv * gv
+        return pv - lr * (m / (1 - b1 ** t)) / (np.sqrt(v) / np.sqrt(1 - b2 ** t) + eps), m, v
+
+    new = [dict() for _ in range(nl)]
+    for li in range(nl):
+        p, mom = params[li], (moments[li] if moments is not None else {})
+        for name, gv in grads[li].items():
+            m0, v0 = mom.get(name, (0.0, 0.0))
+            new[li][name] = adam(p[name].astype(dtype), gv, np.asarray(m0, dtype=dtype), np.asarray(v0, dtype=dtype))
+        w = wI[li]
+        if w is None or w["grad"] is None:
+            continue
+        cfg = cfgs[li]
+        if cfg.B > 0:
+            V = p["weight_I"].reshape(cfg.B, cfg.N, cfg.outdim)
+            pv = np.transpose(V[:, w["rows"], :], (1, 0, 2)).astype(dtype)      # node-major blocks
+        else:
+            pv = p["weight_I"][w["rows"]].astype(dtype)
+        m0, v0 = mom.get("weight_I", (0.0, 0.0))
+        if cfg.B <= 0 and np.ndim(m0) == 2:     # (no bases: the whole (R*N, out) moments, read at the touched rows)
+            m0, v0 = m0[w["rows"]], v0[w["rows"]]
+        new[li]["weight_I"] = adam(pv, w["grad"], np.asarray(m0, dtype=dtype), np.asarray(v0, dtype=dtype))
+    new_extra = {k: adam(np.asarray(extra_params[k], dtype=dtype), gv, 0.0, 0.0) for k, gv in extra_grads.items()}
+    return dict(loss=loss, logits=logits, grads=grads, wI=wI, grad_norm=total, coef=coef, new=new,
+                extra_grads=extra_grads, new_extra=new_extra,
+                levels=[dict(rows=lv["rows"], src=lv["src"], ncols=len(lv["ucol"])) for lv in levels])

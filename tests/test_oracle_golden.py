@@ -213,3 +213,132 @@ def test_comp_gradient_at_rows_matches_reference_gradient(name):
     rows = np.flatnonzero(np.abs(dpre0).sum(1) > 0)
     got = O.input_term_comp_grad_at_rows(cfgs[0], params[0], A, rows, dpre0[rows])
     np.testing.assert_allclose(got, c["grad.layers.layer_0.weight_I_comp"], rtol=1e-4, atol=1e-7)
+
+
+def _ref_blocks(arr, cfg, rows):
+    """Rows of a reference-shaped weight_I array as the at-rows oracle hands them out: node-major blocks `[n, B, out]`
+    of the nodes `rows` (bases) or the literal rows `r*N + j` (no bases)."""
+    if cfg.B > 0:
+        return np.transpose(arr.reshape(cfg.B, cfg.N, cfg.outdim)[:, rows, :], (1, 0, 2))
+    return arr[rows]
+
+
+@pytest.mark.parametrize("name", RGCN_CASES)
+def test_receptive_field_train_step_matches_reference_gradients_and_adam(name):
+    """`rgcn_train_step_at_rows` (the full-size gradient / clip / Adam checker of tests/test_gpu_step_oracle.py) against
+    what the reference's own autograd, `clip_grad_norm_` and `torch.optim.Adam` produced on every golden case: loss,
+    every gradient (`weight_I` at ALL node blocks), the clip norm, the parameters after the first step — and the
+    second step from the full oracle's state after the first (moments handed in) against the full oracle."""
+    c, A = _case(name)
+    N, R, B = int(c["meta.num_nodes"]), int(c["meta.R"]), int(c["meta.num_bases"])
+    bias, fl = bool(c["meta.bias"]), bool(c["meta.featureless"])
+    dims = [tuple(d) for d in c["dims"]]
+    state = {k[len("init."):]: c[k] for k in c.files if k.startswith("init.")}
+    cfgs = O.rgcn_cfgs(dims, R, N, B, bias, fl)
+    params = O.split_params(state, len(cfgs))
+    X = None if fl else c["X"]
+    idx, y = c["labels_idx"], c["labels_y"]
+    nodes = np.arange(N)
+    lp = bool(c["meta.link_prediction"])   # (the golden's loss is the cross-entropy over the ReLU'd embeddings)
+    got = O.rgcn_train_step_at_rows(cfgs, params, X, A, idx, y, sample_nodes=nodes, chunk=11, relu_last=lp)
+    np.testing.assert_allclose(got["loss"], c["loss"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got["logits"], c["logits"][idx], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(got["grad_norm"], c["grad_norm"], rtol=1e-5)
+    for li, cfg in enumerate(cfgs):
+        pre = f"layers.layer_{li}."
+        for k, v in got["grads"][li].items():
+            np.testing.assert_allclose(v, c["grad." + pre + k], rtol=1e-4, atol=1e-6, err_msg=pre + k)
+        w = got["wI"][li]
+        if w is None:
+            continue
+        ref = c["grad." + pre + "weight_I"]
+        dense = np.zeros_like(ref, dtype=np.float64)
+        if cfg.B > 0:
+            dense.reshape(cfg.B, cfg.N, cfg.outdim)[:, w["rows"], :] = np.transpose(w["grad"], (1, 0, 2))
+            # the nodes the oracle calls live are exactly those with any gradient column
+            dead = np.setdiff1d(nodes, w["live_nodes"])
+            assert not np.abs(_ref_blocks(ref, cfg, dead)).any()
+        else:
+            dense[w["rows"]] = w["grad"]
+        np.testing.assert_allclose(dense, ref, rtol=1e-4, atol=1e-6, err_msg=pre + "weight_I")
+    # parameters after the reference's first step; an element may differ by a whole Adam step (lr * sign) only where
+    # its float32 gradient is rounding noise
+    for li, cfg in enumerate(cfgs):
+        pre = f"layers.layer_{li}."
+        for k, (pn, mn, vn) in got["new"][li].items():
+            ref = c["adam1." + pre + k]
+            gk = c["grad." + pre + k]
+            if k == "weight_I":
+                ref, gk = _ref_blocks(ref, cfg, got["wI"][li]["rows"]), _ref_blocks(gk, cfg, got["wI"][li]["rows"])
+            diff = np.abs(pn - ref)
+            assert diff.max() <= 0.0201, pre + k
+            assert not (diff[np.abs(gk) * got["coef"] > 1e-6] > 2e-5).any(), pre + k
+    # the second step, from the full oracle's state and moments after the first
+    full = O.train_steps(dims, R, N, B, bias, fl, state, X, A, idx, y, 2, relu_last=lp)
+    st1 = {k: v for k, v in full[0]["state"].items()}
+    params1 = O.split_params(st1, len(cfgs))
+    coef1 = min(1.0, 1.0 / (full[0]["grad_norm"] + 1e-6))
+    moments = []
+    for li, cfg in enumerate(cfgs):
+        mom = {}
+        for k in list(got["grads"][li]) + (["weight_I"] if got["wI"][li] is not None else []):
+            g1 = full[0]["grads"][f"layers.layer_{li}.{k}"] * coef1
+            m, v = 0.1 * g1, 0.001 * g1 * g1
+            if k == "weight_I":
+                rows = nodes if cfg.B > 0 else np.arange(R * N)
+                m, v = _ref_blocks(m, cfg, rows), _ref_blocks(v, cfg, rows)
+            mom[k] = (m, v)
+        moments.append(mom)
+    samp = nodes
+    got2 = O.rgcn_train_step_at_rows(cfgs, params1, X, A, idx, y, sample_nodes=samp, moments=moments, t=2, chunk=64,
+                                     relu_last=lp)
+    np.testing.assert_allclose(got2["loss"], full[1]["loss"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(got2["grad_norm"], full[1]["grad_norm"], rtol=1e-9)
+    for li, cfg in enumerate(cfgs):
+        for k, (pn, mn, vn) in got2["new"][li].items():
+            ref = full[1]["state"][f"layers.layer_{li}.{k}"]
+            if k == "weight_I":
+                ref = _ref_blocks(ref, cfg, got2["wI"][li]["rows"])
+            np.testing.assert_allclose(pn, ref, rtol=1e-9, atol=1e-12, err_msg=k)
+
+
+def test_receptive_field_step_with_the_decoder_loss_equals_the_full_oracles():
+    """`rgcn_train_step_at_rows(loss_fn=...)` with the DistMult + BCE decoder on top (the FB15k-237 full-shape step
+    checker): against the composition of the two pinned full-size oracles — `rgcn_forward` / `rgcn_backward` (pinned to
+    the reference's autograd above) and `lp_oracle.distmult_bce_grads` (pinned to lp_decoder.npz) — on the golden graph
+    with a one-layer featureless encoder (link_prediction.py:266-275 over rgcn.py:69-89)."""
+    from oracle import lp_oracle as lo
+    c, A = _case("rgcn_small_lp_b2")
+    N, R, B = int(c["meta.num_nodes"]), int(c["meta.R"]), int(c["meta.num_bases"])
+    dims = [tuple(d) for d in c["dims"]]
+    state = {k[len("init."):]: c[k] for k in c.files if k.startswith("init.")}
+    Rel = state.pop("relations").astype(np.float64)
+    cfgs = O.rgcn_cfgs(dims, R, N, B, False, True)
+    params = O.split_params(state, 1)
+    rng = np.random.default_rng(0)
+    P = (R - 1) // 2
+    facts = np.stack([rng.integers(0, N - 7, 60), rng.integers(0, P, 60), rng.integers(0, N - 7, 60)], 1)
+    y = (rng.random(60) < 0.8).astype(np.float64)
+    # full-size composition
+    E, tape = O.rgcn_forward(cfgs, params, None, A.astype(np.float64), relu_last=True)
+    dE, dR = lo.distmult_bce_grads(facts, E, Rel, y)
+    grads, _ = O.rgcn_backward(cfgs, params, A.astype(np.float64), tape, dE)
+    x = (E[facts[:, 0]] * Rel[facts[:, 1]] * E[facts[:, 2]]).sum(-1)
+    want_loss = lo.bce_with_logits(x, y)
+    rows = np.unique(np.concatenate([facts[:, 0], facts[:, 2]]))
+
+    def loss_fn(top_rows, H):
+        local = np.stack([np.searchsorted(top_rows, facts[:, 0]), facts[:, 1], np.searchsorted(top_rows, facts[:, 2])], 1)
+        dEl, dRl = lo.distmult_bce_grads(local, H, Rel, y)
+        xs = (H[local[:, 0]] * Rel[local[:, 1]] * H[local[:, 2]]).sum(-1)
+        return lo.bce_with_logits(xs, y), dEl, {"relations": dRl}
+
+    got = O.rgcn_train_step_at_rows(cfgs, params, None, A, rows, None, sample_nodes=np.arange(N), relu_last=True,
+                                    loss_fn=loss_fn, extra_params={"relations": Rel}, chunk=13)
+    np.testing.assert_allclose(got["loss"], want_loss, rtol=1e-12)
+    np.testing.assert_allclose(got["extra_grads"]["relations"], dR, rtol=1e-10, atol=1e-15)
+    np.testing.assert_allclose(got["grads"][0]["weight_I_comp"], grads[0]["weight_I_comp"], rtol=1e-9, atol=1e-14)
+    dense = np.transpose(got["wI"][0]["grad"], (1, 0, 2)).reshape(B * N, -1)
+    np.testing.assert_allclose(dense, grads[0]["weight_I"], rtol=1e-9, atol=1e-14)
+    flat = [dR] + list(grads[0].values())
+    np.testing.assert_allclose(got["grad_norm"], O.clip_grad_norm(flat)[0], rtol=1e-10)
