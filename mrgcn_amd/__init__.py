@@ -23,16 +23,24 @@ _PARENTS = ("mrgcn", "mrgcn.layers", "mrgcn.models", "mrgcn.data", "mrgcn.data.i
 
 
 _TASK_MODULES = ("mrgcn.tasks.node_classification", "mrgcn.tasks.link_prediction")
+_TASK_ROW_SPARSE = False   # what install_as_mrgcn last asked for (the task modules may be imported later)
 
 
-def patch_task_optimizer(module) -> None:
-    """Gives one of the reference's task modules (`mrgcn.tasks.node_classification`, `...link_prediction`) this
-    package's `optim.RowSparseAdam` (as `optim.Adam`) and `nn.utils.clip_grad_norm_` (mrgcn_amd.optim) — the pair that
-    understands the row-sparse node-table gradient; bound together, never one without the other: the module's names `optim` and `nn`
-    — `import torch.optim as optim`, `import torch.nn as nn` at its top — are rebound to pass-through namespaces that
-    differ from torch's in exactly those two attributes.  The training loop of the module
-    (node_classification.py:35-37, :190-193; link_prediction.py:325) then runs unchanged on the row-sparse fast
-    path.  Nothing outside that module's namespace changes."""
+def patch_task_optimizer(module, row_sparse: bool = True) -> None:
+    """Rebinds `optim.Adam` inside one of the reference's task modules (`mrgcn.tasks.node_classification`,
+    `...link_prediction`; `import torch.optim as optim`, `import torch.nn as nn` at their top) through pass-through
+    namespaces that differ from torch's in exactly the attributes named here.  Nothing outside that module's
+    namespace changes.
+
+    `row_sparse=False`: `optim.Adam` -> `mrgcn_amd.optim.ReferenceLayoutAdam` — torch's own Adam whose `state_dict()` /
+    `load_state_dict()` speak the reference's `(B*N, out)` layout for the node-major `weight_I`, so that the module's
+    unpatched checkpoint lines (node_classification.py:73-80, run.py:230-236) exchange optimizer states with the
+    reference.  `nn` stays torch's.
+
+    `row_sparse=True`: `optim.Adam` -> `optim.RowSparseAdam` and `nn.utils.clip_grad_norm_` -> this package's — the pair
+    that understands the row-sparse node-table gradient; bound together, never one without the other.  The training
+    loop of the module (node_classification.py:35-37, :190-193; link_prediction.py:325) then runs unchanged on the
+    row-sparse fast path (same checkpoint layout)."""
     import types
 
     import torch
@@ -47,6 +55,12 @@ def patch_task_optimizer(module) -> None:
         def __getattr__(self, name):
             return getattr(self.__dict__["_base"], name)
 
+    if not row_sparse:
+        if hasattr(module, "optim"):
+            module.optim = _Through(torch.optim, Adam=fast.ReferenceLayoutAdam)
+        if type(getattr(module, "nn", None)).__name__ == "_Through":
+            module.nn = torch.nn   # (a previous row-sparse patch: the pair goes together)
+        return
     if hasattr(module, "optim"):
         module.optim = _Through(torch.optim, Adam=fast.RowSparseAdam)
     if hasattr(module, "nn"):
@@ -66,9 +80,14 @@ def install_as_mrgcn(patch_optimizer: bool = False):
     importable at all.  Call it before the task modules are imported (a module that already ran
     `from mrgcn.models.mrgcn import MRGCN` keeps the class it bound).  Idempotent.  See INTEGRATION.md.
 
-    `patch_optimizer=True` additionally rebinds `optim.Adam` and `nn.utils.clip_grad_norm_` inside the reference's two
-    task modules (`patch_task_optimizer`), now if they are imported already and otherwise when they are: the
-    reference's training loop then reaches the row-sparse node-table update without a changed line."""
+    The reference's two task modules always get `optim.Adam` rebound (`patch_task_optimizer`), now if they are imported
+    already and otherwise when they are: by default to torch's own Adam with the checkpoint layout translated
+    (`optim.ReferenceLayoutAdam`: a reference-shaped `optimizer_state_dict` loads and steps under the module's
+    unpatched lines, and what it saves loads in the reference); with `patch_optimizer=True` to `RowSparseAdam`
+    together with this package's `nn.utils.clip_grad_norm_`: the reference's training loop then reaches the row-sparse
+    node-table update without a changed line.  The last call's choice wins."""
+    global _TASK_ROW_SPARSE
+    _TASK_ROW_SPARSE = bool(patch_optimizer)
     import importlib
     import importlib.abc
     import importlib.machinery
@@ -113,7 +132,7 @@ def install_as_mrgcn(patch_optimizer: bool = False):
 
         def exec_module(self, module):
             self.inner.exec_module(module)
-            patch_task_optimizer(module)
+            patch_task_optimizer(module, _TASK_ROW_SPARSE)
 
     class _TaskFinder(importlib.abc.MetaPathFinder):
         """Wraps the loader of the reference's task modules: after the module ran, its `optim` / `nn` are patched."""
@@ -133,12 +152,11 @@ def install_as_mrgcn(patch_optimizer: bool = False):
 
     if not any(getattr(f, "_mrgcn_amd", None) == "leaves" for f in sys.meta_path):
         sys.meta_path.insert(0, _LeafFinder())
-    if patch_optimizer:
-        if not any(getattr(f, "_mrgcn_amd", None) == "tasks" for f in sys.meta_path):
-            sys.meta_path.insert(0, _TaskFinder())
-        for name in _TASK_MODULES:
-            if name in sys.modules:
-                patch_task_optimizer(sys.modules[name])
+    if not any(getattr(f, "_mrgcn_amd", None) == "tasks" for f in sys.meta_path):
+        sys.meta_path.insert(0, _TaskFinder())
+    for name in _TASK_MODULES:
+        if name in sys.modules:
+            patch_task_optimizer(sys.modules[name], _TASK_ROW_SPARSE)
     if not any(getattr(f, "_mrgcn_amd", None) == "parents" for f in sys.meta_path):
         sys.meta_path.append(_ParentFinder())
     # leaves that were imported from the reference before this call are replaced in place

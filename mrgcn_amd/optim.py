@@ -9,8 +9,12 @@ The reference drives a step as (mrgcn/tasks/node_classification.py:35-37, :190-1
     optimizer.step()
 
 With `torch.optim.Adam` / `torch.nn.utils.clip_grad_norm_` that loop works on this package's models as it is
-(dense gradients; `reference_state_dict` / `load_reference_state_dict` below make the optimizer checkpoint of
-run.py:232-235 interchangeable), but the node table `weight_I` then costs a dense gradient write, a norm pass, a
+(dense gradients).  The optimizer CHECKPOINT of run.py:232-235 / node_classification.py:73-80 needs one thing more:
+the moments of the node-major `weight_I` must travel in the reference's `(B*N, out)` shape.  `install_as_mrgcn()`
+therefore always binds `optim.Adam` inside the reference's two task modules to `ReferenceLayoutAdam` (torch's own
+Adam with the layout translated in `state_dict()` / `load_state_dict()`), or to `RowSparseAdam` with
+`patch_optimizer=True`; an optimizer built elsewhere gets the same through `speak_reference_layout(optimizer)`
+(`reference_state_dict` / `load_reference_state_dict` are the one-shot forms).  Beyond the checkpoint, the node table `weight_I` then costs a dense gradient write, a norm pass, a
 scaling pass and a dense Adam pass over memory that mostly holds zeros.  `Adam` and `clip_grad_norm_` here are
 drop-ins for the two names with the same call signatures: the backward leaves the gradient of a node-major
 `weight_I` in row-sparse form (mrgcn_amd.functional), `clip_grad_norm_` folds its squared norm — a by-product of
@@ -129,6 +133,66 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
 
 
 # ---- torch.optim.Adam over this package's models: checkpoint layout ---------------------------------------------
+def _ref_layout_post_hook(optimizer, state_dict):
+    """state_dict post-hook: moments of node-major parameters leave in the reference's `(B*N, out)` shape."""
+    idx, _ = _node_major_indices(optimizer)
+    if not idx:
+        return None
+    state = {}
+    for k, st in state_dict["state"].items():
+        if k in idx:
+            st = {key: (_to_reference_layout(v) if torch.is_tensor(v) and v.dim() == 3 else v) for key, v in st.items()}
+        state[k] = st
+    return dict(state_dict, state=state)
+
+
+def _ref_layout_load_pre_hook(optimizer, state_dict):
+    """load_state_dict pre-hook: reference-shaped moments of node-major parameters are transposed on the way in."""
+    idx, params = _node_major_indices(optimizer)
+    if not idx:
+        return None
+    state = {}
+    for k, st in state_dict["state"].items():
+        if k in idx:
+            N, B, F = params[k].shape
+            st = {key: (v.view(B, N, F).permute(1, 0, 2).contiguous()
+                        if torch.is_tensor(v) and v.dim() == 2 and tuple(v.shape) == (B * N, F) else v)
+                  for key, v in st.items()}
+        state[k] = st
+    return dict(state_dict, state=state)
+
+
+def speak_reference_layout(optimizer):
+    """Makes ANY torch optimizer whose state tensors have the parameter's shape (Adam, AdamW, SGD with momentum, ...)
+    save and load its checkpoint in the reference's layout: `optimizer.state_dict()` hands the moments of a node-major
+    `weight_I` out as `(B*N, out)` (what `torch.save(optimizer.state_dict())` of run.py:232-235 holds for the reference
+    model) and `optimizer.load_state_dict()` accepts them in that shape (node_classification.py:73-80) — instance
+    hooks, nothing global.  Idempotent; returns the optimizer.  `ClipAdam` and its subclasses speak it natively."""
+    if isinstance(optimizer, ClipAdam) or optimizer.__dict__.get("_mrgcn_reference_layout"):
+        return optimizer
+    optimizer.register_state_dict_post_hook(_ref_layout_post_hook)
+    optimizer.register_load_state_dict_pre_hook(_ref_layout_load_pre_hook)
+    optimizer.__dict__["_mrgcn_reference_layout"] = True
+    return optimizer
+
+
+class ReferenceLayoutAdam(torch.optim.Adam):
+    """`torch.optim.Adam` itself — torch's arithmetic, dense gradients, every keyword — whose checkpoints are in the
+    reference's layout (`speak_reference_layout`).  What `install_as_mrgcn()` binds for `optim.Adam` inside the
+    reference's task modules by default, so that `optimizer.load_state_dict(checkpoint['optimizer_state_dict'])`
+    (node_classification.py:73-80) takes a checkpoint written by the reference and `optimizer.state_dict()`
+    (run.py:230-236) writes one the reference can load."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        speak_reference_layout(self)
+
+    def __setstate__(self, state):   # (unpickling / deepcopy drop instance hooks)
+        super().__setstate__(state)
+        self.__dict__.pop("_mrgcn_reference_layout", None)
+        speak_reference_layout(self)
+
+
 def _node_major_indices(optimizer):
     params = [p for g in optimizer.param_groups for p in g["params"]]
     return {i for i, p in enumerate(params) if getattr(p, "_mrgcn_node_major", False)}, params
@@ -139,7 +203,7 @@ def reference_state_dict(optimizer) -> dict:
     layout — what `torch.save(optimizer.state_dict())` of run.py:232-235 holds for the reference model.  For
     any optimizer whose state tensors have the parameter's shape (torch.optim.Adam, AdamW, ...)."""
     sd = optimizer.state_dict()
-    if isinstance(optimizer, ClipAdam):
+    if isinstance(optimizer, ClipAdam) or optimizer.__dict__.get("_mrgcn_reference_layout"):
         return sd  # already speaks the reference's layout
     idx, _ = _node_major_indices(optimizer)
     state = {}
@@ -152,7 +216,7 @@ def reference_state_dict(optimizer) -> dict:
 
 def load_reference_state_dict(optimizer, state_dict) -> None:
     """The inverse: loads an optimizer checkpoint written for the reference model (or by `reference_state_dict`)."""
-    if isinstance(optimizer, ClipAdam):
+    if isinstance(optimizer, ClipAdam) or optimizer.__dict__.get("_mrgcn_reference_layout"):
         optimizer.load_state_dict(state_dict)
         return
     idx, params = _node_major_indices(optimizer)

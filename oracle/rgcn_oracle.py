@@ -451,7 +451,7 @@ def _levels_forward(cfgs, params, X, A: sp.csr_matrix, rows, relu_last, chunk, d
 
 def rgcn_train_step_at_rows(cfgs, params, X, A: sp.csr_matrix, idx, targets, sample_nodes=None, moments=None, t=1,
                             lr=0.01, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, relu_last=False, chunk=65536,
-                            dtype=np.float64, loss_fn=None, extra_params=None):
+                            dtype=np.float64, loss_fn=None, extra_params=None, moments_extra=None):
     """One epoch of node_classification.py:166-193 (forward, CE on the labelled rows, backward, clip_grad_norm_ 1.0,
     Adam) in float64 WITHOUT any (R*N) x out array: everything is evaluated on the receptive field of the labelled
     rows, so the AM shape (1.67 M nodes) and the 10 M-node stress shape run on a host in tens of seconds.  The mirror of
@@ -469,7 +469,7 @@ def rgcn_train_step_at_rows(cfgs, params, X, A: sp.csr_matrix, idx, targets, sam
     `rows` of `idx` (`targets` unused) — the link-prediction decoder (oracle.lp_oracle: DistMult + BCE over the
     embeddings, link_prediction.py:266-275); `extra_grads` / `extra_params` {name: array}: parameters outside the
     layers (the decoder's `relations`): they enter the clip norm and get their Adam step under `new_extra`
-    (`moments_extra` would be all that is missing for t > 1: not needed so far).
+    (from `moments_extra` {name: (exp_avg, exp_avg_sq)} when t > 1).
 
     Returns dict(loss, logits [len(idx), C], grads [per layer {name: array}] for every parameter but weight_I,
     wI [per layer: rows / grad — bases: the sampled node ids and their `[n, B, out]` blocks; no bases: the touched
@@ -584,7 +584,9 @@ def rgcn_train_step_at_rows(cfgs, params, X, A: sp.csr_matrix, idx, targets, sam
         if cfg.B <= 0 and np.ndim(m0) == 2:     # (no bases: the whole (R*N, out) moments, read at the touched rows)
             m0, v0 = m0[w["rows"]], v0[w["rows"]]
         new[li]["weight_I"] = adam(pv, w["grad"], np.asarray(m0, dtype=dtype), np.asarray(v0, dtype=dtype))
-    new_extra = {k: adam(np.asarray(extra_params[k], dtype=dtype), gv, 0.0, 0.0) for k, gv in extra_grads.items()}
+    mx = moments_extra or {}
+    new_extra = {k: adam(np.asarray(extra_params[k], dtype=dtype), gv, *[np.asarray(a, dtype=dtype) for a in mx.get(k, (0.0, 0.0))])
+                 for k, gv in extra_grads.items()}
     return dict(loss=loss, logits=logits, grads=grads, wI=wI, grad_norm=total, coef=coef, new=new,
                 extra_grads=extra_grads, new_extra=new_extra,
                 levels=[dict(rows=lv["rows"], src=lv["src"], ncols=len(lv["ucol"])) for lv in levels])

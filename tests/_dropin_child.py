@@ -56,7 +56,12 @@ if order.startswith("patched"):
         assert mod.nn.utils.clip_grad_value_ is torch.nn.utils.clip_grad_value_
     assert torch.optim.Adam is not fast.RowSparseAdam and torch.nn.utils.clip_grad_norm_ is not fast.clip_grad_norm_
 else:
-    assert nc.optim is torch.optim and nc.nn is torch.nn
+    # default install: only `optim.Adam` differs — torch's own Adam whose checkpoints are in the reference's layout
+    import mrgcn_amd.optim as fast
+    for mod in (nc, lp):
+        assert mod.optim.Adam is fast.ReferenceLayoutAdam and issubclass(mod.optim.Adam, torch.optim.Adam)
+        assert mod.optim.SGD is torch.optim.SGD and mod.nn is torch.nn
+    assert torch.optim.Adam is not fast.ReferenceLayoutAdam
 assert nc.MRGCN is my_mrgcn.MRGCN and lp.MRGCN is my_mrgcn.MRGCN
 assert nc.FullBatch is my_batch.FullBatch and nc.MiniBatch is my_batch.MiniBatch
 import mrgcn.layers.graph  # noqa: E402
@@ -84,6 +89,41 @@ assert names == ["rgcn.layers.layer_0.b", "rgcn.layers.layer_0.weight_I", "rgcn.
 # ... and its optimizer grouping (tasks/utils.py:8-45) accepts the model
 groups = mrgcn.tasks.utils.optimizer_params(model, {}, True)
 assert sum(len(g["params"]) for g in groups) == len(names)
+
+# ... and the reference's checkpoint lines (node_classification.py:35-37, :73-80; run.py:230-236), unpatched: an
+# optimizer state shaped like the REFERENCE model's tensors (= this model's state_dict() shapes) loads, steps, and
+# comes back out in that shape — equal to plain torch.optim.Adam over reference-shaped copies of the parameters
+optimizer = nc.optim.Adam(groups, lr=0.01, weight_decay=0.0)
+gen = torch.Generator().manual_seed(0)
+plist = [p for g in groups for p in g["params"]]
+pname = {id(p): n for n, p in model.named_parameters()}
+sd_model = model.state_dict()
+ref_params = [torch.nn.Parameter(sd_model[pname[id(p)]].detach().clone()) for p in plist]
+ref_opt = torch.optim.Adam(ref_params, lr=0.01, weight_decay=0.0)
+for rp in ref_params:
+    rp.grad = torch.randn(rp.shape, generator=gen)
+ref_opt.step()                       # (a state to checkpoint)
+import copy  # noqa: E402
+ckpt = {"optimizer_state_dict": copy.deepcopy(ref_opt.state_dict())}   # (as read back from disk: no shared tensors)
+wi = [pname[id(p)] for p in plist].index("rgcn.layers.layer_0.weight_I")
+assert tuple(ckpt["optimizer_state_dict"]["state"][wi]["exp_avg"].shape) == (2 * N, 8) and tuple(plist[wi].shape) == (N, 2, 8)
+model.load_state_dict({pname[id(p)]: rp.detach() for p, rp in zip(plist, ref_params)})
+optimizer.load_state_dict(ckpt["optimizer_state_dict"])                       # node_classification.py:79
+if not order.startswith("patched"):   # (RowSparseAdam steps with HIP kernels: its step is tests/test_gpu_reference_loop.py's)
+    for p, rp in zip(plist, ref_params):
+        rp.grad = torch.randn(rp.shape, generator=gen)
+        g_ = rp.grad
+        p.grad = (g_.view(2, N, 8).permute(1, 0, 2).contiguous() if getattr(p, "_mrgcn_node_major", False) else g_.clone()).to(p.device)
+    optimizer.step()
+    ref_opt.step()
+    sd_after = model.state_dict()
+    for p, rp in zip(plist, ref_params):
+        torch.testing.assert_close(sd_after[pname[id(p)]].cpu(), rp.detach(), rtol=1e-6, atol=1e-7)
+out_sd, want_sd = optimizer.state_dict(), ref_opt.state_dict()               # run.py:233
+for k, st in want_sd["state"].items():
+    assert tuple(out_sd["state"][k]["exp_avg"].shape) == tuple(st["exp_avg"].shape)
+    torch.testing.assert_close(out_sd["state"][k]["exp_avg"].cpu(), st["exp_avg"], rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(out_sd["state"][k]["exp_avg_sq"].cpu(), st["exp_avg_sq"], rtol=1e-6, atol=1e-10)
 
 # ... and an am.toml-shaped config with its hub tuples (configs/am.toml: distilbert for strings, mobilenet_v2 for
 # images; graph_features.py:184-236 turns them into `modules_config`) builds unchanged: torch.hub.load is the one

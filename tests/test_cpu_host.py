@@ -164,3 +164,63 @@ def test_label_reach_order_puts_reachable_nodes_first():
     r2, c2 = reorder.relabel_coo(rows, cols, N, inv)
     assert (c2 // N == cols // N).all()
     assert (order[r2] == rows).all() and (order[c2 % N] == cols % N).all()
+
+
+@pytest.mark.parametrize("row_sparse", [False])
+def test_reference_optimizer_checkpoint_loads_and_steps_under_the_unpatched_lines(row_sparse):
+    """node_classification.py:35-37, :73-80 / run.py:230-236 on a module namespace as `install_as_mrgcn()` leaves the
+    reference's task modules: `optimizer = optim.Adam(...)`; `optimizer.load_state_dict(checkpoint[...])` with the
+    REFERENCE's own optimizer state (tests/golden/optim_checkpoint.npz: torch.optim.Adam over the reference model after
+    two epochs, `weight_I` moments `(B*N, out)`); one more epoch — gradients from the float64 oracle, there is no GPU
+    here — lands on the reference's parameters and optimizer state after ITS third epoch; `optimizer.state_dict()` hands
+    the moments back in the reference's shapes."""
+    import types
+
+    import mrgcn_amd
+    from mrgcn_amd.models.rgcn import RGCN
+    from oracle import rgcn_oracle as O
+    c = np.load(os.path.join(util.GOLDEN, "optim_checkpoint.npz"))
+    g, A = util.load_graph("graph_small")
+    N, R, B = int(c["meta.num_nodes"]), int(c["meta.R"]), int(c["meta.num_bases"])
+    dims = [tuple(int(x) for x in d) for d in c["dims"]]
+    task = types.ModuleType("fake_task_module")
+    task.optim, task.nn = torch.optim, torch.nn
+    mrgcn_amd.patch_task_optimizer(task, row_sparse=row_sparse)
+    model = RGCN([(6, 8, "mrgcn", torch.nn.ReLU()), (8, 4, "mrgcn", None)], R, N, B, 0.0, False, True, False)
+    names = [n for n, _ in model.named_parameters()]
+    assert names == [str(n) for n in c["param_names"]]
+    optimizer = task.optim.Adam([{"params": list(model.parameters())}], lr=0.01, weight_decay=0.0)
+    assert isinstance(optimizer, torch.optim.Adam)
+    checkpoint = {"model_state_dict": {n: torch.from_numpy(c["state2." + n]) for n in names},
+                  "optimizer_state_dict": {"state": {i: {"step": torch.tensor(float(c[f"optim2.{i}.step"])),
+                                                         "exp_avg": torch.from_numpy(c[f"optim2.{i}.exp_avg"]),
+                                                         "exp_avg_sq": torch.from_numpy(c[f"optim2.{i}.exp_avg_sq"])}
+                                                     for i in range(len(names))},
+                                           "param_groups": torch.optim.Adam([torch.nn.Parameter(torch.zeros(1)) for _ in names],
+                                                                            lr=0.01).state_dict()["param_groups"]}}
+    model.load_state_dict(checkpoint["model_state_dict"])            # node_classification.py:78
+    optimizer.load_state_dict(checkpoint["optimizer_state_dict"])    # node_classification.py:79
+    wI = model.layers["layer_0"].weight_I
+    assert tuple(optimizer.state[wI]["exp_avg"].shape) == tuple(wI.shape) == (N, B, 8)
+    # the third epoch's gradients (float64 oracle on the reference's state after two), clipped like the loop does
+    state = {n: c["state2." + n] for n in names}
+    idx, val = O.csr_to_coo(A, "norm_f32")
+    rec = O.train_steps(dims, R, N, B, True, False, state, c["X"], O.coo_to_csr(idx, val, A.shape), c["labels_idx"],
+                        c["labels_y"], 1)[0]
+    np.testing.assert_allclose(rec["loss"], float(c["loss_step3"]), rtol=1e-5)
+    for n, p in model.named_parameters():
+        gr = torch.from_numpy(rec["grads"][n]).float()
+        p.grad = gr.view(B, N, -1).permute(1, 0, 2).contiguous() if p is wI else gr
+    task.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    optimizer.step()
+    sd = model.state_dict()
+    for n in names:
+        diff = np.abs(sd[n].numpy() - c["state3." + n])
+        assert diff.max() <= 2e-5, (n, float(diff.max()))        # (moments in play: no sign-flip slack needed)
+    out = optimizer.state_dict()                                     # run.py:233
+    for i, n in enumerate(names):
+        st = out["state"][i]
+        assert tuple(st["exp_avg"].shape) == c[f"optim3.{i}.exp_avg"].shape, n
+        np.testing.assert_allclose(st["exp_avg"].numpy(), c[f"optim3.{i}.exp_avg"], rtol=1e-3, atol=1e-7, err_msg=n)
+        np.testing.assert_allclose(st["exp_avg_sq"].numpy(), c[f"optim3.{i}.exp_avg_sq"], rtol=2e-3, atol=1e-10, err_msg=n)
+        assert float(st["step"]) == 3.0

@@ -210,3 +210,83 @@ def test_clip_with_a_gradient_on_another_device_goes_through_torch():
     want = torch.sqrt(sum((p.grad.double().cpu() ** 2).sum() for p in params if p.grad is not None))
     assert abs(float(want) - float(norm)) < 1e-4 * float(norm) + 1e-6
     opt.step()
+
+
+@pytest.mark.parametrize("row_sparse", [False, True])
+def test_optimizer_checkpoints_interchange_with_the_reference_under_its_unpatched_lines(row_sparse):
+    """The reference's checkpoint lines as they are (node_classification.py:35-37, :73-80; run.py:230-236) inside a
+    module namespace as `install_as_mrgcn()` leaves the task modules (default: torch's Adam with the layout translated;
+    `patch_optimizer=True`: RowSparseAdam + this package's clip), against tests/golden/optim_checkpoint.npz — the
+    REFERENCE's model / optimizer state after two and three of its own epochs:
+      (a) two epochs here from the reference's initial parameters, then `optimizer.state_dict()`: every entry has the
+          reference's shape (`weight_I` moments `(B*N, out)`) and the reference's values — a checkpoint written here
+          loads in the reference;
+      (b) a fresh model + optimizer, `load_state_dict` of the reference's checkpoint after two epochs, one epoch of the
+          reference's loop: the reference's parameters, moments and loss of its third epoch."""
+    import os
+    import types
+
+    import mrgcn_amd
+    from mrgcn_amd.models.rgcn import RGCN
+    c = np.load(os.path.join(util.GOLDEN, "optim_checkpoint.npz"))
+    g, A_csr = util.load_graph("graph_small")
+    A = util.coo_tensor(A_csr, "norm_f32", "cuda")
+    N, R, B = int(c["meta.num_nodes"]), int(c["meta.R"]), int(c["meta.num_bases"])
+    task = types.ModuleType("fake_task_module")
+    task.optim, task.nn = torch.optim, torch.nn               # `import torch.optim as optim`, `import torch.nn as nn`
+    mrgcn_amd.patch_task_optimizer(task, row_sparse=row_sparse)
+    optim, nn = task.optim, task.nn
+    X = torch.from_numpy(c["X"]).cuda()
+    idx, tgt = torch.from_numpy(c["labels_idx"]).cuda(), torch.from_numpy(c["labels_y"]).cuda()
+    names = [str(n) for n in c["param_names"]]
+
+    def build():
+        model = RGCN([(6, 8, "mrgcn", torch.nn.ReLU()), (8, 4, "mrgcn", None)], R, N, B, 0.0, False, True, False).cuda()
+        assert [n for n, _ in model.named_parameters()] == names
+        optimizer = optim.Adam([{"params": list(model.parameters())}], lr=0.01, weight_decay=0.0)   # :35-37
+        return model, optimizer, nn.CrossEntropyLoss()
+
+    def epoch(model, optimizer, criterion):
+        loss = criterion(model(X, A)[idx], tgt)
+        optimizer.zero_grad()
+        loss.backward()                                        # :190-193
+        nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        optimizer.step()
+        return float(loss)
+
+    def check_against(model, optimizer, k, tight):
+        sd, osd = model.state_dict(), optimizer.state_dict()   # run.py:232-233
+        for i, n in enumerate(names):
+            diff = np.abs(sd[n].cpu().numpy() - c[f"state{k}.{n}"])
+            assert diff.max() <= (2e-5 if tight else 0.021 * k), (n, float(diff.max()))
+            assert (diff > 2e-5).mean() < 2e-2, n
+            st = osd["state"][i]
+            assert tuple(st["exp_avg"].shape) == c[f"optim{k}.{i}.exp_avg"].shape == tuple(sd[n].shape), n
+            np.testing.assert_allclose(st["exp_avg"].cpu().numpy(), c[f"optim{k}.{i}.exp_avg"], rtol=2e-3,
+                                       atol=2e-5 * float(np.abs(c[f"optim{k}.{i}.exp_avg"]).max()), err_msg=n)
+            np.testing.assert_allclose(st["exp_avg_sq"].cpu().numpy(), c[f"optim{k}.{i}.exp_avg_sq"], rtol=4e-3,
+                                       atol=4e-5 * float(np.abs(c[f"optim{k}.{i}.exp_avg_sq"]).max()), err_msg=n)
+            assert float(st["step"]) == float(k)
+
+    # (a) written here, readable there
+    model, optimizer, criterion = build()
+    model.load_state_dict({n: torch.from_numpy(c["init." + n]) for n in names})
+    losses = [epoch(model, optimizer, criterion) for _ in range(2)]
+    np.testing.assert_allclose(losses, [float(c["loss_step1"]), float(c["loss_step2"])], rtol=2e-4, atol=2e-5)
+    check_against(model, optimizer, 2, tight=False)
+    # (b) written there, resumed here
+    model, optimizer, criterion = build()
+    checkpoint = {"model_state_dict": {n: torch.from_numpy(c["state2." + n]) for n in names},
+                  "optimizer_state_dict": {
+                      "state": {i: {"step": torch.tensor(float(c[f"optim2.{i}.step"])),
+                                    "exp_avg": torch.from_numpy(c[f"optim2.{i}.exp_avg"]),
+                                    "exp_avg_sq": torch.from_numpy(c[f"optim2.{i}.exp_avg_sq"])} for i in range(len(names))},
+                      "param_groups": torch.optim.Adam([torch.nn.Parameter(torch.zeros(1)) for _ in names],
+                                                       lr=0.01).state_dict()["param_groups"]}}
+    model.load_state_dict(checkpoint["model_state_dict"])              # :78
+    optimizer.load_state_dict(checkpoint["optimizer_state_dict"])      # :79
+    loss3 = epoch(model, optimizer, criterion)
+    np.testing.assert_allclose(loss3, float(c["loss_step3"]), rtol=2e-4, atol=2e-5)
+    check_against(model, optimizer, 3, tight=True)
+    wI = model.layers["layer_0"].weight_I
+    assert (wI.grad is None) == bool(row_sparse)        # the fast pair really left the gradient row-sparse
