@@ -1682,6 +1682,7 @@ int long_rows_known(mrgcn_support *q, const int32_t *ptr, int64_t rows, hipStrea
 int32_t *g_up = nullptr;
 size_t g_up_ints = 0;
 hipEvent_t g_up_done = nullptr;
+int g_up_dev = -1;  // the device g_up_done belongs to (an event records only on streams of its own device)
 bool g_up_pending = false;
 
 // the orders' chunk lists of every level: host work on the landed group pointers, then one asynchronous upload per
@@ -1714,7 +1715,16 @@ int supports_upload(std::vector<SupStage> &st, hipStream_t s) {
     MRGCN_HIP_TRY(hipHostMalloc((void **)&g_up, want * sizeof(int32_t), hipHostMallocDefault));
     g_up_ints = want;
   }
-  if (!g_up_done) MRGCN_HIP_TRY(hipEventCreateWithFlags(&g_up_done, hipEventDisableTiming));
+  int dev_now = 0;
+  MRGCN_HIP_TRY(hipGetDevice(&dev_now));
+  if (g_up_done && g_up_dev != dev_now) {  // a build on another device of this process: the event follows it
+    (void)hipEventDestroy(g_up_done);
+    g_up_done = nullptr;
+  }
+  if (!g_up_done) {
+    MRGCN_HIP_TRY(hipEventCreateWithFlags(&g_up_done, hipEventDisableTiming));
+    g_up_dev = dev_now;
+  }
   size_t at = 0;
   for (int i = 0; i < n; ++i) {
     mrgcn_support *q = st[i].q;
@@ -1869,7 +1879,8 @@ void release_support(mrgcn_support *q) {
   parked.push_back(q);
   std::vector<mrgcn_support *> keep;
   for (mrgcn_support *x : parked) {
-    if (x->device != cur) (void)hipSetDevice(x->device);
+    const int xdev = x->device;  // (x may be deleted below)
+    if (xdev != cur) (void)hipSetDevice(xdev);
     const uint64_t ep = pool_sync_begin();
     if (hipDeviceSynchronize() != hipSuccess) {
       (void)hipGetLastError();
@@ -1879,7 +1890,7 @@ void release_support(mrgcn_support *q) {
       for (void *a : x->owned) pool_free(a, x->build_stream, ep);
       delete x;
     }
-    if (x->device != cur) (void)hipSetDevice(cur);
+    if (xdev != cur) (void)hipSetDevice(cur);
   }
   parked.swap(keep);
 }

@@ -343,8 +343,11 @@ class _RgcnLayer(torch.autograd.Function):
         row_flags = meta["row_live"] if meta else None
         if ctx.relu and not (meta and meta["relu_applied"]):
             dY = relu_bwd(dY, Y)
-            row_flags = None
+            if not (meta and meta.get("structural")):
+                row_flags = None   # (a structural row set stays a valid superset under the mask; a scanned one is stale)
         sparse_rows = bool(meta and meta.get("sparse_rows"))
+        if sparse_rows and row_flags is None:
+            raise L.MrgcnError("internal: an output gradient with unwritten rows arrived without its row flags")
         if sparse_rows and has_bias:
             raise L.MrgcnError("internal: an output gradient with unwritten rows reached a layer with a bias")
         dbias = dY.sum(0) if has_bias else None
@@ -437,12 +440,15 @@ class _RgcnLayer(torch.autograd.Function):
                     # and ||dV||^2, and ClipAdam rebuilds each live block from dM inside the Adam pass
                     # (mrgcn_adam_step_rows_fused_f32); otherwise the blocks of the live nodes go to rows["g"]
                     fused = bool(lib.mrgcn_adam_rows_fused_supported(plan.handle, Bn, F))
-                    if rows is None or rows["shape"] != tuple(weight_I.shape) or rows["cur"].device != dev:
-                        rows = dict(g=None, shape=tuple(weight_I.shape),
-                                    cur=torch.zeros(N_, dtype=torch.uint8, device=dev),
+                    if rows is None or rows["shape"] != tuple(weight_I.shape) or rows["ever"].device != dev:
+                        rows = dict(g=None, shape=tuple(weight_I.shape), cur=None, cur_owned=False,
                                     ever=torch.zeros(N_, dtype=torch.uint8, device=dev), sumsq=None, fresh=False,
                                     seeded_for=None, fused=None)
                         param._mrgcn_rows = rows
+                    if not rows.get("cur_owned"):
+                        # (`cur` may be a gradient support's own node flags — _support_weight_I_grads — which this path
+                        # must not overwrite: the flags written below are this entry's own)
+                        rows["cur"], rows["cur_owned"] = torch.zeros(N_, dtype=torch.uint8, device=dev), True
                     if not fused and rows["g"] is None:
                         rows["g"] = torch.empty_like(wI)
                 if rows is not None:
@@ -522,15 +528,25 @@ def _discovered_rows(owner, plan, dY, F, dev):
         return None
     if dY.dim() != 2 or dY.stride(1) != 1 or dY.dtype != torch.float32:
         return None
+    if owner.__dict__.get("_mrgcn_found_rows_dense"):
+        return None   # (most rows carry gradient: the general transposed product is the right backward, see below)
     flags = torch.empty((dY.shape[0],), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         L.check(L.load().mrgcn_rows_nonzero_f32(dY.data_ptr(), dY.stride(0), F, dY.shape[0], flags.data_ptr(),
                                                 _stream(dev)), "mrgcn_rows_nonzero_f32")
     ent = owner.__dict__.get("_mrgcn_found_rows")
+    grown = False
     if ent is None or ent.shape != flags.shape or ent.device != flags.device:
-        ent = flags
+        ent, grown = flags, True
     elif bool((flags > ent).any()):   # a row outside the set so far: the set grows (a new tensor: a new support)
-        ent = torch.maximum(ent, flags)
+        ent, grown = torch.maximum(ent, flags), True
+    if grown and int(ent.sum(dtype=torch.int64)) > _LiveGauge._DENSE * plan.num_rows:
+        # a dense gradient (every node labelled, a loss over all rows): a support over nearly the whole graph would be a
+        # second copy of the transposed arrays for nothing — from now on this layer's plain gradients take the general
+        # transposed product without being looked at
+        owner.__dict__["_mrgcn_found_rows_dense"] = True
+        owner.__dict__.pop("_mrgcn_found_rows", None)
+        return None
     owner.__dict__["_mrgcn_found_rows"] = ent
     # (rows outside the set are exact zeros in THIS gradient: it was just looked at)
     return {"version": dY._version, "row_live": ent, "relu_applied": False, "structural": True, "sparse_rows": False}
@@ -573,7 +589,9 @@ def _support_weight_I_grads(owner, sup, plan, dM, ld, weight_I, comp_I, F, s):
         if not fused and rows["g"] is None:
             rows["g"] = torch.empty_like(wI)
     if rows is not None:
-        rows["cur"] = sup.node_flags()  # the nodes of the support: the same set every epoch
+        # the nodes of the support: the same set every epoch (the support's own tensor, read-only here: the marking
+        # path allocates its own when it takes over — `cur_owned`)
+        rows["cur"], rows["cur_owned"] = sup.node_flags(), False
         if fused:
             # norm-only: dcomp and ||dV||^2 are written whole (no zero fills), nothing is accumulated
             sq = torch.empty((), dtype=torch.float64, device=dev)

@@ -397,7 +397,10 @@ def partitioned_loss(logits_local, idx_global, targets, part: NodePartition, gro
     li, lt, share = _label_shard(idx_global, targets, part, logits_local.device)
     if li is not None:
         local = categorical_crossentropy(logits_local, li, lt) * share
-    elif logits_local.is_cuda:
+    elif logits_local.is_cuda and Fn._SUPPORT:
+        # (the predicate under which train.categorical_crossentropy gives the labelled ranks a structural gradient:
+        # every rank must reach `_ReduceScatterRows.backward` with the same kind of note, or the ranks' collective
+        # sequences differ — with MRGCN_SUPPORT=0 nobody has one and this rank takes the plain zero loss below)
         zf = part.__dict__.get("_zero_flags")
         if zf is None or zf.numel() != logits_local.shape[0] or zf.device != logits_local.device:
             zf = part.__dict__["_zero_flags"] = torch.zeros((logits_local.shape[0],), dtype=torch.uint8,
