@@ -223,7 +223,8 @@ def _row_sparse_backward(case):
     finally:
         Fn.row_sparse_weight_grad(prev)
     ent = Fn.pop_row_grad(case.wI)
-    return logits, loss, ent
+    # (detached: a live autograd graph keeps its AccumulateGrad nodes on THIS stream, which breaks a later capture)
+    return logits.detach(), loss.detach(), ent
 
 
 def _run_nc(case):
@@ -300,15 +301,39 @@ def test_am_gradients_clip_and_adam_against_the_float64_oracle_at_full_size():
     _run_nc(case)
 
 
+def test_the_step_check_catches_one_bad_element_of_one_node_block():
+    """The comparison itself: after a correct default step at AM/20, ONE element of ONE sampled live node block is
+    moved by 2e-5 (parameter) / has its first moment scaled by 1.01 — either must fail the check."""
+    from mrgcn_amd.train import ClipAdam, train_step
+    case = _NcCase("am", scale=0.05, seed=1)
+    case.reset()
+    before = case.snapshot()
+    opt = ClipAdam(case.model.parameters(), lr=LR, max_norm=1.0)
+    train_step(case.model, lambda: case.model(case.X, case.A), case.idx, case.y, opt)
+    case.check_after_step(case.ora1, opt, before, "unmodified")
+    live = np.flatnonzero(np.abs(case.ora1["wI"][0]["grad"]).reshape(len(case.sample), -1).max(1) > 0)
+    node = int(case.sample[live[len(live) // 2]])
+    k = int(np.abs(case.ora1["wI"][0]["grad"][live[len(live) // 2]]).argmax())
+    with torch.no_grad():
+        case.wI.view(case.N, -1)[node, k] += 2e-5
+    with pytest.raises(AssertionError, match="parameter"):
+        case.check_after_step(case.ora1, opt, before, "one parameter element moved")
+    with torch.no_grad():
+        case.wI.view(case.N, -1)[node, k] -= 2e-5
+        opt.state[case.wI]["exp_avg"].view(case.N, -1)[node, k] *= 1.01
+    with pytest.raises(AssertionError, match="exp_avg"):
+        case.check_after_step(case.ora1, opt, before, "one moment element scaled")
+
+
 def test_am_quarter_gradients_clip_and_adam_against_the_float64_oracle():
     """The same at AM/4 with another seed (a cheaper second sample of the same kernels)."""
     _run_nc(_NcCase("am", scale=0.25, seed=3))
 
 
 def test_synth10m_gradients_clip_and_adam_against_the_float64_oracle_at_full_size():
-    """BASELINE config 5 (N = 10 M, R = 101, 10 bases, 155 -> 16 -> 11): the label set is cut to 300 of the 10 000 so
-    that the host side stays within a minute or two; the receptive field still spans about a million nodes."""
-    case = _NcCase("synth10m", labelled=300)
+    """BASELINE config 5 (N = 10 M, R = 101, 10 bases, 155 -> 16 -> 11): the label set is cut to 2 000 of the 10 000 so
+    that the host side stays within a minute or two; the receptive field still spans 4.8 M nodes."""
+    case = _NcCase("synth10m", labelled=2000)
     assert (case.N, case.R) == (10_000_000, 101)
     _run_nc(case)
 
