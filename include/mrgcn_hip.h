@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MRGCN_ABI_VERSION 3
+#define MRGCN_ABI_VERSION 4
 
 enum mrgcn_status {
   MRGCN_OK = 0,
@@ -428,11 +428,16 @@ int64_t mrgcn_support_mix_bwd_workspace(const mrgcn_support_t *support, int32_t 
 int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *support, const float *dM, int64_t ldM, const float *V,
                               const float *comp, int32_t B, int32_t F, float *dV, int32_t dense, float *dcomp,
                               double *dV_sumsq, float *workspace, int64_t workspace_floats, void *stream);
-/* mrgcn_adam_step_rows_fused_f32 on the support: row_cur = NODE_FLAGS */
+/* mrgcn_adam_step_rows_fused_f32 on the support: row_cur = NODE_FLAGS.  The support's nodes are walked as a list
+ * (two node blocks in flight per wave, nontemporal p / m / v); `ever_outside` != 0 adds the pass over the nodes that
+ * are flagged in row_ever without being nodes of this support (moments from steps on another row set: they decay,
+ * their parameters drift on, as torch.optim.Adam does for a zero gradient).  0: the caller states there are none
+ * (every step since row_ever was zeroed ran on this support) and that pass is not launched. */
 int mrgcn_support_adam_rows_fused_f32(const mrgcn_support_t *support, const float *dM, int64_t ldM, const float *comp,
                                       int32_t B, int32_t F, float *param, float *exp_avg, float *exp_avg_sq,
                                       uint8_t *row_ever, float lr, float beta1, float beta2, float eps, int64_t step,
-                                      const float *bc_dev, const float *grad_scale, void *stream);
+                                      const float *bc_dev, const float *grad_scale, int32_t ever_outside,
+                                      void *stream);
 /* mrgcn_rel_transform_bwd_masked_f32 on the support: dW (nullable; written whole) and dX (nullable; every row
  * written, zeros outside NODE_FLAGS; `relu_mask_from_x` as there).  workspace:
  * mrgcn_support_rel_transform_bwd_workspace floats. */

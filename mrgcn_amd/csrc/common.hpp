@@ -145,7 +145,8 @@ int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8
                            const float *dM, int64_t ldM, const float *comp, int32_t B, int32_t F, float *param,
                            float *exp_avg, float *exp_avg_sq, const uint8_t *row_cur, uint8_t *row_ever, float lr,
                            float beta1, float beta2, float eps, int64_t step, const float *bc_dev,
-                           const float *grad_scale, hipStream_t s);
+                           const float *grad_scale, hipStream_t s, const int32_t *lnode = nullptr,
+                           const int32_t *lnptr = nullptr, int64_t NL = 0, int ever_outside = 1);
 bool xform_use_mfma();
 // hipMemsetAsync for the compute calls (plan.hip).  On a capturing stream the fill is one kernel of this package:
 // a captured hipMemsetAsync whose size is not a whole number of 16-byte pieces becomes a memset node that ROCm 7.2

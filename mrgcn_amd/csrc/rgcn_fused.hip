@@ -777,7 +777,7 @@ __global__ __launch_bounds__(kFusedTB, 8) void k_adam_rows_fused(
     const float *__restrict__ dM, int64_t ldM, const float *__restrict__ comp, int64_t N, int R, int B, int F,
     float *__restrict__ p, float *__restrict__ m, float *__restrict__ v, const uint8_t *__restrict__ cur,
     uint8_t *__restrict__ ever, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
-    const float *__restrict__ scale, const float *__restrict__ bc_dev) {
+    const float *__restrict__ scale, const float *__restrict__ bc_dev, int skip_cur) {
   extern __shared__ __align__(16) float s_comp[];  // [R][B]
   for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_comp[t] = comp[t];
   __syncthreads();
@@ -809,7 +809,10 @@ __global__ __launch_bounds__(kFusedTB, 8) void k_adam_rows_fused(
   for (int64_t jb = (int64_t)blockIdx.x * nw + wv; jb < N; jb += 64 * stride) {
     const int64_t jl = jb + lane * stride;
     const int64_t jc = min(jl, N - 1);
-    const int32_t flv = jl < N ? ((int32_t)cur[jc] | ((int32_t)ever[jc] << 1)) : 0;
+    int32_t flv = jl < N ? ((int32_t)cur[jc] | ((int32_t)ever[jc] << 1)) : 0;
+    // skip_cur: the nodes with gradient this step were updated by k_adam_rows_list; what is left are nodes that hold
+    // moments from earlier steps without being in the list (their moments decay, their parameters drift on)
+    if (skip_cur && (flv & 1)) flv = 0;
     const int32_t n0v = nptr[jc], n1v = nptr[jc + 1];
     uint64_t act = __builtin_amdgcn_ballot_w64(flv != 0);
     while (act) {
@@ -877,6 +880,146 @@ __global__ __launch_bounds__(kFusedTB, 8) void k_adam_rows_fused(
       }
       if (c && lane == 0) ever[j] = 1;
     }
+  }
+}
+
+// The same update over a LIST of nodes (a gradient support's live nodes: `lnode`, with `lnptr` their live column ranges
+// by list position) — what the replayed epoch runs.  Against k_adam_rows_fused (stream_lab, AM shape, 828 703 live nodes of
+// 1 600 bytes x 3 arrays in and out: 2 151 -> 1 693 us = the rate of a plain triad over the same blocks, 4.7 TB/s on the
+// box where a float4 copy moves 4.7 TB/s):
+//   * all NH = ceil(B F / 256) 16-byte pieces of a lane are loaded in ONE round (the round-4 kernel took them 64 pieces
+//     at a time, each round behind the previous round's arithmetic);
+//   * the NEXT node's p / m / v pieces are in flight while this node's gradient is formed and its update stored
+//     (twice the registers: 4 waves per SIMD);
+//   * p / m / v are touched once per epoch: nontemporal loads and stores (3.95 -> 4.70 TB/s for the bare triad over the
+//     same blocks — they do not push the rest of the epoch's working set out of the Infinity Cache).
+// Same fmaf chain per element as k_adam_rows_fused: the same bits.
+template <int NH, bool PIPE>
+__global__ __launch_bounds__(kFusedTB, PIPE ? 4 : 8) void k_adam_rows_list(
+    const int32_t *__restrict__ lnode, const int32_t *__restrict__ lnptr, const int32_t *__restrict__ lrel,
+    const float *__restrict__ dM, int64_t ldM, const float *__restrict__ comp, int64_t NL, int R, int B, int F,
+    float *__restrict__ p, float *__restrict__ m, float *__restrict__ v, uint8_t *__restrict__ ever, float lr, float b1,
+    float b2, float eps, float bc1, float bc2_sqrt, const float *__restrict__ scale, const float *__restrict__ bc_dev) {
+  extern __shared__ __align__(16) float s_comp[];  // [R][B]
+  for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_comp[t] = comp[t];
+  __syncthreads();
+  if (bc_dev) {
+    bc1 = bc_dev[0];
+    bc2_sqrt = bc_dev[1];
+  }
+  const float sc = scale ? *scale : 1.f;
+  const float step = lr / bc1;
+  auto upd = [&](float &pp, float gg, float &mm, float &vv) {  // == k_adam with wd = 0
+    gg *= sc;
+    mm = fmaf(b1, mm, (1.f - b1) * gg);
+    vv = fmaf(b2, vv, (1.f - b2) * gg * gg);
+    float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= step * (mm / denom);
+  };
+  using f4 = __attribute__((ext_vector_type(4))) float;
+  const int lane = threadIdx.x & 63;
+  const int nv = (B * F) >> 2;  // 16-byte pieces of a block
+  const unsigned magicF = 65536u / (unsigned)F + 1u;  // e / F == (e * magicF) >> 16 for e * F < 2^16 (B F <= 1024)
+  const int kq = lane >> 4, oq = lane & 15;
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int bf[NH][4];  // (basis, feature) of the lane's elements
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned e = 4u * (unsigned)min(lane + 64 * h, nv - 1) + (unsigned)k;
+      const unsigned bb = (e * magicF) >> 16;
+      bf[h][k] = (int)((bb << 8) | (e - bb * (unsigned)F));
+    }
+  f4 P[NH], M[NH], V[NH];
+  // unconditional at clamped addresses (see the note on straight-line loads)
+  auto load_block = [&](int64_t j, f4 *Pd, f4 *Md, f4 *Vd) {
+    const f4 *p4 = reinterpret_cast<const f4 *>(p) + j * (int64_t)nv;
+    const f4 *m4 = reinterpret_cast<const f4 *>(m) + j * (int64_t)nv;
+    const f4 *v4 = reinterpret_cast<const f4 *>(v) + j * (int64_t)nv;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int q = min(lane + 64 * h, nv - 1);
+      Pd[h] = __builtin_nontemporal_load(p4 + q);
+      Md[h] = __builtin_nontemporal_load(m4 + q);
+      Vd[h] = __builtin_nontemporal_load(v4 + q);
+    }
+  };
+  int64_t i = w;
+  if (i >= NL) return;
+  int64_t j = lnode[i];
+  int32_t n0 = lnptr[i], n1 = lnptr[i + 1];
+  if (PIPE) load_block(j, P, M, V);
+  for (; i < NL; i += nw) {
+    // the node's first four live columns: the 16-lane group kq reads column n0 + kq
+    const int32_t cc0 = max(min(n0 + kq, n1 - 1), 0);
+    bool lv = n0 + kq < n1;
+    int32_t rmine = lrel[cc0];
+    float dmine = dM[(int64_t)cc0 * ldM + min(oq, F - 1)];
+    // the next node's ids and (pipelined) block, issued before this node's arithmetic
+    const int64_t inext = min(i + nw, NL - 1);
+    const int64_t jn = lnode[inext];
+    const int32_t n0n = lnptr[inext], n1n = lnptr[inext + 1];
+    f4 Pn[NH], Mn[NH], Vn[NH];
+    if (PIPE) load_block(jn, Pn, Mn, Vn);
+    else load_block(j, P, M, V);
+    float g[NH][4];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[h][k] = 0.f;
+    for (int32_t cb = n0;;) {
+      const uint64_t bl = __builtin_amdgcn_ballot_w64(lv && oq == 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (!((bl >> (16 * kk)) & 1ull)) continue;  // wave uniform: past the node's columns
+        const int r = __builtin_amdgcn_readlane(rmine, 16 * kk);
+        const float *crow = s_comp + r * B;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            g[h][k] = fmaf(crow[bf[h][k] >> 8], __shfl(dmine, 16 * kk + (bf[h][k] & 255)), g[h][k]);
+      }
+      cb += 4;
+      if (cb >= n1) break;  // (few nodes have more than four live columns)
+      const int32_t cc = min(cb + kq, n1 - 1);
+      lv = cb + kq < n1;
+      rmine = lrel[cc];
+      dmine = dM[(int64_t)cc * ldM + min(oq, F - 1)];
+    }
+    f4 *p4 = reinterpret_cast<f4 *>(p) + j * (int64_t)nv;
+    f4 *m4 = reinterpret_cast<f4 *>(m) + j * (int64_t)nv;
+    f4 *v4 = reinterpret_cast<f4 *>(v) + j * (int64_t)nv;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float pp = P[h][k], mm = M[h][k], vv = V[h][k];
+        upd(pp, g[h][k], mm, vv);
+        P[h][k] = pp;
+        M[h][k] = mm;
+        V[h][k] = vv;
+      }
+      const int q = lane + 64 * h;
+      if (q < nv) {
+        __builtin_nontemporal_store(P[h], p4 + q);
+        __builtin_nontemporal_store(M[h], m4 + q);
+        __builtin_nontemporal_store(V[h], v4 + q);
+      }
+    }
+    if (lane == 0) ever[j] = 1;
+    if (PIPE) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        P[h] = Pn[h];
+        M[h] = Mn[h];
+        V[h] = Vn[h];
+      }
+    }
+    j = jn;
+    n0 = n0n;
+    n1 = n1n;
   }
 }
 
@@ -1724,11 +1867,17 @@ int mix_bwd_nm_arrays(const int32_t *nptr, const int32_t *urel, int64_t N, int R
                                   node_cur);
 }
 
+static bool adam_list_enabled() {
+  static const bool on = !(getenv("MRGCN_ADAM_LIST") && atoi(getenv("MRGCN_ADAM_LIST")) == 0);
+  return on;
+}
+
 int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8_t *col_live, int64_t N, int R,
                            const float *dM, int64_t ldM, const float *comp, int32_t B, int32_t F, float *param,
                            float *exp_avg, float *exp_avg_sq, const uint8_t *row_cur, uint8_t *row_ever, float lr,
                            float beta1, float beta2, float eps, int64_t step, const float *bc_dev,
-                           const float *grad_scale, hipStream_t s) {
+                           const float *grad_scale, hipStream_t s, const int32_t *lnode, const int32_t *lnptr, int64_t NL,
+                           int ever_outside) {
   float bc1 = 1.f, bc2s = 1.f;
   if (!bc_dev) {
     bc1 = (float)(1.0 - pow((double)beta1, (double)step));
@@ -1742,7 +1891,31 @@ int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8
   int64_t grid = (int64_t)256 * per_cu;
   const int64_t want = (N + kFusedTB / 64 - 1) / (kFusedTB / 64);
   if (grid > want) grid = want;
-  {
+  // a list of the nodes with gradient (a gradient support) and blocks of at most two 16-byte pieces per lane: the
+  // pipelined kernel takes the list, the flag scan below then only visits what the list left out
+  const bool listed = lnode && lnptr && !col_live && nv <= 128 && adam_list_enabled();
+  if (listed && NL > 0) {
+    const int64_t lwant = (NL + kFusedTB / 64 - 1) / (kFusedTB / 64);
+    int64_t lgrid = 256;  // 4 waves per SIMD (two node blocks in flight per wave): one block of 16 waves per CU
+    if (lgrid > lwant) lgrid = lwant;
+#define ADAM_LIST_GO(NH_)                                                                                          \
+  do {                                                                                                             \
+    auto kfn = k_adam_rows_list<NH_, true>;                                                                        \
+    static size_t lds_allowed = 48 * 1024;                                                                         \
+    if (lds > lds_allowed) {                                                                                       \
+      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      lds_allowed = lds;                                                                                           \
+    }                                                                                                              \
+    kfn<<<dim3((unsigned)lgrid), dim3(kFusedTB), lds, s>>>(lnode, lnptr, urel, dM, ldM, comp, NL, R, B, F, param,  \
+                                                           exp_avg, exp_avg_sq, row_ever, lr, beta1, beta2, eps,   \
+                                                           bc1, bc2s, grad_scale, bc_dev);                         \
+  } while (0)
+    if (nv <= 64) ADAM_LIST_GO(1);
+    else ADAM_LIST_GO(2);
+#undef ADAM_LIST_GO
+    MRGCN_HIP_TRY(hipGetLastError());
+  }
+  if (!listed || ever_outside) {
     auto kfn = k_adam_rows_fused;
     static size_t lds_allowed = 48 * 1024;
     if (lds > lds_allowed) {
@@ -1751,7 +1924,7 @@ int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8
     }
     kfn<<<dim3((unsigned)grid), dim3(kFusedTB), lds, s>>>(nptr, urel, col_live, dM, ldM, comp, N, R, B, F,
                                                           param, exp_avg, exp_avg_sq, row_cur, row_ever, lr, beta1,
-                                                          beta2, eps, bc1, bc2s, grad_scale, bc_dev);
+                                                          beta2, eps, bc1, bc2s, grad_scale, bc_dev, listed ? 1 : 0);
   }
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;

@@ -456,7 +456,8 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
 int mrgcn_support_adam_rows_fused_f32(const mrgcn_support_t *q, const float *dM, int64_t ldM, const float *comp,
                                       int32_t B, int32_t F, float *param, float *exp_avg, float *exp_avg_sq,
                                       uint8_t *row_ever, float lr, float beta1, float beta2, float eps, int64_t step,
-                                      const float *bc_dev, const float *grad_scale, void *stream) {
+                                      const float *bc_dev, const float *grad_scale, int32_t ever_outside,
+                                      void *stream) {
   MRGCN_REQUIRE(q && dM && comp && param && exp_avg && exp_avg_sq && row_ever, "NULL");
   MRGCN_REQUIRE(mrgcn_adam_rows_fused_supported(q->plan, B, F), "shape outside mrgcn_adam_rows_fused_supported");
   MRGCN_REQUIRE(ldM >= F, "ldM");
@@ -466,7 +467,7 @@ int mrgcn_support_adam_rows_fused_f32(const mrgcn_support_t *q, const float *dM,
   const mrgcn_plan *p = q->plan;
   return adam_rows_fused_arrays(q->nlptr, q->lrel, nullptr, p->num_nodes, (int)p->num_relations, dM, ldM, comp, B, F,
                                 param, exp_avg, exp_avg_sq, q->node_flags, row_ever, lr, beta1, beta2, eps, step,
-                                bc_dev, grad_scale, (hipStream_t)stream);
+                                bc_dev, grad_scale, (hipStream_t)stream, q->lnode, q->lnptr, q->NL, ever_outside);
 }
 
 int64_t mrgcn_support_rel_transform_bwd_workspace(const mrgcn_support_t *q, int32_t K, int32_t F, int32_t need_dX,

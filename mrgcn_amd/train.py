@@ -348,9 +348,11 @@ class ClipAdam(torch.optim.Optimizer):
                     # these flags have not seen this optimizer's moments yet (a loaded or dense-built state,
                     # a fresh gradient entry): every node that holds a non-zero moment counts as `ever`
                     ent["ever"].zero_()
+                    ent["ever_in"] = None      # which row set the flags lie inside: None = none set yet
                     if st["step"] > 0 or self._dev_step:
                         nz = (st["exp_avg"] != 0).flatten(1).any(1) | (st["exp_avg_sq"] != 0).flatten(1).any(1)
                         ent["ever"] |= nz.to(torch.uint8)
+                        ent["ever_in"] = "any"  # (moments from steps this entry has not seen)
                     ent["seeded_for"] = owner
                 st["step"] += 1
                 b1, b2 = group["betas"]
@@ -364,12 +366,18 @@ class ClipAdam(torch.optim.Optimizer):
                     raise L.MrgcnError("row-sparse weight_I gradient: weight_I_comp was modified between backward and "
                                        "the node table's update (the fused update re-reads it)")
                 if fz is not None and fz.get("sup") is not None:  # the same on the gradient support of the label set
+                    # every step since the flags were zeroed ran on THIS support: no node outside it holds moments and
+                    # the pass that looks for such nodes is not launched
+                    inside = ent.get("ever_in", "any")
+                    outside = 0 if (inside is None or inside is fz["sup"]) else 1
+                    ent["ever_in"] = fz["sup"] if not outside else "any"
                     L.check(lib.mrgcn_support_adam_rows_fused_f32(
                         fz["sup"].handle, fz["dM"].data_ptr(), fz["ld"], fz["comp"].data_ptr(), fz["B"], fz["F"],
                         p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), ent["ever"].data_ptr(),
                         float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), bc, coef_ptr,
-                        s), "mrgcn_support_adam_rows_fused_f32")
+                        outside, s), "mrgcn_support_adam_rows_fused_f32")
                     continue
+                ent["ever_in"] = "any"
                 if fz is not None:  # no gradient tensor: the blocks are rebuilt from dM inside the Adam pass
                     L.check(lib.mrgcn_adam_step_rows_fused_f32(
                         fz["plan"].handle, fz["dM"].data_ptr(), fz["ld"], fz["live"].data_ptr(), fz["comp"].data_ptr(),
