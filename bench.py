@@ -1064,7 +1064,17 @@ def main():
         dst = torch.empty_like(src)
         t_cp = event_time_ms(lambda: dst.copy_(src), 5, stream)
         extra["device_copy_gbps"] = 2 * src.numel() * 4 / (t_cp * 1e-3) / 1e9  # read + write
-        del src, dst
+        # the same as hand-written kernels of this library: a float4 copy and a 3-read / 3-write pass (Adam's shape);
+        # THESE are the yardsticks the streaming kernels of the epoch are held against
+        lib_ = L.load()
+        t_cp = event_time_ms(lambda: L.check(lib_.mrgcn_probe_copy_f32(src.data_ptr(), dst.data_ptr(), src.numel(), stream),
+                                             "mrgcn_probe_copy_f32"), 5, stream)
+        extra["device_copy_gbps_hip"] = 2 * src.numel() * 4 / (t_cp * 1e-3) / 1e9
+        third = torch.zeros_like(src)
+        t_tr = event_time_ms(lambda: L.check(lib_.mrgcn_probe_triad_f32(src.data_ptr(), dst.data_ptr(), third.data_ptr(),
+                                                                       src.numel(), stream), "mrgcn_probe_triad_f32"), 5, stream)
+        extra["triad_gbps"] = 6 * src.numel() * 4 / (t_tr * 1e-3) / 1e9
+        del src, dst, third
         if have_model:
             n_params = sum(p.numel() for p in model.parameters())
             extra["param_bytes"] = 4 * n_params * (1 + 1 + 6)  # grad write, clip read, Adam 3 reads + 3 writes

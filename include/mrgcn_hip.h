@@ -496,6 +496,11 @@ int mrgcn_support_rel_transform_bwd_compact_f32(const mrgcn_support_t *support, 
 /* ---- epoch kernels around the layers ----------------------------------------------
  * out = dY * (Y > 0): backward of the nn.ReLU between layers (rgcn.py:86-87) */
 int mrgcn_relu_bwd_f32(const float *dY, const float *Y, int64_t n, float *out, void *stream);
+/* Streaming yardsticks for measurement (bench.py: extra.device_copy_gbps_hip, extra.triad_gbps): dst = src as a plain
+ * float4 copy, and a 3-read / 3-write elementwise pass with Adam's arithmetic (the memory shape of a dense optimizer
+ * step).  n % 4 == 0, 16-byte aligned.  Nothing in the package calls them. */
+int mrgcn_probe_copy_f32(const float *src, float *dst, int64_t n, void *stream);
+int mrgcn_probe_triad_f32(float *p, float *m, float *v, int64_t n, void *stream);
 /* the same with row-strided operands: out[r, 0:F] = dY[r, 0:F] * (Y[r, 0:F] > 0) — the layer output Y of the
  * COMPACT product may live in a buffer with padded rows (MRGCN_SPMM_PAD_WRITABLE) */
 int mrgcn_relu_bwd_rows_f32(const float *dY, int64_t ld_dY, const float *Y, int64_t ldY, int64_t rows, int32_t F,

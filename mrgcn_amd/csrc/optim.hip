@@ -511,7 +511,50 @@ __global__ void k_xent(const float *__restrict__ logits, int64_t ld, int C,
 
 using namespace mrgcn;
 
+namespace mrgcn {
+// Streaming yardsticks (measurement only: bench.py's extra.device_copy_gbps_hip / extra.triad_gbps): what a plain
+// float4 copy and a 3-read / 3-write elementwise pass (the memory shape of a dense Adam step) reach on the box.
+using yf4 = __attribute__((ext_vector_type(4))) float;
+__global__ __launch_bounds__(256) void k_probe_copy4(const yf4 *__restrict__ a, yf4 *__restrict__ b, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void k_probe_triad4(yf4 *__restrict__ p, yf4 *__restrict__ m, yf4 *__restrict__ v,
+                                                      int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    yf4 P = p[i], M = m[i], V = v[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // Adam's arithmetic on a constant gradient
+      const float g = 1e-3f;
+      M[k] = fmaf(0.9f, M[k], 0.1f * g);
+      V[k] = fmaf(0.999f, V[k], 0.001f * g * g);
+      P[k] -= 0.01f * (M[k] / (sqrtf(V[k]) + 1e-8f));
+    }
+    p[i] = P;
+    m[i] = M;
+    v[i] = V;
+  }
+}
+}  // namespace mrgcn
+
 extern "C" {
+
+int mrgcn_probe_copy_f32(const float *src, float *dst, int64_t n, void *stream) {
+  MRGCN_REQUIRE(src && dst && n >= 0 && n % 4 == 0, "NULL / n % 4");
+  MRGCN_REQUIRE(((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "16-byte alignment");
+  if (n == 0) return MRGCN_OK;
+  mrgcn::k_probe_copy4<<<dim3(256 * 8), dim3(256), 0, (hipStream_t)stream>>>((const mrgcn::yf4 *)src, (mrgcn::yf4 *)dst, n / 4);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_probe_triad_f32(float *p, float *m, float *v, int64_t n, void *stream) {
+  MRGCN_REQUIRE(p && m && v && n >= 0 && n % 4 == 0, "NULL / n % 4");
+  MRGCN_REQUIRE(((((uintptr_t)p) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0, "16-byte alignment");
+  if (n == 0) return MRGCN_OK;
+  mrgcn::k_probe_triad4<<<dim3(256 * 8), dim3(256), 0, (hipStream_t)stream>>>((mrgcn::yf4 *)p, (mrgcn::yf4 *)m, (mrgcn::yf4 *)v, n / 4);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
 
 int mrgcn_relu_bwd_f32(const float *dY, const float *Y, int64_t n, float *out, void *stream) {
   MRGCN_REQUIRE(dY && Y && out, "NULL");
