@@ -148,6 +148,10 @@ int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8
                            const float *grad_scale, hipStream_t s, const int32_t *lnode = nullptr,
                            const int32_t *lnptr = nullptr, int64_t NL = 0, int ever_outside = 1);
 bool xform_use_mfma();
+// narrow transform with every relation's weights in LDS, columns in output order (xform_mfma.hip)
+bool xform_cols_lds_supported(const mrgcn_plan *p, int K, int F, int64_t ldOut, bool operand_order);
+int xform_cols_lds(const mrgcn_plan *p, bool operand_order, const float *In, int64_t ldIn, int K, const float *W, int F,
+                   void *Out, int64_t ldOut, hipStream_t s, bool out_bf16);
 // hipMemsetAsync for the compute calls (plan.hip).  On a capturing stream the fill is one kernel of this package:
 // a captured hipMemsetAsync whose size is not a whole number of 16-byte pieces becomes a memset node that ROCm 7.2
 // replays once and then faults on ("write access to a read-only page", second replay; found with the 174 504-byte
@@ -195,6 +199,9 @@ struct mrgcn_plan {
   int32_t *relchunk_ids = nullptr;  // [n_relchunks] chunk ids grouped by relation
   int32_t n_relchunks = 0, max_relchunks = 0;
   int32_t top_rel = -1;  // relation with the most compact columns (the identity block in the reference's layout)
+  // (source node, relation) of every row of the compact operand, in OPERAND order (rows without a primary column —
+  // replicas — hold node -1): what the narrow transform walks, so that its output leaves as one sequential stream
+  int32_t *op_node = nullptr, *op_rel = nullptr;  // [n_op]
   // the same order with narrow bands (kNodeBandNarrow) for transforms of narrow inputs; empty when the graph has a
   // single band either way
   int32_t *n_rperm = nullptr, *n_relptr = nullptr, *n_rnode = nullptr, *n_rmpos = nullptr, *n_relchunk_rel = nullptr,

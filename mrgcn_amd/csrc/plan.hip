@@ -726,6 +726,17 @@ int build_rel_order(mrgcn_plan *p, Scratch &sc, hipStream_t s, int64_t band, boo
   return MRGCN_OK;
 }
 
+// op_node[mpos[c]] = unode[c], op_rel[mpos[c]] = urel[c] (rows without a primary column keep node -1)
+__global__ void k_operand_ids(const int32_t *__restrict__ mpos, const int32_t *__restrict__ unode,
+                              const int32_t *__restrict__ urel, int64_t ncols, int32_t *__restrict__ op_node,
+                              int32_t *__restrict__ op_rel) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  const int32_t pos = mpos[c];
+  op_node[pos] = unode[c];
+  op_rel[pos] = urel[c];
+}
+
 int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_t *cols,
                 const void *vals, int val_dtype, uint32_t flags, hipStream_t s, const StraddleSizes &hint) {
   const int64_t N = p->num_nodes, R = p->num_relations, RN = R * N;
@@ -1053,6 +1064,15 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     }
     MRGCN_HIP_TRY(hipGetLastError());
   }
+  // the operand rows' (node, relation), for the narrow transform that writes the operand as one stream
+  if (!(flags & MRGCN_PLAN_LEAN) && ncols > 0) {
+    MRGCN_HIP_TRY(plan_alloc(p, &p->op_node, p->n_op));
+    MRGCN_HIP_TRY(plan_alloc(p, &p->op_rel, p->n_op));
+    MRGCN_HIP_TRY(hipMemsetAsync(p->op_node, 0xff, (size_t)p->n_op * sizeof(int32_t), s));
+    MRGCN_HIP_TRY(hipMemsetAsync(p->op_rel, 0, (size_t)p->n_op * sizeof(int32_t), s));
+    k_operand_ids<<<nblocks(ncols), kTB, 0, s>>>(p->mpos, p->unode, p->urel, ncols, p->op_node, p->op_rel);
+    MRGCN_HIP_TRY(hipGetLastError());
+  }
   if ((rc = build_long(p, p->rowptr, p->num_rows, s, &p->r_long_row, &p->r_long_cptr, &p->r_chunk_beg,
                        &p->r_chunk_end, &p->r_chunk_row, &p->r_n_long, &p->r_n_chunks, &p->max_row_nnz)))
     return rc;
@@ -1131,7 +1151,7 @@ void release_plan(mrgcn_plan *q, uint64_t ep) {
                   q->rep_src, q->rep_dst, q->partials, q->r3_multi, q->r3_ticket,
                   q->r3s_long_row, q->r3s_long_cptr, q->r3s_chunk_beg, q->r3s_chunk_end, q->r3s_chunk_row,
                   q->n_rperm, q->n_relptr, q->n_rnode, q->n_rmpos, q->n_relchunk_rel, q->n_relchunk_beg,
-                  q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids};
+                  q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids, q->op_node, q->op_rel};
   // (after the wait any stream may take the blocks; the plan's own build stream is where the next build of a
   // similar slice will ask for them again: the pool hands them back without a driver call)
   for (void *a : ptrs) pool_free(a, q->build_stream, ep);

@@ -269,6 +269,9 @@ __global__ __launch_bounds__(256) void k_mix_fwd_wide(const int32_t *__restrict_
 
 // IDS: the nodes are a list (a gradient support's live nodes): entry t owns columns nptr[t] .. nptr[t+1] and its V
 // block is node_ids[t]'s; the ids travel with the node pointers, two steps ahead of their use.
+#ifndef MIX_V_NT
+#define MIX_V_NT 1  // V is read once per epoch: nontemporal loads (A/B: -DMIX_V_NT=0)
+#endif
 template <int KS, int NQ, int TN, bool ADD, typename OT, bool IDS = false>
 __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
     const int32_t *__restrict__ nptr, const int32_t *__restrict__ urel, const int32_t *__restrict__ mpos,
@@ -304,7 +307,8 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
   _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                          \
     const int64_t nid = IDS ? (int64_t)__builtin_amdgcn_readlane(idreg, i) : min((gg) * TN + i, N - 1);     \
     const f32x4m *src = reinterpret_cast<const f32x4m *>(V) + nid * (int64_t)nf4;                           \
-    _Pragma("unroll") for (int q = 0; q < NQ; ++q) pv[i][q] = src[min(lane + 64 * q, nf4 - 1)];            \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                          \
+      pv[i][q] = MIX_V_NT ? __builtin_nontemporal_load(src + min(lane + 64 * q, nf4 - 1)) : src[min(lane + 64 * q, nf4 - 1)]; \
   }
 #define MIX_LOAD_IDX(np, ur, mp)                                                                            \
   {                                                                                                         \
@@ -1674,6 +1678,9 @@ int rel_transform_fwd_impl(const mrgcn_plan_t *p, const float *X, int64_t ldX, i
   const RelOrder o = p->order_for(K);  // narrow inputs: the order with narrow node bands
   if (o.n_relchunks == 0) return MRGCN_OK;
   const int32_t *oidx = operand_order ? p->mpos : nullptr;
+  // narrow rows with every relation's weights in LDS: columns in OUTPUT order, the operand leaves as one stream
+  if (xform_cols_lds_supported(p, K, F, ldOut, operand_order != 0))
+    return xform_cols_lds(p, operand_order != 0, X, ldX, K, W, F, Out, ldOut, (hipStream_t)stream, sizeof(OT) == 2);
   if (use_mfma() && xform_mfma_fwd_supported(K, F))
     return xform_mfma_fwd(p, o, o.rnode, operand_order ? o.rmpos : nullptr, X, ldX, K, W, false, F, Out,
                           ldOut, (hipStream_t)stream, sizeof(OT) == 2);

@@ -36,11 +36,12 @@ __device__ __forceinline__ void load_basis_row(const float *__restrict__ p, int 
     if constexpr ((FT & 1) == 0) {
 #pragma unroll
       for (int o = 0; o + 4 <= FT; o += 4) {
-        const f32x4_a8 t = *reinterpret_cast<const f32x4_a8 *>(p + o);
+        const f32x4_a8 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_a8 *>(p + o));  // (read once per epoch)
         v[o] = t.x; v[o + 1] = t.y; v[o + 2] = t.z; v[o + 3] = t.w;
       }
       if constexpr ((FT & 3) != 0) {
-        const float2 t = *reinterpret_cast<const float2 *>(p + (FT & ~3));
+        typedef float f32x2_nt __attribute__((ext_vector_type(2)));
+        const f32x2_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x2_nt *>(p + (FT & ~3)));
         v[FT & ~3] = t.x;
         v[(FT & ~3) + 1] = t.y;
       }

@@ -555,7 +555,135 @@ __global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Narrow transform, columns in OUTPUT order (a hidden layer: K, F <= 16).  Every relation's weight tile fits LDS at
+// once (AM layer 1: 267 x 10 x 12 floats = 128 KB), so nothing forces the relation-major walk of the kernels above —
+// whose output rows (44-48 bytes each) then land wherever the operand order puts them: 347 us for a 392 MB operand
+// at the AM shape, 2.7x its bytes in fabric traffic.  Here position p of the output is computed by the lanes
+// 4p .. 4p + 3 (four outputs each): the operand leaves as ONE sequential stream, the input rows (40-48 bytes of a
+// 67-80 MB table: cache resident) are gathered by (node, relation) ids stored in output order (plan: op_node /
+// op_rel; compact order: unode / urel themselves).
+//   Out[p, 0:ldOut] = [ In[node_p, 0:K] . W[rel_p][0:K][0:F] | 0 ]
+// LDS: W as [R][K][FP], FP = 4 * ceil(F / 4): lane q of a position reads 16 bytes per k.
+// ---------------------------------------------------------------------------------------------
+template <int KT, typename OT>
+__global__ __launch_bounds__(1024) void k_xform_cols_lds(const int32_t *__restrict__ pnode,
+                                                         const int32_t *__restrict__ prel, int64_t npos,
+                                                         const float *__restrict__ In, int64_t ldIn, int K,
+                                                         const float *__restrict__ W, int R, int F, int FP,
+                                                         OT *__restrict__ Out, int64_t ldOut) {
+  extern __shared__ __align__(16) float s_w[];  // [R][K][FP]
+  const int KF = K * F, KFP = K * FP;
+  for (int t = threadIdx.x; t < R * KFP; t += blockDim.x) {
+    const int r = t / KFP, rem = t - r * KFP;
+    const int k = rem / FP, f = rem - k * FP;
+    s_w[t] = f < F ? W[(int64_t)r * KF + k * F + f] : 0.f;
+  }
+  __syncthreads();
+  const int q = threadIdx.x & 3;
+  const int nq = FP >> 2;  // lanes of a position that hold outputs
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 2);
+  // U positions per lane group and step: their ids, then their input rows, are in flight together (one position at a
+  // time the walk was two dependent round trips per 16 positions and wave: 277 us at the AM shape)
+  constexpr int U = 4;
+  for (int64_t p0 = (int64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2); p0 < npos; p0 += U * stride) {
+    int32_t j[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t pp = min(p0 + u * stride, npos - 1);
+      j[u] = pnode[pp];
+      r[u] = prel[pp];
+    }
+    float h[U][KT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float *xrow = In + (int64_t)max(j[u], 0) * ldIn;
+#pragma unroll
+      for (int k4 = 0; k4 < KT; k4 += 4) {   // the four lanes of a position load the same row: one fetch
+        if (k4 + 4 <= K) {
+          const f32x4 t = *reinterpret_cast<const f32x4 *>(xrow + k4);
+          h[u][k4] = t.x; h[u][k4 + 1] = t.y; h[u][k4 + 2] = t.z; h[u][k4 + 3] = t.w;
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) h[u][k4 + v] = (k4 + v < K) ? xrow[k4 + v] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t pp = p0 + u * stride;
+      if (pp >= npos || j[u] < 0) continue;  // (an operand row without a primary column: a replica, written later)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (q < nq) {
+        const float *wr = s_w + r[u] * KFP + 4 * q;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          if (k < K) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wr + k * FP);
+            acc.x = fmaf(h[u][k], w.x, acc.x);
+            acc.y = fmaf(h[u][k], w.y, acc.y);
+            acc.z = fmaf(h[u][k], w.z, acc.z);
+            acc.w = fmaf(h[u][k], w.w, acc.w);
+          }
+        }
+      }
+      // the row's ldOut elements: zeros past F (the whole padded row is written)
+      OT *orow = Out + pp * ldOut;
+      if constexpr (sizeof(OT) == 4) {
+        if (4 * q + 4 <= ldOut) {  // one 16-byte store per lane (dword-aligned addresses: rows may be 44 bytes)
+          *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(orow) + 4 * q) = acc;
+          continue;
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int n = 4 * q + v;
+        if (n < ldOut) store_operand<OT>(orow + n, acc[v]);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+bool xform_cols_lds_supported(const mrgcn_plan *p, int K, int F, int64_t ldOut, bool operand_order) {
+  static const bool on = !(getenv("MRGCN_XFORM_COLS_LDS") && atoi(getenv("MRGCN_XFORM_COLS_LDS")) == 0);
+  if (!on || !p || K > 16 || F > 16 || ldOut > 16) return false;
+  if (operand_order && !p->op_node) return false;
+  const int FP = (F + 3) / 4 * 4;
+  return (size_t)p->num_relations * K * FP * sizeof(float) <= 150 * 1024;
+}
+
+int xform_cols_lds(const mrgcn_plan *p, bool operand_order, const float *In, int64_t ldIn, int K, const float *W, int F,
+                   void *Out, int64_t ldOut, hipStream_t s, bool out_bf16) {
+  const int64_t npos = operand_order ? p->n_op : p->ncols;
+  if (npos == 0) return MRGCN_OK;
+  const int32_t *pnode = operand_order ? p->op_node : p->unode;
+  const int32_t *prel = operand_order ? p->op_rel : p->urel;
+  const int R = (int)p->num_relations, FP = (F + 3) / 4 * 4;
+  const size_t lds = (size_t)R * K * FP * sizeof(float);
+  int64_t grid = (npos + 255) / 256;
+  if (grid > 256) grid = 256;  // one block of 16 waves per CU (LDS)
+#define XC_GO(KT_, O_)                                                                                             \
+  do {                                                                                                             \
+    auto kfn = k_xform_cols_lds<KT_, O_>;                                                                          \
+    static size_t lds_allowed = 48 * 1024;                                                                         \
+    if (lds > lds_allowed) {                                                                                       \
+      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      lds_allowed = lds;                                                                                           \
+    }                                                                                                              \
+    kfn<<<dim3((unsigned)grid), dim3(1024), lds, s>>>(pnode, prel, npos, In, ldIn, K, W, R, F, FP, (O_ *)Out, ldOut); \
+  } while (0)
+  const int KT = K <= 4 ? 4 : K <= 8 ? 8 : K <= 12 ? 12 : 16;
+  if (out_bf16) {
+    if (KT == 4) XC_GO(4, uint16_t); else if (KT == 8) XC_GO(8, uint16_t); else if (KT == 12) XC_GO(12, uint16_t); else XC_GO(16, uint16_t);
+  } else {
+    if (KT == 4) XC_GO(4, float); else if (KT == 8) XC_GO(8, float); else if (KT == 12) XC_GO(12, float); else XC_GO(16, float);
+  }
+#undef XC_GO
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
 
 // ---- launchers used by the C ABI entry points in rgcn_fused.hip -------------------------------
 bool xform_mfma_fwd_supported(int K, int F) { return K <= kMaxKSteps * 16 && F <= kMaxNT * 16; }

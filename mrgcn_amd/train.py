@@ -349,7 +349,7 @@ class ClipAdam(torch.optim.Optimizer):
                     # a fresh gradient entry): every node that holds a non-zero moment counts as `ever`
                     ent["ever"].zero_()
                     ent["ever_in"] = None      # which row set the flags lie inside: None = none set yet
-                    if st["step"] > 0 or self._dev_step:
+                    if st["step"] > 0:   # (a parameter that never took a step has zero moments)
                         nz = (st["exp_avg"] != 0).flatten(1).any(1) | (st["exp_avg_sq"] != 0).flatten(1).any(1)
                         ent["ever"] |= nz.to(torch.uint8)
                         ent["ever_in"] = "any"  # (moments from steps this entry has not seen)
