@@ -96,7 +96,15 @@ class Normalizer:
             self.mean_values *= 255
             self.std_values *= 255
 
+    def _stats(self, device):
+        # one upload per device, kept: a host -> device copy per call would also be illegal inside a hipGraph capture
+        cache = self.__dict__.setdefault("_dev", {})
+        ent = cache.get(device)
+        if ent is None:
+            ent = cache[device] = (torch.as_tensor(self.mean_values, device=device)[:, None, None],
+                                   torch.as_tensor(self.std_values, device=device)[:, None, None])
+        return ent
+
     def normalize_(self, im):
-        mean = torch.as_tensor(self.mean_values, device=im.device)[:, None, None]
-        std = torch.as_tensor(self.std_values, device=im.device)[:, None, None]
+        mean, std = self._stats(im.device)
         return ((im - mean) / std).float()  # broadcasts over a leading batch dimension
