@@ -33,8 +33,15 @@ PARTITIONED_WORKLOADS = ("synth10m", "fb15k")
 
 
 def _env_switches():
-    """The MRGCN_* environment switches set for this run (they select kernels and layouts: DESIGN.md, switches table)."""
-    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("MRGCN_")}
+    """The MRGCN_* environment switches set for this run, and the library's configuration entries that differ from their
+    defaults (they select kernels and layouts: DESIGN.md, switches table)."""
+    out = {k: v for k, v in sorted(os.environ.items()) if k.startswith("MRGCN_")}
+    try:
+        from mrgcn_amd import _lib
+        out["library_config"] = _lib.config()
+    except Exception:  # noqa: BLE001  (informational)
+        pass
+    return out
 
 def parse():
     ap = argparse.ArgumentParser()

@@ -113,6 +113,17 @@ typedef struct mrgcn_plan_info {
 
 /* ---- library ---------------------------------------------------------------- */
 int mrgcn_abi_version(void);
+/* ---- configuration ----------------------------------------------------------------------------------------------
+ * Every switch the library's launchers look at lives in ONE table (csrc/config.hip): initialised once, on the first
+ * read, from the MRGCN_* environment variables of the same names (upper case, prefixed), changed afterwards only by
+ * mrgcn_config_set.  No compute entry point reads the environment or caches a switch: a value set here takes effect
+ * at the next call (plans keep what they were built with).  Names: mrgcn_config_name(0 .. count - 1), e.g.
+ * "adam_list", "node_band"; the environment spelling ("MRGCN_ADAM_LIST") is accepted too. */
+int32_t mrgcn_config_count(void);
+const char *mrgcn_config_name(int32_t i);
+const char *mrgcn_config_doc(int32_t i);
+int mrgcn_config_get(const char *name, int64_t *value);
+int mrgcn_config_set(const char *name, int64_t value);
 const char *mrgcn_arch(void);       /* "gfx950" */
 const char *mrgcn_last_error(void); /* message of the last failing call on this thread */
 

@@ -8,6 +8,8 @@ PyTorch fallback for the kernels: without the built library the ops raise.
 """
 __version__ = "0.2.0"
 
+from .stats import reset_stats, stats  # noqa: E402,F401  (which path did a step take?)
+
 # the reference modules this package answers for (run.py:12-19, tasks/node_classification.py:9-16,
 # tasks/link_prediction.py:12-19 import these names)
 _ALIASES = {

@@ -54,6 +54,11 @@ _i32, _i64, _u32 = C.c_int32, C.c_int64, C.c_uint32
 # name -> (restype, argtypes); kept in one table so that tests can compare it with the header
 SIGNATURES = {
     "mrgcn_abi_version": (C.c_int, []),
+    "mrgcn_config_count": (_i32, []),
+    "mrgcn_config_name": (C.c_char_p, [_i32]),
+    "mrgcn_config_doc": (C.c_char_p, [_i32]),
+    "mrgcn_config_get": (C.c_int, [C.c_char_p, C.POINTER(_i64)]),
+    "mrgcn_config_set": (C.c_int, [C.c_char_p, _i64]),
     "mrgcn_arch": (C.c_char_p, []),
     "mrgcn_last_error": (C.c_char_p, []),
     "mrgcn_plan_create": (C.c_int, [C.POINTER(_p), _i64, _i64, _i32, _i64, _p, _p, _p, _i32, _u32, _p]),
@@ -206,3 +211,28 @@ def check(rc: int, what: str = ""):
     if rc != OK:
         msg = load().mrgcn_last_error().decode(errors="replace")
         raise MrgcnError(f"{what or 'mrgcn call'} failed (code {rc}): {msg}")
+
+
+def config() -> dict:
+    """The library's configuration table as {name: value} (include/mrgcn_hip.h: mrgcn_config_*)."""
+    lib = load()
+    out = {}
+    for i in range(lib.mrgcn_config_count()):
+        name = lib.mrgcn_config_name(i)
+        v = _i64()
+        check(lib.mrgcn_config_get(name, C.byref(v)), "mrgcn_config_get")
+        out[name.decode()] = int(v.value)
+    return out
+
+
+def set_config(**kw) -> dict:
+    """Sets library switches (`set_config(adam_list=0)`); returns the previous values.  Takes effect at the next call of
+    the entry points concerned; plans keep what they were built with."""
+    lib = load()
+    prev = {}
+    for k, v in kw.items():
+        old = _i64()
+        check(lib.mrgcn_config_get(k.encode(), C.byref(old)), "mrgcn_config_get")
+        check(lib.mrgcn_config_set(k.encode(), int(v)), "mrgcn_config_set")
+        prev[k] = int(old.value)
+    return prev

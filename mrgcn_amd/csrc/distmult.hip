@@ -16,6 +16,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace mrgcn {
 namespace {
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(kCountTB) void k_fill3(const int64_t *__restrict__ 
 }
 
 inline bool rows_vec4_ok(const float *E, int64_t ldE, const float *Rel, int64_t ldR, int H) {
-  static const bool on = !(getenv("MRGCN_LP_VEC4") && atoi(getenv("MRGCN_LP_VEC4")) == 0);
+  const bool on = cfg(CFG_LP_VEC4) != 0;
   return on && H % 4 == 0 && H <= 256 && ldE % 4 == 0 && ldR % 4 == 0 && (((uintptr_t)E | (uintptr_t)Rel) & 15) == 0;
 }
 inline int key_bits(int64_t bound) {

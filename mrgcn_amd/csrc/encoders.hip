@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace mrgcn {
 namespace {
@@ -704,8 +705,8 @@ int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
   // pays for its grid: a grid of fewer than two blocks per CU either splits K (the partial tiles meet in a zeroed C
   // through float atomics: about 145 splits / K of the product's own time) or leaves CUs idle or with one wave per
   // SIMD, whose load latencies nothing covers.
-  static const int target = getenv("MRGCN_MM_BLOCKS") ? atoi(getenv("MRGCN_MM_BLOCKS")) : 768;
-  static const int force_tile = getenv("MRGCN_MM_TILE") ? atoi(getenv("MRGCN_MM_TILE")) : -1;
+  const int target = (int)cfg(CFG_MM_BLOCKS);
+  const int force_tile = (int)cfg(CFG_MM_TILE);
   const bool dense_c = cmode == 2 || ldc == N;
   const bool can_split = dense_c && K >= 512 && !(cmode == 2 && (o.relu || o.mask));
   struct Cand { int bm, bn; double eff; int occ; };  // occ: blocks per CU (registers / LDS)
@@ -735,8 +736,6 @@ int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
   if (best < 0) return MRGCN_ERR_UNSUPPORTED;
   const int BM = cands[best].bm, BN = cands[best].bn, splits = best_splits;
   dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), 1);
-  static const bool log_on = getenv("MRGCN_MM_LOG") && atoi(getenv("MRGCN_MM_LOG"));
-  if (log_on) fprintf(stderr, "mm_tile %d/%d/%d  %d x %d x %d: tile %d x %d, %d splits\n", amode, bmode, cmode, M, N, K, BM, BN, splits);
   if (splits > 1) {
     g.kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
     grid.z = (unsigned)((K + g.kchunk - 1) / g.kchunk);
@@ -859,7 +858,7 @@ int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32
   // the tiled form takes every product with at least 48 rows and columns or a long reduction (operands of at most
   // 2^29 bytes); the heads' few output columns over a short reduction, larger operands and MRGCN_GEMM_TILED=0 take
   // the 64 x 64 kernel with element loaders
-  static const bool tiled_on = !(getenv("MRGCN_GEMM_TILED") && atoi(getenv("MRGCN_GEMM_TILED")) == 0);
+  const bool tiled_on = cfg(CFG_GEMM_TILED) != 0;
   if (tiled_on) {
     const int rc = mm_tile_launch(g, (hipStream_t)stream);
     if (rc != MRGCN_ERR_UNSUPPORTED) return rc;

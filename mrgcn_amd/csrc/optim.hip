@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace mrgcn {
 namespace {
@@ -625,8 +626,8 @@ static int adam_impl(float *param, const float *grad, float *exp_avg, float *exp
   if (n == 0) return MRGCN_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  static const int nt_mode = getenv("MRGCN_ADAM_NT") ? atoi(getenv("MRGCN_ADAM_NT")) : 0;
-  static const int grid_cap = getenv("MRGCN_ADAM_GRID") ? atoi(getenv("MRGCN_ADAM_GRID")) : 8192;
+  const int nt_mode = (int)cfg(CFG_ADAM_NT);
+  const int grid_cap = (int)cfg(CFG_ADAM_GRID);
   int64_t blocks = ((n >> 2) + kTB - 1) / kTB;
   if (blocks < 1) blocks = 1;
   if (blocks > grid_cap) blocks = grid_cap;

@@ -15,6 +15,7 @@
 #include <cstdio>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace mrgcn {
 
@@ -402,7 +403,7 @@ hipError_t pool_alloc(void **p, size_t bytes, hipStream_t s) {
     if (!c.configured) {
       hipMemPool_t pool;
       if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-        c.keep = getenv("MRGCN_POOL_KEEP_MB") ? (uint64_t)atoll(getenv("MRGCN_POOL_KEEP_MB")) << 20 : kPoolKeep;
+        c.keep = (uint64_t)std::max<int64_t>(cfg(CFG_POOL_KEEP_MB), 0) << 20;
         (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &c.keep);
       }
       c.configured = true;
@@ -645,10 +646,8 @@ int build_rel_order(mrgcn_plan *p, Scratch &sc, hipStream_t s, int64_t band, boo
   std::vector<int32_t> h_gptr(ngroups + 1);
   MRGCN_HIP_TRY(hipMemcpyAsync(h_gptr.data(), *relptr, (ngroups + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MRGCN_HIP_TRY(hipStreamSynchronize(s));
-  int rel_chunk = kRelChunk;
-  if (const char *e = getenv("MRGCN_REL_CHUNK"))  // experiments; the live-column lists hold kRelChunk
-    rel_chunk = (atoi(e) > 15 && atoi(e) <= kRelChunk) ? atoi(e) : rel_chunk;
-  std::vector<int32_t> rel, beg, end, cband;
+  const int rel_chunk = kRelChunk;
+  std::vector<int32_t> rel, beg, end;
   std::vector<std::vector<int32_t>> by_rel(R);
   for (int64_t g = 0; g < ngroups; ++g) {
     const int32_t r = (int32_t)(g % R);
@@ -656,42 +655,7 @@ int build_rel_order(mrgcn_plan *p, Scratch &sc, hipStream_t s, int64_t band, boo
       rel.push_back(r);
       beg.push_back(b0);
       end.push_back(std::min(b0 + rel_chunk, h_gptr[g + 1]));
-      cband.push_back((int32_t)(g / R));
     }
-  }
-  // XCD-aware chunk order: workgroup b of a launch runs on XCD b mod 8 (MI355X_MICROARCH.md), each with its own L2.
-  // With the chunks in plain (band, relation) order the ~2 k resident blocks of a transform spread every active band
-  // over all eight L2s; dealt out so that the chunks of band k all get block ids = k mod 8, a band's source rows are
-  // fetched into ONE L2 and the re-reads of a row by the node's other relations hit there — which is what lets a band
-  // be small enough to fit (MRGCN_NODE_BAND).  Positions a short list leaves open take the next chunk of another list
-  // (the pattern degrades, nothing breaks).
-  static const int xcd_order = getenv("MRGCN_XCD_ORDER") ? atoi(getenv("MRGCN_XCD_ORDER")) : 0;
-  if (xcd_order > 0 && !rel.empty()) {
-    const int X = 8;
-    std::vector<std::vector<int32_t>> lists(X);
-    for (size_t c = 0; c < rel.size(); ++c) lists[cband[c] % X].push_back((int32_t)c);
-    std::vector<size_t> at(X, 0);
-    std::vector<int32_t> order;
-    order.reserve(rel.size());
-    while (order.size() < rel.size()) {
-      const int x = (int)(order.size() % X);
-      int pick = x;
-      if (at[pick] >= lists[pick].size()) {  // this XCD's list is used up: the longest remaining one gives
-        size_t best = 0;
-        for (int y = 0; y < X; ++y)
-          if (lists[y].size() - at[y] > best) { best = lists[y].size() - at[y]; pick = y; }
-      }
-      order.push_back(lists[pick][at[pick]++]);
-    }
-    std::vector<int32_t> rel2(rel.size()), beg2(rel.size()), end2(rel.size());
-    for (size_t b = 0; b < order.size(); ++b) {
-      rel2[b] = rel[order[b]];
-      beg2[b] = beg[order[b]];
-      end2[b] = end[order[b]];
-    }
-    rel.swap(rel2);
-    beg.swap(beg2);
-    end.swap(end2);
   }
   for (size_t c = 0; c < rel.size(); ++c) by_rel[rel[c]].push_back((int32_t)c);
   if (set_top_rel) {  // the relation with the most compact columns: k_mix_bwd_nm keeps its dcomp row in registers
@@ -740,7 +704,7 @@ __global__ void k_operand_ids(const int32_t *__restrict__ mpos, const int32_t *_
 int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_t *cols,
                 const void *vals, int val_dtype, uint32_t flags, hipStream_t s, const StraddleSizes &hint) {
   const int64_t N = p->num_nodes, R = p->num_relations, RN = R * N;
-  static const bool rep_default = getenv("MRGCN_REPLICATE") && atoi(getenv("MRGCN_REPLICATE")) != 0;
+  const bool rep_default = cfg(CFG_REPLICATE) != 0;
   const bool replicate = !(flags & MRGCN_PLAN_NO_REPLICATE) && ((flags & MRGCN_PLAN_REPLICATE) || rep_default);
   Scratch sc;
   sc.s = s;
@@ -852,7 +816,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   // re-streaming the whole input once per relation.  Two orders: wide bands for wide inputs, narrow bands
   // (kNodeBandNarrow) for narrow ones — a band of 40-byte rows then fits one XCD's L2 (common.hpp: RelOrder).
   int64_t band = kNodeBand;
-  if (const char *e = getenv("MRGCN_NODE_BAND")) band = atoll(e) > 0 ? atoll(e) : band;  // experiments
+  if (cfg(CFG_NODE_BAND) > 0) band = cfg(CFG_NODE_BAND);
   if (band > N) band = N;
   {
     int rc0 = build_rel_order(p, sc, s, band, true, &p->rperm, &p->relptr, &p->relchunk_rel, &p->relchunk_beg,
@@ -860,7 +824,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
                               &p->max_relchunks, &p->node_band, &p->n_bands);
     if (rc0 != MRGCN_OK) return rc0;
     int64_t nband = kNodeBandNarrow;
-    if (const char *e = getenv("MRGCN_NODE_BAND_NARROW")) nband = atoll(e);  // experiments; <= 0: no second order
+    nband = cfg(CFG_NODE_BAND_NARROW);  // (<= 0: no second order)
     if (nband > 0 && nband < band && !(flags & MRGCN_PLAN_LEAN)) {
       rc0 = build_rel_order(p, sc, s, nband, false, &p->n_rperm, &p->n_relptr, &p->n_relchunk_rel, &p->n_relchunk_beg,
                             &p->n_relchunk_end, &p->n_relchunk_ptr, &p->n_relchunk_ids, &p->n_n_relchunks,
@@ -917,8 +881,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     MRGCN_HIP_TRY(sc.alloc(&len3, rows + 1));
     MRGCN_HIP_TRY(sc.alloc(&cls_ptr, 4));
     // length-sorted windows inside the S and M classes (kLenWindowS / kLenWindowM row ids; 0 = plain id order)
-    static const int64_t win_s = getenv("MRGCN_LEN_WINDOW_S") ? atoll(getenv("MRGCN_LEN_WINDOW_S")) : kLenWindowS;
-    static const int64_t win_m = getenv("MRGCN_LEN_WINDOW_M") ? atoll(getenv("MRGCN_LEN_WINDOW_M")) : kLenWindowM;
+    const int64_t win_s = kLenWindowS, win_m = kLenWindowM;
     const int64_t wmin = std::min(win_s > 0 ? win_s : rows + 1, win_m > 0 ? win_m : rows + 1);
     const int64_t cstride = ((rows + wmin - 1) / wmin + 1) * 64 * std::max<int64_t>(rows, 1);
     if (rows > 0) {
@@ -959,7 +922,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     const int shift = bits_for(ncols);
     const int64_t max_count = p->max_col_nnz + 1;
     int hot_min = kHotMinRefs;
-    if (const char *e = getenv("MRGCN_HOT_MIN")) hot_min = (atoi(e) > 1 || atoi(e) < 0) ? atoi(e) : hot_min;  // experiments
+    if (cfg(CFG_HOT_MIN) > 1 || cfg(CFG_HOT_MIN) < 0) hot_min = (int)cfg(CFG_HOT_MIN);
     k_mpos_keys<<<nblocks(ncols), kTB, 0, s>>>(p->cptr, p->crow, rank3, ncols, max_count, shift, hot_min, mk, ids);
     MRGCN_HIP_TRY(hipGetLastError());
     const int end_bit = shift + bits_for(max_count + 1 + p->num_rows);
@@ -972,16 +935,8 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     MRGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, mk, mk_s, ids, order, (int)ncols, 0,
                                                      end_bit, s));
     {
-      static const bool swap_on = !(getenv("MRGCN_AVOID_STRADDLE") && atoi(getenv("MRGCN_AVOID_STRADDLE")) == 0);
-      StraddleSizes sz = hint;
-      if (const char *e = getenv("MRGCN_STRADDLE_ROW_BYTES")) {  // experiments: "40,44"
-        sz.n = 0;
-        for (const char *q = e; *q && sz.n < 4;) {
-          sz.bytes[sz.n++] = atoi(q);
-          while (*q && *q != ',') ++q;
-          if (*q == ',') ++q;
-        }
-      }
+      const bool swap_on = cfg(CFG_AVOID_STRADDLE) != 0;
+      const StraddleSizes sz = hint;
       // hot columns are the sorted keys below max_count << shift
       MRGCN_HIP_TRY(sc.alloc(&n_hot_d, 2));
       k_lower_bound_ptr<<<1, kTB, 0, s>>>(mk_s, ncols, 1, max_count << shift, n_hot_d);
@@ -1274,7 +1229,7 @@ hipError_t fill_async(void *dst, int byte_value, size_t bytes, hipStream_t s) {
   if (bytes == 0) return hipSuccess;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   // (MRGCN_DEBUG_CAPTURED_MEMSET=1: the runtime's memset also inside a capture — tools/memset_node_repro.py shows the fault)
-  static const bool raw = getenv("MRGCN_DEBUG_CAPTURED_MEMSET") && atoi(getenv("MRGCN_DEBUG_CAPTURED_MEMSET")) != 0;
+  const bool raw = cfg(CFG_DEBUG_CAPTURED_MEMSET) != 0;
   if (raw || hipStreamIsCapturing(s, &st) != hipSuccess || st == hipStreamCaptureStatusNone)
     return hipMemsetAsync(dst, byte_value, bytes, s);
   const uint32_t b = (uint32_t)(byte_value & 0xff);
@@ -1860,7 +1815,7 @@ int build_support_chain(mrgcn_support **qs, int n, const uint8_t *row_flags, hip
     MRGCN_HIP_TRY(hipHostMalloc((void **)&g_land, (size_t)(per * n) * sizeof(int32_t), hipHostMallocDefault));
     g_land_ints = (size_t)(per * n);
   }
-  static const bool timing = getenv("MRGCN_SUP_TIMING") && atoi(getenv("MRGCN_SUP_TIMING")) != 0;
+  const bool timing = cfg(CFG_SUP_TIMING) != 0;
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
   int rc;

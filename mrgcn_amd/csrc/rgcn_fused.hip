@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace mrgcn {
 namespace {
@@ -1325,7 +1326,7 @@ int grid_for(int64_t work_items, int tb = kTB, int max_blocks = 256 * 8) {
 constexpr size_t kLdsBudget = 64 * 1024;  // dynamic LDS these kernels may take
 
 bool use_mfma() {
-  static const bool v = !(getenv("MRGCN_XFORM_MFMA") && atoi(getenv("MRGCN_XFORM_MFMA")) == 0);
+  const bool v = cfg(CFG_XFORM_MFMA) != 0;
   return v;
 }
 
@@ -1369,13 +1370,11 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
   // products land in accumulator lanes that are never stored (test: padding set to 1e30 does
   // not leak): by default only the F real features are computed and written (a sixth fewer
   // lanes and stores at F = 10, ld = 12); MRGCN_MIX_PAD=1 writes zeros there.
-  static const bool write_pad = getenv("MRGCN_MIX_PAD") && atoi(getenv("MRGCN_MIX_PAD")) != 0;
+  const bool write_pad = cfg(CFG_MIX_PAD) != 0;
   const int FW = write_pad ? (int)ldM : F;
   // node-major is the default: measured 2.7 ms vs 4.95 ms for the column-parallel form (AM shape)
-  static const bool by_cols = getenv("MRGCN_MIX_COLS") && atoi(getenv("MRGCN_MIX_COLS")) != 0;
-  // timing experiments only (wrong results): write rows in compact order instead of operand order
-  static const bool dbg_seq = getenv("MRGCN_DEBUG_MIX_SEQ") && atoi(getenv("MRGCN_DEBUG_MIX_SEQ")) != 0;
-  const int32_t *mpos_arg = dbg_seq ? nullptr : p->mpos;
+  const bool by_cols = cfg(CFG_MIX_COLS) != 0;
+  const int32_t *mpos_arg = p->mpos;
   if constexpr (sizeof(OT) == 4) if (by_cols && !node_ids && B <= 64 && F <= 64 && FW <= 64) {
     size_t lds = (size_t)R * (B | 1) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
@@ -1403,7 +1402,7 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
     return MRGCN_OK;
   }
   if constexpr (sizeof(OT) == 4) {
-    static const bool wide_on = !(getenv("MRGCN_MIX_WIDE") && atoi(getenv("MRGCN_MIX_WIDE")) == 0);
+    const bool wide_on = cfg(CFG_MIX_WIDE) != 0;
     if (wide_on && !addend && F > 16 && F <= 256 && F % 4 == 0 && B <= 4 && ldM % 4 == 0 &&
         ((((uintptr_t)V) | ((uintptr_t)M)) & 15) == 0 && (size_t)R * B * sizeof(float) <= 64 * 1024) {
       const size_t lds = (size_t)R * B * sizeof(float);
@@ -1421,7 +1420,7 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
     }
   }
   {
-    static const bool mfma_on = !(getenv("MRGCN_MIX_MFMA") && atoi(getenv("MRGCN_MIX_MFMA")) == 0);
+    const bool mfma_on = cfg(CFG_MIX_MFMA) != 0;
     constexpr int tn = 2;  // nodes per wave step
     const int KS = (B + 15) / 16;
     const int NQ = (B * F + 255) / 256;  // 16-byte pieces of a V block per lane (<= KS)
@@ -1471,7 +1470,7 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
     size_t lds = (size_t)R * comp_stride(BT) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
-    static const int fwd_tb = getenv("MRGCN_MIX_FWD_TB") ? atoi(getenv("MRGCN_MIX_FWD_TB")) : kMixFwdTB;
+    const int fwd_tb = (int)cfg(CFG_MIX_FWD_TB);
     int grid = mix_grid(lds, N * FW);
     const float *add = acc ? nullptr : addend;
 #define MIX_GO(T)                                                                                    \
@@ -1749,7 +1748,7 @@ int mix_bwd_nm_launch_arrays(const int32_t *nptr, const int32_t *urel, int64_t N
                              int64_t ldM, const float *V, const float *comp, int32_t B, int32_t F, float *dV,
                              float *dcomp, double *dV_sumsq, hipStream_t s, const uint8_t *col_live,
                              uint8_t *node_cur) {
-  static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
+  const bool node_on = cfg(CFG_MIX_NODE) != 0;
   bool ok = node_on && F <= 16 && B <= 64 && N > 0;
   if ((F & 1) == 0) ok = ok && (((uintptr_t)V | (uintptr_t)dV) & 7) == 0;  // 8-byte row accesses
   if (!ok) return -1;
@@ -1758,13 +1757,13 @@ int mix_bwd_nm_launch_arrays(const int32_t *nptr, const int32_t *urel, int64_t N
   if (!dc_in_lds) lds = 0;
   // register arrays of exactly F features for the hidden sizes of the BASELINE configs (10, 11)
   const int FT = (F == 10 || F == 11) ? F : (F + 3) / 4 * 4;
-  static const int tb = (getenv("MRGCN_MIX_BWD_TB") && atoi(getenv("MRGCN_MIX_BWD_TB")) >= 64 &&
-                         atoi(getenv("MRGCN_MIX_BWD_TB")) <= kNodeTB) ? atoi(getenv("MRGCN_MIX_BWD_TB")) / 64 * 64 : 512;
+  const int tb_cfg = (int)cfg(CFG_MIX_BWD_TB);
+  const int tb = (tb_cfg >= 64 && tb_cfg <= kNodeTB) ? tb_cfg / 64 * 64 : 512;
   int per_cu = lds > 0 ? (int)((160 * 1024) / (lds + 1024)) : 4;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
   if (per_cu * tb > 2048) per_cu = 2048 / tb;  // 32 waves per CU at most
-  static const int per_cu_cap = getenv("MRGCN_MIX_BWD_PER_CU") ? atoi(getenv("MRGCN_MIX_BWD_PER_CU")) : 0;  // experiments
+  const int per_cu_cap = (int)cfg(CFG_MIX_BWD_PER_CU);  // experiments
   if (per_cu_cap > 0 && per_cu > per_cu_cap) per_cu = per_cu_cap;
   const int64_t want = ((N + kGroup - 1) / kGroup + (tb / 64) - 1) / (tb / 64);
   int64_t grid = (int64_t)256 * per_cu;
@@ -1835,8 +1834,8 @@ int mix_bwd_dv_launch(const mrgcn_plan_t *p, const float *dM, int64_t ldM, const
 extern "C" {
 
 int32_t mrgcn_adam_rows_fused_supported(const mrgcn_plan_t *p, int32_t B, int32_t F) {
-  static const bool on = !(getenv("MRGCN_FUSED_ADAM") && atoi(getenv("MRGCN_FUSED_ADAM")) == 0);
-  static const bool node_on = !(getenv("MRGCN_MIX_NODE") && atoi(getenv("MRGCN_MIX_NODE")) == 0);
+  const bool on = cfg(CFG_FUSED_ADAM) != 0;
+  const bool node_on = cfg(CFG_MIX_NODE) != 0;
   if (!p || !on || !node_on) return 0;
   const int64_t R = p->num_relations;
   return (B > 0 && B <= 64 && F > 0 && F <= 16 && (B * F) % 4 == 0 && p->num_nodes > 0 &&
@@ -1875,7 +1874,7 @@ int mix_bwd_nm_arrays(const int32_t *nptr, const int32_t *urel, int64_t N, int R
 }
 
 static bool adam_list_enabled() {
-  static const bool on = !(getenv("MRGCN_ADAM_LIST") && atoi(getenv("MRGCN_ADAM_LIST")) == 0);
+  const bool on = cfg(CFG_ADAM_LIST) != 0;
   return on;
 }
 
@@ -1974,7 +1973,7 @@ int mrgcn_basis_mix_bwd_f32(const mrgcn_plan_t *p, float *dM, int64_t ldM, const
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
     int grid = mix_grid(lds, p->ncols);
-    static const bool wide_on = !(getenv("MRGCN_DCOMP_WIDE") && atoi(getenv("MRGCN_DCOMP_WIDE")) == 0);
+    const bool wide_on = cfg(CFG_DCOMP_WIDE) != 0;
     if (F > 64 && wide_on) {  // a wave per column over whole rows
       const size_t lds_w = in_lds ? (size_t)R * B * sizeof(float) : 0;
       int64_t blocks = (p->ncols + 3) / 4;

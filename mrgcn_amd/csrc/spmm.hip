@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace mrgcn {
 namespace {
@@ -1037,12 +1038,12 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
   constexpr int SV = VEC > 4 ? 4 : VEC;  // widest single store
   const bool store_vec_ok = (ldY % SV == 0) && (((uintptr_t)Y) % (SV * 4) == 0);
   if constexpr (G <= 4 && VEC == 4) {
-    static const bool v3_on = !(getenv("MRGCN_SPMM_V3") && atoi(getenv("MRGCN_SPMM_V3")) == 0);
+    const bool v3_on = cfg(CFG_SPMM_V3) != 0;
     if (w3 && v3_on && v.rows > 0) {  // one gather batch per wave (k_spmm3); rows = class-major ranks
       // the caller owns the pad of Y's rows: whole 16-byte pieces are stored (zeros past F) — rows of ld = 12 at
       // F = 10 / 11 then leave as three vector stores and consecutive rows fill their lines (-5 % on the product)
       const int padw = (w3->pad_ok && store_vec_ok) ? 2 : 0;
-      static const int wpe = getenv("MRGCN_SPMM_WPE") ? atoi(getenv("MRGCN_SPMM_WPE")) : 7;  // 0: the plain form
+      const int wpe = (int)cfg(CFG_SPMM_WPE);  // 0: the plain form
       const bool off32 = !TAIL && w3->op_rows > 0 && wpe > 0 &&
                          (uint64_t)w3->op_rows * (uint64_t)ldD * sizeof(DT) < ((uint64_t)1 << 32);
       const int64_t short_waves = ((int64_t)w3->n_short + SLOTS - 1) / SLOTS;
@@ -1088,7 +1089,7 @@ int launch(const SparseView &v, const DT *D, int64_t ldD, int F, float *Y, int64
   const int64_t short_waves = (v.rows + SLOTS - 1) / SLOTS;
   const int64_t short_blocks = (short_waves + 3) / 4;
   const int64_t chunk_blocks = ((int64_t)v.n_chunks + 3) / 4;
-  static const bool xcd_map = !(getenv("MRGCN_SPMM_XCD") && atoi(getenv("MRGCN_SPMM_XCD")) == 0);
+  const bool xcd_map = cfg(CFG_SPMM_XCD) != 0;
   const int64_t xcd_per = xcd_map ? (short_blocks + 7) / 8 : 0;
   const int64_t launch_short = xcd_map ? xcd_per * 8 : short_blocks;
   int min_len = 0;
@@ -1134,7 +1135,7 @@ int dispatch(const SparseView &v, const float *D, int64_t ldD, int64_t avail, in
   if (ok(4)) vec = 4; else if (ok(2)) vec = 2;
   // unpadded rows that are only 4/8-byte aligned (e.g. the dY of a 10- or 11-class layer, ld = F):
   // 16-byte loads from dword-aligned addresses with a scalar tail instead of 4- or 8-byte lanes
-  static const bool no_tail = getenv("MRGCN_SPMM_TAIL") && atoi(getenv("MRGCN_SPMM_TAIL")) == 0;
+  const bool no_tail = cfg(CFG_SPMM_TAIL) == 0;
   // (only for operands that stay cache resident: on a table far larger than the Infinity Cache a
   // 16-byte load that straddles two 128-B lines costs two HBM line fetches — measured 463 vs 349 us
   // on the 17.8 GB literal operand, 453 vs 496 / 472 vs 725 us on the 67-73 MB dY)
@@ -1217,7 +1218,7 @@ int dispatch_bf16(const SparseView &v, const uint16_t *D, int64_t ldD, int64_t a
 
 // MRGCN_SPMM_FOLD=0: the separate finalize launch for every call (A/B)
 bool spmm3_fold_default() {
-  static const bool on = !(getenv("MRGCN_SPMM_FOLD") && atoi(getenv("MRGCN_SPMM_FOLD")) == 0);
+  const bool on = cfg(CFG_SPMM_FOLD) != 0;
   return on;
 }
 
@@ -1460,7 +1461,7 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     int w = (F - f < tile) ? (F - f) : tile;
     // optional tiny-row pre-pass for views whose rows are mostly 1-2 entries (the transposed view);
     // measured no faster than the general kernel on the AM shape, so opt-in (MRGCN_SPMM_TINY=1)
-    static const bool tiny_on = getenv("MRGCN_SPMM_TINY") && atoi(getenv("MRGCN_SPMM_TINY")) != 0;
+    const bool tiny_on = cfg(CFG_SPMM_TINY) != 0;
     const bool use_tiny = tiny_on && w <= 64 && v.rows > 0 && (plan->nnz < 3 * v.rows);
     const int64_t operand_rows = view == MRGCN_VIEW_LITERAL ? plan->num_relations * plan->num_nodes
                                  : view == MRGCN_VIEW_COMPACT ? plan->n_op : plan->num_rows;

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace mrgcn {
 namespace {
@@ -387,9 +388,9 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
   // nodes in flight per wave (NB) x waves per CU.  512-thread blocks with two nodes per step (62 VGPRs at F = 10: three
   // blocks of eight waves per CU, bounded by the 42 KB of comp in LDS); MRGCN_SUP_MIX = "<threads>x<nodes>" picks
   // another shape (experiments)
-  static const char *cfg = getenv("MRGCN_SUP_MIX");
-  int tb = 512, nb = 2;  // AM shape, kernel alone on one box: 512x1 598 us, 512x2 512, 512x4 557, 1024x2 501
-  if (cfg && sscanf(cfg, "%dx%d", &tb, &nb) != 2) { tb = 512; nb = 2; }
+  // AM shape, kernel alone on one box: 512x1 598 us, 512x2 512, 512x4 557, 1024x2 501
+  int tb = (int)cfg(CFG_SUP_MIX_TB), nb = (int)cfg(CFG_SUP_MIX_NB);
+  if (nb < 1 || nb > 4) nb = 2;
   if (tb != 1024) tb = 512;
   if (tb == 1024 && nb > 2) nb = 2;
   const int nw = tb / 64;

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace mrgcn {
 namespace {
@@ -161,7 +162,7 @@ int mrgcn_plan_entry_relations(const mrgcn_plan_t *p, int32_t *erel, void *strea
 }
 
 int32_t mrgcn_wide_input_bwd_supported(const mrgcn_plan_t *p, int32_t B, int32_t F) {
-  static const bool on = !(getenv("MRGCN_WIDE_BWD") && atoi(getenv("MRGCN_WIDE_BWD")) == 0);
+  const bool on = cfg(CFG_WIDE_BWD) != 0;
   return (on && p && B >= 1 && B <= 4 && F > 16 && F <= 256 && F % 4 == 0 &&
           (size_t)2 * p->num_relations * B * sizeof(float) <= 64 * 1024) ? 1 : 0;
 }

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace mrgcn {
 namespace {
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(1024) void k_xform_cols_lds(const int32_t *__restri
 }  // namespace
 
 bool xform_cols_lds_supported(const mrgcn_plan *p, int K, int F, int64_t ldOut, bool operand_order) {
-  static const bool on = !(getenv("MRGCN_XFORM_COLS_LDS") && atoi(getenv("MRGCN_XFORM_COLS_LDS")) == 0);
+  const bool on = cfg(CFG_XFORM_COLS_LDS) != 0;
   if (!on || !p || K > 16 || F > 16 || ldOut > 16) return false;
   if (operand_order && !p->op_node) return false;
   const int FP = (F + 3) / 4 * 4;

@@ -8,6 +8,7 @@ import torch
 
 from . import _lib as L
 from .plan import GraphPlan
+from .stats import bump
 
 
 def _stream(device) -> int:
@@ -356,11 +357,14 @@ class _RgcnLayer(torch.autograd.Function):
             # labelled rows): which rows hold anything is looked up, and while that set equals last epoch's the
             # backward runs on the support built for it
             meta = _discovered_rows(ctx.owner, plan, dY, F, dev)
+            if meta:
+                bump("discovered_rows")
             row_flags = meta["row_live"] if meta else row_flags
         sup = _support_of(plan, meta, F, dev) if (_SUPPORT and _LIVE_COLS) else None
         if sup is not None:
             out = _RgcnLayer._backward_on_support(ctx, sup, dY, dbias)
             if out is not None:
+                bump("backward.support")
                 return out
         # (the units of the wide-layer backward are built on first use, with host round trips: not inside a capture)
         if (has_I and has_comp and not has_X and not sparse_rows and weight_I.dim() == 3 and not plan.lean
@@ -380,6 +384,7 @@ class _RgcnLayer(torch.autograd.Function):
                         plan.handle, erel.data_ptr(), un.data_ptr(), ub.data_ptr(), ue.data_ptr(), um.data_ptr(), nu,
                         dY.data_ptr(), dY.stride(0), wI.data_ptr(), comp_I.contiguous().data_ptr(), Bn, F,
                         d_wI.data_ptr(), d_comp.data_ptr(), s), "mrgcn_wide_input_bwd_f32")
+                bump("backward.wide_input")
                 return None, None, d_wI, d_comp, None, None, dbias, None, None, None
         # dM = A'^T dY over touched columns only, plain compact order (its consumers are node-major)
         ld = (F + 3) // 4 * 4
@@ -412,8 +417,10 @@ class _RgcnLayer(torch.autograd.Function):
                     row_flags.data_ptr() if row_flags is not None else 0,
                     node_live.data_ptr() if node_live is not None else 0, s), "mrgcn_spmm_transposed_live_flagged_f32")
             gauge.publish()
+            bump("backward.marking")
         else:
             plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM)
+            bump("backward.general")
         d_wI = d_comp = dX = dW = None
         # The consumers of dM are independent of each other and bound by different resources
         # (dV: HBM writes, dcomp: vector-memory issue, dW/dX: matrix cores + gathers), so the
@@ -458,12 +465,14 @@ class _RgcnLayer(torch.autograd.Function):
                         0 if fused else rows["g"].data_ptr(), rows["cur"].data_ptr(), d_comp.data_ptr(),
                         sq.data_ptr(), s), "mrgcn_basis_mix_bwd_f32")
                     rows["sumsq"], rows["fresh"] = sq, True
+                    bump("weight_I.fused_rows" if fused else "weight_I.rows")
                     # what the fused update reads: dM and the column flags of this backward, and the coefficients
                     # as they were (the optimizer may update weight_I_comp before weight_I)
                     rows["fused"] = dict(plan=plan, dM=dM, ld=ld, live=live, comp=comp_I.detach().clone(), B=Bn,
                                          F=F) if fused else None
                     d_wI = None  # travels in param._mrgcn_rows
                 else:
+                    bump("weight_I.dense")
                     d_wI = torch.empty_like(wI)
                     L.check(lib.mrgcn_basis_mix_bwd_f32(
                         plan.handle, dM.data_ptr(), ld, live.data_ptr() if live is not None else 0, wI.data_ptr(),
@@ -605,11 +614,13 @@ def _support_weight_I_grads(owner, sup, plan, dM, ld, weight_I, comp_I, F, s):
                 sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, rows["g"].data_ptr(), 0,
                 d_comp.data_ptr(), sq.data_ptr(), 0, 0, s), "mrgcn_support_mix_bwd_f32")
         rows["sumsq"], rows["fresh"] = sq, True
+        bump("weight_I.fused_rows" if fused else "weight_I.rows")
         # what the fused update reads: dM of this backward and the coefficients as they were (ClipAdam steps
         # the node table before weight_I_comp; the version is checked there)
         rows["fused"] = dict(sup=sup, plan=plan, dM=dM, ld=ld, live=None, comp=comp_I.detach(),
                              comp_version=comp_I._version, B=Bn, F=F) if fused else None
     else:
+        bump("weight_I.dense")
         d_wI = torch.empty_like(wI)
         L.check(lib.mrgcn_support_mix_bwd_f32(
             sup.handle, dM.data_ptr(), ld, wI.data_ptr(), comp_I.data_ptr(), Bn, F, d_wI.data_ptr(), 1,

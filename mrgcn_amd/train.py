@@ -16,6 +16,7 @@ import torch
 
 from . import _lib as L
 from .functional import clear_row_grads, dense_from_rows, pop_row_grad, row_sparse_weight_grad
+from .stats import bump
 
 # MRGCN_MULTI=0: one launch per small tensor and phase (sum of squares, Adam) instead of the two multi-tensor launches
 _MULTI = os.environ.get("MRGCN_MULTI", "1") != "0"
@@ -111,6 +112,7 @@ def categorical_crossentropy(Y_hat: torch.Tensor, idx: torch.Tensor, targets: to
             flags = ent[0]
             sparse = bool(sole_consumer and ent[1] and getattr(Y_hat, "_mrgcn_sparse_grad_ok", False)
                           and Y_hat.grad_fn is not None and type(Y_hat.grad_fn).__name__ == "_RgcnLayerBackward")
+    bump("loss.sparse_rows" if sparse else "loss.flagged" if flags is not None else "loss.plain")
     return _SoftmaxXent.apply(Y_hat, idx.contiguous(), targets.contiguous(), flags, sparse)
 
 
@@ -371,6 +373,7 @@ class ClipAdam(torch.optim.Optimizer):
                     inside = ent.get("ever_in", "any")
                     outside = 0 if (inside is None or inside is fz["sup"]) else 1
                     ent["ever_in"] = fz["sup"] if not outside else "any"
+                    bump("adam.list")
                     L.check(lib.mrgcn_support_adam_rows_fused_f32(
                         fz["sup"].handle, fz["dM"].data_ptr(), fz["ld"], fz["comp"].data_ptr(), fz["B"], fz["F"],
                         p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), ent["ever"].data_ptr(),
@@ -378,6 +381,7 @@ class ClipAdam(torch.optim.Optimizer):
                         outside, s), "mrgcn_support_adam_rows_fused_f32")
                     continue
                 ent["ever_in"] = "any"
+                bump("adam.rows_fused" if fz is not None else "adam.rows")
                 if fz is not None:  # no gradient tensor: the blocks are rebuilt from dM inside the Adam pass
                     L.check(lib.mrgcn_adam_step_rows_fused_f32(
                         fz["plan"].handle, fz["dM"].data_ptr(), fz["ld"], fz["live"].data_ptr(), fz["comp"].data_ptr(),

@@ -224,3 +224,32 @@ def test_reference_optimizer_checkpoint_loads_and_steps_under_the_unpatched_line
         np.testing.assert_allclose(st["exp_avg"].numpy(), c[f"optim3.{i}.exp_avg"], rtol=1e-3, atol=1e-7, err_msg=n)
         np.testing.assert_allclose(st["exp_avg_sq"].numpy(), c[f"optim3.{i}.exp_avg_sq"], rtol=2e-3, atol=1e-10, err_msg=n)
         assert float(st["step"]) == 3.0
+
+
+def test_library_configuration_table_through_the_abi():
+    """include/mrgcn_hip.h, configuration: one table, read / written through the ABI — no launcher reads the
+    environment after the first use, a set value is what the next call sees."""
+    from mrgcn_amd import _lib
+    cfg = _lib.config()
+    assert len(cfg) >= 30 and cfg["adam_list"] in (0, 1) and cfg["node_band"] == 131072
+    prev = _lib.set_config(adam_list=0, spmm_wpe=3)
+    try:
+        now = _lib.config()
+        assert now["adam_list"] == 0 and now["spmm_wpe"] == 3 and prev["spmm_wpe"] == cfg["spmm_wpe"]
+        # the environment spelling names the same entry; the environment itself is no longer consulted
+        import ctypes as C
+        lib = _lib.load()
+        v = C.c_int64()
+        os.environ["MRGCN_SPMM_WPE"] = "5"
+        try:
+            assert lib.mrgcn_config_get(b"MRGCN_SPMM_WPE", C.byref(v)) == 0 and v.value == 3
+        finally:
+            del os.environ["MRGCN_SPMM_WPE"]
+        assert lib.mrgcn_config_set(b"no_such_switch", 1) != 0
+    finally:
+        _lib.set_config(**prev)
+    assert _lib.config() == cfg
+    # no getenv left in the compute sources (the table's initialiser is the only reader)
+    for f in os.listdir(os.path.join(ROOT, "mrgcn_amd", "csrc")):
+        if f.endswith((".hip", ".hpp")) and f != "config.hip":
+            assert "getenv" not in open(os.path.join(ROOT, "mrgcn_amd", "csrc", f)).read(), f

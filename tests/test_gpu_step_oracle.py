@@ -252,10 +252,15 @@ def _run_nc(case):
                                ora1["grad_norm"], rtol=2e-5)
 
     # (2) one eager step of the default train_step (fused row Adam), then one more replayed from a hipGraph
+    import mrgcn_amd
     case.reset()
     before = case.snapshot()
     opt = ClipAdam(case.model.parameters(), lr=LR, max_norm=1.0, capturable=True)
+    mrgcn_amd.reset_stats()
     step = GraphedTrainStep(case.model, fwd, case.idx, case.y, opt, warmup=1)    # one eager epoch, then the capture
+    st = mrgcn_amd.stats()   # the eager epoch + the captured one: both layers on their gradient supports, every time
+    assert st.get("backward.support") == 4 and st.get("weight_I.fused_rows") == 2 and st.get("adam.list") == 2, st
+    assert not any(k in st for k in ("backward.marking", "backward.general", "weight_I.dense", "adam.rows")), st
     np.testing.assert_allclose(opt.last_grad_norm(), ora1["grad_norm"], rtol=2e-5)
     case.check_after_step(ora1, opt, before, "default path, eager step 1")
     before2, mom2 = case.snapshot(opt)
