@@ -90,14 +90,21 @@ def _epoch_steps(name, ClipAdam, train_step, row_sparse=None):
             np.testing.assert_allclose(opt.last_grad_norm(), float(c["grad_norm"]), rtol=1e-4)
         if step in (1, n_adam):
             sd = model.state_dict()
+            coef = min(1.0, 1.0 / (float(c["grad_norm"]) + 1e-6))
             for k in c.files:
                 if k.startswith(f"adam{step}."):
                     key = k[len(f"adam{step}."):]
                     diff = np.abs(sd[key].cpu().numpy() - c[k])
-                    # Adam's first steps move every element by ~lr*sign(g): elements whose fp32
-                    # gradient is at rounding-noise level may differ by up to 2*lr per step
-                    assert (diff > 2e-5).mean() < 2e-3, (k, float((diff > 2e-5).mean()))
                     assert diff.max() <= 0.021 * step, k
+                    if step == 1 and "grad." + key in c.files:
+                        # Adam's first step moves an element by lr * g / (|g| + eps): a whole lr-sized step may differ
+                        # only where the reference's own (clipped) gradient is rounding noise; every other element —
+                        # every node block of weight_I among them — lands on the reference's value
+                        g = np.abs(c["grad." + key]) * coef
+                        bad = (diff > 2e-5) & (g > 1e-6)
+                        assert not bad.any(), (k, int(bad.sum()), np.argwhere(bad)[:5].tolist())
+                    else:   # (later steps: the goldens hold no gradient to tell noise from signal)
+                        assert (diff > 2e-5).mean() < 2e-3, (k, float((diff > 2e-5).mean()))
 
 
 @pytest.mark.parametrize("name", ["mrgcn_small_featureless_b0", "mrgcn_small_featureless_b3",
