@@ -918,6 +918,37 @@ def partitioned_probe(args, name, dev, world, rank, steps=5, warmup=2, emit=None
             reduce_scatter_rows(full_rows)
     mdist.barrier(dev)
     out["reduce_scatter_ms"] = mdist.max_over_ranks(time.perf_counter() - t0, dev) / steps * 1e3
+    # the other form of SURVEY §8e: row partition + halo exchange of operand rows (mrgcn_amd.partition_halo).  Which of
+    # the two moves fewer bytes is a property of the graph and the rank count (choose_partition: the measured halo);
+    # both are timed here, fail-soft, so that the first contact with several GPUs prices both.
+    try:
+        from mrgcn_amd.partition_halo import HaloPartitionedRGCN, choose_partition, halo_train_step
+        ch = choose_partition(g.rows, g.cols, N, world, [o for _, o in dims])
+        out["partition_choice"] = {"by_received_bytes_per_forward": ch["choice"], "column_bytes": ch["column"],
+                                   "halo_bytes": ch["halo"]}
+        torch.manual_seed(args.seed)
+        hmodel = HaloPartitionedRGCN(modules, R, N, B, featureless, False, part).to(dev)
+        hmodel.load_state_dict(pmodel.state_dict())   # the same shards as the column engine holds now
+        hmodel.build_plan(g.rows, g.cols, g.vals, dev)
+        with torch.no_grad():
+            d = float((hmodel(Xl) - pmodel(Xl)).abs().max())
+        out["halo_logits_maxdiff_vs_column_engine"] = mdist.max_over_ranks(d, dev)
+        hopt = ClipAdam(hmodel.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+        hopt.set_distributed(None, hmodel.sharded_parameters())
+        for _ in range(warmup):
+            halo_train_step(hmodel, Xl, idx_np, y_np, hopt)
+        mdist.barrier(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            hl = halo_train_step(hmodel, Xl, idx_np, y_np, hopt)
+        mdist.barrier(dev)
+        out["halo_ms_per_step"] = mdist.max_over_ranks(time.perf_counter() - t0, dev) / steps * 1e3
+        out["halo_final_loss"] = float(hl)
+        out["halo_columns_this_rank"] = hmodel.plans.halo_columns
+        del hmodel, hopt
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001  (informational: the column engine's record stands)
+        out["halo_error"] = (type(e).__name__ + ": " + str(e))[:300]
     if emit is not None:
         emit(out)   # the eager record is safe (printed) before anything below can go wrong
     # the same step captured into a hipGraph, RCCL collectives included (partition.GraphedPartitionedStep): at 8 ranks a

@@ -1,0 +1,435 @@
+"""Row partition with a halo exchange of OPERAND rows — the second node-partitioned engine ("row
+partition + halo exchange of boundary rows ... pick by measured halo size"; north_star: "node-partitioned ... with halo
+exchange").
+
+Rank g owns the node range [g*S, (g+1)*S): those OUTPUT rows, those rows of the layer input and of `weight_I` (as in
+mrgcn_amd.partition).  Per layer
+
+    forward   M_g   = operand rows of the columns (r, j in range)        local: the mix / transform kernels on P_col
+              halo  = the operand rows of REMOTE columns my rows read     one all-to-all (rows of 4 F bytes)
+              Y_g   = A[rows_g, :] . [M_g | halo]                         local: the product on P_row — own rows only
+    backward  dM    = A[rows_g, :]^T dY_g                                 local
+              the halo columns' gradient rows go back to their owners     one all-to-all (reverse)
+              dV_g / dX_g / d(comp, W_F) from the summed dM_g             local; small gradients all-reduced
+
+Against the column partition (one reduce-scatter of `Np x out` partial sums per layer) the exchange carries only the
+distinct remote columns a rank's rows read: `tools/halo_probe.py` — less at 8 GPUs on the AM and synth10m shapes
+(77.5 vs 122.5 MB, 591 vs 945 MB per layer pass), more at 2-4 GPUs and on FB15k-237.  `choose_partition` picks by
+that measure.  This engine computes the backward on dense index spaces (no gradient support yet: every column of
+P_row gets its gradient row); the arithmetic equals `mrgcn_amd.models.rgcn.RGCN` on one GPU (tests).
+One process per GPU, torch.distributed (RCCL all-to-all over xGMI; gloo, CPU staged, in the tests)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib as L
+from . import functional as Fn
+from .layers.graph import GraphConvolution
+from .partition import NodePartition, _staged, all_reduce_sum_, partitioned_loss
+from .plan import GraphPlan
+
+
+# ---- index maps (host, pure numpy + one exchange of requests): testable without a GPU ---------------------------------
+def halo_requests(part: NodePartition, rows, cols, num_relations: int):
+    """What rank `part.rank` reads: the distinct literal columns (r*N + j, global) of the entries in its own rows, split
+    into the ones whose source node it owns and, per owner rank, the remote ones (each list sorted).
+    Returns (own_lit, {owner: lit array})."""
+    rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+    mine = (rows >= part.j0) & (rows < part.j1)
+    lit = np.unique(cols[mine])
+    owner = (lit % part.N) // part.S
+    own = lit[owner == part.rank]
+    return own, {int(o): lit[owner == o] for o in np.unique(owner) if o != part.rank}
+
+
+def exchange_requests(requests: dict, world: int, rank: int, group=None):
+    """Every rank tells every owner which of its columns it needs.  `requests`: {owner: int64 literal ids}.
+    Returns {requester: int64 literal ids} — what THIS rank must send, per peer, in the peer's order."""
+    # (RCCL moves device tensors only; gloo host tensors)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    counts_out = torch.zeros(world, dtype=torch.int64)
+    for o, ids in requests.items():
+        counts_out[o] = len(ids)
+    counts_in = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(counts_in, counts_out.to(dev), group=group)
+    counts_in = counts_in.cpu()
+    send = torch.from_numpy(np.concatenate([np.asarray(requests.get(o, np.zeros(0, np.int64)), dtype=np.int64)
+                                            for o in range(world)] + [np.zeros(0, np.int64)]))
+    recv = torch.empty(int(counts_in.sum()), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv, send.to(dev), output_split_sizes=counts_in.tolist(),
+                           input_split_sizes=counts_out.tolist(), group=group)
+    recv = recv.cpu()
+    out, at = {}, 0
+    for r in range(world):
+        n = int(counts_in[r])
+        if n:
+            out[r] = recv[at:at + n].numpy()
+        at += n
+    return out
+
+
+# ---- collectives -------------------------------------------------------------------------------------------------------
+def all_to_all_rows(send: torch.Tensor, in_splits, out_splits, group=None) -> torch.Tensor:
+    """rows of `send` (grouped by destination rank: in_splits rows each) -> the rows this rank receives (grouped by
+    source rank: out_splits rows each)."""
+    n_out = int(sum(out_splits))
+    if _staged(send, group):
+        buf = torch.empty((n_out,) + tuple(send.shape[1:]), dtype=send.dtype)
+        dist.all_to_all_single(buf, send.detach().cpu().contiguous(), output_split_sizes=list(out_splits),
+                               input_split_sizes=list(in_splits), group=group)
+        return buf.to(send.device)
+    out = torch.empty((n_out,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(out_splits), input_split_sizes=list(in_splits),
+                           group=group)
+    return out
+
+
+class _AllToAllRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, send, in_splits, out_splits, group):
+        ctx.in_splits, ctx.out_splits, ctx.group = in_splits, out_splits, group
+        return all_to_all_rows(send, in_splits, out_splits, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        # the gradient of a received row goes back to the rank that sent it
+        return all_to_all_rows(g.contiguous(), ctx.out_splits, ctx.in_splits, ctx.group), None, None, None
+
+
+# ---- the two local halves of a layer as autograd functions -----------------------------------------------------------
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _OperandFn(torch.autograd.Function):
+    """M = the compact operand of graph.py:69-94 for the columns of `plan` (operand order, ld = functional._ld_for(F)):
+    M[c] = comp_I[r_c] . V_I[j_c] (or weight_I[r_c*N + j_c]) + X[j_c] . W_F[r_c].  The backward takes the gradient of
+    those rows and runs the plan-level kernels (no gradient-sparsity shortcut)."""
+
+    @staticmethod
+    def forward(ctx, plan: GraphPlan, F: int, weight_I, comp_I, X, W_F):
+        lib = L.load()
+        dev = plan.device
+        ld = Fn._ld_for(F)
+        M = torch.empty((plan.nop, ld), dtype=torch.float32, device=dev)
+        s = _stream(dev)
+        Xc = Wc = None
+        with torch.cuda.device(dev):
+            addend, ldA = 0, 0
+            if X is not None:
+                Xc = X if (X.dim() == 2 and X.stride(1) == 1) else X.contiguous()
+                Wc = W_F.contiguous()
+                if weight_I is not None:
+                    ldA = (F + 3) // 4 * 4
+                    M2 = torch.empty((plan.ncols, ldA), dtype=torch.float32, device=dev)
+                    out, ldo, order = M2, ldA, 0
+                    addend = M2.data_ptr()
+                else:
+                    out, ldo, order = M, ld, 1
+                L.check(lib.mrgcn_rel_transform_fwd_f32(plan.handle, Xc.data_ptr(), Xc.stride(0), Xc.shape[1],
+                                                        Wc.data_ptr(), F, out.data_ptr(), ldo, order, s),
+                        "mrgcn_rel_transform_fwd_f32")
+            if weight_I is not None:
+                wI = weight_I.contiguous()
+                if comp_I is not None:
+                    cI = comp_I.contiguous()
+                    L.check(lib.mrgcn_basis_mix_fwd_f32(plan.handle, wI.data_ptr(), cI.data_ptr(), cI.shape[1], F, addend,
+                                                        ldA, M.data_ptr(), ld, s), "mrgcn_basis_mix_fwd_f32")
+                else:
+                    L.check(lib.mrgcn_gather_rows_f32(plan.handle, wI.data_ptr(), F, addend, ldA, M.data_ptr(), ld, s),
+                            "mrgcn_gather_rows_f32")
+        plan.replicate(M)
+        ctx.plan, ctx.F = plan, F
+        ctx.has = (weight_I is not None, comp_I is not None, X is not None)
+        ctx.save_for_backward(weight_I, comp_I, Xc, Wc)
+        return M
+
+    @staticmethod
+    def backward(ctx, dM_op):
+        lib = L.load()
+        plan, F = ctx.plan, ctx.F
+        weight_I, comp_I, X, W_F = ctx.saved_tensors
+        has_I, has_comp, has_X = ctx.has
+        dev = plan.device
+        s = _stream(dev)
+        ld = (F + 3) // 4 * 4
+        # the gradient rows in plain compact order, as the node-major consumers read them
+        dM = torch.zeros((plan.ncols, ld), dtype=torch.float32, device=dev)
+        dM[:, :F] = dM_op.index_select(0, _mpos_long(plan))[:, :F]
+        d_wI = d_comp = dX = dW = None
+        with torch.cuda.device(dev):
+            if has_I and has_comp:
+                wI = weight_I.contiguous()
+                Bn = wI.shape[1]
+                d_wI, d_comp = torch.empty_like(wI), torch.empty_like(comp_I)
+                L.check(lib.mrgcn_basis_mix_bwd_f32(plan.handle, dM.data_ptr(), ld, 0, wI.data_ptr(),
+                                                    comp_I.contiguous().data_ptr(), Bn, F, d_wI.data_ptr(), 0,
+                                                    d_comp.data_ptr(), 0, s), "mrgcn_basis_mix_bwd_f32")
+            elif has_I:
+                d_wI = torch.zeros_like(weight_I)
+                d_wI.index_copy_(0, plan.ulcol_long(), dM[:, :F])
+            if has_X:
+                need_dX, need_dW = ctx.needs_input_grad[4], ctx.needs_input_grad[5]
+                K = X.shape[1]
+                if need_dX or need_dW:
+                    nws = int(lib.mrgcn_rel_transform_bwd_workspace(plan.handle, K, F, int(need_dX), int(need_dW)))
+                    ws = torch.empty((max(nws, 1),), dtype=torch.float32, device=dev)
+                    if need_dX:
+                        dX = torch.empty((X.shape[0], K), dtype=torch.float32, device=dev)
+                    if need_dW:
+                        dW = torch.empty_like(W_F)
+                    L.check(lib.mrgcn_rel_transform_bwd_masked_f32(
+                        plan.handle, dM.data_ptr(), ld, 0, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
+                        dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0, ws.data_ptr(), nws, 0, 0, 0,
+                        s), "mrgcn_rel_transform_bwd_masked_f32")
+        return None, None, d_wI, d_comp, dX, dW
+
+
+def _mpos_long(plan: GraphPlan) -> torch.Tensor:
+    t = plan.__dict__.get("_mpos_long")
+    if t is None:
+        t = plan.__dict__["_mpos_long"] = torch.from_numpy(plan.export(L.ARR_MPOS).astype(np.int64)).to(plan.device)
+    return t
+
+
+class _ProductFn(torch.autograd.Function):
+    """Y = relu?( A' . M + b ) on the COMPACT view of `plan` (M in operand order); backward: A'^T dY by compact column,
+    scattered back into operand order."""
+
+    @staticmethod
+    def forward(ctx, plan: GraphPlan, M, F: int, bias, relu: bool):
+        Y = plan.spmm(L.VIEW_COMPACT, M.contiguous(), F=F, bias=bias, relu=relu)
+        ctx.plan, ctx.F, ctx.relu, ctx.has_bias, ctx.shape = plan, F, relu, bias is not None, tuple(M.shape)
+        ctx.save_for_backward(Y if relu else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        plan, F = ctx.plan, ctx.F
+        (Y,) = ctx.saved_tensors
+        dY = dY.contiguous()
+        if ctx.relu:
+            dY = Fn.relu_bwd(dY, Y)
+        dbias = dY.sum(0) if ctx.has_bias else None
+        ld = (F + 3) // 4 * 4
+        dMc = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dY.device)
+        plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dMc)
+        dM = torch.zeros(ctx.shape, dtype=torch.float32, device=dY.device)
+        dM[:, :F].index_copy_(0, _mpos_long(plan), dMc[:, :F])
+        return None, dM, None, dbias, None
+
+
+# ---- the partition's index maps on the device ------------------------------------------------------------------------
+class HaloPlans:
+    """P_col (the columns whose source node this rank owns: operand construction and its backward), P_row (this rank's
+    output rows over every column they read: the product) and the maps between them and the exchange buffers."""
+
+    def __init__(self, part: NodePartition, rows, cols, vals, num_relations: int, device, operand_row_bytes, group=None):
+        R, N, S, rank, world = num_relations, part.N, part.S, part.rank, part.world
+        rows, cols, vals = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64), np.asarray(vals)
+        # P_col: as mrgcn_amd.partition (rows global, columns r*S + local node)
+        lr, lc, lv = part.local_coo(rows, cols, vals, R)
+        A_col = torch.sparse_coo_tensor(torch.from_numpy(np.stack([lr, lc])), torch.from_numpy(lv),
+                                        (part.Np, R * S)).to(device)
+        self.p_col = GraphPlan(A_col, S, R, operand_row_bytes=operand_row_bytes)
+        del A_col
+        # P_row: own rows; source nodes renumbered: own nodes 0 .. S-1, then the remote nodes read (rising id)
+        mine = (rows >= part.j0) & (rows < part.j1)
+        er, ec, ev = rows[mine] - part.j0, cols[mine], vals[mine]
+        rel, node = ec // N, ec % N
+        remote = np.unique(node[(node < part.j0) | (node >= part.j1)])
+        Nl = S + len(remote)
+        is_own = (node >= part.j0) & (node < part.j1)
+        jl = np.where(is_own, node - part.j0, S + np.searchsorted(remote, node))
+        A_row = torch.sparse_coo_tensor(torch.from_numpy(np.stack([er, rel * Nl + jl])), torch.from_numpy(ev),
+                                        (S, R * Nl)).to(device)
+        self.p_row = GraphPlan(A_row, Nl, R, operand_row_bytes=operand_row_bytes)
+        del A_row
+        # every compact column of P_row: its global literal id, its owner
+        ul = self.p_row.export(L.ARR_ULCOL).astype(np.int64)
+        r_c, jl_c = ul // Nl, ul % Nl
+        node_c = np.where(jl_c < S, jl_c + part.j0, remote[np.maximum(jl_c - S, 0)] if len(remote) else 0)
+        lit_c = r_c * N + node_c
+        own_c = jl_c < S
+        mpos_row = self.p_row.export(L.ARR_MPOS).astype(np.int64)
+        # P_col: literal id (global) of its compact columns -> operand position
+        ulc = self.p_col.export(L.ARR_ULCOL).astype(np.int64)
+        lit_col = (ulc // S) * N + (ulc % S) + part.j0
+        mpos_col = self.p_col.export(L.ARR_MPOS).astype(np.int64)
+        order = np.argsort(lit_col, kind="stable")
+        lit_sorted = lit_col[order]
+
+        def col_positions(lits):   # operand positions in M_col of the given global literal columns
+            at = np.searchsorted(lit_sorted, lits)
+            if len(lits) and (at.max() >= len(lit_sorted) or not np.array_equal(lit_sorted[at], lits)):
+                raise L.MrgcnError("halo partition: a requested column is not a column of its owner")
+            return mpos_col[order[at]]
+        self.own_src = torch.from_numpy(col_positions(lit_c[own_c])).to(device)
+        self.own_dst = torch.from_numpy(mpos_row[own_c]).to(device)
+        # requests to the owners of the remote columns (in rising literal id per owner), and theirs to me
+        own_of = node_c // S
+        req, halo_dst = {}, []
+        for o in range(world):
+            sel = (~own_c) & (own_of == o)
+            if sel.any():
+                ordr = np.argsort(lit_c[sel], kind="stable")
+                req[o] = lit_c[sel][ordr]
+                halo_dst.append(mpos_row[sel][ordr])
+        self.out_splits = [len(req.get(o, ())) for o in range(world)]
+        self.halo_dst = torch.from_numpy(np.concatenate(halo_dst) if halo_dst else np.zeros(0, np.int64)).to(device)
+        asked = exchange_requests(req, world, rank, group)
+        self.in_splits = [len(asked.get(r, ())) for r in range(world)]
+        self.send_pos = torch.from_numpy(np.concatenate([col_positions(asked[r]) for r in range(world) if r in asked]
+                                                        + [np.zeros(0, np.int64)])).to(device)
+        self.halo_columns = int(sum(self.out_splits))
+
+    def exchange_bytes(self, F: int) -> int:
+        """bytes this rank RECEIVES per layer pass (forward; the backward returns as many)"""
+        return self.halo_columns * Fn._ld_for(F) * 4
+
+
+# ---- the model -----------------------------------------------------------------------------------------------------------
+class HaloPartitionedRGCN(nn.Module):
+    """`RGCN` (models/rgcn.py) with the row partition + operand-row halo exchange.  Same constructor and sharding of the
+    parameters as `partition.PartitionedRGCN`."""
+
+    def __init__(self, modules, num_relations, num_nodes, num_bases, featureless, bias, part: NodePartition, group=None,
+                 link_prediction=False):
+        super().__init__()
+        if link_prediction:
+            self.relations = nn.Parameter(torch.empty((num_relations, modules[-1][1])))
+            nn.init.xavier_uniform_(self.relations)
+        self.part, self.group = part, group
+        self.num_nodes, self.num_relations, self.num_bases = num_nodes, num_relations, num_bases
+        self.layers = nn.ModuleDict()
+        self.relu = []
+        for i, (indim, outdim, _t, act) in enumerate(modules):
+            first = i == 0
+            self.layers[f"layer_{i}"] = GraphConvolution(
+                indim, outdim, num_relations, part.S, num_bases=num_bases, bias=bias, input_layer=first,
+                featureless=featureless if first else False)
+            self.relu.append(isinstance(act, nn.ReLU))
+        self.num_layers = len(self.layers)
+        self.plans = None
+
+    # (the same sharding helpers as the column-partition model)
+    def sharded_parameters(self):
+        return [l.weight_I for l in self.layers.values() if l.weight_I is not None]
+
+    def replicated_parameters(self):
+        sh = {id(p) for p in self.sharded_parameters()}
+        return [p for p in self.parameters() if id(p) not in sh]
+
+    @torch.no_grad()
+    def load_full_state(self, state: dict):
+        if "relations" in state and hasattr(self, "relations"):
+            self.relations.copy_(state["relations"].to(self.relations.device))
+        for i, layer in enumerate(self.layers.values()):
+            for name, p in layer.named_parameters():
+                full = state[f"layers.layer_{i}.{name}"].to(p.device)
+                if name == "weight_I":
+                    S_b = self.num_bases if self.num_bases > 0 else self.num_relations
+                    p.copy_(self.part.shard_weight_I(full, S_b, node_major=layer.weight_I_node_major))
+                else:
+                    p.copy_(full)
+
+    def build_plan(self, rows, cols, vals, device):
+        rb = sorted({l.operand_row_bytes() for l in self.layers.values()})
+        self.plans = HaloPlans(self.part, rows, cols, vals, self.num_relations, device, rb, self.group)
+        return self.plans
+
+    def forward(self, X_local):
+        hp = self.plans
+        H = X_local
+        for i, layer in enumerate(self.layers.values()):
+            F, B = layer.outdim, layer.num_bases
+            weight_I = comp_I = Xin = W_F = None
+            if layer.input_layer:
+                weight_I = layer.weight_I
+                comp_I = layer.weight_I_comp if B > 0 else None
+            if not (layer.input_layer and layer.featureless):
+                Xin, W_F = H, layer.weight_F
+                if B > 0:
+                    W_F = Fn._BasisContract.apply(layer.weight_F_comp, W_F)
+            M_col = _OperandFn.apply(hp.p_col, F, weight_I, comp_I, Xin, W_F)           # my columns' operand rows
+            recv = _AllToAllRows.apply(M_col.index_select(0, hp.send_pos), hp.in_splits, hp.out_splits, self.group)
+            M_row = torch.zeros((hp.p_row.nop, M_col.shape[1]), dtype=torch.float32, device=M_col.device)
+            M_row = M_row.index_copy(0, hp.own_dst, M_col.index_select(0, hp.own_src)).index_copy(0, hp.halo_dst, recv)
+            H = _ProductFn.apply(hp.p_row, M_row, F, layer.b if layer.bias else None, self.relu[i])   # my rows
+        return H
+
+    @torch.no_grad()
+    def sync_replicated(self, src: int = 0):
+        for q in self.replicated_parameters():
+            if _staged(q, self.group):
+                buf = q.detach().cpu()
+                dist.broadcast(buf, src, group=self.group)
+                q.copy_(buf.to(q.device))
+            else:
+                dist.broadcast(q.data, src, group=self.group)
+
+    def allreduce_replicated_grads(self):
+        for p in self.replicated_parameters():
+            if p.grad is not None:
+                all_reduce_sum_(p.grad, self.group)
+
+
+def halo_train_step(model: HaloPartitionedRGCN, X_local, idx_global, targets, optimizer):
+    """One full-batch epoch on the halo engine: dense gradients (`.grad` of every parameter), the replicated ones
+    all-reduced, ClipAdam with the shards' norms added (set_distributed)."""
+    logits = model(X_local)
+    local, total = partitioned_loss(logits, idx_global, targets, model.part, model.group)
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    Fn.clear_row_grads(params)
+    optimizer.zero_grad(set_to_none=True)
+    prev = Fn.row_sparse_weight_grad(False)
+    try:
+        local.backward()
+    finally:
+        Fn.row_sparse_weight_grad(prev)
+    model.allreduce_replicated_grads()
+    optimizer.step()
+    return total
+
+
+def halo_lp_step(model: HaloPartitionedRGCN, X_local, triples, labels, optimizer):
+    """The link-prediction step of partition.partitioned_lp_step on the halo engine."""
+    from .partition import _AllGatherRows
+    from .tasks import link_prediction as lp
+    part, group = model.part, model.group
+    world, rank = part.world, part.rank
+    E = _AllGatherRows.apply(model(X_local), group)[: part.N]
+    n = triples.shape[0]
+    mine = torch.arange(rank, n, world, device=triples.device)
+    t = triples[mine]
+    sc = lp.score_distmult_bc((t[:, 0], t[:, 1], t[:, 2]), E, model.relations)
+    local = lp.binary_crossentropy(sc, labels[mine]) * (float(mine.numel()) / n) if mine.numel() else (E * 0.0).sum()
+    total = local.detach().clone()
+    all_reduce_sum_(total, group)
+    optimizer.zero_grad(set_to_none=True)
+    prev = Fn.row_sparse_weight_grad(False)
+    try:
+        local.backward()
+    finally:
+        Fn.row_sparse_weight_grad(prev)
+    model.allreduce_replicated_grads()
+    optimizer.step()
+    return total
+
+
+def choose_partition(rows, cols, num_nodes: int, world: int, layer_widths) -> dict:
+    """Bytes one rank RECEIVES per forward of all layers under either engine (the probe of tools/halo_probe.py as a
+    library call): {"column": bytes, "halo": bytes, "choice": "column" | "halo"}.  Host arithmetic on the COO arrays."""
+    rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+    S = (num_nodes + world - 1) // world
+    src = cols % num_nodes
+    ro, so = rows // S, src // S
+    halo_cols = [int(np.unique(cols[(ro == r) & (so != r)]).size) for r in range(world)]
+    Np = S * world
+    col_b = sum((world - 1) / world * Np * w * 4 for w in layer_widths)
+    halo_b = sum(float(np.mean(halo_cols)) * w * 4 for w in layer_widths)
+    return {"column": col_b, "halo": halo_b, "choice": "halo" if halo_b < col_b else "column",
+            "halo_columns_per_rank": halo_cols}

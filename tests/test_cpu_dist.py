@@ -184,3 +184,59 @@ def test_live_row_exchange_equals_the_dense_all_gather_gloo_world2():
         compact, dense, total, n_max, cached = out[r]
         assert compact == dense
         assert total == 3 and n_max == 3 and cached
+
+
+# ---- row partition with operand-row halo exchange (mrgcn_amd.partition_halo): index maps + exchange over gloo -------
+def _halo_worker(rank, world, port, out):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    import torch.distributed as dist
+    from mrgcn_amd import synth
+    from mrgcn_amd.partition import NodePartition
+    from mrgcn_amd.partition_halo import _AllToAllRows, exchange_requests, halo_requests
+    dist.init_process_group("gloo")
+    g = synth.make_graph("aifb", seed=2, scale=0.2)
+    N, R = g.num_nodes, g.num_relations
+    part = NodePartition(N, world, rank)
+    own, req = halo_requests(part, g.rows, g.cols, R)
+    asked = exchange_requests(req, world, rank)
+    # every column I am asked for is one I own; every column my rows read is either mine or requested from its owner
+    for r, ids in asked.items():
+        assert r != rank and ((ids % N) // part.S == rank).all()
+    mine = (g.rows >= part.j0) & (g.rows < part.j1)
+    need = np.unique(g.cols[mine])
+    got = np.sort(np.concatenate([own] + list(req.values())))
+    assert np.array_equal(got, need)
+    # the exchange itself: "operand row" of literal column c = [c, 2c + 1]; the rows come back in request order, and
+    # the gradient of a received row returns to the rank that sent it (each requested row once per requester)
+    send_ids = np.concatenate([asked[r] for r in range(world) if r in asked] + [np.zeros(0, np.int64)])
+    send = torch.tensor(np.stack([send_ids, 2 * send_ids + 1], 1), dtype=torch.float64, requires_grad=True)
+    in_splits = [len(asked.get(r, ())) for r in range(world)]
+    out_splits = [len(req.get(o, ())) for o in range(world)]
+    recv = _AllToAllRows.apply(send, in_splits, out_splits, None)
+    want = np.concatenate([req[o] for o in range(world) if o in req] + [np.zeros(0, np.int64)])
+    assert np.array_equal(recv.detach().numpy()[:, 0].astype(np.int64), want)
+    (recv * (rank + 1.0)).sum().backward()
+    # my row sent to peer r comes back scaled by (r + 1)
+    scale = np.concatenate([np.full(len(asked[r]), r + 1.0) for r in range(world) if r in asked] + [np.zeros(0)])
+    assert np.allclose(send.grad.numpy(), np.stack([scale, scale], 1))
+    out[rank] = (len(own), int(sum(out_splits)), int(sum(in_splits)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_requests_and_operand_row_exchange_gloo(world):
+    import numpy as np
+    from mrgcn_amd import synth
+    from mrgcn_amd.partition_halo import choose_partition
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_halo_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = dict(out)
+    assert sum(v[1] for v in res.values()) == sum(v[2] for v in res.values())   # rows requested == rows served
+    g = synth.make_graph("aifb", seed=2, scale=0.2)
+    ch = choose_partition(g.rows, g.cols, g.num_nodes, world, [16, 4])
+    assert ch["halo_columns_per_rank"] == [res[r][1] for r in range(world)]
+    assert ch["choice"] in ("halo", "column") and ch["halo"] == float(np.mean(ch["halo_columns_per_rank"])) * 20 * 4

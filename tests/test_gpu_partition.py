@@ -346,3 +346,108 @@ def test_bench_replicas_also_run_the_partitioned_engine_in_child_processes():
     rec = j["extra"]["partitioned"]["am"]
     assert "error" not in rec, rec
     assert rec["rccl_world"] == 2 and rec["ms_per_step"] > 0 and rec["logits_maxdiff_vs_single"] < 1e-4
+
+
+# ---- the row partition with operand-row halo exchange (mrgcn_amd.partition_halo) ------------------------------------
+def _halo_worker(rank, world, port, state, out, lp_mode=False):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from mrgcn_amd.partition import NodePartition
+    from mrgcn_amd.partition_halo import HaloPartitionedRGCN, halo_lp_step, halo_train_step
+    from mrgcn_amd.train import ClipAdam
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo")
+    if lp_mode:
+        g, facts, Y, mods = _lp_problem()
+        N, R = g.num_nodes, g.num_relations
+        part = NodePartition(N, world, rank)
+        model = HaloPartitionedRGCN(mods, R, N, 2, True, False, part, link_prediction=True).to(dev)
+        model.load_full_state(state)
+        hp = model.build_plan(g.rows, g.cols, g.vals, dev)
+        opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+        opt.set_distributed(None, model.sharded_parameters())
+        tr, yy = torch.from_numpy(facts).to(dev), torch.from_numpy(Y).to(dev)
+        emb0 = model(None).detach().cpu().numpy()[: part.n_local]
+        losses = [float(halo_lp_step(model, None, tr, yy, opt)) for _ in range(2)]
+        out[rank] = (emb0, losses, model.relations.detach().cpu().numpy(), hp.halo_columns)
+        dist.destroy_process_group()
+        return
+    g, X, idx, y, mods = _problem()
+    N, R = g.num_nodes, g.num_relations
+    part = NodePartition(N, world, rank)
+    model = HaloPartitionedRGCN(mods, R, N, 5, False, True, part).to(dev)
+    model.load_full_state(state)
+    hp = model.build_plan(g.rows, g.cols, g.vals, dev)
+    Xl = part.shard_rows(torch.from_numpy(X)).to(dev)
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    opt.set_distributed(None, model.sharded_parameters())
+    logits0 = model(Xl).detach().cpu().numpy()[: part.n_local]
+    losses = [float(halo_train_step(model, Xl, idx, y, opt)) for _ in range(2)]
+    wI = model.layers["layer_0"].weight_I.detach().cpu().permute(1, 0, 2)[:, : part.n_local]
+    out[rank] = (logits0, losses, wI.numpy(), model.layers["layer_1"].weight_F.detach().cpu().numpy(), hp.halo_columns)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_engine_ranks_equal_single_gpu(world):
+    """The row partition with operand-row halo exchange (SURVEY §8e's second form; north_star's wording) with 2 and 3
+    ranks against the single-GPU RGCN: logits before training, the losses of two epochs, the sharded node table and a
+    replicated parameter after them.  The exchange moved exactly the distinct remote columns the probe counts."""
+    from mrgcn_amd.partition_halo import choose_partition
+    state, logits0, losses, final = _single()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_halo_worker, args=(world, _free_port(), state, out), nprocs=world, join=True)
+    ranks = range(world)
+    np.testing.assert_allclose(np.concatenate([out[r][0] for r in ranks], 0), logits0, rtol=1e-4, atol=1e-4)
+    for r in ranks:
+        np.testing.assert_allclose(out[r][1], losses, rtol=2e-4, atol=2e-5)
+    N = logits0.shape[0]
+    wI = np.concatenate([out[r][2] for r in ranks], 1).reshape(5 * N, -1)
+    d = np.abs(wI - final["layers.layer_0.weight_I"].numpy())
+    assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.045
+    for r in ranks:
+        d = np.abs(out[r][3] - final["layers.layer_1.weight_F"].numpy())
+        assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.045
+    g = _problem()[0]
+    ch = choose_partition(g.rows, g.cols, g.num_nodes, world, [8, 4])
+    assert ch["halo_columns_per_rank"] == [out[r][4] for r in ranks]
+
+
+@pytest.mark.timeout(600)
+def test_halo_engine_link_prediction_equals_single_gpu():
+    """BASELINE config 4's computation on the halo engine with two ranks (a wide featureless encoder layer, F = 12;
+    all-gathered embeddings, triples scored rank::world): the embeddings before training, the losses of two epochs and
+    the decoder's relation table against the single-GPU model."""
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.tasks import link_prediction as lp
+    from mrgcn_amd.train import ClipAdam
+    g, tr, y, mods = _lp_problem()
+    N, R = g.num_nodes, g.num_relations
+    torch.manual_seed(5)
+    model = RGCN(mods, R, N, 2, 0.0, True, False, True)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals),
+                                (N, R * N)).cuda()
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0)
+    t, yy = torch.from_numpy(tr).cuda(), torch.from_numpy(y).cuda()
+    emb0 = model(None, A).detach().cpu().numpy()
+    losses = []
+    for _ in range(2):
+        sc = lp.score_distmult_bc((t[:, 0], t[:, 1], t[:, 2]), model(None, A), model.relations)
+        loss = lp.binary_crossentropy(sc, yy)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_halo_worker, args=(2, _free_port(), state, out, True), nprocs=2, join=True)
+    np.testing.assert_allclose(np.concatenate([out[r][0] for r in (0, 1)], 0), emb0, rtol=1e-4, atol=1e-4)
+    for r in (0, 1):
+        np.testing.assert_allclose(out[r][1], losses, rtol=2e-4, atol=2e-5)
+        d = np.abs(out[r][2] - model.relations.detach().cpu().numpy())
+        assert (d > 2e-5).mean() < 5e-3 and d.max() <= 0.05
