@@ -346,6 +346,11 @@ def test_bench_replicas_also_run_the_partitioned_engine_in_child_processes():
     rec = j["extra"]["partitioned"]["am"]
     assert "error" not in rec, rec
     assert rec["rccl_world"] == 2 and rec["ms_per_step"] > 0 and rec["logits_maxdiff_vs_single"] < 1e-4
+    # both engines of SURVEY §8e are priced, and the one with the smaller measured halo is named
+    assert "halo_error" not in rec, rec.get("halo_error")
+    assert rec["halo_ms_per_step"] > 0 and rec["halo_logits_maxdiff_vs_column_engine"] < 1e-4
+    ch = rec["partition_choice"]
+    assert ch["by_received_bytes_per_forward"] == ("halo" if ch["halo_bytes"] < ch["column_bytes"] else "column")
 
 
 # ---- the row partition with operand-row halo exchange (mrgcn_amd.partition_halo) ------------------------------------
