@@ -507,6 +507,12 @@ int mrgcn_support_rel_transform_bwd_compact_f32(const mrgcn_support_t *support, 
 /* ---- epoch kernels around the layers ----------------------------------------------
  * out = dY * (Y > 0): backward of the nn.ReLU between layers (rgcn.py:86-87) */
 int mrgcn_relu_bwd_f32(const float *dY, const float *Y, int64_t n, float *out, void *stream);
+/* dst[n_rows, F] (contiguous) = the rows of `src` scattered to their places, zeros everywhere else, in ONE pass:
+ * dst[sorted_rows[k], :] = src[perm[k], 0:F] (sorted_rows rising, without repeats).  The dense gradient of the literal
+ * (R*N) x out `weight_I` of a layer without bases (autograd of graph.py:75): sorted_rows = the plan's touched literal
+ * columns in rising order, perm = their compact ids, src = the compact gradient rows. */
+int mrgcn_scatter_rows_zero_fill_f32(const int32_t *sorted_rows, const int32_t *perm, int64_t n_touched,
+                                     const float *src, int64_t ldS, int32_t F, float *dst, int64_t n_rows, void *stream);
 /* Streaming yardsticks for measurement (bench.py: extra.device_copy_gbps_hip, extra.triad_gbps): dst = src as a plain
  * float4 copy, and a 3-read / 3-write elementwise pass with Adam's arithmetic (the memory shape of a dense optimizer
  * step).  n % 4 == 0, 16-byte aligned.  Nothing in the package calls them. */

@@ -537,7 +537,49 @@ __global__ __launch_bounds__(256) void k_probe_triad4(yf4 *__restrict__ p, yf4 *
 }
 }  // namespace mrgcn
 
+namespace mrgcn {
+// dst[row, 0:F] = src[perm[k], 0:F] where row == sorted_rows[k], zeros for every other row: the dense gradient of a
+// table of which only some rows received any (the literal (R*N) x out weight_I of a layer without bases: autograd of
+// graph.py:75 — torch produced it as zeros_like + index_copy_, two passes over the table).  A lane group per row, a
+// binary search in the sorted list of touched rows (cache resident), one pass over dst.
+__global__ __launch_bounds__(256) void k_scatter_rows_zero_fill(const int32_t *__restrict__ sorted_rows,
+                                                                const int32_t *__restrict__ perm, int64_t n_touched,
+                                                                const float *__restrict__ src, int64_t ldS, int F,
+                                                                float *__restrict__ dst, int64_t n_rows) {
+  const int P = (F + 3) >> 2;  // 16-byte pieces of a row
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = t / P;
+  const int piece = (int)(t - row * P);
+  if (row >= n_rows) return;
+  int64_t lo = 0, hi = n_touched;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted_rows[mid] < row) lo = mid + 1; else hi = mid;
+  }
+  const bool hit = lo < n_touched && sorted_rows[lo] == row;
+  const float *s = hit ? src + (int64_t)perm[lo] * ldS : nullptr;
+  float *d = dst + row * F;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int f = 4 * piece + u;
+    if (f < F) d[f] = hit ? s[f] : 0.f;
+  }
+}
+}  // namespace mrgcn
+
 extern "C" {
+
+int mrgcn_scatter_rows_zero_fill_f32(const int32_t *sorted_rows, const int32_t *perm, int64_t n_touched,
+                                     const float *src, int64_t ldS, int32_t F, float *dst, int64_t n_rows, void *stream) {
+  MRGCN_REQUIRE(dst && n_rows >= 0 && F > 0 && n_touched >= 0, "NULL / sizes");
+  MRGCN_REQUIRE(n_touched == 0 || (sorted_rows && perm && src && ldS >= F), "NULL / ldS");
+  if (n_rows == 0) return MRGCN_OK;
+  const int64_t threads = n_rows * ((F + 3) / 4);
+  mrgcn::k_scatter_rows_zero_fill<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      sorted_rows, perm, n_touched, src, ldS, F, dst, n_rows);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
 
 int mrgcn_probe_copy_f32(const float *src, float *dst, int64_t n, void *stream) {
   MRGCN_REQUIRE(src && dst && n >= 0 && n % 4 == 0, "NULL / n % 4");

@@ -479,9 +479,15 @@ class _RgcnLayer(torch.autograd.Function):
                         comp_I.data_ptr(), Bn, F, d_wI.data_ptr(), 0, d_comp.data_ptr(), 0, s),
                         "mrgcn_basis_mix_bwd_f32")
             elif has_I:
-                # dense (R*N) x F gradient: zero + scatter of the touched rows
-                d_wI = torch.zeros_like(weight_I)
-                d_wI.index_copy_(0, plan.ulcol_long(), dM[:, :F])
+                # dense (R*N) x F gradient in one pass: the touched rows from dM, zeros everywhere else
+                d_wI = torch.empty(weight_I.shape, dtype=torch.float32, device=dev)
+                if torch.cuda.is_current_stream_capturing() and "_ulcol_sorted" not in plan.__dict__:
+                    raise L.MrgcnError("the sorted column list of this plan is built on first use: run one backward "
+                                       "of the layer before capturing it")
+                srows, sperm = plan.ulcol_sorted()
+                L.check(lib.mrgcn_scatter_rows_zero_fill_f32(srows.data_ptr(), sperm.data_ptr(), srows.numel(),
+                                                             dM.data_ptr(), ld, F, d_wI.data_ptr(), d_wI.shape[0], s),
+                        "mrgcn_scatter_rows_zero_fill_f32")
             if has_X:
                 need_dX = ctx.needs_input_grad[4]
                 need_dW = ctx.needs_input_grad[5]

@@ -255,6 +255,15 @@ class GraphPlan:
             self._ulcol_long = t
         return t
 
+    def ulcol_sorted(self):
+        """(rows, perm): the touched literal columns in rising order (int32) and the compact id of each (int32) — what
+        mrgcn_scatter_rows_zero_fill_f32 walks.  Built once (one device sort), kept."""
+        ent = self.__dict__.get("_ulcol_sorted")
+        if ent is None:
+            rows, perm = torch.sort(self.ulcol_long())
+            ent = self.__dict__["_ulcol_sorted"] = (rows.to(torch.int32).contiguous(), perm.to(torch.int32).contiguous())
+        return ent
+
     # -- per-node entry units of the wide-layer backward (mrgcn_wide_input_bwd_f32) ---------------------
     def wide_units(self, unit_entries: int = 256):
         """(erel, unit_node, unit_beg, unit_end, unit_multi, n_units): the plan's CSC entries cut into per-node units

@@ -34,7 +34,7 @@ python3 tools/prof_summary.py $o/stats 40 > $o/epoch_kernel_stats.md
 python3 tools/trace_summary.py $o/stats > $o/epoch_kernel_trace_medians.md 2>/dev/null
 python3 tools/epoch_sequence.py $o/stats > $o/epoch_sequence.md 2>/dev/null
 bash tools/pmc_passes.sh $o/pmc_epoch all -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-literal-spmm --no-graph --no-seeds --no-side-workloads
-for k in k_mix_fwd k_mix_bwd_sup k_dcomp k_adam_rows k_xform_mfma_fwd k_xform_mfma_dw "k_spmm<" k_spmm3; do
+for k in k_mix_fwd k_mix_bwd_sup k_dcomp k_adam_rows k_xform_mfma_fwd k_xform_cols_lds k_xform_mfma_dw "k_spmm<" k_spmm3; do
   echo "## $k"; python3 tools/pmc_summary.py $o "$k" | tail -n +3
 done > $o/epoch_pmc.md
 python3 tools/roofline_table.py $o/stats $o/bench_line.json $o > $o/kernel_roofline.md 2> $o/kernel_roofline.err

@@ -50,6 +50,8 @@ def main():
         ("mrgcn::k_spmm3<4, 4, false, float, true, 7>", ("forward product, F=10 (SURVEY 8d formula; the F=11 launches move 7.7 % more)", spmm_bytes(N, NCOLS, F0))),
         ("mrgcn::k_xform_mfma_fwd<1, false, 1, float, false>",
          ("layer-1 transform: H read once + W + M written + indices", N * F0 * 4 + R * F0 * F1 * 4 + NCOLS * F1 * 4 + NCOLS * 12)),
+        ("mrgcn::k_xform_cols_lds<12, float>",
+         ("layer-1 transform, output order, all weights in LDS: H read once + W + M written + (node, relation) ids", N * F0 * 4 + R * F0 * F1 * 4 + NCOLS * F1 * 4 + NCOLS * 8)),
         ("mrgcn::k_mix_bwd_sup<10, 2, 512, true>",
          ("norm-only mix backward: V of the live nodes + their dM rows in, D rows out", NL0 * B * F0 * 4 + L0 * (LD * 4 + B * 4 + 4) + NL0 * 8)),
         ("mrgcn::k_dcomp_chunks<10>", ("dcomp: D rows in, by relation", L0 * (B * 4 + 4))),
@@ -57,13 +59,15 @@ def main():
          ("layer-0 dW over the live columns: X rows of the live NODES once + dM rows + lists", NL0 * K0 * 4 + L0 * (LD * 4 + 8))),
         ("mrgcn::k_adam_rows_fused",
          ("Adam, gradient formed on the fly: p, m, v of the live blocks in and out + their dM rows", 6 * 4 * B * NL0 * F0 + L0 * LD * 4 + N * 6)),
+        ("mrgcn::k_adam_rows_list<2, true>",
+         ("Adam over the support's node list, gradient formed on the fly: p, m, v of the live blocks in and out + their dM rows + the list", 6 * 4 * B * NL0 * F0 + L0 * (LD * 4 + 4) + NL0 * 8)),
     ])
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         d[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print(f"source: {f}\n")
-    print("HBM roofline 8.0 TB/s (MI355X spec; a 1 GiB device copy reaches about 5.1 TB/s read + write on these boxes).")
+    print("HBM roofline 8.0 TB/s (MI355X spec; a hand-written float4 copy and a 3-read / 3-write triad reach 4.6-4.7 TB/s on these boxes: extra.device_copy_gbps_hip / extra.triad_gbps of the bench line).")
     print("`alg. MB` are ALGORITHMIC bytes: every operand counted once, gathered rows counted once however often they are")
     print("re-read.  `counter MB` = TCC_EA0_RDREQ (32 / 64 / 128-byte requests) + WRITE_SIZE of separate --pmc passes.\n")
     print("| kernel | what is counted | alg. MB | launches | median us | achieved GB/s | % of 8 TB/s | counter MB | counter / alg. |")
