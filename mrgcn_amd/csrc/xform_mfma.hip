@@ -336,24 +336,27 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const int32_t *__restrict__ r
                                                    const int32_t *__restrict__ relchunk_ptr, int n_seg_max,
                                                    const float *__restrict__ slab, int KF,
                                                    float *__restrict__ dW, int R) {
-  // grid.x = R * n_seg_max: (relation, segment)
+  // grid = (R * n_seg_max, ceil(KF / 256)): (relation, segment) x a 256-element slice of the tile — one element per
+  // thread, the segment's slabs four at a time (the sum order is fixed by the chunk order)
   const int r = blockIdx.x / n_seg_max, seg = blockIdx.x - r * n_seg_max;
   if (r >= R) return;
   const int c0 = relchunk_ptr[r] + seg * kDwSeg;
   const int c1 = min(relchunk_ptr[r + 1], c0 + kDwSeg);
-  if (c0 >= c1) return;
-  for (int t = threadIdx.x; t < KF; t += blockDim.x) {
-    float s0 = 0.f, s1 = 0.f;
-    int c = c0;
-    for (; c + 2 <= c1; c += 2) {
-      s0 += slab[(int64_t)relchunk_ids[c] * KF + t];
-      s1 += slab[(int64_t)relchunk_ids[c + 1] * KF + t];
-    }
-    if (c < c1) s0 += slab[(int64_t)relchunk_ids[c] * KF + t];
-    const float s = s0 + s1;
-    if (relchunk_ptr[r + 1] - relchunk_ptr[r] <= kDwSeg) dW[(int64_t)r * KF + t] = s;  // sole writer
-    else if (s != 0.f) atomicAdd(&dW[(int64_t)r * KF + t], s);
+  const int t = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c0 >= c1 || t >= KF) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = c0;
+  for (; c + 4 <= c1; c += 4) {
+    const int64_t i0 = relchunk_ids[c], i1 = relchunk_ids[c + 1], i2 = relchunk_ids[c + 2], i3 = relchunk_ids[c + 3];
+    s0 += slab[i0 * KF + t];
+    s1 += slab[i1 * KF + t];
+    s2 += slab[i2 * KF + t];
+    s3 += slab[i3 * KF + t];
   }
+  for (; c < c1; ++c) s0 += slab[(int64_t)relchunk_ids[c] * KF + t];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (relchunk_ptr[r + 1] - relchunk_ptr[r] <= kDwSeg) dW[(int64_t)r * KF + t] = s;  // sole writer
+  else if (s != 0.f) atomicAdd(&dW[(int64_t)r * KF + t], s);
 }
 
 // dX[j, 0:K] = sum of the rows Z[nptr[j] .. nptr[j+1]) (Z in compact (j, r) order)
@@ -797,7 +800,7 @@ int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx
   if (slab) {
     const int n_seg_max = (o.max_relchunks + kDwSeg - 1) / kDwSeg;
     if (n_seg_max > 0) {
-      k_dw_reduce<<<dim3((unsigned)(p->num_relations * n_seg_max)), dim3(256), 0, s>>>(
+      k_dw_reduce<<<dim3((unsigned)(p->num_relations * n_seg_max), (unsigned)((K * F + 255) / 256)), dim3(256), 0, s>>>(
           o.relchunk_ids, o.relchunk_ptr, n_seg_max, slab, K * F, dW, (int)p->num_relations);
       MRGCN_HIP_TRY(hipGetLastError());
     }

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--dm-zero-frac", type=float, default=0.0,
                     help="fraction of dM rows set to exact zeros (the AM epoch has ~0.9)")
     ap.add_argument("--x-ld", type=int, default=0, help="row stride of X in floats (default: its width)")
+    ap.add_argument("--sweep", default="", help="library configurations to time every call under, ';' separated sets "
+                    "of k=v pairs: 'xform_hot=0;xform_hot=1,xform_hot_tile=96'")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = L.load()
@@ -99,9 +101,14 @@ def main():
         "adam": lambda: chk(lib.mrgcn_adam_step_f32(P.data_ptr(), G_.data_ptr(), M_.data_ptr(), V_.data_ptr(), P.numel(), 0.01, 0.9, 0.999, 1e-8, 0.0, 1, coef.data_ptr(), s)),
     }
     print(f"N={N} R={R} B={B} F={F} K={K} ncols={nc} nnz={plan.nnz} ldM={ld}")
-    for name in a.which.split(","):
-        ms = event_time_ms(calls[name], a.iters, s)
-        print(f"{name:12s} {ms*1e3:9.1f} us")
+    sweeps = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in part.split(",") if kv)
+              for part in a.sweep.split(";")] if a.sweep else [{}]
+    for cfg in sweeps:
+        old = L.set_config(**cfg)
+        for name in a.which.split(","):
+            ms = event_time_ms(calls[name], a.iters, s)
+            print(f"{name:12s} {ms*1e3:9.1f} us   {cfg if cfg else ''}", flush=True)
+        L.set_config(**old)
 
 
 if __name__ == "__main__":
