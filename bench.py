@@ -442,6 +442,22 @@ def am_encoders_record(args, dev, steps=10, warm=2):
     step2()
     rec["ms_per_step_given_features"], _ = timed(step2, steps)
     rec["encoder_share"] = max(0.0, 1.0 - rec["ms_per_step_given_features"] / rec["ms_per_step"])
+    # what the two frozen stand-in backbones cost by themselves (torch modules: MIOpen / hipBLASLt launches, not this
+    # package's kernels — the small-image convolution goes through MIOpen's im2col + GEMM per image group, ~10 k launches
+    # a step): forward only, they take no gradient (imagecnn.py:17-19, transformer.py:16-18)
+    try:
+        cnn = next(c[1][0] for c in emb_cfg if c[0] == "blob.image")
+        lm = next(c[1][0] for c in emb_cfg if c[0] == "xsd.string")
+        p_dev = next(cnn.parameters()).device
+        img = torch.rand((n_img, 3, 16, 16), device=p_dev)
+        ids = torch.randint(1, 1000, (n_str, 16), device=next(lm.parameters()).device)
+        with torch.no_grad():
+            t_cnn, _ = timed(lambda: cnn.features(img), 3)
+            t_lm, _ = timed(lambda: lm(ids), 3)
+        rec["ms_standin_backbones"] = {"image_cnn_features": t_cnn, "language_model": t_lm}
+        rec["ms_per_step_less_backbones"] = rec["ms_per_step"] - t_cnn - t_lm
+    except Exception as e:  # noqa: BLE001  (informational)
+        rec["ms_standin_backbones"] = {"error": str(e)[:160]}
     return rec
 
 

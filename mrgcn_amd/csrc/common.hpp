@@ -110,6 +110,7 @@ template <typename OT> __device__ __forceinline__ float load_operand(const OT *p
 
 // MFMA relation transforms (xform_mfma.hip)
 bool xform_mfma_fwd_supported(int K, int F);
+bool xform_mfma_dx_supported(int F, int K);  // Z = dM . W^T: F floats in, K out
 bool xform_mfma_dw_supported(int K, int F);
 bool xform_mfma_dw_live_supported(int K, int F);
 // `o`: the relation-major order to walk; rin_idx / rout_idx (nullable) must belong to the same order
@@ -160,6 +161,8 @@ hipError_t fill_async(void *dst, int byte_value, size_t bytes, hipStream_t s);
 // the product scratch of `p` for work submitted on stream `s` (see mrgcn_plan::stream_scratch); the first product of a
 // second, third ... stream allocates that stream's set and must therefore not run inside a stream capture
 int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t **ticket);
+// the literal column of every entry of the COMPACT view (mrgcn_plan::mlcol), built by the first call outside a capture
+bool plan_literal_cols(const mrgcn_plan *p, hipStream_t s);
 }  // namespace mrgcn
 
 struct mrgcn_plan {
@@ -255,6 +258,9 @@ struct mrgcn_plan {
   struct StreamScratch { hipStream_t stream; float *partials; int32_t *ticket; };
   mutable std::vector<StreamScratch> stream_scratch;
   mutable std::mutex scratch_mu;
+  // LITERAL products of narrow layers on the COMPACT view's row classes: the literal column r*N + j of every entry in
+  // the compact view's entry order (built by the first such product outside a capture; plan.hip: plan_literal_cols)
+  mutable int32_t *mlcol = nullptr;  // [nnz]
   int64_t partials_floats = 0;
 
   mrgcn::SparseView view(int which) const {

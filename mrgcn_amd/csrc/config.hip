@@ -46,7 +46,8 @@ const Entry kEntries[CFG_COUNT] = {
     {"sup_mix_tb", "MRGCN_SUP_MIX_TB", 512, "mix backward on a support: block size (512 or 1024)"},
     {"sup_mix_nb", "MRGCN_SUP_MIX_NB", 2, "mix backward on a support: nodes in flight per wave"},
     {"wide_bwd", "MRGCN_WIDE_BWD", 1, "wide featureless layer: backward straight from dY"},
-    {"xform_cols_lds", "MRGCN_XFORM_COLS_LDS", 1, "narrow transform with every relation's weights in LDS, output order"}
+    {"xform_cols_lds", "MRGCN_XFORM_COLS_LDS", 1, "narrow transform with every relation's weights in LDS, output order"},
+    {"spmm_literal_v3", "MRGCN_SPMM_LITERAL_V3", 1, "LITERAL products of narrow layers on the compact view's row classes (k_spmm3 with literal columns)"}
 };
 std::atomic<int64_t> g_values[CFG_COUNT];
 std::once_flag g_once;

@@ -44,6 +44,7 @@ enum CfgKey : int {
   CFG_SUP_MIX_NB,
   CFG_WIDE_BWD,
   CFG_XFORM_COLS_LDS,
+  CFG_SPMM_LITERAL_V3,
   CFG_COUNT
 };
 int64_t cfg(CfgKey k);

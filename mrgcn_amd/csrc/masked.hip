@@ -94,7 +94,7 @@ int mrgcn_support_literal_rows_f32(const mrgcn_support_t *q, int32_t scatter, fl
 
 int32_t mrgcn_support_rel_transform_supported(const mrgcn_support_t *q, int32_t K, int32_t F, int32_t need_dX) {
   return (q && q->has_forward && xform_mfma_fwd_supported(K, F) && xform_mfma_dw_supported(K, F) &&
-          (!need_dX || xform_mfma_fwd_supported(F, K))) ? 1 : 0;
+          (!need_dX || xform_mfma_dx_supported(F, K))) ? 1 : 0;
 }
 
 int mrgcn_support_rel_transform_fwd_f32(const mrgcn_support_t *q, const float *X, int64_t ldX, int32_t x_by_node,

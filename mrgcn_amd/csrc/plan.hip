@@ -1106,7 +1106,7 @@ void release_plan(mrgcn_plan *q, uint64_t ep) {
                   q->rep_src, q->rep_dst, q->partials, q->r3_multi, q->r3_ticket,
                   q->r3s_long_row, q->r3s_long_cptr, q->r3s_chunk_beg, q->r3s_chunk_end, q->r3s_chunk_row,
                   q->n_rperm, q->n_relptr, q->n_rnode, q->n_rmpos, q->n_relchunk_rel, q->n_relchunk_beg,
-                  q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids, q->op_node, q->op_rel};
+                  q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids, q->op_node, q->op_rel, q->mlcol};
   // (after the wait any stream may take the blocks; the plan's own build stream is where the next build of a
   // similar slice will ask for them again: the pool hands them back without a driver call)
   for (void *a : ptrs) pool_free(a, q->build_stream, ep);
@@ -1239,6 +1239,37 @@ hipError_t fill_async(void *dst, int byte_value, size_t bytes, hipStream_t s) {
   const size_t n = words > 4 ? words : 4;
   k_fill_bytes<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>((uint8_t *)dst, b * 0x01010101u, head, words, tail);
   return hipGetLastError();
+}
+
+namespace {
+// mlcol[e] = literal column of entry e of the COMPACT view: (relation, node) of the operand row it reads
+__global__ void k_literal_cols(const int32_t *__restrict__ mcol, const int32_t *__restrict__ op_node,
+                               const int32_t *__restrict__ op_rel, int64_t nnz, int64_t N,
+                               int32_t *__restrict__ mlcol) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz) return;
+  const int32_t pos = mcol[e];
+  mlcol[e] = (int32_t)((int64_t)op_rel[pos] * N + op_node[pos]);
+}
+}  // namespace
+
+// p->mlcol (common.hpp), built by the first caller outside a capture; false: not available for this call
+bool plan_literal_cols(const mrgcn_plan *p, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(p->scratch_mu);
+  if (p->mlcol) return true;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+  int32_t *a = nullptr;
+  if (pool_alloc((void **)&a, (size_t)p->nnz * sizeof(int32_t), s) != hipSuccess) return false;
+  k_literal_cols<<<dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s>>>(p->mcol, p->op_node, p->op_rel, p->nnz,
+                                                                             p->num_nodes, a);
+  // (products on other streams may read it next: one wait, once per plan)
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    pool_free(a, s);
+    return false;
+  }
+  p->mlcol = a;
+  return true;
 }
 
 int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t **ticket) {

@@ -2114,7 +2114,7 @@ int mrgcn_rel_transform_bwd_masked_f32(const mrgcn_plan_t *p, float *dM, int64_t
     const bool dw_live = !dW || (use_mfma() && xform_mfma_dw_live_supported(K, F));
     const int64_t ldZ_ = ((int64_t)K + 3) / 4 * 4;
     const bool dx_live = !dX || (use_mfma() && workspace && workspace_floats >= p->ncols * ldZ_ &&
-                                 xform_mfma_fwd_supported(F, K));
+                                 xform_mfma_dx_supported(F, K));
     if (!(dw_live && dx_live)) {
       int rc = zero_dead_rows(dM, ldM, F, col_live, p->ncols, s);
       if (rc != MRGCN_OK) return rc;
@@ -2137,7 +2137,7 @@ int mrgcn_rel_transform_bwd_masked_f32(const mrgcn_plan_t *p, float *dM, int64_t
     }
   }
   const int64_t ldZ = ((int64_t)K + 3) / 4 * 4;
-  if (dX && use_mfma() && workspace && workspace_floats >= p->ncols * ldZ && xform_mfma_fwd_supported(F, K)) {
+  if (dX && use_mfma() && workspace && workspace_floats >= p->ncols * ldZ && xform_mfma_dx_supported(F, K)) {
     // Z[c, 0:K] = dM[c, 0:F] . W[r_c]^T on the matrix cores, then dX[j] = sum of node j's Z rows
     MRGCN_REQUIRE(lddX >= K, "lddX");
     // (rows of dM and of Z in plain compact order; the walk follows the order of the narrower of the two)

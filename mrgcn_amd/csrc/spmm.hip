@@ -1235,6 +1235,24 @@ View3 view3_of(const mrgcn_plan *p) {
   return w;
 }
 
+// The LITERAL product of a narrow layer (the reference's own operand layout, `(R N) x out`: graph.py:75 /:95) on the
+// COMPACT view's machinery: the same class-major rows, split-row descriptors and k_spmm3 — only the entry -> operand
+// row array differs (literal columns instead of compact operand rows).  AM shape, F = 10 / 11: 335 / 415 us with the
+// general kernel -> 307 / 315 us; every touched operand row is still its own random 64-byte access to a 17.8 GB table
+// (F = 16, rows that ARE one aligned 64-byte piece: 265 us), which is what bounds this view.
+// Returns true and fills v / w3 when the route applies; the index array is built by the first call (not inside a
+// capture: that call takes the general kernel).
+bool literal_on_compact(const mrgcn_plan *p, int F, const int32_t *out_index, hipStream_t s, SparseView *v, View3 *w3) {
+  if (!cfg(CFG_SPMM_LITERAL_V3) || F > 16 || p->lean || out_index || !p->op_node || p->n_rep > 0 || p->nnz == 0)
+    return false;
+  if (!plan_literal_cols(p, s)) return false;
+  *v = p->view(MRGCN_VIEW_COMPACT);
+  v->idx = p->mlcol;
+  *w3 = view3_of(p);
+  w3->op_rows = p->num_relations * p->num_nodes;
+  return true;
+}
+
 }  // namespace
 
 // Y = v . D for any CSR-shaped view (the filtered transposed view of a gradient support): mrgcn_spmm_f32's tiling
@@ -1436,7 +1454,10 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
   MRGCN_REQUIRE(F > 0 && ldD >= F && ldY >= F, "F / leading dimensions");
   MRGCN_REQUIRE(D && Y, "NULL operand");
   SparseView v = plan->view(view);
-  if (view == MRGCN_VIEW_COMPACT) {  // its rows are class-major ranks: results go to row rowmap[rank]
+  hipStream_t s = (hipStream_t)stream;
+  View3 lit3;
+  const bool lit = view == MRGCN_VIEW_LITERAL && literal_on_compact(plan, F, out_index, s, &v, &lit3);
+  if (view == MRGCN_VIEW_COMPACT || lit) {  // its rows are class-major ranks: results go to row rowmap[rank]
     MRGCN_REQUIRE(out_index == nullptr, "out_index is not available on the COMPACT view");
     out_index = plan->rowmap;
   }
@@ -1444,7 +1465,6 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
   const int pad_ok = (relu & MRGCN_SPMM_PAD_WRITABLE) != 0;
   const int fold = (relu & MRGCN_SPMM_TWO_PASS) == 0 && spmm3_fold_default();
   relu &= MRGCN_SPMM_RELU;
-  hipStream_t s = (hipStream_t)stream;
   float *partials;
   int32_t *ticket;
   {
@@ -1467,15 +1487,15 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
                                  : view == MRGCN_VIEW_COMPACT ? plan->n_op : plan->num_rows;
     // (the compact operand is read front to back by the rows that own its single-use columns: a 16-byte load
     // that straddles two lines there fetches lines its neighbours need anyway)
-    const bool operand_cached = operand_rows * ldD * 4 <= (int64_t)200 << 20 || view == MRGCN_VIEW_COMPACT;
+    const bool operand_cached = operand_rows * ldD * 4 <= (int64_t)200 << 20 || view == MRGCN_VIEW_COMPACT || lit;
     // the COMPACT view of a narrow layer takes k_spmm3
-    View3 w3 = view3_of(plan);
+    View3 w3 = lit ? lit3 : view3_of(plan);
     w3.pad_ok = pad_ok;
     w3.fold = fold;
     w3.ticket = ticket;
     int rc = dispatch(v, D + f, ldD, ldD - f, w, Y + f, ldY, bias ? bias + f : nullptr, relu,
                       out_index, partials, use_tiny, operand_cached, s,
-                      (view == MRGCN_VIEW_COMPACT && F <= 16 && !plan->lean) ? &w3 : nullptr);
+                      ((view == MRGCN_VIEW_COMPACT || lit) && F <= 16 && !plan->lean) ? &w3 : nullptr);
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;

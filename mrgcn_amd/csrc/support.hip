@@ -477,7 +477,7 @@ int64_t mrgcn_support_rel_transform_bwd_workspace(const mrgcn_support_t *q, int3
   if (!q) return -1;
   if (!xform_use_mfma()) return -1;
   if (need_dW && !xform_mfma_dw_supported(K, F)) return -1;
-  if (need_dX && !(xform_mfma_fwd_supported(F, K))) return -1;
+  if (need_dX && !(xform_mfma_dx_supported(F, K))) return -1;
   const int64_t a = need_dX ? q->L * (((int64_t)K + 3) / 4 * 4) : 0;
   const int64_t b = need_dW ? (int64_t)q->order_for(K).n_relchunks * K * F : 0;
   const int64_t m = a > b ? a : b;

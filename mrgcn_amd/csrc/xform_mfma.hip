@@ -14,6 +14,7 @@
 // D: col = l&15, row = 4*(l>>4) + reg.  The k slot <-> actual k assignment is free as long as A
 // and B agree: slot kq of the s-th MFMA of a 16-wide K step stands for k = k0 + 4*kq + s, so a
 // lane feeds four MFMAs from ONE 16-byte load of its gathered row.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -104,6 +105,8 @@ __device__ __forceinline__ int compact_live_columns(int32_t beg, int32_t end, co
 // forward: Out[o(c), 0:ldOut] = [ In[i(c), 0:K] . Wm[r][0:K][0:F] | 0 ]   (write only)
 //   TRANS_W = false: Wm[r][k][n] = W[(r*K + k)*F + n]        (weights stored [R][K][F])
 //   TRANS_W = true : Wm[r][k][n] = W[(r*F + n)*K + k]        (weights stored [R][F][K])
+//   (a launch may take a SLICE of the output columns: W and Out arrive offset to the slice's first column, `rstride`
+//   stays the distance between two relations' weights, `n_store` the columns the slice may write)
 //   rin_idx / rout_idx: nullable int32 [ncols] in RELATION-MAJOR order (aligned with rperm):
 //   input / output row of each column; null = the compact id rperm[e] itself
 // ---------------------------------------------------------------------------------------------
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
     const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
     const int32_t *__restrict__ rin_idx, const int32_t *__restrict__ rout_idx,
     const float *__restrict__ In, int64_t ldIn, int K, const float *__restrict__ W, int F,
-    OT *__restrict__ Out, int64_t ldOut, const uint8_t *__restrict__ col_live) {
+    OT *__restrict__ Out, int64_t ldOut, const uint8_t *__restrict__ col_live,
+    int64_t rstride /* floats between two relations' weights */, int n_store /* columns of Out this launch writes */) {
   extern __shared__ float WsT[];  // [NT*16][KP]: n-major, k contiguous, zero padded
   const int ksteps = (K + 15) >> 4;
   const int KP = ksteps * 16 + 4;  // +4 floats: rows start on different banks
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
     const int n = t / KP, k = t - n * KP;
     float w = 0.f;
     if (n < F && k < K)
-      w = TRANS_W ? W[((int64_t)r * F + n) * K + k] : W[((int64_t)r * K + k) * F + n];
+      w = TRANS_W ? W[(int64_t)r * rstride + (int64_t)n * K + k] : W[(int64_t)r * rstride + (int64_t)k * F + n];
     WsT[t] = w;
   }
   __syncthreads();
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int n = nt * 16 + m;
-        if (n < ldOut) store_operand<OT>(Out + orow * ldOut + n, acc[nt][reg]);  // zeros past F: whole padded row
+        if (n < n_store) store_operand<OT>(Out + orow * ldOut + n, acc[nt][reg]);  // zeros past F: whole padded row
       }
     }
   }
@@ -691,6 +695,8 @@ int xform_cols_lds(const mrgcn_plan *p, bool operand_order, const float *In, int
 
 // ---- launchers used by the C ABI entry points in rgcn_fused.hip -------------------------------
 bool xform_mfma_fwd_supported(int K, int F) { return K <= kMaxKSteps * 16 && F <= kMaxNT * 16; }
+// the dX pass Z = dM . W^T: F floats in, K out (sliced by 64 columns)
+bool xform_mfma_dx_supported(int F, int K) { return F <= kMaxKSteps * 16 && K <= 256; }
 bool xform_mfma_dw_supported(int K, int F) { return K <= kMaxTQ * 64 && F <= 16 && (size_t)4 * K * F * 4 <= 64 * 1024; }
 // ... and with room in LDS for the list of live columns
 bool xform_mfma_dw_live_supported(int K, int F) {
@@ -698,11 +704,14 @@ bool xform_mfma_dw_live_supported(int K, int F) {
 }
 
 
-int xform_mfma_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const int32_t *rout_idx,
-                   const float *In, int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out,
-                   int64_t ldOut, hipStream_t s, bool out_bf16, const uint8_t *col_live) {
+// one launch: output columns [0, F) of a slice whose weights start at W (relations `rstride` floats apart) and whose
+// rows start at Out; `n_store` columns of a row may be written (zeros past F)
+static int xform_mfma_fwd_one(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const int32_t *rout_idx,
+                              const float *In, int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out,
+                              int64_t ldOut, hipStream_t s, bool out_bf16, const uint8_t *col_live, int64_t rstride,
+                              int n_store) {
   if (o.n_relchunks == 0) return MRGCN_OK;
-  int NT = (int)((ldOut < 64 ? ldOut : 64) + 15) / 16;  // tiles that cover the padded row
+  int NT = (n_store + 15) / 16;  // tiles that cover the columns to write
   if (NT < (F + 15) / 16) NT = (F + 15) / 16;
   const int ksteps = (K + 15) / 16;
   size_t lds = (size_t)NT * 16 * (ksteps * 16 + 4) * sizeof(float);
@@ -717,11 +726,11 @@ int xform_mfma_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_id
     if (ksteps <= 1)                                                                                       \
       k_xform_mfma_fwd<N_, true, 1, float, true><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(             \
           o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, nullptr, nullptr, In, ldIn, K, W,   \
-          F, (float *)Out, ldOut, col_live);                                                               \
+          F, (float *)Out, ldOut, col_live, rstride, n_store);                                             \
     else                                                                                                   \
       k_xform_mfma_fwd<N_, true, 4, float, true><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(             \
           o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, nullptr, nullptr, In, ldIn, K, W,   \
-          F, (float *)Out, ldOut, col_live);                                                               \
+          F, (float *)Out, ldOut, col_live, rstride, n_store);                                             \
   } while (0)
     switch (NT) { case 1: XF_LIVE(1); break; case 2: XF_LIVE(2); break;
                   case 3: XF_LIVE(3); break; default: XF_LIVE(4); break; }
@@ -734,15 +743,15 @@ int xform_mfma_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_id
     if (ksteps <= 1)                                                                                    \
       k_xform_mfma_fwd<N_, T_, 1, O_><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                     \
           o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn,     \
-          K, W, F, (O_ *)Out, ldOut, nullptr);                                                          \
+          K, W, F, (O_ *)Out, ldOut, nullptr, rstride, n_store);                                        \
     else if (ksteps <= 4)                                                                               \
       k_xform_mfma_fwd<N_, T_, 4, O_><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                     \
           o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn,     \
-          K, W, F, (O_ *)Out, ldOut, nullptr);                                                          \
+          K, W, F, (O_ *)Out, ldOut, nullptr, rstride, n_store);                                        \
     else                                                                                                \
       k_xform_mfma_fwd<N_, T_, kMaxKSteps, O_><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(            \
           o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn,     \
-          K, W, F, (O_ *)Out, ldOut, nullptr);                                                          \
+          K, W, F, (O_ *)Out, ldOut, nullptr, rstride, n_store);                                        \
   } while (0)
 #define XF_GO(N_, T_)                                                  \
   do {                                                                 \
@@ -759,6 +768,31 @@ int xform_mfma_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_id
 #undef XF_GO
 #undef XF_GO3
   MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int xform_mfma_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const int32_t *rout_idx,
+                   const float *In, int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out,
+                   int64_t ldOut, hipStream_t s, bool out_bf16, const uint8_t *col_live) {
+  const int64_t rstride = (int64_t)K * F;
+  // columns a row may receive: zeros past F up to the end of the padded row (at most the launch's 64 / the last tile)
+  const int width = (int)std::min<int64_t>(ldOut, F <= kMaxNT * 16 ? kMaxNT * 16 : (F + 15) / 16 * 16);
+  if (F <= kMaxNT * 16)
+    return xform_mfma_fwd_one(p, o, rin_idx, rout_idx, In, ldIn, K, W, trans_w, F, Out, ldOut, s, out_bf16, col_live,
+                              rstride, std::min(width, kMaxNT * 16));
+  // wide outputs (the dX pass of a wide layer: Z[c, 0:K_x] = dM[c] . W[r_c]^T with K_x up to 256): slices of 64
+  // columns, one launch each — the input rows are 40 bytes, every slice reads them again
+  if (!trans_w || out_bf16) {
+    set_error("xform_mfma_fwd: more than 64 output columns only with transposed weights (the dX pass)");
+    return MRGCN_ERR_UNSUPPORTED;
+  }
+  for (int n0 = 0; n0 < F; n0 += kMaxNT * 16) {
+    const int nw = std::min(kMaxNT * 16, F - n0);
+    const int rc = xform_mfma_fwd_one(p, o, rin_idx, rout_idx, In, ldIn, K, W + (int64_t)n0 * K, true, nw,
+                                      (float *)Out + n0, ldOut, s, false, col_live, rstride,
+                                      std::min(width - n0, kMaxNT * 16));
+    if (rc != MRGCN_OK) return rc;
+  }
   return MRGCN_OK;
 }
 

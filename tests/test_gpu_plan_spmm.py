@@ -301,7 +301,8 @@ def test_transposed_product_with_zero_operand_rows(skewed, F, zero_frac):
 
 
 @pytest.mark.parametrize("K,F,need_dX", [(7, 10, True), (155, 10, False), (10, 11, True), (40, 33, True),
-                                         (200, 16, True)])
+                                         (200, 16, True), (155, 10, True), (256, 10, True), (65, 3, True),
+                                         (129, 11, True)])
 @pytest.mark.parametrize("live_frac", [0.0, 0.08, 1.0])
 def test_transform_backward_over_live_columns(skewed, K, F, need_dX, live_frac):
     """mrgcn_rel_transform_bwd_live_f32 == mrgcn_rel_transform_bwd_f32 when the rows of dM that
@@ -334,6 +335,18 @@ def test_transform_backward_over_live_columns(skewed, K, F, need_dX, live_frac):
                                                      dW.data_ptr(), ws.data_ptr(), nws, s))
         outs.append((dX.cpu().numpy(), dW.cpu().numpy()))
     (dX0, dW0), (dX1, dW1) = outs
+    # float64 restatement (autograd of graph.py:93-94): dX[j] = sum_c dM[c] W[r_c]^T, dW[r] = sum_c X[j_c]^T dM[c] —
+    # wide inputs take the dX pass in slices of 64 output columns on the matrix cores
+    ul = ref["ulcol"]
+    rel, node = ul // N, ul % N
+    dM64, W64, X64 = dM[:, :F].astype(np.float64), W.cpu().numpy().astype(np.float64), X.cpu().numpy().astype(np.float64)
+    dW_want = np.zeros((R, K, F))
+    np.add.at(dW_want, rel, X64[node][:, :, None] * dM64[:, None, :])
+    np.testing.assert_allclose(dW0, dW_want, rtol=1e-4, atol=1e-4 * (np.abs(dW_want).max() + 1e-30))
+    if need_dX:
+        dX_want = np.zeros((N, K))
+        np.add.at(dX_want, node, np.einsum("cf,ckf->ck", dM64, W64[rel]))
+        np.testing.assert_allclose(dX0, dX_want, rtol=1e-4, atol=1e-4 * (np.abs(dX_want).max() + 1e-30))
     np.testing.assert_allclose(dW1, dW0, rtol=1e-5, atol=1e-5 * (np.abs(dW0).max() + 1e-30))
     if need_dX:
         np.testing.assert_allclose(dX1, dX0, rtol=1e-5, atol=1e-5 * (np.abs(dX0).max() + 1e-30))
@@ -643,3 +656,44 @@ def test_the_general_product_finishes_split_rows_in_kernel_like_the_two_pass_for
         torch.cuda.synchronize()
         for it, y in enumerate(outs):
             assert torch.equal(y, want[it % 2]), f"view {view} launch {it}"
+
+
+@pytest.mark.parametrize("F", [1, 3, 4, 7, 8, 10, 11, 12, 16])
+def test_literal_product_on_the_compact_views_row_classes(skewed, F):
+    """LITERAL products of narrow layers run k_spmm3 on the compact view's class-major rows with literal columns
+    (`spmm_literal_v3`; the index array is built by the first such call): equal to scipy and, to rounding, to the
+    general kernel; bias / ReLU epilogue, padded and packed operand rows, a captured call included."""
+    from mrgcn_amd import _lib as L
+    plan, A, ref, rng = skewed
+    RN = A.shape[1]
+    D = rng.standard_normal((RN, F)).astype(np.float32)
+    b = rng.standard_normal(F).astype(np.float32)
+    want = np.maximum(A @ D.astype(np.float64) + b, 0)
+    for ld in sorted({F, (F + 3) // 4 * 4}):
+        Dg = torch.zeros((RN, ld), device="cuda")
+        Dg[:, :F] = torch.from_numpy(D).cuda()
+        got = {}
+        for on in (0, 1):
+            old = L.set_config(spmm_literal_v3=on)
+            try:
+                got[on] = plan.spmm(L.VIEW_LITERAL, Dg, F=F, bias=torch.from_numpy(b).cuda(), relu=True)
+                assert torch.equal(got[on], plan.spmm(L.VIEW_LITERAL, Dg, F=F, bias=torch.from_numpy(b).cuda(), relu=True))
+            finally:
+                L.set_config(**old)
+        for on in (0, 1):
+            np.testing.assert_allclose(got[on].cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got[1].cpu().numpy(), got[0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # inside a capture (the index array exists by now)
+    Dg = torch.from_numpy(D).cuda()
+    out = torch.empty((A.shape[0], F), device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.spmm(L.VIEW_LITERAL, Dg, out=out)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            plan.spmm(L.VIEW_LITERAL, Dg, out=out)
+        out.zero_()
+        g.replay()
+    side.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), A @ D.astype(np.float64), rtol=1e-4, atol=1e-4)
