@@ -513,6 +513,13 @@ int mrgcn_relu_bwd_f32(const float *dY, const float *Y, int64_t n, float *out, v
  * columns in rising order, perm = their compact ids, src = the compact gradient rows. */
 int mrgcn_scatter_rows_zero_fill_f32(const int32_t *sorted_rows, const int32_t *perm, int64_t n_touched,
                                      const float *src, int64_t ldS, int32_t F, float *dst, int64_t n_rows, void *stream);
+/* out[0:F] = the column sums of X[M, F] (row stride ld) over the rows with row_flags[m] != 0 (NULL: every row; rows
+ * flagged 0 are not read — they may be unwritten).  The bias gradient `dY.sum(0)` of a narrow layer (autograd of
+ * `AFW + self.b`, graph.py:98-101) in one pass, summed in a fixed order.  F <= 16; workspace of
+ * mrgcn_colsum_rows_workspace(F) floats (-1: F outside the kernel's range). */
+int64_t mrgcn_colsum_rows_workspace(int32_t F);
+int mrgcn_colsum_rows_f32(const float *X, int64_t ld, int64_t M, int32_t F, const uint8_t *row_flags, float *out,
+                          float *workspace, int64_t workspace_floats, void *stream);
 /* Streaming yardsticks for measurement (bench.py: extra.device_copy_gbps_hip, extra.triad_gbps): dst = src as a plain
  * float4 copy, and a 3-read / 3-write elementwise pass with Adam's arithmetic (the memory shape of a dense optimizer
  * step).  n % 4 == 0, 16-byte aligned.  Nothing in the package calls them. */

@@ -106,6 +106,8 @@ SIGNATURES = {
     "mrgcn_rel_transform_bwd_masked_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p,
                                                      _i64, _i32, _p, _p, _p]),
     "mrgcn_spmm_transposed_live_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _p, _p, _p, _i32, _p]),
+    "mrgcn_colsum_rows_workspace": (_i64, [_i32]),
+    "mrgcn_colsum_rows_f32": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),
     "mrgcn_scatter_rows_zero_fill_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i64, _p]),
     "mrgcn_probe_copy_f32": (C.c_int, [_p, _p, _i64, _p]),
     "mrgcn_probe_triad_f32": (C.c_int, [_p, _p, _p, _i64, _p]),

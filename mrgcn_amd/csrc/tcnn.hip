@@ -227,6 +227,165 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx(const float *__restrict__ x, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// SHORT sequences (T <= 32: rows of under 128 bytes — the S-size TCNN runs at T = 20, 10, 5, 1).  The kernels above
+// give a block ONE channel: a wave then reads T floats per batch row, C T floats apart — 80-byte, 40-byte, 20-byte,
+// 4-byte pieces of different cache lines (the seven BatchNorm blocks of TCNN-S on 20 000 literals: 5.2 ms for
+// passes over 100 MB arrays, 0.3 TB/s).  Here a block takes a slab of batch rows over ALL channels: thread t owns the
+// positions p = t, t + 256, ... of a batch row's C T floats (a fixed channel each) and walks the slab's rows — every
+// load instruction reads 1 KB of consecutive floats.  Per-channel sums meet in LDS (fp64), one global atomic per
+// channel and block.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFlatUnroll = 4;
+
+__global__ __launch_bounds__(256) void k_bn_stats_flat(const float *__restrict__ x, int B, int C, int T, int rows_per,
+                                                       double *__restrict__ acc) {
+  extern __shared__ double s_acc[];  // [C][2]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) s_acc[i] = 0.0;
+  __syncthreads();
+  const int CT = C * T;
+  const int b0 = blockIdx.x * rows_per, b1 = min(B, b0 + rows_per);
+  for (int p = threadIdx.x; p < CT; p += 256) {
+    const int c = p / T;
+    const float *col = x + (int64_t)b0 * CT + p;
+    double a = 0.0, q = 0.0;
+    int b = b0;
+    for (; b + kFlatUnroll <= b1; b += kFlatUnroll) {
+      float v[kFlatUnroll];
+#pragma unroll
+      for (int u = 0; u < kFlatUnroll; ++u) v[u] = col[(int64_t)(b - b0 + u) * CT];
+#pragma unroll
+      for (int u = 0; u < kFlatUnroll; ++u) { a += (double)v[u]; q += (double)v[u] * (double)v[u]; }
+    }
+    for (; b < b1; ++b) { const double v = col[(int64_t)(b - b0) * CT]; a += v; q += v * v; }
+    atomicAdd(&s_acc[2 * c], a);
+    atomicAdd(&s_acc[2 * c + 1], q);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256)
+    if (s_acc[i] != 0.0) atomicAdd(&acc[i], s_acc[i]);
+}
+
+__global__ __launch_bounds__(256) void k_bn_relu_pool_fwd_flat(const float *__restrict__ x, int B, int C, int T, int Tout,
+                                                               int rows_per, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta,
+                                                               const float *__restrict__ mean,
+                                                               const float *__restrict__ var, float eps, int kind, int arg,
+                                                               float *__restrict__ y, int32_t *__restrict__ argmax) {
+  const int CT = C * T, CTo = C * Tout;
+  const int b0 = blockIdx.x * rows_per, b1 = min(B, b0 + rows_per);
+  for (int po = threadIdx.x; po < CTo; po += 256) {  // output position (c, to) of a batch row
+    const int c = po / Tout, to = po - c * Tout;
+    const float mu = mean[c], sc = (gamma ? gamma[c] : 1.f) / sqrtf(var[c] + eps), sh = beta ? beta[c] : 0.f;
+    int t0, t1;
+    pool_window(kind, arg, T, to, t0, t1);
+    for (int b = b0; b < b1; ++b) {
+      const float *row = x + (int64_t)b * CT + c * T;
+      float best = -1.f;
+      int bi = t0;
+      for (int t = t0; t < t1; ++t) {
+        const float z = fmaxf((row[t] - mu) * sc + sh, 0.f);
+        if (z > best) {  // first maximum wins (ATen's order)
+          best = z;
+          bi = t;
+        }
+      }
+      const int64_t o = (int64_t)b * CTo + po;
+      y[o] = best;
+      if (argmax) argmax[o] = bi;
+    }
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce_flat(const float *__restrict__ x, const float *__restrict__ dz,
+                                                            const float *__restrict__ y, const float *__restrict__ dy,
+                                                            const int32_t *__restrict__ argmax, int B, int C, int T,
+                                                            int Tout, uint32_t arg_magic, int rows_per,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ var, float eps,
+                                                            double *__restrict__ acc) {
+  extern __shared__ double s_acc[];  // [C][2]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) s_acc[i] = 0.0;
+  __syncthreads();
+  const int CT = C * T;
+  const int b0 = blockIdx.x * rows_per, b1 = min(B, b0 + rows_per);
+  for (int p = threadIdx.x; p < CT; p += 256) {
+    const int c = p / T, t = p - c * T;
+    const double m = mean[c], istd = 1.0 / sqrt((double)var[c] + (double)eps);
+    double a = 0.0, q = 0.0;
+    for (int b = b0; b < b1; ++b) {
+      const int64_t bc = (int64_t)b * C + c;
+      const double gg = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg_magic);
+      a += gg;
+      q += gg * ((double)x[bc * T + t] - m) * istd;
+    }
+    atomicAdd(&s_acc[2 * c], a);
+    atomicAdd(&s_acc[2 * c + 1], q);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256)
+    if (s_acc[i] != 0.0) atomicAdd(&acc[i], s_acc[i]);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_bn_bwd_dx_flat(const float *__restrict__ x, const float *__restrict__ dz,
+                                                        const float *__restrict__ y, const float *__restrict__ dy,
+                                                        const int32_t *__restrict__ argmax, int B, int C, int T, int Tout,
+                                                        uint32_t arg_magic, int rows_per, const float *__restrict__ gamma,
+                                                        const float *__restrict__ mean, const float *__restrict__ var,
+                                                        float eps, const float *__restrict__ dgamma,
+                                                        const float *__restrict__ dbeta, int training,
+                                                        float *__restrict__ dx, float *__restrict__ chan_sum) {
+  extern __shared__ double s_acc[];  // [C]
+  if (chan_sum) {
+    for (int i = threadIdx.x; i < C; i += 256) s_acc[i] = 0.0;
+    __syncthreads();
+  }
+  const int CT = C * T;
+  const int b0 = blockIdx.x * rows_per, b1 = min(B, b0 + rows_per);
+  const float inv_n = 1.f / (float)((int64_t)B * T);
+  for (int p = threadIdx.x; p < CT; p += 256) {
+    const int c = p / T, t = p - c * T;
+    const float istd = 1.f / sqrtf(var[c] + eps);
+    const float g = (gamma ? gamma[c] : 1.f) * istd;
+    const float mu = mean[c], k_b = training ? dbeta[c] * inv_n : 0.f, k_g = training ? dgamma[c] * inv_n : 0.f;
+    double rsum = 0.0;
+    for (int b = b0; b < b1; ++b) {
+      const int64_t bc = (int64_t)b * C + c, e = bc * T + t;
+      float v = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg_magic);
+      if (training) v = v - k_b - (x[e] - mu) * istd * k_g;
+      v *= g;
+      dx[e] = v;
+      rsum += (double)v;
+    }
+    if (chan_sum) atomicAdd(&s_acc[c], rsum);
+  }
+  if (chan_sum) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256)
+      if (s_acc[i] != 0.0) atomicAdd(&chan_sum[i], (float)s_acc[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chan_sum_flat(const float *__restrict__ x, int B, int C, int T, int rows_per,
+                                                       float *__restrict__ out) {
+  extern __shared__ double s_acc[];  // [C]
+  for (int i = threadIdx.x; i < C; i += 256) s_acc[i] = 0.0;
+  __syncthreads();
+  const int CT = C * T;
+  const int b0 = blockIdx.x * rows_per, b1 = min(B, b0 + rows_per);
+  for (int p = threadIdx.x; p < CT; p += 256) {
+    const float *col = x + (int64_t)b0 * CT + p;
+    double a = 0.0;
+    for (int b = b0; b < b1; ++b) a += (double)col[(int64_t)(b - b0) * CT];
+    atomicAdd(&s_acc[p / T], a);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256)
+    if (s_acc[i] != 0.0) atomicAdd(&out[i], (float)s_acc[i]);
+}
+
 // out[c] += sum over (b, t) of x[b][c][t] (out zeroed by the launcher): the bias gradient of a Conv1d.  Block (c, y)
 // sums its batch slab in fp64, one float atomic per block
 __global__ __launch_bounds__(256) void k_chan_sum_part(const float *__restrict__ x, int B, int C, int T, int tp_log2,
@@ -276,6 +435,10 @@ static inline int tp_log2_of(int T) {  // log2 of the power of two >= min(T, 64)
   return l;
 }
 
+// the short-sequence kernels (k_*_flat): rows of under 128 bytes, per-channel sums in LDS
+static inline bool bn_flat(int C, int T) { return T <= 32 && C <= 2048; }
+static inline int bn_flat_rows(int B) { return std::max(1, (B + 1023) / 1024); }  // batch rows per block: <= 1 024 blocks
+
 static inline unsigned bn_slabs(int B, int C) {
   int s = 2048 / (C > 0 ? C : 1);
   if (s < 1) s = 1;
@@ -298,10 +461,18 @@ int mrgcn_bn_relu_pool_fwd_f32(const float *x, int32_t B, int32_t C, int32_t T, 
   if (training) {
     double *acc = (double *)workspace;
     MRGCN_HIP_TRY(mrgcn::fill_async(acc, 0, mrgcn_bn_workspace_bytes(C), s));
-    k_bn_stats_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, tp_log2_of(T), acc);
+    if (bn_flat(C, T)) {
+      const int rp = bn_flat_rows(B);
+      k_bn_stats_flat<<<dim3((B + rp - 1) / rp), dim3(256), (size_t)C * 2 * sizeof(double), s>>>(x, B, C, T, rp, acc);
+    } else
+      k_bn_stats_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, tp_log2_of(T), acc);
     k_bn_stats_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, (int64_t)B * T, mean, var);
   }
-  {
+  if (bn_flat(C, T)) {
+    const int rp = bn_flat_rows(B);
+    k_bn_relu_pool_fwd_flat<<<dim3((B + rp - 1) / rp), dim3(256), 0, s>>>(x, B, C, T, Tout, rp, gamma, beta, mean, var, eps,
+                                                                        pool_kind, pool_arg, y, argmax);
+  } else {
     const int tpo = tp_log2_of(Tout), rpw = 64 >> tpo;
     const unsigned slabs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(((int64_t)B + 4 * rpw - 1) / (4 * rpw),
                                                                              std::max<int64_t>(1, 8192 / C)));
@@ -326,7 +497,11 @@ int mrgcn_channel_sum_f32(const float *x, int32_t B, int32_t C, int32_t T, float
   MRGCN_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "operands");
   hipStream_t s = (hipStream_t)stream;
   MRGCN_HIP_TRY(mrgcn::fill_async(out, 0, (size_t)C * sizeof(float), s));
-  k_chan_sum_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, tp_log2_of(T), out);
+  if (bn_flat(C, T)) {
+    const int rp = bn_flat_rows(B);
+    k_chan_sum_flat<<<dim3((B + rp - 1) / rp), dim3(256), (size_t)C * sizeof(double), s>>>(x, B, C, T, rp, out);
+  } else
+    k_chan_sum_part<<<dim3(C, bn_slabs(B, C)), dim3(256), 0, s>>>(x, B, C, T, tp_log2_of(T), out);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
@@ -362,8 +537,20 @@ int mrgcn_bn_relu_pool_bwd_sum_f32(const float *x, const float *y, const float *
   const int rpw = 64 >> tp_log2;
   unsigned xslabs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(((int64_t)B + 4 * rpw - 1) / (4 * rpw), std::max<int64_t>(1, 8192 / C)));
   const dim3 xgrid(C, xslabs);
+  const bool flat = bn_flat(C, T);
+  const int frp = bn_flat_rows(B);
+  const dim3 fgrid((B + frp - 1) / frp);
 #define BN_BWD_GO(KIND_)                                                                                             \
   do {                                                                                                               \
+    if (flat) {                                                                                                      \
+      k_bn_bwd_reduce_flat<KIND_><<<fgrid, dim3(256), (size_t)C * 2 * sizeof(double), s>>>(                          \
+          x, dz, y, dy, argmax, B, C, T, Tout, arg_magic, frp, mean, var, eps, acc);                                 \
+      k_bn_bwd_reduce_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, dgamma, dbeta);                        \
+      k_bn_bwd_dx_flat<KIND_><<<fgrid, dim3(256), (size_t)C * sizeof(double), s>>>(                                  \
+          x, dz, y, dy, argmax, B, C, T, Tout, arg_magic, frp, gamma, mean, var, eps, dgamma, dbeta, training, dx,   \
+          dx_chan_sum);                                                                                              \
+      break;                                                                                                         \
+    }                                                                                                                \
     k_bn_bwd_reduce_part<KIND_><<<rgrid, dim3(256), 0, s>>>(x, dz, y, dy, argmax, B, C, T, Tout, arg_magic,         \
                                                             tp_log2, mean, var, eps, acc);                                          \
     k_bn_bwd_reduce_fin<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(acc, C, dgamma, dbeta);                          \

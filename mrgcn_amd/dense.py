@@ -275,7 +275,8 @@ class _MlpGateScatter(torch.autograd.Function):
     perceptron.py:6-46 inside).  XF is written in place and handed on."""
 
     @staticmethod
-    def forward(ctx, XF, enc, rows, gate_weights, i_gate: int, offset: int, n_layers: int, *params):
+    def forward(ctx, XF, enc, rows, gate_weights, i_gate: int, offset: int, n_layers: int, fresh: bool, *params):
+        ctx.fresh = bool(fresh)
         weights = [p.contiguous() for p in params[:n_layers]]
         biases = [(p.contiguous() if p is not None else None) for p in params[n_layers:]]
         dims = mlp_dims(weights)
@@ -317,15 +318,48 @@ class _MlpGateScatter(torch.autograd.Function):
         # kernel argument: indexed assignment of a Python scalar stages it through a host copy, which a stream
         # capture refuses)
         dXF_in = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.fresh:
+            # the block held constants before this op (a fresh zero buffer filled block by block): whoever made XF's
+            # other blocks reads only those — the gradient goes on as it is, no copy of the whole matrix per encoder
+            dXF_in = dXF
+        elif ctx.needs_input_grad[0]:
             dXF_in = dXF.clone()
             blk = dXF_in[:, offset:offset + dims[-1]]
             if rows is not None:
                 blk.index_fill_(0, rows, 0.0)
             else:
                 blk.fill_(0.0)
-        return (dXF_in, None, None, dgate, None, None, None, *dW, *db)
+        return (dXF_in, None, None, dgate, None, None, None, None, *dW, *db)
 
 
-def mlp_gate_scatter(XF, enc, rows, gate_weights, i_gate, offset, weights, biases):
-    return _MlpGateScatter.apply(XF, enc, rows, gate_weights, int(i_gate), int(offset), len(weights), *weights, *biases)
+def mlp_gate_scatter(XF, enc, rows, gate_weights, i_gate, offset, weights, biases, fresh=False):
+    """`fresh`: XF is a zero buffer that is being filled block by block (every block written once, nothing else reads
+    it in between): the backward then hands XF's gradient on without copying it."""
+    return _MlpGateScatter.apply(XF, enc, rows, gate_weights, int(i_gate), int(offset), len(weights), bool(fresh),
+                                 *weights, *biases)
+
+
+class _ScatterBlock(torch.autograd.Function):
+    """XF[rows, off : off + d] = out, in place, for a zero buffer that is filled block by block (mrgcn.py:303): the
+    backward gathers the block's rows and hands XF's gradient on untouched — autograd's own indexed assignment copies
+    the whole gradient matrix (1.07 GB at the AM shape) once per encoder."""
+
+    @staticmethod
+    def forward(ctx, XF, out, rows, offset: int):
+        d = out.shape[1]
+        XF[rows, offset:offset + d] = out
+        ctx.mark_dirty(XF)
+        ctx.save_for_backward(rows)
+        ctx.blk = (int(offset), int(d))
+        return XF
+
+    @staticmethod
+    def backward(ctx, dXF):
+        (rows,) = ctx.saved_tensors
+        off, d = ctx.blk
+        d_out = dXF[:, off:off + d].index_select(0, rows) if ctx.needs_input_grad[1] else None
+        return dXF, d_out, None, None
+
+
+def scatter_block(XF, out, rows, offset):
+    return _ScatterBlock.apply(XF, out, rows, int(offset))

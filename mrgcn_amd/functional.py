@@ -221,7 +221,7 @@ class _SpmmLiteral(torch.autograd.Function):
         (Y,) = ctx.saved_tensors
         if ctx.relu:
             dY = relu_bwd(dY, Y)
-        dbias = dY.sum(0) if ctx.has_bias else None
+        dbias = _bias_grad(dY) if ctx.has_bias else None
         dD = None
         if ctx.needs_input_grad[1]:
             F = dY.shape[1]
@@ -256,6 +256,25 @@ def relu_bwd(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
 # is the very object, unchanged, that the upper layer returned: autograd hands a sole consumer's gradient through as
 # it is, and sums the gradients of several consumers either into a new tensor (no note) or in place (the tensor's
 # version counter moves) — in both cases the lower layer falls back to masking and scanning by itself.
+def _bias_grad(dY: torch.Tensor, row_flags=None) -> torch.Tensor:
+    """`dY.sum(0)`: the gradient of a layer's bias (autograd of `AFW + self.b`, graph.py:98-101).  Narrow layers take
+    one pass of this package (fixed summation order; rows flagged 0 are not read — a gradient whose unflagged rows
+    were never written is fine); wide ones torch's reduction."""
+    F = dY.shape[1]
+    if dY.is_cuda and dY.dtype == torch.float32 and F <= 16 and dY.stride(1) == 1 and dY.shape[0] > 0:
+        lib = L.load()
+        out = torch.empty(F, dtype=torch.float32, device=dY.device)
+        ws = torch.empty(int(lib.mrgcn_colsum_rows_workspace(F)), dtype=torch.float32, device=dY.device)
+        with torch.cuda.device(dY.device):
+            L.check(lib.mrgcn_colsum_rows_f32(dY.data_ptr(), dY.stride(0), dY.shape[0], F,
+                                              row_flags.data_ptr() if row_flags is not None else 0, out.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), _stream(dY.device)), "mrgcn_colsum_rows_f32")
+        return out
+    if row_flags is not None:
+        return (dY * row_flags.to(dY.dtype)[:, None]).sum(0)
+    return dY.sum(0)
+
+
 def _set_grad_meta(t, row_live, relu_applied: bool, structural: bool = False, sparse_rows: bool = False):
     """`structural`: `row_live` is a row set fixed by the label set and the graph (the same tensor every epoch; rows
     outside it are certainly zero, rows inside it may be): the key of a gradient support.  `sparse_rows`: the rows
@@ -349,9 +368,8 @@ class _RgcnLayer(torch.autograd.Function):
         sparse_rows = bool(meta and meta.get("sparse_rows"))
         if sparse_rows and row_flags is None:
             raise L.MrgcnError("internal: an output gradient with unwritten rows arrived without its row flags")
-        if sparse_rows and has_bias:
-            raise L.MrgcnError("internal: an output gradient with unwritten rows reached a layer with a bias")
-        dbias = dY.sum(0) if has_bias else None
+        # (rows outside the flags are zeros — or, with `sparse_rows`, unwritten: the flagged rows are all there is to add)
+        dbias = _bias_grad(dY, row_flags) if has_bias else None
         if meta is None and _SUPPORT and _LIVE_COLS and _DISCOVER and F <= 16:
             # a plain dense gradient (the reference's own loss: CrossEntropyLoss on Y_hat[idx] leaves zeros + the
             # labelled rows): which rows hold anything is looked up, and while that set equals last epoch's the
@@ -771,7 +789,7 @@ class _MaskedLayer(torch.autograd.Function):
         meta = _grad_meta(dY)
         if ctx.relu and not (meta and meta["relu_applied"]):
             dY = relu_bwd(dY, Y)
-        dbias = dY.sum(0) if has_bias else None
+        dbias = _bias_grad(dY) if has_bias else None
         d_wI = d_comp = dX = dW = None
         Lc = max(sup.L, 1)
         with torch.cuda.device(dev):
@@ -901,7 +919,7 @@ def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False, input_term: bool =
     Y = _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, bias, relu, bf16, layer)
     if relu:
         Y._mrgcn_relu_out = True  # (a Python attribute of this tensor object: a copy or a view does not carry it)
-    if bias is None and F <= 16 and _SUPPORT and _LIVE_COLS and not plan.lean:
+    if F <= 16 and _SUPPORT and _LIVE_COLS and not plan.lean:
         # this layer's backward reads the flagged rows of its output gradient only: a loss that knows the rows it
         # touches (train.categorical_crossentropy) need not zero-fill the rest (AM shape: 73 MB per epoch)
         Y._mrgcn_sparse_grad_ok = True

@@ -165,7 +165,7 @@ class MRGCN(nn.Module):
             X0, F = batch.X[0], batch.X[1:]
             batch_idx = batch.A.neighbours[-1]
             XF = self._compute_modality_embeddings(F, batch_idx)
-            X = torch.cat([X0.to(dev), XF], dim=1).float()
+            X = XF.float() if X0.shape[1] == 0 else torch.cat([X0.to(dev), XF], dim=1).float()
         return self.rgcn(X, batch.A)
 
     def _forward_full_batch(self, batch):
@@ -175,7 +175,8 @@ class MRGCN(nn.Module):
         if self.compute_modality_embeddings:
             batch_idx = torch.arange(self.num_nodes)
             XF = self._compute_modality_embeddings(F, batch_idx, full_batch=True)
-            X = torch.cat([X0.to(dev), XF], dim=1).float()
+            # (no given feature columns: the encoders' matrix is X — a concatenation would copy it once more)
+            X = XF.float() if X0.shape[1] == 0 else torch.cat([X0.to(dev), XF], dim=1).float()
         return self.rgcn(X, batch.A)
 
     def _compute_modality_embeddings(self, F, batch_idx, full_batch=False):
@@ -252,9 +253,13 @@ class MRGCN(nn.Module):
                     from .. import dense
                     lin = module.linears()
                     X = dense.mlp_gate_scatter(X, data, rows, self.gate_weights, i_gate, offset,
-                                               [l.weight for l in lin], [l.bias for l in lin])
+                                               [l.weight for l in lin], [l.bias for l in lin], fresh=True)
                 else:
                     out = module(data).to(dev) * gate.to(dev)
-                    X[rows, offset:offset + out_dim] = out
+                    if X.is_cuda and out.dtype == X.dtype:
+                        from .. import dense
+                        X = dense.scatter_block(X, out, rows, offset)   # (X: this call's zero buffer)
+                    else:
+                        X[rows, offset:offset + out_dim] = out
                 offset += out_dim
         return X
