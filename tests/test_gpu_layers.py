@@ -905,3 +905,34 @@ def test_a_plain_dense_gradient_finds_its_gradient_support():
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)   # (another summation order)
     assert taken == [True] * len(sets), taken
     assert int(layer.__dict__["_mrgcn_found_rows"].sum()) == 42   # the union of every set seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,F,ld", [(1, 1, 1), (257, 3, 4), (5000, 10, 10), (5000, 11, 12), (70001, 16, 16), (70001, 7, 9)])
+def test_bias_gradient_column_sums_over_flagged_rows_through_the_c_abi(M, F, ld):
+    """mrgcn_colsum_rows_f32 = `dY.sum(0)` (the gradient of `+ self.b`, graph.py:98-101): every row, or the flagged rows
+    only — unflagged rows are never read (they hold NaN here, like the unwritten rows of the loss's
+    labelled-rows-only gradient); two calls give the same bits (fixed summation order)."""
+    from mrgcn_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(M + F)
+    X = rng.standard_normal((M, ld)).astype(np.float32)
+    flags = (rng.random(M) < 0.3).astype(np.uint8)
+    flags[rng.integers(0, M)] = 1
+    Xg = torch.from_numpy(X).cuda()
+    ws = torch.empty(int(lib.mrgcn_colsum_rows_workspace(F)), device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    out = torch.full((F,), 7.0, device="cuda")
+    L.check(lib.mrgcn_colsum_rows_f32(Xg.data_ptr(), ld, M, F, 0, out.data_ptr(), ws.data_ptr(), ws.numel(), s))
+    np.testing.assert_allclose(out.cpu().numpy(), X[:, :F].astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+    Xp = X.copy()
+    Xp[flags == 0] = np.nan
+    Xpg, fg = torch.from_numpy(Xp).cuda(), torch.from_numpy(flags).cuda()
+    outs = []
+    for _ in range(2):
+        o = torch.empty(F, device="cuda")
+        L.check(lib.mrgcn_colsum_rows_f32(Xpg.data_ptr(), ld, M, F, fg.data_ptr(), o.data_ptr(), ws.data_ptr(), ws.numel(), s))
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0].cpu().numpy(), X[flags == 1][:, :F].astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+    assert lib.mrgcn_colsum_rows_workspace(17) < 0
