@@ -1162,6 +1162,27 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     final_loss = float(loss)
 
+    def measure_roofline():
+        # ---- roofline of the dominant sparse kernel: the stacked-CSR SpMM of layer 0 ----
+        plan_, F_ = live["plan"], dims[0][1]
+        rf = spmm_roofline(plan_, F_, args.operand if not partitioned else "f32", args.spmm_iters, dev, name, args.scale)
+        if len(dims) > 1 and dims[1][1] != F_ and dims[1][1] <= 16:
+            # the epoch launches this product once per layer: both widths are timed and the LOWER fraction is the
+            # line's `roofline` (the other one stays beside it)
+            other = spmm_roofline(plan_, dims[1][1], args.operand if not partitioned else "f32", args.spmm_iters, dev,
+                                  name, args.scale, pmc_ok=False)
+            lo, hi = (rf, other) if rf["frac"] <= other["frac"] else (other, rf)
+            lo = dict(lo)
+            lo["other_width"] = {k: hi[k] for k in ("kernel", "frac", "achieved", "avg_ms", "algorithmic_bytes")}
+            if lo["traffic"] is None and hi.get("traffic") is not None:
+                lo["traffic_other_width"] = hi["traffic"]
+            rf = lo
+        return rf
+    # (with several ranks the replica's model is dropped before the big partition probe: rank 0 measures first)
+    early_roofline = measure_roofline() if (rank == 0 and world > 1 and "plan" in live) else None
+    if world > 1:
+        barrier()
+
     # --gpus N on a replica workload: the node-partitioned engine on the same graph (and on the 10 M-node graph),
     # every rank takes part; a failure (RCCL, memory) leaves its message and the replica line still prints
     part_records = None
@@ -1182,21 +1203,10 @@ def main():
         have_model = "plan" in live
         plan, model = live.get("plan"), live.get("model")
         A, X, idx, tgt = live.get("A"), live.get("X"), live.get("idx"), live.get("tgt")
-        if have_model:
-            # ---- roofline of the dominant sparse kernel: the stacked-CSR SpMM of layer 0 ----
-            roofline = spmm_roofline(plan, F, args.operand if not partitioned else "f32", args.spmm_iters, dev, name,
-                                     args.scale)
-            if len(dims) > 1 and dims[1][1] != F and dims[1][1] <= 16:
-                # the epoch launches this product once per layer: both widths are timed and the LOWER fraction is the
-                # line's `roofline` (the other one stays beside it)
-                other = spmm_roofline(plan, dims[1][1], args.operand if not partitioned else "f32", args.spmm_iters, dev,
-                                      name, args.scale, pmc_ok=False)
-                lo, hi = (roofline, other) if roofline["frac"] <= other["frac"] else (other, roofline)
-                lo = dict(lo)
-                lo["other_width"] = {k: hi[k] for k in ("kernel", "frac", "achieved", "avg_ms", "algorithmic_bytes")}
-                if lo["traffic"] is None and hi.get("traffic") is not None:
-                    lo["traffic_other_width"] = hi["traffic"]
-                roofline = lo
+        if early_roofline is not None:
+            roofline = early_roofline
+        elif have_model:
+            roofline = measure_roofline()
         else:
             roofline = None
         ach = roofline["achieved"] if roofline else None
