@@ -6,7 +6,7 @@ tag=${2:-$src}
 o=gpurun_out/$src
 for f in bench_line.json bench_fb15k.json bench_under_rocprof.json epoch_kernel_stats.md \
          epoch_kernel_trace_medians.md epoch_sequence.md epoch_pmc.md kernel_roofline.md lp_epoch_sequence.md spmm_pmc.md \
-         spmm_pmc_fb15k.md next_rows.json minibatch_step_sequence.md halo.json gemm_probe.txt gemm_probe.json rocm_smi_during_bench.txt; do
+         spmm_pmc_fb15k.md next_rows.json minibatch_step_sequence.md halo.json gemm_probe.txt gemm_probe.json rocm_smi_during_bench.txt am_encoders_step.md; do
   [ -s $o/$f ] && cp $o/$f profiles/${tag}_$f
 done
 cp $o/spmm_pmc_latest.json profiles/spmm_pmc_latest.json

@@ -8,7 +8,7 @@
 # (4) epoch PMC (memory + SQ sets) for the weight_I streamers and the transforms -> epoch_pmc.md and, with (3),
 # kernel_roofline.md, (5) the fb15k line + its launch sequence, (6) the encoders' product probe + MFMA counters,
 # (7) the next-rows probe (mini-batch incl. the masked pass, encoders, ingestion) + the launch sequence of one
-# re-sampled mini-batch step, (8) the halo-size probe.
+# re-sampled mini-batch step, (8) the halo-size probe, (9) one replayed step of the full-multimodal model kernel by kernel.
 tag=${1:-rXX}
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
@@ -54,4 +54,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_mb -o run -- py
 python3 tools/epoch_sequence.py $o/stats_mb k_sup_rowcount 2 > $o/minibatch_step_sequence.md 2>&1
 rm -rf $o/stats_mb
 python3 tools/halo_probe.py > $o/halo.json 2> $o/halo.err
+rocprofv3 --kernel-trace --output-format csv -d $o/stats_enc -o run -- python3 tools/am_encoders_step.py run > $o/am_encoders_step.txt 2> $o/am_encoders_step.err
+python3 tools/am_encoders_step.py summary $o/stats_enc > $o/am_encoders_step.md 2>> $o/am_encoders_step.err
+rm -rf $o/stats_enc
 ls -la $o
