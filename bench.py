@@ -642,6 +642,50 @@ def reference_loop_ms(args, kind, A, X, idx, tgt, modules, R, N, B, featureless,
     return (time.perf_counter() - t0) / n * 1e3
 
 
+def labelled_batch_epoch_ms(args, plan, X, idx_np, y_np, modules, R, N, B, featureless, dev):
+    """Informational: the same training step driven through the MINI-BATCH machinery with ONE batch that holds every
+    labelled node (data/batch.py:185-263: `getNeighboursSparse` takes all neighbours, no sampling) and the adjacency's
+    values kept for both terms (`A_BatchMasked(full_batch_values=True)`): the full-batch arithmetic on the labelled
+    nodes' receptive field only — the parameters after the step equal the full-batch step's (tests/test_minibatch.py).
+    Not the headline: the headline epoch computes all N rows, as the reference's full-batch mode does."""
+    import torch
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
+    torch.manual_seed(args.seed)
+    model = RGCN(modules, R, N, B, 0.0, featureless, False, False).to(dev)
+    order = np.argsort(idx_np, kind="stable")
+    nodes = np.asarray(idx_np)[order]
+    ys = torch.from_numpy(np.asarray(y_np)[order]).to(dev)
+    rows = torch.arange(len(nodes), device=dev)
+    am = mb.A_BatchMasked(plan, nodes, len(modules), full_batch_values=True)
+    fwd = lambda: model(X, am)   # noqa: E731
+    launch = "hipGraph replay"
+    try:
+        opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0, capturable=True)
+        step = GraphedTrainStep(model, fwd, rows, ys, opt, warmup=max(args.warmup, 2))
+        step()
+    except Exception as e:  # noqa: BLE001  (informational leg: the eager figure stands)
+        launch = "eager (capture failed: %s)" % str(e)[:100]
+        opt = ClipAdam(model.parameters(), lr=0.01, weight_decay=0.0, max_norm=1.0)
+        step = lambda: train_step(model, fwd, rows, ys, opt)   # noqa: E731
+        for _ in range(max(args.warmup, 2)):
+            step()
+    torch.cuda.synchronize(dev)
+    n = max(args.steps // 2, 5)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / n * 1e3
+    sizes = [(s_.NR, s_.NL, s_.E) for s_ in am.supports]
+    am.close()
+    return {"ms_per_step": ms, "launch": launch, "batch_nodes": int(len(nodes)),
+            "levels_rows_neighbours_entries": sizes,
+            "what": "one batch = all labelled nodes (all neighbours, no sampling), adjacency values kept for both terms: "
+                    "the step of the headline restricted to the labels' receptive field; same parameters after the step"}
+
+
 def lp_cpu_baseline(args, sh, train_frac):
     """The reference's op sequence for one full-batch link-prediction epoch on the host (encoder: the literal ATen
     port of graph.py:62-102; decoder, loss, clip and Adam: the torch ops of tasks/link_prediction.py:244-326) on a
@@ -1240,6 +1284,13 @@ def main():
                     except Exception as e:  # noqa: BLE001  (informational leg only)
                         extra[key + "_error"] = str(e)[:200]
                     torch.cuda.empty_cache()
+            if args.reference_loop and not featureless and plan.nnz <= 40_000_000 and not plan.lean:
+                try:
+                    extra["labelled_nodes_as_one_batch"] = labelled_batch_epoch_ms(
+                        args, plan, X, idx_np, y_np, modules, R, N, B, featureless, dev)
+                except Exception as e:  # noqa: BLE001  (informational leg only)
+                    extra["labelled_nodes_as_one_batch"] = {"error": (type(e).__name__ + ": " + str(e))[:200]}
+                torch.cuda.empty_cache()
             if not args.no_literal_spmm:
                 try:  # the reference's own operand layout: dense (R*N) x F, 17.8 GB at AM scale
                     D = torch.randn((R * plan.num_nodes, F), device=dev)

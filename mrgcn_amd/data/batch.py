@@ -389,9 +389,14 @@ class A_BatchMasked:
     `neighbours[i]` are the same sorted node ids `getNeighboursSparse` returns (int64, on the plan's device), so the
     caller's `X[batch.neighbours[-1]]` is unchanged; `row[i]` is the support (what `RGCN.forward` hands to layer
     num_layers-1-i).  A re-sampled batch costs `num_layers` support builds on the existing plan: no slice tensors, no
-    per-batch plans, no worker threads.  Rows of the output follow `batch_idx` (any order, repeats allowed)."""
+    per-batch plans, no worker threads.  Rows of the output follow `batch_idx` (any order, repeats allowed).
 
-    def __init__(self, plan, batch_idx, num_layers):
+    `full_batch_values=True`: the feature term multiplies the adjacency's stored values like the input term does —
+    not the reference's mini-batch arithmetic (its slices drop the values: batch.py:258-270) but its FULL-batch
+    arithmetic (graph.py:93-95) restricted to the batch's receptive field: a batch that holds every labelled node then
+    trains exactly like the full-batch epoch while computing only the rows the loss can see."""
+
+    def __init__(self, plan, batch_idx, num_layers, full_batch_values=False):
         from ..plan import GraphSupport
         dev = plan.device
         if plan.num_rows != plan.num_nodes:
@@ -404,6 +409,8 @@ class A_BatchMasked:
         flags[idx] = 1
         # every layer's support in one build (one host wait): level i+1's rows are level i's NODE_FLAGS
         self.supports = GraphSupport.chain(plan, flags, num_layers, forward=True) if num_layers else []
+        for sup in self.supports:
+            sup.feature_values = bool(full_batch_values)
         self.neighbours = [sup.view(L_.SUP_LNODE).long() for sup in self.supports]
         self.row = self.supports
         # position of every batch node among the (sorted, distinct) rows the top layer computes

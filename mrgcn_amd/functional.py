@@ -757,18 +757,22 @@ class _MaskedLayer(torch.autograd.Function):
                     L.check(lib.mrgcn_support_literal_rows_f32(sup.handle, 0, wI.data_ptr(), F, M.data_ptr(), ld, s),
                             "mrgcn_support_literal_rows_f32")
             b = bias.data_ptr() if bias is not None else 0
+            # the feature term multiplies the all-ones slice (the reference's mini-batch arithmetic: `sliceSparseCOO`
+            # drops the values, batch.py:258-270) — or, for a batch built with `full_batch_values`, the stored values
+            # like the input term: the FULL-batch arithmetic of graph.py:93-95 restricted to the batch's receptive field
+            fv = int(bool(getattr(sup, "feature_values", False)))
             if has_I and has_X:
                 YI = torch.empty((NR, F), dtype=torch.float32, device=dev)
                 L.check(lib.mrgcn_support_spmm_fwd_f32(sup.handle, 1, M.data_ptr(), ld, F, YI.data_ptr(), F, 0, 0, s),
                         "mrgcn_support_spmm_fwd_f32")
-                L.check(lib.mrgcn_support_spmm_fwd_f32(sup.handle, 0, T.data_ptr(), ld, F, Y.data_ptr(), F, b, 0, s),
+                L.check(lib.mrgcn_support_spmm_fwd_f32(sup.handle, fv, T.data_ptr(), ld, F, Y.data_ptr(), F, b, 0, s),
                         "mrgcn_support_spmm_fwd_f32")
                 # (graph.py:95-101: AIW + AFW, the bias inside AFW)
                 Y = torch.add(YI, Y, out=Y)
                 if relu:
                     Y.relu_()
             else:
-                L.check(lib.mrgcn_support_spmm_fwd_f32(sup.handle, int(has_I), (M if has_I else T).data_ptr(), ld, F,
+                L.check(lib.mrgcn_support_spmm_fwd_f32(sup.handle, int(has_I or fv), (M if has_I else T).data_ptr(), ld, F,
                                                        Y.data_ptr(), F, b, int(relu), s), "mrgcn_support_spmm_fwd_f32")
         ctx.sup, ctx.plan, ctx.F, ctx.ld, ctx.relu, ctx.owner = sup, plan, F, ld, relu, owner
         ctx.x_by_node = bool(has_X and x_by_node)
@@ -808,8 +812,9 @@ class _MaskedLayer(torch.autograd.Function):
             if need_dX or need_dW:
                 K = X.shape[1]
                 dT = torch.empty((Lc, ld), dtype=torch.float32, device=dev)
-                L.check(lib.mrgcn_support_spmm_t_compact_f32(sup.handle, 0, dY.data_ptr(), dY.stride(0), F,
-                                                             dT.data_ptr(), ld, s), "mrgcn_support_spmm_t_compact_f32")
+                L.check(lib.mrgcn_support_spmm_t_compact_f32(sup.handle, int(bool(getattr(sup, "feature_values", False))),
+                                                             dY.data_ptr(), dY.stride(0), F, dT.data_ptr(), ld, s),
+                        "mrgcn_support_spmm_t_compact_f32")
                 nws = int(lib.mrgcn_support_rel_transform_bwd_workspace(sup.handle, K, F, int(need_dX), int(need_dW)))
                 ws = sup.workspace(("xform", K, F), nws)
                 if need_dX:

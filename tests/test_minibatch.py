@@ -531,3 +531,64 @@ def test_masked_batch_with_node_dropout_and_three_layers_matches_the_slice_path(
     np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-3, atol=1e-5)
     for n in outs[0][2]:
         np.testing.assert_allclose(outs[1][2][n], outs[0][2][n], rtol=1e-3, atol=1e-5, err_msg=n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bias", [False, True])
+def test_one_batch_of_all_labelled_nodes_trains_like_the_full_batch(bias):
+    """Mini-batch mode takes ALL neighbours (data/batch.py:185-263, no sampling): one batch that holds every labelled
+    node computes the labels' receptive field only.  With the adjacency's values kept for the feature term
+    (`full_batch_values`: the reference's own slices drop them, batch.py:258-270) three training steps leave the same
+    losses and the same parameters as the full-batch steps (node_classification.py:166-193) — eager and replayed from
+    a hipGraph (bench.py: extra.labelled_nodes_as_one_batch); without it (the reference's mini-batch arithmetic) they
+    do not."""
+    from mrgcn_amd.data import batch as mb
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.plan import GraphPlan
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
+    import scipy.sparse as sp
+    from mrgcn_amd import synth
+    g = synth.make_graph("am", seed=2, scale=0.03)
+    N, R = g.num_nodes, g.num_relations
+    idx_np, y_np = synth.make_labels("am", N, 2, 0.03)
+    rng = np.random.default_rng(0)
+    K, H, C, B = 20, 10, int(y_np.max()) + 1, 5
+    X = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
+    A_csr = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([g.rows, g.cols])), torch.from_numpy(g.vals), (N, R * N)).cuda()
+    plan = GraphPlan.from_csr(A_csr, N, R, value_mode="norm_f32")
+    mods = [(K, H, "mrgcn", torch.nn.ReLU()), (H, C, "mrgcn", None)]
+    idx, tgt = torch.from_numpy(idx_np).cuda(), torch.from_numpy(y_np).cuda()
+    order = np.argsort(idx_np, kind="stable")
+    nodes, ys = idx_np[order], torch.from_numpy(y_np[order]).cuda()
+    rows = torch.arange(len(nodes), device="cuda")
+
+    def run(kind):
+        torch.manual_seed(0)
+        model = RGCN(mods, R, N, B, 0.0, False, bias, False).cuda()
+        opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0, capturable=(kind == "graph"))
+        losses = []
+        if kind == "full":
+            for _ in range(3):
+                losses.append(float(train_step(model, lambda: model(X, A), idx, tgt, opt)))
+        else:
+            am = mb.A_BatchMasked(plan, nodes, 2, full_batch_values=(kind != "reference-slices"))
+            if kind == "graph":
+                # (the constructor runs ONE eager warm-up step before the capture: it is step 1 of the three)
+                step = GraphedTrainStep(model, lambda: model(X, am), rows, ys, opt, warmup=1)
+                losses = [float("nan"), float(step()), float(step())]
+            else:
+                for _ in range(3):
+                    losses.append(float(train_step(model, lambda: model(X, am), rows, ys, opt)))
+            torch.cuda.synchronize()
+            am.close()
+        return losses, {n: p.detach().cpu().numpy() for n, p in model.named_parameters()}
+
+    l0, p0 = run("full")
+    for kind in ("eager", "graph"):
+        l1, p1 = run(kind)
+        np.testing.assert_allclose(l1[1:], l0[1:], rtol=1e-5, atol=1e-6, err_msg=kind)
+        for n in p0:
+            np.testing.assert_allclose(p1[n], p0[n], rtol=2e-4, atol=2e-6, err_msg=f"{kind}: {n}")
+    l2, _ = run("reference-slices")
+    assert abs(l2[1] - l0[1]) > 1e-4   # (the synthetic graph's values are 1 / in-degree per relation: not all ones)
