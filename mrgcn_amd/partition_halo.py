@@ -6,8 +6,10 @@ Rank g owns the node range [g*S, (g+1)*S): those OUTPUT rows, those rows of the 
 mrgcn_amd.partition).  Per layer
 
     forward   M_g   = operand rows of the columns (r, j in range)        local: the mix / transform kernels on P_col
-              halo  = the operand rows of REMOTE columns my rows read     one all-to-all (rows of 4 F bytes)
-              Y_g   = A[rows_g, :] . [M_g | halo]                         local: the product on P_row — own rows only
+              halo  = the operand rows of REMOTE columns my rows read     one all-to-all (rows of 4 F bytes), started
+                                                                          first and in flight under the next line
+              Y_g   = A[rows_g, own] . M_g                                local: the product on P_own
+              Y_g  += A[rows_g, remote] . halo                            local, after the wait: the product on P_halo
     backward  dM    = A[rows_g, :]^T dY_g                                 local
               the halo columns' gradient rows go back to their owners     one all-to-all (reverse)
               dV_g / dX_g / d(comp, W_F) from the summed dM_g             local; small gradients all-reduced
@@ -16,7 +18,7 @@ Against the column partition (one reduce-scatter of `Np x out` partial sums per 
 distinct remote columns a rank's rows read: `tools/halo_probe.py` — less at 8 GPUs on the AM and synth10m shapes
 (77.5 vs 122.5 MB, 591 vs 945 MB per layer pass), more at 2-4 GPUs and on FB15k-237.  `choose_partition` picks by
 that measure.  This engine computes the backward on dense index spaces (no gradient support yet: every column of
-P_row gets its gradient row); the arithmetic equals `mrgcn_amd.models.rgcn.RGCN` on one GPU (tests).
+P_own / P_halo gets its gradient row; the reverse exchange is blocking); the arithmetic equals `mrgcn_amd.models.rgcn.RGCN` on one GPU (tests).
 One process per GPU, torch.distributed (RCCL all-to-all over xGMI; gloo, CPU staged, in the tests)."""
 from __future__ import annotations
 
@@ -97,6 +99,52 @@ class _AllToAllRows(torch.autograd.Function):
     def backward(ctx, g):
         # the gradient of a received row goes back to the rank that sent it
         return all_to_all_rows(g.contiguous(), ctx.out_splits, ctx.in_splits, ctx.group), None, None, None
+
+
+class _Pending:
+    """a collective in flight: the receive buffer and what to wait on"""
+    __slots__ = ("work", "buf", "host")
+
+    def __init__(self):
+        self.work = self.buf = self.host = None
+
+
+class _AllToAllRowsStart(torch.autograd.Function):
+    """Starts the exchange of operand rows and returns at once (RCCL: the collective runs on the communicator's own
+    stream, the caller's stream goes on with the local product; `_AllToAllRowsWait` makes it wait).  gloo (the tests):
+    staged through the host, blocking.  Backward: the gradient rows go back to their senders (blocking)."""
+
+    @staticmethod
+    def forward(ctx, send, in_splits, out_splits, group, pending: _Pending):
+        ctx.in_splits, ctx.out_splits, ctx.group = in_splits, out_splits, group
+        n_out = int(sum(out_splits))
+        if _staged(send, group):
+            pending.buf = all_to_all_rows(send, in_splits, out_splits, group)
+            return pending.buf
+        out = torch.empty((n_out,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        pending.work = dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(out_splits),
+                                              input_split_sizes=list(in_splits), group=group, async_op=True)
+        pending.buf = out
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return all_to_all_rows(g.contiguous(), ctx.out_splits, ctx.in_splits, ctx.group), None, None, None, None
+
+
+class _AllToAllRowsWait(torch.autograd.Function):
+    """The current stream waits for the exchange started by `_AllToAllRowsStart`; identity for autograd."""
+
+    @staticmethod
+    def forward(ctx, recv, pending: _Pending):
+        if pending.work is not None:
+            pending.work.wait()
+            pending.work = None
+        return recv.view_as(recv)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
 
 
 # ---- the two local halves of a layer as autograd functions -----------------------------------------------------------
@@ -213,7 +261,7 @@ class _ProductFn(torch.autograd.Function):
         dY = dY.contiguous()
         if ctx.relu:
             dY = Fn.relu_bwd(dY, Y)
-        dbias = dY.sum(0) if ctx.has_bias else None
+        dbias = Fn._bias_grad(dY) if ctx.has_bias else None
         ld = (F + 3) // 4 * 4
         dMc = torch.empty((plan.ncols, ld), dtype=torch.float32, device=dY.device)
         plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dMc)
@@ -224,8 +272,10 @@ class _ProductFn(torch.autograd.Function):
 
 # ---- the partition's index maps on the device ------------------------------------------------------------------------
 class HaloPlans:
-    """P_col (the columns whose source node this rank owns: operand construction and its backward), P_row (this rank's
-    output rows over every column they read: the product) and the maps between them and the exchange buffers."""
+    """P_col (the columns whose source node this rank owns, over ALL rows: operand construction and its backward),
+    P_own (this rank's rows over its OWN columns) and P_halo (this rank's rows over the REMOTE columns they read): the
+    product of a layer is `P_own . M_own + P_halo . M_halo`, and the exchange that fills `M_halo` is in flight while the
+    first product runs.  Plus the maps between those operands and the exchange buffers."""
 
     def __init__(self, part: NodePartition, rows, cols, vals, num_relations: int, device, operand_row_bytes, group=None):
         R, N, S, rank, world = num_relations, part.N, part.S, part.rank, part.world
@@ -236,25 +286,22 @@ class HaloPlans:
                                         (part.Np, R * S)).to(device)
         self.p_col = GraphPlan(A_col, S, R, operand_row_bytes=operand_row_bytes)
         del A_col
-        # P_row: own rows; source nodes renumbered: own nodes 0 .. S-1, then the remote nodes read (rising id)
+        # my rows, split by who owns the source node
         mine = (rows >= part.j0) & (rows < part.j1)
         er, ec, ev = rows[mine] - part.j0, cols[mine], vals[mine]
         rel, node = ec // N, ec % N
-        remote = np.unique(node[(node < part.j0) | (node >= part.j1)])
-        Nl = S + len(remote)
         is_own = (node >= part.j0) & (node < part.j1)
-        jl = np.where(is_own, node - part.j0, S + np.searchsorted(remote, node))
-        A_row = torch.sparse_coo_tensor(torch.from_numpy(np.stack([er, rel * Nl + jl])), torch.from_numpy(ev),
-                                        (S, R * Nl)).to(device)
-        self.p_row = GraphPlan(A_row, Nl, R, operand_row_bytes=operand_row_bytes)
-        del A_row
-        # every compact column of P_row: its global literal id, its owner
-        ul = self.p_row.export(L.ARR_ULCOL).astype(np.int64)
-        r_c, jl_c = ul // Nl, ul % Nl
-        node_c = np.where(jl_c < S, jl_c + part.j0, remote[np.maximum(jl_c - S, 0)] if len(remote) else 0)
-        lit_c = r_c * N + node_c
-        own_c = jl_c < S
-        mpos_row = self.p_row.export(L.ARR_MPOS).astype(np.int64)
+        A_own = torch.sparse_coo_tensor(torch.from_numpy(np.stack([er[is_own], rel[is_own] * S + (node[is_own] - part.j0)])),
+                                        torch.from_numpy(ev[is_own]), (S, R * S)).to(device)
+        self.p_own = GraphPlan(A_own, S, R, operand_row_bytes=operand_row_bytes)
+        del A_own
+        remote = np.unique(node[~is_own])          # the remote source nodes my rows read (rising id)
+        Nr = max(len(remote), 1)
+        jr = np.searchsorted(remote, node[~is_own])
+        A_halo = torch.sparse_coo_tensor(torch.from_numpy(np.stack([er[~is_own], rel[~is_own] * Nr + jr])),
+                                         torch.from_numpy(ev[~is_own]), (S, R * Nr)).to(device)
+        self.p_halo = GraphPlan(A_halo, Nr, R, operand_row_bytes=operand_row_bytes)
+        del A_halo
         # P_col: literal id (global) of its compact columns -> operand position
         ulc = self.p_col.export(L.ARR_ULCOL).astype(np.int64)
         lit_col = (ulc // S) * N + (ulc % S) + part.j0
@@ -267,17 +314,24 @@ class HaloPlans:
             if len(lits) and (at.max() >= len(lit_sorted) or not np.array_equal(lit_sorted[at], lits)):
                 raise L.MrgcnError("halo partition: a requested column is not a column of its owner")
             return mpos_col[order[at]]
-        self.own_src = torch.from_numpy(col_positions(lit_c[own_c])).to(device)
-        self.own_dst = torch.from_numpy(mpos_row[own_c]).to(device)
-        # requests to the owners of the remote columns (in rising literal id per owner), and theirs to me
-        own_of = node_c // S
+        # P_own's columns inside M_col
+        ulo = self.p_own.export(L.ARR_ULCOL).astype(np.int64)
+        lit_own = (ulo // S) * N + (ulo % S) + part.j0
+        self.own_src = torch.from_numpy(col_positions(lit_own)).to(device)
+        self.own_dst = torch.from_numpy(self.p_own.export(L.ARR_MPOS).astype(np.int64)).to(device)
+        # P_halo's columns: global literal id, owner; requests per owner in rising literal id
+        ulh = self.p_halo.export(L.ARR_ULCOL).astype(np.int64)
+        node_h = remote[ulh % Nr] if len(remote) else np.zeros(0, np.int64)
+        lit_h = (ulh // Nr) * N + node_h
+        mpos_h = self.p_halo.export(L.ARR_MPOS).astype(np.int64)
+        own_of = node_h // S
         req, halo_dst = {}, []
         for o in range(world):
-            sel = (~own_c) & (own_of == o)
+            sel = own_of == o
             if sel.any():
-                ordr = np.argsort(lit_c[sel], kind="stable")
-                req[o] = lit_c[sel][ordr]
-                halo_dst.append(mpos_row[sel][ordr])
+                ordr = np.argsort(lit_h[sel], kind="stable")
+                req[o] = lit_h[sel][ordr]
+                halo_dst.append(mpos_h[sel][ordr])
         self.out_splits = [len(req.get(o, ())) for o in range(world)]
         self.halo_dst = torch.from_numpy(np.concatenate(halo_dst) if halo_dst else np.zeros(0, np.int64)).to(device)
         asked = exchange_requests(req, world, rank, group)
@@ -355,10 +409,24 @@ class HaloPartitionedRGCN(nn.Module):
                 if B > 0:
                     W_F = Fn._BasisContract.apply(layer.weight_F_comp, W_F)
             M_col = _OperandFn.apply(hp.p_col, F, weight_I, comp_I, Xin, W_F)           # my columns' operand rows
-            recv = _AllToAllRows.apply(M_col.index_select(0, hp.send_pos), hp.in_splits, hp.out_splits, self.group)
-            M_row = torch.zeros((hp.p_row.nop, M_col.shape[1]), dtype=torch.float32, device=M_col.device)
-            M_row = M_row.index_copy(0, hp.own_dst, M_col.index_select(0, hp.own_src)).index_copy(0, hp.halo_dst, recv)
-            H = _ProductFn.apply(hp.p_row, M_row, F, layer.b if layer.bias else None, self.relu[i])   # my rows
+            # the rows the other ranks read leave first; the product over my own columns runs under the exchange
+            pending = _Pending()
+            recv = _AllToAllRowsStart.apply(M_col.index_select(0, hp.send_pos), hp.in_splits, hp.out_splits, self.group,
+                                            pending)
+            M_own = torch.zeros((hp.p_own.nop, M_col.shape[1]), dtype=torch.float32, device=M_col.device)
+            M_own = M_own.index_copy(0, hp.own_dst, M_col.index_select(0, hp.own_src))
+            b = layer.b if layer.bias else None
+            Y = _ProductFn.apply(hp.p_own, M_own, F, None, False)
+            recv = _AllToAllRowsWait.apply(recv, pending)
+            if hp.halo_columns > 0:
+                M_halo = torch.zeros((hp.p_halo.nop, M_col.shape[1]), dtype=torch.float32, device=M_col.device)
+                M_halo = M_halo.index_copy(0, hp.halo_dst, recv)
+                Y = Y + _ProductFn.apply(hp.p_halo, M_halo, F, None, False)
+            else:   # (a rank that reads no remote column still takes part in the backward's exchange)
+                Y = Y + recv.sum() * 0.0
+            if b is not None:
+                Y = Y + b
+            H = torch.relu(Y) if self.relu[i] else Y
         return H
 
     @torch.no_grad()

@@ -354,7 +354,7 @@ def test_bench_replicas_also_run_the_partitioned_engine_in_child_processes():
 
 
 # ---- the row partition with operand-row halo exchange (mrgcn_amd.partition_halo) ------------------------------------
-def _halo_worker(rank, world, port, state, out, lp_mode=False):
+def _halo_worker(rank, world, port, state, out, lp_mode=False, backend="gloo"):
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -362,7 +362,11 @@ def _halo_worker(rank, world, port, state, out, lp_mode=False):
     from mrgcn_amd.partition_halo import HaloPartitionedRGCN, halo_lp_step, halo_train_step
     from mrgcn_amd.train import ClipAdam
     dev = torch.device("cuda:0")
-    dist.init_process_group("gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
     if lp_mode:
         g, facts, Y, mods = _lp_problem()
         N, R = g.num_nodes, g.num_relations
@@ -419,6 +423,20 @@ def test_halo_engine_ranks_equal_single_gpu(world):
     g = _problem()[0]
     ch = choose_partition(g.rows, g.cols, g.num_nodes, world, [8, 4])
     assert ch["halo_columns_per_rank"] == [out[r][4] for r in ranks]
+
+
+@pytest.mark.timeout(600)
+def test_halo_engine_over_rccl_with_one_rank():
+    """The halo engine's collectives as they run on a multi-GPU node — device tensors over the nccl (= RCCL) backend,
+    the operand-row exchange started asynchronously and waited for after the local product — with the one rank this
+    box has: the exchanges are empty, the model equals the single-GPU RGCN."""
+    state, logits0, losses, final = _single()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_halo_worker, args=(1, _free_port(), state, out, False, "nccl"), nprocs=1, join=True)
+    np.testing.assert_allclose(out[0][0], logits0, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out[0][1], losses, rtol=2e-4, atol=2e-5)
+    assert out[0][4] == 0
 
 
 @pytest.mark.timeout(600)
