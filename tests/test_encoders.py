@@ -389,8 +389,14 @@ def test_products_cut_along_the_batch_equal_the_single_launch(monkeypatch):
     assert len(dense._batch_pieces(37, 16 * 40, 24 * 40)) > 5
     gen.manual_seed(4)
     got = run()
-    for a, c in zip(got, ref):
-        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-4)
+    # outputs: the same sums in the same order.  Gradients of W / b: sums over 37 x 40 (sample, position) terms whose
+    # split-K partial tiles meet through float atomics — the order of the pieces differs from launch to launch, so
+    # the slack is the sibling test's rounding bound, not 1e-4 (seen: one element of 1 152 off by 4.9e-4 at 30)
+    for i, (a, c) in enumerate(zip(got, ref)):
+        if i < 2:
+            torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-4)
+        else:
+            torch.testing.assert_close(a, c, rtol=2e-5, atol=2e-4 * (37 * 40 / 100) ** 0.5)
 
 
 @pytest.mark.gpu
