@@ -45,6 +45,7 @@ enum CfgKey : int {
   CFG_WIDE_BWD,
   CFG_XFORM_COLS_LDS,
   CFG_SPMM_LITERAL_V3,
+  CFG_MIX_ADD_VEC,
   CFG_COUNT
 };
 int64_t cfg(CfgKey k);

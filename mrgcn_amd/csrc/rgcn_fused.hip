@@ -19,6 +19,9 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.hpp"
 #include "config.hpp"
 
@@ -168,12 +171,15 @@ constexpr int kFwdTB = 1024;  // 16 waves share one LDS copy of comp (R x 52 flo
 // and the addend words of the node's (single) tile sit in `pa`; the products then hold no global load at all,
 // so the waits the compiler places never drain the loads of the NEXT step (a load merged into the same
 // registers would: the wait sits at the use, after the merge).
-template <int KS, bool NEAR, bool ADD, typename OT>
+// ADD: 0 no addend; 1 the addend words of a NEAR node's tile in `pa`; 2 the addend rows of the step's columns staged
+// in the wave's LDS piece `s_add` (row of column `base` first, ldA floats per row)
+template <int KS, bool NEAR, int ADD, typename OT>
 __device__ __forceinline__ void mix_node_tiles(int32_t c0, int32_t c1, int32_t base, int32_t ur, int32_t mp,
                                                const float (&pa)[4], const int32_t *__restrict__ urel,
                                                const int32_t *__restrict__ mpos, const float *s_comp,
                                                const float *s_v, int B, int F, const float *__restrict__ addend,
-                                               int64_t ldA, OT *__restrict__ M, int64_t ldM, int m, int kq) {
+                                               int64_t ldA, OT *__restrict__ M, int64_t ldM, int m, int kq,
+                                               const float *s_add = nullptr) {
   constexpr int KP = KS * 16 + 4;
   // B operand of this node: V_j[16 ks + 4 kq + s][m]
   f32x4m bv[KS];
@@ -196,7 +202,8 @@ __device__ __forceinline__ void mix_node_tiles(int32_t c0, int32_t c1, int32_t b
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         pos[reg] = __shfl(mp, (cb - base + 4 * kq + reg) & 63);
-        if (ADD) acc[reg] = pa[reg];
+        if (ADD == 1) acc[reg] = pa[reg];
+        if (ADD == 2) acc[reg] = s_add[(min(cb + 4 * kq + reg, c1 - 1) - base) * (int)ldA + min(m, F - 1)];
       }
     } else {
       r = urel[min(cm, c1 - 1)];
@@ -273,7 +280,12 @@ __global__ __launch_bounds__(256) void k_mix_fwd_wide(const int32_t *__restrict_
 #ifndef MIX_V_NT
 #define MIX_V_NT 1  // V is read once per epoch: nontemporal loads (A/B: -DMIX_V_NT=0)
 #endif
-template <int KS, int NQ, int TN, bool ADD, typename OT, bool IDS = false>
+// ADD = 2: the addend rows of a step's columns are ONE contiguous run (a node's columns are consecutive, rows of ldA
+// <= 16 floats, ldA % 4 == 0): they come in as one or two 16-byte loads per lane, a step ahead like the V blocks, and
+// reach the accumulator layout through a per-wave LDS piece — instead of four 4-byte loads per node whose lanes
+// address four different rows (ADD = 1, kept for other row strides).
+constexpr int kAddPieces = 128;  // 16-byte pieces of addend rows per step: 2 nodes x 16 columns x 16 floats
+template <int KS, int NQ, int TN, int ADD, typename OT, bool IDS = false>
 __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
     const int32_t *__restrict__ nptr, const int32_t *__restrict__ urel, const int32_t *__restrict__ mpos,
     const float *__restrict__ V, const float *__restrict__ comp, int64_t N, int R, int B, int F,
@@ -287,6 +299,8 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = blockDim.x >> 6;
   float *s_tile = s_mem + ((R * KP + 3) & ~3) + wv * (TN * BF);
+  float *s_add = s_mem + ((R * KP + 3) & ~3) + nw * (TN * BF) + wv * (kAddPieces * 4);  // (ADD == 2 only)
+  const int q4 = (int)(ldA >> 2);
   for (int t = threadIdx.x; t < R * KP; t += blockDim.x) {
     const int r = t / KP, k = t - r * KP;
     s_comp[t] = k < B ? comp[(int64_t)r * B + k] : 0.f;
@@ -317,7 +331,13 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
     const int32_t ci = max(min(a0 + lane, a1 - 1), 0);                                                      \
     ur = urel[ci];                                                                                          \
     mp = mpos ? mpos[ci] : ci;                                                                              \
-    if (ADD) {                                                                                              \
+    if (ADD == 2) {                                                                                         \
+      const int64_t p0 = (int64_t)a0 * q4, p1 = (int64_t)a1 * q4;                                           \
+      const f32x4m *a4 = reinterpret_cast<const f32x4m *>(addend);                                          \
+      pa4_n1[0] = a4[max(min(p0 + lane, p1 - 1), (int64_t)0)];                                              \
+      pa4_n1[1] = a4[max(min(p0 + 64 + lane, p1 - 1), (int64_t)0)];                                         \
+    }                                                                                                       \
+    if (ADD == 1) {                                                                                         \
       _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                      \
         const int32_t b0 = __builtin_amdgcn_readlane(np, i), b1 = __builtin_amdgcn_readlane(np, i + 1);     \
         _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) pa_n1[i][reg] =                                 \
@@ -326,6 +346,7 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
     }                                                                                                       \
   }
   f32x4m pv[TN][NQ];
+  f32x4m pa4_n1[2];
   float pa_n1[TN][4], pa_cur[TN][4];
   int32_t np_cur = MIX_LOAD_NP(g), np_n1 = MIX_LOAD_NP(g + nwaves);
   int32_t id_cur = MIX_LOAD_ID(g), id_n1 = MIX_LOAD_ID(g + nwaves);
@@ -343,8 +364,10 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       if (ADD) {
+        if (ADD == 1) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) pa_cur[i][reg] = pa_n1[i][reg];
+          for (int reg = 0; reg < 4; ++reg) pa_cur[i][reg] = pa_n1[i][reg];
+        }
         near = near && __builtin_amdgcn_readlane(np_now, i + 1) - __builtin_amdgcn_readlane(np_now, i) <= 16;
       }
       // this step's V blocks: registers -> the wave's tile
@@ -352,6 +375,10 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         if (lane + 64 * q < nf4) dst[lane + 64 * q] = pv[i][q];
+    }
+    if (ADD == 2) {  // this step's addend rows (a NEAR step: at most TN x 16 columns x ldA <= 16 floats)
+      reinterpret_cast<f32x4m *>(s_add)[lane] = pa4_n1[0];
+      reinterpret_cast<f32x4m *>(s_add)[64 + lane] = pa4_n1[1];
     }
     wave_lds_fence();
     MIX_LOAD_V(g + nwaves, id_n1)  // next step's blocks (the last step re-reads its own)
@@ -365,7 +392,7 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
         const int32_t c0 = __builtin_amdgcn_readlane(np_now, i), c1 = __builtin_amdgcn_readlane(np_now, i + 1);
         if (c1 > c0)
           mix_node_tiles<KS, true, ADD, OT>(c0, c1, cbase, ur_cur, mp_cur, pa_cur[i], urel, mpos, s_comp,
-                                            s_tile + i * BF, B, F, addend, ldA, M, ldM, m, kq);
+                                            s_tile + i * BF, B, F, addend, ldA, M, ldM, m, kq, s_add);
       }
     } else {
 #pragma unroll 1
@@ -1349,6 +1376,19 @@ using namespace mrgcn;
 namespace {
 
 // the columns a basis mix walks: a plan's (every node) or a gradient support's (a node list, rows by live number)
+// dynamic LDS beyond 48 KB needs the kernel's limit raised once — per kernel, whatever call site launches it
+hipError_t raise_lds_limit(const void *fn, size_t lds) {
+  static std::mutex mu;
+  static std::unordered_map<const void *, size_t> allowed;
+  std::lock_guard<std::mutex> g(mu);
+  size_t &a = allowed[fn];
+  if (a == 0) a = 48 * 1024;
+  if (lds <= a) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) a = lds;
+  return e;
+}
+
 struct MixCols {
   const int32_t *nptr, *urel, *mpos, *unode, *node_ids;
   int64_t N, ncols;
@@ -1424,8 +1464,12 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
     constexpr int tn = 2;  // nodes per wave step
     const int KS = (B + 15) / 16;
     const int NQ = (B * F + 255) / 256;  // 16-byte pieces of a V block per lane (<= KS)
+    // the addend as 16-byte pieces through LDS (k_mix_fwd_mfma, ADD = 2) when its rows allow it
+    const bool add_vec = addend && ldA % 4 == 0 && ldA <= 16 && (((uintptr_t)addend) & 15) == 0 && !node_ids &&
+                         cfg(CFG_MIX_ADD_VEC) != 0;
     const size_t lds =
-        ((size_t)((R * (KS * 16 + 4) + 3) & ~3) + (size_t)(kFwdTB / 64) * tn * B * F) * sizeof(float);
+        ((size_t)((R * (KS * 16 + 4) + 3) & ~3) + (size_t)(kFwdTB / 64) * tn * B * F +
+         (add_vec ? (size_t)(kFwdTB / 64) * kAddPieces * 4 : 0)) * sizeof(float);
     if (mfma_on && B <= 64 && F <= 16 && (B * F) % 4 == 0 && (((uintptr_t)V) & 15) == 0 &&
         lds <= 150 * 1024 && !(node_ids && (addend || sizeof(OT) != 4))) {
       const int64_t want = ((N + tn - 1) / tn + (kFwdTB / 64) - 1) / (kFwdTB / 64);
@@ -1433,14 +1477,10 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
       if (grid > want) grid = want;
 #define MIXM_GO(KS_, NQ_, TN_)                                                                              \
   do {                                                                                                      \
-    auto kfn = addend ? k_mix_fwd_mfma<KS_, NQ_, TN_, true, OT> : k_mix_fwd_mfma<KS_, NQ_, TN_, false, OT>; \
-    if constexpr (sizeof(OT) == 4) if (node_ids) kfn = k_mix_fwd_mfma<KS_, NQ_, TN_, false, OT, true>;      \
-    static size_t lds_allowed = 48 * 1024;                                                                  \
-    if (lds > lds_allowed) {                                                                                \
-      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                        (int)lds));                                                         \
-      lds_allowed = lds;                                                                                    \
-    }                                                                                                       \
+    auto kfn = addend ? (add_vec ? k_mix_fwd_mfma<KS_, NQ_, TN_, 2, OT> : k_mix_fwd_mfma<KS_, NQ_, TN_, 1, OT>) \
+                      : k_mix_fwd_mfma<KS_, NQ_, TN_, 0, OT>;                                               \
+    if constexpr (sizeof(OT) == 4) if (node_ids) kfn = k_mix_fwd_mfma<KS_, NQ_, TN_, 0, OT, true>;          \
+    MRGCN_HIP_TRY(raise_lds_limit((const void *)kfn, lds)); /* (per kernel: the variants share this site) */ \
     kfn<<<dim3((unsigned)grid), dim3(kFwdTB), lds, s>>>(p->nptr, p->urel, mpos_arg, V, comp, N, R, B, F,     \
                                                         addend, ldA, M, ldM, node_ids);                     \
   } while (0)
