@@ -48,7 +48,8 @@ const Entry kEntries[CFG_COUNT] = {
     {"wide_bwd", "MRGCN_WIDE_BWD", 1, "wide featureless layer: backward straight from dY"},
     {"xform_cols_lds", "MRGCN_XFORM_COLS_LDS", 1, "narrow transform with every relation's weights in LDS, output order"},
     {"spmm_literal_v3", "MRGCN_SPMM_LITERAL_V3", 1, "LITERAL products of narrow layers on the compact view's row classes (k_spmm3 with literal columns)"},
-    {"mix_add_vec", "MRGCN_MIX_ADD_VEC", 1, "basis mix forward: the feature term's rows come in as 16-byte pieces through LDS (0: four 4-byte loads per node)"}
+    {"mix_add_vec", "MRGCN_MIX_ADD_VEC", 1, "basis mix forward: the feature term's rows come in as 16-byte pieces through LDS (0: four 4-byte loads per node)"},
+    {"sup_rel_chunk", "MRGCN_SUP_REL_CHUNK", 512, "gradient supports: live columns of one (band, relation) group per transform block (64..1024; read when a support is built)"}
 };
 std::atomic<int64_t> g_values[CFG_COUNT];
 std::once_flag g_once;

@@ -46,6 +46,7 @@ enum CfgKey : int {
   CFG_XFORM_COLS_LDS,
   CFG_SPMM_LITERAL_V3,
   CFG_MIX_ADD_VEC,
+  CFG_SUP_REL_CHUNK,
   CFG_COUNT
 };
 int64_t cfg(CfgKey k);

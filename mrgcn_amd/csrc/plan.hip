@@ -1598,14 +1598,20 @@ int support_stage1(SupStage &b, hipStream_t s) {
 
 // the chunk lists of one order from its group pointers (host): chunk_ptr[R+1] | ids | rel | beg | end, every array
 // with at least one element.  Two passes, no allocation per call: `count` sizes, `write` fills `dst` (pinned memory).
+// columns per chunk of a support's relation-major orders (<= kRelChunk: the transforms' LDS lists are sized for that)
+int sup_rel_chunk() {
+  const int64_t v = cfg(CFG_SUP_REL_CHUNK);
+  return (int)std::min<int64_t>(std::max<int64_t>(v, 64), kRelChunk);
+}
 size_t order_chunks_count(const int32_t *h_gptr, int64_t ngroups, int64_t R, std::vector<int32_t> &cnt_rel,
                           int32_t *n_chunks, int32_t *max_chunks) {
+  const int kChunk = sup_rel_chunk();
   cnt_rel.assign((size_t)R, 0);
   int32_t n = 0;
   for (int64_t g = 0; g < ngroups; ++g) {
     const int32_t len = h_gptr[g + 1] - h_gptr[g];
     if (len <= 0) continue;
-    const int32_t c = (len + kRelChunk - 1) / kRelChunk;
+    const int32_t c = (len + kChunk - 1) / kChunk;
     cnt_rel[(size_t)(g % R)] += c;
     n += c;
   }
@@ -1617,6 +1623,7 @@ size_t order_chunks_count(const int32_t *h_gptr, int64_t ngroups, int64_t R, std
 }
 void order_chunks_write(const int32_t *h_gptr, int64_t ngroups, int64_t R, const std::vector<int32_t> &cnt_rel,
                         int32_t n_chunks, int32_t *dst, size_t base, size_t offs[5], std::vector<int32_t> &fill) {
+  const int kChunk = sup_rel_chunk();
   const size_t m = (size_t)std::max(n_chunks, 1);
   offs[0] = base;
   offs[1] = offs[0] + (size_t)(R + 1);
@@ -1636,11 +1643,11 @@ void order_chunks_write(const int32_t *h_gptr, int64_t ngroups, int64_t R, const
   int32_t ci = 0;
   for (int64_t g = 0; g < ngroups; ++g) {
     const int32_t r = (int32_t)(g % R);
-    for (int32_t b0 = h_gptr[g]; b0 < h_gptr[g + 1]; b0 += kRelChunk) {
+    for (int32_t b0 = h_gptr[g]; b0 < h_gptr[g + 1]; b0 += kChunk) {
       ids[fill[(size_t)r]++] = ci;
       rel[ci] = r;
       beg[ci] = b0;
-      end[ci] = std::min(b0 + kRelChunk, h_gptr[g + 1]);
+      end[ci] = std::min(b0 + kChunk, h_gptr[g + 1]);
       ++ci;
     }
   }
