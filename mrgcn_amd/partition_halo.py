@@ -18,7 +18,8 @@ Against the column partition (one reduce-scatter of `Np x out` partial sums per 
 distinct remote columns a rank's rows read: `tools/halo_probe.py` — less at 8 GPUs on the AM and synth10m shapes
 (77.5 vs 122.5 MB, 591 vs 945 MB per layer pass), more at 2-4 GPUs and on FB15k-237.  `choose_partition` picks by
 that measure.  This engine computes the backward on dense index spaces (no gradient support yet: every column of
-P_own / P_halo gets its gradient row; the reverse exchange is blocking); the arithmetic equals `mrgcn_amd.models.rgcn.RGCN` on one GPU (tests).
+P_own / P_halo gets its gradient row); both exchanges are started first and run under the product over the rank's own
+columns (forward) and under that product's backward (reverse exchange); the arithmetic equals `mrgcn_amd.models.rgcn.RGCN` on one GPU (tests).
 One process per GPU, torch.distributed (RCCL all-to-all over xGMI; gloo, CPU staged, in the tests)."""
 from __future__ import annotations
 
@@ -109,42 +110,67 @@ class _Pending:
         self.work = self.buf = self.host = None
 
 
-class _AllToAllRowsStart(torch.autograd.Function):
-    """Starts the exchange of operand rows and returns at once (RCCL: the collective runs on the communicator's own
-    stream, the caller's stream goes on with the local product; `_AllToAllRowsWait` makes it wait).  gloo (the tests):
-    staged through the host, blocking.  Backward: the gradient rows go back to their senders (blocking)."""
+def start_rows_exchange(send: torch.Tensor, in_splits, out_splits, group, pending: _Pending) -> torch.Tensor:
+    """Starts the all-to-all of `send`'s rows (no autograd: a side effect) and returns the receive buffer at once.  Over
+    RCCL the collective runs on the communicator's own stream; `pending.work` is what the consumer waits on.  gloo (the
+    tests): staged through the host, blocking."""
+    n_out = int(sum(out_splits))
+    send = send.detach()
+    if _staged(send, group) or dist.get_backend(group) != "nccl":
+        pending.buf = all_to_all_rows(send, in_splits, out_splits, group)
+        pending.work = None
+        return pending.buf
+    out = torch.empty((n_out,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    pending.work = dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(out_splits),
+                                          input_split_sizes=list(in_splits), group=group, async_op=True)
+    pending.buf = out
+    return out
+
+
+def wait_rows_exchange(pending: _Pending):
+    if pending.work is not None:
+        pending.work.wait()   # the current stream waits for the communicator's
+        pending.work = None
+
+
+class _SendRows(torch.autograd.Function):
+    """send = M[pos] (the operand rows the other ranks read).  Backward: the gradient rows that came back from those
+    ranks — `_ExchangedRows.backward` STARTED their exchange and handed the receive buffer on; here, after the backward
+    of the product over this rank's own columns (created later in the forward: autograd runs it first), the stream waits
+    for it and adds the rows into the operand's gradient."""
 
     @staticmethod
-    def forward(ctx, send, in_splits, out_splits, group, pending: _Pending):
-        ctx.in_splits, ctx.out_splits, ctx.group = in_splits, out_splits, group
-        n_out = int(sum(out_splits))
-        if _staged(send, group):
-            pending.buf = all_to_all_rows(send, in_splits, out_splits, group)
-            return pending.buf
-        out = torch.empty((n_out,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        pending.work = dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(out_splits),
-                                              input_split_sizes=list(in_splits), group=group, async_op=True)
-        pending.buf = out
-        return out
+    def forward(ctx, M, pos, back: _Pending):
+        ctx.back, ctx.n = back, M.shape[0]
+        ctx.save_for_backward(pos)
+        return M.index_select(0, pos)
 
     @staticmethod
     def backward(ctx, g):
-        return all_to_all_rows(g.contiguous(), ctx.out_splits, ctx.in_splits, ctx.group), None, None, None, None
+        (pos,) = ctx.saved_tensors
+        wait_rows_exchange(ctx.back)
+        dM = torch.zeros((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        dM.index_add_(0, pos, g)
+        return dM, None, None
 
 
-class _AllToAllRowsWait(torch.autograd.Function):
-    """The current stream waits for the exchange started by `_AllToAllRowsStart`; identity for autograd."""
+class _ExchangedRows(torch.autograd.Function):
+    """The autograd node of the operand-row exchange.  Forward: the exchange itself was started earlier
+    (`start_rows_exchange`, before the product over the rank's own columns); this node waits for it and returns the
+    received rows.  It is created AFTER that product, so that in the backward it runs BEFORE the product's: the reverse
+    exchange (gradient rows back to their senders) is started here and is in flight under the own product's backward;
+    `_SendRows.backward` waits for it."""
 
     @staticmethod
-    def forward(ctx, recv, pending: _Pending):
-        if pending.work is not None:
-            pending.work.wait()
-            pending.work = None
-        return recv.view_as(recv)
+    def forward(ctx, send, in_splits, out_splits, group, fwd: _Pending, back: _Pending):
+        ctx.in_splits, ctx.out_splits, ctx.group, ctx.back = in_splits, out_splits, group, back
+        wait_rows_exchange(fwd)
+        return fwd.buf.view_as(fwd.buf)
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        out = start_rows_exchange(g.contiguous(), ctx.out_splits, ctx.in_splits, ctx.group, ctx.back)
+        return out, None, None, None, None, None
 
 
 # ---- the two local halves of a layer as autograd functions -----------------------------------------------------------
@@ -409,15 +435,16 @@ class HaloPartitionedRGCN(nn.Module):
                 if B > 0:
                     W_F = Fn._BasisContract.apply(layer.weight_F_comp, W_F)
             M_col = _OperandFn.apply(hp.p_col, F, weight_I, comp_I, Xin, W_F)           # my columns' operand rows
-            # the rows the other ranks read leave first; the product over my own columns runs under the exchange
-            pending = _Pending()
-            recv = _AllToAllRowsStart.apply(M_col.index_select(0, hp.send_pos), hp.in_splits, hp.out_splits, self.group,
-                                            pending)
+            # the rows the other ranks read leave first; the product over my own columns runs under the exchange — and
+            # its backward under the reverse exchange (see _ExchangedRows)
+            fwd, back = _Pending(), _Pending()
+            send = _SendRows.apply(M_col, hp.send_pos, back)
+            start_rows_exchange(send, hp.in_splits, hp.out_splits, self.group, fwd)
             M_own = torch.zeros((hp.p_own.nop, M_col.shape[1]), dtype=torch.float32, device=M_col.device)
             M_own = M_own.index_copy(0, hp.own_dst, M_col.index_select(0, hp.own_src))
             b = layer.b if layer.bias else None
             Y = _ProductFn.apply(hp.p_own, M_own, F, None, False)
-            recv = _AllToAllRowsWait.apply(recv, pending)
+            recv = _ExchangedRows.apply(send, hp.in_splits, hp.out_splits, self.group, fwd, back)
             if hp.halo_columns > 0:
                 M_halo = torch.zeros((hp.p_halo.nop, M_col.shape[1]), dtype=torch.float32, device=M_col.device)
                 M_halo = M_halo.index_copy(0, hp.halo_dst, recv)

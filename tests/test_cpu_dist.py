@@ -240,3 +240,72 @@ def test_halo_requests_and_operand_row_exchange_gloo(world):
     ch = choose_partition(g.rows, g.cols, g.num_nodes, world, [16, 4])
     assert ch["halo_columns_per_rank"] == [res[r][1] for r in range(world)]
     assert ch["choice"] in ("halo", "column") and ch["halo"] == float(np.mean(ch["halo_columns_per_rank"])) * 20 * 4
+
+
+# ---- the halo engine's exchange nodes: values over gloo (world 2) and the ORDER of the backward -----------------------
+def _halo_order_worker(rank, world, port, out):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from mrgcn_amd import partition_halo as ph
+    dist.init_process_group("gloo")
+    log = []
+    real_start = ph.start_rows_exchange
+
+    def logged_start(send, i, o, group, pending):
+        log.append("exchange started")
+        return real_start(send, i, o, group, pending)
+
+    class _Own(torch.autograd.Function):   # stands in for the product over the rank's own columns
+        @staticmethod
+        def forward(ctx, M):
+            return M * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            log.append("own product backward")
+            return g * 2.0
+
+    real_wait = ph.wait_rows_exchange
+
+    def logged_wait(p):
+        log.append("exchange awaited")
+        return real_wait(p)
+
+    ph.start_rows_exchange, ph.wait_rows_exchange = logged_start, logged_wait
+    try:
+        # every rank sends its rows 0, 1 to the other rank (world 2) and receives two
+        M = (torch.arange(8, dtype=torch.float64).view(4, 2) + 100.0 * rank).requires_grad_(True)
+        pos = torch.tensor([0, 1]) if rank == 0 else torch.tensor([3, 1])
+        splits_in = [0, 2] if rank == 0 else [2, 0]
+        fwd, back = ph._Pending(), ph._Pending()
+        send = ph._SendRows.apply(M, pos, back)
+        ph.start_rows_exchange(send, splits_in, splits_in, None, fwd)
+        Y = _Own.apply(M).sum()
+        recv = ph._ExchangedRows.apply(send, splits_in, splits_in, None, fwd, back)
+        del log[:]
+        (Y + (recv * (rank + 1.0)).sum()).backward()
+    finally:
+        ph.start_rows_exchange, ph.wait_rows_exchange = real_start, real_wait
+    out[rank] = (list(log), recv.detach().tolist(), M.grad.tolist())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_halo_reverse_exchange_starts_before_the_own_products_backward():
+    """`HaloPartitionedRGCN.forward` builds its graph so that autograd STARTS the reverse exchange of gradient rows, then
+    runs the backward of the product over the rank's own columns, and only then waits for the rows and adds them into
+    the operand's gradient (over RCCL: the collective is in flight under that product's backward).  Values: a row's
+    gradient comes back from the rank that read it."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_halo_order_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = dict(out)
+    for rank in (0, 1):
+        log, recv, grad = res[rank]
+        assert log == ["exchange started", "own product backward", "exchange awaited"], log
+    # rank 0 received rank 1's rows 3 and 1, rank 1 received rank 0's rows 0 and 1
+    assert res[0][1] == [[106.0, 107.0], [102.0, 103.0]] and res[1][1] == [[0.0, 1.0], [2.0, 3.0]]
+    # d/dM: 2 everywhere (the own product) + the reader's scale on the rows it read (rank 1 scales by 2, rank 0 by 1)
+    assert res[0][2] == [[4.0, 4.0], [4.0, 4.0], [2.0, 2.0], [2.0, 2.0]]
+    assert res[1][2] == [[2.0, 2.0], [3.0, 3.0], [2.0, 2.0], [3.0, 3.0]]
