@@ -1465,11 +1465,12 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
     const int KS = (B + 15) / 16;
     const int NQ = (B * F + 255) / 256;  // 16-byte pieces of a V block per lane (<= KS)
     // the addend as 16-byte pieces through LDS (k_mix_fwd_mfma, ADD = 2) when its rows allow it
+    const size_t lds_plain =
+        ((size_t)((R * (KS * 16 + 4) + 3) & ~3) + (size_t)(kFwdTB / 64) * tn * B * F) * sizeof(float);
+    const size_t lds_add = (size_t)(kFwdTB / 64) * kAddPieces * 4 * sizeof(float);
     const bool add_vec = addend && ldA % 4 == 0 && ldA <= 16 && (((uintptr_t)addend) & 15) == 0 && !node_ids &&
-                         cfg(CFG_MIX_ADD_VEC) != 0;
-    const size_t lds =
-        ((size_t)((R * (KS * 16 + 4) + 3) & ~3) + (size_t)(kFwdTB / 64) * tn * B * F +
-         (add_vec ? (size_t)(kFwdTB / 64) * kAddPieces * 4 : 0)) * sizeof(float);
+                         cfg(CFG_MIX_ADD_VEC) != 0 && lds_plain + lds_add <= 150 * 1024;  // (else the 4-byte form)
+    const size_t lds = lds_plain + (add_vec ? lds_add : 0);
     if (mfma_on && B <= 64 && F <= 16 && (B * F) % 4 == 0 && (((uintptr_t)V) & 15) == 0 &&
         lds <= 150 * 1024 && !(node_ids && (addend || sizeof(OT) != 4))) {
       const int64_t want = ((N + tn - 1) / tn + (kFwdTB / 64) - 1) / (kFwdTB / 64);

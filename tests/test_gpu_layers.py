@@ -333,6 +333,18 @@ def test_basis_mix_forward_shapes_through_the_c_abi(B, F, with_addend):
         scale = np.abs(want).max()
         np.testing.assert_allclose(got[mpos][:, :F], want, rtol=tol, atol=tol * scale, err_msg=sfx)
         assert (got[:, F:] == 7.0).all() or (got[:, F:] == 0.0).all()   # padding: untouched (or zeroed)
+        if with_addend:
+            # the addend through LDS as 16-byte pieces (the default where its rows allow it) and as 4-byte loads per
+            # node are the same arithmetic: equal bits
+            old = L.set_config(mix_add_vec=0)
+            try:
+                M2 = torch.full((plan.nop, ld), 7.0, dtype=dt, device="cuda")
+                L.check(getattr(lib, "mrgcn_basis_mix_fwd_" + sfx)(
+                    plan.handle, Vt.data_ptr(), ct.data_ptr(), B, F, at.data_ptr(), ldA, M2.data_ptr(), ld, s))
+            finally:
+                L.set_config(**old)
+            assert torch.equal(M.view(torch.int16 if dt == torch.bfloat16 else torch.int32),
+                               M2.view(torch.int16 if dt == torch.bfloat16 else torch.int32)), sfx
 
 
 @pytest.mark.parametrize("zero_frac", [0.0, 0.5, 0.93, 1.0])
