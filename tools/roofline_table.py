@@ -45,7 +45,7 @@ def main():
     ALG = collections.OrderedDict([  # kernel-name prefix -> (what is counted, bytes)
         ("mrgcn::k_xform_mfma_fwd<1, false, 16, float, false>",
          ("layer-0 transform: X read once + W + addend written + indices", N * K0 * 4 + R * K0 * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8)),
-        ("mrgcn::k_mix_fwd_mfma<3, 2, 2, true, float",
+        ("mrgcn::k_mix_fwd_mfma<3, 2, 2, 2, float",
          ("basis mix: V read once + addend read + M written + 3 index arrays", 4 * B * N * F0 + NCOLS * (LD * 4 + F0 * 4) + NCOLS * 8 + N * 4)),
         ("mrgcn::k_spmm3<4, 4, false, float, true, 7>", ("forward product, F=10 (SURVEY 8d formula; the F=11 launches move 7.7 % more)", spmm_bytes(N, NCOLS, F0))),
         ("mrgcn::k_xform_mfma_fwd<1, false, 1, float, false>",
