@@ -1034,7 +1034,7 @@ def partitioned_probe(args, name, dev, world, rank, steps=5, warmup=2, emit=None
     return out
 
 
-def run_probe_child(args, workload, k, world, rank, local_rank):
+def run_probe_child(args, workload, k, world, rank, local_rank, limit=None):
     """Runs `partitioned_probe` in a CHILD process per rank, with a process group of its own (the parent's rendezvous
     port + 1 + k): whatever happens in there — an RCCL failure, a rank that runs out of memory while the others wait
     in a collective — ends with the child (killed after a time limit at the latest) and leaves the parent, its
@@ -1050,7 +1050,8 @@ def run_probe_child(args, workload, k, world, rank, local_rank):
     cmd = [sys.executable, os.path.abspath(__file__), "--probe-child", workload, "--gpus", str(world),
            "--seed", str(args.seed), "--value-mode", args.value_mode,
            "--scale", str(args.scale if workload == args.workload else 1.0)]
-    limit = float(os.environ.get("MRGCN_BENCH_PROBE_TIMEOUT", "420" if workload == "synth10m" else "240"))
+    if limit is None:
+        limit = float(os.environ.get("MRGCN_BENCH_PROBE_TIMEOUT", "420" if workload == "synth10m" else "240"))
     def last_record(text):
         for line in reversed((text or "").strip().splitlines()):
             if line.startswith("{"):
@@ -1233,11 +1234,22 @@ def main():
     if world > 1 and not partitioned and os.environ.get("MRGCN_BENCH_PARTITION_PROBE", "1") != "0":
         part_records = {}
         probes = [name] + (["synth10m"] if name == "am" and args.scale == 1.0 else [])
+        # the probes share ONE time budget (what a hung first contact with a multi-GPU node may add to the run: the
+        # replica line must still leave before whoever launched this gives up); every rank takes the same decision
+        # (the slowest rank's clock)
+        budget = float(os.environ.get("MRGCN_BENCH_PROBE_BUDGET", "420"))
+        t_probe = time.perf_counter()
         for k, wl in enumerate(probes):
+            spent = mdist.max_over_ranks(time.perf_counter() - t_probe, dev)
+            own = float(os.environ.get("MRGCN_BENCH_PROBE_TIMEOUT", "420" if wl == "synth10m" else "240"))
+            limit = min(own, budget - spent)
+            if limit < 90.0:
+                part_records[wl] = {"skipped": "%.0f s of the probes' %.0f s budget left" % (budget - spent, budget)}
+                continue
             if wl != name:   # drop the replica's model first: the big graph wants the memory
                 step = None
                 drop_live()
-            part_records[wl] = run_probe_child(args, wl, k, world, rank, local_rank)
+            part_records[wl] = run_probe_child(args, wl, k, world, rank, local_rank, limit=limit)
             barrier()
 
     out = None
