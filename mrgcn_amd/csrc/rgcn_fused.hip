@@ -1375,20 +1375,23 @@ using namespace mrgcn;
 
 namespace {
 
-// the columns a basis mix walks: a plan's (every node) or a gradient support's (a node list, rows by live number)
-// dynamic LDS beyond 48 KB needs the kernel's limit raised once — per kernel, whatever call site launches it
+// dynamic LDS beyond 48 KB needs the kernel's limit raised once — per (device, kernel), whatever call site launches it
 hipError_t raise_lds_limit(const void *fn, size_t lds) {
   static std::mutex mu;
-  static std::unordered_map<const void *, size_t> allowed;
+  static std::unordered_map<uint64_t, size_t> allowed;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
   std::lock_guard<std::mutex> g(mu);
-  size_t &a = allowed[fn];
+  size_t &a = allowed[(uint64_t)(uintptr_t)fn * 64 + (uint64_t)(dev & 63)];
   if (a == 0) a = 48 * 1024;
   if (lds <= a) return hipSuccess;
-  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e == hipSuccess) a = lds;
   return e;
 }
 
+// the columns a basis mix walks: a plan's (every node) or a gradient support's (a node list, rows by live number)
 struct MixCols {
   const int32_t *nptr, *urel, *mpos, *unode, *node_ids;
   int64_t N, ncols;
