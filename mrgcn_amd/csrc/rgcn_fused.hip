@@ -228,7 +228,7 @@ __device__ __forceinline__ void mix_node_tiles(int32_t c0, int32_t c1, int32_t b
       for (int reg = 0; reg < 4; ++reg)
         if (cb + 4 * kq + reg < c1) store_operand<OT>(M + (int64_t)pos[reg] * ldM + m, acc[reg]);
     }
-    if (NEAR && ADD) break;  // (such a node has one tile)
+    if (NEAR && ADD == 1) break;  // (such a node has one tile: `pa` holds one tile's words)
   }
 }
 
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_mix_fwd_wide(const int32_t *__restrict_
 // <= 16 floats, ldA % 4 == 0): they come in as one or two 16-byte loads per lane, a step ahead like the V blocks, and
 // reach the accumulator layout through a per-wave LDS piece — instead of four 4-byte loads per node whose lanes
 // address four different rows (ADD = 1, kept for other row strides).
-constexpr int kAddPieces = 128;  // 16-byte pieces of addend rows per step: 2 nodes x 16 columns x 16 floats
+constexpr int kAddPieces = 128;  // 16-byte pieces of addend rows per step (two loads per lane): 42 columns at ldA = 12
 template <int KS, int NQ, int TN, int ADD, typename OT, bool IDS = false>
 __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
     const int32_t *__restrict__ nptr, const int32_t *__restrict__ urel, const int32_t *__restrict__ mpos,
@@ -361,13 +361,15 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
     ur_cur = ur_n1;
     mp_cur = mp_n1;
     bool near = cend - cbase <= 64;  // wave uniform
+    // ADD == 2: the step's addend rows must fit the wave's LDS piece (nodes of any size: 42 columns at ldA = 12 — at
+    // the AM shape 1.7 % of the steps / 12 % of the columns leave the prefetched path; with one tile per node, the
+    // 4-byte form's limit, 6.7 % / 26 %)
+    if (ADD == 2) near = near && (cend - cbase) * q4 <= kAddPieces;
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      if (ADD) {
-        if (ADD == 1) {
+      if (ADD == 1) {  // (one tile's addend words per node in `pa`)
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) pa_cur[i][reg] = pa_n1[i][reg];
-        }
+        for (int reg = 0; reg < 4; ++reg) pa_cur[i][reg] = pa_n1[i][reg];
         near = near && __builtin_amdgcn_readlane(np_now, i + 1) - __builtin_amdgcn_readlane(np_now, i) <= 16;
       }
       // this step's V blocks: registers -> the wave's tile
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
       for (int q = 0; q < NQ; ++q)
         if (lane + 64 * q < nf4) dst[lane + 64 * q] = pv[i][q];
     }
-    if (ADD == 2) {  // this step's addend rows (a NEAR step: at most TN x 16 columns x ldA <= 16 floats)
+    if (ADD == 2) {  // this step's addend rows (used by a NEAR step: at most kAddPieces 16-byte pieces)
       reinterpret_cast<f32x4m *>(s_add)[lane] = pa4_n1[0];
       reinterpret_cast<f32x4m *>(s_add)[64 + lane] = pa4_n1[1];
     }
