@@ -158,6 +158,9 @@ int xform_cols_lds(const mrgcn_plan *p, bool operand_order, const float *In, int
 // replays once and then faults on ("write access to a read-only page", second replay; found with the 174 504-byte
 // histogram of mrgcn_distmult_orders_counting) — kernel nodes replay fine.
 hipError_t fill_async(void *dst, int byte_value, size_t bytes, hipStream_t s);
+// dynamic LDS beyond 48 KB needs the kernel's limit raised once — per (device, kernel), whatever call site launches it
+// (plan.hip); every launch with more than 48 KB of dynamic LDS goes through it
+hipError_t raise_lds_limit(const void *fn, size_t lds);
 // the product scratch of `p` for work submitted on stream `s` (see mrgcn_plan::stream_scratch); the first product of a
 // second, third ... stream allocates that stream's set and must therefore not run inside a stream capture
 int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t **ticket);

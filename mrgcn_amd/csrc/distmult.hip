@@ -748,14 +748,8 @@ int mrgcn_distmult_orders_counting(const int64_t *triples, int64_t n, int64_t nu
   // (the columns whose bins fit LDS: the array is sized for the larger of them)
   const int64_t big = std::max(num_nodes <= kCountLdsBins ? num_nodes : 0, num_relations <= kCountLdsBins ? num_relations : 0);
   const size_t lds1 = (size_t)big * sizeof(int32_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)k_count3, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kCountLdsBins * (int)sizeof(int32_t)));
-    MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)k_fill3, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      2 * kCountLdsBins * (int)sizeof(int32_t)));
-    attr_set = true;
-  }
+  MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)k_count3, kCountLdsBins * sizeof(int32_t)));
+  MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)k_fill3, 2 * kCountLdsBins * sizeof(int32_t)));
   k_count3<<<dim3(blocks, 3), dim3(kCountTB), lds1, s>>>(triples, n, cnt, stride, num_nodes, num_relations);
   k_scan3<<<dim3(3), dim3(1024), 0, s>>>(cnt, stride, num_nodes, num_relations);
   k_fill3<<<dim3(blocks, 3), dim3(kCountTB), 2 * lds1, s>>>(triples, n, cnt, stride, num_nodes, num_relations, order_s,

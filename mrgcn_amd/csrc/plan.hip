@@ -1225,6 +1225,22 @@ __global__ void k_fill_bytes(uint8_t *__restrict__ dst, uint32_t word, size_t he
 }
 }  // namespace
 
+hipError_t raise_lds_limit(const void *fn, size_t lds) {
+  static std::mutex mu;
+  static std::unordered_map<uint64_t, size_t> allowed;
+  if (lds <= 48 * 1024) return hipSuccess;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> g(mu);
+  size_t &a = allowed[(uint64_t)(uintptr_t)fn * 64 + (uint64_t)(dev & 63)];
+  if (a == 0) a = 48 * 1024;
+  if (lds <= a) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) a = lds;
+  return e;
+}
+
 hipError_t fill_async(void *dst, int byte_value, size_t bytes, hipStream_t s) {
   if (bytes == 0) return hipSuccess;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

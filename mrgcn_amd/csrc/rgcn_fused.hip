@@ -1377,22 +1377,6 @@ using namespace mrgcn;
 
 namespace {
 
-// dynamic LDS beyond 48 KB needs the kernel's limit raised once — per (device, kernel), whatever call site launches it
-hipError_t raise_lds_limit(const void *fn, size_t lds) {
-  static std::mutex mu;
-  static std::unordered_map<uint64_t, size_t> allowed;
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  std::lock_guard<std::mutex> g(mu);
-  size_t &a = allowed[(uint64_t)(uintptr_t)fn * 64 + (uint64_t)(dev & 63)];
-  if (a == 0) a = 48 * 1024;
-  if (lds <= a) return hipSuccess;
-  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess) a = lds;
-  return e;
-}
-
 // the columns a basis mix walks: a plan's (every node) or a gradient support's (a node list, rows by live number)
 struct MixCols {
   const int32_t *nptr, *urel, *mpos, *unode, *node_ids;
@@ -1817,12 +1801,7 @@ int mix_bwd_nm_launch_arrays(const int32_t *nptr, const int32_t *urel, int64_t N
 #define NODE_GO(T)                                                                                        \
   do {                                                                                                    \
     auto kfn = k_mix_bwd_nm<T>;                                                                           \
-    static size_t lds_allowed = 48 * 1024; /* per instantiation: raise the dynamic-LDS limit once */      \
-    if (lds > lds_allowed) {                                                                              \
-      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                        (int)lds));                                                       \
-      lds_allowed = lds;                                                                                  \
-    }                                                                                                     \
+    MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, lds));                                                 \
     kfn<<<dim3((unsigned)grid), dim3(tb), lds, s>>>(nptr, urel, dM, ldM, V, comp, N, R, B, F, dV,        \
                                                          dcomp, dV_sumsq, top_rel, col_live,              \
                                                          node_cur, dc_in_lds);                           \
@@ -1953,11 +1932,7 @@ int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8
 #define ADAM_LIST_GO(NH_)                                                                                          \
   do {                                                                                                             \
     auto kfn = k_adam_rows_list<NH_, true>;                                                                        \
-    static size_t lds_allowed = 48 * 1024;                                                                         \
-    if (lds > lds_allowed) {                                                                                       \
-      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      lds_allowed = lds;                                                                                           \
-    }                                                                                                              \
+    MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, lds));                                                 \
     kfn<<<dim3((unsigned)lgrid), dim3(kFusedTB), lds, s>>>(lnode, lnptr, urel, dM, ldM, comp, NL, R, B, F, param,  \
                                                            exp_avg, exp_avg_sq, row_ever, lr, beta1, beta2, eps,   \
                                                            bc1, bc2s, grad_scale, bc_dev);                         \
@@ -1969,11 +1944,7 @@ int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8
   }
   if (!listed || ever_outside) {
     auto kfn = k_adam_rows_fused;
-    static size_t lds_allowed = 48 * 1024;
-    if (lds > lds_allowed) {
-      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      lds_allowed = lds;
-    }
+    MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, lds));
     kfn<<<dim3((unsigned)grid), dim3(kFusedTB), lds, s>>>(nptr, urel, col_live, dM, ldM, comp, N, R, B, F,
                                                           param, exp_avg, exp_avg_sq, row_cur, row_ever, lr, beta1,
                                                           beta2, eps, bc1, bc2s, grad_scale, bc_dev, listed ? 1 : 0);
@@ -2085,11 +2056,7 @@ int mrgcn_basis_contract_bwd_f32(const float *comp, const float *V, const float 
 #define CONTRACT_BWD(BT_)                                                                                          \
   do {                                                                                                             \
     auto kfn = k_basis_contract_bwd<BT_>;                                                                          \
-    static size_t lds_allowed = 48 * 1024; /* per instantiation: raise the dynamic-LDS limit once */               \
-    if (sh > lds_allowed) {                                                                                        \
-      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));  \
-      lds_allowed = sh;                                                                                            \
-    }                                                                                                              \
+    MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, sh));                                                  \
     kfn<<<grid, dim3(kTB), sh, (hipStream_t)stream>>>(comp, V, dW, R, B, X, dcomp, dV, dv_blocks, tiled);          \
   } while (0)
   if (BT == 16) CONTRACT_BWD(16);

@@ -409,11 +409,7 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
 #define SUP_GO4(T, NB_, TB_, EX_)                                                                                   \
   do {                                                                                                              \
     auto kfn = k_mix_bwd_sup<T, NB_, TB_, EX_>;                                                                     \
-    static size_t lds_allowed = 48 * 1024; /* per instantiation: raise the dynamic-LDS limit once */                \
-    if (lds > lds_allowed) {                                                                                        \
-      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
-      lds_allowed = lds;                                                                                            \
-    }                                                                                                               \
+    MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, lds));                                                 \
     kfn<<<dim3((unsigned)grid), dim3(TB_), lds, s>>>(q->lnode, q->lnptr, q->lrel, dM, ldM, V, comp, q->NL, R, B, F, \
                                                      D, sq_part);                                                   \
   } while (0)

@@ -675,11 +675,7 @@ int xform_cols_lds(const mrgcn_plan *p, bool operand_order, const float *In, int
 #define XC_GO(KT_, O_)                                                                                             \
   do {                                                                                                             \
     auto kfn = k_xform_cols_lds<KT_, O_>;                                                                          \
-    static size_t lds_allowed = 48 * 1024;                                                                         \
-    if (lds > lds_allowed) {                                                                                       \
-      MRGCN_HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      lds_allowed = lds;                                                                                           \
-    }                                                                                                              \
+    MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, lds));                                                 \
     kfn<<<dim3((unsigned)grid), dim3(1024), lds, s>>>(pnode, prel, npos, In, ldIn, K, W, R, F, FP, (O_ *)Out, ldOut); \
   } while (0)
   const int KT = K <= 4 ? 4 : K <= 8 ? 8 : K <= 12 ? 12 : 16;

@@ -271,7 +271,8 @@ def _bias_grad(dY: torch.Tensor, row_flags=None) -> torch.Tensor:
                                               ws.data_ptr(), ws.numel(), _stream(dY.device)), "mrgcn_colsum_rows_f32")
         return out
     if row_flags is not None:
-        return (dY * row_flags.to(dY.dtype)[:, None]).sum(0)
+        # unflagged rows may never have been written: select, do not multiply (NaN * 0 is NaN)
+        return torch.where(row_flags.bool()[:, None], dY, torch.zeros((), dtype=dY.dtype, device=dY.device)).sum(0)
     return dY.sum(0)
 
 

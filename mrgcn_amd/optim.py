@@ -189,7 +189,9 @@ class ReferenceLayoutAdam(torch.optim.Adam):
 
     def __setstate__(self, state):   # (unpickling / deepcopy drop instance hooks)
         super().__setstate__(state)
-        self.__dict__.pop("_mrgcn_reference_layout", None)
+        # load_state_dict ends in __setstate__ too, with the hook dicts intact: register again only when they are gone
+        if not self.__dict__.get("_optimizer_state_dict_post_hooks"):
+            self.__dict__.pop("_mrgcn_reference_layout", None)
         speak_reference_layout(self)
 
 

@@ -301,7 +301,9 @@ class HaloPlans:
     """P_col (the columns whose source node this rank owns, over ALL rows: operand construction and its backward),
     P_own (this rank's rows over its OWN columns) and P_halo (this rank's rows over the REMOTE columns they read): the
     product of a layer is `P_own . M_own + P_halo . M_halo`, and the exchange that fills `M_halo` is in flight while the
-    first product runs.  Plus the maps between those operands and the exchange buffers."""
+    first product runs.  Plus the maps between those operands and the exchange buffers.  The plans are built WITHOUT
+    operand replicas whatever the library's default says: the operands of `P_own` / `P_halo` are filled through index
+    maps over their MPOS rows, a replica row would stay zero."""
 
     def __init__(self, part: NodePartition, rows, cols, vals, num_relations: int, device, operand_row_bytes, group=None):
         R, N, S, rank, world = num_relations, part.N, part.S, part.rank, part.world
@@ -310,7 +312,7 @@ class HaloPlans:
         lr, lc, lv = part.local_coo(rows, cols, vals, R)
         A_col = torch.sparse_coo_tensor(torch.from_numpy(np.stack([lr, lc])), torch.from_numpy(lv),
                                         (part.Np, R * S)).to(device)
-        self.p_col = GraphPlan(A_col, S, R, operand_row_bytes=operand_row_bytes)
+        self.p_col = GraphPlan(A_col, S, R, operand_row_bytes=operand_row_bytes, replicate=False)
         del A_col
         # my rows, split by who owns the source node
         mine = (rows >= part.j0) & (rows < part.j1)
@@ -319,14 +321,14 @@ class HaloPlans:
         is_own = (node >= part.j0) & (node < part.j1)
         A_own = torch.sparse_coo_tensor(torch.from_numpy(np.stack([er[is_own], rel[is_own] * S + (node[is_own] - part.j0)])),
                                         torch.from_numpy(ev[is_own]), (S, R * S)).to(device)
-        self.p_own = GraphPlan(A_own, S, R, operand_row_bytes=operand_row_bytes)
+        self.p_own = GraphPlan(A_own, S, R, operand_row_bytes=operand_row_bytes, replicate=False)
         del A_own
         remote = np.unique(node[~is_own])          # the remote source nodes my rows read (rising id)
         Nr = max(len(remote), 1)
         jr = np.searchsorted(remote, node[~is_own])
         A_halo = torch.sparse_coo_tensor(torch.from_numpy(np.stack([er[~is_own], rel[~is_own] * Nr + jr])),
                                          torch.from_numpy(ev[~is_own]), (S, R * Nr)).to(device)
-        self.p_halo = GraphPlan(A_halo, Nr, R, operand_row_bytes=operand_row_bytes)
+        self.p_halo = GraphPlan(A_halo, Nr, R, operand_row_bytes=operand_row_bytes, replicate=False)
         del A_halo
         # P_col: literal id (global) of its compact columns -> operand position
         ulc = self.p_col.export(L.ARR_ULCOL).astype(np.int64)
