@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MRGCN_ABI_VERSION 4
+#define MRGCN_ABI_VERSION 5
 
 enum mrgcn_status {
   MRGCN_OK = 0,
@@ -263,6 +263,27 @@ int mrgcn_rel_transform_fwd_bf16(const mrgcn_plan_t *plan, const float *X, int64
                                  const float *W, int32_t F, uint16_t *Out, int64_t ldOut,
                                  int32_t operand_order, void *stream);
 
+/* ---- the bf16 pipeline (BASELINE config 3; SURVEY 8d "dense operands in bf16 with fp32 accumulation") ---------
+ * The reference computes graph.py:93-95 in fp32 and has no reduced precision anywhere; in this mode every ACTIVATION
+ * the layer reads or writes in bulk is stored in bf16 — the layer input X (rows of ldX elements, ldX % 8 == 0, zeros
+ * past K), the feature term's rows (`addend`), the compact operand M — while parameters, every accumulation, the
+ * layer output Y and the whole backward's sums stay fp32.
+ *   mrgcn_cast_rows_bf16          dst[row, 0:ldDst] = [ bf16(src[row, 0:K]) | 0 ]  (round to nearest even)
+ *   mrgcn_rel_transform_fwd_xbf16 mrgcn_rel_transform_fwd_f32 on bf16 input rows, v_mfma_f32_16x16x32_bf16 (W is
+ *                                 rounded to bf16 as it is staged): K <= 256, F <= ldOut <= 16; Out fp32 or bf16
+ *   mrgcn_basis_mix_fwd_abf16     mrgcn_basis_mix_fwd_f32 / _bf16 with the addend rows in bf16 (ldA elements)
+ *   mrgcn_support_rel_transform_bwd_xbf16   (below, with the gradient supports) */
+int mrgcn_cast_rows_bf16(const float *src, int64_t ldSrc, int64_t rows, int32_t K, uint16_t *dst, int64_t ldDst,
+                         void *stream);
+int32_t mrgcn_rel_transform_xbf16_supported(const mrgcn_plan_t *plan, int32_t K, int32_t F, int64_t ldX,
+                                            int64_t ldOut);
+int mrgcn_rel_transform_fwd_xbf16(const mrgcn_plan_t *plan, const uint16_t *X, int64_t ldX, int32_t K,
+                                  const float *W, int32_t F, void *Out, int64_t ldOut, int32_t operand_order,
+                                  int32_t out_bf16, void *stream);
+int mrgcn_basis_mix_fwd_abf16(const mrgcn_plan_t *plan, const float *V, const float *comp, int32_t B, int32_t F,
+                              const uint16_t *addend, int64_t ldA, void *M, int64_t ldM, int32_t out_bf16,
+                              void *stream);
+
 
 /* ---- compact dense operand: backward (autograd of graph.py:69-72, :93-94) -------------
  *     dV[j, b, :]  = sum_{c in node j} comp[r_c, b] * dM[c, :]          (node-major, like V)
@@ -458,6 +479,12 @@ int mrgcn_support_rel_transform_bwd_f32(const mrgcn_support_t *support, const fl
                                         int64_t ldX, int32_t K, const float *W, int32_t F, float *dX, int64_t lddX,
                                         float *dW, float *workspace, int64_t workspace_floats,
                                         int32_t relu_mask_from_x, void *stream);
+/* the same with the layer input X in bf16 rows (the bf16 pipeline; ldX in elements): dW's products and sums are fp32
+ * on the widened elements; dX (= dM . W^T summed per node) never reads X */
+int mrgcn_support_rel_transform_bwd_xbf16(const mrgcn_support_t *support, const float *dM, int64_t ldM,
+                                          const uint16_t *X, int64_t ldX, int32_t K, const float *W, int32_t F,
+                                          float *dX, int64_t lddX, float *dW, float *workspace,
+                                          int64_t workspace_floats, void *stream);
 /* dlogits[idx[i], 0:C] = *g * drows[i, 0:C] for the n labelled rows ONLY (idx without repeats): the rest of dlogits
  * is not touched — for a consumer that reads the labelled rows only (mrgcn_support_spmm_t_f32).  The 73 MB zero fill
  * of mrgcn_softmax_xent_bwd_f32 (AM shape) goes away. */

@@ -21,7 +21,7 @@ OK = 0
 VAL_I8, VAL_F32 = 0, 1
 PLAN_PRUNE_ZEROS, PLAN_REPLICATE, PLAN_NO_REPLICATE, PLAN_LEAN = 1, 2, 4, 8
 VIEW_LITERAL, VIEW_COMPACT, VIEW_TRANSPOSED = 0, 1, 2
-ABI_VERSION = 4  # include/mrgcn_hip.h: MRGCN_ABI_VERSION
+ABI_VERSION = 5  # include/mrgcn_hip.h: MRGCN_ABI_VERSION
 SPMM_RELU, SPMM_PAD_WRITABLE, SPMM_TWO_PASS = 1, 2, 4  # flag word of mrgcn_spmm_f32 / _bf16 (`relu` argument)
 (ARR_ROWPTR, ARR_LCOL, ARR_CCOL, ARR_VAL, ARR_CPTR, ARR_CROW, ARR_CVAL, ARR_UREL, ARR_UNODE,
  ARR_NPTR, ARR_ROWIDX, ARR_ULCOL, ARR_RPERM, ARR_RELPTR, ARR_MPOS, ARR_MCOL, ARR_MVAL, ARR_ROWMAP,
@@ -80,6 +80,12 @@ SIGNATURES = {
     "mrgcn_basis_mix_fwd_bf16": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _i64, _p]),
     "mrgcn_gather_rows_bf16": (C.c_int, [_p, _p, _i32, _p, _i64, _p, _i64, _p]),
     "mrgcn_rel_transform_fwd_bf16": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p]),
+    "mrgcn_cast_rows_bf16": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),
+    "mrgcn_rel_transform_xbf16_supported": (_i32, [_p, _i32, _i32, _i64, _i64]),
+    "mrgcn_rel_transform_fwd_xbf16": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p]),
+    "mrgcn_basis_mix_fwd_abf16": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _i64, _p, _i64, _i32, _p]),
+    "mrgcn_support_rel_transform_bwd_xbf16": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _i64,
+                                                        _p]),
     "mrgcn_rel_transform_bwd_workspace": (C.c_int64, [_p, _i32, _i32, _i32, _i32]),
     "mrgcn_basis_mix_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     "mrgcn_adam_step_rows_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, C.c_float, C.c_float, C.c_float,

@@ -117,9 +117,16 @@ bool xform_mfma_dw_live_supported(int K, int F);
 int xform_mfma_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const int32_t *rout_idx,
                    const float *In, int64_t ldIn, int K, const float *W, bool trans_w, int F, void *Out,
                    int64_t ldOut, hipStream_t s, bool out_bf16 = false, const uint8_t *col_live = nullptr);
-int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const float *In, int64_t ldIn,
+// (in_bf16: `In` holds bf16 rows, ldIn in elements — the bf16 pipeline's X; the products stay fp32)
+int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const void *In, int64_t ldIn,
                   int K, const float *G, int64_t ldG, int F, float *dW, float *workspace,
-                  int64_t workspace_floats, hipStream_t s, const uint8_t *col_live = nullptr);
+                  int64_t workspace_floats, hipStream_t s, const uint8_t *col_live = nullptr, bool in_bf16 = false);
+// the bf16 pipeline's forward transform (bf16 input rows, v_mfma_f32_16x16x32_bf16), F <= 16, K <= 256, ldOut <= 16
+bool xform_bf16_fwd_supported(int K, int F, int64_t ldIn, int64_t ldOut);
+int xform_bf16_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const int32_t *rout_idx,
+                   const uint16_t *In, int64_t ldIn, int K, const float *W, int F, void *Out, int64_t ldOut,
+                   hipStream_t s, bool out_bf16);
+int cast_rows_bf16(const float *src, int64_t ldSrc, int64_t rows, int K, uint16_t *dst, int64_t ldDst, hipStream_t s);
 int segment_sum(const mrgcn_plan *p, const float *Z, int64_t ldZ, int K, float *dX, int64_t lddX,
                 hipStream_t s, const uint8_t *col_live = nullptr, const float *mask_src = nullptr,
                 int64_t ldMask = 0, uint8_t *row_live = nullptr, const uint8_t *node_live = nullptr);

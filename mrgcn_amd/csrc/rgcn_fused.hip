@@ -173,13 +173,14 @@ constexpr int kFwdTB = 1024;  // 16 waves share one LDS copy of comp (R x 52 flo
 // registers would: the wait sits at the use, after the merge).
 // ADD: 0 no addend; 1 the addend words of a NEAR node's tile in `pa`; 2 the addend rows of the step's columns staged
 // in the wave's LDS piece `s_add` (row of column `base` first, ldA floats per row)
-template <int KS, bool NEAR, int ADD, typename OT>
+// AT: element type of the addend rows (float, or uint16_t = bf16: the bf16 pipeline's feature term)
+template <int KS, bool NEAR, int ADD, typename OT, typename AT = float>
 __device__ __forceinline__ void mix_node_tiles(int32_t c0, int32_t c1, int32_t base, int32_t ur, int32_t mp,
                                                const float (&pa)[4], const int32_t *__restrict__ urel,
                                                const int32_t *__restrict__ mpos, const float *s_comp,
-                                               const float *s_v, int B, int F, const float *__restrict__ addend,
+                                               const float *s_v, int B, int F, const AT *__restrict__ addend,
                                                int64_t ldA, OT *__restrict__ M, int64_t ldM, int m, int kq,
-                                               const float *s_add = nullptr) {
+                                               const AT *s_add = nullptr) {
   constexpr int KP = KS * 16 + 4;
   // B operand of this node: V_j[16 ks + 4 kq + s][m]
   f32x4m bv[KS];
@@ -203,7 +204,7 @@ __device__ __forceinline__ void mix_node_tiles(int32_t c0, int32_t c1, int32_t b
       for (int reg = 0; reg < 4; ++reg) {
         pos[reg] = __shfl(mp, (cb - base + 4 * kq + reg) & 63);
         if (ADD == 1) acc[reg] = pa[reg];
-        if (ADD == 2) acc[reg] = s_add[(min(cb + 4 * kq + reg, c1 - 1) - base) * (int)ldA + min(m, F - 1)];
+        if (ADD == 2) acc[reg] = load_operand<AT>(s_add + (min(cb + 4 * kq + reg, c1 - 1) - base) * (int)ldA + min(m, F - 1));
       }
     } else {
       r = urel[min(cm, c1 - 1)];
@@ -211,7 +212,7 @@ __device__ __forceinline__ void mix_node_tiles(int32_t c0, int32_t c1, int32_t b
       for (int reg = 0; reg < 4; ++reg) {
         const int32_t c = min(cb + 4 * kq + reg, c1 - 1);
         pos[reg] = mpos ? mpos[c] : c;
-        if (ADD) acc[reg] = addend[(int64_t)c * ldA + min(m, F - 1)];
+        if (ADD) acc[reg] = load_operand<AT>(addend + (int64_t)c * ldA + min(m, F - 1));
       }
     }
 #pragma unroll
@@ -285,11 +286,11 @@ __global__ __launch_bounds__(256) void k_mix_fwd_wide(const int32_t *__restrict_
 // reach the accumulator layout through a per-wave LDS piece — instead of four 4-byte loads per node whose lanes
 // address four different rows (ADD = 1, kept for other row strides).
 constexpr int kAddPieces = 128;  // 16-byte pieces of addend rows per step (two loads per lane): 42 columns at ldA = 12
-template <int KS, int NQ, int TN, int ADD, typename OT, bool IDS = false>
+template <int KS, int NQ, int TN, int ADD, typename OT, bool IDS = false, typename AT = float>
 __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
     const int32_t *__restrict__ nptr, const int32_t *__restrict__ urel, const int32_t *__restrict__ mpos,
     const float *__restrict__ V, const float *__restrict__ comp, int64_t N, int R, int B, int F,
-    const float *__restrict__ addend, int64_t ldA, OT *__restrict__ M, int64_t ldM,
+    const AT *__restrict__ addend, int64_t ldA, OT *__restrict__ M, int64_t ldM,
     const int32_t *__restrict__ node_ids = nullptr) {
   extern __shared__ __align__(16) float s_mem[];
   constexpr int KP = KS * 16 + 4;  // padded comp row: rows start on different banks
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
   const int nw = blockDim.x >> 6;
   float *s_tile = s_mem + ((R * KP + 3) & ~3) + wv * (TN * BF);
   float *s_add = s_mem + ((R * KP + 3) & ~3) + nw * (TN * BF) + wv * (kAddPieces * 4);  // (ADD == 2 only)
-  const int q4 = (int)(ldA >> 2);
+  const int q4 = (int)((ldA * (int64_t)sizeof(AT)) >> 4);  // 16-byte pieces of an addend row
   for (int t = threadIdx.x; t < R * KP; t += blockDim.x) {
     const int r = t / KP, k = t - r * KP;
     s_comp[t] = k < B ? comp[(int64_t)r * B + k] : 0.f;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
       _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                      \
         const int32_t b0 = __builtin_amdgcn_readlane(np, i), b1 = __builtin_amdgcn_readlane(np, i + 1);     \
         _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) pa_n1[i][reg] =                                 \
-            addend[(int64_t)max(min(b0 + 4 * kq + reg, b1 - 1), 0) * ldA + min(m, F - 1)];                  \
+            load_operand<AT>(addend + (int64_t)max(min(b0 + 4 * kq + reg, b1 - 1), 0) * ldA + min(m, F - 1)); \
       }                                                                                                     \
     }                                                                                                       \
   }
@@ -393,16 +394,17 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
       for (int i = 0; i < TN; ++i) {
         const int32_t c0 = __builtin_amdgcn_readlane(np_now, i), c1 = __builtin_amdgcn_readlane(np_now, i + 1);
         if (c1 > c0)
-          mix_node_tiles<KS, true, ADD, OT>(c0, c1, cbase, ur_cur, mp_cur, pa_cur[i], urel, mpos, s_comp,
-                                            s_tile + i * BF, B, F, addend, ldA, M, ldM, m, kq, s_add);
+          mix_node_tiles<KS, true, ADD, OT, AT>(c0, c1, cbase, ur_cur, mp_cur, pa_cur[i], urel, mpos, s_comp,
+                                                s_tile + i * BF, B, F, addend, ldA, M, ldM, m, kq,
+                                                reinterpret_cast<const AT *>(s_add));
       }
     } else {
 #pragma unroll 1
       for (int i = 0; i < TN; ++i)
-        mix_node_tiles<KS, false, ADD, OT>(__builtin_amdgcn_readlane(np_now, i),
-                                           __builtin_amdgcn_readlane(np_now, i + 1), cbase, ur_cur, mp_cur,
-                                           pa_cur[0], urel, mpos, s_comp, s_tile + i * BF, B, F, addend, ldA, M,
-                                           ldM, m, kq);
+        mix_node_tiles<KS, false, ADD, OT, AT>(__builtin_amdgcn_readlane(np_now, i),
+                                               __builtin_amdgcn_readlane(np_now, i + 1), cbase, ur_cur, mp_cur,
+                                               pa_cur[0], urel, mpos, s_comp, s_tile + i * BF, B, F, addend, ldA, M,
+                                               ldM, m, kq);
     }
     wave_lds_fence();  // the tile is rewritten by the next step
   }
@@ -1384,9 +1386,9 @@ struct MixCols {
   int R;
 };
 
-template <typename OT>
+template <typename OT, typename AT = float>
 int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B, int32_t F,
-                 const float *addend, int64_t ldA, OT *M, int64_t ldM, void *stream) {
+                 const AT *addend, int64_t ldA, OT *M, int64_t ldM, void *stream) {
   MRGCN_REQUIRE(V && comp && M, "NULL");
   MRGCN_REQUIRE(B > 0 && F > 0 && ldM >= F, "B / F / ldM");
   MRGCN_REQUIRE(!addend || ldA >= F, "ldA");
@@ -1404,7 +1406,7 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
   // node-major is the default: measured 2.7 ms vs 4.95 ms for the column-parallel form (AM shape)
   const bool by_cols = cfg(CFG_MIX_COLS) != 0;
   const int32_t *mpos_arg = p->mpos;
-  if constexpr (sizeof(OT) == 4) if (by_cols && !node_ids && B <= 64 && F <= 64 && FW <= 64) {
+  if constexpr (sizeof(OT) == 4 && sizeof(AT) == 4) if (by_cols && !node_ids && B <= 64 && F <= 64 && FW <= 64) {
     size_t lds = (size_t)R * (B | 1) * sizeof(float);
     int in_lds = lds <= kLdsBudget;
     if (!in_lds) lds = 0;
@@ -1457,8 +1459,9 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
     const size_t lds_plain =
         ((size_t)((R * (KS * 16 + 4) + 3) & ~3) + (size_t)(kFwdTB / 64) * tn * B * F) * sizeof(float);
     const size_t lds_add = (size_t)(kFwdTB / 64) * kAddPieces * 4 * sizeof(float);
-    const bool add_vec = addend && ldA % 4 == 0 && ldA <= 16 && (((uintptr_t)addend) & 15) == 0 && !node_ids &&
-                         cfg(CFG_MIX_ADD_VEC) != 0 && lds_plain + lds_add <= 150 * 1024;  // (else the 4-byte form)
+    const bool add_vec = addend && (ldA * sizeof(AT)) % 16 == 0 && ldA <= 16 && (((uintptr_t)addend) & 15) == 0 &&
+                         !node_ids && cfg(CFG_MIX_ADD_VEC) != 0 &&
+                         lds_plain + lds_add <= 150 * 1024;  // (else the element-wise form)
     const size_t lds = lds_plain + (add_vec ? lds_add : 0);
     if (mfma_on && B <= 64 && F <= 16 && (B * F) % 4 == 0 && (((uintptr_t)V) & 15) == 0 &&
         lds <= 150 * 1024 && !(node_ids && (addend || sizeof(OT) != 4))) {
@@ -1467,9 +1470,10 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
       if (grid > want) grid = want;
 #define MIXM_GO(KS_, NQ_, TN_)                                                                              \
   do {                                                                                                      \
-    auto kfn = addend ? (add_vec ? k_mix_fwd_mfma<KS_, NQ_, TN_, 2, OT> : k_mix_fwd_mfma<KS_, NQ_, TN_, 1, OT>) \
-                      : k_mix_fwd_mfma<KS_, NQ_, TN_, 0, OT>;                                               \
-    if constexpr (sizeof(OT) == 4) if (node_ids) kfn = k_mix_fwd_mfma<KS_, NQ_, TN_, 0, OT, true>;          \
+    auto kfn = addend ? (add_vec ? k_mix_fwd_mfma<KS_, NQ_, TN_, 2, OT, false, AT>                          \
+                                 : k_mix_fwd_mfma<KS_, NQ_, TN_, 1, OT, false, AT>)                         \
+                      : k_mix_fwd_mfma<KS_, NQ_, TN_, 0, OT, false, AT>;                                    \
+    if constexpr (sizeof(OT) == 4 && sizeof(AT) == 4) if (node_ids) kfn = k_mix_fwd_mfma<KS_, NQ_, TN_, 0, OT, true>; \
     MRGCN_HIP_TRY(raise_lds_limit((const void *)kfn, lds)); /* (per kernel: the variants share this site) */ \
     kfn<<<dim3((unsigned)grid), dim3(kFwdTB), lds, s>>>(p->nptr, p->urel, mpos_arg, V, comp, N, R, B, F,     \
                                                         addend, ldA, M, ldM, node_ids);                     \
@@ -1493,6 +1497,10 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
       return MRGCN_OK;
     }
   }
+  if constexpr (sizeof(AT) != 4) {
+    set_error("basis mix with a bf16 addend: outside the matrix-core form's limits (B <= 64, F <= 16, B*F % 4 == 0)");
+    return MRGCN_ERR_UNSUPPORTED;
+  } else {
   int acc = 0;
   for (int b0 = 0; b0 < B; b0 += 64) {
     const int nb = (B - b0 < 64) ? (B - b0) : 64;
@@ -1520,6 +1528,7 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
     acc = 1;
   }
   return MRGCN_OK;
+  }
 }
 
 template <typename OT>
@@ -1536,7 +1545,7 @@ int mix_fwd_arrays(const int32_t *nptr, const int32_t *urel, const int32_t *node
                    int R, const float *V, const float *comp, int32_t B, int32_t F, float *M, int64_t ldM,
                    hipStream_t s) {
   const MixCols c{nptr, urel, nullptr, nullptr, node_ids, n_nodes, ncols, R};
-  return mix_fwd_cols<float>(&c, V, comp, B, F, nullptr, 0, M, ldM, (void *)s);
+  return mix_fwd_cols<float, float>(&c, V, comp, B, F, (const float *)nullptr, 0, M, ldM, (void *)s);
 }
 }  // namespace mrgcn
 
@@ -1747,6 +1756,44 @@ int mrgcn_rel_transform_fwd_bf16(const mrgcn_plan_t *p, const float *X, int64_t 
                                  const float *W, int32_t F, uint16_t *Out, int64_t ldOut,
                                  int32_t operand_order, void *stream) {
   return rel_transform_fwd_impl<uint16_t>(p, X, ldX, K, W, F, Out, ldOut, operand_order, stream);
+}
+
+// ---- the bf16 pipeline (activations stored in bf16; parameters, accumulation and the backward's sums fp32) ----------
+int mrgcn_cast_rows_bf16(const float *src, int64_t ldSrc, int64_t rows, int32_t K, uint16_t *dst, int64_t ldDst,
+                         void *stream) {
+  MRGCN_REQUIRE(src && dst, "NULL");
+  MRGCN_REQUIRE(K > 0 && ldSrc >= K && ldDst >= K && ldDst % 8 == 0, "K / leading dimensions (ldDst: whole 16-byte pieces)");
+  MRGCN_REQUIRE((((uintptr_t)dst) & 15) == 0, "dst must be 16-byte aligned");
+  return cast_rows_bf16(src, ldSrc, rows, K, dst, ldDst, (hipStream_t)stream);
+}
+
+int32_t mrgcn_rel_transform_xbf16_supported(const mrgcn_plan_t *p, int32_t K, int32_t F, int64_t ldX, int64_t ldOut) {
+  return p && use_mfma() && xform_bf16_fwd_supported(K, F, ldX, ldOut) ? 1 : 0;
+}
+
+int mrgcn_rel_transform_fwd_xbf16(const mrgcn_plan_t *p, const uint16_t *X, int64_t ldX, int32_t K, const float *W,
+                                  int32_t F, void *Out, int64_t ldOut, int32_t operand_order, int32_t out_bf16,
+                                  void *stream) {
+  MRGCN_REQUIRE(p && X && W && Out, "NULL");
+  MRGCN_REQUIRE((((uintptr_t)X) & 15) == 0, "X must be 16-byte aligned");
+  if (!mrgcn_rel_transform_xbf16_supported(p, K, F, ldX, ldOut)) {
+    set_error("mrgcn_rel_transform_fwd_xbf16: K <= 256, F <= ldOut <= 16, ldX a multiple of 8 elements");
+    return MRGCN_ERR_UNSUPPORTED;
+  }
+  const RelOrder o = p->order_for(K);
+  if (o.n_relchunks == 0) return MRGCN_OK;
+  return xform_bf16_fwd(p, o, o.rnode, operand_order ? o.rmpos : nullptr, X, ldX, K, W, F, Out, ldOut,
+                        (hipStream_t)stream, out_bf16 != 0);
+}
+
+int mrgcn_basis_mix_fwd_abf16(const mrgcn_plan_t *p, const float *V, const float *comp, int32_t B, int32_t F,
+                              const uint16_t *addend, int64_t ldA, void *M, int64_t ldM, int32_t out_bf16,
+                              void *stream) {
+  MRGCN_REQUIRE(p && addend, "NULL");
+  MRGCN_REQUIRE(B <= 64 && F <= 16 && (B * F) % 4 == 0, "basis_mix_fwd_abf16: B <= 64, F <= 16, B*F % 4 == 0");
+  const MixCols c{p->nptr, p->urel, p->mpos, p->unode, nullptr, p->num_nodes, p->ncols, (int)p->num_relations};
+  if (out_bf16) return mix_fwd_cols<uint16_t, uint16_t>(&c, V, comp, B, F, addend, ldA, (uint16_t *)M, ldM, stream);
+  return mix_fwd_cols<float, uint16_t>(&c, V, comp, B, F, addend, ldA, (float *)M, ldM, stream);
 }
 
 }  // extern "C"

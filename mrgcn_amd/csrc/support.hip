@@ -480,11 +480,13 @@ int64_t mrgcn_support_rel_transform_bwd_workspace(const mrgcn_support_t *q, int3
   return m > 0 ? m : 1;
 }
 
-int mrgcn_support_rel_transform_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t ldM, const float *X,
-                                        int64_t ldX, int32_t K, const float *W, int32_t F, float *dX, int64_t lddX,
-                                        float *dW, float *workspace, int64_t workspace_floats,
-                                        int32_t relu_mask_from_x, void *stream) {
+static int support_rel_transform_bwd(const mrgcn_support_t *q, const float *dM, int64_t ldM, const void *X_, bool x_bf16,
+                                     int64_t ldX, int32_t K, const float *W, int32_t F, float *dX, int64_t lddX,
+                                     float *dW, float *workspace, int64_t workspace_floats,
+                                     int32_t relu_mask_from_x, void *stream) {
+  const float *X = (const float *)X_;
   MRGCN_REQUIRE(q && dM && X && W, "NULL");
+  MRGCN_REQUIRE(!(x_bf16 && relu_mask_from_x), "the ReLU mask is read from fp32 rows");
   MRGCN_REQUIRE(K > 0 && F > 0 && ldX >= K && ldM >= F, "K / F / leading dimensions");
   const int64_t need = mrgcn_support_rel_transform_bwd_workspace(q, K, F, dX != nullptr, dW != nullptr);
   if (need < 0) {
@@ -497,7 +499,7 @@ int mrgcn_support_rel_transform_bwd_f32(const mrgcn_support_t *q, const float *d
   const mrgcn_plan *p = q->plan;
   if (dW) {
     const RelOrder o = q->order_for(K);
-    int rc = xform_mfma_dw(p, o, o.rnode, X, ldX, K, dM, ldM, F, dW, workspace, workspace_floats, s, nullptr);
+    int rc = xform_mfma_dw(p, o, o.rnode, X_, ldX, K, dM, ldM, F, dW, workspace, workspace_floats, s, nullptr, x_bf16);
     if (rc != MRGCN_OK) return rc;
   }
   if (dX) {
@@ -512,6 +514,22 @@ int mrgcn_support_rel_transform_bwd_f32(const mrgcn_support_t *q, const float *d
     if (rc != MRGCN_OK) return rc;
   }
   return MRGCN_OK;
+}
+
+int mrgcn_support_rel_transform_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t ldM, const float *X,
+                                        int64_t ldX, int32_t K, const float *W, int32_t F, float *dX, int64_t lddX,
+                                        float *dW, float *workspace, int64_t workspace_floats,
+                                        int32_t relu_mask_from_x, void *stream) {
+  return support_rel_transform_bwd(q, dM, ldM, X, false, ldX, K, W, F, dX, lddX, dW, workspace, workspace_floats,
+                                   relu_mask_from_x, stream);
+}
+
+// the same with the layer's input in bf16 rows (the bf16 pipeline's X: ldX in elements); dW's sums stay fp32
+int mrgcn_support_rel_transform_bwd_xbf16(const mrgcn_support_t *q, const float *dM, int64_t ldM, const uint16_t *X,
+                                          int64_t ldX, int32_t K, const float *W, int32_t F, float *dX, int64_t lddX,
+                                          float *dW, float *workspace, int64_t workspace_floats, void *stream) {
+  return support_rel_transform_bwd(q, dM, ldM, X, true, ldX, K, W, F, dX, lddX, dW, workspace, workspace_floats, 0,
+                                   stream);
 }
 
 int mrgcn_softmax_xent_bwd_rows_f32(const float *drows, const int64_t *idx, int64_t n, int32_t C, const float *g,

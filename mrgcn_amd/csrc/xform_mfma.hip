@@ -42,6 +42,25 @@ __device__ __forceinline__ f32x4 load4_fast(const float *p) {
   // 16-byte load from a dword-aligned address (global loads need dword alignment only)
   return *reinterpret_cast<const f32x4 *>(p);
 }
+// the same four elements of a bf16 row (the bf16 pipeline's X): one 8-byte load, widened in registers
+__device__ __forceinline__ f32x4 load4_guarded(const uint16_t *row, int k, int K) {
+  f32x4 v;
+  v.x = (k + 0 < K) ? bf16_to_f32(row[k + 0]) : 0.f;
+  v.y = (k + 1 < K) ? bf16_to_f32(row[k + 1]) : 0.f;
+  v.z = (k + 2 < K) ? bf16_to_f32(row[k + 2]) : 0.f;
+  v.w = (k + 3 < K) ? bf16_to_f32(row[k + 3]) : 0.f;
+  return v;
+}
+__device__ __forceinline__ f32x4 load4_fast(const uint16_t *p) {
+  using u32x2_ = __attribute__((ext_vector_type(2))) uint32_t;
+  const u32x2_ w = *reinterpret_cast<const u32x2_ *>(p);
+  f32x4 v;
+  v.x = __uint_as_float(w.x << 16);
+  v.y = __uint_as_float(w.x & 0xffff0000u);
+  v.z = __uint_as_float(w.y << 16);
+  v.w = __uint_as_float(w.y & 0xffff0000u);
+  return v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Live columns of one relation chunk.  In the backward of a semi-supervised epoch most rows of
@@ -113,6 +132,12 @@ __device__ __forceinline__ int compact_live_columns(int32_t beg, int32_t end, co
 //   LIVE: `col_live` names the columns whose input row is not all zeros; only those are
 //   multiplied and only their output rows are written (rin_idx / rout_idx must be null: the
 //   backward dX pass, In = dM) — the consumer (k_segment_sum) skips the same columns.
+//   KS >= ceil(K / 16), the smallest instantiated (round 6): the loads of a step are straight-line code — no
+//   `ks < ksteps` test, no guarded last piece, no nullable index array inside the loop (the compiler had put every such
+//   load into its own basic block with an `s_waitcnt vmcnt(0)` behind it).  Every piece starts at min(k, K - 4) and is
+//   shifted into place with selects; what then sits in k slots >= K is real row data that meets the zero rows of the
+//   staged weights.  K < 4 (the dX pass of a two-class head) keeps the element-wise loads, behind ONE wave-uniform
+//   branch around the group.
 template <int NT, bool TRANS_W, int KS, typename OT, bool LIVE = false>
 __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
     const int32_t *__restrict__ relchunk_rel, const int32_t *__restrict__ relchunk_beg,
@@ -122,8 +147,7 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
     OT *__restrict__ Out, int64_t ldOut, const uint8_t *__restrict__ col_live,
     int64_t rstride /* floats between two relations' weights */, int n_store /* columns of Out this launch writes */) {
   extern __shared__ float WsT[];  // [NT*16][KP]: n-major, k contiguous, zero padded
-  const int ksteps = (K + 15) >> 4;
-  const int KP = ksteps * 16 + 4;  // +4 floats: rows start on different banks
+  constexpr int KP = KS * 16 + 4;  // +4 floats: rows start on different banks
   const int chunk = blockIdx.x;
   const int r = relchunk_rel[chunk];
   int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
@@ -148,17 +172,18 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
   const int m = lane & 15, kq = lane >> 4;
   // relation-major position e -> input row / output row; the indices of the next tile are
   // fetched while the current one is multiplied (no dependent index round trips in the loop)
+  const int32_t *pin = rin_idx ? rin_idx : rperm, *pout = rout_idx ? rout_idx : rperm;
   auto fetch = [&](int32_t e, int32_t &valid, int32_t &rin, int32_t &rout) {
     valid = e < end ? 1 : -1;
     const int32_t ee = e < end ? e : beg;
     if constexpr (LIVE) {
       rin = rout = s_cid[ee];
     } else {
-      const int32_t c = (rin_idx && rout_idx) ? 0 : rperm[ee];
-      rin = rin_idx ? rin_idx[ee] : c;
-      rout = rout_idx ? rout_idx[ee] : c;
+      rin = pin[ee];
+      rout = pout[ee];
     }
   };
+  const bool tiny = K < 4;  // wave uniform
   int32_t n_valid, n_rin, n_rout;
   fetch(beg + wv * 16 + m, n_valid, n_rin, n_rout);
   for (int32_t t0 = beg + wv * 16; t0 < end; t0 += 64) {  // 4 waves x 16 columns per sweep
@@ -166,13 +191,22 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
     const int64_t rin = n_rin;
     fetch(t0 + 64 + m, n_valid, n_rin, n_rout);
     const float *xrow = In + rin * ldIn;
-    // all K steps of the gathered row in flight at once
+    // all K steps of the gathered row in flight at once: every piece one 16-byte load whose start is clamped into the
+    // row (pieces wholly inside it: unchanged), then shifted into place
     f32x4 a[KS];
+    if (tiny) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks < ksteps) {
-        const int k = ks * 16 + 4 * kq;
-        a[ks] = (k + 4 <= K) ? load4_fast(xrow + k) : load4_guarded(xrow, k, K);
+      for (int ks = 0; ks < KS; ++ks) a[ks] = load4_guarded(xrow, ks * 16 + 4 * kq, K);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[ks] = load4_fast(xrow + min(ks * 16 + 4 * kq, K - 4));
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int shift = ks * 16 + 4 * kq - min(ks * 16 + 4 * kq, K - 4);
+        const f32x4 w = a[ks];
+        a[ks].x = shift == 0 ? w.x : shift == 1 ? w.y : shift == 2 ? w.z : w.w;
+        a[ks].y = shift == 0 ? w.y : shift == 1 ? w.z : w.w;
+        a[ks].z = shift == 0 ? w.z : w.w;
       }
     }
     f32x4 acc[NT];
@@ -180,17 +214,15 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (ks < ksteps) {
-        f32x4 av = a[ks];
-        if (cid < 0) av = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 av = a[ks];
+      if (cid < 0) av = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const f32x4 bv = *reinterpret_cast<const f32x4 *>(&WsT[(nt * 16 + m) * KP + ks * 16 + 4 * kq]);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[nt], 0, 0, 0);
-        }
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(&WsT[(nt * 16 + m) * KP + ks * 16 + 4 * kq]);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[nt], 0, 0, 0);
       }
     }
     // D: lane (n = l&15, g = l>>4) holds rows 4g + reg of the 16-column tile, feature nt*16 + n
@@ -217,11 +249,19 @@ __global__ __launch_bounds__(256) void k_xform_mfma_fwd(
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxTQ = 4;  // K <= 256
 
-template <int TQ, int U, bool LIVE>
+// The loop holds NO branch around a load (DESIGN "straight-line loads"): until round 6 every gathered piece sat in its
+// own conditional — `tq < ntq`, the guarded last piece of a row, nullable index arrays — and the compiler put an
+// `s_waitcnt vmcnt(0)` behind each of them: ~10 dependent round trips per step of 8 columns, 0.5 ms alone / 0.93 ms
+// beside the mix backward for 0.6 GB of rows at the AM shape (8 % of the roofline, "nobody has yet said why").  Now
+// TQ = ceil(K / 64) exactly, every piece is one unconditional load at a clamped address — the row's LAST piece starts
+// at min(i, Kr - 4) (Kr = readable elements of a row: K, or the padded row of a bf16 input) and is shifted into place
+// with selects; what lands in tile rows i >= K is real row data that no store ever reads — and the indices of the
+// next step are fetched before this step's rows.
+template <int TQ, int U, bool LIVE, typename IT = float>
 __global__ __launch_bounds__(256) void k_xform_mfma_dw(
     const int32_t *__restrict__ relchunk_rel, const int32_t *__restrict__ relchunk_beg,
     const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
-    const int32_t *__restrict__ rin_idx, const float *__restrict__ In, int64_t ldIn, int K,
+    const int32_t *__restrict__ rin_idx /* required */, const IT *__restrict__ In, int64_t ldIn, int K,
     const float *__restrict__ G, int64_t ldG, int F, float *__restrict__ dW,
     float *__restrict__ slab, const uint8_t *__restrict__ col_live, int64_t zero_dw) {
   extern __shared__ float dWs[];  // [4 waves][K*F]: every wave stores its own partial tile set
@@ -246,28 +286,36 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
       return;
     }
   }
-  const int ntq = (K + 63) >> 6;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m = lane & 15, kq = lane >> 4;
   f32x4 acc[TQ * 4];
 #pragma unroll
   for (int t = 0; t < TQ * 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the last piece of a row: start clamped into the row, elements shifted into place
+  const int Kr = sizeof(IT) == 2 ? (int)ldIn : K;
+  const int i_last = 64 * (TQ - 1) + 4 * m;
+  const int i_clamped = min(i_last, Kr - 4);
+  const int shift = i_last - i_clamped;  // 0: the piece as loaded; >= 4: nothing of it is real (tile rows >= K)
+  const int mG = min(m, F - 1);
 
-  // indices of the next sweep are fetched while the current one is multiplied
+  // indices of the next sweep are fetched while the current one is multiplied; positions past the chunk's end
+  // read the last valid position's (their G element is zeroed: they add nothing)
   int32_t n_cid[U], n_rin[U];
   auto fetch = [&](int32_t t0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int32_t e = t0 + 4 * u + kq;
+      const int32_t ee = min(e, end - 1);
+      int32_t c, ri;
       if constexpr (LIVE) {
-        n_cid[u] = e < end ? s_cid[e] : -1;
-        n_rin[u] = e < end ? s_rin[e] : 0;
+        c = s_cid[ee];
+        ri = s_rin[ee];
       } else {
-        const int32_t ee = e < end ? e : beg;
-        const int32_t c = rperm[ee];
-        n_cid[u] = e < end ? c : -1;
-        n_rin[u] = rin_idx ? rin_idx[ee] : c;
+        c = rperm[ee];
+        ri = rin_idx[ee];
       }
+      n_cid[u] = e < end ? c : -1 - c;  // (negative: invalid; the id itself stays recoverable for a valid address)
+      n_rin[u] = ri;
     }
   };
   fetch(beg + wv * 4 * U);
@@ -281,41 +329,43 @@ __global__ __launch_bounds__(256) void k_xform_mfma_dw(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int32_t cid = cidv[u];
-      const float *xrow = In + (int64_t)rinv[u] * ldIn;
-      b[u] = (cid >= 0 && m < F) ? G[(int64_t)cid * ldG + m] : 0.f;
+      const IT *xrow = In + (int64_t)rinv[u] * ldIn;
+      b[u] = G[(int64_t)(cid >= 0 ? cid : -1 - cid) * ldG + mG];
 #pragma unroll
-      for (int tq = 0; tq < TQ; ++tq) {
-        if (tq < ntq) {
-          const int i = 64 * tq + 4 * m;
-          a[u][tq] = (i + 4 <= K) ? load4_fast(xrow + i) : load4_guarded(xrow, i, K);
-          if (cid < 0) a[u][tq] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
+      for (int tq = 0; tq < TQ - 1; ++tq) a[u][tq] = load4_fast(xrow + 64 * tq + 4 * m);
+      a[u][TQ - 1] = load4_fast(xrow + i_clamped);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (cidv[u] < 0 || m >= F) b[u] = 0.f;
+      const f32x4 w = a[u][TQ - 1];
+      f32x4 v;
+      v.x = shift == 0 ? w.x : shift == 1 ? w.y : shift == 2 ? w.z : w.w;
+      v.y = shift == 0 ? w.y : shift == 1 ? w.z : w.w;
+      v.z = shift == 0 ? w.z : w.w;
+      v.w = w.w;
+      a[u][TQ - 1] = v;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int tq = 0; tq < TQ; ++tq) {
-        if (tq < ntq) {
-          acc[tq * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].x, b[u], acc[tq * 4 + 0], 0, 0, 0);
-          acc[tq * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].y, b[u], acc[tq * 4 + 1], 0, 0, 0);
-          acc[tq * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].z, b[u], acc[tq * 4 + 2], 0, 0, 0);
-          acc[tq * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].w, b[u], acc[tq * 4 + 3], 0, 0, 0);
-        }
+        acc[tq * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].x, b[u], acc[tq * 4 + 0], 0, 0, 0);
+        acc[tq * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].y, b[u], acc[tq * 4 + 1], 0, 0, 0);
+        acc[tq * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].z, b[u], acc[tq * 4 + 2], 0, 0, 0);
+        acc[tq * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][tq].w, b[u], acc[tq * 4 + 3], 0, 0, 0);
       }
     }
   }
   // D of tile (tq, s): lane (o = l&15, g = l>>4), reg -> row m' = 4g + reg -> i = 64tq + 4m' + s
 #pragma unroll
   for (int tq = 0; tq < TQ; ++tq) {
-    if (tq < ntq) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int i = 64 * tq + 4 * (4 * kq + reg) + s;
-          if (i < K && m < F) dWs[wv * K * F + i * F + m] = acc[tq * 4 + s][reg];  // each (i, o) once per wave
-        }
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = 64 * tq + 4 * (4 * kq + reg) + s;
+        if (i < K && m < F) dWs[wv * K * F + i * F + m] = acc[tq * 4 + s][reg];  // each (i, o) once per wave
       }
     }
   }
@@ -603,18 +653,35 @@ __global__ __launch_bounds__(1024) void k_xform_cols_lds(const int32_t *__restri
       r[u] = prel[pp];
     }
     float h[U][KT];
+    if (K >= 4) {
+      // straight-line loads (no branch around any of them: every piece's waits would drain the others): a piece
+      // starts at min(k4, K - 4) — inside the row — and is shifted into place; slots >= K are never multiplied
+      f32x4 t[U][KT / 4];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float *xrow = In + (int64_t)max(j[u], 0) * ldIn;
+      for (int u = 0; u < U; ++u) {
+        const float *xrow = In + (int64_t)max(j[u], 0) * ldIn;
 #pragma unroll
-      for (int k4 = 0; k4 < KT; k4 += 4) {   // the four lanes of a position load the same row: one fetch
-        if (k4 + 4 <= K) {
-          const f32x4 t = *reinterpret_cast<const f32x4 *>(xrow + k4);
-          h[u][k4] = t.x; h[u][k4 + 1] = t.y; h[u][k4 + 2] = t.z; h[u][k4 + 3] = t.w;
-        } else {
+        for (int k4 = 0; k4 < KT; k4 += 4)   // the four lanes of a position load the same row: one fetch
+          t[u][k4 / 4] = *reinterpret_cast<const f32x4 *>(xrow + min(k4, K - 4));
+      }
 #pragma unroll
-          for (int v = 0; v < 4; ++v) h[u][k4 + v] = (k4 + v < K) ? xrow[k4 + v] : 0.f;
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int k4 = 0; k4 < KT; k4 += 4) {
+          const int shift = k4 - min(k4, K - 4);   // wave uniform
+          const f32x4 w = t[u][k4 / 4];
+          h[u][k4] = shift == 0 ? w.x : shift == 1 ? w.y : shift == 2 ? w.z : w.w;
+          h[u][k4 + 1] = shift == 0 ? w.y : shift == 1 ? w.z : w.w;
+          h[u][k4 + 2] = shift == 0 ? w.z : w.w;
+          h[u][k4 + 3] = w.w;
         }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float *xrow = In + (int64_t)max(j[u], 0) * ldIn;
+#pragma unroll
+        for (int v = 0; v < KT; ++v) h[u][v] = (v < K) ? xrow[v] : 0.f;
       }
     }
 #pragma unroll
@@ -647,6 +714,134 @@ __global__ __launch_bounds__(1024) void k_xform_cols_lds(const int32_t *__restri
       for (int v = 0; v < 4; ++v) {
         const int n = 4 * q + v;
         if (n < ldOut) store_operand<OT>(orow + n, acc[v]);
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The bf16 pipeline (BASELINE config 3: "bf16 dense operands, fp32 accumulation"; the reference has no reduced
+// precision anywhere — graph.py:93-95 is fp32).  Activations (X, H, the feature term's rows, M) are STORED in bf16,
+// parameters and every accumulation stay fp32.
+//
+// k_cast_rows_bf16: dst[row, 0:ldDst] = [ bf16(src[row, 0:K]) | 0 ] — rows padded to whole 16-byte pieces.
+// ---------------------------------------------------------------------------------------------
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__global__ __launch_bounds__(256) void k_cast_rows_bf16(const float *__restrict__ src, int64_t ldSrc, int64_t rows,
+                                                        int K, uint16_t *__restrict__ dst, int64_t ldDst) {
+  // one thread per 16-byte piece of dst (8 elements)
+  const int pieces = (int)(ldDst >> 3);
+  const int64_t total = rows * pieces;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / pieces;
+    const int k0 = (int)(t - row * pieces) * 8;
+    const float *x = src + row * ldSrc + k0;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (k0 + i < K) ? x[i] : 0.f;
+    u32x4 o;
+    o.x = pack_bf16(v[0], v[1]);
+    o.y = pack_bf16(v[2], v[3]);
+    o.z = pack_bf16(v[4], v[5]);
+    o.w = pack_bf16(v[6], v[7]);
+    *reinterpret_cast<u32x4 *>(dst + row * ldDst + k0) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward on bf16 input rows, v_mfma_f32_16x16x32_bf16:
+//   Out[o(c), 0:ldOut] = [ In[i(c), 0:K] . Wm[r][0:K][0:F] | 0 ],  F <= 16, In rows of ldIn bf16 (ldIn % 8 == 0,
+//   zero past K), Wm[r][k][n] = W[(r*K + k)*F + n] in fp32, rounded to bf16 when the block stages it.
+// The product is taken TRANSPOSED — A = Wm^T (row = output feature n), B = In^T (column = graph column) — so that the
+// accumulator of lane (c = l & 15, g = l >> 4) holds features 4g .. 4g+3 of ITS OWN column c: the row leaves as one
+// 16-byte (fp32) or 8-byte (bf16) store per lane, no lane exchange, and the lane that fetched a column's indices is
+// the one that stores it.  A lane's B fragment of k-step ks is the 16 bytes In[i(c), 32 ks + 8 g ..+7]: the gather of
+// a 320-byte row (K = 155) is five such loads in four lanes, half the bytes of the fp32 kernel's ten.
+// U tiles of 16 columns per wave and step (their loads all in flight); the indices of the next step are fetched under
+// the products of this one.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int U, typename OT>
+__global__ __launch_bounds__(256) void k_xform_bf16_fwd(
+    const int32_t *__restrict__ relchunk_rel, const int32_t *__restrict__ relchunk_beg,
+    const int32_t *__restrict__ relchunk_end, const int32_t *__restrict__ rperm,
+    const int32_t *__restrict__ rin_idx, const int32_t *__restrict__ rout_idx,
+    const uint16_t *__restrict__ In, int64_t ldIn, int K, const float *__restrict__ W, int F,
+    OT *__restrict__ Out, int64_t ldOut) {
+  extern __shared__ __align__(16) uint16_t WsB[];  // [16][KP] bf16: n-major, k contiguous, zero padded
+  constexpr int KP = KS * 32 + 8;  // KS = ceil(K / 32) exactly; +16 bytes: the 16 rows' pieces start in different banks
+  const int chunk = blockIdx.x;
+  const int r = relchunk_rel[chunk];
+  const int32_t beg = relchunk_beg[chunk], end = relchunk_end[chunk];
+  for (int t = threadIdx.x; t < 16 * KP / 2; t += blockDim.x) reinterpret_cast<uint32_t *>(WsB)[t] = 0u;
+  __syncthreads();
+  {
+    const float *Wr = W + (int64_t)r * K * F;
+    for (int t = threadIdx.x; t < K * F; t += blockDim.x) {  // source order: coalesced
+      const int k = t / F, n = t - k * F;
+      WsB[n * KP + k] = f32_to_bf16(Wr[t]);
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  // A fragments (the relation's weights): constant over the chunk
+  bf16x8 aw[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    aw[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(WsB + c * KP + ks * 32 + 8 * g));
+  const int32_t *pin = rin_idx ? rin_idx : rperm, *pout = rout_idx ? rout_idx : rperm;
+  auto fetch = [&](int32_t e, int32_t &rin, int32_t &rout) {  // (no branch around a load: straight-line steps)
+    const int32_t ee = e < end ? e : beg;
+    rin = pin[ee];
+    rout = pout[ee];
+  };
+  int32_t n_rin[U], n_rout[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) fetch(beg + (wv * U + u) * 16 + c, n_rin[u], n_rout[u]);
+  for (int32_t t0 = beg + wv * U * 16; t0 < end; t0 += 4 * U * 16) {  // 4 waves x U tiles x 16 columns per sweep
+    int32_t rout[U];
+    u32x4 x[U][KS];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rout[u] = n_rout[u];
+      // (a piece that starts past the padded row is read from the row's last piece instead: its k slots meet zero
+      // weights, and no load leaves the row)
+      const uint16_t *xrow = In + (int64_t)n_rin[u] * ldIn;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        x[u][ks] = *reinterpret_cast<const u32x4 *>(xrow + min(32 * ks + 8 * g, (int)ldIn - 8));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) fetch(t0 + (4 * U + u) * 16 + c, n_rin[u], n_rout[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[ks], __builtin_bit_cast(bf16x8, x[u][ks]), acc, 0, 0, 0);
+      if (t0 + u * 16 + c >= end) continue;
+      OT *orow = Out + (int64_t)rout[u] * ldOut + 4 * g;
+      if (4 * g + 4 <= ldOut) {  // whole pieces: zeros past F come out of the zero rows of WsB
+        if constexpr (sizeof(OT) == 4) {
+          *reinterpret_cast<f32x4 *>(orow) = acc;
+        } else {
+          u32x2 o;
+          o.x = pack_bf16(acc.x, acc.y);
+          o.y = pack_bf16(acc.z, acc.w);
+          *reinterpret_cast<u32x2 *>(orow) = o;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * g + i < ldOut) store_operand<OT>(orow + i, acc[i]);
       }
     }
   }
@@ -693,7 +888,9 @@ int xform_cols_lds(const mrgcn_plan *p, bool operand_order, const float *In, int
 bool xform_mfma_fwd_supported(int K, int F) { return K <= kMaxKSteps * 16 && F <= kMaxNT * 16; }
 // the dX pass Z = dM . W^T: F floats in, K out (sliced by 64 columns)
 bool xform_mfma_dx_supported(int F, int K) { return F <= kMaxKSteps * 16 && K <= 256; }
-bool xform_mfma_dw_supported(int K, int F) { return K <= kMaxTQ * 64 && F <= 16 && (size_t)4 * K * F * 4 <= 64 * 1024; }
+bool xform_mfma_dw_supported(int K, int F) {  // (K >= 4: a row's last piece is a whole 16-byte load inside the row)
+  return K >= 4 && K <= kMaxTQ * 64 && F <= 16 && (size_t)4 * K * F * 4 <= 64 * 1024;
+}
 // ... and with room in LDS for the list of live columns
 bool xform_mfma_dw_live_supported(int K, int F) {
   return xform_mfma_dw_supported(K, F) && (size_t)4 * K * F * 4 + kLiveLds <= 64 * 1024;
@@ -710,21 +907,21 @@ static int xform_mfma_fwd_one(const mrgcn_plan *p, const RelOrder &o, const int3
   int NT = (n_store + 15) / 16;  // tiles that cover the columns to write
   if (NT < (F + 15) / 16) NT = (F + 15) / 16;
   const int ksteps = (K + 15) / 16;
-  size_t lds = (size_t)NT * 16 * (ksteps * 16 + 4) * sizeof(float);
+  // (the staged weight tile is sized by the INSTANTIATED k-step count: its row stride is a compile-time constant)
+  auto lds_for = [&](int ks_inst) { return (size_t)NT * 16 * (ks_inst * 16 + 4) * sizeof(float); };
   if (col_live) {  // backward dX pass over the live columns only
     if (!trans_w || rin_idx || rout_idx || out_bf16 || ksteps > 4) {
       set_error("xform_mfma_fwd: col_live is for the dX pass (transposed weights, K <= 64)");
       return MRGCN_ERR_UNSUPPORTED;
     }
-    lds += kLiveLds;
 #define XF_LIVE(N_)                                                                                        \
   do {                                                                                                     \
     if (ksteps <= 1)                                                                                       \
-      k_xform_mfma_fwd<N_, true, 1, float, true><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(             \
+      k_xform_mfma_fwd<N_, true, 1, float, true><<<dim3(o.n_relchunks), dim3(256), lds_for(1) + kLiveLds, s>>>( \
           o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, nullptr, nullptr, In, ldIn, K, W,   \
           F, (float *)Out, ldOut, col_live, rstride, n_store);                                             \
     else                                                                                                   \
-      k_xform_mfma_fwd<N_, true, 4, float, true><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(             \
+      k_xform_mfma_fwd<N_, true, 4, float, true><<<dim3(o.n_relchunks), dim3(256), lds_for(4) + kLiveLds, s>>>( \
           o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, nullptr, nullptr, In, ldIn, K, W,   \
           F, (float *)Out, ldOut, col_live, rstride, n_store);                                             \
   } while (0)
@@ -734,20 +931,25 @@ static int xform_mfma_fwd_one(const mrgcn_plan *p, const RelOrder &o, const int3
     MRGCN_HIP_TRY(hipGetLastError());
     return MRGCN_OK;
   }
+#define XF_K(N_, T_, O_, KS_)                                                                          \
+  k_xform_mfma_fwd<N_, T_, KS_, O_><<<dim3(o.n_relchunks), dim3(256), lds_for(KS_), s>>>(              \
+      o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn, K, W, F,  \
+      (O_ *)Out, ldOut, nullptr, rstride, n_store)
 #define XF_GO3(N_, T_, O_)                                                                              \
   do {                                                                                                  \
-    if (ksteps <= 1)                                                                                    \
-      k_xform_mfma_fwd<N_, T_, 1, O_><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                     \
-          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn,     \
-          K, W, F, (O_ *)Out, ldOut, nullptr, rstride, n_store);                                        \
-    else if (ksteps <= 4)                                                                               \
-      k_xform_mfma_fwd<N_, T_, 4, O_><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                     \
-          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn,     \
-          K, W, F, (O_ *)Out, ldOut, nullptr, rstride, n_store);                                        \
-    else                                                                                                \
-      k_xform_mfma_fwd<N_, T_, kMaxKSteps, O_><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(            \
-          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn,     \
-          K, W, F, (O_ *)Out, ldOut, nullptr, rstride, n_store);                                        \
+    if (N_ == 1) { /* narrow outputs (the layer transforms): the k-step count in steps of one or two */ \
+      if (ksteps <= 1) XF_K(1, T_, O_, 1);                                                              \
+      else if (ksteps <= 2) XF_K(1, T_, O_, 2);                                                         \
+      else if (ksteps <= 3) XF_K(1, T_, O_, 3);                                                         \
+      else if (ksteps <= 4) XF_K(1, T_, O_, 4);                                                         \
+      else if (ksteps <= 6) XF_K(1, T_, O_, 6);                                                         \
+      else if (ksteps <= 8) XF_K(1, T_, O_, 8);                                                         \
+      else if (ksteps <= 10) XF_K(1, T_, O_, 10);                                                       \
+      else if (ksteps <= 12) XF_K(1, T_, O_, 12);                                                       \
+      else XF_K(1, T_, O_, kMaxKSteps);                                                                 \
+    } else if (ksteps <= 1) XF_K(N_, T_, O_, 1);                                                        \
+    else if (ksteps <= 4) XF_K(N_, T_, O_, 4);                                                          \
+    else XF_K(N_, T_, O_, kMaxKSteps);                                                                  \
   } while (0)
 #define XF_GO(N_, T_)                                                  \
   do {                                                                 \
@@ -792,14 +994,68 @@ int xform_mfma_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_id
   return MRGCN_OK;
 }
 
-int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const float *In, int64_t ldIn,
+bool xform_bf16_fwd_supported(int K, int F, int64_t ldIn, int64_t ldOut) {
+  return K >= 1 && K <= 256 && F >= 1 && F <= 16 && ldOut <= 16 && ldOut >= F && (ldIn & 7) == 0 && ldIn >= K;
+}
+
+int xform_bf16_fwd(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const int32_t *rout_idx,
+                   const uint16_t *In, int64_t ldIn, int K, const float *W, int F, void *Out, int64_t ldOut,
+                   hipStream_t s, bool out_bf16) {
+  if (!xform_bf16_fwd_supported(K, F, ldIn, ldOut)) {
+    set_error("xform_bf16_fwd: K <= 256, F <= ldOut <= 16, input rows of whole 16-byte pieces");
+    return MRGCN_ERR_UNSUPPORTED;
+  }
+  if (o.n_relchunks == 0) return MRGCN_OK;
+  const int ksteps = (K + 31) / 32;
+  const size_t lds = (size_t)16 * (ksteps * 32 + 8) * sizeof(uint16_t);
+#define XB_GO(KS_, U_)                                                                                          \
+  do {                                                                                                          \
+    if (out_bf16)                                                                                               \
+      k_xform_bf16_fwd<KS_, U_, uint16_t><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                         \
+          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn, K, W, F,      \
+          (uint16_t *)Out, ldOut);                                                                              \
+    else                                                                                                        \
+      k_xform_bf16_fwd<KS_, U_, float><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                            \
+          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, rout_idx, In, ldIn, K, W, F,      \
+          (float *)Out, ldOut);                                                                                 \
+  } while (0)
+  // (U: tiles of 16 columns in flight per wave; rows of up to two k-steps are short, four tiles keep as many bytes
+  // in flight as two tiles of the long ones)
+  switch (ksteps) {  // (exact: the kernel reads KS pieces of every row)
+    case 1: XB_GO(1, 4); break;
+    case 2: XB_GO(2, 4); break;
+    case 3: XB_GO(3, 2); break;
+    case 4: XB_GO(4, 2); break;
+    case 5: XB_GO(5, 2); break;
+    case 6: XB_GO(6, 2); break;
+    case 7: XB_GO(7, 1); break;
+    default: XB_GO(8, 1); break;
+  }
+#undef XB_GO
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int cast_rows_bf16(const float *src, int64_t ldSrc, int64_t rows, int K, uint16_t *dst, int64_t ldDst, hipStream_t s) {
+  if (rows == 0) return MRGCN_OK;
+  const int64_t total = rows * (ldDst >> 3);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  k_cast_rows_bf16<<<dim3((unsigned)grid), dim3(256), 0, s>>>(src, ldSrc, rows, K, dst, ldDst);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx, const void *In_, int64_t ldIn,
                   int K, const float *G, int64_t ldG, int F, float *dW, float *workspace,
-                  int64_t workspace_floats, hipStream_t s, const uint8_t *col_live) {
+                  int64_t workspace_floats, hipStream_t s, const uint8_t *col_live, bool in_bf16) {
+  const float *In = (const float *)In_;
   if (o.n_relchunks == 0) {
     MRGCN_HIP_TRY(mrgcn::fill_async(dW, 0, (size_t)p->num_relations * K * F * sizeof(float), s));
     return MRGCN_OK;
   }
   size_t lds = (size_t)4 * K * F * sizeof(float);
+  if (in_bf16) col_live = nullptr;  // (the bf16 pipeline's backward runs on gradient supports: dense index spaces)
   if (col_live && lds + kLiveLds <= 64 * 1024) lds += kLiveLds;
   else col_live = nullptr;  // no room for the list: every column is swept (same result)
   float *slab = (workspace && workspace_floats >= (int64_t)o.n_relchunks * K * F) ? workspace : nullptr;
@@ -812,7 +1068,11 @@ int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx
   // K = 155: <4,4> 1.92 ms, <3,4> 1.65 ms, <3,2> 1.62 ms.
 #define DW_GO(TQ_, U_)                                                                                   \
   do {                                                                                                   \
-    if (col_live)                                                                                        \
+    if (in_bf16)                                                                                         \
+      k_xform_mfma_dw<TQ_, U_, false, uint16_t><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(            \
+          o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, (const uint16_t *)In_, ldIn, \
+          K, G, ldG, F, dW, slab, nullptr, zero_dw);                                                     \
+    else if (col_live)                                                                                   \
       k_xform_mfma_dw<TQ_, U_, true><<<dim3(o.n_relchunks), dim3(256), lds, s>>>(                       \
           o.relchunk_rel, o.relchunk_beg, o.relchunk_end, o.rperm, rin_idx, In, ldIn, K, G, ldG, F,  \
           dW, slab, col_live, zero_dw);                                                                  \
@@ -822,9 +1082,14 @@ int xform_mfma_dw(const mrgcn_plan *p, const RelOrder &o, const int32_t *rin_idx
           dW, slab, nullptr, zero_dw);                                                                   \
   } while (0)
   // (live form, K = 155, columns in flight per wave 4 / 8 / 16: 591 / 463 / 485 us)
+  if (!rin_idx || K < 4 || (in_bf16 && (ldIn < 4 || (ldIn & 3)))) {
+    set_error("xform_mfma_dw: needs the input-row index of every column, K >= 4 (bf16 rows: ld a multiple of 4)");
+    return MRGCN_ERR_UNSUPPORTED;
+  }
   if (K <= 64) DW_GO(1, 2);
+  else if (K <= 128) DW_GO(2, 2);
   else if (K <= 192) DW_GO(3, 2);
-  else DW_GO(kMaxTQ, 4);
+  else DW_GO(4, 2);
 #undef DW_GO
   MRGCN_HIP_TRY(hipGetLastError());
   if (slab) {

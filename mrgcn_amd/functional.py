@@ -26,6 +26,8 @@ _LIVE_COLS = os.environ.get("MRGCN_LIVE_COLS", "1") != "0"
 # the live columns, their kept entries and the relation-major lists are built once and every epoch runs on dense index
 # spaces (csrc/support.hip).  MRGCN_SUPPORT=0: the per-epoch marking path for every backward (A/B).
 _SUPPORT = os.environ.get("MRGCN_SUPPORT", "1") != "0"
+# bf16 layers read a wide input as bf16 rows (0: only the compact operand M is bf16, the round-5 form — the A/B switch)
+_BF16_PIPELINE = os.environ.get("MRGCN_BF16_PIPELINE", "1") != "0"
 
 # tests: start dM as NaNs, so that any read of a row the producer left unwritten shows
 _POISON_DEAD = False
@@ -200,6 +202,44 @@ def _ld_for_bf16(F: int) -> int:
     return (F + a - 1) // a * a
 
 
+# ---- the bf16 pipeline's layer input ---------------------------------------------------------------------------------
+# BASELINE config 3 / SURVEY §8d: activations stored in bf16, fp32 accumulation.  A layer whose `operand_dtype` is
+# "bf16" reads a WIDE input (K > 16) as bf16 rows padded to whole 16-byte pieces: half the bytes per gathered row in the
+# transform and in its dW.  An input that is DATA (no gradient: the feature matrix of a run without encoders, the same
+# tensor every epoch) is converted once and the copy kept while the tensor object lives unchanged — like the graph
+# plan, preparation of a constant input; an input that is an activation (it requires grad, or its version moves) is
+# converted by every forward.  A bf16 tensor is taken as it is.
+_XB_CACHE = {}   # id(X) -> (weakref(X), version, data_ptr, Xb)
+
+
+def bf16_rows(X: torch.Tensor) -> torch.Tensor:
+    """[n, ld] bf16 copy of the fp32 rows X[n, K], ld = K rounded up to 8 elements, zeros past K."""
+    if X.dtype == torch.bfloat16:
+        if X.dim() != 2 or X.stride(1) != 1 or X.stride(0) % 8 or X.data_ptr() % 16:
+            raise L.MrgcnError("a bf16 layer input needs rows of whole 16-byte pieces")
+        return X
+    import weakref
+    cacheable = not X.requires_grad
+    if cacheable:
+        ent = _XB_CACHE.get(id(X))
+        if ent is not None and ent[0]() is X and ent[1] == X._version and ent[2] == X.data_ptr():
+            bump("bf16.x_cached")
+            return ent[3]
+    Xc = X if (X.dim() == 2 and X.stride(1) == 1) else X.contiguous()
+    n, K = Xc.shape
+    ld = (K + 7) // 8 * 8
+    Xb = torch.empty((n, ld), dtype=torch.bfloat16, device=X.device)
+    with torch.cuda.device(X.device):
+        L.check(L.load().mrgcn_cast_rows_bf16(Xc.data_ptr(), Xc.stride(0), n, K, Xb.data_ptr(), ld, _stream(X.device)),
+                "mrgcn_cast_rows_bf16")
+    bump("bf16.x_cast")
+    if cacheable:
+        for k in [k for k, e in _XB_CACHE.items() if e[0]() is None]:
+            del _XB_CACHE[k]
+        _XB_CACHE[id(X)] = (weakref.ref(X), X._version, X.data_ptr(), Xb)
+    return Xb
+
+
 class _SpmmLiteral(torch.autograd.Function):
     """Y = A . D with D the dense (R*N) x F operand in the reference's row order
     (mrgcn/layers/graph.py:75, :95).  Backward = A^T dY scattered into a dense
@@ -300,8 +340,9 @@ class _RgcnLayer(torch.autograd.Function):
                 owner=None):
         lib = L.load()
         dev = plan.device
-        # bf16: only the compact operand M is stored in bf16 (one rounding at its store); inputs,
-        # every accumulation, Y and the whole backward stay fp32
+        # bf16: the compact operand M is stored in bf16 (one rounding at its store); a WIDE input (K > 16) is read as
+        # bf16 rows by the transform on v_mfma_f32_16x16x32_bf16 and the feature term's rows travel in bf16 too (the
+        # bf16 pipeline, `bf16_rows`); parameters, every accumulation, Y and the backward's sums stay fp32
         ld = _ld_for_bf16(F) if bf16 else _ld_for(F)
         M = torch.empty((plan.nop, ld), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
         sfx = "bf16" if bf16 else "f32"
@@ -309,30 +350,52 @@ class _RgcnLayer(torch.autograd.Function):
         mix_fwd = getattr(lib, "mrgcn_basis_mix_fwd_" + sfx)
         gather_rows = getattr(lib, "mrgcn_gather_rows_" + sfx)
         s = _stream(dev)
-        Xc = Wc = None
+        Xc = Wc = Xb = None
         with torch.cuda.device(dev):
-            addend, ldA = 0, 0
+            addend, ldA, addend_bf16 = 0, 0, False
             if X is not None:
-                Xc = X if (X.dim() == 2 and X.stride(1) == 1) else X.contiguous()  # row-strided X is taken as it is
+                K = X.shape[1]
                 Wc = W_F.contiguous()
+                if bf16 and (K > 16 or X.dtype == torch.bfloat16) and _BF16_PIPELINE:
+                    ldo = 16 if weight_I is not None else ld
+                    if lib.mrgcn_rel_transform_xbf16_supported(plan.handle, K, F, (K + 7) // 8 * 8, ldo):
+                        Xb = bf16_rows(X)
+                if Xb is None and X.dtype != torch.float32:
+                    raise L.MrgcnError("a bf16 layer input needs operand_dtype 'bf16' and a shape the bf16 transform takes")
+                Xc = X if (X.dim() == 2 and X.stride(1) == 1) else X.contiguous()  # row-strided X is taken as it is
                 if weight_I is not None:
                     # feature term in plain compact order (sequential writes); the input-term
                     # pass below adds it while it emits the final rows in operand order
-                    ldA = (F + 3) // 4 * 4
-                    M2 = torch.empty((plan.ncols, ldA), dtype=torch.float32, device=dev)
+                    addend_bf16 = (Xb is not None and comp_I is not None and comp_I.shape[1] <= 64
+                                   and (comp_I.shape[1] * F) % 4 == 0)
+                    ldA = 16 if addend_bf16 else (F + 3) // 4 * 4
+                    M2 = torch.empty((plan.ncols, ldA), dtype=torch.bfloat16 if addend_bf16 else torch.float32,
+                                     device=dev)
                     out, ldo, order = M2, ldA, 0
                     addend = M2.data_ptr()
                 else:
                     out, ldo, order = M, ld, 1
-                fwd = xform_fwd if out is M else lib.mrgcn_rel_transform_fwd_f32  # M2 stays fp32
-                L.check(fwd(plan.handle, Xc.data_ptr(), Xc.stride(0), Xc.shape[1], Wc.data_ptr(), F,
-                            out.data_ptr(), ldo, order, s), "mrgcn_rel_transform_fwd_" + sfx)
+                if Xb is not None:
+                    bump("bf16.xform_xbf16")
+                    L.check(lib.mrgcn_rel_transform_fwd_xbf16(plan.handle, Xb.data_ptr(), Xb.stride(0), K, Wc.data_ptr(), F,
+                                                              out.data_ptr(), ldo, order,
+                                                              int(out.dtype == torch.bfloat16), s),
+                            "mrgcn_rel_transform_fwd_xbf16")
+                else:
+                    fwd = xform_fwd if out is M else lib.mrgcn_rel_transform_fwd_f32  # M2 stays fp32
+                    L.check(fwd(plan.handle, Xc.data_ptr(), Xc.stride(0), Xc.shape[1], Wc.data_ptr(), F,
+                                out.data_ptr(), ldo, order, s), "mrgcn_rel_transform_fwd_" + sfx)
             if weight_I is not None:
                 wI = weight_I.contiguous()
                 if comp_I is not None:
                     cI = comp_I.contiguous()
-                    L.check(mix_fwd(plan.handle, wI.data_ptr(), cI.data_ptr(), cI.shape[1], F, addend, ldA,
-                                    M.data_ptr(), ld, s), "mrgcn_basis_mix_fwd_" + sfx)
+                    if addend_bf16:
+                        L.check(lib.mrgcn_basis_mix_fwd_abf16(plan.handle, wI.data_ptr(), cI.data_ptr(), cI.shape[1], F,
+                                                              addend, ldA, M.data_ptr(), ld, 1, s),
+                                "mrgcn_basis_mix_fwd_abf16")
+                    else:
+                        L.check(mix_fwd(plan.handle, wI.data_ptr(), cI.data_ptr(), cI.shape[1], F, addend, ldA,
+                                        M.data_ptr(), ld, s), "mrgcn_basis_mix_fwd_" + sfx)
                 else:
                     L.check(gather_rows(plan.handle, wI.data_ptr(), F, addend, ldA, M.data_ptr(), ld, s),
                             "mrgcn_gather_rows_" + sfx)
@@ -342,6 +405,7 @@ class _RgcnLayer(torch.autograd.Function):
         Y = plan.spmm(L.VIEW_COMPACT, M, F=F, bias=bias, relu=relu,
                       padded_rows=bool(getattr(owner, "padded_output", False)))
         ctx.plan, ctx.F, ctx.ld, ctx.relu, ctx.owner = plan, F, ld, relu, owner
+        ctx.Xb = Xb   # the input's bf16 rows (the bf16 pipeline): what the backward's dW gathers
         # the layer's input is the output of a fused ReLU (marked by the layer that made it): its own sign is that
         # ReLU's mask, so this layer's backward can hand its input gradient on already masked
         ctx.x_is_relu_out = X is not None and bool(getattr(X, "_mrgcn_relu_out", False))
@@ -697,10 +761,18 @@ def _backward_on_support(ctx, sup, dY, dbias):
                     dW = torch.empty_like(W_F)
                 ws = sup.workspace(("xform", K, F), nws)
                 mask = bool(need_dX and ctx.x_is_relu_out and K <= 16)
-                L.check(lib.mrgcn_support_rel_transform_bwd_f32(
-                    sup.handle, dM.data_ptr(), ld, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
-                    dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0, ws.data_ptr(), ws.numel(),
-                    int(mask), side.cuda_stream), "mrgcn_support_rel_transform_bwd_f32")
+                Xb = getattr(ctx, "Xb", None)
+                if Xb is not None and not mask:
+                    bump("bf16.dw_xbf16")
+                    L.check(lib.mrgcn_support_rel_transform_bwd_xbf16(
+                        sup.handle, dM.data_ptr(), ld, Xb.data_ptr(), Xb.stride(0), K, W_F.data_ptr(), F,
+                        dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0, ws.data_ptr(), ws.numel(),
+                        side.cuda_stream), "mrgcn_support_rel_transform_bwd_xbf16")
+                else:
+                    L.check(lib.mrgcn_support_rel_transform_bwd_f32(
+                        sup.handle, dM.data_ptr(), ld, X.data_ptr(), X.stride(0), K, W_F.data_ptr(), F,
+                        dX.data_ptr() if need_dX else 0, K, dW.data_ptr() if need_dW else 0, ws.data_ptr(), ws.numel(),
+                        int(mask), side.cuda_stream), "mrgcn_support_rel_transform_bwd_f32")
                 if need_dX:
                     # the rows that can hold anything: the nodes of this support — the row set of the layer below
                     _set_grad_meta(dX, sup.node_flags(), mask, structural=True)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()  # raises if the .so is missing or a symbol is absent
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.mrgcn_abi_version() == 4
+    assert lib.mrgcn_abi_version() == 5
     assert lib.mrgcn_arch() == b"gfx950"
 
 

@@ -82,7 +82,19 @@ def main():
     def chk(rc):
         L.check(rc)
 
+    # the bf16 pipeline's operands (X rows of 160 bf16, feature-term rows of 16 bf16, M rows of 10 bf16)
+    ldXb = (K + 7) // 8 * 8
+    Xb = torch.zeros((N, ldXb), dtype=torch.bfloat16, device=dev)
+    M2b = torch.randn((nc, 16), device=dev).to(torch.bfloat16)
+    Mb = torch.empty((plan.nop, F), dtype=torch.bfloat16, device=dev)
+    M2f = torch.empty((nc, 12), device=dev)
+    chk(lib.mrgcn_cast_rows_bf16(X.data_ptr(), ldx, N, K, Xb.data_ptr(), ldXb, s))
     calls = {
+        "cast_x": lambda: chk(lib.mrgcn_cast_rows_bf16(X.data_ptr(), ldx, N, K, Xb.data_ptr(), ldXb, s)),
+        "xf_fwd0_xb": lambda: chk(lib.mrgcn_rel_transform_fwd_xbf16(h, Xb.data_ptr(), ldXb, K, W0.data_ptr(), F, M2b.data_ptr(), 16, 0, 1, s)),
+        "xf_fwd0_xb_f32": lambda: chk(lib.mrgcn_rel_transform_fwd_xbf16(h, Xb.data_ptr(), ldXb, K, W0.data_ptr(), F, M2f.data_ptr(), 12, 0, 0, s)),
+        "mix_fwd_addb": lambda: chk(lib.mrgcn_basis_mix_fwd_abf16(h, V.data_ptr(), comp.data_ptr(), B, F, M2b.data_ptr(), 16, Mb.data_ptr(), F, 1, s)),
+        "mix_fwd_add_b": lambda: chk(lib.mrgcn_basis_mix_fwd_bf16(h, V.data_ptr(), comp.data_ptr(), B, F, M2.data_ptr(), 12, Mb.data_ptr(), F, s)),
         "mix_fwd": lambda: chk(lib.mrgcn_basis_mix_fwd_f32(h, V.data_ptr(), comp.data_ptr(), B, F, 0, 0, M.data_ptr(), ld, s)),
         "mix_fwd_add": lambda: chk(lib.mrgcn_basis_mix_fwd_f32(h, V.data_ptr(), comp.data_ptr(), B, F, M2.data_ptr(), 12, M.data_ptr(), ld, s)),
         "mix_bwd": lambda: chk(lib.mrgcn_basis_mix_bwd_f32(h, dM.data_ptr(), 12, 0, V.data_ptr(), comp.data_ptr(), B, F, dV.data_ptr(), 0, dcomp.data_ptr(), 0, s)),
