@@ -49,7 +49,8 @@ const Entry kEntries[CFG_COUNT] = {
     {"xform_cols_lds", "MRGCN_XFORM_COLS_LDS", 1, "narrow transform with every relation's weights in LDS, output order"},
     {"spmm_literal_v3", "MRGCN_SPMM_LITERAL_V3", 1, "LITERAL products of narrow layers on the compact view's row classes (k_spmm3 with literal columns)"},
     {"mix_add_vec", "MRGCN_MIX_ADD_VEC", 1, "basis mix forward: the feature term's rows come in as 16-byte pieces through LDS (0: four 4-byte loads per node)"},
-    {"sup_rel_chunk", "MRGCN_SUP_REL_CHUNK", 512, "gradient supports: live columns of one (band, relation) group per transform block (64..1024; read when a support is built)"}
+    {"sup_rel_chunk", "MRGCN_SUP_REL_CHUNK", 512, "gradient supports: live columns of one (band, relation) group per transform block (64..1024; read when a support is built)"},
+    {"adam_once", "MRGCN_ADAM_ONCE", 1, "fused row Adam on a support as a ONE-SHOT grid: list entries per wave (1, 2 or 4; 0: the persistent list kernel)"}
 };
 std::atomic<int64_t> g_values[CFG_COUNT];
 std::once_flag g_once;

@@ -47,6 +47,7 @@ enum CfgKey : int {
   CFG_SPMM_LITERAL_V3,
   CFG_MIX_ADD_VEC,
   CFG_SUP_REL_CHUNK,
+  CFG_ADAM_ONCE,
   CFG_COUNT
 };
 int64_t cfg(CfgKey k);

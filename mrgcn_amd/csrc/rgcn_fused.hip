@@ -1059,6 +1059,150 @@ __global__ __launch_bounds__(kFusedTB, PIPE ? 4 : 8) void k_adam_rows_list(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_adam_rows_once (round 6): the same update as k_adam_rows_list as a ONE-SHOT grid — a wave owns NPW consecutive list
+// entries and ends; there is no persistent loop and no workgroup state.  Why: tools/lab/copy_lab.hip (profiles/
+// r06_copy_lab.txt).  On these boxes a float4 copy moves 4.8 TB/s as a persistent grid-stride loop (round 5's yardstick, and
+// the shape of every streaming kernel of the epoch) and 6.25 TB/s as a one-shot grid (MI355X_MICROARCH.md's 6.29); a
+// 3-read / 3-write triad 4.9 against 6.0.  The hardware's block dispatcher hands out work in address order as blocks
+// retire, so what is in flight stays one narrow, advancing window of DRAM pages; resident waves striding through the
+// array drift apart.  (In-order ticket counters reproduce part of it — 5.5 TB/s with 16 counters — but one agent-scope
+// atomic costs 12 ns; the dispatcher is the cheap in-order counter.)
+// What kept the Adam pass persistent was the 43 KB `comp` table in LDS.  Here a wave reads the `comp` ROW of each live
+// column of its nodes straight from the (L2-resident) table — lane b holds comp[r][b], the products fetch it with a
+// lane permute — so a wave needs nothing but its own registers.  Same fmaf chain per element as k_adam_rows_list and
+// k_adam_rows_fused: the same bits.  Measured in the AM epoch, alternating processes on one box (rocprofv3): the
+// persistent list kernel 1 485 us, one entry per wave 1 374 / 1 385 us (5.9 TB/s), two per wave 1 444 / 1 550 us.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NH, int NPW>
+__global__ __launch_bounds__(256) void k_adam_rows_once(
+    const int32_t *__restrict__ lnode, const int32_t *__restrict__ lnptr, const int32_t *__restrict__ lrel,
+    const float *__restrict__ dM, int64_t ldM, const float *__restrict__ comp, int64_t NL, int R, int B, int F,
+    float *__restrict__ p, float *__restrict__ m, float *__restrict__ v, uint8_t *__restrict__ ever, float lr, float b1,
+    float b2, float eps, float bc1, float bc2_sqrt, const float *__restrict__ scale, const float *__restrict__ bc_dev) {
+  using f4 = __attribute__((ext_vector_type(4))) float;
+  const int lane = threadIdx.x & 63;
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t i0 = w * NPW;
+  if (i0 >= NL) return;  // wave uniform
+  const int nv = (B * F) >> 2;  // 16-byte pieces of a block
+  const unsigned magicF = 65536u / (unsigned)F + 1u;  // e / F == (e * magicF) >> 16 for e * F < 2^16 (B F <= 1024)
+  const int kq = lane >> 4, oq = lane & 15;
+  // round 1: the list entries (clamped: a wave past the end repeats the last entry and stores nothing for it)
+  int64_t j[NPW];
+  int32_t n0[NPW], n1[NPW];
+#pragma unroll
+  for (int t = 0; t < NPW; ++t) {
+    const int64_t i = min(i0 + t, NL - 1);
+    j[t] = lnode[i];
+    n0[t] = lnptr[i];
+    n1[t] = lnptr[i + 1];
+  }
+  // round 2: the nodes' blocks, and relation / gradient row of their first four live columns
+  f4 P[NPW][NH], M[NPW][NH], V[NPW][NH];
+  int32_t rmine[NPW];
+  float dmine[NPW];
+#pragma unroll
+  for (int t = 0; t < NPW; ++t) {
+    const f4 *p4 = reinterpret_cast<const f4 *>(p) + j[t] * (int64_t)nv;
+    const f4 *m4 = reinterpret_cast<const f4 *>(m) + j[t] * (int64_t)nv;
+    const f4 *v4 = reinterpret_cast<const f4 *>(v) + j[t] * (int64_t)nv;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int q = min(lane + 64 * h, nv - 1);
+      P[t][h] = __builtin_nontemporal_load(p4 + q);
+      M[t][h] = __builtin_nontemporal_load(m4 + q);
+      V[t][h] = __builtin_nontemporal_load(v4 + q);
+    }
+    const int32_t cc0 = max(min(n0[t] + kq, n1[t] - 1), 0);
+    rmine[t] = lrel[cc0];
+    dmine[t] = dM[(int64_t)cc0 * ldM + min(oq, F - 1)];
+  }
+  if (bc_dev) {
+    bc1 = bc_dev[0];
+    bc2_sqrt = bc_dev[1];
+  }
+  const float sc = scale ? *scale : 1.f;
+  const float step = lr / bc1;
+  int bf[NH][4];  // (basis, feature) of the lane's elements
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned e = 4u * (unsigned)min(lane + 64 * h, nv - 1) + (unsigned)k;
+      const unsigned bb = (e * magicF) >> 16;
+      bf[h][k] = (int)((bb << 8) | (e - bb * (unsigned)F));
+    }
+  // round 3: the comp rows of those columns (lane b: comp[r][b]) — four unconditional loads per node
+  float cv[NPW][4];
+#pragma unroll
+  for (int t = 0; t < NPW; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int r = __builtin_amdgcn_readlane(rmine[t], 16 * kk);
+      cv[t][kk] = comp[(int64_t)r * B + min(lane, B - 1)];
+    }
+#pragma unroll
+  for (int t = 0; t < NPW; ++t) {
+    float g[NH][4];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[h][k] = 0.f;
+    bool lv = n0[t] + kq < n1[t];
+    int32_t rm = rmine[t];
+    float dm = dmine[t];
+    float c4[4] = {cv[t][0], cv[t][1], cv[t][2], cv[t][3]};
+    for (int32_t cb = n0[t];;) {
+      const uint64_t bl = __builtin_amdgcn_ballot_w64(lv && oq == 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (!((bl >> (16 * kk)) & 1ull)) continue;  // wave uniform: past the node's columns
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            g[h][k] = fmaf(__shfl(c4[kk], bf[h][k] >> 8), __shfl(dm, 16 * kk + (bf[h][k] & 255)), g[h][k]);
+      }
+      cb += 4;
+      if (cb >= n1[t]) break;  // (few nodes have more than four live columns)
+      const int32_t cc = min(cb + kq, n1[t] - 1);
+      lv = cb + kq < n1[t];
+      rm = lrel[cc];
+      dm = dM[(int64_t)cc * ldM + min(oq, F - 1)];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        c4[kk] = comp[(int64_t)__builtin_amdgcn_readlane(rm, 16 * kk) * B + min(lane, B - 1)];
+    }
+    if (i0 + t >= NL) continue;  // wave uniform
+    f4 *p4 = reinterpret_cast<f4 *>(p) + j[t] * (int64_t)nv;
+    f4 *m4 = reinterpret_cast<f4 *>(m) + j[t] * (int64_t)nv;
+    f4 *v4 = reinterpret_cast<f4 *>(v) + j[t] * (int64_t)nv;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float pp = P[t][h][k], mm = M[t][h][k], vv = V[t][h][k];
+        float gg = g[h][k] * sc;  // == k_adam with wd = 0
+        mm = fmaf(b1, mm, (1.f - b1) * gg);
+        vv = fmaf(b2, vv, (1.f - b2) * gg * gg);
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp -= step * (mm / denom);
+        P[t][h][k] = pp;
+        M[t][h][k] = mm;
+        V[t][h][k] = vv;
+      }
+      const int q = lane + 64 * h;
+      if (q < nv) {
+        __builtin_nontemporal_store(P[t][h], p4 + q);
+        __builtin_nontemporal_store(M[t][h], m4 + q);
+        __builtin_nontemporal_store(V[t][h], v4 + q);
+      }
+    }
+    if (lane == 0) ever[j[t]] = 1;
+  }
+}
+
 template <int FT, bool VEC2>
 __global__ __launch_bounds__(kMixTB) void k_mix_bwd_dcomp(const int32_t *__restrict__ urel,
                                                           const int32_t *__restrict__ unode,
@@ -1976,6 +2120,21 @@ int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8
     const int64_t lwant = (NL + kFusedTB / 64 - 1) / (kFusedTB / 64);
     int64_t lgrid = 256;  // 4 waves per SIMD (two node blocks in flight per wave): one block of 16 waves per CU
     if (lgrid > lwant) lgrid = lwant;
+    const int once = (int)cfg(CFG_ADAM_ONCE);  // nodes per wave of the one-shot form (0: the persistent list kernel)
+    if (once > 0 && B <= 64) {
+      // one-shot grid: a wave owns `once` consecutive list entries (see k_adam_rows_once)
+      const int npw = once >= 4 ? 4 : once >= 2 ? 2 : 1;
+      const int64_t waves = (NL + npw - 1) / npw;
+      const dim3 ogrid((unsigned)((waves + 3) / 4));
+#define ADAM_ONCE_GO(NH_, NPW_)                                                                                    \
+  k_adam_rows_once<NH_, NPW_><<<ogrid, dim3(256), 0, s>>>(lnode, lnptr, urel, dM, ldM, comp, NL, R, B, F, param,   \
+                                                          exp_avg, exp_avg_sq, row_ever, lr, beta1, beta2, eps,    \
+                                                          bc1, bc2s, grad_scale, bc_dev)
+      if (nv <= 64) { if (npw == 4) ADAM_ONCE_GO(1, 4); else if (npw == 2) ADAM_ONCE_GO(1, 2); else ADAM_ONCE_GO(1, 1); }
+      else { if (npw == 4) ADAM_ONCE_GO(2, 4); else if (npw == 2) ADAM_ONCE_GO(2, 2); else ADAM_ONCE_GO(2, 1); }
+#undef ADAM_ONCE_GO
+      MRGCN_HIP_TRY(hipGetLastError());
+    } else {
 #define ADAM_LIST_GO(NH_)                                                                                          \
   do {                                                                                                             \
     auto kfn = k_adam_rows_list<NH_, true>;                                                                        \
@@ -1988,6 +2147,7 @@ int adam_rows_fused_arrays(const int32_t *nptr, const int32_t *urel, const uint8
     else ADAM_LIST_GO(2);
 #undef ADAM_LIST_GO
     MRGCN_HIP_TRY(hipGetLastError());
+    }
   }
   if (!listed || ever_outside) {
     auto kfn = k_adam_rows_fused;

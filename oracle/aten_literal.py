@@ -125,9 +125,10 @@ def coo_tensor(rows, cols, vals, shape):
 
 
 def time_epochs(dims, R, N, B, rows, cols, vals, X, idx, targets, featureless, warmup=1, steps=2,
-                threads=None, seed=0):
+                threads=None, seed=0, per_epoch=False):
     """Times `steps` epochs (after `warmup`) of the literal ATen path; returns
-    (ms per epoch, threads used)."""
+    (ms per epoch, threads used) — with `per_epoch` the list of every timed epoch's ms instead of their mean
+    (BASELINE.md's protocol reports median and min)."""
     if threads:
         torch.set_num_threads(threads)
     A = coo_tensor(rows, cols, vals, (N, R * N))
@@ -138,6 +139,13 @@ def time_epochs(dims, R, N, B, rows, cols, vals, X, idx, targets, featureless, w
     tt = torch.from_numpy(targets)
     for _ in range(warmup):
         ep.step(Xt, A, it, tt)
+    if per_epoch:
+        each = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            ep.step(Xt, A, it, tt)
+            each.append((time.perf_counter() - t0) * 1e3)
+        return each, torch.get_num_threads()
     t0 = time.perf_counter()
     for _ in range(steps):
         ep.step(Xt, A, it, tt)
