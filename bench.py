@@ -383,23 +383,26 @@ def side_workloads(args, dev):
         out["fb15k"] = {"error": (type(e).__name__ + ": " + str(e))[:300]}
     gc.collect()
     torch.cuda.empty_cache()
-    try:
-        out["am_encoders"] = am_encoders_record(args, dev)
-    except Exception as e:  # noqa: BLE001
-        out["am_encoders"] = {"error": (type(e).__name__ + ": " + str(e))[:300]}
-    gc.collect()
-    torch.cuda.empty_cache()
+    for key, compute in (("am_encoders", "f32"), ("am_encoders_bf16", "bf16")):
+        try:
+            out[key] = am_encoders_record(args, dev, compute=compute)
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": (type(e).__name__ + ": " + str(e))[:300]}
+        gc.collect()
+        torch.cuda.empty_cache()
     return out
 
 
-def am_encoders_record(args, dev, steps=10, warm=2):
+def am_encoders_record(args, dev, steps=10, warm=2, compute="f32"):
     """extra.workloads.am_encoders — BASELINE config 3 "full multimodal": `MRGCN(FullBatch)` on the AM-shaped graph with
     the modality encoders in front of the R-GCN instead of given feature columns (mrgcn/models/mrgcn.py:189-214,
     :250-305): two xsd.numeric MLPs (-> 4 each), an xsd.date MLP (-> 3), an xsd.string head (-> 16) on a stand-in
     language model, a blob.image head (-> 128) on a stand-in CNN backbone (no pretrained weights offline: small frozen
     torch modules), and an ogc.wktLiteral TCNN (-> 5): X is N x 160.  One step = encoders + gates + scatter + the two
     R-GCN layers + CE + backward through everything + clip + Adam, replayed from a hipGraph.  `encoder_share` compares
-    it with the same epoch on given feature columns of the same width."""
+    it with the same epoch on given feature columns of the same width.  `compute` = "bf16": the bf16 pipeline
+    (`MRGCN.set_compute_dtype`): bf16 activations in the R-GCN layers, the encoders' products and the stand-in backbones
+    on the bf16 matrix cores, fp32 accumulation / parameters / BatchNorm statistics / optimizer."""
     import scipy.sparse as sp
     import torch
     import torch.nn as nn
@@ -451,6 +454,7 @@ def am_encoders_record(args, dev, steps=10, warm=2):
     modules = [(W, 10, "mrgcn", nn.ReLU()), (10, 11, "mrgcn", None)]
     model = MRGCN(modules, emb_cfg, R, N, num_bases=B, p_dropout=0.0, featureless=False, bias=True,
                   gcn_gpu_acceleration=True)
+    model.set_compute_dtype(compute)
     A = sp.csr_matrix((g.vals, (g.rows, g.cols)), shape=(N, R * N))
     X = [np.empty((N, 0), dtype=np.float32)] + [[dt, enc[dt], False] for dt in sorted(enc)]
     batch = FullBatch(A, X, np.arange(N), value_mode="norm_f32")
@@ -471,7 +475,7 @@ def am_encoders_record(args, dev, steps=10, warm=2):
         return (time.perf_counter() - t) / k * 1e3, out
     rec = {"config": {"workload": "AM-shaped synthetic KG, MRGCN(FullBatch) with modality encoders (SURVEY §8d config 3, "
                                   "full multimodal)", "N": N, "R": R, "nnz": g.nnz, "num_bases": B,
-                      "layers": [[W, 10], [10, 11]],
+                      "layers": [[W, 10], [10, 11]], "compute": compute,
                       "literals": {"xsd.numeric": [n_num1, n_num2], "xsd.date": n_date, "xsd.string (16 tokens)": n_str,
                                    "blob.image (3x16x16)": n_img, "ogc.wktLiteral (9x20)": n_wkt},
                       "backbones": "stand-in torch modules (no pretrained weights offline), frozen; heads / MLPs / TCNN "
@@ -493,6 +497,7 @@ def am_encoders_record(args, dev, steps=10, warm=2):
     # the same epoch with the encoders' output given as feature columns: what the R-GCN part costs at this width
     torch.manual_seed(args.seed)
     ref = RGCN(modules, R, N, B, 0.0, False, True, False).to(dev)
+    ref.set_operand_dtype(compute)
     Xg = torch.randn((N, W), device=dev)
     opt2 = ClipAdam(ref.parameters(), lr=0.01, max_norm=1.0, capturable=True)
     step2 = GraphedTrainStep(ref, lambda: ref(Xg, batch.A), idx, y, opt2, warmup=2)

@@ -724,6 +724,12 @@ int mrgcn_mlp_gate_scatter_bwd_f32(int32_t L, const int32_t *dims, const float *
 int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32_t N, int32_t K, const float *A,
                    int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias,
                    int32_t relu, const float *mask, float alpha, const int32_t *conv_geom, void *stream);
+/* The same product on the bf16 matrix cores (the bf16 pipeline, BASELINE config 3): operands and result stay fp32 in
+ * memory; tiles are rounded to bf16 (nearest even) as they are staged, v_mfma_f32_16x16x32_bf16, fp32 accumulation.
+ * Shapes outside the tiled form's limits run the exact fp32 element-loader kernel. */
+int mrgcn_gemm_bf16mm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32_t N, int32_t K, const float *A,
+                          int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias,
+                          int32_t relu, const float *mask, float alpha, const int32_t *conv_geom, void *stream);
 /* out[n] = sum_m X[m*ld + n]  (bias gradients) */
 int mrgcn_colsum_f32(const float *X, int64_t ld, int32_t M, int32_t N, float *out, void *stream);
 

@@ -146,6 +146,8 @@ SIGNATURES = {
                                                  _p]),
     "mrgcn_gemm_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i32, _p,
                                  C.c_float, _p, _p]),
+    "mrgcn_gemm_bf16mm_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i32, _p,
+                                 C.c_float, _p, _p]),
     "mrgcn_colsum_f32": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "mrgcn_channel_sum_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "mrgcn_bn_running_stats_f32": (C.c_int, [_p, _p, _i32, _i64, C.c_float, _p, _p, _p]),

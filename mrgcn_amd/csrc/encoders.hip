@@ -348,6 +348,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 //     bias; a ReLU / mask epilogue then runs as k_mm_finish.
 // ---------------------------------------------------------------------------------------------------
 using rsrc_t = __amdgpu_buffer_rsrc_t;
+using u32x4m = __attribute__((ext_vector_type(4))) uint32_t;
+using bf16x8m = __attribute__((ext_vector_type(8))) __bf16;
 constexpr uint32_t kOOB = 1u << 30;
 constexpr int64_t kMmMaxBytes = (int64_t)1 << 29;
 
@@ -416,11 +418,13 @@ __device__ __forceinline__ Coord mm_col(const MmArgs &g, int k, int kend) {
   }
 }
 
-template <bool IS_A, int MODE, bool ROWL, int ROWS, int BK>
+// ST: the element type the tile is STAGED in — float (v_mfma_f32_16x16x4_f32) or uint16_t = bf16 (the bf16 pipeline:
+// operands stay fp32 in memory, are rounded as they enter LDS and multiplied by v_mfma_f32_16x16x32_bf16; BK = 32)
+template <bool IS_A, int MODE, bool ROWL, int ROWS, int BK, typename ST = float>
 struct MmLoader {
   static constexpr bool CONV = IS_A && MODE >= 2;
   static constexpr int NE = ROWS * BK / 256;  // elements per thread and K step
-  static constexpr int LDK = BK + 4;
+  static constexpr int LDK = sizeof(ST) == 4 ? BK + 4 : BK + 8;  // row stride in elements: rows stay 16-byte aligned
   static constexpr int RS = 256 / BK;         // KL: distance of a thread's rows
   static constexpr int NR = ROWL ? 1 : NE;
   uint32_t roff[NR];
@@ -461,28 +465,48 @@ struct MmLoader {
         v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, at(g, i, c), 0, 0));
     }
   }
-  __device__ __forceinline__ void stage(float *Xs, const float (&v)[NE]) const {
+  __device__ __forceinline__ void stage(ST *Xs, const float (&v)[NE]) const {
     if constexpr (ROWL) {
-      float *dst = Xs + (threadIdx.x % ROWS) * LDK + (threadIdx.x / ROWS) * NE;
+      ST *dst = Xs + (threadIdx.x % ROWS) * LDK + (threadIdx.x / ROWS) * NE;
+      if constexpr (sizeof(ST) == 4) {
 #pragma unroll
-      for (int h = 0; h < NE / 4; ++h)
-        *reinterpret_cast<f32x4 *>(dst + 4 * h) = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+        for (int h = 0; h < NE / 4; ++h)
+          *reinterpret_cast<f32x4 *>(dst + 4 * h) = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+      } else {
+        static_assert(sizeof(ST) == 4 || NE % 8 == 0, "bf16 staging stores whole 16-byte pieces");
+#pragma unroll
+        for (int h = 0; h < NE / 8; ++h) {
+          u32x4m o;
+          o.x = (uint32_t)f32_to_bf16(v[8 * h + 0]) | ((uint32_t)f32_to_bf16(v[8 * h + 1]) << 16);
+          o.y = (uint32_t)f32_to_bf16(v[8 * h + 2]) | ((uint32_t)f32_to_bf16(v[8 * h + 3]) << 16);
+          o.z = (uint32_t)f32_to_bf16(v[8 * h + 4]) | ((uint32_t)f32_to_bf16(v[8 * h + 5]) << 16);
+          o.w = (uint32_t)f32_to_bf16(v[8 * h + 6]) | ((uint32_t)f32_to_bf16(v[8 * h + 7]) << 16);
+          *reinterpret_cast<u32x4m *>(dst + 8 * h) = o;
+        }
+      }
     } else {
-      float *dst = Xs + (threadIdx.x / BK) * LDK + (threadIdx.x % BK);
+      ST *dst = Xs + (threadIdx.x / BK) * LDK + (threadIdx.x % BK);
 #pragma unroll
-      for (int i = 0; i < NE; ++i) dst[RS * i * LDK] = v[i];
+      for (int i = 0; i < NE; ++i) {
+        if constexpr (sizeof(ST) == 4) dst[RS * i * LDK] = v[i];
+        else dst[RS * i * LDK] = f32_to_bf16(v[i]);
+      }
     }
   }
 };
 
 // MT / NT: 16 x 16 MFMA tiles per wave along m / n — block tile 32 MT x 32 NT (128 x 128, 128 x 64, 64 x 64)
 // AR / BR: the lanes of the A / B loader run along the tile rows (else along k)
-template <int AMODE, int BMODE, int CMODE, bool AR, bool BR, int MT, int NT, int BK>
+template <int AMODE, int BMODE, int CMODE, bool AR, bool BR, int MT, int NT, int BK, typename ST = float>
 __global__ __launch_bounds__(256) void k_mm_tile(MmArgs g) {
-  constexpr int BM = 32 * MT, BN = 32 * NT, LDK = BK + 4, ASZ = BM * LDK, BSZ = BN * LDK;
+  constexpr bool BF = sizeof(ST) == 2;
+  static_assert(!BF || BK == 32, "the bf16 form multiplies one 32-wide k-step per stage");
+  constexpr int BM = 32 * MT, BN = 32 * NT, LDK = BF ? BK + 8 : BK + 4, ASZ = BM * LDK, BSZ = BN * LDK;
   constexpr int WR = 16 * MT, CST = WR + 4;  // rows of a wave; row stride of its transposition buffer
-  static_assert(2 * (ASZ + BSZ) >= 4 * 16 * CST, "the epilogue's transposition buffer fits the stages");
-  __shared__ __align__(16) float smem[2 * (ASZ + BSZ)];
+  static_assert(2 * (ASZ + BSZ) * sizeof(ST) >= 4 * 16 * CST * sizeof(float),
+                "the epilogue's transposition buffer fits the stages");
+  __shared__ __align__(16) ST smem_st[2 * (ASZ + BSZ)];
+  float *smem = reinterpret_cast<float *>(smem_st);  // (the epilogue's view)
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = (wv >> 1) * WR, wn = (wv & 1) * (16 * NT);
@@ -494,8 +518,8 @@ __global__ __launch_bounds__(256) void k_mm_tile(MmArgs g) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, g.a_bytes, 0x00020000);
   const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)g.B, 0, g.b_bytes, 0x00020000);
-  MmLoader<true, AMODE, AR, BM, BK> la;
-  MmLoader<false, BMODE, BR, BN, BK> lb;
+  MmLoader<true, AMODE, AR, BM, BK, ST> la;
+  MmLoader<false, BMODE, BR, BN, BK, ST> lb;
   la.init(g, m0);
   lb.init(g, n0);
   const int kbeg = g.kchunk > 0 ? blockIdx.z * g.kchunk : 0;
@@ -503,8 +527,8 @@ __global__ __launch_bounds__(256) void k_mm_tile(MmArgs g) {
   float va[decltype(la)::NE], vb[decltype(lb)::NE];
   la.load(g, ra, kbeg, kend, va);
   lb.load(g, rb, kbeg, kend, vb);
-  la.stage(smem, va);
-  lb.stage(smem + ASZ, vb);
+  la.stage(smem_st, va);
+  lb.stage(smem_st + ASZ, vb);
   __syncthreads();
   int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -513,24 +537,40 @@ __global__ __launch_bounds__(256) void k_mm_tile(MmArgs g) {
       la.load(g, ra, k0 + BK, kend, va);
       lb.load(g, rb, k0 + BK, kend, vb);
     }
-    const float *Ac = smem + cur * (ASZ + BSZ), *Bc = Ac + ASZ;
+    const ST *Ac = smem_st + cur * (ASZ + BSZ), *Bc = Ac + ASZ;
+    if constexpr (BF) {
+      // one k-step of 32: lane (m = lane & 15, g = lane >> 4) holds k = 8 g .. 8 g + 7 of its row (16 bytes)
+      bf16x8m a[MT], b[NT];
 #pragma unroll
-    for (int kg = 0; kg < BK / 16; ++kg) {
-      f32x4 a[MT], b[NT];
+      for (int i = 0; i < MT; ++i)
+        a[i] = __builtin_bit_cast(bf16x8m, *reinterpret_cast<const u32x4m *>(Ac + (wm + 16 * i + lm) * LDK + 8 * kq));
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4 *>(Ac + (wm + 16 * i + lm) * LDK + 16 * kg + 4 * kq);
+      for (int j = 0; j < NT; ++j)
+        b[j] = __builtin_bit_cast(bf16x8m, *reinterpret_cast<const u32x4m *>(Bc + (wn + 16 * j + lm) * LDK + 8 * kq));
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4 *>(Bc + (wn + 16 * j + lm) * LDK + 16 * kg + 4 * kq);
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    } else {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+      for (int kg = 0; kg < BK / 16; ++kg) {
+        f32x4 a[MT], b[NT];
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4 *>(Ac + (wm + 16 * i + lm) * LDK + 16 * kg + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4 *>(Bc + (wn + 16 * j + lm) * LDK + 16 * kg + 4 * kq);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+      }
     }
     if (more) {
-      float *An = smem + (cur ^ 1) * (ASZ + BSZ);
+      ST *An = smem_st + (cur ^ 1) * (ASZ + BSZ);
       la.stage(An, va);
       lb.stage(An + ASZ, vb);
     }
@@ -650,7 +690,7 @@ namespace {
 
 // launch of k_mm_tile; MRGCN_ERR_UNSUPPORTED = not a shape / mode combination it takes (the caller goes on to the
 // older forms)
-int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
+int mm_tile_launch(const GemmArgs &o, hipStream_t stream, bool bf16 = false) {
   const int M = o.M, N = o.N, K = o.K;
   int cmode = o.cmode;
   int64_t ldc = o.ldc;
@@ -744,9 +784,15 @@ int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
   }
 #define MM_GO1(AM_, BM_, CM_, AR_, BR_, MT_, NT_, BK_) \
   k_mm_tile<AM_, BM_, CM_, AR_, BR_, MT_, NT_, BK_><<<grid, dim3(256), 0, stream>>>(g)
+#define MM_GOB(AM_, BM_, CM_, AR_, BR_, MT_, NT_) \
+  k_mm_tile<AM_, BM_, CM_, AR_, BR_, MT_, NT_, 32, uint16_t><<<grid, dim3(256), 0, stream>>>(g)
 #define MM_GO(AM_, BM_, CM_, AR_, BR_)                                     \
   do {                                                                     \
-    if (BM == 64) MM_GO1(AM_, BM_, CM_, AR_, BR_, 2, 2, 32);               \
+    if (bf16) { /* operands rounded to bf16 as they are staged, v_mfma_f32_16x16x32_bf16, fp32 sums */ \
+      if (BM == 64) MM_GOB(AM_, BM_, CM_, AR_, BR_, 2, 2);                 \
+      else if (BN == 64) MM_GOB(AM_, BM_, CM_, AR_, BR_, 4, 2);            \
+      else MM_GOB(AM_, BM_, CM_, AR_, BR_, 4, 4);                          \
+    } else if (BM == 64) MM_GO1(AM_, BM_, CM_, AR_, BR_, 2, 2, 32);        \
     else if (BN == 64) MM_GO1(AM_, BM_, CM_, AR_, BR_, 4, 2, 16);          \
     else MM_GO1(AM_, BM_, CM_, AR_, BR_, 4, 4, 16);                        \
   } while (0)
@@ -763,6 +809,7 @@ int mm_tile_launch(const GemmArgs &o, hipStream_t stream) {
     default: MM_GO(3, 2, 0, true, true); break;
   }
 #undef MM_GO
+#undef MM_GOB
 #undef MM_GO1
   MRGCN_HIP_TRY(hipGetLastError());
   if (splits > 1 && (o.relu || o.mask)) {
@@ -861,6 +908,28 @@ int mrgcn_gemm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32
   const bool tiled_on = cfg(CFG_GEMM_TILED) != 0;
   if (tiled_on) {
     const int rc = mm_tile_launch(g, (hipStream_t)stream);
+    if (rc != MRGCN_ERR_UNSUPPORTED) return rc;
+  }
+  dim3 grid((unsigned)((N + kGT - 1) / kGT), (unsigned)((M + kGT - 1) / kGT));
+  k_gemm_f32<<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+// The same product with bf16 matrix-core arithmetic (the bf16 pipeline of BASELINE config 3): operands and result stay
+// fp32 in memory, the operands are rounded to bf16 (nearest even) as tiles are staged, v_mfma_f32_16x16x32_bf16 with
+// fp32 accumulation.  Shapes outside the tiled form's limits take the fp32 element-loader kernel (exact fp32).
+int mrgcn_gemm_bf16mm_f32(int32_t amode, int32_t bmode, int32_t cmode, int32_t M, int32_t N, int32_t K, const float *A,
+                          int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, const float *bias,
+                          int32_t relu, const float *mask, float alpha, const int32_t *conv_geom, void *stream) {
+  MRGCN_REQUIRE(A && B && C && M >= 0 && N >= 0 && K >= 0, "operands");
+  MRGCN_REQUIRE(amode >= 0 && amode <= 3 && bmode >= 0 && bmode <= 2 && (cmode == 0 || cmode == 2), "modes");
+  MRGCN_REQUIRE((amode < 2 && bmode < 2 && cmode == 0) || conv_geom, "conv modes need the geometry");
+  if (M == 0 || N == 0) return MRGCN_OK;
+  GemmArgs g{A, B, C, lda, ldb, ldc, M, N, K, amode, bmode, cmode, bias, relu, mask, alpha, ConvGeom{}};
+  if (conv_geom) g.cg = ConvGeom{conv_geom[0], conv_geom[1], conv_geom[2], conv_geom[3], conv_geom[4], conv_geom[5]};
+  if (cfg(CFG_GEMM_TILED) != 0) {
+    const int rc = mm_tile_launch(g, (hipStream_t)stream, true);
     if (rc != MRGCN_ERR_UNSUPPORTED) return rc;
   }
   dim3 grid((unsigned)((N + kGT - 1) / kGT), (unsigned)((M + kGT - 1) / kGT));

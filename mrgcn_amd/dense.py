@@ -14,14 +14,37 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# Arithmetic of the encoders' products: "f32" (v_mfma_f32_16x16x4_f32, exact fp32 — the parity default) or "bf16" (the
+# bf16 pipeline of BASELINE config 3: operands rounded to bf16 as tiles are staged, v_mfma_f32_16x16x32_bf16, fp32
+# accumulation; activations, parameters, BatchNorm statistics and every gradient stay fp32 in memory).  Process-wide,
+# like torch's matmul precision switches; MRGCN.set_compute_dtype sets it.
+_MATMUL_DTYPE = "f32"
+
+
+def set_matmul_dtype(dtype: str) -> str:
+    """Returns the previous setting."""
+    global _MATMUL_DTYPE
+    assert dtype in ("f32", "bf16")
+    prev, _MATMUL_DTYPE = _MATMUL_DTYPE, dtype
+    return prev
+
+
+def matmul_dtype() -> str:
+    return _MATMUL_DTYPE
+
+
 def _gemm(amode, bmode, cmode, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, relu=False, mask=None, alpha=1.0,
-          geom=None):
+          geom=None, mm=None):
+    """`mm`: the arithmetic ("f32" / "bf16"; None = the process-wide setting) — a backward passes what its forward ran
+    with."""
     g = (C.c_int32 * 6)(*geom) if geom is not None else None
+    lib = L.load()
+    fn, name = ((lib.mrgcn_gemm_bf16mm_f32, "mrgcn_gemm_bf16mm_f32") if (mm or _MATMUL_DTYPE) == "bf16"
+                else (lib.mrgcn_gemm_f32, "mrgcn_gemm_f32"))
     with torch.cuda.device(Cout.device):
-        L.check(L.load().mrgcn_gemm_f32(
-            amode, bmode, cmode, M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, Cout.data_ptr(), ldc,
-            bias.data_ptr() if bias is not None else 0, 1 if relu else 0, mask.data_ptr() if mask is not None else 0,
-            float(alpha), g, _stream(Cout.device)), "mrgcn_gemm_f32")
+        L.check(fn(amode, bmode, cmode, M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, Cout.data_ptr(), ldc,
+                   bias.data_ptr() if bias is not None else 0, 1 if relu else 0, mask.data_ptr() if mask is not None else 0,
+                   float(alpha), g, _stream(Cout.device)), name)
     return Cout
 
 
@@ -67,7 +90,7 @@ class _Linear(torch.autograd.Function):
         bc = b.contiguous() if b is not None else None
         for r0, r1 in _batch_pieces(n, K, N):
             _gemm(0, 1, 0, r1 - r0, N, K, x2[r0:r1], K, Wc, K, y[r0:r1], N, bias=bc, relu=relu)
-        ctx.relu, ctx.shape, ctx.has_b = relu, x.shape, b is not None
+        ctx.relu, ctx.shape, ctx.has_b, ctx.mm = relu, x.shape, b is not None, _MATMUL_DTYPE
         ctx.save_for_backward(x2, Wc, y if relu else None)
         return y.view(*x.shape[:-1], N)
 
@@ -84,12 +107,12 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((n, K), dtype=torch.float32, device=dy.device)
             for r0, r1 in _batch_pieces(n, K, N):
-                _gemm(0, 0, 0, r1 - r0, K, N, dy2[r0:r1], N, W, K, dx[r0:r1], K)   # dx = dy . W
+                _gemm(0, 0, 0, r1 - r0, K, N, dy2[r0:r1], N, W, K, dx[r0:r1], K, mm=ctx.mm)   # dx = dy . W
             dx = dx.view(ctx.shape)
         if ctx.needs_input_grad[1]:
             for r0, r1 in _batch_pieces(n, K, N):
                 part = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-                _gemm(1, 0, 0, N, K, r1 - r0, dy2[r0:r1], N, x2[r0:r1], K, part, K)   # dW = dy^T . x
+                _gemm(1, 0, 0, N, K, r1 - r0, dy2[r0:r1], N, x2[r0:r1], K, part, K, mm=ctx.mm)   # dW = dy^T . x
                 dW = part if dW is None else dW.add_(part)
             if dW is None:
                 dW = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
@@ -128,7 +151,7 @@ class _Conv1d(torch.autograd.Function):
         for b0, b1 in _batch_pieces(Bn, Cin * Tin, Cout * Tout):
             _gemm(2, 1, 2, (b1 - b0) * Tout, Cout, Cin * KW, x[b0:b1], 0, Wc.view(Cout, Cin * KW), Cin * KW, y[b0:b1], 0,
                   bias=bc, geom=geom)
-        ctx.geom, ctx.has_b = geom, b is not None
+        ctx.geom, ctx.has_b, ctx.mm = geom, b is not None, _MATMUL_DTYPE
         ctx.save_for_backward(x, Wc)
         return y
 
@@ -145,13 +168,14 @@ class _Conv1d(torch.autograd.Function):
             dx = torch.empty_like(x)
             for b0, b1 in _batch_pieces(Bn, Cin * Tin, Cout * Tout):
                 _gemm(2, 0, 2, (b1 - b0) * Tin, Cin, Cout * KW, dy[b0:b1], 0, Wf, Cin, dx[b0:b1], 0,
-                      geom=(Cout, Tout, KW, KW - 1 - pad, Tin, Cin))
+                      geom=(Cout, Tout, KW, KW - 1 - pad, Tin, Cin), mm=ctx.mm)
         if ctx.needs_input_grad[1]:
             # dW^T[(ci, kw)][co] = sum_{b, t} x[b, ci, t + kw - pad] dy[b, co, t]
             dWt = None
             for b0, b1 in _batch_pieces(Bn, Cin * Tin, Cout * Tout):
                 part = torch.empty((Cin * KW, Cout), dtype=torch.float32, device=dy.device)
-                _gemm(3, 2, 0, Cin * KW, Cout, (b1 - b0) * Tout, x[b0:b1], 0, dy[b0:b1], 0, part, Cout, geom=ctx.geom)
+                _gemm(3, 2, 0, Cin * KW, Cout, (b1 - b0) * Tout, x[b0:b1], 0, dy[b0:b1], 0, part, Cout, geom=ctx.geom,
+                      mm=ctx.mm)
                 dWt = part if dWt is None else dWt.add_(part)
             if dWt is None:
                 dWt = torch.zeros((Cin * KW, Cout), dtype=torch.float32, device=dy.device)

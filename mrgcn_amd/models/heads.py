@@ -38,6 +38,11 @@ def inferOutputDim(model):
     return -1
 
 
+def _widen(t):
+    """a backbone output that came out of the bf16 autocast goes on in fp32 (the heads' parameters are fp32)"""
+    return t.float() if t.dtype in (torch.bfloat16, torch.float16) else t
+
+
 class _Head(nn.Module):
     def __init__(self, base_model, inter_dim, output_dim, p_dropout, bias, finetune):
         super().__init__()
@@ -49,6 +54,16 @@ class _Head(nn.Module):
         self.pre_fc = nn.Linear(inter_dim, inter_dim, bias=bias)
         self.fc = nn.Linear(inter_dim, output_dim, bias=bias)
         self.f_activation = nn.ReLU()
+
+    def _backbone(self, X):
+        """The (frozen or fine-tuned) backbone.  With the bf16 pipeline on (`dense.matmul_dtype() == "bf16"`: BASELINE
+        config 3) it runs under torch's bf16 autocast — its convolutions and products on the bf16 matrix cores, fp32
+        parameters; the reference has no reduced precision (imagecnn.py:9-41, transformer.py:8-38)."""
+        from .. import dense
+        if dense.matmul_dtype() == "bf16" and torch.is_tensor(X) and X.is_cuda:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return self.base_model(X)
+        return self.base_model(X)
 
     def _project(self, pooled):
         """pre_fc -> ReLU -> dropout -> fc (imagecnn.py:31-41, transformer.py:29-38); on the GPU the two products
@@ -73,7 +88,7 @@ class ImageCNN(_Head):
         self.dropout = nn.Dropout(p=p_dropout) if p_dropout > 0 else None
 
     def forward(self, X):
-        return self._project(torch.flatten(self.avgpool(self.base_model(X)), 1))
+        return self._project(_widen(torch.flatten(self.avgpool(self._backbone(X)), 1)))
 
 
 class Transformer(_Head):
@@ -82,8 +97,8 @@ class Transformer(_Head):
         self.dropout = nn.Dropout(p=p_dropout) if p_dropout > 0 else None
 
     def forward(self, X):
-        hidden_state = self.base_model(X)[0]      # (batch, seq_len, dim)
-        return self._project(hidden_state[:, 0])  # first token
+        hidden_state = self._backbone(X)[0]      # (batch, seq_len, dim)
+        return self._project(_widen(hidden_state[:, 0]))  # first token
 
 
 class Normalizer:

@@ -151,10 +151,24 @@ class MRGCN(nn.Module):
             self.gate_weights = self.gate_weights.to(device)
 
     # ------------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype: str):
+        """"f32" (the reference's arithmetic: the parity default) or "bf16" — BASELINE config 3's pipeline: the R-GCN
+        layers store their activations in bf16 (`RGCN.set_operand_dtype`), the encoders' products (MLP / TCNN / heads)
+        and the backbones run on the bf16 matrix cores with fp32 accumulation; parameters, BatchNorm statistics,
+        gradients and the optimizer stay fp32.  The reference has no reduced precision anywhere (mrgcn.py:250-305)."""
+        assert dtype in ("f32", "bf16")
+        self.compute_dtype = dtype
+        self.rgcn.set_operand_dtype(dtype)
+
     def forward(self, batch):
-        if type(batch).__name__ == "MiniBatch":
-            return self._forward_mini_batch(batch)
-        return self._forward_full_batch(batch)
+        from .. import dense
+        prev = dense.set_matmul_dtype(getattr(self, "compute_dtype", "f32"))
+        try:   # (the backward of every product runs with what its forward ran with: dense._Linear / _Conv1d)
+            if type(batch).__name__ == "MiniBatch":
+                return self._forward_mini_batch(batch)
+            return self._forward_full_batch(batch)
+        finally:
+            dense.set_matmul_dtype(prev)
 
     def _forward_mini_batch(self, batch):
         """mrgcn.py:216-248: modality embeddings only for the outermost neighbours, then the

@@ -368,6 +368,74 @@ def test_conv1d_on_the_matrix_cores_vs_torch(B, Cin, T, Cout, KW, pad):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(70, 130, 65), (300, 1100, 200), (1000, 96, 520), (130, 2050, 70), (33, 768, 16),
+                                   (5, 3, 2)])
+def test_linear_on_the_bf16_matrix_cores(shape):
+    """The bf16 pipeline's products (`dense.set_matmul_dtype("bf16")`, mrgcn_gemm_bf16mm_f32): fp32 operands rounded to
+    bf16 as tiles are staged, v_mfma_f32_16x16x32_bf16, fp32 accumulation.  A tiled shape equals the float64 product of
+    the ROUNDED operands to fp32 accuracy; every shape (the small ones run the exact fp32 kernel) stays within 1e-2 of
+    the largest element of the unrounded float64 result — forward and all three gradients, whose products run with
+    what the forward ran with even after the switch is back at "f32"."""
+    from mrgcn_amd import dense
+    n, K, N = shape
+    gen = torch.Generator("cuda").manual_seed(n + K)
+    x = torch.randn((n, K), device="cuda", generator=gen, requires_grad=True)
+    W = torch.randn((N, K), device="cuda", generator=gen, requires_grad=True)
+    b = torch.randn((N,), device="cuda", generator=gen, requires_grad=True)
+    w = torch.randn((n, N), device="cuda", generator=gen)
+    prev = dense.set_matmul_dtype("bf16")
+    try:
+        y = dense.linear(x, W, b, relu=False)   # (no ReLU in front of the gradient check: a unit at the kink flips whole)
+        yr = dense.linear(x.detach(), W.detach(), b.detach(), relu=True)
+    finally:
+        dense.set_matmul_dtype(prev)
+    assert dense.matmul_dtype() == "f32"
+    (y * w).sum().backward()
+    tiled = (n >= 48 and N >= 48) or K >= 1024
+    xr, Wr = (t.detach().to(torch.bfloat16).double() for t in (x, W))
+    if tiled:
+        exact = xr @ Wr.t() + b.detach().double()
+        tol = dict(rtol=1e-5, atol=1e-5 * max(1.0, K ** 0.5))
+        torch.testing.assert_close(y.detach().double(), exact, **tol)
+        torch.testing.assert_close(yr.double(), torch.relu(exact), **tol)
+        assert float((y.detach().double() - (x.detach().double() @ W.detach().double().t() + b.detach().double())).abs().max()) > 0
+    x64, W64, b64 = (t.detach().double().requires_grad_(True) for t in (x, W, b))
+    r = x64 @ W64.t() + b64
+    (r * w.double()).sum().backward()
+    for name, got, ref in (("y", y, r), ("dx", x.grad, x64.grad), ("dW", W.grad, W64.grad), ("db", b.grad, b64.grad)):
+        err = float((got.double() - ref).abs().max())
+        assert err <= 1e-2 * float(ref.abs().max()) + 1e-6, (name, err, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,T,Cout,KW,pad", [(500, 9, 20, 64, 3, 1), (300, 64, 5, 128, 3, 1), (600, 128, 2, 256, 2, 0),
+                                                 (24, 37, 300, 64, 7, 3), (40, 128, 33, 256, 3, 1), (150, 512, 3, 1024, 3, 0),
+                                                 (64, 32, 1, 48, 3, 1), (2, 3, 20, 5, 3, 1)])
+def test_conv1d_on_the_bf16_matrix_cores(B, Cin, T, Cout, KW, pad):
+    """The TCNN's convolutions with bf16 matrix-core arithmetic (every loader mode of the tiled product: im2col rows,
+    its transpose, the y[b][n][t] operand and output) against torch's float64 convolution: forward and gradients within
+    1e-2 of the result's largest element."""
+    from mrgcn_amd import dense
+    gen = torch.Generator("cuda").manual_seed(B + T)
+    x = torch.randn((B, Cin, T), device="cuda", generator=gen, requires_grad=True)
+    W = torch.randn((Cout, Cin, KW), device="cuda", generator=gen, requires_grad=True)
+    b = torch.randn((Cout,), device="cuda", generator=gen, requires_grad=True)
+    prev = dense.set_matmul_dtype("bf16")
+    try:
+        y = dense.conv1d(x, W, b, padding=pad)
+    finally:
+        dense.set_matmul_dtype(prev)
+    w = torch.randn(y.shape, device="cuda", generator=gen)
+    (y * w).sum().backward()
+    x64, W64, b64 = (t.detach().double().cpu().requires_grad_(True) for t in (x, W, b))
+    r = torch.nn.functional.conv1d(x64, W64, b64, padding=pad)
+    (r * w.double().cpu()).sum().backward()
+    for name, got, ref in (("y", y, r), ("dx", x.grad, x64.grad), ("dW", W.grad, W64.grad), ("db", b.grad, b64.grad)):
+        err = float((got.double().cpu() - ref).abs().max())
+        assert err <= 1e-2 * float(ref.abs().max()) + 1e-6, (name, err, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
 def test_products_cut_along_the_batch_equal_the_single_launch(monkeypatch):
     """Operands beyond the tiled product's 2^29-byte reach are multiplied piece by piece along the batch
     (dense._batch_pieces): forced here with a small limit, the results equal the single launch."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One replayed step of bench.am_encoders_record (BASELINE config 3, full multimodal) kernel by kernel.
 
-  rocprofv3 --kernel-trace --output-format csv -d <dir> -o run -- python3 tools/am_encoders_step.py run
+  rocprofv3 --kernel-trace --output-format csv -d <dir> -o run -- python3 tools/am_encoders_step.py run [f32|bf16]
   python3 tools/am_encoders_step.py summary <dir>        -> markdown on stdout
 """
 import argparse
@@ -15,10 +15,10 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run():
+def run(compute="f32"):
     import torch
     import bench
-    rec = bench.am_encoders_record(argparse.Namespace(seed=0), torch.device("cuda:0"), steps=10, warm=2)
+    rec = bench.am_encoders_record(argparse.Namespace(seed=0), torch.device("cuda:0"), steps=10, warm=2, compute=compute)
     print(json.dumps({k: v for k, v in rec.items() if k != "config"}))
 
 
@@ -27,7 +27,7 @@ def summary(d):
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # a step of the encoders model = between two Adam passes over the node table with encoder kernels in between
-    marks = [i for i, r in enumerate(rows) if "k_adam_rows_list" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "k_adam_rows_list" in r["Kernel_Name"] or "k_adam_rows_once" in r["Kernel_Name"]]
     best = None
     for a, b in zip(marks[:-1], marks[1:]):
         if any("k_mm_tile" in rows[i]["Kernel_Name"] for i in range(a, b)):
@@ -62,4 +62,4 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "summary":
         summary(sys.argv[2])
     else:
-        run()
+        run(sys.argv[2] if len(sys.argv) >= 3 and sys.argv[1] == "run" else "f32")
