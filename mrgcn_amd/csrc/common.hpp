@@ -90,6 +90,8 @@ struct RelOrder {
   const int32_t *relchunk_ids = nullptr;  // [n_relchunks] chunk ids grouped by relation
   int32_t n_relchunks = 0, max_relchunks = 0;
 };
+constexpr int kWorkTickets = 64;       // counters of mrgcn_plan::work_tickets
+constexpr int kWorkTicketStride = 64;  // unsigned long longs between two counters (512 bytes)
 constexpr int kNarrowInput = 32;       // inputs of up to this many floats per row take the narrow order
 constexpr int kNodeBandNarrow = 32768; // source nodes per band of the narrow order
 // bf16 <-> f32 (raw uint16_t storage; round to nearest even, NaN kept quiet)
@@ -257,6 +259,9 @@ struct mrgcn_plan {
   int32_t *r3_ticket = nullptr;  // [ticket_ints] arrival counters of the in-kernel finalize (zero between launches):
                                  // one per long row of whichever view a product runs on
   int64_t ticket_ints = 1;
+  // in-order work tickets of the persistent streaming kernels (k_mix_fwd_mfma's TK form): kWorkTickets counters, one
+  // 512-byte slot each (different channels); zeroed by the launcher in front of every launch
+  unsigned long long *work_tickets = nullptr;
   // k_spmm3's one-wave rows (kMid3Rows < len <= kChunk3Entries); r3_* above describe the longer, blockwise rows
   int32_t *r3s_long_row = nullptr, *r3s_long_cptr = nullptr, *r3s_chunk_beg = nullptr, *r3s_chunk_end = nullptr,
           *r3s_chunk_row = nullptr;

@@ -48,6 +48,8 @@ enum CfgKey : int {
   CFG_MIX_ADD_VEC,
   CFG_SUP_REL_CHUNK,
   CFG_ADAM_ONCE,
+  CFG_MIX_TICKETS,
+  CFG_MIX_TICKET_TILE,
   CFG_COUNT
 };
 int64_t cfg(CfgKey k);

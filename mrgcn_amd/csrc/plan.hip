@@ -1065,6 +1065,8 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
     p->ticket_ints = std::max<int64_t>(std::max<int64_t>(std::max(p->r3_n_long, p->r_n_long), std::max(p->q_n_long, p->c_n_long)), 1);
     MRGCN_HIP_TRY(plan_alloc(p, &p->r3_ticket, p->ticket_ints));
     MRGCN_HIP_TRY(hipMemsetAsync(p->r3_ticket, 0, (size_t)p->ticket_ints * sizeof(int32_t), s));
+    MRGCN_HIP_TRY(plan_alloc(p, &p->work_tickets, (int64_t)kWorkTickets * kWorkTicketStride));
+    MRGCN_HIP_TRY(hipMemsetAsync(p->work_tickets, 0, (size_t)kWorkTickets * kWorkTicketStride * sizeof(unsigned long long), s));
   }
   {  // the rows k_spmm3 leaves partial sums of (more than one block): the two-pass form's finalize launches one wave for each
     const int64_t nl = p->r3_n_long;
@@ -1106,7 +1108,8 @@ void release_plan(mrgcn_plan *q, uint64_t ep) {
                   q->rep_src, q->rep_dst, q->partials, q->r3_multi, q->r3_ticket,
                   q->r3s_long_row, q->r3s_long_cptr, q->r3s_chunk_beg, q->r3s_chunk_end, q->r3s_chunk_row,
                   q->n_rperm, q->n_relptr, q->n_rnode, q->n_rmpos, q->n_relchunk_rel, q->n_relchunk_beg,
-                  q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids, q->op_node, q->op_rel, q->mlcol};
+                  q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids, q->op_node, q->op_rel, q->mlcol,
+                  q->work_tickets};
   // (after the wait any stream may take the blocks; the plan's own build stream is where the next build of a
   // similar slice will ask for them again: the pool hands them back without a driver call)
   for (void *a : ptrs) pool_free(a, q->build_stream, ep);

@@ -286,12 +286,21 @@ __global__ __launch_bounds__(256) void k_mix_fwd_wide(const int32_t *__restrict_
 // reach the accumulator layout through a per-wave LDS piece — instead of four 4-byte loads per node whose lanes
 // address four different rows (ADD = 1, kept for other row strides).
 constexpr int kAddPieces = 128;  // 16-byte pieces of addend rows per step (two loads per lane): 42 columns at ldA = 12
-template <int KS, int NQ, int TN, int ADD, typename OT, bool IDS = false, typename AT = float>
+// TK (round 6): the waves take their steps IN ORDER from ticket counters instead of striding through the node range.
+// tools/lab/copy_lab.hip: a persistent grid-stride stream runs at 4.8-4.9 TB/s on these boxes, a one-shot grid — work
+// handed out in address order as blocks retire — at 6.0-6.25; resident waves drift apart and what is in flight stops
+// being one narrow window of DRAM pages.  This kernel cannot be a one-shot grid (its comp table is most of a CU's LDS),
+// so a wave draws TILES of kMixTile consecutive steps from one of kWorkTickets counters (counter c serves the c-th
+// contiguous slice of the node range; one agent-scope atomic costs ~12 ns at a single address: per-step tickets from
+// one counter would take longer than the kernel), the next tile's ticket one tile ahead.
+constexpr int kMixTile = 4;  // default steps (of TN nodes) per ticket (`mix_ticket_tile`)
+template <int KS, int NQ, int TN, int ADD, typename OT, bool IDS = false, typename AT = float, bool TK = false>
 __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
     const int32_t *__restrict__ nptr, const int32_t *__restrict__ urel, const int32_t *__restrict__ mpos,
     const float *__restrict__ V, const float *__restrict__ comp, int64_t N, int R, int B, int F,
     const AT *__restrict__ addend, int64_t ldA, OT *__restrict__ M, int64_t ldM,
-    const int32_t *__restrict__ node_ids = nullptr) {
+    const int32_t *__restrict__ node_ids = nullptr, unsigned long long *__restrict__ tickets = nullptr,
+    int n_counters = 0, int tile = kMixTile) {
   extern __shared__ __align__(16) float s_mem[];
   constexpr int KP = KS * 16 + 4;  // padded comp row: rows start on different banks
   float *s_comp = s_mem;           // [R][KP], zero beyond B
@@ -310,7 +319,39 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
   const int m = lane & 15, kq = lane >> 4;  // A: column m of the tile, k quarter kq;  D: feature m, column quarter kq
   const int64_t ngroups = (N + TN - 1) / TN;
   const int64_t nwaves = (int64_t)gridDim.x * nw;
-  int64_t g = (int64_t)blockIdx.x * nw + wv;
+  // the wave's sequence of steps g, g1 (next), g2 (the one after): a stride of `nwaves`, or (TK) consecutive steps of
+  // tiles drawn from the wave's ticket counter
+  int64_t g = (int64_t)blockIdx.x * nw + wv, g1 = g + nwaves, g2 = g + 2 * nwaves;
+  unsigned long long *ctr = nullptr;
+  int64_t seg_lo = 0, seg_hi = 0;      // TK: the steps [seg_lo, seg_hi) this wave's counter serves
+  unsigned long long tk_ahead = 0;     // TK: the ticket after the tile g2 is in (lane 0 holds the atomic's answer)
+  auto tile_first = [&](unsigned long long t) {  // first step of ticket t of this wave's segment (>= ngroups: none)
+    const int64_t st = seg_lo + (int64_t)t * tile;
+    return st < seg_hi ? st : ngroups;
+  };
+  auto next_step = [&](int64_t x) {    // the step after x in this wave's sequence (TK)
+    if (x >= ngroups) return x;
+    if ((x - seg_lo + 1) % tile != 0 && x + 1 < seg_hi) return x + 1;
+    const unsigned long long t = __shfl(tk_ahead, 0, 64);
+    if (lane == 0) tk_ahead = atomicAdd(ctr, 1ull);
+    return tile_first(t);
+  };
+  if (TK) {
+    const int64_t wid = g;  // global wave id
+    const int c = (int)(wid % n_counters);
+    ctr = tickets + (int64_t)c * kWorkTicketStride;
+    const int64_t per = ((ngroups + n_counters - 1) / n_counters + tile - 1) / tile * tile;
+    seg_lo = (int64_t)c * per;
+    seg_hi = min(seg_lo + per, ngroups);
+    unsigned long long t0 = 0;
+    if (lane == 0) {
+      t0 = atomicAdd(ctr, 1ull);
+      tk_ahead = atomicAdd(ctr, 1ull);
+    }
+    g = tile_first(__shfl(t0, 0, 64));
+    g1 = next_step(g);
+    g2 = next_step(g1);
+  }
   if (g >= ngroups) return;
   // software pipeline over the wave's steps (TN nodes each): the node pointers run two steps ahead; the V
   // blocks (registers: NQ = ceil(B F / 256) 16-byte pieces per lane and node), the relation / position words
@@ -349,16 +390,16 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
   f32x4m pv[TN][NQ];
   f32x4m pa4_n1[2];
   float pa_n1[TN][4], pa_cur[TN][4];
-  int32_t np_cur = MIX_LOAD_NP(g), np_n1 = MIX_LOAD_NP(g + nwaves);
-  int32_t id_cur = MIX_LOAD_ID(g), id_n1 = MIX_LOAD_ID(g + nwaves);
+  int32_t np_cur = MIX_LOAD_NP(g), np_n1 = MIX_LOAD_NP(g1);
+  int32_t id_cur = MIX_LOAD_ID(g), id_n1 = MIX_LOAD_ID(g1);
   int32_t ur_cur, mp_cur, ur_n1, mp_n1;
   MIX_LOAD_IDX(np_cur, ur_n1, mp_n1)
   MIX_LOAD_V(g, id_cur)
-  for (; g < ngroups; g += nwaves) {
+  for (; g < ngroups; g = g1, g1 = g2, g2 = TK ? next_step(g2) : g2 + nwaves) {
     const int32_t np_now = np_cur;
     const int32_t cbase = __builtin_amdgcn_readlane(np_now, 0), cend = __builtin_amdgcn_readlane(np_now, TN);
-    const int32_t np_n2 = MIX_LOAD_NP(g + 2 * nwaves);
-    const int32_t id_n2 = MIX_LOAD_ID(g + 2 * nwaves);
+    const int32_t np_n2 = MIX_LOAD_NP(g2);
+    const int32_t id_n2 = MIX_LOAD_ID(g2);
     ur_cur = ur_n1;
     mp_cur = mp_n1;
     bool near = cend - cbase <= 64;  // wave uniform
@@ -384,7 +425,7 @@ __global__ __launch_bounds__(kFwdTB) void k_mix_fwd_mfma(
       reinterpret_cast<f32x4m *>(s_add)[64 + lane] = pa4_n1[1];
     }
     wave_lds_fence();
-    MIX_LOAD_V(g + nwaves, id_n1)  // next step's blocks (the last step re-reads its own)
+    MIX_LOAD_V(g1, id_n1)  // next step's blocks (the last step re-reads its own)
     MIX_LOAD_IDX(np_n1, ur_n1, mp_n1)
     np_cur = np_n1;
     np_n1 = np_n2;
@@ -1528,6 +1569,7 @@ struct MixCols {
   const int32_t *nptr, *urel, *mpos, *unode, *node_ids;
   int64_t N, ncols;
   int R;
+  unsigned long long *tickets = nullptr;  // the plan's work-ticket counters (k_mix_fwd_mfma's TK form), or NULL
 };
 
 template <typename OT, typename AT = float>
@@ -1612,15 +1654,26 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
       const int64_t want = ((N + tn - 1) / tn + (kFwdTB / 64) - 1) / (kFwdTB / 64);
       int64_t grid = 256;  // one block of 16 waves per CU (LDS and the 128-register budget allow no second)
       if (grid > want) grid = want;
+      // in-order tickets (see k_mix_fwd_mfma, TK): a full grid over a plan that carries the counters
+      const int n_ctr = (int)std::min<int64_t>(std::max<int64_t>(cfg(CFG_MIX_TICKETS), 0), kWorkTickets);
+      const int tk_tile = (int)std::min<int64_t>(std::max<int64_t>(cfg(CFG_MIX_TICKET_TILE), 1), 64);
+      const bool tk = p->tickets && !node_ids && n_ctr > 0 && grid == 256 &&
+                      (N + tn - 1) / tn >= (int64_t)kWorkTickets * 64 * 64;
+      if (tk)
+        MRGCN_HIP_TRY(mrgcn::fill_async(p->tickets, 0, (size_t)kWorkTickets * kWorkTicketStride * sizeof(unsigned long long), s));
 #define MIXM_GO(KS_, NQ_, TN_)                                                                              \
   do {                                                                                                      \
     auto kfn = addend ? (add_vec ? k_mix_fwd_mfma<KS_, NQ_, TN_, 2, OT, false, AT>                          \
                                  : k_mix_fwd_mfma<KS_, NQ_, TN_, 1, OT, false, AT>)                         \
                       : k_mix_fwd_mfma<KS_, NQ_, TN_, 0, OT, false, AT>;                                    \
+    if (tk) kfn = addend ? (add_vec ? k_mix_fwd_mfma<KS_, NQ_, TN_, 2, OT, false, AT, true>                 \
+                                    : k_mix_fwd_mfma<KS_, NQ_, TN_, 1, OT, false, AT, true>)                \
+                         : k_mix_fwd_mfma<KS_, NQ_, TN_, 0, OT, false, AT, true>;                           \
     if constexpr (sizeof(OT) == 4 && sizeof(AT) == 4) if (node_ids) kfn = k_mix_fwd_mfma<KS_, NQ_, TN_, 0, OT, true>; \
     MRGCN_HIP_TRY(raise_lds_limit((const void *)kfn, lds)); /* (per kernel: the variants share this site) */ \
     kfn<<<dim3((unsigned)grid), dim3(kFwdTB), lds, s>>>(p->nptr, p->urel, mpos_arg, V, comp, N, R, B, F,     \
-                                                        addend, ldA, M, ldM, node_ids);                     \
+                                                        addend, ldA, M, ldM, node_ids, p->tickets,          \
+                                                        n_ctr, tk_tile);                                    \
   } while (0)
 #define MIXM_TN(KS_, NQ_) MIXM_GO(KS_, NQ_, tn)
       switch (KS * 8 + NQ) {
@@ -1679,7 +1732,8 @@ template <typename OT>
 int mix_fwd_impl(const mrgcn_plan_t *p, const float *V, const float *comp, int32_t B, int32_t F,
                  const float *addend, int64_t ldA, OT *M, int64_t ldM, void *stream) {
   MRGCN_REQUIRE(p, "NULL");
-  const MixCols c{p->nptr, p->urel, p->mpos, p->unode, nullptr, p->num_nodes, p->ncols, (int)p->num_relations};
+  const MixCols c{p->nptr, p->urel, p->mpos, p->unode, nullptr, p->num_nodes, p->ncols, (int)p->num_relations,
+                  p->work_tickets};
   return mix_fwd_cols<OT>(&c, V, comp, B, F, addend, ldA, M, ldM, stream);
 }
 }  // namespace
@@ -1935,7 +1989,8 @@ int mrgcn_basis_mix_fwd_abf16(const mrgcn_plan_t *p, const float *V, const float
                               void *stream) {
   MRGCN_REQUIRE(p && addend, "NULL");
   MRGCN_REQUIRE(B <= 64 && F <= 16 && (B * F) % 4 == 0, "basis_mix_fwd_abf16: B <= 64, F <= 16, B*F % 4 == 0");
-  const MixCols c{p->nptr, p->urel, p->mpos, p->unode, nullptr, p->num_nodes, p->ncols, (int)p->num_relations};
+  const MixCols c{p->nptr, p->urel, p->mpos, p->unode, nullptr, p->num_nodes, p->ncols, (int)p->num_relations,
+                  p->work_tickets};
   if (out_bf16) return mix_fwd_cols<uint16_t, uint16_t>(&c, V, comp, B, F, addend, ldA, (uint16_t *)M, ldM, stream);
   return mix_fwd_cols<float, uint16_t>(&c, V, comp, B, F, addend, ldA, (float *)M, ldM, stream);
 }
