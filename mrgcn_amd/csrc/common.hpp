@@ -175,6 +175,12 @@ hipError_t raise_lds_limit(const void *fn, size_t lds);
 int plan_scratch(const mrgcn_plan *p, hipStream_t s, float **partials, int32_t **ticket);
 // the literal column of every entry of the COMPACT view (mrgcn_plan::mlcol), built by the first call outside a capture
 bool plan_literal_cols(const mrgcn_plan *p, hipStream_t s);
+// the compact column of every CSC entry (mrgcn_plan::ecol), built by the first call outside a capture
+bool plan_entry_cols(const mrgcn_plan *p, hipStream_t s);
+// entries a wave of the entry-sliced transposed product owns; records it leaves: 2 per wave x (1 + 16) floats
+constexpr int kSegWaveEntries = 256;
+inline int64_t seg_waves(int64_t nnz) { return (nnz + kSegWaveEntries - 1) / kSegWaveEntries; }
+inline int64_t seg_scratch_floats(int64_t nnz) { return 2 * seg_waves(nnz) * 17; }
 }  // namespace mrgcn
 
 struct mrgcn_plan {
@@ -276,6 +282,7 @@ struct mrgcn_plan {
   // LITERAL products of narrow layers on the COMPACT view's row classes: the literal column r*N + j of every entry in
   // the compact view's entry order (built by the first such product outside a capture; plan.hip: plan_literal_cols)
   mutable int32_t *mlcol = nullptr;  // [nnz]
+  mutable int32_t *ecol = nullptr;   // [nnz] compact column of every CSC entry (the entry-sliced transposed product)
   int64_t partials_floats = 0;
 
   mrgcn::SparseView view(int which) const {

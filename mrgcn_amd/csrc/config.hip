@@ -51,8 +51,9 @@ const Entry kEntries[CFG_COUNT] = {
     {"mix_add_vec", "MRGCN_MIX_ADD_VEC", 1, "basis mix forward: the feature term's rows come in as 16-byte pieces through LDS (0: four 4-byte loads per node)"},
     {"sup_rel_chunk", "MRGCN_SUP_REL_CHUNK", 512, "gradient supports: live columns of one (band, relation) group per transform block (64..1024; read when a support is built)"},
     {"adam_once", "MRGCN_ADAM_ONCE", 1, "fused row Adam on a support as a ONE-SHOT grid: list entries per wave (1, 2 or 4; 0: the persistent list kernel)"},
-    {"mix_tickets", "MRGCN_MIX_TICKETS", 8, "basis mix forward: waves draw tiles of steps in order from this many ticket counters (1..64; 0: a stride through the node range)"},
-    {"mix_ticket_tile", "MRGCN_MIX_TICKET_TILE", 4, "steps (two nodes each) a wave takes per ticket"}
+    {"mix_tickets", "MRGCN_MIX_TICKETS", 12, "basis mix forward: waves draw tiles of steps in order from this many ticket counters (1..64; 0: a stride through the node range)"},
+    {"mix_ticket_tile", "MRGCN_MIX_TICKET_TILE", 4, "steps (two nodes each) a wave takes per ticket"},
+    {"spmm_t_seg", "MRGCN_SPMM_T_SEG", 0, "general TRANSPOSED product of narrow layers: entry-sliced with a segmented sum (measured 417 vs 436 us at the AM shape — the product is bound by line fetches of the gathered rows, not by issue — and its sums are ordered differently from the live / support forms': opt-in)"}
 };
 std::atomic<int64_t> g_values[CFG_COUNT];
 std::once_flag g_once;

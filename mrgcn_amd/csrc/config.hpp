@@ -50,6 +50,7 @@ enum CfgKey : int {
   CFG_ADAM_ONCE,
   CFG_MIX_TICKETS,
   CFG_MIX_TICKET_TILE,
+  CFG_SPMM_T_SEG,
   CFG_COUNT
 };
 int64_t cfg(CfgKey k);

@@ -1087,6 +1087,7 @@ int create_impl(mrgcn_plan *p, int64_t nnz_in, const int64_t *rows, const int64_
   }
   int64_t ws = (int64_t)std::max(std::max(p->r_n_chunks, p->q_n_chunks), p->c_n_chunks) * kWsFeatures;
   ws = std::max<int64_t>(ws, (int64_t)p->r3_n_chunks * 16);
+  if (!p->lean) ws = std::max<int64_t>(ws, seg_scratch_floats(p->nnz));  // the entry-sliced transposed product's records
   MRGCN_HIP_TRY(plan_alloc(p, &p->partials, ws));
   p->partials_floats = std::max<int64_t>(ws, 1);
   return MRGCN_OK;
@@ -1109,7 +1110,7 @@ void release_plan(mrgcn_plan *q, uint64_t ep) {
                   q->r3s_long_row, q->r3s_long_cptr, q->r3s_chunk_beg, q->r3s_chunk_end, q->r3s_chunk_row,
                   q->n_rperm, q->n_relptr, q->n_rnode, q->n_rmpos, q->n_relchunk_rel, q->n_relchunk_beg,
                   q->n_relchunk_end, q->n_relchunk_ptr, q->n_relchunk_ids, q->op_node, q->op_rel, q->mlcol,
-                  q->work_tickets};
+                  q->work_tickets, q->ecol};
   // (after the wait any stream may take the blocks; the plan's own build stream is where the next build of a
   // similar slice will ask for them again: the pool hands them back without a driver call)
   for (void *a : ptrs) pool_free(a, q->build_stream, ep);
@@ -1288,6 +1289,30 @@ bool plan_literal_cols(const mrgcn_plan *p, hipStream_t s) {
     return false;
   }
   p->mlcol = a;
+  return true;
+}
+
+__global__ void k_entry_cols(const int32_t *__restrict__ cptr, int64_t ncols, int32_t *__restrict__ ecol) {
+  // one thread per column: its (few) entries get its id; long columns are written by their thread alone — a column of
+  // 100 k entries is rare enough not to matter for a once-per-plan pass
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * blockDim.x)
+    for (int32_t e = cptr[c]; e < cptr[c + 1]; ++e) ecol[e] = (int32_t)c;
+}
+
+bool plan_entry_cols(const mrgcn_plan *p, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(p->scratch_mu);
+  if (p->ecol) return true;
+  if (p->lean || p->nnz == 0 || !p->cptr) return false;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+  int32_t *a = nullptr;
+  if (pool_alloc((void **)&a, (size_t)p->nnz * sizeof(int32_t), s) != hipSuccess) return false;
+  k_entry_cols<<<dim3((unsigned)std::min<int64_t>((p->ncols + 255) / 256, 65535)), dim3(256), 0, s>>>(p->cptr, p->ncols, a);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    pool_free(a, s);
+    return false;
+  }
+  p->ecol = a;
   return true;
 }
 

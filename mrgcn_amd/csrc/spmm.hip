@@ -1404,6 +1404,279 @@ extern "C" int mrgcn_spmm_transposed_live_flagged_f32(const mrgcn_plan_t *plan, 
   return MRGCN_OK;
 }
 
+// =====================================================================================================================
+// ENTRY-SLICED product for views whose rows hold one or two entries (round 6; the general TRANSPOSED product: 1.7 entries
+// per compact column at the AM shape).  With a slot of four lanes per ROW the wave's trip count is its longest row's
+// and most gather slots idle: 436 us, 14.6 % of the roofline, bound by instruction issue.  Here a slot owns K = 4
+// consecutive ENTRIES: every wave runs the same straight loop over super-rounds of 64 entries — stage (coalesced row-of-
+// entry / operand-row / value), gather, accumulate with a flush whenever the row id changes — with the next super-
+// round's staging in flight under this one's gathers.  Rows that span slots are joined by one segmented scan per
+// super-round, rows that span super-rounds by a carry, rows that span WAVES by head / tail records that a second,
+// tiny launch sums in wave order: no atomics, bitwise reproducible.  (Measured first as tools/lab/spmm_lab.hip::k_seg.)
+// RESULT: 417 us against 436 — the product was not issue bound after all: 13.6 M random gathers of 40-byte rows out of a
+// 67 MB dY are 1.7-2.2 GB of 128-byte line fetches from the Infinity Cache, whatever form issues them.  Rows that span
+// slots are summed in a different order than by the slot-per-row kernels, so results differ in the last bit from the
+// live / support forms of the same product: the form is OPT-IN (`spmm_t_seg`), the default stays the slot-per-row kernel.
+// F <= 16 (four lanes x four floats); operand rows of >= 4 floats, read with the row's last piece clamped into the row.
+// =====================================================================================================================
+namespace mrgcn {
+namespace {
+using f32x4s = __attribute__((ext_vector_type(4))) float;
+struct SegArgs {
+  const int32_t *idx;   // [nnz] operand row of every entry
+  const float *val;     // [nnz]
+  const int32_t *row;   // [nnz] output row of every entry (non-decreasing)
+  const float *D;
+  int64_t ldD;
+  int F;
+  float *Y;
+  int64_t ldY;
+  int32_t *rec_row;     // [2 * nwaves]
+  float *rec_val;       // [2 * nwaves][16]
+  int64_t nwaves, nnz, xcd_per;
+  int32_t last_row;     // what the padding past nnz pretends to belong to (value 0)
+};
+
+__device__ __forceinline__ void seg_store(const SegArgs &A, int32_t r, const float (&v)[4], int f0) {
+  float *y = A.Y + (int64_t)r * A.ldY + f0;
+  if (f0 + 4 <= A.F) {   // a whole piece of the row
+    *reinterpret_cast<f32x4s *>(y) = f32x4s{v[0], v[1], v[2], v[3]};
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (f0 + i < A.F) y[i] = v[i];
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_seg(SegArgs A) {
+  constexpr int G = 4, SLOTS = kWave / G, KR = K / G, SRE = SLOTS * K;
+  constexpr int SRW = kSegWaveEntries / SRE;   // super-rounds per wave
+  static_assert(K % G == 0 && kSegWaveEntries % SRE == 0, "a wave owns a whole number of super-rounds");
+  const int lane = threadIdx.x & 63, slot = lane / G, q = lane % G;
+  const int f0 = q * 4;
+  const bool active = f0 < A.F;
+  // the row's last piece starts inside the row (k_spmm3 `pack`): lo = min(f0, F - 4), shifted into place after the sum
+  const int lo = active ? min(f0, A.F - 4) : 0, shift = active ? f0 - lo : 0;
+  int64_t wb = blockIdx.x;
+  if (A.xcd_per > 0) wb = (wb & 7) * A.xcd_per + (wb >> 3);
+  const int64_t w = wb * 4 + (threadIdx.x >> 6);
+  if (w >= A.nwaves) return;
+  const int64_t e0 = w * (int64_t)kSegWaveEntries, e1 = e0 + kSegWaveEntries;
+  const int32_t wave_prev_row = e0 > 0 ? A.row[e0 - 1] : -1;
+  const int32_t wave_next_row = e1 < A.nnz ? A.row[e1] : -1;
+  const int32_t wave_first_row = A.row[e0];
+  const bool wave_open_left = wave_prev_row == wave_first_row;
+
+  int32_t ci[KR], cr[KR], ci2[KR], cr2[KR];
+  float ca[KR], ca2[KR];
+  auto stage = [&](int64_t es, int32_t(&xi)[KR], float(&xa)[KR], int32_t(&xr)[KR]) {
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int64_t m = es + slot * K + k * G + q;
+      const int64_t mc = m < A.nnz ? m : A.nnz - 1;   // (unconditional loads at clamped addresses)
+      const int32_t i_ = A.idx[mc], r_ = A.row[mc];
+      const float a_ = A.val[mc];
+      xi[k] = m < A.nnz ? i_ : 0;
+      xa[k] = m < A.nnz ? a_ : 0.f;
+      xr[k] = m < A.nnz ? r_ : A.last_row;
+    }
+  };
+  stage(e0, ci, ca, cr);
+  int32_t carry_row = -1;    // row of the chain that is open at the end of the previous super-round
+  float carry[4] = {0.f, 0.f, 0.f, 0.f};
+  int32_t prev_last_row = wave_prev_row;
+
+  auto unshift = [&](const float(&v)[4], float(&o)[4]) {  // sums sit in the loaded layout: move them to f0 ..
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (shift == j && i + j < 4) o[i] = v[i + j];
+    }
+  };
+  auto rec_write = [&](int which, int32_t r, const float(&v)[4]) {  // lanes of ONE slot call this
+    if (active) {
+      float o[4];
+      unshift(v, o);
+      float *p = A.rec_val + ((int64_t)2 * w + which) * 16 + f0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p[i] = o[i];
+    }
+    if (q == 0) A.rec_row[2 * w + which] = r;
+  };
+  // a finished row: to Y, or — when it began before this wave — to the wave's head record
+  auto finish = [&](int32_t r, const float(&v)[4]) {
+    if (wave_open_left && r == wave_first_row) rec_write(0, r, v);
+    else if (active) {
+      float o[4];
+      unshift(v, o);
+      seg_store(A, r, o, f0);
+    }
+  };
+
+  for (int sr = 0; sr < SRW; ++sr) {
+    const int64_t es = e0 + (int64_t)sr * SRE;
+    // ---- gathers of this super-round (indices staged one super-round ago) ----------------------
+    f32x4s x[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      const int32_t c = __shfl(ci[t / G], slot * G + (t % G), kWave);
+      x[t] = *reinterpret_cast<const f32x4s *>(A.D + (int64_t)c * A.ldD + lo);
+    }
+    const bool more = sr + 1 < SRW;  // compile-time per unrolled trip
+    if (more) stage(es + SRE, ci2, ca2, cr2);
+    // ---- rows before / after the slot's range ---------------------------------------------------
+    int32_t prev_row = __shfl(cr[KR - 1], (slot > 0 ? slot - 1 : 0) * G + (G - 1), kWave);
+    if (slot == 0) prev_row = prev_last_row;
+    const int32_t sr_next_first = more ? __shfl(cr2[0], 0, kWave) : wave_next_row;
+    int32_t next_row = __shfl(cr[0], (slot < SLOTS - 1 ? slot + 1 : 0) * G, kWave);
+    if (slot == SLOTS - 1) next_row = sr_next_first;
+    // ---- K entries of the slot ------------------------------------------------------------------
+    int32_t cur_row = __shfl(cr[0], slot * G, kWave);
+    const int32_t first_row = cur_row;
+    const bool open_left = prev_row == first_row;
+    bool is_first = true;
+    float cur[4] = {0.f, 0.f, 0.f, 0.f}, first[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      const int32_t r = __shfl(cr[t / G], slot * G + (t % G), kWave);
+      const float a = __shfl(ca[t / G], slot * G + (t % G), kWave);
+      if (r != cur_row) {
+        if (is_first && open_left) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) first[i] = cur[i];
+        } else {
+          finish(cur_row, cur);
+        }
+        is_first = false;
+        cur_row = r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cur[i] = fmaf(a, x[t][i], cur[i]);
+    }
+    const bool open_right = next_row == cur_row;
+    const bool whole = is_first;  // one row fills the slot
+    // last segment closed at the slot's end and not part of a chain from the left: done
+    if (!open_right && !(whole && open_left)) finish(cur_row, cur);
+    // ---- chains across slots: out = pass ? in + H : base -------------------------------------------
+    const bool pass = whole && open_left;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = cur[i];  // whole: the slot's sum; else: its tail piece (chain start)
+    bool reset = !pass;
+#pragma unroll
+    for (int d = 1; d < SLOTS; d <<= 1) {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = __shfl_up(v[i], d * G, kWave);
+      const int orst = __shfl_up((int)reset, d * G, kWave);
+      if (slot >= d && !reset) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += o[i];
+        reset = orst != 0;
+      }
+    }
+    // chains that reach back beyond slot 0 take the carry of the previous super-round
+    float cin[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cin[i] = __shfl(carry[i], q, kWave);  // carry lives in slot 0's lanes
+    if (!reset) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += cin[i];
+    }
+    // what flows INTO each slot from the left
+    float in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      in[i] = __shfl_up(v[i], G, kWave);
+      if (slot == 0) in[i] = cin[i];
+    }
+    // a chain ends in this slot: first segment closed inside it, or the whole slot and nothing to the right
+    if (open_left && (!whole || !open_right)) {
+      float tot[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tot[i] = whole ? v[i] : in[i] + first[i];
+      finish(first_row, tot);
+    }
+    // ---- carry into the next super-round (kept in slot 0's lanes) -------------------------------------
+    const int last = (SLOTS - 1) * G;
+    const int32_t l_row = __shfl(cur_row, last, kWave);
+    const int l_open = __shfl((int)open_right, last, kWave);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) carry[i] = l_open ? __shfl(v[i], last + q, kWave) : 0.f;
+    carry_row = l_open ? l_row : -1;
+    prev_last_row = __shfl(cr[KR - 1], 63, kWave);
+    if (more) {
+#pragma unroll
+      for (int k = 0; k < KR; ++k) { ci[k] = ci2[k]; ca[k] = ca2[k]; cr[k] = cr2[k]; }
+    }
+  }
+  // ---- what is still open belongs to a row that continues in the next wave ---------------------------
+  if (slot == 0) {
+    const bool head_is_tail = carry_row >= 0 && wave_open_left && carry_row == wave_first_row;
+    if (head_is_tail) {          // the wave lies inside one row: a single record
+      rec_write(0, carry_row, carry);
+      if (q == 0) A.rec_row[2 * w + 1] = -1;
+    } else {
+      if (carry_row >= 0) rec_write(1, carry_row, carry);
+      else if (q == 0) A.rec_row[2 * w + 1] = -1;
+      // head record: written by finish() if the first row closed in this wave and began before it
+      if (!wave_open_left && q == 0) A.rec_row[2 * w] = -1;
+    }
+  }
+}
+
+// rows that span waves: records in wave order; the thread of a row's FIRST record sums them all
+__global__ void k_seg_fix(SegArgs A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = 2 * A.nwaves;
+  if (i >= n) return;
+  const int32_t r = A.rec_row[i];
+  if (r < 0) return;
+  for (int64_t k = i - 1; k >= 0; --k) {
+    const int32_t pr = A.rec_row[k];
+    if (pr == r) return;  // not the first record of this row
+    if (pr >= 0) break;
+  }
+  float s[16];
+#pragma unroll
+  for (int f = 0; f < 16; ++f) s[f] = 0.f;
+  for (int64_t k = i; k < n; ++k) {
+    const int32_t kr = A.rec_row[k];
+    if (kr < 0) continue;
+    if (kr != r) break;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) s[f] += A.rec_val[k * 16 + f];
+  }
+  for (int f = 0; f < A.F; ++f) A.Y[(int64_t)r * A.ldY + f] = s[f];
+}
+
+// Y[row, 0:F] = sum of val * D[idx] over the entries of `row` (entries sorted by row: CSC order for the TRANSPOSED view);
+// `scratch`: seg_scratch_floats(nnz) floats
+static int spmm_entry_sliced(const int32_t *idx, const float *val, const int32_t *row, int64_t nnz, int64_t rows,
+                             const float *D, int64_t ldD, int F, float *Y, int64_t ldY, float *scratch, hipStream_t s) {
+  SegArgs A{};
+  A.idx = idx; A.val = val; A.row = row; A.D = D; A.ldD = ldD; A.F = F; A.Y = Y; A.ldY = ldY;
+  A.nwaves = seg_waves(nnz);
+  A.nnz = nnz;
+  A.last_row = (int32_t)(rows - 1);
+  A.rec_row = reinterpret_cast<int32_t *>(scratch);
+  A.rec_val = scratch + 2 * A.nwaves;
+  const int64_t blocks = (A.nwaves + 3) / 4;
+  A.xcd_per = (blocks + 7) / 8;
+  k_seg<4><<<dim3((unsigned)(A.xcd_per * 8)), dim3(256), 0, s>>>(A);
+  MRGCN_HIP_TRY(hipGetLastError());
+  k_seg_fix<<<dim3((unsigned)((2 * A.nwaves + 255) / 256)), dim3(256), 0, s>>>(A);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+}  // namespace
+}  // namespace mrgcn
+
 extern "C" int mrgcn_spmm_bf16(const mrgcn_plan_t *plan, int32_t view, const uint16_t *D, int64_t ldD,
                                int32_t F, float *Y, int64_t ldY, const float *bias, int32_t relu,
                                const int32_t *out_index, void *stream) {
@@ -1472,6 +1745,11 @@ extern "C" int mrgcn_spmm_f32(const mrgcn_plan_t *plan, int32_t view, const floa
     if (rc != MRGCN_OK) return rc;
   }
   v.ticket = (fold && plan->ticket_ints >= v.n_long) ? ticket : nullptr;  // split rows finished inside the product
+  // the general TRANSPOSED product of a narrow layer: entry-sliced (rows of 1-2 entries; see k_seg)
+  if (view == MRGCN_VIEW_TRANSPOSED && F >= 4 && F <= 16 && !out_index && !bias && !relu && !plan->lean &&
+      plan->nnz > 0 && cfg(CFG_SPMM_T_SEG) != 0 && plan->partials_floats >= seg_scratch_floats(plan->nnz) &&
+      plan_entry_cols(plan, s))
+    return spmm_entry_sliced(plan->crow, plan->cval, plan->ecol, plan->nnz, plan->ncols, D, ldD, F, Y, ldY, partials, s);
   // feature tiles: one pass covers up to 64 lanes x VEC floats; the split-row workspace
   // holds kWsFeatures floats per chunk
   int tile = 64;  // scalar-load worst case

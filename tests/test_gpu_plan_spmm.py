@@ -244,6 +244,29 @@ def test_spmm_autograd_functions(skewed):
     torch.testing.assert_close(bias.grad, b2.grad, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("F", [4, 7, 10, 11, 12, 16])
+def test_entry_sliced_transposed_product_opt_in(skewed, F):
+    """`spmm_t_seg` (opt-in): the general TRANSPOSED product with a slot per four ENTRIES and a segmented sum — rows
+    that span slots, super-rounds and waves (hub columns of > 1 000 entries), dense and padded outputs — against the
+    float64 product; two runs are bitwise equal (no atomics)."""
+    from mrgcn_amd import _lib as L
+    plan, A, ref, rng = skewed
+    dY = torch.from_numpy(rng.standard_normal((A.shape[0], F)).astype(np.float32)).cuda()
+    ref64 = (A.T @ dY.double().cpu().numpy())[ref["ulcol"]]
+    old = L.set_config(spmm_t_seg=1)
+    try:
+        for ld in sorted({F, (F + 3) // 4 * 4}):
+            out = torch.full((plan.ncols, ld), 9.0, device="cuda")
+            got = plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=out[:, :F] if ld != F else out)
+            np.testing.assert_allclose(got.cpu().numpy()[:, :F], ref64, rtol=1e-4, atol=1e-4)
+            again = plan.spmm(L.VIEW_TRANSPOSED, dY, F=F)
+            assert torch.equal(again, got.contiguous())
+            if ld != F:
+                assert float(out[:, F:].min()) == 9.0 and float(out[:, F:].max()) == 9.0   # the pad is the caller's
+    finally:
+        L.set_config(**old)
+
+
 @pytest.mark.parametrize("F", [1, 3, 10, 11, 16, 20])
 @pytest.mark.parametrize("zero_frac", [0.0, 0.9, 0.997, 1.0])
 def test_transposed_product_with_zero_operand_rows(skewed, F, zero_frac):
