@@ -1342,6 +1342,16 @@ def main():
             t_t = event_time_ms(lambda: plan.spmm(L.VIEW_TRANSPOSED, dY, F=F, out=dM), args.spmm_iters, stream)
             extra["spmm_transposed_ms"] = t_t
             extra["spmm_transposed_gbps"] = bytes_alg_f32 / (t_t * 1e-3) / 1e9
+            # what the memory system's line size allows these two views (algorithmic bytes per second if every access
+            # ran at the 8 TB/s peak): the TRANSPOSED product gathers one dY row per ENTRY (13.6 M random 40-byte rows of
+            # a 67 MB table: a 128-byte line each), the LITERAL product one operand row per touched column out of the
+            # reference's (R*N) x F table (17.8 GB: every row its own line).  Index / value streams and the output as
+            # in SURVEY 8(d)'s formula.
+            line = 128
+            t_min_T = (plan.nnz * (8 + line) + (plan.ncols + 1) * 4 + plan.ncols * F * 4) / (HBM_PEAK_GBS * 1e9)
+            t_min_L = (plan.nnz * 8 + (plan.num_rows + 1) * 4 + plan.ncols * line + plan.num_rows * F * 4) / (HBM_PEAK_GBS * 1e9)
+            extra["spmm_transposed_bound_gbps"] = bytes_alg_f32 / t_min_T / 1e9
+            extra["spmm_literal_bound_gbps"] = bytes_alg_f32 / t_min_L / 1e9
             del dY, dM
             ab = epoch_algorithmic_bytes(plan, dims, B, R, N, args.operand)
             if ab:

@@ -717,33 +717,60 @@ def _support_weight_I_grads(owner, sup, plan, dM, ld, weight_I, comp_I, F, s):
     return d_wI, d_comp
 
 
-def _backward_on_support(ctx, sup, dY, dbias):
-    """_RgcnLayer.backward on a gradient support: dM and every per-column product are [L, ld] arrays by live number;
-    no marking, no flags, no zero fills (csrc/support.hip).  None when a shape is outside what the support calls
-    take (the caller then runs the per-epoch marking path)."""
+def _support_backward_workspace(ctx, sup):
+    """floats of workspace the transform's backward on `sup` needs (0: no feature term), or None when a shape is outside
+    what the support calls take (the caller then runs another path)."""
     lib = L.load()
-    plan, F = ctx.plan, ctx.F
     weight_I, comp_I, X, W_F, Y = ctx.saved_tensors
     has_I, has_comp, has_X, has_bias = ctx.has
-    dev = plan.device
+    F = ctx.F
     if has_I and not has_comp:
         return None  # (the literal (R*N) x F gradient is scattered from plain compact order)
     if has_I and (comp_I.shape[1] > 64 or F > 16):
         return None  # (outside the support's node-major mix backward: mrgcn_support_mix_bwd_f32)
     need_dX = has_X and ctx.needs_input_grad[4]
     need_dW = has_X and ctx.needs_input_grad[5]
-    K = X.shape[1] if has_X else 0
     nws = 0
     if need_dX or need_dW:
-        nws = int(lib.mrgcn_support_rel_transform_bwd_workspace(sup.handle, K, F, int(need_dX), int(need_dW)))
+        nws = int(lib.mrgcn_support_rel_transform_bwd_workspace(sup.handle, X.shape[1], F, int(need_dX), int(need_dW)))
         if nws < 0:
             return None
+    return nws
+
+
+def _backward_on_support(ctx, sup, dY, dbias):
+    """_RgcnLayer.backward on a gradient support: dM and every per-column product are [L, ld] arrays by live number;
+    no marking, no flags, no zero fills (csrc/support.hip).  None when a shape is outside what the support calls
+    take (the caller then runs the per-epoch marking path)."""
+    lib = L.load()
+    nws = _support_backward_workspace(ctx, sup)
+    if nws is None:
+        return None
+    plan, F = ctx.plan, ctx.F
+    dev = plan.device
     s = _stream(dev)
     ld = (F + 3) // 4 * 4
     dM = torch.empty((max(sup.L, 1), ld), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         L.check(lib.mrgcn_support_spmm_t_f32(sup.handle, dY.data_ptr(), dY.stride(0), F, dM.data_ptr(), ld, s),
                 "mrgcn_support_spmm_t_f32")
+    return _support_backward_from_dM(ctx, sup, dM, ld, dbias, nws)
+
+
+def _support_backward_from_dM(ctx, sup, dM, ld, dbias, nws):
+    """The layer's parameter / input gradients from dM [L, ld] (the gradient of the live columns' operand rows, by the
+    support's live numbers): mix backward, the transform's dW / dX.  `ctx`: anything with _RgcnLayer's context fields
+    (plan, F, saved_tensors, has, needs_input_grad, owner, x_is_relu_out, Xb) — the node-partitioned halo engine sums
+    the ranks' contributions into dM first and calls this on its own columns' support (partition_halo.py)."""
+    lib = L.load()
+    plan, F = ctx.plan, ctx.F
+    weight_I, comp_I, X, W_F, Y = ctx.saved_tensors
+    has_I, has_comp, has_X, has_bias = ctx.has
+    dev = plan.device
+    need_dX = has_X and ctx.needs_input_grad[4]
+    need_dW = has_X and ctx.needs_input_grad[5]
+    K = X.shape[1] if has_X else 0
+    s = _stream(dev)
     d_wI = d_comp = dX = dW = None
     overlap = has_I and has_X and _OVERLAP
     main = torch.cuda.current_stream(dev)
