@@ -317,6 +317,18 @@ int mrgcn_wide_input_bwd_f32(const mrgcn_plan_t *plan, const int32_t *erel, cons
                              const int32_t *unit_beg, const int32_t *unit_end, const uint8_t *unit_multi,
                              int64_t n_units, const float *dY, int64_t ldY, const float *V, const float *comp,
                              int32_t B, int32_t F, float *dV, float *dcomp, void *stream);
+/* The same, BITWISE REPRODUCIBLE (no float atomic): a unit of a node with several units writes its partial sums to
+ * slot unit_slot[u] of the workspace (-1: the node's only unit, stored straight into dV) and a second launch adds a
+ * node's slots in unit order (hub_node / hub_ptr: the nodes with several units and their slot ranges); dcomp is summed
+ * per wave, per block and over the blocks in fixed orders.  What lets the units be small (64 entries: hub nodes stop
+ * being the tail of the launch) without the atomics' reordering of cancelling sums. */
+int64_t mrgcn_wide_input_bwd_det_workspace(const mrgcn_plan_t *plan, int64_t n_slots, int32_t B, int32_t F);
+int mrgcn_wide_input_bwd_det_f32(const mrgcn_plan_t *plan, const int32_t *erel, const int32_t *unit_node,
+                                 const int32_t *unit_beg, const int32_t *unit_end, const int32_t *unit_slot,
+                                 int64_t n_units, const int32_t *hub_node, const int32_t *hub_ptr, int64_t n_hubs,
+                                 int64_t n_slots, const float *dY, int64_t ldY, const float *V, const float *comp,
+                                 int32_t B, int32_t F, float *dV, float *dcomp, float *workspace,
+                                 int64_t workspace_floats, void *stream);
 
 /*     dX[j, 0:K]  = sum_{c in node j} W[r_c] . dM[c, :]     (nullable; every row written)
  *     dW[r, :, :] = sum_{c: r_c = r} X[j_c, :]^T dM[c, :]    (nullable; zeroed inside)

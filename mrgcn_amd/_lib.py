@@ -165,6 +165,9 @@ SIGNATURES = {
     "mrgcn_plan_entry_relations": (C.c_int, [_p, _p, _p]),
     "mrgcn_wide_input_bwd_supported": (_i32, [_p, _i32, _i32]),
     "mrgcn_wide_input_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
+    "mrgcn_wide_input_bwd_det_workspace": (_i64, [_p, _i64, _i32, _i32]),
+    "mrgcn_wide_input_bwd_det_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _p, _i32,
+                                               _i32, _p, _p, _p, _i64, _p]),
     "mrgcn_support_create": (C.c_int, [C.POINTER(_p), _p, _p, _p]),
     "mrgcn_support_create_ex": (C.c_int, [C.POINTER(_p), _p, _p, _u32, _p]),
     "mrgcn_support_create_chain": (C.c_int, [C.POINTER(_p), _i32, _p, _p, _u32, _p]),

@@ -26,6 +26,10 @@ _LIVE_COLS = os.environ.get("MRGCN_LIVE_COLS", "1") != "0"
 # the live columns, their kept entries and the relation-major lists are built once and every epoch runs on dense index
 # spaces (csrc/support.hip).  MRGCN_SUPPORT=0: the per-epoch marking path for every backward (A/B).
 _SUPPORT = os.environ.get("MRGCN_SUPPORT", "1") != "0"
+# the wide featureless layer's backward in its bitwise-reproducible form (64-entry units, no float atomics); 0: the
+# round-5 form (256-entry units, atomics for hub nodes)
+_WIDE_DET = os.environ.get("MRGCN_WIDE_DET", "1") != "0"
+_WIDE_UNIT = int(os.environ.get("MRGCN_WIDE_UNIT", "64"))   # entries per unit of the reproducible form
 # bf16 layers read a wide input as bf16 rows (0: only the compact operand M is bf16, the round-5 form — the A/B switch)
 _BF16_PIPELINE = os.environ.get("MRGCN_BF16_PIPELINE", "1") != "0"
 
@@ -452,21 +456,37 @@ class _RgcnLayer(torch.autograd.Function):
         # (the units of the wide-layer backward are built on first use, with host round trips: not inside a capture)
         if (has_I and has_comp and not has_X and not sparse_rows and weight_I.dim() == 3 and not plan.lean
                 and dY.stride(0) % 4 == 0
-                and ("_wide_units" in plan.__dict__ or not torch.cuda.is_current_stream_capturing())):
+                and (("_wide_units_det" if _WIDE_DET else "_wide_units") in plan.__dict__
+                     or not torch.cuda.is_current_stream_capturing())):
             Bn = weight_I.shape[1]
             param = getattr(ctx.owner, "weight_I", None)
             if (lib.mrgcn_wide_input_bwd_supported(plan.handle, Bn, F)
                     and not (param is not None and _row_sparse_for(param) and _LIVE_COLS)):
                 # a wide featureless layer with few bases (the link-prediction encoder): dV and dcomp straight from
                 # dY over the plan's entries — the 4 F-byte rows of dM are never written (csrc/wide_input.hip)
-                erel, un, ub, ue, um, nu = plan.wide_units()
                 wI = weight_I.contiguous()
                 d_wI, d_comp = torch.empty_like(wI), torch.empty_like(comp_I)
-                with torch.cuda.device(dev):
-                    L.check(lib.mrgcn_wide_input_bwd_f32(
-                        plan.handle, erel.data_ptr(), un.data_ptr(), ub.data_ptr(), ue.data_ptr(), um.data_ptr(), nu,
-                        dY.data_ptr(), dY.stride(0), wI.data_ptr(), comp_I.contiguous().data_ptr(), Bn, F,
-                        d_wI.data_ptr(), d_comp.data_ptr(), s), "mrgcn_wide_input_bwd_f32")
+                if _WIDE_DET:
+                    # units of 64 entries, no float atomics: bitwise reproducible (plan.wide_units_det)
+                    u = plan.wide_units_det(_WIDE_UNIT)
+                    nws = int(lib.mrgcn_wide_input_bwd_det_workspace(plan.handle, u["n_slots"], Bn, F))
+                    ws = u["ws"].get((Bn, F))
+                    if ws is None or ws.numel() < nws:
+                        ws = u["ws"][(Bn, F)] = torch.empty((max(nws, 4),), dtype=torch.float32, device=dev)
+                    with torch.cuda.device(dev):
+                        L.check(lib.mrgcn_wide_input_bwd_det_f32(
+                            plan.handle, u["erel"].data_ptr(), u["node"].data_ptr(), u["beg"].data_ptr(),
+                            u["end"].data_ptr(), u["slot"].data_ptr(), u["n_units"], u["hub_node"].data_ptr(),
+                            u["hub_ptr"].data_ptr(), u["n_hubs"], u["n_slots"], dY.data_ptr(), dY.stride(0), wI.data_ptr(),
+                            comp_I.contiguous().data_ptr(), Bn, F, d_wI.data_ptr(), d_comp.data_ptr(), ws.data_ptr(),
+                            ws.numel(), s), "mrgcn_wide_input_bwd_det_f32")
+                else:
+                    erel, un, ub, ue, um, nu = plan.wide_units()
+                    with torch.cuda.device(dev):
+                        L.check(lib.mrgcn_wide_input_bwd_f32(
+                            plan.handle, erel.data_ptr(), un.data_ptr(), ub.data_ptr(), ue.data_ptr(), um.data_ptr(), nu,
+                            dY.data_ptr(), dY.stride(0), wI.data_ptr(), comp_I.contiguous().data_ptr(), Bn, F,
+                            d_wI.data_ptr(), d_comp.data_ptr(), s), "mrgcn_wide_input_bwd_f32")
                 bump("backward.wide_input")
                 return None, None, d_wI, d_comp, None, None, dbias, None, None, None
         # dM = A'^T dY over touched columns only, plain compact order (its consumers are node-major)

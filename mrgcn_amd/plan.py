@@ -295,6 +295,39 @@ class GraphPlan:
             self.__dict__["_wide_units"] = ent
         return ent
 
+    def wide_units_det(self, unit_entries: int = 64):
+        """The units of the BITWISE-REPRODUCIBLE wide-layer backward (mrgcn_wide_input_bwd_det_f32): per-node units of at
+        most `unit_entries` entries; a unit of a node with several units gets a slot in the hub workspace (`unit_slot`,
+        -1 otherwise), `hub_node` / `hub_ptr` list those nodes and their slot ranges (a node's units, hence its slots,
+        are consecutive).  Returns a dict, built once and kept."""
+        ent = self.__dict__.get("_wide_units_det")
+        if ent is None:
+            nptr = self.export(L.ARR_NPTR).astype(np.int64)
+            cptr = self.export(L.ARR_CPTR).astype(np.int64)
+            eptr = cptr[nptr]                                   # entry range of every node
+            n = np.diff(eptr)
+            k = (n + unit_entries - 1) // unit_entries          # units per node (0 for a node without entries)
+            node = np.repeat(np.arange(self.num_nodes), k)
+            first = np.cumsum(k) - k
+            idx = np.arange(int(k.sum())) - np.repeat(first, k)  # unit number inside its node
+            beg = eptr[node] + idx * unit_entries
+            end = np.minimum(beg + unit_entries, eptr[node + 1])
+            multi = k[node] > 1
+            slot = np.full(len(node), -1, dtype=np.int64)
+            slot[multi] = np.arange(int(multi.sum()))
+            hubs = np.flatnonzero(k > 1)
+            hub_ptr = np.concatenate([[0], np.cumsum(k[hubs])])
+            dev = self.device
+            erel = torch.empty((max(self.nnz, 1),), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                L.check(L.load().mrgcn_plan_entry_relations(self.handle, erel.data_ptr(), _stream_ptr(dev)),
+                        "mrgcn_plan_entry_relations")
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(dev)  # noqa: E731
+            ent = dict(erel=erel, node=up(node), beg=up(beg), end=up(end), slot=up(slot), n_units=int(len(node)),
+                       hub_node=up(hubs), hub_ptr=up(hub_ptr), n_hubs=int(len(hubs)), n_slots=int(multi.sum()), ws={})
+            self.__dict__["_wide_units_det"] = ent
+        return ent
+
     # -- gradient support (include/mrgcn_hip.h: mrgcn_support_*) --------------------------------
     def support_for(self, row_flags: torch.Tensor):
         """The gradient support of the output rows flagged in `row_flags` (uint8 [num_rows], device), built on first

@@ -191,6 +191,33 @@ def test_featureless_wide_layer_vs_oracle(N, R, B, F, bias, hub):
     for k, v in grads.items():
         got = util.ref_layout(getattr(layer, k).grad, k).cpu().numpy()
         np.testing.assert_allclose(got, v, rtol=2e-4, atol=2e-5 * (np.abs(v).max() + 1e-12) + 1e-6, err_msg=k)
+    # the default backward (units of 64 entries, hub partials summed in unit order, no float atomics) gives the same
+    # BITS every run; the round-5 form (256-entry units, atomics on hub blocks: MRGCN_WIDE_DET=0) the same values
+    import mrgcn_amd
+    from mrgcn_amd import functional as Fn
+    first = {k: getattr(layer, k).grad.clone() for k in grads}
+
+    def again():
+        layer.zero_grad(set_to_none=True)
+        Y2 = layer._forward_fused(None, plan_of(At, N, R), relu=True)
+        (Y2 * w).sum().backward()
+        return {k: getattr(layer, k).grad.clone() for k in grads}
+    mrgcn_amd.reset_stats()
+    second = again()
+    wide = mrgcn_amd.stats().get("backward.wide_input") == 1
+    assert wide == (1 <= B <= 4 and F % 4 == 0 and F > 16)
+    for k in grads:   # (the other shapes' general path sums dcomp with float atomics: equal to rounding only)
+        if wide:
+            assert torch.equal(first[k], second[k]), k
+        else:
+            torch.testing.assert_close(second[k], first[k], rtol=1e-4, atol=1e-5 * float(first[k].abs().max()) + 1e-7)
+    prev, Fn._WIDE_DET = Fn._WIDE_DET, False
+    try:
+        third = again()
+    finally:
+        Fn._WIDE_DET = prev
+    for k in grads:
+        torch.testing.assert_close(third[k], first[k], rtol=1e-4, atol=1e-5 * float(first[k].abs().max()) + 1e-7)
 
 
 def _oracle_layer_case(rng, N, R, B, K, F, nnz, hub):
