@@ -160,7 +160,11 @@ __global__ __launch_bounds__(kTB) void k_distmult_fwd4(const float *__restrict__
   }
 }
 
-template <int WHICH>
+// RUNS: runs of kRun sorted triples a wave walks one after the other, keeping its open sum across them.  The relation
+// pass (WHICH = 1: a few hundred keys, segments of thousands of triples) takes four: every wave of a long segment adds
+// its sum into the same 4 H-byte row, and a quarter of the waves means a quarter of those contended atomics
+// (FB15k-237: 176 us with one run per wave — the entity passes, whose segments are short, take 111 / 123 us).
+template <int WHICH, int RUNS = 1>
 __global__ __launch_bounds__(kTB) void k_distmult_bwd_sorted4(const float *__restrict__ E, int64_t ldE,
                                                               const float *__restrict__ Rel, int64_t ldR, int H,
                                                               const int64_t *__restrict__ tr,
@@ -169,14 +173,7 @@ __global__ __launch_bounds__(kTB) void k_distmult_bwd_sorted4(const float *__res
                                                               int64_t ldo) {
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * (kTB / kWave) + (threadIdx.x >> 6);
-  const int64_t t0 = w * kRun;
-  if (t0 >= n) return;
-  const int cnt = (int)((n - t0 < kRun) ? n - t0 : kRun);
-  // lane l < cnt holds sorted triple t0 + l: its three ids and its score gradient (two dependent loads for the whole
-  // wave instead of three per triple)
-  const int64_t i = order[t0 + (lane < cnt ? lane : cnt - 1)];
-  const int32_t si = (int32_t)tr[3 * i], pi = (int32_t)tr[3 * i + 1], oi = (int32_t)tr[3 * i + 2];
-  const float gi = g[i];
+  if (w * RUNS * kRun >= n) return;
   const bool on = 4 * lane < H;
   const int f0 = on ? 4 * lane : 0;
   f32x4d acc = {0.f, 0.f, 0.f, 0.f};
@@ -191,6 +188,16 @@ __global__ __launch_bounds__(kTB) void k_distmult_bwd_sorted4(const float *__res
     }
     acc = f32x4d{0.f, 0.f, 0.f, 0.f};
   };
+#pragma unroll 1
+  for (int run = 0; run < RUNS; ++run) {
+  const int64_t t0 = (w * RUNS + run) * kRun;
+  if (t0 >= n) break;
+  const int cnt = (int)((n - t0 < kRun) ? n - t0 : kRun);
+  // lane l < cnt holds sorted triple t0 + l: its three ids and its score gradient (two dependent loads for the whole
+  // wave instead of three per triple)
+  const int64_t i = order[t0 + (lane < cnt ? lane : cnt - 1)];
+  const int32_t si = (int32_t)tr[3 * i], pi = (int32_t)tr[3 * i + 1], oi = (int32_t)tr[3 * i + 2];
+  const float gi = g[i];
   for (int tb = 0; tb < cnt; tb += 4) {
     f32x4d a[4], b[4];
 #pragma unroll
@@ -215,6 +222,7 @@ __global__ __launch_bounds__(kTB) void k_distmult_bwd_sorted4(const float *__res
         acc += (a[u] * gt) * b[u];
       }
     }
+  }
   }
   flush();
 }
@@ -775,8 +783,11 @@ int mrgcn_distmult_score_bwd_sorted_f32(const float *E, int64_t ldE, const float
       k_distmult_bwd_sorted4<0><<<g4, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_s, n, dscores, dE, lddE);
       k_distmult_bwd_sorted4<2><<<g4, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_o, n, dscores, dE, lddE);
     }
-    if (dRel)
-      k_distmult_bwd_sorted4<1><<<g4, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_p, n, dscores, dRel, lddR);
+    if (dRel) {
+      constexpr int kRelRuns = 4;
+      dim3 gr((unsigned)(((waves + kRelRuns - 1) / kRelRuns + kTB / kWave - 1) / (kTB / kWave)));
+      k_distmult_bwd_sorted4<1, kRelRuns><<<gr, kTB, 0, st>>>(E, ldE, Rel, ldR, H, triples, order_p, n, dscores, dRel, lddR);
+    }
     MRGCN_HIP_TRY(hipGetLastError());
     return MRGCN_OK;
   }

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
 o=gpurun_out/r6; mkdir -p $o
-for v in 48 64 96 64; do MRGCN_WIDE_UNIT=$v timeout 600 python bench.py --workload fb15k --no-cpu-baseline > $o/fbu_$v.json 2>$o/fbu_$v.err; python - <<PY
+for v in 64 64; do MRGCN_WIDE_UNIT=$v timeout 600 python bench.py --workload fb15k --no-cpu-baseline > $o/fbu_$v.json 2>$o/fbu_$v.err; python - <<PY
 import json
 d=json.loads(open("gpurun_out/r6/fbu_$v.json").read().strip().splitlines()[-1]); print("unit=$v", round(d["ms_per_step"],4))
 PY
