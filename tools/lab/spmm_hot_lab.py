@@ -35,8 +35,9 @@ def main():
     a = ap.parse_args()
     here = os.path.dirname(os.path.abspath(__file__))
     so = os.path.join(here, "libspmm_hot_lab.so")
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-                    os.path.join(here, "spmm_hot_lab.hip"), "-o", so], check=True)
+    src = os.path.join(here, "spmm_hot_lab.hip")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", src, "-o", so], check=True)
     lab = C.CDLL(so)
     lab.lab_hot.restype = C.c_int
     lab.lab_hot.argtypes = [C.c_int64] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
