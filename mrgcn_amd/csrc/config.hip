@@ -53,7 +53,8 @@ const Entry kEntries[CFG_COUNT] = {
     {"adam_once", "MRGCN_ADAM_ONCE", 1, "fused row Adam on a support as a ONE-SHOT grid: list entries per wave (1, 2 or 4; 0: the persistent list kernel)"},
     {"mix_tickets", "MRGCN_MIX_TICKETS", 12, "basis mix forward: waves draw tiles of steps in order from this many ticket counters (1..64; 0: a stride through the node range)"},
     {"mix_ticket_tile", "MRGCN_MIX_TICKET_TILE", 4, "steps (two nodes each) a wave takes per ticket"},
-    {"spmm_t_seg", "MRGCN_SPMM_T_SEG", 0, "general TRANSPOSED product of narrow layers: entry-sliced with a segmented sum (measured 417 vs 436 us at the AM shape — the product is bound by line fetches of the gathered rows, not by issue — and its sums are ordered differently from the live / support forms': opt-in)"}
+    {"spmm_t_seg", "MRGCN_SPMM_T_SEG", 0, "general TRANSPOSED product of narrow layers: entry-sliced with a segmented sum (measured 417 vs 436 us at the AM shape — the product is bound by line fetches of the gathered rows, not by issue — and its sums are ordered differently from the live / support forms': opt-in)"},
+    {"sup_mix_once", "MRGCN_SUP_MIX_ONCE", 0, "mix backward on a support as a one-shot grid (a wave per 64 list entries: measured 739 vs 670 us in the AM epoch — its blocks re-stage the 43 KB comp table too often; 0: a resident grid striding through the list)"}
 };
 std::atomic<int64_t> g_values[CFG_COUNT];
 std::once_flag g_once;

@@ -51,6 +51,7 @@ enum CfgKey : int {
   CFG_MIX_TICKETS,
   CFG_MIX_TICKET_TILE,
   CFG_SPMM_T_SEG,
+  CFG_SUP_MIX_ONCE,
   CFG_COUNT
 };
 int64_t cfg(CfgKey k);

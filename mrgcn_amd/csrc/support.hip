@@ -397,7 +397,9 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
   int64_t grid = (q->NL + 64 * nw - 1) / (64 * nw);
   int per_cu = (int)std::min<size_t>(tb == 1024 ? 2 : 4, (160 * 1024) / (lds + 1024));
   if (per_cu < 1) per_cu = 1;
-  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  // (`sup_mix_once`: a ONE-SHOT grid — a wave takes one group of 64 list entries and ends; the block dispatcher hands the
+  // groups out in address order: tools/lab/copy_lab.hip.  0: a resident grid striding through the list)
+  if (cfg(CFG_SUP_MIX_ONCE) == 0 && grid > 256 * per_cu) grid = 256 * per_cu;
   if (grid > kSqParts) grid = kSqParts;
   if (grid < 1) grid = 1;
   const int FT = (F == 10 || F == 11) ? F : (F + 3) / 4 * 4;
