@@ -32,7 +32,7 @@ kill $smi_pid 2>/dev/null; wait $smi_pid 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-seeds --no-side-workloads > $o/bench_under_rocprof.json 2> $o/bench_under_rocprof.err
 python3 tools/prof_summary.py $o/stats 40 > $o/epoch_kernel_stats.md
 python3 tools/trace_summary.py $o/stats > $o/epoch_kernel_trace_medians.md 2>/dev/null
-python3 tools/epoch_sequence.py $o/stats > $o/epoch_sequence.md 2>/dev/null
+python3 tools/epoch_sequence.py $o/stats "k_xform_mfma_fwd<1, false, 10" > $o/epoch_sequence.md 2>/dev/null
 bash tools/pmc_passes.sh $o/pmc_epoch all -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-literal-spmm --no-graph --no-seeds --no-side-workloads
 for k in k_mix_fwd k_mix_bwd_sup k_dcomp k_adam_rows k_xform_mfma_fwd k_xform_cols_lds k_xform_mfma_dw "k_spmm<" k_spmm3; do
   echo "## $k"; python3 tools/pmc_summary.py $o "$k" | tail -n +3
@@ -57,4 +57,19 @@ python3 tools/halo_probe.py > $o/halo.json 2> $o/halo.err
 rocprofv3 --kernel-trace --output-format csv -d $o/stats_enc -o run -- python3 tools/am_encoders_step.py run > $o/am_encoders_step.txt 2> $o/am_encoders_step.err
 python3 tools/am_encoders_step.py summary $o/stats_enc > $o/am_encoders_step.md 2>> $o/am_encoders_step.err
 rm -rf $o/stats_enc
+rocprofv3 --kernel-trace --output-format csv -d $o/stats_encb -o run -- python3 tools/am_encoders_step.py run bf16 > $o/am_encoders_step_bf16.txt 2> $o/am_encoders_step_bf16.err
+python3 tools/am_encoders_step.py summary $o/stats_encb > $o/am_encoders_step_bf16.md 2>> $o/am_encoders_step_bf16.err
+rm -rf $o/stats_encb
+# (10) the bf16 pipeline's epoch in launch order; (11) the yardstick and LDS labs (tools/lab)
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_bf16 -o run -- python3 bench.py --operand bf16 --steps 20 --warmup 3 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-seeds --no-side-workloads --no-literal-spmm > $o/bench_bf16_under_rocprof.json 2> $o/bench_bf16_under_rocprof.err
+python3 tools/epoch_sequence.py $o/stats_bf16 k_xform_bf16_fwd > $o/bf16_epoch_sequence.md 2>&1
+rm -rf $o/stats_bf16
+hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/lab/copy_lab.hip -o /tmp/copy_lab 2>/dev/null && /tmp/copy_lab > $o/copy_lab.txt 2>&1
+python3 tools/lab/spmm_hot_lab.py > $o/spmm_hot_lab.txt 2>&1
+# the CPU suite last: the tree these artefacts describe is green
+python3 -m pytest tests -q -x -m "not gpu" > $o/cpu_suite.txt 2>&1; tail -2 $o/cpu_suite.txt
+ls -la $o
+# (12) the driver's multi-rank command with two ranks on this one GPU (gloo: the ranks share the device, so the times
+# are time-shared upper bounds): both partitioned engines priced, logits against the single-GPU model
+timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-seeds --no-side-workloads --no-literal-spmm > $o/bench_two_ranks_one_gpu.json 2> $o/bench_two_ranks_one_gpu.err
 ls -la $o

@@ -43,7 +43,7 @@ def main():
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
     ALG = collections.OrderedDict([  # kernel-name prefix -> (what is counted, bytes)
-        ("mrgcn::k_xform_mfma_fwd<1, false, 16, float, false>",
+        ("mrgcn::k_xform_mfma_fwd<1, false, 10, float, false>",
          ("layer-0 transform: X read once + W + addend written + indices", N * K0 * 4 + R * K0 * F0 * 4 + NCOLS * LD * 4 + NCOLS * 8)),
         ("mrgcn::k_mix_fwd_mfma<3, 2, 2, 2, float",
          ("basis mix: V read once + addend read + M written + 3 index arrays", 4 * B * N * F0 + NCOLS * (LD * 4 + F0 * 4) + NCOLS * 8 + N * 4)),
@@ -55,10 +55,12 @@ def main():
         ("mrgcn::k_mix_bwd_sup<10, 2, 512, true>",
          ("norm-only mix backward: V of the live nodes + their dM rows in, D rows out", NL0 * B * F0 * 4 + L0 * (LD * 4 + B * 4 + 4) + NL0 * 8)),
         ("mrgcn::k_dcomp_chunks<10>", ("dcomp: D rows in, by relation", L0 * (B * 4 + 4))),
-        ("mrgcn::k_xform_mfma_dw<3, 2, false>",
+        ("mrgcn::k_xform_mfma_dw<3, 2, false, float>",
          ("layer-0 dW over the live columns: X rows of the live NODES once + dM rows + lists", NL0 * K0 * 4 + L0 * (LD * 4 + 8))),
         ("mrgcn::k_adam_rows_fused",
          ("Adam, gradient formed on the fly: p, m, v of the live blocks in and out + their dM rows", 6 * 4 * B * NL0 * F0 + L0 * LD * 4 + N * 6)),
+        ("mrgcn::k_adam_rows_once<2, 1>",
+         ("Adam as a one-shot grid over the support's node list (a wave per node), gradient formed on the fly: p, m, v of the live blocks in and out + their dM rows + the list", 6 * 4 * B * NL0 * F0 + L0 * (LD * 4 + 4) + NL0 * 8)),
         ("mrgcn::k_adam_rows_list<2, true>",
          ("Adam over the support's node list, gradient formed on the fly: p, m, v of the live blocks in and out + their dM rows + the list", 6 * 4 * B * NL0 * F0 + L0 * (LD * 4 + 4) + NL0 * 8)),
     ])
@@ -67,7 +69,7 @@ def main():
         k = short(r["Kernel_Name"])
         d[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print(f"source: {f}\n")
-    print("HBM roofline 8.0 TB/s (MI355X spec; a hand-written float4 copy and a 3-read / 3-write triad reach 4.6-4.7 TB/s on these boxes: extra.device_copy_gbps_hip / extra.triad_gbps of the bench line).")
+    print("HBM roofline 8.0 TB/s (MI355X spec; on these boxes a float4 copy reaches 6.25 TB/s and a 3-read / 3-write triad 6.0 TB/s as ONE-SHOT grids, 4.8 / 4.9 as persistent grid-stride loops: profiles/r06_copy_lab.txt).")
     print("`alg. MB` are ALGORITHMIC bytes: every operand counted once, gathered rows counted once however often they are")
     print("re-read.  `counter MB` = TCC_EA0_RDREQ (32 / 64 / 128-byte requests) + WRITE_SIZE of separate --pmc passes.\n")
     print("| kernel | what is counted | alg. MB | launches | median us | achieved GB/s | % of 8 TB/s | counter MB | counter / alg. |")
