@@ -1404,8 +1404,8 @@ def main():
         dst = torch.empty_like(src)
         t_cp = event_time_ms(lambda: dst.copy_(src), 5, stream)
         extra["device_copy_gbps"] = 2 * src.numel() * 4 / (t_cp * 1e-3) / 1e9  # read + write
-        # the same as hand-written kernels of this library: a float4 copy and a 3-read / 3-write pass (Adam's shape);
-        # THESE are the yardsticks the streaming kernels of the epoch are held against
+        # the same as hand-written kernels of this library, ONE-SHOT grids: a float4 copy and a 3-read / 3-write pass (Adam's
+        # shape) — the yardsticks the streaming kernels of the epoch are held against
         lib_ = L.load()
         t_cp = event_time_ms(lambda: L.check(lib_.mrgcn_probe_copy_f32(src.data_ptr(), dst.data_ptr(), src.numel(), stream),
                                              "mrgcn_probe_copy_f32"), 5, stream)
@@ -1414,6 +1414,13 @@ def main():
         t_tr = event_time_ms(lambda: L.check(lib_.mrgcn_probe_triad_f32(src.data_ptr(), dst.data_ptr(), third.data_ptr(),
                                                                        src.numel(), stream), "mrgcn_probe_triad_f32"), 5, stream)
         extra["triad_gbps"] = 6 * src.numel() * 4 / (t_tr * 1e-3) / 1e9
+        # the same two as persistent grid-stride loops (round 5's yardsticks): the shape of a kernel with per-block state
+        t_cp = event_time_ms(lambda: L.check(lib_.mrgcn_probe_copy_persistent_f32(src.data_ptr(), dst.data_ptr(), src.numel(), stream),
+                                             "mrgcn_probe_copy_persistent_f32"), 5, stream)
+        extra["device_copy_gbps_hip_persistent"] = 2 * src.numel() * 4 / (t_cp * 1e-3) / 1e9
+        t_tr = event_time_ms(lambda: L.check(lib_.mrgcn_probe_triad_persistent_f32(src.data_ptr(), dst.data_ptr(), third.data_ptr(),
+                                                                                  src.numel(), stream), "mrgcn_probe_triad_persistent_f32"), 5, stream)
+        extra["triad_gbps_persistent"] = 6 * src.numel() * 4 / (t_tr * 1e-3) / 1e9
         del src, dst, third
         if have_model:
             n_params = sum(p.numel() for p in model.parameters())

@@ -564,6 +564,10 @@ int mrgcn_colsum_rows_f32(const float *X, int64_t ld, int64_t M, int32_t F, cons
  * step).  n % 4 == 0, 16-byte aligned.  Nothing in the package calls them. */
 int mrgcn_probe_copy_f32(const float *src, float *dst, int64_t n, void *stream);
 int mrgcn_probe_triad_f32(float *p, float *m, float *v, int64_t n, void *stream);
+/* the same two as PERSISTENT grids (2 048 resident blocks striding through the arrays): what a kernel with per-block
+ * state reaches — 4.8 / 4.9 TB/s on the bench boxes against 6.25 / 6.0 for the one-shot grids above */
+int mrgcn_probe_copy_persistent_f32(const float *src, float *dst, int64_t n, void *stream);
+int mrgcn_probe_triad_persistent_f32(float *p, float *m, float *v, int64_t n, void *stream);
 /* the same with row-strided operands: out[r, 0:F] = dY[r, 0:F] * (Y[r, 0:F] > 0) — the layer output Y of the
  * COMPACT product may live in a buffer with padded rows (MRGCN_SPMM_PAD_WRITABLE) */
 int mrgcn_relu_bwd_rows_f32(const float *dY, int64_t ld_dY, const float *Y, int64_t ldY, int64_t rows, int32_t F,

@@ -117,6 +117,8 @@ SIGNATURES = {
     "mrgcn_scatter_rows_zero_fill_f32": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i64, _p]),
     "mrgcn_probe_copy_f32": (C.c_int, [_p, _p, _i64, _p]),
     "mrgcn_probe_triad_f32": (C.c_int, [_p, _p, _p, _i64, _p]),
+    "mrgcn_probe_triad_persistent_f32": (C.c_int, [_p, _p, _p, _i64, _p]),
+    "mrgcn_probe_copy_persistent_f32": (C.c_int, [_p, _p, _i64, _p]),
     "mrgcn_relu_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "mrgcn_relu_bwd_rows_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _i64, _p]),
     "mrgcn_softmax_xent_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _i64, _i64, _p]),

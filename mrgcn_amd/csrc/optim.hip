@@ -521,10 +521,13 @@ using yf4 = __attribute__((ext_vector_type(4))) float;
 __global__ __launch_bounds__(256) void k_probe_copy4(const yf4 *__restrict__ a, yf4 *__restrict__ b, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) b[i] = a[i];
 }
+template <bool NT>
 __global__ __launch_bounds__(256) void k_probe_triad4(yf4 *__restrict__ p, yf4 *__restrict__ m, yf4 *__restrict__ v,
                                                       int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    yf4 P = p[i], M = m[i], V = v[i];
+    yf4 P, M, V;
+    if (NT) { P = __builtin_nontemporal_load(p + i); M = __builtin_nontemporal_load(m + i); V = __builtin_nontemporal_load(v + i); }
+    else { P = p[i]; M = m[i]; V = v[i]; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {  // Adam's arithmetic on a constant gradient
       const float g = 1e-3f;
@@ -532,9 +535,8 @@ __global__ __launch_bounds__(256) void k_probe_triad4(yf4 *__restrict__ p, yf4 *
       V[k] = fmaf(0.999f, V[k], 0.001f * g * g);
       P[k] -= 0.01f * (M[k] / (sqrtf(V[k]) + 1e-8f));
     }
-    p[i] = P;
-    m[i] = M;
-    v[i] = V;
+    if (NT) { __builtin_nontemporal_store(P, p + i); __builtin_nontemporal_store(M, m + i); __builtin_nontemporal_store(V, v + i); }
+    else { p[i] = P; m[i] = M; v[i] = V; }
   }
 }
 }  // namespace mrgcn
@@ -652,7 +654,22 @@ int mrgcn_colsum_rows_f32(const float *X, int64_t ld, int64_t M, int32_t F, cons
   return MRGCN_OK;
 }
 
+// The yardsticks as ONE-SHOT grids (a thread per 16-byte piece): what the memory system gives a stream whose work is
+// handed out in address order by the block dispatcher — 6.25 TB/s (copy) / 6.0 TB/s (triad, nontemporal) on the bench
+// boxes, MI355X_MICROARCH.md's 6.29.  The `_persistent` forms are round 5's (2 048 resident blocks striding through
+// the arrays: 4.8 / 4.9 TB/s): the shape a kernel with per-block state is stuck with (tools/lab/copy_lab.hip).
 int mrgcn_probe_copy_f32(const float *src, float *dst, int64_t n, void *stream) {
+  MRGCN_REQUIRE(src && dst && n >= 0 && n % 4 == 0, "NULL / n % 4");
+  MRGCN_REQUIRE(((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "16-byte alignment");
+  if (n == 0) return MRGCN_OK;
+  const int64_t n4 = n / 4;
+  mrgcn::k_probe_copy4<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      (const mrgcn::yf4 *)src, (mrgcn::yf4 *)dst, n4);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_probe_copy_persistent_f32(const float *src, float *dst, int64_t n, void *stream) {
   MRGCN_REQUIRE(src && dst && n >= 0 && n % 4 == 0, "NULL / n % 4");
   MRGCN_REQUIRE(((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "16-byte alignment");
   if (n == 0) return MRGCN_OK;
@@ -661,11 +678,21 @@ int mrgcn_probe_copy_f32(const float *src, float *dst, int64_t n, void *stream) 
   return MRGCN_OK;
 }
 
+int mrgcn_probe_triad_persistent_f32(float *p, float *m, float *v, int64_t n, void *stream) {
+  MRGCN_REQUIRE(p && m && v && n >= 0 && n % 4 == 0, "NULL / n % 4");
+  MRGCN_REQUIRE(((((uintptr_t)p) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0, "16-byte alignment");
+  if (n == 0) return MRGCN_OK;
+  mrgcn::k_probe_triad4<false><<<dim3(256 * 8), dim3(256), 0, (hipStream_t)stream>>>((mrgcn::yf4 *)p, (mrgcn::yf4 *)m, (mrgcn::yf4 *)v, n / 4);
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
 int mrgcn_probe_triad_f32(float *p, float *m, float *v, int64_t n, void *stream) {
   MRGCN_REQUIRE(p && m && v && n >= 0 && n % 4 == 0, "NULL / n % 4");
   MRGCN_REQUIRE(((((uintptr_t)p) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0, "16-byte alignment");
   if (n == 0) return MRGCN_OK;
-  mrgcn::k_probe_triad4<<<dim3(256 * 8), dim3(256), 0, (hipStream_t)stream>>>((mrgcn::yf4 *)p, (mrgcn::yf4 *)m, (mrgcn::yf4 *)v, n / 4);
+  const int64_t n4 = n / 4;
+  mrgcn::k_probe_triad4<true><<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>((mrgcn::yf4 *)p, (mrgcn::yf4 *)m, (mrgcn::yf4 *)v, n4);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
