@@ -54,7 +54,7 @@ const Entry kEntries[CFG_COUNT] = {
     {"mix_tickets", "MRGCN_MIX_TICKETS", 12, "basis mix forward: waves draw tiles of steps in order from this many ticket counters (1..64; 0: a stride through the node range)"},
     {"mix_ticket_tile", "MRGCN_MIX_TICKET_TILE", 4, "steps (two nodes each) a wave takes per ticket"},
     {"spmm_t_seg", "MRGCN_SPMM_T_SEG", 0, "general TRANSPOSED product of narrow layers: entry-sliced with a segmented sum (measured 417 vs 436 us at the AM shape — the product is bound by line fetches of the gathered rows, not by issue — and its sums are ordered differently from the live / support forms': opt-in)"},
-    {"sup_mix_once", "MRGCN_SUP_MIX_ONCE", 0, "mix backward on a support as a one-shot grid (a wave per 64 list entries: measured 739 vs 670 us in the AM epoch — its blocks re-stage the 43 KB comp table too often; 0: a resident grid striding through the list)"}
+    {"sup_mix_once", "MRGCN_SUP_MIX_ONCE", 0, "mix backward on a support as a one-shot grid (a wave per 64 list entries): 1 = with the LDS comp table (measured 739 vs 670 us in the AM epoch: its blocks re-stage 43 KB too often), 2 = comp rows read from the global table; 0: a resident grid striding through the list"}
 };
 std::atomic<int64_t> g_values[CFG_COUNT];
 std::once_flag g_once;

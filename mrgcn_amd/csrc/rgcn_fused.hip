@@ -1657,8 +1657,7 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
       // in-order tickets (see k_mix_fwd_mfma, TK): a full grid over a plan that carries the counters
       const int n_ctr = (int)std::min<int64_t>(std::max<int64_t>(cfg(CFG_MIX_TICKETS), 0), kWorkTickets);
       const int tk_tile = (int)std::min<int64_t>(std::max<int64_t>(cfg(CFG_MIX_TICKET_TILE), 1), 64);
-      const bool tk = p->tickets && !node_ids && n_ctr > 0 && grid == 256 &&
-                      (N + tn - 1) / tn >= (int64_t)kWorkTickets * 64 * 64;
+      const bool tk = p->tickets && !node_ids && n_ctr > 0 && grid == 256;  // (a full grid: >= 8 192 nodes)
       if (tk)
         MRGCN_HIP_TRY(mrgcn::fill_async(p->tickets, 0, (size_t)kWorkTickets * kWorkTicketStride * sizeof(unsigned long long), s));
 #define MIXM_GO(KS_, NQ_, TN_)                                                                              \

@@ -87,7 +87,10 @@ __device__ __forceinline__ void load_basis_row(const float *__restrict__ p, int 
 // trip on every node).  v_readlane hands a dM row and its relation round; lane b stores D[k][b] (a live column's B
 // products: one 4 B-byte row per column, coalesced) and keeps the column's share of its dV row for the squared norm.
 // Nodes with more than four live columns (9 % at the AM shape) walk the rest of their columns with direct loads.
-template <int FT, int NB, int TB, bool EXACT>
+// GC (round 6): `comp` is read from the (L2-resident) global table — lane b loads comp[r][b] of the node's first four
+// live columns right behind their relation ids — instead of from an LDS image: the kernel then has no workgroup state
+// and runs as a ONE-SHOT grid (a wave per 64 list entries) without re-staging 43 KB per block (`sup_mix_once = 2`).
+template <int FT, int NB, int TB, bool EXACT, bool GC = false>
 __global__ __launch_bounds__(TB) void k_mix_bwd_sup(const int32_t *__restrict__ lnode,
                                                         const int32_t *__restrict__ lnptr,
                                                         const int32_t *__restrict__ lrel,
@@ -96,9 +99,11 @@ __global__ __launch_bounds__(TB) void k_mix_bwd_sup(const int32_t *__restrict__ 
                                                         int64_t NL, int R, int B, int F_, float *__restrict__ D,
                                                         double *__restrict__ sq_part) {
   const int F = EXACT ? FT : F_;  // (a compile-time constant in the shapes that matter)
-  extern __shared__ __align__(16) float s_comp[];  // [R][B]
-  for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_comp[t] = comp[t];
-  __syncthreads();
+  extern __shared__ __align__(16) float s_comp[];  // [R][B]  (not with GC)
+  if constexpr (!GC) {
+    for (int t = threadIdx.x; t < R * B; t += blockDim.x) s_comp[t] = comp[t];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = blockDim.x >> 6;
@@ -126,6 +131,14 @@ __global__ __launch_bounds__(TB) void k_mix_bwd_sup(const int32_t *__restrict__ 
         dmine[u] = dM[(int64_t)kk * ldM + oqc];
         rmine[u] = lrel[kk];
       }
+      float w4[NB][4];
+      if constexpr (GC) {  // the comp rows of the first four live columns of every node of the step: unconditional loads
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            w4[u][t] = comp[(int64_t)__builtin_amdgcn_readlane(rmine[u], 16 * t) * B + b];
+      }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         if (i0 + u < cnt) {  // wave uniform
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(TB) void k_mix_bwd_sup(const int32_t *__restrict__ 
           for (int t = 0; t < 4; ++t) {
             if (t < nc) {  // wave uniform
               const int r = __builtin_amdgcn_readlane(rmine[u], 16 * t);
-              const float w = s_comp[r * B + b];
+              const float w = GC ? w4[u][t] : s_comp[r * B + b];
               float d[FT];
 #pragma unroll
               for (int o = 0; o < FT; ++o)
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(TB) void k_mix_bwd_sup(const int32_t *__restrict__ 
             for (int t = 0; t < 4; ++t) {
               if (t < nc2) {
                 const int r = __builtin_amdgcn_readlane(rm, 16 * t);
-                const float w = s_comp[r * B + b];
+                const float w = GC ? comp[(int64_t)r * B + b] : s_comp[r * B + b];
                 float d[FT];
 #pragma unroll
                 for (int o = 0; o < FT; ++o)
@@ -399,7 +412,8 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
   if (per_cu < 1) per_cu = 1;
   // (`sup_mix_once`: a ONE-SHOT grid — a wave takes one group of 64 list entries and ends; the block dispatcher hands the
   // groups out in address order: tools/lab/copy_lab.hip.  0: a resident grid striding through the list)
-  if (cfg(CFG_SUP_MIX_ONCE) == 0 && grid > 256 * per_cu) grid = 256 * per_cu;
+  const int once = (int)cfg(CFG_SUP_MIX_ONCE);  // 0: resident grid; 1: one-shot, LDS comp; 2: one-shot, comp from global
+  if (once == 0 && grid > 256 * per_cu) grid = 256 * per_cu;
   if (grid > kSqParts) grid = kSqParts;
   if (grid < 1) grid = 1;
   const int FT = (F == 10 || F == 11) ? F : (F + 3) / 4 * 4;
@@ -410,10 +424,15 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
   } while (0)
 #define SUP_GO4(T, NB_, TB_, EX_)                                                                                   \
   do {                                                                                                              \
-    auto kfn = k_mix_bwd_sup<T, NB_, TB_, EX_>;                                                                     \
-    MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, lds));                                                 \
-    kfn<<<dim3((unsigned)grid), dim3(TB_), lds, s>>>(q->lnode, q->lnptr, q->lrel, dM, ldM, V, comp, q->NL, R, B, F, \
-                                                     D, sq_part);                                                   \
+    if (once == 2 && EX_) {                                                                                         \
+      k_mix_bwd_sup<T, NB_, TB_, EX_, true><<<dim3((unsigned)grid), dim3(TB_), 0, s>>>(                             \
+          q->lnode, q->lnptr, q->lrel, dM, ldM, V, comp, q->NL, R, B, F, D, sq_part);                               \
+    } else {                                                                                                        \
+      auto kfn = k_mix_bwd_sup<T, NB_, TB_, EX_>;                                                                   \
+      MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, lds));                                               \
+      kfn<<<dim3((unsigned)grid), dim3(TB_), lds, s>>>(q->lnode, q->lnptr, q->lrel, dM, ldM, V, comp, q->NL, R, B,  \
+                                                       F, D, sq_part);                                              \
+    }                                                                                                               \
   } while (0)
 #define SUP_GO(T)                                  \
   do {                                             \

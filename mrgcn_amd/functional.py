@@ -223,8 +223,9 @@ def bf16_rows(X: torch.Tensor) -> torch.Tensor:
             raise L.MrgcnError("a bf16 layer input needs rows of whole 16-byte pieces")
         return X
     import weakref
-    cacheable = not X.requires_grad
-    if cacheable:
+    # (kept only when made outside a capture: a tensor allocated inside one lives in the graph's pool)
+    cacheable = not X.requires_grad and not torch.cuda.is_current_stream_capturing()
+    if not X.requires_grad:
         ent = _XB_CACHE.get(id(X))
         if ent is not None and ent[0]() is X and ent[1] == X._version and ent[2] == X.data_ptr():
             bump("bf16.x_cached")
@@ -242,6 +243,37 @@ def bf16_rows(X: torch.Tensor) -> torch.Tensor:
             del _XB_CACHE[k]
         _XB_CACHE[id(X)] = (weakref.ref(X), X._version, X.data_ptr(), Xb)
     return Xb
+
+
+_XPAD_CACHE = {}   # id(X) -> (weakref(X), version, data_ptr, padded copy)
+_XPAD = os.environ.get("MRGCN_X_LINE_ROWS", "1") != "0"
+
+
+def line_aligned_rows(X: torch.Tensor) -> torch.Tensor:
+    """A wide fp32 layer input that is DATA (no gradient; the same tensor every epoch) whose rows are not whole 128-byte
+    lines, as a view of a copy with rows padded to whole lines (K = 155: 620 -> 640 bytes) — made once, kept while the
+    tensor object lives unchanged, like the plan and the bf16 copy.  The relation transforms gather whole rows: an
+    unaligned 620-byte row touches 5.9 lines on average, an aligned one 5 (layer-0 transform 875 -> 834 us, its dW
+    945 -> 873 at the AM shape).  Anything else is returned as it is."""
+    if (not _XPAD or X.dtype != torch.float32 or X.requires_grad or X.dim() != 2 or X.shape[1] < 64
+            or X.stride(1) != 1 or (X.stride(0) * 4) % 128 == 0 or not X.is_cuda):
+        return X
+    import weakref
+    ent = _XPAD_CACHE.get(id(X))
+    if ent is not None and ent[0]() is X and ent[1] == X._version and ent[2] == X.data_ptr():
+        return ent[3]
+    if torch.cuda.is_current_stream_capturing():
+        return X   # (a copy made inside a capture would live in the graph's pool: the first eager step makes it)
+    n, K = X.shape
+    ld = (K + 31) // 32 * 32
+    buf = torch.zeros((n, ld), dtype=torch.float32, device=X.device)
+    buf[:, :K].copy_(X)
+    Xp = buf[:, :K]
+    bump("x_line_rows.copy")
+    for k in [k for k, e in _XPAD_CACHE.items() if e[0]() is None]:
+        del _XPAD_CACHE[k]
+    _XPAD_CACHE[id(X)] = (weakref.ref(X), X._version, X.data_ptr(), Xp)
+    return Xp
 
 
 class _SpmmLiteral(torch.autograd.Function):
@@ -367,6 +399,8 @@ class _RgcnLayer(torch.autograd.Function):
                 if Xb is None and X.dtype != torch.float32:
                     raise L.MrgcnError("a bf16 layer input needs operand_dtype 'bf16' and a shape the bf16 transform takes")
                 Xc = X if (X.dim() == 2 and X.stride(1) == 1) else X.contiguous()  # row-strided X is taken as it is
+                if Xb is None:
+                    Xc = line_aligned_rows(Xc)   # (a constant feature matrix: rows of whole 128-byte lines, copied once)
                 if weight_I is not None:
                     # feature term in plain compact order (sequential writes); the input-term
                     # pass below adds it while it emits the final rows in operand order

@@ -374,6 +374,89 @@ def test_basis_mix_forward_shapes_through_the_c_abi(B, F, with_addend):
                                M2.view(torch.int16 if dt == torch.bfloat16 else torch.int32)), sfx
 
 
+def test_constant_wide_input_is_read_from_line_aligned_rows():
+    """A wide fp32 feature matrix without gradient whose rows are not whole 128-byte lines (K = 155: 620 bytes) is
+    copied ONCE into rows padded to whole lines and read from there (functional.line_aligned_rows): the same bits as
+    reading it in place, one copy however many epochs, a new copy when the tensor changes in place, none for an input
+    that takes a gradient."""
+    import mrgcn_amd
+    from mrgcn_amd import functional as Fn
+    from mrgcn_amd.layers.graph import GraphConvolution
+    from mrgcn_amd.plan import plan_of
+    rng = np.random.default_rng(5)
+    N, R, B, K, F = 700, 5, 4, 155, 10
+    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, K, F, 6 * N, 100)
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    torch.manual_seed(3)
+    layer = GraphConvolution(K, F, R, N, num_bases=B, bias=True, input_layer=True, featureless=False).cuda()
+    X = torch.randn(N, K, device="cuda")
+    plan = plan_of(At, N, R)
+
+    def run():
+        layer.zero_grad(set_to_none=True)
+        Y = layer._forward_fused(X, plan, relu=True)
+        Y.sum().backward()
+        return Y.detach().clone(), layer.weight_F.grad.clone()
+    prev, Fn._XPAD = Fn._XPAD, False
+    try:
+        y0, g0 = run()
+    finally:
+        Fn._XPAD = prev
+    mrgcn_amd.reset_stats()
+    y1, g1 = run()
+    y2, g2 = run()
+    assert mrgcn_amd.stats().get("x_line_rows.copy") == 1
+    assert torch.equal(y1, y0) and torch.equal(y2, y0)
+    for g in (g1, g2):   # (this small layer's dW adds its chunks with float atomics: equal to rounding)
+        torch.testing.assert_close(g, g0, rtol=1e-5, atol=1e-5 * float(g0.abs().max()))
+    X.mul_(2.0)
+    y3, _ = run()
+    assert mrgcn_amd.stats().get("x_line_rows.copy") == 2 and not torch.equal(y3, y0)
+    Xg = X.detach().clone().requires_grad_(True)
+    mrgcn_amd.reset_stats()
+    layer._forward_fused(Xg, plan, relu=True).sum().backward()
+    assert mrgcn_amd.stats().get("x_line_rows.copy") is None and Xg.grad is not None
+
+
+@pytest.mark.parametrize("B,F", [(40, 10), (5, 11), (64, 16)])
+def test_mix_forward_in_ticket_order_equals_the_strided_walk(B, F):
+    """`mix_tickets` (round 6: the waves of the resident mix forward draw tiles of steps in order from ticket counters)
+    changes which wave computes a node, not what it computes: a graph large enough for a full grid (>= 8 192 nodes), with
+    hub nodes of several tiles, f32 and bf16 operands, with and without the feature term, several counter / tile
+    settings — the same bits as the strided walk (`mix_tickets=0`)."""
+    from mrgcn_amd import _lib as L
+    from mrgcn_amd.plan import GraphPlan
+    rng = np.random.default_rng(B * F)
+    N, R = 20000, 9
+    rows, cols, vals, _ = _oracle_layer_case(rng, N, R, B, 1, F, 6 * N, 900)
+    At = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    plan = GraphPlan(At, N, R)
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator("cuda").manual_seed(F)
+    V = torch.randn((N, B, F), device="cuda", generator=g)
+    comp = torch.randn((R, B), device="cuda", generator=g)
+    ldA = (F + 3) // 4 * 4
+    add = torch.randn((plan.ncols, ldA), device="cuda", generator=g)
+
+    def run(sfx, dt, with_add):
+        M = torch.full((plan.nop, ldA), 7.0, dtype=dt, device="cuda")
+        L.check(getattr(lib, "mrgcn_basis_mix_fwd_" + sfx)(plan.handle, V.data_ptr(), comp.data_ptr(), B, F,
+                                                           add.data_ptr() if with_add else 0, ldA, M.data_ptr(), ldA, s))
+        torch.cuda.synchronize()
+        return M.view(torch.int16 if dt == torch.bfloat16 else torch.int32).clone()
+    for sfx, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        for with_add in (False, True):
+            old = L.set_config(mix_tickets=0)
+            try:
+                want = run(sfx, dt, with_add)
+                for ctr, tile in ((12, 4), (1, 2), (64, 1), (8, 7)):
+                    L.set_config(mix_tickets=ctr, mix_ticket_tile=tile)
+                    assert torch.equal(run(sfx, dt, with_add), want), (sfx, with_add, ctr, tile)
+            finally:
+                L.set_config(**old)
+
+
 @pytest.mark.parametrize("zero_frac", [0.0, 0.5, 0.93, 1.0])
 @pytest.mark.parametrize("N,R,B,F,hub", [(900, 7, 40, 10, 500), (333, 5, 3, 11, 0), (640, 9, 64, 16, 200),
                                          (500, 6, 70, 12, 0)])  # the last one: B > 64, two-kernel fallback

@@ -136,6 +136,28 @@ def test_epochs_on_the_support_equal_epochs_on_the_marking_path(case_name, row_s
         assert (diff > 2e-5).mean() <= 2e-3, (k, float(diff.max()))
 
 
+@pytest.mark.parametrize("row_sparse", [None])
+def test_row_adam_forms_leave_the_same_bits(row_sparse):
+    """The fused row Adam on a support as a ONE-SHOT grid (`adam_once` = 1, 2 or 4 list entries per wave; round 6) and as
+    the persistent list kernel (`adam_once=0`) run the same fmaf chain per element: three epochs leave bitwise equal
+    parameters and moments."""
+    from mrgcn_amd import _lib as L
+    name = [n for n in _cases() if "smoke" in n and "ft" in n and "b5" in n][0]
+    runs = {}
+    for once in (0, 1, 2, 4):
+        old = L.set_config(adam_once=once)
+        try:
+            runs[once] = _epoch_runs(name, True, steps=3, row_sparse=row_sparse)
+        finally:
+            L.set_config(**old)
+    l0, p0 = runs[0]
+    for once in (1, 2, 4):
+        l1, p1 = runs[once]
+        assert l1 == l0, (once, l1, l0)
+        for k in p0:
+            assert np.array_equal(p1[k], p0[k]), (once, k)
+
+
 def test_the_default_epoch_runs_its_backward_on_supports(monkeypatch):
     """a labelled model's train_step takes the support path in every layer: the C entry points are called, the
     per-epoch marking product is not"""
