@@ -65,6 +65,11 @@ def _row_bytes_arg(operand_row_bytes):
     return (C.c_int32 * len(sizes))(*sizes), len(sizes)
 
 
+# row stride (floats) of a hidden layer's padded output at least this (16: rows of one 64-byte sector — the next layer's
+# transform gathers them)
+_PAD_OUT_LD = int(__import__("os").environ.get("MRGCN_PAD_OUT_LD", "0"))
+
+
 class GraphPlan:
     def __init__(self, A: torch.Tensor, num_nodes: int, num_relations: int,
                  prune_zeros: bool = False, replicate=None, operand_row_bytes=None, lean: bool = False):
@@ -221,7 +226,7 @@ class GraphPlan:
         if out is None:
             rows = self.view_rows(view) if out_rows is None else out_rows
             if padded_rows and view == L.VIEW_COMPACT and F <= 16 and F % 4 and not out_index:
-                out = torch.empty((rows, (F + 3) // 4 * 4), dtype=torch.float32, device=D.device)[:, :F]
+                out = torch.empty((rows, max((F + 3) // 4 * 4, _PAD_OUT_LD)), dtype=torch.float32, device=D.device)[:, :F]
                 pad_writable = True
             else:
                 out = torch.empty((rows, F), dtype=torch.float32, device=D.device)
