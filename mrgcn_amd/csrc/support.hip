@@ -404,6 +404,9 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
   // AM shape, kernel alone on one box: 512x1 598 us, 512x2 512, 512x4 557, 1024x2 501
   int tb = (int)cfg(CFG_SUP_MIX_TB), nb = (int)cfg(CFG_SUP_MIX_NB);
   if (nb < 1 || nb > 4) nb = 2;
+  // (a small support: a wave's 64 list entries are one serial chain of 64 / NB steps — 122 us at MUTAG's 23 k nodes with
+  // two per step; four per step halve the chain where occupancy does not matter)
+  if (q->NL < 262144 && nb < 4) nb = 4;
   if (tb != 1024) tb = 512;
   if (tb == 1024 && nb > 2) nb = 2;
   const int nw = tb / 64;
