@@ -1643,13 +1643,17 @@ int support_stage1(SupStage &b, hipStream_t s) {
 // the chunk lists of one order from its group pointers (host): chunk_ptr[R+1] | ids | rel | beg | end, every array
 // with at least one element.  Two passes, no allocation per call: `count` sizes, `write` fills `dst` (pinned memory).
 // columns per chunk of a support's relation-major orders (<= kRelChunk: the transforms' LDS lists are sized for that)
-int sup_rel_chunk() {
+// A small order (fewer live columns than ~1024 chunks' worth) is cut finer, down to 64 columns: its transforms are
+// chains of dependent steps per block, and a few dozen blocks leave most of the chip idle.
+int sup_rel_chunk(int64_t live_cols) {
   const int64_t v = cfg(CFG_SUP_REL_CHUNK);
-  return (int)std::min<int64_t>(std::max<int64_t>(v, 64), kRelChunk);
+  int64_t c = std::min<int64_t>(std::max<int64_t>(v, 64), kRelChunk);
+  if (live_cols < c * 1024) c = std::min<int64_t>(c, std::max<int64_t>(64, (live_cols / 1024 + 63) / 64 * 64));
+  return (int)c;
 }
 size_t order_chunks_count(const int32_t *h_gptr, int64_t ngroups, int64_t R, std::vector<int32_t> &cnt_rel,
                           int32_t *n_chunks, int32_t *max_chunks) {
-  const int kChunk = sup_rel_chunk();
+  const int kChunk = sup_rel_chunk(h_gptr[ngroups] - h_gptr[0]);
   cnt_rel.assign((size_t)R, 0);
   int32_t n = 0;
   for (int64_t g = 0; g < ngroups; ++g) {
@@ -1667,7 +1671,7 @@ size_t order_chunks_count(const int32_t *h_gptr, int64_t ngroups, int64_t R, std
 }
 void order_chunks_write(const int32_t *h_gptr, int64_t ngroups, int64_t R, const std::vector<int32_t> &cnt_rel,
                         int32_t n_chunks, int32_t *dst, size_t base, size_t offs[5], std::vector<int32_t> &fill) {
-  const int kChunk = sup_rel_chunk();
+  const int kChunk = sup_rel_chunk(h_gptr[ngroups] - h_gptr[0]);
   const size_t m = (size_t)std::max(n_chunks, 1);
   offs[0] = base;
   offs[1] = offs[0] + (size_t)(R + 1);

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(TB) void k_mix_bwd_sup(const int32_t *__restrict__ 
                                                         const float *__restrict__ dM, int64_t ldM,
                                                         const float *__restrict__ V, const float *__restrict__ comp,
                                                         int64_t NL, int R, int B, int F_, float *__restrict__ D,
-                                                        double *__restrict__ sq_part) {
+                                                        double *__restrict__ sq_part, int epw) {
   const int F = EXACT ? FT : F_;  // (a compile-time constant in the shapes that matter)
   extern __shared__ __align__(16) float s_comp[];  // [R][B]  (not with GC)
   if constexpr (!GC) {
@@ -113,10 +113,12 @@ __global__ __launch_bounds__(TB) void k_mix_bwd_sup(const int32_t *__restrict__ 
   const int oqc = oq < F ? oq : F - 1;
   const int64_t nwaves = (int64_t)gridDim.x * nw;
   float sq = 0.f;
-  for (int64_t base = ((int64_t)blockIdx.x * nw + wv) * 64; base < NL; base += nwaves * 64) {
+  // (`epw` <= 64 list entries per wave and round: 64 on a large support; a small one spreads its few entries over many
+  // waves instead of walking 64 of them as one serial chain)
+  for (int64_t base = ((int64_t)blockIdx.x * nw + wv) * epw; base < NL; base += nwaves * epw) {
     const int64_t me = (base + lane < NL) ? base + lane : NL - 1;
     const int32_t jn = lnode[me], k0v = lnptr[me], k1v = lnptr[me + 1];
-    const int cnt = (int)((NL - base < 64) ? NL - base : 64);
+    const int cnt = (int)((NL - base < epw) ? NL - base : epw);
     for (int i0 = 0; i0 < cnt; i0 += NB) {
       int32_t klo[NB], khi[NB], rmine[NB];
       float v[NB][FT], dmine[NB];
@@ -410,7 +412,12 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
   if (tb != 1024) tb = 512;
   if (tb == 1024 && nb > 2) nb = 2;
   const int nw = tb / 64;
-  int64_t grid = (q->NL + 64 * nw - 1) / (64 * nw);
+  int epw = 64;
+  if (q->NL < 262144) {  // ~2048 waves' worth of entries each, a multiple of the step
+    epw = (int)((q->NL / 2048 + nb - 1) / nb * nb);
+    epw = std::min(64, std::max(epw, nb));
+  }
+  int64_t grid = (q->NL + (int64_t)epw * nw - 1) / ((int64_t)epw * nw);
   int per_cu = (int)std::min<size_t>(tb == 1024 ? 2 : 4, (160 * 1024) / (lds + 1024));
   if (per_cu < 1) per_cu = 1;
   // (`sup_mix_once`: a ONE-SHOT grid — a wave takes one group of 64 list entries and ends; the block dispatcher hands the
@@ -429,12 +436,12 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
   do {                                                                                                              \
     if (once == 2 && EX_) {                                                                                         \
       k_mix_bwd_sup<T, NB_, TB_, EX_, true><<<dim3((unsigned)grid), dim3(TB_), 0, s>>>(                             \
-          q->lnode, q->lnptr, q->lrel, dM, ldM, V, comp, q->NL, R, B, F, D, sq_part);                               \
+          q->lnode, q->lnptr, q->lrel, dM, ldM, V, comp, q->NL, R, B, F, D, sq_part, epw);                          \
     } else {                                                                                                        \
       auto kfn = k_mix_bwd_sup<T, NB_, TB_, EX_>;                                                                   \
       MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, lds));                                               \
       kfn<<<dim3((unsigned)grid), dim3(TB_), lds, s>>>(q->lnode, q->lnptr, q->lrel, dM, ldM, V, comp, q->NL, R, B,  \
-                                                       F, D, sq_part);                                              \
+                                                       F, D, sq_part, epw);                                         \
     }                                                                                                               \
   } while (0)
 #define SUP_GO(T)                                  \
