@@ -693,6 +693,16 @@ int mrgcn_adam_step_rows_f32(float *param, const float *grad, float *exp_avg, fl
                              int64_t nrows, int32_t rowlen, const uint8_t *row_cur, uint8_t *row_ever,
                              float lr, float beta1, float beta2, float eps, int64_t step,
                              const float *bc_dev, const float *grad_scale, void *stream);
+/* mrgcn_adam_step_f32 / _dev_f32 (weight_decay = 0) on the rows index[0 .. n_index) of a parameter of rows of `rowlen`
+ * floats, the gradient of row index[c] in row c of a COMPACT gradient (`grad`: [n_index, ld_grad]); every other row is
+ * left alone.  For the literal (R*N) x F operand of a featureless layer without bases (graph.py:69-75: weight_I is the
+ * operand of torch.mm(A, .)): the autograd of that product (SparseAddmmBackward) puts gradient on the rows that are
+ * columns of A only — the plan's compact columns (MRGCN_ARR_ULCOL), for every label set — so the other rows keep zero
+ * moments and never move.  `index` holds distinct rows; rowlen, ld_grad multiples of 4; 16-byte aligned arrays. */
+int mrgcn_adam_step_index_rows_f32(float *param, const float *grad, int64_t ld_grad, float *exp_avg,
+                                   float *exp_avg_sq, const int32_t *index, int64_t n_index, int32_t rowlen, float lr,
+                                   float beta1, float beta2, float eps, int64_t step, const float *bc_dev,
+                                   const float *grad_scale, void *stream);
 /* The same update with the gradient formed on the fly: the backward called mrgcn_basis_mix_bwd_f32 with dV = NULL
  * (flags, dcomp and ||dV||^2 only) and this call rebuilds every live node's block from its dM rows,
  *     dV[j][b][f] = sum_{live c of j} comp[r_c][b] * dM[c][f]        (the sums mrgcn_basis_mix_bwd_f32 forms, bit for bit),

@@ -90,6 +90,8 @@ SIGNATURES = {
     "mrgcn_basis_mix_bwd_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     "mrgcn_adam_step_rows_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, C.c_float, C.c_float, C.c_float,
                                            C.c_float, _i64, _p, _p, _p]),
+    "mrgcn_adam_step_index_rows_f32": (C.c_int, [_p, _p, _i64, _p, _p, _p, _i64, _i32, C.c_float, C.c_float,
+                                                 C.c_float, C.c_float, _i64, _p, _p, _p]),
     "mrgcn_adam_rows_fused_supported": (_i32, [_p, _i32, _i32]),
     "mrgcn_adam_step_rows_fused_f32": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, C.c_float,
                                                  C.c_float, C.c_float, C.c_float, _i64, _p, _p, _p]),

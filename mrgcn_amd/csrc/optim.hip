@@ -224,6 +224,49 @@ __global__ __launch_bounds__(256) void k_adam_rows(float *__restrict__ p, const 
   }
 }
 
+// Adam on the rows `index[c]` of a parameter (rows of rowlen4 16-byte pieces) with the gradient of row index[c] in
+// row c of a COMPACT gradient — the literal operand of a featureless layer without bases (functional._SpmmLiteral): the
+// only rows of the (R*N) x F table that ever see gradient are the graph's compact columns, whatever the label set; the
+// others keep zero moments and never move (weight_decay = 0).  One thread per piece, a one-shot grid; the arithmetic is
+// k_adam's with wd = 0.  `index` holds distinct rows.
+__global__ __launch_bounds__(256) void k_adam_index_rows(float *__restrict__ p, const float *__restrict__ g,
+                                                         int64_t ldg4, float *__restrict__ m, float *__restrict__ v,
+                                                         const int32_t *__restrict__ index, int64_t n, int rowlen4,
+                                                         float lr, float b1, float b2, float eps, float bc1,
+                                                         float bc2_sqrt, const float *__restrict__ scale,
+                                                         const float *__restrict__ bc_dev) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * rowlen4) return;
+  if (bc_dev) {
+    bc1 = bc_dev[0];
+    bc2_sqrt = bc_dev[1];
+  }
+  const float sc = scale ? *scale : 1.f;
+  const float step = lr / bc1;
+  const int64_t c = i / rowlen4;
+  const int q = (int)(i - c * rowlen4);
+  const int64_t at = (int64_t)index[c] * rowlen4 + q;
+  float4 *p4 = reinterpret_cast<float4 *>(p) + at;
+  float4 *m4 = reinterpret_cast<float4 *>(m) + at;
+  float4 *v4 = reinterpret_cast<float4 *>(v) + at;
+  const float4 G = reinterpret_cast<const float4 *>(g)[c * ldg4 + q];
+  float4 P = *p4, M = *m4, V = *v4;
+  auto upd = [&](float &pp, float gg, float &mm, float &vv) {  // == k_adam with wd = 0
+    gg *= sc;
+    mm = fmaf(b1, mm, (1.f - b1) * gg);
+    vv = fmaf(b2, vv, (1.f - b2) * gg * gg);
+    float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= step * (mm / denom);
+  };
+  upd(P.x, G.x, M.x, V.x);
+  upd(P.y, G.y, M.y, V.y);
+  upd(P.z, G.z, M.z, V.z);
+  upd(P.w, G.w, M.w, V.w);
+  *p4 = P;
+  *m4 = M;
+  *v4 = V;
+}
+
 __global__ void k_clip_coef(const double *__restrict__ sumsq, float max_norm, float *__restrict__ coef,
                             float *__restrict__ norm) {
   float nrm = (float)sqrt(*sumsq);
@@ -847,6 +890,29 @@ int mrgcn_adam_step_rows_f32(float *param, const float *grad, float *exp_avg, fl
   else if (rowlen4 >= 16) ROWS_GO(16);
   else ROWS_GO(64);
 #undef ROWS_GO
+  MRGCN_HIP_TRY(hipGetLastError());
+  return MRGCN_OK;
+}
+
+int mrgcn_adam_step_index_rows_f32(float *param, const float *grad, int64_t ld_grad, float *exp_avg,
+                                   float *exp_avg_sq, const int32_t *index, int64_t n_index, int32_t rowlen, float lr,
+                                   float beta1, float beta2, float eps, int64_t step, const float *bc_dev,
+                                   const float *grad_scale, void *stream) {
+  MRGCN_REQUIRE(param && grad && exp_avg && exp_avg_sq && index, "NULL");
+  MRGCN_REQUIRE(step >= 1 || bc_dev, "step counts from 1");
+  MRGCN_REQUIRE(n_index >= 0 && rowlen > 0 && rowlen % 4 == 0 && ld_grad >= rowlen && ld_grad % 4 == 0,
+                "rows of whole 16-byte pieces (rowlen, ld_grad multiples of 4)");
+  MRGCN_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                "param / grad / moments must be 16-byte aligned");
+  if (n_index == 0) return MRGCN_OK;
+  const double bc1 = bc_dev ? 1.0 : 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = bc_dev ? 1.0 : 1.0 - pow((double)beta2, (double)step);
+  const int rowlen4 = rowlen >> 2;
+  const int64_t blocks = (n_index * rowlen4 + 255) / 256;
+  MRGCN_REQUIRE(blocks <= 0x7fffffff, "too many rows for one launch");
+  mrgcn::k_adam_index_rows<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
+      param, grad, ld_grad >> 2, exp_avg, exp_avg_sq, index, n_index, rowlen4, lr, beta1, beta2, eps, (float)bc1,
+      (float)sqrt(bc2), grad_scale, bc_dev);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }

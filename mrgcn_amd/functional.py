@@ -72,6 +72,10 @@ def dense_from_rows(param: torch.Tensor, ent) -> torch.Tensor:
     """The dense gradient a row-sparse entry stands for (zeros for the nodes without gradient): for the rare step
     that needs it after all — another term (a weight regulariser) put a dense gradient on the same parameter."""
     lib = L.load()
+    if ent.get("kind") == "index":   # compact rows of a literal operand (_SpmmLiteral)
+        g = torch.zeros_like(param)
+        g.index_copy_(0, ent["index"], ent["g"])
+        return g
     fz = ent.get("fused")
     if fz is None:
         return torch.where(ent["cur"].bool().view(-1, *([1] * (param.dim() - 1))), ent["g"], torch.zeros_like(ent["g"]))
@@ -282,7 +286,12 @@ class _SpmmLiteral(torch.autograd.Function):
     (R*N) x F gradient, as SparseAddmmBackward produces for the reference."""
 
     @staticmethod
-    def forward(ctx, plan: GraphPlan, D: torch.Tensor, bias, relu: bool):
+    def forward(ctx, plan: GraphPlan, D: torch.Tensor, bias, relu: bool, owner=None):
+        # `owner`: the layer whose `weight_I` parameter IS the operand (a featureless layer without bases): its
+        # gradient may then travel in compact form (below)
+        ctx.param = None
+        if owner is not None and D is getattr(owner, "weight_I", None) and D.is_contiguous():
+            ctx.param = D
         D = D.contiguous()
         Y = plan.spmm(L.VIEW_LITERAL, D, bias=bias, relu=relu)
         ctx.plan, ctx.relu, ctx.has_bias = plan, relu, bias is not None
@@ -301,14 +310,43 @@ class _SpmmLiteral(torch.autograd.Function):
         dD = None
         if ctx.needs_input_grad[1]:
             F = dY.shape[1]
+            param = ctx.param
+            rows = getattr(param, "_mrgcn_rows", None) if param is not None else None
+            if rows is not None and rows.get("kind") == "index" and rows.get("plan") is not plan:
+                # another adjacency (mini-batches, a second graph): other compact columns — rows outside THIS set may
+                # hold moments that must keep decaying: dense gradients for this parameter from now on
+                rows["dense_only"] = True
+            compact = (param is not None and F % 4 == 0 and plan.ncols > 0 and not plan.lean and _row_sparse_for(param)
+                       # (moments outside the compact columns: the optimizer asked for dense gradients from now on)
+                       and not (rows is not None and rows.get("kind") == "index" and rows.get("dense_only")))
+            if compact:
+                # The rows of the (R*N) x F operand that are columns of A — the plan's compact columns — are the only
+                # ones this product's autograd ever gives gradient to, whatever the labels: the gradient stays in
+                # compact order ([ncols, F], no zero fill of the table) and the consumer on the parameter
+                # (ClipAdam: mrgcn_adam_step_index_rows_f32) updates those rows only.  `.grad` stays None.
+                if rows is not None and rows["fresh"]:
+                    raise L.MrgcnError("row-sparse weight_I gradient: the layer ran twice in one train_step "
+                                       "(use train_step(..., row_sparse=False))")
+                if rows is None or rows.get("kind") != "index":
+                    if torch.cuda.is_current_stream_capturing() and getattr(plan, "_ulcol_long", None) is None:
+                        raise L.MrgcnError("the literal column list of this plan is built on first use: run one "
+                                           "backward of the layer before capturing it")
+                    rows = dict(kind="index", plan=plan, shape=tuple(param.shape), g=None, index=plan.ulcol_long(),
+                                index_ptr=plan.array_ptr(L.ARR_ULCOL)[0], fresh=False, seeded_for=None, dense_only=False)
+                    param._mrgcn_rows = rows
+                g = torch.empty((plan.ncols, F), dtype=torch.float32, device=dY.device)
+                plan.spmm(L.VIEW_TRANSPOSED, dY, out=g)
+                rows["g"], rows["fresh"] = g, True
+                bump("weight_I.index_rows")
+                return None, None, dbias, None, None
             dD = torch.zeros((ctx.d_rows, F), dtype=torch.float32, device=dY.device)
             ulcol_ptr, _ = plan.array_ptr(L.ARR_ULCOL)
             plan.spmm(L.VIEW_TRANSPOSED, dY, out=dD, out_index=ulcol_ptr)
-        return None, dD, dbias, None
+        return None, dD, dbias, None, None
 
 
-def spmm_literal(plan: GraphPlan, D: torch.Tensor, bias=None, relu: bool = False) -> torch.Tensor:
-    return _SpmmLiteral.apply(plan, D, bias, relu)
+def spmm_literal(plan: GraphPlan, D: torch.Tensor, bias=None, relu: bool = False, owner=None) -> torch.Tensor:
+    return _SpmmLiteral.apply(plan, D, bias, relu, owner)
 
 
 def relu_bwd(dY: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
@@ -1074,7 +1112,7 @@ def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False, input_term: bool =
     bias = layer.b if (layer.bias and use_bias) else None
     if weight_I is not None and comp_I is None and Xin is None and not bf16:
         # featureless layer without bases: weight_I already *is* the literal operand
-        return spmm_literal(plan, weight_I, bias=bias, relu=relu)
+        return spmm_literal(plan, weight_I, bias=bias, relu=relu, owner=layer)
     Y = _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, bias, relu, bf16, layer)
     if relu:
         Y._mrgcn_relu_out = True  # (a Python attribute of this tensor object: a copy or a view does not carry it)

@@ -120,7 +120,11 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
             gc = g if g.is_contiguous() else g.contiguous()
             L.check(lib.mrgcn_sumsq_accum_f32(gc.data_ptr(), gc.numel(), sumsq.data_ptr(), s), "mrgcn_sumsq_accum_f32")
         for _, e in rows:
-            sumsq.add_(e["sumsq"])
+            if e.get("kind") == "index":   # compact rows of a literal operand: the norm of the compact gradient
+                L.check(lib.mrgcn_sumsq_accum_f32(e["g"].data_ptr(), e["g"].numel(), sumsq.data_ptr(), s),
+                        "mrgcn_sumsq_accum_f32")
+            else:
+                sumsq.add_(e["sumsq"])
         L.check(lib.mrgcn_clip_coef_f32(sumsq.data_ptr(), float(max_norm), coef.data_ptr(), norm.data_ptr(), s),
                 "mrgcn_clip_coef_f32")
     if error_if_nonfinite and not bool(torch.isfinite(norm)):

@@ -225,6 +225,24 @@ class ClipAdam(torch.optim.Optimizer):
             self._scratch[device] = s
         return s
 
+    def _index_rows_ok(self, p, ent) -> bool:
+        """A compact-rows gradient (kind "index") may skip the rows outside its index set only while those rows hold no
+        moments: checked once per optimizer state (a loaded state, dense steps in between), with one host read."""
+        owner = (id(self), self._state_gen)
+        if ent.get("seeded_for") != owner:
+            if p.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise L.MrgcnError("ClipAdam: the first step with a compact literal gradient looks at the moments "
+                                   "(a host read): run one step before capturing")
+            st = self.state.get(p)
+            ok = p.dim() == 2 and p.is_contiguous() and p.shape[1] % 4 == 0
+            if ok and st and int(st.get("step", 0)) > 0:
+                outside = torch.ones(p.shape[0], dtype=torch.bool, device=p.device)
+                outside[ent["index"]] = False
+                ok = not bool(((st["exp_avg"][outside] != 0).any() | (st["exp_avg_sq"][outside] != 0).any()).item())
+            ent["dense_only"] = not ok
+            ent["seeded_for"] = owner
+        return not ent["dense_only"]
+
     def _new_state(self, p):
         st = self.state[p]
         if not st:
@@ -237,19 +255,26 @@ class ClipAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         lib = L.load()
         rowsparse = []  # gradient left on the parameter in row-sparse form (functional._ROW_SPARSE)
+        indexed = []    # ... as compact rows of a literal operand (functional._SpmmLiteral: kind "index")
         for g in self.param_groups:
             for p in g["params"]:
                 ent = pop_row_grad(p)
                 if ent is None:
                     continue
-                if p.grad is None and float(g["weight_decay"]) == 0.0:
+                if ent.get("kind") == "index":
+                    if (p.grad is None and float(g["weight_decay"]) == 0.0 and self._dist is None
+                            and self._index_rows_ok(p, ent)):
+                        indexed.append((g, p, ent))
+                    else:
+                        merge_row_grad(p, ent)
+                elif p.grad is None and float(g["weight_decay"]) == 0.0:
                     rowsparse.append((g, p, ent))
                 else:  # another term left a dense gradient on the same parameter (a regulariser): one dense step
                     merge_row_grad(p, ent)
         live = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
-        if not live and not rowsparse:
+        if not live and not rowsparse and not indexed:
             return None
-        device = (live[0][1] if live else rowsparse[0][1]).device
+        device = (live[0][1] if live else (rowsparse or indexed)[0][1]).device
         if not all(p.device == device for _, p in live):
             raise L.MrgcnError("ClipAdam: all parameters must live on one GPU")
         sc = self._dev_scratch(device)
@@ -264,7 +289,7 @@ class ClipAdam(torch.optim.Optimizer):
         # (mrgcn_sumsq_clip_multi_f32) and their Adam updates another (mrgcn_adam_step_multi_f32) when every group
         # shares (beta1, beta2, eps) — the reference's groups do (tasks/utils.py:8-45 vary lr / weight_decay only).
         hyper = {(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g, _ in live} | \
-                {(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g, _, _ in rowsparse}
+                {(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g, _, _ in rowsparse + indexed}
         small = [i for i, g in enumerate(grads) if g.numel() <= _MULTI_MAX_NUMEL]
         # (16 tensors per launch: a model with more — an MRGCN with encoders has ~40 — takes a few launches, not 2 x 40)
         multi = (_MULTI and self._dist is None and len(hyper) == 1 and len(small) >= 1 and len(rowsparse) <= 16)
@@ -299,12 +324,19 @@ class ClipAdam(torch.optim.Optimizer):
                             (C.c_int64 * len(part))(*[grads[i].numel() for i in part]), sc["accum"].data_ptr(), s),
                             "mrgcn_sumsq_accum_multi_f32")
                     last = small[(len(small) - 1) // 16 * 16:]   # the launch that also closes the norm
-                    gp = (C.c_void_p * len(last))(*[grads[i].data_ptr() for i in last])
-                    gn = (C.c_int64 * len(last))(*[grads[i].numel() for i in last])
+                    closing = [grads[i] for i in last]
+                    for _, _, ent in indexed:  # (a compact gradient: in the closing launch while it has room for it)
+                        if len(closing) < 16 and ent["g"].numel() <= 4 * _MULTI_MAX_NUMEL:
+                            closing.append(ent["g"])
+                        else:
+                            L.check(lib.mrgcn_sumsq_accum_f32(ent["g"].data_ptr(), ent["g"].numel(),
+                                                              sc["accum"].data_ptr(), s), "mrgcn_sumsq_accum_f32")
+                    gp = (C.c_void_p * len(closing))(*[g.data_ptr() for g in closing])
+                    gn = (C.c_int64 * len(closing))(*[g.numel() for g in closing])
                     ex = (C.c_void_p * max(len(rowsparse), 1))(*[ent["sumsq"].data_ptr() for _, _, ent in rowsparse])
                     dstep = self._dev_step.get((b1m, b2m)) if self.capturable else None
                     L.check(lib.mrgcn_sumsq_clip_multi_f32(
-                        len(last), gp, gn, len(rowsparse), ex, sc["accum"].data_ptr(), sc["ticket"].data_ptr(),
+                        len(closing), gp, gn, len(rowsparse), ex, sc["accum"].data_ptr(), sc["ticket"].data_ptr(),
                         float(self.max_norm) if use_clip else 0.0, sc["sumsq"].data_ptr(), sc["coef"].data_ptr(),
                         sc["norm"].data_ptr(), dstep[0].data_ptr() if dstep else 0, b1m, b2m,
                         dstep[1].data_ptr() if dstep else 0, s), "mrgcn_sumsq_clip_multi_f32")
@@ -328,6 +360,9 @@ class ClipAdam(torch.optim.Optimizer):
                             "mrgcn_sumsq_accum_f32")
                 for _, p, ent in rowsparse:  # ||g||^2 came for free with the gradient
                     (sc["sumsq_sharded"] if id(p) in sharded else sc["sumsq"]).add_(ent["sumsq"])
+                for _, _, ent in indexed:
+                    L.check(lib.mrgcn_sumsq_accum_f32(ent["g"].data_ptr(), ent["g"].numel(), sc["sumsq"].data_ptr(), s),
+                            "mrgcn_sumsq_accum_f32")
                 if self._dist:
                     from .partition import all_reduce_sum_
                     all_reduce_sum_(sc["sumsq_sharded"], self._dist[0])
@@ -394,12 +429,25 @@ class ClipAdam(torch.optim.Optimizer):
                     nrows, p.numel() // max(nrows, 1), ent["cur"].data_ptr(), ent["ever"].data_ptr(),
                     float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), bc, coef_ptr, s),
                     "mrgcn_adam_step_rows_f32")
+            for group, p, ent in indexed:
+                st = self._new_state(p)
+                st["step"] += 1
+                b1, b2 = group["betas"]
+                bc = bias[(float(b1), float(b2))].data_ptr() if self.capturable else 0
+                pre = ent.pop("coef", None)
+                g = ent["g"]
+                bump("adam.index_rows")
+                L.check(lib.mrgcn_adam_step_index_rows_f32(
+                    p.data_ptr(), g.data_ptr(), g.stride(0), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                    ent["index_ptr"], g.shape[0], p.numel() // max(p.shape[0], 1), float(group["lr"]), float(b1),
+                    float(b2), float(group["eps"]), int(st["step"]), bc,
+                    pre.data_ptr() if pre is not None else step_coef_ptr, s), "mrgcn_adam_step_index_rows_f32")
             coef_ptr = step_coef_ptr
             for (group, p) in live:
                 st = self._new_state(p)
                 st["step"] += 1
                 rows = getattr(p, "_mrgcn_rows", None)
-                if rows is not None:
+                if rows is not None and not rows.get("dense_only"):
                     rows["seeded_for"] = None  # a dense step may put moments where the row flags never looked
             # (host-side bias corrections are per step count: the one launch needs the tensors to share it)
             adam_multi = multi and (self.capturable or len({int(self.state[live[i][1]]["step"]) for i in small}) == 1)

@@ -1058,3 +1058,135 @@ def test_bias_gradient_column_sums_over_flagged_rows_through_the_c_abi(M, F, ld)
     assert torch.equal(outs[0], outs[1])
     np.testing.assert_allclose(outs[0].cpu().numpy(), X[flags == 1][:, :F].astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
     assert lib.mrgcn_colsum_rows_workspace(17) < 0
+
+
+# ---- the literal operand of a featureless layer without bases: compact-rows gradient (round 6) -------------------
+def _train_featureless(rows, cols, vals, N, R, idx, y, steps, row_sparse, graphed=False, seed=0, hidden=16,
+                       opt_state=None, model_state=None, weight_decay=0.0):
+    from mrgcn_amd.models.rgcn import RGCN
+    from mrgcn_amd.train import ClipAdam, GraphedTrainStep, train_step
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, R * N)).cuda()
+    torch.manual_seed(seed)
+    model = RGCN([(N, hidden, "mrgcn", torch.nn.ReLU()), (hidden, 4, "mrgcn", None)], R, N, 0, 0.0, True, True,
+                 False).cuda()
+    if model_state is not None:
+        model.load_state_dict(model_state)
+    ig, yg = torch.from_numpy(idx).cuda(), torch.from_numpy(y).cuda()
+    opt = ClipAdam(model.parameters(), lr=0.01, max_norm=1.0, capturable=graphed, weight_decay=weight_decay)
+    if opt_state is not None:
+        opt.load_state_dict(opt_state)
+    if graphed:
+        step = GraphedTrainStep(model, lambda: model(None, A), ig, yg, opt, warmup=1, row_sparse=row_sparse)
+        losses = [float(step()) for _ in range(steps - 1)]
+    else:
+        losses = [float(train_step(model, lambda: model(None, A), ig, yg, opt, row_sparse=row_sparse))
+                  for _ in range(steps)]
+    torch.cuda.synchronize()
+    return {k: v.clone() for k, v in model.state_dict().items()}, losses, opt, model
+
+
+def test_literal_operand_gradient_in_compact_rows_trains_like_the_dense_one():
+    """A featureless layer without bases (AIFB's shape): weight_I is the (R*N) x F operand of A . W itself
+    (graph.py:69-75).  train_step's default keeps its gradient as the compact columns' rows and Adam touches those rows
+    only (mrgcn_adam_step_index_rows_f32); row_sparse=False builds the dense (R*N) x F gradient and runs the dense
+    Adam — same parameters after 4 epochs, eager and replayed; rows that are no column of A never move."""
+    import mrgcn_amd
+    N, R = 5000, 3
+    rows, cols, vals, idx, y = _sparse_label_problem(N, R, labelled=40)
+    dense, ld, _, m0 = _train_featureless(rows, cols, vals, N, R, idx, y, 4, False)
+    assert m0.layers["layer_0"].weight_I.grad is not None
+    mrgcn_amd.reset_stats()
+    sparse, ls, opt, model = _train_featureless(rows, cols, vals, N, R, idx, y, 4, None)
+    st = mrgcn_amd.stats()
+    assert st.get("weight_I.index_rows") == 4 and st.get("adam.index_rows") == 4, st
+    wI = model.layers["layer_0"].weight_I
+    assert wI.grad is None and wI._mrgcn_rows["kind"] == "index"
+    assert wI._mrgcn_rows["g"].shape[0] < 0.7 * wI.shape[0]     # (a good part of the table is no column of A)
+    np.testing.assert_allclose(ls, ld, rtol=1e-6, atol=1e-7)
+    for k in dense:
+        torch.testing.assert_close(sparse[k], dense[k], rtol=1e-6, atol=1e-7, msg=k)
+    # rows outside the compact columns: exactly the initial values, zero moments
+    torch.manual_seed(0)
+    from mrgcn_amd.models.rgcn import RGCN
+    init = RGCN([(N, 16, "mrgcn", torch.nn.ReLU()), (16, 4, "mrgcn", None)], R, N, 0, 0.0, True, True, False).cuda()
+    outside = torch.ones(wI.shape[0], dtype=torch.bool, device="cuda")
+    outside[wI._mrgcn_rows["index"]] = False
+    assert torch.equal(wI.detach()[outside], init.layers["layer_0"].weight_I.detach()[outside])
+    assert not bool(opt.state[wI]["exp_avg"][outside].any())
+    graphed, lg, _, _ = _train_featureless(rows, cols, vals, N, R, idx, y, 4, None, graphed=True)
+    np.testing.assert_allclose(lg, ld[1:], rtol=1e-5, atol=1e-6)
+    for k in dense:
+        torch.testing.assert_close(graphed[k], dense[k], rtol=1e-5, atol=1e-6, msg=k)
+
+
+def test_literal_compact_rows_give_way_to_moments_outside_their_columns():
+    """An optimizer state with moments on a row that is no column of A (built elsewhere: a weight-decayed run, another
+    graph): skipping that row would freeze a parameter that Adam keeps moving — the compact form steps aside, once, and
+    the run equals the dense one.  With weight_decay the gradient is dense from the start."""
+    import copy
+    import mrgcn_amd
+    N, R = 3000, 3
+    rows, cols, vals, idx, y = _sparse_label_problem(N, R, seed=5, labelled=20)
+    sd1, _, opt1, model1 = _train_featureless(rows, cols, vals, N, R, idx, y, 2, False)
+    osd = copy.deepcopy(opt1.state_dict())
+    names = [n for n, _ in model1.named_parameters()]
+    k = names.index("layers.layer_0.weight_I")
+    used = set((cols.astype(np.int64)).tolist())
+    free = next(r for r in range(R * N) if r not in used)
+    osd["state"][k]["exp_avg"][free] += 0.25
+    osd["state"][k]["exp_avg_sq"][free] += 0.5
+    res = []
+    for rs in (False, None):
+        mrgcn_amd.reset_stats()
+        sd2, l2, _, m2 = _train_featureless(rows, cols, vals, N, R, idx, y, 3, rs, opt_state=copy.deepcopy(osd),
+                                            model_state=sd1)
+        if rs is None:
+            st = mrgcn_amd.stats()
+            assert st.get("adam.index_rows") is None and st.get("weight_I.index_rows") == 1, st
+            assert m2.layers["layer_0"].weight_I._mrgcn_rows["dense_only"]
+        res.append((sd2, l2))
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-6, atol=1e-7)
+    for key in res[0][0]:
+        torch.testing.assert_close(res[0][0][key], res[1][0][key], rtol=1e-6, atol=1e-7, msg=key)
+    assert not torch.equal(res[1][0]["layers.layer_0.weight_I"][free], sd1["layers.layer_0.weight_I"][free])
+    a = _train_featureless(rows, cols, vals, N, R, idx, y, 3, False, weight_decay=0.01)
+    mrgcn_amd.reset_stats()
+    b = _train_featureless(rows, cols, vals, N, R, idx, y, 3, None, weight_decay=0.01)
+    assert mrgcn_amd.stats().get("adam.index_rows") is None
+    for key in a[0]:
+        torch.testing.assert_close(a[0][key], b[0][key], rtol=1e-6, atol=1e-7, msg=key)
+
+
+def test_adam_on_indexed_rows_equals_the_dense_step_on_those_rows():
+    """mrgcn_adam_step_index_rows_f32 against mrgcn_adam_step_f32 fed the scattered gradient: the indexed rows bit for
+    bit, every other row untouched (also with a padded gradient row stride and a clip coefficient)."""
+    from mrgcn_amd import _lib as L
+    lib = L.load()
+    gen = torch.Generator("cuda").manual_seed(3)
+    nrows, F, n = 5000, 12, 700
+    index = torch.randperm(nrows, device="cuda", generator=gen)[:n].to(torch.int32)
+    p0 = torch.randn((nrows, F), device="cuda", generator=gen)
+    m0 = torch.randn((nrows, F), device="cuda", generator=gen) * 0.1
+    v0 = torch.rand((nrows, F), device="cuda", generator=gen) * 0.1
+    gbuf = torch.randn((n, 16), device="cuda", generator=gen)
+    coef = torch.tensor(0.37, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for ld, g in ((F, gbuf[:, :F].contiguous()), (16, gbuf)):
+        dense_g = torch.zeros_like(p0)
+        dense_g[index.long()] = g[:, :F]
+        pd, md, vd = p0.clone(), m0.clone(), v0.clone()
+        L.check(lib.mrgcn_adam_step_f32(pd.data_ptr(), dense_g.data_ptr(), md.data_ptr(), vd.data_ptr(), pd.numel(),
+                                        0.01, 0.9, 0.999, 1e-8, 0.0, 3, coef.data_ptr(), s))
+        pi, mi, vi = p0.clone(), m0.clone(), v0.clone()
+        L.check(lib.mrgcn_adam_step_index_rows_f32(pi.data_ptr(), g.data_ptr(), ld, mi.data_ptr(), vi.data_ptr(),
+                                                   index.data_ptr(), n, F, 0.01, 0.9, 0.999, 1e-8, 3, 0,
+                                                   coef.data_ptr(), s))
+        torch.cuda.synchronize()
+        ii = index.long()
+        assert torch.equal(pi[ii], pd[ii]) and torch.equal(mi[ii], md[ii]) and torch.equal(vi[ii], vd[ii])
+        out = torch.ones(nrows, dtype=torch.bool, device="cuda")
+        out[ii] = False
+        assert torch.equal(pi[out], p0[out]) and torch.equal(mi[out], m0[out]) and torch.equal(vi[out], v0[out])
+    with pytest.raises(L.MrgcnError):
+        L.check(lib.mrgcn_adam_step_index_rows_f32(p0.data_ptr(), gbuf.data_ptr(), 16, m0.data_ptr(), v0.data_ptr(),
+                                                   index.data_ptr(), n, 10, 0.01, 0.9, 0.999, 1e-8, 3, 0, 0, s))
