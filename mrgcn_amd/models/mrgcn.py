@@ -12,6 +12,7 @@ In a mini-batch the encoders run for the outermost neighbours only."""
 from __future__ import annotations
 
 import logging
+import os
 import warnings
 
 import torch
@@ -24,6 +25,7 @@ from .temporal_cnn import TCNN
 
 logger = logging.getLogger(__name__)
 
+_GATE_READBACK = os.environ.get("MRGCN_GATE_READBACK", "0") == "1"
 _MLP_LAYERS = {"xsd.boolean": 1, "xsd.numeric": 1, "xsd.date": 2, "xsd.dateTime": 2, "xsd.gYear": 2}
 _COUNTER_GROUP = {"xsd.boolean": "num", "xsd.numeric": "num", "xsd.date": "temp",
                   "xsd.dateTime": "temp", "xsd.gYear": "temp", "xsd.string": "llm", "xsd.anyURI": "llm",
@@ -193,27 +195,43 @@ class MRGCN(nn.Module):
             X = XF.float() if X0.shape[1] == 0 else torch.cat([X0.to(dev), XF], dim=1).float()
         return self.rgcn(X, batch.A)
 
+    def _gate_decisions(self):
+        """(which gates are zero as far as the host knows — a list of bools, or None: compute every set —,
+        the gate vector with its zero entries masked on the device).
+
+        mrgcn.py:263-266 skips a set whose gate `isclose` to zero; reading the gates back for that costs a host wait
+        per forward (the reference: one per set) and cannot happen inside a captured epoch.  The test runs on the
+        device instead and masks the gate vector: a zero gate's block of X is exactly zero and no gradient reaches the
+        gate or its encoder — what the skip produces (a skipped encoder's parameters keep `.grad = None`, a masked
+        one's get zeros: the same Adam step from zero moments) — without the host ever looking.  What is lost is the
+        saving: a zero-gated set's encoder still runs (and an encoder output that is not finite would turn its block
+        NaN where the skip would not have looked).  Gates start at 0.1 and are trained (mrgcn.py:150-154): one
+        that is exactly zero was put there by hand; MRGCN_GATE_READBACK=1 then buys the skip back for one host wait per
+        forward (outside captures).  Gates on the CPU are read directly."""
+        g = self.gate_weights
+        zero = torch.isclose(g.detach(), torch.zeros((), device=g.device))
+        gates = torch.where(zero, torch.zeros_like(g), g)
+        if not g.is_cuda:
+            return zero.tolist(), gates                      # (no device to wait for)
+        if _GATE_READBACK and not torch.cuda.is_current_stream_capturing():
+            return zero.cpu().tolist(), gates
+        return None, gates
+
     def _compute_modality_embeddings(self, F, batch_idx, full_batch=False):
         """XF[node, off:off+dim] = gate * encoder(encodings[node]) per encoding set
         (mrgcn.py:250-305).
 
         The reference resolves, per call and per set, which rows of the batch carry the encoding
-        (`torch_intersect1d` + two `isin` masks) and reads every gate back to test it against zero.
-        Here the gates are read back once per forward (one host wait instead of one per set), a
-        full batch resolves its sets once (the row positions are the node ids, the encodings do
-        not change between epochs) and a mini-batch matches node ids on the device the encodings
-        live on."""
+        (`torch_intersect1d` + two `isin` masks) and reads every gate back to test it against zero
+        (mrgcn.py:263-266: a zero gate's set is skipped).  Here no forward waits for the device:
+        the zero test runs there and masks the gate vector (`_gate_decisions`).  A full batch resolves its sets once (the row positions
+        are the node ids, the encodings do not change between epochs) and a mini-batch matches
+        node ids on the device the encodings live on."""
         dev = self.devices["relational"]
         X = torch.zeros((len(batch_idx), self.modality_out_dim), dtype=torch.float32, device=dev)
+        gates = self.gate_weights
         if isinstance(self.gate_weights, nn.Parameter):
-            if X.is_cuda and torch.cuda.is_current_stream_capturing():
-                # a captured epoch (train.GraphedTrainStep) cannot read back: it keeps the decisions of the
-                # warm-up step before it
-                gate_is_zero = self.__dict__.get("_gate_is_zero")
-            else:
-                gate_is_zero = torch.isclose(self.gate_weights.detach(),
-                                             torch.zeros((), device=self.gate_weights.device)).cpu().tolist()
-                self.__dict__["_gate_is_zero"] = gate_is_zero
+            gate_is_zero, gates = self._gate_decisions()
         else:
             gate_is_zero = None             # ungated: constant ones (mrgcn.py:150-156)
         cache = self.__dict__.setdefault("_full_batch_sets", {}) if full_batch else None
@@ -252,7 +270,7 @@ class MRGCN(nn.Module):
                 if rows is None:            # no node of this batch has the datatype
                     offset += out_dim
                     continue
-                gate = self.gate_weights[i_gate]
+                gate = gates[i_gate]
                 if datatype == "blob.image" and self.im_norm is not None:
                     data = self.im_norm.normalize_(data)
                 elif datatype == "blob.image":
@@ -266,7 +284,7 @@ class MRGCN(nn.Module):
                     # every Linear + ReLU, the gate and the scatter in one kernel (csrc/encoders.hip)
                     from .. import dense
                     lin = module.linears()
-                    X = dense.mlp_gate_scatter(X, data, rows, self.gate_weights, i_gate, offset,
+                    X = dense.mlp_gate_scatter(X, data, rows, gates, i_gate, offset,
                                                [l.weight for l in lin], [l.bias for l in lin], fresh=True)
                 else:
                     out = module(data).to(dev) * gate.to(dev)

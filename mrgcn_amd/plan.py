@@ -274,9 +274,11 @@ class GraphPlan:
         """(erel, unit_node, unit_beg, unit_end, unit_multi, n_units): the plan's CSC entries cut into per-node units
         of at most `unit_entries` entries (a source node's entries are contiguous), built once and kept.  (Measured on
         the FB15k-237 epoch: 1.42 / 1.23 / 1.17 / 1.18 / 1.18 / 1.20 / 1.24 / 1.36 ms with units of 16 / 32 / 48 / 64 /
-        96 / 128 / 256 / 512 entries — hub nodes stop being the tail of the launch.  256 stays: with 64 the pieces'
-        float atomics into dV reorder a cancelling hub sum enough to leave the step oracle's interval for 29 of 5.8 M
-        elements of one replayed step, `tests/test_gpu_step_oracle.py`, in one test order.)"""
+        96 / 128 / 256 / 512 entries — hub nodes stop being the tail of the launch.  Round 5 kept 256 because with 64
+        the step oracle once saw 29 of 5.8 M elements of a replayed step outside their interval and blamed the order of
+        the float atomics; round 6 found the cause — one hidden unit whose pre-activation is within 1e-10 of zero, its
+        ReLU mask decided by rounding: `tests/test_gpu_step_oracle.py::_kink_mask` — and the reproducible form
+        (`wide_units_det`) runs with 64.)"""
         ent = self.__dict__.get("_wide_units")
         if ent is None:
             nptr = self.export(L.ARR_NPTR).astype(np.int64)

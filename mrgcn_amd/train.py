@@ -482,6 +482,9 @@ class ClipAdam(torch.optim.Optimizer):
                     p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                     p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                     float(group["weight_decay"]), int(st["step"]), coef_ptr, s), "mrgcn_adam_step_f32")
+        # the kernels wrote through raw pointers: tell autograd (and every cache keyed by a tensor's version — the gate
+        # decisions of models.mrgcn) that these parameters changed, as an in-place torch update would
+        torch.autograd.graph.increment_version([p for _, p in live] + [p for _, p, _ in rowsparse + indexed])
         return None
 
     def last_grad_norm(self) -> float:

@@ -444,9 +444,32 @@ def _levels_forward(cfgs, params, X, A: sp.csr_matrix, rows, relu_last, chunk, d
         if cfg.bias:
             pre = pre + p["b"].astype(dtype)
         act = (li < nl - 1) or relu_last
-        lv.update(pre=pre, act=act, feat=feat)
+        lv.update(pre=pre, act=act, feat=feat, kinks=_kinks(lv["sub_c"], D, pre, lv) if act else None)
         H = np.maximum(pre, 0.0) if act else pre
     return subs, H
+
+
+def _kinks(sub_c, D, pre, lv, k=64):
+    """The k pre-activations of a ReLU layer that lie closest to zero RELATIVE to the size of the sums they come from
+    (`mag` = sum |a| |d| over the row's entries: what a float32 evaluation's rounding error scales with).  Where
+    |pre| <~ 1e-6 mag a float32 forward may land on the other side of the kink: the unit's mask, and with it one whole
+    term of the gradient of every source node of that row, is then decided by rounding — tests widen their intervals
+    there instead of calling it a mismatch.  dict(row [global row ids], col, pre, mag, nodes [per entry: the source
+    nodes j of the row's entries])."""
+    if pre.size == 0:
+        return dict(row=np.zeros(0, np.int64), col=np.zeros(0, np.int64), pre=np.zeros(0), mag=np.zeros(0), nodes=[])
+    k = min(k, pre.size)
+    absd = np.abs(D)
+    rowmag = abs(sub_c) @ absd.max(1)                      # a cheap upper bound per row, to rank candidates
+    score = np.abs(pre) / np.maximum(rowmag[:, None], 1e-300)
+    flat = np.argpartition(score.ravel(), k - 1)[:k]
+    ri, ci = np.unravel_index(flat, pre.shape)
+    mags, nodes = [], []
+    for i, f in zip(ri, ci):
+        a = sub_c[i]
+        mags.append(float(np.abs(a.data) @ absd[a.indices, f]))
+        nodes.append(np.unique(lv["j_u"][a.indices]))
+    return dict(row=lv["rows"][ri], col=ci.astype(np.int64), pre=pre[ri, ci], mag=np.asarray(mags), nodes=nodes)
 
 
 def rgcn_train_step_at_rows(cfgs, params, X, A: sp.csr_matrix, idx, targets, sample_nodes=None, moments=None, t=1,
@@ -589,4 +612,4 @@ def rgcn_train_step_at_rows(cfgs, params, X, A: sp.csr_matrix, idx, targets, sam
                  for k, gv in extra_grads.items()}
     return dict(loss=loss, logits=logits, grads=grads, wI=wI, grad_norm=total, coef=coef, new=new,
                 extra_grads=extra_grads, new_extra=new_extra,
-                levels=[dict(rows=lv["rows"], src=lv["src"], ncols=len(lv["ucol"])) for lv in levels])
+                levels=[dict(rows=lv["rows"], src=lv["src"], ncols=len(lv["ucol"]), kinks=lv.get("kinks")) for lv in levels])

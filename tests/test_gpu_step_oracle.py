@@ -17,6 +17,8 @@ after the step must lie inside the interval Adam maps that gradient uncertainty 
 lr-sized step only where its gradient is that close to zero), so one mishandled node block fails."""
 import numpy as np
 import pytest
+import os
+
 import scipy.sparse as sp
 import torch
 
@@ -51,9 +53,30 @@ def _adam_update(g, m0, v0, t, coef):
     return LR * (m / (1 - B1 ** t)) / (np.sqrt(v) / np.sqrt(1 - B2 ** t) + EPS), m, v
 
 
-def _check_adam(name, p_before, g, coef, got_p, got_m, got_v, m0=0.0, v0=0.0, t=1, per_block=False):
+KINK = 1e-7   # a ReLU unit whose float64 pre-activation is within KINK of zero, relative to the sum of the magnitudes
+              # of its terms (two float32 roundings of that sum), may carry the other mask in a float32 forward
+
+
+def _kink_mask(shape, kinks):
+    """bool [N, B, F] (node-major weight_I blocks): the elements whose gradient holds a term that a unit on the ReLU
+    kink switches on or off — feature f of every source node of such a unit's row (oracle: `_kinks`)."""
+    mask = np.zeros(shape, dtype=bool)
+    if kinks is None:
+        return mask
+    for pre, mag, col, nodes in zip(kinks["pre"], kinks["mag"], kinks["col"], kinks["nodes"]):
+        if abs(pre) <= KINK * mag:
+            mask[nodes, :, col] = True
+    return mask
+
+
+def _check_adam(name, p_before, g, coef, got_p, got_m, got_v, m0=0.0, v0=0.0, t=1, per_block=False, uncertain=None):
     """`got_*` (the GPU's parameter and moments after the step) against Adam applied to the oracle's gradient `g`
-    (unclipped; `coef` the oracle's clip coefficient) with the gradient tolerance mapped through the update."""
+    (unclipped; `coef` the oracle's clip coefficient) with the gradient tolerance mapped through the update.
+    `uncertain` (bool, like the parameter): elements left out — their gradient depends on which side of the ReLU kink a
+    float32 forward puts a unit that float64 has within rounding of zero (`_kink_mask`); at most 5e-4 of the tensor."""
+    if uncertain is not None:
+        assert uncertain.mean() <= 5e-4, (name, "too many elements declared uncertain", int(uncertain.sum()))
+    certain = True if uncertain is None else ~uncertain
     g = np.asarray(g, np.float64)
     p0 = np.asarray(p_before, np.float64)
     d = 1e-3 * np.abs(g) + _gtol(g, per_block)
@@ -62,16 +85,19 @@ def _check_adam(name, p_before, g, coef, got_p, got_m, got_v, m0=0.0, v0=0.0, t=
     lo, hi = p0 - u.max(0), p0 - u.min(0)
     tol = 1e-7 + 3e-7 * np.abs(p0)
     gp = np.asarray(got_p, np.float64)
-    bad = (gp < lo - tol) | (gp > hi + tol)
-    assert not bad.any(), (name, "parameter", int(bad.sum()), np.argwhere(bad)[:5].tolist())
+    bad = ((gp < lo - tol) | (gp > hi + tol)) & certain
+    over = np.where(certain, np.maximum(lo - tol - gp, gp - hi - tol) / (hi - lo + 2 * tol), -1.0)  # (in interval widths)
+    if os.environ.get("MRGCN_TEST_MARGINS"):   # (how close the closest element comes: <= 0 inside, in interval widths)
+        print("margin", name, float(over.max()), np.unravel_index(int(over.argmax()), over.shape))
+    assert not bad.any(), (name, "parameter", int(bad.sum()), np.argwhere(bad)[:5].tolist(), float(over.max()))
     _, m_ref, v_ref = ups[1]
     dm = (1 - B1) * coef * d
-    bad = np.abs(np.asarray(got_m, np.float64) - m_ref) > dm + 1e-6 * np.abs(m_ref) + 1e-30
+    bad = (np.abs(np.asarray(got_m, np.float64) - m_ref) > dm + 1e-6 * np.abs(m_ref) + 1e-30) & certain
     assert not bad.any(), (name, "exp_avg", int(bad.sum()), np.argwhere(bad)[:5].tolist())
     # exp_avg_sq is quadratic in the gradient: compared through its square root
     sv_ref, sv_got = np.sqrt(v_ref), np.sqrt(np.maximum(np.asarray(got_v, np.float64), 0.0))
     dv = np.sqrt(1 - B2) * coef * d
-    bad = np.abs(sv_got - sv_ref) > 1.5 * dv + 2e-6 * sv_ref + 1e-30
+    bad = (np.abs(sv_got - sv_ref) > 1.5 * dv + 2e-6 * sv_ref + 1e-30) & certain
     assert not bad.any(), (name, "exp_avg_sq", int(bad.sum()), np.argwhere(bad)[:5].tolist())
 
 
@@ -505,8 +531,16 @@ def test_fb15k_lp_step_against_the_float64_oracle_at_full_shape():
                                    ("weight_I", wI, ora["wI"][0]["grad"], "wI")):
             s = opt.state[p]
             m0, v0 = mom[key] if mom else (0.0, 0.0)
+            unc = None
+            if name == "weight_I":   # every node block is compared: the few that hang on a unit at the ReLU kink are not
+                kk = ora["levels"][0]["kinks"]
+                unc = _kink_mask(tuple(p.shape), kk)
+                if os.environ.get("MRGCN_TEST_MARGINS"):
+                    o = np.argsort(np.abs(kk["pre"]) / kk["mag"])[:3]
+                    print("kinks", where, [(int(kk["row"][i]), int(kk["col"][i]), float(kk["pre"][i]), float(kk["mag"][i]),
+                                            len(kk["nodes"][i])) for i in o], int(unc.sum()))
             _check_adam(f"{where}: {name}", before[key], gref, coef, _np(p), _np(s["exp_avg"]), _np(s["exp_avg_sq"]),
-                        m0, v0, t, per_block=(name == "weight_I"))
+                        m0, v0, t, per_block=(name == "weight_I"), uncertain=unc)
 
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     before = snapshot()
