@@ -484,7 +484,10 @@ def am_encoders_record(args, dev, steps=10, warm=2, compute="f32"):
     fwd = lambda: model(batch)   # noqa: E731
     for _ in range(warm):
         train_step(model, fwd, idx, y, opt)
-    rec["ms_per_step_eager"], _ = timed(lambda: train_step(model, fwd, idx, y, opt), 3)
+    # (eager steps one by one, the median: the first few also grow torch's caching allocator — fresh segments cost
+    # tens of ms each on first touch — which says nothing about the step)
+    eager = [timed(lambda: train_step(model, fwd, idx, y, opt), 1)[0] for _ in range(6)]
+    rec["ms_per_step_eager"], rec["ms_per_step_eager_all"] = float(np.median(eager)), [round(t, 2) for t in eager]
     try:
         step = GraphedTrainStep(model, fwd, idx, y, opt, warmup=1)
         step()   # (the first replay uploads the graph)

@@ -3,7 +3,7 @@
 launches of the epoch's first kernel (default: the layer-0 relation transform).  Shows every launch — this package's
 kernels, torch's, the runtime's fill / copy kernels — with its start offset, duration, grid and stream (queue), and
 the gaps in which the device idled.
-usage: python tools/epoch_sequence.py <dir> [first-kernel-substring [launches of that kernel per epoch]]"""
+usage: python tools/epoch_sequence.py <dir> [first-kernel-substring [launches of that kernel per epoch | shortest]]"""
 import csv
 import glob
 import sys
@@ -21,10 +21,14 @@ def main():
     first = sys.argv[2] if len(sys.argv) > 2 else "k_xform_mfma_fwd<1, false, 16"
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
-    per = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    shortest = len(sys.argv) > 3 and sys.argv[3] == "shortest"
+    per = int(sys.argv[3]) if len(sys.argv) > 3 and not shortest else 1
     if len(starts) < per + 1:
         raise SystemExit("fewer than two epochs in the trace")
     a, b = starts[-1 - per], starts[-1]
+    if shortest:  # the shortest stretch: a replayed epoch of a small graph (the run's last epochs may be eager ones)
+        a, b = min(zip(starts[:-1], starts[1:]),
+                   key=lambda ab: int(rows[ab[1]]["Start_Timestamp"]) - int(rows[ab[0]]["Start_Timestamp"]))
     t0 = int(rows[a]["Start_Timestamp"])
     print(f"source: {f}\nepoch = launches {a}..{b - 1}: {(int(rows[b]['Start_Timestamp']) - t0) / 1e3:.1f} us from first "
           f"kernel to the next epoch's first kernel\n")

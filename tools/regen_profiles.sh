@@ -64,6 +64,12 @@ rm -rf $o/stats_encb
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_bf16 -o run -- python3 bench.py --operand bf16 --steps 20 --warmup 3 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-seeds --no-side-workloads --no-literal-spmm > $o/bench_bf16_under_rocprof.json 2> $o/bench_bf16_under_rocprof.err
 python3 tools/epoch_sequence.py $o/stats_bf16 k_xform_bf16_fwd > $o/bf16_epoch_sequence.md 2>&1
 rm -rf $o/stats_bf16
+# (10b) the small graphs' replayed epochs in launch order (BASELINE configs 1 and 2: launch-bound)
+for w in aifb mutag; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_$w -o run -- python3 bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --no-renumbered-extra --no-reference-loop --no-seeds --no-side-workloads --no-literal-spmm > $o/bench_${w}_under_rocprof.json 2> $o/bench_${w}_under_rocprof.err
+  python3 tools/epoch_sequence.py $o/stats_$w k_xent_rows shortest > $o/${w}_epoch_sequence.md 2>&1
+  rm -rf $o/stats_$w
+done
 hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/lab/copy_lab.hip -o /tmp/copy_lab 2>/dev/null && /tmp/copy_lab > $o/copy_lab.txt 2>&1
 python3 tools/lab/spmm_hot_lab.py > $o/spmm_hot_lab.txt 2>&1
 # the CPU suite last: the tree these artefacts describe is green
