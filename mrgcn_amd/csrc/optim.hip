@@ -460,12 +460,20 @@ __global__ __launch_bounds__(kTB) void k_sumsq_multi(MultiSumsq a, double *__res
   const int64_t n = a.n[t], nv = n >> 2;
   const float4 *x4 = reinterpret_cast<const float4 *>(x);
   float s = 0.f;
-  for (int64_t i = (int64_t)b * kTB + threadIdx.x; i < nv; i += (int64_t)nb * kTB) {
-    float4 v = x4[i];
-    s = fmaf(v.x, v.x, s);
-    s = fmaf(v.y, v.y, s);
-    s = fmaf(v.z, v.z, s);
-    s = fmaf(v.w, v.w, s);
+  const int64_t stride = (int64_t)nb * kTB;
+  for (int64_t i = (int64_t)b * kTB + threadIdx.x; i < nv; i += 4 * stride) {  // four pieces in flight (clamped loads)
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x4[i + u * stride < nv ? i + u * stride : i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i + u * stride < nv) {
+        s = fmaf(v[u].x, v[u].x, s);
+        s = fmaf(v[u].y, v[u].y, s);
+        s = fmaf(v[u].z, v[u].z, s);
+        s = fmaf(v[u].w, v[u].w, s);
+      }
+    }
   }
   if (b == 0)
     for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += kTB) s = fmaf(x[i], x[i], s);
