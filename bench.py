@@ -602,7 +602,8 @@ def cpu_baseline(args, shape_name):
     probe = sample(min(big, args.scale / 64))
     t_start = time.time()
     sweep = {}
-    for th in sorted({min(c, cores) for c in (8, 16, 32, 64)}):
+    quota = cpu_quota()
+    for th in sorted({min(c, cores) for c in (8, 16, 32, 64)} | ({max(1, min(int(quota), cores))} if quota else set())):
         sweep[th], _ = timed(probe, 1, th)
         if time.time() - t_start > 30:
             break
@@ -623,12 +624,13 @@ def cpu_baseline(args, shape_name):
         "sample": (f"{shape_name} x {big:.4g} (N={g.num_nodes}, R={g.num_relations}, nnz={g.nnz}): median {ms:.1f} / min "
                    f"{ms_min:.1f} ms/epoch over {n_big} timed epochs after {n_warm} warm-ups (BASELINE.md's protocol) with "
                    f"the reference's literal ATen op sequence on {threads} of "
-                   f"{cores} host threads (best of a sweep on a 1/64 sample: "
+                   f"{cores} host threads" + (f" (container CPU quota: {quota:g})" if quota else "") +
+                   f" (best of a sweep on a 1/64 sample: "
                    f"{ {k: round(v, 1) for k, v in sweep.items()} }); value = median / {big:.4g}.  Second scale "
                    f"{shape_name} x {small:.4g} (N={n_small}): {ms_small:.1f} ms/epoch over 3 epochs after 3 warm-ups, i.e. "
                    f"{ms_small / small:.0f} ms/epoch extrapolated — the pair shows how linear the extrapolation is"),
         "measured_ms": ms, "measured_min_ms": ms_min, "timed_epochs": n_big, "warmup_epochs": n_warm,
-        "sample_scale": big, "host_cores": cores,
+        "sample_scale": big, "host_cores": cores, "host_cpu_quota": quota,
         "second_scale": {"sample_scale": small, "measured_ms": ms_small, "extrapolated_ms": ms_small / small},
     }
 
@@ -1184,8 +1186,26 @@ def probe_child_main(args):
         pass
 
 
+def cpu_quota():
+    """CPUs this container may use per scheduling period (cgroup v2 cpu.max), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:  # noqa: BLE001  (no cgroup v2 file: no quota known)
+        return None
+
+
 def main():
     args = parse()
+    # The bench boxes give this container a CPU quota (cgroup cpu.max: 16 CPUs of a 256-thread host).  torch's intra-op
+    # pool defaults to one thread per host thread: every parallel CPU op then wakes 256 spinning workers, the quota of
+    # the 100 ms period is gone in a few ms and the kernel parks the WHOLE process for the rest of it — found as 35-60 ms
+    # stalls in every second or third eager step of the encoders workload (one `torch.arange(N)` per forward, since
+    # removed).  The pool is sized to the quota; `cpu_baseline` runs its own thread sweep.
+    quota = cpu_quota()
+    if quota:
+        import torch
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), int(quota))))
     if args.probe_child:
         return probe_child_main(args)
     if args.workload == "fb15k":

@@ -189,7 +189,11 @@ class MRGCN(nn.Module):
         dev = self.devices["relational"]
         X = None
         if self.compute_modality_embeddings:
-            batch_idx = torch.arange(self.num_nodes)
+            # (every node, in order — the same tensor every epoch: a fresh 1.67 M-element arange per forward is a
+            # parallel CPU op that wakes torch's whole intra-op pool each step)
+            batch_idx = self.__dict__.get("_full_batch_idx")
+            if batch_idx is None or batch_idx.numel() != self.num_nodes:
+                batch_idx = self.__dict__["_full_batch_idx"] = torch.arange(self.num_nodes)
             XF = self._compute_modality_embeddings(F, batch_idx, full_batch=True)
             # (no given feature columns: the encoders' matrix is X — a concatenation would copy it once more)
             X = XF.float() if X0.shape[1] == 0 else torch.cat([X0.to(dev), XF], dim=1).float()
