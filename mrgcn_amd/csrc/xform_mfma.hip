@@ -443,6 +443,51 @@ __global__ void k_segment_sum(const int32_t *__restrict__ nptr, const float *__r
   }
 }
 
+// The same for WIDE rows (64 < K <= 256: the input gradient of a layer-0 transform whose input has a gradient — the
+// encoders' X) as a one-shot grid, a wave per node: lane l sums floats l, l + 64, ... of the node's Z rows (coalesced
+// dwords), four rows' loads in flight at clamped addresses; a node without rows stores zeros.  The thread-per-element
+// form above walks nptr and one dependent 4-byte load per element and row: 822 us for 3 GB at the AM shape.
+template <int NK>
+__global__ __launch_bounds__(256) void k_segment_sum_wide(const int32_t *__restrict__ nptr, const float *__restrict__ Z,
+                                                          int64_t ldZ, int64_t N, int K, float *__restrict__ dX,
+                                                          int64_t lddX) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= N) return;
+  const int32_t c0 = nptr[j], c1 = nptr[j + 1];
+  int kk[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) kk[k] = (lane + 64 * k < K) ? lane + 64 * k : K - 1;  // (clamped: masked at the store)
+  float acc[4][NK];  // (the four partial sums of k_segment_sum, in its order: the same bits)
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int k = 0; k < NK; ++k) acc[u][k] = 0.f;
+  for (int32_t c = c0; c < c1; c += 4) {
+    float v[4][NK];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float *z = Z + (int64_t)(c + u < c1 ? c + u : c) * ldZ;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) v[u][k] = z[kk[k]];
+    }
+    const bool whole = c + 4 <= c1;  // (wave uniform; the rows of a last, partial group all go to the first sum)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c + u < c1) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          if (whole) acc[u][k] += v[u][k];
+          else acc[0][k] += v[u][k];
+        }
+      }
+  }
+  float *o = dX + j * lddX;
+#pragma unroll
+  for (int k = 0; k < NK; ++k)
+    if (lane + 64 * k < K) o[lane + 64 * k] = (acc[0][k] + acc[1][k]) + (acc[2][k] + acc[3][k]);
+}
+
 // The same with liveness flags, K <= 16: one thread per node.  Nearly every node has no live
 // column (layer 1 of a semi-supervised epoch: the 1-hop neighbourhood of the labelled nodes):
 // it reads its flag bytes and stores a zero row.
@@ -735,6 +780,9 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// VEC: whole 32-byte pieces of 16-byte aligned source rows (K % 8 == 0, ldSrc % 4 == 0) — two 16-byte loads per
+// thread, a one-shot grid (the encoders' X, N x 160 every forward: 467 -> ~300 us)
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_cast_rows_bf16(const float *__restrict__ src, int64_t ldSrc, int64_t rows,
                                                         int K, uint16_t *__restrict__ dst, int64_t ldDst) {
   // one thread per 16-byte piece of dst (8 elements)
@@ -745,8 +793,15 @@ __global__ __launch_bounds__(256) void k_cast_rows_bf16(const float *__restrict_
     const int k0 = (int)(t - row * pieces) * 8;
     const float *x = src + row * ldSrc + k0;
     float v[8];
+    if constexpr (VEC) {
+      const bool in = k0 < K;  // (pieces past K: the row's zero padding)
+      const float4 a = *reinterpret_cast<const float4 *>(in ? x : src), b = *reinterpret_cast<const float4 *>(in ? x + 4 : src);
+      v[0] = in ? a.x : 0.f; v[1] = in ? a.y : 0.f; v[2] = in ? a.z : 0.f; v[3] = in ? a.w : 0.f;
+      v[4] = in ? b.x : 0.f; v[5] = in ? b.y : 0.f; v[6] = in ? b.z : 0.f; v[7] = in ? b.w : 0.f;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (k0 + i < K) ? x[i] : 0.f;
+      for (int i = 0; i < 8; ++i) v[i] = (k0 + i < K) ? x[i] : 0.f;
+    }
     u32x4 o;
     o.x = pack_bf16(v[0], v[1]);
     o.y = pack_bf16(v[2], v[3]);
@@ -1040,8 +1095,14 @@ int cast_rows_bf16(const float *src, int64_t ldSrc, int64_t rows, int K, uint16_
   if (rows == 0) return MRGCN_OK;
   const int64_t total = rows * (ldDst >> 3);
   int64_t grid = (total + 255) / 256;
+  const bool vec = K % 8 == 0 && ldSrc % 4 == 0 && (((uintptr_t)src) & 15) == 0 && grid <= 0x7fffffff;
+  if (vec) {
+    k_cast_rows_bf16<true><<<dim3((unsigned)grid), dim3(256), 0, s>>>(src, ldSrc, rows, K, dst, ldDst);
+    MRGCN_HIP_TRY(hipGetLastError());
+    return MRGCN_OK;
+  }
   if (grid > 256 * 32) grid = 256 * 32;
-  k_cast_rows_bf16<<<dim3((unsigned)grid), dim3(256), 0, s>>>(src, ldSrc, rows, K, dst, ldDst);
+  k_cast_rows_bf16<false><<<dim3((unsigned)grid), dim3(256), 0, s>>>(src, ldSrc, rows, K, dst, ldDst);
   MRGCN_HIP_TRY(hipGetLastError());
   return MRGCN_OK;
 }
@@ -1158,6 +1219,14 @@ int segment_sum_arrays(const int32_t *nptr, int64_t num_nodes, int64_t nz_rows, 
   if (mask_src) {
     set_error("segment_sum: the masked form needs K <= 16");
     return MRGCN_ERR_UNSUPPORTED;
+  }
+  if (K > 64 && K <= 256 && (num_nodes + 3) / 4 <= 0x7fffffff) {  // wide rows: a wave per node, one-shot
+    const dim3 grid((unsigned)((num_nodes + 3) / 4));
+    if (K <= 128) k_segment_sum_wide<2><<<grid, dim3(256), 0, s>>>(nptr, Z, ldZ, num_nodes, K, dX, lddX);
+    else if (K <= 192) k_segment_sum_wide<3><<<grid, dim3(256), 0, s>>>(nptr, Z, ldZ, num_nodes, K, dX, lddX);
+    else k_segment_sum_wide<4><<<grid, dim3(256), 0, s>>>(nptr, Z, ldZ, num_nodes, K, dX, lddX);
+    MRGCN_HIP_TRY(hipGetLastError());
+    return MRGCN_OK;
   }
   int64_t blocks = (num_nodes * K + 255) / 256;
   if (blocks > 4096) blocks = 4096;
