@@ -279,7 +279,33 @@ __global__ __launch_bounds__(256) void k_bn_relu_pool_fwd_flat(const float *__re
     const float mu = mean[c], sc = (gamma ? gamma[c] : 1.f) / sqrtf(var[c] + eps), sh = beta ? beta[c] : 0.f;
     int t0, t1;
     pool_window(kind, arg, T, to, t0, t1);
-    for (int b = b0; b < b1; ++b) {
+    int b = b0;
+    for (; b + kFlatUnroll <= b1; b += kFlatUnroll) {  // four rows side by side: their loads of a window step in flight
+      float best[kFlatUnroll];
+      int bi[kFlatUnroll];
+#pragma unroll
+      for (int u = 0; u < kFlatUnroll; ++u) { best[u] = -1.f; bi[u] = t0; }
+      for (int t = t0; t < t1; ++t) {
+        float v[kFlatUnroll];
+#pragma unroll
+        for (int u = 0; u < kFlatUnroll; ++u) v[u] = x[(int64_t)(b + u) * CT + c * T + t];
+#pragma unroll
+        for (int u = 0; u < kFlatUnroll; ++u) {
+          const float z = fmaxf((v[u] - mu) * sc + sh, 0.f);
+          if (z > best[u]) {  // first maximum wins (ATen's order)
+            best[u] = z;
+            bi[u] = t;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kFlatUnroll; ++u) {
+        const int64_t o = (int64_t)(b + u) * CTo + po;
+        y[o] = best[u];
+        if (argmax) argmax[o] = bi[u];
+      }
+    }
+    for (; b < b1; ++b) {
       const float *row = x + (int64_t)b * CT + c * T;
       float best = -1.f;
       int bi = t0;
@@ -314,7 +340,23 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_flat(const float *__restr
     const int c = p / T, t = p - c * T;
     const double m = mean[c], istd = 1.0 / sqrt((double)var[c] + (double)eps);
     double a = 0.0, q = 0.0;
-    for (int b = b0; b < b1; ++b) {
+    int b = b0;
+    for (; b + kFlatUnroll <= b1; b += kFlatUnroll) {  // the rows' loads first (a plain loop waits for each row in turn)
+      float gv[kFlatUnroll], xv[kFlatUnroll];
+#pragma unroll
+      for (int u = 0; u < kFlatUnroll; ++u) {
+        const int64_t bc = (int64_t)(b + u) * C + c;
+        gv[u] = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg_magic);
+        xv[u] = x[bc * T + t];
+      }
+#pragma unroll
+      for (int u = 0; u < kFlatUnroll; ++u) {
+        const double gg = gv[u];
+        a += gg;
+        q += gg * ((double)xv[u] - m) * istd;
+      }
+    }
+    for (; b < b1; ++b) {
       const int64_t bc = (int64_t)b * C + c;
       const double gg = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg_magic);
       a += gg;
@@ -351,7 +393,26 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx_flat(const float *__restrict_
     const float g = (gamma ? gamma[c] : 1.f) * istd;
     const float mu = mean[c], k_b = training ? dbeta[c] * inv_n : 0.f, k_g = training ? dgamma[c] * inv_n : 0.f;
     double rsum = 0.0;
-    for (int b = b0; b < b1; ++b) {
+    int b = b0;
+    for (; b + kFlatUnroll <= b1; b += kFlatUnroll) {  // (loads of four rows in flight)
+      float gv[kFlatUnroll], xv[kFlatUnroll];
+#pragma unroll
+      for (int u = 0; u < kFlatUnroll; ++u) {
+        const int64_t bc = (int64_t)(b + u) * C + c;
+        gv[u] = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg_magic);
+        xv[u] = training ? x[bc * T + t] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kFlatUnroll; ++u) {
+        const int64_t e = ((int64_t)(b + u) * C + c) * T + t;
+        float v = gv[u];
+        if (training) v = v - k_b - (xv[u] - mu) * istd * k_g;
+        v *= g;
+        dx[e] = v;
+        rsum += (double)v;
+      }
+    }
+    for (; b < b1; ++b) {
       const int64_t bc = (int64_t)b * C + c, e = bc * T + t;
       float v = dz_at<KIND>(y, dy, argmax, dz, bc, t, T, Tout, arg_magic);
       if (training) v = v - k_b - (x[e] - mu) * istd * k_g;
