@@ -671,7 +671,14 @@ __global__ __launch_bounds__(64) void k_colsum_final(const float *__restrict__ p
   constexpr int Q = 64 / FT;
   const int f = threadIdx.x % FT, q = threadIdx.x / FT;
   float v = 0.f;
-  for (int b = q; b < n_blocks; b += Q) v += partials[(int64_t)b * FT + f];
+  for (int b = q; b < n_blocks; b += 8 * Q) {  // eight loads in flight (one at a time: 60 us for 1 024 partials), same order
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = partials[(int64_t)(b + u * Q < n_blocks ? b + u * Q : b) * FT + f];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (b + u * Q < n_blocks) v += x[u];
+  }
 #pragma unroll
   for (int off = FT; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
   if (q == 0 && f < F) out[f] = v;
