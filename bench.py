@@ -1187,12 +1187,8 @@ def probe_child_main(args):
 
 
 def cpu_quota():
-    """CPUs this container may use per scheduling period (cgroup v2 cpu.max), or None when unlimited / unknown."""
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        return None if q == "max" else float(q) / float(per)
-    except Exception:  # noqa: BLE001  (no cgroup v2 file: no quota known)
-        return None
+    from mrgcn_amd.host import cpu_quota as q
+    return q()
 
 
 def main():
@@ -1201,11 +1197,9 @@ def main():
     # pool defaults to one thread per host thread: every parallel CPU op then wakes 256 spinning workers, the quota of
     # the 100 ms period is gone in a few ms and the kernel parks the WHOLE process for the rest of it — found as 35-60 ms
     # stalls in every second or third eager step of the encoders workload (one `torch.arange(N)` per forward, since
-    # removed).  The pool is sized to the quota; `cpu_baseline` runs its own thread sweep.
-    quota = cpu_quota()
-    if quota:
-        import torch
-        torch.set_num_threads(max(1, min(torch.get_num_threads(), int(quota))))
+    # removed).  The pool is sized to the quota (mrgcn_amd.host); `cpu_baseline` runs its own thread sweep.
+    from mrgcn_amd.host import fit_cpu_pool_to_quota
+    fit_cpu_pool_to_quota()
     if args.probe_child:
         return probe_child_main(args)
     if args.workload == "fb15k":

@@ -8,6 +8,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
 from mrgcn_amd import synth
+from mrgcn_amd.host import fit_cpu_pool_to_quota
+fit_cpu_pool_to_quota()   # (a container CPU quota: mrgcn_amd/host.py)
 from mrgcn_amd.data import batch as mb
 from mrgcn_amd.models.rgcn import RGCN
 from mrgcn_amd.plan import GraphPlan

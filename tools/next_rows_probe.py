@@ -16,6 +16,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mrgcn_amd import synth  # noqa: E402
+from mrgcn_amd.host import fit_cpu_pool_to_quota  # noqa: E402
+
+fit_cpu_pool_to_quota()   # (a container CPU quota: mrgcn_amd/host.py)
 
 
 def timed(fn, iters=10, warm=2):
