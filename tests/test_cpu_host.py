@@ -275,3 +275,31 @@ def test_library_configuration_table_through_the_abi():
     for f in os.listdir(os.path.join(ROOT, "mrgcn_amd", "csrc")):
         if f.endswith((".hip", ".hpp")) and f != "config.hip":
             assert "getenv" not in open(os.path.join(ROOT, "mrgcn_amd", "csrc", f)).read(), f
+
+
+def test_cpu_pool_follows_the_container_quota(monkeypatch, tmp_path):
+    """mrgcn_amd.host: cgroup v2 `cpu.max` -> CPUs per period (None for "max" / no file); the torch intra-op pool is
+    sized to it, never enlarged."""
+    import builtins
+    import torch
+    from mrgcn_amd import host
+    real_open = builtins.open
+
+    def fake(content):
+        f = tmp_path / "cpu.max"
+        f.write_text(content)
+        return lambda p, *a, **k: real_open(f if p == "/sys/fs/cgroup/cpu.max" else p, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert host.cpu_quota() == 16.0
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert host.cpu_quota() is None
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setattr(builtins, "open", fake("200000 100000\n"))
+        assert host.fit_cpu_pool_to_quota() == 2.0 and torch.get_num_threads() == min(before, 2)
+        monkeypatch.setattr(builtins, "open", fake("%d 100000\n" % (100000 * 4096)))
+        host.fit_cpu_pool_to_quota()
+        assert torch.get_num_threads() == min(before, 2)      # (never enlarged)
+    finally:
+        monkeypatch.undo()
+        torch.set_num_threads(before)
