@@ -39,10 +39,13 @@ def _gtol(ref, per_block):
     return 2e-5 * top + 1e-30
 
 
-def _close_grad(got, ref, name, per_block=False, rtol=1e-3):
+def _close_grad(got, ref, name, per_block=False, rtol=1e-3, uncertain=None, max_uncertain=5e-4):
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     bad = np.abs(got - ref) > rtol * np.abs(ref) + _gtol(ref, per_block)
+    if uncertain is not None:   # elements that hang on a unit at the ReLU kink (`_kink_mask`)
+        assert uncertain.mean() <= max_uncertain, (name, "too many elements declared uncertain", int(uncertain.sum()))
+        bad &= ~uncertain
     assert not bad.any(), (name, int(bad.sum()), float(np.abs(got - ref).max()), np.argwhere(bad)[:5].tolist())
 
 
@@ -57,25 +60,34 @@ KINK = 1e-7   # a ReLU unit whose float64 pre-activation is within KINK of zero,
               # of its terms (two float32 roundings of that sum), may carry the other mask in a float32 forward
 
 
-def _kink_mask(shape, kinks):
+def _kink_mask(shape, kinks, sample=None):
     """bool [N, B, F] (node-major weight_I blocks): the elements whose gradient holds a term that a unit on the ReLU
-    kink switches on or off — feature f of every source node of such a unit's row (oracle: `_kinks`)."""
+    kink switches on or off — feature f of every source node of such a unit's row (oracle: `_kinks`).  `sample`
+    (sorted node ids): the mask over those nodes' blocks only, [len(sample), B, F]."""
     mask = np.zeros(shape, dtype=bool)
     if kinks is None:
         return mask
     for pre, mag, col, nodes in zip(kinks["pre"], kinks["mag"], kinks["col"], kinks["nodes"]):
         if abs(pre) <= KINK * mag:
+            if sample is not None:   # positions of the unit's source nodes among the sampled blocks
+                nodes = np.asarray(nodes)
+                at = np.searchsorted(sample, nodes)
+                ok = at < len(sample)
+                ok[ok] &= sample[at[ok]] == nodes[ok]
+                nodes = at[ok]
             mask[nodes, :, col] = True
     return mask
 
 
-def _check_adam(name, p_before, g, coef, got_p, got_m, got_v, m0=0.0, v0=0.0, t=1, per_block=False, uncertain=None):
+def _check_adam(name, p_before, g, coef, got_p, got_m, got_v, m0=0.0, v0=0.0, t=1, per_block=False, uncertain=None,
+                max_uncertain=5e-4):
     """`got_*` (the GPU's parameter and moments after the step) against Adam applied to the oracle's gradient `g`
     (unclipped; `coef` the oracle's clip coefficient) with the gradient tolerance mapped through the update.
     `uncertain` (bool, like the parameter): elements left out — their gradient depends on which side of the ReLU kink a
-    float32 forward puts a unit that float64 has within rounding of zero (`_kink_mask`); at most 5e-4 of the tensor."""
+    float32 forward puts a unit that float64 has within rounding of zero (`_kink_mask`); at most `max_uncertain` of the
+    tensor (5e-4 of a whole parameter; a sample of node blocks that seeks out hubs and long rows: 2e-2)."""
     if uncertain is not None:
-        assert uncertain.mean() <= 5e-4, (name, "too many elements declared uncertain", int(uncertain.sum()))
+        assert uncertain.mean() <= max_uncertain, (name, "too many elements declared uncertain", int(uncertain.sum()))
     certain = True if uncertain is None else ~uncertain
     g = np.asarray(g, np.float64)
     p0 = np.asarray(p_before, np.float64)
@@ -187,6 +199,15 @@ class _NcCase:
         li, key = int(name.split(".")[1].split("_")[1]), name.split(".")[2]
         return ora["grads"][li][key]
 
+    def kinks(self, ora):
+        """bool [len(sample), B, F]: the sampled weight_I elements that hang on a hidden unit at the ReLU kink."""
+        kk = ora["levels"][0]["kinks"]
+        m = _kink_mask((len(self.sample), self.B, self.dims[0][1]), kk, sample=self.sample)
+        if os.environ.get("MRGCN_TEST_MARGINS"):
+            print("kinks", int((np.abs(kk["pre"]) <= KINK * kk["mag"]).sum()), "units within the band,",
+                  int(m.sum()), "of", m.size, "sampled elements left out")
+        return m
+
     def check_small_grads(self, ora, where):
         for n, p in self.small:
             assert p.grad is not None, (where, n)
@@ -203,7 +224,8 @@ class _NcCase:
         st = opt.state[self.wI]
         m0, v0 = moments_before["wI"] if moments_before else (0.0, 0.0)
         _check_adam(f"{where}: weight_I blocks", before["wI"], ora["wI"][0]["grad"], coef, _np(self.wI[self.sel]),
-                    _np(st["exp_avg"][self.sel]), _np(st["exp_avg_sq"][self.sel]), m0, v0, t, per_block=True)
+                    _np(st["exp_avg"][self.sel]), _np(st["exp_avg_sq"][self.sel]), m0, v0, t, per_block=True,
+                    uncertain=self.kinks(ora), max_uncertain=2e-2)
         # a node outside the receptive field never moves and never gets moments
         if len(self.dead):
             d = torch.from_numpy(self.dead[:: max(len(self.dead) // 5000, 1)]).cuda()
@@ -268,7 +290,8 @@ def _run_nc(case):
     assert ent["fused"] is not None and ent["fused"].get("sup") is not None, "not on the gradient support / fused Adam"
     assert int(ent["cur"].sum()) == case.n_live == len(ora1["wI"][0]["live_nodes"])
     g = Fn.dense_from_rows(case.wI, ent)
-    _close_grad(_np(g[case.sel]), ora1["wI"][0]["grad"], "support path: d weight_I blocks", per_block=True)
+    _close_grad(_np(g[case.sel]), ora1["wI"][0]["grad"], "support path: d weight_I blocks", per_block=True,
+                uncertain=case.kinks(ora1), max_uncertain=2e-2)
     if len(case.dead):
         d = torch.from_numpy(case.dead[:: max(len(case.dead) // 5000, 1)]).cuda()
         assert not bool(g[d].any())
@@ -305,7 +328,8 @@ def _run_nc(case):
     loss = train_step(case.model, fwd, case.idx, case.y, opt, row_sparse=False)
     np.testing.assert_allclose(float(loss), ora1["loss"], rtol=2e-5, atol=1e-6)
     assert case.wI.grad is not None
-    _close_grad(_np(case.wI.grad[case.sel]), ora1["wI"][0]["grad"], "dense path: d weight_I blocks", per_block=True)
+    _close_grad(_np(case.wI.grad[case.sel]), ora1["wI"][0]["grad"], "dense path: d weight_I blocks", per_block=True,
+                uncertain=case.kinks(ora1), max_uncertain=2e-2)
     case.check_small_grads(ora1, "dense path")
     np.testing.assert_allclose(opt.last_grad_norm(), ora1["grad_norm"], rtol=2e-5)
     case.check_after_step(ora1, opt, before, "dense path, step 1")
@@ -319,7 +343,8 @@ def _run_nc(case):
         loss = train_step(case.model, fwd, case.idx, case.y, opt, row_sparse=False)
     finally:
         Fn._LIVE_COLS = prev
-    _close_grad(_np(case.wI.grad[case.sel]), ora1["wI"][0]["grad"], "plain path: d weight_I blocks", per_block=True)
+    _close_grad(_np(case.wI.grad[case.sel]), ora1["wI"][0]["grad"], "plain path: d weight_I blocks", per_block=True,
+                uncertain=case.kinks(ora1), max_uncertain=2e-2)
     case.check_small_grads(ora1, "plain path")
     np.testing.assert_allclose(opt.last_grad_norm(), ora1["grad_norm"], rtol=2e-5)
     case.check_after_step(ora1, opt, before, "plain path, step 1")
