@@ -564,11 +564,21 @@ __global__ __launch_bounds__(256) void k_segment_sum_mask(const int32_t *__restr
       }
     }
     if (any && lane_max > 0 && c1 - c0 <= lane_max) {
-      for (int32_t c = c0; c < c1; ++c) {
-        const float *z = Z + (int64_t)c * ldZ;
+      for (int32_t c = c0; c < c1; c += 4) {  // four rows' loads in flight (clamped), added in order
+        float zz[4][KT];
 #pragma unroll
-        for (int i = 0; i < KT; ++i)
-          if (i < K) acc[i] += z[i];
+        for (int u = 0; u < 4; ++u) {
+          const float *z = Z + (int64_t)(c + u < c1 ? c + u : c) * ldZ;
+#pragma unroll
+          for (int i = 0; i < KT; ++i) zz[u][i] = z[i < K ? i : K - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c + u < c1) {
+#pragma unroll
+            for (int i = 0; i < KT; ++i)
+              if (i < K) acc[i] += zz[u][i];
+          }
       }
       any = false;
       own_out = true;

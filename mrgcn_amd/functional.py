@@ -304,7 +304,11 @@ class _SpmmLiteral(torch.autograd.Function):
         plan = ctx.plan
         dY = dY.contiguous()
         (Y,) = ctx.saved_tensors
-        if ctx.relu:
+        # (the layer above may hand its input gradient on already masked: `_grad_meta`, as for _RgcnLayer)
+        meta = _grad_meta(dY)
+        if meta and meta.get("sparse_rows"):
+            raise L.MrgcnError("internal: an output gradient with unwritten rows reached the literal product")
+        if ctx.relu and not (meta and meta["relu_applied"]):
             dY = relu_bwd(dY, Y)
         dbias = _bias_grad(dY) if ctx.has_bias else None
         dD = None
@@ -1112,7 +1116,10 @@ def rgcn_layer(plan: GraphPlan, layer, X, relu: bool = False, input_term: bool =
     bias = layer.b if (layer.bias and use_bias) else None
     if weight_I is not None and comp_I is None and Xin is None and not bf16:
         # featureless layer without bases: weight_I already *is* the literal operand
-        return spmm_literal(plan, weight_I, bias=bias, relu=relu, owner=layer)
+        Y = spmm_literal(plan, weight_I, bias=bias, relu=relu, owner=layer)
+        if relu:
+            Y._mrgcn_relu_out = True   # (the layer above masks its input gradient with this output's sign)
+        return Y
     Y = _RgcnLayer.apply(plan, F, weight_I, comp_I, Xin, W_F, bias, relu, bf16, layer)
     if relu:
         Y._mrgcn_relu_out = True  # (a Python attribute of this tensor object: a copy or a view does not carry it)
