@@ -687,10 +687,16 @@ __global__ __launch_bounds__(1024) void k_xform_cols_lds(const int32_t *__restri
                                                          OT *__restrict__ Out, int64_t ldOut) {
   extern __shared__ __align__(16) float s_w[];  // [R][K][FP]
   const int KF = K * F, KFP = K * FP;
-  for (int t = threadIdx.x; t < R * KFP; t += blockDim.x) {
-    const int r = t / KFP, rem = t - r * KFP;
-    const int k = rem / FP, f = rem - k * FP;
-    s_w[t] = f < F ? W[(int64_t)r * KF + k * F + f] : 0.f;
+  if (F == FP && (((uintptr_t)W) & 15) == 0) {  // rows of whole 16-byte pieces: the table is copied as it lies
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(W);
+    f32x4 *s4 = reinterpret_cast<f32x4 *>(s_w);
+    for (int t = threadIdx.x; t < (R * KFP) >> 2; t += blockDim.x) s4[t] = w4[t];
+  } else {
+    for (int t = threadIdx.x; t < R * KFP; t += blockDim.x) {
+      const int r = t / KFP, rem = t - r * KFP;
+      const int k = rem / FP, f = rem - k * FP;
+      s_w[t] = f < F ? W[(int64_t)r * KF + k * F + f] : 0.f;
+    }
   }
   __syncthreads();
   const int q = threadIdx.x & 3;
