@@ -1657,7 +1657,11 @@ int mix_fwd_cols(const MixCols *p, const float *V, const float *comp, int32_t B,
       // in-order tickets (see k_mix_fwd_mfma, TK): a full grid over a plan that carries the counters
       const int n_ctr = (int)std::min<int64_t>(std::max<int64_t>(cfg(CFG_MIX_TICKETS), 0), kWorkTickets);
       const int tk_tile = (int)std::min<int64_t>(std::max<int64_t>(cfg(CFG_MIX_TICKET_TILE), 1), 64);
-      const bool tk = p->tickets && !node_ids && n_ctr > 0 && grid == 256;  // (a full grid: >= 8 192 nodes)
+      // (a full grid with at least four tiles per resident wave: on a small graph the plain stride keeps every wave busy —
+      // with tiles of four MUTAG's 11.8 k steps occupied 2 956 of the 4 096 waves with four serial steps each)
+      const int64_t mix_steps = (N + tn - 1) / tn;
+      const bool tk = p->tickets && !node_ids && n_ctr > 0 && grid == 256 &&
+                      mix_steps >= (int64_t)4 * tk_tile * grid * (kFwdTB / 64);
       if (tk)
         MRGCN_HIP_TRY(mrgcn::fill_async(p->tickets, 0, (size_t)kWorkTickets * kWorkTicketStride * sizeof(unsigned long long), s));
 #define MIXM_GO(KS_, NQ_, TN_)                                                                              \
