@@ -424,8 +424,8 @@ int mrgcn_support_mix_bwd_f32(const mrgcn_support_t *q, const float *dM, int64_t
   if (tb == 1024 && nb > 2) nb = 2;
   const int nw = tb / 64;
   int epw = 64;
-  if (q->NL < 262144) {  // ~2048 waves' worth of entries each, a multiple of the step
-    epw = (int)((q->NL / 2048 + nb - 1) / nb * nb);
+  if (q->NL < 262144) {  // ~4096 waves' worth of entries each, a multiple of the step
+    epw = (int)((q->NL / 4096 + nb - 1) / nb * nb);
     epw = std::min(64, std::max(epw, nb));
   }
   int64_t grid = (q->NL + (int64_t)epw * nw - 1) / ((int64_t)epw * nw);
