@@ -1780,12 +1780,16 @@ __global__ __launch_bounds__(kTB) void k_basis_contract(const float *__restrict_
 //   in LDS in a fixed order.  B <= kContractMaxB and R * BT * 4 + 4 * BT * 256 bytes of LDS; otherwise the plain
 //   thread-per-output walk.  (Measured on the way: comp through 4-byte loads in a loop 120 us, through scalar loads per
 //   relation 150 us — both a chain of dependent round trips.)
+//   NW waves per block (round 6: 16 where the launch has few blocks — X / 64: 25 and 2 at the AM shape — and is a chain
+//   of comp-staging and relation rounds: 24 -> 17 us; waves 4 .. NW - 1 add their partial sums into the four LDS slots
+//   in three further phases, a fixed order).
 constexpr int kContractMaxB = 64;
-template <int BT>
-__global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restrict__ comp, const float *__restrict__ V,
+template <int BT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_basis_contract_bwd(const float *__restrict__ comp, const float *__restrict__ V,
                                                             const float *__restrict__ dW, int R, int B, int64_t X,
                                                             float *__restrict__ dcomp, float *__restrict__ dV,
                                                             int dv_blocks, int tiled) {
+  constexpr int kTB = 64 * NW;  // (shadows the file's 256)
   extern __shared__ float s_mem[];
   {
     if (!tiled) {  // dV[b, x]: a thread per output
@@ -1828,13 +1832,13 @@ __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restr
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[b] = 0.f;
     int r = q;
-    for (; r + 28 < R; r += 32) {
+    for (; r + 7 * NW < R; r += 8 * NW) {
       float d[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) d[u] = dW[(int64_t)(r + 4 * u) * X + xc];
+      for (int u = 0; u < 8; ++u) d[u] = dW[(int64_t)(r + NW * u) * X + xc];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const float4 *c4 = reinterpret_cast<const float4 *>(s_comp + (r + 4 * u) * BT);  // broadcast 16-byte LDS reads
+        const float4 *c4 = reinterpret_cast<const float4 *>(s_comp + (r + NW * u) * BT);  // broadcast 16-byte LDS reads
 #pragma unroll
         for (int b = 0; b < BT; b += 4) {
           const float4 c = c4[b >> 2];
@@ -1845,7 +1849,7 @@ __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restr
         }
       }
     }
-    for (; r < R; r += 4) {
+    for (; r < R; r += NW) {
       const float d = dW[(int64_t)r * X + xc];
       const float4 *c4 = reinterpret_cast<const float4 *>(s_comp + r * BT);
 #pragma unroll
@@ -1857,10 +1861,19 @@ __global__ __launch_bounds__(kTB) void k_basis_contract_bwd(const float *__restr
         acc[b + 3] = fmaf(c.w, d, acc[b + 3]);
       }
     }
+    // waves 0 .. 3 store, then waves 4 .. 7, 8 .. 11, 12 .. 15 add into slot q % 4 one group after the other
 #pragma unroll
-    for (int b = 0; b < BT; ++b)
-      if (b < B) s_part[(q * BT + b) * 64 + xl] = acc[b];
-    __syncthreads();
+    for (int ph = 0; ph < NW / 4; ++ph) {
+      if ((q >> 2) == ph) {
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+          if (b < B) {
+            float *slot = s_part + ((q & 3) * BT + b) * 64 + xl;
+            *slot = ph == 0 ? acc[b] : *slot + acc[b];
+          }
+      }
+      __syncthreads();
+    }
     for (int t = threadIdx.x; t < B * 64; t += kTB) {
       const int b = t >> 6, xx = t & 63;
       const int64_t xo = (int64_t)blockIdx.x * 64 + xx;
@@ -2318,11 +2331,19 @@ int mrgcn_basis_contract_bwd_f32(const float *comp, const float *V, const float 
   if (dv_blocks == 0) return MRGCN_OK;
   const dim3 grid(dv_blocks);
   const size_t sh = tiled ? lds : 0;
+  // few blocks (X / 64) and many relations: sixteen waves each; otherwise four (more blocks per CU, shorter chains)
+  const bool wide_blocks = tiled && dv_blocks <= 256 && R >= 128;
 #define CONTRACT_BWD(BT_)                                                                                          \
   do {                                                                                                             \
-    auto kfn = k_basis_contract_bwd<BT_>;                                                                          \
-    MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, sh));                                                  \
-    kfn<<<grid, dim3(kTB), sh, (hipStream_t)stream>>>(comp, V, dW, R, B, X, dcomp, dV, dv_blocks, tiled);          \
+    if (wide_blocks) {                                                                                             \
+      auto kfn = k_basis_contract_bwd<BT_, 16>;                                                                    \
+      MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, sh));                                                \
+      kfn<<<grid, dim3(1024), sh, (hipStream_t)stream>>>(comp, V, dW, R, B, X, dcomp, dV, dv_blocks, tiled);       \
+    } else {                                                                                                       \
+      auto kfn = k_basis_contract_bwd<BT_>;                                                                        \
+      MRGCN_HIP_TRY(mrgcn::raise_lds_limit((const void *)kfn, sh));                                                \
+      kfn<<<grid, dim3(kTB), sh, (hipStream_t)stream>>>(comp, V, dW, R, B, X, dcomp, dV, dv_blocks, tiled);        \
+    }                                                                                                              \
   } while (0)
   if (BT == 16) CONTRACT_BWD(16);
   else if (BT == 32) CONTRACT_BWD(32);
