@@ -475,11 +475,47 @@ __global__ __launch_bounds__(kCountTB) void k_count3(const int64_t *__restrict__
 // exclusive scan of cnt[c * stride .. + bins_c) in place, one 1024-thread block per column
 __global__ __launch_bounds__(1024) void k_scan3(int32_t *__restrict__ cnt, int64_t stride, int64_t bins_n, int64_t bins_r) {
   __shared__ int32_t s_sum[1024];
+  __shared__ int32_t s_wave[16];
   const int c = blockIdx.x;
   const int64_t bins = c == 1 ? bins_r : bins_n;
   int32_t *a = cnt + c * stride;
   const int64_t per = (bins + 1023) / 1024;
   const int64_t b0 = threadIdx.x * per, b1 = min(b0 + per, bins);
+  constexpr int kPer = 16;
+  if (per <= kPer && bins > 0) {
+    // the slice in registers: its loads in flight together (one at a time, twice over, and twenty barriers of a
+    // Hillis-Steele scan over 1 024 sums: 15 us for FB15k-237's 14 541 bins), a wave-level scan of the slice sums
+    int32_t v[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) v[u] = a[min(b0 + u, bins - 1)];
+    int32_t t = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      if (b0 + u >= b1) v[u] = 0;
+      t += v[u];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int32_t inc = t;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    int32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w)
+      if (w < wv) base += s_wave[w];
+    int32_t run = base + inc - t;  // exclusive prefix of this thread's slice
+#pragma unroll
+    for (int u = 0; u < kPer; ++u)
+      if (b0 + u < b1) {
+        a[b0 + u] = run;
+        run += v[u];
+      }
+    return;
+  }
   int32_t t = 0;
   for (int64_t k = b0; k < b1; ++k) t += a[k];
   s_sum[threadIdx.x] = t;
