@@ -45,7 +45,12 @@ def main():
     ap.add_argument("--json", action="store_true")
     ap.add_argument("--wt", action="store_true", help="forward products read the transposed weight ([Cin KW][Cout])")
     ap.add_argument("--only", default="", help="substring of the product names to time")
+    ap.add_argument("--mm", default="f32", choices=["f32", "bf16"],
+                    help="bf16: tiles rounded to bf16 as they are staged, v_mfma_f32_16x16x32_bf16 (the bf16 pipeline)")
     a = ap.parse_args()
+    if a.mm == "bf16":
+        dense.set_matmul_dtype("bf16")
+    peak, peak_name = (2500.0, "bf16 MFMA (dense)") if a.mm == "bf16" else (157.3, "fp32 MFMA")
     global ONLY
     ONLY = a.only
     dev = torch.device("cuda:0")
@@ -107,13 +112,15 @@ def main():
         print(json.dumps({"products": [{"name": r[0], "M": r[1], "N": r[2], "K": r[3], "ms": round(r[5], 4),
                                         "tflops": round(r[4] / r[5] / 1e9, 1)} for r in rows],
                           "total_ms": round(tot_ms, 3), "total_tflops": round(tot_f / tot_ms / 1e9, 1),
-                          "peak_tflops_f32_mfma": 157.3, "frac": round(tot_f / tot_ms / 1e9 / 157.3, 3)}))
+                          "arithmetic": a.mm, "peak_tflops": peak, "peak": peak_name,
+                          "frac": round(tot_f / tot_ms / 1e9 / peak, 4)}))
         return
+    print(f"arithmetic: {a.mm}")
     print(f"{'product':34s} {'M':>8s} {'N':>5s} {'K':>7s} {'ms':>8s} {'TFLOP/s':>8s}")
     for name, M, N, K, flop, ms in rows:
         print(f"{name:34s} {M:8d} {N:5d} {K:7d} {ms:8.4f} {flop / ms / 1e9:8.1f}")
     print(f"{'all products':34s} {'':8s} {'':5s} {'':7s} {tot_ms:8.3f} {tot_f / tot_ms / 1e9:8.1f}   "
-          f"({tot_f / tot_ms / 1e9 / 157.3 * 100:.1f} % of 157.3)")
+          f"({tot_f / tot_ms / 1e9 / peak * 100:.1f} % of {peak:g}: {peak_name})")
 
 
 if __name__ == "__main__":

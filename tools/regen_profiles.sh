@@ -45,6 +45,7 @@ python3 tools/epoch_sequence.py $o/stats_lp k_corrupt_triples > $o/lp_epoch_sequ
 rm -rf $o/stats_lp
 # (6) the encoders' tiled product over the TCNN-M shapes: per-product rates, MFMA counters; (7) the next-rows probe
 python3 tools/gemm_probe.py > $o/gemm_probe.txt 2> $o/gemm_probe.err
+python3 tools/gemm_probe.py --mm bf16 >> $o/gemm_probe.txt 2>> $o/gemm_probe.err
 python3 tools/gemm_probe.py --json > $o/gemm_probe.json 2>> $o/gemm_probe.err
 bash tools/pmc_passes.sh $o/pmc_mm mfma -- python3 tools/gemm_probe.py --iters 3
 python3 tools/pmc_summary.py $o k_mm_tile > $o/mfma_mm.md
